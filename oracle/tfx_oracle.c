@@ -1,0 +1,412 @@
+/*
+ * tfx_oracle.c - CPU restatement of the Tomofast-x sensitivity-kernel hot path (see tfx_oracle.h).
+ * TEST INFRASTRUCTURE ONLY: the checker for tests/, smoke() and bench.py's cpu_baseline; never the product.
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/Makefile).
+ */
+#include "tfx_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* gravity_field.f90:26 - `G_grav = 6.674e-11` is a default-real (fp32) literal assigned to a fp64
+ * parameter, so the value used is (double)(float)6.674e-11 = 6.674000241346789e-11. */
+static const double G_GRAV = (double)6.674e-11f;
+
+int orc_graviprism_z(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                     const double *Z1, const double *Z2, double xd, double yd, double zd, double *line)
+{
+    const double twopi = 2.0 * 3.14159265358979323846;
+    static const double signo[2] = {-1.0, 1.0};
+    for (int64_t i = 0; i < n; ++i) {
+        double XX[2], YY[2], ZZ[2];
+        XX[0] = xd - X1[i]; XX[1] = xd - X2[i];              /* gravity_field.f90:151-156 */
+        YY[0] = yd - Y1[i]; YY[1] = yd - Y2[i];
+        ZZ[0] = zd - Z1[i]; ZZ[1] = zd - Z2[i];
+        double gz = 0.0;
+        for (int K = 0; K < 2; ++K)
+            for (int L = 0; L < 2; ++L)
+                for (int M = 0; M < 2; ++M) {
+                    double dmu = signo[K] * signo[L] * signo[M];
+                    double Rs = sqrt(XX[K] * XX[K] + YY[L] * YY[L] + ZZ[M] * ZZ[M]);   /* :165 */
+                    double arg3 = atan2(XX[K] * YY[L], ZZ[M] * Rs);                    /* :167 */
+                    if (arg3 < 0) arg3 = arg3 + twopi;                                 /* :169-171 */
+                    double arg4 = Rs + XX[K];
+                    double arg5 = Rs + YY[L];
+                    if (arg4 <= 0.) return -1;                                         /* :176-181 */
+                    if (arg5 <= 0.) return -2;
+                    arg4 = log(arg4);
+                    arg5 = log(arg5);
+                    gz = gz + dmu * (ZZ[M] * arg3 - XX[K] * arg5 - YY[L] * arg4);      /* :186 */
+                }
+        line[i] = G_GRAV * gz;                                                         /* :192 */
+    }
+    return 0;
+}
+
+int orc_column_weight_type1(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                            const double *Z1, const double *Z2, double power, double Z0, double multiplier,
+                            double *cw)
+{
+    double norm = -HUGE_VAL;
+    for (int64_t i = 0; i < n; ++i) {
+        double depth = 0.5 * (Z1[i] + Z2[i]);                           /* grid.F90:277 */
+        if (!(depth + Z0 > 0.0)) return -1;                             /* weights_gravmag.f90:214-219 */
+        double w = pow(depth + Z0, -power / 2.0);                       /* :215 */
+        double vol = fabs((X2[i] - X1[i]) * (Y2[i] - Y1[i]) * (Z2[i] - Z1[i]));   /* grid.F90:289-291 */
+        w = w * sqrt(vol);                                              /* weights_gravmag.f90:174 */
+        cw[i] = w;
+        if (w > norm) norm = w;
+    }
+    if (norm == 0) return -2;
+    for (int64_t i = 0; i < n; ++i) {
+        cw[i] = cw[i] / norm;                                           /* :243 */
+        if (cw[i] == 0.0) return -2;
+        cw[i] = 1.0 / cw[i];                                            /* :190 */
+        cw[i] = cw[i] * multiplier;                                     /* problem_joint_gravmag.F90:178 */
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Lifting wavelets, wavelet_transform.F90.  One axis at a time (x, y, z), per axis all levels.
+ * idx(a, o) addresses element a (0-based) of a line along the axis; the other two indices are
+ * folded into the `base` offset, exactly like the whole-plane slices s(ig,:,:) of the reference.
+ * ------------------------------------------------------------------------------------------- */
+/* wavelet_transform.F90:85: nscale = int(log(real(L)) / log(2.)).  Equal to floor(log2 L) for every
+ * L < 5000 (checked against the reference build); computed in integers here so no libm is involved. */
+static int nscale_of(int L) { int n = 0; while ((2 << n) <= L) ++n; return n; }
+
+typedef void (*line_fn)(double *s, int64_t stride, int L, int nscale);
+
+static void haar_fwd_line(double *s, int64_t st, int L, int nscale)
+{
+    const double sq2 = sqrt(2.0);
+    for (int istep = 1; istep <= nscale; ++istep) {
+        int step = 1 << istep;
+        int ngmin = step / 2 + 1;                                        /* 1-based */
+        if (L < ngmin) continue;
+        int ng = (L - ngmin) / step + 1;
+        for (int m = 0; m < ng; ++m) {                                   /* :103-149, fused per pair */
+            double *lo = s + (int64_t)(m * step) * st;
+            double *hi = s + (int64_t)(ngmin - 1 + m * step) * st;
+            *hi = *hi - *lo;
+            *lo = *lo + *hi / 2.0;
+            *lo = *lo * sq2;
+            *hi = *hi / sq2;
+        }
+    }
+}
+
+static void haar_inv_line(double *s, int64_t st, int L, int nscale)
+{
+    const double sq2 = sqrt(2.0);
+    for (int istep = nscale; istep >= 1; --istep) {
+        int step = 1 << istep;
+        int ngmin = step / 2 + 1;
+        if (L < ngmin) continue;
+        int ng = (L - ngmin) / step + 1;
+        for (int m = 0; m < ng; ++m) {                                   /* :186-232 */
+            double *lo = s + (int64_t)(m * step) * st;
+            double *hi = s + (int64_t)(ngmin - 1 + m * step) * st;
+            *lo = *lo / sq2;
+            *hi = *hi * sq2;
+            *lo = *lo - *hi / 2.0;
+            *hi = *hi + *lo;
+        }
+    }
+}
+
+static void d4_fwd_line(double *s, int64_t st, int L, int nscale)
+{
+    const double c0 = sqrt(3.0), c1 = sqrt(3.0) / 4.0, c2 = (sqrt(3.0) - 2.0) / 4.0;
+    const double c3 = (sqrt(3.0) - 1.0) / sqrt(2.0), c4 = (sqrt(3.0) + 1.0) / sqrt(2.0);   /* :252-256 */
+    for (int istep = 1; istep <= nscale; ++istep) {
+        int step = 1 << istep;
+        int ngmin = step / 2 + 1;
+        if (L < ngmin) continue;
+        int ng = (L - ngmin) / step + 1;
+        int64_t ilmax = (int64_t)(ng - 1) * step;                        /* 0-based; :281 */
+#define LO(m) s[(int64_t)((m) * step) * st]
+#define HI(m) s[(int64_t)(ngmin - 1 + (m) * step) * st]
+        for (int m = 0; m < ng; ++m) LO(m) = LO(m) + HI(m) * c0;                           /* update 1 :284-296 */
+        HI(0) = HI(0) - LO(0) * c1 - s[ilmax * st] * c2;                                   /* :299-308 */
+        for (int m = 1; m < ng; ++m) HI(m) = HI(m) - LO(m) * c1 - LO(m - 1) * c2;          /* :310-322 */
+        for (int m = 0; m < ng - 1; ++m) LO(m) = LO(m) - HI(m + 1);                        /* update 2 :325-337 */
+        s[ilmax * st] = s[ilmax * st] - HI(0);                                             /* :340-348 */
+        for (int m = 0; m < ng; ++m) { LO(m) = LO(m) * c3; HI(m) = HI(m) * c4; }           /* :351-365 */
+    }
+}
+
+static void d4_inv_line(double *s, int64_t st, int L, int nscale)
+{
+    const double c0 = sqrt(3.0), c1 = sqrt(3.0) / 4.0, c2 = (sqrt(3.0) - 2.0) / 4.0;
+    const double c3 = (sqrt(3.0) - 1.0) / sqrt(2.0), c4 = (sqrt(3.0) + 1.0) / sqrt(2.0);
+    for (int istep = nscale; istep >= 1; --istep) {
+        int step = 1 << istep;
+        int ngmin = step / 2 + 1;
+        if (L < ngmin) continue;
+        int ng = (L - ngmin) / step + 1;
+        int64_t ilmax = (int64_t)(ng - 1) * step;
+        for (int m = 0; m < ng; ++m) { LO(m) = LO(m) * c4; HI(m) = HI(m) * c3; }           /* :413-427 */
+        for (int m = ng - 2; m >= 0; --m) LO(m) = LO(m) + HI(m + 1);                       /* :430-442 */
+        s[ilmax * st] = s[ilmax * st] + HI(0);                                             /* :445-453 */
+        for (int m = ng - 1; m >= 1; --m) HI(m) = HI(m) + LO(m) * c1 + LO(m - 1) * c2;     /* :456-468 */
+        HI(0) = HI(0) + LO(0) * c1 + s[ilmax * st] * c2;                                   /* :471-480 */
+        for (int m = 0; m < ng; ++m) LO(m) = LO(m) - HI(m) * c0;                           /* :483-495 */
+#undef LO
+#undef HI
+    }
+}
+
+static void apply_3d(double *s, int n1, int n2, int n3, line_fn fn)
+{
+    /* axis order x -> y -> z (wavelet_transform.F90:82-93) */
+    int ns1 = nscale_of(n1), ns2 = nscale_of(n2), ns3 = nscale_of(n3);
+    for (int k = 0; k < n3; ++k)
+        for (int j = 0; j < n2; ++j)
+            fn(s + ((int64_t)k * n2 + j) * n1, 1, n1, ns1);
+    for (int k = 0; k < n3; ++k)
+        for (int i = 0; i < n1; ++i)
+            fn(s + (int64_t)k * n2 * n1 + i, n1, n2, ns2);
+    for (int j = 0; j < n2; ++j)
+        for (int i = 0; i < n1; ++i)
+            fn(s + (int64_t)j * n1 + i, (int64_t)n1 * n2, n3, ns3);
+}
+
+int orc_forward_wavelet(double *s, int n1, int n2, int n3, int type)
+{
+    if (type == 1) apply_3d(s, n1, n2, n3, haar_fwd_line);
+    else if (type == 2) apply_3d(s, n1, n2, n3, d4_fwd_line);
+    else return -1;
+    return 0;
+}
+
+int orc_inverse_wavelet(double *s, int n1, int n2, int n3, int type)
+{
+    if (type == 1) apply_3d(s, n1, n2, n3, haar_inv_line);
+    else if (type == 2) apply_3d(s, n1, n2, n3, d4_inv_line);
+    else return -1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+static int cmp_double(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+int64_t orc_compress_row(const double *row, int64_t N, int64_t K, int32_t *cols, float *vals,
+                         double *thr_out, double *cost_discarded_out)
+{
+    double thr;
+    if (K >= N) {
+        thr = -1.0;                                                      /* sensitivity_gravmag.F90:244-246 */
+    } else {
+        double *sorted = (double *)malloc((size_t)N * sizeof(double));
+        for (int64_t p = 0; p < N; ++p) sorted[p] = fabs(row[p]);        /* :240 */
+        qsort(sorted, (size_t)N, sizeof(double), cmp_double);            /* :241 (same order statistic) */
+        thr = fabs(sorted[N - K - 1]);                                   /* :248-249, 1-based p = N-K */
+        free(sorted);
+    }
+    if (thr < 1.e-30) thr = 1.e-30;                                      /* :252-256 */
+    int64_t nel = 0;
+    double cost_discarded = 0.0;
+    for (int64_t p = 0; p < N; ++p) {                                    /* :260-272 */
+        if (fabs(row[p]) > thr) {
+            cols[nel] = (int32_t)(p + 1);
+            vals[nel] = (float)row[p];
+            ++nel;
+        } else {
+            cost_discarded = cost_discarded + row[p] * row[p];
+        }
+    }
+    if (thr_out) *thr_out = thr;
+    if (cost_discarded_out) *cost_discarded_out = cost_discarded;
+    return nel;
+}
+
+int64_t orc_build_row_grav(int64_t N, int nx, int ny, int nz, const double *X1, const double *X2,
+                           const double *Y1, const double *Y2, const double *Z1, const double *Z2,
+                           const double *cw, double xd, double yd, double zd, int compression_type,
+                           int64_t K, double *work, int32_t *cols, float *vals, double *error_r, int *ierr)
+{
+    *ierr = orc_graviprism_z(N, X1, X2, Y1, Y2, Z1, Z2, xd, yd, zd, work);      /* :196 */
+    if (*ierr) return 0;
+    for (int64_t p = 0; p < N; ++p) work[p] = work[p] * cw[p];                  /* :228, :1042-1054 */
+    if (compression_type > 0) {
+        double cost_full = 0.0;
+        for (int64_t p = 0; p < N; ++p) cost_full = cost_full + work[p] * work[p];   /* :234 */
+        orc_forward_wavelet(work, nx, ny, nz, compression_type);                /* :237 */
+        double thr, cost_discarded;
+        int64_t nel = orc_compress_row(work, N, K, cols, vals, &thr, &cost_discarded);
+        if (error_r) *error_r = sqrt(cost_discarded / cost_full);               /* :283 */
+        return nel;
+    }
+    for (int64_t p = 0; p < N; ++p) { cols[p] = (int32_t)(p + 1); vals[p] = (float)work[p]; }   /* :289-295 */
+    if (error_r) *error_r = 0.0;
+    return N;
+}
+
+void orc_partition(const int32_t *nnz, int64_t N, int P, int32_t *nel_at_cpu, int64_t *nnz_at_cpu)
+{
+    int64_t nnz_total = 0;
+    for (int64_t p = 0; p < N; ++p) nnz_total += nnz[p];                         /* :484-488 */
+    int64_t *cum = (int64_t *)malloc((size_t)P * sizeof(int64_t));
+    int64_t run = 0;
+    for (int c = 0; c < P; ++c) {                                                /* :491-493 */
+        int64_t best = nnz_total / P;
+        if (c == P - 1) best += nnz_total % P;
+        run += best;
+        cum[c] = run;
+        nel_at_cpu[c] = 0;
+        nnz_at_cpu[c] = 0;
+    }
+    int cpu = 0;
+    int64_t nnz_new = 0, sum_nnz = 0;
+    int32_t nel_new = 0;
+    for (int64_t p = 0; p < N; ++p) {                                            /* :501-514 */
+        nnz_new += nnz[p];
+        sum_nnz += nnz[p];
+        nel_new += 1;
+        if ((cpu < P - 1 && sum_nnz >= cum[cpu]) || p == N - 1) {
+            if (cpu < P) { nnz_at_cpu[cpu] = nnz_new; nel_at_cpu[cpu] = nel_new; }
+            nnz_new = 0;
+            nel_new = 0;
+            cpu++;
+        }
+    }
+    free(cum);
+}
+
+void orc_spmv_add(int64_t nrows, const int64_t *rowptr, const int32_t *cols, const float *vals,
+                  const double *x, double *b)
+{
+    for (int64_t i = 0; i < nrows; ++i)                                          /* sparse_matrix.f90:322-327 */
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+            b[i] = b[i] + (double)vals[k] * x[cols[k] - 1];
+}
+
+void orc_spmtv_add(int64_t nrows, const int64_t *rowptr, const int32_t *cols, const float *vals,
+                   const double *x, double *b)
+{
+    for (int64_t i = 0; i < nrows; ++i)                                          /* sparse_matrix.f90:397-403 */
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            int64_t j = cols[k] - 1;
+            b[j] = b[j] + (double)vals[k] * x[i];
+        }
+}
+
+void orc_soft_threshold(double *x, int64_t n, double gamma)
+{
+    for (int64_t i = 0; i < n; ++i) {                                            /* lsqr_solver2.F90:485-493 */
+        if (fabs(x[i]) <= gamma) x[i] = 0.0;
+        else if (x[i] <= -gamma) x[i] = x[i] + gamma;
+        else if (x[i] >= gamma) x[i] = x[i] - gamma;
+    }
+}
+
+static double norm2_plain(const double *x, int64_t n)
+{
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += x[i] * x[i];
+    return sqrt(s);
+}
+
+/* lsqr_solver2.F90:501-530: returns -1 when the norm is zero (vector left untouched). */
+static int normalize_vec(double *x, int64_t n, double *s)
+{
+    *s = norm2_plain(x, n);
+    if (*s == 0.0) return -1;
+    double ss = 1.0 / *s;
+    for (int64_t i = 0; i < n; ++i) x[i] = ss * x[i];
+    return 0;
+}
+
+int orc_lsqr_solve_sensit(int64_t nl_s, int64_t nl_c, int64_t ncols, int niter, double rmin, double gamma,
+                          double target_misfit,
+                          const int64_t *s_rowptr, const int32_t *s_cols, const float *s_vals,
+                          const int64_t *c_rowptr, const int32_t *c_cols, const float *c_vals,
+                          double *u, double *x, double *r_out)
+{
+    int64_t nlines = nl_s + nl_c;
+    double *v = (double *)calloc((size_t)ncols, sizeof(double));
+    double *w = (double *)calloc((size_t)ncols, sizeof(double));
+    double *v2 = (double *)calloc((size_t)ncols, sizeof(double));
+    double *b0 = NULL, *Sx = NULL;
+    int calc_misfit = target_misfit > 0.0;
+    if (calc_misfit) {
+        b0 = (double *)malloc((size_t)nl_s * sizeof(double));
+        Sx = (double *)malloc((size_t)nl_s * sizeof(double));
+        memcpy(b0, u, (size_t)nl_s * sizeof(double));                            /* :105 */
+    }
+    double alpha, beta, rho, rhobar, phi, phibar, theta, b1, c, s, t1, t2, rho_inv, r = 1.0;
+    int iter = 1;
+    memset(x, 0, (size_t)ncols * sizeof(double));                                /* :120 */
+    if (norm2_plain(u, nlines) == 0.0) { r = 0.0; iter = 1; goto done; }         /* :123-126 */
+    normalize_vec(u, nlines, &beta);                                             /* :129 */
+    b1 = beta;
+    orc_spmtv_add(nl_s, s_rowptr, s_cols, s_vals, u, v2);                        /* :137 (v2 starts at 0) */
+    memcpy(v, v2, (size_t)ncols * sizeof(double));                               /* :145 */
+    if (nl_c > 0) orc_spmtv_add(nl_c, c_rowptr, c_cols, c_vals, u + nl_s, v);    /* :147 */
+    normalize_vec(v, ncols, &alpha);                                             /* :150 */
+    rhobar = alpha;
+    phibar = beta;
+    memcpy(w, v, (size_t)ncols * sizeof(double));
+
+    while (iter <= niter && r > rmin) {                                          /* :163 */
+        if (calc_misfit) {                                                       /* :168-189 */
+            memset(Sx, 0, (size_t)nl_s * sizeof(double));
+            orc_spmv_add(nl_s, s_rowptr, s_cols, s_vals, x, Sx);
+            double ss = 0.0;
+            for (int64_t i = 0; i < nl_s; ++i) ss += (Sx[i] - b0[i]) * (Sx[i] - b0[i]);
+            if (sqrt(ss / (double)nl_s) <= target_misfit) break;
+        }
+        for (int64_t i = 0; i < nlines; ++i) u[i] = -alpha * u[i];               /* :195 */
+        orc_spmv_add(nl_s, s_rowptr, s_cols, s_vals, v, u);                      /* :209 */
+        if (nl_c > 0) orc_spmv_add(nl_c, c_rowptr, c_cols, c_vals, v, u + nl_s); /* :211 */
+        normalize_vec(u, nlines, &beta);                                         /* :218 */
+        for (int64_t i = 0; i < ncols; ++i) v[i] = -beta * v[i];                 /* :225 */
+        memset(v2, 0, (size_t)ncols * sizeof(double));
+        orc_spmtv_add(nl_s, s_rowptr, s_cols, s_vals, u, v2);                    /* :228 */
+        for (int64_t i = 0; i < ncols; ++i) v[i] = v[i] + v2[i];                 /* :236 */
+        if (nl_c > 0) orc_spmtv_add(nl_c, c_rowptr, c_cols, c_vals, u + nl_s, v);/* :238 */
+        normalize_vec(v, ncols, &alpha);                                         /* :241 */
+        rho = sqrt(rhobar * rhobar + beta * beta);                               /* :248 */
+        if (rho == 0.0) break;                                                   /* :251-254 */
+        rho_inv = 1.0 / rho;                                                     /* :257-266 */
+        c = rhobar * rho_inv;
+        s = beta * rho_inv;
+        theta = s * alpha;
+        rhobar = -c * alpha;
+        phi = c * phibar;
+        phibar = s * phibar;
+        t1 = phi * rho_inv;
+        t2 = -theta * rho_inv;
+        for (int64_t i = 0; i < ncols; ++i) x[i] = t1 * w[i] + x[i];             /* :269 */
+        for (int64_t i = 0; i < ncols; ++i) w[i] = t2 * w[i] + v[i];             /* :270 */
+        if (gamma != 0.0) orc_soft_threshold(x, ncols, gamma);                   /* :272-274 */
+        r = phibar / b1;                                                         /* :277-280 */
+        iter = iter + 1;
+        if (fabs(rhobar) < 1.e-30) break;                                        /* :286-289 */
+    }
+done:
+    free(v); free(w); free(v2); free(b0); free(Sx);
+    if (r_out) *r_out = r;
+    return iter - 1;
+}
+
+int orc_calc_data(int64_t N, int nx, int ny, int nz, int64_t ndata, const double *model, const double *cw,
+                  int compression_type, const int64_t *s_rowptr, const int32_t *s_cols, const float *s_vals,
+                  double problem_weight, const double *data_weight, double *work, double *data_calc)
+{
+    for (int64_t i = 0; i < N; ++i)                                              /* model.F90:242-250 */
+        work[i] = (cw[i] != 0.0) ? model[i] / cw[i] : 0.0;
+    if (compression_type > 0) orc_forward_wavelet(work, nx, ny, nz, compression_type);   /* :277-279 */
+    for (int64_t i = 0; i < ndata; ++i) data_calc[i] = 0.0;
+    orc_spmv_add(ndata, s_rowptr, s_cols, s_vals, work, data_calc);              /* :285-286 */
+    if (problem_weight == 0.0) return -1;                                        /* :295-299 */
+    for (int64_t i = 0; i < ndata; ++i) data_calc[i] = data_calc[i] / problem_weight;
+    for (int64_t i = 0; i < ndata; ++i) data_calc[i] = data_calc[i] / data_weight[i];    /* :302 */
+    return 0;
+}

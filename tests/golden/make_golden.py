@@ -1,0 +1,367 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors in tests/golden/*.npz by RUNNING THE REFERENCE in the development container.
+
+Needs oracle/_ref (built from /root/reference by oracle/ref_build.sh) - i.e. it only runs where
+/root/reference exists.  The fixtures it writes are data only: inputs we generate here (seeded), inputs
+shipped in the reference's data/ folder for its own example run (mansf_slice), and the outputs the
+reference produced for them.  No reference source text is stored.
+
+  python tests/golden/make_golden.py            # regenerate everything
+
+Files written:
+  wavelet.npz    forward/inverse Haar + D4 on several (odd-sized too) arrays          [gold_wavelet driver]
+  prism.npz      graviprism_z rows on a non-uniform 8x6x5 grid                        [gold_prism driver]
+  lsqr.npz       S.x, S^T.y and lsqr_solve_sensit solutions for [S; C] systems        [gold_lsqr driver]
+  e2e_*.npz      full `tomofastx -p Parfile` runs: SENSIT rows, weights, nnz, partition, models, data
+  mansf.npz      BASELINE config 1 (parfiles/Parfile_mansf_slice.txt), trimmed
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFBIN = os.path.join(ROOT, "oracle", "_ref")
+REFROOT = "/root/reference"
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def run(cmd, stdin=None, cwd=None, timeout=1200):
+    p = subprocess.run(cmd, input=stdin, cwd=cwd, capture_output=True, text=True, timeout=timeout)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout[-3000:] + "\n" + p.stderr[-3000:])
+        raise RuntimeError("command failed: %s" % (cmd,))
+    return p.stdout
+
+
+def be(a, dt):
+    return np.ascontiguousarray(a).astype(dt).tobytes()
+
+
+# ----------------------------------------------------------------------------------------------------
+def make_wavelet(tmp):
+    rng = np.random.default_rng(1234)
+    out = {}
+    shapes = [(3, 4, 5), (10, 11, 12), (16, 16, 8), (13, 7, 33), (2, 128, 32), (1, 5, 1), (7, 1, 2)]
+    for (n1, n2, n3) in shapes:
+        a = rng.standard_normal(n1 * n2 * n3)
+        for wt in (1, 2):
+            fin, ffw, fiv = [os.path.join(tmp, x) for x in ("w_in.bin", "w_fw.bin", "w_iv.bin")]
+            open(fin, "wb").write(be(a, ">f8"))
+            run([os.path.join(REFBIN, "gold_wavelet")], stdin="%d %d %d %d 1\n%s\n%s\n" % (n1, n2, n3, wt, fin, ffw))
+            run([os.path.join(REFBIN, "gold_wavelet")], stdin="%d %d %d %d 2\n%s\n%s\n" % (n1, n2, n3, wt, fin, fiv))
+            key = "%dx%dx%d_t%d" % (n1, n2, n3, wt)
+            out[key + "_in"] = a
+            out[key + "_fwd"] = np.fromfile(ffw, ">f8").astype(np.float64)
+            out[key + "_inv"] = np.fromfile(fiv, ">f8").astype(np.float64)
+    np.savez_compressed(os.path.join(HERE, "wavelet.npz"), **out)
+    print("wavelet.npz:", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------------------------
+def nonuniform_grid(nx, ny, nz, rng, x0=100.0, y0=-50.0, z0=0.0):
+    dx = rng.uniform(20, 90, nx)
+    dy = rng.uniform(20, 90, ny)
+    dz = rng.uniform(10, 60, nz)
+    xe = x0 + np.concatenate([[0], np.cumsum(dx)])
+    ye = y0 + np.concatenate([[0], np.cumsum(dy)])
+    ze = z0 + np.concatenate([[0], np.cumsum(dz)])
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    i, j, k = i.ravel(), j.ravel(), k.ravel()          # i fastest
+    return xe[i], xe[i + 1], ye[j], ye[j + 1], ze[k], ze[k + 1]
+
+
+def make_prism(tmp):
+    rng = np.random.default_rng(42)
+    nx, ny, nz = 8, 6, 5
+    g = nonuniform_grid(nx, ny, nz, rng)
+    xe0, xe1 = g[0].min(), g[1].max()
+    ye0, ye1 = g[2].min(), g[3].max()
+    obs = np.array([
+        [0.5 * (xe0 + xe1) + 0.37, 0.5 * (ye0 + ye1) + 0.41, -1.0],      # above the centre
+        [xe0 - 150.0, ye0 - 77.0, -25.0],                                 # outside the footprint
+        [xe1 + 10.3, 0.5 * (ye0 + ye1), -0.1],
+        [g[0][3] + 7.77, g[2][9] + 3.33, -0.5],
+        [0.5 * (g[0][20] + g[1][20]) + 1.234, 0.5 * (g[2][20] + g[3][20]) - 2.2, 0.5 * (g[4][100] + g[5][100]) + 0.77],  # inside the mesh
+    ])
+    nel, nd = nx * ny * nz, obs.shape[0]
+    fg, fo, fout = [os.path.join(tmp, x) for x in ("p_grid.bin", "p_obs.bin", "p_out.bin")]
+    open(fg, "wb").write(b"".join(be(a, ">f8") for a in g))
+    open(fo, "wb").write(be(obs[:, 0], ">f8") + be(obs[:, 1], ">f8") + be(obs[:, 2], ">f8"))
+    run([os.path.join(REFBIN, "gold_prism")], stdin="%d %d\n%s\n%s\n%s\n" % (nel, nd, fg, fo, fout))
+    rows = np.fromfile(fout, ">f8").astype(np.float64).reshape(nd, nel)
+    np.savez_compressed(os.path.join(HERE, "prism.npz"), nx=nx, ny=ny, nz=nz, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3],
+                        Z1=g[4], Z2=g[5], obs=obs, rows=rows)
+    print("prism.npz: rows", rows.shape)
+
+
+# ----------------------------------------------------------------------------------------------------
+def rand_csr(rng, nl, ncols, density, empty_rows=()):
+    rc = np.zeros(nl, np.int32)
+    cols, vals = [], []
+    for r in range(nl):
+        if r in empty_rows:
+            continue
+        m = rng.random(ncols) < density
+        c = np.nonzero(m)[0].astype(np.int32) + 1
+        rc[r] = c.size
+        cols.append(c)
+        vals.append(rng.standard_normal(c.size).astype(np.float32))
+    cols = np.concatenate(cols) if cols else np.zeros(0, np.int32)
+    vals = np.concatenate(vals) if vals else np.zeros(0, np.float32)
+    return rc, cols, vals
+
+
+def make_lsqr(tmp):
+    rng = np.random.default_rng(7)
+    out = {}
+    cases = {}
+    # case "damp": S random 40 x 60, C = 1e-1 * I (the damping block of damping.F90:158-179)
+    nl_s, ncols = 40, 60
+    S = rand_csr(rng, nl_s, ncols, 0.3, empty_rows=(5, 17))
+    C = (np.ones(ncols, np.int32), np.arange(1, ncols + 1, dtype=np.int32), np.full(ncols, 0.1, np.float32))
+    cases["damp"] = (nl_s, ncols, ncols, S, C, [(1, 1e-13, 0.0), (2, 1e-13, 0.0), (5, 1e-13, 0.0), (20, 1e-13, 0.0),
+                                                 (100, 1e-13, 0.0), (30, 1e-3, 0.0), (20, 1e-13, 1e-3)])
+    # case "gen": tall S, general sparse C with empty rows
+    nl_s, ncols, nl_c = 90, 50, 70
+    S = rand_csr(rng, nl_s, ncols, 0.2, empty_rows=(0, 89))
+    C = rand_csr(rng, nl_c, ncols, 0.05, empty_rows=(3, 4, 5, 69))
+    cases["gen"] = (nl_s, ncols, nl_c, S, C, [(3, 1e-13, 0.0), (50, 1e-13, 0.0), (400, 1e-13, 0.0)])
+    # case "noC": no constraint rows at all
+    nl_s, ncols = 30, 30
+    S = rand_csr(rng, nl_s, ncols, 0.5)
+    C = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    cases["noC"] = (nl_s, ncols, 0, S, C, [(10, 1e-13, 0.0), (200, 1e-13, 0.0)])
+    for name, (nl_s, ncols, nl_c, S, C, runs) in cases.items():
+        xin = rng.standard_normal(ncols)
+        yin = rng.standard_normal(nl_s)
+        b = rng.standard_normal(nl_s + nl_c)
+        fin, fout = os.path.join(tmp, "l_in.bin"), os.path.join(tmp, "l_out.bin")
+        with open(fin, "wb") as f:
+            f.write(be([nl_s, nl_c, ncols, S[1].size, C[1].size, len(runs)], ">i4"))
+            f.write(be(S[0], ">i4") + be(S[1], ">i4") + be(S[2], ">f4"))
+            f.write(be(C[0], ">i4") + be(C[1], ">i4") + be(C[2], ">f4"))
+            f.write(be(xin, ">f8") + be(yin, ">f8") + be(b, ">f8"))
+            for (niter, rmin, gamma) in runs:
+                f.write(be([niter], ">i4") + be([rmin, gamma], ">f8"))
+        log = run([os.path.join(REFBIN, "gold_lsqr")], stdin="%s\n%s\n" % (fin, fout))
+        res = np.fromfile(fout, ">f8").astype(np.float64)
+        sx, sty = res[:nl_s], res[nl_s:nl_s + ncols]
+        xs = res[nl_s + ncols:].reshape(len(runs), ncols)
+        fin_r = [float(m.group(1)) for m in re.finditer(r"Finished lsqr solver, r =\s*([0-9.eE+-]+)", log)]
+        fin_it = [int(m.group(1)) for m in re.finditer(r"iter =\s*(\d+)", log)]
+        out.update({name + "_nl_s": nl_s, name + "_nl_c": nl_c, name + "_ncols": ncols,
+                    name + "_S_rc": S[0], name + "_S_cols": S[1], name + "_S_vals": S[2],
+                    name + "_C_rc": C[0], name + "_C_cols": C[1], name + "_C_vals": C[2],
+                    name + "_xin": xin, name + "_yin": yin, name + "_b": b,
+                    name + "_runs": np.array(runs, np.float64), name + "_Sx": sx, name + "_STy": sty,
+                    name + "_x": xs, name + "_r": np.array(fin_r), name + "_iters": np.array(fin_it)})
+        assert len(fin_r) == len(runs) and len(fin_it) == len(runs), (name, fin_r, fin_it)
+    np.savez_compressed(os.path.join(HERE, "lsqr.npz"), **out)
+    print("lsqr.npz:", list(cases))
+
+
+# ----------------------------------------------------------------------------------------------------
+def write_grid_file(path, g, nx, ny, nz):
+    n = nx * ny * nz
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    with open(path, "w") as f:
+        f.write("%d\n" % n)
+        for p in range(n):
+            f.write("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %d\n" % (
+                g[0][p], g[1][p], g[2][p], g[3][p], g[4][p], g[5][p], i.ravel()[p] + 1, j.ravel()[p] + 1, k.ravel()[p] + 1))
+
+
+def parse_sensit(path):
+    """SENSIT row file (sensitivity_gravmag.F90:183, :306-309): big-endian stream."""
+    raw = open(path, "rb").read()
+    hdr = np.frombuffer(raw, ">i4", 5, 0)
+    ndata_loc = int(hdr[0])
+    off = 20
+    rows = []
+    for _ in range(ndata_loc):
+        idata, nel, k, d = [int(v) for v in np.frombuffer(raw, ">i4", 4, off)]
+        off += 16
+        cols = np.frombuffer(raw, ">i4", nel, off).astype(np.int32)
+        off += 4 * nel
+        vals = np.frombuffer(raw, ">f4", nel, off).astype(np.float32)
+        off += 4 * nel
+        rows.append((idata, cols, vals))
+    assert off == len(raw)
+    return hdr.astype(np.int64), rows
+
+
+def read_col(path, col, skip=1):
+    return np.loadtxt(path, skiprows=skip, usecols=[col], ndmin=1).astype(np.float64)
+
+
+def run_parfile(tmp, name, parfile_text, nproc, workdir_links=()):
+    wd = os.path.join(tmp, name + "_np%d" % nproc)
+    shutil.rmtree(wd, ignore_errors=True)
+    os.makedirs(wd)
+    for src, dst in workdir_links:
+        os.symlink(src, os.path.join(wd, dst))
+    pf = os.path.join(wd, "Parfile.txt")
+    open(pf, "w").write(parfile_text)
+    log = run([MPIEXEC, "-n", str(nproc), os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+    open(os.path.join(wd, "log.txt"), "w").write(log)
+    return wd, log
+
+
+def collect_run(wd, log, outdir, nproc, max_rows=None):
+    o = {}
+    sd = os.path.join(wd, outdir, "SENSIT")
+    rows_all = []
+    for r in range(nproc):
+        hdr, rows = parse_sensit(os.path.join(sd, "sensit_grav_%d_%d" % (nproc, r)))
+        rows_all += rows
+    rows_all.sort(key=lambda t: t[0])
+    nel = np.array([r[1].size for r in rows_all], np.int64)
+    o["row_nel"] = nel
+    keep = rows_all if max_rows is None else rows_all[:max_rows]
+    o["rows_kept"] = np.array([r[0] for r in keep], np.int64)
+    o["row_ptr"] = np.concatenate([[0], np.cumsum([r[1].size for r in keep])]).astype(np.int64)
+    o["cols"] = np.concatenate([r[1] for r in keep])
+    o["vals"] = np.concatenate([r[2] for r in keep])
+    w = open(os.path.join(sd, "sensit_grav_weight"), "rb").read()
+    o["column_weight"] = np.frombuffer(w, ">f8", offset=4).astype(np.float64)
+    z = open(os.path.join(sd, "sensit_grav_nnz"), "rb").read()
+    o["sensit_nnz"] = np.frombuffer(z, ">i4", offset=4).astype(np.int32)
+    meta = open(os.path.join(sd, "sensit_grav_meta.txt")).read().split()
+    o["comp_error"] = float(meta[8])
+    o["nnz_total"] = int(meta[11])
+    m = re.search(r"nelements_at_cpu =\s*([0-9 ]+)", log)
+    o["nelements_at_cpu"] = np.array([int(v) for v in m.group(1).split()], np.int64)
+    m = re.search(r"nnz_at_cpu =\s*([0-9 ]+)", log)
+    o["nnz_at_cpu"] = np.array([int(v) for v in m.group(1).split()], np.int64)
+    dd = os.path.join(wd, outdir, "data")
+    o["data_observed"] = read_col(os.path.join(dd, "grav_observed.txt"), 3)
+    o["data_final"] = read_col(os.path.join(dd, "grav_final.txt"), 3)
+    o["model_final"] = read_col(os.path.join(wd, outdir, "model", "grav_final_model_full.txt"), 0)
+    # costs.txt: 6 wrapped header lines (20 column names), then 20 list-directed numbers per major iteration
+    txt = open(os.path.join(wd, outdir, "costs.txt")).read()
+    toks = txt[txt.index("clustering_cost_mag") + len("clustering_cost_mag"):].split()
+    # (the reference never flushes the last record: it is cut after 5 fields - pad it with NaN)
+    vals = [float(t) for t in toks]
+    vals += [np.nan] * ((-len(vals)) % 20)
+    o["costs"] = np.array(vals, np.float64).reshape(-1, 20)
+    o["lsqr_r"] = np.array([float(m.group(1)) for m in re.finditer(r"Finished lsqr solver, r =\s*([0-9.eE+-]+)", log)])
+    return o
+
+
+PAR_TMPL = """global.outputFolderPath     = out/
+global.description          = golden synthetic
+modelGrid.size                      = {nx} {ny} {nz}
+modelGrid.grav.file                 = grid.txt
+forward.data.grav.nData             = {nd}
+forward.data.grav.dataGridFile      = data_grid.txt
+forward.data.grav.useSyntheticModelForDataValues = 1
+forward.data.grav.syntheticModelFile = model_true.txt
+forward.depthWeighting.type         = 1
+forward.depthWeighting.grav.power   = 2.0d0
+sensit.readFromFiles                = 0
+sensit.folderPath                   = out/SENSIT/
+forward.matrixCompression.type      = {ctype}
+forward.matrixCompression.rate      = {rate}
+inversion.priorModel.type           = 1
+inversion.priorModel.grav.value     = 0.d0
+inversion.startingModel.type        = 1
+inversion.startingModel.grav.value  = 0.d0
+inversion.nMajorIterations          = {nmajor}
+inversion.nMinorIterations          = {nminor}
+inversion.writeModelEveryNiter      = 0
+inversion.minResidual               = 1.d-13
+inversion.modelDamping.grav.weight  = {alpha}
+inversion.modelDamping.normPower    = 2.0d0
+inversion.joint.grav.problemWeight  = 1.d0
+inversion.joint.magn.problemWeight  = 0.d0
+inversion.admm.enableADMM           = 0
+"""
+
+
+def synthetic_problem(nx, ny, nz, ox, oy, h=100.0):
+    """SURVEY.md 8(d) generator: uniform cells, lattice of observations 1 m above the surface, 300 kg/m3 block."""
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    i, j, k = i.ravel(), j.ravel(), k.ravel()
+    g = (i * h, (i + 1) * h, j * h, (j + 1) * h, k * h, (k + 1) * h)
+    a, b = np.meshgrid(np.arange(ox), np.arange(oy), indexing="xy")
+    xs = (a.ravel() + 0.5) * nx * h / ox + 0.37
+    ys = (b.ravel() + 0.5) * ny * h / oy + 0.41
+    zs = np.full(xs.size, -1.0)
+    m = np.where((k >= nz // 4) & (k < nz // 2) & (j >= ny // 3) & (j < 2 * ny // 3) & (i >= nx // 3) & (i < 2 * nx // 3), 300.0, 0.0)
+    return [np.asarray(v, np.float64) for v in g], np.stack([xs, ys, zs], 1), m
+
+
+def make_e2e(tmp):
+    cfgs = {
+        "e2e_haar": dict(nx=16, ny=12, nz=8, ox=6, oy=5, ctype=1, rate="0.1d0", nmajor=3, nminor=20, alpha="1.d-7"),
+        "e2e_d4": dict(nx=13, ny=7, nz=9, ox=4, oy=3, ctype=2, rate="0.2d0", nmajor=2, nminor=30, alpha="1.d-7"),
+        "e2e_full": dict(nx=8, ny=6, nz=5, ox=3, oy=3, ctype=0, rate="1.d0", nmajor=2, nminor=25, alpha="1.d-6"),
+    }
+    for name, c in cfgs.items():
+        g, obs, mtrue = synthetic_problem(c["nx"], c["ny"], c["nz"], c["ox"], c["oy"])
+        nd = obs.shape[0]
+        par = PAR_TMPL.format(nd=nd, **c)
+        res = {}
+        for nproc in (1, 2):
+            wd = os.path.join(tmp, name + "_np%d" % nproc)
+            shutil.rmtree(wd, ignore_errors=True)
+            os.makedirs(wd)
+            write_grid_file(os.path.join(wd, "grid.txt"), g, c["nx"], c["ny"], c["nz"])
+            with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+                f.write("%d\n" % nd)
+                for r in obs:
+                    f.write("%.17g %.17g %.17g 0.0\n" % tuple(r))
+            with open(os.path.join(wd, "model_true.txt"), "w") as f:
+                f.write("%d\n" % mtrue.size)
+                for v in mtrue:
+                    f.write("%.17g\n" % v)
+            pf = os.path.join(wd, "Parfile.txt")
+            open(pf, "w").write(par)
+            log = run([MPIEXEC, "-n", str(nproc), os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+            o = collect_run(wd, log, "out", nproc)
+            for kk, vv in o.items():
+                res["np%d_%s" % (nproc, kk)] = vv
+        res.update(dict(nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=float(c["rate"].replace("d", "e")),
+                        nmajor=c["nmajor"], nminor=c["nminor"], alpha=float(c["alpha"].replace("d", "e")),
+                        X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs, model_true=mtrue))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+        print(name + ".npz: nnz", res["np1_nnz_total"], "partition np2", res["np2_nelements_at_cpu"])
+
+
+def make_mansf(tmp):
+    """BASELINE config 1.  Inputs are the reference's shipped example data (data/gravmag/mansf_slice)."""
+    par = open(os.path.join(REFROOT, "parfiles", "Parfile_mansf_slice.txt")).read()
+    res = {}
+    for nproc in (1, 2, 4):
+        wd, log = run_parfile(tmp, "mansf", par, nproc, workdir_links=[(os.path.join(REFROOT, "data"), "data")])
+        o = collect_run(wd, log, "output/mansf_slice", nproc, max_rows=8)
+        if nproc == 1:
+            for kk, vv in o.items():
+                res[kk] = vv
+        else:
+            for kk in ("nelements_at_cpu", "nnz_at_cpu", "model_final", "costs"):
+                res["np%d_%s" % (nproc, kk)] = o[kk]
+    dd = os.path.join(REFROOT, "data", "gravmag", "mansf_slice")
+    grid = np.loadtxt(os.path.join(dd, "true_model_grav_3litho-grid.txt"), skiprows=1)
+    res.update(dict(nx=2, ny=128, nz=32, X1=grid[:, 0], X2=grid[:, 1], Y1=grid[:, 2], Y2=grid[:, 3], Z1=grid[:, 4], Z2=grid[:, 5],
+                    obs=np.loadtxt(os.path.join(dd, "data_grid.txt"), skiprows=1)[:, :3],
+                    model_true=read_col(os.path.join(dd, "true_model_grav_3litho-values.txt"), 0),
+                    admm_bounds=np.array([-20., 20., 90., 130., 220., 260.]), admm_weight=1e-5,
+                    rate=0.15, nmajor=60, nminor=100))
+    np.savez_compressed(os.path.join(HERE, "mansf.npz"), **res)
+    print("mansf.npz: nnz", res["nnz_total"], "err", res["comp_error"], "P2", res["np2_nelements_at_cpu"], "P4", res["np4_nelements_at_cpu"])
+
+
+if __name__ == "__main__":
+    if not os.path.isfile(os.path.join(REFBIN, "tomofastx")):
+        sys.exit("oracle/_ref is not built (run oracle/ref_build.sh in the development container)")
+    what = sys.argv[1:] or ["wavelet", "prism", "lsqr", "e2e", "mansf"]
+    with tempfile.TemporaryDirectory() as tmp:
+        for w in what:
+            globals()["make_" + w](tmp)

@@ -1,0 +1,80 @@
+"""Major inversion loop restated on top of the oracle's C functions (test infrastructure).
+
+Follows src/problem_joint_gravmag.F90:473-547 and src/inversion/joint_inverse_problem.F90:393-573 for a
+single gravity problem on one rank with WAVELET_DOMAIN = true (or compression off):
+  residuals (problem_joint_gravmag.F90:666-675) -> RHS + damping / ADMM diagonal blocks
+  (damping.F90:97-234, admm_method.F90:70-134) -> lsqr_solve_sensit -> inverse wavelet + rescale
+  (joint_inverse_problem.F90:559-571) -> model update -> calculate_data (model.F90:220-307).
+"""
+import numpy as np
+
+import oracle_lib as orc
+
+
+def admm_iterate(z, u, x, bounds):
+    """admm_method.F90:70-134 with global bounds [lo1 hi1 lo2 hi2 ...]; updates z, u in place; returns x0."""
+    lo, hi = np.asarray(bounds[0::2]), np.asarray(bounds[1::2])
+    arg = x + u
+    inside = ((lo[None, :] <= arg[:, None]) & (arg[:, None] <= hi[None, :])).any(1)
+    cand = np.stack([np.abs(np.stack([lo, hi], 1).ravel()[None, :] - arg[:, None])], 0)[0]
+    ends = np.stack([lo, hi], 1).ravel()
+    closest = ends[np.argmin(cand, axis=1)]          # first minimum wins, like the strict '<' of :113-121
+    z[:] = np.where(inside, arg, closest)
+    u[:] = u + x - z
+    return z - u
+
+
+def run_inversion(S, cw, dims, ctype, d_obs, nmajor, nminor, alpha=0.0, rmin=1e-13, pw=1.0, m0=None, m_prior=None,
+                  admm=None, lsqr=None, calc_data=None):
+    """S = (rowptr, cols, vals) CSR.  admm = dict(bounds=..., rho=...) or None.
+    lsqr / calc_data: replaceable callables (default: oracle) so that tests can run the SAME loop on the HIP path.
+    Returns final model, calculated data and per-iteration records."""
+    N = int(np.prod(dims))
+    nd = d_obs.size
+    dw = np.ones(nd)
+    m = np.zeros(N) if m0 is None else np.array(m0, np.float64)
+    mp = np.zeros(N) if m_prior is None else np.asarray(m_prior, np.float64)
+    lsqr = lsqr or (lambda blocks, b, niter: orc.lsqr(S, _blocks_csr(blocks, N), N, b, niter, rmin)[:3])
+    calc_data = calc_data or (lambda model: orc.calc_data(model, cw, dims, ctype, S, pw, dw))
+    d_calc = calc_data(m)
+    z, u = np.zeros(N), np.zeros(N)
+    hist = []
+    for it in range(nmajor):
+        res = dw * (d_obs - d_calc)                                       # problem_joint_gravmag.F90:666-675
+        rhs = [pw * res]                                                  # joint_inverse_problem.F90:379-387
+        blocks = []
+        if alpha != 0.0:                                                  # damping.F90:97-234
+            md = (m - mp) / cw
+            if ctype > 0:
+                md = orc.wavelet(md, dims[0], dims[1], dims[2], ctype)
+            blocks.append(np.full(N, np.float32(alpha * pw), np.float32))
+            rhs.append(-alpha * pw * md)
+        if admm is not None:                                              # joint_inverse_problem.F90:497-527
+            x0 = admm_iterate(z, u, m, admm["bounds"])
+            md = (m - x0) / cw
+            if ctype > 0:
+                md = orc.wavelet(md, dims[0], dims[1], dims[2], ctype)
+            blocks.append(np.full(N, np.float32(admm["rho"] * pw), np.float32))
+            rhs.append(-admm["rho"] * pw * md)
+        x, iters, r = lsqr(blocks, np.concatenate(rhs), nminor)
+        dm = orc.wavelet(x, dims[0], dims[1], dims[2], ctype, inverse=True) if ctype > 0 else x.copy()
+        dm = dm * cw                                                      # joint_inverse_problem.F90:570
+        m = m + dm
+        d_calc = calc_data(m)
+        hist.append(dict(iters=iters, r=r, cost=float(np.linalg.norm(d_calc - d_obs) / np.linalg.norm(d_obs))))
+    return m, d_calc, hist
+
+
+def _blocks_csr(blocks, N):
+    """Stack of diagonal blocks -> one CSR (what damping%add builds row by row)."""
+    rp, cs, vs = [np.zeros(1, np.int64)], [], []
+    off = 0
+    for d in blocks:
+        r, c, v = orc.diag_csr(d)
+        rp.append(r[1:] + off)
+        off += int(r[-1])
+        cs.append(c)
+        vs.append(v)
+    if not blocks:
+        return np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32)
+    return np.concatenate(rp), np.concatenate(cs), np.concatenate(vs)
