@@ -1,0 +1,150 @@
+/*
+ * tfx.h - C ABI of the MI355X-native Tomofast-x sensitivity-kernel hot path (libtfx.so).
+ *
+ * Drop-in boundary.  The reference (Tomofast-x, Fortran 2008 + MPI) has no FFI: its "plugin interface" for
+ * this path is the set of Fortran procedures that src/problem_joint_gravmag.F90 and
+ * src/inversion/joint_inverse_problem.F90 call.  Each entry point below replaces one of them; a Fortran host
+ * binds them with iso_c_binding (interface blocks in INTEGRATION.md, module tomofast-x_amd/host/tfx_binding.f90).
+ *
+ * Conventions
+ *  - Plain C: pointers + sizes, scalars by value, no C++/torch types.  All entry points return 0 on success,
+ *    <0 on error (TFX_E_*); tfx_last_error() gives the message.  The reference's convention is
+ *    print-banner + MPI_Abort (src/utils/mpi_tools.F90:29-53); the host turns a non-zero status into that.
+ *  - One tfx_ctx per GPU (one process per GPU, or one host thread per ctx).  Not thread-safe per ctx.
+ *  - Vector arguments may be HOST or DEVICE pointers (unified addressing, hipMemcpyDefault); they are
+ *    borrowed for the duration of the call.  Device memory is owned by the ctx.
+ *  - Column indices crossing the ABI are 1-based int32, as in the reference's SENSIT files and `ija`
+ *    (src/inversion/sparse_matrix.f90:57).  Values are fp32 (MATRIX_PRECISION, src/global_typedefs.F90:42),
+ *    vectors fp64 (CUSTOM_REAL, :31).  Cell order is i-fastest (src/inversion/grid.F90:409-426).
+ *  - Multi-GPU: the ctx of rank r holds a contiguous column range of S (reference: nelements_at_cpu,
+ *    src/forward/gravmag/sensitivity_gravmag.F90:470-524).  The two per-iteration reductions of LSQR
+ *    (src/inversion/lsqr_solver2.F90:214, :514) go through the all-reduce hook (tfx_set_allreduce); the host
+ *    language supplies RCCL (torch.distributed / ncclAllReduce) there.
+ */
+#ifndef TFX_H
+#define TFX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tfx_ctx tfx_ctx;
+
+enum {
+    TFX_OK = 0,
+    TFX_E_ARG = -1,        /* bad argument / size mismatch                                    */
+    TFX_E_HIP = -2,        /* HIP runtime error (no GPU, out of memory, launch failure)       */
+    TFX_E_GEOMETRY = -3,   /* "Data coordinate coincides with model grid boundary"            */
+                           /*   (src/forward/gravmag/grav/gravity_field.f90:176-181)          */
+    TFX_E_STATE = -4,      /* call order (no grid / no matrix / no solve in progress)         */
+    TFX_E_NUMERIC = -5,    /* zero norm / zero weight where the reference aborts              */
+    TFX_E_COMM = -6        /* the all-reduce hook reported failure                            */
+};
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+/* Creates a context on HIP device `device`.  `stream` = hipStream_t to launch on (NULL = null stream).      */
+int tfx_create(int device, void *stream, tfx_ctx **ctx);
+int tfx_destroy(tfx_ctx *ctx);
+const char *tfx_last_error(void);
+/* Library / device facts for logs: fills name[len], returns CU count (or <0). */
+int tfx_device_info(tfx_ctx *ctx, char *name, int len, int64_t *hbm_bytes);
+
+/* All-reduce hook (sum, fp64, in place on a DEVICE buffer of n doubles, enqueued on `stream`).
+ * NULL = single rank.  rank/nranks tell LSQR who adds the -alpha*u term (lsqr_solver2.F90:194-198).         */
+typedef int (*tfx_allreduce_fn)(void *user, double *dev_buf, int64_t n, void *stream);
+int tfx_set_allreduce(tfx_ctx *ctx, tfx_allreduce_fn fn, void *user, int rank, int nranks);
+
+/* ---- model grid ------------------------------------------------------------------------------------------
+ * Replaces t_grid (src/inversion/grid.F90:30-50): six fp64 arrays of nx*ny*nz cell bounds, uploaded once.   */
+int tfx_set_grid(tfx_ctx *ctx, int nx, int ny, int nz, const double *X1, const double *X2, const double *Y1,
+                 const double *Y2, const double *Z1, const double *Z2);
+
+/* calculate_depth_weight type 1 (src/forward/gravmag/weights_gravmag.f90:71-79,170-250) followed by
+ * column_weight *= multiplier (src/problem_joint_gravmag.F90:178).  cw_out: N doubles.                      */
+int tfx_column_weight_type1(tfx_ctx *ctx, double power, double Z0, double multiplier, double *cw_out);
+
+/* ---- unit-level kernels (also what the parity tests call) ------------------------------------------------ */
+/* graviprism_z (src/forward/gravmag/grav/gravity_field.f90:131-195): ndata rows of N, rows_out[ndata*N].    */
+int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
+                      double *rows_out);
+/* forward_wavelet / inverse_wavelet (src/utils/wavelet_transform.F90:37-70), in place on nvec arrays of
+ * n1*n2*n3 doubles stored back to back.  type 1 Haar, 2 D4; direction 1 forward, 2 inverse.                 */
+int tfx_wavelet(tfx_ctx *ctx, double *s, int n1, int n2, int n3, int64_t nvec, int type, int direction);
+/* Threshold + compaction of one row of wavelet coefficients (sensitivity_gravmag.F90:230-295).
+ * cols_out/vals_out need room for K entries.  Returns nel in *nel_out.                                      */
+int tfx_compress_row(tfx_ctx *ctx, const double *row, int64_t N, int64_t K, int32_t *cols_out, float *vals_out,
+                     int64_t *nel_out, double *thr_out, double *cost_discarded_out);
+
+/* ---- sensitivity matrix ----------------------------------------------------------------------------------
+ * calculate_and_write_sensit + read_sensitivity_kernel (sensitivity_gravmag.F90:82-410, :648-883) without the
+ * disk round trip: builds rows [0, ndata) for the observation points, keeps columns [col_begin, col_end)
+ * (0-based, half-open; whole matrix = [0, N)) and stores S device-resident.  Values are scaled by
+ * (float)(problem_weight * data_weight[i]) like :834-843 (data_weight NULL = 1).
+ * compression_type 0 none / 1 Haar / 2 D4; K = int(rate*N) (:64-77).
+ * Outputs: nnz kept in this ctx, sum over rows of the compression error r_i (:283) (divide by ndata for the
+ * reference's "COMPRESSION ERROR"), and optionally the per-column nnz histogram over ALL N columns (:267),
+ * which is what calculate_new_partitioning consumes.                                                        */
+int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
+                          const double *column_weight, int compression_type, double rate, double problem_weight,
+                          const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
+                          double *error_sum_out, int32_t *nnz_hist_out);
+
+/* Alternative to building: upload a CSR (what read_sensitivity_kernel assembles from SENSIT files;
+ * t_sparse_matrix add_row/new_row/finalize, src/inversion/sparse_matrix.f90:213-293).  rowptr: nrows+1
+ * 0-based offsets; cols 1-based local column indices in [1, ncols], ascending within a row.                 */
+int tfx_matrix_upload_csr(tfx_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr,
+                          const int32_t *cols, const float *vals);
+/* Size query, then download as CSR (for SENSIT-format writers and tests).                                   */
+int tfx_matrix_info(tfx_ctx *ctx, int64_t *nrows, int64_t *ncols, int64_t *nnz, int64_t *device_bytes);
+int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float *vals);
+int tfx_matrix_free(tfx_ctx *ctx);
+
+/* get_load_balancing_nelements (sensitivity_gravmag.F90:470-524): host-side, exact integer rule.            */
+int tfx_partition_columns(const int32_t *nnz_hist, int64_t N, int nparts, int32_t *nel_at_part,
+                          int64_t *nnz_at_part);
+
+/* t_sparse_matrix%mult_vector / add_mult_vector (sparse_matrix.f90:298-329): b (+)= S x.  x: ncols, b: nrows. */
+int tfx_spmv(tfx_ctx *ctx, const double *x, double *b, int add);
+/* trans_mult_vector / add_trans_mult_vector (sparse_matrix.f90:373-405): b (+)= S^T x.  x: nrows, b: ncols.  */
+int tfx_spmtv(tfx_ctx *ctx, const double *x, double *b, int add);
+
+/* ---- LSQR ------------------------------------------------------------------------------------------------
+ * lsqr_solve_sensit (src/inversion/lsqr_solver2.F90:47-308) over [S; C] where C is a stack of `nblocks`
+ * diagonal blocks diag(diag[b]) (the damping / ADMM blocks that damping%add builds, src/inversion/damping.F90:
+ * 97-201; values are fp32 like matrix%add stores them, sparse_matrix.f90:226), never materialised as CSR.
+ *   b_data: nrows (replicated on all ranks), rhs_blocks[b]: ncols (local), x_out: ncols (local).
+ * In the multi-rank case the constraint rows stay rank-local and only ||u_cons||^2 joins the all-reduce
+ * (mathematically identical to the reference's all-reduce over all rows, DESIGN.md "Multi-GPU").
+ * gamma != 0 enables soft thresholding (:478-494); target_misfit > 0 the misfit exit (:168-189).
+ * Returns iterations done and the final relative residual r = phibar / |b|.                                 */
+int tfx_lsqr_solve(tfx_ctx *ctx, int niter, double rmin, double gamma, double target_misfit,
+                   const double *b_data, int nblocks, const float *const *diag, const double *const *rhs_blocks,
+                   double *x_out, int *iters_out, double *r_out);
+
+/* The same solver in three steps, so that a caller (bench.py) can time exactly k iterations with everything
+ * resident: begin = lines :120-157 (x=0, normalise u, v = A^T u, ...), iterate = k passes of the loop body
+ * :163-290 (stops early on the reference's exit conditions; returns iterations actually done), end = copy x. */
+int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit, const double *b_data,
+                   int nblocks, const float *const *diag, const double *const *rhs_blocks);
+int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out);
+int tfx_lsqr_end(tfx_ctx *ctx, double *x_out);
+
+/* model_calculate_data (src/inversion/model.F90:220-307) after the model has been un-weighted and wavelet-
+ * transformed by the caller or by tfx_model_to_wavelet: data_calc[i] = (S xw)[i] / problem_weight /
+ * data_weight[i]; this is tfx_spmv + the two divisions, all-reduced through the hook.                       */
+int tfx_calc_data(tfx_ctx *ctx, const double *xw_local, double problem_weight, const double *data_weight,
+                  double *data_calc);
+
+/* ---- timing (HIP events on the ctx stream; what bench.py brackets the timed region with) ----------------- */
+int tfx_timer_start(tfx_ctx *ctx);
+int tfx_timer_stop_ms(tfx_ctx *ctx, double *ms_out);       /* synchronises                                  */
+/* Per-kernel accumulated GPU time (HIP events around every launch of the two matrix kernels) since the last
+ * reset: which = 0 SpMV, 1 SpMtV.  Enabled with tfx_profile_enable(ctx, 1).                                 */
+int tfx_profile_enable(tfx_ctx *ctx, int on);
+int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,376 @@
+"""Parity of the HIP path (libtfx.so through its C ABI) with the CPU oracle and the reference's golden vectors.
+Runs on a real MI355X only (`pytest -m gpu`).
+
+Stated tolerances
+  wavelets, threshold, compaction on identical inputs ......... bit-exact
+  prism rows (device libm atan2/log vs glibc, <= 2 ulp/term) ... 1e-13 of the row's max magnitude
+  column weights (device pow) ................................... 1e-14 relative
+  built matrix vs reference SENSIT rows ......................... same nel per row (+-1 on threshold ties), >= 99.9 %
+                                                                  identical sparsity, kept values within 2 fp32 ulp
+  S x, S^T y (fp64 accumulation, different summation order) ..... 1e-12 of |S| |x|
+  LSQR on the same matrix ....................................... x rel-L2 1e-9 (converged) / 1e-5 (mid-convergence, see
+                                                                  test_oracle_golden.py for why)
+  end-to-end inversion .......................................... final model rel-L2 1e-6, data cost rel 1e-5
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import kat_cases
+import oracle_lib as orc
+import oracle_inversion as oinv
+
+pytestmark = pytest.mark.gpu
+
+tfx = importlib.import_module("tomofast-x_amd")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = tfx.Context(0)
+    yield c
+    c.close()
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def bits_equal(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def test_wavelets_bit_exact_vs_reference(ctx, golden_dir):
+    g = load(golden_dir, "wavelet")
+    keys = sorted(k[:-3] for k in g.files if k.endswith("_in"))
+    for k in keys:
+        dims, t = k.split("_t")
+        n1, n2, n3 = [int(v) for v in dims.split("x")]
+        a = g[k + "_in"]
+        assert bits_equal(ctx.forward_wavelet(a, n1, n2, n3, int(t)), g[k + "_fwd"]), k
+        assert bits_equal(ctx.inverse_wavelet(a, n1, n2, n3, int(t)), g[k + "_inv"]), k
+
+
+@pytest.mark.parametrize("dims", [(64, 48, 40), (100, 3, 17), (512, 4, 2), (5, 600, 3)])
+@pytest.mark.parametrize("wtype", [1, 2])
+def test_wavelets_bit_exact_vs_oracle_larger(ctx, dims, wtype):
+    rng = np.random.default_rng(11)
+    n1, n2, n3 = dims
+    a = rng.standard_normal((3, n1 * n2 * n3))
+    fw = ctx.forward_wavelet(a, n1, n2, n3, wtype)          # batched: 3 vectors at once
+    for v in range(3):
+        ref = orc.wavelet(a[v], n1, n2, n3, wtype)
+        assert bits_equal(fw[v], ref)
+        assert bits_equal(ctx.inverse_wavelet(ref, n1, n2, n3, wtype), orc.wavelet(ref, n1, n2, n3, wtype, inverse=True))
+
+
+def test_wavelet_unknown_type(ctx):
+    with pytest.raises(ValueError):
+        ctx.forward_wavelet(np.zeros(8), 2, 2, 2, 3)
+
+
+def test_prism_rows_vs_reference(ctx, golden_dir):
+    g = load(golden_dir, "prism")
+    ctx.set_grid(int(g["nx"]), int(g["ny"]), int(g["nz"]), *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    rows = ctx.graviprism_z(g["obs"][:, 0], g["obs"][:, 1], g["obs"][:, 2])
+    for r, ref in zip(rows, g["rows"]):
+        assert np.max(np.abs(r - ref)) <= 1e-13 * np.max(np.abs(ref))
+
+
+def test_prism_geometry_error(ctx):
+    one = [np.array([v], np.float64) for v in (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)]
+    ctx.set_grid(1, 1, 1, *one)
+    with pytest.raises(tfx.TfxError) as e:
+        ctx.graviprism_z([-1.0], [0.0], [0.0])
+    assert e.value.code == -3 and "coincides with model grid boundary" in str(e.value)
+
+
+def test_column_weight_vs_reference(ctx, golden_dir):
+    g = load(golden_dir, "e2e_haar")
+    ctx.set_grid(int(g["nx"]), int(g["ny"]), int(g["nz"]), *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+    assert np.max(np.abs(cw - g["np1_column_weight"]) / g["np1_column_weight"]) <= 1e-14
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.01, 0.1, 0.15, 0.5, 1.0])
+def test_threshold_and_compaction_bit_exact(ctx, golden_dir, rate):
+    g = load(golden_dir, "wavelet")
+    for key in ("16x16x8_t1_fwd", "13x7x33_t2_fwd", "10x11x12_t1_fwd"):
+        row = g[key].copy()
+        row[5] = 0.0                      # exact zeros are always dropped (threshold floor 1e-30)
+        row[7] = row[9]                   # a tie
+        N = row.size
+        K = int(rate * N)
+        c_ref, v_ref, thr_ref, cd_ref = orc.compress_row(row, K)
+        c, v, thr, cd = ctx.compress_row(row, K)
+        assert thr == thr_ref
+        assert np.array_equal(c, c_ref) and bits_equal(v, v_ref)
+        assert abs(cd - cd_ref) <= 1e-13 * max(cd_ref, 1e-300)
+
+
+def test_threshold_degenerate_rows(ctx):
+    N = 5000
+    for row in (np.zeros(N), np.full(N, 3.5), np.concatenate([np.zeros(N - 3), [1e-31, -2.0, 7.0]])):
+        for K in (0, 1, 2, N // 2, N):
+            c_ref, v_ref, thr_ref, _ = orc.compress_row(row, K)
+            c, v, thr, _ = ctx.compress_row(row, K)
+            assert thr == thr_ref and np.array_equal(c, c_ref) and bits_equal(v, v_ref), (K,)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def random_csr(rng, nrows, ncols, mean_nnz, empty_frac=0.1, clustered=False):
+    rp = [0]
+    cols, vals = [], []
+    for r in range(nrows):
+        if rng.random() < empty_frac:
+            rp.append(rp[-1])
+            continue
+        n = max(1, int(rng.poisson(mean_nnz)))
+        n = min(n, ncols)
+        if clustered:
+            centre = rng.integers(0, ncols)
+            c = np.unique(np.clip((centre + rng.standard_normal(n) * mean_nnz * 2).astype(np.int64), 0, ncols - 1))
+        else:
+            c = np.unique(rng.integers(0, ncols, n))
+        cols.append((c + 1).astype(np.int32))
+        vals.append((rng.standard_normal(c.size) * np.exp(rng.normal(0, 3, c.size))).astype(np.float32))
+        rp.append(rp[-1] + c.size)
+    return np.array(rp, np.int64), np.concatenate(cols), np.concatenate(vals)
+
+
+CSR_SHAPES = [
+    (7, 9, 4, False),              # tiny, single tile
+    (300, 20000, 50, False),       # 2 column tiles
+    (2500, 40000, 30, False),      # 2 row blocks x 3 column tiles, short segments
+    (2500, 40000, 400, True),      # clustered: long dense segments + many empty (row, tile) segments
+    (64, 70000, 6000, False),      # long rows
+    (4100, 1000, 3, False),        # 3 row blocks, narrow
+]
+
+
+@pytest.mark.parametrize("shape", CSR_SHAPES)
+def test_matrix_roundtrip_and_products(ctx, shape):
+    nrows, ncols, mean_nnz, clustered = shape
+    rng = np.random.default_rng(nrows * 7 + ncols)
+    S = random_csr(rng, nrows, ncols, mean_nnz, clustered=clustered)
+    ctx.matrix_upload_csr(nrows, ncols, *S)
+    info = ctx.matrix_info()
+    assert (info["nrows"], info["ncols"], info["nnz"]) == (nrows, ncols, int(S[0][-1]))
+    rp, c, v = ctx.matrix_download_csr()
+    assert np.array_equal(rp, S[0]) and np.array_equal(c, S[1]) and bits_equal(v, S[2])
+    x = rng.standard_normal(ncols)
+    y = rng.standard_normal(nrows)
+    absS = (S[0], S[1], np.abs(S[2]))
+    b = ctx.mult_vector(x)
+    ref = orc.spmv(*S, x)
+    assert np.all(np.abs(b - ref) <= 1e-12 * orc.spmv(*absS, np.abs(x)) + 1e-300)
+    bt = ctx.trans_mult_vector(y)
+    reft = orc.spmtv(*S, y, ncols)
+    assert np.all(np.abs(bt - reft) <= 1e-12 * orc.spmtv(*absS, np.abs(y), ncols) + 1e-300)
+    # add_mult_vector / add_trans_mult_vector
+    b0 = rng.standard_normal(nrows)
+    assert np.allclose(ctx.mult_vector(x, b0), b0 + ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    t0 = rng.standard_normal(ncols)
+    assert np.allclose(ctx.trans_mult_vector(y, t0), t0 + reft, rtol=1e-12, atol=1e-12 * np.abs(reft).max())
+    # adjoint identity <S x, y> = <x, S^T y>
+    assert abs(np.dot(b, y) - np.dot(x, bt)) <= 1e-11 * np.dot(orc.spmv(*absS, np.abs(x)), np.abs(y))
+
+
+def test_products_vs_reference_golden(ctx, golden_dir):
+    g = load(golden_dir, "lsqr")
+    for case in ("damp", "gen", "noC"):
+        S = (orc.rc_to_rowptr(g[case + "_S_rc"]), g[case + "_S_cols"], g[case + "_S_vals"])
+        ctx.matrix_upload_csr(int(g[case + "_nl_s"]), int(g[case + "_ncols"]), *S)
+        assert np.allclose(ctx.mult_vector(g[case + "_xin"]), g[case + "_Sx"], rtol=1e-13, atol=1e-13)
+        assert np.allclose(ctx.trans_mult_vector(g[case + "_yin"]), g[case + "_STy"], rtol=1e-13, atol=1e-13)
+
+
+def test_matrix_validation_errors(ctx):
+    with pytest.raises(tfx.TfxError) as e:
+        ctx.matrix_upload_csr(1, 3, [0, 1], [4], [1.0])
+    assert "column-index validation failed" in str(e.value)
+    with pytest.raises(tfx.TfxError):
+        ctx.matrix_upload_csr(1, 3, [0, 2], [2, 1], [1.0, 1.0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(kat_cases.cases()))
+def test_lsqr_reference_known_answers(ctx, name):
+    """The reference's own LSQR unit tests (src/tests/tests_lsqr.f90) through the HIP path."""
+    c = kat_cases.cases()[name]
+    S = kat_cases.dense_to_csr(c["A"])
+    ctx.matrix_upload_csr(c["A"].shape[0], c["A"].shape[1], *S)
+    x, it, r = ctx.lsqr_solve_sensit(c["b"], c["niter"], c["rmin"])
+    kat_cases.check(c, x)
+
+
+@pytest.mark.parametrize("case", ["damp", "noC"])
+def test_lsqr_vs_reference_golden(ctx, golden_dir, case):
+    g = load(golden_dir, "lsqr")
+    nl_s, ncols = int(g[case + "_nl_s"]), int(g[case + "_ncols"])
+    S = (orc.rc_to_rowptr(g[case + "_S_rc"]), g[case + "_S_cols"], g[case + "_S_vals"])
+    ctx.matrix_upload_csr(nl_s, ncols, *S)
+    b = g[case + "_b"]
+    if case == "damp":
+        diag, rhs = [g[case + "_C_vals"]], [b[nl_s:]]          # C = 0.1 I as one diagonal block
+    else:
+        diag, rhs = [], []
+    for (niter, rmin, gamma), xref, rref, itref in zip(g[case + "_runs"], g[case + "_x"], g[case + "_r"], g[case + "_iters"]):
+        x, it, r = ctx.lsqr_solve_sensit(b[:nl_s], int(niter), rmin, gamma, 0.0, diag, rhs)
+        early = itref < niter
+        if early:
+            assert abs(it - itref) <= 0.1 * itref
+        else:
+            assert it == itref
+            assert abs(r - rref) <= 1e-7 * abs(rref)
+        tol = 1e-12 if niter <= 5 else (1e-9 if (early or niter >= 50) else 1e-5)
+        assert np.linalg.norm(x - xref) <= tol * np.linalg.norm(xref), (case, niter)
+
+
+def test_lsqr_stepping_api_matches_one_shot(ctx, golden_dir):
+    g = load(golden_dir, "lsqr")
+    case = "damp"
+    nl_s, ncols = int(g[case + "_nl_s"]), int(g[case + "_ncols"])
+    S = (orc.rc_to_rowptr(g[case + "_S_rc"]), g[case + "_S_cols"], g[case + "_S_vals"])
+    ctx.matrix_upload_csr(nl_s, ncols, *S)
+    b = g[case + "_b"]
+    diag, rhs = [g[case + "_C_vals"]], [b[nl_s:]]
+    x1, it1, r1 = ctx.lsqr_solve_sensit(b[:nl_s], 12, 1e-13, 0.0, 0.0, diag, rhs)
+    ctx.lsqr_begin(b[:nl_s], 1e-13, 0.0, 0.0, diag, rhs)
+    d1, _ = ctx.lsqr_iterate(5)
+    d2, r2 = ctx.lsqr_iterate(7)
+    x2 = ctx.lsqr_end()
+    assert d1 + d2 == it1 == 12
+    assert np.linalg.norm(x1 - x2) <= 1e-9 * np.linalg.norm(x1) and abs(r1 - r2) <= 1e-9 * r1
+
+
+def test_lsqr_zero_rhs_is_exact(ctx):
+    S = kat_cases.dense_to_csr(np.eye(4))
+    ctx.matrix_upload_csr(4, 4, *S)
+    x, it, r = ctx.lsqr_solve_sensit(np.zeros(4), 10)
+    assert it == 0 and np.all(x == 0.0)
+
+
+def test_lsqr_target_misfit_exit(ctx, golden_dir):
+    g = load(golden_dir, "e2e_full")
+    S = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+    N = int(g["nx"]) * int(g["ny"]) * int(g["nz"])
+    ctx.matrix_upload_csr(g["obs"].shape[0], N, *S)
+    b = g["np1_data_observed"]
+    alpha = np.float32(1e-6)
+    blocks = ([np.full(N, alpha, np.float32)], [np.zeros(N)])
+    target = 0.3 * np.sqrt(np.mean(b ** 2))
+    x, it, r = ctx.lsqr_solve_sensit(b, 200, 1e-13, 0.0, target, *blocks)
+    xo, ito, ro = orc.lsqr(S, orc.diag_csr(blocks[0][0]), N, np.concatenate([b, np.zeros(N)]), 200, 1e-13, 0.0, target)
+    assert it == ito and it < 200
+    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def compare_built_matrix(built, ref, nd):
+    """built / ref: (rowptr, cols, vals).  Returns (fraction of identical sparsity, max ulp distance on common entries)."""
+    same, total, maxulp = 0, 0, 0
+    for r in range(nd):
+        cb, vb = built[1][built[0][r]:built[0][r + 1]], built[2][built[0][r]:built[0][r + 1]]
+        cr, vr = ref[1][ref[0][r]:ref[0][r + 1]], ref[2][ref[0][r]:ref[0][r + 1]]
+        assert abs(cb.size - cr.size) <= 2, (r, cb.size, cr.size)
+        common, ib, ir = np.intersect1d(cb, cr, return_indices=True)
+        same += common.size
+        total += max(cb.size, cr.size)
+        if common.size:
+            ulp = np.abs(vb[ib].view(np.int32).astype(np.int64) - vr[ir].view(np.int32).astype(np.int64))
+            maxulp = max(maxulp, int(ulp.max()))
+    return same / max(total, 1), maxulp
+
+
+@pytest.mark.parametrize("name", ["e2e_haar", "e2e_d4", "e2e_full"])
+def test_build_kernel_vs_reference_sensit(ctx, golden_dir, name):
+    g = load(golden_dir, name)
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    cw = g["np1_column_weight"]
+    obs = g["obs"]
+    res = ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, int(g["ctype"]), float(g["rate"]), want_hist=True)
+    built = ctx.matrix_download_csr()
+    ref = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+    frac, maxulp = compare_built_matrix(built, ref, obs.shape[0])
+    assert frac >= 0.999 and maxulp <= 2, (frac, maxulp)
+    assert abs(res["nnz"] - int(g["np1_nnz_total"])) <= 2 * obs.shape[0]
+    assert int(res["nnz_hist"].sum()) == res["nnz"]
+    if int(g["ctype"]) > 0:
+        assert abs(res["comp_error"] - float(g["np1_comp_error"])) <= 1e-9 * float(g["np1_comp_error"])
+    # partition rule on the built histogram vs the reference's 2-rank partition (exact unless a tie flipped)
+    nel, nnz = tfx.get_load_balancing_nelements(res["nnz_hist"], 2)
+    assert np.all(np.abs(nel - g["np2_nelements_at_cpu"]) <= 2)
+
+
+@pytest.mark.parametrize("name", ["e2e_haar", "e2e_d4", "e2e_full"])
+def test_end_to_end_inversion_vs_reference(ctx, golden_dir, name):
+    """Build on the GPU, invert on the GPU, compare with the reference's final model / data."""
+    g = load(golden_dir, name)
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+    obs = g["obs"]
+    ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, int(g["ctype"]), float(g["rate"]))
+    m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, int(g["ctype"]), g["np1_data_observed"], int(g["nmajor"]),
+                                                     int(g["nminor"]), alpha=float(g["alpha"]))
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(m - ref) <= 1e-6 * np.linalg.norm(ref)
+    cost_ref = np.linalg.norm(g["np1_data_final"] - g["np1_data_observed"]) / np.linalg.norm(g["np1_data_observed"])
+    assert abs(hist[-1]["cost"] - cost_ref) <= 1e-5 * cost_ref + 1e-16
+
+
+def test_config1_mansf_end_to_end(ctx, golden_dir):
+    """BASELINE config 1 (parfiles/Parfile_mansf_slice.txt: 2x128x32 cells, 256 obs, Haar 0.15, ADMM, 60 x 100 LSQR
+    iterations) entirely on the HIP path vs the reference's final model."""
+    g = load(golden_dir, "mansf")
+    ctx.set_grid(2, 128, 32, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+    obs = g["obs"]
+    res = ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, 1, 0.15, want_hist=True)
+    assert abs(res["nnz"] - 314368) <= 16
+    assert abs(res["comp_error"] - 2.1542534704846925e-03) <= 1e-9
+    built = ctx.matrix_download_csr()
+    n8 = int(g["row_ptr"][-1])
+    frac, maxulp = compare_built_matrix((built[0][:9], built[1], built[2]), (g["row_ptr"], g["cols"][:n8], g["vals"][:n8]), 8)
+    assert frac >= 0.999 and maxulp <= 2
+    m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, 1, g["data_observed"], 60, 100, alpha=0.0,
+                                                     admm=dict(bounds=g["admm_bounds"], rho=float(g["admm_weight"])))
+    ref = g["model_final"]
+    rel = np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    assert rel <= 1e-6, rel
+    assert abs(m.min() - (-19.951562372333093)) < 1e-4 and abs(m.max() - 259.9972445968676) < 1e-4
+    assert abs(hist[-1]["cost"] - 9.339172972115141e-11) <= 1e-2 * 9.339172972115141e-11
+
+
+def test_medium_synthetic_build_vs_oracle_and_adjoint_identity(ctx):
+    """64x64x32 cells, 8x8 obs, Haar 0.05 (SURVEY 8d generator): sampled rows vs the oracle, then the size-independent
+    properties on the whole matrix: <S x, y> = <x, S^T y>, linearity, and S x against a dense re-evaluation of rows."""
+    nx, ny, nz, ox, oy = 64, 64, 32, 8, 8
+    grid = tfx.synthetic.grid(nx, ny, nz)
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, ox, oy)
+    ctx.set_grid(nx, ny, nz, *grid)
+    cw = ctx.calculate_depth_weight()
+    res = ctx.calculate_sensit(xs, ys, zs, cw, 1, 0.05)
+    N = nx * ny * nz
+    K = int(0.05 * N)
+    rp, cols, vals = ctx.matrix_download_csr()
+    cw_o = orc.column_weight_type1(grid)
+    for r in (0, 27, 63):
+        c_ref, v_ref, _ = orc.build_row_grav(grid, (nx, ny, nz), cw_o, (xs[r], ys[r], zs[r]), 1, K)
+        cb, vb = cols[rp[r]:rp[r + 1]], vals[rp[r]:rp[r + 1]]
+        common, ib, ir = np.intersect1d(cb, c_ref, return_indices=True)
+        assert common.size >= 0.999 * c_ref.size
+        assert np.max(np.abs(vb[ib].view(np.int32).astype(np.int64) - v_ref[ir].view(np.int32).astype(np.int64))) <= 2
+    rng = np.random.default_rng(0)
+    x, x2, y = rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(xs.size)
+    Sx, Sx2, STy = ctx.mult_vector(x), ctx.mult_vector(x2), ctx.trans_mult_vector(y)
+    scale = np.dot(np.abs(orc.spmv(rp, cols, np.abs(vals), np.abs(x))), np.abs(y))
+    assert abs(np.dot(Sx, y) - np.dot(x, STy)) <= 1e-12 * scale
+    assert np.allclose(ctx.mult_vector(2.0 * x - 3.0 * x2), 2.0 * Sx - 3.0 * Sx2, rtol=0, atol=1e-12 * np.abs(Sx).max() * 10)
+    assert np.allclose(Sx, orc.spmv(rp, cols, vals, x), rtol=0, atol=1e-12 * np.abs(Sx).max() * 10)

@@ -1,0 +1,359 @@
+// api.hip - extern "C" entry points of libtfx.so that are not kernels themselves: context, grid upload,
+// CSR upload/download, the two products with host-or-device pointers, partitioning, timers.
+#include "common.h"
+#include <algorithm>
+
+using namespace tfx;
+
+extern "C" {
+
+const char *tfx_last_error(void) { return g_last_error.c_str(); }
+
+int tfx_create(int device, void *stream, tfx_ctx **out)
+{
+    if (!out) return fail(TFX_E_ARG, "tfx_create: null output");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(TFX_E_HIP, "tfx_create: no HIP device visible (%s) - the MI355X path has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= count) return fail(TFX_E_ARG, "tfx_create: device %d out of range [0,%d)", device, count);
+    TFX_HIP(hipSetDevice(device));
+    tfx_ctx *c = new tfx_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    TFX_HIP(hipEventCreate(&c->ev0));
+    TFX_HIP(hipEventCreate(&c->ev1));
+    TFX_HIP(hipEventCreate(&c->pev0));
+    TFX_HIP(hipEventCreate(&c->pev1));
+    *out = c;
+    return 0;
+}
+
+int lsqr_free(tfx_ctx *ctx);   // lsqr.hip
+
+int tfx_destroy(tfx_ctx *ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    lsqr_free(ctx);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->pev0) (void)hipEventDestroy(ctx->pev0);
+    if (ctx->pev1) (void)hipEventDestroy(ctx->pev1);
+    delete ctx;
+    return 0;
+}
+
+int tfx_device_info(tfx_ctx *ctx, char *name, int len, int64_t *hbm_bytes)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    hipDeviceProp_t prop;
+    TFX_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && len > 0) {
+        snprintf(name, (size_t)len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return prop.multiProcessorCount;
+}
+
+int tfx_set_allreduce(tfx_ctx *ctx, tfx_allreduce_fn fn, void *user, int rank, int nranks)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(TFX_E_ARG, "bad rank %d / %d", rank, nranks);
+    if (nranks > 1 && !fn) return fail(TFX_E_ARG, "nranks > 1 needs an all-reduce hook");
+    ctx->allreduce = fn;
+    ctx->allreduce_user = user;
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return 0;
+}
+
+int tfx_set_grid(tfx_ctx *ctx, int nx, int ny, int nz, const double *X1, const double *X2, const double *Y1,
+                 const double *Y2, const double *Z1, const double *Z2)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    if (nx <= 0 || ny <= 0 || nz <= 0) return fail(TFX_E_ARG, "bad grid size %d %d %d", nx, ny, nz);
+    TFX_HIP(hipSetDevice(ctx->device));
+    const double *src[6] = {X1, X2, Y1, Y2, Z1, Z2};
+    int64_t N = (int64_t)nx * ny * nz;
+    for (int i = 0; i < 6; ++i) {
+        if (!src[i]) return fail(TFX_E_ARG, "tfx_set_grid: null array %d", i);
+        TFX_TRY(ctx->grid[i].alloc((size_t)N));
+        TFX_TRY(copy_any(ctx->grid[i].p, src[i], (size_t)N * sizeof(double), ctx->stream));
+    }
+    ctx->nx = nx;
+    ctx->ny = ny;
+    ctx->nz = nz;
+    ctx->N = N;
+    return 0;
+}
+
+// ---- matrix upload / download ------------------------------------------------------------------------------
+int tfx_matrix_upload_csr(tfx_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
+                          const float *vals)
+{
+    if (!ctx || !rowptr) return fail(TFX_E_ARG, "tfx_matrix_upload_csr: null argument");
+    if (ncols > 0x7fffffffLL || nrows > 0x7fffffffLL) return fail(TFX_E_ARG, "matrix dimension exceeds int32");
+    TFX_HIP(hipSetDevice(ctx->device));
+    int64_t nnz = rowptr[nrows];
+    if (nnz < 0) return fail(TFX_E_ARG, "negative nnz");
+    if (nnz > 0 && (!cols || !vals)) return fail(TFX_E_ARG, "null cols/vals");
+    // validation like t_sparse_matrix%validate (sparse_matrix.f90:188-207) + ascending columns within a row
+    for (int64_t r = 0; r < nrows; ++r) {
+        if (rowptr[r + 1] < rowptr[r]) return fail(TFX_E_ARG, "rowptr not monotone at row %lld", (long long)r);
+        for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+            if (cols[k] < 1 || cols[k] > ncols)
+                return fail(TFX_E_ARG, "Sparse matrix column-index validation failed! row %lld col %d", (long long)r, cols[k]);
+            if (k > rowptr[r] && cols[k] <= cols[k - 1])
+                return fail(TFX_E_ARG, "columns must ascend within a row (row %lld)", (long long)r);
+        }
+    }
+    TFX_TRY(matrix_begin(ctx, nrows, ncols, nnz));
+    TiledMatrix &m = ctx->mat;
+    hipStream_t s = ctx->stream;
+    for (int rb = 0; rb < m.nrb; ++rb) {
+        int64_t r0 = (int64_t)rb * m.RB, r1 = std::min<int64_t>(nrows, r0 + m.RB);
+        int nr = (int)(r1 - r0);
+        int64_t e0 = rowptr[r0], e1 = rowptr[r1];
+        int64_t ne = e1 - e0;
+        std::vector<int32_t> hc((size_t)ne), hn(nr);
+        std::vector<int64_t> ho(nr);
+        int64_t maxlen = 0;
+        for (int r = 0; r < nr; ++r) {
+            ho[r] = rowptr[r0 + r] - e0;
+            hn[r] = (int32_t)(rowptr[r0 + r + 1] - rowptr[r0 + r]);
+            maxlen = std::max<int64_t>(maxlen, hn[r]);
+        }
+        for (int64_t k = 0; k < ne; ++k) hc[(size_t)k] = cols[e0 + k] - 1;     // 0-based local
+        DBuf<int32_t> dc, dn;
+        DBuf<float> dv;
+        DBuf<int64_t> dof;
+        TFX_TRY(dc.alloc((size_t)std::max<int64_t>(1, ne)));
+        TFX_TRY(dv.alloc((size_t)std::max<int64_t>(1, ne)));
+        TFX_TRY(dn.alloc(nr));
+        TFX_TRY(dof.alloc(nr));
+        if (ne > 0) {
+            TFX_HIP(hipMemcpyAsync(dc.p, hc.data(), (size_t)ne * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            TFX_HIP(hipMemcpyAsync(dv.p, vals + e0, (size_t)ne * sizeof(float), hipMemcpyHostToDevice, s));
+        }
+        TFX_HIP(hipMemcpyAsync(dn.p, hn.data(), nr * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        TFX_HIP(hipMemcpyAsync(dof.p, ho.data(), nr * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        TFX_TRY(matrix_append_rows(ctx, r0, nr, dc.p, dv.p, dn.p, dof.p, maxlen));
+    }
+    TFX_TRY(matrix_finish(ctx));
+    m.nnz = nnz;
+    return 0;
+}
+
+int tfx_matrix_info(tfx_ctx *ctx, int64_t *nrows, int64_t *ncols, int64_t *nnz, int64_t *device_bytes)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    if (!ctx->mat.valid) return fail(TFX_E_STATE, "no matrix");
+    if (nrows) *nrows = ctx->mat.nrows;
+    if (ncols) *ncols = ctx->mat.ncols;
+    if (nnz) *nnz = ctx->mat.nnz;
+    if (device_bytes) *device_bytes = (int64_t)ctx->mat.device_bytes();
+    return 0;
+}
+
+// Host-side decode of the tiled layout back to CSR (tests, SENSIT-format writers; not on the hot path).
+int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float *vals)
+{
+    if (!ctx || !rowptr) return fail(TFX_E_ARG, "null argument");
+    TiledMatrix &m = ctx->mat;
+    if (!m.valid) return fail(TFX_E_STATE, "no matrix");
+    TFX_HIP(hipSetDevice(ctx->device));
+    std::vector<uint16_t> hc((size_t)m.n_entries);
+    std::vector<float> hv((size_t)m.n_entries);
+    if (m.n_entries > 0) {
+        TFX_HIP(hipMemcpy(hc.data(), m.codes.p, (size_t)m.n_entries * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        TFX_HIP(hipMemcpy(hv.data(), m.vals.p, (size_t)m.n_entries * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    std::vector<int32_t> hrow0((size_t)(m.n_entries / CHUNK));
+    if (!hrow0.empty())
+        TFX_HIP(hipMemcpy(hrow0.data(), m.chunk_row0.p, hrow0.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // tiles sorted by (rb, t): columns of a row come out ascending
+    std::vector<TileMeta> tl = m.h_tiles;
+    std::sort(tl.begin(), tl.end(), [](const TileMeta &a, const TileMeta &b) { return a.rb != b.rb ? a.rb < b.rb : a.t < b.t; });
+    // pass 1: counts
+    std::vector<int64_t> cnt((size_t)m.nrows + 1, 0);
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<int64_t> fill;
+        if (pass == 1) {
+            int64_t run = 0;
+            for (int64_t r = 0; r < m.nrows; ++r) { int64_t c = cnt[(size_t)r]; rowptr[r] = run; run += c; }
+            rowptr[m.nrows] = run;
+            fill.assign(rowptr, rowptr + m.nrows);
+        }
+        for (const TileMeta &tm : tl) {
+            int cur = hrow0[(size_t)(tm.off / CHUNK)];
+            for (int32_t e = 0; e < tm.cnt; ++e) {
+                uint16_t code = hc[(size_t)(tm.off + e)];
+                if (code & ROWSTART) cur += 1;
+                float v = hv[(size_t)(tm.off + e)];
+                bool marker = (code & ROWSTART) && v == 0.0f && (code & COLMASK) == 0 &&
+                              (e + 1 == tm.cnt || (hc[(size_t)(tm.off + e + 1)] & ROWSTART));
+                // a marker is indistinguishable from a stored exact zero in column 0 of the tile that is alone in
+                // its row segment; the reference never stores zeros (sparse_matrix.f90:219, threshold >= 1e-30)
+                if (marker) continue;
+                int64_t row = (int64_t)tm.rb * m.RB + cur;
+                if (row < 0 || row >= m.nrows) return fail(TFX_E_STATE, "corrupt tile: row %lld", (long long)row);
+                if (pass == 0) cnt[(size_t)row] += 1;
+                else {
+                    int64_t p = fill[(size_t)row]++;
+                    if (cols) cols[p] = (int32_t)((int64_t)tm.t * m.TC + (code & COLMASK) + 1);
+                    if (vals) vals[p] = v;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+int tfx_matrix_free(tfx_ctx *ctx)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    (void)hipStreamSynchronize(ctx->stream);
+    TiledMatrix &m = ctx->mat;
+    m.codes.release(); m.vals.release(); m.chunk_row0.release(); m.tiles.release(); m.fwd.release(); m.adj.release();
+    m.fwd_order.release(); m.adj_order.release(); m.fwd_partial.release(); m.adj_partial.release();
+    m.fwd_nslots.release(); m.fwd_pbase.release(); m.adj_nslots.release(); m.adj_pbase.release();
+    m.h_tiles.clear(); m.h_fwd.clear(); m.h_adj.clear();
+    m.valid = false;
+    return 0;
+}
+
+// get_load_balancing_nelements, src/forward/gravmag/sensitivity_gravmag.F90:470-524 (exact integer rule)
+int tfx_partition_columns(const int32_t *nnz, int64_t N, int P, int32_t *nel_at, int64_t *nnz_at)
+{
+    if (!nnz || !nel_at || !nnz_at || P < 1 || N < P) return fail(TFX_E_ARG, "tfx_partition_columns: bad arguments");
+    int64_t total = 0;
+    for (int64_t p = 0; p < N; ++p) total += nnz[p];
+    std::vector<int64_t> cum(P);
+    int64_t run = 0;
+    for (int c = 0; c < P; ++c) {
+        run += total / P + (c == P - 1 ? total % P : 0);
+        cum[c] = run;
+        nel_at[c] = 0;
+        nnz_at[c] = 0;
+    }
+    int cpu = 0;
+    int64_t nnz_new = 0, sum = 0;
+    int32_t nel_new = 0;
+    for (int64_t p = 0; p < N; ++p) {
+        nnz_new += nnz[p];
+        sum += nnz[p];
+        nel_new += 1;
+        if ((cpu < P - 1 && sum >= cum[cpu]) || p == N - 1) {
+            if (cpu >= P) return fail(TFX_E_NUMERIC, "Wrong cpu in get_load_balancing_nelements!");
+            nnz_at[cpu] = nnz_new;
+            nel_at[cpu] = nel_new;
+            nnz_new = 0;
+            nel_new = 0;
+            ++cpu;
+        }
+    }
+    if (cpu != P) return fail(TFX_E_NUMERIC, "Wrong cpu in get_load_balancing_nelements! (%d of %d parts filled)", cpu, P);
+    return 0;
+}
+
+// ---- products with host-or-device vectors ------------------------------------------------------------------
+static bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+int tfx_spmv(tfx_ctx *ctx, const double *x, double *b, int add)
+{
+    if (!ctx || !x || !b) return fail(TFX_E_ARG, "tfx_spmv: null argument");
+    TiledMatrix &m = ctx->mat;
+    if (!m.valid) return fail(TFX_E_STATE, "tfx_spmv: no matrix");
+    TFX_HIP(hipSetDevice(ctx->device));
+    const double *dx = x;
+    double *db = b;
+    if (!is_device_ptr(x)) {
+        TFX_TRY(ctx->vx.ensure((size_t)m.ncols));
+        TFX_TRY(copy_any(ctx->vx.p, x, (size_t)m.ncols * sizeof(double), ctx->stream));
+        dx = ctx->vx.p;
+    }
+    bool hostb = !is_device_ptr(b);
+    if (hostb) {
+        TFX_TRY(ctx->vb.ensure((size_t)m.nrows));
+        if (add) TFX_TRY(copy_any(ctx->vb.p, b, (size_t)m.nrows * sizeof(double), ctx->stream));
+        db = ctx->vb.p;
+    }
+    TFX_TRY(spmv_dev(ctx, dx, db, add));
+    if (hostb) TFX_TRY(copy_any(b, db, (size_t)m.nrows * sizeof(double), ctx->stream));
+    return 0;
+}
+
+int tfx_spmtv(tfx_ctx *ctx, const double *x, double *b, int add)
+{
+    if (!ctx || !x || !b) return fail(TFX_E_ARG, "tfx_spmtv: null argument");
+    TiledMatrix &m = ctx->mat;
+    if (!m.valid) return fail(TFX_E_STATE, "tfx_spmtv: no matrix");
+    TFX_HIP(hipSetDevice(ctx->device));
+    const double *dx = x;
+    double *db = b;
+    if (!is_device_ptr(x)) {
+        TFX_TRY(ctx->vb.ensure((size_t)m.nrows));
+        TFX_TRY(copy_any(ctx->vb.p, x, (size_t)m.nrows * sizeof(double), ctx->stream));
+        dx = ctx->vb.p;
+    }
+    bool hostb = !is_device_ptr(b);
+    if (hostb) {
+        TFX_TRY(ctx->vx.ensure((size_t)m.ncols));
+        if (add) TFX_TRY(copy_any(ctx->vx.p, b, (size_t)m.ncols * sizeof(double), ctx->stream));
+        db = ctx->vx.p;
+    }
+    TFX_TRY(spmtv_dev(ctx, dx, db, add));
+    if (hostb) TFX_TRY(copy_any(b, db, (size_t)m.ncols * sizeof(double), ctx->stream));
+    return 0;
+}
+
+// ---- timers ------------------------------------------------------------------------------------------------
+int tfx_timer_start(tfx_ctx *ctx)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    TFX_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return 0;
+}
+
+int tfx_timer_stop_ms(tfx_ctx *ctx, double *ms_out)
+{
+    if (!ctx || !ms_out) return fail(TFX_E_ARG, "null argument");
+    TFX_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    TFX_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    TFX_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ms_out = ms;
+    return 0;
+}
+
+int tfx_profile_enable(tfx_ctx *ctx, int on)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    ctx->profile = on != 0;
+    ctx->prof_ms[0] = ctx->prof_ms[1] = 0;
+    ctx->prof_n[0] = ctx->prof_n[1] = 0;
+    return 0;
+}
+
+int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches)
+{
+    if (!ctx || which < 0 || which > 1) return fail(TFX_E_ARG, "bad argument");
+    if (total_ms) *total_ms = ctx->prof_ms[which];
+    if (launches) *launches = ctx->prof_n[which];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,920 @@
+// build.hip - sensitivity-kernel build pipeline on the device:
+//   prism rows   graviprism_z                 src/forward/gravmag/grav/gravity_field.f90:131-195
+//   weights      calculate_depth_weight (1)   src/forward/gravmag/weights_gravmag.f90:71-79,170-250
+//   wavelets     Haar3D / DaubD43D (+inverse) src/utils/wavelet_transform.F90:75-498
+//   threshold    quicksort + order statistic  src/forward/gravmag/sensitivity_gravmag.F90:240-256, src/utils/sort.f90
+//   compaction   keep |c| > thr, fp32 cast    src/forward/gravmag/sensitivity_gravmag.F90:258-272
+// and tfx_build_kernel_grav = calculate_and_write_sensit + read_sensitivity_kernel without the disk round trip
+// (sensitivity_gravmag.F90:82-410, :648-883).
+//
+// Compiled with -ffp-contract=off: the lifting steps and the prism polynomial are evaluated with the reference's
+// operation order (separate multiply / add), so wavelets are bit-identical to the reference and prism rows differ
+// only through the device libm (atan2 / log, <= 2 ulp).
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+
+namespace tfx {
+
+// =============================================================================================================
+// prism rows
+// =============================================================================================================
+// gravity_field.f90:26 - `G_grav = 6.674e-11` is a default-real literal: the value used is (double)(float)6.674e-11.
+__device__ __forceinline__ double g_grav() { return (double)6.674e-11f; }
+
+// One thread per cell, loops over the observation batch (coordinates are wave-uniform scalar loads).
+// rows[o*N + p] = G*gz (* cw[p] when cw != null: apply_column_weight, sensitivity_gravmag.F90:1042-1054).
+__global__ __launch_bounds__(256) void k_prism_gz(int64_t N, const double *__restrict__ X1, const double *__restrict__ X2,
+                                                  const double *__restrict__ Y1, const double *__restrict__ Y2,
+                                                  const double *__restrict__ Z1, const double *__restrict__ Z2,
+                                                  int nobs, const double *__restrict__ xd, const double *__restrict__ yd,
+                                                  const double *__restrict__ zd, const double *__restrict__ cw,
+                                                  double *__restrict__ rows, int *__restrict__ err)
+{
+    const double twopi = 2.0 * 3.14159265358979323846;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
+        const double x1 = X1[p], x2 = X2[p], y1 = Y1[p], y2 = Y2[p], z1 = Z1[p], z2 = Z2[p];
+        const double w = cw ? cw[p] : 1.0;
+        for (int o = 0; o < nobs; ++o) {
+            double XX[2], YY[2], ZZ[2];
+            XX[0] = xd[o] - x1; XX[1] = xd[o] - x2;                     // :151-156
+            YY[0] = yd[o] - y1; YY[1] = yd[o] - y2;
+            ZZ[0] = zd[o] - z1; ZZ[1] = zd[o] - z2;
+            double gz = 0.0;
+            int bad = 0;
+#pragma unroll
+            for (int K = 0; K < 2; ++K)
+#pragma unroll
+                for (int L = 0; L < 2; ++L)
+#pragma unroll
+                    for (int M = 0; M < 2; ++M) {
+                        const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;   // signo(K)*signo(L)*signo(M), signo = (-1, +1)
+                        const double Rs = sqrt(XX[K] * XX[K] + YY[L] * YY[L] + ZZ[M] * ZZ[M]);      // :165
+                        double arg3 = atan2(XX[K] * YY[L], ZZ[M] * Rs);                             // :167
+                        if (arg3 < 0) arg3 = arg3 + twopi;
+                        double arg4 = Rs + XX[K];
+                        double arg5 = Rs + YY[L];
+                        if (arg4 <= 0.) bad |= 1;                                                   // :176-181
+                        if (arg5 <= 0.) bad |= 2;
+                        arg4 = log(arg4);
+                        arg5 = log(arg5);
+                        gz = gz + dmu * (ZZ[M] * arg3 - XX[K] * arg5 - YY[L] * arg4);               // :186
+                    }
+            if (bad) atomicOr(err, bad);
+            double v = g_grav() * gz;                                                               // :192
+            if (cw) v = v * w;
+            rows[(int64_t)o * N + p] = v;
+        }
+    }
+}
+
+// dmu check: K,L,M in {0,1}; signo(0) = -1, signo(1) = +1; product = (-1)^(number of zeros) = (-1)^(3-(K+L+M));
+// K+L+M odd -> even number of zeros... (3 - odd) is even -> +1.  K+L+M even -> -1.  Matches the expression above.
+
+// =============================================================================================================
+// column weight, depth weighting type 1
+// =============================================================================================================
+__global__ void k_depth_weight(int64_t N, const double *__restrict__ X1, const double *__restrict__ X2,
+                               const double *__restrict__ Y1, const double *__restrict__ Y2, const double *__restrict__ Z1,
+                               const double *__restrict__ Z2, double power, double Z0, double *__restrict__ w,
+                               unsigned long long *__restrict__ maxbits, int *__restrict__ err)
+{
+    double mx = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
+        const double depth = 0.5 * (Z1[p] + Z2[p]);                                          // grid.F90:277
+        double v = 0.0;
+        if (depth + Z0 > 0.0) v = pow(depth + Z0, -power / 2.0);                             // weights_gravmag.f90:214-215
+        else atomicOr(err, 1);
+        const double vol = fabs((X2[p] - X1[p]) * (Y2[p] - Y1[p]) * (Z2[p] - Z1[p]));        // grid.F90:289-291
+        v = v * sqrt(vol);                                                                   // :174
+        w[p] = v;
+        mx = fmax(mx, v);
+    }
+    // positive doubles order like their bit patterns
+    atomicMax(maxbits, (unsigned long long)__double_as_longlong(mx));
+}
+
+__global__ void k_depth_weight_finish(int64_t N, double *__restrict__ w, const unsigned long long *__restrict__ maxbits,
+                                      double multiplier, int *__restrict__ err)
+{
+    const double norm = __longlong_as_double((long long)*maxbits);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
+        double v = w[p] / norm;                                                              // :243
+        if (v == 0.0) { atomicOr(err, 2); continue; }
+        v = 1.0 / v;                                                                         // :190
+        w[p] = v * multiplier;                                                               // problem_joint_gravmag.F90:178
+    }
+}
+
+// =============================================================================================================
+// lifting wavelets: one LDS tile = XT lines x L positions, all levels of the axis done in LDS
+// =============================================================================================================
+struct WaveAxis {
+    int L;            // line length
+    int XT;           // lines per tile
+    int P;            // LDS pitch (doubles) between consecutive positions
+    int64_t astride;  // global stride between consecutive positions of a line
+    int mode;         // 0: x axis (lines contiguous: line l at l*L), 1: y/z axis (inner-contiguous)
+    int64_t inner;    // mode 1: number of contiguous inner elements (nx for y, nx*ny for z)
+    int64_t outer_stride;   // mode 1: stride between outer slabs (nx*ny for y; unused for z)
+    int64_t nlines;   // mode 0: number of lines per vector
+    int64_t ntiles_inner;   // mode 1: tiles per outer slab
+};
+
+struct WaveConst { double sq2, c0, c1, c2, c3, c4; };
+
+template <int TYPE, int DIR>
+__global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, int64_t vec_stride, WaveAxis ax, WaveConst wc)
+{
+    extern __shared__ __attribute__((aligned(16))) double T[];
+    const int L = ax.L, XT = ax.XT, P = ax.P;
+    double *base = s + (int64_t)blockIdx.y * vec_stride;
+    // which lines does this tile hold
+    int64_t g0;       // global offset of (line q = 0, position 0)
+    int nq;           // valid lines in the tile
+    int64_t qstride;  // global stride between consecutive lines of the tile
+    if (ax.mode == 0) {
+        const int64_t l0 = (int64_t)blockIdx.x * XT;
+        nq = (int)min((int64_t)XT, ax.nlines - l0);
+        g0 = l0 * L;
+        qstride = L;
+    } else {
+        const int64_t o = blockIdx.x / ax.ntiles_inner, ti = blockIdx.x % ax.ntiles_inner;
+        const int64_t m0 = ti * XT;
+        nq = (int)min((int64_t)XT, ax.inner - m0);
+        g0 = o * ax.outer_stride + m0;
+        qstride = 1;
+    }
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // ---- load
+    if (ax.mode == 0) {
+        for (int e = tid; e < nq * L; e += nt) { const int q = e / L, a = e - q * L; T[a * P + q] = base[g0 + (int64_t)q * qstride + a]; }
+    } else {
+        for (int e = tid; e < nq * L; e += nt) { const int a = e / nq, q = e - a * nq; T[a * P + q] = base[g0 + (int64_t)a * ax.astride + q]; }
+    }
+    __syncthreads();
+    int nscale = 0;
+    while ((2 << nscale) <= L) ++nscale;      // = int(log(L)/log(2)) of wavelet_transform.F90:85 for every L < 5000
+    for (int lv = 0; lv < nscale; ++lv) {
+        const int istep = (DIR == 1) ? (lv + 1) : (nscale - lv);
+        const int step = 1 << istep;
+        const int ngmin = step / 2;               // 0-based index of the first detail slot
+        const int ng = (L - 1 - ngmin) / step + 1;
+        const int ilmax = (ng - 1) * step;
+        const int work = ng * nq;
+#define LO(m) T[((m) * step) * P + q]
+#define HI(m) T[(ngmin + (m) * step) * P + q]
+        if (TYPE == 1 && DIR == 1) {          // Haar forward, wavelet_transform.F90:103-149 (per pair, fused)
+            for (int e = tid; e < work; e += nt) {
+                const int m = e / nq, q = e - m * nq;
+                double lo = LO(m), hi = HI(m);
+                hi = hi - lo;
+                lo = lo + hi / 2.0;
+                lo = lo * wc.sq2;
+                hi = hi / wc.sq2;
+                LO(m) = lo; HI(m) = hi;
+            }
+            __syncthreads();
+        } else if (TYPE == 1 && DIR == 2) {   // Haar inverse, :186-232
+            for (int e = tid; e < work; e += nt) {
+                const int m = e / nq, q = e - m * nq;
+                double lo = LO(m), hi = HI(m);
+                lo = lo / wc.sq2;
+                hi = hi * wc.sq2;
+                lo = lo - hi / 2.0;
+                hi = hi + lo;
+                LO(m) = lo; HI(m) = hi;
+            }
+            __syncthreads();
+        } else if (TYPE == 2 && DIR == 1) {   // D4 forward, :284-365
+            for (int e = tid; e < work; e += nt) { const int m = e / nq, q = e - m * nq; LO(m) = LO(m) + HI(m) * wc.c0; }
+            __syncthreads();
+            for (int e = tid; e < work; e += nt) {
+                const int m = e / nq, q = e - m * nq;
+                const double prev = (m == 0) ? T[ilmax * P + q] : LO(m - 1);
+                HI(m) = HI(m) - LO(m) * wc.c1 - prev * wc.c2;
+            }
+            __syncthreads();
+            for (int e = tid; e < work; e += nt) {
+                const int m = e / nq, q = e - m * nq;
+                const double nxt = (m == ng - 1) ? HI(0) : HI(m + 1);
+                LO(m) = LO(m) - nxt;
+            }
+            __syncthreads();
+            for (int e = tid; e < work; e += nt) { const int m = e / nq, q = e - m * nq; LO(m) = LO(m) * wc.c3; HI(m) = HI(m) * wc.c4; }
+            __syncthreads();
+        } else {                              // D4 inverse, :413-495
+            for (int e = tid; e < work; e += nt) { const int m = e / nq, q = e - m * nq; LO(m) = LO(m) * wc.c4; HI(m) = HI(m) * wc.c3; }
+            __syncthreads();
+            for (int e = tid; e < work; e += nt) {
+                const int m = e / nq, q = e - m * nq;
+                const double nxt = (m == ng - 1) ? HI(0) : HI(m + 1);
+                LO(m) = LO(m) + nxt;
+            }
+            __syncthreads();
+            for (int e = tid; e < work; e += nt) {
+                const int m = e / nq, q = e - m * nq;
+                const double prev = (m == 0) ? T[ilmax * P + q] : LO(m - 1);
+                HI(m) = HI(m) + LO(m) * wc.c1 + prev * wc.c2;
+            }
+            __syncthreads();
+            for (int e = tid; e < work; e += nt) { const int m = e / nq, q = e - m * nq; LO(m) = LO(m) - HI(m) * wc.c0; }
+            __syncthreads();
+        }
+#undef LO
+#undef HI
+    }
+    // ---- store
+    if (ax.mode == 0) {
+        for (int e = tid; e < nq * L; e += nt) { const int q = e / L, a = e - q * L; base[g0 + (int64_t)q * qstride + a] = T[a * P + q]; }
+    } else {
+        for (int e = tid; e < nq * L; e += nt) { const int a = e / nq, q = e - a * nq; base[g0 + (int64_t)a * ax.astride + q] = T[a * P + q]; }
+    }
+}
+
+static WaveConst wave_consts()
+{
+    WaveConst w;
+    w.sq2 = std::sqrt(2.0);
+    w.c0 = std::sqrt(3.0);                                  // wavelet_transform.F90:252-256
+    w.c1 = std::sqrt(3.0) / 4.0;
+    w.c2 = (std::sqrt(3.0) - 2.0) / 4.0;
+    w.c3 = (std::sqrt(3.0) - 1.0) / std::sqrt(2.0);
+    w.c4 = (std::sqrt(3.0) + 1.0) / std::sqrt(2.0);
+    return w;
+}
+
+constexpr size_t WAVE_LDS_BUDGET = 96 * 1024;
+
+template <int TYPE, int DIR>
+static int launch_axis(tfx_ctx *ctx, double *d, int64_t vec_stride, int64_t nvec, WaveAxis ax, unsigned ntiles)
+{
+    const size_t lds = (size_t)ax.L * ax.P * sizeof(double);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        TFX_HIP(hipFuncSetAttribute((const void *)k_wavelet_axis<TYPE, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS_BUDGET + 4096));
+        lds_set = WAVE_LDS_BUDGET + 4096;
+    }
+    hipLaunchKernelGGL((k_wavelet_axis<TYPE, DIR>), dim3(ntiles, (unsigned)nvec), dim3(256), lds, ctx->stream, d, vec_stride, ax, wave_consts());
+    TFX_HIP(hipGetLastError());
+    return 0;
+}
+
+static int pick_xt(int L, int64_t avail, int want, int *XT, int *P)
+{
+    int xt = (int)std::min<int64_t>(want, std::max<int64_t>(1, avail));
+    while (xt > 1 && (size_t)L * (size_t)(xt | 1) * sizeof(double) > WAVE_LDS_BUDGET) xt /= 2;
+    int p = xt | 1;     // odd pitch
+    if ((size_t)L * p * sizeof(double) > WAVE_LDS_BUDGET)
+        return fail(TFX_E_ARG, "wavelet axis length %d exceeds the LDS line budget", L);
+    *XT = xt;
+    *P = p;
+    return 0;
+}
+
+// in place on nvec device arrays of n1*n2*n3 doubles, back to back (vec_stride = n1*n2*n3)
+int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, int type, int dir)
+{
+    if (type != 1 && type != 2) return fail(TFX_E_ARG, "Unknown wavelet type!");      // wavelet_transform.F90:46-48
+    if (dir != 1 && dir != 2) return fail(TFX_E_ARG, "bad wavelet direction");
+    if (nvec <= 0) return 0;
+    const int64_t N = (int64_t)n1 * n2 * n3;
+    for (int axis = 0; axis < 3; ++axis) {             // axis order x -> y -> z for forward AND inverse (:82-93, :165-176)
+        WaveAxis ax{};
+        unsigned ntiles = 0;
+        if (axis == 0) {
+            if (n1 < 2) continue;
+            ax.L = n1; ax.mode = 0; ax.astride = 1; ax.nlines = (int64_t)n2 * n3;
+            TFX_TRY(pick_xt(n1, ax.nlines, 16, &ax.XT, &ax.P));
+            ntiles = (unsigned)((ax.nlines + ax.XT - 1) / ax.XT);
+        } else if (axis == 1) {
+            if (n2 < 2) continue;
+            ax.L = n2; ax.mode = 1; ax.astride = n1; ax.inner = n1; ax.outer_stride = (int64_t)n1 * n2;
+            TFX_TRY(pick_xt(n2, n1, 16, &ax.XT, &ax.P));
+            ax.ntiles_inner = (n1 + ax.XT - 1) / ax.XT;
+            ntiles = (unsigned)(ax.ntiles_inner * n3);
+        } else {
+            if (n3 < 2) continue;
+            ax.L = n3; ax.mode = 1; ax.astride = (int64_t)n1 * n2; ax.inner = (int64_t)n1 * n2; ax.outer_stride = 0;
+            TFX_TRY(pick_xt(n3, ax.inner, 16, &ax.XT, &ax.P));
+            ax.ntiles_inner = (ax.inner + ax.XT - 1) / ax.XT;
+            ntiles = (unsigned)ax.ntiles_inner;
+        }
+        if (type == 1 && dir == 1) TFX_TRY((launch_axis<1, 1>(ctx, d, N, nvec, ax, ntiles)));
+        else if (type == 1 && dir == 2) TFX_TRY((launch_axis<1, 2>(ctx, d, N, nvec, ax, ntiles)));
+        else if (type == 2 && dir == 1) TFX_TRY((launch_axis<2, 1>(ctx, d, N, nvec, ax, ntiles)));
+        else TFX_TRY((launch_axis<2, 2>(ctx, d, N, nvec, ax, ntiles)));
+    }
+    return 0;
+}
+
+// =============================================================================================================
+// exact order statistic: thr = sort_ascending(|row|)[N-K]  (sensitivity_gravmag.F90:240-250)
+// radix select on the 63-bit pattern of |x| (non-negative doubles order like unsigned integers)
+// =============================================================================================================
+constexpr int SEL_BINS = 4096;
+constexpr int SEL_NDIG = 6;
+__constant__ int c_sel_shift[SEL_NDIG] = {52, 40, 28, 16, 4, 0};
+__constant__ int c_sel_bits[SEL_NDIG] = {12, 12, 12, 12, 12, 4};
+
+struct SelState {
+    unsigned long long prefix;    // selected high bits so far (already shifted into place)
+    unsigned long long rank;      // 1-based rank (ascending) inside the candidate set
+    unsigned long long ncand;     // candidates in the current buffer
+    unsigned long long nnext;     // append counter for the next buffer
+    unsigned int bin, pad;
+};
+
+// digit 0 reads |row| directly; later digits read the candidate key buffer
+__global__ __launch_bounds__(256) void k_sel_hist(const double *__restrict__ rows, int64_t N,
+                                                  const unsigned long long *__restrict__ cand, int64_t cand_stride,
+                                                  const SelState *__restrict__ st, int digit, unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int h[SEL_BINS];
+    const int row = blockIdx.y;
+    for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const int shift = c_sel_shift[digit];
+    const unsigned int mask = (1u << c_sel_bits[digit]) - 1u;
+    if (digit == 0) {
+        const double *r = rows + (int64_t)row * N;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(r[i]));
+            atomicAdd(&h[(unsigned int)(key >> shift) & mask], 1u);
+        }
+    } else {
+        const unsigned long long *c = cand + (int64_t)row * cand_stride;
+        const int64_t n = (int64_t)st[row].ncand;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            atomicAdd(&h[(unsigned int)(c[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    unsigned int *g = hist + (int64_t)row * SEL_BINS;
+    for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x)
+        if (h[i]) atomicAdd(&g[i], h[i]);
+}
+
+// one block per row: find the bin holding the rank-th smallest, update prefix / rank
+__global__ void k_sel_pick(SelState *__restrict__ st, unsigned int *__restrict__ hist, int digit)
+{
+    const int row = blockIdx.x;
+    __shared__ unsigned long long part[256];
+    unsigned int *g = hist + (int64_t)row * SEL_BINS;
+    const int per = SEL_BINS / 256;
+    unsigned long long s = 0;
+    for (int i = 0; i < per; ++i) s += g[threadIdx.x * per + i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long rank = st[row].rank;
+        unsigned long long run = 0;
+        int t = 0;
+        while (t < 255 && run + part[t] < rank) { run += part[t]; ++t; }
+        int b = t * per;
+        while (b < SEL_BINS - 1 && run + g[b] < rank) { run += g[b]; ++b; }
+        st[row].bin = (unsigned int)b;
+        st[row].rank = rank - run;
+        st[row].prefix |= ((unsigned long long)b) << c_sel_shift[digit];
+        st[row].nnext = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) g[i] = 0;     // ready for the next digit
+}
+
+// keep the keys that fall into the picked bin
+__global__ __launch_bounds__(256) void k_sel_filter(const double *__restrict__ rows, int64_t N,
+                                                    const unsigned long long *__restrict__ cand_in,
+                                                    unsigned long long *__restrict__ cand_out, int64_t cand_stride,
+                                                    SelState *__restrict__ st, int digit)
+{
+    const int row = blockIdx.y;
+    const int shift = c_sel_shift[digit];
+    const unsigned int mask = (1u << c_sel_bits[digit]) - 1u;
+    const unsigned int bin = st[row].bin;
+    unsigned long long *out = cand_out + (int64_t)row * cand_stride;
+    const int64_t n = (digit == 0) ? N : (int64_t)st[row].ncand;
+    const double *r = rows + (int64_t)row * N;
+    const unsigned long long *c = cand_in + (int64_t)row * cand_stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long key = (digit == 0) ? (unsigned long long)__double_as_longlong(fabs(r[i])) : c[i];
+        if (((unsigned int)(key >> shift) & mask) == bin) {
+            const unsigned long long pos = atomicAdd(&st[row].nnext, 1ull);
+            out[pos] = key;
+        }
+    }
+}
+
+__global__ void k_sel_advance(SelState *__restrict__ st, int nrows)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < nrows) st[row].ncand = st[row].nnext;
+}
+
+__global__ void k_sel_init(SelState *__restrict__ st, int nrows, unsigned long long rank)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < nrows) { st[row].prefix = 0; st[row].rank = rank; st[row].ncand = 0; st[row].nnext = 0; st[row].bin = 0; }
+}
+
+__global__ void k_sel_result(const SelState *__restrict__ st, int nrows, double *__restrict__ thr)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < nrows) {
+        double t = __longlong_as_double((long long)st[row].prefix);
+        if (t < 1.e-30) t = 1.e-30;                        // sensitivity_gravmag.F90:252-256
+        thr[row] = t;
+    }
+}
+
+struct SelectWork {
+    DBuf<SelState> st;
+    DBuf<unsigned int> hist;
+    DBuf<unsigned long long> candA, candB;
+    int cap_rows = 0;
+    int64_t cap_N = 0;
+};
+
+// thr[row] for nrows rows of N coefficients; K = entries to keep
+int select_threshold_dev(tfx_ctx *ctx, SelectWork &wk, const double *d_rows, int nrows, int64_t N, int64_t K, double *d_thr)
+{
+    hipStream_t s = ctx->stream;
+    if (K >= N) {                                            // "Taking all elements": thr = -1 -> floor 1e-30 (:244-256)
+        std::vector<double> h((size_t)nrows, 1.e-30);
+        TFX_HIP(hipMemcpyAsync(d_thr, h.data(), nrows * sizeof(double), hipMemcpyHostToDevice, s));
+        TFX_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
+    if (wk.cap_rows < nrows || wk.cap_N < N) {
+        TFX_TRY(wk.st.alloc(nrows));
+        TFX_TRY(wk.hist.alloc((size_t)nrows * SEL_BINS));
+        TFX_TRY(wk.candA.alloc((size_t)nrows * N));
+        TFX_TRY(wk.candB.alloc((size_t)nrows * N));
+        wk.cap_rows = nrows;
+        wk.cap_N = N;
+    }
+    TFX_HIP(hipMemsetAsync(wk.hist.p, 0, (size_t)nrows * SEL_BINS * sizeof(unsigned int), s));
+    hipLaunchKernelGGL(k_sel_init, dim3((nrows + 63) / 64), dim3(64), 0, s, wk.st.p, nrows, (unsigned long long)(N - K));
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->num_cu * 4 / std::max(1, nrows) + 1, (N + 255) / 256));
+    unsigned long long *in = wk.candA.p, *out = wk.candB.p;
+    for (int d = 0; d < SEL_NDIG; ++d) {
+        hipLaunchKernelGGL(k_sel_hist, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, wk.cap_N, wk.st.p, d, wk.hist.p);
+        hipLaunchKernelGGL(k_sel_pick, dim3(nrows), dim3(256), 0, s, wk.st.p, wk.hist.p, d);
+        if (d + 1 < SEL_NDIG) {
+            hipLaunchKernelGGL(k_sel_filter, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, out, wk.cap_N, wk.st.p, d);
+            hipLaunchKernelGGL(k_sel_advance, dim3((nrows + 63) / 64), dim3(64), 0, s, wk.st.p, nrows);
+            std::swap(in, out);
+        }
+    }
+    hipLaunchKernelGGL(k_sel_result, dim3((nrows + 63) / 64), dim3(64), 0, s, wk.st.p, nrows, d_thr);
+    TFX_HIP(hipGetLastError());
+    return 0;
+}
+
+// =============================================================================================================
+// ordered compaction: keep |c| > thr in ascending column order (sensitivity_gravmag.F90:258-272)
+// =============================================================================================================
+constexpr int CMP_THREADS = 256;
+constexpr int CMP_PER_THREAD = 8;
+constexpr int CMP_SEG = CMP_THREADS * CMP_PER_THREAD;     // 2048 elements per block
+
+struct CompactArgs {
+    const double *rows;       // [nrows][N]
+    int64_t N;
+    const double *thr;        // [nrows]
+    int keep_all;             // compression off: every column is stored (:289-295)
+    int64_t col_begin, col_end;   // columns kept by this rank, output column = p - col_begin
+    int nseg;                 // segments per row
+    int32_t *seg_cnt;         // [nrows][nseg] kept-in-range counts
+    int32_t *seg_off;         // [nrows][nseg] exclusive scan
+    double *seg_cost;         // [nrows][nseg] sum of discarded^2
+    int32_t *out_cols;        // [.. ][stride]
+    float *out_vals;
+    int64_t out_stride;
+    int32_t *nel;             // [nrows] kept in range
+    int32_t *nel_all;         // [nrows] kept over all columns (the reference's nel)
+    double *cost_disc;        // [nrows]
+    const float *scale;       // [nrows] (float)(problem_weight*data_weight)   (:841)
+    int32_t *hist;            // [N] per-column nnz (sensit_nnz, :267) or null
+};
+
+__device__ __forceinline__ bool keep_elem(double v, double thr, int keep_all) { return keep_all || fabs(v) > thr; }
+
+__global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
+{
+    const int row = blockIdx.y, seg = blockIdx.x;
+    const double *r = a.rows + (int64_t)row * a.N;
+    const double thr = a.thr[row];
+    const int64_t base = (int64_t)seg * CMP_SEG + (int64_t)threadIdx.x * CMP_PER_THREAD;
+    int cnt = 0, cnt_all = 0;
+    double cost = 0.0;
+    for (int k = 0; k < CMP_PER_THREAD; ++k) {
+        const int64_t p = base + k;
+        if (p < a.N) {
+            const double v = r[p];
+            if (keep_elem(v, thr, a.keep_all)) {
+                cnt_all += 1;
+                if (p >= a.col_begin && p < a.col_end) cnt += 1;
+                if (a.hist) atomicAdd(&a.hist[p], 1);
+            } else cost = fma(v, v, cost);
+        }
+    }
+    __shared__ int s_cnt[CMP_THREADS / 64], s_all[CMP_THREADS / 64];
+    __shared__ double s_cost[CMP_THREADS / 64];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); cnt_all += __shfl_down(cnt_all, d); cost += __shfl_down(cost, d); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_cnt[wave] = cnt; s_all[wave] = cnt_all; s_cost[wave] = cost; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0, ca = 0;
+        double cs = 0.0;
+        for (int i = 0; i < CMP_THREADS / 64; ++i) { c += s_cnt[i]; ca += s_all[i]; cs += s_cost[i]; }
+        a.seg_cnt[(int64_t)row * a.nseg + seg] = c;
+        a.seg_cost[(int64_t)row * a.nseg + seg] = cs;
+        atomicAdd(&a.nel_all[row], ca);
+    }
+}
+
+// one block per row: exclusive scan of the segment counts, totals
+__global__ void k_cmp_scan(CompactArgs a)
+{
+    const int row = blockIdx.x;
+    __shared__ int part[256];
+    __shared__ double cpart[256];
+    const int per = (a.nseg + 255) / 256;
+    const int b = threadIdx.x * per, e = min(b + per, a.nseg);
+    int s = 0;
+    double cs = 0.0;
+    for (int i = b; i < e; ++i) { s += a.seg_cnt[(int64_t)row * a.nseg + i]; cs += a.seg_cost[(int64_t)row * a.nseg + i]; }
+    part[threadIdx.x] = s;
+    cpart[threadIdx.x] = cs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        double crun = 0.0;
+        for (int i = 0; i < 256; ++i) { int v = part[i]; part[i] = run; run += v; crun += cpart[i]; }
+        a.nel[row] = run;
+        a.cost_disc[row] = crun;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = b; i < e; ++i) { a.seg_off[(int64_t)row * a.nseg + i] = run; run += a.seg_cnt[(int64_t)row * a.nseg + i]; }
+}
+
+__global__ __launch_bounds__(CMP_THREADS) void k_cmp_write(CompactArgs a)
+{
+    const int row = blockIdx.y, seg = blockIdx.x;
+    const double *r = a.rows + (int64_t)row * a.N;
+    const double thr = a.thr[row];
+    const float sc = a.scale ? a.scale[row] : 1.0f;
+    const int64_t base = (int64_t)seg * CMP_SEG + (int64_t)threadIdx.x * CMP_PER_THREAD;
+    double v[CMP_PER_THREAD];
+    unsigned keepmask = 0;
+    for (int k = 0; k < CMP_PER_THREAD; ++k) {
+        const int64_t p = base + k;
+        v[k] = 0.0;
+        if (p < a.N && p >= a.col_begin && p < a.col_end) {
+            v[k] = r[p];
+            if (keep_elem(v[k], thr, a.keep_all)) keepmask |= 1u << k;
+        }
+    }
+    const int mine = __popc(keepmask);
+    // exclusive scan over the block's threads (thread order = column order)
+    int incl = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    __shared__ int wsum[CMP_THREADS / 64];
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < wave; ++i) woff += wsum[i];
+    int pos = a.seg_off[(int64_t)row * a.nseg + seg] + woff + incl - mine;
+    int32_t *oc = a.out_cols + (int64_t)row * a.out_stride;
+    float *ov = a.out_vals + (int64_t)row * a.out_stride;
+    for (int k = 0; k < CMP_PER_THREAD; ++k)
+        if (keepmask & (1u << k)) {
+            oc[pos] = (int32_t)(base + k - a.col_begin);
+            float f = (float)v[k];                           // real(x, MATRIX_PRECISION), :265
+            if (a.scale) f = f * sc;                         // :841
+            ov[pos] = f;
+            ++pos;
+        }
+}
+
+// sum of squares of each row (cost_full, :234); red: [nrows][gridDim.x]
+__global__ __launch_bounds__(256) void k_row_sumsq(const double *__restrict__ rows, int64_t N, double *__restrict__ red)
+{
+    const int row = blockIdx.y;
+    const double *r = rows + (int64_t)row * N;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) s = fma(r[i], r[i], s);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) red[(int64_t)row * gridDim.x + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+struct CompactWork {
+    DBuf<int32_t> seg_cnt, seg_off, nel, nel_all;
+    DBuf<double> seg_cost, cost_disc, thr, red;
+    DBuf<float> scale;
+    int cap_rows = 0;
+    int nseg = 0;
+};
+
+static int compact_prepare(CompactWork &cw, int nrows, int64_t N)
+{
+    const int nseg = (int)((N + CMP_SEG - 1) / CMP_SEG);
+    if (cw.cap_rows >= nrows && cw.nseg == nseg) return 0;
+    TFX_TRY(cw.seg_cnt.alloc((size_t)nrows * nseg));
+    TFX_TRY(cw.seg_off.alloc((size_t)nrows * nseg));
+    TFX_TRY(cw.seg_cost.alloc((size_t)nrows * nseg));
+    TFX_TRY(cw.nel.alloc(nrows));
+    TFX_TRY(cw.nel_all.alloc(nrows));
+    TFX_TRY(cw.cost_disc.alloc(nrows));
+    TFX_TRY(cw.thr.alloc(nrows));
+    TFX_TRY(cw.scale.alloc(nrows));
+    TFX_TRY(cw.red.alloc((size_t)nrows * 256));
+    cw.cap_rows = nrows;
+    cw.nseg = nseg;
+    return 0;
+}
+
+// rows [nrows][N] (device) -> out_cols/out_vals rows (stride), nel / nel_all / cost_disc in cw
+static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int nrows, int64_t N, int keep_all,
+                       int64_t col_begin, int64_t col_end, int32_t *out_cols, float *out_vals, int64_t out_stride,
+                       int32_t *d_nel_out, const float *d_scale, int32_t *d_hist)
+{
+    hipStream_t s = ctx->stream;
+    CompactArgs a{};
+    a.rows = d_rows; a.N = N; a.thr = cw.thr.p; a.keep_all = keep_all; a.col_begin = col_begin; a.col_end = col_end;
+    a.nseg = cw.nseg; a.seg_cnt = cw.seg_cnt.p; a.seg_off = cw.seg_off.p; a.seg_cost = cw.seg_cost.p;
+    a.out_cols = out_cols; a.out_vals = out_vals; a.out_stride = out_stride; a.nel = d_nel_out; a.nel_all = cw.nel_all.p;
+    a.cost_disc = cw.cost_disc.p; a.scale = d_scale; a.hist = d_hist;
+    TFX_HIP(hipMemsetAsync(cw.nel_all.p, 0, nrows * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_cmp_count, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_cmp_scan, dim3(nrows), dim3(256), 0, s, a);
+    if (out_cols) hipLaunchKernelGGL(k_cmp_write, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+    TFX_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace tfx
+
+using namespace tfx;
+
+extern "C" {
+
+int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double *rows_out)
+{
+    if (!ctx || !xd || !yd || !zd || !rows_out) return fail(TFX_E_ARG, "tfx_prism_rows_gz: null argument");
+    if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_prism_rows_gz: set the grid first");
+    TFX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int64_t N = ctx->N;
+    const int B = (int)std::min<int64_t>(ndata, std::max<int64_t>(1, (int64_t)(1u << 28) / N));   // <= 2 GB of rows per batch
+    DBuf<double> dobs, drows;
+    DBuf<int> derr;
+    TFX_TRY(dobs.alloc((size_t)3 * B));
+    TFX_TRY(drows.alloc((size_t)B * N));
+    TFX_TRY(derr.alloc(1));
+    TFX_HIP(hipMemsetAsync(derr.p, 0, sizeof(int), s));
+    const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
+    for (int64_t o0 = 0; o0 < ndata; o0 += B) {
+        const int nb = (int)std::min<int64_t>(B, ndata - o0);
+        TFX_HIP(hipMemcpyAsync(dobs.p, xd + o0, nb * sizeof(double), hipMemcpyDefault, s));
+        TFX_HIP(hipMemcpyAsync(dobs.p + B, yd + o0, nb * sizeof(double), hipMemcpyDefault, s));
+        TFX_HIP(hipMemcpyAsync(dobs.p + 2 * B, zd + o0, nb * sizeof(double), hipMemcpyDefault, s));
+        hipLaunchKernelGGL(k_prism_gz, dim3(grid), dim3(256), 0, s, N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
+                           ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nb, dobs.p, dobs.p + B, dobs.p + 2 * B,
+                           (const double *)nullptr, drows.p, derr.p);
+        TFX_HIP(hipGetLastError());
+        TFX_HIP(hipMemcpyAsync(rows_out + o0 * N, drows.p, (size_t)nb * N * sizeof(double), hipMemcpyDefault, s));
+        TFX_HIP(hipStreamSynchronize(s));
+    }
+    int herr = 0;
+    TFX_HIP(hipMemcpy(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (herr & 1) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (YZ). Adjust the model grid!");
+    if (herr & 2) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (XZ). Adjust the model grid!");
+    return 0;
+}
+
+int tfx_column_weight_type1(tfx_ctx *ctx, double power, double Z0, double multiplier, double *cw_out)
+{
+    if (!ctx || !cw_out) return fail(TFX_E_ARG, "tfx_column_weight_type1: null argument");
+    if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_column_weight_type1: set the grid first");
+    TFX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int64_t N = ctx->N;
+    DBuf<double> w;
+    DBuf<unsigned long long> mx;
+    DBuf<int> derr;
+    TFX_TRY(w.alloc((size_t)N));
+    TFX_TRY(mx.alloc(1));
+    TFX_TRY(derr.alloc(1));
+    TFX_HIP(hipMemsetAsync(mx.p, 0, sizeof(unsigned long long), s));
+    TFX_HIP(hipMemsetAsync(derr.p, 0, sizeof(int), s));
+    const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 8);
+    hipLaunchKernelGGL(k_depth_weight, dim3(grid), dim3(256), 0, s, N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
+                       ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, power, Z0, w.p, mx.p, derr.p);
+    hipLaunchKernelGGL(k_depth_weight_finish, dim3(grid), dim3(256), 0, s, N, w.p, mx.p, multiplier, derr.p);
+    TFX_HIP(hipGetLastError());
+    int herr = 0;
+    TFX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipStreamSynchronize(s));
+    if (herr & 1) return fail(TFX_E_NUMERIC, "Error: non-positive depth in calc_depth_weight_pixel!");
+    if (herr & 2) return fail(TFX_E_NUMERIC, "Zero damping weight! Exiting.");
+    TFX_TRY(copy_any(cw_out, w.p, (size_t)N * sizeof(double), s));
+    return 0;
+}
+
+int tfx_wavelet(tfx_ctx *ctx, double *sarr, int n1, int n2, int n3, int64_t nvec, int type, int direction)
+{
+    if (!ctx || !sarr) return fail(TFX_E_ARG, "tfx_wavelet: null argument");
+    if (n1 <= 0 || n2 <= 0 || n3 <= 0 || nvec < 0) return fail(TFX_E_ARG, "tfx_wavelet: bad size");
+    TFX_HIP(hipSetDevice(ctx->device));
+    const int64_t N = (int64_t)n1 * n2 * n3;
+    hipPointerAttribute_t attr;
+    bool dev = hipPointerGetAttributes(&attr, sarr) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    if (!dev) (void)hipGetLastError();
+    if (dev) {
+        TFX_TRY(wavelet_dev(ctx, sarr, n1, n2, n3, nvec, type, direction));
+        TFX_HIP(hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
+    DBuf<double> d;
+    TFX_TRY(d.alloc((size_t)(N * nvec)));
+    TFX_TRY(copy_any(d.p, sarr, (size_t)(N * nvec) * sizeof(double), ctx->stream));
+    TFX_TRY(wavelet_dev(ctx, d.p, n1, n2, n3, nvec, type, direction));
+    TFX_TRY(copy_any(sarr, d.p, (size_t)(N * nvec) * sizeof(double), ctx->stream));
+    return 0;
+}
+
+int tfx_compress_row(tfx_ctx *ctx, const double *row, int64_t N, int64_t K, int32_t *cols_out, float *vals_out,
+                     int64_t *nel_out, double *thr_out, double *cost_discarded_out)
+{
+    if (!ctx || !row || !cols_out || !vals_out || !nel_out) return fail(TFX_E_ARG, "tfx_compress_row: null argument");
+    if (N <= 0 || K < 0) return fail(TFX_E_ARG, "tfx_compress_row: bad size");
+    TFX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DBuf<double> d;
+    DBuf<int32_t> oc;
+    DBuf<float> ov;
+    TFX_TRY(d.alloc((size_t)N));
+    const int64_t stride = std::max<int64_t>(1, std::min<int64_t>(N, K));
+    TFX_TRY(oc.alloc((size_t)stride));
+    TFX_TRY(ov.alloc((size_t)stride));
+    TFX_TRY(copy_any(d.p, row, (size_t)N * sizeof(double), s));
+    SelectWork sw;
+    CompactWork cw;
+    TFX_TRY(compact_prepare(cw, 1, N));
+    TFX_TRY(select_threshold_dev(ctx, sw, d.p, 1, N, K, cw.thr.p));
+    TFX_TRY(compact_dev(ctx, cw, d.p, 1, N, 0, 0, N, oc.p, ov.p, stride, cw.nel.p, nullptr, nullptr));
+    int32_t nel = 0;
+    double thr = 0, cd = 0;
+    TFX_HIP(hipMemcpyAsync(&nel, cw.nel.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipMemcpyAsync(&thr, cw.thr.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipMemcpyAsync(&cd, cw.cost_disc.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipStreamSynchronize(s));
+    if (nel > stride) return fail(TFX_E_NUMERIC, "Wrong number of elements in calculate_and_write_sensit!");   // :275-277
+    std::vector<int32_t> hc((size_t)nel);
+    TFX_TRY(copy_any(hc.data(), oc.p, (size_t)nel * sizeof(int32_t), s));
+    for (int32_t i = 0; i < nel; ++i) cols_out[i] = hc[(size_t)i] + 1;     // 1-based across the ABI
+    TFX_TRY(copy_any(vals_out, ov.p, (size_t)nel * sizeof(float), s));
+    *nel_out = nel;
+    if (thr_out) *thr_out = thr;
+    if (cost_discarded_out) *cost_discarded_out = cd;
+    return 0;
+}
+
+int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
+                          const double *column_weight, int compression_type, double rate, double problem_weight,
+                          const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
+                          double *error_sum_out, int32_t *nnz_hist_out)
+{
+    if (!ctx || !xd || !yd || !zd || !column_weight) return fail(TFX_E_ARG, "tfx_build_kernel_grav: null argument");
+    if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_build_kernel_grav: set the grid first");
+    if (compression_type < 0 || compression_type > 2) return fail(TFX_E_ARG, "Unknown wavelet type!");
+    if (rate < 0 || rate > 1) return fail(TFX_E_ARG, "Wrong compression rate! It must be between 0 and 1.");   // :112-114
+    const int64_t N = ctx->N;
+    if (col_begin < 0 || col_end > N || col_begin > col_end) return fail(TFX_E_ARG, "bad column range");
+    if (ndata <= 0) return fail(TFX_E_ARG, "no data");
+    TFX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int64_t ncols = col_end - col_begin;
+    const bool keep_matrix = ncols > 0;
+    const int64_t K = compression_type > 0 ? (int64_t)(rate * (double)N) : N;      // get_nel_compressed, :64-77
+    const int64_t stride = std::max<int64_t>(1, std::min<int64_t>(K, std::max<int64_t>(ncols, 1)));
+    // observation coordinates and scale factors on the device
+    DBuf<double> dobs, dcw, drows, dred;
+    DBuf<int> derr;
+    DBuf<int32_t> dhist;
+    TFX_TRY(dobs.alloc((size_t)3 * ndata));
+    TFX_TRY(dcw.alloc((size_t)N));
+    TFX_TRY(derr.alloc(1));
+    TFX_HIP(hipMemcpyAsync(dobs.p, xd, ndata * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemcpyAsync(dobs.p + ndata, yd, ndata * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemcpyAsync(dobs.p + 2 * ndata, zd, ndata * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemcpyAsync(dcw.p, column_weight, (size_t)N * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemsetAsync(derr.p, 0, sizeof(int), s));
+    if (nnz_hist_out) {
+        TFX_TRY(dhist.alloc((size_t)N));
+        TFX_HIP(hipMemsetAsync(dhist.p, 0, (size_t)N * sizeof(int32_t), s));
+    }
+    std::vector<float> hscale((size_t)ndata);
+    {
+        std::vector<double> hdw;
+        if (data_weight) {
+            hdw.resize((size_t)ndata);
+            TFX_TRY(copy_any(hdw.data(), data_weight, (size_t)ndata * sizeof(double), s));
+        }
+        for (int64_t i = 0; i < ndata; ++i) hscale[(size_t)i] = (float)(problem_weight * (data_weight ? hdw[(size_t)i] : 1.0));   // :841
+    }
+    if (keep_matrix) TFX_TRY(matrix_begin(ctx, ndata, ncols, ndata * std::min<int64_t>(K, ncols)));
+    TiledMatrix &m = ctx->mat;
+    const int RB = keep_matrix ? m.RB : (int)std::min<int64_t>(RB_MAX, (ndata + 63) / 64 * 64);
+    // rows processed per batch: row buffer + select candidates (2x) must stay around 6 GB
+    const int B = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, RB), (int64_t)(1u << 28) / N));
+    TFX_TRY(drows.alloc((size_t)B * N));
+    TFX_TRY(dred.alloc((size_t)B * 256));
+    DBuf<int32_t> ell_cols, ell_nel;
+    DBuf<float> ell_vals, dscale;
+    DBuf<int64_t> ell_off;
+    if (keep_matrix) {
+        TFX_TRY(ell_cols.alloc((size_t)RB * stride));
+        TFX_TRY(ell_vals.alloc((size_t)RB * stride));
+        TFX_TRY(ell_off.alloc(RB));
+        std::vector<int64_t> ho(RB);
+        for (int r = 0; r < RB; ++r) ho[r] = (int64_t)r * stride;
+        TFX_HIP(hipMemcpyAsync(ell_off.p, ho.data(), RB * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    }
+    TFX_TRY(ell_nel.alloc(RB));
+    TFX_TRY(dscale.alloc((size_t)ndata));
+    TFX_HIP(hipMemcpyAsync(dscale.p, hscale.data(), (size_t)ndata * sizeof(float), hipMemcpyHostToDevice, s));
+    SelectWork sw;
+    CompactWork cw;
+    TFX_TRY(compact_prepare(cw, B, N));
+    const int pgrid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
+    const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(256, (N + 255) / 256));
+    double err_sum = 0.0;
+    int64_t nnz_total = 0;
+    std::vector<double> h_red((size_t)B * rgrid), h_cd(B);
+    std::vector<int32_t> h_nel(RB), h_nel_all(B);
+    for (int64_t r0 = 0; r0 < ndata; r0 += RB) {
+        const int nr = (int)std::min<int64_t>(RB, ndata - r0);
+        for (int b0 = 0; b0 < nr; b0 += B) {
+            const int nb = std::min(B, nr - b0);
+            const int64_t g = r0 + b0;
+            hipLaunchKernelGGL(k_prism_gz, dim3(pgrid), dim3(256), 0, s, N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
+                               ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nb, dobs.p + g, dobs.p + ndata + g,
+                               dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p);
+            if (compression_type > 0) {
+                hipLaunchKernelGGL(k_row_sumsq, dim3(rgrid, nb), dim3(256), 0, s, drows.p, N, dred.p);             // cost_full :234
+                TFX_HIP(hipGetLastError());
+                TFX_TRY(wavelet_dev(ctx, drows.p, ctx->nx, ctx->ny, ctx->nz, nb, compression_type, 1));              // :237
+                TFX_TRY(select_threshold_dev(ctx, sw, drows.p, nb, N, K, cw.thr.p));                                 // :240-256
+            }
+            TFX_TRY(compact_dev(ctx, cw, drows.p, nb, N, compression_type == 0, col_begin, col_end,
+                                keep_matrix ? ell_cols.p + (size_t)b0 * stride : nullptr,
+                                keep_matrix ? ell_vals.p + (size_t)b0 * stride : nullptr, stride, ell_nel.p + b0,
+                                dscale.p + g, nnz_hist_out ? dhist.p : nullptr));
+            // per-row statistics
+            TFX_HIP(hipMemcpyAsync(h_nel_all.data(), cw.nel_all.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            if (compression_type > 0) {
+                TFX_HIP(hipMemcpyAsync(h_red.data(), dred.p, (size_t)nb * rgrid * sizeof(double), hipMemcpyDeviceToHost, s));
+                TFX_HIP(hipMemcpyAsync(h_cd.data(), cw.cost_disc.p, nb * sizeof(double), hipMemcpyDeviceToHost, s));
+            }
+            TFX_HIP(hipStreamSynchronize(s));
+            for (int i = 0; i < nb; ++i) {
+                if (h_nel_all[i] > K) return fail(TFX_E_NUMERIC, "Wrong number of elements in calculate_and_write_sensit!");
+                if (compression_type > 0) {
+                    double cf = 0.0;
+                    for (int k = 0; k < rgrid; ++k) cf += h_red[(size_t)i * rgrid + k];
+                    err_sum += std::sqrt(h_cd[i] / cf);                                                            // :283
+                }
+            }
+        }
+        int herr = 0;
+        TFX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        TFX_HIP(hipMemcpyAsync(h_nel.data(), ell_nel.p, nr * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        TFX_HIP(hipStreamSynchronize(s));
+        if (herr & 1) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (YZ). Adjust the model grid!");
+        if (herr & 2) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (XZ). Adjust the model grid!");
+        for (int i = 0; i < nr; ++i) nnz_total += h_nel[i];
+        if (keep_matrix) TFX_TRY(matrix_append_rows(ctx, r0, nr, ell_cols.p, ell_vals.p, ell_nel.p, ell_off.p, stride));
+    }
+    if (keep_matrix) {
+        TFX_TRY(matrix_finish(ctx));
+        m.nnz = nnz_total;
+    }
+    if (nnz_out) *nnz_out = nnz_total;
+    if (error_sum_out) *error_sum_out = err_sum;
+    if (nnz_hist_out) TFX_TRY(copy_any(nnz_hist_out, dhist.p, (size_t)N * sizeof(int32_t), s));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+// common.h - context, error handling and device-buffer helpers of libtfx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/tfx.h"
+
+namespace tfx {
+
+extern thread_local std::string g_last_error;
+
+inline int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define TFX_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return tfx::fail(TFX_E_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define TFX_TRY(expr)                 \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != 0) return rc_;     \
+    } while (0)
+
+// Owning device allocation.
+template <typename T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DBuf() = default;
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    ~DBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(size_t count)
+    {
+        release();
+        if (count == 0) return 0;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess)
+            return fail(TFX_E_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        n = count;
+        return 0;
+    }
+    int ensure(size_t count) { return count <= n ? 0 : alloc(count); }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// ---- tiled sensitivity matrix (DESIGN.md "Data layout in HBM") ------------------------------------------
+constexpr int CHUNK = 512;            // entries per chunk = 64 lanes x 8 entries
+constexpr int TC_MAX = 16384;         // columns per column tile (14-bit local column)
+constexpr int RB_MAX = 2048;          // rows per row block
+constexpr uint16_t ROWSTART = 0x8000; // code bit 15: this entry starts a new row inside the tile
+constexpr uint16_t COLMASK = 0x3fff;
+
+struct TileMeta {
+    int64_t off;      // first entry (multiple of CHUNK) in codes[] / vals[]
+    int32_t nchunks;  // padded length / CHUNK
+    int32_t cnt;      // real entries (incl. empty-row markers)
+    int32_t t;        // column tile
+    int32_t rb;       // row block
+};
+
+struct WorkItem {     // one workgroup's work: a run of tiles sharing rb (forward) or t (adjoint)
+    int32_t begin, end;   // range in the order[] array of tile ids
+    int32_t key;          // rb (forward) / t (adjoint)
+    int32_t slot;         // position inside the run of items with the same key
+    int32_t pidx;         // partial-sum tile owned by this item (-1: adjoint slot 0 adds straight into y)
+};
+
+struct TiledMatrix {
+    int64_t nrows = 0, ncols = 0, nnz = 0;
+    int TC = TC_MAX, RB = RB_MAX;
+    int ntc = 0, nrb = 0;
+    DBuf<uint16_t> codes;
+    DBuf<float> vals;
+    int64_t n_entries = 0;        // used (padded) entries
+    DBuf<int32_t> chunk_row0;     // per chunk: local row of the entry preceding the chunk
+    std::vector<TileMeta> h_tiles;
+    DBuf<TileMeta> tiles;
+    // work lists
+    std::vector<WorkItem> h_fwd, h_adj;
+    DBuf<WorkItem> fwd, adj;
+    DBuf<int32_t> fwd_order, adj_order;
+    DBuf<double> fwd_partial;     // one RB-tile of row sums per forward item
+    DBuf<double> adj_partial;     // one TC-tile of column sums per adjoint item with slot >= 1
+    DBuf<int32_t> fwd_nslots, fwd_pbase;   // per row block
+    DBuf<int32_t> adj_nslots, adj_pbase;   // per column tile
+    bool adj_has_partials = false;
+    bool valid = false;
+    size_t device_bytes() const;
+};
+
+struct LsqrState;
+
+}  // namespace tfx
+
+struct tfx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+    // grid
+    int nx = 0, ny = 0, nz = 0;
+    int64_t N = 0;
+    tfx::DBuf<double> grid[6];
+    // matrix
+    tfx::TiledMatrix mat;
+    // scratch vectors for spmv / spmtv with host pointers
+    tfx::DBuf<double> vx, vb;
+    // comm
+    tfx_allreduce_fn allreduce = nullptr;
+    void *allreduce_user = nullptr;
+    int rank = 0, nranks = 1;
+    // lsqr
+    tfx::LsqrState *lsqr = nullptr;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profile = false;
+    double prof_ms[2] = {0, 0};
+    int64_t prof_n[2] = {0, 0};
+    hipEvent_t pev0 = nullptr, pev1 = nullptr;
+};
+
+namespace tfx {
+// matrix.hip
+int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const int32_t *d_cols, const float *d_vals,
+                       const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen);
+int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper);
+int matrix_finish(tfx_ctx *ctx);
+int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);     // b (+)= S x   (device pointers)
+int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);    // b (+)= S^T x
+int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
+}  // namespace tfx

@@ -1,0 +1,458 @@
+// lsqr.hip - device-resident LSQR over [S; C]: lsqr_solve_sensit, src/inversion/lsqr_solver2.F90:47-308.
+//
+// S is the tiled sensitivity matrix (matrix.hip); C is a stack of diagonal blocks (the damping / ADMM blocks that
+// damping%add builds row by row, src/inversion/damping.F90:158-179) applied on the fly.  All vectors and the
+// Golub-Kahan scalars live on the device; per iteration the host reads back one 48-byte record to evaluate the
+// reference's exit conditions (:163, :251-254, :286-289).
+//
+// Multi-rank (column-partitioned S, one rank per GPU): u_data is replicated, v/w/x and the constraint rows are local.
+//   reduction 1 (lsqr_solver2.F90:214): all-reduce of [S_loc v ; ||u_cons,loc||^2]   (nrows + 1 doubles)
+//   reduction 2 (:511-515):             all-reduce of ||v_loc||^2                     (1 double)
+// The reference all-reduces the N constraint rows too; they are block-diagonal by construction (each rank fills only
+// its own rows, damping.F90:158-179), so keeping them local and reducing only their squared norm is identical math.
+#include "common.h"
+#include <cmath>
+
+namespace tfx {
+
+struct Scalars {
+    double alpha, beta, rhobar, phibar, b1, r, t1, t2;
+    double sum_u, sum_uc, sum_v, misfit_ss;
+    int32_t rho_zero, u_zero, v_zero, pad;
+};
+
+struct LsqrState {
+    int64_t nrows = 0, ncols = 0;
+    int nblocks = 0;
+    double rmin = 0, gamma = 0, target_misfit = 0;
+    DBuf<double> u;        // nrows + 1 (last = local ||u_cons||^2, rides along in reduction 1)
+    DBuf<double> v, w, x;
+    DBuf<double> uc;       // nblocks * ncols
+    DBuf<float> diag;      // nblocks * ncols
+    DBuf<double> b0, sx;   // target-misfit only
+    DBuf<double> red;      // block partial sums
+    DBuf<Scalars> sc;
+    Scalars *h_sc = nullptr;   // pinned
+    int iter = 0;          // iterations completed
+    double r = 1.0;
+    bool active = false, exact = false, finished = false;
+};
+
+constexpr int RED_BLOCKS = 1024;
+constexpr int RED_THREADS = 256;
+
+__device__ __forceinline__ double block_sum(double v)
+{
+    __shared__ double sm[RED_THREADS / 64];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < RED_THREADS / 64; ++i) s += sm[i];
+    return s;   // valid in thread 0
+}
+
+// red[block] = sum over the block's grid-stride range of x[i]^2
+__global__ void k_sumsq(const double *__restrict__ x, int64_t n, double *__restrict__ red)
+{
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s = fma(x[i], x[i], s);
+    s = block_sum(s);
+    if (threadIdx.x == 0) red[blockIdx.x] = s;
+}
+
+// *dst = sum of red[0..n) in index order (deterministic)
+__global__ void k_final_sum(const double *__restrict__ red, int n, double *dst)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += red[i];
+    s = block_sum(s);
+    if (threadIdx.x == 0) *dst = s;
+}
+
+__global__ void k_scale(double *__restrict__ x, int64_t n, const double *factor_ptr, int negate_or_zero)
+{
+    // negate_or_zero: 0 -> x *= f ; 1 -> x = -f * x ; 2 -> x = 0
+    const double f = *factor_ptr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (negate_or_zero == 0) x[i] = f * x[i];
+        else if (negate_or_zero == 1) x[i] = -f * x[i];
+        else x[i] = 0.0;
+    }
+}
+
+// u_cons[b] = -alpha * u_cons[b] + diag[b] .* v  ; red[block] = partial ||u_cons||^2      (lsqr_solver2.F90:194-211)
+__global__ void k_cons_forward(double *__restrict__ uc, const float *__restrict__ diag, const double *__restrict__ v,
+                               int64_t ncols, int nblocks, const Scalars *sc, double *__restrict__ red)
+{
+    const double alpha = sc->alpha;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncols; i += (int64_t)gridDim.x * blockDim.x) {
+        const double vi = v[i];
+        for (int b = 0; b < nblocks; ++b) {
+            const int64_t k = (int64_t)b * ncols + i;
+            const double t = -alpha * uc[k] + (double)diag[k] * vi;
+            uc[k] = t;
+            s = fma(t, t, s);
+        }
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0) red[blockIdx.x] = s;
+}
+
+// v += sum_b diag[b] .* u_cons[b] ; red[block] = partial ||v||^2                          (lsqr_solver2.F90:236-241)
+__global__ void k_cons_adjoint(double *__restrict__ v, const float *__restrict__ diag, const double *__restrict__ uc,
+                               int64_t ncols, int nblocks, double *__restrict__ red)
+{
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncols; i += (int64_t)gridDim.x * blockDim.x) {
+        double t = v[i];
+        for (int b = 0; b < nblocks; ++b) {
+            const int64_t k = (int64_t)b * ncols + i;
+            t = fma((double)diag[k], uc[k], t);
+        }
+        v[i] = t;
+        s = fma(t, t, s);
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0) red[blockIdx.x] = s;
+}
+
+// beta = sqrt(sum_u + sum_uc); scale factor 1/beta (normalize, lsqr_solver2.F90:501-530)
+__global__ void k_beta(Scalars *sc, const double *uc_total)
+{
+    const double ss = sc->sum_u + *uc_total;
+    const double beta = sqrt(ss);
+    sc->beta = beta;
+    sc->u_zero = (beta == 0.0);
+    sc->t1 = (beta != 0.0) ? 1.0 / beta : 1.0;     // t1 doubles as the scale factor until k_rotate overwrites it
+}
+
+__global__ void k_alpha(Scalars *sc)
+{
+    const double alpha = sqrt(sc->sum_v);
+    sc->alpha = alpha;
+    sc->v_zero = (alpha == 0.0);
+    sc->t2 = (alpha != 0.0) ? 1.0 / alpha : 1.0;
+}
+
+// first-iteration initialisation (lsqr_solver2.F90:134, :155-157)
+__global__ void k_init_scalars(Scalars *sc)
+{
+    sc->b1 = sc->beta;
+    sc->rhobar = sc->alpha;
+    sc->phibar = sc->beta;
+    sc->r = 1.0;
+    sc->rho_zero = 0;
+}
+
+// plane rotation (lsqr_solver2.F90:248-266, :277-280)
+__global__ void k_rotate(Scalars *sc)
+{
+    const double alpha = sc->alpha, beta = sc->beta;
+    const double rho = sqrt(sc->rhobar * sc->rhobar + beta * beta);
+    if (rho == 0.0) { sc->rho_zero = 1; sc->t1 = 0.0; sc->t2 = 0.0; return; }
+    const double rho_inv = 1.0 / rho;
+    const double c = sc->rhobar * rho_inv;
+    const double s = beta * rho_inv;
+    const double theta = s * alpha;
+    sc->rhobar = -c * alpha;
+    const double phi = c * sc->phibar;
+    sc->phibar = s * sc->phibar;
+    sc->t1 = phi * rho_inv;
+    sc->t2 = -theta * rho_inv;
+    sc->r = sc->phibar / sc->b1;
+}
+
+// v *= 1/alpha (normalize) ; x = t1*w + x ; w = t2*w + v ; soft threshold            (lsqr_solver2.F90:241, :269-274)
+__global__ void k_update_xw(double *__restrict__ v, double *__restrict__ w, double *__restrict__ x, int64_t n,
+                            const Scalars *sc, double inv_alpha_known, double gamma)
+{
+    (void)inv_alpha_known;
+    const double t1 = sc->t1, t2 = sc->t2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double wi = w[i];
+        double xi = t1 * wi + x[i];
+        w[i] = t2 * wi + v[i];
+        if (gamma != 0.0) {                                    // :478-494
+            if (fabs(xi) <= gamma) xi = 0.0;
+            else if (xi <= -gamma) xi = xi + gamma;
+            else if (xi >= gamma) xi = xi - gamma;
+        }
+        x[i] = xi;
+    }
+}
+
+__global__ void k_copy(double *__restrict__ dst, const double *__restrict__ src, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// red[block] = partial sum (sx - b0)^2                                                 (lsqr_solver2.F90:183)
+__global__ void k_misfit(const double *__restrict__ sx, const double *__restrict__ b0, int64_t n, double *__restrict__ red)
+{
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double d = sx[i] - b0[i];
+        s = fma(d, d, s);
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0) red[blockIdx.x] = s;
+}
+
+static inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(RED_BLOCKS, (n + RED_THREADS - 1) / RED_THREADS)); }
+
+#define LAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(RED_THREADS), 0, s, __VA_ARGS__)
+
+static int allreduce(tfx_ctx *ctx, double *buf, int64_t n)
+{
+    if (ctx->nranks <= 1 || !ctx->allreduce) return 0;
+    int rc = ctx->allreduce(ctx->allreduce_user, buf, n, (void *)ctx->stream);
+    if (rc != 0) return fail(TFX_E_COMM, "all-reduce hook failed (%d)", rc);
+    return 0;
+}
+
+static int read_scalars(tfx_ctx *ctx, LsqrState *L)
+{
+    TFX_HIP(hipMemcpyAsync(L->h_sc, L->sc.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
+    TFX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ||u||: sum over u_data (replicated) + all-reduced local ||u_cons||^2 which sits in u[nrows]
+static int norm_u(tfx_ctx *ctx, LsqrState *L)
+{
+    hipStream_t s = ctx->stream;
+    const int g = grid_for(L->nrows);
+    LAUNCH(k_sumsq, g, L->u.p, L->nrows, L->red.p);
+    LAUNCH(k_final_sum, 1, L->red.p, g, &L->sc.p->sum_u);
+    LAUNCH(k_beta, 1, L->sc.p, L->u.p + L->nrows);
+    TFX_HIP(hipGetLastError());
+    return 0;
+}
+
+static int scale_u(tfx_ctx *ctx, LsqrState *L)
+{
+    hipStream_t s = ctx->stream;
+    LAUNCH(k_scale, grid_for(L->nrows), L->u.p, L->nrows, &L->sc.p->t1, 0);
+    if (L->nblocks > 0) LAUNCH(k_scale, grid_for((int64_t)L->nblocks * L->ncols), L->uc.p, (int64_t)L->nblocks * L->ncols, &L->sc.p->t1, 0);
+    TFX_HIP(hipGetLastError());
+    return 0;
+}
+
+// v (+)= S^T u_data + C^T u_cons ; alpha = ||v|| ; v /= alpha
+static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L)
+{
+    hipStream_t s = ctx->stream;
+    TFX_TRY(spmtv_dev(ctx, L->u.p, L->v.p, 1));
+    const int g = grid_for(L->ncols);
+    LAUNCH(k_cons_adjoint, g, L->v.p, L->diag.p, L->uc.p, L->ncols, L->nblocks, L->red.p);
+    LAUNCH(k_final_sum, 1, L->red.p, g, &L->sc.p->sum_v);
+    TFX_HIP(hipGetLastError());
+    TFX_TRY(allreduce(ctx, &L->sc.p->sum_v, 1));
+    LAUNCH(k_alpha, 1, L->sc.p);
+    LAUNCH(k_scale, g, L->v.p, L->ncols, &L->sc.p->t2, 0);
+    TFX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lsqr_free(tfx_ctx *ctx)
+{
+    if (ctx && ctx->lsqr) {
+        if (ctx->lsqr->h_sc) (void)hipHostFree(ctx->lsqr->h_sc);
+        delete ctx->lsqr;
+        ctx->lsqr = nullptr;
+    }
+    return 0;
+}
+
+}  // namespace tfx
+
+using namespace tfx;
+
+extern "C" {
+
+int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit, const double *b_data, int nblocks,
+                   const float *const *diag, const double *const *rhs_blocks)
+{
+    if (!ctx || !b_data) return fail(TFX_E_ARG, "tfx_lsqr_begin: null argument");
+    TiledMatrix &m = ctx->mat;
+    if (!m.valid) return fail(TFX_E_STATE, "tfx_lsqr_begin: no matrix");
+    if (nblocks < 0 || (nblocks > 0 && (!diag || !rhs_blocks))) return fail(TFX_E_ARG, "bad constraint blocks");
+    TFX_HIP(hipSetDevice(ctx->device));
+    if (!ctx->lsqr) {
+        ctx->lsqr = new LsqrState();
+        TFX_HIP(hipHostMalloc((void **)&ctx->lsqr->h_sc, sizeof(Scalars), hipHostMallocDefault));
+    }
+    LsqrState *L = ctx->lsqr;
+    hipStream_t s = ctx->stream;
+    L->nrows = m.nrows;
+    L->ncols = m.ncols;
+    L->nblocks = nblocks;
+    L->rmin = rmin;
+    L->gamma = gamma;
+    L->target_misfit = target_misfit;
+    L->iter = 0;
+    L->r = 1.0;
+    L->active = true;
+    L->exact = false;
+    L->finished = false;
+    const int64_t nc = L->ncols, nr = L->nrows;
+    TFX_TRY(L->u.ensure((size_t)nr + 1));
+    TFX_TRY(L->v.ensure((size_t)nc));
+    TFX_TRY(L->w.ensure((size_t)nc));
+    TFX_TRY(L->x.ensure((size_t)nc));
+    TFX_TRY(L->uc.ensure((size_t)std::max<int64_t>(1, nblocks * nc)));
+    TFX_TRY(L->diag.ensure((size_t)std::max<int64_t>(1, nblocks * nc)));
+    TFX_TRY(L->red.ensure(RED_BLOCKS));
+    TFX_TRY(L->sc.ensure(1));
+    TFX_HIP(hipMemsetAsync(L->sc.p, 0, sizeof(Scalars), s));
+    TFX_HIP(hipMemsetAsync(L->x.p, 0, (size_t)nc * sizeof(double), s));                  // :120
+    TFX_HIP(hipMemsetAsync(L->v.p, 0, (size_t)nc * sizeof(double), s));
+    TFX_HIP(hipMemcpyAsync(L->u.p, b_data, (size_t)nr * sizeof(double), hipMemcpyDefault, s));
+    for (int b = 0; b < nblocks; ++b) {
+        if (!diag[b] || !rhs_blocks[b]) return fail(TFX_E_ARG, "null constraint block %d", b);
+        TFX_HIP(hipMemcpyAsync(L->diag.p + (size_t)b * nc, diag[b], (size_t)nc * sizeof(float), hipMemcpyDefault, s));
+        TFX_HIP(hipMemcpyAsync(L->uc.p + (size_t)b * nc, rhs_blocks[b], (size_t)nc * sizeof(double), hipMemcpyDefault, s));
+    }
+    if (target_misfit > 0.0) {                                                            // :98-106
+        TFX_TRY(L->b0.ensure((size_t)nr));
+        TFX_TRY(L->sx.ensure((size_t)nr));
+        TFX_HIP(hipMemcpyAsync(L->b0.p, L->u.p, (size_t)nr * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    // ||u_cons,loc||^2 -> u[nrows], summed over ranks
+    {
+        const int64_t n = (int64_t)nblocks * nc;
+        const int g = grid_for(std::max<int64_t>(1, n));
+        LAUNCH(k_sumsq, g, L->uc.p, n, L->red.p);
+        LAUNCH(k_final_sum, 1, L->red.p, g, L->u.p + nr);
+        TFX_HIP(hipGetLastError());
+        TFX_TRY(allreduce(ctx, L->u.p + nr, 1));
+    }
+    TFX_TRY(norm_u(ctx, L));                                                             // :123-129
+    TFX_TRY(read_scalars(ctx, L));
+    if (L->h_sc->beta == 0.0) {                                                           // |b| = 0: the model is exact
+        L->exact = true;
+        L->finished = true;
+        L->r = 0.0;
+        return 0;
+    }
+    TFX_TRY(scale_u(ctx, L));
+    TFX_TRY(adjoint_and_alpha(ctx, L));                                                  // :137-150
+    LAUNCH(k_init_scalars, 1, L->sc.p);                                                  // :134, :155-156
+    LAUNCH(k_copy, grid_for(nc), L->w.p, L->v.p, nc);                                    // :157
+    TFX_HIP(hipGetLastError());
+    TFX_TRY(read_scalars(ctx, L));
+    if (L->h_sc->v_zero) return fail(TFX_E_NUMERIC, "Could not normalize initial v, zero denominator!");
+    return 0;
+}
+
+int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
+{
+    if (!ctx || !ctx->lsqr || !ctx->lsqr->active) return fail(TFX_E_STATE, "tfx_lsqr_iterate: call tfx_lsqr_begin first");
+    LsqrState *L = ctx->lsqr;
+    hipStream_t s = ctx->stream;
+    TFX_HIP(hipSetDevice(ctx->device));
+    const int64_t nc = L->ncols, nr = L->nrows;
+    int done = 0;
+    while (done < k && !L->finished && L->r > L->rmin) {                                  // :163
+        if (L->target_misfit > 0.0) {                                                     // :168-189
+            TFX_TRY(spmv_dev(ctx, L->x.p, L->sx.p, 0));
+            TFX_TRY(allreduce(ctx, L->sx.p, nr));
+            const int g = grid_for(nr);
+            LAUNCH(k_misfit, g, L->sx.p, L->b0.p, nr, L->red.p);
+            LAUNCH(k_final_sum, 1, L->red.p, g, &L->sc.p->misfit_ss);
+            TFX_TRY(read_scalars(ctx, L));
+            if (std::sqrt(L->h_sc->misfit_ss / (double)nr) <= L->target_misfit) { L->finished = true; break; }
+        }
+        // u = -alpha u (rank 0) | 0 (others), then u += S_loc v                           :194-209
+        LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
+        TFX_TRY(spmv_dev(ctx, L->v.p, L->u.p, 1));
+        {                                                                                 // :211 (constraint rows, local)
+            const int g = grid_for(nc);
+            LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p);
+            LAUNCH(k_final_sum, 1, L->red.p, g, L->u.p + nr);
+        }
+        TFX_HIP(hipGetLastError());
+        TFX_TRY(allreduce(ctx, L->u.p, nr + 1));                                          // :214
+        TFX_TRY(norm_u(ctx, L));                                                          // :218
+        TFX_TRY(scale_u(ctx, L));
+        LAUNCH(k_scale, grid_for(nc), L->v.p, nc, &L->sc.p->beta, 1);                     // :225  v = -beta v
+        TFX_TRY(adjoint_and_alpha(ctx, L));                                               // :228-241
+        LAUNCH(k_rotate, 1, L->sc.p);                                                     // :248-266
+        LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, 0.0, L->gamma);   // :269-274
+        TFX_HIP(hipGetLastError());
+        TFX_TRY(read_scalars(ctx, L));
+        if (L->h_sc->rho_zero) { L->finished = true; break; }                             // :251-254 (x, w untouched: t1 = t2 = 0 ... see note)
+        L->r = L->h_sc->r;
+        L->iter += 1;
+        done += 1;
+        if (std::fabs(L->h_sc->rhobar) < 1.e-30) { L->finished = true; break; }           // :286-289
+    }
+    if (done_out) *done_out = done;
+    if (r_out) *r_out = L->r;
+    return 0;
+}
+
+int tfx_lsqr_end(tfx_ctx *ctx, double *x_out)
+{
+    if (!ctx || !ctx->lsqr || !ctx->lsqr->active) return fail(TFX_E_STATE, "tfx_lsqr_end: no solve in progress");
+    LsqrState *L = ctx->lsqr;
+    if (x_out) TFX_TRY(copy_any(x_out, L->x.p, (size_t)L->ncols * sizeof(double), ctx->stream));
+    L->active = false;
+    return 0;
+}
+
+int tfx_lsqr_solve(tfx_ctx *ctx, int niter, double rmin, double gamma, double target_misfit, const double *b_data,
+                   int nblocks, const float *const *diag, const double *const *rhs_blocks, double *x_out, int *iters_out,
+                   double *r_out)
+{
+    TFX_TRY(tfx_lsqr_begin(ctx, rmin, gamma, target_misfit, b_data, nblocks, diag, rhs_blocks));
+    int done = 0;
+    double r = 1.0;
+    TFX_TRY(tfx_lsqr_iterate(ctx, niter, &done, &r));
+    if (iters_out) *iters_out = done;
+    if (r_out) *r_out = r;
+    return tfx_lsqr_end(ctx, x_out);
+}
+
+int tfx_calc_data(tfx_ctx *ctx, const double *xw_local, double problem_weight, const double *data_weight,
+                  double *data_calc)
+{
+    if (!ctx || !xw_local || !data_calc) return fail(TFX_E_ARG, "tfx_calc_data: null argument");
+    TiledMatrix &m = ctx->mat;
+    if (!m.valid) return fail(TFX_E_STATE, "tfx_calc_data: no matrix");
+    if (problem_weight == 0.0) return fail(TFX_E_NUMERIC, "Zero problem weight in model_calculate_data!");
+    TFX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DBuf<double> dx, db;
+    TFX_TRY(dx.alloc((size_t)m.ncols));
+    TFX_TRY(db.alloc((size_t)m.nrows));
+    TFX_HIP(hipMemcpyAsync(dx.p, xw_local, (size_t)m.ncols * sizeof(double), hipMemcpyDefault, s));
+    TFX_TRY(spmv_dev(ctx, dx.p, db.p, 0));                                                // model.F90:285-286
+    if (ctx->nranks > 1) {                                                                // model.F90:290
+        int rc = ctx->allreduce(ctx->allreduce_user, db.p, m.nrows, (void *)s);
+        if (rc != 0) return fail(TFX_E_COMM, "all-reduce hook failed (%d)", rc);
+    }
+    std::vector<double> h((size_t)m.nrows);
+    TFX_HIP(hipMemcpyAsync(h.data(), db.p, (size_t)m.nrows * sizeof(double), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipStreamSynchronize(s));
+    std::vector<double> dw;
+    if (data_weight) {
+        dw.resize((size_t)m.nrows);
+        TFX_TRY(copy_any(dw.data(), data_weight, (size_t)m.nrows * sizeof(double), s));
+    }
+    for (int64_t i = 0; i < m.nrows; ++i) {                                               // model.F90:295-302
+        double d = h[(size_t)i] / problem_weight;
+        if (data_weight) d = d / dw[(size_t)i];
+        h[(size_t)i] = d;
+    }
+    TFX_TRY(copy_any(data_calc, h.data(), (size_t)m.nrows * sizeof(double), s));
+    return 0;
+}
+
+}  // extern "C"

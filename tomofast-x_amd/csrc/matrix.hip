@@ -1,0 +1,627 @@
+// matrix.hip - device-resident sensitivity matrix in the column-tiled compressed layout, and the two products
+// that dominate an LSQR iteration:
+//   forward  b (+)= S x    (t_sparse_matrix%add_mult_vector,       src/inversion/sparse_matrix.f90:316-329)
+//   adjoint  b (+)= S^T x  (t_sparse_matrix%add_trans_mult_vector, src/inversion/sparse_matrix.f90:391-405)
+//
+// Layout (DESIGN.md "Data layout in HBM").  The reference keeps CSR with 4-byte values + 4-byte columns
+// (8 B per non-zero).  Here S is cut into tiles of (RB <= 2048 rows) x (TC <= 16384 columns).  Inside a tile the
+// entries are in (row, column) order and stored as two streams:
+//     codes[]  uint16 : bit 15 = "first entry of a new row inside this tile", bits 0-13 = column inside the tile
+//     vals[]   float  : the value exactly as the reference stores it
+// i.e. 6 B per non-zero.  A row that is empty inside a tile but lies between two non-empty rows carries one marker
+// entry (ROWSTART, value 0).  A tile is padded to a multiple of 512 entries (one chunk = 64 lanes x 8 entries, so a
+// lane fetches its 8 codes with one 16-byte load and its 8 values with two).  chunk_row0[] gives each chunk the
+// local row of the entry preceding it, so any wave can start at any chunk.
+//
+// Both products stream every tile once, coalesced, and keep the vector side of the product in LDS:
+//   forward: the x tile (TC doubles, 128 KB) is staged in LDS, row sums are accumulated in LDS (RB doubles);
+//   adjoint: the u rows of the block are staged in LDS, the column sums live in LDS (TC doubles) and are
+//            written once.
+// Row membership is recovered from the ROWSTART bits with ballot + mbcnt prefix counts; short row segments are
+// summed inside a lane, the segment tails are merged across lanes with one segmented wave reduction per chunk.
+#include "common.h"
+#include <algorithm>
+#include <numeric>
+
+namespace tfx {
+
+thread_local std::string g_last_error;
+
+size_t TiledMatrix::device_bytes() const
+{
+    return codes.bytes() + vals.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
+           fwd_order.bytes() + adj_order.bytes() + fwd_partial.bytes() + adj_partial.bytes() + adj_nslots.bytes() +
+           adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes();
+}
+
+int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return 0;
+    TFX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s));
+    TFX_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+// LDS index swizzle: a lane reads 8 consecutive entries, so for dense column runs lanes L and L+4 would hit the
+// same bank pair (stride 8 doubles).  XOR-ing bits 3..5 into bits 0..2 makes 32 consecutive lanes conflict-free
+// and is a bijection inside every aligned group of 64 indices (TC is a multiple of 64).
+__device__ __forceinline__ int swz(int i) { return i ^ ((i >> 3) & 7); }
+
+// ------------------------------------------------------------------------------------------------------------
+// Conversion: row block in ELL form (cols ascending, 0-based local) -> tiles
+// ------------------------------------------------------------------------------------------------------------
+
+// pos[r][t] = index of the first entry of row r with column >= t*TC  (t = 0..ntc), one wave per row.
+__global__ void k_tile_pos(const int32_t *__restrict__ cols, const int32_t *__restrict__ nel,
+                           const int64_t *__restrict__ rowoff, int nr, int ntc, int TC, int32_t *__restrict__ pos)
+{
+    int r = blockIdx.x;
+    if (r >= nr) return;
+    const int32_t *c = cols + rowoff[r];
+    int n = nel[r];
+    for (int t = threadIdx.x; t <= ntc; t += blockDim.x) {
+        int64_t key = (int64_t)t * TC;
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if ((int64_t)c[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+        pos[(int64_t)r * (ntc + 1) + t] = lo;
+    }
+}
+
+// One block per column tile: segment lengths (with empty-row markers) and their exclusive scan over the rows.
+// segoff[t][r] (r = 0..nr), first/last non-empty row.
+__global__ void k_tile_scan(const int32_t *__restrict__ pos, int nr, int ntc, int32_t *__restrict__ segoff,
+                            int32_t *__restrict__ first_ne, int32_t *__restrict__ last_ne)
+{
+    extern __shared__ int32_t sm[];     // nr + 1 ints + 2
+    int t = blockIdx.x;
+    __shared__ int s_first, s_last;
+    if (threadIdx.x == 0) { s_first = 0x7fffffff; s_last = -1; }
+    __syncthreads();
+    for (int r = threadIdx.x; r < nr; r += blockDim.x) {
+        int cnt = pos[(int64_t)r * (ntc + 1) + t + 1] - pos[(int64_t)r * (ntc + 1) + t];
+        sm[r] = cnt;
+        if (cnt > 0) { atomicMin(&s_first, r); atomicMax(&s_last, r); }
+    }
+    __syncthreads();
+    int f = s_first, l = s_last;
+    // serial-per-thread blocked scan (nr <= 2048, blockDim = 256 -> 8 per thread)
+    int per = (nr + blockDim.x - 1) / blockDim.x;
+    int b = threadIdx.x * per, e = min(b + per, nr);
+    int sum = 0;
+    for (int r = b; r < e; ++r) {
+        int len = sm[r];
+        if (len == 0 && r > f && r < l) len = 1;      // marker for an empty row between non-empty ones
+        sm[r] = len;
+        sum += len;
+    }
+    __shared__ int part[1024];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < (int)blockDim.x; ++i) { int v = part[i]; part[i] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    int32_t *so = segoff + (int64_t)t * (nr + 1);
+    for (int r = b; r < e; ++r) { so[r] = run; run += sm[r]; }
+    if (e == nr && b < nr) so[nr] = run;
+    if (nr == 0 && threadIdx.x == 0) so[0] = 0;
+    if (threadIdx.x == 0) { first_ne[t] = (l >= 0) ? f : -1; last_ne[t] = l; }
+}
+
+// Scatter the entries of one row block into their tiles.  grid = (ceil(maxlen/256), nr).
+__global__ void k_tile_scatter(const int32_t *__restrict__ cols, const float *__restrict__ vals,
+                               const int32_t *__restrict__ nel, const int64_t *__restrict__ rowoff, int ntc, int TC, int nr,
+                               const int32_t *__restrict__ pos, const int32_t *__restrict__ segoff,
+                               const int64_t *__restrict__ tile_off, uint16_t *__restrict__ codes,
+                               float *__restrict__ ovals)
+{
+    int r = blockIdx.y;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nel[r]) return;
+    const int64_t src = rowoff[r] + j;
+    int32_t c = cols[src];
+    int t = c / TC;
+    int p0 = pos[(int64_t)r * (ntc + 1) + t];
+    int64_t dst = tile_off[t] + segoff[(int64_t)t * (nr + 1) + r] + (j - p0);
+    codes[dst] = (uint16_t)((c - t * TC) | (j == p0 ? ROWSTART : 0));
+    ovals[dst] = vals[src];
+}
+
+// Markers for empty rows strictly between the first and last non-empty row of a tile.  grid = (ntc), block 256.
+__global__ void k_tile_markers(const int32_t *__restrict__ pos, int nr, int ntc, const int32_t *__restrict__ segoff,
+                               const int32_t *__restrict__ first_ne, const int32_t *__restrict__ last_ne,
+                               const int64_t *__restrict__ tile_off, uint16_t *__restrict__ codes,
+                               float *__restrict__ ovals)
+{
+    int t = blockIdx.x;
+    int f = first_ne[t], l = last_ne[t];
+    if (f < 0) return;
+    for (int r = f + 1 + threadIdx.x; r < l; r += blockDim.x) {
+        int cnt = pos[(int64_t)r * (ntc + 1) + t + 1] - pos[(int64_t)r * (ntc + 1) + t];
+        if (cnt == 0) {
+            int64_t dst = tile_off[t] + segoff[(int64_t)t * (nr + 1) + r];
+            codes[dst] = ROWSTART;
+            ovals[dst] = 0.0f;
+        }
+    }
+}
+
+// chunk_row0[chunk] = local row of the entry just before the chunk (first chunk: first_ne - 1).
+__global__ void k_chunk_row0(int nr, const int32_t *__restrict__ segoff, const int32_t *__restrict__ first_ne,
+                             const int64_t *__restrict__ tile_off, const int32_t *__restrict__ tile_nchunks,
+                             int32_t *__restrict__ chunk_row0)
+{
+    int t = blockIdx.x;
+    int nch = tile_nchunks[t];
+    if (nch == 0) return;
+    const int32_t *so = segoff + (int64_t)t * (nr + 1);
+    int total = so[nr];
+    int64_t cbase = tile_off[t] / CHUNK;
+    for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+        int row;
+        if (c == 0) row = first_ne[t] - 1;
+        else {
+            int q = c * CHUNK - 1;              // entry before the chunk
+            if (q >= total) q = total - 1;      // padding region: stay on the last row
+            // largest r with so[r] <= q and segment r non-empty: upper_bound(q) - 1
+            int lo = 0, hi = nr;                // so[0..nr]
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (so[mid + 1] <= q) lo = mid + 1;
+                else hi = mid;
+            }
+            row = lo;
+        }
+        chunk_row0[cbase + c] = row;
+    }
+}
+
+int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
+{
+    TiledMatrix &m = ctx->mat;
+    m.valid = false;
+    m.nrows = nrows;
+    m.ncols = ncols;
+    m.nnz = 0;
+    if (nrows <= 0 || ncols <= 0) return fail(TFX_E_ARG, "matrix_begin: empty matrix %lld x %lld", (long long)nrows, (long long)ncols);
+    m.TC = (int)std::min<int64_t>(TC_MAX, (ncols + 63) / 64 * 64);
+    m.RB = (int)std::min<int64_t>(RB_MAX, (nrows + 63) / 64 * 64);
+    m.ntc = (int)((ncols + m.TC - 1) / m.TC);
+    m.nrb = (int)((nrows + m.RB - 1) / m.RB);
+    int64_t markers = std::min<int64_t>(nnz_upper, (int64_t)nrows * m.ntc);
+    int64_t cap = nnz_upper + markers + (int64_t)m.nrb * m.ntc * CHUNK + CHUNK;
+    cap = (cap + CHUNK - 1) / CHUNK * CHUNK;
+    TFX_TRY(m.codes.alloc((size_t)cap));
+    TFX_TRY(m.vals.alloc((size_t)cap));
+    TFX_TRY(m.chunk_row0.alloc((size_t)(cap / CHUNK)));
+    m.n_entries = 0;
+    m.h_tiles.clear();
+    return 0;
+}
+
+// Appends the tiles of one row block.  Row r of the block has d_nel[r] entries starting at d_cols/d_vals +
+// d_rowoff[r] (columns ascending, 0-based local); maxlen >= max d_nel.  row_begin must be a multiple of RB, nr <= RB.
+int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int32_t *d_cols, const float *d_vals,
+                       const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen)
+{
+    TiledMatrix &m = ctx->mat;
+    hipStream_t s = ctx->stream;
+    int nr = (int)nr64;
+    if (row_begin % m.RB != 0 || nr > m.RB || nr <= 0)
+        return fail(TFX_E_ARG, "matrix_append_rows: rows [%lld, +%d) not aligned to row block %d", (long long)row_begin, nr, m.RB);
+    int rb = (int)(row_begin / m.RB);
+    int ntc = m.ntc;
+    DBuf<int32_t> pos, segoff, first_ne, last_ne, tile_nch;
+    DBuf<int64_t> tile_off;
+    TFX_TRY(pos.alloc((size_t)nr * (ntc + 1)));
+    TFX_TRY(segoff.alloc((size_t)ntc * (nr + 1)));
+    TFX_TRY(first_ne.alloc(ntc));
+    TFX_TRY(last_ne.alloc(ntc));
+    TFX_TRY(tile_nch.alloc(ntc));
+    TFX_TRY(tile_off.alloc(ntc));
+    hipLaunchKernelGGL(k_tile_pos, dim3(nr), dim3(256), 0, s, d_cols, d_nel, d_rowoff, nr, ntc, m.TC, pos.p);
+    hipLaunchKernelGGL(k_tile_scan, dim3(ntc), dim3(256), (size_t)(nr + 1) * sizeof(int32_t), s, pos.p, nr, ntc,
+                       segoff.p, first_ne.p, last_ne.p);
+    TFX_HIP(hipGetLastError());
+    // tile totals -> host
+    std::vector<int32_t> h_segoff_last(ntc), h_first(ntc);
+    TFX_HIP(hipMemcpy2DAsync(h_segoff_last.data(), sizeof(int32_t), segoff.p + nr, (size_t)(nr + 1) * sizeof(int32_t),
+                             sizeof(int32_t), ntc, hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipStreamSynchronize(s));
+    std::vector<int64_t> h_off(ntc);
+    std::vector<int32_t> h_nch(ntc);
+    int64_t cur = m.n_entries;
+    int64_t nnz_block = 0;
+    for (int t = 0; t < ntc; ++t) {
+        int32_t cnt = h_segoff_last[t];
+        int32_t nch = (cnt + CHUNK - 1) / CHUNK;
+        h_off[t] = cur;
+        h_nch[t] = nch;
+        if (cnt > 0) {
+            TileMeta tm;
+            tm.off = cur;
+            tm.nchunks = nch;
+            tm.cnt = cnt;
+            tm.t = t;
+            tm.rb = rb;
+            m.h_tiles.push_back(tm);
+        }
+        cur += (int64_t)nch * CHUNK;
+        nnz_block += cnt;
+    }
+    if ((size_t)cur > m.codes.n)
+        return fail(TFX_E_STATE, "tiled matrix capacity exceeded (%lld > %zu entries)", (long long)cur, m.codes.n);
+    // zero the destination range (padding: code 0 / value 0)
+    TFX_HIP(hipMemsetAsync(m.codes.p + m.n_entries, 0, (size_t)(cur - m.n_entries) * sizeof(uint16_t), s));
+    TFX_HIP(hipMemsetAsync(m.vals.p + m.n_entries, 0, (size_t)(cur - m.n_entries) * sizeof(float), s));
+    TFX_HIP(hipMemcpyAsync(tile_off.p, h_off.data(), ntc * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    TFX_HIP(hipMemcpyAsync(tile_nch.p, h_nch.data(), ntc * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (maxlen > 0)
+        hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((maxlen + 255) / 256), nr), dim3(256), 0, s, d_cols, d_vals,
+                           d_nel, d_rowoff, ntc, m.TC, nr, pos.p, segoff.p, tile_off.p, m.codes.p, m.vals.p);
+    hipLaunchKernelGGL(k_tile_markers, dim3(ntc), dim3(256), 0, s, pos.p, nr, ntc, segoff.p, first_ne.p, last_ne.p,
+                       tile_off.p, m.codes.p, m.vals.p);
+    hipLaunchKernelGGL(k_chunk_row0, dim3(ntc), dim3(256), 0, s, nr, segoff.p, first_ne.p, tile_off.p, tile_nch.p,
+                       m.chunk_row0.p);
+    TFX_HIP(hipGetLastError());
+    TFX_HIP(hipStreamSynchronize(s));    // temporaries are freed on return
+    m.n_entries = cur;
+    (void)nnz_block;
+    return 0;
+}
+
+// Cuts the tile list into work items.  Forward: every item owns one partial-sum tile (pidx) of RB doubles, the
+// items of row block rb are pbase[rb] .. pbase[rb]+nslots[rb]-1.  Adjoint: slot 0 of a column tile adds straight
+// into y, slots >= 1 own partial tiles pbase[t] .. pbase[t]+nslots[t]-2 of TC doubles.
+static void build_items(const std::vector<TileMeta> &tiles, bool forward, int64_t target, std::vector<WorkItem> &items,
+                        std::vector<int32_t> &order, int &npartial, std::vector<int32_t> &nslots,
+                        std::vector<int32_t> &pbase, int nkeys)
+{
+    std::vector<int32_t> idx(tiles.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) {
+        int ka = forward ? tiles[a].rb : tiles[a].t, kb = forward ? tiles[b].rb : tiles[b].t;
+        if (ka != kb) return ka < kb;
+        int sa = forward ? tiles[a].t : tiles[a].rb, sb = forward ? tiles[b].t : tiles[b].rb;
+        return sa < sb;
+    });
+    order = idx;
+    items.clear();
+    nslots.assign(nkeys, 0);
+    pbase.assign(nkeys, 0);
+    npartial = 0;
+    std::vector<int64_t> item_sz;
+    size_t i = 0;
+    while (i < idx.size()) {
+        int key = forward ? tiles[idx[i]].rb : tiles[idx[i]].t;
+        size_t j = i;
+        while (j < idx.size() && (forward ? tiles[idx[j]].rb : tiles[idx[j]].t) == key) ++j;
+        // split [i, j) into runs of about `target` entries
+        int slot = 0;
+        size_t b = i;
+        pbase[key] = npartial;
+        while (b < j) {
+            int64_t acc = 0;
+            size_t e = b;
+            while (e < j && (acc == 0 || acc + (int64_t)tiles[idx[e]].nchunks * CHUNK <= target)) {
+                acc += (int64_t)tiles[idx[e]].nchunks * CHUNK;
+                ++e;
+            }
+            WorkItem w;
+            w.begin = (int32_t)b;
+            w.end = (int32_t)e;
+            w.key = key;
+            w.slot = slot;
+            w.pidx = forward ? npartial++ : (slot == 0 ? -1 : npartial++);
+            ++slot;
+            items.push_back(w);
+            item_sz.push_back(acc);
+            b = e;
+        }
+        nslots[key] = slot;
+        i = j;
+    }
+    // largest first: the dispatcher hands out workgroups in order, so this approximates LPT scheduling
+    std::vector<int32_t> perm(items.size());
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return item_sz[a] > item_sz[b]; });
+    std::vector<WorkItem> sorted(items.size());
+    for (size_t k = 0; k < perm.size(); ++k) sorted[k] = items[perm[k]];
+    items.swap(sorted);
+}
+
+int matrix_finish(tfx_ctx *ctx)
+{
+    TiledMatrix &m = ctx->mat;
+    hipStream_t s = ctx->stream;
+    int64_t real = 0;
+    for (auto &t : m.h_tiles) real += t.cnt;     // includes empty-row markers; exact nnz is set by the caller
+    TFX_TRY(m.tiles.alloc(std::max<size_t>(1, m.h_tiles.size())));
+    if (!m.h_tiles.empty())
+        TFX_HIP(hipMemcpyAsync(m.tiles.p, m.h_tiles.data(), m.h_tiles.size() * sizeof(TileMeta), hipMemcpyHostToDevice, s));
+    // about 8 work items per CU, but never finer than 16 chunks
+    int64_t target = std::max<int64_t>((int64_t)16 * CHUNK, m.n_entries / std::max(1, ctx->num_cu * 8));
+    std::vector<int32_t> fo, ao, fns, ans, fpb, apb;
+    int nfp = 0, nap = 0;
+    build_items(m.h_tiles, true, target, m.h_fwd, fo, nfp, fns, fpb, m.nrb);
+    build_items(m.h_tiles, false, target, m.h_adj, ao, nap, ans, apb, m.ntc);
+    TFX_TRY(m.fwd.alloc(std::max<size_t>(1, m.h_fwd.size())));
+    TFX_TRY(m.adj.alloc(std::max<size_t>(1, m.h_adj.size())));
+    TFX_TRY(m.fwd_order.alloc(std::max<size_t>(1, fo.size())));
+    TFX_TRY(m.adj_order.alloc(std::max<size_t>(1, ao.size())));
+    TFX_TRY(m.adj_nslots.alloc(std::max<size_t>(1, ans.size())));
+    TFX_TRY(m.adj_pbase.alloc(std::max<size_t>(1, apb.size())));
+    TFX_TRY(m.fwd_nslots.alloc(std::max<size_t>(1, fns.size())));
+    TFX_TRY(m.fwd_pbase.alloc(std::max<size_t>(1, fpb.size())));
+    if (!m.h_fwd.empty()) {
+        TFX_HIP(hipMemcpyAsync(m.fwd.p, m.h_fwd.data(), m.h_fwd.size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
+        TFX_HIP(hipMemcpyAsync(m.adj.p, m.h_adj.data(), m.h_adj.size() * sizeof(WorkItem), hipMemcpyHostToDevice, s));
+        TFX_HIP(hipMemcpyAsync(m.fwd_order.p, fo.data(), fo.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        TFX_HIP(hipMemcpyAsync(m.adj_order.p, ao.data(), ao.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    TFX_HIP(hipMemcpyAsync(m.adj_nslots.p, ans.data(), ans.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    TFX_HIP(hipMemcpyAsync(m.adj_pbase.p, apb.data(), apb.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    TFX_HIP(hipMemcpyAsync(m.fwd_nslots.p, fns.data(), fns.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    TFX_HIP(hipMemcpyAsync(m.fwd_pbase.p, fpb.data(), fpb.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    TFX_TRY(m.fwd_partial.alloc(std::max<size_t>(1, (size_t)nfp * m.RB)));
+    TFX_TRY(m.adj_partial.alloc(std::max<size_t>(1, (size_t)nap * m.TC)));
+    TFX_HIP(hipStreamSynchronize(s));
+    m.adj_has_partials = nap > 0;
+    m.nnz = real;
+    m.valid = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The two matrix kernels
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SPMV_THREADS = 1024;
+constexpr int SPMV_WAVES = SPMV_THREADS / 64;
+
+struct ChunkRegs {
+    uint32_t w[4];    // 8 codes
+    float v[8];
+};
+
+__device__ __forceinline__ void load_chunk(const uint16_t *__restrict__ codes, const float *__restrict__ vals,
+                                           int64_t base, ChunkRegs &c)
+{
+    const uint4 cw = *reinterpret_cast<const uint4 *>(codes + base);
+    const float4 a = *reinterpret_cast<const float4 *>(vals + base);
+    const float4 b = *reinterpret_cast<const float4 *>(vals + base + 4);
+    c.w[0] = cw.x; c.w[1] = cw.y; c.w[2] = cw.z; c.w[3] = cw.w;
+    c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w;
+    c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w;
+}
+
+__device__ __forceinline__ uint32_t code_of(const ChunkRegs &c, int k) { return (c.w[k >> 1] >> ((k & 1) * 16)) & 0xffffu; }
+
+// number of ROWSTART flags in all lanes below this one (all 8 entries of those lanes)
+__device__ __forceinline__ int flags_before_lane(const ChunkRegs &c, bool &any)
+{
+    int acc = 0;
+    unsigned long long all = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unsigned long long mk = __ballot((code_of(c, k) & ROWSTART) != 0);
+        all |= mk;
+        acc = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, acc));
+    }
+    any = all != 0;
+    return acc;
+}
+
+// forward: one workgroup = a run of tiles of one row block; partial[slot][row] = sum over the run.
+__global__ __launch_bounds__(SPMV_THREADS) void k_spmv_fwd(const WorkItem *__restrict__ items,
+                                                             const int32_t *__restrict__ order,
+                                                             const TileMeta *__restrict__ tiles,
+                                                             const uint16_t *__restrict__ codes,
+                                                             const float *__restrict__ vals,
+                                                             const int32_t *__restrict__ chunk_row0,
+                                                             const double *__restrict__ x, double *__restrict__ partial,
+                                                             int64_t ncols, int TC, int RB)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *xs = lds;          // TC
+    double *outs = lds + TC;   // RB
+    const WorkItem it = items[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < RB; i += SPMV_THREADS) outs[i] = 0.0;
+    for (int ti = it.begin; ti < it.end; ++ti) {
+        const TileMeta tm = tiles[order[ti]];
+        __syncthreads();
+        const int64_t col0 = (int64_t)tm.t * TC;
+        const int ncol = (int)min((int64_t)TC, ncols - col0);
+        for (int i = tid; i < TC; i += SPMV_THREADS) xs[swz(i)] = (i < ncol) ? x[col0 + i] : 0.0;
+        __syncthreads();
+        const int64_t cbase = tm.off / CHUNK;
+        for (int c = wave; c < tm.nchunks; c += SPMV_WAVES) {
+            ChunkRegs cr;
+            load_chunk(codes, vals, tm.off + (int64_t)c * CHUNK + lane * 8, cr);
+            int cur = chunk_row0[cbase + c];
+            bool any;
+            cur += flags_before_lane(cr, any);
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t code = code_of(cr, k);
+                if (code & ROWSTART) {
+                    if (cur >= 0 && acc != 0.0) atomicAdd(&outs[cur], acc);
+                    cur += 1;
+                    acc = 0.0;
+                }
+                acc = fma((double)cr.v[k], xs[swz((int)(code & COLMASK))], acc);
+            }
+            // merge the tails of lanes that end on the same row (equal rows are contiguous lanes)
+            double sum = acc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double o = __shfl_down(sum, d);
+                const int ocur = __shfl_down(cur, d);
+                if (lane + d < 64 && ocur == cur) sum += o;
+            }
+            const int pcur = __shfl_up(cur, 1);
+            if ((lane == 0 || pcur != cur) && cur >= 0 && sum != 0.0) atomicAdd(&outs[cur], sum);
+        }
+    }
+    __syncthreads();
+    double *dst = partial + (int64_t)it.pidx * RB;
+    for (int i = tid; i < RB; i += SPMV_THREADS) dst[i] = outs[i];
+}
+
+// b[row] = (add ? b[row] : 0) + sum over the partial tiles of the row's block (fixed order: deterministic)
+__global__ void k_fwd_reduce(const double *__restrict__ partial, const int32_t *__restrict__ nslots,
+                             const int32_t *__restrict__ pbase, int RB, int64_t nrows, double *__restrict__ b, int add)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const int rb = (int)(r / RB), lr = (int)(r - (int64_t)rb * RB);
+    const int ns = nslots[rb], p0 = pbase[rb];
+    double s = add ? b[r] : 0.0;
+    for (int k = 0; k < ns; ++k) s += partial[(int64_t)(p0 + k) * RB + lr];
+    b[r] = s;
+}
+
+// adjoint: one workgroup = a run of tiles of one column tile; slot 0 adds into y, the others write partials.
+__global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adj(const WorkItem *__restrict__ items,
+                                                             const int32_t *__restrict__ order,
+                                                             const TileMeta *__restrict__ tiles,
+                                                             const uint16_t *__restrict__ codes,
+                                                             const float *__restrict__ vals,
+                                                             const int32_t *__restrict__ chunk_row0,
+                                                             const double *__restrict__ u, double *__restrict__ y,
+                                                             double *__restrict__ partial, int64_t nrows, int64_t ncols,
+                                                             int TC, int RB)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *acc = lds;        // TC
+    double *us = lds + TC;    // RB
+    const WorkItem it = items[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < TC; i += SPMV_THREADS) acc[i] = 0.0;
+    for (int ti = it.begin; ti < it.end; ++ti) {
+        const TileMeta tm = tiles[order[ti]];
+        __syncthreads();
+        const int64_t row0 = (int64_t)tm.rb * RB;
+        const int nrow = (int)min((int64_t)RB, nrows - row0);
+        for (int i = tid; i < RB; i += SPMV_THREADS) us[i] = (i < nrow) ? u[row0 + i] : 0.0;
+        __syncthreads();
+        const int64_t cbase = tm.off / CHUNK;
+        for (int c = wave; c < tm.nchunks; c += SPMV_WAVES) {
+            ChunkRegs cr;
+            load_chunk(codes, vals, tm.off + (int64_t)c * CHUNK + lane * 8, cr);
+            int cur = chunk_row0[cbase + c];
+            bool any;
+            cur += flags_before_lane(cr, any);
+            double uval = us[max(cur, 0)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t code = code_of(cr, k);
+                if (code & ROWSTART) {
+                    cur += 1;
+                    uval = us[cur];
+                }
+                const float v = cr.v[k];
+                if (v != 0.0f) atomicAdd(&acc[swz((int)(code & COLMASK))], (double)v * uval);
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t col0 = (int64_t)it.key * TC;
+    const int ncol = (int)min((int64_t)TC, ncols - col0);
+    if (it.slot == 0) {
+        for (int i = tid; i < ncol; i += SPMV_THREADS) y[col0 + i] += acc[swz(i)];
+    } else {
+        double *dst = partial + (int64_t)it.pidx * TC;
+        for (int i = tid; i < TC; i += SPMV_THREADS) dst[i] = acc[swz(i)];
+    }
+}
+
+// y[col] += sum over the partial tiles (slots >= 1) of the column tile, fixed order
+__global__ void k_adj_reduce(const double *__restrict__ partial, const int32_t *__restrict__ nslots,
+                             const int32_t *__restrict__ pbase, int TC, int64_t ncols, double *__restrict__ y)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    const int t = (int)(c / TC), lc = (int)(c - (int64_t)t * TC);
+    const int ns = nslots[t];
+    if (ns <= 1) return;
+    const int p0 = pbase[t];
+    double s = y[c];
+    for (int k = 0; k < ns - 1; ++k) s += partial[(int64_t)(p0 + k) * TC + lc];
+    y[c] = s;
+}
+
+static int set_lds_limit(const void *fn, size_t bytes)
+{
+    TFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+static void prof_begin(tfx_ctx *ctx)
+{
+    if (ctx->profile) (void)hipEventRecord(ctx->pev0, ctx->stream);
+}
+static void prof_end(tfx_ctx *ctx, int which)
+{
+    if (!ctx->profile) return;
+    (void)hipEventRecord(ctx->pev1, ctx->stream);
+    (void)hipEventSynchronize(ctx->pev1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1);
+    ctx->prof_ms[which] += ms;
+    ctx->prof_n[which] += 1;
+}
+
+int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add)
+{
+    TiledMatrix &m = ctx->mat;
+    if (!m.valid) return fail(TFX_E_STATE, "spmv: no matrix");
+    hipStream_t s = ctx->stream;
+    const size_t lds = (size_t)(m.TC + m.RB) * sizeof(double);
+    if (!m.h_fwd.empty()) {
+        static size_t lds_set = 0;
+        if (lds > lds_set) { TFX_TRY(set_lds_limit((const void *)k_spmv_fwd, lds)); lds_set = lds; }
+        prof_begin(ctx);
+        hipLaunchKernelGGL(k_spmv_fwd, dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, m.fwd.p, m.fwd_order.p,
+                           m.tiles.p, m.codes.p, m.vals.p, m.chunk_row0.p, d_x, m.fwd_partial.p, m.ncols, m.TC, m.RB);
+        prof_end(ctx, 0);
+        TFX_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_fwd_reduce, dim3((unsigned)((m.nrows + 255) / 256)), dim3(256), 0, s, m.fwd_partial.p,
+                       m.fwd_nslots.p, m.fwd_pbase.p, m.RB, m.nrows, d_b, add);
+    TFX_HIP(hipGetLastError());
+    return 0;
+}
+
+int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add)
+{
+    TiledMatrix &m = ctx->mat;
+    if (!m.valid) return fail(TFX_E_STATE, "spmtv: no matrix");
+    hipStream_t s = ctx->stream;
+    const size_t lds = (size_t)(m.TC + m.RB) * sizeof(double);
+    if (!add) TFX_HIP(hipMemsetAsync(d_b, 0, (size_t)m.ncols * sizeof(double), s));
+    if (!m.h_adj.empty()) {
+        static size_t lds_set = 0;
+        if (lds > lds_set) { TFX_TRY(set_lds_limit((const void *)k_spmv_adj, lds)); lds_set = lds; }
+        prof_begin(ctx);
+        hipLaunchKernelGGL(k_spmv_adj, dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, m.adj.p, m.adj_order.p,
+                           m.tiles.p, m.codes.p, m.vals.p, m.chunk_row0.p, d_x, d_b, m.adj_partial.p, m.nrows, m.ncols,
+                           m.TC, m.RB);
+        prof_end(ctx, 1);
+        TFX_HIP(hipGetLastError());
+        if (m.adj_has_partials)
+            hipLaunchKernelGGL(k_adj_reduce, dim3((unsigned)((m.ncols + 255) / 256)), dim3(256), 0, s, m.adj_partial.p,
+                               m.adj_nslots.p, m.adj_pbase.p, m.TC, m.ncols, d_b);
+        TFX_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace tfx

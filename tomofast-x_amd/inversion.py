@@ -1,0 +1,80 @@
+"""Major inversion loop on top of the HIP path - the slice of solve_problem_joint_gravmag
+(src/problem_joint_gravmag.F90:65-613) and joint_inversion_solve (src/inversion/joint_inverse_problem.F90:393-573)
+that drives the hot path, for one gravity problem with WAVELET_DOMAIN = true (or compression off):
+
+  residuals (problem_joint_gravmag.F90:666-675) -> right-hand side + damping / ADMM diagonal blocks
+  (src/inversion/damping.F90:97-234, src/inversion/admm_method.F90:70-134) -> lsqr_solve_sensit ->
+  inverse wavelet + column un-weighting (joint_inverse_problem.F90:559-571) -> model update ->
+  model_calculate_data (src/inversion/model.F90:220-307).
+
+All O(N) and O(nnz) work (wavelets, products, LSQR) runs on the device through Context; this file is control flow.
+With a multi-rank Context (distributed.RankContext) the model vectors are the rank-local column slices in the wavelet
+domain, exactly like the reference's nelements_at_cpu partition."""
+import numpy as np
+
+
+class AdmmState:
+    """admm_method.F90:25-66: z, u persist across major iterations."""
+
+    def __init__(self, n):
+        self.z = np.zeros(n)
+        self.u = np.zeros(n)
+
+    def iterate_admm_arrays(self, x, bounds):
+        """admm_method.F90:70-134 with global bounds [lo1 hi1 lo2 hi2 ...] (boundType 1)."""
+        ends = np.asarray(bounds, np.float64)
+        lo, hi = ends[0::2], ends[1::2]
+        arg = x + self.u
+        inside = ((lo[None, :] <= arg[:, None]) & (arg[:, None] <= hi[None, :])).any(1)
+        # closest boundary; np.argmin returns the first minimum = the strict '<' scan order xmin(1), xmax(1), xmin(2)...
+        closest = ends[np.argmin(np.abs(ends[None, :] - arg[:, None]), axis=1)]
+        self.z = np.where(inside, arg, closest)
+        self.u = self.u + x - self.z
+        return self.z - self.u
+
+
+def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor, nminor, alpha=0.0, rmin=1e-13,
+                          problem_weight=1.0, data_weight=None, model_start=None, model_prior=None, admm=None,
+                          gamma=0.0, target_misfit=0.0, log=None):
+    """ctx: Context holding the sensitivity matrix S (already scaled by problem_weight * data_weight) over ALL columns.
+    admm: dict(bounds=[...], rho=...) or None.  Returns (model, data_calc, history)."""
+    nx, ny, nz = ctx.dims
+    N = nx * ny * nz
+    cw = np.asarray(column_weight, np.float64)
+    pw = float(problem_weight)
+    dw = np.ones(data_obs.size) if data_weight is None else np.asarray(data_weight, np.float64)
+    m = np.zeros(N) if model_start is None else np.array(model_start, np.float64)
+    mp = np.zeros(N) if model_prior is None else np.asarray(model_prior, np.float64)
+
+    def to_wavelet(v):
+        return ctx.forward_wavelet(v, nx, ny, nz, compression_type) if compression_type > 0 else v
+
+    def calculate_data(model):                       # model.F90:242-305
+        scaled = np.where(cw != 0.0, model / cw, 0.0)
+        return ctx.calc_data(to_wavelet(scaled), pw, dw)
+
+    d_calc = calculate_data(m)
+    st = AdmmState(N) if admm is not None else None
+    hist = []
+    for it in range(1, nmajor + 1):
+        res = dw * (data_obs - d_calc)               # problem_joint_gravmag.F90:666-675
+        b_data = pw * res                            # joint_inverse_problem.F90:379-387
+        diag, rhs = [], []
+        if alpha != 0.0:                             # damping.F90:97-234 (L2, no local weights)
+            md = to_wavelet((m - mp) / cw)
+            diag.append(np.full(N, np.float32(alpha * pw), np.float32))
+            rhs.append(-alpha * pw * md)
+        if admm is not None:                         # joint_inverse_problem.F90:497-527
+            x0 = st.iterate_admm_arrays(m, admm["bounds"])
+            md = to_wavelet((m - x0) / cw)
+            diag.append(np.full(N, np.float32(admm["rho"] * pw), np.float32))
+            rhs.append(-admm["rho"] * pw * md)
+        x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
+        dm = ctx.inverse_wavelet(x, nx, ny, nz, compression_type) if compression_type > 0 else x
+        m = m + dm * cw                              # joint_inverse_problem.F90:570, model update :500
+        d_calc = calculate_data(m)
+        cost = float(np.linalg.norm(d_calc - data_obs) / np.linalg.norm(data_obs))   # data_gravmag.f90:123-129
+        hist.append(dict(it=it, iters=iters, r=r, cost=cost))
+        if log:
+            log("it %d: lsqr iters %d r %.6e data cost %.6e" % (it, iters, r, cost))
+    return m, d_calc, hist

@@ -1,0 +1,269 @@
+"""Host-side mirror of the reference's interface for the sensitivity-kernel hot path.
+
+Names follow the reference (Tomofast-x): t_sparse_matrix's products (src/inversion/sparse_matrix.f90), lsqr_solve_sensit
+(src/inversion/lsqr_solver2.F90), calculate_and_write_sensit / get_load_balancing_nelements
+(src/forward/gravmag/sensitivity_gravmag.F90), model_calculate_data (src/inversion/model.F90),
+forward_wavelet / inverse_wavelet (src/utils/wavelet_transform.F90), graviprism_z (src/forward/gravmag/grav/
+gravity_field.f90), calculate_depth_weight (src/forward/gravmag/weights_gravmag.f90).  Everything executes in the
+hand-written HIP kernels of libtfx.so; this module only marshals arguments."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as L
+from .lib import TfxError, check, f64, ptr
+
+
+class Context:
+    """One MI355X.  Owns the device-resident grid and sensitivity matrix (tfx_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = L.load()
+        h = C.c_void_p()
+        check(self._lib.tfx_create(int(device), C.c_void_p(stream or 0), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.dims = None
+        self._hook = None          # keeps the ctypes callback alive
+        self.rank, self.nranks = 0, 1
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tfx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- facts
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        mem = C.c_int64()
+        cus = self._lib.tfx_device_info(self._h, name, 256, C.byref(mem))
+        return dict(name=name.value.decode(), cus=cus, hbm_bytes=mem.value)
+
+    # ---- multi-GPU hook
+    def set_allreduce(self, fn, rank, nranks):
+        """fn(dev_ptr:int, n:int, stream:int) -> None : in-place fp64 sum all-reduce of a device buffer."""
+        if fn is None:
+            self._hook = None
+            check(self._lib.tfx_set_allreduce(self._h, C.cast(None, L.ALLREDUCE_FN), None, int(rank), int(nranks)))
+        else:
+            def tramp(user, buf, n, stream):
+                try:
+                    fn(int(buf or 0), int(n), int(stream or 0))
+                    return 0
+                except Exception as e:       # never let an exception cross the C frame
+                    import sys
+                    sys.stderr.write("all-reduce hook failed: %r\n" % (e,))
+                    return 1
+            self._hook = L.ALLREDUCE_FN(tramp)
+            check(self._lib.tfx_set_allreduce(self._h, self._hook, None, int(rank), int(nranks)))
+        self.rank, self.nranks = int(rank), int(nranks)
+
+    # ---- grid (t_grid, src/inversion/grid.F90:30-50)
+    def set_grid(self, nx, ny, nz, X1, X2, Y1, Y2, Z1, Z2):
+        arrs = [f64(a) for a in (X1, X2, Y1, Y2, Z1, Z2)]
+        n = nx * ny * nz
+        for a in arrs:
+            if a.size != n:
+                raise ValueError("grid array size %d != nx*ny*nz = %d" % (a.size, n))
+        check(self._lib.tfx_set_grid(self._h, nx, ny, nz, *[ptr(a) for a in arrs]))
+        self.dims = (int(nx), int(ny), int(nz))
+
+    @property
+    def nelements_total(self):
+        return int(np.prod(self.dims))
+
+    # ---- calculate_depth_weight type 1 + columnWeightMultiplier
+    def calculate_depth_weight(self, power=2.0, Z0=0.0, multiplier=4.0e3):
+        cw = np.empty(self.nelements_total)
+        check(self._lib.tfx_column_weight_type1(self._h, C.c_double(power), C.c_double(Z0), C.c_double(multiplier), ptr(cw)))
+        return cw
+
+    # ---- graviprism_z
+    def graviprism_z(self, Xdata, Ydata, Zdata):
+        xd, yd, zd = f64(np.atleast_1d(Xdata)), f64(np.atleast_1d(Ydata)), f64(np.atleast_1d(Zdata))
+        rows = np.empty((xd.size, self.nelements_total))
+        check(self._lib.tfx_prism_rows_gz(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(rows)))
+        return rows
+
+    # ---- forward_wavelet / inverse_wavelet
+    def forward_wavelet(self, s, n1, n2, n3, wavelet_type):
+        return self._wavelet(s, n1, n2, n3, wavelet_type, 1)
+
+    def inverse_wavelet(self, s, n1, n2, n3, wavelet_type):
+        return self._wavelet(s, n1, n2, n3, wavelet_type, 2)
+
+    def _wavelet(self, s, n1, n2, n3, wtype, direction):
+        if wtype not in (1, 2):
+            raise ValueError("Unknown wavelet type!")
+        a = f64(s).copy()
+        n = n1 * n2 * n3
+        if a.size % n != 0:
+            raise ValueError("array size is not a multiple of n1*n2*n3")
+        check(self._lib.tfx_wavelet(self._h, ptr(a), n1, n2, n3, C.c_int64(a.size // n), wtype, direction))
+        return a
+
+    def compress_row(self, row, K):
+        row = f64(row)
+        N = row.size
+        cap = max(1, min(N, K))
+        cols = np.empty(cap, np.int32)
+        vals = np.empty(cap, np.float32)
+        nel = C.c_int64()
+        thr = C.c_double()
+        cd = C.c_double()
+        check(self._lib.tfx_compress_row(self._h, ptr(row), C.c_int64(N), C.c_int64(K), ptr(cols), ptr(vals), C.byref(nel),
+                                         C.byref(thr), C.byref(cd)))
+        return cols[:nel.value].copy(), vals[:nel.value].copy(), thr.value, cd.value
+
+    # ---- calculate_and_write_sensit + read_sensitivity_kernel (no disk round trip)
+    def calculate_sensit(self, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate, problem_weight=1.0,
+                         data_weight=None, col_range=None, want_hist=False):
+        xd, yd, zd = f64(Xdata), f64(Ydata), f64(Zdata)
+        cw = f64(column_weight)
+        N = self.nelements_total
+        c0, c1 = (0, N) if col_range is None else col_range
+        dw = None if data_weight is None else f64(data_weight)
+        nnz = C.c_int64()
+        err = C.c_double()
+        hist = np.zeros(N, np.int32) if want_hist else None
+        check(self._lib.tfx_build_kernel_grav(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw), int(compression_type),
+                                              C.c_double(compression_rate), C.c_double(problem_weight), ptr(dw), C.c_int64(c0),
+                                              C.c_int64(c1), C.byref(nnz), C.byref(err), ptr(hist)))
+        return dict(nnz=nnz.value, error_sum=err.value, comp_error=err.value / xd.size, nnz_hist=hist)
+
+    # ---- t_sparse_matrix
+    def matrix_upload_csr(self, nrows, ncols, rowptr, cols, vals):
+        rp = np.ascontiguousarray(rowptr, np.int64)
+        c = np.ascontiguousarray(cols, np.int32)
+        v = np.ascontiguousarray(vals, np.float32)
+        if rp.size != nrows + 1:
+            raise ValueError("rowptr size")
+        check(self._lib.tfx_matrix_upload_csr(self._h, C.c_int64(nrows), C.c_int64(ncols), ptr(rp), ptr(c), ptr(v)))
+
+    def matrix_info(self):
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(self._lib.tfx_matrix_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(nrows=a.value, ncols=b.value, nnz=c.value, device_bytes=d.value)
+
+    def matrix_download_csr(self):
+        info = self.matrix_info()
+        rp = np.empty(info["nrows"] + 1, np.int64)
+        cols = np.empty(max(1, info["nnz"]), np.int32)
+        vals = np.empty(max(1, info["nnz"]), np.float32)
+        check(self._lib.tfx_matrix_download_csr(self._h, ptr(rp), ptr(cols), ptr(vals)))
+        return rp, cols[:rp[-1]], vals[:rp[-1]]
+
+    def matrix_free(self):
+        check(self._lib.tfx_matrix_free(self._h))
+
+    def mult_vector(self, x, b=None):
+        """b = S x (mult_vector) or b += S x when b is given (add_mult_vector)."""
+        info = self.matrix_info()
+        x = f64(x)
+        if x.size != info["ncols"]:
+            raise ValueError("x size %d != ncols %d" % (x.size, info["ncols"]))
+        add = b is not None
+        out = f64(b).copy() if add else np.empty(info["nrows"])
+        check(self._lib.tfx_spmv(self._h, ptr(x), ptr(out), int(add)))
+        return out
+
+    def trans_mult_vector(self, x, b=None):
+        info = self.matrix_info()
+        x = f64(x)
+        if x.size != info["nrows"]:
+            raise ValueError("x size %d != nrows %d" % (x.size, info["nrows"]))
+        add = b is not None
+        out = f64(b).copy() if add else np.empty(info["ncols"])
+        check(self._lib.tfx_spmtv(self._h, ptr(x), ptr(out), int(add)))
+        return out
+
+    # ---- lsqr_solve_sensit
+    def _blocks(self, diag_blocks, rhs_blocks, ncols):
+        nb = len(diag_blocks)
+        if nb != len(rhs_blocks):
+            raise ValueError("diag / rhs block count mismatch")
+        keep = []
+        dp = (C.c_void_p * max(1, nb))()
+        rp = (C.c_void_p * max(1, nb))()
+        for i, (d, r) in enumerate(zip(diag_blocks, rhs_blocks)):
+            d = np.ascontiguousarray(d, np.float32)
+            r = f64(r)
+            if d.size != ncols or r.size != ncols:
+                raise ValueError("constraint block size != ncols")
+            keep += [d, r]
+            dp[i] = d.ctypes.data
+            rp[i] = r.ctypes.data
+        return nb, dp, rp, keep
+
+    def lsqr_solve_sensit(self, b_data, niter, rmin=1e-13, gamma=0.0, target_misfit=0.0, diag_blocks=(), rhs_blocks=()):
+        info = self.matrix_info()
+        b = f64(b_data)
+        if b.size != info["nrows"]:
+            raise ValueError("Wrong matrix sizes in lsqr_solve_sensit!")
+        nb, dp, rp, keep = self._blocks(diag_blocks, rhs_blocks, info["ncols"])
+        x = np.empty(info["ncols"])
+        it = C.c_int()
+        r = C.c_double()
+        check(self._lib.tfx_lsqr_solve(self._h, int(niter), C.c_double(rmin), C.c_double(gamma), C.c_double(target_misfit), ptr(b),
+                                       nb, dp, rp, ptr(x), C.byref(it), C.byref(r)))
+        return x, it.value, r.value
+
+    def lsqr_begin(self, b_data, rmin=1e-13, gamma=0.0, target_misfit=0.0, diag_blocks=(), rhs_blocks=()):
+        info = self.matrix_info()
+        b = f64(b_data)
+        nb, dp, rp, keep = self._blocks(diag_blocks, rhs_blocks, info["ncols"])
+        check(self._lib.tfx_lsqr_begin(self._h, C.c_double(rmin), C.c_double(gamma), C.c_double(target_misfit), ptr(b), nb, dp, rp))
+
+    def lsqr_iterate(self, k):
+        done = C.c_int()
+        r = C.c_double()
+        check(self._lib.tfx_lsqr_iterate(self._h, int(k), C.byref(done), C.byref(r)))
+        return done.value, r.value
+
+    def lsqr_end(self):
+        x = np.empty(self.matrix_info()["ncols"])
+        check(self._lib.tfx_lsqr_end(self._h, ptr(x)))
+        return x
+
+    # ---- model_calculate_data (after un-weighting + wavelet)
+    def calc_data(self, xw_local, problem_weight=1.0, data_weight=None):
+        info = self.matrix_info()
+        x = f64(xw_local)
+        dw = None if data_weight is None else f64(data_weight)
+        out = np.empty(info["nrows"])
+        check(self._lib.tfx_calc_data(self._h, ptr(x), C.c_double(problem_weight), ptr(dw), ptr(out)))
+        return out
+
+    # ---- timing
+    def timer_start(self):
+        check(self._lib.tfx_timer_start(self._h))
+
+    def timer_stop_ms(self):
+        ms = C.c_double()
+        check(self._lib.tfx_timer_stop_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        check(self._lib.tfx_profile_enable(self._h, int(bool(on))))
+
+    def profile_get(self, which):
+        ms = C.c_double()
+        n = C.c_int64()
+        check(self._lib.tfx_profile_get(self._h, int(which), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def get_load_balancing_nelements(sensit_nnz, nbproc):
+    """src/forward/gravmag/sensitivity_gravmag.F90:470-524: returns (nelements_at_cpu, nnz_at_cpu)."""
+    lib = L.load()
+    h = np.ascontiguousarray(sensit_nnz, np.int32)
+    nel = np.zeros(nbproc, np.int32)
+    nnz = np.zeros(nbproc, np.int64)
+    check(lib.tfx_partition_columns(ptr(h), C.c_int64(h.size), int(nbproc), ptr(nel), ptr(nnz)))
+    return nel, nnz
