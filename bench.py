@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py - LSQR iterations/s (and cell.obs/s) of the MI355X-native Tomofast-x hot path on a synthetic gravity inversion.
+
+  python bench.py [--gpus N --steps K --warmup W] [--workload NAME]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one LSQR iteration (the loop body of lsqr_solve_sensit, src/inversion/lsqr_solver2.F90:163-290) over the
+wavelet-compressed sensitivity matrix, everything resident in HBM.  Setup (not timed, reported separately as build
+cell.obs/s): prism rows -> column weights -> wavelet -> threshold -> tiled matrix, all on the GPU.
+Strong scaling: the same problem on N GPUs, column-partitioned like the reference's MPI decomposition, two RCCL
+all-reduces per iteration through torch.distributed.
+
+One JSON line on rank 0.  `roofline` prices the dominant kernel (compressed SpMV or its adjoint, whichever is slower)
+with SURVEY.md 8(d)'s algorithmic bytes (8 B per non-zero per pass) over its HIP-event duration; `cpu_baseline` is the
+CPU oracle (oracle/, a C restatement of the reference pinned to it bit-for-bit) timed on a bounded sample of the same
+workload on this box's host cores."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[4] - the configuration the metric is quoted on ("10^7-cell / 10^5-obs ... D4")
+    "hamersley_1e7": dict(nx=256, ny=256, nz=152, ox=316, oy=316, ctype=2, rate=0.02,
+                          desc="synthetic gravity 256x256x152 cells (9.96e6), 316x316 obs (99856), D4 wavelet r=0.02"),
+    # BASELINE.json configs[2]
+    "haar_512": dict(nx=512, ny=512, nz=128, ox=256, oy=256, ctype=1, rate=0.01,
+                     desc="synthetic gravity 512x512x128 cells, 256x256 obs, Haar r=0.01"),
+    # reduced sizes for quick checks (NOT the headline; bench prints which one ran)
+    "medium": dict(nx=128, ny=128, nz=64, ox=64, oy=64, ctype=2, rate=0.02,
+                   desc="synthetic gravity 128x128x64 cells, 64x64 obs, D4 r=0.02 (reduced)"),
+    "small": dict(nx=64, ny=64, nz=32, ox=32, oy=32, ctype=1, rate=0.1,
+                  desc="synthetic gravity 64x64x32 cells, 32x32 obs, Haar r=0.1 (SURVEY 6 CPU-baseline size)"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy ceiling)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("TFX_BENCH_WORKLOAD", "hamersley_1e7"))
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket the matrix kernels with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    import torch
+    tfx = importlib.import_module("tomofast-x_amd")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(local_rank)
+
+    def log(msg):
+        if rank == 0:
+            sys.stderr.write("[bench] %s\n" % msg)
+            sys.stderr.flush()
+
+    w = WORKLOADS[args.workload]
+    nx, ny, nz = w["nx"], w["ny"], w["nz"]
+    N = nx * ny * nz
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, w["ox"], w["oy"])
+    D = xs.size
+    ctx = tfx.Context(local_rank)
+    info = ctx.device_info()
+    log("device %s, %d CUs, %.0f GB; workload %s" % (info["name"], info["cus"], info["hbm_bytes"] / 1e9, w["desc"]))
+    ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
+    cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+    if world > 1:
+        ctx.set_allreduce(tfx.distributed.TorchAllreduce(local_rank), rank, world)
+
+    # ---- build (setup; reported as cell.obs/s)
+    barrier()
+    t0 = time.time()
+    part = tfx.distributed.build_partitioned(ctx, rank, world, xs, ys, zs, cw, w["ctype"], w["rate"])
+    barrier()
+    t_build = time.time() - t0
+    minfo = ctx.matrix_info()
+    nnz_total = part["nnz_total"]
+    c0, c1 = part["col_range"]
+    log("build %.1f s (%.3e cell.obs/s), nnz %d, compression error %.3e, rank-0 matrix %.2f GB, cols [%d,%d)" %
+        (t_build, N * D / t_build, nnz_total, part["comp_error"], minfo["device_bytes"] / 1e9, c0, c1))
+
+    # ---- right-hand side: data of the synthetic block model, d = S Wav(m_true / cw)   (model.F90:220-307)
+    mtrue = tfx.synthetic.true_model(nx, ny, nz)
+    xw = ctx.forward_wavelet(mtrue / cw, nx, ny, nz, w["ctype"]) if w["ctype"] > 0 else mtrue / cw
+    d_obs = ctx.calc_data(xw[c0:c1], 1.0, None)
+    alpha = 1e-7
+    ncl = c1 - c0
+    diag = [np.full(ncl, np.float32(alpha), np.float32)]
+    rhs = [np.zeros(ncl)]
+
+    # ---- size-independent property at full size: <S x, y> = <x, S^T y>
+    rng = np.random.default_rng(1 + rank)
+    xr = rng.standard_normal(ncl)
+    yr = np.random.default_rng(99).standard_normal(D)
+    lhs = float(np.dot(ctx.mult_vector(xr), yr))
+    rhs_dot = float(np.dot(xr, ctx.trans_mult_vector(yr)))
+    adj_err = abs(lhs - rhs_dot) / max(abs(lhs), abs(rhs_dot), 1e-300)
+    log("adjoint identity rel. mismatch %.2e" % adj_err)
+
+    # ---- LSQR: W warm-up iterations, then exactly K timed iterations
+    ctx.lsqr_begin(d_obs, 1e-300, 0.0, 0.0, diag, rhs)        # rmin tiny: never stop early inside the timed region
+    done, r = ctx.lsqr_iterate(args.warmup)
+    assert done == args.warmup, "LSQR stopped during warm-up (%d of %d)" % (done, args.warmup)
+    if not args.no_profile:
+        ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    done, r = ctx.lsqr_iterate(args.steps)
+    ms_gpu = ctx.timer_stop_ms()
+    barrier()
+    t_steps = time.perf_counter() - t0
+    assert done == args.steps, "LSQR stopped early (%d of %d)" % (done, args.steps)
+    prof = [ctx.profile_get(0), ctx.profile_get(1)] if not args.no_profile else [(0.0, 0), (0.0, 0)]
+    ctx.profile_enable(False)
+    ctx.lsqr_end()
+    if dist is not None:
+        tt = torch.tensor([t_steps], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_steps = float(tt.item())
+    ms_per_step = 1e3 * t_steps / args.steps
+    value = args.steps / t_steps
+
+    # ---- roofline of the dominant kernel (rank 0's share of the matrix)
+    nnz_loc = minfo["nnz"]
+    names = ["k_spmv_fwd (compressed SpMV, b += S x)", "k_spmv_adj (compressed SpMtV, b += S^T x)"]
+    roof = None
+    if prof[0][1] and prof[1][1]:
+        avg = [prof[0][0] / prof[0][1], prof[1][0] / prof[1][1]]
+        dom = 0 if avg[0] >= avg[1] else 1
+        achieved = 8.0 * nnz_loc / (avg[dom] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": 8 * nnz_loc, "stored_bytes_per_launch": 6 * nnz_loc,
+                "avg_launch_ms": {"spmv_fwd": round(avg[0], 4), "spmv_adj": round(avg[1], 4)},
+                "achieved_other_GBs": round(8.0 * nnz_loc / (avg[1 - dom] * 1e-3) / 1e9, 1)}
+
+    # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same workload
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(tfx, w, args.cpu_seconds, cw, log)
+
+    if rank == 0:
+        out = {
+            "metric": "LSQR iterations/s, synthetic gravity inversion (wavelet-compressed sensitivity kernel)",
+            "value": round(value, 4), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64 (fp32-stored matrix values, fp64 vectors and accumulation)", "data": "synthetic",
+            "config": {"workload": args.workload + ": " + w["desc"], "cells": N, "obs": D, "nnz": int(nnz_total),
+                       "compression": {0: "none", 1: "haar", 2: "d4"}[w["ctype"]], "rate": w["rate"],
+                       "parallelism": "column-partitioned x%d" % world, "damping_alpha": alpha},
+            "cell_obs_per_s_solve": round(N * D * value, 1),
+            "cell_obs_per_s_build": round(N * D / t_build, 1), "build_s": round(t_build, 2),
+            "gpu_ms_per_step_hip_events": round(ms_gpu / args.steps, 4),
+            "lsqr_bytes_per_iteration_algorithmic": 16 * int(nnz_total) + 112 * N + 48 * (D + N),
+            "adjoint_identity_rel_err": adj_err, "final_r": r,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+        sys.stdout.flush()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tfx, w, budget_s, cw, log):
+    """The CPU oracle (tests/oracle_lib.py -> oracle/libtfx_oracle.so, one core) on a bounded sample: it builds R rows of
+    the same matrix and runs LSQR iterations on them; one iteration over all D rows costs D/R times that (LSQR cost is
+    linear in nnz), so value = 1 / (t_iter_sample * D / R)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    nx, ny, nz = w["nx"], w["ny"], w["nz"]
+    N = nx * ny * nz
+    grid = tfx.synthetic.grid(nx, ny, nz)
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, w["ox"], w["oy"])
+    D = xs.size
+    K = int(w["rate"] * N) if w["ctype"] > 0 else N
+    rows = []
+    t0 = time.time()
+    idx = np.linspace(0, D - 1, 64).astype(int)
+    for r in idx:
+        rows.append(orc.build_row_grav(grid, (nx, ny, nz), cw, (xs[r], ys[r], zs[r]), w["ctype"], K))
+        if time.time() - t0 > 0.6 * budget_s:
+            break
+    t_build = time.time() - t0
+    R = len(rows)
+    rp = np.concatenate([[0], np.cumsum([c.size for c, _, _ in rows])]).astype(np.int64)
+    cols = np.concatenate([c for c, _, _ in rows])
+    vals = np.concatenate([v for _, v, _ in rows])
+    b = np.random.default_rng(0).standard_normal(R + N)
+    b[R:] = 0.0
+    Cm = orc.diag_csr(np.full(N, np.float32(1e-7), np.float32))
+    niter = 2
+    t0 = time.time()
+    orc.lsqr((rp, cols, vals), Cm, N, b, niter)
+    t1 = time.time() - t0
+    niter = max(2, min(50, int(0.4 * budget_s / max(t1 / 2, 1e-6))))
+    t0 = time.time()
+    _, it, _ = orc.lsqr((rp, cols, vals), Cm, N, b, niter)
+    t_iter = (time.time() - t0) / max(it, 1)
+    # an iteration = 2 passes over nnz (scales with rows) + vector work over N (does not)
+    t_vec = measure_vector_part(orc, N, Cm)
+    t_full = (t_iter - t_vec) * D / R + t_vec
+    val = 1.0 / t_full
+    log("cpu baseline: %d sample rows built in %.1f s (%.3e cell.obs/s/core), %.4f s per sample iteration -> %.5f it/s" %
+        (R, t_build, R * N / t_build, t_iter, val))
+    return {"value": val, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d of %d rows built and iterated by the C oracle (oracle/tfx_oracle.c) on one core; the matrix part of "
+                      "the measured iteration time is scaled by D/R (LSQR is linear in nnz)" % (R, D),
+            "build_cell_obs_per_s_per_core": R * N / t_build, "sample_rows": R, "sample_iteration_s": t_iter}
+
+
+def measure_vector_part(orc, N, Cm):
+    """Cost of an LSQR iteration with an empty S (the O(N) vector and damping work)."""
+    b = np.zeros(1 + N)
+    b[0] = 1.0
+    b[1:] = 1e-3
+    S = (np.zeros(2, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    S[0][1] = 0
+    t0 = time.time()
+    _, it, _ = orc.lsqr(S, Cm, N, b, 3)
+    return (time.time() - t0) / max(it, 1)
+
+
+if __name__ == "__main__":
+    main()

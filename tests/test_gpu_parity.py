@@ -3,7 +3,7 @@ Runs on a real MI355X only (`pytest -m gpu`).
 
 Stated tolerances
   wavelets, threshold, compaction on identical inputs ......... bit-exact
-  prism rows (device libm atan2/log vs glibc, <= 2 ulp/term) ... 1e-13 of the row's max magnitude
+  prism rows (device libm atan2/log vs glibc, <= 2 ulp/term) ... 8 ulp of G * sum|terms| (the 24 terms cancel heavily)
   column weights (device pow) ................................... 1e-14 relative
   built matrix vs reference SENSIT rows ......................... same nel per row (+-1 on threshold ties), >= 99.9 %
                                                                   identical sparsity, kept values within 2 fp32 ulp
@@ -77,8 +77,23 @@ def test_prism_rows_vs_reference(ctx, golden_dir):
     g = load(golden_dir, "prism")
     ctx.set_grid(int(g["nx"]), int(g["ny"]), int(g["nz"]), *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
     rows = ctx.graviprism_z(g["obs"][:, 0], g["obs"][:, 1], g["obs"][:, 2])
-    for r, ref in zip(rows, g["rows"]):
-        assert np.max(np.abs(r - ref)) <= 1e-13 * np.max(np.abs(ref))
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    for o, r, ref in zip(g["obs"], rows, g["rows"]):
+        # gz is a sum of 24 terms that cancel heavily; device atan2/log differ from glibc by <= 2 ulp per term, so the
+        # error bound is a few ulp of the TERM magnitude, not of the result
+        assert np.all(np.abs(r - ref) <= 8 * 2.3e-16 * prism_term_scale(grid, o))
+
+
+def prism_term_scale(grid, o):
+    X1, X2, Y1, Y2, Z1, Z2 = grid
+    s = np.zeros(X1.size)
+    for xx in (o[0] - X1, o[0] - X2):
+        for yy in (o[1] - Y1, o[1] - Y2):
+            for zz in (o[2] - Z1, o[2] - Z2):
+                R = np.sqrt(xx * xx + yy * yy + zz * zz)
+                s += np.abs(zz) * 2 * np.pi + np.abs(xx * np.log(R + yy)) + np.abs(yy * np.log(R + xx))
+    return 6.674e-11 * s
+
 
 
 def test_prism_geometry_error(ctx):
