@@ -211,39 +211,37 @@ def cpu_baseline(tfx, w, budget_s, cw, log):
     rp = np.concatenate([[0], np.cumsum([c.size for c, _, _ in rows])]).astype(np.int64)
     cols = np.concatenate([c for c, _, _ in rows])
     vals = np.concatenate([v for _, v, _ in rows])
+    S = (rp, cols, vals)
     b = np.random.default_rng(0).standard_normal(R + N)
     b[R:] = 0.0
     Cm = orc.diag_csr(np.full(N, np.float32(1e-7), np.float32))
-    niter = 2
+    # whole sample iterations (matrix passes over R rows + the O(N) vector / damping work)
     t0 = time.time()
-    orc.lsqr((rp, cols, vals), Cm, N, b, niter)
-    t1 = time.time() - t0
-    niter = max(2, min(50, int(0.4 * budget_s / max(t1 / 2, 1e-6))))
+    _, it, _ = orc.lsqr(S, Cm, N, b, 2)
+    t1 = (time.time() - t0) / max(it, 1)
+    niter = max(2, min(40, int(0.25 * budget_s / max(t1, 1e-6))))
     t0 = time.time()
-    _, it, _ = orc.lsqr((rp, cols, vals), Cm, N, b, niter)
+    _, it, _ = orc.lsqr(S, Cm, N, b, niter)
     t_iter = (time.time() - t0) / max(it, 1)
-    # an iteration = 2 passes over nnz (scales with rows) + vector work over N (does not)
-    t_vec = measure_vector_part(orc, N, Cm)
-    t_full = (t_iter - t_vec) * D / R + t_vec
+    # the two matrix passes alone (this is the part that scales with the number of rows)
+    x = np.random.default_rng(1).standard_normal(N)
+    y = np.random.default_rng(2).standard_normal(R)
+    reps = max(2, min(40, int(0.15 * budget_s / max(t1, 1e-6))))
+    t0 = time.time()
+    for _ in range(reps):
+        orc.spmv(rp, cols, vals, x)
+        orc.spmtv(rp, cols, vals, y, N)
+    t_mat = (time.time() - t0) / reps
+    t_vec = max(t_iter - t_mat, 0.0)
+    t_full = t_mat * D / R + t_vec
     val = 1.0 / t_full
     log("cpu baseline: %d sample rows built in %.1f s (%.3e cell.obs/s/core), %.4f s per sample iteration -> %.5f it/s" %
         (R, t_build, R * N / t_build, t_iter, val))
     return {"value": val, "unit": "iterations/s", "cores": 1, "kind": "port",
             "sample": "%d of %d rows built and iterated by the C oracle (oracle/tfx_oracle.c) on one core; the matrix part of "
                       "the measured iteration time is scaled by D/R (LSQR is linear in nnz)" % (R, D),
-            "build_cell_obs_per_s_per_core": R * N / t_build, "sample_rows": R, "sample_iteration_s": t_iter}
-
-
-def measure_vector_part(orc, N, Cm):
-    """Cost of an LSQR iteration with an empty S (the O(N) vector and damping work)."""
-    b = np.zeros(1 + N)
-    b[0] = 1.0
-    b[1:] = 1e-3
-    S = (np.zeros(2, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
-    S[0][1] = 0
-    t0 = time.time()
-    _, it, _ = orc.lsqr(S, Cm, N, b, 3)
-    return (time.time() - t0) / max(it, 1)
+            "build_cell_obs_per_s_per_core": R * N / t_build, "sample_rows": R, "sample_iteration_s": t_iter,
+            "sample_matrix_passes_s": t_mat}
 
 
 if __name__ == "__main__":

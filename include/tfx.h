@@ -144,6 +144,10 @@ int tfx_timer_stop_ms(tfx_ctx *ctx, double *ms_out);       /* synchronises      
 int tfx_profile_enable(tfx_ctx *ctx, int on);
 int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches);
 
+/* Test / diagnostics switchboard.  key "force_general_prism" (value 0/1): always use the six-array prism kernel even
+ * when the grid is a tensor product; key "tensor_grid": returns 1 when the tensor-product fast path is active.       */
+int tfx_debug_set(tfx_ctx *ctx, const char *key, int value);
+
 #ifdef __cplusplus
 }
 #endif

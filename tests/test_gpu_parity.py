@@ -96,6 +96,32 @@ def prism_term_scale(grid, o):
 
 
 
+def test_prism_tensor_path_bit_identical_to_general(ctx, golden_dir):
+    """Tensor-product grids take the shared-node kernel; it must give the same bits as the six-array kernel."""
+    g = load(golden_dir, "prism")
+    cases = [((int(g["nx"]), int(g["ny"]), int(g["nz"])), [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")], g["obs"])]
+    xs, ys, zs = tfx.synthetic.observations(70, 37, 3, 2)
+    cases.append(((70, 37, 19), list(tfx.synthetic.grid(70, 37, 19)), np.stack([xs, ys, zs], 1)))
+    for dims, grid, obs in cases:
+        ctx.set_grid(*dims, *grid)
+        assert ctx.debug_set("tensor_grid") == 1
+        rows_t = ctx.graviprism_z(obs[:, 0], obs[:, 1], obs[:, 2])
+        ctx.debug_set("force_general_prism", 1)
+        assert ctx.debug_set("tensor_grid") == 0
+        rows_g = ctx.graviprism_z(obs[:, 0], obs[:, 1], obs[:, 2])
+        ctx.debug_set("force_general_prism", 0)
+        assert bits_equal(rows_t, rows_g)
+    # a grid whose cells do not share faces is not a tensor grid: general kernel
+    dims, grid, obs = cases[0]
+    bent = [a.copy() for a in grid]
+    bent[1][7] += 1e-9
+    ctx.set_grid(*dims, *bent)
+    assert ctx.debug_set("tensor_grid") == 0
+    ierr, ref = orc.graviprism_z(bent, *obs[0])
+    r = ctx.graviprism_z(obs[:1, 0], obs[:1, 1], obs[:1, 2])[0]
+    assert np.all(np.abs(r - ref) <= 8 * 2.3e-16 * prism_term_scale(bent, obs[0]))
+
+
 def test_prism_geometry_error(ctx):
     one = [np.array([v], np.float64) for v in (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)]
     ctx.set_grid(1, 1, 1, *one)

@@ -89,7 +89,19 @@ int tfx_set_grid(tfx_ctx *ctx, int nx, int ny, int nz, const double *X1, const d
     ctx->ny = ny;
     ctx->nz = nz;
     ctx->N = N;
-    return 0;
+    return detect_tensor_grid(ctx);
+}
+
+int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
+{
+    if (!ctx || !key) return fail(TFX_E_ARG, "null argument");
+    if (!strcmp(key, "force_general_prism")) {
+        ctx->force_general_prism = value != 0;
+        if (ctx->N) return detect_tensor_grid(ctx);
+        return 0;
+    }
+    if (!strcmp(key, "tensor_grid")) return ctx->tensor_grid ? 1 : 0;     // query
+    return fail(TFX_E_ARG, "unknown debug key %s", key);
 }
 
 // ---- matrix upload / download ------------------------------------------------------------------------------

@@ -22,8 +22,27 @@ namespace tfx {
 // gravity_field.f90:26 - `G_grav = 6.674e-11` is a default-real literal: the value used is (double)(float)6.674e-11.
 __device__ __forceinline__ double g_grav() { return (double)6.674e-11f; }
 
-// One thread per cell, loops over the observation batch (coordinates are wave-uniform scalar loads).
-// rows[o*N + p] = G*gz (* cw[p] when cw != null: apply_column_weight, sensitivity_gravmag.F90:1042-1054).
+// One corner of the prism integral (gravity_field.f90:165-186): returns ZZ*atan2'(XX*YY, ZZ*R) - XX*log(R+YY) - YY*log(R+XX)
+// and flags R+XX <= 0 / R+YY <= 0 (:176-181).  Shared by the general and the tensor-grid kernel so both produce the
+// same bits.
+__device__ __forceinline__ double corner_term(double XX, double YY, double ZZ, int &bad)
+{
+    const double twopi = 2.0 * 3.14159265358979323846;
+    const double Rs = sqrt(XX * XX + YY * YY + ZZ * ZZ);                                            // :165
+    double arg3 = atan2(XX * YY, ZZ * Rs);                                                          // :167
+    if (arg3 < 0) arg3 = arg3 + twopi;
+    double arg4 = Rs + XX;
+    double arg5 = Rs + YY;
+    if (arg4 <= 0.) bad |= 1;
+    if (arg5 <= 0.) bad |= 2;
+    arg4 = log(arg4);
+    arg5 = log(arg5);
+    return ZZ * arg3 - XX * arg5 - YY * arg4;                                                       // :186
+}
+
+// General grid (six independent arrays): one thread per cell, loops over the observation batch (coordinates are
+// wave-uniform scalar loads).  rows[o*N + p] = G*gz (* cw[p] when cw != null: apply_column_weight,
+// sensitivity_gravmag.F90:1042-1054).
 __global__ __launch_bounds__(256) void k_prism_gz(int64_t N, const double *__restrict__ X1, const double *__restrict__ X2,
                                                   const double *__restrict__ Y1, const double *__restrict__ Y2,
                                                   const double *__restrict__ Z1, const double *__restrict__ Z2,
@@ -31,7 +50,6 @@ __global__ __launch_bounds__(256) void k_prism_gz(int64_t N, const double *__res
                                                   const double *__restrict__ zd, const double *__restrict__ cw,
                                                   double *__restrict__ rows, int *__restrict__ err)
 {
-    const double twopi = 2.0 * 3.14159265358979323846;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
         const double x1 = X1[p], x2 = X2[p], y1 = Y1[p], y2 = Y2[p], z1 = Z1[p], z2 = Z2[p];
         const double w = cw ? cw[p] : 1.0;
@@ -49,16 +67,7 @@ __global__ __launch_bounds__(256) void k_prism_gz(int64_t N, const double *__res
 #pragma unroll
                     for (int M = 0; M < 2; ++M) {
                         const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;   // signo(K)*signo(L)*signo(M), signo = (-1, +1)
-                        const double Rs = sqrt(XX[K] * XX[K] + YY[L] * YY[L] + ZZ[M] * ZZ[M]);      // :165
-                        double arg3 = atan2(XX[K] * YY[L], ZZ[M] * Rs);                             // :167
-                        if (arg3 < 0) arg3 = arg3 + twopi;
-                        double arg4 = Rs + XX[K];
-                        double arg5 = Rs + YY[L];
-                        if (arg4 <= 0.) bad |= 1;                                                   // :176-181
-                        if (arg5 <= 0.) bad |= 2;
-                        arg4 = log(arg4);
-                        arg5 = log(arg5);
-                        gz = gz + dmu * (ZZ[M] * arg3 - XX[K] * arg5 - YY[L] * arg4);               // :186
+                        gz = gz + dmu * corner_term(XX[K], YY[L], ZZ[M], bad);
                     }
             if (bad) atomicOr(err, bad);
             double v = g_grav() * gz;                                                               // :192
@@ -66,6 +75,134 @@ __global__ __launch_bounds__(256) void k_prism_gz(int64_t N, const double *__res
             rows[(int64_t)o * N + p] = v;
         }
     }
+}
+
+// Tensor-product grid (X1/X2 depend on i only, Y on j, Z on k, and neighbouring cells share their faces bit-for-bit -
+// what the reference's grid files describe in practice): the corner term depends only on the NODE, and a node is
+// shared by up to 8 cells.  A workgroup evaluates the (TX+1)(TY+1)(TZ+1) nodes of its TX x TY x TZ cell tile once into
+// LDS (1.3 transcendental evaluations per cell instead of 8) and then forms each cell's 8-term sum in the reference's
+// order (K outer, L, M inner), so the result is bit-identical to k_prism_gz.
+constexpr int PT_X = 32, PT_Y = 8, PT_Z = 8;
+constexpr int PT_NODES = (PT_X + 1) * (PT_Y + 1) * (PT_Z + 1);
+__global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz, const double *__restrict__ xe,
+                                                         const double *__restrict__ ye, const double *__restrict__ ze,
+                                                         int nobs, const double *__restrict__ xd,
+                                                         const double *__restrict__ yd, const double *__restrict__ zd,
+                                                         const double *__restrict__ cw, double *__restrict__ rows,
+                                                         int *__restrict__ err)
+{
+    __shared__ double T[PT_NODES];
+    const int tiles_x = (nx + PT_X - 1) / PT_X, tiles_y = (ny + PT_Y - 1) / PT_Y;
+    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
+    const int i0 = bx * PT_X, j0 = by * PT_Y, k0 = bz * PT_Z;
+    const int cx = min(PT_X, nx - i0), cy = min(PT_Y, ny - j0), cz = min(PT_Z, nz - k0);
+    const int64_t N = (int64_t)nx * ny * nz;
+    const int nnode = (cx + 1) * (cy + 1) * (cz + 1);
+    const int ncell = cx * cy * cz;
+    int bad = 0;
+    for (int o = 0; o < nobs; ++o) {
+        const double xo = xd[o], yo = yd[o], zo = zd[o];
+        __syncthreads();
+        for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
+            const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
+            T[(c * (PT_Y + 1) + b) * (PT_X + 1) + a] = corner_term(xo - xe[i0 + a], yo - ye[j0 + b], zo - ze[k0 + c], bad);
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < ncell; q += blockDim.x) {
+            const int a = q % cx, b = (q / cx) % cy, c = q / (cx * cy);
+            double gz = 0.0;
+#pragma unroll
+            for (int K = 0; K < 2; ++K)
+#pragma unroll
+                for (int L = 0; L < 2; ++L)
+#pragma unroll
+                    for (int M = 0; M < 2; ++M) {
+                        const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;
+                        gz = gz + dmu * T[((c + M) * (PT_Y + 1) + (b + L)) * (PT_X + 1) + (a + K)];
+                    }
+            const int64_t p = ((int64_t)(k0 + c) * ny + (j0 + b)) * nx + (i0 + a);
+            double v = g_grav() * gz;
+            if (cw) v = v * cw[p];
+            rows[(int64_t)o * N + p] = v;
+        }
+    }
+    if (bad) atomicOr(err, bad);
+}
+
+// Verifies that the six cell arrays describe a tensor-product grid with shared faces; ok[0] is cleared otherwise.
+__global__ void k_check_tensor(int nx, int ny, int nz, const double *__restrict__ X1, const double *__restrict__ X2,
+                               const double *__restrict__ Y1, const double *__restrict__ Y2, const double *__restrict__ Z1,
+                               const double *__restrict__ Z2, const double *__restrict__ xe, const double *__restrict__ ye,
+                               const double *__restrict__ ze, int *__restrict__ ok)
+{
+    const int64_t N = (int64_t)nx * ny * nz;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(p % nx), j = (int)((p / nx) % ny), k = (int)(p / ((int64_t)nx * ny));
+        const bool good = X1[p] == xe[i] && X2[p] == xe[i + 1] && Y1[p] == ye[j] && Y2[p] == ye[j + 1] && Z1[p] == ze[k] &&
+                          Z2[p] == ze[k + 1];
+        if (!good) *ok = 0;
+    }
+}
+
+__global__ void k_gather_edges(int nx, int ny, int nz, const double *__restrict__ X1, const double *__restrict__ X2,
+                               const double *__restrict__ Y1, const double *__restrict__ Y2, const double *__restrict__ Z1,
+                               const double *__restrict__ Z2, double *__restrict__ xe, double *__restrict__ ye,
+                               double *__restrict__ ze)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t sxy = (int64_t)nx * ny;
+    if (t < nx) xe[t] = X1[t];
+    if (t == nx) xe[nx] = X2[nx - 1];
+    if (t < ny) ye[t] = Y1[(int64_t)t * nx];
+    if (t == ny) ye[ny] = Y2[(int64_t)(ny - 1) * nx];
+    if (t < nz) ze[t] = Z1[(int64_t)t * sxy];
+    if (t == nz) ze[nz] = Z2[(int64_t)(nz - 1) * sxy];
+}
+
+int detect_tensor_grid(tfx_ctx *ctx)
+{
+    hipStream_t s = ctx->stream;
+    const int nx = ctx->nx, ny = ctx->ny, nz = ctx->nz;
+    ctx->tensor_grid = false;
+    TFX_TRY(ctx->edges[0].alloc(nx + 1));
+    TFX_TRY(ctx->edges[1].alloc(ny + 1));
+    TFX_TRY(ctx->edges[2].alloc(nz + 1));
+    DBuf<int> ok;
+    TFX_TRY(ok.alloc(1));
+    int one = 1;
+    TFX_HIP(hipMemcpyAsync(ok.p, &one, sizeof(int), hipMemcpyHostToDevice, s));
+    const int m = std::max(nx, std::max(ny, nz)) + 1;
+    hipLaunchKernelGGL(k_gather_edges, dim3((m + 255) / 256), dim3(256), 0, s, nx, ny, nz, ctx->grid[0].p, ctx->grid[1].p,
+                       ctx->grid[2].p, ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, ctx->edges[0].p, ctx->edges[1].p,
+                       ctx->edges[2].p);
+    const int grid = (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->num_cu * 8);
+    hipLaunchKernelGGL(k_check_tensor, dim3(grid), dim3(256), 0, s, nx, ny, nz, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
+                       ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, ctx->edges[0].p, ctx->edges[1].p, ctx->edges[2].p, ok.p);
+    TFX_HIP(hipGetLastError());
+    int h = 0;
+    TFX_HIP(hipMemcpyAsync(&h, ok.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipStreamSynchronize(s));
+    ctx->tensor_grid = (h == 1) && !ctx->force_general_prism;
+    return 0;
+}
+
+// rows[o*N + p] for a batch of observations already on the device; picks the tensor-grid kernel when it applies
+int prism_rows_dev(tfx_ctx *ctx, int nobs, const double *d_x, const double *d_y, const double *d_z, const double *d_cw,
+                   double *d_rows, int *d_err)
+{
+    hipStream_t s = ctx->stream;
+    const int64_t N = ctx->N;
+    if (ctx->tensor_grid) {
+        const int tiles = ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
+        hipLaunchKernelGGL(k_prism_gz_tensor, dim3(tiles), dim3(256), 0, s, ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p,
+                           ctx->edges[1].p, ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err);
+    } else {
+        const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
+        hipLaunchKernelGGL(k_prism_gz, dim3(grid), dim3(256), 0, s, N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
+                           ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err);
+    }
+    TFX_HIP(hipGetLastError());
+    return 0;
 }
 
 // dmu check: K,L,M in {0,1}; signo(0) = -1, signo(1) = +1; product = (-1)^(number of zeros) = (-1)^(3-(K+L+M));
@@ -683,16 +820,12 @@ int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const doubl
     TFX_TRY(drows.alloc((size_t)B * N));
     TFX_TRY(derr.alloc(1));
     TFX_HIP(hipMemsetAsync(derr.p, 0, sizeof(int), s));
-    const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
     for (int64_t o0 = 0; o0 < ndata; o0 += B) {
         const int nb = (int)std::min<int64_t>(B, ndata - o0);
         TFX_HIP(hipMemcpyAsync(dobs.p, xd + o0, nb * sizeof(double), hipMemcpyDefault, s));
         TFX_HIP(hipMemcpyAsync(dobs.p + B, yd + o0, nb * sizeof(double), hipMemcpyDefault, s));
         TFX_HIP(hipMemcpyAsync(dobs.p + 2 * B, zd + o0, nb * sizeof(double), hipMemcpyDefault, s));
-        hipLaunchKernelGGL(k_prism_gz, dim3(grid), dim3(256), 0, s, N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
-                           ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nb, dobs.p, dobs.p + B, dobs.p + 2 * B,
-                           (const double *)nullptr, drows.p, derr.p);
-        TFX_HIP(hipGetLastError());
+        TFX_TRY(prism_rows_dev(ctx, nb, dobs.p, dobs.p + B, dobs.p + 2 * B, nullptr, drows.p, derr.p));
         TFX_HIP(hipMemcpyAsync(rows_out + o0 * N, drows.p, (size_t)nb * N * sizeof(double), hipMemcpyDefault, s));
         TFX_HIP(hipStreamSynchronize(s));
     }
@@ -858,7 +991,6 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
     SelectWork sw;
     CompactWork cw;
     TFX_TRY(compact_prepare(cw, B, N));
-    const int pgrid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
     const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(256, (N + 255) / 256));
     double err_sum = 0.0;
     int64_t nnz_total = 0;
@@ -869,9 +1001,7 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
         for (int b0 = 0; b0 < nr; b0 += B) {
             const int nb = std::min(B, nr - b0);
             const int64_t g = r0 + b0;
-            hipLaunchKernelGGL(k_prism_gz, dim3(pgrid), dim3(256), 0, s, N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
-                               ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nb, dobs.p + g, dobs.p + ndata + g,
-                               dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p);
+            TFX_TRY(prism_rows_dev(ctx, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p));
             if (compression_type > 0) {
                 hipLaunchKernelGGL(k_row_sumsq, dim3(rgrid, nb), dim3(256), 0, s, drows.p, N, dred.p);             // cost_full :234
                 TFX_HIP(hipGetLastError());

@@ -123,6 +123,9 @@ struct tfx_ctx {
     int nx = 0, ny = 0, nz = 0;
     int64_t N = 0;
     tfx::DBuf<double> grid[6];
+    tfx::DBuf<double> edges[3];       // xe[nx+1], ye[ny+1], ze[nz+1] when the grid is a tensor product
+    bool tensor_grid = false;
+    bool force_general_prism = false; // tests: always use the six-array kernel
     // matrix
     tfx::TiledMatrix mat;
     // scratch vectors for spmv / spmtv with host pointers
@@ -150,4 +153,6 @@ int matrix_finish(tfx_ctx *ctx);
 int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);     // b (+)= S x   (device pointers)
 int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);    // b (+)= S^T x
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
+// build.hip
+int detect_tensor_grid(tfx_ctx *ctx);
 }  // namespace tfx

@@ -240,6 +240,12 @@ class Context:
         check(self._lib.tfx_calc_data(self._h, ptr(x), C.c_double(problem_weight), ptr(dw), ptr(out)))
         return out
 
+    def debug_set(self, key, value=0):
+        rc = self._lib.tfx_debug_set(self._h, key.encode(), int(value))
+        if rc < 0:
+            check(rc)
+        return rc
+
     # ---- timing
     def timer_start(self):
         check(self._lib.tfx_timer_start(self._h))
