@@ -415,3 +415,28 @@ def test_medium_synthetic_build_vs_oracle_and_adjoint_identity(ctx):
     assert abs(np.dot(Sx, y) - np.dot(x, STy)) <= 1e-12 * scale
     assert np.allclose(ctx.mult_vector(2.0 * x - 3.0 * x2), 2.0 * Sx - 3.0 * Sx2, rtol=0, atol=1e-12 * np.abs(Sx).max() * 10)
     assert np.allclose(Sx, orc.spmv(rp, cols, vals, x), rtol=0, atol=1e-12 * np.abs(Sx).max() * 10)
+
+
+def test_fortran_host_through_c_abi(ctx):
+    """The Fortran host (tomofast-x_amd/host, amdflang + iso_c_binding) drives the same C ABI; its fingerprints must match
+    the Python host on the same synthetic problem."""
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tomofast-x_amd", "host", "tfx_host_demo")
+    if not os.path.isfile(exe):
+        pytest.skip("Fortran host not built (no amdflang)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "THE END." in out.stdout, out.stdout + out.stderr
+    f = {k: float(v) for k, v in re.findall(r"(nnz_total|r|lsqr iters|model min|max|data cost) =\s*([-+0-9.Ee]+)", out.stdout)}
+    nx, ny, nz = 16, 12, 8
+    N = nx * ny * nz
+    ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
+    cw = ctx.calculate_depth_weight()
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, 6, 5)
+    res = ctx.calculate_sensit(xs, ys, zs, cw, 1, 0.1)
+    assert int(f["nnz_total"]) == res["nnz"]
+    d_obs = ctx.calc_data(ctx.forward_wavelet(tfx.synthetic.true_model(nx, ny, nz) / cw, nx, ny, nz, 1))
+    x, it, r = ctx.lsqr_solve_sensit(d_obs, 20, 1e-13, 0.0, 0.0, [np.full(N, np.float32(1e-7), np.float32)], [np.zeros(N)])
+    dm = ctx.inverse_wavelet(x, nx, ny, nz, 1) * cw
+    assert int(f["lsqr iters"]) == it
+    assert abs(f["model min"] - dm.min()) <= 1e-6 * abs(dm.min()) and abs(f["max"] - dm.max()) <= 1e-6 * abs(dm.max())

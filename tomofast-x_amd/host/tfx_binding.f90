@@ -1,0 +1,178 @@
+!=========================================================================================================
+! tfx_binding - iso_c_binding interface of libtfx.so (include/tfx.h) for a Fortran host.
+!
+! This is the binding a Tomofast-x maintainer adds to call the MI355X path from the existing Fortran code:
+! each procedure below replaces the body of one reference routine (file:line in include/tfx.h and
+! INTEGRATION.md).  Arrays are passed as assumed-size, contiguous, exactly as the reference holds them
+! (real(8) vectors, real(4) matrix values, 1-based integer(4) column indices).
+!=========================================================================================================
+module tfx_binding
+  use iso_c_binding
+  implicit none
+
+  integer(c_int), parameter :: TFX_OK = 0, TFX_E_ARG = -1, TFX_E_HIP = -2, TFX_E_GEOMETRY = -3, &
+                               TFX_E_STATE = -4, TFX_E_NUMERIC = -5, TFX_E_COMM = -6
+
+  interface
+    integer(c_int) function tfx_create(device, stream, ctx) bind(C, name="tfx_create")
+      import :: c_int, c_ptr
+      integer(c_int), value :: device
+      type(c_ptr), value :: stream
+      type(c_ptr), intent(out) :: ctx
+    end function
+
+    integer(c_int) function tfx_destroy(ctx) bind(C, name="tfx_destroy")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    type(c_ptr) function tfx_last_error() bind(C, name="tfx_last_error")
+      import :: c_ptr
+    end function
+
+    integer(c_int) function tfx_set_allreduce(ctx, fn, user, rank, nranks) bind(C, name="tfx_set_allreduce")
+      import :: c_int, c_ptr, c_funptr
+      type(c_ptr), value :: ctx, user
+      type(c_funptr), value :: fn
+      integer(c_int), value :: rank, nranks
+    end function
+
+    ! t_grid (src/inversion/grid.F90:30-50)
+    integer(c_int) function tfx_set_grid(ctx, nx, ny, nz, X1, X2, Y1, Y2, Z1, Z2) bind(C, name="tfx_set_grid")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nx, ny, nz
+      real(c_double), intent(in) :: X1(*), X2(*), Y1(*), Y2(*), Z1(*), Z2(*)
+    end function
+
+    ! calculate_depth_weight type 1 (src/forward/gravmag/weights_gravmag.f90:46-196)
+    integer(c_int) function tfx_column_weight_type1(ctx, power, Z0, multiplier, cw) bind(C, name="tfx_column_weight_type1")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), value :: power, Z0, multiplier
+      real(c_double), intent(out) :: cw(*)
+    end function
+
+    ! graviprism_z (src/forward/gravmag/grav/gravity_field.f90:131-195)
+    integer(c_int) function tfx_prism_rows_gz(ctx, ndata, xd, yd, zd, rows) bind(C, name="tfx_prism_rows_gz")
+      import :: c_int, c_ptr, c_double, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: ndata
+      real(c_double), intent(in) :: xd(*), yd(*), zd(*)
+      real(c_double), intent(out) :: rows(*)
+    end function
+
+    ! forward_wavelet / inverse_wavelet (src/utils/wavelet_transform.F90:37-70)
+    integer(c_int) function tfx_wavelet(ctx, s, n1, n2, n3, nvec, wtype, direction) bind(C, name="tfx_wavelet")
+      import :: c_int, c_ptr, c_double, c_int64_t
+      type(c_ptr), value :: ctx
+      real(c_double), intent(inout) :: s(*)
+      integer(c_int), value :: n1, n2, n3, wtype, direction
+      integer(c_int64_t), value :: nvec
+    end function
+
+    ! calculate_and_write_sensit + read_sensitivity_kernel (src/forward/gravmag/sensitivity_gravmag.F90:82-410, :648-883)
+    integer(c_int) function tfx_build_kernel_grav(ctx, ndata, xd, yd, zd, column_weight, compression_type, rate, &
+                                                  problem_weight, data_weight, col_begin, col_end, nnz, error_sum, nnz_hist) &
+                                                  bind(C, name="tfx_build_kernel_grav")
+      import :: c_int, c_ptr, c_double, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: ndata, col_begin, col_end
+      real(c_double), intent(in) :: xd(*), yd(*), zd(*), column_weight(*)
+      integer(c_int), value :: compression_type
+      real(c_double), value :: rate, problem_weight
+      type(c_ptr), value :: data_weight      ! c_loc(array) or c_null_ptr
+      integer(c_int64_t), intent(out) :: nnz
+      real(c_double), intent(out) :: error_sum
+      type(c_ptr), value :: nnz_hist         ! c_loc(int32 array of N) or c_null_ptr
+    end function
+
+    ! t_sparse_matrix add_row/new_row/finalize (src/inversion/sparse_matrix.f90:213-293)
+    integer(c_int) function tfx_matrix_upload_csr(ctx, nrows, ncols, rowptr, cols, vals) bind(C, name="tfx_matrix_upload_csr")
+      import :: c_int, c_ptr, c_float, c_int64_t, c_int32_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: nrows, ncols
+      integer(c_int64_t), intent(in) :: rowptr(*)
+      integer(c_int32_t), intent(in) :: cols(*)
+      real(c_float), intent(in) :: vals(*)
+    end function
+
+    integer(c_int) function tfx_matrix_info(ctx, nrows, ncols, nnz, device_bytes) bind(C, name="tfx_matrix_info")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), intent(out) :: nrows, ncols, nnz, device_bytes
+    end function
+
+    ! get_load_balancing_nelements (src/forward/gravmag/sensitivity_gravmag.F90:470-524)
+    integer(c_int) function tfx_partition_columns(nnz_hist, N, nparts, nel_at, nnz_at) bind(C, name="tfx_partition_columns")
+      import :: c_int, c_int64_t, c_int32_t
+      integer(c_int32_t), intent(in) :: nnz_hist(*)
+      integer(c_int64_t), value :: N
+      integer(c_int), value :: nparts
+      integer(c_int32_t), intent(out) :: nel_at(*)
+      integer(c_int64_t), intent(out) :: nnz_at(*)
+    end function
+
+    ! mult_vector / add_mult_vector (src/inversion/sparse_matrix.f90:298-329)
+    integer(c_int) function tfx_spmv(ctx, x, b, add) bind(C, name="tfx_spmv")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(in) :: x(*)
+      real(c_double), intent(inout) :: b(*)
+      integer(c_int), value :: add
+    end function
+
+    ! trans_mult_vector / add_trans_mult_vector (src/inversion/sparse_matrix.f90:373-405)
+    integer(c_int) function tfx_spmtv(ctx, x, b, add) bind(C, name="tfx_spmtv")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(in) :: x(*)
+      real(c_double), intent(inout) :: b(*)
+      integer(c_int), value :: add
+    end function
+
+    ! lsqr_solve_sensit (src/inversion/lsqr_solver2.F90:47-308); diag / rhs_blocks: arrays of c_loc() pointers
+    integer(c_int) function tfx_lsqr_solve(ctx, niter, rmin, gamma, target_misfit, b_data, nblocks, diag, rhs_blocks, &
+                                           x, iters, r) bind(C, name="tfx_lsqr_solve")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: niter, nblocks
+      real(c_double), value :: rmin, gamma, target_misfit
+      real(c_double), intent(in) :: b_data(*)
+      type(c_ptr), intent(in) :: diag(*), rhs_blocks(*)
+      real(c_double), intent(out) :: x(*)
+      integer(c_int), intent(out) :: iters
+      real(c_double), intent(out) :: r
+    end function
+
+    ! model_calculate_data (src/inversion/model.F90:220-307), after un-weighting + wavelet
+    integer(c_int) function tfx_calc_data(ctx, xw, problem_weight, data_weight, data_calc) bind(C, name="tfx_calc_data")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(in) :: xw(*)
+      real(c_double), value :: problem_weight
+      type(c_ptr), value :: data_weight
+      real(c_double), intent(out) :: data_calc(*)
+    end function
+  end interface
+
+contains
+
+  ! The reference's error convention (src/utils/mpi_tools.F90:29-53): print the message and stop.
+  subroutine tfx_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    integer :: i
+    if (rc == 0) return
+    call c_f_pointer(tfx_last_error(), msg, [1024])
+    write(*, '(a)', advance='no') 'tfx error in '//where//': '
+    do i = 1, 1024
+      if (msg(i) == c_null_char) exit
+      write(*, '(a)', advance='no') msg(i)
+    enddo
+    write(*, *)
+    stop 1
+  end subroutine tfx_check
+
+end module tfx_binding
