@@ -153,8 +153,9 @@ def main():
         avg = [prof[0][0] / prof[0][1], prof[1][0] / prof[1][1]]
         dom = 0 if avg[0] >= avg[1] else 1
         achieved = 8.0 * nnz_loc / (avg[dom] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.workload, "k_spmv_fwd" if dom == 0 else "k_spmv_adj", nnz_loc)
         roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": 8 * nnz_loc, "stored_bytes_per_launch": 6 * nnz_loc,
                 "avg_launch_ms": {"spmv_fwd": round(avg[0], 4), "spmv_adj": round(avg[1], 4)},
                 "achieved_other_GBs": round(8.0 * nnz_loc / (avg[1 - dom] * 1e-3) / 1e9, 1)}
@@ -185,6 +186,21 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, kernel, nnz_loc):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_summary.json:
+    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc passes) for this workload and matrix; None when there is none.
+    PMC counters cannot be read from inside the benchmark process, so this is the value measured on the same command."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("workload") == workload and int(d.get("nnz", -1)) == int(nnz_loc) and kernel in d.get("kernels", {}):
+                return d["kernels"][kernel]["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(tfx, w, budget_s, cw, log):

@@ -1,0 +1,83 @@
+"""The real multi-rank path of libtfx.so on the GPU box: 2 processes share GPU 0, torch.distributed with gloo (NCCL/RCCL
+needs one GPU per rank; the hook, the column partition, the rank-local constraint rows and both reductions are the same
+code that runs over RCCL at N > 1).  Compared with the single-rank oracle on the same problem."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tfx = importlib.import_module("tomofast-x_amd")
+        import oracle_lib as orc
+        g = np.load(os.path.join(GOLDEN, "e2e_haar.npz"))
+        dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+        N = int(np.prod(dims))
+        obs = g["obs"]
+        cw = g["np1_column_weight"]
+        ctx = tfx.Context(0)
+        ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+        hook = tfx.distributed.TorchAllreduce(0)
+        ctx.set_allreduce(hook, rank, world)
+        part = tfx.distributed.build_partitioned(ctx, rank, world, obs[:, 0], obs[:, 1], obs[:, 2], cw, 1, float(g["rate"]))
+        c0, c1 = part["col_range"]
+        # the GPU-built histogram may differ from the reference's by a threshold tie or two
+        assert np.all(np.abs(part["nelements_at_cpu"] - g["np2_nelements_at_cpu"]) <= 2)
+        assert abs(part["nnz_total"] - int(g["np1_nnz_total"])) <= 2 * obs.shape[0]
+        # identical matrices on both sides for the solver comparison: upload this rank's slice of the reference's rows
+        import multirank_model as mm
+        S_full = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+        S_loc = mm.column_slice(S_full, c0, c1)
+        ctx.matrix_upload_csr(obs.shape[0], c1 - c0, *S_loc)
+        b = g["np1_data_observed"]
+        alpha = np.float32(float(g["alpha"]))
+        rng = np.random.default_rng(5)
+        rhs_full = rng.standard_normal(N) * 1e-9
+        Cm = orc.diag_csr(np.full(N, alpha, np.float32))
+        for niter, tol in ((3, 1e-11), (25, 1e-3)):
+            x_loc, it, r = ctx.lsqr_solve_sensit(b, niter, 1e-13, 0.0, 0.0, [np.full(c1 - c0, alpha, np.float32)], [rhs_full[c0:c1]])
+            x_ref, it_ref, r_ref = orc.lsqr(S_full, Cm, N, np.concatenate([b, rhs_full]), niter)
+            assert it == it_ref == niter
+            err = np.linalg.norm(x_loc - x_ref[c0:c1]) / np.linalg.norm(x_ref)
+            assert err <= tol, (niter, err)
+        # forward data through the hook (model.F90:288-293)
+        xw = rng.standard_normal(N)
+        d = ctx.calc_data(xw[c0:c1], 1.0, None)
+        assert np.allclose(d, orc.spmv(*S_full, xw), rtol=1e-11, atol=1e-20)
+        ctx.close()
+        q.put((rank, "ok zero_copy=%s" % hook.zero_copy))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu():
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctxm.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg.startswith("ok"), "rank %d: %s" % (rank, msg)
+    print(res)

@@ -40,6 +40,8 @@ __device__ __forceinline__ double corner_term(double XX, double YY, double ZZ, i
     return ZZ * arg3 - XX * arg5 - YY * arg4;                                                       // :186
 }
 
+constexpr int PRISM_MAX_BATCH = 64;      // observations per launch (bounded by the build's batch size, <= 32)
+
 // General grid (six independent arrays): one thread per cell, loops over the observation batch (coordinates are
 // wave-uniform scalar loads).  rows[o*N + p] = G*gz (* cw[p] when cw != null: apply_column_weight,
 // sensitivity_gravmag.F90:1042-1054).
@@ -48,11 +50,20 @@ __global__ __launch_bounds__(256) void k_prism_gz(int64_t N, const double *__res
                                                   const double *__restrict__ Z1, const double *__restrict__ Z2,
                                                   int nobs, const double *__restrict__ xd, const double *__restrict__ yd,
                                                   const double *__restrict__ zd, const double *__restrict__ cw,
-                                                  double *__restrict__ rows, int *__restrict__ err)
+                                                  double *__restrict__ rows, int *__restrict__ err,
+                                                  double *__restrict__ sumsq /* [nobs][gridDim.x] or null */)
 {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
-        const double x1 = X1[p], x2 = X2[p], y1 = Y1[p], y2 = Y2[p], z1 = Z1[p], z2 = Z2[p];
-        const double w = cw ? cw[p] : 1.0;
+    __shared__ double s_sq[PRISM_MAX_BATCH];
+    if (sumsq) {
+        for (int o = threadIdx.x; o < nobs; o += blockDim.x) s_sq[o] = 0.0;
+        __syncthreads();
+    }
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < N; p0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = p0 + threadIdx.x;
+        const bool active = p < N;
+        const int64_t pc = active ? p : N - 1;
+        const double x1 = X1[pc], x2 = X2[pc], y1 = Y1[pc], y2 = Y2[pc], z1 = Z1[pc], z2 = Z2[pc];
+        const double w = cw ? cw[pc] : 1.0;
         for (int o = 0; o < nobs; ++o) {
             double XX[2], YY[2], ZZ[2];
             XX[0] = xd[o] - x1; XX[1] = xd[o] - x2;                     // :151-156
@@ -69,11 +80,21 @@ __global__ __launch_bounds__(256) void k_prism_gz(int64_t N, const double *__res
                         const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;   // signo(K)*signo(L)*signo(M), signo = (-1, +1)
                         gz = gz + dmu * corner_term(XX[K], YY[L], ZZ[M], bad);
                     }
-            if (bad) atomicOr(err, bad);
+            if (bad && active) atomicOr(err, bad);
             double v = g_grav() * gz;                                                               // :192
             if (cw) v = v * w;
-            rows[(int64_t)o * N + p] = v;
+            if (active) rows[(int64_t)o * N + p] = v;
+            if (sumsq) {                                    // cost_full (sensitivity_gravmag.F90:234), diagnostic only
+                double sq = active ? v * v : 0.0;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) sq += __shfl_down(sq, d);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&s_sq[o], sq);
+            }
         }
+    }
+    if (sumsq) {
+        __syncthreads();
+        for (int o = threadIdx.x; o < nobs; o += blockDim.x) sumsq[(int64_t)o * gridDim.x + blockIdx.x] = s_sq[o];
     }
 }
 
@@ -89,9 +110,10 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
                                                          int nobs, const double *__restrict__ xd,
                                                          const double *__restrict__ yd, const double *__restrict__ zd,
                                                          const double *__restrict__ cw, double *__restrict__ rows,
-                                                         int *__restrict__ err)
+                                                         int *__restrict__ err, double *__restrict__ sumsq)
 {
     __shared__ double T[PT_NODES];
+    __shared__ double s_w[4];
     const int tiles_x = (nx + PT_X - 1) / PT_X, tiles_y = (ny + PT_Y - 1) / PT_Y;
     const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
     const int i0 = bx * PT_X, j0 = by * PT_Y, k0 = bz * PT_Z;
@@ -108,6 +130,7 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
             T[(c * (PT_Y + 1) + b) * (PT_X + 1) + a] = corner_term(xo - xe[i0 + a], yo - ye[j0 + b], zo - ze[k0 + c], bad);
         }
         __syncthreads();
+        double sq = 0.0;
         for (int q = threadIdx.x; q < ncell; q += blockDim.x) {
             const int a = q % cx, b = (q / cx) % cy, c = q / (cx * cy);
             double gz = 0.0;
@@ -124,6 +147,14 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
             double v = g_grav() * gz;
             if (cw) v = v * cw[p];
             rows[(int64_t)o * N + p] = v;
+            sq = fma(v, v, sq);
+        }
+        if (sumsq) {                                        // cost_full (sensitivity_gravmag.F90:234), fixed order
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) sq += __shfl_down(sq, d);
+            if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sq;
+            __syncthreads();
+            if (threadIdx.x == 0) sumsq[(int64_t)o * gridDim.x + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
         }
     }
     if (bad) atomicOr(err, bad);
@@ -187,22 +218,48 @@ int detect_tensor_grid(tfx_ctx *ctx)
 }
 
 // rows[o*N + p] for a batch of observations already on the device; picks the tensor-grid kernel when it applies
+// d_sumsq (optional): [nobs][*nblk] partial sums of squares per observation row; *nblk returns the partials per row
 int prism_rows_dev(tfx_ctx *ctx, int nobs, const double *d_x, const double *d_y, const double *d_z, const double *d_cw,
-                   double *d_rows, int *d_err)
+                   double *d_rows, int *d_err, double *d_sumsq = nullptr, int *nblk = nullptr)
 {
+    if (nobs > PRISM_MAX_BATCH) return fail(TFX_E_ARG, "prism batch %d > %d", nobs, PRISM_MAX_BATCH);
     hipStream_t s = ctx->stream;
     const int64_t N = ctx->N;
     if (ctx->tensor_grid) {
         const int tiles = ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
         hipLaunchKernelGGL(k_prism_gz_tensor, dim3(tiles), dim3(256), 0, s, ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p,
-                           ctx->edges[1].p, ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err);
+                           ctx->edges[1].p, ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err, d_sumsq);
+        if (nblk) *nblk = tiles;
     } else {
         const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
         hipLaunchKernelGGL(k_prism_gz, dim3(grid), dim3(256), 0, s, N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
-                           ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err);
+                           ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err, d_sumsq);
+        if (nblk) *nblk = grid;
     }
     TFX_HIP(hipGetLastError());
     return 0;
+}
+
+// number of sum-of-squares partials per row that prism_rows_dev will write
+int prism_partials(tfx_ctx *ctx)
+{
+    if (ctx->tensor_grid) return ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
+    return (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->num_cu * 16);
+}
+
+// out[row] = sum of red[row][0..n) in index order
+__global__ void k_rows_final_sum(const double *__restrict__ red, int n, double *__restrict__ out)
+{
+    const int row = blockIdx.x;
+    const double *r = red + (int64_t)row * n;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += r[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[row] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
 // dmu check: K,L,M in {0,1}; signo(0) = -1, signo(1) = +1; product = (-1)^(number of zeros) = (-1)^(3-(K+L+M));
@@ -283,11 +340,15 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
         qstride = 1;
     }
     const int tid = threadIdx.x, nt = blockDim.x;
+    // e -> (e / nq, e % nq) without an integer division when nq is a power of two (full tiles)
+    const bool nq_pow2 = (nq & (nq - 1)) == 0;
+    const int nq_shift = 31 - __clz(nq);
+#define DIVQ(e) (nq_pow2 ? ((e) >> nq_shift) : ((e) / nq))
     // ---- load
     if (ax.mode == 0) {
         for (int e = tid; e < nq * L; e += nt) { const int q = e / L, a = e - q * L; T[a * P + q] = base[g0 + (int64_t)q * qstride + a]; }
     } else {
-        for (int e = tid; e < nq * L; e += nt) { const int a = e / nq, q = e - a * nq; T[a * P + q] = base[g0 + (int64_t)a * ax.astride + q]; }
+        for (int e = tid; e < nq * L; e += nt) { const int a = DIVQ(e), q = e - a * nq; T[a * P + q] = base[g0 + (int64_t)a * ax.astride + q]; }
     }
     __syncthreads();
     int nscale = 0;
@@ -303,7 +364,7 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
 #define HI(m) T[(ngmin + (m) * step) * P + q]
         if (TYPE == 1 && DIR == 1) {          // Haar forward, wavelet_transform.F90:103-149 (per pair, fused)
             for (int e = tid; e < work; e += nt) {
-                const int m = e / nq, q = e - m * nq;
+                const int m = DIVQ(e), q = e - m * nq;
                 double lo = LO(m), hi = HI(m);
                 hi = hi - lo;
                 lo = lo + hi / 2.0;
@@ -314,7 +375,7 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
             __syncthreads();
         } else if (TYPE == 1 && DIR == 2) {   // Haar inverse, :186-232
             for (int e = tid; e < work; e += nt) {
-                const int m = e / nq, q = e - m * nq;
+                const int m = DIVQ(e), q = e - m * nq;
                 double lo = LO(m), hi = HI(m);
                 lo = lo / wc.sq2;
                 hi = hi * wc.sq2;
@@ -324,38 +385,38 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
             }
             __syncthreads();
         } else if (TYPE == 2 && DIR == 1) {   // D4 forward, :284-365
-            for (int e = tid; e < work; e += nt) { const int m = e / nq, q = e - m * nq; LO(m) = LO(m) + HI(m) * wc.c0; }
+            for (int e = tid; e < work; e += nt) { const int m = DIVQ(e), q = e - m * nq; LO(m) = LO(m) + HI(m) * wc.c0; }
             __syncthreads();
             for (int e = tid; e < work; e += nt) {
-                const int m = e / nq, q = e - m * nq;
+                const int m = DIVQ(e), q = e - m * nq;
                 const double prev = (m == 0) ? T[ilmax * P + q] : LO(m - 1);
                 HI(m) = HI(m) - LO(m) * wc.c1 - prev * wc.c2;
             }
             __syncthreads();
             for (int e = tid; e < work; e += nt) {
-                const int m = e / nq, q = e - m * nq;
+                const int m = DIVQ(e), q = e - m * nq;
                 const double nxt = (m == ng - 1) ? HI(0) : HI(m + 1);
                 LO(m) = LO(m) - nxt;
             }
             __syncthreads();
-            for (int e = tid; e < work; e += nt) { const int m = e / nq, q = e - m * nq; LO(m) = LO(m) * wc.c3; HI(m) = HI(m) * wc.c4; }
+            for (int e = tid; e < work; e += nt) { const int m = DIVQ(e), q = e - m * nq; LO(m) = LO(m) * wc.c3; HI(m) = HI(m) * wc.c4; }
             __syncthreads();
         } else {                              // D4 inverse, :413-495
-            for (int e = tid; e < work; e += nt) { const int m = e / nq, q = e - m * nq; LO(m) = LO(m) * wc.c4; HI(m) = HI(m) * wc.c3; }
+            for (int e = tid; e < work; e += nt) { const int m = DIVQ(e), q = e - m * nq; LO(m) = LO(m) * wc.c4; HI(m) = HI(m) * wc.c3; }
             __syncthreads();
             for (int e = tid; e < work; e += nt) {
-                const int m = e / nq, q = e - m * nq;
+                const int m = DIVQ(e), q = e - m * nq;
                 const double nxt = (m == ng - 1) ? HI(0) : HI(m + 1);
                 LO(m) = LO(m) + nxt;
             }
             __syncthreads();
             for (int e = tid; e < work; e += nt) {
-                const int m = e / nq, q = e - m * nq;
+                const int m = DIVQ(e), q = e - m * nq;
                 const double prev = (m == 0) ? T[ilmax * P + q] : LO(m - 1);
                 HI(m) = HI(m) + LO(m) * wc.c1 + prev * wc.c2;
             }
             __syncthreads();
-            for (int e = tid; e < work; e += nt) { const int m = e / nq, q = e - m * nq; LO(m) = LO(m) - HI(m) * wc.c0; }
+            for (int e = tid; e < work; e += nt) { const int m = DIVQ(e), q = e - m * nq; LO(m) = LO(m) - HI(m) * wc.c0; }
             __syncthreads();
         }
 #undef LO
@@ -365,8 +426,9 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
     if (ax.mode == 0) {
         for (int e = tid; e < nq * L; e += nt) { const int q = e / L, a = e - q * L; base[g0 + (int64_t)q * qstride + a] = T[a * P + q]; }
     } else {
-        for (int e = tid; e < nq * L; e += nt) { const int a = e / nq, q = e - a * nq; base[g0 + (int64_t)a * ax.astride + q] = T[a * P + q]; }
+        for (int e = tid; e < nq * L; e += nt) { const int a = DIVQ(e), q = e - a * nq; base[g0 + (int64_t)a * ax.astride + q] = T[a * P + q]; }
     }
+#undef DIVQ
 }
 
 static WaveConst wave_consts()
@@ -427,13 +489,13 @@ int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, i
         } else if (axis == 1) {
             if (n2 < 2) continue;
             ax.L = n2; ax.mode = 1; ax.astride = n1; ax.inner = n1; ax.outer_stride = (int64_t)n1 * n2;
-            TFX_TRY(pick_xt(n2, n1, 16, &ax.XT, &ax.P));
+            TFX_TRY(pick_xt(n2, n1, 32, &ax.XT, &ax.P));
             ax.ntiles_inner = (n1 + ax.XT - 1) / ax.XT;
             ntiles = (unsigned)(ax.ntiles_inner * n3);
         } else {
             if (n3 < 2) continue;
             ax.L = n3; ax.mode = 1; ax.astride = (int64_t)n1 * n2; ax.inner = (int64_t)n1 * n2; ax.outer_stride = 0;
-            TFX_TRY(pick_xt(n3, ax.inner, 16, &ax.XT, &ax.P));
+            TFX_TRY(pick_xt(n3, ax.inner, 32, &ax.XT, &ax.P));
             ax.ntiles_inner = (ax.inner + ax.XT - 1) / ax.XT;
             ntiles = (unsigned)ax.ntiles_inner;
         }
@@ -636,16 +698,18 @@ struct CompactArgs {
 
 __device__ __forceinline__ bool keep_elem(double v, double thr, int keep_all) { return keep_all || fabs(v) > thr; }
 
+// A block owns CMP_SEG = 8 x 256 consecutive elements; thread t reads elements base + k*256 + t (coalesced).
 __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
 {
     const int row = blockIdx.y, seg = blockIdx.x;
     const double *r = a.rows + (int64_t)row * a.N;
     const double thr = a.thr[row];
-    const int64_t base = (int64_t)seg * CMP_SEG + (int64_t)threadIdx.x * CMP_PER_THREAD;
+    const int64_t base = (int64_t)seg * CMP_SEG + threadIdx.x;
     int cnt = 0, cnt_all = 0;
     double cost = 0.0;
+#pragma unroll
     for (int k = 0; k < CMP_PER_THREAD; ++k) {
-        const int64_t p = base + k;
+        const int64_t p = base + (int64_t)k * CMP_THREADS;
         if (p < a.N) {
             const double v = r[p];
             if (keep_elem(v, thr, a.keep_all)) {
@@ -704,38 +768,44 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_write(CompactArgs a)
     const double *r = a.rows + (int64_t)row * a.N;
     const double thr = a.thr[row];
     const float sc = a.scale ? a.scale[row] : 1.0f;
-    const int64_t base = (int64_t)seg * CMP_SEG + (int64_t)threadIdx.x * CMP_PER_THREAD;
+    const int64_t base = (int64_t)seg * CMP_SEG + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = CMP_THREADS / 64;
+    __shared__ int wcnt[CMP_PER_THREAD * NW];           // kept count of (sub-block k, wave w), column order = (k, w, lane)
     double v[CMP_PER_THREAD];
+    int lpre[CMP_PER_THREAD];
     unsigned keepmask = 0;
+#pragma unroll
     for (int k = 0; k < CMP_PER_THREAD; ++k) {
-        const int64_t p = base + k;
+        const int64_t p = base + (int64_t)k * CMP_THREADS;
         v[k] = 0.0;
+        bool keep = false;
         if (p < a.N && p >= a.col_begin && p < a.col_end) {
             v[k] = r[p];
-            if (keep_elem(v[k], thr, a.keep_all)) keepmask |= 1u << k;
+            keep = keep_elem(v[k], thr, a.keep_all);
         }
+        const unsigned long long m = __ballot(keep);
+        lpre[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (keep) keepmask |= 1u << k;
+        if (lane == 0) wcnt[k * NW + wave] = __popcll(m);
     }
-    const int mine = __popc(keepmask);
-    // exclusive scan over the block's threads (thread order = column order)
-    int incl = mine;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-    __shared__ int wsum[CMP_THREADS / 64];
-    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int woff = 0;
-    for (int i = 0; i < wave; ++i) woff += wsum[i];
-    int pos = a.seg_off[(int64_t)row * a.nseg + seg] + woff + incl - mine;
+    if (threadIdx.x == 0) {                              // exclusive scan of the 32 (k, w) counts
+        int run = 0;
+        for (int i = 0; i < CMP_PER_THREAD * NW; ++i) { const int c = wcnt[i]; wcnt[i] = run; run += c; }
+    }
+    __syncthreads();
+    const int segoff = a.seg_off[(int64_t)row * a.nseg + seg];
     int32_t *oc = a.out_cols + (int64_t)row * a.out_stride;
     float *ov = a.out_vals + (int64_t)row * a.out_stride;
+#pragma unroll
     for (int k = 0; k < CMP_PER_THREAD; ++k)
         if (keepmask & (1u << k)) {
-            oc[pos] = (int32_t)(base + k - a.col_begin);
+            const int pos = segoff + wcnt[k * NW + wave] + lpre[k];
+            oc[pos] = (int32_t)(base + (int64_t)k * CMP_THREADS - a.col_begin);
             float f = (float)v[k];                           // real(x, MATRIX_PRECISION), :265
             if (a.scale) f = f * sc;                         // :841
             ov[pos] = f;
-            ++pos;
         }
 }
 
@@ -973,7 +1043,10 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
     // rows processed per batch: row buffer + select candidates (2x) must stay around 6 GB
     const int B = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, RB), (int64_t)(1u << 28) / N));
     TFX_TRY(drows.alloc((size_t)B * N));
-    TFX_TRY(dred.alloc((size_t)B * 256));
+    const int npart = prism_partials(ctx);
+    DBuf<double> dcf;
+    TFX_TRY(dred.alloc((size_t)B * npart));
+    TFX_TRY(dcf.alloc(B));
     DBuf<int32_t> ell_cols, ell_nel;
     DBuf<float> ell_vals, dscale;
     DBuf<int64_t> ell_off;
@@ -991,19 +1064,19 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
     SelectWork sw;
     CompactWork cw;
     TFX_TRY(compact_prepare(cw, B, N));
-    const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(256, (N + 255) / 256));
     double err_sum = 0.0;
     int64_t nnz_total = 0;
-    std::vector<double> h_red((size_t)B * rgrid), h_cd(B);
+    std::vector<double> h_red(B), h_cd(B);
     std::vector<int32_t> h_nel(RB), h_nel_all(B);
     for (int64_t r0 = 0; r0 < ndata; r0 += RB) {
         const int nr = (int)std::min<int64_t>(RB, ndata - r0);
         for (int b0 = 0; b0 < nr; b0 += B) {
             const int nb = std::min(B, nr - b0);
             const int64_t g = r0 + b0;
-            TFX_TRY(prism_rows_dev(ctx, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p));
+            TFX_TRY(prism_rows_dev(ctx, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p,
+                                   compression_type > 0 ? dred.p : nullptr, nullptr));
             if (compression_type > 0) {
-                hipLaunchKernelGGL(k_row_sumsq, dim3(rgrid, nb), dim3(256), 0, s, drows.p, N, dred.p);             // cost_full :234
+                hipLaunchKernelGGL(k_rows_final_sum, dim3(nb), dim3(256), 0, s, dred.p, npart, dcf.p);             // cost_full :234
                 TFX_HIP(hipGetLastError());
                 TFX_TRY(wavelet_dev(ctx, drows.p, ctx->nx, ctx->ny, ctx->nz, nb, compression_type, 1));              // :237
                 TFX_TRY(select_threshold_dev(ctx, sw, drows.p, nb, N, K, cw.thr.p));                                 // :240-256
@@ -1015,16 +1088,14 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
             // per-row statistics
             TFX_HIP(hipMemcpyAsync(h_nel_all.data(), cw.nel_all.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             if (compression_type > 0) {
-                TFX_HIP(hipMemcpyAsync(h_red.data(), dred.p, (size_t)nb * rgrid * sizeof(double), hipMemcpyDeviceToHost, s));
+                TFX_HIP(hipMemcpyAsync(h_red.data(), dcf.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, s));
                 TFX_HIP(hipMemcpyAsync(h_cd.data(), cw.cost_disc.p, nb * sizeof(double), hipMemcpyDeviceToHost, s));
             }
             TFX_HIP(hipStreamSynchronize(s));
             for (int i = 0; i < nb; ++i) {
                 if (h_nel_all[i] > K) return fail(TFX_E_NUMERIC, "Wrong number of elements in calculate_and_write_sensit!");
                 if (compression_type > 0) {
-                    double cf = 0.0;
-                    for (int k = 0; k < rgrid; ++k) cf += h_red[(size_t)i * rgrid + k];
-                    err_sum += std::sqrt(h_cd[i] / cf);                                                            // :283
+                    err_sum += std::sqrt(h_cd[i] / h_red[i]);                                                            // :283
                 }
             }
         }
