@@ -344,11 +344,23 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
     const bool nq_pow2 = (nq & (nq - 1)) == 0;
     const int nq_shift = 31 - __clz(nq);
 #define DIVQ(e) (nq_pow2 ? ((e) >> nq_shift) : ((e) / nq))
-    // ---- load
-    if (ax.mode == 0) {
-        for (int e = tid; e < nq * L; e += nt) { const int q = e / L, a = e - q * L; T[a * P + q] = base[g0 + (int64_t)q * qstride + a]; }
-    } else {
-        for (int e = tid; e < nq * L; e += nt) { const int a = DIVQ(e), q = e - a * nq; T[a * P + q] = base[g0 + (int64_t)a * ax.astride + q]; }
+    // ---- load: 8 independent global loads in flight per thread, then the LDS writes
+    const int total = nq * L;
+    for (int e0 = tid; e0 < total; e0 += nt * 8) {
+        double tmp[8];
+        int la[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + k * nt;
+            la[k] = -1;
+            if (e < total) {
+                if (ax.mode == 0) { const int q = e / L, a = e - q * L; la[k] = a * P + q; tmp[k] = base[g0 + (int64_t)q * qstride + a]; }
+                else { const int a = DIVQ(e), q = e - a * nq; la[k] = a * P + q; tmp[k] = base[g0 + (int64_t)a * ax.astride + q]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (la[k] >= 0) T[la[k]] = tmp[k];
     }
     __syncthreads();
     int nscale = 0;
@@ -423,10 +435,15 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
 #undef HI
     }
     // ---- store
-    if (ax.mode == 0) {
-        for (int e = tid; e < nq * L; e += nt) { const int q = e / L, a = e - q * L; base[g0 + (int64_t)q * qstride + a] = T[a * P + q]; }
-    } else {
-        for (int e = tid; e < nq * L; e += nt) { const int a = DIVQ(e), q = e - a * nq; base[g0 + (int64_t)a * ax.astride + q] = T[a * P + q]; }
+    for (int e0 = tid; e0 < total; e0 += nt * 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + k * nt;
+            if (e < total) {
+                if (ax.mode == 0) { const int q = e / L, a = e - q * L; base[g0 + (int64_t)q * qstride + a] = T[a * P + q]; }
+                else { const int a = DIVQ(e), q = e - a * nq; base[g0 + (int64_t)a * ax.astride + q] = T[a * P + q]; }
+            }
+        }
     }
 #undef DIVQ
 }
@@ -489,13 +506,13 @@ int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, i
         } else if (axis == 1) {
             if (n2 < 2) continue;
             ax.L = n2; ax.mode = 1; ax.astride = n1; ax.inner = n1; ax.outer_stride = (int64_t)n1 * n2;
-            TFX_TRY(pick_xt(n2, n1, 32, &ax.XT, &ax.P));
+            TFX_TRY(pick_xt(n2, n1, 16, &ax.XT, &ax.P));
             ax.ntiles_inner = (n1 + ax.XT - 1) / ax.XT;
             ntiles = (unsigned)(ax.ntiles_inner * n3);
         } else {
             if (n3 < 2) continue;
             ax.L = n3; ax.mode = 1; ax.astride = (int64_t)n1 * n2; ax.inner = (int64_t)n1 * n2; ax.outer_stride = 0;
-            TFX_TRY(pick_xt(n3, ax.inner, 32, &ax.XT, &ax.P));
+            TFX_TRY(pick_xt(n3, ax.inner, 16, &ax.XT, &ax.P));
             ax.ntiles_inner = (ax.inner + ax.XT - 1) / ax.XT;
             ntiles = (unsigned)ax.ntiles_inner;
         }
@@ -580,12 +597,15 @@ __global__ void k_sel_pick(SelState *__restrict__ st, unsigned int *__restrict__
     for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) g[i] = 0;     // ready for the next digit
 }
 
-// keep the keys that fall into the picked bin
+// keep the keys that fall into the picked bin.  Each wave stages its candidates in LDS and reserves output space with
+// one global atomic per flush (same-address device atomics serialise at the memory side).
+constexpr int SEL_STAGE = 512;
 __global__ __launch_bounds__(256) void k_sel_filter(const double *__restrict__ rows, int64_t N,
                                                     const unsigned long long *__restrict__ cand_in,
                                                     unsigned long long *__restrict__ cand_out, int64_t cand_stride,
                                                     SelState *__restrict__ st, int digit)
 {
+    __shared__ unsigned long long stage[4][SEL_STAGE];
     const int row = blockIdx.y;
     const int shift = c_sel_shift[digit];
     const unsigned int mask = (1u << c_sel_bits[digit]) - 1u;
@@ -594,12 +614,43 @@ __global__ __launch_bounds__(256) void k_sel_filter(const double *__restrict__ r
     const int64_t n = (digit == 0) ? N : (int64_t)st[row].ncand;
     const double *r = rows + (int64_t)row * N;
     const unsigned long long *c = cand_in + (int64_t)row * cand_stride;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long key = (digit == 0) ? (unsigned long long)__double_as_longlong(fabs(r[i])) : c[i];
-        if (((unsigned int)(key >> shift) & mask) == bin) {
-            const unsigned long long pos = atomicAdd(&st[row].nnext, 1ull);
-            out[pos] = key;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long *mine = stage[wave];
+    int fill = 0;                                                   // wave-uniform
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + wave * 64; i0 < n; i0 += stride) {
+        const int64_t i = i0 + lane;
+        unsigned long long key = 0;
+        bool hit = false;
+        if (i < n) {
+            key = (digit == 0) ? (unsigned long long)__double_as_longlong(fabs(r[i])) : c[i];
+            hit = ((unsigned int)(key >> shift) & mask) == bin;
         }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (hit) mine[fill + pre] = key;
+            fill += __popcll(m);
+            if (fill > SEL_STAGE - 64) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&st[row].nnext, (unsigned long long)fill);
+                base = __shfl(base, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // staged keys of all lanes visible to the wave
+                __builtin_amdgcn_wave_barrier();
+                for (int k = lane; k < fill; k += 64) out[base + k] = mine[k];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                fill = 0;
+            }
+        }
+    }
+    if (fill > 0) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&st[row].nnext, (unsigned long long)fill);
+        base = __shfl(base, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < fill; k += 64) out[base + k] = mine[k];
     }
 }
 
@@ -684,6 +735,7 @@ struct CompactArgs {
     int64_t col_begin, col_end;   // columns kept by this rank, output column = p - col_begin
     int nseg;                 // segments per row
     int32_t *seg_cnt;         // [nrows][nseg] kept-in-range counts
+    int32_t *seg_all;         // [nrows][nseg] kept over all columns
     int32_t *seg_off;         // [nrows][nseg] exclusive scan
     double *seg_cost;         // [nrows][nseg] sum of discarded^2
     int32_t *out_cols;        // [.. ][stride]
@@ -731,8 +783,8 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
         double cs = 0.0;
         for (int i = 0; i < CMP_THREADS / 64; ++i) { c += s_cnt[i]; ca += s_all[i]; cs += s_cost[i]; }
         a.seg_cnt[(int64_t)row * a.nseg + seg] = c;
+        a.seg_all[(int64_t)row * a.nseg + seg] = ca;
         a.seg_cost[(int64_t)row * a.nseg + seg] = cs;
-        atomicAdd(&a.nel_all[row], ca);
     }
 }
 
@@ -740,21 +792,27 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
 __global__ void k_cmp_scan(CompactArgs a)
 {
     const int row = blockIdx.x;
-    __shared__ int part[256];
+    __shared__ int part[256], apart[256];
     __shared__ double cpart[256];
     const int per = (a.nseg + 255) / 256;
     const int b = threadIdx.x * per, e = min(b + per, a.nseg);
-    int s = 0;
+    int s = 0, sa = 0;
     double cs = 0.0;
-    for (int i = b; i < e; ++i) { s += a.seg_cnt[(int64_t)row * a.nseg + i]; cs += a.seg_cost[(int64_t)row * a.nseg + i]; }
+    for (int i = b; i < e; ++i) {
+        s += a.seg_cnt[(int64_t)row * a.nseg + i];
+        sa += a.seg_all[(int64_t)row * a.nseg + i];
+        cs += a.seg_cost[(int64_t)row * a.nseg + i];
+    }
     part[threadIdx.x] = s;
+    apart[threadIdx.x] = sa;
     cpart[threadIdx.x] = cs;
     __syncthreads();
     if (threadIdx.x == 0) {
-        int run = 0;
+        int run = 0, arun = 0;
         double crun = 0.0;
-        for (int i = 0; i < 256; ++i) { int v = part[i]; part[i] = run; run += v; crun += cpart[i]; }
+        for (int i = 0; i < 256; ++i) { int v = part[i]; part[i] = run; run += v; arun += apart[i]; crun += cpart[i]; }
         a.nel[row] = run;
+        a.nel_all[row] = arun;
         a.cost_disc[row] = crun;
     }
     __syncthreads();
@@ -826,7 +884,7 @@ __global__ __launch_bounds__(256) void k_row_sumsq(const double *__restrict__ ro
 }
 
 struct CompactWork {
-    DBuf<int32_t> seg_cnt, seg_off, nel, nel_all;
+    DBuf<int32_t> seg_cnt, seg_all, seg_off, nel, nel_all;
     DBuf<double> seg_cost, cost_disc, thr, red;
     DBuf<float> scale;
     int cap_rows = 0;
@@ -839,6 +897,7 @@ static int compact_prepare(CompactWork &cw, int nrows, int64_t N)
     if (cw.cap_rows >= nrows && cw.nseg == nseg) return 0;
     TFX_TRY(cw.seg_cnt.alloc((size_t)nrows * nseg));
     TFX_TRY(cw.seg_off.alloc((size_t)nrows * nseg));
+    TFX_TRY(cw.seg_all.alloc((size_t)nrows * nseg));
     TFX_TRY(cw.seg_cost.alloc((size_t)nrows * nseg));
     TFX_TRY(cw.nel.alloc(nrows));
     TFX_TRY(cw.nel_all.alloc(nrows));
@@ -859,10 +918,9 @@ static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int 
     hipStream_t s = ctx->stream;
     CompactArgs a{};
     a.rows = d_rows; a.N = N; a.thr = cw.thr.p; a.keep_all = keep_all; a.col_begin = col_begin; a.col_end = col_end;
-    a.nseg = cw.nseg; a.seg_cnt = cw.seg_cnt.p; a.seg_off = cw.seg_off.p; a.seg_cost = cw.seg_cost.p;
+    a.nseg = cw.nseg; a.seg_cnt = cw.seg_cnt.p; a.seg_all = cw.seg_all.p; a.seg_off = cw.seg_off.p; a.seg_cost = cw.seg_cost.p;
     a.out_cols = out_cols; a.out_vals = out_vals; a.out_stride = out_stride; a.nel = d_nel_out; a.nel_all = cw.nel_all.p;
     a.cost_disc = cw.cost_disc.p; a.scale = d_scale; a.hist = d_hist;
-    TFX_HIP(hipMemsetAsync(cw.nel_all.p, 0, nrows * sizeof(int32_t), s));
     hipLaunchKernelGGL(k_cmp_count, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_cmp_scan, dim3(nrows), dim3(256), 0, s, a);
     if (out_cols) hipLaunchKernelGGL(k_cmp_write, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
