@@ -68,6 +68,12 @@ int tfx_column_weight_type1(tfx_ctx *ctx, double power, double Z0, double multip
 /* graviprism_z (src/forward/gravmag/grav/gravity_field.f90:131-195): ndata rows of N, rows_out[ndata*N].    */
 int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
                       double *rows_out);
+/* magnetic_field_magprism + sharmbox + dircos (src/forward/gravmag/mag/magnetic_field.f90:118-297, :321-457, :91-110)
+ * for the scalar-susceptibility model and TMI data (nModelComponents = nDataComponents = 1): ndata rows of N.
+ * incl / decl / azim in degrees, intensity in nT (parfile keys forward.magneticField.*).  Observations strictly
+ * inside a cell take the reference's 6-sub-box split (:139-226).                                             */
+int tfx_prism_rows_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double incl,
+                       double decl, double azim, double intensity, double *rows_out);
 /* forward_wavelet / inverse_wavelet (src/utils/wavelet_transform.F90:37-70), in place on nvec arrays of
  * n1*n2*n3 doubles stored back to back.  type 1 Haar, 2 D4; direction 1 forward, 2 inverse.                 */
 int tfx_wavelet(tfx_ctx *ctx, double *s, int n1, int n2, int n3, int64_t nvec, int type, int direction);
@@ -89,6 +95,13 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
                           const double *column_weight, int compression_type, double rate, double problem_weight,
                           const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
                           double *error_sum_out, int32_t *nnz_hist_out);
+
+/* The same for the magnetic problem (problem_type 2, sensitivity_gravmag.F90:215-219): rows from magprism.  */
+int tfx_build_kernel_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
+                         const double *column_weight, double incl, double decl, double azim, double intensity,
+                         int compression_type, double rate, double problem_weight, const double *data_weight,
+                         int64_t col_begin, int64_t col_end, int64_t *nnz_out, double *error_sum_out,
+                         int32_t *nnz_hist_out);
 
 /* Alternative to building: upload a CSR (what read_sensitivity_kernel assembles from SENSIT files;
  * t_sparse_matrix add_row/new_row/finalize, src/inversion/sparse_matrix.f90:213-293).  rowptr: nrows+1

@@ -43,6 +43,100 @@ int orc_graviprism_z(int64_t n, const double *X1, const double *X2, const double
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Magnetic kernel: magnetic_field.f90.  dircos (:91-110), sharmbox (:321-457), magprism (:118-297) for the
+ * scalar-susceptibility model and TMI data (nmodel_components = ndata_components = 1).
+ * ------------------------------------------------------------------------------------------- */
+void orc_dircos(double incl, double decl, double azim, double *magv)
+{
+    const double PI = 3.14159265358979323846;
+    const double d2rad = PI / 180.0;                                    /* :28 */
+    double decl2 = fmod(450.0 - decl, 360.0);                           /* :99 */
+    double xincl = incl * d2rad, xdecl = decl2 * d2rad, xazim = azim * d2rad;
+    magv[0] = cos(xincl) * cos(xdecl - xazim);                          /* :106-108 */
+    magv[1] = cos(xincl) * sin(xdecl - xazim);
+    magv[2] = sin(xincl);
+}
+
+/* returns 0, or -1 / -2 when the X / Y grid boundary coincides with the data position (:345-354) */
+static int sharmbox(double x0, double y0, double z0, double x1, double y1, double z1, double x2, double y2, double z2,
+                    double *tx, double *ty, double *tz)
+{
+    const double eps = 0.;
+    double rx1 = x1 - x0 + eps, rx2 = x2 - x0 + eps;                    /* :336-341 */
+    double ry1 = y1 - y0 + eps, ry2 = y2 - y0 + eps;
+    double rz1 = z1 - z0 + eps, rz2 = z2 - z0 + eps;
+    if (rx1 == 0. || rx2 == 0.) return -1;
+    if (ry1 == 0. || ry2 == 0.) return -2;
+    double rx1sq = rx1 * rx1, rx2sq = rx2 * rx2, ry1sq = ry1 * ry1, ry2sq = ry2 * ry2, rz1sq = rz1 * rz1, rz2sq = rz2 * rz2;
+    double R1 = ry2sq + rx2sq, R2 = ry2sq + rx1sq, R3 = ry1sq + rx2sq, R4 = ry1sq + rx1sq;     /* :361-364 */
+    double a1 = sqrt(rz2sq + R2), a2 = sqrt(rz2sq + R1), a3 = sqrt(rz1sq + R1), a4 = sqrt(rz1sq + R2);
+    double a5 = sqrt(rz2sq + R3), a6 = sqrt(rz2sq + R4), a7 = sqrt(rz1sq + R4), a8 = sqrt(rz1sq + R3);
+    tx[0] = atan2(ry1 * rz2, (rx2 * a5 + eps)) - atan2(ry2 * rz2, (rx2 * a2 + eps)) + atan2(ry2 * rz1, (rx2 * a3 + eps)) -
+            atan2(ry1 * rz1, (rx2 * a8 + eps)) + atan2(ry2 * rz2, (rx1 * a1 + eps)) - atan2(ry1 * rz2, (rx1 * a6 + eps)) +
+            atan2(ry1 * rz1, (rx1 * a7 + eps)) - atan2(ry2 * rz1, (rx1 * a4 + eps));                  /* :376-383 */
+    ty[0] = log((rz2 + a2 + eps) / (rz1 + a3 + eps)) - log((rz2 + a1 + eps) / (rz1 + a4 + eps)) +
+            log((rz2 + a6 + eps) / (rz1 + a7 + eps)) - log((rz2 + a5 + eps) / (rz1 + a8 + eps));     /* :386-389 */
+    ty[1] = atan2(rx1 * rz2, (ry2 * a1 + eps)) - atan2(rx2 * rz2, (ry2 * a2 + eps)) + atan2(rx2 * rz1, (ry2 * a3 + eps)) -
+            atan2(rx1 * rz1, (ry2 * a4 + eps)) + atan2(rx2 * rz2, (ry1 * a5 + eps)) - atan2(rx1 * rz2, (ry1 * a6 + eps)) +
+            atan2(rx1 * rz1, (ry1 * a7 + eps)) - atan2(rx2 * rz1, (ry1 * a8 + eps));                  /* :392-399 */
+    R1 = ry2sq + rz1sq; R2 = ry2sq + rz2sq; R3 = ry1sq + rz1sq; R4 = ry1sq + rz2sq;                 /* :404-407 */
+    a1 = sqrt(rx1sq + R1); a2 = sqrt(rx2sq + R1); a3 = sqrt(rx1sq + R2); a4 = sqrt(rx2sq + R2);
+    a5 = sqrt(rx1sq + R3); a6 = sqrt(rx2sq + R3); a7 = sqrt(rx1sq + R4); a8 = sqrt(rx2sq + R4);
+    ty[2] = log((rx1 + a1 + eps) / (rx2 + a2 + eps)) - log((rx1 + a3 + eps) / (rx2 + a4 + eps)) +
+            log((rx1 + a7 + eps) / (rx2 + a8 + eps)) - log((rx1 + a5 + eps) / (rx2 + a6 + eps));     /* :419-422 */
+    R1 = rx2sq + rz1sq; R2 = rx2sq + rz2sq; R3 = rx1sq + rz1sq; R4 = rx1sq + rz2sq;                 /* :424-427 */
+    a1 = sqrt(ry1sq + R1); a2 = sqrt(ry2sq + R1); a3 = sqrt(ry1sq + R2); a4 = sqrt(ry2sq + R2);
+    a5 = sqrt(ry1sq + R3); a6 = sqrt(ry2sq + R3); a7 = sqrt(ry1sq + R4); a8 = sqrt(ry2sq + R4);
+    tx[2] = log((ry1 + a1 + eps) / (ry2 + a2 + eps)) - log((ry1 + a3 + eps) / (ry2 + a4 + eps)) +
+            log((ry1 + a7 + eps) / (ry2 + a8 + eps)) - log((ry1 + a5 + eps) / (ry2 + a6 + eps));     /* :439-442 */
+    tz[2] = -1 * (tx[0] + ty[1]);                                                                    /* :446 */
+    tz[1] = ty[2];
+    tx[1] = ty[0];
+    tz[0] = tx[2];
+    return 0;
+}
+
+int orc_magprism_tmi(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                     const double *Z1, const double *Z2, double xd, double yd, double zd, const double *magv,
+                     double intensity, double *line)
+{
+    const double PI = 3.14159265358979323846;
+    for (int64_t i = 0; i < n; ++i) {
+        double tx[3], ty[3], tz[3];
+        int ierr;
+        if (X1[i] < xd && X2[i] > xd && Y1[i] < yd && Y2[i] > yd && Z1[i] < zd && Z2[i] > zd) {     /* :139-141 */
+            double width = (double)0.1f;                                 /* :144 `width = 0.1` (default-real literal) */
+            double min_clr = fmin(fmin(fmin(fabs(xd - X1[i]), fabs(xd - X2[i])), fmin(fabs(yd - Y1[i]), fabs(yd - Y2[i]))),
+                                  fmin(fabs(zd - Z1[i]), fabs(zd - Z2[i])));
+            if (width > min_clr) width = 0.5 * min_clr;                  /* :153 */
+            double bx1[6] = {X1[i], X1[i], X1[i], xd + width, xd - width, xd - width};
+            double bx2[6] = {X2[i], X2[i], xd - width, X2[i], xd + width, xd + width};
+            double by1[6] = {Y1[i], Y1[i], Y1[i], Y1[i], Y1[i], yd + width};
+            double by2[6] = {Y2[i], Y2[i], Y2[i], Y2[i], yd - width, Y2[i]};
+            double bz1[6] = {Z1[i], zd + width, zd - width, zd - width, zd - width, zd - width};
+            double bz2[6] = {zd - width, Z2[i], zd + width, zd + width, zd + width, zd + width};     /* :157-204 */
+            tx[0] = tx[1] = tx[2] = ty[0] = ty[1] = ty[2] = tz[0] = tz[1] = tz[2] = 0.0;
+            for (int j = 0; j < 6; ++j) {                                /* :210-226 */
+                double sx[3], sy[3], sz[3];
+                ierr = sharmbox(xd, yd, zd, bx1[j], by1[j], bz1[j], bx2[j], by2[j], bz2[j], sx, sy, sz);
+                if (ierr) return ierr;
+                for (int k = 0; k < 3; ++k) { tx[k] = tx[k] + sx[k]; ty[k] = ty[k] + sy[k]; tz[k] = tz[k] + sz[k]; }
+            }
+        } else {
+            ierr = sharmbox(xd, yd, zd, X1[i], Y1[i], Z1[i], X2[i], Y2[i], Z2[i], tx, ty, tz);       /* :230-240 */
+            if (ierr) return ierr;
+        }
+        double mx = (tx[0] * magv[0] + tx[1] * magv[1]) + tx[2] * magv[2];                           /* :246-248 */
+        double my = (ty[0] * magv[0] + ty[1] * magv[1]) + ty[2] * magv[2];
+        double mz = (tz[0] * magv[0] + tz[1] * magv[1]) + tz[2] * magv[2];
+        double v = mx * magv[0] + my * magv[1] + mz * magv[2];                                       /* :251 */
+        v = intensity * v;                                                                           /* :287 */
+        line[i] = v / (4.0 * PI);                                                                    /* :295 */
+    }
+    return 0;
+}
+
 int orc_column_weight_type1(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
                             const double *Z1, const double *Z2, double power, double Z0, double multiplier,
                             double *cw)
@@ -226,6 +320,20 @@ int64_t orc_compress_row(const double *row, int64_t N, int64_t K, int32_t *cols,
     return nel;
 }
 
+static int64_t compress_weighted_row(int64_t N, int nx, int ny, int nz, const double *cw, int compression_type,
+                                     int64_t K, double *work, int32_t *cols, float *vals, double *error_r);
+
+int64_t orc_build_row_mag(int64_t N, int nx, int ny, int nz, const double *X1, const double *X2,
+                          const double *Y1, const double *Y2, const double *Z1, const double *Z2,
+                          const double *cw, double xd, double yd, double zd, const double *magv, double intensity,
+                          int compression_type, int64_t K, double *work, int32_t *cols, float *vals, double *error_r,
+                          int *ierr)
+{
+    *ierr = orc_magprism_tmi(N, X1, X2, Y1, Y2, Z1, Z2, xd, yd, zd, magv, intensity, work);   /* sensitivity_gravmag.F90:217-219 */
+    if (*ierr) return 0;
+    return compress_weighted_row(N, nx, ny, nz, cw, compression_type, K, work, cols, vals, error_r);
+}
+
 int64_t orc_build_row_grav(int64_t N, int nx, int ny, int nz, const double *X1, const double *X2,
                            const double *Y1, const double *Y2, const double *Z1, const double *Z2,
                            const double *cw, double xd, double yd, double zd, int compression_type,
@@ -233,6 +341,12 @@ int64_t orc_build_row_grav(int64_t N, int nx, int ny, int nz, const double *X1, 
 {
     *ierr = orc_graviprism_z(N, X1, X2, Y1, Y2, Z1, Z2, xd, yd, zd, work);      /* :196 */
     if (*ierr) return 0;
+    return compress_weighted_row(N, nx, ny, nz, cw, compression_type, K, work, cols, vals, error_r);
+}
+
+static int64_t compress_weighted_row(int64_t N, int nx, int ny, int nz, const double *cw, int compression_type,
+                                     int64_t K, double *work, int32_t *cols, float *vals, double *error_r)
+{
     for (int64_t p = 0; p < N; ++p) work[p] = work[p] * cw[p];                  /* :228, :1042-1054 */
     if (compression_type > 0) {
         double cost_full = 0.0;

@@ -28,6 +28,19 @@ extern "C" {
 int orc_graviprism_z(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
                      const double *Z1, const double *Z2, double xd, double yd, double zd, double *line);
 
+/* src/forward/gravmag/mag/magnetic_field.f90: dircos (:91-110) -> magv[3]; magprism (:118-297) + sharmbox (:321-457)
+ * for scalar susceptibility and TMI data (1 model component, 1 data component), incl. the in-cell 6-sub-box split.
+ * Returns 0 or -1 / -2 (model grid X / Y boundary coincides with the data position, :345-354). */
+void orc_dircos(double incl, double decl, double azim, double *magv);
+int orc_magprism_tmi(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                     const double *Z1, const double *Z2, double xd, double yd, double zd, const double *magv,
+                     double intensity, double *line);
+int64_t orc_build_row_mag(int64_t N, int nx, int ny, int nz, const double *X1, const double *X2,
+                          const double *Y1, const double *Y2, const double *Z1, const double *Z2,
+                          const double *cw, double xd, double yd, double zd, const double *magv, double intensity,
+                          int compression_type, int64_t K, double *work, int32_t *cols, float *vals, double *error_r,
+                          int *ierr);
+
 /* src/forward/gravmag/weights_gravmag.f90:71-79,170-195,204-250 (depth weighting type 1) followed by
  * src/problem_joint_gravmag.F90:178 (column_weight *= multiplier). z_axis: cell centre = (Z1+Z2)/2.
  * Returns 0 or -1 (non-positive depth) / -2 (zero weight). */

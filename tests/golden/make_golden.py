@@ -11,6 +11,7 @@ reference produced for them.  No reference source text is stored.
 Files written:
   wavelet.npz    forward/inverse Haar + D4 on several (odd-sized too) arrays          [gold_wavelet driver]
   prism.npz      graviprism_z rows on a non-uniform 8x6x5 grid                        [gold_prism driver]
+  magprism.npz   magprism rows (TMI, scalar model; obs outside and INSIDE cells)      [gold_magprism driver]
   lsqr.npz       S.x, S^T.y and lsqr_solve_sensit solutions for [S; C] systems        [gold_lsqr driver]
   e2e_*.npz      full `tomofastx -p Parfile` runs: SENSIT rows, weights, nnz, partition, models, data
   mansf.npz      BASELINE config 1 (parfiles/Parfile_mansf_slice.txt), trimmed
@@ -98,6 +99,34 @@ def make_prism(tmp):
     np.savez_compressed(os.path.join(HERE, "prism.npz"), nx=nx, ny=ny, nz=nz, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3],
                         Z1=g[4], Z2=g[5], obs=obs, rows=rows)
     print("prism.npz: rows", rows.shape)
+
+
+def make_magprism(tmp):
+    rng = np.random.default_rng(43)
+    nx, ny, nz = 8, 6, 5
+    g = nonuniform_grid(nx, ny, nz, rng)
+    xe0, xe1 = g[0].min(), g[1].max()
+    ye0, ye1 = g[2].min(), g[3].max()
+    c = 100                                        # a cell for the in-cell (drill-hole) observations
+    obs = np.array([
+        [0.5 * (xe0 + xe1) + 0.37, 0.5 * (ye0 + ye1) + 0.41, -1.0],
+        [xe0 - 150.0, ye0 - 77.0, -25.0],
+        [xe1 + 10.3, 0.5 * (ye0 + ye1), -0.1],
+        [0.5 * (g[0][c] + g[1][c]) + 1.234, 0.5 * (g[2][c] + g[3][c]) - 2.2, 0.5 * (g[4][c] + g[5][c]) + 0.77],   # inside, clearance > 0.1
+        [g[0][c] + 0.03, g[2][c] + 5.0, g[4][c] + 4.0],                                                       # inside, clearance 0.03 < 0.1
+    ])
+    out = dict(nx=nx, ny=ny, nz=nz, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs)
+    nel, nd = nx * ny * nz, obs.shape[0]
+    fg, fo, fout = [os.path.join(tmp, x) for x in ("m_grid.bin", "m_obs.bin", "m_out.bin")]
+    open(fg, "wb").write(b"".join(be(a, ">f8") for a in g))
+    open(fo, "wb").write(be(obs[:, 0], ">f8") + be(obs[:, 1], ">f8") + be(obs[:, 2], ">f8"))
+    fields = [(90.0, 0.0, 0.0, 50000.0), (-62.0, 11.0, 0.0, 57000.0), (35.5, -140.0, 20.0, 43210.0)]
+    out["fields"] = np.array(fields)
+    for fi, (incl, decl, azim, inten) in enumerate(fields):
+        run([os.path.join(REFBIN, "gold_magprism")], stdin="%d %d %.17g %.17g %.17g %.17g\n%s\n%s\n%s\n" % (nel, nd, incl, decl, azim, inten, fg, fo, fout))
+        out["rows_%d" % fi] = np.fromfile(fout, ">f8").astype(np.float64).reshape(nd, nel)
+    np.savez_compressed(os.path.join(HERE, "magprism.npz"), **out)
+    print("magprism.npz: rows", out["rows_0"].shape, "x", len(fields), "fields")
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -361,7 +390,7 @@ def make_mansf(tmp):
 if __name__ == "__main__":
     if not os.path.isfile(os.path.join(REFBIN, "tomofastx")):
         sys.exit("oracle/_ref is not built (run oracle/ref_build.sh in the development container)")
-    what = sys.argv[1:] or ["wavelet", "prism", "lsqr", "e2e", "mansf"]
+    what = sys.argv[1:] or ["wavelet", "prism", "magprism", "lsqr", "e2e", "mansf"]
     with tempfile.TemporaryDirectory() as tmp:
         for w in what:
             globals()["make_" + w](tmp)

@@ -49,6 +49,22 @@ def graviprism_z(grid, xd, yd, zd):
     return ierr, line
 
 
+def dircos(incl, decl, azim):
+    magv = np.empty(3)
+    lib().orc_dircos(C.c_double(incl), C.c_double(decl), C.c_double(azim), dp(magv))
+    return magv
+
+
+def magprism_tmi(grid, xd, yd, zd, magv, intensity):
+    X1, X2, Y1, Y2, Z1, Z2 = [f64(g) for g in grid]
+    n = X1.size
+    line = np.empty(n)
+    magv = f64(magv)
+    ierr = lib().orc_magprism_tmi(C.c_int64(n), dp(X1), dp(X2), dp(Y1), dp(Y2), dp(Z1), dp(Z2), C.c_double(xd), C.c_double(yd),
+                                  C.c_double(zd), dp(magv), C.c_double(intensity), dp(line))
+    return ierr, line
+
+
 def column_weight_type1(grid, power=2.0, Z0=0.0, multiplier=4.0e3):
     X1, X2, Y1, Y2, Z1, Z2 = [f64(g) for g in grid]
     n = X1.size

@@ -122,6 +122,60 @@ def test_prism_tensor_path_bit_identical_to_general(ctx, golden_dir):
     assert np.all(np.abs(r - ref) <= 8 * 2.3e-16 * prism_term_scale(bent, obs[0]))
 
 
+def mag_term_scale(grid, o, inten):
+    """|intensity| / 4 pi times the sum of |atan2| and |log| terms (each O(1..pi)): the tensor entries cancel to O((h/R)^3)."""
+    return abs(inten) / (4 * np.pi) * 60.0 * np.ones(grid[0].size)
+
+
+def test_magprism_rows_vs_reference(ctx, golden_dir):
+    """magprism (TMI, scalar model): observations above, beside and INSIDE cells (6-sub-box split), three field directions."""
+    g = load(golden_dir, "magprism")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    ctx.set_grid(int(g["nx"]), int(g["ny"]), int(g["nz"]), *grid)
+    for fi, field in enumerate(g["fields"]):
+        rows = ctx.magprism(g["obs"][:, 0], g["obs"][:, 1], g["obs"][:, 2], field)
+        for o, r, ref in zip(g["obs"], rows, g["rows_%d" % fi]):
+            # 36 transcendental terms of magnitude <= pi cancel; device libm differs by <= 2 ulp per term
+            assert np.all(np.abs(r - ref) <= 8 * 2.3e-16 * mag_term_scale(grid, o, field[3])), (fi, o)
+            assert np.max(np.abs(r - ref)) <= 1e-9 * np.max(np.abs(ref))
+
+
+def test_magprism_boundary_error(ctx):
+    one = [np.array([v], np.float64) for v in (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)]
+    ctx.set_grid(1, 1, 1, *one)
+    with pytest.raises(tfx.TfxError) as e:
+        ctx.magprism([1.0], [0.5], [-1.0], (90.0, 0.0, 0.0, 5e4))
+    assert e.value.code == -3 and "X-boundary" in str(e.value)
+
+
+def test_build_mag_kernel_vs_oracle(ctx):
+    """Magnetic sensitivity kernel through the same compress / tile pipeline (problem_type 2) vs the oracle's rows."""
+    nx, ny, nz, ox, oy = 24, 20, 10, 4, 3
+    grid = tfx.synthetic.grid(nx, ny, nz)
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, ox, oy)
+    field = (-62.0, 11.0, 0.0, 57000.0)
+    ctx.set_grid(nx, ny, nz, *grid)
+    cw = orc.column_weight_type1(grid, 3.0, 0.0, 1.0)
+    res = ctx.calculate_sensit(xs, ys, zs, cw, 1, 0.2, mag_field=field)
+    rp, cols, vals = ctx.matrix_download_csr()
+    N = nx * ny * nz
+    K = int(0.2 * N)
+    magv = orc.dircos(*field[:3])
+    tot = 0
+    for r in range(xs.size):
+        ierr, row = orc.magprism_tmi(grid, xs[r], ys[r], zs[r], magv, field[3])
+        assert ierr == 0
+        w = orc.wavelet(row * cw, nx, ny, nz, 1)
+        c_ref, v_ref, _, _ = orc.compress_row(w, K)
+        cb, vb = cols[rp[r]:rp[r + 1]], vals[rp[r]:rp[r + 1]]
+        common, ib, ir = np.intersect1d(cb, c_ref, return_indices=True)
+        assert common.size >= 0.995 * c_ref.size and abs(cb.size - c_ref.size) <= 4
+        # values: relative to the row scale (small coefficients carry the cancellation error of the tensor entries)
+        assert np.max(np.abs(vb[ib].astype(np.float64) - v_ref[ir].astype(np.float64))) <= 1e-9 * np.max(np.abs(v_ref))
+        tot += cb.size
+    assert tot == res["nnz"]
+
+
 def test_prism_geometry_error(ctx):
     one = [np.array([v], np.float64) for v in (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)]
     ctx.set_grid(1, 1, 1, *one)

@@ -148,3 +148,24 @@ def test_config1_mansf_end_to_end(golden_dir):
     assert rel <= 1e-9, rel
     assert abs(m.min() - (-19.951562372333093)) < 1e-6 and abs(m.max() - 259.9972445968676) < 1e-6
     assert abs(hist[-1]["cost"] - 9.339172972115141e-11) <= 1e-3 * 9.339172972115141e-11
+
+
+def test_magprism_rows_bit_exact(golden_dir):
+    """magnetic_field.f90 magprism + sharmbox + dircos (TMI, scalar model), observations outside AND inside cells
+    (6-sub-box split with the 0.1f void and the 50 %-of-clearance rule)."""
+    g = load(golden_dir, "magprism")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    for fi, (incl, decl, azim, inten) in enumerate(g["fields"]):
+        magv = orc.dircos(incl, decl, azim)
+        for o, ref in zip(g["obs"], g["rows_%d" % fi]):
+            ierr, row = orc.magprism_tmi(grid, o[0], o[1], o[2], magv, inten)
+            assert ierr == 0
+            assert bits_equal(row, ref), (fi, o)
+
+
+def test_magprism_boundary_error():
+    grid = [np.array([v], np.float64) for v in (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)]
+    ierr, _ = orc.magprism_tmi(grid, 1.0, 0.5, -1.0, orc.dircos(90, 0, 0), 5e4)      # on the X2 face plane
+    assert ierr == -1
+    ierr, _ = orc.magprism_tmi(grid, 0.5, 0.0, -1.0, orc.dircos(90, 0, 0), 5e4)      # on the Y1 face plane
+    assert ierr == -2

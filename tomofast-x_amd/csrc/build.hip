@@ -160,6 +160,133 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
     if (bad) atomicOr(err, bad);
 }
 
+// =============================================================================================================
+// magnetic rows: magprism + sharmbox (src/forward/gravmag/mag/magnetic_field.f90:118-297, :321-457),
+// scalar susceptibility model, TMI data
+// =============================================================================================================
+struct MagField { double magv[3]; double intensity; };
+
+// magnetic tensor of one box; bad |= 4 / 8 when the X / Y grid boundary coincides with the data position (:345-354)
+__device__ __forceinline__ void sharmbox_dev(double x0, double y0, double z0, double x1, double y1, double z1, double x2,
+                                             double y2, double z2, double *tx, double *ty, double *tz, int &bad)
+{
+    const double eps = 0.;
+    const double rx1 = x1 - x0 + eps, rx2 = x2 - x0 + eps;                 // :336-341
+    const double ry1 = y1 - y0 + eps, ry2 = y2 - y0 + eps;
+    const double rz1 = z1 - z0 + eps, rz2 = z2 - z0 + eps;
+    if (rx1 == 0. || rx2 == 0.) bad |= 4;
+    if (ry1 == 0. || ry2 == 0.) bad |= 8;
+    const double rx1sq = rx1 * rx1, rx2sq = rx2 * rx2, ry1sq = ry1 * ry1, ry2sq = ry2 * ry2, rz1sq = rz1 * rz1, rz2sq = rz2 * rz2;
+    double R1 = ry2sq + rx2sq, R2 = ry2sq + rx1sq, R3 = ry1sq + rx2sq, R4 = ry1sq + rx1sq;        // :361-364
+    double a1 = sqrt(rz2sq + R2), a2 = sqrt(rz2sq + R1), a3 = sqrt(rz1sq + R1), a4 = sqrt(rz1sq + R2);
+    double a5 = sqrt(rz2sq + R3), a6 = sqrt(rz2sq + R4), a7 = sqrt(rz1sq + R4), a8 = sqrt(rz1sq + R3);
+    tx[0] = atan2(ry1 * rz2, (rx2 * a5 + eps)) - atan2(ry2 * rz2, (rx2 * a2 + eps)) + atan2(ry2 * rz1, (rx2 * a3 + eps)) -
+            atan2(ry1 * rz1, (rx2 * a8 + eps)) + atan2(ry2 * rz2, (rx1 * a1 + eps)) - atan2(ry1 * rz2, (rx1 * a6 + eps)) +
+            atan2(ry1 * rz1, (rx1 * a7 + eps)) - atan2(ry2 * rz1, (rx1 * a4 + eps));                     // :376-383
+    ty[0] = log((rz2 + a2 + eps) / (rz1 + a3 + eps)) - log((rz2 + a1 + eps) / (rz1 + a4 + eps)) +
+            log((rz2 + a6 + eps) / (rz1 + a7 + eps)) - log((rz2 + a5 + eps) / (rz1 + a8 + eps));        // :386-389
+    ty[1] = atan2(rx1 * rz2, (ry2 * a1 + eps)) - atan2(rx2 * rz2, (ry2 * a2 + eps)) + atan2(rx2 * rz1, (ry2 * a3 + eps)) -
+            atan2(rx1 * rz1, (ry2 * a4 + eps)) + atan2(rx2 * rz2, (ry1 * a5 + eps)) - atan2(rx1 * rz2, (ry1 * a6 + eps)) +
+            atan2(rx1 * rz1, (ry1 * a7 + eps)) - atan2(rx2 * rz1, (ry1 * a8 + eps));                     // :392-399
+    R1 = ry2sq + rz1sq; R2 = ry2sq + rz2sq; R3 = ry1sq + rz1sq; R4 = ry1sq + rz2sq;                    // :404-407
+    a1 = sqrt(rx1sq + R1); a2 = sqrt(rx2sq + R1); a3 = sqrt(rx1sq + R2); a4 = sqrt(rx2sq + R2);
+    a5 = sqrt(rx1sq + R3); a6 = sqrt(rx2sq + R3); a7 = sqrt(rx1sq + R4); a8 = sqrt(rx2sq + R4);
+    ty[2] = log((rx1 + a1 + eps) / (rx2 + a2 + eps)) - log((rx1 + a3 + eps) / (rx2 + a4 + eps)) +
+            log((rx1 + a7 + eps) / (rx2 + a8 + eps)) - log((rx1 + a5 + eps) / (rx2 + a6 + eps));        // :419-422
+    R1 = rx2sq + rz1sq; R2 = rx2sq + rz2sq; R3 = rx1sq + rz1sq; R4 = rx1sq + rz2sq;                    // :424-427
+    a1 = sqrt(ry1sq + R1); a2 = sqrt(ry2sq + R1); a3 = sqrt(ry1sq + R2); a4 = sqrt(ry2sq + R2);
+    a5 = sqrt(ry1sq + R3); a6 = sqrt(ry2sq + R3); a7 = sqrt(ry1sq + R4); a8 = sqrt(ry2sq + R4);
+    tx[2] = log((ry1 + a1 + eps) / (ry2 + a2 + eps)) - log((ry1 + a3 + eps) / (ry2 + a4 + eps)) +
+            log((ry1 + a7 + eps) / (ry2 + a8 + eps)) - log((ry1 + a5 + eps) / (ry2 + a6 + eps));        // :439-442
+    tz[2] = -1 * (tx[0] + ty[1]);                                                                       // :446
+    tz[1] = ty[2];
+    tx[1] = ty[0];
+    tz[0] = tx[2];
+}
+
+__global__ __launch_bounds__(256) void k_magprism_tmi(int64_t N, const double *__restrict__ X1, const double *__restrict__ X2,
+                                                      const double *__restrict__ Y1, const double *__restrict__ Y2,
+                                                      const double *__restrict__ Z1, const double *__restrict__ Z2,
+                                                      int nobs, const double *__restrict__ xd, const double *__restrict__ yd,
+                                                      const double *__restrict__ zd, const double *__restrict__ cw,
+                                                      MagField mf, double *__restrict__ rows, int *__restrict__ err,
+                                                      double *__restrict__ sumsq)
+{
+    const double PI = 3.14159265358979323846;
+    __shared__ double s_sq[PRISM_MAX_BATCH];
+    if (sumsq) {
+        for (int o = threadIdx.x; o < nobs; o += blockDim.x) s_sq[o] = 0.0;
+        __syncthreads();
+    }
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < N; p0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = p0 + threadIdx.x;
+        const bool active = p < N;
+        const int64_t pc = active ? p : N - 1;
+        const double x1 = X1[pc], x2 = X2[pc], y1 = Y1[pc], y2 = Y2[pc], z1 = Z1[pc], z2 = Z2[pc];
+        const double w = cw ? cw[pc] : 1.0;
+        for (int o = 0; o < nobs; ++o) {
+            const double xo = xd[o], yo = yd[o], zo = zd[o];
+            double tx[3], ty[3], tz[3];
+            int bad = 0;
+            if (x1 < xo && x2 > xo && y1 < yo && y2 > yo && z1 < zo && z2 > zo) {                          // :139-141
+                double width = (double)0.1f;                                                               // :144
+                const double min_clr = fmin(fmin(fmin(fabs(xo - x1), fabs(xo - x2)), fmin(fabs(yo - y1), fabs(yo - y2))),
+                                            fmin(fabs(zo - z1), fabs(zo - z2)));
+                if (width > min_clr) width = 0.5 * min_clr;                                                // :153
+                tx[0] = tx[1] = tx[2] = ty[0] = ty[1] = ty[2] = tz[0] = tz[1] = tz[2] = 0.0;
+                for (int j = 0; j < 6; ++j) {                                                              // :157-226
+                    double bx1 = x1, bx2 = x2, by1 = y1, by2 = y2, bz1 = zo - width, bz2 = zo + width;
+                    if (j == 0) { bz1 = z1; bz2 = zo - width; }
+                    else if (j == 1) { bz1 = zo + width; bz2 = z2; }
+                    else if (j == 2) { bx2 = xo - width; }
+                    else if (j == 3) { bx1 = xo + width; }
+                    else if (j == 4) { bx1 = xo - width; bx2 = xo + width; by2 = yo - width; }
+                    else { bx1 = xo - width; bx2 = xo + width; by1 = yo + width; }
+                    double sx[3], sy[3], sz[3];
+                    sharmbox_dev(xo, yo, zo, bx1, by1, bz1, bx2, by2, bz2, sx, sy, sz, bad);
+                    for (int k = 0; k < 3; ++k) { tx[k] = tx[k] + sx[k]; ty[k] = ty[k] + sy[k]; tz[k] = tz[k] + sz[k]; }
+                }
+            } else {
+                sharmbox_dev(xo, yo, zo, x1, y1, z1, x2, y2, z2, tx, ty, tz, bad);                         // :230-240
+            }
+            const double mx = (tx[0] * mf.magv[0] + tx[1] * mf.magv[1]) + tx[2] * mf.magv[2];              // :246-248
+            const double my = (ty[0] * mf.magv[0] + ty[1] * mf.magv[1]) + ty[2] * mf.magv[2];
+            const double mz = (tz[0] * mf.magv[0] + tz[1] * mf.magv[1]) + tz[2] * mf.magv[2];
+            double v = mx * mf.magv[0] + my * mf.magv[1] + mz * mf.magv[2];                                // :251
+            v = mf.intensity * v;                                                                          // :287
+            v = v / (4.0 * PI);                                                                            // :295
+            if (cw) v = v * w;
+            if (bad && active) atomicOr(err, bad);
+            if (active) rows[(int64_t)o * N + p] = v;
+            if (sumsq) {
+                double sq = active ? v * v : 0.0;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) sq += __shfl_down(sq, d);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&s_sq[o], sq);
+            }
+        }
+    }
+    if (sumsq) {
+        __syncthreads();
+        for (int o = threadIdx.x; o < nobs; o += blockDim.x) sumsq[(int64_t)o * gridDim.x + blockIdx.x] = s_sq[o];
+    }
+}
+
+// dircos, magnetic_field.f90:91-110 (host)
+static MagField make_mag_field(double incl, double decl, double azim, double intensity)
+{
+    const double PI = 3.14159265358979323846;
+    const double d2rad = PI / 180.0;
+    const double decl2 = std::fmod(450.0 - decl, 360.0);
+    const double xincl = incl * d2rad, xdecl = decl2 * d2rad, xazim = azim * d2rad;
+    MagField mf;
+    mf.magv[0] = std::cos(xincl) * std::cos(xdecl - xazim);
+    mf.magv[1] = std::cos(xincl) * std::sin(xdecl - xazim);
+    mf.magv[2] = std::sin(xincl);
+    mf.intensity = intensity;
+    return mf;
+}
+
 // Verifies that the six cell arrays describe a tensor-product grid with shared faces; ok[0] is cleared otherwise.
 __global__ void k_check_tensor(int nx, int ny, int nz, const double *__restrict__ X1, const double *__restrict__ X2,
                                const double *__restrict__ Y1, const double *__restrict__ Y2, const double *__restrict__ Z1,
@@ -220,9 +347,18 @@ int detect_tensor_grid(tfx_ctx *ctx)
 // rows[o*N + p] for a batch of observations already on the device; picks the tensor-grid kernel when it applies
 // d_sumsq (optional): [nobs][*nblk] partial sums of squares per observation row; *nblk returns the partials per row
 int prism_rows_dev(tfx_ctx *ctx, int nobs, const double *d_x, const double *d_y, const double *d_z, const double *d_cw,
-                   double *d_rows, int *d_err, double *d_sumsq = nullptr, int *nblk = nullptr)
+                   double *d_rows, int *d_err, double *d_sumsq = nullptr, int *nblk = nullptr, const MagField *mag = nullptr)
 {
     if (nobs > PRISM_MAX_BATCH) return fail(TFX_E_ARG, "prism batch %d > %d", nobs, PRISM_MAX_BATCH);
+    if (mag) {
+        hipStream_t s = ctx->stream;
+        const int grid = (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->num_cu * 16);
+        hipLaunchKernelGGL(k_magprism_tmi, dim3(grid), dim3(256), 0, s, ctx->N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
+                           ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nobs, d_x, d_y, d_z, d_cw, *mag, d_rows, d_err, d_sumsq);
+        if (nblk) *nblk = grid;
+        TFX_HIP(hipGetLastError());
+        return 0;
+    }
     hipStream_t s = ctx->stream;
     const int64_t N = ctx->N;
     if (ctx->tensor_grid) {
@@ -241,9 +377,9 @@ int prism_rows_dev(tfx_ctx *ctx, int nobs, const double *d_x, const double *d_y,
 }
 
 // number of sum-of-squares partials per row that prism_rows_dev will write
-int prism_partials(tfx_ctx *ctx)
+int prism_partials(tfx_ctx *ctx, bool mag)
 {
-    if (ctx->tensor_grid) return ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
+    if (ctx->tensor_grid && !mag) return ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
     return (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->num_cu * 16);
 }
 
@@ -934,14 +1070,24 @@ using namespace tfx;
 
 extern "C" {
 
-int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double *rows_out)
+static int geometry_error(int herr)
 {
-    if (!ctx || !xd || !yd || !zd || !rows_out) return fail(TFX_E_ARG, "tfx_prism_rows_gz: null argument");
-    if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_prism_rows_gz: set the grid first");
+    if (herr & 1) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (YZ). Adjust the model grid!");
+    if (herr & 2) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (XZ). Adjust the model grid!");
+    if (herr & 4) return fail(TFX_E_GEOMETRY, "The model grid X-boundary coincides with the data position");
+    if (herr & 8) return fail(TFX_E_GEOMETRY, "The model grid Y-boundary coincides with the data position");
+    return 0;
+}
+
+static int prism_rows_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double *rows_out,
+                          const MagField *mag)
+{
+    if (!ctx || !xd || !yd || !zd || !rows_out) return fail(TFX_E_ARG, "tfx_prism_rows: null argument");
+    if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_prism_rows: set the grid first");
     TFX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int64_t N = ctx->N;
-    const int B = (int)std::min<int64_t>(ndata, std::max<int64_t>(1, (int64_t)(1u << 28) / N));   // <= 2 GB of rows per batch
+    const int B = (int)std::min<int64_t>(std::min<int64_t>(ndata, PRISM_MAX_BATCH), std::max<int64_t>(1, (int64_t)(1u << 28) / N));   // <= 2 GB of rows per batch
     DBuf<double> dobs, drows;
     DBuf<int> derr;
     TFX_TRY(dobs.alloc((size_t)3 * B));
@@ -953,15 +1099,25 @@ int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const doubl
         TFX_HIP(hipMemcpyAsync(dobs.p, xd + o0, nb * sizeof(double), hipMemcpyDefault, s));
         TFX_HIP(hipMemcpyAsync(dobs.p + B, yd + o0, nb * sizeof(double), hipMemcpyDefault, s));
         TFX_HIP(hipMemcpyAsync(dobs.p + 2 * B, zd + o0, nb * sizeof(double), hipMemcpyDefault, s));
-        TFX_TRY(prism_rows_dev(ctx, nb, dobs.p, dobs.p + B, dobs.p + 2 * B, nullptr, drows.p, derr.p));
+        TFX_TRY(prism_rows_dev(ctx, nb, dobs.p, dobs.p + B, dobs.p + 2 * B, nullptr, drows.p, derr.p, nullptr, nullptr, mag));
         TFX_HIP(hipMemcpyAsync(rows_out + o0 * N, drows.p, (size_t)nb * N * sizeof(double), hipMemcpyDefault, s));
         TFX_HIP(hipStreamSynchronize(s));
     }
     int herr = 0;
     TFX_HIP(hipMemcpy(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost));
-    if (herr & 1) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (YZ). Adjust the model grid!");
-    if (herr & 2) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (XZ). Adjust the model grid!");
-    return 0;
+    return geometry_error(herr);
+}
+
+int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double *rows_out)
+{
+    return prism_rows_any(ctx, ndata, xd, yd, zd, rows_out, nullptr);
+}
+
+int tfx_prism_rows_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double incl,
+                       double decl, double azim, double intensity, double *rows_out)
+{
+    const MagField mf = make_mag_field(incl, decl, azim, intensity);
+    return prism_rows_any(ctx, ndata, xd, yd, zd, rows_out, &mf);
 }
 
 int tfx_column_weight_type1(tfx_ctx *ctx, double power, double Z0, double multiplier, double *cw_out)
@@ -1052,13 +1208,13 @@ int tfx_compress_row(tfx_ctx *ctx, const double *row, int64_t N, int64_t K, int3
     return 0;
 }
 
-int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
-                          const double *column_weight, int compression_type, double rate, double problem_weight,
-                          const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
-                          double *error_sum_out, int32_t *nnz_hist_out)
+static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
+                            const double *column_weight, int compression_type, double rate, double problem_weight,
+                            const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
+                            double *error_sum_out, int32_t *nnz_hist_out, const MagField *mag)
 {
-    if (!ctx || !xd || !yd || !zd || !column_weight) return fail(TFX_E_ARG, "tfx_build_kernel_grav: null argument");
-    if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_build_kernel_grav: set the grid first");
+    if (!ctx || !xd || !yd || !zd || !column_weight) return fail(TFX_E_ARG, "tfx_build_kernel: null argument");
+    if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_build_kernel: set the grid first");
     if (compression_type < 0 || compression_type > 2) return fail(TFX_E_ARG, "Unknown wavelet type!");
     if (rate < 0 || rate > 1) return fail(TFX_E_ARG, "Wrong compression rate! It must be between 0 and 1.");   // :112-114
     const int64_t N = ctx->N;
@@ -1101,7 +1257,7 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
     // rows processed per batch: row buffer + select candidates (2x) must stay around 6 GB
     const int B = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, RB), (int64_t)(1u << 28) / N));
     TFX_TRY(drows.alloc((size_t)B * N));
-    const int npart = prism_partials(ctx);
+    const int npart = prism_partials(ctx, mag != nullptr);
     DBuf<double> dcf;
     TFX_TRY(dred.alloc((size_t)B * npart));
     TFX_TRY(dcf.alloc(B));
@@ -1132,7 +1288,7 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
             const int nb = std::min(B, nr - b0);
             const int64_t g = r0 + b0;
             TFX_TRY(prism_rows_dev(ctx, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p,
-                                   compression_type > 0 ? dred.p : nullptr, nullptr));
+                                   compression_type > 0 ? dred.p : nullptr, nullptr, mag));
             if (compression_type > 0) {
                 hipLaunchKernelGGL(k_rows_final_sum, dim3(nb), dim3(256), 0, s, dred.p, npart, dcf.p);             // cost_full :234
                 TFX_HIP(hipGetLastError());
@@ -1161,8 +1317,7 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
         TFX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, s));
         TFX_HIP(hipMemcpyAsync(h_nel.data(), ell_nel.p, nr * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         TFX_HIP(hipStreamSynchronize(s));
-        if (herr & 1) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (YZ). Adjust the model grid!");
-        if (herr & 2) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (XZ). Adjust the model grid!");
+        TFX_TRY(geometry_error(herr));
         for (int i = 0; i < nr; ++i) nnz_total += h_nel[i];
         if (keep_matrix) TFX_TRY(matrix_append_rows(ctx, r0, nr, ell_cols.p, ell_vals.p, ell_nel.p, ell_off.p, stride));
     }
@@ -1174,6 +1329,25 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
     if (error_sum_out) *error_sum_out = err_sum;
     if (nnz_hist_out) TFX_TRY(copy_any(nnz_hist_out, dhist.p, (size_t)N * sizeof(int32_t), s));
     return 0;
+}
+
+int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
+                          const double *column_weight, int compression_type, double rate, double problem_weight,
+                          const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
+                          double *error_sum_out, int32_t *nnz_hist_out)
+{
+    return build_kernel_any(ctx, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight,
+                            col_begin, col_end, nnz_out, error_sum_out, nnz_hist_out, nullptr);
+}
+
+int tfx_build_kernel_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
+                         const double *column_weight, double incl, double decl, double azim, double intensity,
+                         int compression_type, double rate, double problem_weight, const double *data_weight,
+                         int64_t col_begin, int64_t col_end, int64_t *nnz_out, double *error_sum_out, int32_t *nnz_hist_out)
+{
+    const MagField mf = make_mag_field(incl, decl, azim, intensity);
+    return build_kernel_any(ctx, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight,
+                            col_begin, col_end, nnz_out, error_sum_out, nnz_hist_out, &mf);
 }
 
 }  // extern "C"

@@ -91,6 +91,15 @@ class Context:
         check(self._lib.tfx_prism_rows_gz(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(rows)))
         return rows
 
+    # ---- magprism (TMI, scalar susceptibility); field = (inclination, declination, XaxisDeclination, intensity_nT)
+    def magprism(self, Xdata, Ydata, Zdata, field):
+        xd, yd, zd = f64(np.atleast_1d(Xdata)), f64(np.atleast_1d(Ydata)), f64(np.atleast_1d(Zdata))
+        rows = np.empty((xd.size, self.nelements_total))
+        incl, decl, azim, inten = [float(v) for v in field]
+        check(self._lib.tfx_prism_rows_mag(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), C.c_double(incl), C.c_double(decl),
+                                           C.c_double(azim), C.c_double(inten), ptr(rows)))
+        return rows
+
     # ---- forward_wavelet / inverse_wavelet
     def forward_wavelet(self, s, n1, n2, n3, wavelet_type):
         return self._wavelet(s, n1, n2, n3, wavelet_type, 1)
@@ -123,7 +132,8 @@ class Context:
 
     # ---- calculate_and_write_sensit + read_sensitivity_kernel (no disk round trip)
     def calculate_sensit(self, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate, problem_weight=1.0,
-                         data_weight=None, col_range=None, want_hist=False):
+                         data_weight=None, col_range=None, want_hist=False, mag_field=None):
+        """mag_field = None: gravity (graviprism_z); (incl, decl, azim, intensity_nT): magnetic TMI kernel (magprism)."""
         xd, yd, zd = f64(Xdata), f64(Ydata), f64(Zdata)
         cw = f64(column_weight)
         N = self.nelements_total
@@ -132,9 +142,16 @@ class Context:
         nnz = C.c_int64()
         err = C.c_double()
         hist = np.zeros(N, np.int32) if want_hist else None
-        check(self._lib.tfx_build_kernel_grav(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw), int(compression_type),
-                                              C.c_double(compression_rate), C.c_double(problem_weight), ptr(dw), C.c_int64(c0),
-                                              C.c_int64(c1), C.byref(nnz), C.byref(err), ptr(hist)))
+        if mag_field is None:
+            check(self._lib.tfx_build_kernel_grav(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw), int(compression_type),
+                                                  C.c_double(compression_rate), C.c_double(problem_weight), ptr(dw), C.c_int64(c0),
+                                                  C.c_int64(c1), C.byref(nnz), C.byref(err), ptr(hist)))
+        else:
+            incl, decl, azim, inten = [float(v) for v in mag_field]
+            check(self._lib.tfx_build_kernel_mag(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw), C.c_double(incl),
+                                                 C.c_double(decl), C.c_double(azim), C.c_double(inten), int(compression_type),
+                                                 C.c_double(compression_rate), C.c_double(problem_weight), ptr(dw), C.c_int64(c0),
+                                                 C.c_int64(c1), C.byref(nnz), C.byref(err), ptr(hist)))
         return dict(nnz=nnz.value, error_sum=err.value, comp_error=err.value / xd.size, nnz_hist=hist)
 
     # ---- t_sparse_matrix
