@@ -179,19 +179,19 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
     TiledMatrix &m = ctx->mat;
     if (!m.valid) return fail(TFX_E_STATE, "no matrix");
     TFX_HIP(hipSetDevice(ctx->device));
-    std::vector<uint8_t> hd((size_t)m.n_entries);
+    std::vector<uint16_t> hc((size_t)m.n_entries);
     std::vector<float> hv((size_t)m.n_entries);
-    std::vector<uint16_t> hx((size_t)std::max<int64_t>(1, m.n_exc));
-    std::vector<ChunkMeta> hcm((size_t)(m.n_entries / CHUNK));
     if (m.n_entries > 0) {
-        TFX_HIP(hipMemcpy(hd.data(), m.d8.p, (size_t)m.n_entries * sizeof(uint8_t), hipMemcpyDeviceToHost));
+        TFX_HIP(hipMemcpy(hc.data(), m.codes.p, (size_t)m.n_entries * sizeof(uint16_t), hipMemcpyDeviceToHost));
         TFX_HIP(hipMemcpy(hv.data(), m.vals.p, (size_t)m.n_entries * sizeof(float), hipMemcpyDeviceToHost));
-        TFX_HIP(hipMemcpy(hcm.data(), m.cmeta.p, hcm.size() * sizeof(ChunkMeta), hipMemcpyDeviceToHost));
     }
-    if (m.n_exc > 0) TFX_HIP(hipMemcpy(hx.data(), m.exc.p, (size_t)m.n_exc * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> hrow0((size_t)(m.n_entries / CHUNK));
+    if (!hrow0.empty())
+        TFX_HIP(hipMemcpy(hrow0.data(), m.chunk_row0.p, hrow0.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     // tiles sorted by (rb, t): columns of a row come out ascending
     std::vector<TileMeta> tl = m.h_tiles;
     std::sort(tl.begin(), tl.end(), [](const TileMeta &a, const TileMeta &b) { return a.rb != b.rb ? a.rb < b.rb : a.t < b.t; });
+    // pass 1: counts
     std::vector<int64_t> cnt((size_t)m.nrows + 1, 0);
     for (int pass = 0; pass < 2; ++pass) {
         std::vector<int64_t> fill;
@@ -202,31 +202,22 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
             fill.assign(rowptr, rowptr + m.nrows);
         }
         for (const TileMeta &tm : tl) {
-            int cur = 0, col = 0;
-            int64_t ex = 0;
+            int cur = hrow0[(size_t)(tm.off / CHUNK)];
             for (int32_t e = 0; e < tm.cnt; ++e) {
-                if (e % CHUNK == 0) {
-                    const ChunkMeta &cm = hcm[(size_t)((tm.off + e) / CHUNK)];
-                    cur = cm.row0;
-                    ex = cm.exc_off;
-                }
-                const int b = hd[(size_t)(tm.off + e)];
-                const bool rs = b == D8_EXC_ROWSTART;
-                if (b == D8_EXC || rs) col = hx[(size_t)ex++];
-                else col += b;
-                if (rs) cur += 1;
-                const float v = hv[(size_t)(tm.off + e)];
-                // an empty-row marker (row start, column 0, value 0, followed by another row start) is indistinguishable
-                // from a stored exact zero alone in its row segment; the reference never stores zeros
-                // (sparse_matrix.f90:219, threshold >= 1e-30)
-                const bool next_rs = (e + 1 == tm.cnt) || hd[(size_t)(tm.off + e + 1)] == D8_EXC_ROWSTART;
-                if (rs && v == 0.0f && col == 0 && next_rs) continue;
-                const int64_t row = (int64_t)tm.rb * m.RB + cur;
-                if (row < 0 || row >= m.nrows || col < 0 || col >= m.TC) return fail(TFX_E_STATE, "corrupt tile: row %lld col %d", (long long)row, col);
+                uint16_t code = hc[(size_t)(tm.off + e)];
+                if (code & ROWSTART) cur += 1;
+                float v = hv[(size_t)(tm.off + e)];
+                bool marker = (code & ROWSTART) && v == 0.0f && (code & COLMASK) == 0 &&
+                              (e + 1 == tm.cnt || (hc[(size_t)(tm.off + e + 1)] & ROWSTART));
+                // a marker is indistinguishable from a stored exact zero in column 0 of the tile that is alone in
+                // its row segment; the reference never stores zeros (sparse_matrix.f90:219, threshold >= 1e-30)
+                if (marker) continue;
+                int64_t row = (int64_t)tm.rb * m.RB + cur;
+                if (row < 0 || row >= m.nrows) return fail(TFX_E_STATE, "corrupt tile: row %lld", (long long)row);
                 if (pass == 0) cnt[(size_t)row] += 1;
                 else {
-                    const int64_t p = fill[(size_t)row]++;
-                    if (cols) cols[p] = (int32_t)((int64_t)tm.t * m.TC + col + 1);
+                    int64_t p = fill[(size_t)row]++;
+                    if (cols) cols[p] = (int32_t)((int64_t)tm.t * m.TC + (code & COLMASK) + 1);
                     if (vals) vals[p] = v;
                 }
             }
@@ -240,7 +231,7 @@ int tfx_matrix_free(tfx_ctx *ctx)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     (void)hipStreamSynchronize(ctx->stream);
     TiledMatrix &m = ctx->mat;
-    m.d8.release(); m.vals.release(); m.exc.release(); m.cmeta.release(); m.tiles.release(); m.fwd.release(); m.adj.release();
+    m.codes.release(); m.vals.release(); m.chunk_row0.release(); m.tiles.release(); m.fwd.release(); m.adj.release();
     m.fwd_order.release(); m.adj_order.release(); m.fwd_partial.release(); m.adj_partial.release();
     m.fwd_nslots.release(); m.fwd_pbase.release(); m.adj_nslots.release(); m.adj_pbase.release();
     m.h_tiles.clear(); m.h_fwd.clear(); m.h_adj.clear();

@@ -70,25 +70,15 @@ struct DBuf {
 constexpr int CHUNK = 512;            // entries per chunk = 64 lanes x 8 entries
 constexpr int TC_MAX = 16384;         // columns per column tile (14-bit local column)
 constexpr int RB_MAX = 2048;          // rows per row block
-constexpr uint16_t ROWSTART = 0x8000; // build-time code bit 15: this entry starts a new row inside the tile
+constexpr uint16_t ROWSTART = 0x8000; // code bit 15: this entry starts a new row inside the tile
 constexpr uint16_t COLMASK = 0x3fff;
-// stored index stream: one byte per entry
-constexpr int D8_EXC_ROWSTART = 0;    // exception entry that also starts a new row inside the tile
-constexpr int D8_EXC = 255;           // exception entry (absolute column in exc[]), same row
-constexpr int D8_MAX_DELTA = 254;     // 1..254: column = previous column + delta
 
 struct TileMeta {
-    int64_t off;      // first entry (multiple of CHUNK) in d8[] / vals[]
+    int64_t off;      // first entry (multiple of CHUNK) in codes[] / vals[]
     int32_t nchunks;  // padded length / CHUNK
     int32_t cnt;      // real entries (incl. empty-row markers)
     int32_t t;        // column tile
     int32_t rb;       // row block
-};
-
-struct ChunkMeta {
-    int32_t row0;     // local row of the entry preceding the chunk
-    int32_t nexc;     // exception entries in the chunk
-    int64_t exc_off;  // first exception of the chunk in exc[]
 };
 
 struct WorkItem {     // one workgroup's work: a run of tiles sharing rb (forward) or t (adjoint)
@@ -102,12 +92,10 @@ struct TiledMatrix {
     int64_t nrows = 0, ncols = 0, nnz = 0;
     int TC = TC_MAX, RB = RB_MAX;
     int ntc = 0, nrb = 0;
-    DBuf<uint8_t> d8;             // per entry: column delta / exception marker
-    DBuf<float> vals;             // per entry: value
-    DBuf<uint16_t> exc;           // absolute in-tile columns of the exception entries, chunk by chunk
+    DBuf<uint16_t> codes;
+    DBuf<float> vals;
     int64_t n_entries = 0;        // used (padded) entries
-    int64_t n_exc = 0;            // used exception slots
-    DBuf<ChunkMeta> cmeta;        // per chunk
+    DBuf<int32_t> chunk_row0;     // per chunk: local row of the entry preceding the chunk
     std::vector<TileMeta> h_tiles;
     DBuf<TileMeta> tiles;
     // work lists

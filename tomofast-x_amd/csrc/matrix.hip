@@ -5,25 +5,20 @@
 //
 // Layout (DESIGN.md "Data layout in HBM").  The reference keeps CSR with 4-byte values + 4-byte columns
 // (8 B per non-zero).  Here S is cut into tiles of (RB <= 2048 rows) x (TC <= 16384 columns).  Inside a tile the
-// entries are in (row, column) order and stored as streams:
-//     vals[]  float : the value exactly as the reference stores it
-//     d8[]    uint8 : 1..254 = column delta to the previous entry of the same row; 255 = "exception": the in-tile
-//                     column is the next uint16 of the chunk's slice of exc[]; 0 = exception that also starts a new row
-//     exc[]   uint16: absolute in-tile columns of the exception entries (row starts, gaps >= 255, first entry of a chunk)
-// i.e. 5 B per non-zero + 2 B per exception (2-3 % of the entries for wavelet-compressed kernels: ~5.06 B/nnz).
-// A row that is empty inside a tile but lies between two non-empty rows carries one marker entry (row start, value 0).
-// A tile is padded to a multiple of 512 entries (one chunk = 64 lanes x 8 entries: a lane fetches its 8 deltas with one
-// 8-byte load and its 8 values with two 16-byte loads).  cmeta[] gives each chunk the local row of the entry preceding
-// it and its exception slice, so any wave can start at any chunk.
+// entries are in (row, column) order and stored as two streams:
+//     codes[]  uint16 : bit 15 = "first entry of a new row inside this tile", bits 0-13 = column inside the tile
+//     vals[]   float  : the value exactly as the reference stores it
+// i.e. 6 B per non-zero.  A row that is empty inside a tile but lies between two non-empty rows carries one marker
+// entry (ROWSTART, value 0).  A tile is padded to a multiple of 512 entries (one chunk = 64 lanes x 8 entries, so a
+// lane fetches its 8 codes with one 16-byte load and its 8 values with two).  chunk_row0[] gives each chunk the
+// local row of the entry preceding it, so any wave can start at any chunk.
 //
 // Both products stream every tile once, coalesced, and keep the vector side of the product in LDS:
 //   forward: the x tile (TC doubles, 128 KB) is staged in LDS, row sums are accumulated in LDS (RB doubles);
 //   adjoint: the u rows of the block are staged in LDS, the column sums live in LDS (TC doubles) and are
 //            written once.
-// Decoding a chunk: exception / row-start ranks from ballot + mbcnt prefix counts, exception columns fetched with
-// wave shuffles from two registers that hold the chunk's exc slice, columns from an in-lane running sum plus one
-// segmented wave scan for the carry into each lane.  Short row segments are summed inside a lane, the segment tails
-// are merged across lanes with one segmented wave reduction per chunk.
+// Row membership is recovered from the ROWSTART bits with ballot + mbcnt prefix counts; short row segments are
+// summed inside a lane, the segment tails are merged across lanes with one segmented wave reduction per chunk.
 #include "common.h"
 #include <algorithm>
 #include <numeric>
@@ -34,7 +29,7 @@ thread_local std::string g_last_error;
 
 size_t TiledMatrix::device_bytes() const
 {
-    return d8.bytes() + vals.bytes() + exc.bytes() + cmeta.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
+    return codes.bytes() + vals.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
            fwd_order.bytes() + adj_order.bytes() + fwd_partial.bytes() + adj_partial.bytes() + adj_nslots.bytes() +
            adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes();
 }
@@ -160,7 +155,7 @@ __global__ void k_tile_markers(const int32_t *__restrict__ pos, int nr, int ntc,
 // chunk_row0[chunk] = local row of the entry just before the chunk (first chunk: first_ne - 1).
 __global__ void k_chunk_row0(int nr, const int32_t *__restrict__ segoff, const int32_t *__restrict__ first_ne,
                              const int64_t *__restrict__ tile_off, const int32_t *__restrict__ tile_nchunks,
-                             ChunkMeta *__restrict__ cmeta)
+                             int32_t *__restrict__ chunk_row0)
 {
     int t = blockIdx.x;
     int nch = tile_nchunks[t];
@@ -183,95 +178,8 @@ __global__ void k_chunk_row0(int nr, const int32_t *__restrict__ segoff, const i
             }
             row = lo;
         }
-        cmeta[cbase + c].row0 = row;
+        chunk_row0[cbase + c] = row;
     }
-}
-
-
-// ---- build-time uint16 codes (ROWSTART | column) -> stored byte stream + exception list ---------------------------
-// One workgroup per column tile of the row block, one wave per chunk, a lane owns 8 consecutive entries.
-__device__ __forceinline__ uint32_t code16(const uint4 &w, int k)
-{
-    const uint32_t v = (k < 2) ? w.x : (k < 4) ? w.y : (k < 6) ? w.z : w.w;
-    return (v >> ((k & 1) * 16)) & 0xffffu;
-}
-
-// pass 1: d8 bytes + exception count per chunk; pass 2 (write_exc != 0): exception columns into exc[]
-__global__ __launch_bounds__(256) void k_encode_d8(const int64_t *__restrict__ tile_off, const int32_t *__restrict__ tile_nchunks,
-                                                   const int32_t *__restrict__ tile_cnt, const uint16_t *__restrict__ codes,
-                                                   int64_t codes_base, uint8_t *__restrict__ d8, ChunkMeta *__restrict__ cmeta,
-                                                   uint16_t *__restrict__ exc, int write_exc)
-{
-    const int t = blockIdx.x;
-    const int nch = tile_nchunks[t];
-    if (nch == 0) return;
-    const int64_t off = tile_off[t];
-    const int cnt = tile_cnt[t];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    for (int c = wave; c < nch; c += nwave) {
-        const int64_t base = off + (int64_t)c * CHUNK;
-        const uint4 w = *reinterpret_cast<const uint4 *>(codes + (base - codes_base) + lane * 8);
-        const int nvalid = min(CHUNK, cnt - c * CHUNK);
-        // column of the entry just before this lane's first one
-        int prev = (int)(code16(w, 7) & COLMASK);
-        prev = __shfl_up(prev, 1);
-        uint32_t lo = 0, hi = 0;
-        int nx = 0;
-        uint32_t xcol[8];
-        unsigned xmask = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t code = code16(w, k);
-            const int col = (int)(code & COLMASK);
-            const int idx = lane * 8 + k;
-            const bool valid = idx < nvalid;
-            const bool rs = (code & ROWSTART) != 0;
-            const int delta = col - prev;
-            const bool ex = valid && (idx == 0 || rs || delta > D8_MAX_DELTA || delta <= 0);
-            const uint32_t byte = !valid ? 1u : (ex ? (rs ? (uint32_t)D8_EXC_ROWSTART : (uint32_t)D8_EXC) : (uint32_t)delta);
-            if (k < 4) lo |= byte << (8 * k);
-            else hi |= byte << (8 * (k - 4));
-            xcol[k] = (uint32_t)col;
-            if (ex) { xmask |= 1u << k; nx += 1; }
-            prev = col;
-        }
-        // exclusive prefix of the exception counts over the lanes
-        int incl = nx;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-        const int total = __shfl(incl, 63);
-        const int64_t ci = base / CHUNK;
-        if (!write_exc) {
-            *reinterpret_cast<uint2 *>(d8 + base + lane * 8) = make_uint2(lo, hi);
-            if (lane == 0) cmeta[ci].nexc = total;
-        } else {
-            int pos = incl - nx;
-            uint16_t *e = exc + cmeta[ci].exc_off;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (xmask & (1u << k)) e[pos++] = (uint16_t)xcol[k];
-        }
-    }
-}
-
-// exclusive scan of cmeta[c0 .. c0+n).nexc into exc_off (starting at `start`); *total_out = sum.  One block of 1024.
-__global__ void k_exc_scan(ChunkMeta *__restrict__ cmeta, int64_t c0, int64_t n, int64_t start, int64_t *__restrict__ total_out)
-{
-    __shared__ int64_t part[1024];
-    const int64_t per = (n + blockDim.x - 1) / blockDim.x;
-    const int64_t b = (int64_t)threadIdx.x * per, e = min(b + per, n);
-    int64_t s = 0;
-    for (int64_t i = b; i < e; ++i) s += cmeta[c0 + i].nexc;
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int64_t run = 0;
-        for (int i = 0; i < (int)blockDim.x; ++i) { const int64_t v = part[i]; part[i] = run; run += v; }
-        *total_out = run;
-    }
-    __syncthreads();
-    int64_t run = start + part[threadIdx.x];
-    for (int64_t i = b; i < e; ++i) { cmeta[c0 + i].exc_off = run; run += cmeta[c0 + i].nexc; }
 }
 
 int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
@@ -289,12 +197,10 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
     int64_t markers = std::min<int64_t>(nnz_upper, (int64_t)nrows * m.ntc);
     int64_t cap = nnz_upper + markers + (int64_t)m.nrb * m.ntc * CHUNK + CHUNK;
     cap = (cap + CHUNK - 1) / CHUNK * CHUNK;
-    TFX_TRY(m.d8.alloc((size_t)cap));
+    TFX_TRY(m.codes.alloc((size_t)cap));
     TFX_TRY(m.vals.alloc((size_t)cap));
-    TFX_TRY(m.cmeta.alloc((size_t)(cap / CHUNK)));
-    TFX_TRY(m.exc.alloc((size_t)std::max<int64_t>(4096, cap / 16)));     // grown on demand
+    TFX_TRY(m.chunk_row0.alloc((size_t)(cap / CHUNK)));
     m.n_entries = 0;
-    m.n_exc = 0;
     m.h_tiles.clear();
     return 0;
 }
@@ -349,51 +255,23 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
         cur += (int64_t)nch * CHUNK;
         nnz_block += cnt;
     }
-    if ((size_t)cur > m.d8.n)
-        return fail(TFX_E_STATE, "tiled matrix capacity exceeded (%lld > %zu entries)", (long long)cur, m.d8.n);
-    const int64_t nloc = cur - m.n_entries;
-    if (nloc == 0) return 0;
-    // build-time codes of this row block (uint16: ROWSTART | column), then the stored byte stream + exception list
-    DBuf<uint16_t> codes;
-    DBuf<int32_t> tile_cnt;
-    DBuf<int64_t> d_total;
-    TFX_TRY(codes.alloc((size_t)nloc));
-    TFX_TRY(tile_cnt.alloc(ntc));
-    TFX_TRY(d_total.alloc(1));
-    uint16_t *codes_v = codes.p - m.n_entries;            // indexed with global entry numbers
-    TFX_HIP(hipMemsetAsync(codes.p, 0, (size_t)nloc * sizeof(uint16_t), s));
-    TFX_HIP(hipMemsetAsync(m.vals.p + m.n_entries, 0, (size_t)nloc * sizeof(float), s));
+    if ((size_t)cur > m.codes.n)
+        return fail(TFX_E_STATE, "tiled matrix capacity exceeded (%lld > %zu entries)", (long long)cur, m.codes.n);
+    // zero the destination range (padding: code 0 / value 0)
+    TFX_HIP(hipMemsetAsync(m.codes.p + m.n_entries, 0, (size_t)(cur - m.n_entries) * sizeof(uint16_t), s));
+    TFX_HIP(hipMemsetAsync(m.vals.p + m.n_entries, 0, (size_t)(cur - m.n_entries) * sizeof(float), s));
     TFX_HIP(hipMemcpyAsync(tile_off.p, h_off.data(), ntc * sizeof(int64_t), hipMemcpyHostToDevice, s));
     TFX_HIP(hipMemcpyAsync(tile_nch.p, h_nch.data(), ntc * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    TFX_HIP(hipMemcpyAsync(tile_cnt.p, h_segoff_last.data(), ntc * sizeof(int32_t), hipMemcpyHostToDevice, s));
     if (maxlen > 0)
         hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((maxlen + 255) / 256), nr), dim3(256), 0, s, d_cols, d_vals,
-                           d_nel, d_rowoff, ntc, m.TC, nr, pos.p, segoff.p, tile_off.p, codes_v, m.vals.p);
+                           d_nel, d_rowoff, ntc, m.TC, nr, pos.p, segoff.p, tile_off.p, m.codes.p, m.vals.p);
     hipLaunchKernelGGL(k_tile_markers, dim3(ntc), dim3(256), 0, s, pos.p, nr, ntc, segoff.p, first_ne.p, last_ne.p,
-                       tile_off.p, codes_v, m.vals.p);
-    hipLaunchKernelGGL(k_chunk_row0, dim3(ntc), dim3(256), 0, s, nr, segoff.p, first_ne.p, tile_off.p, tile_nch.p, m.cmeta.p);
-    hipLaunchKernelGGL(k_encode_d8, dim3(ntc), dim3(256), 0, s, tile_off.p, tile_nch.p, tile_cnt.p, codes.p, m.n_entries,
-                       m.d8.p, m.cmeta.p, (uint16_t *)nullptr, 0);
-    const int64_t c0 = m.n_entries / CHUNK, nchunks = nloc / CHUNK;
-    hipLaunchKernelGGL(k_exc_scan, dim3(1), dim3(1024), 0, s, m.cmeta.p, c0, nchunks, m.n_exc, d_total.p);
-    TFX_HIP(hipGetLastError());
-    int64_t h_total = 0;
-    TFX_HIP(hipMemcpyAsync(&h_total, d_total.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    TFX_HIP(hipStreamSynchronize(s));
-    if ((size_t)(m.n_exc + h_total) > m.exc.n) {          // grow the exception list (it is ~1 % of the matrix)
-        DBuf<uint16_t> bigger;
-        TFX_TRY(bigger.alloc((size_t)((m.n_exc + h_total) * 3 / 2 + 4096)));
-        if (m.n_exc > 0) TFX_HIP(hipMemcpyAsync(bigger.p, m.exc.p, (size_t)m.n_exc * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
-        TFX_HIP(hipStreamSynchronize(s));
-        std::swap(m.exc.p, bigger.p);
-        std::swap(m.exc.n, bigger.n);
-    }
-    hipLaunchKernelGGL(k_encode_d8, dim3(ntc), dim3(256), 0, s, tile_off.p, tile_nch.p, tile_cnt.p, codes.p, m.n_entries,
-                       m.d8.p, m.cmeta.p, m.exc.p, 1);
+                       tile_off.p, m.codes.p, m.vals.p);
+    hipLaunchKernelGGL(k_chunk_row0, dim3(ntc), dim3(256), 0, s, nr, segoff.p, first_ne.p, tile_off.p, tile_nch.p,
+                       m.chunk_row0.p);
     TFX_HIP(hipGetLastError());
     TFX_HIP(hipStreamSynchronize(s));    // temporaries are freed on return
     m.n_entries = cur;
-    m.n_exc += h_total;
     (void)nnz_block;
     return 0;
 }
@@ -506,89 +384,46 @@ int matrix_finish(tfx_ctx *ctx)
 constexpr int SPMV_THREADS = 1024;
 constexpr int SPMV_WAVES = SPMV_THREADS / 64;
 
-// One chunk decoded for one lane: 8 consecutive entries.
-struct Decoded {
-    int col[8];        // in-tile column
+struct ChunkRegs {
+    uint32_t w[4];    // 8 codes
     float v[8];
-    unsigned rsmask;   // bit k: entry k starts a new row
-    unsigned vmask;    // bit k: entry k exists (not tile padding)
-    int cur;           // local row of the entry preceding this lane's first entry
 };
 
-__device__ __forceinline__ void decode_chunk(const uint8_t *__restrict__ d8, const float *__restrict__ vals,
-                                             const uint16_t *__restrict__ exc, const ChunkMeta cm, int64_t base, int nvalid,
-                                             int lane, Decoded &D)
+__device__ __forceinline__ void load_chunk(const uint16_t *__restrict__ codes, const float *__restrict__ vals,
+                                           int64_t base, ChunkRegs &c)
 {
-    const uint2 db = *reinterpret_cast<const uint2 *>(d8 + base + lane * 8);
-    const float4 va = *reinterpret_cast<const float4 *>(vals + base + lane * 8);
-    const float4 vb = *reinterpret_cast<const float4 *>(vals + base + lane * 8 + 4);
-    D.v[0] = va.x; D.v[1] = va.y; D.v[2] = va.z; D.v[3] = va.w;
-    D.v[4] = vb.x; D.v[5] = vb.y; D.v[6] = vb.z; D.v[7] = vb.w;
-    // the chunk's exception columns: two registers per lane cover 128 of them, the rest (rare) is read directly
-    const uint16_t *ex = exc + cm.exc_off;
-    const int e0 = (lane < cm.nexc) ? (int)ex[lane] : 0;
-    const bool two = cm.nexc > 64;                         // wave-uniform
-    const int e1 = (two && lane + 64 < cm.nexc) ? (int)ex[lane + 64] : 0;
-    int byte[8];
-    unsigned xmask = 0, rsmask = 0, vmask = 0;
-    int pre_x = 0, pre_r = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        byte[k] = (int)(((k < 4 ? db.x : db.y) >> (8 * (k & 3))) & 0xffu);
-        const bool valid = lane * 8 + k < nvalid;
-        const bool isx = valid && (byte[k] == D8_EXC || byte[k] == D8_EXC_ROWSTART);
-        const bool rs = valid && byte[k] == D8_EXC_ROWSTART;
-        const unsigned long long mx = __ballot(isx), mr = __ballot(rs);
-        pre_x = __builtin_amdgcn_mbcnt_hi((uint32_t)(mx >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mx, pre_x));
-        pre_r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mr, pre_r));
-        if (valid) vmask |= 1u << k;
-        if (isx) xmask |= 1u << k;
-        if (rs) rsmask |= 1u << k;
-    }
-    // running column inside the lane; before the lane's first exception it is relative to the carry from lower lanes
-    int acc = 0, eidx = pre_x;
-    unsigned absmask = 0;
-    bool seen = false;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        int code = __shfl(e0, eidx & 63);
-        if (two) { const int c1 = __shfl(e1, eidx & 63); if (eidx >= 64) code = c1; }
-        if (xmask & (1u << k)) {
-            if (eidx >= 128) code = (int)ex[eidx];
-            acc = code;
-            seen = true;
-            eidx += 1;
-        } else if (vmask & (1u << k)) {
-            acc += byte[k];
-        }
-        D.col[k] = acc;
-        if (seen) absmask |= 1u << k;
-    }
-    // carry into each lane: segmented inclusive scan of (seen, acc) over the lanes (lane 0 always starts absolute)
-    int f = seen ? 1 : 0, val = acc;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int of = __shfl_up(f, d), ov = __shfl_up(val, d);
-        if (lane >= d && !f) { val += ov; f |= of; }
-    }
-    int carry = __shfl_up(val, 1);
-    if (lane == 0) carry = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (!(absmask & (1u << k))) D.col[k] += carry;
-    D.rsmask = rsmask;
-    D.vmask = vmask;
-    D.cur = cm.row0 + pre_r;
+    const uint4 cw = *reinterpret_cast<const uint4 *>(codes + base);
+    const float4 a = *reinterpret_cast<const float4 *>(vals + base);
+    const float4 b = *reinterpret_cast<const float4 *>(vals + base + 4);
+    c.w[0] = cw.x; c.w[1] = cw.y; c.w[2] = cw.z; c.w[3] = cw.w;
+    c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w;
+    c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w;
 }
 
-// forward: one workgroup = a run of tiles of one row block; its partial tile = sum over the run.
+__device__ __forceinline__ uint32_t code_of(const ChunkRegs &c, int k) { return (c.w[k >> 1] >> ((k & 1) * 16)) & 0xffffu; }
+
+// number of ROWSTART flags in all lanes below this one (all 8 entries of those lanes)
+__device__ __forceinline__ int flags_before_lane(const ChunkRegs &c, bool &any)
+{
+    int acc = 0;
+    unsigned long long all = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unsigned long long mk = __ballot((code_of(c, k) & ROWSTART) != 0);
+        all |= mk;
+        acc = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, acc));
+    }
+    any = all != 0;
+    return acc;
+}
+
+// forward: one workgroup = a run of tiles of one row block; partial[slot][row] = sum over the run.
 __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_fwd(const WorkItem *__restrict__ items,
                                                              const int32_t *__restrict__ order,
                                                              const TileMeta *__restrict__ tiles,
-                                                             const uint8_t *__restrict__ d8,
+                                                             const uint16_t *__restrict__ codes,
                                                              const float *__restrict__ vals,
-                                                             const uint16_t *__restrict__ exc,
-                                                             const ChunkMeta *__restrict__ cmeta,
+                                                             const int32_t *__restrict__ chunk_row0,
                                                              const double *__restrict__ x, double *__restrict__ partial,
                                                              int64_t ncols, int TC, int RB)
 {
@@ -607,18 +442,21 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_fwd(const WorkItem *__res
         __syncthreads();
         const int64_t cbase = tm.off / CHUNK;
         for (int c = wave; c < tm.nchunks; c += SPMV_WAVES) {
-            Decoded D;
-            decode_chunk(d8, vals, exc, cmeta[cbase + c], tm.off + (int64_t)c * CHUNK, min(CHUNK, tm.cnt - c * CHUNK), lane, D);
-            int cur = D.cur;
+            ChunkRegs cr;
+            load_chunk(codes, vals, tm.off + (int64_t)c * CHUNK + lane * 8, cr);
+            int cur = chunk_row0[cbase + c];
+            bool any;
+            cur += flags_before_lane(cr, any);
             double acc = 0.0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (D.rsmask & (1u << k)) {
+                const uint32_t code = code_of(cr, k);
+                if (code & ROWSTART) {
                     if (cur >= 0 && acc != 0.0) atomicAdd(&outs[cur], acc);
                     cur += 1;
                     acc = 0.0;
                 }
-                if (D.vmask & (1u << k)) acc = fma((double)D.v[k], xs[swz(D.col[k])], acc);
+                acc = fma((double)cr.v[k], xs[swz((int)(code & COLMASK))], acc);
             }
             // merge the tails of lanes that end on the same row (equal rows are contiguous lanes)
             double sum = acc;
@@ -650,14 +488,13 @@ __global__ void k_fwd_reduce(const double *__restrict__ partial, const int32_t *
     b[r] = s;
 }
 
-// adjoint: one workgroup = a run of tiles of one column tile; slot 0 adds into y, the others write partial tiles.
+// adjoint: one workgroup = a run of tiles of one column tile; slot 0 adds into y, the others write partials.
 __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adj(const WorkItem *__restrict__ items,
                                                              const int32_t *__restrict__ order,
                                                              const TileMeta *__restrict__ tiles,
-                                                             const uint8_t *__restrict__ d8,
+                                                             const uint16_t *__restrict__ codes,
                                                              const float *__restrict__ vals,
-                                                             const uint16_t *__restrict__ exc,
-                                                             const ChunkMeta *__restrict__ cmeta,
+                                                             const int32_t *__restrict__ chunk_row0,
                                                              const double *__restrict__ u, double *__restrict__ y,
                                                              double *__restrict__ partial, int64_t nrows, int64_t ncols,
                                                              int TC, int RB)
@@ -677,18 +514,21 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adj(const WorkItem *__res
         __syncthreads();
         const int64_t cbase = tm.off / CHUNK;
         for (int c = wave; c < tm.nchunks; c += SPMV_WAVES) {
-            Decoded D;
-            decode_chunk(d8, vals, exc, cmeta[cbase + c], tm.off + (int64_t)c * CHUNK, min(CHUNK, tm.cnt - c * CHUNK), lane, D);
-            int cur = D.cur;
+            ChunkRegs cr;
+            load_chunk(codes, vals, tm.off + (int64_t)c * CHUNK + lane * 8, cr);
+            int cur = chunk_row0[cbase + c];
+            bool any;
+            cur += flags_before_lane(cr, any);
             double uval = us[max(cur, 0)];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (D.rsmask & (1u << k)) {
+                const uint32_t code = code_of(cr, k);
+                if (code & ROWSTART) {
                     cur += 1;
                     uval = us[cur];
                 }
-                const float v = D.v[k];
-                if ((D.vmask & (1u << k)) && v != 0.0f) atomicAdd(&acc[swz(D.col[k])], (double)v * uval);
+                const float v = cr.v[k];
+                if (v != 0.0f) atomicAdd(&acc[swz((int)(code & COLMASK))], (double)v * uval);
             }
         }
     }
@@ -750,7 +590,7 @@ int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add)
         if (lds > lds_set) { TFX_TRY(set_lds_limit((const void *)k_spmv_fwd, lds)); lds_set = lds; }
         prof_begin(ctx);
         hipLaunchKernelGGL(k_spmv_fwd, dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, m.fwd.p, m.fwd_order.p,
-                           m.tiles.p, m.d8.p, m.vals.p, m.exc.p, m.cmeta.p, d_x, m.fwd_partial.p, m.ncols, m.TC, m.RB);
+                           m.tiles.p, m.codes.p, m.vals.p, m.chunk_row0.p, d_x, m.fwd_partial.p, m.ncols, m.TC, m.RB);
         prof_end(ctx, 0);
         TFX_HIP(hipGetLastError());
     }
@@ -772,7 +612,7 @@ int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add)
         if (lds > lds_set) { TFX_TRY(set_lds_limit((const void *)k_spmv_adj, lds)); lds_set = lds; }
         prof_begin(ctx);
         hipLaunchKernelGGL(k_spmv_adj, dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, m.adj.p, m.adj_order.p,
-                           m.tiles.p, m.d8.p, m.vals.p, m.exc.p, m.cmeta.p, d_x, d_b, m.adj_partial.p, m.nrows, m.ncols,
+                           m.tiles.p, m.codes.p, m.vals.p, m.chunk_row0.p, d_x, d_b, m.adj_partial.p, m.nrows, m.ncols,
                            m.TC, m.RB);
         prof_end(ctx, 1);
         TFX_HIP(hipGetLastError());
