@@ -113,6 +113,15 @@ int tfx_matrix_info(tfx_ctx *ctx, int64_t *nrows, int64_t *ncols, int64_t *nnz, 
 int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float *vals);
 int tfx_matrix_free(tfx_ctx *ctx);
 
+/* General constraint rows: matrix_cons as the cross-gradient / clustering / gradient-damping / local-bound ADMM
+ * builders assemble it on the host (src/inversion/joint_inverse_problem.F90:332, :466-544), uploaded as CSR with its
+ * right-hand side (the b_RHS(lc:) slice).  Same layout and kernels as S; consumed by tfx_lsqr_* together with the
+ * diagonal blocks.  Multi-rank: the rows are replicated, each rank uploads its column range (local 1-based columns),
+ * like S.  tfx_cons_clear drops it.                                                                          */
+int tfx_cons_upload_csr(tfx_ctx *ctx, int64_t nrows, const int64_t *rowptr, const int32_t *cols, const float *vals,
+                        const double *rhs);
+int tfx_cons_clear(tfx_ctx *ctx);
+
 /* get_load_balancing_nelements (sensitivity_gravmag.F90:470-524): host-side, exact integer rule.            */
 int tfx_partition_columns(const int32_t *nnz_hist, int64_t N, int nparts, int32_t *nel_at_part,
                           int64_t *nnz_at_part);

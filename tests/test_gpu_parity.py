@@ -328,6 +328,36 @@ def test_lsqr_vs_reference_golden(ctx, golden_dir, case):
         assert np.linalg.norm(x - xref) <= tol * np.linalg.norm(xref), (case, niter)
 
 
+def test_lsqr_general_constraint_matrix_vs_reference(ctx, golden_dir):
+    """[S; C] with a general sparse C (empty rows included) uploaded as CSR - the reference's matrix_cons path
+    (lsqr_solver2.F90:147, :211, :238) - against the reference's own solutions."""
+    g = load(golden_dir, "lsqr")
+    case = "gen"
+    nl_s, nl_c, ncols = int(g[case + "_nl_s"]), int(g[case + "_nl_c"]), int(g[case + "_ncols"])
+    S = (orc.rc_to_rowptr(g[case + "_S_rc"]), g[case + "_S_cols"], g[case + "_S_vals"])
+    Cm = (orc.rc_to_rowptr(g[case + "_C_rc"]), g[case + "_C_cols"], g[case + "_C_vals"])
+    b = g[case + "_b"]
+    ctx.matrix_upload_csr(nl_s, ncols, *S)
+    ctx.cons_upload_csr(*Cm, b[nl_s:])
+    try:
+        for (niter, rmin, gamma), xref, rref, itref in zip(g[case + "_runs"], g[case + "_x"], g[case + "_r"], g[case + "_iters"]):
+            x, it, r = ctx.lsqr_solve_sensit(b[:nl_s], int(niter), rmin, gamma)
+            early = itref < niter
+            assert (abs(it - itref) <= 0.1 * itref) if early else (it == itref)
+            tol = 1e-12 if niter <= 5 else (1e-9 if (early or niter >= 50) else 1e-3)
+            assert np.linalg.norm(x - xref) <= tol * np.linalg.norm(xref), (niter,)
+        # diagonal blocks and a general C together: [S; C; 0.05 I] vs the oracle
+        d = np.full(ncols, np.float32(0.05), np.float32)
+        rhs = np.linspace(-1, 1, ncols)
+        x, it, r = ctx.lsqr_solve_sensit(b[:nl_s], 300, 1e-13, 0.0, 0.0, [d], [rhs])
+        Dm = orc.diag_csr(d)
+        stacked = (np.concatenate([Cm[0], Cm[0][-1] + Dm[0][1:]]), np.concatenate([Cm[1], Dm[1]]), np.concatenate([Cm[2], Dm[2]]))
+        xo, ito, ro = orc.lsqr(S, stacked, ncols, np.concatenate([b, rhs]), 300)
+        assert np.linalg.norm(x - xo) <= 1e-9 * np.linalg.norm(xo)
+    finally:
+        ctx.cons_clear()
+
+
 def test_lsqr_stepping_api_matches_one_shot(ctx, golden_dir):
     g = load(golden_dir, "lsqr")
     case = "damp"

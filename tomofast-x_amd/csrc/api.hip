@@ -105,10 +105,50 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
 }
 
 // ---- matrix upload / download ------------------------------------------------------------------------------
+static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_t ncols, const int64_t *rowptr,
+                           const int32_t *cols, const float *vals, bool require_ascending);
+
 int tfx_matrix_upload_csr(tfx_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
                           const float *vals)
 {
     if (!ctx || !rowptr) return fail(TFX_E_ARG, "tfx_matrix_upload_csr: null argument");
+    return upload_csr_into(ctx, ctx->mat, nrows, ncols, rowptr, cols, vals, true);
+}
+
+// General constraint rows (matrix_cons of joint_inverse_problem.F90:332,544): same storage and kernels as S.
+int tfx_cons_upload_csr(tfx_ctx *ctx, int64_t nrows, const int64_t *rowptr, const int32_t *cols, const float *vals,
+                        const double *rhs)
+{
+    if (!ctx || !rowptr || !rhs) return fail(TFX_E_ARG, "tfx_cons_upload_csr: null argument");
+    if (!ctx->mat.valid) return fail(TFX_E_STATE, "tfx_cons_upload_csr: upload / build S first (it defines ncolumns)");
+    TFX_TRY(upload_csr_into(ctx, ctx->cons, nrows, ctx->mat.ncols, rowptr, cols, vals, true));
+    TFX_TRY(ctx->cons_rhs.ensure((size_t)nrows));
+    TFX_TRY(copy_any(ctx->cons_rhs.p, rhs, (size_t)nrows * sizeof(double), ctx->stream));
+    return 0;
+}
+
+int tfx_cons_clear(tfx_ctx *ctx)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    (void)hipStreamSynchronize(ctx->stream);
+    TiledMatrix &m = ctx->cons;
+    m.codes.release(); m.vals.release(); m.chunk_row0.release(); m.tiles.release(); m.fwd.release(); m.adj.release();
+    m.fwd_order.release(); m.adj_order.release(); m.fwd_partial.release(); m.adj_partial.release();
+    m.fwd_nslots.release(); m.fwd_pbase.release(); m.adj_nslots.release(); m.adj_pbase.release();
+    m.h_tiles.clear(); m.h_fwd.clear(); m.h_adj.clear();
+    m.valid = false;
+    return 0;
+}
+
+static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_t ncols, const int64_t *rowptr,
+                           const int32_t *cols, const float *vals, bool require_ascending)
+{
+    (void)require_ascending;
+    struct Retarget {
+        tfx_ctx *c;
+        Retarget(tfx_ctx *cc, TiledMatrix *t) : c(cc) { c->target = t; }
+        ~Retarget() { c->target = &c->mat; }
+    } retarget(ctx, &dst);
     if (ncols > 0x7fffffffLL || nrows > 0x7fffffffLL) return fail(TFX_E_ARG, "matrix dimension exceeds int32");
     TFX_HIP(hipSetDevice(ctx->device));
     int64_t nnz = rowptr[nrows];
@@ -125,7 +165,7 @@ int tfx_matrix_upload_csr(tfx_ctx *ctx, int64_t nrows, int64_t ncols, const int6
         }
     }
     TFX_TRY(matrix_begin(ctx, nrows, ncols, nnz));
-    TiledMatrix &m = ctx->mat;
+    TiledMatrix &m = dst;
     hipStream_t s = ctx->stream;
     for (int rb = 0; rb < m.nrb; ++rb) {
         int64_t r0 = (int64_t)rb * m.RB, r1 = std::min<int64_t>(nrows, r0 + m.RB);

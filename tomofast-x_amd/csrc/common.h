@@ -126,8 +126,11 @@ struct tfx_ctx {
     tfx::DBuf<double> edges[3];       // xe[nx+1], ye[ny+1], ze[nz+1] when the grid is a tensor product
     bool tensor_grid = false;
     bool force_general_prism = false; // tests: always use the six-array kernel
-    // matrix
+    // matrix S and (optional) general constraint matrix C
     tfx::TiledMatrix mat;
+    tfx::TiledMatrix cons;
+    tfx::DBuf<double> cons_rhs;        // right-hand side of the C rows (replicated)
+    tfx::TiledMatrix *target = &mat;   // which matrix matrix_begin / append / finish assemble
     // scratch vectors for spmv / spmtv with host pointers
     tfx::DBuf<double> vx, vb;
     // comm
@@ -152,6 +155,8 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper);
 int matrix_finish(tfx_ctx *ctx);
 int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);     // b (+)= S x   (device pointers)
 int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);    // b (+)= S^T x
+int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add);
+int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add);
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
 // build.hip
 int detect_tensor_grid(tfx_ctx *ctx);

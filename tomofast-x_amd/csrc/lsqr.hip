@@ -22,7 +22,8 @@ struct Scalars {
 };
 
 struct LsqrState {
-    int64_t nrows = 0, ncols = 0;
+    int64_t nrows = 0, ncols = 0;   // nrows = data rows + rows of the general constraint matrix (if any)
+    int64_t nrows_data = 0;
     int nblocks = 0;
     double rmin = 0, gamma = 0, target_misfit = 0;
     DBuf<double> u;        // nrows + 1 (last = local ||u_cons||^2, rides along in reduction 1)
@@ -249,6 +250,7 @@ static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L)
 {
     hipStream_t s = ctx->stream;
     TFX_TRY(spmtv_dev(ctx, L->u.p, L->v.p, 1));
+    if (ctx->cons.valid) TFX_TRY(spmtv_dev(ctx, ctx->cons, L->u.p + L->nrows_data, L->v.p, 1));     // lsqr_solver2.F90:147, :238
     const int g = grid_for(L->ncols);
     LAUNCH(k_cons_adjoint, g, L->v.p, L->diag.p, L->uc.p, L->ncols, L->nblocks, L->red.p);
     LAUNCH(k_final_sum, 1, L->red.p, g, &L->sc.p->sum_v);
@@ -290,7 +292,11 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     }
     LsqrState *L = ctx->lsqr;
     hipStream_t s = ctx->stream;
-    L->nrows = m.nrows;
+    const bool have_cons = ctx->cons.valid;
+    if (have_cons && ctx->cons.ncols != m.ncols) return fail(TFX_E_STATE, "constraint matrix has %lld columns, S has %lld",
+                                                             (long long)ctx->cons.ncols, (long long)m.ncols);
+    L->nrows_data = m.nrows;
+    L->nrows = m.nrows + (have_cons ? ctx->cons.nrows : 0);
     L->ncols = m.ncols;
     L->nblocks = nblocks;
     L->rmin = rmin;
@@ -313,16 +319,18 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     TFX_HIP(hipMemsetAsync(L->sc.p, 0, sizeof(Scalars), s));
     TFX_HIP(hipMemsetAsync(L->x.p, 0, (size_t)nc * sizeof(double), s));                  // :120
     TFX_HIP(hipMemsetAsync(L->v.p, 0, (size_t)nc * sizeof(double), s));
-    TFX_HIP(hipMemcpyAsync(L->u.p, b_data, (size_t)nr * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemcpyAsync(L->u.p, b_data, (size_t)L->nrows_data * sizeof(double), hipMemcpyDefault, s));
+    if (have_cons)
+        TFX_HIP(hipMemcpyAsync(L->u.p + L->nrows_data, ctx->cons_rhs.p, (size_t)ctx->cons.nrows * sizeof(double), hipMemcpyDeviceToDevice, s));
     for (int b = 0; b < nblocks; ++b) {
         if (!diag[b] || !rhs_blocks[b]) return fail(TFX_E_ARG, "null constraint block %d", b);
         TFX_HIP(hipMemcpyAsync(L->diag.p + (size_t)b * nc, diag[b], (size_t)nc * sizeof(float), hipMemcpyDefault, s));
         TFX_HIP(hipMemcpyAsync(L->uc.p + (size_t)b * nc, rhs_blocks[b], (size_t)nc * sizeof(double), hipMemcpyDefault, s));
     }
     if (target_misfit > 0.0) {                                                            // :98-106
-        TFX_TRY(L->b0.ensure((size_t)nr));
-        TFX_TRY(L->sx.ensure((size_t)nr));
-        TFX_HIP(hipMemcpyAsync(L->b0.p, L->u.p, (size_t)nr * sizeof(double), hipMemcpyDeviceToDevice, s));
+        TFX_TRY(L->b0.ensure((size_t)L->nrows_data));
+        TFX_TRY(L->sx.ensure((size_t)L->nrows_data));
+        TFX_HIP(hipMemcpyAsync(L->b0.p, L->u.p, (size_t)L->nrows_data * sizeof(double), hipMemcpyDeviceToDevice, s));
     }
     // ||u_cons,loc||^2 -> u[nrows], summed over ranks
     {
@@ -361,18 +369,20 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
     int done = 0;
     while (done < k && !L->finished && L->r > L->rmin) {                                  // :163
         if (L->target_misfit > 0.0) {                                                     // :168-189
+            const int64_t nd = L->nrows_data;
             TFX_TRY(spmv_dev(ctx, L->x.p, L->sx.p, 0));
-            TFX_TRY(allreduce(ctx, L->sx.p, nr));
-            const int g = grid_for(nr);
-            LAUNCH(k_misfit, g, L->sx.p, L->b0.p, nr, L->red.p);
+            TFX_TRY(allreduce(ctx, L->sx.p, nd));
+            const int g = grid_for(nd);
+            LAUNCH(k_misfit, g, L->sx.p, L->b0.p, nd, L->red.p);
             LAUNCH(k_final_sum, 1, L->red.p, g, &L->sc.p->misfit_ss);
             TFX_TRY(read_scalars(ctx, L));
-            if (std::sqrt(L->h_sc->misfit_ss / (double)nr) <= L->target_misfit) { L->finished = true; break; }
+            if (std::sqrt(L->h_sc->misfit_ss / (double)nd) <= L->target_misfit) { L->finished = true; break; }
         }
         // u = -alpha u (rank 0) | 0 (others), then u += S_loc v                           :194-209
         LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
         TFX_TRY(spmv_dev(ctx, L->v.p, L->u.p, 1));
-        {                                                                                 // :211 (constraint rows, local)
+        if (ctx->cons.valid) TFX_TRY(spmv_dev(ctx, ctx->cons, L->v.p, L->u.p + L->nrows_data, 1));   // :211 (general C rows)
+        {                                                                                 // :211 (diagonal blocks, local)
             const int g = grid_for(nc);
             LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p);
             LAUNCH(k_final_sum, 1, L->red.p, g, L->u.p + nr);

@@ -184,7 +184,7 @@ __global__ void k_chunk_row0(int nr, const int32_t *__restrict__ segoff, const i
 
 int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 {
-    TiledMatrix &m = ctx->mat;
+    TiledMatrix &m = *ctx->target;
     m.valid = false;
     m.nrows = nrows;
     m.ncols = ncols;
@@ -210,7 +210,7 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int32_t *d_cols, const float *d_vals,
                        const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen)
 {
-    TiledMatrix &m = ctx->mat;
+    TiledMatrix &m = *ctx->target;
     hipStream_t s = ctx->stream;
     int nr = (int)nr64;
     if (row_begin % m.RB != 0 || nr > m.RB || nr <= 0)
@@ -338,7 +338,7 @@ static void build_items(const std::vector<TileMeta> &tiles, bool forward, int64_
 
 int matrix_finish(tfx_ctx *ctx)
 {
-    TiledMatrix &m = ctx->mat;
+    TiledMatrix &m = *ctx->target;
     hipStream_t s = ctx->stream;
     int64_t real = 0;
     for (auto &t : m.h_tiles) real += t.cnt;     // includes empty-row markers; exact nnz is set by the caller
@@ -579,19 +579,22 @@ static void prof_end(tfx_ctx *ctx, int which)
     ctx->prof_n[which] += 1;
 }
 
-int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add)
+int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spmv_dev(ctx, ctx->mat, d_x, d_b, add); }
+int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spmtv_dev(ctx, ctx->mat, d_x, d_b, add); }
+
+int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add)
 {
-    TiledMatrix &m = ctx->mat;
     if (!m.valid) return fail(TFX_E_STATE, "spmv: no matrix");
+    const bool prof = (&m == &ctx->mat);
     hipStream_t s = ctx->stream;
     const size_t lds = (size_t)(m.TC + m.RB) * sizeof(double);
     if (!m.h_fwd.empty()) {
         static size_t lds_set = 0;
         if (lds > lds_set) { TFX_TRY(set_lds_limit((const void *)k_spmv_fwd, lds)); lds_set = lds; }
-        prof_begin(ctx);
+        if (prof) prof_begin(ctx);
         hipLaunchKernelGGL(k_spmv_fwd, dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, m.fwd.p, m.fwd_order.p,
                            m.tiles.p, m.codes.p, m.vals.p, m.chunk_row0.p, d_x, m.fwd_partial.p, m.ncols, m.TC, m.RB);
-        prof_end(ctx, 0);
+        if (prof) prof_end(ctx, 0);
         TFX_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(k_fwd_reduce, dim3((unsigned)((m.nrows + 255) / 256)), dim3(256), 0, s, m.fwd_partial.p,
@@ -600,21 +603,21 @@ int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add)
     return 0;
 }
 
-int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add)
+int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add)
 {
-    TiledMatrix &m = ctx->mat;
     if (!m.valid) return fail(TFX_E_STATE, "spmtv: no matrix");
+    const bool prof = (&m == &ctx->mat);
     hipStream_t s = ctx->stream;
     const size_t lds = (size_t)(m.TC + m.RB) * sizeof(double);
     if (!add) TFX_HIP(hipMemsetAsync(d_b, 0, (size_t)m.ncols * sizeof(double), s));
     if (!m.h_adj.empty()) {
         static size_t lds_set = 0;
         if (lds > lds_set) { TFX_TRY(set_lds_limit((const void *)k_spmv_adj, lds)); lds_set = lds; }
-        prof_begin(ctx);
+        if (prof) prof_begin(ctx);
         hipLaunchKernelGGL(k_spmv_adj, dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, m.adj.p, m.adj_order.p,
                            m.tiles.p, m.codes.p, m.vals.p, m.chunk_row0.p, d_x, d_b, m.adj_partial.p, m.nrows, m.ncols,
                            m.TC, m.RB);
-        prof_end(ctx, 1);
+        if (prof) prof_end(ctx, 1);
         TFX_HIP(hipGetLastError());
         if (m.adj_has_partials)
             hipLaunchKernelGGL(k_adj_reduce, dim3((unsigned)((m.ncols + 255) / 256)), dim3(256), 0, s, m.adj_partial.p,

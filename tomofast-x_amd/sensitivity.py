@@ -176,6 +176,19 @@ class Context:
         check(self._lib.tfx_matrix_download_csr(self._h, ptr(rp), ptr(cols), ptr(vals)))
         return rp, cols[:rp[-1]], vals[:rp[-1]]
 
+    def cons_upload_csr(self, rowptr, cols, vals, rhs):
+        """General constraint rows (matrix_cons) + their right-hand side; used by the next lsqr_* calls."""
+        rp = np.ascontiguousarray(rowptr, np.int64)
+        c = np.ascontiguousarray(cols, np.int32)
+        v = np.ascontiguousarray(vals, np.float32)
+        b = f64(rhs)
+        if b.size != rp.size - 1:
+            raise ValueError("rhs size != number of constraint rows")
+        check(self._lib.tfx_cons_upload_csr(self._h, C.c_int64(rp.size - 1), ptr(rp), ptr(c), ptr(v), ptr(b)))
+
+    def cons_clear(self):
+        check(self._lib.tfx_cons_clear(self._h))
+
     def matrix_free(self):
         check(self._lib.tfx_matrix_free(self._h))
 
