@@ -1,0 +1,107 @@
+"""BASELINE config 1 driven the reference's way: `tomofastx_amd -p Parfile` (Fortran host, amdflang + iso_c_binding over
+libtfx.so) on the mansf_slice example (2 x 128 x 32 cells, 256 data, Haar 0.15, ADMM with 3 lithologies, 60 x 100 LSQR
+iterations), reading the reference's ASCII input formats and writing its output files.  Compared with the files the
+reference itself wrote for the same Parfile (tests/golden/mansf.npz)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tomofast-x_amd", "host", "tomofastx_amd")
+
+# The keys / values of parfiles/Parfile_mansf_slice.txt (section banners and comments of the original omitted)
+PARFILE = """
+global.outputFolderPath     = output/mansf_slice/
+global.description          = Gravity inversion with ADMM constraints (Mansfield area)
+modelGrid.size                      = 2 128 32
+modelGrid.grav.file                 = data/gravmag/mansf_slice/true_model_grav_3litho-grid.txt
+forward.data.grav.nData             = 256
+forward.data.grav.dataGridFile      = data/gravmag/mansf_slice/data_grid.txt
+forward.data.grav.useSyntheticModelForDataValues = 1
+forward.data.grav.syntheticModelFile = data/gravmag/mansf_slice/true_model_grav_3litho-values.txt
+forward.depthWeighting.type         = 1
+forward.depthWeighting.grav.power   = 2.0d0
+sensit.readFromFiles                = 0
+sensit.folderPath                   = output/mansf_slice/SENSIT/
+forward.matrixCompression.type      = 1
+forward.matrixCompression.rate      = 0.15
+inversion.priorModel.type           = 1
+inversion.priorModel.grav.value     = 0.d0
+inversion.startingModel.type        = 1
+inversion.startingModel.grav.value  = 0.d0
+inversion.nMajorIterations          = 60
+inversion.nMinorIterations          = 100
+inversion.writeModelEveryNiter      = 0
+inversion.minResidual               = 1.d-13
+inversion.modelDamping.grav.weight  = 0.d0
+inversion.modelDamping.normPower    = 2.0d0
+inversion.joint.grav.problemWeight  = 1.d0
+inversion.joint.magn.problemWeight  = 0.d0
+inversion.admm.enableADMM           = 1
+inversion.admm.nLithologies         = 3
+inversion.admm.grav.bounds          = -20. 20. 90. 130. 220. 260.
+inversion.admm.grav.weight          = 1.d-5
+"""
+
+
+def write_inputs(wd, g):
+    dd = os.path.join(wd, "data", "gravmag", "mansf_slice")
+    os.makedirs(dd)
+    n = g["X1"].size
+    nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    with open(os.path.join(dd, "true_model_grav_3litho-grid.txt"), "w") as f:
+        f.write("%d\n" % n)
+        for p in range(n):
+            f.write("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %d\n" % (g["X1"][p], g["X2"][p], g["Y1"][p], g["Y2"][p], g["Z1"][p],
+                                                                      g["Z2"][p], i.ravel()[p] + 1, j.ravel()[p] + 1, k.ravel()[p] + 1))
+    with open(os.path.join(dd, "true_model_grav_3litho-values.txt"), "w") as f:
+        f.write("%d\n" % n)
+        f.write("\n".join("%.17g" % v for v in g["model_true"]) + "\n")
+    with open(os.path.join(dd, "data_grid.txt"), "w") as f:
+        f.write("%d\n" % g["obs"].shape[0])
+        for o in g["obs"]:
+            f.write("%.17g %.17g %.17g 0.0\n" % tuple(o))
+    open(os.path.join(wd, "Parfile.txt"), "w").write("# tomofastx_amd parity run\n" + PARFILE)
+
+
+def test_config1_from_parfile_matches_reference_outputs(tmp_path, golden_dir):
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    g = np.load(os.path.join(golden_dir, "mansf.npz"))
+    wd = str(tmp_path)
+    write_inputs(wd, g)
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "nnz_total =" in out.stdout
+    nnz = int(out.stdout.split("nnz_total =")[1].split()[0])
+    assert abs(nnz - 314368) <= 16
+    model = np.loadtxt(os.path.join(wd, "output", "mansf_slice", "model", "grav_final_model_full.txt"), skiprows=1)
+    ref = g["model_final"]
+    assert model.size == ref.size
+    rel = np.linalg.norm(model - ref) / np.linalg.norm(ref)
+    assert rel <= 1e-6, rel
+    dfin = np.loadtxt(os.path.join(wd, "output", "mansf_slice", "data", "grav_final.txt"), skiprows=1)
+    assert np.allclose(dfin[:, :3], g["obs"], rtol=1e-12)
+    assert np.allclose(dfin[:, 3], g["data_final"], rtol=1e-6, atol=1e-9 * np.abs(g["data_final"]).max())
+    dobs = np.loadtxt(os.path.join(wd, "output", "mansf_slice", "data", "grav_observed.txt"), skiprows=1)
+    assert np.allclose(dobs[:, 3], g["data_observed"], rtol=1e-9, atol=1e-12 * np.abs(g["data_observed"]).max())
+    costs = [l.split() for l in open(os.path.join(wd, "output", "mansf_slice", "costs.txt")) if not l.lstrip().startswith("#")]
+    assert len(costs) == 61 and int(costs[-1][0]) == 60
+    assert abs(float(costs[-1][1]) - 9.339172972115141e-11) <= 1e-2 * 9.339172972115141e-11        # final data cost
+    assert abs(float(costs[-1][2]) - 0.22595168071843558) <= 1e-5 * 0.22595168071843558            # final model cost
+
+
+def test_parfile_errors_like_the_reference(tmp_path):
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    out = subprocess.run([EXE], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "UNKNOWN Parfile" in out.stdout
+    open(os.path.join(str(tmp_path), "P.txt"), "w").write("inversion.joint.grav.problemWeight = 1.d0\nfoo.bar = 3\nmodelGrid.size = 2 2 2\n"
+                                                           "forward.data.grav.nData = 3\nforward.depthWeighting.type = 2\n")
+    out = subprocess.run([EXE, "-p", "P.txt"], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "Unknown parameter name: foo.bar" in out.stdout and "depthWeighting.type" in out.stdout

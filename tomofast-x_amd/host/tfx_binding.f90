@@ -87,6 +87,23 @@ module tfx_binding
       type(c_ptr), value :: nnz_hist         ! c_loc(int32 array of N) or c_null_ptr
     end function
 
+    ! the same for the magnetic problem (magprism, src/forward/gravmag/mag/magnetic_field.f90:118-297)
+    integer(c_int) function tfx_build_kernel_mag(ctx, ndata, xd, yd, zd, column_weight, incl, decl, azim, intensity, &
+                                                 compression_type, rate, problem_weight, data_weight, col_begin, col_end, &
+                                                 nnz, error_sum, nnz_hist) bind(C, name="tfx_build_kernel_mag")
+      import :: c_int, c_ptr, c_double, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: ndata, col_begin, col_end
+      real(c_double), intent(in) :: xd(*), yd(*), zd(*), column_weight(*)
+      real(c_double), value :: incl, decl, azim, intensity
+      integer(c_int), value :: compression_type
+      real(c_double), value :: rate, problem_weight
+      type(c_ptr), value :: data_weight
+      integer(c_int64_t), intent(out) :: nnz
+      real(c_double), intent(out) :: error_sum
+      type(c_ptr), value :: nnz_hist
+    end function
+
     ! t_sparse_matrix add_row/new_row/finalize (src/inversion/sparse_matrix.f90:213-293)
     integer(c_int) function tfx_matrix_upload_csr(ctx, nrows, ncols, rowptr, cols, vals) bind(C, name="tfx_matrix_upload_csr")
       import :: c_int, c_ptr, c_float, c_int64_t, c_int32_t

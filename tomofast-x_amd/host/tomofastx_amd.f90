@@ -1,0 +1,541 @@
+!=========================================================================================================
+! tomofastx_amd - Fortran host for the MI355X path with the reference's command line and Parfile interface:
+!
+!     ./tomofastx_amd -p <Parfile>          (src/program_tomofastx.F90:77-80, src/parameters_init.f90:104-119)
+!
+! It re-states the control flow of solve_problem_joint_gravmag (src/problem_joint_gravmag.F90:65-613) and
+! joint_inversion_solve (src/inversion/joint_inverse_problem.F90:393-573) for ONE problem (gravity or magnetic,
+! selected by the problem weights like the reference) and hands every O(N), O(N.Ndata) and O(nnz) step to libtfx.so
+! through tfx_binding (iso_c_binding): depth weight, sensitivity kernel, wavelets, LSQR, forward data.
+! What stays in Fortran is what the reference also does on the host: Parfile parsing, ASCII readers / writers in
+! the reference's formats, the ADMM projection (src/inversion/admm_method.F90:70-134), residuals and costs.
+!
+! Supported Parfile subset: gravity or magnetic (TMI, scalar model) single inversion, depth weighting type 1, Haar / D4
+! compression or none, model damping (L2), ADMM with global bounds, prior / starting model by value or file, data from
+! file or from a synthetic model.  Keys of features whose constraint builders are out of scope (cross-gradient,
+! clustering, gradient damping, local weights, distance weighting) stop with a message when enabled, like the
+! reference stops on an unknown solver (joint_inverse_problem.F90:547-554); unknown keys only warn (:944-947).
+!=========================================================================================================
+module tfx_host_params
+  implicit none
+  integer, parameter :: dp = kind(1.d0)
+
+  type t_par
+    character(len=256) :: path_output = 'output/test/'
+    character(len=256) :: description = ''
+    real(dp) :: data_units_mult(2) = 1.d0, model_units_mult(2) = 1.d0
+    integer :: z_axis_dir = 1
+    integer :: nx = 0, ny = 0, nz = 0
+    character(len=256) :: grid_file(2) = 'None'
+    integer :: ndata(2) = 0
+    character(len=256) :: data_grid_file(2) = 'None'
+    integer :: use_synth(2) = 0
+    character(len=256) :: synth_file(2) = 'None'
+    real(dp) :: mag_incl = 90.d0, mag_decl = 0.d0, mag_intensity = 50000.d0, mag_xaxis_decl = 0.d0
+    integer :: dw_type = 2
+    real(dp) :: dw_power(2) = (/2.d0, 3.d0/), dw_Z0(2) = 0.d0
+    integer :: comp_type = 0
+    real(dp) :: comp_rate = 0.1d0
+    integer :: prior_type = 1, start_type = 1
+    real(dp) :: prior_val(2) = 0.d0, start_val(2) = 0.d0
+    character(len=256) :: prior_file(2) = 'None', start_file(2) = 'None'
+    integer :: nmajor = 10, nminor = 100
+    real(dp) :: target_misfit = 0.d0, rmin = 1.d-13, gamma = 0.d0
+    real(dp) :: alpha(2) = (/1.d-11, 1.d-8/), norm_power = 2.d0
+    real(dp) :: pw(2) = (/1.d0, 0.d0/), cwm(2) = (/4.d3, 1.d0/)
+    integer :: admm = 0, admm_bound_type = 1, nlithos = 1
+    real(dp), allocatable :: bounds(:)
+    real(dp) :: rho(2) = 1.d-7, admm_cost_thr = 1.d-4, admm_mult = 1.d0, admm_max = 1.d+10
+    ! features that need the out-of-scope constraint builders
+    real(dp) :: beta_grad(2) = 0.d0, w_cross = 0.d0, w_clust(2) = 0.d0
+    integer :: apply_local_dw = 0, apply_local_damp = 0, use_error(2) = 0, sensit_read = 0, nmodel_comp = 1, ndata_comp(2) = 1
+  end type t_par
+
+contains
+
+  subroutine stop_msg(msg)
+    character(len=*), intent(in) :: msg
+    ! src/utils/mpi_tools.F90:29-53: banner + abort
+    print *, '**********************************************'
+    print *, 'ERROR: ', trim(msg)
+    print *, '**********************************************'
+    stop 1
+  end subroutine stop_msg
+
+  subroutine read_parfile(path, par)
+    character(len=*), intent(in) :: path
+    type(t_par), intent(inout) :: par
+    character(len=512) :: line, key, val
+    integer :: ios, eq, u
+    open(newunit=u, file=trim(path), status='old', action='read', iostat=ios)
+    if (ios /= 0) call stop_msg('Parfile "'//trim(path)//'" cannot be opened!')
+    do
+      read(u, '(A)', iostat=ios) line
+      if (ios /= 0) exit
+      if (line(1:1) == '#') cycle
+      eq = index(line, '=')
+      if (eq <= 1) cycle
+      key = adjustl(line(:eq - 1))
+      val = adjustl(line(eq + 1:))
+      if (len_trim(key) == 0) cycle
+      select case (trim(key))
+      case ('global.outputFolderPath');            par%path_output = trim(val)
+      case ('global.description');                 par%description = trim(val)
+      case ('global.grav.dataUnitsMultiplier');    read(val, *) par%data_units_mult(1)
+      case ('global.magn.dataUnitsMultiplier');    read(val, *) par%data_units_mult(2)
+      case ('global.grav.modelUnitsMultiplier');   read(val, *) par%model_units_mult(1)
+      case ('global.magn.modelUnitsMultiplier');   read(val, *) par%model_units_mult(2)
+      case ('global.zAxisDirection');              read(val, *) par%z_axis_dir
+      case ('modelGrid.size');                     read(val, *) par%nx, par%ny, par%nz
+      case ('modelGrid.grav.file');                par%grid_file(1) = trim(val)
+      case ('modelGrid.magn.file');                par%grid_file(2) = trim(val)
+      case ('modelGrid.magn.nModelComponents');    read(val, *) par%nmodel_comp
+      case ('forward.data.grav.nData');            read(val, *) par%ndata(1)
+      case ('forward.data.magn.nData');            read(val, *) par%ndata(2)
+      case ('forward.data.grav.dataGridFile');     par%data_grid_file(1) = trim(val)
+      case ('forward.data.magn.dataGridFile');     par%data_grid_file(2) = trim(val)
+      case ('forward.data.grav.nDataComponents');  read(val, *) par%ndata_comp(1)
+      case ('forward.data.magn.nDataComponents');  read(val, *) par%ndata_comp(2)
+      case ('forward.data.grav.useError');         read(val, *) par%use_error(1)
+      case ('forward.data.magn.useError');         read(val, *) par%use_error(2)
+      case ('forward.data.grav.useSyntheticModelForDataValues'); read(val, *) par%use_synth(1)
+      case ('forward.data.magn.useSyntheticModelForDataValues'); read(val, *) par%use_synth(2)
+      case ('forward.data.grav.syntheticModelFile'); par%synth_file(1) = trim(val)
+      case ('forward.data.magn.syntheticModelFile'); par%synth_file(2) = trim(val)
+      case ('forward.magneticField.inclination');  read(val, *) par%mag_incl
+      case ('forward.magneticField.declination');  read(val, *) par%mag_decl
+      case ('forward.magneticField.intensity_nT'); read(val, *) par%mag_intensity
+      case ('forward.magneticField.XaxisDeclination'); read(val, *) par%mag_xaxis_decl
+      case ('forward.depthWeighting.type');        read(val, *) par%dw_type
+      case ('forward.depthWeighting.grav.power');  read(val, *) par%dw_power(1)
+      case ('forward.depthWeighting.magn.power');  read(val, *) par%dw_power(2)
+      case ('forward.depthWeighting.grav.Z0');     read(val, *) par%dw_Z0(1)
+      case ('forward.depthWeighting.magn.Z0');     read(val, *) par%dw_Z0(2)
+      case ('forward.depthWeighting.applyLocalWeight'); read(val, *) par%apply_local_dw
+      case ('sensit.readFromFiles');               read(val, *) par%sensit_read
+      case ('forward.matrixCompression.type');     read(val, *) par%comp_type
+      case ('forward.matrixCompression.rate');     read(val, *) par%comp_rate
+      case ('inversion.priorModel.type');          read(val, *) par%prior_type
+      case ('inversion.priorModel.grav.value');    read(val, *) par%prior_val(1)
+      case ('inversion.priorModel.magn.value');    read(val, *) par%prior_val(2)
+      case ('inversion.priorModel.grav.file');     par%prior_file(1) = trim(val)
+      case ('inversion.priorModel.magn.file');     par%prior_file(2) = trim(val)
+      case ('inversion.startingModel.type');       read(val, *) par%start_type
+      case ('inversion.startingModel.grav.value'); read(val, *) par%start_val(1)
+      case ('inversion.startingModel.magn.value'); read(val, *) par%start_val(2)
+      case ('inversion.startingModel.grav.file');  par%start_file(1) = trim(val)
+      case ('inversion.startingModel.magn.file');  par%start_file(2) = trim(val)
+      case ('inversion.nMajorIterations');         read(val, *) par%nmajor
+      case ('inversion.nMinorIterations');         read(val, *) par%nminor
+      case ('inversion.targetMisfit');             read(val, *) par%target_misfit
+      case ('inversion.minResidual');              read(val, *) par%rmin
+      case ('inversion.softThresholdL1');          read(val, *) par%gamma
+      case ('inversion.modelDamping.grav.weight'); read(val, *) par%alpha(1)
+      case ('inversion.modelDamping.magn.weight'); read(val, *) par%alpha(2)
+      case ('inversion.modelDamping.normPower');   read(val, *) par%norm_power
+      case ('inversion.modelDamping.applyLocalWeight'); read(val, *) par%apply_local_damp
+      case ('inversion.joint.grav.problemWeight'); read(val, *) par%pw(1)
+      case ('inversion.joint.magn.problemWeight'); read(val, *) par%pw(2)
+      case ('inversion.joint.grav.columnWeightMultiplier'); read(val, *) par%cwm(1)
+      case ('inversion.joint.magn.columnWeightMultiplier'); read(val, *) par%cwm(2)
+      case ('inversion.admm.enableADMM');          read(val, *) par%admm
+      case ('inversion.admm.boundType');           read(val, *) par%admm_bound_type
+      case ('inversion.admm.nLithologies');        read(val, *) par%nlithos
+      case ('inversion.admm.grav.bounds', 'inversion.admm.magn.bounds')
+        if (par%admm > 0 .and. par%admm_bound_type == 1) then
+          if (allocated(par%bounds)) deallocate(par%bounds)
+          allocate(par%bounds(2 * par%nlithos))
+          read(val, *) par%bounds
+        endif
+      case ('inversion.admm.grav.weight');         read(val, *) par%rho(1)
+      case ('inversion.admm.magn.weight');         read(val, *) par%rho(2)
+      case ('inversion.admm.dataCostThreshold');   read(val, *) par%admm_cost_thr
+      case ('inversion.admm.weightMultiplier');    read(val, *) par%admm_mult
+      case ('inversion.admm.maxWeight');           read(val, *) par%admm_max
+      case ('inversion.dampingGradient.grav.weight'); read(val, *) par%beta_grad(1)
+      case ('inversion.dampingGradient.magn.weight'); read(val, *) par%beta_grad(2)
+      case ('inversion.crossGradient.weight');     read(val, *) par%w_cross
+      case ('inversion.clustering.grav.weight');   read(val, *) par%w_clust(1)
+      case ('inversion.clustering.magn.weight');   read(val, *) par%w_clust(2)
+      case ('sensit.folderPath', 'inversion.writeModelEveryNiter', 'inversion.solver', 'forward.data.grav.type', &
+            'output.paraview.grav.modelLabel', 'output.paraview.magn.modelLabel', 'inversion.priorModel.nModels', &
+            'forward.depthWeighting.grav.beta', 'forward.depthWeighting.magn.beta')
+        continue
+      case default
+        print *, 'WARNING: Unknown parameter name: ', trim(key)
+      end select
+    enddo
+    close(u)
+    print *, 'Finished reading the parameter file.'
+  end subroutine read_parfile
+
+end module tfx_host_params
+
+!=========================================================================================================
+module tfx_host_io
+  use tfx_host_params
+  implicit none
+contains
+
+  ! Model grid file, 9-column format "X1 X2 Y1 Y2 Z1 Z2 i j k" after a header line with the cell count
+  ! (src/inversion/model_IO.F90:135-241)
+  subroutine read_model_grid(file, n, X1, X2, Y1, Y2, Z1, Z2)
+    character(len=*), intent(in) :: file
+    integer, intent(in) :: n
+    real(dp), intent(out) :: X1(n), X2(n), Y1(n), Y2(n), Z1(n), Z2(n)
+    integer :: u, ios, nfile, p, i, j, k
+    open(newunit=u, file=trim(file), status='old', action='read', iostat=ios)
+    if (ios /= 0) call stop_msg('Error in opening the model grid file '//trim(file))
+    read(u, *) nfile
+    if (nfile /= n) call stop_msg('The grid is not correctly defined (nx*ny*nz differs from the file)!')
+    do p = 1, n
+      read(u, *, iostat=ios) X1(p), X2(p), Y1(p), Y2(p), Z1(p), Z2(p), i, j, k
+      if (ios /= 0) call stop_msg('Problem while reading the model grid file!')
+    enddo
+    close(u)
+  end subroutine read_model_grid
+
+  ! One value per line after a header line with the count (src/inversion/model_IO.F90:87-130)
+  subroutine read_model_values(file, n, val)
+    character(len=*), intent(in) :: file
+    integer, intent(in) :: n
+    real(dp), intent(out) :: val(n)
+    integer :: u, ios, nfile, p
+    open(newunit=u, file=trim(file), status='old', action='read', iostat=ios)
+    if (ios /= 0) call stop_msg('Error in opening the model file '//trim(file))
+    read(u, *) nfile
+    if (nfile /= n) call stop_msg('The model size in the file differs from the grid!')
+    do p = 1, n
+      read(u, *, iostat=ios) val(p)
+      if (ios /= 0) call stop_msg('Problem while reading the model file!')
+    enddo
+    close(u)
+  end subroutine read_model_values
+
+  ! "x y z value" per line after a header line with the count (src/forward/gravmag/data_gravmag.f90:204-239)
+  subroutine read_data(file, n, X, Y, Z, val)
+    character(len=*), intent(in) :: file
+    integer, intent(in) :: n
+    real(dp), intent(out) :: X(n), Y(n), Z(n), val(n)
+    integer :: u, ios, nfile, i
+    open(newunit=u, file=trim(file), status='old', action='read', iostat=ios)
+    if (ios /= 0) call stop_msg('Error in opening the data file!')
+    read(u, *) nfile
+    if (nfile /= n) call stop_msg('The number of data in Parfile differs from the data file!')
+    do i = 1, n
+      read(u, *, iostat=ios) X(i), Y(i), Z(i), val(i)
+      if (ios /= 0) call stop_msg('Problem while reading the data file! Verify the number of data components.')
+    enddo
+    close(u)
+  end subroutine read_data
+
+  subroutine make_dir(path)
+    character(len=*), intent(in) :: path
+    call execute_command_line('mkdir -p "'//trim(path)//'"')       ! src/utils/file_utils.F90:31-41
+  end subroutine make_dir
+
+  ! src/forward/gravmag/data_gravmag.f90:293-336
+  subroutine write_data(path_output, name, n, X, Y, Z, val, units_mult, z_axis_dir)
+    character(len=*), intent(in) :: path_output, name
+    integer, intent(in) :: n, z_axis_dir
+    real(dp), intent(in) :: X(n), Y(n), Z(n), val(n), units_mult
+    integer :: u, i
+    call make_dir(trim(path_output)//'/data')
+    open(newunit=u, file=trim(path_output)//'/data/'//trim(name)//'.txt', status='replace', action='write')
+    write(u, *) n
+    do i = 1, n
+      write(u, *) X(i), Y(i), real(z_axis_dir, dp) * Z(i), val(i) / units_mult
+    enddo
+    close(u)
+  end subroutine write_data
+
+  ! src/inversion/model_IO.F90:504-539
+  subroutine write_model(path_output, name, n, val, units_mult)
+    character(len=*), intent(in) :: path_output, name
+    integer, intent(in) :: n
+    real(dp), intent(in) :: val(n), units_mult
+    integer :: u, p
+    call make_dir(trim(path_output)//'/model')
+    open(newunit=u, file=trim(path_output)//'/model/'//trim(name), status='replace', action='write')
+    write(u, *) n
+    do p = 1, n
+      write(u, *) val(p) / units_mult
+    enddo
+    close(u)
+  end subroutine write_model
+
+end module tfx_host_io
+
+!=========================================================================================================
+program tomofastx_amd
+  use iso_c_binding
+  use tfx_binding
+  use tfx_host_params
+  use tfx_host_io
+  implicit none
+
+  type(t_par) :: par
+  character(len=256) :: arg, parfile
+  character(len=4) :: suffix(2) = (/'grav', 'magn'/)
+  integer :: ip, n, nd, it, i, nblocks, ucost, narg
+  integer(c_int) :: iters
+  integer(c_int64_t) :: nnz
+  real(c_double) :: err_sum, r
+  type(c_ptr) :: ctx, dptr(2), rptr(2)
+  real(dp), allocatable, target :: X1(:), X2(:), Y1(:), Y2(:), Z1(:), Z2(:), cw(:)
+  real(dp), allocatable, target :: Xd(:), Yd(:), Zd(:), d_meas(:), d_calc(:), dw(:), res(:), b_data(:)
+  real(dp), allocatable, target :: m(:), m_prior(:), m_synth(:), work(:), x(:), rhs1(:), rhs2(:), z_admm(:), u_admm(:), x0(:)
+  real(c_float), allocatable, target :: diag1(:), diag2(:)
+  real(dp) :: cost_data, cost_model, cost_admm, pw, rho, s1, s2
+
+  ! ---- command line (src/parameters_init.f90:104-119)
+  parfile = ''
+  narg = command_argument_count()
+  i = 1
+  do while (i <= narg)
+    call get_command_argument(i, arg)
+    if (trim(arg) == '-p' .or. trim(arg) == '-j') then
+      if (i + 1 > narg) call stop_msg('UNKNOWN Parfile! Use -p <Parfile_path>')
+      call get_command_argument(i + 1, parfile)
+      i = i + 1
+    endif
+    i = i + 1
+  enddo
+  if (len_trim(parfile) == 0) call stop_msg('UNKNOWN Parfile! Use -p <Parfile_path>')
+  print *, 'Started Tomofast-x (MI355X host), Parfile = ', trim(parfile)
+  call read_parfile(parfile, par)
+
+  ! ---- which problem (src/problem_joint_gravmag.F90:108-112)
+  if (par%pw(1) /= 0.d0 .and. par%pw(2) /= 0.d0) &
+    call stop_msg('Joint inversion needs the coupling-constraint builders (cross-gradient / clustering): not in this host.')
+  ip = merge(1, 2, par%pw(1) /= 0.d0)
+  if (par%pw(ip) == 0.d0) call stop_msg('Both problem weights are zero!')
+  pw = par%pw(ip)
+  if (par%dw_type /= 1) call stop_msg('forward.depthWeighting.type /= 1 is not supported by this host yet (SURVEY 8f-3).')
+  if (par%beta_grad(ip) /= 0.d0 .or. par%w_cross /= 0.d0 .or. par%w_clust(ip) /= 0.d0) &
+    call stop_msg('Gradient damping / cross-gradient / clustering constraints are not supported by this host.')
+  if (par%apply_local_dw /= 0 .or. par%apply_local_damp /= 0 .or. par%use_error(ip) /= 0) &
+    call stop_msg('Local weights / data errors are not supported by this host yet.')
+  if (par%norm_power /= 2.d0) call stop_msg('inversion.modelDamping.normPower /= 2 is not supported by this host yet.')
+  if (par%admm > 0 .and. par%admm_bound_type /= 1) call stop_msg('ADMM with local bounds (boundType 2) is not supported yet.')
+  if (par%sensit_read /= 0) call stop_msg('sensit.readFromFiles /= 0 is not supported by this host yet (SURVEY 8f-2).')
+  if (par%nmodel_comp /= 1 .or. par%ndata_comp(ip) /= 1) call stop_msg('Only 1 model and 1 data component are supported.')
+  if (par%admm > 0 .and. .not. allocated(par%bounds)) call stop_msg('Global bounds are not defined!')
+
+  n = par%nx * par%ny * par%nz
+  nd = par%ndata(ip)
+  if (n <= 0 .or. nd <= 0) call stop_msg('Wrong model grid size or number of data!')
+  allocate(X1(n), X2(n), Y1(n), Y2(n), Z1(n), Z2(n), cw(n), m(n), m_prior(n), m_synth(n), work(n), x(n), rhs1(n), rhs2(n))
+  allocate(z_admm(n), u_admm(n), x0(n), diag1(n), diag2(n))
+  allocate(Xd(nd), Yd(nd), Zd(nd), d_meas(nd), d_calc(nd), dw(nd), res(nd), b_data(nd))
+
+  ! ---- (I) model grid and data (problem_joint_gravmag.F90:140-157)
+  call read_model_grid(par%grid_file(ip), n, X1, X2, Y1, Y2, Z1, Z2)
+  call read_data(par%data_grid_file(ip), nd, Xd, Yd, Zd, d_meas)
+  d_meas = d_meas * par%data_units_mult(ip)
+  dw = 1.d0
+
+  call tfx_check(tfx_create(0_c_int, c_null_ptr, ctx), 'tfx_create')
+  call tfx_check(tfx_set_grid(ctx, par%nx, par%ny, par%nz, X1, X2, Y1, Y2, Z1, Z2), 'tfx_set_grid')
+
+  ! ---- (II) depth weight (:174-178)
+  print *, 'Calculating the depth weight, type = ', par%dw_type
+  call tfx_check(tfx_column_weight_type1(ctx, par%dw_power(ip), par%dw_Z0(ip), par%cwm(ip), cw), 'calculate_depth_weight')
+
+  ! ---- (III) sensitivity kernel (:197-248)
+  if (ip == 1) then
+    print *, 'Calculating GRAVITY sensitivity kernel...'
+    call tfx_check(tfx_build_kernel_grav(ctx, int(nd, c_int64_t), Xd, Yd, Zd, cw, par%comp_type, par%comp_rate, pw, c_null_ptr, &
+                                         0_c_int64_t, int(n, c_int64_t), nnz, err_sum, c_null_ptr), 'calculate_and_write_sensit')
+  else
+    print *, 'Calculating MAGNETIC sensitivity kernel...'
+    call tfx_check(tfx_build_kernel_mag(ctx, int(nd, c_int64_t), Xd, Yd, Zd, cw, par%mag_incl, par%mag_decl, par%mag_xaxis_decl, &
+                                        par%mag_intensity, par%comp_type, par%comp_rate, pw, c_null_ptr, 0_c_int64_t, &
+                                        int(n, c_int64_t), nnz, err_sum, c_null_ptr), 'calculate_and_write_sensit')
+  endif
+  print *, 'nnz_total = ', nnz
+  print *, 'COMPRESSION RATE = ', dble(nnz) / dble(n) / dble(nd)
+  print *, 'COMPRESSION ERROR, r = ', err_sum / dble(nd)
+
+  ! ---- data from the synthetic model (:318-345)
+  if (par%use_synth(ip) > 0) then
+    call read_model_values(par%synth_file(ip), n, m_synth)
+    m_synth = m_synth * par%model_units_mult(ip)
+    call calculate_data(m_synth, d_calc)
+    d_meas = d_calc
+    call write_data(par%path_output, suffix(ip)//'_synthetic', nd, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
+  endif
+  call write_data(par%path_output, suffix(ip)//'_observed', nd, Xd, Yd, Zd, d_meas, par%data_units_mult(ip), par%z_axis_dir)
+
+  ! ---- prior and starting models (:350-441)
+  if (par%prior_type == 1) then
+    m_prior = par%prior_val(ip)
+  else
+    call read_model_values(par%prior_file(ip), n, m_prior)
+  endif
+  m_prior = m_prior * par%model_units_mult(ip)
+  if (par%start_type == 1) then
+    m = par%start_val(ip)
+  else
+    call read_model_values(par%start_file(ip), n, m)
+  endif
+  m = m * par%model_units_mult(ip)
+  call calculate_data(m, d_calc)
+  call write_data(par%path_output, suffix(ip)//'_starting', nd, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
+
+  ! ---- costs (:443-470)
+  call model_cost(cost_model)
+  cost_data = norm2(d_calc - d_meas) / norm2(d_meas)
+  cost_admm = 0.d0
+  call make_dir(par%path_output)
+  open(newunit=ucost, file=trim(par%path_output)//'/costs.txt', status='replace', action='write')
+  write(ucost, *) '# 1:iteration, 2:data_cost, 3:model_cost, 4:ADMM_cost, 5:ADMM_weight'
+  z_admm = 0.d0
+  u_admm = 0.d0
+  rho = par%rho(ip)
+
+  ! ---- (V) major inversion loop (:473-547)
+  do it = 1, par%nmajor
+    if (stop_file_exists()) then
+      print *, 'Stop file found! Exiting the loop.'
+      exit
+    endif
+    print *, '======================================================='
+    print *, 'Iteration =', it
+    print *, '======================================================='
+    res = dw * (d_meas - d_calc)                                   ! :666-675
+    b_data = pw * res                                              ! joint_inverse_problem.F90:379-387
+    nblocks = 0
+    if (par%alpha(ip) /= 0.d0) then                                ! damping.F90:97-234
+      nblocks = nblocks + 1
+      work = (m - m_prior) / cw
+      call to_wavelet(work)
+      diag1 = real(par%alpha(ip) * pw, c_float)
+      rhs1 = -par%alpha(ip) * pw * work
+      dptr(nblocks) = c_loc(diag1)
+      rptr(nblocks) = c_loc(rhs1)
+    endif
+    if (par%admm > 0) then                                         ! joint_inverse_problem.F90:497-527
+      nblocks = nblocks + 1
+      call iterate_admm_arrays(n, par%nlithos, par%bounds, m, z_admm, u_admm, x0)
+      work = (m - x0) / cw
+      call to_wavelet(work)
+      diag2 = real(rho * pw, c_float)
+      rhs2 = -rho * pw * work
+      dptr(nblocks) = c_loc(diag2)
+      rptr(nblocks) = c_loc(rhs2)
+      s1 = sum((z_admm - m)**2)
+      s2 = sum(z_admm**2)
+      cost_admm = 0.d0
+      if (s2 /= 0.d0) cost_admm = sqrt(s1 / s2)                    ! costs.f90:38-69
+      print *, 'ADMM cost |x - z| / |z| =', cost_admm
+    endif
+    call tfx_check(tfx_lsqr_solve(ctx, par%nminor, par%rmin, par%gamma, par%target_misfit, b_data, nblocks, dptr, rptr, x, &
+                                  iters, r), 'lsqr_solve_sensit')
+    print *, 'Finished lsqr solver, r =', r, ' iter =', iters
+    if (par%comp_type > 0) &                                       ! :559-567
+      call tfx_check(tfx_wavelet(ctx, x, par%nx, par%ny, par%nz, 1_c_int64_t, par%comp_type, 2_c_int), 'inverse_wavelet')
+    x = x * cw                                                     ! :570
+    m = m + x                                                      ! problem_joint_gravmag.F90:500
+    call calculate_data(m, d_calc)                                 ! :513
+    write(ucost, *) it - 1, cost_data, cost_model, cost_admm, rho  ! :519-528 (costs of the previous iteration)
+    flush(ucost)
+    call model_cost(cost_model)
+    cost_data = norm2(d_calc - d_meas) / norm2(d_meas)             ! data_gravmag.f90:123-129
+    print *, 'data cost (new) =', cost_data
+    if (par%admm > 0 .and. cost_data < par%admm_cost_thr .and. rho < par%admm_max .and. par%admm_mult /= 1.d0) then
+      rho = par%admm_mult * rho                                    ! :618-638
+      print *, 'Increased the ADMM weight to:', rho
+    endif
+  enddo
+  write(ucost, *) par%nmajor, cost_data, cost_model, cost_admm, rho
+  close(ucost)
+
+  ! ---- outputs (:552-600)
+  call write_data(par%path_output, suffix(ip)//'_final', nd, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
+  call write_model(par%path_output, suffix(ip)//'_final_model_full.txt', n, m, par%model_units_mult(ip))
+  print *, 'model min / max =', minval(m), maxval(m)
+  call tfx_check(tfx_destroy(ctx), 'tfx_destroy')
+  print *, 'THE END.'
+
+contains
+
+  subroutine to_wavelet(v)
+    real(dp), intent(inout) :: v(n)
+    if (par%comp_type > 0) &
+      call tfx_check(tfx_wavelet(ctx, v, par%nx, par%ny, par%nz, 1_c_int64_t, par%comp_type, 1_c_int), 'forward_wavelet')
+  end subroutine to_wavelet
+
+  ! model_calculate_data, src/inversion/model.F90:220-307
+  subroutine calculate_data(model, dcalc)
+    real(dp), intent(in) :: model(n)
+    real(dp), intent(out) :: dcalc(nd)
+    integer :: p
+    do p = 1, n
+      if (cw(p) /= 0.d0) then
+        work(p) = model(p) / cw(p)
+      else
+        work(p) = 0.d0
+      endif
+    enddo
+    call to_wavelet(work)
+    call tfx_check(tfx_calc_data(ctx, work, pw, c_null_ptr, dcalc), 'model_calculate_data')
+  end subroutine calculate_data
+
+  ! calculate_cost_model, src/utils/costs.f90:74-113
+  subroutine model_cost(cost)
+    real(dp), intent(out) :: cost
+    integer :: p
+    cost = 0.d0
+    do p = 1, n
+      if (cw(p) /= 0.d0) cost = cost + (abs((m(p) - m_prior(p)) / cw(p)))**par%norm_power
+    enddo
+  end subroutine model_cost
+
+  ! src/problem_joint_gravmag.F90:680-700
+  logical function stop_file_exists()
+    inquire(file='stop', exist=stop_file_exists)
+  end function stop_file_exists
+
+  ! admm_method_iterate_admm_arrays, src/inversion/admm_method.F90:70-134 (global bounds)
+  subroutine iterate_admm_arrays(nel, nlithos, bounds, xm, z, u, x0out)
+    integer, intent(in) :: nel, nlithos
+    real(dp), intent(in) :: bounds(2 * nlithos), xm(nel)
+    real(dp), intent(inout) :: z(nel), u(nel)
+    real(dp), intent(out) :: x0out(nel)
+    integer :: p, j
+    real(dp) :: a, mindist, v, closest
+    logical :: inside
+    do p = 1, nel
+      a = xm(p) + u(p)
+      inside = .false.
+      do j = 1, nlithos
+        if (bounds(2 * j - 1) <= a .and. a <= bounds(2 * j)) then
+          inside = .true.
+          z(p) = a
+          exit
+        endif
+      enddo
+      if (.not. inside) then
+        mindist = 1.d30
+        closest = a
+        do j = 1, nlithos
+          v = dabs(bounds(2 * j - 1) - a)
+          if (v < mindist) then
+            mindist = v
+            closest = bounds(2 * j - 1)
+          endif
+          v = dabs(bounds(2 * j) - a)
+          if (v < mindist) then
+            mindist = v
+            closest = bounds(2 * j)
+          endif
+        enddo
+        z(p) = closest
+      endif
+    enddo
+    u = u + xm - z
+    x0out = z - u
+  end subroutine iterate_admm_arrays
+
+end program tomofastx_amd
