@@ -5,4 +5,4 @@ The directory name follows the project convention and is not a Python identifier
 Everything numerical runs in hand-written HIP kernels (csrc/ -> libtfx.so) behind the C ABI of include/tfx.h."""
 from .lib import TfxError, SO_PATH, SYMBOLS, load          # noqa: F401
 from .sensitivity import Context, get_load_balancing_nelements   # noqa: F401
-from . import synthetic, inversion, distributed             # noqa: F401
+from . import synthetic, inversion, distributed, sensit_io  # noqa: F401
