@@ -64,6 +64,11 @@ int tfx_set_grid(tfx_ctx *ctx, int nx, int ny, int nz, const double *X1, const d
  * column_weight *= multiplier (src/problem_joint_gravmag.F90:178).  cw_out: N doubles.                      */
 int tfx_column_weight_type1(tfx_ctx *ctx, double power, double Z0, double multiplier, double *cw_out);
 
+/* calculate_depth_weight type 2, distance weighting (weights_gravmag.f90:81-138, the reference's default type), with the
+ * same tail (sqrt(volume), max-normalise, invert, multiplier).                                                   */
+int tfx_column_weight_type2(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double power,
+                            double beta, double multiplier, double *cw_out);
+
 /* ---- unit-level kernels (also what the parity tests call) ------------------------------------------------ */
 /* graviprism_z (src/forward/gravmag/grav/gravity_field.f90:131-195): ndata rows of N, rows_out[ndata*N].    */
 int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,

@@ -161,6 +161,47 @@ int orc_column_weight_type1(int64_t n, const double *X1, const double *X2, const
     return 0;
 }
 
+/* Distance weighting (type 2), weights_gravmag.f90:81-138 + the common tail :170-195 and problem_joint_gravmag.F90:178.
+ * Li & Oldenburg (2000) Eq. 19: per cell, sum over the data of the squared 8-point estimate of the kernel integral. */
+int orc_column_weight_type2(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                            const double *Z1, const double *Z2, int64_t ndata, const double *xd, const double *yd,
+                            const double *zd, double power, double beta, double multiplier, double *cw)
+{
+    const double R0 = 0.1, dfactor = 0.25;                               /* :85-88 */
+    double norm = -HUGE_VAL;
+    for (int64_t p = 0; p < n; ++p) {
+        double dVj = fabs((X2[p] - X1[p]) * (Y2[p] - Y1[p]) * (Z2[p] - Z1[p]));
+        double dhx = dfactor * fabs(X2[p] - X1[p]), dhy = dfactor * fabs(Y2[p] - Y1[p]), dhz = dfactor * fabs(Z2[p] - Z1[p]);
+        double wr = 0.0;
+        for (int64_t j = 0; j < ndata; ++j) {
+            double dx[2], dy[2], dz[2];
+            dx[0] = pow(X1[p] + dhx - xd[j], 2.0); dy[0] = pow(Y1[p] + dhy - yd[j], 2.0); dz[0] = pow(Z1[p] + dhz - zd[j], 2.0);
+            dx[1] = pow(X2[p] - dhx - xd[j], 2.0); dy[1] = pow(Y2[p] - dhy - yd[j], 2.0); dz[1] = pow(Z2[p] - dhz - zd[j], 2.0);
+            double integral = 0.0;
+            for (int ii = 0; ii < 2; ++ii)
+                for (int jj = 0; jj < 2; ++jj)
+                    for (int kk = 0; kk < 2; ++kk) {
+                        double R = sqrt(dx[ii] + dy[jj] + dz[kk]);                               /* :115 */
+                        integral = integral + 1.0 / pow(R + R0, power);                          /* :121-123 */
+                    }
+            integral = integral * dVj / 8.0;                                                     /* :124 */
+            wr = wr + pow(integral, 2.0);                                                        /* :126 */
+        }
+        double w = (1.0 / sqrt(dVj)) * pow(wr, beta / 4.0);                                      /* :130 */
+        w = w * sqrt(dVj);                                                                       /* :174 */
+        cw[p] = w;
+        if (w > norm) norm = w;
+    }
+    if (norm == 0) return -2;
+    for (int64_t i = 0; i < n; ++i) {
+        cw[i] = cw[i] / norm;
+        if (cw[i] == 0.0) return -2;
+        cw[i] = 1.0 / cw[i];
+        cw[i] = cw[i] * multiplier;
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Lifting wavelets, wavelet_transform.F90.  One axis at a time (x, y, z), per axis all levels.
  * idx(a, o) addresses element a (0-based) of a line along the axis; the other two indices are

@@ -291,7 +291,7 @@ forward.data.grav.nData             = {nd}
 forward.data.grav.dataGridFile      = data_grid.txt
 forward.data.grav.useSyntheticModelForDataValues = 1
 forward.data.grav.syntheticModelFile = model_true.txt
-forward.depthWeighting.type         = 1
+forward.depthWeighting.type         = {dwtype}
 forward.depthWeighting.grav.power   = 2.0d0
 sensit.readFromFiles                = 0
 sensit.folderPath                   = out/SENSIT/
@@ -331,10 +331,16 @@ def make_e2e(tmp):
         "e2e_haar": dict(nx=16, ny=12, nz=8, ox=6, oy=5, ctype=1, rate="0.1d0", nmajor=3, nminor=20, alpha="1.d-7"),
         "e2e_d4": dict(nx=13, ny=7, nz=9, ox=4, oy=3, ctype=2, rate="0.2d0", nmajor=2, nminor=30, alpha="1.d-7"),
         "e2e_full": dict(nx=8, ny=6, nz=5, ox=3, oy=3, ctype=0, rate="1.d0", nmajor=2, nminor=25, alpha="1.d-6"),
+        # distance weighting (forward.depthWeighting.type = 2, the reference's default)
+        "e2e_dw2": dict(nx=10, ny=9, nz=6, ox=4, oy=3, ctype=1, rate="0.2d0", nmajor=2, nminor=20, alpha="1.d-7", dwtype=2),
     }
+    only = os.environ.get("GOLDEN_E2E_ONLY")
+    if only:
+        cfgs = {k: v for k, v in cfgs.items() if k in only.split(",")}
     for name, c in cfgs.items():
         g, obs, mtrue = synthetic_problem(c["nx"], c["ny"], c["nz"], c["ox"], c["oy"])
         nd = obs.shape[0]
+        c.setdefault("dwtype", 1)
         par = PAR_TMPL.format(nd=nd, **c)
         res = {}
         for nproc in (1, 2):
@@ -356,7 +362,7 @@ def make_e2e(tmp):
             o = collect_run(wd, log, "out", nproc)
             for kk, vv in o.items():
                 res["np%d_%s" % (nproc, kk)] = vv
-        res.update(dict(nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=float(c["rate"].replace("d", "e")),
+        res.update(dict(dwtype=c["dwtype"], nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=float(c["rate"].replace("d", "e")),
                         nmajor=c["nmajor"], nminor=c["nminor"], alpha=float(c["alpha"].replace("d", "e")),
                         X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs, model_true=mtrue))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)

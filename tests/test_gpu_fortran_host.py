@@ -102,6 +102,6 @@ def test_parfile_errors_like_the_reference(tmp_path):
     out = subprocess.run([EXE], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "UNKNOWN Parfile" in out.stdout
     open(os.path.join(str(tmp_path), "P.txt"), "w").write("inversion.joint.grav.problemWeight = 1.d0\nfoo.bar = 3\nmodelGrid.size = 2 2 2\n"
-                                                           "forward.data.grav.nData = 3\nforward.depthWeighting.type = 2\n")
+                                                           "forward.data.grav.nData = 3\nforward.depthWeighting.type = 3\n")
     out = subprocess.run([EXE, "-p", "P.txt"], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "Unknown parameter name: foo.bar" in out.stdout and "depthWeighting.type" in out.stdout

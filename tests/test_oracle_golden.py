@@ -93,6 +93,12 @@ def test_build_rows_weights_partition(golden_dir, name):
     assert bits_equal(g["np2_cols"], g["np1_cols"]) and bits_equal(g["np2_vals"], g["np1_vals"])
 
 
+def test_distance_weight_type2_bit_exact(golden_dir):
+    g = load(golden_dir, "e2e_dw2")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    assert bits_equal(orc.column_weight_type2(grid, g["obs"]), g["np1_column_weight"])
+
+
 @pytest.mark.parametrize("name", ["e2e_haar", "e2e_d4", "e2e_full"])
 def test_end_to_end_inversion(golden_dir, name):
     g = load(golden_dir, name)

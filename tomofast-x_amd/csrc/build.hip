@@ -436,6 +436,60 @@ __global__ void k_depth_weight_finish(int64_t N, double *__restrict__ w, const u
     }
 }
 
+// distance weighting, type 2 (weights_gravmag.f90:81-138): one thread per cell, sequential sum over the data in the
+// reference's order; the data coordinates are wave-uniform scalar loads.  (R+R0)^power: x*x / x*x*x for the usual
+// integer powers (what a correctly rounded pow returns up to the last bit), pow() otherwise.
+__device__ __forceinline__ double pow_int_or_general(double x, double p)
+{
+    if (p == 2.0) return x * x;
+    if (p == 3.0) return x * x * x;
+    return pow(x, p);
+}
+
+__global__ __launch_bounds__(256) void k_distance_weight(int64_t N, const double *__restrict__ X1, const double *__restrict__ X2,
+                                                         const double *__restrict__ Y1, const double *__restrict__ Y2,
+                                                         const double *__restrict__ Z1, const double *__restrict__ Z2,
+                                                         int64_t ndata, const double *__restrict__ xd, const double *__restrict__ yd,
+                                                         const double *__restrict__ zd, double power, double beta,
+                                                         double *__restrict__ w, unsigned long long *__restrict__ maxbits)
+{
+    const double R0 = 0.1, dfactor = 0.25;                                                  // :85-88
+    double mx = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
+        const double x1 = X1[p], x2 = X2[p], y1 = Y1[p], y2 = Y2[p], z1 = Z1[p], z2 = Z2[p];
+        const double dVj = fabs((x2 - x1) * (y2 - y1) * (z2 - z1));
+        const double dhx = dfactor * fabs(x2 - x1), dhy = dfactor * fabs(y2 - y1), dhz = dfactor * fabs(z2 - z1);
+        double wr = 0.0;
+        for (int64_t j = 0; j < ndata; ++j) {
+            double dx[2], dy[2], dz[2];
+            double t;
+            t = x1 + dhx - xd[j]; dx[0] = t * t;                                            // :100-106
+            t = y1 + dhy - yd[j]; dy[0] = t * t;
+            t = z1 + dhz - zd[j]; dz[0] = t * t;
+            t = x2 - dhx - xd[j]; dx[1] = t * t;
+            t = y2 - dhy - yd[j]; dy[1] = t * t;
+            t = z2 - dhz - zd[j]; dz[1] = t * t;
+            double integral = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const double R = sqrt(dx[ii] + dy[jj] + dz[kk]);                    // :115
+                        integral = integral + 1.0 / pow_int_or_general(R + R0, power);      // :121-123
+                    }
+            integral = integral * dVj / 8.0;                                                // :124
+            wr = wr + integral * integral;                                                  // :126
+        }
+        double v = (1.0 / sqrt(dVj)) * pow(wr, beta / 4.0);                                 // :130
+        v = v * sqrt(dVj);                                                                  // :174
+        w[p] = v;
+        mx = fmax(mx, v);
+    }
+    atomicMax(maxbits, (unsigned long long)__double_as_longlong(mx));
+}
+
 // =============================================================================================================
 // lifting wavelets: one LDS tile = XT lines x L positions, all levels of the axis done in LDS
 // =============================================================================================================
@@ -1144,6 +1198,41 @@ int tfx_column_weight_type1(tfx_ctx *ctx, double power, double Z0, double multip
     TFX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, s));
     TFX_HIP(hipStreamSynchronize(s));
     if (herr & 1) return fail(TFX_E_NUMERIC, "Error: non-positive depth in calc_depth_weight_pixel!");
+    if (herr & 2) return fail(TFX_E_NUMERIC, "Zero damping weight! Exiting.");
+    TFX_TRY(copy_any(cw_out, w.p, (size_t)N * sizeof(double), s));
+    return 0;
+}
+
+int tfx_column_weight_type2(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double power,
+                            double beta, double multiplier, double *cw_out)
+{
+    if (!ctx || !cw_out || !xd || !yd || !zd) return fail(TFX_E_ARG, "tfx_column_weight_type2: null argument");
+    if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_column_weight_type2: set the grid first");
+    if (ndata <= 0) return fail(TFX_E_ARG, "no data");
+    TFX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int64_t N = ctx->N;
+    DBuf<double> w, dobs;
+    DBuf<unsigned long long> mx;
+    DBuf<int> derr;
+    TFX_TRY(w.alloc((size_t)N));
+    TFX_TRY(dobs.alloc((size_t)3 * ndata));
+    TFX_TRY(mx.alloc(1));
+    TFX_TRY(derr.alloc(1));
+    TFX_HIP(hipMemcpyAsync(dobs.p, xd, ndata * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemcpyAsync(dobs.p + ndata, yd, ndata * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemcpyAsync(dobs.p + 2 * ndata, zd, ndata * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemsetAsync(mx.p, 0, sizeof(unsigned long long), s));
+    TFX_HIP(hipMemsetAsync(derr.p, 0, sizeof(int), s));
+    const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
+    hipLaunchKernelGGL(k_distance_weight, dim3(grid), dim3(256), 0, s, N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
+                       ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, ndata, dobs.p, dobs.p + ndata, dobs.p + 2 * ndata, power,
+                       beta, w.p, mx.p);
+    hipLaunchKernelGGL(k_depth_weight_finish, dim3(grid), dim3(256), 0, s, N, w.p, mx.p, multiplier, derr.p);
+    TFX_HIP(hipGetLastError());
+    int herr = 0;
+    TFX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipStreamSynchronize(s));
     if (herr & 2) return fail(TFX_E_NUMERIC, "Zero damping weight! Exiting.");
     TFX_TRY(copy_any(cw_out, w.p, (size_t)N * sizeof(double), s));
     return 0;

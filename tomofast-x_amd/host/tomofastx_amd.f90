@@ -10,10 +10,10 @@
 ! What stays in Fortran is what the reference also does on the host: Parfile parsing, ASCII readers / writers in
 ! the reference's formats, the ADMM projection (src/inversion/admm_method.F90:70-134), residuals and costs.
 !
-! Supported Parfile subset: gravity or magnetic (TMI, scalar model) single inversion, depth weighting type 1, Haar / D4
+! Supported Parfile subset: gravity or magnetic (TMI, scalar model) single inversion, depth weighting types 1 and 2, Haar / D4
 ! compression or none, model damping (L2), ADMM with global bounds, prior / starting model by value or file, data from
 ! file or from a synthetic model.  Keys of features whose constraint builders are out of scope (cross-gradient,
-! clustering, gradient damping, local weights, distance weighting) stop with a message when enabled, like the
+! clustering, gradient damping, local weights) stop with a message when enabled, like the
 ! reference stops on an unknown solver (joint_inverse_problem.F90:547-554); unknown keys only warn (:944-947).
 !=========================================================================================================
 module tfx_host_params
@@ -33,7 +33,7 @@ module tfx_host_params
     character(len=256) :: synth_file(2) = 'None'
     real(dp) :: mag_incl = 90.d0, mag_decl = 0.d0, mag_intensity = 50000.d0, mag_xaxis_decl = 0.d0
     integer :: dw_type = 2
-    real(dp) :: dw_power(2) = (/2.d0, 3.d0/), dw_Z0(2) = 0.d0
+    real(dp) :: dw_power(2) = (/2.d0, 3.d0/), dw_Z0(2) = 0.d0, dw_beta(2) = 1.d0
     integer :: comp_type = 0
     real(dp) :: comp_rate = 0.1d0
     integer :: prior_type = 1, start_type = 1
@@ -109,6 +109,8 @@ contains
       case ('forward.depthWeighting.type');        read(val, *) par%dw_type
       case ('forward.depthWeighting.grav.power');  read(val, *) par%dw_power(1)
       case ('forward.depthWeighting.magn.power');  read(val, *) par%dw_power(2)
+      case ('forward.depthWeighting.grav.beta');   read(val, *) par%dw_beta(1)
+      case ('forward.depthWeighting.magn.beta');   read(val, *) par%dw_beta(2)
       case ('forward.depthWeighting.grav.Z0');     read(val, *) par%dw_Z0(1)
       case ('forward.depthWeighting.magn.Z0');     read(val, *) par%dw_Z0(2)
       case ('forward.depthWeighting.applyLocalWeight'); read(val, *) par%apply_local_dw
@@ -158,8 +160,7 @@ contains
       case ('inversion.clustering.grav.weight');   read(val, *) par%w_clust(1)
       case ('inversion.clustering.magn.weight');   read(val, *) par%w_clust(2)
       case ('sensit.folderPath', 'inversion.writeModelEveryNiter', 'inversion.solver', 'forward.data.grav.type', &
-            'output.paraview.grav.modelLabel', 'output.paraview.magn.modelLabel', 'inversion.priorModel.nModels', &
-            'forward.depthWeighting.grav.beta', 'forward.depthWeighting.magn.beta')
+            'output.paraview.grav.modelLabel', 'output.paraview.magn.modelLabel', 'inversion.priorModel.nModels')
         continue
       case default
         print *, 'WARNING: Unknown parameter name: ', trim(key)
@@ -311,7 +312,7 @@ program tomofastx_amd
   ip = merge(1, 2, par%pw(1) /= 0.d0)
   if (par%pw(ip) == 0.d0) call stop_msg('Both problem weights are zero!')
   pw = par%pw(ip)
-  if (par%dw_type /= 1) call stop_msg('forward.depthWeighting.type /= 1 is not supported by this host yet (SURVEY 8f-3).')
+  if (par%dw_type /= 1 .and. par%dw_type /= 2) call stop_msg('forward.depthWeighting.type must be 1 or 2 in this host.')
   if (par%beta_grad(ip) /= 0.d0 .or. par%w_cross /= 0.d0 .or. par%w_clust(ip) /= 0.d0) &
     call stop_msg('Gradient damping / cross-gradient / clustering constraints are not supported by this host.')
   if (par%apply_local_dw /= 0 .or. par%apply_local_damp /= 0 .or. par%use_error(ip) /= 0) &
@@ -340,7 +341,12 @@ program tomofastx_amd
 
   ! ---- (II) depth weight (:174-178)
   print *, 'Calculating the depth weight, type = ', par%dw_type
-  call tfx_check(tfx_column_weight_type1(ctx, par%dw_power(ip), par%dw_Z0(ip), par%cwm(ip), cw), 'calculate_depth_weight')
+  if (par%dw_type == 1) then
+    call tfx_check(tfx_column_weight_type1(ctx, par%dw_power(ip), par%dw_Z0(ip), par%cwm(ip), cw), 'calculate_depth_weight')
+  else
+    call tfx_check(tfx_column_weight_type2(ctx, int(nd, c_int64_t), Xd, Yd, Zd, par%dw_power(ip), par%dw_beta(ip), par%cwm(ip), cw), &
+                   'calculate_depth_weight')
+  endif
 
   ! ---- (III) sensitivity kernel (:197-248)
   if (ip == 1) then

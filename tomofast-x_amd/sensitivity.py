@@ -84,6 +84,14 @@ class Context:
         check(self._lib.tfx_column_weight_type1(self._h, C.c_double(power), C.c_double(Z0), C.c_double(multiplier), ptr(cw)))
         return cw
 
+    def calculate_distance_weight(self, Xdata, Ydata, Zdata, power=2.0, beta=1.0, multiplier=4.0e3):
+        """forward.depthWeighting.type = 2 (weights_gravmag.f90:81-138)."""
+        xd, yd, zd = f64(Xdata), f64(Ydata), f64(Zdata)
+        cw = np.empty(self.nelements_total)
+        check(self._lib.tfx_column_weight_type2(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), C.c_double(power),
+                                                C.c_double(beta), C.c_double(multiplier), ptr(cw)))
+        return cw
+
     # ---- graviprism_z
     def graviprism_z(self, Xdata, Ydata, Zdata):
         xd, yd, zd = f64(np.atleast_1d(Xdata)), f64(np.atleast_1d(Ydata)), f64(np.atleast_1d(Zdata))
