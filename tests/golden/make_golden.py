@@ -369,6 +369,83 @@ def make_e2e(tmp):
         print(name + ".npz: nnz", res["np1_nnz_total"], "partition np2", res["np2_nelements_at_cpu"])
 
 
+PAR_MAG = """global.outputFolderPath     = out/
+global.description          = golden synthetic magnetic
+modelGrid.size                      = {nx} {ny} {nz}
+modelGrid.magn.file                 = grid.txt
+forward.data.magn.nData             = {nd}
+forward.data.magn.dataGridFile      = data_grid.txt
+forward.data.magn.useSyntheticModelForDataValues = 1
+forward.data.magn.syntheticModelFile = model_true.txt
+forward.magneticField.inclination          = {incl}
+forward.magneticField.declination          = {decl}
+forward.magneticField.intensity_nT         = {inten}
+forward.magneticField.XaxisDeclination     = {azim}
+forward.depthWeighting.type         = 1
+forward.depthWeighting.magn.power   = 3.0d0
+sensit.readFromFiles                = 0
+sensit.folderPath                   = out/SENSIT/
+forward.matrixCompression.type      = {ctype}
+forward.matrixCompression.rate      = {rate}
+inversion.priorModel.type           = 1
+inversion.priorModel.magn.value     = 0.d0
+inversion.startingModel.type        = 1
+inversion.startingModel.magn.value  = 0.d0
+inversion.nMajorIterations          = {nmajor}
+inversion.nMinorIterations          = {nminor}
+inversion.writeModelEveryNiter      = 0
+inversion.minResidual               = 1.d-13
+inversion.modelDamping.magn.weight  = {alpha}
+inversion.modelDamping.normPower    = 2.0d0
+inversion.joint.grav.problemWeight  = 0.d0
+inversion.joint.magn.problemWeight  = 1.d0
+inversion.admm.enableADMM           = 0
+"""
+
+
+def make_mag_e2e(tmp):
+    """Full magnetic inversion (problem 2): TMI kernel, depth weight power 3, Haar compression, damping."""
+    c = dict(nx=12, ny=10, nz=6, ox=5, oy=4, ctype=1, rate="0.25d0", nmajor=2, nminor=25, alpha="1.d-9",
+             incl="-62.d0", decl="11.d0", azim="0.d0", inten="57000.d0")
+    g, obs, mtrue = synthetic_problem(c["nx"], c["ny"], c["nz"], c["ox"], c["oy"])
+    mtrue = mtrue * 1e-4          # susceptibility contrast 0.03 SI
+    nd = obs.shape[0]
+    wd = os.path.join(tmp, "mag_e2e")
+    shutil.rmtree(wd, ignore_errors=True)
+    os.makedirs(wd)
+    write_grid_file(os.path.join(wd, "grid.txt"), g, c["nx"], c["ny"], c["nz"])
+    with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+        f.write("%d\n" % nd)
+        for r in obs:
+            f.write("%.17g %.17g %.17g 0.0\n" % tuple(r))
+    with open(os.path.join(wd, "model_true.txt"), "w") as f:
+        f.write("%d\n" % mtrue.size)
+        for v in mtrue:
+            f.write("%.17g\n" % v)
+    pf = os.path.join(wd, "Parfile.txt")
+    par = PAR_MAG.format(nd=nd, **c)
+    open(pf, "w").write(par)
+    log = run([MPIEXEC, "-n", "1", os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+    sd = os.path.join(wd, "out", "SENSIT")
+    hdr, rows = parse_sensit(os.path.join(sd, "sensit_magn_1_0"))
+    res = dict(nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=0.25, nmajor=c["nmajor"], nminor=c["nminor"], alpha=1e-9,
+               field=np.array([-62.0, 11.0, 0.0, 57000.0]), X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs,
+               model_true=mtrue, parfile=par)
+    res["row_ptr"] = np.concatenate([[0], np.cumsum([r[1].size for r in rows])]).astype(np.int64)
+    res["cols"] = np.concatenate([r[1] for r in rows])
+    res["vals"] = np.concatenate([r[2] for r in rows])
+    res["column_weight"] = np.frombuffer(open(os.path.join(sd, "sensit_magn_weight"), "rb").read(), ">f8", offset=4).astype(np.float64)
+    meta = open(os.path.join(sd, "sensit_magn_meta.txt")).read().split()
+    res["comp_error"] = float(meta[8])
+    res["nnz_total"] = int(meta[11])
+    res["data_observed"] = read_col(os.path.join(wd, "out", "data", "mag_observed.txt"), 3)
+    res["data_final"] = read_col(os.path.join(wd, "out", "data", "mag_final.txt"), 3)
+    res["model_final"] = read_col(os.path.join(wd, "out", "model", "mag_final_model_full.txt"), 0)
+    res["lsqr_r"] = np.array([float(m.group(1)) for m in re.finditer(r"Finished lsqr solver, r =\s*([0-9.eE+-]+)", log)])
+    np.savez_compressed(os.path.join(HERE, "e2e_mag.npz"), **res)
+    print("e2e_mag.npz: nnz", res["nnz_total"], "err", res["comp_error"])
+
+
 def make_mansf(tmp):
     """BASELINE config 1.  Inputs are the reference's shipped example data (data/gravmag/mansf_slice)."""
     par = open(os.path.join(REFROOT, "parfiles", "Parfile_mansf_slice.txt")).read()
@@ -396,7 +473,7 @@ def make_mansf(tmp):
 if __name__ == "__main__":
     if not os.path.isfile(os.path.join(REFBIN, "tomofastx")):
         sys.exit("oracle/_ref is not built (run oracle/ref_build.sh in the development container)")
-    what = sys.argv[1:] or ["wavelet", "prism", "magprism", "lsqr", "e2e", "mansf"]
+    what = sys.argv[1:] or ["wavelet", "prism", "magprism", "lsqr", "e2e", "mag_e2e", "mansf"]
     with tempfile.TemporaryDirectory() as tmp:
         for w in what:
             globals()["make_" + w](tmp)

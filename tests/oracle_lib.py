@@ -143,6 +143,26 @@ def build_matrix_grav(grid, dims, cw, obs, ctype, rate):
     return np.array(rp, np.int64), cols, np.concatenate(vs), hist, float(np.sum(errs) / len(errs))
 
 
+def build_matrix_mag(grid, dims, cw, obs, field, ctype, rate):
+    """Magnetic (TMI, scalar) rows -> CSR like build_matrix_grav."""
+    N = int(np.prod(dims))
+    K = int(rate * N) if ctype > 0 else N
+    magv = dircos(*field[:3])
+    rp, cs, vs = [0], [], []
+    for o in np.asarray(obs):
+        ierr, row = magprism_tmi(grid, o[0], o[1], o[2], magv, field[3])
+        assert ierr == 0
+        row = row * f64(cw)
+        if ctype > 0:
+            c, v, _, _ = compress_row(wavelet(row, dims[0], dims[1], dims[2], ctype), K)
+        else:
+            c, v = np.arange(1, N + 1, dtype=np.int32), row.astype(np.float32)
+        cs.append(c)
+        vs.append(v)
+        rp.append(rp[-1] + c.size)
+    return np.array(rp, np.int64), np.concatenate(cs), np.concatenate(vs)
+
+
 def partition(nnz, P):
     nnz = np.ascontiguousarray(nnz, np.int32)
     nel = np.zeros(P, np.int32)

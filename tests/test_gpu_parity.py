@@ -176,6 +176,31 @@ def test_build_mag_kernel_vs_oracle(ctx):
     assert tot == res["nnz"]
 
 
+def test_magnetic_end_to_end_vs_reference(ctx, golden_dir):
+    """Magnetic inversion (problem 2) built and solved on the GPU vs the reference's SENSIT rows and final model."""
+    g = load(golden_dir, "e2e_mag")
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    cw = ctx.calculate_depth_weight(3.0, 0.0, 1.0)
+    assert np.max(np.abs(cw - g["column_weight"]) / g["column_weight"]) <= 1e-14
+    obs = g["obs"]
+    res = ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, 1, float(g["rate"]), mag_field=g["field"])
+    built = ctx.matrix_download_csr()
+    nd = obs.shape[0]
+    same = tot = 0
+    for r in range(nd):
+        cb = built[1][built[0][r]:built[0][r + 1]]
+        cr = g["cols"][g["row_ptr"][r]:g["row_ptr"][r + 1]]
+        same += np.intersect1d(cb, cr).size
+        tot += max(cb.size, cr.size)
+    assert same >= 0.995 * tot
+    assert abs(res["comp_error"] - float(g["comp_error"])) <= 1e-6 * float(g["comp_error"])
+    m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, 1, g["data_observed"], int(g["nmajor"]), int(g["nminor"]),
+                                                     alpha=float(g["alpha"]))
+    ref = g["model_final"]
+    assert np.linalg.norm(m - ref) <= 1e-5 * np.linalg.norm(ref)
+
+
 def test_prism_geometry_error(ctx):
     one = [np.array([v], np.float64) for v in (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)]
     ctx.set_grid(1, 1, 1, *one)
