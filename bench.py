@@ -162,8 +162,10 @@ def main():
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same workload
     cpu = None
+    ref_cfg1 = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(tfx, w, args.cpu_seconds, cw, log)
+        ref_cfg1 = reference_config1(log)
 
     if rank == 0:
         out = {
@@ -179,13 +181,53 @@ def main():
             "gpu_ms_per_step_hip_events": round(ms_gpu / args.steps, 4),
             "lsqr_bytes_per_iteration_algorithmic": 16 * int(nnz_total) + 112 * N + 48 * (D + N),
             "adjoint_identity_rel_err": adj_err, "final_r": r,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "reference_config1": ref_cfg1,
         }
         print(json.dumps(out))
         sys.stdout.flush()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def reference_config1(log):
+    """BASELINE config 1 (parfiles/Parfile_mansf_slice.txt, 2x128x32 cells, 256 data, 60 x 100 LSQR iterations) end to end:
+    the REAL reference (oracle/_ref/tomofastx, built from /root/reference by oracle/ref_build.sh; 1 MPI rank = 1 host core)
+    next to this repo's Fortran host on the GPU (tomofast-x_amd/host/tomofastx_amd), same Parfile, same input files
+    (written from tests/golden/mansf.npz).  Wall-clock of the whole program, I/O included.  None when a binary is missing."""
+    import shutil
+    import subprocess
+    import tempfile
+    ref = os.path.join(ROOT, "oracle", "_ref", "tomofastx")
+    ours = os.path.join(ROOT, "tomofast-x_amd", "host", "tomofastx_amd")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.isfile(ref) and os.path.isfile(ours) and os.path.isfile(mpiexec)):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import test_gpu_fortran_host as tf
+        g = np.load(os.path.join(ROOT, "tests", "golden", "mansf.npz"))
+        out = {"config": "parfiles/Parfile_mansf_slice.txt (BASELINE configs[0])", "cores": 1}
+        for name, cmd in (("reference_s", [mpiexec, "-n", "1", ref, "-p", "Parfile.txt"]), ("gpu_host_s", [ours, "-p", "Parfile.txt"])):
+            wd = tempfile.mkdtemp(prefix="tfx_cfg1_")
+            try:
+                tf.write_inputs(wd, g)
+                t0 = time.time()
+                p = subprocess.run(cmd, cwd=wd, capture_output=True, text=True, timeout=600)
+                dt = time.time() - t0
+                if p.returncode != 0 or "THE END." not in p.stdout:
+                    log("config-1 run failed: %s" % " ".join(cmd))
+                    return None
+                out[name] = round(dt, 3)
+                m = np.loadtxt(os.path.join(wd, "output", "mansf_slice", "model", "grav_final_model_full.txt"), skiprows=1)
+                out[name.replace("_s", "_model_rel_l2_vs_golden")] = float(np.linalg.norm(m - g["model_final"]) / np.linalg.norm(g["model_final"]))
+            finally:
+                shutil.rmtree(wd, ignore_errors=True)
+        log("config 1 end to end: reference %.2f s (1 core) vs GPU host %.2f s" % (out["reference_s"], out["gpu_host_s"]))
+        return out
+    except Exception as e:      # the baseline leg must never take the benchmark down
+        log("reference_config1 skipped: %r" % (e,))
+        return None
 
 
 def pmc_traffic(workload, kernel, nnz_loc):
