@@ -33,6 +33,9 @@ WORKLOADS = {
     # BASELINE.json configs[2]
     "haar_512": dict(nx=512, ny=512, nz=128, ox=256, oy=256, ctype=1, rate=0.01,
                      desc="synthetic gravity 512x512x128 cells, 256x256 obs, Haar r=0.01"),
+    # BASELINE.json configs[1]: dense (uncompressed) sensitivity
+    "dense_256": dict(nx=256, ny=256, nz=64, ox=64, oy=64, ctype=0, rate=1.0,
+                      desc="synthetic gravity 256x256x64 cells, 64x64 obs, dense (uncompressed) sensitivity"),
     # reduced sizes for quick checks (NOT the headline; bench prints which one ran)
     "medium": dict(nx=128, ny=128, nz=64, ox=64, oy=64, ctype=2, rate=0.02,
                    desc="synthetic gravity 128x128x64 cells, 64x64 obs, D4 r=0.02 (reduced)"),
