@@ -68,8 +68,15 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # TFX_BENCH_BACKEND=gloo + TFX_BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a single-GPU box
+        backend = os.environ.get("TFX_BENCH_BACKEND", "nccl")
+        if os.environ.get("TFX_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if dist is not None:
@@ -142,7 +149,7 @@ def main():
     ctx.profile_enable(False)
     ctx.lsqr_end()
     if dist is not None:
-        tt = torch.tensor([t_steps], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([t_steps], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_steps = float(tt.item())
     ms_per_step = 1e3 * t_steps / args.steps
