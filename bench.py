@@ -158,17 +158,21 @@ def main():
     # ---- roofline of the dominant kernel (rank 0's share of the matrix)
     nnz_loc = minfo["nnz"]
     names = ["k_spmv_fwd (compressed SpMV, b += S x)", "k_spmv_adj (compressed SpMtV, b += S^T x)"]
+    if w["ctype"] == 0:
+        names = ["k_dense_fwd (dense fp32 block, b += S x)", "k_dense_adj (dense fp32 block, b += S^T x)"]
     roof = None
     if prof[0][1] and prof[1][1]:
         avg = [prof[0][0] / prof[0][1], prof[1][0] / prof[1][1]]
         dom = 0 if avg[0] >= avg[1] else 1
-        achieved = 8.0 * nnz_loc / (avg[dom] * 1e-3) / 1e9
+        # 8 B per non-zero per pass for the compressed kernel, 4 B per entry for the dense (uncompressed) block
+        alg_b, stored_b = (4.0, 4) if w["ctype"] == 0 else (8.0, 6)
+        achieved = alg_b * nnz_loc / (avg[dom] * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args.workload, "k_spmv_fwd" if dom == 0 else "k_spmv_adj", nnz_loc)
         roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": 8 * nnz_loc, "stored_bytes_per_launch": 6 * nnz_loc,
+                "algorithmic_bytes_per_launch": int(alg_b) * nnz_loc, "stored_bytes_per_launch": stored_b * nnz_loc,
                 "avg_launch_ms": {"spmv_fwd": round(avg[0], 4), "spmv_adj": round(avg[1], 4)},
-                "achieved_other_GBs": round(8.0 * nnz_loc / (avg[1 - dom] * 1e-3) / 1e9, 1)}
+                "achieved_other_GBs": round(alg_b * nnz_loc / (avg[1 - dom] * 1e-3) / 1e9, 1)}
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same workload
     cpu = None

@@ -219,6 +219,19 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
     TiledMatrix &m = ctx->mat;
     if (!m.valid) return fail(TFX_E_STATE, "no matrix");
     TFX_HIP(hipSetDevice(ctx->device));
+    if (m.is_dense) {                       // every entry is a stored entry (sensitivity_gravmag.F90:287-295)
+        std::vector<float> row((size_t)m.ld);
+        for (int64_t r = 0; r < m.nrows; ++r) {
+            rowptr[r] = r * m.ncols;
+            TFX_HIP(hipMemcpy(row.data(), m.dense.p + r * m.ld, (size_t)m.ncols * sizeof(float), hipMemcpyDeviceToHost));
+            for (int64_t c = 0; c < m.ncols; ++c) {
+                if (cols) cols[r * m.ncols + c] = (int32_t)(c + 1);
+                if (vals) vals[r * m.ncols + c] = row[(size_t)c];
+            }
+        }
+        rowptr[m.nrows] = m.nrows * m.ncols;
+        return 0;
+    }
     std::vector<uint16_t> hc((size_t)m.n_entries);
     std::vector<float> hv((size_t)m.n_entries);
     if (m.n_entries > 0) {
@@ -275,6 +288,7 @@ int tfx_matrix_free(tfx_ctx *ctx)
     m.fwd_order.release(); m.adj_order.release(); m.fwd_partial.release(); m.adj_partial.release();
     m.fwd_nslots.release(); m.fwd_pbase.release(); m.adj_nslots.release(); m.adj_pbase.release();
     m.h_tiles.clear(); m.h_fwd.clear(); m.h_adj.clear();
+    m.dense.release(); m.dense_partial.release(); m.is_dense = false;
     m.valid = false;
     return 0;
 }

@@ -1073,6 +1073,26 @@ __global__ __launch_bounds__(256) void k_row_sumsq(const double *__restrict__ ro
     if (threadIdx.x == 0) red[(int64_t)row * gridDim.x + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// dense store of a batch of rows: out[row][c] = (float)rows[row][col_begin + c] * scale[row]   (:289-295, :841)
+__global__ __launch_bounds__(256) void k_dense_store(const double *__restrict__ rows, int64_t N, int64_t col_begin, int64_t ncols,
+                                                     const float *__restrict__ scale, float *__restrict__ out, int64_t ld)
+{
+    const int row = blockIdx.y;
+    const double *r = rows + (int64_t)row * N + col_begin;
+    float *o = out + (int64_t)row * ld;
+    const float sc = scale[row];
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * blockDim.x) {
+        float f = (float)r[c];
+        f = f * sc;
+        o[c] = f;
+    }
+}
+
+__global__ void k_fill_i32(int32_t *__restrict__ p, int64_t n, int32_t v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] += v;
+}
+
 struct CompactWork {
     DBuf<int32_t> seg_cnt, seg_all, seg_off, nel, nel_all;
     DBuf<double> seg_cost, cost_disc, thr, red;
@@ -1340,8 +1360,39 @@ static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const
         }
         for (int64_t i = 0; i < ndata; ++i) hscale[(size_t)i] = (float)(problem_weight * (data_weight ? hdw[(size_t)i] : 1.0));   // :841
     }
-    if (keep_matrix) TFX_TRY(matrix_begin(ctx, ndata, ncols, ndata * std::min<int64_t>(K, ncols)));
     TiledMatrix &m = ctx->mat;
+    if (keep_matrix && compression_type == 0) {
+        // No compression (sensitivity_gravmag.F90:287-295): every column is stored -> dense fp32 block, no index stream.
+        TFX_TRY(matrix_begin_dense(ctx, ndata, ncols));
+        const int Bd = (int)std::max<int64_t>(1, std::min<int64_t>(32, (int64_t)(1u << 28) / N));
+        TFX_TRY(drows.alloc((size_t)Bd * N));
+        DBuf<float> dsc;
+        TFX_TRY(dsc.alloc((size_t)ndata));
+        TFX_HIP(hipMemcpyAsync(dsc.p, hscale.data(), (size_t)ndata * sizeof(float), hipMemcpyHostToDevice, s));
+        const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (ncols + 255) / 256));
+        for (int64_t g = 0; g < ndata; g += Bd) {
+            const int nb = (int)std::min<int64_t>(Bd, ndata - g);
+            TFX_TRY(prism_rows_dev(ctx, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p, nullptr,
+                                   nullptr, mag));
+            hipLaunchKernelGGL(k_dense_store, dim3(gx, nb), dim3(256), 0, s, drows.p, N, col_begin, ncols, dsc.p + g,
+                               m.dense.p + g * m.ld, m.ld);
+            TFX_HIP(hipGetLastError());
+        }
+        int herr = 0;
+        TFX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        TFX_HIP(hipStreamSynchronize(s));
+        TFX_TRY(geometry_error(herr));
+        TFX_TRY(matrix_finish(ctx));
+        if (nnz_out) *nnz_out = ndata * ncols;
+        if (error_sum_out) *error_sum_out = 0.0;
+        if (nnz_hist_out) {
+            hipLaunchKernelGGL(k_fill_i32, dim3(1024), dim3(256), 0, s, dhist.p, N, (int32_t)ndata);       // :291-294: every column, every row
+            TFX_HIP(hipGetLastError());
+            TFX_TRY(copy_any(nnz_hist_out, dhist.p, (size_t)N * sizeof(int32_t), s));
+        }
+        return 0;
+    }
+    if (keep_matrix) TFX_TRY(matrix_begin(ctx, ndata, ncols, ndata * std::min<int64_t>(K, ncols)));
     const int RB = keep_matrix ? m.RB : (int)std::min<int64_t>(RB_MAX, (ndata + 63) / 64 * 64);
     // rows processed per batch: row buffer + select candidates (2x) must stay around 6 GB
     const int B = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, RB), (int64_t)(1u << 28) / N));

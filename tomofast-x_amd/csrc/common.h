@@ -107,6 +107,11 @@ struct TiledMatrix {
     DBuf<int32_t> fwd_nslots, fwd_pbase;   // per row block
     DBuf<int32_t> adj_nslots, adj_pbase;   // per column tile
     bool adj_has_partials = false;
+    // dense storage (compression off): fp32 [nrows][ld], no index stream (4 B per entry)
+    bool is_dense = false;
+    int64_t ld = 0;
+    DBuf<float> dense;
+    DBuf<double> dense_partial;   // forward: [nchunks][nrows] partial row sums
     bool valid = false;
     size_t device_bytes() const;
 };
@@ -157,6 +162,7 @@ int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);     // b (+
 int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);    // b (+)= S^T x
 int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add);
 int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add);
+int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols);
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
 // build.hip
 int detect_tensor_grid(tfx_ctx *ctx);

@@ -31,7 +31,7 @@ size_t TiledMatrix::device_bytes() const
 {
     return codes.bytes() + vals.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
            fwd_order.bytes() + adj_order.bytes() + fwd_partial.bytes() + adj_partial.bytes() + adj_nslots.bytes() +
-           adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes();
+           adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes() + dense.bytes() + dense_partial.bytes();
 }
 
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s)
@@ -182,10 +182,102 @@ __global__ void k_chunk_row0(int nr, const int32_t *__restrict__ segoff, const i
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Dense storage for an uncompressed kernel (forward.matrixCompression.type = 0): fp32 [nrows][ld], 4 B per entry.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int DN_CHUNK = 8192;          // columns per workgroup (x chunk = 64 KB of LDS)
+constexpr int DN_THREADS = 1024;
+
+int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols)
+{
+    TiledMatrix &m = *ctx->target;
+    m.valid = false;
+    if (nrows <= 0 || ncols <= 0) return fail(TFX_E_ARG, "matrix_begin_dense: empty matrix");
+    m.nrows = nrows;
+    m.ncols = ncols;
+    m.is_dense = true;
+    m.ld = (ncols + 3) / 4 * 4;
+    m.nnz = nrows * ncols;
+    TFX_TRY(m.dense.alloc((size_t)(nrows * m.ld)));
+    const int64_t nchunks = (ncols + DN_CHUNK - 1) / DN_CHUNK;
+    TFX_TRY(m.dense_partial.alloc((size_t)(nchunks * nrows)));
+    m.h_tiles.clear();
+    m.h_fwd.clear();
+    m.h_adj.clear();
+    m.n_entries = 0;
+    return 0;
+}
+
+// forward: workgroup = one column chunk, its x slice in LDS; a wave per row, partial[chunk][row] = dot over the chunk
+__global__ __launch_bounds__(DN_THREADS) void k_dense_fwd(const float *__restrict__ A, int64_t ld, int64_t nrows, int64_t ncols,
+                                                           const double *__restrict__ x, double *__restrict__ partial)
+{
+    __shared__ double xs[DN_CHUNK];
+    const int64_t c0 = (int64_t)blockIdx.x * DN_CHUNK;
+    const int nc = (int)min((int64_t)DN_CHUNK, ncols - c0);
+    for (int i = threadIdx.x; i < DN_CHUNK; i += DN_THREADS) xs[i] = (i < nc) ? x[c0 + i] : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nc4 = nc & ~3;
+    for (int64_t r = wave; r < nrows; r += DN_THREADS / 64) {
+        const float *row = A + r * ld + c0;
+        double acc = 0.0;
+        for (int i = lane * 4; i < nc4; i += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + i);
+            acc = fma((double)v.x, xs[i], acc);
+            acc = fma((double)v.y, xs[i + 1], acc);
+            acc = fma((double)v.z, xs[i + 2], acc);
+            acc = fma((double)v.w, xs[i + 3], acc);
+        }
+        if (lane < nc - nc4) acc = fma((double)row[nc4 + lane], xs[nc4 + lane], acc);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+        if (lane == 0) partial[(int64_t)blockIdx.x * nrows + r] = acc;
+    }
+}
+
+__global__ void k_dense_fwd_reduce(const double *__restrict__ partial, int nchunks, int64_t nrows, double *__restrict__ b, int add)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    double s = add ? b[r] : 0.0;
+    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * nrows + r];
+    b[r] = s;
+}
+
+// adjoint: workgroup = one column chunk over all rows; a thread owns 8 columns, u[r] is a wave-uniform scalar load
+__global__ __launch_bounds__(DN_THREADS) void k_dense_adj(const float *__restrict__ A, int64_t ld, int64_t nrows, int64_t ncols,
+                                                           const double *__restrict__ u, double *__restrict__ y)
+{
+    const int64_t c0 = (int64_t)blockIdx.x * DN_CHUNK + (int64_t)threadIdx.x * 8;
+    if (c0 >= ncols) return;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool full = c0 + 8 <= ncols;
+    const int nmine = (int)min((int64_t)8, ncols - c0);
+#pragma unroll 4
+    for (int64_t r = 0; r < nrows; ++r) {
+        const double ur = u[r];
+        const float *p = A + r * ld + c0;
+        if (full) {
+            const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+            acc[0] = fma((double)a.x, ur, acc[0]); acc[1] = fma((double)a.y, ur, acc[1]);
+            acc[2] = fma((double)a.z, ur, acc[2]); acc[3] = fma((double)a.w, ur, acc[3]);
+            acc[4] = fma((double)b.x, ur, acc[4]); acc[5] = fma((double)b.y, ur, acc[5]);
+            acc[6] = fma((double)b.z, ur, acc[6]); acc[7] = fma((double)b.w, ur, acc[7]);
+        } else {
+            for (int k = 0; k < nmine; ++k) acc[k] = fma((double)p[k], ur, acc[k]);
+        }
+    }
+    for (int k = 0; k < nmine; ++k) y[c0 + k] += acc[k];
+}
+
 int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 {
     TiledMatrix &m = *ctx->target;
     m.valid = false;
+    m.is_dense = false;
+    m.dense.release();
+    m.dense_partial.release();
     m.nrows = nrows;
     m.ncols = ncols;
     m.nnz = 0;
@@ -339,6 +431,10 @@ static void build_items(const std::vector<TileMeta> &tiles, bool forward, int64_
 int matrix_finish(tfx_ctx *ctx)
 {
     TiledMatrix &m = *ctx->target;
+    if (m.is_dense) {
+        m.valid = true;
+        return 0;
+    }
     hipStream_t s = ctx->stream;
     int64_t real = 0;
     for (auto &t : m.h_tiles) real += t.cnt;     // includes empty-row markers; exact nnz is set by the caller
@@ -586,6 +682,17 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
 {
     if (!m.valid) return fail(TFX_E_STATE, "spmv: no matrix");
     const bool prof = (&m == &ctx->mat);
+    if (m.is_dense) {
+        hipStream_t s = ctx->stream;
+        const int nchunks = (int)((m.ncols + DN_CHUNK - 1) / DN_CHUNK);
+        if (prof) prof_begin(ctx);
+        hipLaunchKernelGGL(k_dense_fwd, dim3(nchunks), dim3(DN_THREADS), 0, s, m.dense.p, m.ld, m.nrows, m.ncols, d_x, m.dense_partial.p);
+        if (prof) prof_end(ctx, 0);
+        hipLaunchKernelGGL(k_dense_fwd_reduce, dim3((unsigned)((m.nrows + 255) / 256)), dim3(256), 0, s, m.dense_partial.p, nchunks,
+                           m.nrows, d_b, add);
+        TFX_HIP(hipGetLastError());
+        return 0;
+    }
     hipStream_t s = ctx->stream;
     const size_t lds = (size_t)(m.TC + m.RB) * sizeof(double);
     if (!m.h_fwd.empty()) {
@@ -607,6 +714,16 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
 {
     if (!m.valid) return fail(TFX_E_STATE, "spmtv: no matrix");
     const bool prof = (&m == &ctx->mat);
+    if (m.is_dense) {
+        hipStream_t s = ctx->stream;
+        if (!add) TFX_HIP(hipMemsetAsync(d_b, 0, (size_t)m.ncols * sizeof(double), s));
+        const int nchunks = (int)((m.ncols + DN_CHUNK - 1) / DN_CHUNK);
+        if (prof) prof_begin(ctx);
+        hipLaunchKernelGGL(k_dense_adj, dim3(nchunks), dim3(DN_THREADS), 0, s, m.dense.p, m.ld, m.nrows, m.ncols, d_x, d_b);
+        if (prof) prof_end(ctx, 1);
+        TFX_HIP(hipGetLastError());
+        return 0;
+    }
     hipStream_t s = ctx->stream;
     const size_t lds = (size_t)(m.TC + m.RB) * sizeof(double);
     if (!add) TFX_HIP(hipMemsetAsync(d_b, 0, (size_t)m.ncols * sizeof(double), s));
