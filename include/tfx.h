@@ -149,6 +149,12 @@ int tfx_lsqr_solve(tfx_ctx *ctx, int niter, double rmin, double gamma, double ta
                    const double *b_data, int nblocks, const float *const *diag, const double *const *rhs_blocks,
                    double *x_out, int *iters_out, double *r_out);
 
+/* WAVELET_DOMAIN switch of the reference (src/inversion/joint_inverse_problem.F90:189-198).  1 (default): the unknowns
+ * live in the wavelet domain and S is applied as stored.  0: spatial unknowns (needed by constraints that act in space:
+ * cross-gradient, clustering, gradient damping, local bounds) - every product with S goes through the 3-D transform
+ * (lsqr_solver2.F90:200-206, :228-234).  Single rank, the whole model (n1*n2*n3 = ncolumns) on this ctx.        */
+int tfx_lsqr_set_wavelet_domain(tfx_ctx *ctx, int wavelet_domain, int n1, int n2, int n3, int wavelet_type);
+
 /* The same solver in three steps, so that a caller (bench.py) can time exactly k iterations with everything
  * resident: begin = lines :120-157 (x=0, normalise u, v = A^T u, ...), iterate = k passes of the loop body
  * :163-290 (stops early on the reference's exit conditions; returns iterations actually done), end = copy x. */

@@ -397,6 +397,31 @@ def test_lsqr_general_constraint_matrix_vs_reference(ctx, golden_dir):
         ctx.cons_clear()
 
 
+def test_lsqr_spatial_unknowns_equal_wavelet_domain_solution(ctx, golden_dir):
+    """WAVELET_DOMAIN = F (lsqr_solver2.F90:200-206, :228-234).  Haar lifting is orthonormal, so LSQR on S.Wav with
+    spatial unknowns produces x_k = InvWav(y_k) of the wavelet-domain run, iteration by iteration."""
+    g = load(golden_dir, "e2e_haar")
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    N = int(np.prod(dims))
+    ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    S = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+    ctx.matrix_upload_csr(g["obs"].shape[0], N, *S)
+    b = g["np1_data_observed"]
+    blocks = ([np.full(N, np.float32(1e-7), np.float32)], [np.zeros(N)])
+    try:
+        for niter in (1, 4, 15):
+            y, it1, r1 = ctx.lsqr_solve_sensit(b, niter, 1e-13, 0.0, 0.0, *blocks)
+            ctx.lsqr_set_wavelet_domain(False, 1)
+            x, it2, r2 = ctx.lsqr_solve_sensit(b, niter, 1e-13, 0.0, 0.0, *blocks)
+            ctx.lsqr_set_wavelet_domain(True)
+            assert it1 == it2 == niter
+            ref = ctx.inverse_wavelet(y, *dims, 1)
+            assert np.linalg.norm(x - ref) <= (1e-11 if niter <= 4 else 1e-6) * np.linalg.norm(ref)
+            assert abs(r1 - r2) <= 1e-9 * r1
+    finally:
+        ctx.lsqr_set_wavelet_domain(True)
+
+
 def test_lsqr_stepping_api_matches_one_shot(ctx, golden_dir):
     g = load(golden_dir, "lsqr")
     case = "damp"

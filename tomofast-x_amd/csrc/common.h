@@ -144,6 +144,9 @@ struct tfx_ctx {
     int rank = 0, nranks = 1;
     // lsqr
     tfx::LsqrState *lsqr = nullptr;
+    // WAVELET_DOMAIN = F (joint_inverse_problem.F90:189-198): LSQR unknowns are spatial, S acts on Wav(v)
+    bool spatial_unknowns = false;
+    int wd_n1 = 0, wd_n2 = 0, wd_n3 = 0, wd_type = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profile = false;
@@ -166,4 +169,5 @@ int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols);
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
 // build.hip
 int detect_tensor_grid(tfx_ctx *ctx);
+int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, int type, int dir);
 }  // namespace tfx

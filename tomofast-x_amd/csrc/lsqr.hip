@@ -31,6 +31,7 @@ struct LsqrState {
     DBuf<double> uc;       // nblocks * ncols
     DBuf<float> diag;      // nblocks * ncols
     DBuf<double> b0, sx;   // target-misfit only
+    DBuf<double> tw;       // WAVELET_DOMAIN = F: wavelet-domain image of v / x, or S^T u before the inverse transform
     DBuf<double> red;      // block partial sums
     DBuf<Scalars> sc;
     Scalars *h_sc = nullptr;   // pinned
@@ -188,6 +189,12 @@ __global__ void k_update_xw(double *__restrict__ v, double *__restrict__ w, doub
     }
 }
 
+// y += x
+__global__ void k_axpy1(double *__restrict__ y, const double *__restrict__ x, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += x[i];
+}
+
 __global__ void k_copy(double *__restrict__ dst, const double *__restrict__ src, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -249,7 +256,13 @@ static int scale_u(tfx_ctx *ctx, LsqrState *L)
 static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L)
 {
     hipStream_t s = ctx->stream;
-    TFX_TRY(spmtv_dev(ctx, L->u.p, L->v.p, 1));
+    if (ctx->spatial_unknowns) {                                         // lsqr_solver2.F90:137-145, :228-236
+        TFX_TRY(spmtv_dev(ctx, L->u.p, L->tw.p, 0));
+        TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, 1, ctx->wd_type, 2));
+        LAUNCH(k_axpy1, grid_for(L->ncols), L->v.p, L->tw.p, L->ncols);
+    } else {
+        TFX_TRY(spmtv_dev(ctx, L->u.p, L->v.p, 1));
+    }
     if (ctx->cons.valid) TFX_TRY(spmtv_dev(ctx, ctx->cons, L->u.p + L->nrows_data, L->v.p, 1));     // lsqr_solver2.F90:147, :238
     const int g = grid_for(L->ncols);
     LAUNCH(k_cons_adjoint, g, L->v.p, L->diag.p, L->uc.p, L->ncols, L->nblocks, L->red.p);
@@ -315,6 +328,12 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     TFX_TRY(L->uc.ensure((size_t)std::max<int64_t>(1, nblocks * nc)));
     TFX_TRY(L->diag.ensure((size_t)std::max<int64_t>(1, nblocks * nc)));
     TFX_TRY(L->red.ensure(RED_BLOCKS));
+    if (ctx->spatial_unknowns) {
+        if ((int64_t)ctx->wd_n1 * ctx->wd_n2 * ctx->wd_n3 != nc)
+            return fail(TFX_E_STATE, "WAVELET_DOMAIN = F needs the whole model on this rank (ncolumns %lld != n1*n2*n3)", (long long)nc);
+        if (ctx->nranks > 1) return fail(TFX_E_STATE, "WAVELET_DOMAIN = F is single-rank for now");
+        TFX_TRY(L->tw.ensure((size_t)nc));
+    }
     TFX_TRY(L->sc.ensure(1));
     TFX_HIP(hipMemsetAsync(L->sc.p, 0, sizeof(Scalars), s));
     TFX_HIP(hipMemsetAsync(L->x.p, 0, (size_t)nc * sizeof(double), s));                  // :120
@@ -359,6 +378,22 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     return 0;
 }
 
+// WAVELET_DOMAIN (joint_inverse_problem.F90:189-198): 1 = unknowns in the wavelet domain (default; S applied as is),
+// 0 = spatial unknowns: every product with S goes through the 3-D wavelet transform (lsqr_solver2.F90:200-206, :228-234)
+int tfx_lsqr_set_wavelet_domain(tfx_ctx *ctx, int wavelet_domain, int n1, int n2, int n3, int wavelet_type)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    if (wavelet_domain || wavelet_type == 0) {
+        ctx->spatial_unknowns = false;
+        return 0;
+    }
+    if (wavelet_type != 1 && wavelet_type != 2) return fail(TFX_E_ARG, "Unknown wavelet type!");
+    if (n1 <= 0 || n2 <= 0 || n3 <= 0) return fail(TFX_E_ARG, "bad grid size");
+    ctx->spatial_unknowns = true;
+    ctx->wd_n1 = n1; ctx->wd_n2 = n2; ctx->wd_n3 = n3; ctx->wd_type = wavelet_type;
+    return 0;
+}
+
 int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
 {
     if (!ctx || !ctx->lsqr || !ctx->lsqr->active) return fail(TFX_E_STATE, "tfx_lsqr_iterate: call tfx_lsqr_begin first");
@@ -370,6 +405,11 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
     while (done < k && !L->finished && L->r > L->rmin) {                                  // :163
         if (L->target_misfit > 0.0) {                                                     // :168-189
             const int64_t nd = L->nrows_data;
+            if (ctx->spatial_unknowns) {                                                  // :171-176
+                LAUNCH(k_copy, grid_for(nc), L->tw.p, L->x.p, nc);
+                TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, 1, ctx->wd_type, 1));
+                TFX_TRY(spmv_dev(ctx, L->tw.p, L->sx.p, 0));
+            } else
             TFX_TRY(spmv_dev(ctx, L->x.p, L->sx.p, 0));
             TFX_TRY(allreduce(ctx, L->sx.p, nd));
             const int g = grid_for(nd);
@@ -380,7 +420,13 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
         }
         // u = -alpha u (rank 0) | 0 (others), then u += S_loc v                           :194-209
         LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
-        TFX_TRY(spmv_dev(ctx, L->v.p, L->u.p, 1));
+        if (ctx->spatial_unknowns) {                                                      // :200-209
+            LAUNCH(k_copy, grid_for(nc), L->tw.p, L->v.p, nc);
+            TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, 1, ctx->wd_type, 1));
+            TFX_TRY(spmv_dev(ctx, L->tw.p, L->u.p, 1));
+        } else {
+            TFX_TRY(spmv_dev(ctx, L->v.p, L->u.p, 1));
+        }
         if (ctx->cons.valid) TFX_TRY(spmv_dev(ctx, ctx->cons, L->v.p, L->u.p + L->nrows_data, 1));   // :211 (general C rows)
         {                                                                                 // :211 (diagonal blocks, local)
             const int g = grid_for(nc);

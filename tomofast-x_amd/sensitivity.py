@@ -252,6 +252,11 @@ class Context:
                                        nb, dp, rp, ptr(x), C.byref(it), C.byref(r)))
         return x, it.value, r.value
 
+    def lsqr_set_wavelet_domain(self, wavelet_domain, wavelet_type=0):
+        """WAVELET_DOMAIN = False: spatial unknowns, S applied through the wavelet transform (single rank)."""
+        n1, n2, n3 = self.dims if self.dims else (0, 0, 0)
+        check(self._lib.tfx_lsqr_set_wavelet_domain(self._h, int(bool(wavelet_domain)), n1, n2, n3, int(wavelet_type)))
+
     def lsqr_begin(self, b_data, rmin=1e-13, gamma=0.0, target_misfit=0.0, diag_blocks=(), rhs_blocks=()):
         info = self.matrix_info()
         b = f64(b_data)
