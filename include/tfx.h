@@ -127,6 +127,28 @@ int tfx_cons_upload_csr(tfx_ctx *ctx, int64_t nrows, const int64_t *rowptr, cons
                         const double *rhs);
 int tfx_cons_clear(tfx_ctx *ctx);
 
+/* ---- multi-GPU build: row-parallel compression + relayout (what the reference does through SENSIT files and a
+ * rank-0 MPI_Scatterv per row, sensitivity_gravmag.F90:179-189 and :795-830).
+ * tfx_rowstore_build: like tfx_build_kernel_* for THIS rank's share of the observations, but the compressed rows stay
+ *   row-major on the device with all their columns (problem_type 1 grav / 2 magn with mag_field = incl, decl, azim, nT).
+ * tfx_rowstore_counts: counts_out[r*nparts + d] = entries of local row r with column in [bounds[d], bounds[d+1]).
+ * tfx_rowstore_pack: segment [col_begin, col_end) of local rows [row_begin, +nrows) packed row after row into DEVICE
+ *   buffers (columns re-based to col_begin) - the piece to send to the owner of that column range.
+ * tfx_matrix_begin / _append_rows / _finish: the receiving side assembles its column range from such pieces
+ *   (row_begin must be a multiple of 2048 = the row-block size; pieces arrive in row-block order).               */
+int tfx_rowstore_build(tfx_ctx *ctx, int problem_type, int64_t ndata, const double *xd, const double *yd, const double *zd,
+                       const double *column_weight, const double *mag_field, int compression_type, double rate,
+                       double problem_weight, const double *data_weight, int64_t *nnz_out, double *error_sum_out,
+                       int32_t *nnz_hist_out);
+int tfx_rowstore_counts(tfx_ctx *ctx, int nparts, const int64_t *bounds, int32_t *counts_out);
+int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t col_begin, int64_t col_end,
+                      int32_t *cols_dev_out, float *vals_dev_out, int64_t capacity, int64_t *n_out);
+int tfx_rowstore_free(tfx_ctx *ctx);
+int tfx_matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper);
+int tfx_matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const int32_t *cols_dev, const float *vals_dev,
+                           const int32_t *nel_host);
+int tfx_matrix_finish(tfx_ctx *ctx);
+
 /* get_load_balancing_nelements (sensitivity_gravmag.F90:470-524): host-side, exact integer rule.            */
 int tfx_partition_columns(const int32_t *nnz_hist, int64_t N, int nparts, int32_t *nel_at_part,
                           int64_t *nnz_at_part);

@@ -1320,8 +1320,13 @@ int tfx_compress_row(tfx_ctx *ctx, const double *row, int64_t N, int64_t K, int3
 static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
                             const double *column_weight, int compression_type, double rate, double problem_weight,
                             const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
-                            double *error_sum_out, int32_t *nnz_hist_out, const MagField *mag)
+                            double *error_sum_out, int32_t *nnz_hist_out, const MagField *mag, RowStore *rs = nullptr)
 {
+    // rs != null: keep the compressed rows (all columns, global 0-based column indices) row-major on the device instead of
+    // laying them out as this rank's tiled matrix - the row-parallel half of the multi-GPU build
+    const bool to_rs = rs != nullptr;
+    if (to_rs) { col_begin = 0; col_end = ctx ? ctx->N : 0; }
+    if (to_rs && compression_type == 0) return fail(TFX_E_ARG, "the row store is for compressed kernels (dense kernels are built per column range)");
     if (!ctx || !xd || !yd || !zd || !column_weight) return fail(TFX_E_ARG, "tfx_build_kernel: null argument");
     if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_build_kernel: set the grid first");
     if (compression_type < 0 || compression_type > 2) return fail(TFX_E_ARG, "Unknown wavelet type!");
@@ -1332,7 +1337,7 @@ static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const
     TFX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int64_t ncols = col_end - col_begin;
-    const bool keep_matrix = ncols > 0;
+    const bool keep_matrix = ncols > 0 && !to_rs;
     const int64_t K = compression_type > 0 ? (int64_t)(rate * (double)N) : N;      // get_nel_compressed, :64-77
     const int64_t stride = std::max<int64_t>(1, std::min<int64_t>(K, std::max<int64_t>(ncols, 1)));
     // observation coordinates and scale factors on the device
@@ -1413,6 +1418,13 @@ static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const
         TFX_HIP(hipMemcpyAsync(ell_off.p, ho.data(), RB * sizeof(int64_t), hipMemcpyHostToDevice, s));
     }
     TFX_TRY(ell_nel.alloc(RB));
+    if (to_rs) {
+        rs->nrows = ndata;
+        rs->stride = std::max<int64_t>(1, K);
+        TFX_TRY(rs->cols.alloc((size_t)(ndata * rs->stride)));
+        TFX_TRY(rs->vals.alloc((size_t)(ndata * rs->stride)));
+        TFX_TRY(rs->nel.alloc((size_t)ndata));
+    }
     TFX_TRY(dscale.alloc((size_t)ndata));
     TFX_HIP(hipMemcpyAsync(dscale.p, hscale.data(), (size_t)ndata * sizeof(float), hipMemcpyHostToDevice, s));
     SelectWork sw;
@@ -1435,6 +1447,11 @@ static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const
                 TFX_TRY(wavelet_dev(ctx, drows.p, ctx->nx, ctx->ny, ctx->nz, nb, compression_type, 1));              // :237
                 TFX_TRY(select_threshold_dev(ctx, sw, drows.p, nb, N, K, cw.thr.p));                                 // :240-256
             }
+            if (to_rs)
+                TFX_TRY(compact_dev(ctx, cw, drows.p, nb, N, 0, 0, N, rs->cols.p + (size_t)g * rs->stride,
+                                    rs->vals.p + (size_t)g * rs->stride, rs->stride, ell_nel.p + b0, dscale.p + g,
+                                    nnz_hist_out ? dhist.p : nullptr));
+            else
             TFX_TRY(compact_dev(ctx, cw, drows.p, nb, N, compression_type == 0, col_begin, col_end,
                                 keep_matrix ? ell_cols.p + (size_t)b0 * stride : nullptr,
                                 keep_matrix ? ell_vals.p + (size_t)b0 * stride : nullptr, stride, ell_nel.p + b0,
@@ -1459,6 +1476,7 @@ static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const
         TFX_HIP(hipStreamSynchronize(s));
         TFX_TRY(geometry_error(herr));
         for (int i = 0; i < nr; ++i) nnz_total += h_nel[i];
+        if (to_rs) TFX_HIP(hipMemcpyAsync(rs->nel.p + r0, ell_nel.p, nr * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         if (keep_matrix) TFX_TRY(matrix_append_rows(ctx, r0, nr, ell_cols.p, ell_vals.p, ell_nel.p, ell_off.p, stride));
     }
     if (keep_matrix) {
@@ -1468,6 +1486,182 @@ static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const
     if (nnz_out) *nnz_out = nnz_total;
     if (error_sum_out) *error_sum_out = err_sum;
     if (nnz_hist_out) TFX_TRY(copy_any(nnz_hist_out, dhist.p, (size_t)N * sizeof(int32_t), s));
+    return 0;
+}
+
+// ---- row store: the row-parallel half of the multi-GPU build -------------------------------------------------
+int tfx_rowstore_build(tfx_ctx *ctx, int problem_type, int64_t ndata, const double *xd, const double *yd, const double *zd,
+                       const double *column_weight, const double *mag_field, int compression_type, double rate,
+                       double problem_weight, const double *data_weight, int64_t *nnz_out, double *error_sum_out,
+                       int32_t *nnz_hist_out)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    if (problem_type != 1 && problem_type != 2) return fail(TFX_E_ARG, "problem_type must be 1 (grav) or 2 (magn)");
+    if (problem_type == 2 && !mag_field) return fail(TFX_E_ARG, "magnetic field (incl, decl, azim, intensity) missing");
+    MagField mf{};
+    if (problem_type == 2) mf = make_mag_field(mag_field[0], mag_field[1], mag_field[2], mag_field[3]);
+    return build_kernel_any(ctx, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight, 0, 0,
+                            nnz_out, error_sum_out, nnz_hist_out, problem_type == 2 ? &mf : nullptr, &ctx->rowstore);
+}
+
+// first entry of every row with column >= bounds[d] (d = 0..nparts); counts[r*nparts + d] = entries in [bounds[d], bounds[d+1])
+__global__ void k_rs_bounds(const int32_t *__restrict__ cols, const int32_t *__restrict__ nel, int64_t stride, int64_t nrows,
+                            const int64_t *__restrict__ bounds, int nparts, int32_t *__restrict__ counts)
+{
+    const int64_t r = blockIdx.x;
+    const int32_t *c = cols + r * stride;
+    const int n = nel[r];
+    __shared__ int pos[1026];
+    for (int d = threadIdx.x; d <= nparts; d += blockDim.x) {
+        const int64_t key = bounds[d];
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)c[mid] < key) lo = mid + 1; else hi = mid; }
+        pos[d] = lo;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < nparts; d += blockDim.x) counts[r * nparts + d] = pos[d + 1] - pos[d];
+}
+
+int tfx_rowstore_counts(tfx_ctx *ctx, int nparts, const int64_t *bounds, int32_t *counts_out)
+{
+    if (!ctx || !bounds || !counts_out) return fail(TFX_E_ARG, "tfx_rowstore_counts: null argument");
+    RowStore &rs = ctx->rowstore;
+    if (rs.nrows == 0) return fail(TFX_E_STATE, "no row store");
+    if (nparts < 1 || nparts > 1024) return fail(TFX_E_ARG, "nparts out of range");
+    TFX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DBuf<int64_t> db;
+    DBuf<int32_t> dc;
+    TFX_TRY(db.alloc(nparts + 1));
+    TFX_TRY(dc.alloc((size_t)(rs.nrows * nparts)));
+    TFX_HIP(hipMemcpyAsync(db.p, bounds, (nparts + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_rs_bounds, dim3((unsigned)rs.nrows), dim3(64), 0, s, rs.cols.p, rs.nel.p, rs.stride, rs.nrows, db.p, nparts, dc.p);
+    TFX_HIP(hipGetLastError());
+    TFX_TRY(copy_any(counts_out, dc.p, (size_t)(rs.nrows * nparts) * sizeof(int32_t), s));
+    return 0;
+}
+
+// segment [col_begin, col_end) of rows [row_begin, row_begin + nrows): offsets by an exclusive scan, then a copy
+__global__ void k_rs_seg(const int32_t *__restrict__ cols, const int32_t *__restrict__ nel, int64_t stride, int64_t row_begin,
+                         int nrows, int64_t col_begin, int64_t col_end, int32_t *__restrict__ p0, int32_t *__restrict__ cnt)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const int32_t *c = cols + (row_begin + r) * stride;
+    const int n = nel[row_begin + r];
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)c[mid] < col_begin) lo = mid + 1; else hi = mid; }
+    const int a = lo;
+    hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)c[mid] < col_end) lo = mid + 1; else hi = mid; }
+    p0[r] = a;
+    cnt[r] = lo - a;
+}
+
+__global__ void k_rs_scan(const int32_t *__restrict__ cnt, int nrows, int64_t *__restrict__ off)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t run = 0;
+        for (int r = 0; r < nrows; ++r) { off[r] = run; run += cnt[r]; }
+        off[nrows] = run;
+    }
+}
+
+__global__ void k_rs_copy(const int32_t *__restrict__ cols, const float *__restrict__ vals, int64_t stride, int64_t row_begin,
+                          const int32_t *__restrict__ p0, const int32_t *__restrict__ cnt, const int64_t *__restrict__ off,
+                          int64_t col_begin, int32_t *__restrict__ ocols, float *__restrict__ ovals)
+{
+    const int r = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cnt[r]) return;
+    const int64_t src = (row_begin + r) * stride + p0[r] + j;
+    ocols[off[r] + j] = (int32_t)(cols[src] - col_begin);
+    ovals[off[r] + j] = vals[src];
+}
+
+int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t col_begin, int64_t col_end, int32_t *cols_dev_out,
+                      float *vals_dev_out, int64_t capacity, int64_t *n_out)
+{
+    if (!ctx || !n_out) return fail(TFX_E_ARG, "tfx_rowstore_pack: null argument");
+    RowStore &rs = ctx->rowstore;
+    if (rs.nrows == 0) return fail(TFX_E_STATE, "no row store");
+    if (row_begin < 0 || nrows <= 0 || row_begin + nrows > rs.nrows) return fail(TFX_E_ARG, "row range outside the row store");
+    TFX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int nr = (int)nrows;
+    DBuf<int32_t> p0, cnt;
+    DBuf<int64_t> off;
+    TFX_TRY(p0.alloc(nr));
+    TFX_TRY(cnt.alloc(nr));
+    TFX_TRY(off.alloc(nr + 1));
+    hipLaunchKernelGGL(k_rs_seg, dim3((nr + 255) / 256), dim3(256), 0, s, rs.cols.p, rs.nel.p, rs.stride, row_begin, nr, col_begin,
+                       col_end, p0.p, cnt.p);
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(64), 0, s, cnt.p, nr, off.p);
+    int64_t total = 0;
+    TFX_HIP(hipMemcpyAsync(&total, off.p + nr, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipStreamSynchronize(s));
+    *n_out = total;
+    if (total > capacity) return fail(TFX_E_ARG, "tfx_rowstore_pack: %lld entries do not fit the buffer (%lld)", (long long)total, (long long)capacity);
+    if (total > 0) {
+        if (!cols_dev_out || !vals_dev_out) return fail(TFX_E_ARG, "null output buffer");
+        hipLaunchKernelGGL(k_rs_copy, dim3((unsigned)((rs.stride + 255) / 256), nr), dim3(256), 0, s, rs.cols.p, rs.vals.p, rs.stride,
+                           row_begin, p0.p, cnt.p, off.p, col_begin, cols_dev_out, vals_dev_out);
+        TFX_HIP(hipGetLastError());
+    }
+    TFX_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int tfx_rowstore_free(tfx_ctx *ctx)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->rowstore.cols.release();
+    ctx->rowstore.vals.release();
+    ctx->rowstore.nel.release();
+    ctx->rowstore.nrows = 0;
+    return 0;
+}
+
+// ---- assembling this rank's matrix from row pieces that arrive from other ranks ------------------------------------
+int tfx_matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    TFX_HIP(hipSetDevice(ctx->device));
+    ctx->target = &ctx->mat;
+    return matrix_begin(ctx, nrows, ncols, nnz_upper);
+}
+
+// rows [row_begin, row_begin + nr) (row_begin a multiple of the row-block size 2048, nr <= 2048), consecutive in the DEVICE
+// buffers cols_dev (0-based local columns, ascending within a row) / vals_dev; nel_host[r] = entries of row r
+int tfx_matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const int32_t *cols_dev, const float *vals_dev,
+                           const int32_t *nel_host)
+{
+    if (!ctx || !nel_host) return fail(TFX_E_ARG, "tfx_matrix_append_rows: null argument");
+    TFX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    std::vector<int64_t> ho((size_t)nr);
+    int64_t run = 0, maxlen = 0;
+    for (int64_t r = 0; r < nr; ++r) { ho[(size_t)r] = run; run += nel_host[r]; maxlen = std::max<int64_t>(maxlen, nel_host[r]); }
+    DBuf<int32_t> dn;
+    DBuf<int64_t> dof;
+    TFX_TRY(dn.alloc((size_t)nr));
+    TFX_TRY(dof.alloc((size_t)nr));
+    TFX_HIP(hipMemcpyAsync(dn.p, nel_host, (size_t)nr * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    TFX_HIP(hipMemcpyAsync(dof.p, ho.data(), (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    ctx->target = &ctx->mat;
+    TFX_TRY(matrix_append_rows(ctx, row_begin, nr, cols_dev, vals_dev, dn.p, dof.p, maxlen));
+    ctx->mat.nnz += run;
+    return 0;
+}
+
+int tfx_matrix_finish(tfx_ctx *ctx)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    ctx->target = &ctx->mat;
+    const int64_t nnz = ctx->mat.nnz;
+    TFX_TRY(matrix_finish(ctx));
+    ctx->mat.nnz = nnz;
     return 0;
 }
 

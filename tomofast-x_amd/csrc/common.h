@@ -116,6 +116,14 @@ struct TiledMatrix {
     size_t device_bytes() const;
 };
 
+// compressed rows kept row-major on the device (all columns): the row-parallel half of the multi-GPU build
+struct RowStore {
+    DBuf<int32_t> cols;    // [nrows][stride], global 0-based, ascending
+    DBuf<float> vals;
+    DBuf<int32_t> nel;     // [nrows]
+    int64_t nrows = 0, stride = 0;
+};
+
 struct LsqrState;
 
 }  // namespace tfx
@@ -136,6 +144,7 @@ struct tfx_ctx {
     tfx::TiledMatrix cons;
     tfx::DBuf<double> cons_rhs;        // right-hand side of the C rows (replicated)
     tfx::TiledMatrix *target = &mat;   // which matrix matrix_begin / append / finish assemble
+    tfx::RowStore rowstore;
     // scratch vectors for spmv / spmtv with host pointers
     tfx::DBuf<double> vx, vb;
     // comm

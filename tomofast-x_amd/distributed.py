@@ -91,6 +91,119 @@ def allreduce_numpy(arr, op="sum"):
     return t.cpu().numpy()
 
 
+def block_row_partition(ndata, nranks, row_block):
+    """Row blocks (of `row_block` observations) dealt out contiguously: rank r builds blocks [b[r], b[r+1])."""
+    nblocks = (ndata + row_block - 1) // row_block
+    base, rem = divmod(nblocks, nranks)
+    counts = [base + (1 if r < rem else 0) for r in range(nranks)]
+    starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return nblocks, starts
+
+
+def _p2p(tensors_to_send, recv_specs, backend):
+    """tensors_to_send: list of (dst_rank, tensor); recv_specs: list of (src_rank, tensor) filled in place.
+    NCCL moves device tensors; gloo (CPU tests / single-GPU rehearsal) stages through host memory."""
+    import torch
+    import torch.distributed as dist
+    ops, staged = [], []
+    for dst, t in tensors_to_send:
+        tt = t if backend == "nccl" else t.cpu()
+        staged.append(tt)
+        ops.append(dist.P2POp(dist.isend, tt, dst))
+    for src, t in recv_specs:
+        tt = t if backend == "nccl" else torch.empty(t.shape, dtype=t.dtype)
+        staged.append((t, tt))
+        ops.append(dist.P2POp(dist.irecv, tt, src))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for item in staged:
+        if isinstance(item, tuple) and item[0] is not item[1]:
+            item[0].copy_(item[1])
+
+
+def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate,
+                               problem_weight=1.0, data_weight=None, mag_field=None, get_partition=None, device_index=0):
+    """Row-parallel build + relayout: every rank compresses only ITS row blocks (all columns, kept row-major on
+    the device), the per-column histogram is all-reduced, the reference's greedy rule gives the column ranges, and each
+    row block is then cut into column ranges and sent to the owners, who lay their pieces out as tiles.  Every row is
+    computed once; the matrix crosses the links once (the reference does this through SENSIT files and a rank-0
+    MPI_Scatterv per row: sensitivity_gravmag.F90:179-189, :306-309, :795-830)."""
+    import torch
+    import torch.distributed as dist
+    from .sensitivity import get_load_balancing_nelements
+    backend = dist.get_backend()
+    dev = torch.device("cuda", device_index)
+    N = ctx.nelements_total
+    nd = len(Xdata)
+    RB = ctx.ROW_BLOCK
+    nblocks, bstart = block_row_partition(nd, nranks, RB)
+    owner = np.repeat(np.arange(nranks), np.diff(bstart))
+    r0, r1 = int(bstart[rank]) * RB, min(int(bstart[rank + 1]) * RB, nd)
+    nloc = max(0, r1 - r0)
+    # 1. my rows, all columns
+    if nloc > 0:
+        dw = None if data_weight is None else data_weight[r0:r1]
+        res = ctx.rowstore_build(Xdata[r0:r1], Ydata[r0:r1], Zdata[r0:r1], column_weight, compression_type, compression_rate,
+                                 problem_weight, dw, mag_field)
+        hist, err = res["nnz_hist"].astype(np.int64), res["error_sum"]
+    else:
+        hist, err = np.zeros(N, np.int64), 0.0
+    # 2. partition (sensitivity_gravmag.F90:322, :470-524)
+    hist = allreduce_numpy(hist)
+    err = float(allreduce_numpy(np.array([err]))[0])
+    nel, nnz = (get_partition or get_load_balancing_nelements)(hist.astype(np.int32), nranks)
+    bounds = np.concatenate([[0], np.cumsum(np.asarray(nel, np.int64))])
+    c0, c1 = int(bounds[rank]), int(bounds[rank + 1])
+    # 3. who sends how much of which row to whom
+    counts_loc = ctx.rowstore_counts(nloc, bounds) if nloc > 0 else np.zeros((0, nranks), np.int32)
+    maxloc = int(max(np.diff(bstart))) * RB
+    pad = np.zeros((maxloc, nranks), np.int32)
+    pad[:nloc] = counts_loc
+    gathered = [torch.zeros((maxloc, nranks), dtype=torch.int32, device=dev if backend == "nccl" else "cpu") for _ in range(nranks)]
+    dist.all_gather(gathered, torch.from_numpy(pad).to(gathered[0].device))
+    counts = np.zeros((nd, nranks), np.int32)                       # counts[row, dest]
+    for r in range(nranks):
+        a, b = int(bstart[r]) * RB, min(int(bstart[r + 1]) * RB, nd)
+        if b > a:
+            counts[a:b] = gathered[r].cpu().numpy()[:b - a]
+    assert int(counts[:, rank].sum()) == int(nnz[rank]), (counts[:, rank].sum(), nnz[rank])
+    # 4. relayout, row block by row block
+    ctx.matrix_begin(nd, c1 - c0, int(nnz[rank]))
+    for b in range(nblocks):
+        ga, gb = b * RB, min((b + 1) * RB, nd)
+        o = int(owner[b])
+        n_in = int(counts[ga:gb, rank].sum())
+        rc = torch.empty(max(n_in, 1), dtype=torch.int32, device=dev)
+        rv = torch.empty(max(n_in, 1), dtype=torch.float32, device=dev)
+        sends, recvs, keep = [], [], []
+        if o == rank:
+            for d in range(nranks):
+                n_out = int(counts[ga:gb, d].sum())
+                if n_out == 0:
+                    continue
+                if d == rank:
+                    got = ctx.rowstore_pack(ga - r0, gb - ga, int(bounds[d]), int(bounds[d + 1]), rc, rv, n_out)
+                    assert got == n_out
+                    continue
+                sc = torch.empty(n_out, dtype=torch.int32, device=dev)
+                sv = torch.empty(n_out, dtype=torch.float32, device=dev)
+                got = ctx.rowstore_pack(ga - r0, gb - ga, int(bounds[d]), int(bounds[d + 1]), sc, sv, n_out)
+                assert got == n_out
+                keep += [sc, sv]
+                sends += [(d, sc), (d, sv)]
+        elif n_in > 0:
+            recvs += [(o, rc[:n_in]), (o, rv[:n_in])]
+        if backend == "nccl":
+            torch.cuda.synchronize(dev)                              # pack kernels ran on the ctx stream
+        _p2p(sends, recvs, backend)
+        torch.cuda.synchronize(dev)
+        ctx.matrix_append_rows(ga, rc, rv, counts[ga:gb, rank])
+    ctx.matrix_finish()
+    ctx.rowstore_free()
+    return dict(col_range=(c0, c1), nelements_at_cpu=nel, nnz_at_cpu=nnz, nnz_total=int(hist.sum()), comp_error=err / nd)
+
+
 def build_partitioned(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate,
                       problem_weight=1.0, data_weight=None, get_partition=None):
     """Column-partitioned sensitivity build for `nranks` GPUs.

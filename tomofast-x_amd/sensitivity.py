@@ -162,6 +162,46 @@ class Context:
                                                  C.c_int64(c1), C.byref(nnz), C.byref(err), ptr(hist)))
         return dict(nnz=nnz.value, error_sum=err.value, comp_error=err.value / xd.size, nnz_hist=hist)
 
+    # ---- row store / piecewise assembly (multi-GPU build, distributed.build_partitioned)
+    ROW_BLOCK = 2048
+
+    def rowstore_build(self, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate, problem_weight=1.0,
+                       data_weight=None, mag_field=None):
+        xd, yd, zd, cw = f64(Xdata), f64(Ydata), f64(Zdata), f64(column_weight)
+        dw = None if data_weight is None else f64(data_weight)
+        mf = None if mag_field is None else f64(mag_field)
+        nnz, err = C.c_int64(), C.c_double()
+        hist = np.zeros(self.nelements_total, np.int32)
+        check(self._lib.tfx_rowstore_build(self._h, 1 if mag_field is None else 2, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw),
+                                           ptr(mf), int(compression_type), C.c_double(compression_rate), C.c_double(problem_weight),
+                                           ptr(dw), C.byref(nnz), C.byref(err), ptr(hist)))
+        return dict(nnz=nnz.value, error_sum=err.value, nnz_hist=hist)
+
+    def rowstore_counts(self, nrows_local, bounds):
+        b = np.ascontiguousarray(bounds, np.int64)
+        out = np.zeros((nrows_local, b.size - 1), np.int32)
+        check(self._lib.tfx_rowstore_counts(self._h, int(b.size - 1), ptr(b), ptr(out)))
+        return out
+
+    def rowstore_pack(self, row_begin, nrows, col_begin, col_end, cols_dev, vals_dev, capacity):
+        n = C.c_int64()
+        check(self._lib.tfx_rowstore_pack(self._h, C.c_int64(row_begin), C.c_int64(nrows), C.c_int64(col_begin), C.c_int64(col_end),
+                                          ptr(cols_dev), ptr(vals_dev), C.c_int64(capacity), C.byref(n)))
+        return n.value
+
+    def rowstore_free(self):
+        check(self._lib.tfx_rowstore_free(self._h))
+
+    def matrix_begin(self, nrows, ncols, nnz_upper):
+        check(self._lib.tfx_matrix_begin(self._h, C.c_int64(nrows), C.c_int64(ncols), C.c_int64(nnz_upper)))
+
+    def matrix_append_rows(self, row_begin, cols_dev, vals_dev, nel):
+        nel = np.ascontiguousarray(nel, np.int32)
+        check(self._lib.tfx_matrix_append_rows(self._h, C.c_int64(row_begin), C.c_int64(nel.size), ptr(cols_dev), ptr(vals_dev), ptr(nel)))
+
+    def matrix_finish(self):
+        check(self._lib.tfx_matrix_finish(self._h))
+
     # ---- t_sparse_matrix
     def matrix_upload_csr(self, nrows, ncols, rowptr, cols, vals):
         rp = np.ascontiguousarray(rowptr, np.int64)
