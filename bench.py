@@ -104,7 +104,14 @@ def main():
     # ---- build (setup; reported as cell.obs/s)
     barrier()
     t0 = time.time()
-    part = tfx.distributed.build_partitioned(ctx, rank, world, xs, ys, zs, cw, w["ctype"], w["rate"])
+    # N > 1: row-parallel build + point-to-point relayout (every row computed once); TFX_BUILD_MODE=redundant selects the
+    # simpler scheme where every rank rebuilds all rows for its column range (also used for uncompressed kernels)
+    if world > 1 and w["ctype"] > 0 and os.environ.get("TFX_BUILD_MODE", "exchange") == "exchange":
+        part = tfx.distributed.build_partitioned_exchange(ctx, rank, world, xs, ys, zs, cw, w["ctype"], w["rate"], device_index=local_rank)
+        build_mode = "row-parallel + relayout"
+    else:
+        part = tfx.distributed.build_partitioned(ctx, rank, world, xs, ys, zs, cw, w["ctype"], w["rate"])
+        build_mode = "direct" if world == 1 else "redundant rows per column range"
     barrier()
     t_build = time.time() - t0
     minfo = ctx.matrix_info()
@@ -191,7 +198,7 @@ def main():
                        "compression": {0: "none", 1: "haar", 2: "d4"}[w["ctype"]], "rate": w["rate"],
                        "parallelism": "column-partitioned x%d" % world, "damping_alpha": alpha},
             "cell_obs_per_s_solve": round(N * D * value, 1),
-            "cell_obs_per_s_build": round(N * D / t_build, 1), "build_s": round(t_build, 2),
+            "cell_obs_per_s_build": round(N * D / t_build, 1), "build_s": round(t_build, 2), "build_mode": build_mode,
             "gpu_ms_per_step_hip_events": round(ms_gpu / args.steps, 4),
             "lsqr_bytes_per_iteration_algorithmic": 16 * int(nnz_total) + 112 * N + 48 * (D + N),
             "adjoint_identity_rel_err": adj_err, "final_r": r,
