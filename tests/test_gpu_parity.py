@@ -314,6 +314,56 @@ def test_matrix_roundtrip_and_products(ctx, shape):
     assert abs(np.dot(b, y) - np.dot(x, bt)) <= 1e-11 * np.dot(orc.spmv(*absS, np.abs(x)), np.abs(y))
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (1, 16384), (1, 16385), (2048, 3), (2049, 16385), (3, 70000)])
+def test_matrix_edge_shapes(ctx, shape):
+    """Tile-boundary sizes (row block 2048, column tile 16384), single rows / columns, dense and nearly empty patterns."""
+    nrows, ncols = shape
+    rng = np.random.default_rng(nrows * 131 + ncols)
+    for pattern in ("dense_row0", "last_col_only", "diag", "empty"):
+        rp, cols, vals = [0], [], []
+        for r in range(nrows):
+            if pattern == "dense_row0":
+                c = np.arange(ncols) if r == 0 else np.zeros(0, np.int64)
+            elif pattern == "last_col_only":
+                c = np.array([ncols - 1])
+            elif pattern == "diag":
+                c = np.array([r % ncols])
+            else:
+                c = np.zeros(0, np.int64)
+            cols.append((c + 1).astype(np.int32))
+            vals.append(rng.standard_normal(c.size).astype(np.float32) + np.float32(3.0))
+            rp.append(rp[-1] + c.size)
+        S = (np.array(rp, np.int64), np.concatenate(cols), np.concatenate(vals))
+        ctx.matrix_upload_csr(nrows, ncols, *S)
+        back = ctx.matrix_download_csr()
+        assert np.array_equal(back[0], S[0]) and np.array_equal(back[1], S[1]) and bits_equal(back[2], S[2]), (shape, pattern)
+        x, y = rng.standard_normal(ncols), rng.standard_normal(nrows)
+        assert np.allclose(ctx.mult_vector(x), orc.spmv(*S, x), rtol=1e-12, atol=1e-12)
+        assert np.allclose(ctx.trans_mult_vector(y), orc.spmtv(*S, y, ncols), rtol=1e-12, atol=1e-12)
+
+
+def test_lsqr_two_diagonal_blocks_and_soft_threshold(ctx, golden_dir):
+    """Damping AND ADMM block together (two diagonal blocks, joint_inverse_problem.F90:452-527) with soft thresholding
+    (lsqr_solver2.F90:478-494) against the oracle on the same [S; a I; b I] system."""
+    g = load(golden_dir, "e2e_d4")
+    N = int(g["nx"]) * int(g["ny"]) * int(g["nz"])
+    S = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+    ctx.matrix_upload_csr(g["obs"].shape[0], N, *S)
+    b = g["np1_data_observed"]
+    rng = np.random.default_rng(9)
+    d1 = np.full(N, np.float32(1e-7), np.float32)
+    d2 = (np.float32(3e-7) * (1 + rng.random(N))).astype(np.float32)
+    r1, r2 = rng.standard_normal(N) * 1e-10, rng.standard_normal(N) * 1e-10
+    for gamma in (0.0, 1e-6):
+        x, it, r = ctx.lsqr_solve_sensit(b, 6, 1e-13, gamma, 0.0, [d1, d2], [r1, r2])
+        D1, D2 = orc.diag_csr(d1), orc.diag_csr(d2)
+        Cm = (np.concatenate([D1[0], D1[0][-1] + D2[0][1:]]), np.concatenate([D1[1], D2[1]]), np.concatenate([D1[2], D2[2]]))
+        xo, ito, ro = orc.lsqr(S, Cm, N, np.concatenate([b, r1, r2]), 6, 1e-13, gamma)
+        assert it == ito == 6
+        assert np.linalg.norm(x - xo) <= 1e-9 * np.linalg.norm(xo), gamma
+        assert abs(r - ro) <= 1e-9 * ro
+
+
 def test_products_vs_reference_golden(ctx, golden_dir):
     g = load(golden_dir, "lsqr")
     for case in ("damp", "gen", "noC"):
