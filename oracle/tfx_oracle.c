@@ -97,11 +97,15 @@ static int sharmbox(double x0, double y0, double z0, double x1, double y1, doubl
     return 0;
 }
 
-int orc_magprism_tmi(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
-                     const double *Z1, const double *Z2, double xd, double yd, double zd, const double *magv,
-                     double intensity, double *line)
+/* magnetic_field.f90:118-297: sensit_line(nelements, nmodel_components, ndata_components), Fortran order:
+ * line[i + n*(k + ncm*d)].  ncm 1 (susceptibility) or 3 (magnetisation), ncd 1 (TMI) or 3 (Bx, By, Bz). */
+int orc_magprism(int64_t n, int ncm, int ncd, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                 const double *Z1, const double *Z2, double xd, double yd, double zd, const double *magv,
+                 double intensity, double *line)
 {
     const double PI = 3.14159265358979323846;
+    const double mu0 = 4.0 * PI * 1.e-7, T2nT = 1.e+9;                   /* :31-34 */
+    if (!((ncm == 1 || ncm == 3) && (ncd == 1 || ncd == 3))) return -3;  /* :263-282 */
     for (int64_t i = 0; i < n; ++i) {
         double tx[3], ty[3], tz[3];
         int ierr;
@@ -127,12 +131,92 @@ int orc_magprism_tmi(int64_t n, const double *X1, const double *X2, const double
             ierr = sharmbox(xd, yd, zd, X1[i], Y1[i], Z1[i], X2[i], Y2[i], Z2[i], tx, ty, tz);       /* :230-240 */
             if (ierr) return ierr;
         }
-        double mx = (tx[0] * magv[0] + tx[1] * magv[1]) + tx[2] * magv[2];                           /* :246-248 */
-        double my = (ty[0] * magv[0] + ty[1] * magv[1]) + ty[2] * magv[2];
-        double mz = (tz[0] * magv[0] + tz[1] * magv[1]) + tz[2] * magv[2];
-        double v = mx * magv[0] + my * magv[1] + mz * magv[2];                                       /* :251 */
-        v = intensity * v;                                                                           /* :287 */
-        line[i] = v / (4.0 * PI);                                                                    /* :295 */
+#define LINE(k, d) line[i + n * ((k) + (int64_t)ncm * (d))]
+        if (ncm == 1) {
+            double mx = (tx[0] * magv[0] + tx[1] * magv[1]) + tx[2] * magv[2];                       /* :246-248 */
+            double my = (ty[0] * magv[0] + ty[1] * magv[1]) + ty[2] * magv[2];
+            double mz = (tz[0] * magv[0] + tz[1] * magv[1]) + tz[2] * magv[2];
+            if (ncd == 1) {
+                LINE(0, 0) = mx * magv[0] + my * magv[1] + mz * magv[2];                             /* :251 */
+            } else {
+                LINE(0, 0) = mx; LINE(0, 1) = my; LINE(0, 2) = mz;                                   /* :254-256 */
+            }
+        } else {
+            for (int k = 0; k < 3; ++k) {
+                if (ncd == 1) {
+                    LINE(k, 0) = tx[k] * magv[0] + ty[k] * magv[1] + tz[k] * magv[2];                /* :268 */
+                } else {
+                    LINE(k, 0) = tx[k]; LINE(k, 1) = ty[k]; LINE(k, 2) = tz[k];                      /* :273-275 */
+                }
+            }
+        }
+        for (int d = 0; d < ncd; ++d)
+            for (int k = 0; k < ncm; ++k) {
+                double v = LINE(k, d);
+                v = (ncm == 1) ? intensity * v : (mu0 * T2nT) * v;                                   /* :286-291 */
+                LINE(k, d) = v / (4.0 * PI);                                                         /* :295 */
+            }
+#undef LINE
+    }
+    return 0;
+}
+
+int orc_magprism_tmi(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                     const double *Z1, const double *Z2, double xd, double yd, double zd, const double *magv,
+                     double intensity, double *line)
+{
+    return orc_magprism(n, 1, 1, X1, X2, Y1, Y2, Z1, Z2, xd, yd, zd, magv, intensity, line);
+}
+
+/* gravity_field.f90:207-310 (gradiprism_full): lines[6][n] in the order the build stores them
+ * (sensitivity_gravmag.F90:210-212): XX, YY, ZZ, XY, YZ, ZX.  Returns 0, -4 (zero denominator, :275-277) or
+ * -5 (bad log argument, :282-284).  only_zz != 0: gradiprism_zz (:315-362), line = lines[0..n). */
+int orc_gradiprism(int64_t n, int only_zz, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                   const double *Z1, const double *Z2, double xd, double yd, double zd, double *lines)
+{
+    const double twopi = 2.0 * 3.14159265358979323846;
+    static const double signo[2] = {-1.0, 1.0};
+    for (int64_t i = 0; i < n; ++i) {
+        double XX[2], YY[2], ZZ[2];
+        XX[0] = xd - X1[i]; XX[1] = xd - X2[i];
+        YY[0] = yd - Y1[i]; YY[1] = yd - Y2[i];
+        ZZ[0] = -(zd - Z1[i]); ZZ[1] = -(zd - Z2[i]);                                   /* :236-237 */
+        double gxx = 0, gxy = 0, gyy = 0, gzx = 0, gyz = 0, gzz = 0;
+        for (int K = 0; K < 2; ++K)
+            for (int L = 0; L < 2; ++L)
+                for (int M = 0; M < 2; ++M) {
+                    double dmu = signo[K] * signo[L] * signo[M];
+                    double Rs = sqrt(XX[K] * XX[K] + YY[L] * YY[L] + ZZ[M] * ZZ[M]);     /* :251 */
+                    double vzz = -atan2(XX[K] * YY[L], Rs * ZZ[M]);                      /* :255 */
+                    if (vzz < 0) vzz = vzz + twopi;
+                    gzz = gzz + dmu * vzz;
+                    if (only_zz) continue;
+                    double vxx = atan2(XX[K] * YY[L], XX[K] * XX[K] + Rs * ZZ[M] + ZZ[M] * ZZ[M]);   /* :253 */
+                    double vyy = atan2(XX[K] * YY[L], Rs * Rs + Rs * ZZ[M] - XX[K] * XX[K]);         /* :254 */
+                    if (vxx < 0) vxx = vxx + twopi;
+                    if (vyy < 0) vyy = vyy + twopi;
+                    double arg1 = Rs + ZZ[M];
+                    double arg21 = Rs - YY[L], arg22 = Rs + YY[L];
+                    double arg31 = Rs - XX[K], arg32 = Rs + XX[K];
+                    if (arg22 == 0. || arg32 == 0.) return -4;
+                    double arg2 = arg21 / arg22, arg3 = arg31 / arg32;
+                    if (arg1 <= 0. || arg2 <= 0. || arg3 <= 0.) return -5;
+                    double vxy = log(arg1);
+                    double vzx = 0.5 * log(arg2);
+                    double vyz = 0.5 * log(arg3);
+                    gxx = gxx + dmu * vxx;
+                    gyy = gyy + dmu * vyy;
+                    gxy = gxy + dmu * vxy;
+                    gyz = gyz + dmu * vyz;
+                    gzx = gzx + dmu * vzx;
+                }
+        if (only_zz) { lines[i] = G_GRAV * gzz; continue; }
+        lines[i] = G_GRAV * gxx;
+        lines[i + n] = G_GRAV * gyy;
+        lines[i + 2 * n] = G_GRAV * gzz;
+        lines[i + 3 * n] = G_GRAV * gxy;
+        lines[i + 4 * n] = G_GRAV * gyz;
+        lines[i + 5 * n] = G_GRAV * gzx;
     }
     return 0;
 }
@@ -401,6 +485,14 @@ static int64_t compress_weighted_row(int64_t N, int nx, int ny, int nz, const do
     for (int64_t p = 0; p < N; ++p) { cols[p] = (int32_t)(p + 1); vals[p] = (float)work[p]; }   /* :289-295 */
     if (error_r) *error_r = 0.0;
     return N;
+}
+
+/* one (data, data-component, model-component) line: weight -> cost -> wavelet -> threshold -> compaction
+ * (sensitivity_gravmag.F90:222-311).  line (N) is overwritten. */
+int64_t orc_compress_line(int64_t N, int nx, int ny, int nz, const double *cw, int compression_type, int64_t K,
+                          double *line, int32_t *cols, float *vals, double *error_r)
+{
+    return compress_weighted_row(N, nx, ny, nz, cw, compression_type, K, line, cols, vals, error_r);
 }
 
 void orc_partition(const int32_t *nnz, int64_t N, int P, int32_t *nel_at_cpu, int64_t *nnz_at_cpu)

@@ -35,6 +35,23 @@ void orc_dircos(double incl, double decl, double azim, double *magv);
 int orc_magprism_tmi(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
                      const double *Z1, const double *Z2, double xd, double yd, double zd, const double *magv,
                      double intensity, double *line);
+/* General form: ncm = nmodel_components (1 susceptibility | 3 magnetisation vector), ncd = ndata_components (1 TMI | 3).
+ * line[i + n*(k + ncm*d)] = sensit_line(i, k, d) (magnetic_field.f90:243-295). -3: wrong component counts. */
+int orc_magprism(int64_t n, int ncm, int ncd, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                 const double *Z1, const double *Z2, double xd, double yd, double zd, const double *magv,
+                 double intensity, double *line);
+
+/* src/forward/gravmag/grav/gravity_field.f90:207-310 (gradiprism_full) / :315-362 (gradiprism_zz, only_zz != 0).
+ * lines[c*n + i], c in the order the build stores the components (sensitivity_gravmag.F90:210-212):
+ * XX, YY, ZZ, XY, YZ, ZX.  Returns 0, -4 (zero denominator) or -5 (bad log argument). */
+int orc_gradiprism(int64_t n, int only_zz, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                   const double *Z1, const double *Z2, double xd, double yd, double zd, double *lines);
+
+/* One (data, data-component, model-component) line of the build loop (sensitivity_gravmag.F90:222-311):
+ * column weight -> cost_full -> wavelet -> threshold -> compaction.  line (N) is overwritten.  Returns nel. */
+int64_t orc_compress_line(int64_t N, int nx, int ny, int nz, const double *cw, int compression_type, int64_t K,
+                          double *line, int32_t *cols, float *vals, double *error_r);
+
 int64_t orc_build_row_mag(int64_t N, int nx, int ny, int nz, const double *X1, const double *X2,
                           const double *Y1, const double *Y2, const double *Z1, const double *Z2,
                           const double *cw, double xd, double yd, double zd, const double *magv, double intensity,

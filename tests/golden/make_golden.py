@@ -129,6 +129,60 @@ def make_magprism(tmp):
     print("magprism.npz: rows", out["rows_0"].shape, "x", len(fields), "fields")
 
 
+def make_gradprism(tmp):
+    """gradiprism_zz and gradiprism_full rows (gravity gradiometry) on the prism.npz grid/observations."""
+    rng = np.random.default_rng(42)
+    nx, ny, nz = 8, 6, 5
+    g = nonuniform_grid(nx, ny, nz, rng)
+    xe0, xe1 = g[0].min(), g[1].max()
+    ye0, ye1 = g[2].min(), g[3].max()
+    obs = np.array([
+        [0.5 * (xe0 + xe1) + 0.37, 0.5 * (ye0 + ye1) + 0.41, -1.0],
+        [xe0 - 150.0, ye0 - 77.0, -25.0],
+        [xe1 + 10.3, 0.5 * (ye0 + ye1), -0.1],
+        [g[0][3] + 7.77, g[2][9] + 3.33, -0.5],
+        [0.5 * (g[0][20] + g[1][20]) + 1.234, 0.5 * (g[2][20] + g[3][20]) - 2.2, 0.5 * (g[4][100] + g[5][100]) + 0.77],
+    ])
+    nel, nd = nx * ny * nz, obs.shape[0]
+    fg, fo, fout = [os.path.join(tmp, x) for x in ("gp_grid.bin", "gp_obs.bin", "gp_out.bin")]
+    open(fg, "wb").write(b"".join(be(a, ">f8") for a in g))
+    open(fo, "wb").write(be(obs[:, 0], ">f8") + be(obs[:, 1], ">f8") + be(obs[:, 2], ">f8"))
+    run([os.path.join(REFBIN, "gold_gradprism")], stdin="%d %d\n%s\n%s\n%s\n" % (nel, nd, fg, fo, fout))
+    a = np.fromfile(fout, ">f8").astype(np.float64).reshape(nd, 7, nel)
+    np.savez_compressed(os.path.join(HERE, "gradprism.npz"), nx=nx, ny=ny, nz=nz, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3],
+                        Z1=g[4], Z2=g[5], obs=obs, rows_zz=a[:, 0, :], rows_full=a[:, 1:, :])
+    print("gradprism.npz: zz", a[:, 0, :].shape, "full", a[:, 1:, :].shape)
+
+
+def make_magprism_comp(tmp):
+    """magprism with 3 model components (magnetisation vector) and / or 3 data components, same grid/obs as magprism.npz."""
+    rng = np.random.default_rng(43)
+    nx, ny, nz = 8, 6, 5
+    g = nonuniform_grid(nx, ny, nz, rng)
+    xe0, xe1 = g[0].min(), g[1].max()
+    ye0, ye1 = g[2].min(), g[3].max()
+    c = 100
+    obs = np.array([
+        [0.5 * (xe0 + xe1) + 0.37, 0.5 * (ye0 + ye1) + 0.41, -1.0],
+        [xe0 - 150.0, ye0 - 77.0, -25.0],
+        [0.5 * (g[0][c] + g[1][c]) + 1.234, 0.5 * (g[2][c] + g[3][c]) - 2.2, 0.5 * (g[4][c] + g[5][c]) + 0.77],
+        [g[0][c] + 0.03, g[2][c] + 5.0, g[4][c] + 4.0],
+    ])
+    out = dict(nx=nx, ny=ny, nz=nz, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs)
+    nel, nd = nx * ny * nz, obs.shape[0]
+    fg, fo, fout = [os.path.join(tmp, x) for x in ("mc_grid.bin", "mc_obs.bin", "mc_out.bin")]
+    open(fg, "wb").write(b"".join(be(a, ">f8") for a in g))
+    open(fo, "wb").write(be(obs[:, 0], ">f8") + be(obs[:, 1], ">f8") + be(obs[:, 2], ">f8"))
+    incl, decl, azim, inten = -62.0, 11.0, 20.0, 57000.0
+    out["field"] = np.array([incl, decl, azim, inten])
+    for ncm, ncd in ((1, 3), (3, 1), (3, 3)):
+        run([os.path.join(REFBIN, "gold_magprism_comp")], stdin="%d %d %d %d %.17g %.17g %.17g %.17g\n%s\n%s\n%s\n" % (nel, nd, ncm, ncd, incl, decl, azim, inten, fg, fo, fout))
+        # (obs, d, k, cell): Fortran sensit_line(nel, ncm, ncd)
+        out["rows_m%d_d%d" % (ncm, ncd)] = np.fromfile(fout, ">f8").astype(np.float64).reshape(nd, ncd, ncm, nel)
+    np.savez_compressed(os.path.join(HERE, "magprism_comp.npz"), **out)
+    print("magprism_comp.npz:", [k for k in out if k.startswith("rows")])
+
+
 # ----------------------------------------------------------------------------------------------------
 def rand_csr(rng, nl, ncols, density, empty_rows=()):
     rc = np.zeros(nl, np.int32)

@@ -65,6 +65,79 @@ def magprism_tmi(grid, xd, yd, zd, magv, intensity):
     return ierr, line
 
 
+def magprism(grid, xd, yd, zd, magv, intensity, ncm, ncd):
+    """-> (ierr, lines[ncd, ncm, n])  (Fortran sensit_line(n, ncm, ncd))."""
+    X1, X2, Y1, Y2, Z1, Z2 = [f64(g) for g in grid]
+    n = X1.size
+    line = np.empty(n * ncm * ncd)
+    magv = f64(magv)
+    ierr = lib().orc_magprism(C.c_int64(n), ncm, ncd, dp(X1), dp(X2), dp(Y1), dp(Y2), dp(Z1), dp(Z2), C.c_double(xd),
+                              C.c_double(yd), C.c_double(zd), dp(magv), C.c_double(intensity), dp(line))
+    return ierr, line.reshape(ncd, ncm, n)
+
+
+def gradiprism(grid, xd, yd, zd, only_zz):
+    """-> (ierr, lines[1 or 6, n]); component order XX, YY, ZZ, XY, YZ, ZX."""
+    X1, X2, Y1, Y2, Z1, Z2 = [f64(g) for g in grid]
+    n = X1.size
+    nc = 1 if only_zz else 6
+    line = np.empty(n * nc)
+    ierr = lib().orc_gradiprism(C.c_int64(n), 1 if only_zz else 0, dp(X1), dp(X2), dp(Y1), dp(Y2), dp(Z1), dp(Z2),
+                                C.c_double(xd), C.c_double(yd), C.c_double(zd), dp(line))
+    return ierr, line.reshape(nc, n)
+
+
+def compress_line(line, cw, dims, ctype, K):
+    """One build-loop line: weight -> wavelet -> threshold -> compaction.  -> cols (1-based), vals, error_r."""
+    line = f64(line).copy()
+    cw = f64(cw)
+    N = line.size
+    cols = np.empty(N, np.int32)
+    vals = np.empty(N, np.float32)
+    err = C.c_double()
+    lib().orc_compress_line.restype = C.c_int64
+    nel = lib().orc_compress_line(C.c_int64(N), dims[0], dims[1], dims[2], dp(cw), ctype, C.c_int64(K), dp(line),
+                                  cols.ctypes.data_as(c_ip), vals.ctypes.data_as(c_fp), C.byref(err))
+    return cols[:nel].copy(), vals[:nel].copy(), err.value
+
+
+def rowgen(kind, grid, o, field=None, ncm=1, ncd=1):
+    """Lines of one observation, [ncd, ncm, N].  kind: 'gz' | 'gzz' | 'ftg' | 'mag'."""
+    if kind == "gz":
+        ierr, line = graviprism_z(grid, o[0], o[1], o[2])
+        lines = line.reshape(1, 1, -1)
+    elif kind in ("gzz", "ftg"):
+        ierr, l = gradiprism(grid, o[0], o[1], o[2], kind == "gzz")
+        lines = l.reshape(l.shape[0], 1, -1)
+    else:
+        ierr, lines = magprism(grid, o[0], o[1], o[2], dircos(*field[:3]), field[3], ncm, ncd)
+    assert ierr == 0, ierr
+    return lines
+
+
+def build_matrix_comp(kind, grid, dims, cw, obs, ctype, rate, field=None, ncm=1, ncd=1):
+    """Multi-component kernel -> CSR with ndata*ncd rows and ncm*N columns (1-based; model component k occupies
+    columns k*N + cell, sensitivity_gravmag.F90:829-846), nnz histogram over cells, mean compression error."""
+    N = int(np.prod(dims))
+    K = int(rate * N) if ctype > 0 else N
+    rp, cs, vs, errs = [0], [], [], []
+    hist = np.zeros(N, np.int64)
+    for o in np.asarray(obs):
+        lines = rowgen(kind, grid, o, field, ncm, ncd)
+        for d in range(lines.shape[0]):
+            n_row = 0
+            for k in range(lines.shape[1]):
+                c, v, e = compress_line(lines[d, k], cw, dims, ctype, K)
+                hist += np.bincount(c - 1, minlength=N)
+                cs.append(c + k * N)
+                vs.append(v)
+                errs.append(e)
+                n_row += c.size
+            rp.append(rp[-1] + n_row)
+    return (np.array(rp, np.int64), np.concatenate(cs).astype(np.int32), np.concatenate(vs), hist.astype(np.int32),
+            float(np.sum(errs) / len(errs)))
+
+
 def column_weight_type1(grid, power=2.0, Z0=0.0, multiplier=4.0e3):
     X1, X2, Y1, Y2, Z1, Z2 = [f64(g) for g in grid]
     n = X1.size

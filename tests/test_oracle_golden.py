@@ -191,3 +191,31 @@ def test_magnetic_end_to_end_vs_reference(golden_dir):
     # the first solve converges to r ~ 4e-14 (below minResidual), so the second one starts from rounding noise and its
     # residual ratio is only reproducible to a few digits
     assert np.allclose([h["r"] for h in hist], g["lsqr_r"], rtol=1e-3)
+
+
+def test_gradiprism_rows_bit_exact(golden_dir):
+    """gradiprism_zz / gradiprism_full (gravity_field.f90:207-362) vs the reference's rows."""
+    g = load(golden_dir, "gradprism")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    for i, o in enumerate(g["obs"]):
+        ierr, zz = orc.gradiprism(grid, o[0], o[1], o[2], True)
+        assert ierr == 0
+        assert bits_equal(zz[0], g["rows_zz"][i])
+        ierr, full = orc.gradiprism(grid, o[0], o[1], o[2], False)
+        assert ierr == 0
+        assert bits_equal(full, g["rows_full"][i])
+        assert bits_equal(full[2], zz[0])           # ZZ of the full tensor == gradiprism_zz
+
+
+def test_magprism_components_bit_exact(golden_dir):
+    """magprism with 3 model and / or 3 data components (magnetic_field.f90:243-295)."""
+    g = load(golden_dir, "magprism_comp")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    f = g["field"]
+    magv = orc.dircos(f[0], f[1], f[2])
+    for ncm, ncd in ((1, 3), (3, 1), (3, 3)):
+        ref = g["rows_m%d_d%d" % (ncm, ncd)]
+        for i, o in enumerate(g["obs"]):
+            ierr, lines = orc.magprism(grid, o[0], o[1], o[2], magv, f[3], ncm, ncd)
+            assert ierr == 0
+            assert bits_equal(lines, ref[i]), (ncm, ncd, i)
