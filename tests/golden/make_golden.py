@@ -260,14 +260,15 @@ def write_grid_file(path, g, nx, ny, nz):
                 g[0][p], g[1][p], g[2][p], g[3][p], g[4][p], g[5][p], i.ravel()[p] + 1, j.ravel()[p] + 1, k.ravel()[p] + 1))
 
 
-def parse_sensit(path):
-    """SENSIT row file (sensitivity_gravmag.F90:183, :306-309): big-endian stream."""
+def parse_sensit(path, nsub=1):
+    """SENSIT row file (sensitivity_gravmag.F90:183, :306-309): big-endian stream; nsub = lines per datum
+    (ndata_components * nmodel_components, written d outer, k inner)."""
     raw = open(path, "rb").read()
     hdr = np.frombuffer(raw, ">i4", 5, 0)
     ndata_loc = int(hdr[0])
     off = 20
     rows = []
-    for _ in range(ndata_loc):
+    for _ in range(ndata_loc * nsub):
         idata, nel, k, d = [int(v) for v in np.frombuffer(raw, ">i4", 4, off)]
         off += 16
         cols = np.frombuffer(raw, ">i4", nel, off).astype(np.int32)
@@ -281,6 +282,13 @@ def parse_sensit(path):
 
 def read_col(path, col, skip=1):
     return np.loadtxt(path, skiprows=skip, usecols=[col], ndmin=1).astype(np.float64)
+
+
+def read_tokens(path, ncol):
+    """List-directed output wraps long records: read every number after the count line and reshape."""
+    t = open(path).read().split()
+    n = int(t[0])
+    return np.array([float(v) for v in t[1:1 + n * ncol]], np.float64).reshape(n, ncol)
 
 
 def run_parfile(tmp, name, parfile_text, nproc, workdir_links=()):
@@ -498,6 +506,129 @@ def make_mag_e2e(tmp):
     res["lsqr_r"] = np.array([float(m.group(1)) for m in re.finditer(r"Finished lsqr solver, r =\s*([0-9.eE+-]+)", log)])
     np.savez_compressed(os.path.join(HERE, "e2e_mag.npz"), **res)
     print("e2e_mag.npz: nnz", res["nnz_total"], "err", res["comp_error"])
+
+
+PAR_COMP = """global.outputFolderPath     = out/
+global.description          = golden synthetic multi-component
+modelGrid.size                      = {nx} {ny} {nz}
+modelGrid.{pn}.file                 = grid.txt
+{extra}
+forward.data.{pn}.nData             = {nd}
+forward.data.{pn}.dataGridFile      = data_grid.txt
+forward.data.{pn}.nDataComponents   = {ncd}
+forward.data.{pn}.useSyntheticModelForDataValues = 1
+forward.data.{pn}.syntheticModelFile = model_true.txt
+forward.magneticField.inclination          = -62.d0
+forward.magneticField.declination          = 11.d0
+forward.magneticField.intensity_nT         = 57000.d0
+forward.magneticField.XaxisDeclination     = 20.d0
+forward.depthWeighting.type         = {dwtype}
+forward.depthWeighting.{pn}.power   = {power}
+sensit.readFromFiles                = 0
+sensit.folderPath                   = out/SENSIT/
+forward.matrixCompression.type      = {ctype}
+forward.matrixCompression.rate      = {rate}
+inversion.priorModel.type           = 1
+inversion.priorModel.{pn}.value     = 0.d0
+inversion.startingModel.type        = 1
+inversion.startingModel.{pn}.value  = 0.d0
+inversion.nMajorIterations          = {nmajor}
+inversion.nMinorIterations          = {nminor}
+inversion.writeModelEveryNiter      = 0
+inversion.minResidual               = 1.d-13
+inversion.modelDamping.{pn}.weight  = {alpha}
+inversion.modelDamping.normPower    = 2.0d0
+inversion.joint.grav.problemWeight  = {pwg}
+inversion.joint.magn.problemWeight  = {pwm}
+inversion.admm.enableADMM           = 0
+"""
+
+
+def make_comp_e2e(tmp):
+    """Full inversions with several data and / or model components: gravity gradiometry (Gzz, full tensor),
+    three-component magnetic data, magnetisation-vector model."""
+    cfgs = {
+        # name: problem, ncm, ncd
+        "e2e_gzz": dict(prob=1, ncm=1, ncd=1, gtype=2, nx=8, ny=6, nz=5, ox=3, oy=3, ctype=0, rate="1.d0", nmajor=2, nminor=6,
+                        alpha="1.d-9", dwtype=1, power="2.0d0"),
+        "e2e_ftg": dict(prob=1, ncm=1, ncd=6, gtype=2, nx=13, ny=7, nz=9, ox=4, oy=3, ctype=2, rate="0.2d0", nmajor=2, nminor=30,
+                        alpha="1.d-9", dwtype=1, power="2.0d0"),
+        "e2e_mag13": dict(prob=2, ncm=1, ncd=3, nx=10, ny=9, nz=6, ox=4, oy=3, ctype=1, rate="0.2d0", nmajor=2, nminor=20,
+                          alpha="1.d-9", dwtype=1, power="3.0d0"),
+        "e2e_mag31": dict(prob=2, ncm=3, ncd=1, nx=12, ny=10, nz=6, ox=5, oy=4, ctype=1, rate="0.25d0", nmajor=2, nminor=25,
+                          alpha="1.d-9", dwtype=2, power="3.0d0"),
+        "e2e_mag33": dict(prob=2, ncm=3, ncd=3, nx=9, ny=8, nz=5, ox=3, oy=3, ctype=2, rate="0.3d0", nmajor=2, nminor=20,
+                          alpha="1.d-9", dwtype=1, power="3.0d0"),
+    }
+    only = os.environ.get("GOLDEN_E2E_ONLY")
+    if only:
+        cfgs = {k: v for k, v in cfgs.items() if k in only.split(",")}
+    for name, c in cfgs.items():
+        g, obs, mtrue = synthetic_problem(c["nx"], c["ny"], c["nz"], c["ox"], c["oy"])
+        nd = obs.shape[0]
+        pn = "grav" if c["prob"] == 1 else "magn"
+        sfx = "grav" if c["prob"] == 1 else "mag"
+        if c["prob"] == 2:
+            if c["ncm"] == 3:          # magnetisation vector, A/m
+                mt = np.stack([mtrue / 300.0 * 0.3, mtrue / 300.0 * (-0.2), mtrue / 300.0 * 0.9], 1)
+            else:
+                mt = (mtrue * 1e-4)[:, None]
+            extra = "modelGrid.magn.nModelComponents     = %d" % c["ncm"]
+        else:
+            mt = mtrue[:, None]
+            extra = "forward.data.grav.type              = %d" % c["gtype"]
+        par = PAR_COMP.format(nd=nd, pn=pn, extra=extra, pwg="1.d0" if c["prob"] == 1 else "0.d0",
+                              pwm="1.d0" if c["prob"] == 2 else "0.d0", **c)
+        res = {}
+        for nproc in (1, 2):
+            wd = os.path.join(tmp, name + "_np%d" % nproc)
+            shutil.rmtree(wd, ignore_errors=True)
+            os.makedirs(wd)
+            write_grid_file(os.path.join(wd, "grid.txt"), g, c["nx"], c["ny"], c["nz"])
+            with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+                f.write("%d\n" % nd)
+                for r in obs:
+                    f.write("%.17g %.17g %.17g" % tuple(r) + " 0.0" * c["ncd"] + "\n")
+            with open(os.path.join(wd, "model_true.txt"), "w") as f:
+                f.write("%d\n" % mt.shape[0])
+                for v in mt:
+                    f.write(" ".join("%.17g" % x for x in v) + "\n")
+            pf = os.path.join(wd, "Parfile.txt")
+            open(pf, "w").write(par)
+            log = run([MPIEXEC, "-n", str(nproc), os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+            sd = os.path.join(wd, "out", "SENSIT")
+            tag = "grav" if c["prob"] == 1 else "magn"
+            o = {}
+            if nproc == 1:
+                hdr, rows = parse_sensit(os.path.join(sd, "sensit_%s_1_0" % tag), nsub=c["ncm"] * c["ncd"])
+                o["row_ptr"] = np.concatenate([[0], np.cumsum([r[1].size for r in rows])]).astype(np.int64)   # per (i, d, k) line
+                o["cols"] = np.concatenate([r[1] for r in rows])
+                o["vals"] = np.concatenate([r[2] for r in rows])
+                o["column_weight"] = np.frombuffer(open(os.path.join(sd, "sensit_%s_weight" % tag), "rb").read(), ">f8", offset=4).astype(np.float64)
+                o["sensit_nnz"] = np.frombuffer(open(os.path.join(sd, "sensit_%s_nnz" % tag), "rb").read(), ">i4", offset=4).astype(np.int32)
+                meta = open(os.path.join(sd, "sensit_%s_meta.txt" % tag)).read().split()
+                o["comp_error"] = float(meta[8])
+                o["nnz_total"] = int(meta[11])
+                dd = os.path.join(wd, "out", "data")
+                cols = list(range(3, 3 + c["ncd"]))
+                o["data_observed"] = read_tokens(os.path.join(dd, "%s_observed.txt" % sfx), 3 + c["ncd"])[:, cols]
+                o["data_final"] = read_tokens(os.path.join(dd, "%s_final.txt" % sfx), 3 + c["ncd"])[:, cols]
+                o["lsqr_r"] = np.array([float(m.group(1)) for m in re.finditer(r"Finished lsqr solver, r =\s*([0-9.eE+-]+)", log)])
+            m = re.search(r"nelements_at_cpu =\s*([0-9 ]+)", log)
+            o["nelements_at_cpu"] = np.array([int(v) for v in m.group(1).split()], np.int64)
+            m = re.search(r"nnz_at_cpu =\s*([0-9 ]+)", log)
+            o["nnz_at_cpu"] = np.array([int(v) for v in m.group(1).split()], np.int64)
+            o["model_final"] = read_tokens(os.path.join(wd, "out", "model", "%s_final_model_full.txt" % sfx), c["ncm"])
+            for kk, vv in o.items():
+                res["np%d_%s" % (nproc, kk)] = vv
+        res.update(dict(prob=c["prob"], ncm=c["ncm"], ncd=c["ncd"], gtype=c.get("gtype", 1), dwtype=c["dwtype"],
+                        power=float(c["power"].replace("d", "e")), nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"],
+                        rate=float(c["rate"].replace("d", "e")), nmajor=c["nmajor"], nminor=c["nminor"],
+                        alpha=float(c["alpha"].replace("d", "e")), field=np.array([-62.0, 11.0, 20.0, 57000.0]),
+                        X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs, model_true=mt, parfile=par))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+        print(name + ".npz: nnz", res["np1_nnz_total"], "err", res["np1_comp_error"], "partition np2", res["np2_nelements_at_cpu"],
+              "lsqr r", res["np1_lsqr_r"])
 
 
 def make_mansf(tmp):

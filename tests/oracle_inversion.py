@@ -24,18 +24,51 @@ def admm_iterate(z, u, x, bounds):
     return z - u
 
 
+def wavelet_comp(v, dims, ctype, ncm, inverse=False):
+    """Per-component 3-D transform of a component-major vector [k*N + cell] (wavelet_utils.F90:37-72 loops k)."""
+    N = int(np.prod(dims))
+    return np.concatenate([orc.wavelet(v[k * N:(k + 1) * N], dims[0], dims[1], dims[2], ctype, inverse=inverse)
+                           for k in range(ncm)])
+
+
+def calc_data_comp(model, cw, dims, ctype, S, pw, dw, ncm):
+    """model_calculate_data (model.F90:220-307) for ncm model components; data index = idata*ncd + d."""
+    scaled = np.where(cw != 0.0, model / cw, 0.0)
+    if ctype > 0:
+        scaled = wavelet_comp(scaled, dims, ctype, ncm)
+    return orc.spmv(S[0], S[1], S[2], scaled) / pw / dw
+
+
 def run_inversion(S, cw, dims, ctype, d_obs, nmajor, nminor, alpha=0.0, rmin=1e-13, pw=1.0, m0=None, m_prior=None,
-                  admm=None, lsqr=None, calc_data=None):
+                  admm=None, lsqr=None, calc_data=None, ncm=1):
     """S = (rowptr, cols, vals) CSR.  admm = dict(bounds=..., rho=...) or None.
     lsqr / calc_data: replaceable callables (default: oracle) so that tests can run the SAME loop on the HIP path.
+    ncm > 1: model vectors are component-major [k*N + cell] (the reference's model%val(:, k) flattened), the data vector is
+    [idata*ncd + d]; the damping block repeats per component (joint_inverse_problem.F90:456-463).
     Returns final model, calculated data and per-iteration records."""
-    N = int(np.prod(dims))
+    N1 = int(np.prod(dims))
+    if ncm > 1:
+        cw = np.tile(np.asarray(cw, np.float64), ncm)
+        assert admm is None
+        dims_w = dims
+        class _W:                                   # per-component transforms behind the single-component call sites
+            @staticmethod
+            def wavelet(v, n1, n2, n3, t, inverse=False):
+                return wavelet_comp(v, dims_w, t, ncm, inverse)
+        worc = _W
+    else:
+        worc = orc
+    N = N1 * ncm
     nd = d_obs.size
     dw = np.ones(nd)
     m = np.zeros(N) if m0 is None else np.array(m0, np.float64)
     mp = np.zeros(N) if m_prior is None else np.asarray(m_prior, np.float64)
     lsqr = lsqr or (lambda blocks, b, niter: orc.lsqr(S, _blocks_csr(blocks, N), N, b, niter, rmin)[:3])
-    calc_data = calc_data or (lambda model: orc.calc_data(model, cw, dims, ctype, S, pw, dw))
+    if calc_data is None:
+        if ncm > 1:
+            calc_data = lambda model: calc_data_comp(model, cw, dims, ctype, S, pw, dw, ncm)
+        else:
+            calc_data = lambda model: orc.calc_data(model, cw, dims, ctype, S, pw, dw)
     d_calc = calc_data(m)
     z, u = np.zeros(N), np.zeros(N)
     hist = []
@@ -46,18 +79,18 @@ def run_inversion(S, cw, dims, ctype, d_obs, nmajor, nminor, alpha=0.0, rmin=1e-
         if alpha != 0.0:                                                  # damping.F90:97-234
             md = (m - mp) / cw
             if ctype > 0:
-                md = orc.wavelet(md, dims[0], dims[1], dims[2], ctype)
+                md = worc.wavelet(md, dims[0], dims[1], dims[2], ctype)
             blocks.append(np.full(N, np.float32(alpha * pw), np.float32))
             rhs.append(-alpha * pw * md)
         if admm is not None:                                              # joint_inverse_problem.F90:497-527
             x0 = admm_iterate(z, u, m, admm["bounds"])
             md = (m - x0) / cw
             if ctype > 0:
-                md = orc.wavelet(md, dims[0], dims[1], dims[2], ctype)
+                md = worc.wavelet(md, dims[0], dims[1], dims[2], ctype)
             blocks.append(np.full(N, np.float32(admm["rho"] * pw), np.float32))
             rhs.append(-admm["rho"] * pw * md)
         x, iters, r = lsqr(blocks, np.concatenate(rhs), nminor)
-        dm = orc.wavelet(x, dims[0], dims[1], dims[2], ctype, inverse=True) if ctype > 0 else x.copy()
+        dm = worc.wavelet(x, dims[0], dims[1], dims[2], ctype, inverse=True) if ctype > 0 else x.copy()
         dm = dm * cw                                                      # joint_inverse_problem.F90:570
         m = m + dm
         d_calc = calc_data(m)
