@@ -79,6 +79,15 @@ int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const doubl
  * inside a cell take the reference's 6-sub-box split (:139-226).                                             */
 int tfx_prism_rows_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double incl,
                        double decl, double azim, double intensity, double *rows_out);
+/* Any row generator of the build loop (src/forward/gravmag/sensitivity_gravmag.F90:193-220):
+ *   problem_type 1, data_type 1, 1 component     graviprism_z       gravity_field.f90:131-195
+ *   problem_type 1, data_type 2, 1 component     gradiprism_zz      gravity_field.f90:315-362
+ *   problem_type 1, data_type 2, 6 components    gradiprism_full    gravity_field.f90:207-310   (XX, YY, ZZ, XY, YZ, ZX)
+ *   problem_type 2, nmodel_components 1|3 (susceptibility | magnetisation vector), ndata_components 1|3 (TMI | Bx, By, Bz)
+ *                                                magprism           magnetic_field.f90:118-297, mag_field = incl, decl, azim, nT
+ * rows_out[ndata][ndata_components][nmodel_components][N] = sensit_line(:, k, d) of every observation.            */
+int tfx_prism_rows(tfx_ctx *ctx, int problem_type, int data_type, int ndata_components, int nmodel_components, int64_t ndata,
+                   const double *xd, const double *yd, const double *zd, const double *mag_field, double *rows_out);
 /* forward_wavelet / inverse_wavelet (src/utils/wavelet_transform.F90:37-70), in place on nvec arrays of
  * n1*n2*n3 doubles stored back to back.  type 1 Haar, 2 D4; direction 1 forward, 2 inverse.                 */
 int tfx_wavelet(tfx_ctx *ctx, double *s, int n1, int n2, int n3, int64_t nvec, int type, int direction);
@@ -107,6 +116,17 @@ int tfx_build_kernel_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const do
                          int compression_type, double rate, double problem_weight, const double *data_weight,
                          int64_t col_begin, int64_t col_end, int64_t *nnz_out, double *error_sum_out,
                          int32_t *nnz_hist_out);
+
+/* General form: any data type / component counts the reference's build loop handles (:193-311).  The matrix has
+ * ndata*ndata_components rows (row = idata*ndata_components + d, like read_sensitivity_kernel's new_row per (i, d), :855)
+ * and nmodel_components*(col_end - col_begin) columns: model component k occupies columns
+ * k*(col_end - col_begin) + (cell - col_begin) (:829-846).  Every (i, d, k) line is weighted, transformed and thresholded
+ * on its own (:222-295).  data_weight[ndata*ndata_components], d fastest = data_weight(d, i); nnz_hist_out over the N cells
+ * counts every line (:267).  mag_field = incl, decl, azim, intensity_nT (problem_type 2) or NULL.                    */
+int tfx_build_kernel(tfx_ctx *ctx, int problem_type, int data_type, int ndata_components, int nmodel_components, int64_t ndata,
+                     const double *xd, const double *yd, const double *zd, const double *column_weight, const double *mag_field,
+                     int compression_type, double rate, double problem_weight, const double *data_weight, int64_t col_begin,
+                     int64_t col_end, int64_t *nnz_out, double *error_sum_out, int32_t *nnz_hist_out);
 
 /* Alternative to building: upload a CSR (what read_sensitivity_kernel assembles from SENSIT files;
  * t_sparse_matrix add_row/new_row/finalize, src/inversion/sparse_matrix.f90:213-293).  rowptr: nrows+1
@@ -140,6 +160,11 @@ int tfx_rowstore_build(tfx_ctx *ctx, int problem_type, int64_t ndata, const doub
                        const double *column_weight, const double *mag_field, int compression_type, double rate,
                        double problem_weight, const double *data_weight, int64_t *nnz_out, double *error_sum_out,
                        int32_t *nnz_hist_out);
+/* ... with a data type / several data components (one model component); local row = idata_local*ndata_components + d. */
+int tfx_rowstore_build_ex(tfx_ctx *ctx, int problem_type, int data_type, int ndata_components, int64_t ndata, const double *xd,
+                          const double *yd, const double *zd, const double *column_weight, const double *mag_field,
+                          int compression_type, double rate, double problem_weight, const double *data_weight, int64_t *nnz_out,
+                          double *error_sum_out, int32_t *nnz_hist_out);
 int tfx_rowstore_counts(tfx_ctx *ctx, int nparts, const int64_t *bounds, int32_t *counts_out);
 int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t col_begin, int64_t col_end,
                       int32_t *cols_dev_out, float *vals_dev_out, int64_t capacity, int64_t *n_out);

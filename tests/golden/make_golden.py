@@ -549,15 +549,15 @@ def make_comp_e2e(tmp):
     three-component magnetic data, magnetisation-vector model."""
     cfgs = {
         # name: problem, ncm, ncd
-        "e2e_gzz": dict(prob=1, ncm=1, ncd=1, gtype=2, nx=8, ny=6, nz=5, ox=3, oy=3, ctype=0, rate="1.d0", nmajor=2, nminor=6,
+        "e2e_gzz": dict(prob=1, ncm=1, ncd=1, gtype=2, nx=8, ny=6, nz=5, ox=3, oy=3, ctype=0, rate="1.d0", nmajor=2, nminor=25,
                         alpha="1.d-9", dwtype=1, power="2.0d0"),
-        "e2e_ftg": dict(prob=1, ncm=1, ncd=6, gtype=2, nx=13, ny=7, nz=9, ox=4, oy=3, ctype=2, rate="0.2d0", nmajor=2, nminor=30,
+        "e2e_ftg": dict(prob=1, ncm=1, ncd=6, gtype=2, nx=13, ny=7, nz=9, ox=4, oy=3, ctype=2, rate="0.2d0", nmajor=2, nminor=150,
                         alpha="1.d-9", dwtype=1, power="2.0d0"),
-        "e2e_mag13": dict(prob=2, ncm=1, ncd=3, nx=10, ny=9, nz=6, ox=4, oy=3, ctype=1, rate="0.2d0", nmajor=2, nminor=20,
+        "e2e_mag13": dict(prob=2, ncm=1, ncd=3, nx=10, ny=9, nz=6, ox=4, oy=3, ctype=1, rate="0.2d0", nmajor=1, nminor=80,
                           alpha="1.d-9", dwtype=1, power="3.0d0"),
         "e2e_mag31": dict(prob=2, ncm=3, ncd=1, nx=12, ny=10, nz=6, ox=5, oy=4, ctype=1, rate="0.25d0", nmajor=2, nminor=25,
                           alpha="1.d-9", dwtype=2, power="3.0d0"),
-        "e2e_mag33": dict(prob=2, ncm=3, ncd=3, nx=9, ny=8, nz=5, ox=3, oy=3, ctype=2, rate="0.3d0", nmajor=2, nminor=20,
+        "e2e_mag33": dict(prob=2, ncm=3, ncd=3, nx=9, ny=8, nz=5, ox=3, oy=3, ctype=2, rate="0.3d0", nmajor=2, nminor=60,
                           alpha="1.d-9", dwtype=1, power="3.0d0"),
     }
     only = os.environ.get("GOLDEN_E2E_ONLY")

@@ -204,18 +204,23 @@ __device__ __forceinline__ void sharmbox_dev(double x0, double y0, double z0, do
     tz[0] = tx[2];
 }
 
-__global__ __launch_bounds__(256) void k_magprism_tmi(int64_t N, const double *__restrict__ X1, const double *__restrict__ X2,
-                                                      const double *__restrict__ Y1, const double *__restrict__ Y2,
-                                                      const double *__restrict__ Z1, const double *__restrict__ Z2,
-                                                      int nobs, const double *__restrict__ xd, const double *__restrict__ yd,
-                                                      const double *__restrict__ zd, const double *__restrict__ cw,
-                                                      MagField mf, double *__restrict__ rows, int *__restrict__ err,
-                                                      double *__restrict__ sumsq)
+// NCM model components (1 susceptibility | 3 magnetisation vector), NCD data components (1 TMI | 3): sub-row
+// (o*NCD + d)*NCM + k of the output holds sensit_line(:, k, d) of observation o (magnetic_field.f90:243-295).
+template <int NCM, int NCD>
+__global__ __launch_bounds__(256) void k_magprism(int64_t N, const double *__restrict__ X1, const double *__restrict__ X2,
+                                                  const double *__restrict__ Y1, const double *__restrict__ Y2,
+                                                  const double *__restrict__ Z1, const double *__restrict__ Z2,
+                                                  int nobs, const double *__restrict__ xd, const double *__restrict__ yd,
+                                                  const double *__restrict__ zd, const double *__restrict__ cw,
+                                                  MagField mf, double *__restrict__ rows, int *__restrict__ err,
+                                                  double *__restrict__ sumsq)
 {
+    constexpr int NSUB = NCM * NCD;
     const double PI = 3.14159265358979323846;
+    const double mu0 = 4.0 * PI * 1.e-7, T2nT = 1.e+9;                                                     // :31-34
     __shared__ double s_sq[PRISM_MAX_BATCH];
     if (sumsq) {
-        for (int o = threadIdx.x; o < nobs; o += blockDim.x) s_sq[o] = 0.0;
+        for (int o = threadIdx.x; o < nobs * NSUB; o += blockDim.x) s_sq[o] = 0.0;
         __syncthreads();
     }
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < N; p0 += (int64_t)gridDim.x * blockDim.x) {
@@ -249,28 +254,143 @@ __global__ __launch_bounds__(256) void k_magprism_tmi(int64_t N, const double *_
             } else {
                 sharmbox_dev(xo, yo, zo, x1, y1, z1, x2, y2, z2, tx, ty, tz, bad);                         // :230-240
             }
-            const double mx = (tx[0] * mf.magv[0] + tx[1] * mf.magv[1]) + tx[2] * mf.magv[2];              // :246-248
-            const double my = (ty[0] * mf.magv[0] + ty[1] * mf.magv[1]) + ty[2] * mf.magv[2];
-            const double mz = (tz[0] * mf.magv[0] + tz[1] * mf.magv[1]) + tz[2] * mf.magv[2];
-            double v = mx * mf.magv[0] + my * mf.magv[1] + mz * mf.magv[2];                                // :251
-            v = mf.intensity * v;                                                                          // :287
-            v = v / (4.0 * PI);                                                                            // :295
-            if (cw) v = v * w;
-            if (bad && active) atomicOr(err, bad);
-            if (active) rows[(int64_t)o * N + p] = v;
-            if (sumsq) {
-                double sq = active ? v * v : 0.0;
+            double out[NCD][NCM];
+            if (NCM == 1) {
+                const double mx = (tx[0] * mf.magv[0] + tx[1] * mf.magv[1]) + tx[2] * mf.magv[2];          // :246-248
+                const double my = (ty[0] * mf.magv[0] + ty[1] * mf.magv[1]) + ty[2] * mf.magv[2];
+                const double mz = (tz[0] * mf.magv[0] + tz[1] * mf.magv[1]) + tz[2] * mf.magv[2];
+                if (NCD == 1) out[0][0] = mx * mf.magv[0] + my * mf.magv[1] + mz * mf.magv[2];             // :251
+                else { out[0][0] = mx; out[NCD > 1 ? 1 : 0][0] = my; out[NCD > 2 ? 2 : 0][0] = mz; }       // :254-256
+            } else {
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) sq += __shfl_down(sq, d);
-                if ((threadIdx.x & 63) == 0) atomicAdd(&s_sq[o], sq);
+                for (int k = 0; k < NCM; ++k) {
+                    if (NCD == 1) out[0][k] = tx[k] * mf.magv[0] + ty[k] * mf.magv[1] + tz[k] * mf.magv[2];    // :268
+                    else { out[0][k] = tx[k]; out[NCD > 1 ? 1 : 0][k] = ty[k]; out[NCD > 2 ? 2 : 0][k] = tz[k]; }   // :273-275
+                }
+            }
+            if (bad && active) atomicOr(err, bad);
+#pragma unroll
+            for (int d = 0; d < NCD; ++d)
+#pragma unroll
+                for (int k = 0; k < NCM; ++k) {
+                    double v = out[d][k];
+                    v = (NCM == 1) ? mf.intensity * v : (mu0 * T2nT) * v;                                  // :286-291
+                    v = v / (4.0 * PI);                                                                    // :295
+                    if (cw) v = v * w;
+                    const int sub = (o * NCD + d) * NCM + k;
+                    if (active) rows[(int64_t)sub * N + p] = v;
+                    if (sumsq) {
+                        double sq = active ? v * v : 0.0;
+#pragma unroll
+                        for (int dd = 32; dd > 0; dd >>= 1) sq += __shfl_down(sq, dd);
+                        if ((threadIdx.x & 63) == 0) atomicAdd(&s_sq[sub], sq);
+                    }
+                }
+        }
+    }
+    if (sumsq) {
+        __syncthreads();
+        for (int o = threadIdx.x; o < nobs * NSUB; o += blockDim.x) sumsq[(int64_t)o * gridDim.x + blockIdx.x] = s_sq[o];
+    }
+}
+
+// =============================================================================================================
+// gravity gradiometry rows: gradiprism_zz / gradiprism_full (src/forward/gravmag/grav/gravity_field.f90:315-362, :207-310)
+// FULL: six sub-rows per observation in the order the build stores them (sensitivity_gravmag.F90:210-212):
+// XX, YY, ZZ, XY, YZ, ZX.  bad |= 16 zero denominator (:275-277), 32 bad log argument (:282-284).
+// =============================================================================================================
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_gradiprism(int64_t N, const double *__restrict__ X1, const double *__restrict__ X2,
+                                                    const double *__restrict__ Y1, const double *__restrict__ Y2,
+                                                    const double *__restrict__ Z1, const double *__restrict__ Z2,
+                                                    int nobs, const double *__restrict__ xd, const double *__restrict__ yd,
+                                                    const double *__restrict__ zd, const double *__restrict__ cw,
+                                                    double *__restrict__ rows, int *__restrict__ err,
+                                                    double *__restrict__ sumsq)
+{
+    constexpr int NC = FULL ? 6 : 1;
+    const double twopi = 2.0 * 3.14159265358979323846;
+    __shared__ double s_sq[PRISM_MAX_BATCH];
+    if (sumsq) {
+        for (int o = threadIdx.x; o < nobs * NC; o += blockDim.x) s_sq[o] = 0.0;
+        __syncthreads();
+    }
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < N; p0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = p0 + threadIdx.x;
+        const bool active = p < N;
+        const int64_t pc = active ? p : N - 1;
+        const double x1 = X1[pc], x2 = X2[pc], y1 = Y1[pc], y2 = Y2[pc], z1 = Z1[pc], z2 = Z2[pc];
+        const double w = cw ? cw[pc] : 1.0;
+        for (int o = 0; o < nobs; ++o) {
+            double XX[2], YY[2], ZZ[2];
+            XX[0] = xd[o] - x1; XX[1] = xd[o] - x2;                                                        // :232-237
+            YY[0] = yd[o] - y1; YY[1] = yd[o] - y2;
+            ZZ[0] = -(zd[o] - z1); ZZ[1] = -(zd[o] - z2);
+            double gxx = 0.0, gyy = 0.0, gzz = 0.0, gxy = 0.0, gyz = 0.0, gzx = 0.0;
+            int bad = 0;
+#pragma unroll
+            for (int K = 0; K < 2; ++K)
+#pragma unroll
+                for (int L = 0; L < 2; ++L)
+#pragma unroll
+                    for (int M = 0; M < 2; ++M) {
+                        const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;
+                        const double Rs = sqrt(XX[K] * XX[K] + YY[L] * YY[L] + ZZ[M] * ZZ[M]);            // :251
+                        double vzz = -atan2(XX[K] * YY[L], Rs * ZZ[M]);                                    // :255
+                        if (vzz < 0) vzz = vzz + twopi;
+                        gzz = gzz + dmu * vzz;
+                        if (FULL) {
+                            double vxx = atan2(XX[K] * YY[L], XX[K] * XX[K] + Rs * ZZ[M] + ZZ[M] * ZZ[M]);   // :253
+                            double vyy = atan2(XX[K] * YY[L], Rs * Rs + Rs * ZZ[M] - XX[K] * XX[K]);         // :254
+                            if (vxx < 0) vxx = vxx + twopi;
+                            if (vyy < 0) vyy = vyy + twopi;
+                            const double arg1 = Rs + ZZ[M];
+                            const double arg21 = Rs - YY[L], arg22 = Rs + YY[L];
+                            const double arg31 = Rs - XX[K], arg32 = Rs + XX[K];
+                            if (arg22 == 0. || arg32 == 0.) bad |= 16;
+                            const double arg2 = arg21 / arg22, arg3 = arg31 / arg32;
+                            if (arg1 <= 0. || arg2 <= 0. || arg3 <= 0.) bad |= 32;
+                            const double vxy = log(arg1);
+                            const double vzx = 0.5 * log(arg2);
+                            const double vyz = 0.5 * log(arg3);
+                            gxx = gxx + dmu * vxx;
+                            gyy = gyy + dmu * vyy;
+                            gxy = gxy + dmu * vxy;
+                            gyz = gyz + dmu * vyz;
+                            gzx = gzx + dmu * vzx;
+                        }
+                    }
+            if (bad && active) atomicOr(err, bad);
+            const double g6[6] = {gxx, gyy, gzz, gxy, gyz, gzx};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double v = g_grav() * (FULL ? g6[c] : gzz);                                                // :301-306, :358
+                if (cw) v = v * w;
+                const int sub = o * NC + c;
+                if (active) rows[(int64_t)sub * N + p] = v;
+                if (sumsq) {
+                    double sq = active ? v * v : 0.0;
+#pragma unroll
+                    for (int dd = 32; dd > 0; dd >>= 1) sq += __shfl_down(sq, dd);
+                    if ((threadIdx.x & 63) == 0) atomicAdd(&s_sq[sub], sq);
+                }
             }
         }
     }
     if (sumsq) {
         __syncthreads();
-        for (int o = threadIdx.x; o < nobs; o += blockDim.x) sumsq[(int64_t)o * gridDim.x + blockIdx.x] = s_sq[o];
+        for (int o = threadIdx.x; o < nobs * NC; o += blockDim.x) sumsq[(int64_t)o * gridDim.x + blockIdx.x] = s_sq[o];
     }
 }
+
+// What produces the lines of one observation (sensitivity_gravmag.F90:193-220): nsub = ncd*ncm lines in (d, k) order.
+enum { GEN_GZ = 0, GEN_GZZ = 1, GEN_FTG = 2, GEN_MAG = 3 };
+struct RowGen {
+    int kind = GEN_GZ;
+    int ncd = 1, ncm = 1;
+    MagField mf{};
+    int nsub() const { return ncd * ncm; }
+};
 
 // dircos, magnetic_field.f90:91-110 (host)
 static MagField make_mag_field(double incl, double decl, double azim, double intensity)
@@ -344,42 +464,47 @@ int detect_tensor_grid(tfx_ctx *ctx)
     return 0;
 }
 
-// rows[o*N + p] for a batch of observations already on the device; picks the tensor-grid kernel when it applies
-// d_sumsq (optional): [nobs][*nblk] partial sums of squares per observation row; *nblk returns the partials per row
-int prism_rows_dev(tfx_ctx *ctx, int nobs, const double *d_x, const double *d_y, const double *d_z, const double *d_cw,
-                   double *d_rows, int *d_err, double *d_sumsq = nullptr, int *nblk = nullptr, const MagField *mag = nullptr)
+// Lines of a batch of observations already on the device: d_rows[(o*nsub + sub)*N + p]; picks the tensor-grid kernel
+// when it applies.  d_sumsq (optional): [nobs*nsub][*nblk] partial sums of squares per line.
+int prism_rows_dev(tfx_ctx *ctx, const RowGen &gen, int nobs, const double *d_x, const double *d_y, const double *d_z,
+                   const double *d_cw, double *d_rows, int *d_err, double *d_sumsq = nullptr, int *nblk = nullptr)
 {
-    if (nobs > PRISM_MAX_BATCH) return fail(TFX_E_ARG, "prism batch %d > %d", nobs, PRISM_MAX_BATCH);
-    if (mag) {
-        hipStream_t s = ctx->stream;
-        const int grid = (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->num_cu * 16);
-        hipLaunchKernelGGL(k_magprism_tmi, dim3(grid), dim3(256), 0, s, ctx->N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
-                           ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nobs, d_x, d_y, d_z, d_cw, *mag, d_rows, d_err, d_sumsq);
-        if (nblk) *nblk = grid;
-        TFX_HIP(hipGetLastError());
-        return 0;
-    }
+    if (nobs * gen.nsub() > PRISM_MAX_BATCH) return fail(TFX_E_ARG, "prism batch %d > %d", nobs * gen.nsub(), PRISM_MAX_BATCH);
     hipStream_t s = ctx->stream;
     const int64_t N = ctx->N;
-    if (ctx->tensor_grid) {
+    const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
+#define GRID_ARGS N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p, ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nobs, d_x, d_y, d_z, d_cw
+    if (gen.kind == GEN_MAG) {
+        if (gen.ncm == 1 && gen.ncd == 1) hipLaunchKernelGGL((k_magprism<1, 1>), dim3(grid), dim3(256), 0, s, GRID_ARGS, gen.mf, d_rows, d_err, d_sumsq);
+        else if (gen.ncm == 1 && gen.ncd == 3) hipLaunchKernelGGL((k_magprism<1, 3>), dim3(grid), dim3(256), 0, s, GRID_ARGS, gen.mf, d_rows, d_err, d_sumsq);
+        else if (gen.ncm == 3 && gen.ncd == 1) hipLaunchKernelGGL((k_magprism<3, 1>), dim3(grid), dim3(256), 0, s, GRID_ARGS, gen.mf, d_rows, d_err, d_sumsq);
+        else if (gen.ncm == 3 && gen.ncd == 3) hipLaunchKernelGGL((k_magprism<3, 3>), dim3(grid), dim3(256), 0, s, GRID_ARGS, gen.mf, d_rows, d_err, d_sumsq);
+        else return fail(TFX_E_ARG, "Wrong number of components in magnetic_field_magprism!");            // magnetic_field.f90:258-282
+        if (nblk) *nblk = grid;
+    } else if (gen.kind == GEN_GZZ) {
+        hipLaunchKernelGGL((k_gradiprism<false>), dim3(grid), dim3(256), 0, s, GRID_ARGS, d_rows, d_err, d_sumsq);
+        if (nblk) *nblk = grid;
+    } else if (gen.kind == GEN_FTG) {
+        hipLaunchKernelGGL((k_gradiprism<true>), dim3(grid), dim3(256), 0, s, GRID_ARGS, d_rows, d_err, d_sumsq);
+        if (nblk) *nblk = grid;
+    } else if (ctx->tensor_grid) {
         const int tiles = ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
         hipLaunchKernelGGL(k_prism_gz_tensor, dim3(tiles), dim3(256), 0, s, ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p,
                            ctx->edges[1].p, ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err, d_sumsq);
         if (nblk) *nblk = tiles;
     } else {
-        const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
-        hipLaunchKernelGGL(k_prism_gz, dim3(grid), dim3(256), 0, s, N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p,
-                           ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err, d_sumsq);
+        hipLaunchKernelGGL(k_prism_gz, dim3(grid), dim3(256), 0, s, GRID_ARGS, d_rows, d_err, d_sumsq);
         if (nblk) *nblk = grid;
     }
+#undef GRID_ARGS
     TFX_HIP(hipGetLastError());
     return 0;
 }
 
-// number of sum-of-squares partials per row that prism_rows_dev will write
-int prism_partials(tfx_ctx *ctx, bool mag)
+// number of sum-of-squares partials per line that prism_rows_dev will write
+int prism_partials(tfx_ctx *ctx, const RowGen &gen)
 {
-    if (ctx->tensor_grid && !mag) return ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
+    if (ctx->tensor_grid && gen.kind == GEN_GZ) return ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
     return (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->num_cu * 16);
 }
 
@@ -931,7 +1056,9 @@ struct CompactArgs {
     int32_t *out_cols;        // [.. ][stride]
     float *out_vals;
     int64_t out_stride;
-    int32_t *nel;             // [nrows] kept in range
+    int32_t *nel;             // [nrows] kept in range, per line
+    int ncm;                  // lines per matrix row (model components): line r is component r % ncm of output row r / ncm,
+    int64_t comp_stride;      //   appended after the earlier components with columns shifted by k*comp_stride (:829-846)
     int32_t *nel_all;         // [nrows] kept over all columns (the reference's nel)
     double *cost_disc;        // [nrows]
     const float *scale;       // [nrows] (float)(problem_weight*data_weight)   (:841)
@@ -1043,18 +1170,31 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_write(CompactArgs a)
         for (int i = 0; i < CMP_PER_THREAD * NW; ++i) { const int c = wcnt[i]; wcnt[i] = run; run += c; }
     }
     __syncthreads();
-    const int segoff = a.seg_off[(int64_t)row * a.nseg + seg];
-    int32_t *oc = a.out_cols + (int64_t)row * a.out_stride;
-    float *ov = a.out_vals + (int64_t)row * a.out_stride;
+    int segoff = a.seg_off[(int64_t)row * a.nseg + seg];
+    const int comp = row % a.ncm, mrow = row / a.ncm;
+    for (int kk = 0; kk < comp; ++kk) segoff += a.nel[row - comp + kk];
+    const int64_t cshift = (int64_t)comp * a.comp_stride - a.col_begin;
+    int32_t *oc = a.out_cols + (int64_t)mrow * a.out_stride;
+    float *ov = a.out_vals + (int64_t)mrow * a.out_stride;
 #pragma unroll
     for (int k = 0; k < CMP_PER_THREAD; ++k)
         if (keepmask & (1u << k)) {
             const int pos = segoff + wcnt[k * NW + wave] + lpre[k];
-            oc[pos] = (int32_t)(base + (int64_t)k * CMP_THREADS - a.col_begin);
+            oc[pos] = (int32_t)(base + (int64_t)k * CMP_THREADS + cshift);
             float f = (float)v[k];                           // real(x, MATRIX_PRECISION), :265
             if (a.scale) f = f * sc;                         // :841
             ov[pos] = f;
         }
+}
+
+// entries of the matrix rows = sum over the model-component lines
+__global__ void k_merge_nel(const int32_t *__restrict__ nel_sub, int ncm, int nrows, int32_t *__restrict__ out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    int n = 0;
+    for (int k = 0; k < ncm; ++k) n += nel_sub[r * ncm + k];
+    out[r] = n;
 }
 
 // sum of squares of each row (cost_full, :234); red: [nrows][gridDim.x]
@@ -1074,12 +1214,13 @@ __global__ __launch_bounds__(256) void k_row_sumsq(const double *__restrict__ ro
 }
 
 // dense store of a batch of rows: out[row][c] = (float)rows[row][col_begin + c] * scale[row]   (:289-295, :841)
+// (line = blockIdx.y: component line % ncm of matrix row line / ncm, stored at column offset (line % ncm)*ncols)
 __global__ __launch_bounds__(256) void k_dense_store(const double *__restrict__ rows, int64_t N, int64_t col_begin, int64_t ncols,
-                                                     const float *__restrict__ scale, float *__restrict__ out, int64_t ld)
+                                                     const float *__restrict__ scale, float *__restrict__ out, int64_t ld, int ncm)
 {
     const int row = blockIdx.y;
     const double *r = rows + (int64_t)row * N + col_begin;
-    float *o = out + (int64_t)row * ld;
+    float *o = out + (int64_t)(row / ncm) * ld + (int64_t)(row % ncm) * ncols;
     const float sc = scale[row];
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * blockDim.x) {
         float f = (float)r[c];
@@ -1120,20 +1261,22 @@ static int compact_prepare(CompactWork &cw, int nrows, int64_t N)
     return 0;
 }
 
-// rows [nrows][N] (device) -> out_cols/out_vals rows (stride), nel / nel_all / cost_disc in cw
+// lines [nrows][N] (device) -> out_cols/out_vals matrix rows (stride; ncm consecutive lines form one row),
+// d_nel_out[nrows/ncm] entries per matrix row; per-line nel / nel_all / cost_disc stay in cw
 static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int nrows, int64_t N, int keep_all,
                        int64_t col_begin, int64_t col_end, int32_t *out_cols, float *out_vals, int64_t out_stride,
-                       int32_t *d_nel_out, const float *d_scale, int32_t *d_hist)
+                       int32_t *d_nel_out, const float *d_scale, int32_t *d_hist, int ncm = 1)
 {
     hipStream_t s = ctx->stream;
     CompactArgs a{};
     a.rows = d_rows; a.N = N; a.thr = cw.thr.p; a.keep_all = keep_all; a.col_begin = col_begin; a.col_end = col_end;
     a.nseg = cw.nseg; a.seg_cnt = cw.seg_cnt.p; a.seg_all = cw.seg_all.p; a.seg_off = cw.seg_off.p; a.seg_cost = cw.seg_cost.p;
-    a.out_cols = out_cols; a.out_vals = out_vals; a.out_stride = out_stride; a.nel = d_nel_out; a.nel_all = cw.nel_all.p;
-    a.cost_disc = cw.cost_disc.p; a.scale = d_scale; a.hist = d_hist;
+    a.out_cols = out_cols; a.out_vals = out_vals; a.out_stride = out_stride; a.nel = cw.nel.p; a.nel_all = cw.nel_all.p;
+    a.cost_disc = cw.cost_disc.p; a.scale = d_scale; a.hist = d_hist; a.ncm = ncm; a.comp_stride = col_end - col_begin;
     hipLaunchKernelGGL(k_cmp_count, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_cmp_scan, dim3(nrows), dim3(256), 0, s, a);
     if (out_cols) hipLaunchKernelGGL(k_cmp_write, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+    if (d_nel_out) hipLaunchKernelGGL(k_merge_nel, dim3((nrows / ncm + 63) / 64), dim3(64), 0, s, cw.nel.p, ncm, nrows / ncm, d_nel_out);
     TFX_HIP(hipGetLastError());
     return 0;
 }
@@ -1150,22 +1293,52 @@ static int geometry_error(int herr)
     if (herr & 2) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (XZ). Adjust the model grid!");
     if (herr & 4) return fail(TFX_E_GEOMETRY, "The model grid X-boundary coincides with the data position");
     if (herr & 8) return fail(TFX_E_GEOMETRY, "The model grid Y-boundary coincides with the data position");
+    if (herr & 16) return fail(TFX_E_GEOMETRY, "Zero denominator in gradiprism_full! Adjust the model grid.");      // gravity_field.f90:275-277
+    if (herr & 32) return fail(TFX_E_GEOMETRY, "Bad log argument in gradiprism_full! Adjust the model grid.");      // :282-284
     return 0;
 }
 
-static int prism_rows_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double *rows_out,
-                          const MagField *mag)
+static int make_rowgen(RowGen &gen, int problem_type, int data_type, int ncd, int ncm, const double *mag_field)
+{
+    gen = RowGen{};
+    gen.ncd = ncd;
+    gen.ncm = ncm;
+    if (problem_type == 1) {
+        if (ncm != 1) return fail(TFX_E_ARG, "gravity kernels have one model component");
+        if (data_type == 1) {                                                                   // sensitivity_gravmag.F90:195-198
+            if (ncd != 1) return fail(TFX_E_ARG, "gravity data (type 1) has one data component");
+            gen.kind = GEN_GZ;
+        } else if (data_type == 2) {                                                            // :199-214
+            if (ncd == 1) gen.kind = GEN_GZZ;
+            else if (ncd == 6) gen.kind = GEN_FTG;
+            else return fail(TFX_E_ARG, "Wrong number of gravity gradiometry data components!");
+        } else return fail(TFX_E_ARG, "unknown gravity data type %d", data_type);
+    } else if (problem_type == 2) {
+        if (!mag_field) return fail(TFX_E_ARG, "magnetic field (incl, decl, azim, intensity) missing");
+        if (!((ncm == 1 || ncm == 3) && (ncd == 1 || ncd == 3)))
+            return fail(TFX_E_ARG, "Wrong number of components in magnetic_field_magprism!");   // magnetic_field.f90:258-282
+        gen.kind = GEN_MAG;
+        gen.mf = make_mag_field(mag_field[0], mag_field[1], mag_field[2], mag_field[3]);
+    } else return fail(TFX_E_ARG, "problem_type must be 1 (grav) or 2 (magn)");
+    return 0;
+}
+
+static int prism_rows_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, const double *xd, const double *yd, const double *zd,
+                          double *rows_out)
 {
     if (!ctx || !xd || !yd || !zd || !rows_out) return fail(TFX_E_ARG, "tfx_prism_rows: null argument");
     if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_prism_rows: set the grid first");
     TFX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int64_t N = ctx->N;
-    const int B = (int)std::min<int64_t>(std::min<int64_t>(ndata, PRISM_MAX_BATCH), std::max<int64_t>(1, (int64_t)(1u << 28) / N));   // <= 2 GB of rows per batch
+    const int nsub = gen.nsub();
+    // observations per batch: <= 64 lines per launch, <= 2 GB of lines
+    const int B = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ndata, PRISM_MAX_BATCH / nsub),
+                                                              (int64_t)(1u << 28) / (N * nsub)));
     DBuf<double> dobs, drows;
     DBuf<int> derr;
     TFX_TRY(dobs.alloc((size_t)3 * B));
-    TFX_TRY(drows.alloc((size_t)B * N));
+    TFX_TRY(drows.alloc((size_t)B * nsub * N));
     TFX_TRY(derr.alloc(1));
     TFX_HIP(hipMemsetAsync(derr.p, 0, sizeof(int), s));
     for (int64_t o0 = 0; o0 < ndata; o0 += B) {
@@ -1173,8 +1346,8 @@ static int prism_rows_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
         TFX_HIP(hipMemcpyAsync(dobs.p, xd + o0, nb * sizeof(double), hipMemcpyDefault, s));
         TFX_HIP(hipMemcpyAsync(dobs.p + B, yd + o0, nb * sizeof(double), hipMemcpyDefault, s));
         TFX_HIP(hipMemcpyAsync(dobs.p + 2 * B, zd + o0, nb * sizeof(double), hipMemcpyDefault, s));
-        TFX_TRY(prism_rows_dev(ctx, nb, dobs.p, dobs.p + B, dobs.p + 2 * B, nullptr, drows.p, derr.p, nullptr, nullptr, mag));
-        TFX_HIP(hipMemcpyAsync(rows_out + o0 * N, drows.p, (size_t)nb * N * sizeof(double), hipMemcpyDefault, s));
+        TFX_TRY(prism_rows_dev(ctx, gen, nb, dobs.p, dobs.p + B, dobs.p + 2 * B, nullptr, drows.p, derr.p));
+        TFX_HIP(hipMemcpyAsync(rows_out + o0 * nsub * N, drows.p, (size_t)nb * nsub * N * sizeof(double), hipMemcpyDefault, s));
         TFX_HIP(hipStreamSynchronize(s));
     }
     int herr = 0;
@@ -1184,14 +1357,24 @@ static int prism_rows_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
 
 int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double *rows_out)
 {
-    return prism_rows_any(ctx, ndata, xd, yd, zd, rows_out, nullptr);
+    return prism_rows_any(ctx, RowGen{}, ndata, xd, yd, zd, rows_out);
 }
 
 int tfx_prism_rows_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double incl,
                        double decl, double azim, double intensity, double *rows_out)
 {
-    const MagField mf = make_mag_field(incl, decl, azim, intensity);
-    return prism_rows_any(ctx, ndata, xd, yd, zd, rows_out, &mf);
+    RowGen gen;
+    gen.kind = GEN_MAG;
+    gen.mf = make_mag_field(incl, decl, azim, intensity);
+    return prism_rows_any(ctx, gen, ndata, xd, yd, zd, rows_out);
+}
+
+int tfx_prism_rows(tfx_ctx *ctx, int problem_type, int data_type, int ndata_components, int nmodel_components, int64_t ndata,
+                   const double *xd, const double *yd, const double *zd, const double *mag_field, double *rows_out)
+{
+    RowGen gen;
+    TFX_TRY(make_rowgen(gen, problem_type, data_type, ndata_components, nmodel_components, mag_field));
+    return prism_rows_any(ctx, gen, ndata, xd, yd, zd, rows_out);
 }
 
 int tfx_column_weight_type1(tfx_ctx *ctx, double power, double Z0, double multiplier, double *cw_out)
@@ -1299,7 +1482,7 @@ int tfx_compress_row(tfx_ctx *ctx, const double *row, int64_t N, int64_t K, int3
     CompactWork cw;
     TFX_TRY(compact_prepare(cw, 1, N));
     TFX_TRY(select_threshold_dev(ctx, sw, d.p, 1, N, K, cw.thr.p));
-    TFX_TRY(compact_dev(ctx, cw, d.p, 1, N, 0, 0, N, oc.p, ov.p, stride, cw.nel.p, nullptr, nullptr));
+    TFX_TRY(compact_dev(ctx, cw, d.p, 1, N, 0, 0, N, oc.p, ov.p, stride, nullptr, nullptr, nullptr));
     int32_t nel = 0;
     double thr = 0, cd = 0;
     TFX_HIP(hipMemcpyAsync(&nel, cw.nel.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1317,16 +1500,21 @@ int tfx_compress_row(tfx_ctx *ctx, const double *row, int64_t N, int64_t K, int3
     return 0;
 }
 
-static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
+// General build.  One observation yields nsub = ncd*ncm LINES (d outer, k inner - the record order of the reference's
+// SENSIT files, sensitivity_gravmag.F90:222-311); every line is weighted, transformed, thresholded and compacted on its
+// own.  Matrix row (i*ncd + d) is the concatenation of its ncm lines with columns k*ncols + (cell - col_begin)
+// (read_sensitivity_kernel, :829-852).  data_weight: [ndata*ncd], d fastest (data_weight(d, i)).
+static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, const double *xd, const double *yd, const double *zd,
                             const double *column_weight, int compression_type, double rate, double problem_weight,
                             const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
-                            double *error_sum_out, int32_t *nnz_hist_out, const MagField *mag, RowStore *rs = nullptr)
+                            double *error_sum_out, int32_t *nnz_hist_out, RowStore *rs = nullptr)
 {
     // rs != null: keep the compressed rows (all columns, global 0-based column indices) row-major on the device instead of
     // laying them out as this rank's tiled matrix - the row-parallel half of the multi-GPU build
     const bool to_rs = rs != nullptr;
     if (to_rs) { col_begin = 0; col_end = ctx ? ctx->N : 0; }
     if (to_rs && compression_type == 0) return fail(TFX_E_ARG, "the row store is for compressed kernels (dense kernels are built per column range)");
+    if (to_rs && gen.ncm != 1) return fail(TFX_E_ARG, "the row store holds single-model-component kernels (build magnetisation kernels per column range)");
     if (!ctx || !xd || !yd || !zd || !column_weight) return fail(TFX_E_ARG, "tfx_build_kernel: null argument");
     if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_build_kernel: set the grid first");
     if (compression_type < 0 || compression_type > 2) return fail(TFX_E_ARG, "Unknown wavelet type!");
@@ -1336,10 +1524,14 @@ static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const
     if (ndata <= 0) return fail(TFX_E_ARG, "no data");
     TFX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const int64_t ncols = col_end - col_begin;
+    const int ncd = gen.ncd, ncm = gen.ncm, nsub = gen.nsub();
+    const int64_t ncols = col_end - col_begin;            // cells kept; the matrix has ncm*ncols columns
+    const int64_t nrows_m = ndata * ncd;                  // matrix rows
+    const int64_t nlines = ndata * nsub;
     const bool keep_matrix = ncols > 0 && !to_rs;
     const int64_t K = compression_type > 0 ? (int64_t)(rate * (double)N) : N;      // get_nel_compressed, :64-77
-    const int64_t stride = std::max<int64_t>(1, std::min<int64_t>(K, std::max<int64_t>(ncols, 1)));
+    const int64_t lstride = std::max<int64_t>(1, std::min<int64_t>(K, std::max<int64_t>(ncols, 1)));   // entries per line, at most
+    const int64_t stride = lstride * ncm;                 // ... per matrix row
     // observation coordinates and scale factors on the device
     DBuf<double> dobs, dcw, drows, dred;
     DBuf<int> derr;
@@ -1356,31 +1548,36 @@ static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const
         TFX_TRY(dhist.alloc((size_t)N));
         TFX_HIP(hipMemsetAsync(dhist.p, 0, (size_t)N * sizeof(int32_t), s));
     }
-    std::vector<float> hscale((size_t)ndata);
+    std::vector<float> hscale((size_t)nlines);            // per line: (float)(problem_weight * data_weight(d, i)), :838
     {
         std::vector<double> hdw;
         if (data_weight) {
-            hdw.resize((size_t)ndata);
-            TFX_TRY(copy_any(hdw.data(), data_weight, (size_t)ndata * sizeof(double), s));
+            hdw.resize((size_t)nrows_m);
+            TFX_TRY(copy_any(hdw.data(), data_weight, (size_t)nrows_m * sizeof(double), s));
         }
-        for (int64_t i = 0; i < ndata; ++i) hscale[(size_t)i] = (float)(problem_weight * (data_weight ? hdw[(size_t)i] : 1.0));   // :841
+        for (int64_t r = 0; r < nrows_m; ++r) {
+            const float sc = (float)(problem_weight * (data_weight ? hdw[(size_t)r] : 1.0));
+            for (int k = 0; k < ncm; ++k) hscale[(size_t)(r * ncm + k)] = sc;
+        }
     }
+    DBuf<float> dscale;
+    TFX_TRY(dscale.alloc((size_t)nlines));
+    TFX_HIP(hipMemcpyAsync(dscale.p, hscale.data(), (size_t)nlines * sizeof(float), hipMemcpyHostToDevice, s));
+    // observations per batch: the line buffer + select candidates (2x) stay around 6 GB, at most 32 lines (one observation
+    // at least)
+    const int64_t lines_cap = std::max<int64_t>(1, std::min<int64_t>(32, (int64_t)(1u << 28) / N));
+    const int ob_max = (int)std::max<int64_t>(1, lines_cap / nsub);
     TiledMatrix &m = ctx->mat;
     if (keep_matrix && compression_type == 0) {
         // No compression (sensitivity_gravmag.F90:287-295): every column is stored -> dense fp32 block, no index stream.
-        TFX_TRY(matrix_begin_dense(ctx, ndata, ncols));
-        const int Bd = (int)std::max<int64_t>(1, std::min<int64_t>(32, (int64_t)(1u << 28) / N));
-        TFX_TRY(drows.alloc((size_t)Bd * N));
-        DBuf<float> dsc;
-        TFX_TRY(dsc.alloc((size_t)ndata));
-        TFX_HIP(hipMemcpyAsync(dsc.p, hscale.data(), (size_t)ndata * sizeof(float), hipMemcpyHostToDevice, s));
+        TFX_TRY(matrix_begin_dense(ctx, nrows_m, ncm * ncols));
+        TFX_TRY(drows.alloc((size_t)ob_max * nsub * N));
         const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (ncols + 255) / 256));
-        for (int64_t g = 0; g < ndata; g += Bd) {
-            const int nb = (int)std::min<int64_t>(Bd, ndata - g);
-            TFX_TRY(prism_rows_dev(ctx, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p, nullptr,
-                                   nullptr, mag));
-            hipLaunchKernelGGL(k_dense_store, dim3(gx, nb), dim3(256), 0, s, drows.p, N, col_begin, ncols, dsc.p + g,
-                               m.dense.p + g * m.ld, m.ld);
+        for (int64_t g = 0; g < ndata; g += ob_max) {
+            const int nb = (int)std::min<int64_t>(ob_max, ndata - g);
+            TFX_TRY(prism_rows_dev(ctx, gen, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p));
+            hipLaunchKernelGGL(k_dense_store, dim3(gx, nb * nsub), dim3(256), 0, s, drows.p, N, col_begin, ncols, dscale.p + g * nsub,
+                               m.dense.p + g * ncd * m.ld, m.ld, ncm);
             TFX_HIP(hipGetLastError());
         }
         int herr = 0;
@@ -1388,96 +1585,110 @@ static int build_kernel_any(tfx_ctx *ctx, int64_t ndata, const double *xd, const
         TFX_HIP(hipStreamSynchronize(s));
         TFX_TRY(geometry_error(herr));
         TFX_TRY(matrix_finish(ctx));
-        if (nnz_out) *nnz_out = ndata * ncols;
+        if (nnz_out) *nnz_out = nrows_m * ncm * ncols;
         if (error_sum_out) *error_sum_out = 0.0;
         if (nnz_hist_out) {
-            hipLaunchKernelGGL(k_fill_i32, dim3(1024), dim3(256), 0, s, dhist.p, N, (int32_t)ndata);       // :291-294: every column, every row
+            hipLaunchKernelGGL(k_fill_i32, dim3(1024), dim3(256), 0, s, dhist.p, N, (int32_t)nlines);       // :291-294: every column, every line
             TFX_HIP(hipGetLastError());
             TFX_TRY(copy_any(nnz_hist_out, dhist.p, (size_t)N * sizeof(int32_t), s));
         }
         return 0;
     }
-    if (keep_matrix) TFX_TRY(matrix_begin(ctx, ndata, ncols, ndata * std::min<int64_t>(K, ncols)));
-    const int RB = keep_matrix ? m.RB : (int)std::min<int64_t>(RB_MAX, (ndata + 63) / 64 * 64);
-    // rows processed per batch: row buffer + select candidates (2x) must stay around 6 GB
-    const int B = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(32, RB), (int64_t)(1u << 28) / N));
-    TFX_TRY(drows.alloc((size_t)B * N));
-    const int npart = prism_partials(ctx, mag != nullptr);
+    if (keep_matrix) TFX_TRY(matrix_begin(ctx, nrows_m, ncm * ncols, nrows_m * stride));
+    const int RB = keep_matrix ? m.RB : (int)std::min<int64_t>(RB_MAX, (nrows_m + 63) / 64 * 64);
+    TFX_TRY(drows.alloc((size_t)ob_max * nsub * N));
+    const int npart = prism_partials(ctx, gen);
+    const int lines_max = ob_max * nsub;
     DBuf<double> dcf;
-    TFX_TRY(dred.alloc((size_t)B * npart));
-    TFX_TRY(dcf.alloc(B));
+    TFX_TRY(dred.alloc((size_t)lines_max * npart));
+    TFX_TRY(dcf.alloc(lines_max));
+    // staging area of finished matrix rows: a row block (RB rows) plus the rows of one observation that may straddle it
+    const int stage_rows = RB + ncd;
     DBuf<int32_t> ell_cols, ell_nel;
-    DBuf<float> ell_vals, dscale;
+    DBuf<float> ell_vals;
     DBuf<int64_t> ell_off;
     if (keep_matrix) {
-        TFX_TRY(ell_cols.alloc((size_t)RB * stride));
-        TFX_TRY(ell_vals.alloc((size_t)RB * stride));
-        TFX_TRY(ell_off.alloc(RB));
-        std::vector<int64_t> ho(RB);
-        for (int r = 0; r < RB; ++r) ho[r] = (int64_t)r * stride;
-        TFX_HIP(hipMemcpyAsync(ell_off.p, ho.data(), RB * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        TFX_TRY(ell_cols.alloc((size_t)stage_rows * stride));
+        TFX_TRY(ell_vals.alloc((size_t)stage_rows * stride));
+        TFX_TRY(ell_off.alloc(stage_rows));
+        std::vector<int64_t> ho(stage_rows);
+        for (int r = 0; r < stage_rows; ++r) ho[r] = (int64_t)r * stride;
+        TFX_HIP(hipMemcpyAsync(ell_off.p, ho.data(), stage_rows * sizeof(int64_t), hipMemcpyHostToDevice, s));
     }
-    TFX_TRY(ell_nel.alloc(RB));
+    TFX_TRY(ell_nel.alloc(stage_rows));
     if (to_rs) {
-        rs->nrows = ndata;
+        rs->nrows = nrows_m;
         rs->stride = std::max<int64_t>(1, K);
-        TFX_TRY(rs->cols.alloc((size_t)(ndata * rs->stride)));
-        TFX_TRY(rs->vals.alloc((size_t)(ndata * rs->stride)));
-        TFX_TRY(rs->nel.alloc((size_t)ndata));
+        TFX_TRY(rs->cols.alloc((size_t)(nrows_m * rs->stride)));
+        TFX_TRY(rs->vals.alloc((size_t)(nrows_m * rs->stride)));
+        TFX_TRY(rs->nel.alloc((size_t)nrows_m));
     }
-    TFX_TRY(dscale.alloc((size_t)ndata));
-    TFX_HIP(hipMemcpyAsync(dscale.p, hscale.data(), (size_t)ndata * sizeof(float), hipMemcpyHostToDevice, s));
     SelectWork sw;
     CompactWork cw;
-    TFX_TRY(compact_prepare(cw, B, N));
+    TFX_TRY(compact_prepare(cw, lines_max, N));
     double err_sum = 0.0;
     int64_t nnz_total = 0;
-    std::vector<double> h_red(B), h_cd(B);
-    std::vector<int32_t> h_nel(RB), h_nel_all(B);
-    for (int64_t r0 = 0; r0 < ndata; r0 += RB) {
-        const int nr = (int)std::min<int64_t>(RB, ndata - r0);
-        for (int b0 = 0; b0 < nr; b0 += B) {
-            const int nb = std::min(B, nr - b0);
-            const int64_t g = r0 + b0;
-            TFX_TRY(prism_rows_dev(ctx, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p,
-                                   compression_type > 0 ? dred.p : nullptr, nullptr, mag));
-            if (compression_type > 0) {
-                hipLaunchKernelGGL(k_rows_final_sum, dim3(nb), dim3(256), 0, s, dred.p, npart, dcf.p);             // cost_full :234
-                TFX_HIP(hipGetLastError());
-                TFX_TRY(wavelet_dev(ctx, drows.p, ctx->nx, ctx->ny, ctx->nz, nb, compression_type, 1));              // :237
-                TFX_TRY(select_threshold_dev(ctx, sw, drows.p, nb, N, K, cw.thr.p));                                 // :240-256
-            }
-            if (to_rs)
-                TFX_TRY(compact_dev(ctx, cw, drows.p, nb, N, 0, 0, N, rs->cols.p + (size_t)g * rs->stride,
-                                    rs->vals.p + (size_t)g * rs->stride, rs->stride, ell_nel.p + b0, dscale.p + g,
-                                    nnz_hist_out ? dhist.p : nullptr));
-            else
-            TFX_TRY(compact_dev(ctx, cw, drows.p, nb, N, compression_type == 0, col_begin, col_end,
-                                keep_matrix ? ell_cols.p + (size_t)b0 * stride : nullptr,
-                                keep_matrix ? ell_vals.p + (size_t)b0 * stride : nullptr, stride, ell_nel.p + b0,
-                                dscale.p + g, nnz_hist_out ? dhist.p : nullptr));
-            // per-row statistics
-            TFX_HIP(hipMemcpyAsync(h_nel_all.data(), cw.nel_all.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            if (compression_type > 0) {
-                TFX_HIP(hipMemcpyAsync(h_red.data(), dcf.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, s));
-                TFX_HIP(hipMemcpyAsync(h_cd.data(), cw.cost_disc.p, nb * sizeof(double), hipMemcpyDeviceToHost, s));
-            }
+    std::vector<double> h_red(lines_max), h_cd(lines_max);
+    std::vector<int32_t> h_nel(lines_max), h_nel_all(lines_max);
+    int fill = 0;                 // finished rows waiting in the staging area
+    int64_t r0 = 0;               // first matrix row of the staging area
+    for (int64_t g = 0; g < ndata;) {
+        // just enough observations to complete the current row block (so that with one data component blocks never straddle)
+        const int64_t want = ((int64_t)RB - fill + ncd - 1) / ncd;
+        const int nb = (int)std::min<int64_t>(std::min<int64_t>(ob_max, std::max<int64_t>(1, want)), ndata - g);
+        const int nl = nb * nsub;                                   // lines of this batch
+        TFX_TRY(prism_rows_dev(ctx, gen, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p,
+                               compression_type > 0 ? dred.p : nullptr));
+        if (compression_type > 0) {
+            hipLaunchKernelGGL(k_rows_final_sum, dim3(nl), dim3(256), 0, s, dred.p, npart, dcf.p);                  // cost_full :234
+            TFX_HIP(hipGetLastError());
+            TFX_TRY(wavelet_dev(ctx, drows.p, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1));                   // :237
+            TFX_TRY(select_threshold_dev(ctx, sw, drows.p, nl, N, K, cw.thr.p));                                      // :240-256
+        }
+        if (to_rs)
+            TFX_TRY(compact_dev(ctx, cw, drows.p, nl, N, 0, 0, N, rs->cols.p + (size_t)(g * ncd) * rs->stride,
+                                rs->vals.p + (size_t)(g * ncd) * rs->stride, rs->stride, rs->nel.p + g * ncd, dscale.p + g * nsub,
+                                nnz_hist_out ? dhist.p : nullptr, 1));
+        else
+            TFX_TRY(compact_dev(ctx, cw, drows.p, nl, N, compression_type == 0, col_begin, col_end,
+                                keep_matrix ? ell_cols.p + (size_t)fill * stride : nullptr,
+                                keep_matrix ? ell_vals.p + (size_t)fill * stride : nullptr, stride, ell_nel.p + fill,
+                                dscale.p + g * nsub, nnz_hist_out ? dhist.p : nullptr, ncm));
+        // per-line statistics
+        TFX_HIP(hipMemcpyAsync(h_nel_all.data(), cw.nel_all.p, nl * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        TFX_HIP(hipMemcpyAsync(h_nel.data(), cw.nel.p, nl * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (compression_type > 0) {
+            TFX_HIP(hipMemcpyAsync(h_red.data(), dcf.p, (size_t)nl * sizeof(double), hipMemcpyDeviceToHost, s));
+            TFX_HIP(hipMemcpyAsync(h_cd.data(), cw.cost_disc.p, nl * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
+        TFX_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < nl; ++i) {
+            if (h_nel_all[i] > K) return fail(TFX_E_NUMERIC, "Wrong number of elements in calculate_and_write_sensit!");   // :275-277
+            if (compression_type > 0) err_sum += std::sqrt(h_cd[i] / h_red[i]);                                          // :283
+            nnz_total += h_nel[i];
+        }
+        g += nb;
+        fill += nb * ncd;
+        if (fill >= RB || g >= ndata) {
+            int herr = 0;
+            TFX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, s));
             TFX_HIP(hipStreamSynchronize(s));
-            for (int i = 0; i < nb; ++i) {
-                if (h_nel_all[i] > K) return fail(TFX_E_NUMERIC, "Wrong number of elements in calculate_and_write_sensit!");
-                if (compression_type > 0) {
-                    err_sum += std::sqrt(h_cd[i] / h_red[i]);                                                            // :283
+            TFX_TRY(geometry_error(herr));
+            while (fill >= RB || (g >= ndata && fill > 0)) {
+                const int nr = std::min(fill, RB);
+                if (keep_matrix) TFX_TRY(matrix_append_rows(ctx, r0, nr, ell_cols.p, ell_vals.p, ell_nel.p, ell_off.p, stride));
+                r0 += nr;
+                const int left = fill - nr;
+                if (left > 0) {        // rows of the straddling observation move to the front (left < ncd <= nr: no overlap)
+                    if (keep_matrix) {
+                        TFX_HIP(hipMemcpyAsync(ell_cols.p, ell_cols.p + (size_t)nr * stride, (size_t)left * stride * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+                        TFX_HIP(hipMemcpyAsync(ell_vals.p, ell_vals.p + (size_t)nr * stride, (size_t)left * stride * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    }
+                    TFX_HIP(hipMemcpyAsync(ell_nel.p, ell_nel.p + nr, (size_t)left * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
                 }
+                fill = left;
             }
         }
-        int herr = 0;
-        TFX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        TFX_HIP(hipMemcpyAsync(h_nel.data(), ell_nel.p, nr * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        TFX_HIP(hipStreamSynchronize(s));
-        TFX_TRY(geometry_error(herr));
-        for (int i = 0; i < nr; ++i) nnz_total += h_nel[i];
-        if (to_rs) TFX_HIP(hipMemcpyAsync(rs->nel.p + r0, ell_nel.p, nr * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        if (keep_matrix) TFX_TRY(matrix_append_rows(ctx, r0, nr, ell_cols.p, ell_vals.p, ell_nel.p, ell_off.p, stride));
     }
     if (keep_matrix) {
         TFX_TRY(matrix_finish(ctx));
@@ -1496,12 +1707,23 @@ int tfx_rowstore_build(tfx_ctx *ctx, int problem_type, int64_t ndata, const doub
                        int32_t *nnz_hist_out)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
-    if (problem_type != 1 && problem_type != 2) return fail(TFX_E_ARG, "problem_type must be 1 (grav) or 2 (magn)");
-    if (problem_type == 2 && !mag_field) return fail(TFX_E_ARG, "magnetic field (incl, decl, azim, intensity) missing");
-    MagField mf{};
-    if (problem_type == 2) mf = make_mag_field(mag_field[0], mag_field[1], mag_field[2], mag_field[3]);
-    return build_kernel_any(ctx, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight, 0, 0,
-                            nnz_out, error_sum_out, nnz_hist_out, problem_type == 2 ? &mf : nullptr, &ctx->rowstore);
+    RowGen gen;
+    TFX_TRY(make_rowgen(gen, problem_type, 1, 1, 1, mag_field));
+    return build_kernel_any(ctx, gen, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight, 0, 0,
+                            nnz_out, error_sum_out, nnz_hist_out, &ctx->rowstore);
+}
+
+// the same with any data type / data components the reference supports (one model component)
+int tfx_rowstore_build_ex(tfx_ctx *ctx, int problem_type, int data_type, int ndata_components, int64_t ndata, const double *xd,
+                          const double *yd, const double *zd, const double *column_weight, const double *mag_field,
+                          int compression_type, double rate, double problem_weight, const double *data_weight, int64_t *nnz_out,
+                          double *error_sum_out, int32_t *nnz_hist_out)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    RowGen gen;
+    TFX_TRY(make_rowgen(gen, problem_type, data_type, ndata_components, 1, mag_field));
+    return build_kernel_any(ctx, gen, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight, 0, 0,
+                            nnz_out, error_sum_out, nnz_hist_out, &ctx->rowstore);
 }
 
 // first entry of every row with column >= bounds[d] (d = 0..nparts); counts[r*nparts + d] = entries in [bounds[d], bounds[d+1])
@@ -1670,8 +1892,8 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
                           const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
                           double *error_sum_out, int32_t *nnz_hist_out)
 {
-    return build_kernel_any(ctx, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight,
-                            col_begin, col_end, nnz_out, error_sum_out, nnz_hist_out, nullptr);
+    return build_kernel_any(ctx, RowGen{}, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight,
+                            col_begin, col_end, nnz_out, error_sum_out, nnz_hist_out);
 }
 
 int tfx_build_kernel_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,
@@ -1679,9 +1901,22 @@ int tfx_build_kernel_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const do
                          int compression_type, double rate, double problem_weight, const double *data_weight,
                          int64_t col_begin, int64_t col_end, int64_t *nnz_out, double *error_sum_out, int32_t *nnz_hist_out)
 {
-    const MagField mf = make_mag_field(incl, decl, azim, intensity);
-    return build_kernel_any(ctx, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight,
-                            col_begin, col_end, nnz_out, error_sum_out, nnz_hist_out, &mf);
+    RowGen gen;
+    gen.kind = GEN_MAG;
+    gen.mf = make_mag_field(incl, decl, azim, intensity);
+    return build_kernel_any(ctx, gen, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight,
+                            col_begin, col_end, nnz_out, error_sum_out, nnz_hist_out);
+}
+
+int tfx_build_kernel(tfx_ctx *ctx, int problem_type, int data_type, int ndata_components, int nmodel_components, int64_t ndata,
+                     const double *xd, const double *yd, const double *zd, const double *column_weight, const double *mag_field,
+                     int compression_type, double rate, double problem_weight, const double *data_weight, int64_t col_begin,
+                     int64_t col_end, int64_t *nnz_out, double *error_sum_out, int32_t *nnz_hist_out)
+{
+    RowGen gen;
+    TFX_TRY(make_rowgen(gen, problem_type, data_type, ndata_components, nmodel_components, mag_field));
+    return build_kernel_any(ctx, gen, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight,
+                            col_begin, col_end, nnz_out, error_sum_out, nnz_hist_out);
 }
 
 }  // extern "C"

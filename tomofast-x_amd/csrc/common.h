@@ -156,6 +156,7 @@ struct tfx_ctx {
     // WAVELET_DOMAIN = F (joint_inverse_problem.F90:189-198): LSQR unknowns are spatial, S acts on Wav(v)
     bool spatial_unknowns = false;
     int wd_n1 = 0, wd_n2 = 0, wd_n3 = 0, wd_type = 0;
+    int64_t wd_nvec = 1;      // model components transformed one after the other
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profile = false;

@@ -258,7 +258,7 @@ static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L)
     hipStream_t s = ctx->stream;
     if (ctx->spatial_unknowns) {                                         // lsqr_solver2.F90:137-145, :228-236
         TFX_TRY(spmtv_dev(ctx, L->u.p, L->tw.p, 0));
-        TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, 1, ctx->wd_type, 2));
+        TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, 2));
         LAUNCH(k_axpy1, grid_for(L->ncols), L->v.p, L->tw.p, L->ncols);
     } else {
         TFX_TRY(spmtv_dev(ctx, L->u.p, L->v.p, 1));
@@ -329,8 +329,10 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     TFX_TRY(L->diag.ensure((size_t)std::max<int64_t>(1, nblocks * nc)));
     TFX_TRY(L->red.ensure(RED_BLOCKS));
     if (ctx->spatial_unknowns) {
-        if ((int64_t)ctx->wd_n1 * ctx->wd_n2 * ctx->wd_n3 != nc)
-            return fail(TFX_E_STATE, "WAVELET_DOMAIN = F needs the whole model on this rank (ncolumns %lld != n1*n2*n3)", (long long)nc);
+        const int64_t n123 = (int64_t)ctx->wd_n1 * ctx->wd_n2 * ctx->wd_n3;
+        if (n123 <= 0 || nc % n123 != 0)       // ncolumns = nmodel_components * nelements (wavelet_utils.F90:37-72 loops the components)
+            return fail(TFX_E_STATE, "WAVELET_DOMAIN = F needs the whole model on this rank (ncolumns %lld is not a multiple of n1*n2*n3)", (long long)nc);
+        ctx->wd_nvec = nc / n123;
         if (ctx->nranks > 1) return fail(TFX_E_STATE, "WAVELET_DOMAIN = F is single-rank for now");
         TFX_TRY(L->tw.ensure((size_t)nc));
     }
@@ -407,7 +409,7 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
             const int64_t nd = L->nrows_data;
             if (ctx->spatial_unknowns) {                                                  // :171-176
                 LAUNCH(k_copy, grid_for(nc), L->tw.p, L->x.p, nc);
-                TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, 1, ctx->wd_type, 1));
+                TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, 1));
                 TFX_TRY(spmv_dev(ctx, L->tw.p, L->sx.p, 0));
             } else
             TFX_TRY(spmv_dev(ctx, L->x.p, L->sx.p, 0));
@@ -422,7 +424,7 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
         LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
         if (ctx->spatial_unknowns) {                                                      // :200-209
             LAUNCH(k_copy, grid_for(nc), L->tw.p, L->v.p, nc);
-            TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, 1, ctx->wd_type, 1));
+            TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, 1));
             TFX_TRY(spmv_dev(ctx, L->tw.p, L->u.p, 1));
         } else {
             TFX_TRY(spmv_dev(ctx, L->v.p, L->u.p, 1));

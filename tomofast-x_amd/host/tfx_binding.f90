@@ -115,6 +115,38 @@ module tfx_binding
       type(c_ptr), value :: nnz_hist
     end function
 
+    ! the general build: gradiometry (data_type 2, 1 | 6 data components), three-component magnetic data, magnetisation-vector
+    ! model (3 model components) - the whole loop of src/forward/gravmag/sensitivity_gravmag.F90:189-311.
+    ! mag_field = c_loc of (/ incl, decl, azim, intensity /) or c_null_ptr; data_weight(ndata_components, ndata)
+    integer(c_int) function tfx_build_kernel(ctx, problem_type, data_type, ndata_components, nmodel_components, ndata, xd, yd, zd, &
+                                             column_weight, mag_field, compression_type, rate, problem_weight, data_weight, &
+                                             col_begin, col_end, nnz, error_sum, nnz_hist) bind(C, name="tfx_build_kernel")
+      import :: c_int, c_ptr, c_double, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: problem_type, data_type, ndata_components, nmodel_components
+      integer(c_int64_t), value :: ndata, col_begin, col_end
+      real(c_double), intent(in) :: xd(*), yd(*), zd(*), column_weight(*)
+      type(c_ptr), value :: mag_field
+      integer(c_int), value :: compression_type
+      real(c_double), value :: rate, problem_weight
+      type(c_ptr), value :: data_weight
+      integer(c_int64_t), intent(out) :: nnz
+      real(c_double), intent(out) :: error_sum
+      type(c_ptr), value :: nnz_hist
+    end function
+
+    ! sensit_line(nelements, nmodel_components, ndata_components) of every observation, any generator of :193-220
+    integer(c_int) function tfx_prism_rows(ctx, problem_type, data_type, ndata_components, nmodel_components, ndata, xd, yd, zd, &
+                                           mag_field, rows) bind(C, name="tfx_prism_rows")
+      import :: c_int, c_ptr, c_double, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: problem_type, data_type, ndata_components, nmodel_components
+      integer(c_int64_t), value :: ndata
+      real(c_double), intent(in) :: xd(*), yd(*), zd(*)
+      type(c_ptr), value :: mag_field
+      real(c_double), intent(out) :: rows(*)
+    end function
+
     ! t_sparse_matrix add_row/new_row/finalize (src/inversion/sparse_matrix.f90:213-293)
     integer(c_int) function tfx_matrix_upload_csr(ctx, nrows, ncols, rowptr, cols, vals) bind(C, name="tfx_matrix_upload_csr")
       import :: c_int, c_ptr, c_float, c_int64_t, c_int32_t

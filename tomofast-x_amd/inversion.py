@@ -35,12 +35,19 @@ class AdmmState:
 
 def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor, nminor, alpha=0.0, rmin=1e-13,
                           problem_weight=1.0, data_weight=None, model_start=None, model_prior=None, admm=None,
-                          gamma=0.0, target_misfit=0.0, log=None):
+                          gamma=0.0, target_misfit=0.0, log=None, nmodel_components=1):
     """ctx: Context holding the sensitivity matrix S (already scaled by problem_weight * data_weight) over ALL columns.
-    admm: dict(bounds=[...], rho=...) or None.  Returns (model, data_calc, history)."""
+    admm: dict(bounds=[...], rho=...) or None.  Returns (model, data_calc, history).
+    One problem of either kind (the name is historical).  nmodel_components = 3 (magnetisation vector): model vectors are
+    component-major [k*N + cell] (model%val(:, k) flattened), the wavelet transform runs per component
+    (wavelet_utils.F90:37-72) and the damping block repeats per component (joint_inverse_problem.F90:456-463);
+    data vectors are [idata*ndata_components + d]."""
     nx, ny, nz = ctx.dims
-    N = nx * ny * nz
-    cw = np.asarray(column_weight, np.float64)
+    ncm = int(nmodel_components)
+    N = nx * ny * nz * ncm
+    cw = np.tile(np.asarray(column_weight, np.float64), ncm)
+    if admm is not None and ncm != 1:
+        raise NotImplementedError("ADMM bounds act on Mz only for vector models (joint_inverse_problem.F90:497-506)")
     pw = float(problem_weight)
     dw = np.ones(data_obs.size) if data_weight is None else np.asarray(data_weight, np.float64)
     m = np.zeros(N) if model_start is None else np.array(model_start, np.float64)

@@ -108,6 +108,17 @@ class Context:
                                            C.c_double(azim), C.c_double(inten), ptr(rows)))
         return rows
 
+    # ---- any row generator of the build loop (graviprism_z, gradiprism_zz / _full, magprism with 1|3 components)
+    def sensit_lines(self, problem_type, Xdata, Ydata, Zdata, data_type=1, ndata_components=1, nmodel_components=1, mag_field=None):
+        """-> rows[ndata, ndata_components, nmodel_components, N] = the reference's sensit_line_full(:, k, d) per observation
+        (sensitivity_gravmag.F90:193-220)."""
+        xd, yd, zd = f64(np.atleast_1d(Xdata)), f64(np.atleast_1d(Ydata)), f64(np.atleast_1d(Zdata))
+        rows = np.empty((xd.size, ndata_components, nmodel_components, self.nelements_total))
+        mf = None if mag_field is None else f64(mag_field)
+        check(self._lib.tfx_prism_rows(self._h, int(problem_type), int(data_type), int(ndata_components), int(nmodel_components),
+                                       C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(mf), ptr(rows)))
+        return rows
+
     # ---- forward_wavelet / inverse_wavelet
     def forward_wavelet(self, s, n1, n2, n3, wavelet_type):
         return self._wavelet(s, n1, n2, n3, wavelet_type, 1)
@@ -140,8 +151,12 @@ class Context:
 
     # ---- calculate_and_write_sensit + read_sensitivity_kernel (no disk round trip)
     def calculate_sensit(self, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate, problem_weight=1.0,
-                         data_weight=None, col_range=None, want_hist=False, mag_field=None):
-        """mag_field = None: gravity (graviprism_z); (incl, decl, azim, intensity_nT): magnetic TMI kernel (magprism)."""
+                         data_weight=None, col_range=None, want_hist=False, mag_field=None, data_type=1, ndata_components=1,
+                         nmodel_components=1):
+        """mag_field = None: gravity (graviprism_z, or gradiometry with data_type = 2 and 1 | 6 data components);
+        (incl, decl, azim, intensity_nT): magnetic kernel (magprism; 1 | 3 data components, 1 | 3 model components).
+        With several components the matrix has ndata*ndata_components rows (d fastest) and nmodel_components column blocks;
+        data_weight is then [ndata, ndata_components]."""
         xd, yd, zd = f64(Xdata), f64(Ydata), f64(Zdata)
         cw = f64(column_weight)
         N = self.nelements_total
@@ -150,6 +165,14 @@ class Context:
         nnz = C.c_int64()
         err = C.c_double()
         hist = np.zeros(N, np.int32) if want_hist else None
+        if data_type != 1 or ndata_components != 1 or nmodel_components != 1:
+            mf = None if mag_field is None else f64(mag_field)
+            check(self._lib.tfx_build_kernel(self._h, 1 if mag_field is None else 2, int(data_type), int(ndata_components),
+                                             int(nmodel_components), C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw), ptr(mf),
+                                             int(compression_type), C.c_double(compression_rate), C.c_double(problem_weight), ptr(dw),
+                                             C.c_int64(c0), C.c_int64(c1), C.byref(nnz), C.byref(err), ptr(hist)))
+            nlines = xd.size * ndata_components * nmodel_components
+            return dict(nnz=nnz.value, error_sum=err.value, comp_error=err.value / nlines, nnz_hist=hist)
         if mag_field is None:
             check(self._lib.tfx_build_kernel_grav(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw), int(compression_type),
                                                   C.c_double(compression_rate), C.c_double(problem_weight), ptr(dw), C.c_int64(c0),
@@ -166,12 +189,18 @@ class Context:
     ROW_BLOCK = 2048
 
     def rowstore_build(self, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate, problem_weight=1.0,
-                       data_weight=None, mag_field=None):
+                       data_weight=None, mag_field=None, data_type=1, ndata_components=1):
         xd, yd, zd, cw = f64(Xdata), f64(Ydata), f64(Zdata), f64(column_weight)
         dw = None if data_weight is None else f64(data_weight)
         mf = None if mag_field is None else f64(mag_field)
         nnz, err = C.c_int64(), C.c_double()
         hist = np.zeros(self.nelements_total, np.int32)
+        if data_type != 1 or ndata_components != 1:
+            check(self._lib.tfx_rowstore_build_ex(self._h, 1 if mag_field is None else 2, int(data_type), int(ndata_components),
+                                                  C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw), ptr(mf), int(compression_type),
+                                                  C.c_double(compression_rate), C.c_double(problem_weight), ptr(dw), C.byref(nnz),
+                                                  C.byref(err), ptr(hist)))
+            return dict(nnz=nnz.value, error_sum=err.value, nnz_hist=hist)
         check(self._lib.tfx_rowstore_build(self._h, 1 if mag_field is None else 2, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw),
                                            ptr(mf), int(compression_type), C.c_double(compression_rate), C.c_double(problem_weight),
                                            ptr(dw), C.byref(nnz), C.byref(err), ptr(hist)))
