@@ -96,6 +96,59 @@ def test_config1_from_parfile_matches_reference_outputs(tmp_path, golden_dir):
     assert abs(float(costs[-1][2]) - 0.22595168071843558) <= 1e-5 * 0.22595168071843558            # final model cost
 
 
+def read_tokens(path, ncol):
+    """List-directed output wraps long records: all numbers after the count line, reshaped."""
+    t = open(path).read().split()
+    n = int(t[0])
+    return np.array([float(v) for v in t[1:1 + n * ncol]]).reshape(n, ncol)
+
+
+@pytest.mark.parametrize("name", ["e2e_ftg", "e2e_mag13", "e2e_mag31", "e2e_mag33"])
+def test_multicomponent_parfiles_match_reference_outputs(tmp_path, golden_dir, name):
+    """The Parfile the reference ran for the multi-component fixtures (gradiometry full tensor, three-component magnetic data,
+    magnetisation vector; the Parfile text is ours, tests/golden/make_golden.py) through the Fortran host: same input
+    files, same output files."""
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    wd = str(tmp_path)
+    n = g["X1"].size
+    nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
+    ncm, ncd = int(g["ncm"]), int(g["ncd"])
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    with open(os.path.join(wd, "grid.txt"), "w") as f:
+        f.write("%d\n" % n)
+        for p in range(n):
+            f.write("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %d\n" % (g["X1"][p], g["X2"][p], g["Y1"][p], g["Y2"][p], g["Z1"][p],
+                                                                      g["Z2"][p], i.ravel()[p] + 1, j.ravel()[p] + 1, k.ravel()[p] + 1))
+    with open(os.path.join(wd, "model_true.txt"), "w") as f:
+        f.write("%d\n" % n)
+        for v in g["model_true"]:
+            f.write(" ".join("%.17g" % x for x in v) + "\n")
+    with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+        f.write("%d\n" % g["obs"].shape[0])
+        for o in g["obs"]:
+            f.write("%.17g %.17g %.17g" % tuple(o) + " 0.0" * ncd + "\n")
+    open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    sfx = "grav" if int(g["prob"]) == 1 else "mag"
+    nnz = int(out.stdout.split("nnz_total =")[1].split()[0])
+    assert abs(nnz - int(g["np1_nnz_total"])) <= 2 * g["obs"].shape[0] * ncm * ncd
+    err = float(out.stdout.split("COMPRESSION ERROR, r =")[1].split()[0])
+    assert abs(err - float(g["np1_comp_error"])) <= 1e-6 * float(g["np1_comp_error"])
+    model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), ncm)
+    ref, ref2 = g["np1_model_final"], g["np2_model_final"]
+    self_diff = np.linalg.norm(ref2 - ref) / np.linalg.norm(ref)
+    tol = max(1e-6, 100.0 * self_diff)
+    assert np.linalg.norm(model - ref) <= tol * np.linalg.norm(ref), (np.linalg.norm(model - ref) / np.linalg.norm(ref), self_diff)
+    dobs = read_tokens(os.path.join(wd, "out", "data", sfx + "_observed.txt"), 3 + ncd)
+    assert np.allclose(dobs[:, :3], g["obs"], rtol=1e-12)
+    assert np.allclose(dobs[:, 3:], g["np1_data_observed"], rtol=1e-9, atol=1e-11 * np.abs(g["np1_data_observed"]).max())
+    dfin = read_tokens(os.path.join(wd, "out", "data", sfx + "_final.txt"), 3 + ncd)
+    assert np.linalg.norm(dfin[:, 3:] - g["np1_data_final"]) <= 10.0 * tol * np.linalg.norm(g["np1_data_final"])
+
+
 def test_parfile_errors_like_the_reference(tmp_path):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")

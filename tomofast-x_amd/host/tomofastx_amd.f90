@@ -10,7 +10,8 @@
 ! What stays in Fortran is what the reference also does on the host: Parfile parsing, ASCII readers / writers in
 ! the reference's formats, the ADMM projection (src/inversion/admm_method.F90:70-134), residuals and costs.
 !
-! Supported Parfile subset: gravity or magnetic (TMI, scalar model) single inversion, depth weighting types 1 and 2, Haar / D4
+! Supported Parfile subset: gravity (g_z, or gradiometry Gzz / full tensor with forward.data.grav.type = 2) or magnetic
+! (TMI or three-component data; susceptibility or magnetisation-vector model) single inversion, depth weighting types 1 and 2, Haar / D4
 ! compression or none, model damping (L2), ADMM with global bounds, prior / starting model by value or file, data from
 ! file or from a synthetic model.  Keys of features whose constraint builders are out of scope (cross-gradient,
 ! clustering, gradient damping, local weights) stop with a message when enabled, like the
@@ -49,6 +50,7 @@ module tfx_host_params
     ! features that need the out-of-scope constraint builders
     real(dp) :: beta_grad(2) = 0.d0, w_cross = 0.d0, w_clust(2) = 0.d0
     integer :: apply_local_dw = 0, apply_local_damp = 0, use_error(2) = 0, sensit_read = 0, nmodel_comp = 1, ndata_comp(2) = 1
+    integer :: grav_data_type = 1
   end type t_par
 
 contains
@@ -96,6 +98,7 @@ contains
       case ('forward.data.magn.dataGridFile');     par%data_grid_file(2) = trim(val)
       case ('forward.data.grav.nDataComponents');  read(val, *) par%ndata_comp(1)
       case ('forward.data.magn.nDataComponents');  read(val, *) par%ndata_comp(2)
+      case ('forward.data.grav.type');             read(val, *) par%grav_data_type
       case ('forward.data.grav.useError');         read(val, *) par%use_error(1)
       case ('forward.data.magn.useError');         read(val, *) par%use_error(2)
       case ('forward.data.grav.useSyntheticModelForDataValues'); read(val, *) par%use_synth(1)
@@ -159,7 +162,7 @@ contains
       case ('inversion.crossGradient.weight');     read(val, *) par%w_cross
       case ('inversion.clustering.grav.weight');   read(val, *) par%w_clust(1)
       case ('inversion.clustering.magn.weight');   read(val, *) par%w_clust(2)
-      case ('sensit.folderPath', 'inversion.writeModelEveryNiter', 'inversion.solver', 'forward.data.grav.type', &
+      case ('sensit.folderPath', 'inversion.writeModelEveryNiter', 'inversion.solver', &
             'output.paraview.grav.modelLabel', 'output.paraview.magn.modelLabel', 'inversion.priorModel.nModels')
         continue
       case default
@@ -196,35 +199,35 @@ contains
     close(u)
   end subroutine read_model_grid
 
-  ! One value per line after a header line with the count (src/inversion/model_IO.F90:87-130)
-  subroutine read_model_values(file, n, val)
+  ! nc values (model components) per line after a header line with the count (src/inversion/model_IO.F90:87-130)
+  subroutine read_model_values(file, n, nc, val)
     character(len=*), intent(in) :: file
-    integer, intent(in) :: n
-    real(dp), intent(out) :: val(n)
+    integer, intent(in) :: n, nc
+    real(dp), intent(out) :: val(n, nc)
     integer :: u, ios, nfile, p
     open(newunit=u, file=trim(file), status='old', action='read', iostat=ios)
     if (ios /= 0) call stop_msg('Error in opening the model file '//trim(file))
     read(u, *) nfile
     if (nfile /= n) call stop_msg('The model size in the file differs from the grid!')
     do p = 1, n
-      read(u, *, iostat=ios) val(p)
+      read(u, *, iostat=ios) val(p, :)
       if (ios /= 0) call stop_msg('Problem while reading the model file!')
     enddo
     close(u)
   end subroutine read_model_values
 
-  ! "x y z value" per line after a header line with the count (src/forward/gravmag/data_gravmag.f90:204-239)
-  subroutine read_data(file, n, X, Y, Z, val)
+  ! "x y z value(1:ncomp)" per line after a header line with the count (src/forward/gravmag/data_gravmag.f90:204-239)
+  subroutine read_data(file, n, ncomp, X, Y, Z, val)
     character(len=*), intent(in) :: file
-    integer, intent(in) :: n
-    real(dp), intent(out) :: X(n), Y(n), Z(n), val(n)
+    integer, intent(in) :: n, ncomp
+    real(dp), intent(out) :: X(n), Y(n), Z(n), val(ncomp, n)
     integer :: u, ios, nfile, i
     open(newunit=u, file=trim(file), status='old', action='read', iostat=ios)
     if (ios /= 0) call stop_msg('Error in opening the data file!')
     read(u, *) nfile
     if (nfile /= n) call stop_msg('The number of data in Parfile differs from the data file!')
     do i = 1, n
-      read(u, *, iostat=ios) X(i), Y(i), Z(i), val(i)
+      read(u, *, iostat=ios) X(i), Y(i), Z(i), val(:, i)
       if (ios /= 0) call stop_msg('Problem while reading the data file! Verify the number of data components.')
     enddo
     close(u)
@@ -236,31 +239,31 @@ contains
   end subroutine make_dir
 
   ! src/forward/gravmag/data_gravmag.f90:293-336
-  subroutine write_data(path_output, name, n, X, Y, Z, val, units_mult, z_axis_dir)
+  subroutine write_data(path_output, name, n, ncomp, X, Y, Z, val, units_mult, z_axis_dir)
     character(len=*), intent(in) :: path_output, name
-    integer, intent(in) :: n, z_axis_dir
-    real(dp), intent(in) :: X(n), Y(n), Z(n), val(n), units_mult
+    integer, intent(in) :: n, ncomp, z_axis_dir
+    real(dp), intent(in) :: X(n), Y(n), Z(n), val(ncomp, n), units_mult
     integer :: u, i
     call make_dir(trim(path_output)//'/data')
     open(newunit=u, file=trim(path_output)//'/data/'//trim(name)//'.txt', status='replace', action='write')
     write(u, *) n
     do i = 1, n
-      write(u, *) X(i), Y(i), real(z_axis_dir, dp) * Z(i), val(i) / units_mult
+      write(u, *) X(i), Y(i), real(z_axis_dir, dp) * Z(i), val(:, i) / units_mult
     enddo
     close(u)
   end subroutine write_data
 
   ! src/inversion/model_IO.F90:504-539
-  subroutine write_model(path_output, name, n, val, units_mult)
+  subroutine write_model(path_output, name, n, nc, val, units_mult)
     character(len=*), intent(in) :: path_output, name
-    integer, intent(in) :: n
-    real(dp), intent(in) :: val(n), units_mult
+    integer, intent(in) :: n, nc
+    real(dp), intent(in) :: val(n, nc), units_mult
     integer :: u, p
     call make_dir(trim(path_output)//'/model')
     open(newunit=u, file=trim(path_output)//'/model/'//trim(name), status='replace', action='write')
     write(u, *) n
     do p = 1, n
-      write(u, *) val(p) / units_mult
+      write(u, *) val(p, :) / units_mult
     enddo
     close(u)
   end subroutine write_model
@@ -277,8 +280,11 @@ program tomofastx_amd
 
   type(t_par) :: par
   character(len=256) :: arg, parfile
-  character(len=4) :: suffix(2) = (/'grav', 'magn'/)
-  integer :: ip, n, nd, it, i, nblocks, ucost, narg
+  ! output file prefixes (src/problem_joint_gravmag.F90:340-362, :554-555): 'grav_...' and 'mag_...'
+  character(len=4) :: suffix(2) = (/'grav', 'mag '/)
+  integer :: ip, n, nd, it, i, k, nblocks, ucost, narg, nc, ndc, nm, ndt, kadm, dtype
+  real(dp), target :: mag_field(4)
+  type(c_ptr) :: mag_ptr
   integer(c_int) :: iters
   integer(c_int64_t) :: nnz
   real(c_double) :: err_sum, r
@@ -320,19 +326,32 @@ program tomofastx_amd
   if (par%norm_power /= 2.d0) call stop_msg('inversion.modelDamping.normPower /= 2 is not supported by this host yet.')
   if (par%admm > 0 .and. par%admm_bound_type /= 1) call stop_msg('ADMM with local bounds (boundType 2) is not supported yet.')
   if (par%sensit_read /= 0) call stop_msg('sensit.readFromFiles /= 0 is not supported by this host yet (SURVEY 8f-2).')
-  if (par%nmodel_comp /= 1 .or. par%ndata_comp(ip) /= 1) call stop_msg('Only 1 model and 1 data component are supported.')
+  ! components (src/parameters_init.f90:187-197, src/forward/gravmag/sensitivity_gravmag.F90:193-220)
+  nc = 1
+  if (ip == 2) nc = par%nmodel_comp
+  if (ip == 1 .and. par%nmodel_comp > 1) call stop_msg('For the magnetisation inversion the gravity problem should be disabled!')
+  ndc = par%ndata_comp(ip)
+  dtype = 1
+  if (ip == 1) dtype = par%grav_data_type
+  if (ip == 1 .and. dtype == 1 .and. ndc /= 1) call stop_msg('Gravity data (type 1) has one data component!')
+  if (ip == 1 .and. dtype == 2 .and. ndc /= 1 .and. ndc /= 6) call stop_msg('Wrong number of gravity gradiometry data components!')
+  if (ip == 1 .and. dtype /= 1 .and. dtype /= 2) call stop_msg('Unknown gravity data type!')
+  if (ip == 2 .and. .not. ((nc == 1 .or. nc == 3) .and. (ndc == 1 .or. ndc == 3))) &
+    call stop_msg('Wrong number of components in magnetic_field_magprism!')
   if (par%admm > 0 .and. .not. allocated(par%bounds)) call stop_msg('Global bounds are not defined!')
 
   n = par%nx * par%ny * par%nz
   nd = par%ndata(ip)
   if (n <= 0 .or. nd <= 0) call stop_msg('Wrong model grid size or number of data!')
-  allocate(X1(n), X2(n), Y1(n), Y2(n), Z1(n), Z2(n), cw(n), m(n), m_prior(n), m_synth(n), work(n), x(n), rhs1(n), rhs2(n))
-  allocate(z_admm(n), u_admm(n), x0(n), diag1(n), diag2(n))
-  allocate(Xd(nd), Yd(nd), Zd(nd), d_meas(nd), d_calc(nd), dw(nd), res(nd), b_data(nd))
+  nm = n * nc              ! model vectors are component-major: m((k-1)*n + cell) = model%val(cell, k)
+  ndt = nd * ndc           ! data vectors are d-fastest: d((i-1)*ndc + d) = data(d, i)
+  allocate(X1(n), X2(n), Y1(n), Y2(n), Z1(n), Z2(n), cw(n), m(nm), m_prior(nm), m_synth(nm), work(nm), x(nm), rhs1(nm), rhs2(nm))
+  allocate(z_admm(n), u_admm(n), x0(n), diag1(nm), diag2(nm))
+  allocate(Xd(nd), Yd(nd), Zd(nd), d_meas(ndt), d_calc(ndt), dw(ndt), res(ndt), b_data(ndt))
 
   ! ---- (I) model grid and data (problem_joint_gravmag.F90:140-157)
   call read_model_grid(par%grid_file(ip), n, X1, X2, Y1, Y2, Z1, Z2)
-  call read_data(par%data_grid_file(ip), nd, Xd, Yd, Zd, d_meas)
+  call read_data(par%data_grid_file(ip), nd, ndc, Xd, Yd, Zd, d_meas)
   d_meas = d_meas * par%data_units_mult(ip)
   dw = 1.d0
 
@@ -349,45 +368,46 @@ program tomofastx_amd
   endif
 
   ! ---- (III) sensitivity kernel (:197-248)
+  mag_ptr = c_null_ptr
   if (ip == 1) then
     print *, 'Calculating GRAVITY sensitivity kernel...'
-    call tfx_check(tfx_build_kernel_grav(ctx, int(nd, c_int64_t), Xd, Yd, Zd, cw, par%comp_type, par%comp_rate, pw, c_null_ptr, &
-                                         0_c_int64_t, int(n, c_int64_t), nnz, err_sum, c_null_ptr), 'calculate_and_write_sensit')
   else
     print *, 'Calculating MAGNETIC sensitivity kernel...'
-    call tfx_check(tfx_build_kernel_mag(ctx, int(nd, c_int64_t), Xd, Yd, Zd, cw, par%mag_incl, par%mag_decl, par%mag_xaxis_decl, &
-                                        par%mag_intensity, par%comp_type, par%comp_rate, pw, c_null_ptr, 0_c_int64_t, &
-                                        int(n, c_int64_t), nnz, err_sum, c_null_ptr), 'calculate_and_write_sensit')
+    mag_field = (/par%mag_incl, par%mag_decl, par%mag_xaxis_decl, par%mag_intensity/)
+    mag_ptr = c_loc(mag_field)
   endif
+  call tfx_check(tfx_build_kernel(ctx, ip, dtype, ndc, nc, int(nd, c_int64_t), Xd, Yd, Zd, cw, mag_ptr, par%comp_type, &
+                                  par%comp_rate, pw, c_null_ptr, 0_c_int64_t, int(n, c_int64_t), nnz, err_sum, c_null_ptr), &
+                 'calculate_and_write_sensit')
   print *, 'nnz_total = ', nnz
-  print *, 'COMPRESSION RATE = ', dble(nnz) / dble(n) / dble(nd)
-  print *, 'COMPRESSION ERROR, r = ', err_sum / dble(nd)
+  print *, 'COMPRESSION RATE = ', dble(nnz) / dble(n) / dble(nd) / dble(nc) / dble(ndc)
+  print *, 'COMPRESSION ERROR, r = ', err_sum / dble(nd * ndc * nc)
 
   ! ---- data from the synthetic model (:318-345)
   if (par%use_synth(ip) > 0) then
-    call read_model_values(par%synth_file(ip), n, m_synth)
+    call read_model_values(par%synth_file(ip), n, nc, m_synth)
     m_synth = m_synth * par%model_units_mult(ip)
     call calculate_data(m_synth, d_calc)
     d_meas = d_calc
-    call write_data(par%path_output, suffix(ip)//'_synthetic', nd, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
+    call write_data(par%path_output, trim(suffix(ip))//'_synthetic', nd, ndc, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
   endif
-  call write_data(par%path_output, suffix(ip)//'_observed', nd, Xd, Yd, Zd, d_meas, par%data_units_mult(ip), par%z_axis_dir)
+  call write_data(par%path_output, trim(suffix(ip))//'_observed', nd, ndc, Xd, Yd, Zd, d_meas, par%data_units_mult(ip), par%z_axis_dir)
 
   ! ---- prior and starting models (:350-441)
   if (par%prior_type == 1) then
     m_prior = par%prior_val(ip)
   else
-    call read_model_values(par%prior_file(ip), n, m_prior)
+    call read_model_values(par%prior_file(ip), n, nc, m_prior)
   endif
   m_prior = m_prior * par%model_units_mult(ip)
   if (par%start_type == 1) then
     m = par%start_val(ip)
   else
-    call read_model_values(par%start_file(ip), n, m)
+    call read_model_values(par%start_file(ip), n, nc, m)
   endif
   m = m * par%model_units_mult(ip)
   call calculate_data(m, d_calc)
-  call write_data(par%path_output, suffix(ip)//'_starting', nd, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
+  call write_data(par%path_output, trim(suffix(ip))//'_starting', nd, ndc, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
 
   ! ---- costs (:443-470)
   call model_cost(cost_model)
@@ -414,7 +434,9 @@ program tomofastx_amd
     nblocks = 0
     if (par%alpha(ip) /= 0.d0) then                                ! damping.F90:97-234
       nblocks = nblocks + 1
-      work = (m - m_prior) / cw
+      do k = 1, nc                                                 ! one block per component (joint_inverse_problem.F90:456-463)
+        work((k - 1) * n + 1:k * n) = (m((k - 1) * n + 1:k * n) - m_prior((k - 1) * n + 1:k * n)) / cw
+      enddo
       call to_wavelet(work)
       diag1 = real(par%alpha(ip) * pw, c_float)
       rhs1 = -par%alpha(ip) * pw * work
@@ -423,14 +445,17 @@ program tomofastx_amd
     endif
     if (par%admm > 0) then                                         ! joint_inverse_problem.F90:497-527
       nblocks = nblocks + 1
-      call iterate_admm_arrays(n, par%nlithos, par%bounds, m, z_admm, u_admm, x0)
-      work = (m - x0) / cw
+      kadm = merge(1, 3, nc == 1)                                  ! vector model: bounds on Mz (:499-506)
+      call iterate_admm_arrays(n, par%nlithos, par%bounds, m((kadm - 1) * n + 1:kadm * n), z_admm, u_admm, x0)
+      work = 0.d0
+      work((kadm - 1) * n + 1:kadm * n) = (m((kadm - 1) * n + 1:kadm * n) - x0) / cw
       call to_wavelet(work)
-      diag2 = real(rho * pw, c_float)
+      diag2 = 0.0
+      diag2((kadm - 1) * n + 1:kadm * n) = real(rho * pw, c_float)
       rhs2 = -rho * pw * work
       dptr(nblocks) = c_loc(diag2)
       rptr(nblocks) = c_loc(rhs2)
-      s1 = sum((z_admm - m)**2)
+      s1 = sum((z_admm - m((kadm - 1) * n + 1:kadm * n))**2)
       s2 = sum(z_admm**2)
       cost_admm = 0.d0
       if (s2 /= 0.d0) cost_admm = sqrt(s1 / s2)                    ! costs.f90:38-69
@@ -440,8 +465,10 @@ program tomofastx_amd
                                   iters, r), 'lsqr_solve_sensit')
     print *, 'Finished lsqr solver, r =', r, ' iter =', iters
     if (par%comp_type > 0) &                                       ! :559-567
-      call tfx_check(tfx_wavelet(ctx, x, par%nx, par%ny, par%nz, 1_c_int64_t, par%comp_type, 2_c_int), 'inverse_wavelet')
-    x = x * cw                                                     ! :570
+      call tfx_check(tfx_wavelet(ctx, x, par%nx, par%ny, par%nz, int(nc, c_int64_t), par%comp_type, 2_c_int), 'inverse_wavelet')
+    do k = 1, nc
+      x((k - 1) * n + 1:k * n) = x((k - 1) * n + 1:k * n) * cw     ! :570
+    enddo
     m = m + x                                                      ! problem_joint_gravmag.F90:500
     call calculate_data(m, d_calc)                                 ! :513
     write(ucost, *) it - 1, cost_data, cost_model, cost_admm, rho  ! :519-528 (costs of the previous iteration)
@@ -458,8 +485,8 @@ program tomofastx_amd
   close(ucost)
 
   ! ---- outputs (:552-600)
-  call write_data(par%path_output, suffix(ip)//'_final', nd, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
-  call write_model(par%path_output, suffix(ip)//'_final_model_full.txt', n, m, par%model_units_mult(ip))
+  call write_data(par%path_output, trim(suffix(ip))//'_final', nd, ndc, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
+  call write_model(par%path_output, trim(suffix(ip))//'_final_model_full.txt', n, nc, m, par%model_units_mult(ip))
   print *, 'model min / max =', minval(m), maxval(m)
   call tfx_check(tfx_destroy(ctx), 'tfx_destroy')
   print *, 'THE END.'
@@ -467,28 +494,30 @@ program tomofastx_amd
 contains
 
   subroutine to_wavelet(v)
-    real(dp), intent(inout) :: v(n)
-    if (par%comp_type > 0) &
-      call tfx_check(tfx_wavelet(ctx, v, par%nx, par%ny, par%nz, 1_c_int64_t, par%comp_type, 1_c_int), 'forward_wavelet')
+    real(dp), intent(inout) :: v(nm)
+    if (par%comp_type > 0) &      ! every model component on its own (src/inversion/wavelet_utils.F90:37-72)
+      call tfx_check(tfx_wavelet(ctx, v, par%nx, par%ny, par%nz, int(nc, c_int64_t), par%comp_type, 1_c_int), 'forward_wavelet')
   end subroutine to_wavelet
 
   ! model_calculate_data, src/inversion/model.F90:220-307
   subroutine calculate_data(model, dcalc)
-    real(dp), intent(in) :: model(n)
-    real(dp), intent(out) :: dcalc(nd)
-    integer :: p
-    do p = 1, n
-      if (cw(p) /= 0.d0) then
-        work(p) = model(p) / cw(p)
-      else
-        work(p) = 0.d0
-      endif
+    real(dp), intent(in) :: model(nm)
+    real(dp), intent(out) :: dcalc(ndt)
+    integer :: p, kc
+    do kc = 1, nc
+      do p = 1, n
+        if (cw(p) /= 0.d0) then
+          work((kc - 1) * n + p) = model((kc - 1) * n + p) / cw(p)
+        else
+          work((kc - 1) * n + p) = 0.d0
+        endif
+      enddo
     enddo
     call to_wavelet(work)
     call tfx_check(tfx_calc_data(ctx, work, pw, c_null_ptr, dcalc), 'model_calculate_data')
   end subroutine calculate_data
 
-  ! calculate_cost_model, src/utils/costs.f90:74-113
+  ! calculate_cost_model, src/utils/costs.f90:74-113 (first model component only, problem_joint_gravmag.F90:655-657)
   subroutine model_cost(cost)
     real(dp), intent(out) :: cost
     integer :: p
