@@ -641,26 +641,47 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
     // which lines does this tile hold
     int64_t g0;       // global offset of (line q = 0, position 0)
     int nq;           // valid lines in the tile
-    int64_t qstride;  // global stride between consecutive lines of the tile
     if (ax.mode == 0) {
         const int64_t l0 = (int64_t)blockIdx.x * XT;
         nq = (int)min((int64_t)XT, ax.nlines - l0);
         g0 = l0 * L;
-        qstride = L;
     } else {
         const int64_t o = blockIdx.x / ax.ntiles_inner, ti = blockIdx.x % ax.ntiles_inner;
         const int64_t m0 = ti * XT;
         nq = (int)min((int64_t)XT, ax.inner - m0);
         g0 = o * ax.outer_stride + m0;
-        qstride = 1;
     }
     const int tid = threadIdx.x, nt = blockDim.x;
     // e -> (e / nq, e % nq) without an integer division when nq is a power of two (full tiles)
     const bool nq_pow2 = (nq & (nq - 1)) == 0;
     const int nq_shift = 31 - __clz(nq);
 #define DIVQ(e) (nq_pow2 ? ((e) >> nq_shift) : ((e) / nq))
+    const bool fast = nq == XT && nq_pow2 && (nt & (nq - 1)) == 0;
+    const int q = tid & (nq - 1), mr = tid >> nq_shift, MR = nt >> nq_shift;      // fast path: line and first pair of this thread
     // ---- load: 8 independent global loads in flight per thread, then the LDS writes
+    // (x axis: element e = q*L + a; e advances by nt per step, so (q, a) advance by (nt / L, nt % L) - one integer division
+    // per thread instead of one per element)
     const int total = nq * L;
+    const int dq = nt / L, da = nt - dq * L;
+    int rq = tid / L, ra = tid - rq * L;
+    if (ax.mode == 1 && fast) {
+        // y / z axis, full tile: thread (q, mr) walks positions a = mr, mr + MR, ... of line q with constant strides
+        const double *gp = base + g0 + (int64_t)mr * ax.astride + q;
+        const int64_t gstep = (int64_t)MR * ax.astride;
+        int la0 = mr * P + q;
+        const int lstep = MR * P;
+        for (int ab = mr; ab < L; ab += MR * 8) {
+            double tmp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ab + k * MR < L) tmp[k] = gp[k * gstep];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ab + k * MR < L) T[la0 + k * lstep] = tmp[k];
+            gp += 8 * gstep;
+            la0 += 8 * lstep;
+        }
+    } else
     for (int e0 = tid; e0 < total; e0 += nt * 8) {
         double tmp[8];
         int la[8];
@@ -669,9 +690,11 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
             const int e = e0 + k * nt;
             la[k] = -1;
             if (e < total) {
-                if (ax.mode == 0) { const int q = e / L, a = e - q * L; la[k] = a * P + q; tmp[k] = base[g0 + (int64_t)q * qstride + a]; }
+                if (ax.mode == 0) { la[k] = ra * P + rq; tmp[k] = base[g0 + e]; }      // the XT lines of an x tile are contiguous: q*L + a = e
                 else { const int a = DIVQ(e), q = e - a * nq; la[k] = a * P + q; tmp[k] = base[g0 + (int64_t)a * ax.astride + q]; }
             }
+            rq += dq; ra += da;
+            if (ra >= L) { ra -= L; rq += 1; }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -687,6 +710,65 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
         const int ng = (L - 1 - ngmin) / step + 1;
         const int ilmax = (ng - 1) * step;
         const int work = ng * nq;
+        if (fast) {
+            // Full tile (nq == XT, a power of two): thread (q, mr) owns line q and the pairs m = mr, mr + MR, ...; the LDS index of
+            // LO(m) advances by a constant per item, so a pass costs two integer adds per item instead of a divide / multiply chain.
+            const int a0 = (mr * step) * P + q, dA = MR * step * P, dHI = ngmin * P, dS = step * P;
+#define FOR_ITEMS for (int m = mr, a = a0; m < ng; m += MR, a += dA)
+            if (TYPE == 1 && DIR == 1) {
+                FOR_ITEMS {
+                    double lo = T[a], hi = T[a + dHI];
+                    hi = hi - lo;
+                    lo = lo + hi / 2.0;
+                    lo = lo * wc.sq2;
+                    hi = hi / wc.sq2;
+                    T[a] = lo; T[a + dHI] = hi;
+                }
+                __syncthreads();
+            } else if (TYPE == 1 && DIR == 2) {
+                FOR_ITEMS {
+                    double lo = T[a], hi = T[a + dHI];
+                    lo = lo / wc.sq2;
+                    hi = hi * wc.sq2;
+                    lo = lo - hi / 2.0;
+                    hi = hi + lo;
+                    T[a] = lo; T[a + dHI] = hi;
+                }
+                __syncthreads();
+            } else if (TYPE == 2 && DIR == 1) {
+                FOR_ITEMS { T[a] = T[a] + T[a + dHI] * wc.c0; }
+                __syncthreads();
+                FOR_ITEMS {
+                    const double prev = (m == 0) ? T[ilmax * P + q] : T[a - dS];
+                    T[a + dHI] = T[a + dHI] - T[a] * wc.c1 - prev * wc.c2;
+                }
+                __syncthreads();
+                FOR_ITEMS {
+                    const double nxt = (m == ng - 1) ? T[dHI + q] : T[a + dHI + dS];
+                    T[a] = T[a] - nxt;
+                }
+                __syncthreads();
+                FOR_ITEMS { T[a] = T[a] * wc.c3; T[a + dHI] = T[a + dHI] * wc.c4; }
+                __syncthreads();
+            } else {
+                FOR_ITEMS { T[a] = T[a] * wc.c4; T[a + dHI] = T[a + dHI] * wc.c3; }
+                __syncthreads();
+                FOR_ITEMS {
+                    const double nxt = (m == ng - 1) ? T[dHI + q] : T[a + dHI + dS];
+                    T[a] = T[a] + nxt;
+                }
+                __syncthreads();
+                FOR_ITEMS {
+                    const double prev = (m == 0) ? T[ilmax * P + q] : T[a - dS];
+                    T[a + dHI] = T[a + dHI] + T[a] * wc.c1 + prev * wc.c2;
+                }
+                __syncthreads();
+                FOR_ITEMS { T[a] = T[a] - T[a + dHI] * wc.c0; }
+                __syncthreads();
+            }
+#undef FOR_ITEMS
+            continue;
+        }
 #define LO(m) T[((m) * step) * P + q]
 #define HI(m) T[(ngmin + (m) * step) * P + q]
         if (TYPE == 1 && DIR == 1) {          // Haar forward, wavelet_transform.F90:103-149 (per pair, fused)
@@ -750,14 +832,30 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
 #undef HI
     }
     // ---- store
+    rq = tid / L; ra = tid - rq * L;
+    if (ax.mode == 1 && fast) {
+        double *gp = base + g0 + (int64_t)mr * ax.astride + q;
+        const int64_t gstep = (int64_t)MR * ax.astride;
+        int la0 = mr * P + q;
+        const int lstep = MR * P;
+        for (int ab = mr; ab < L; ab += MR * 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ab + k * MR < L) gp[k * gstep] = T[la0 + k * lstep];
+            gp += 8 * gstep;
+            la0 += 8 * lstep;
+        }
+    } else
     for (int e0 = tid; e0 < total; e0 += nt * 8) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int e = e0 + k * nt;
             if (e < total) {
-                if (ax.mode == 0) { const int q = e / L, a = e - q * L; base[g0 + (int64_t)q * qstride + a] = T[a * P + q]; }
+                if (ax.mode == 0) { base[g0 + e] = T[ra * P + rq]; }
                 else { const int a = DIVQ(e), q = e - a * nq; base[g0 + (int64_t)a * ax.astride + q] = T[a * P + q]; }
             }
+            rq += dq; ra += da;
+            if (ra >= L) { ra -= L; rq += 1; }
         }
     }
 #undef DIVQ
