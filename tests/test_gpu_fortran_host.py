@@ -149,6 +149,81 @@ def test_multicomponent_parfiles_match_reference_outputs(tmp_path, golden_dir, n
     assert np.linalg.norm(dfin[:, 3:] - g["np1_data_final"]) <= 10.0 * tol * np.linalg.norm(g["np1_data_final"])
 
 
+def write_case_inputs(wd, g):
+    n = g["X1"].size
+    nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
+    ncd = int(g["ncd"]) if "ncd" in g.files else 1
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    with open(os.path.join(wd, "grid.txt"), "w") as f:
+        f.write("%d\n" % n)
+        for p in range(n):
+            f.write("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %d\n" % (g["X1"][p], g["X2"][p], g["Y1"][p], g["Y2"][p], g["Z1"][p],
+                                                                      g["Z2"][p], i.ravel()[p] + 1, j.ravel()[p] + 1, k.ravel()[p] + 1))
+    mt = g["model_true"] if g["model_true"].ndim == 2 else g["model_true"][:, None]
+    with open(os.path.join(wd, "model_true.txt"), "w") as f:
+        f.write("%d\n" % n)
+        for v in mt:
+            f.write(" ".join("%.17g" % x for x in v) + "\n")
+    with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+        f.write("%d\n" % g["obs"].shape[0])
+        for o in g["obs"]:
+            f.write("%.17g %.17g %.17g" % tuple(o) + " 0.0" * ncd + "\n")
+
+
+@pytest.mark.parametrize("name", ["e2e_ftg", "e2e_mag31"])
+def test_sensit_files_written_like_the_reference_and_reloaded(tmp_path, golden_dir, name):
+    """calculate_and_write_sensit / read_sensitivity_kernel through the Fortran host: (1) the SENSIT set it writes parses
+    with the reference's layout and matches the reference's lines; (2) a SENSIT set holding exactly the reference's kernel
+    (written from the fixture) is re-loaded with sensit.readFromFiles = 1 and gives the reference's model."""
+    import importlib
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    sio = importlib.import_module("tomofast-x_amd").sensit_io
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    wd = str(tmp_path)
+    write_case_inputs(wd, g)
+    par = str(g["parfile"])
+    open(os.path.join(wd, "Parfile.txt"), "w").write(par)
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    prob = int(g["prob"])
+    ncm, ncd = int(g["ncm"]), int(g["ncd"])
+    N = g["X1"].size
+    got = sio.read_sensit(os.path.join(wd, "out", "SENSIT"), prob)
+    assert got["meta"]["nmodel_components"] == ncm and got["meta"]["ndata_components"] == ncd
+    assert got["column_weight"].tobytes() != b"" and np.max(np.abs(got["column_weight"] - g["np1_column_weight"]) / g["np1_column_weight"]) <= 1e-14
+    sub_rp = g["np1_row_ptr"]
+    kk = np.repeat(np.tile(np.arange(ncm), (sub_rp.size - 1) // ncm), np.diff(sub_rp))
+    ref = (sub_rp[::ncm], (g["np1_cols"] + kk * N).astype(np.int32), g["np1_vals"])
+    same = tot = 0
+    for r in range(ref[0].size - 1):
+        cb = got["cols"][got["rowptr"][r]:got["rowptr"][r + 1]]
+        cr = ref[1][ref[0][r]:ref[0][r + 1]]
+        same += np.intersect1d(cb, cr).size
+        tot += max(cb.size, cr.size)
+    assert same >= 0.995 * tot
+    assert int(got["nnz_hist"].sum()) == got["meta"]["nnz_total"] == int(got["rowptr"][-1])
+    # (2) reload the reference's own kernel
+    wd2 = os.path.join(wd, "reload")
+    os.makedirs(wd2)
+    write_case_inputs(wd2, g)
+    sio.write_sensit(os.path.join(wd2, "SENSIT_REF"), prob, ref, N, (int(g["nx"]), int(g["ny"]), int(g["nz"])), g["np1_column_weight"],
+                     int(g["ctype"]), float(g["np1_comp_error"]), depth_weighting_type=int(g["dwtype"]), ndata_components=ncd,
+                     nmodel_components=ncm)
+    par2 = par.replace("sensit.readFromFiles                = 0", "sensit.readFromFiles                = 1")
+    par2 = par2.replace("sensit.folderPath                   = out/SENSIT/", "sensit.folderPath                   = SENSIT_REF/")
+    assert par2 != par
+    open(os.path.join(wd2, "Parfile.txt"), "w").write(par2)
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd2, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "Finished reading the sensitivity kernel." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    sfx = "grav" if prob == 1 else "mag"
+    model = read_tokens(os.path.join(wd2, "out", "model", sfx + "_final_model_full.txt"), ncm)
+    refm, ref2 = g["np1_model_final"], g["np2_model_final"]
+    self_diff = np.linalg.norm(ref2 - refm) / np.linalg.norm(refm)
+    tol = max(1e-6, 10.0 * self_diff)
+    assert np.linalg.norm(model - refm) <= tol * np.linalg.norm(refm), (np.linalg.norm(model - refm) / np.linalg.norm(refm), self_diff)
+
+
 def test_parfile_errors_like_the_reference(tmp_path):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")

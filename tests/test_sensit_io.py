@@ -51,3 +51,29 @@ def test_reader_accepts_any_rank_count(tmp_path, golden_dir):
     back = tfx.sensit_io.read_sensit(folder, 1)
     assert back["meta"]["nbproc"] == 2
     assert np.array_equal(back["rowptr"], S[0]) and np.array_equal(back["cols"], S[1])
+
+
+def test_multicomponent_lines_roundtrip(tmp_path, golden_dir):
+    """Magnetisation-vector kernel with three-component data: one file line per (datum, data component, model component)."""
+    g = np.load(os.path.join(golden_dir, "e2e_mag33.npz"))
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    N = int(np.prod(dims))
+    ncm, ncd = 3, 3
+    sub_rp = g["np1_row_ptr"]                                  # the reference's file lines
+    kk = np.repeat(np.tile(np.arange(ncm), (sub_rp.size - 1) // ncm), np.diff(sub_rp))
+    S = (sub_rp[::ncm], (g["np1_cols"] + kk * N).astype(np.int32), g["np1_vals"])      # matrix rows, component column blocks
+    folder = str(tmp_path / "S33")
+    tfx.sensit_io.write_sensit(folder, 2, S, N, dims, g["np1_column_weight"], int(g["ctype"]), float(g["np1_comp_error"]),
+                               ndata_components=ncd, nmodel_components=ncm)
+    raw = open(os.path.join(folder, "sensit_magn_1_0"), "rb").read()
+    nlines = sub_rp.size - 1
+    assert len(raw) == 20 + nlines * 16 + int(sub_rp[-1]) * 8
+    # second line of the file = (datum 1, data component 1, model component 2) with CELL columns, as the reference wrote it
+    off = 20 + 16 + int(sub_rp[1]) * 8
+    assert list(np.frombuffer(raw, ">i4", 4, off)) == [1, int(sub_rp[2] - sub_rp[1]), 2, 1]
+    assert np.array_equal(np.frombuffer(raw, ">i4", int(sub_rp[2] - sub_rp[1]), off + 16), g["np1_cols"][sub_rp[1]:sub_rp[2]])
+    back = tfx.sensit_io.read_sensit(folder, 2)
+    assert back["meta"]["nmodel_components"] == 3 and back["meta"]["ndata_components"] == 3
+    assert np.array_equal(back["rowptr"], S[0]) and np.array_equal(back["cols"], S[1])
+    assert back["vals"].tobytes() == np.asarray(S[2], np.float32).tobytes()
+    assert np.array_equal(back["nnz_hist"], g["np1_sensit_nnz"])

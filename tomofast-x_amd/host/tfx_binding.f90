@@ -157,6 +157,15 @@ module tfx_binding
       real(c_float), intent(in) :: vals(*)
     end function
 
+    ! the matrix back as CSR (what the reference writes to its SENSIT files): rowptr(nrows+1) 0-based offsets, 1-based columns
+    integer(c_int) function tfx_matrix_download_csr(ctx, rowptr, cols, vals) bind(C, name="tfx_matrix_download_csr")
+      import :: c_int, c_ptr, c_float, c_int64_t, c_int32_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), intent(out) :: rowptr(*)
+      integer(c_int32_t), intent(out) :: cols(*)
+      real(c_float), intent(out) :: vals(*)
+    end function
+
     integer(c_int) function tfx_matrix_info(ctx, nrows, ncols, nnz, device_bytes) bind(C, name="tfx_matrix_info")
       import :: c_int, c_ptr, c_int64_t
       type(c_ptr), value :: ctx

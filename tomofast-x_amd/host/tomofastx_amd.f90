@@ -51,6 +51,7 @@ module tfx_host_params
     real(dp) :: beta_grad(2) = 0.d0, w_cross = 0.d0, w_clust(2) = 0.d0
     integer :: apply_local_dw = 0, apply_local_damp = 0, use_error(2) = 0, sensit_read = 0, nmodel_comp = 1, ndata_comp(2) = 1
     integer :: grav_data_type = 1
+    character(len=256) :: sensit_path = 'SENSIT/'        ! src/parameters_init.f90:296-297
   end type t_par
 
 contains
@@ -118,6 +119,7 @@ contains
       case ('forward.depthWeighting.magn.Z0');     read(val, *) par%dw_Z0(2)
       case ('forward.depthWeighting.applyLocalWeight'); read(val, *) par%apply_local_dw
       case ('sensit.readFromFiles');               read(val, *) par%sensit_read
+      case ('sensit.folderPath');                  if (len_trim(val) > 0) par%sensit_path = trim(val)
       case ('forward.matrixCompression.type');     read(val, *) par%comp_type
       case ('forward.matrixCompression.rate');     read(val, *) par%comp_rate
       case ('inversion.priorModel.type');          read(val, *) par%prior_type
@@ -162,7 +164,7 @@ contains
       case ('inversion.crossGradient.weight');     read(val, *) par%w_cross
       case ('inversion.clustering.grav.weight');   read(val, *) par%w_clust(1)
       case ('inversion.clustering.magn.weight');   read(val, *) par%w_clust(2)
-      case ('sensit.folderPath', 'inversion.writeModelEveryNiter', 'inversion.solver', &
+      case ('inversion.writeModelEveryNiter', 'inversion.solver', &
             'output.paraview.grav.modelLabel', 'output.paraview.magn.modelLabel', 'inversion.priorModel.nModels')
         continue
       case default
@@ -271,14 +273,204 @@ contains
 end module tfx_host_io
 
 !=========================================================================================================
+! Reference-compatible SENSIT files (src/forward/gravmag/sensitivity_gravmag.F90:142-153, :183, :306-309, :360-392,
+! :415-464 written; :648-883, :920-1030 read): big-endian streams like the reference's -fconvert=big-endian build.
+module tfx_host_sensit
+  use iso_c_binding
+  use tfx_binding
+  use tfx_host_params
+  implicit none
+  character(len=4), parameter :: SENSIT_SUFFIX(2) = (/'grav', 'magn'/)
+contains
+
+  ! The device matrix back as CSR, cut into the (datum, data component, model component) lines of the reference's file.
+  subroutine write_sensit_files(ctx, folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, comp_error, pw, cw)
+    type(c_ptr), intent(in) :: ctx
+    character(len=*), intent(in) :: folder
+    integer, intent(in) :: ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type
+    real(dp), intent(in) :: comp_error, pw, cw(:)
+    integer(c_int64_t) :: nrows, ncols, nnz, dbytes
+    integer(c_int64_t), allocatable :: rowptr(:)
+    integer(c_int32_t), allocatable :: cols(:), hist(:)
+    real(c_float), allocatable :: vals(:)
+    integer :: u, n, i, d, k, r
+    integer(c_int64_t) :: a, b, e, p
+    character(len=512) :: fname
+    n = nx * ny * nz
+    if (tfx_matrix_info(ctx, nrows, ncols, nnz, dbytes) /= 0) call stop_msg('tfx_matrix_info failed')
+    allocate(rowptr(nrows + 1), cols(max(nnz, 1_c_int64_t)), vals(max(nnz, 1_c_int64_t)), hist(n))
+    if (tfx_matrix_download_csr(ctx, rowptr, cols, vals) /= 0) call stop_msg('tfx_matrix_download_csr failed')
+    if (pw /= 1.d0) vals = vals / real(pw, c_float)          ! the file holds the unscaled kernel (:834-843 scales on reload)
+    call execute_command_line('mkdir -p "'//trim(folder)//'"')
+    fname = trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_1_0'
+    print *, 'Writing the sensitivity to file ', trim(fname)
+    open(newunit=u, file=trim(fname), status='replace', access='stream', form='unformatted', action='write', convert='big_endian')
+    write(u) int(nd, c_int32_t), int(nd, c_int32_t), int(n, c_int32_t), 0_c_int32_t, 1_c_int32_t          ! :183
+    hist = 0
+    r = 0
+    do i = 1, nd
+      do d = 1, ndc
+        r = r + 1
+        a = rowptr(r) + 1
+        b = rowptr(r + 1)
+        do k = 1, nc                                            ! columns (k-1)*n + cell, ascending (:829-846)
+          e = a
+          do while (e <= b)
+            if (cols(e) > k * n) exit
+            e = e + 1
+          enddo
+          write(u) int(i, c_int32_t), int(e - a, c_int32_t), int(k, c_int32_t), int(d, c_int32_t)            ! :306
+          if (e > a) then
+            do p = a, e - 1
+              cols(p) = cols(p) - (k - 1) * n
+              hist(cols(p)) = hist(cols(p)) + 1
+            enddo
+            write(u) cols(a:e - 1), vals(a:e - 1)                                                               ! :308
+          endif
+          a = e
+        enddo
+      enddo
+    enddo
+    close(u)
+    fname = trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_meta.txt'                                          ! :360-375
+    open(newunit=u, file=trim(fname), form='formatted', status='replace', action='write')
+    write(u, *) nx, ny, nz, nd
+    write(u, *) 1, 4, dw_type
+    write(u, *) comp_type, comp_error
+    write(u, *) nc, ndc
+    write(u, *) nnz
+    close(u)
+    fname = trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_nnz'                                               ! :380-392
+    open(newunit=u, file=trim(fname), status='replace', access='stream', form='unformatted', action='write', convert='big_endian')
+    write(u) int(n, c_int32_t)
+    write(u) hist
+    close(u)
+    call write_weight_file(folder, ip, n, cw)
+  end subroutine write_sensit_files
+
+  subroutine write_weight_file(folder, ip, n, cw)                                                             ! :415-464
+    character(len=*), intent(in) :: folder
+    integer, intent(in) :: ip, n
+    real(dp), intent(in) :: cw(n)
+    integer :: u
+    call execute_command_line('mkdir -p "'//trim(folder)//'"')
+    open(newunit=u, file=trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_weight', status='replace', access='stream', &
+         form='unformatted', action='write', convert='big_endian')
+    write(u) int(n, c_int32_t)
+    write(u) cw
+    close(u)
+  end subroutine write_weight_file
+
+  subroutine read_weight_file(folder, ip, n, cw)                                                              ! :920-970
+    character(len=*), intent(in) :: folder
+    integer, intent(in) :: ip, n
+    real(dp), intent(out) :: cw(n)
+    integer :: u, ios
+    integer(c_int32_t) :: nread
+    open(newunit=u, file=trim(folder)//'sensit_'//SENSIT_SUFFIX(ip)//'_weight', status='old', access='stream', &
+         form='unformatted', action='read', convert='big_endian', iostat=ios)
+    if (ios /= 0) call stop_msg('Error in opening the depth weight file! path='//trim(folder))
+    read(u) nread
+    if (nread /= n) call stop_msg('Depth weight file header does not match the Parfile!')
+    read(u) cw
+    close(u)
+  end subroutine read_weight_file
+
+  ! read_sensitivity_metadata + read_sensitivity_kernel (any number of rank files) -> CSR uploaded to the device
+  subroutine read_sensit_files(ctx, folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, pw, nnz_out)
+    type(c_ptr), intent(in) :: ctx
+    character(len=*), intent(in) :: folder
+    integer, intent(in) :: ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type
+    real(dp), intent(in) :: pw
+    integer(c_int64_t), intent(out) :: nnz_out
+    integer :: u, ios, n, rank, nbproc_sensit, precision_read, wtype, ctype, ncm_read, ncd_read, nxr, nyr, nzr, ndr
+    integer :: i, d, k, r, idata_glob
+    real(dp) :: comp_error
+    integer(c_int64_t) :: nnz_total, pos, j
+    integer(c_int32_t) :: hdr(5), desc(4)
+    integer(c_int64_t), allocatable :: rowptr(:)
+    integer(c_int32_t), allocatable :: cols(:)
+    real(c_float), allocatable :: vals(:)
+    character(len=512) :: fname
+    character(len=16) :: s1, s2
+    n = nx * ny * nz
+    fname = trim(folder)//'sensit_'//SENSIT_SUFFIX(ip)//'_meta.txt'
+    print *, 'Reading the sensitivity metadata file ', trim(fname)
+    open(newunit=u, file=trim(fname), form='formatted', status='old', action='read', iostat=ios)
+    if (ios /= 0) call stop_msg('Error in opening the sensitivity metadata file! path='//trim(fname))
+    read(u, *) nxr, nyr, nzr, ndr
+    read(u, *) nbproc_sensit, precision_read, wtype
+    read(u, *) ctype, comp_error
+    read(u, *) ncm_read, ncd_read
+    read(u, *) nnz_total
+    close(u)
+    print *, 'COMPRESSION ERROR (read) =', comp_error
+    if (nxr /= nx .or. nyr /= ny .or. nzr /= nz .or. ndr /= nd .or. wtype /= dw_type .or. ncm_read /= nc .or. ncd_read /= ndc) &
+      call stop_msg('Sensitivity metadata file info does not match the Parfile!')                            ! :1001-1006
+    if (ctype /= comp_type) call stop_msg('Compression type is inconsistent!')
+    if (precision_read /= 4) call stop_msg('Matrix precision is not consistent!')
+    allocate(rowptr(nd * ndc + 1), cols(max(nnz_total, 1_c_int64_t)), vals(max(nnz_total, 1_c_int64_t)))
+    rowptr(1) = 0
+    pos = 0
+    r = 0
+    idata_glob = 0
+    do rank = 0, nbproc_sensit - 1
+      write(s1, '(I0)') nbproc_sensit
+      write(s2, '(I0)') rank
+      fname = trim(folder)//'sensit_'//SENSIT_SUFFIX(ip)//'_'//trim(s1)//'_'//trim(s2)
+      if (rank == 0) print *, 'Reading the sensitivity file (new) ', trim(fname)
+      open(newunit=u, file=trim(fname), status='old', access='stream', form='unformatted', action='read', convert='big_endian', &
+           iostat=ios)
+      if (ios /= 0) call stop_msg('Error in opening the sensitivity file! path='//trim(fname))
+      read(u) hdr
+      if (hdr(2) /= nd .or. hdr(3) /= n .or. hdr(4) /= rank .or. hdr(5) /= nbproc_sensit) &
+        call stop_msg('Wrong file header in read_sensitivity_kernel!')                                       ! :744-747
+      do i = 1, hdr(1)
+        idata_glob = idata_glob + 1
+        do d = 1, ndc
+          r = r + 1
+          do k = 1, nc
+            read(u) desc
+            if (desc(1) /= idata_glob) call stop_msg('Wrong data index in read_sensitivity_kernel!')
+            if (desc(3) /= k) call stop_msg('Wrong model component index in read_sensitivity_kernel!')
+            if (desc(4) /= d) call stop_msg('Wrong data component index in read_sensitivity_kernel!')
+            if (pos + desc(2) > nnz_total) call stop_msg('Wrong number of elements in read_sensitivity_kernel!')
+            if (desc(2) > 0) then
+              read(u) cols(pos + 1:pos + desc(2)), vals(pos + 1:pos + desc(2))
+              do j = pos + 1, pos + desc(2)
+                cols(j) = cols(j) + (k - 1) * n                                                              ! :832
+                vals(j) = vals(j) * real(pw, c_float)                                                        ! :835-843
+              enddo
+              pos = pos + desc(2)
+            endif
+          enddo
+          rowptr(r + 1) = pos
+        enddo
+      enddo
+      close(u)
+    enddo
+    if (idata_glob /= nd .or. pos /= nnz_total) call stop_msg('The SENSIT files do not hold the whole kernel!')
+    print *, 'nnz_total (of the read kernel)  = ', nnz_total
+    if (tfx_matrix_upload_csr(ctx, int(nd * ndc, c_int64_t), int(n, c_int64_t) * nc, rowptr, cols, vals) /= 0) &
+      call stop_msg('tfx_matrix_upload_csr failed')
+    nnz_out = nnz_total
+    print *, 'Finished reading the sensitivity kernel.'
+  end subroutine read_sensit_files
+
+end module tfx_host_sensit
+
+!=========================================================================================================
 program tomofastx_amd
   use iso_c_binding
   use tfx_binding
   use tfx_host_params
   use tfx_host_io
+  use tfx_host_sensit
   implicit none
 
   type(t_par) :: par
+  character(len=256) :: envv
+  integer :: envlen, envstat
   character(len=256) :: arg, parfile
   ! output file prefixes (src/problem_joint_gravmag.F90:340-362, :554-555): 'grav_...' and 'mag_...'
   character(len=4) :: suffix(2) = (/'grav', 'mag '/)
@@ -325,7 +517,7 @@ program tomofastx_amd
     call stop_msg('Local weights / data errors are not supported by this host yet.')
   if (par%norm_power /= 2.d0) call stop_msg('inversion.modelDamping.normPower /= 2 is not supported by this host yet.')
   if (par%admm > 0 .and. par%admm_bound_type /= 1) call stop_msg('ADMM with local bounds (boundType 2) is not supported yet.')
-  if (par%sensit_read /= 0) call stop_msg('sensit.readFromFiles /= 0 is not supported by this host yet (SURVEY 8f-2).')
+  if (par%sensit_read < 0 .or. par%sensit_read > 2) call stop_msg('sensit.readFromFiles must be 0, 1 or 2.')
   ! components (src/parameters_init.f90:187-197, src/forward/gravmag/sensitivity_gravmag.F90:193-220)
   nc = 1
   if (ip == 2) nc = par%nmodel_comp
@@ -358,16 +550,24 @@ program tomofastx_amd
   call tfx_check(tfx_create(0_c_int, c_null_ptr, ctx), 'tfx_create')
   call tfx_check(tfx_set_grid(ctx, par%nx, par%ny, par%nz, X1, X2, Y1, Y2, Z1, Z2), 'tfx_set_grid')
 
-  ! ---- (II) depth weight (:174-178)
-  print *, 'Calculating the depth weight, type = ', par%dw_type
-  if (par%dw_type == 1) then
-    call tfx_check(tfx_column_weight_type1(ctx, par%dw_power(ip), par%dw_Z0(ip), par%cwm(ip), cw), 'calculate_depth_weight')
+  ! ---- (II) depth weight (:174-178, :189-193): computed, or read from the SENSIT folder
+  if (par%sensit_read == 0) then
+    print *, 'Calculating the depth weight, type = ', par%dw_type
+    if (par%dw_type == 1) then
+      call tfx_check(tfx_column_weight_type1(ctx, par%dw_power(ip), par%dw_Z0(ip), par%cwm(ip), cw), 'calculate_depth_weight')
+    else
+      call tfx_check(tfx_column_weight_type2(ctx, int(nd, c_int64_t), Xd, Yd, Zd, par%dw_power(ip), par%dw_beta(ip), par%cwm(ip), cw), &
+                     'calculate_depth_weight')
+    endif
   else
-    call tfx_check(tfx_column_weight_type2(ctx, int(nd, c_int64_t), Xd, Yd, Zd, par%dw_power(ip), par%dw_beta(ip), par%cwm(ip), cw), &
-                   'calculate_depth_weight')
+    call read_weight_file(par%sensit_path, ip, n, cw)
   endif
 
-  ! ---- (III) sensitivity kernel (:197-248)
+  ! ---- (III) sensitivity kernel (:197-248): built on the device, or re-loaded from SENSIT files
+  if (par%sensit_read == 1) then
+    call read_sensit_files(ctx, par%sensit_path, ip, par%nx, par%ny, par%nz, nd, ndc, nc, par%dw_type, par%comp_type, pw, nnz)
+    err_sum = 0.d0
+  else
   mag_ptr = c_null_ptr
   if (ip == 1) then
     print *, 'Calculating GRAVITY sensitivity kernel...'
@@ -379,6 +579,12 @@ program tomofastx_amd
   call tfx_check(tfx_build_kernel(ctx, ip, dtype, ndc, nc, int(nd, c_int64_t), Xd, Yd, Zd, cw, mag_ptr, par%comp_type, &
                                   par%comp_rate, pw, c_null_ptr, 0_c_int64_t, int(n, c_int64_t), nnz, err_sum, c_null_ptr), &
                  'calculate_and_write_sensit')
+  ! the reference always writes the kernel (calculate_and_write_sensit); TFX_WRITE_SENSIT=0 skips the download + write
+  call get_environment_variable('TFX_WRITE_SENSIT', envv, envlen, envstat)
+  if (.not. (envstat == 0 .and. envlen > 0 .and. envv(1:1) == '0')) &
+    call write_sensit_files(ctx, trim(par%path_output)//'/SENSIT', ip, par%nx, par%ny, par%nz, nd, ndc, nc, par%dw_type, &
+                            par%comp_type, err_sum / dble(nd * ndc * nc), pw, cw)
+  endif
   print *, 'nnz_total = ', nnz
   print *, 'COMPRESSION RATE = ', dble(nnz) / dble(n) / dble(nd) / dble(nc) / dble(ndc)
   print *, 'COMPRESSION ERROR, r = ', err_sum / dble(nd * ndc * nc)

@@ -18,29 +18,39 @@ SUFFIX = {1: "grav", 2: "magn"}
 
 
 def write_sensit(folder, problem_type, ctx_csr, nelements_total, grid_dims, column_weight, compression_type, comp_error,
-                 depth_weighting_type=1, nbproc=1, rank=0, row_begin=0, ndata_total=None):
-    """ctx_csr = (rowptr, cols, vals) of the rows [row_begin, row_begin + nrows) over ALL columns (1-based cols)."""
+                 depth_weighting_type=1, nbproc=1, rank=0, row_begin=0, ndata_total=None, ndata_components=1,
+                 nmodel_components=1):
+    """ctx_csr = (rowptr, cols, vals) of the matrix rows of the data [row_begin, row_begin + ndata_loc) over ALL columns
+    (1-based cols).  With several components the matrix row idata*ndata_components + d holds model component k in columns
+    k*nelements_total + cell; the file stores one line per (idata, d, k) with cell columns (sensitivity_gravmag.F90:222-311)."""
     rp, cols, vals = ctx_csr
+    ncd, ncm, N = int(ndata_components), int(nmodel_components), int(nelements_total)
     nrows = rp.size - 1
-    ndata_total = nrows if ndata_total is None else ndata_total
+    assert nrows % ncd == 0
+    ndata_loc = nrows // ncd
+    ndata_total = ndata_loc if ndata_total is None else ndata_total
     sfx = SUFFIX[problem_type]
     os.makedirs(folder, exist_ok=True)
+    cols = np.asarray(cols, np.int64)
     with open(os.path.join(folder, "sensit_%s_%d_%d" % (sfx, nbproc, rank)), "wb") as f:
-        f.write(np.array([nrows, ndata_total, nelements_total, rank, nbproc], ">i4").tobytes())
+        f.write(np.array([ndata_loc, ndata_total, N, rank, nbproc], ">i4").tobytes())
         for r in range(nrows):
             a, b = int(rp[r]), int(rp[r + 1])
-            f.write(np.array([row_begin + r + 1, b - a, 1, 1], ">i4").tobytes())
-            if b > a:
-                f.write(np.asarray(cols[a:b]).astype(">i4").tobytes())
-                f.write(np.asarray(vals[a:b]).astype(">f4").tobytes())
+            comp = (cols[a:b] - 1) // N
+            for k in range(ncm):
+                sel = np.nonzero(comp == k)[0] + a
+                f.write(np.array([row_begin + r // ncd + 1, sel.size, k + 1, r % ncd + 1], ">i4").tobytes())
+                if sel.size:
+                    f.write((cols[sel] - k * N).astype(">i4").tobytes())
+                    f.write(np.asarray(vals)[sel].astype(">f4").tobytes())
     if rank == 0:
         nx, ny, nz = grid_dims
-        hist = np.bincount(np.asarray(cols, np.int64) - 1, minlength=nelements_total).astype(np.int32)
+        hist = np.bincount((cols - 1) % N, minlength=N).astype(np.int32)
         with open(os.path.join(folder, "sensit_%s_meta.txt" % sfx), "w") as f:
             f.write(" %d %d %d %d\n" % (nx, ny, nz, ndata_total))
             f.write(" %d %d %d\n" % (nbproc, 4, depth_weighting_type))
             f.write(" %d %.17g\n" % (compression_type, comp_error))
-            f.write(" %d %d\n" % (1, 1))
+            f.write(" %d %d\n" % (ncm, ncd))
             f.write(" %d\n" % int(rp[-1]))
         with open(os.path.join(folder, "sensit_%s_nnz" % sfx), "wb") as f:
             f.write(np.array([nelements_total], ">i4").tobytes() + hist.astype(">i4").tobytes())
@@ -56,7 +66,9 @@ def read_sensit(folder, problem_type):
     nx, ny, nz, ndata = [int(v) for v in meta_txt[:4]]
     nbproc, precision, dw_type = [int(v) for v in meta_txt[4:7]]
     ctype, comp_error = int(meta_txt[7]), float(meta_txt[8])
+    ncm, ncd = int(meta_txt[9]), int(meta_txt[10])
     nnz_total = int(meta_txt[11])
+    N = nx * ny * nz
     if precision != 4:
         raise ValueError("SENSIT matrix precision %d is not the 4-byte real this path stores" % precision)
     rows = {}
@@ -66,19 +78,22 @@ def read_sensit(folder, problem_type):
         if int(hdr[1]) != ndata or int(hdr[2]) != nx * ny * nz or int(hdr[4]) != nbproc:
             raise ValueError("SENSIT file header is inconsistent with the metadata")
         off = 20
-        for _ in range(int(hdr[0])):
+        for _ in range(int(hdr[0]) * ncd * ncm):
             idata, nel, k, d = [int(v) for v in np.frombuffer(raw, ">i4", 4, off)]
             off += 16
             c = np.frombuffer(raw, ">i4", nel, off).astype(np.int32)
             off += 4 * nel
             v = np.frombuffer(raw, ">f4", nel, off).astype(np.float32)
             off += 4 * nel
-            rows[idata] = (c, v)
+            # matrix row (idata, d); model component k in columns (k-1)*N + cell (sensitivity_gravmag.F90:829-846)
+            key = (idata - 1) * ncd + d
+            pc, pv = rows.get(key, (np.zeros(0, np.int32), np.zeros(0, np.float32)))
+            rows[key] = (np.concatenate([pc, c + (k - 1) * N]).astype(np.int32), np.concatenate([pv, v]))
         if off != len(raw):
             raise ValueError("trailing bytes in SENSIT file")
-    if sorted(rows) != list(range(1, ndata + 1)):
+    if sorted(rows) != list(range(1, ndata * ncd + 1)):
         raise ValueError("SENSIT row set is incomplete")
-    order = [rows[i] for i in range(1, ndata + 1)]
+    order = [rows[i] for i in range(1, ndata * ncd + 1)]
     rowptr = np.concatenate([[0], np.cumsum([c.size for c, _ in order])]).astype(np.int64)
     if int(rowptr[-1]) != nnz_total:
         raise ValueError("nnz_total in the metadata differs from the rows read")
@@ -88,4 +103,5 @@ def read_sensit(folder, problem_type):
                 nnz_hist=np.frombuffer(z, ">i4", offset=4).astype(np.int32),
                 column_weight=np.frombuffer(w, ">f8", offset=4).astype(np.float64),
                 meta=dict(nx=nx, ny=ny, nz=nz, ndata=ndata, nbproc=nbproc, depth_weighting_type=dw_type,
+                          nmodel_components=ncm, ndata_components=ncd,
                           compression_type=ctype, comp_error=comp_error, nnz_total=nnz_total))
