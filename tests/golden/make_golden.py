@@ -631,6 +631,107 @@ def make_comp_e2e(tmp):
               "lsqr r", res["np1_lsqr_r"])
 
 
+PAR_JOINT = """global.outputFolderPath     = out/
+global.description          = golden synthetic joint grav + mag (no structural coupling)
+modelGrid.size                      = {nx} {ny} {nz}
+modelGrid.grav.file                 = grid.txt
+modelGrid.magn.file                 = grid.txt
+forward.data.grav.nData             = {ndg}
+forward.data.magn.nData             = {ndm}
+forward.data.grav.dataGridFile      = data_grid_grav.txt
+forward.data.magn.dataGridFile      = data_grid_magn.txt
+forward.data.grav.useSyntheticModelForDataValues = 1
+forward.data.magn.useSyntheticModelForDataValues = 1
+forward.data.grav.syntheticModelFile = model_true_grav.txt
+forward.data.magn.syntheticModelFile = model_true_magn.txt
+forward.magneticField.inclination          = -62.d0
+forward.magneticField.declination          = 11.d0
+forward.magneticField.intensity_nT         = 57000.d0
+forward.magneticField.XaxisDeclination     = 0.d0
+forward.depthWeighting.type         = 1
+forward.depthWeighting.grav.power   = 2.0d0
+forward.depthWeighting.magn.power   = 3.0d0
+sensit.readFromFiles                = 0
+sensit.folderPath                   = out/SENSIT/
+forward.matrixCompression.type      = {ctype}
+forward.matrixCompression.rate      = {rate}
+inversion.priorModel.type           = 1
+inversion.priorModel.grav.value     = 0.d0
+inversion.priorModel.magn.value     = 0.d0
+inversion.startingModel.type        = 1
+inversion.startingModel.grav.value  = 0.d0
+inversion.startingModel.magn.value  = 0.d0
+inversion.nMajorIterations          = {nmajor}
+inversion.nMinorIterations          = {nminor}
+inversion.writeModelEveryNiter      = 0
+inversion.minResidual               = 1.d-13
+inversion.modelDamping.grav.weight  = {alpha_g}
+inversion.modelDamping.magn.weight  = {alpha_m}
+inversion.modelDamping.normPower    = 2.0d0
+inversion.joint.grav.problemWeight  = {pwg}
+inversion.joint.magn.problemWeight  = {pwm}
+inversion.joint.grav.columnWeightMultiplier = 4.d+3
+inversion.joint.magn.columnWeightMultiplier = 1.d0
+inversion.admm.enableADMM           = 0
+"""
+
+
+def make_joint_e2e(tmp):
+    """Joint gravity + magnetic inversion: two sensitivity kernels in one LSQR system (block-diagonal S, both damping blocks),
+    no structural coupling (cross-gradient / clustering weights 0).  BASELINE config 4 at fixture size."""
+    c = dict(nx=10, ny=9, nz=6, ctype=1, rate="0.2d0", nmajor=2, nminor=80, alpha_g="1.d-7", alpha_m="1.d-9", pwg="1.d0", pwm="0.5d0")
+    g, obs_g, mtrue = synthetic_problem(c["nx"], c["ny"], c["nz"], 4, 3)
+    _, obs_m, _ = synthetic_problem(c["nx"], c["ny"], c["nz"], 3, 3)
+    obs_m = obs_m + np.array([11.0, -7.0, 0.0])            # different stations for the two surveys
+    mt = [mtrue, mtrue * 1e-4]
+    res = {}
+    for nproc in (1, 2):
+        wd = os.path.join(tmp, "joint_np%d" % nproc)
+        shutil.rmtree(wd, ignore_errors=True)
+        os.makedirs(wd)
+        write_grid_file(os.path.join(wd, "grid.txt"), g, c["nx"], c["ny"], c["nz"])
+        for tag, obs, m in (("grav", obs_g, mt[0]), ("magn", obs_m, mt[1])):
+            with open(os.path.join(wd, "data_grid_%s.txt" % tag), "w") as f:
+                f.write("%d\n" % obs.shape[0])
+                for r in obs:
+                    f.write("%.17g %.17g %.17g 0.0\n" % tuple(r))
+            with open(os.path.join(wd, "model_true_%s.txt" % tag), "w") as f:
+                f.write("%d\n" % m.size)
+                for v in m:
+                    f.write("%.17g\n" % v)
+        par = PAR_JOINT.format(ndg=obs_g.shape[0], ndm=obs_m.shape[0], **c)
+        pf = os.path.join(wd, "Parfile.txt")
+        open(pf, "w").write(par)
+        log = run([MPIEXEC, "-n", str(nproc), os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+        sd = os.path.join(wd, "out", "SENSIT")
+        o = {}
+        for ip, (tag, sfx) in enumerate((("grav", "grav"), ("magn", "mag"))):
+            if nproc == 1:
+                hdr, rows = parse_sensit(os.path.join(sd, "sensit_%s_1_0" % tag))
+                o["%s_row_ptr" % tag] = np.concatenate([[0], np.cumsum([r[1].size for r in rows])]).astype(np.int64)
+                o["%s_cols" % tag] = np.concatenate([r[1] for r in rows])
+                o["%s_vals" % tag] = np.concatenate([r[2] for r in rows])
+                o["%s_column_weight" % tag] = np.frombuffer(open(os.path.join(sd, "sensit_%s_weight" % tag), "rb").read(), ">f8", offset=4).astype(np.float64)
+                o["%s_sensit_nnz" % tag] = np.frombuffer(open(os.path.join(sd, "sensit_%s_nnz" % tag), "rb").read(), ">i4", offset=4).astype(np.int32)
+                dd = os.path.join(wd, "out", "data")
+                o["%s_data_observed" % tag] = read_tokens(os.path.join(dd, "%s_observed.txt" % sfx), 4)[:, 3]
+                o["%s_data_final" % tag] = read_tokens(os.path.join(dd, "%s_final.txt" % sfx), 4)[:, 3]
+            o["%s_model_final" % tag] = read_tokens(os.path.join(wd, "out", "model", "%s_final_model_full.txt" % sfx), 1)[:, 0]
+        o["lsqr_r"] = np.array([float(m.group(1)) for m in re.finditer(r"Finished lsqr solver, r =\s*([0-9.eE+-]+)", log)])
+        m = re.search(r"nelements_at_cpu =\s*([0-9 ]+)", log)
+        o["nelements_at_cpu"] = np.array([int(v) for v in m.group(1).split()], np.int64)
+        for kk, vv in o.items():
+            res["np%d_%s" % (nproc, kk)] = vv
+    res.update(dict(nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=0.2, nmajor=c["nmajor"], nminor=c["nminor"],
+                    alpha=np.array([1e-7, 1e-9]), pw=np.array([1.0, 0.5]), cwm=np.array([4e3, 1.0]), power=np.array([2.0, 3.0]),
+                    field=np.array([-62.0, 11.0, 0.0, 57000.0]), X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5],
+                    obs_grav=obs_g, obs_magn=obs_m, model_true_grav=mt[0], model_true_magn=mt[1], parfile=par))
+    np.savez_compressed(os.path.join(HERE, "e2e_joint.npz"), **res)
+    a, b = res["np1_grav_model_final"], res["np2_grav_model_final"]
+    print("e2e_joint.npz: lsqr r", res["np1_lsqr_r"], "partition np2", res["np2_nelements_at_cpu"],
+          "self diff grav", np.linalg.norm(a - b) / np.linalg.norm(a))
+
+
 def make_mansf(tmp):
     """BASELINE config 1.  Inputs are the reference's shipped example data (data/gravmag/mansf_slice)."""
     par = open(os.path.join(REFROOT, "parfiles", "Parfile_mansf_slice.txt")).read()

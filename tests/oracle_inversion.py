@@ -111,3 +111,54 @@ def _blocks_csr(blocks, N):
     if not blocks:
         return np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32)
     return np.concatenate(rp), np.concatenate(cs), np.concatenate(vs)
+
+
+def run_joint_inversion(problems, dims, ctype, nmajor, nminor, rmin=1e-13, lsqr=None, calc_data=None):
+    """Joint inversion of several problems on one grid without structural coupling (cross-gradient / clustering weights 0):
+    one LSQR system  [pw_1 S_1, 0; 0, pw_2 S_2; damping_1; damping_2] [x_1; x_2] = [pw_1 res_1; pw_2 res_2; ...]
+    (joint_inverse_problem.F90:393-573: block layout :712-739, right-hand side :379-387, damping per problem :448-463).
+    problems: list of dict(S=(rowptr, cols, vals) already scaled by float32(pw) like read_sensitivity_kernel :834-843,
+    cw, d_obs, pw, alpha).  lsqr / calc_data replaceable (HIP path).  Returns models, data, history."""
+    N = int(np.prod(dims))
+    P = len(problems)
+    m = [np.zeros(N) for _ in problems]
+    if lsqr is None:
+        # block-diagonal CSR: problem i occupies columns [i*N, (i+1)*N)
+        rp = [np.zeros(1, np.int64)]
+        cs, vs = [], []
+        off = 0
+        for i, pr in enumerate(problems):
+            r, c, v = pr["S"]
+            rp.append(np.asarray(r[1:], np.int64) + off)
+            off += int(r[-1])
+            cs.append(np.asarray(c, np.int64) + i * N)
+            vs.append(v)
+        Sj = (np.concatenate(rp), np.concatenate(cs).astype(np.int32), np.concatenate(vs))
+        lsqr = lambda blocks, b, niter: orc.lsqr(Sj, _blocks_csr(blocks, P * N), P * N, b, niter, rmin)[:3]
+    if calc_data is None:
+        calc_data = lambda i, model: orc.calc_data(model, problems[i]["cw"], dims, ctype, problems[i]["S"], problems[i]["pw"],
+                                                   np.ones(problems[i]["d_obs"].size))
+    d = [calc_data(i, m[i]) for i in range(P)]
+    hist = []
+    for it in range(nmajor):
+        rhs = [pr["pw"] * (pr["d_obs"] - d[i]) for i, pr in enumerate(problems)]
+        blocks = []
+        for i, pr in enumerate(problems):
+            if pr["alpha"] != 0.0:
+                md = m[i] / pr["cw"]
+                if ctype > 0:
+                    md = orc.wavelet(md, dims[0], dims[1], dims[2], ctype)
+                blk = np.zeros(P * N, np.float32)
+                blk[i * N:(i + 1) * N] = np.float32(pr["alpha"] * pr["pw"])
+                r = np.zeros(P * N)
+                r[i * N:(i + 1) * N] = -pr["alpha"] * pr["pw"] * md
+                blocks.append(blk)
+                rhs.append(r)
+        x, iters, r = lsqr(blocks, np.concatenate(rhs), nminor)
+        for i, pr in enumerate(problems):
+            xi = x[i * N:(i + 1) * N]
+            dm = orc.wavelet(xi, dims[0], dims[1], dims[2], ctype, inverse=True) if ctype > 0 else xi.copy()
+            m[i] = m[i] + dm * pr["cw"]
+            d[i] = calc_data(i, m[i])
+        hist.append(dict(iters=iters, r=r))
+    return m, d, hist

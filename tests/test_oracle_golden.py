@@ -289,3 +289,48 @@ def test_multicomponent_end_to_end(golden_dir, name):
     dref = g["np1_data_final"].ravel()
     assert np.allclose(d, dref, rtol=100 * tol, atol=10 * tol * np.abs(dref).max())
     assert np.allclose(hist[0]["r"], g["np1_lsqr_r"][0], rtol=1e-5)
+
+
+def joint_problems(g, scale=True):
+    """The two problems of e2e_joint.npz with the reference's SENSIT rows (values scaled by float32(pw) like the reload)."""
+    out = []
+    for i, tag in enumerate(("grav", "magn")):
+        pw = float(g["pw"][i])
+        vals = g["np1_%s_vals" % tag]
+        if scale:
+            vals = (vals * np.float32(pw)).astype(np.float32)
+        out.append(dict(S=(g["np1_%s_row_ptr" % tag], g["np1_%s_cols" % tag], vals), cw=g["np1_%s_column_weight" % tag],
+                        d_obs=g["np1_%s_data_observed" % tag], pw=pw, alpha=float(g["alpha"][i])))
+    return out
+
+
+def test_joint_kernels_bit_exact(golden_dir):
+    g = load(golden_dir, "e2e_joint")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    cwg = orc.column_weight_type1(grid, 2.0, 0.0, 4.0e3)
+    cwm = orc.column_weight_type1(grid, 3.0, 0.0, 1.0)
+    assert bits_equal(cwg, g["np1_grav_column_weight"]) and bits_equal(cwm, g["np1_magn_column_weight"])
+    rp, cols, vals, hist, _ = orc.build_matrix_grav(grid, dims, cwg, g["obs_grav"], 1, 0.2)
+    assert np.array_equal(rp, g["np1_grav_row_ptr"]) and bits_equal(cols, g["np1_grav_cols"]) and bits_equal(vals, g["np1_grav_vals"])
+    rp2, cols2, vals2 = orc.build_matrix_mag(grid, dims, cwm, g["obs_magn"], g["field"], 1, 0.2)
+    assert np.array_equal(rp2, g["np1_magn_row_ptr"]) and bits_equal(cols2, g["np1_magn_cols"]) and bits_equal(vals2, g["np1_magn_vals"])
+    # joint load balancing: the histograms of both kernels are added (sensitivity_gravmag.F90:598-606)
+    nel, _ = orc.partition((g["np1_grav_sensit_nnz"].astype(np.int64) + g["np1_magn_sensit_nnz"]).astype(np.int32), 2)
+    assert np.array_equal(nel, g["np2_nelements_at_cpu"])
+
+
+def test_joint_inversion_end_to_end(golden_dir):
+    """Two kernels in one LSQR system (BASELINE config 4 at fixture size) vs the reference's final models."""
+    g = load(golden_dir, "e2e_joint")
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    m, d, hist = oinv.run_joint_inversion(joint_problems(g), dims, int(g["ctype"]), int(g["nmajor"]), int(g["nminor"]))
+    for i, tag in enumerate(("grav", "magn")):
+        ref = g["np1_%s_model_final" % tag]
+        # the reference's own 1- vs 2-rank difference: 2.8e-10 (grav), 5.7e-8 (magn; its block is weighted 0.5 and damped 1e-9)
+        self_diff = np.linalg.norm(g["np2_%s_model_final" % tag] - ref) / np.linalg.norm(ref)
+        tol = max(1e-8, 3.0 * self_diff)
+        assert np.linalg.norm(m[i] - ref) <= tol * np.linalg.norm(ref), (tag, np.linalg.norm(m[i] - ref) / np.linalg.norm(ref))
+        dref = g["np1_%s_data_final" % tag]
+        assert np.allclose(d[i], dref, rtol=100 * tol, atol=10 * tol * np.abs(dref).max())
+    assert np.allclose(hist[0]["r"], g["np1_lsqr_r"][0], rtol=1e-4)
