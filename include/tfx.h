@@ -128,6 +128,13 @@ int tfx_build_kernel(tfx_ctx *ctx, int problem_type, int data_type, int ndata_co
                      int compression_type, double rate, double problem_weight, const double *data_weight, int64_t col_begin,
                      int64_t col_end, int64_t *nnz_out, double *error_sum_out, int32_t *nnz_hist_out);
 
+/* Joint inversion of two problems on one grid (gravity + magnetic, src/inversion/joint_inverse_problem.F90:712-739): slot 0 / 1
+ * selects the sensitivity matrix that tfx_build_kernel*, tfx_matrix_*, tfx_rowstore_*, tfx_spmv / tfx_spmtv and tfx_calc_data act
+ * on (default 0).  When slot 1 holds a matrix, tfx_lsqr_* solve with S = blockdiag(slot 0, slot 1): b_data = [rows of problem 1;
+ * rows of problem 2], x = [model 1; model 2] (the reference's line_start / param_shift layout), diagonal blocks and the general
+ * constraint matrix span both column blocks.  tfx_select_problem(ctx, 1) + tfx_matrix_free drops the second problem.        */
+int tfx_select_problem(tfx_ctx *ctx, int slot);
+
 /* Alternative to building: upload a CSR (what read_sensitivity_kernel assembles from SENSIT files;
  * t_sparse_matrix add_row/new_row/finalize, src/inversion/sparse_matrix.f90:213-293).  rowptr: nrows+1
  * 0-based offsets; cols 1-based local column indices in [1, ncols], ascending within a row.                 */

@@ -711,6 +711,73 @@ def test_multicomponent_dense_and_column_range(ctx):
             assert bits_equal(vals2[rp2[r]:rp2[r + 1]], v[keep]), r
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# joint inversion: two kernels, one LSQR system (BASELINE config 4 at fixture size)
+def build_joint(ctx, g, matrix):
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    N = int(np.prod(dims))
+    ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    probs = []
+    for i, tag in enumerate(("grav", "magn")):
+        cw = g["np1_%s_column_weight" % tag]
+        pw = float(g["pw"][i])
+        obs = g["obs_%s" % tag]
+        ctx.select_problem(i)
+        if matrix == "built":
+            ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, int(g["ctype"]), float(g["rate"]), problem_weight=pw,
+                                 mag_field=g["field"] if i == 1 else None)
+        else:
+            vals = (g["np1_%s_vals" % tag] * np.float32(pw)).astype(np.float32)
+            ctx.matrix_upload_csr(obs.shape[0], N, g["np1_%s_row_ptr" % tag], g["np1_%s_cols" % tag], vals)
+        probs.append(dict(column_weight=cw, data_obs=g["np1_%s_data_observed" % tag], problem_weight=pw, alpha=float(g["alpha"][i])))
+    ctx.select_problem(0)
+    return dims, N, probs
+
+
+@pytest.mark.parametrize("matrix", ["reference", "built"])
+def test_joint_inversion_vs_reference(ctx, golden_dir, matrix):
+    g = load(golden_dir, "e2e_joint")
+    try:
+        dims, N, probs = build_joint(ctx, g, matrix)
+        assert ctx.system_dims() == (g["obs_grav"].shape[0] + g["obs_magn"].shape[0], 2 * N)
+        m, d, hist = tfx.inversion.solve_problem_joint(ctx, probs, int(g["ctype"]), int(g["nmajor"]), int(g["nminor"]))
+        for i, tag in enumerate(("grav", "magn")):
+            ref = g["np1_%s_model_final" % tag]
+            self_diff = np.linalg.norm(g["np2_%s_model_final" % tag] - ref) / np.linalg.norm(ref)
+            tol = max(1e-6, (10.0 if matrix == "reference" else 100.0) * self_diff)
+            assert np.linalg.norm(m[i] - ref) <= tol * np.linalg.norm(ref), (tag, np.linalg.norm(m[i] - ref) / np.linalg.norm(ref))
+            dref = g["np1_%s_data_final" % tag]
+            assert np.linalg.norm(d[i] - dref) <= 10 * tol * np.linalg.norm(dref)
+        assert np.allclose(hist[0]["r"], g["np1_lsqr_r"][0], rtol=0.5) or hist[0]["r"] < 1e-9
+    finally:
+        ctx.select_problem(1)
+        ctx.matrix_free()
+        ctx.select_problem(0)
+
+
+def test_joint_products_are_block_diagonal(ctx, golden_dir):
+    """LSQR on blockdiag(S1, S2) with zero right-hand side in one block leaves that block's unknowns at zero, and equals the
+    single-problem solve of the other block."""
+    g = load(golden_dir, "e2e_joint")
+    try:
+        dims, N, probs = build_joint(ctx, g, "reference")
+        nd1, nd2 = g["obs_grav"].shape[0], g["obs_magn"].shape[0]
+        b = np.concatenate([probs[0]["data_obs"], np.zeros(nd2)])
+        xj, itj, rj = ctx.lsqr_solve_sensit(b, 30, 1e-13)
+        assert np.all(xj[N:] == 0.0)
+        ctx.select_problem(1)
+        ctx.matrix_free()
+        ctx.select_problem(0)
+        xs, its, rs = ctx.lsqr_solve_sensit(probs[0]["data_obs"], 30, 1e-13)
+        assert its == itj and np.linalg.norm(xs - xj[:N]) <= 1e-9 * np.linalg.norm(xs)
+    finally:
+        ctx.select_problem(1)
+        try:
+            ctx.matrix_free()
+        finally:
+            ctx.select_problem(0)
+
+
 def test_config1_mansf_end_to_end(ctx, golden_dir):
     """BASELINE config 1 (parfiles/Parfile_mansf_slice.txt: 2x128x32 cells, 256 obs, Haar 0.15, ADMM, 60 x 100 LSQR
     iterations) entirely on the HIP path vs the reference's final model."""

@@ -104,6 +104,17 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
     return fail(TFX_E_ARG, "unknown debug key %s", key);
 }
 
+// Joint inversion (two problems on one grid): slot 0 / 1 selects which sensitivity matrix the build / upload / download / info /
+// free / product / calc_data entry points act on; LSQR solves with S = blockdiag(slot 0, slot 1) when slot 1 holds a matrix.
+int tfx_select_problem(tfx_ctx *ctx, int slot)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    if (slot != 0 && slot != 1) return fail(TFX_E_ARG, "tfx_select_problem: slot must be 0 or 1");
+    ctx->slot = slot;
+    ctx->target = &ctx->selmat();
+    return 0;
+}
+
 // ---- matrix upload / download ------------------------------------------------------------------------------
 static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_t ncols, const int64_t *rowptr,
                            const int32_t *cols, const float *vals, bool require_ascending);
@@ -112,7 +123,7 @@ int tfx_matrix_upload_csr(tfx_ctx *ctx, int64_t nrows, int64_t ncols, const int6
                           const float *vals)
 {
     if (!ctx || !rowptr) return fail(TFX_E_ARG, "tfx_matrix_upload_csr: null argument");
-    return upload_csr_into(ctx, ctx->mat, nrows, ncols, rowptr, cols, vals, true);
+    return upload_csr_into(ctx, ctx->selmat(), nrows, ncols, rowptr, cols, vals, true);
 }
 
 // General constraint rows (matrix_cons of joint_inverse_problem.F90:332,544): same storage and kernels as S.
@@ -121,7 +132,7 @@ int tfx_cons_upload_csr(tfx_ctx *ctx, int64_t nrows, const int64_t *rowptr, cons
 {
     if (!ctx || !rowptr || !rhs) return fail(TFX_E_ARG, "tfx_cons_upload_csr: null argument");
     if (!ctx->mat.valid) return fail(TFX_E_STATE, "tfx_cons_upload_csr: upload / build S first (it defines ncolumns)");
-    TFX_TRY(upload_csr_into(ctx, ctx->cons, nrows, ctx->mat.ncols, rowptr, cols, vals, true));
+    TFX_TRY(upload_csr_into(ctx, ctx->cons, nrows, ctx->total_cols(), rowptr, cols, vals, true));
     TFX_TRY(ctx->cons_rhs.ensure((size_t)nrows));
     TFX_TRY(copy_any(ctx->cons_rhs.p, rhs, (size_t)nrows * sizeof(double), ctx->stream));
     return 0;
@@ -147,7 +158,7 @@ static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_
     struct Retarget {
         tfx_ctx *c;
         Retarget(tfx_ctx *cc, TiledMatrix *t) : c(cc) { c->target = t; }
-        ~Retarget() { c->target = &c->mat; }
+        ~Retarget() { c->target = &c->selmat(); }
     } retarget(ctx, &dst);
     if (ncols > 0x7fffffffLL || nrows > 0x7fffffffLL) return fail(TFX_E_ARG, "matrix dimension exceeds int32");
     TFX_HIP(hipSetDevice(ctx->device));
@@ -204,11 +215,12 @@ static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_
 int tfx_matrix_info(tfx_ctx *ctx, int64_t *nrows, int64_t *ncols, int64_t *nnz, int64_t *device_bytes)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
-    if (!ctx->mat.valid) return fail(TFX_E_STATE, "no matrix");
-    if (nrows) *nrows = ctx->mat.nrows;
-    if (ncols) *ncols = ctx->mat.ncols;
-    if (nnz) *nnz = ctx->mat.nnz;
-    if (device_bytes) *device_bytes = (int64_t)ctx->mat.device_bytes();
+    const TiledMatrix &m = ctx->selmat();
+    if (!m.valid) return fail(TFX_E_STATE, "no matrix");
+    if (nrows) *nrows = m.nrows;
+    if (ncols) *ncols = m.ncols;
+    if (nnz) *nnz = m.nnz;
+    if (device_bytes) *device_bytes = (int64_t)m.device_bytes();
     return 0;
 }
 
@@ -216,7 +228,7 @@ int tfx_matrix_info(tfx_ctx *ctx, int64_t *nrows, int64_t *ncols, int64_t *nnz, 
 int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float *vals)
 {
     if (!ctx || !rowptr) return fail(TFX_E_ARG, "null argument");
-    TiledMatrix &m = ctx->mat;
+    TiledMatrix &m = ctx->selmat();
     if (!m.valid) return fail(TFX_E_STATE, "no matrix");
     TFX_HIP(hipSetDevice(ctx->device));
     if (m.is_dense) {                       // every entry is a stored entry (sensitivity_gravmag.F90:287-295)
@@ -283,7 +295,7 @@ int tfx_matrix_free(tfx_ctx *ctx)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     (void)hipStreamSynchronize(ctx->stream);
-    TiledMatrix &m = ctx->mat;
+    TiledMatrix &m = ctx->selmat();
     m.codes.release(); m.vals.release(); m.chunk_row0.release(); m.tiles.release(); m.fwd.release(); m.adj.release();
     m.fwd_order.release(); m.adj_order.release(); m.fwd_partial.release(); m.adj_partial.release();
     m.fwd_nslots.release(); m.fwd_pbase.release(); m.adj_nslots.release(); m.adj_pbase.release();
@@ -341,7 +353,7 @@ static bool is_device_ptr(const void *p)
 int tfx_spmv(tfx_ctx *ctx, const double *x, double *b, int add)
 {
     if (!ctx || !x || !b) return fail(TFX_E_ARG, "tfx_spmv: null argument");
-    TiledMatrix &m = ctx->mat;
+    TiledMatrix &m = ctx->selmat();
     if (!m.valid) return fail(TFX_E_STATE, "tfx_spmv: no matrix");
     TFX_HIP(hipSetDevice(ctx->device));
     const double *dx = x;
@@ -365,7 +377,7 @@ int tfx_spmv(tfx_ctx *ctx, const double *x, double *b, int add)
 int tfx_spmtv(tfx_ctx *ctx, const double *x, double *b, int add)
 {
     if (!ctx || !x || !b) return fail(TFX_E_ARG, "tfx_spmtv: null argument");
-    TiledMatrix &m = ctx->mat;
+    TiledMatrix &m = ctx->selmat();
     if (!m.valid) return fail(TFX_E_STATE, "tfx_spmtv: no matrix");
     TFX_HIP(hipSetDevice(ctx->device));
     const double *dx = x;

@@ -1665,7 +1665,8 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     // at least)
     const int64_t lines_cap = std::max<int64_t>(1, std::min<int64_t>(32, (int64_t)(1u << 28) / N));
     const int ob_max = (int)std::max<int64_t>(1, lines_cap / nsub);
-    TiledMatrix &m = ctx->mat;
+    TiledMatrix &m = ctx->selmat();
+    ctx->target = &m;
     if (keep_matrix && compression_type == 0) {
         // No compression (sensitivity_gravmag.F90:287-295): every column is stored -> dense fp32 block, no index stream.
         TFX_TRY(matrix_begin_dense(ctx, nrows_m, ncm * ncols));
@@ -1948,7 +1949,7 @@ int tfx_matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upp
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     TFX_HIP(hipSetDevice(ctx->device));
-    ctx->target = &ctx->mat;
+    ctx->target = &ctx->selmat();
     return matrix_begin(ctx, nrows, ncols, nnz_upper);
 }
 
@@ -1969,19 +1970,19 @@ int tfx_matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const in
     TFX_TRY(dof.alloc((size_t)nr));
     TFX_HIP(hipMemcpyAsync(dn.p, nel_host, (size_t)nr * sizeof(int32_t), hipMemcpyHostToDevice, s));
     TFX_HIP(hipMemcpyAsync(dof.p, ho.data(), (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    ctx->target = &ctx->mat;
+    ctx->target = &ctx->selmat();
     TFX_TRY(matrix_append_rows(ctx, row_begin, nr, cols_dev, vals_dev, dn.p, dof.p, maxlen));
-    ctx->mat.nnz += run;
+    ctx->selmat().nnz += run;
     return 0;
 }
 
 int tfx_matrix_finish(tfx_ctx *ctx)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
-    ctx->target = &ctx->mat;
-    const int64_t nnz = ctx->mat.nnz;
+    ctx->target = &ctx->selmat();
+    const int64_t nnz = ctx->selmat().nnz;
     TFX_TRY(matrix_finish(ctx));
-    ctx->mat.nnz = nnz;
+    ctx->selmat().nnz = nnz;
     return 0;
 }
 

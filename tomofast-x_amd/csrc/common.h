@@ -141,6 +141,11 @@ struct tfx_ctx {
     bool force_general_prism = false; // tests: always use the six-array kernel
     // matrix S and (optional) general constraint matrix C
     tfx::TiledMatrix mat;
+    tfx::TiledMatrix mat2;             // second problem of a joint inversion: S = blockdiag(mat, mat2)  (joint_inverse_problem.F90:712-739)
+    int slot = 0;                      // which of the two the matrix-level entry points act on (tfx_select_problem)
+    tfx::TiledMatrix &selmat() { return slot ? mat2 : mat; }
+    int64_t total_rows() const { return mat.nrows + (mat2.valid ? mat2.nrows : 0); }
+    int64_t total_cols() const { return mat.ncols + (mat2.valid ? mat2.ncols : 0); }
     tfx::TiledMatrix cons;
     tfx::DBuf<double> cons_rhs;        // right-hand side of the C rows (replicated)
     tfx::TiledMatrix *target = &mat;   // which matrix matrix_begin / append / finish assemble

@@ -216,6 +216,22 @@ static inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::mi
 
 #define LAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(RED_THREADS), 0, s, __VA_ARGS__)
 
+// S = blockdiag(slot 0, slot 1): the second problem of a joint inversion owns the rows after the first problem's data and the
+// columns after its model (joint_inverse_problem.F90:712-739: line_start / param_shift)
+static int S_forward(tfx_ctx *ctx, const double *x, double *b, int add)
+{
+    TFX_TRY(spmv_dev(ctx, ctx->mat, x, b, add));
+    if (ctx->mat2.valid) TFX_TRY(spmv_dev(ctx, ctx->mat2, x + ctx->mat.ncols, b + ctx->mat.nrows, add));
+    return 0;
+}
+
+static int S_adjoint(tfx_ctx *ctx, const double *x, double *b, int add)
+{
+    TFX_TRY(spmtv_dev(ctx, ctx->mat, x, b, add));
+    if (ctx->mat2.valid) TFX_TRY(spmtv_dev(ctx, ctx->mat2, x + ctx->mat.nrows, b + ctx->mat.ncols, add));
+    return 0;
+}
+
 static int allreduce(tfx_ctx *ctx, double *buf, int64_t n)
 {
     if (ctx->nranks <= 1 || !ctx->allreduce) return 0;
@@ -257,11 +273,11 @@ static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L)
 {
     hipStream_t s = ctx->stream;
     if (ctx->spatial_unknowns) {                                         // lsqr_solver2.F90:137-145, :228-236
-        TFX_TRY(spmtv_dev(ctx, L->u.p, L->tw.p, 0));
+        TFX_TRY(S_adjoint(ctx, L->u.p, L->tw.p, 0));
         TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, 2));
         LAUNCH(k_axpy1, grid_for(L->ncols), L->v.p, L->tw.p, L->ncols);
     } else {
-        TFX_TRY(spmtv_dev(ctx, L->u.p, L->v.p, 1));
+        TFX_TRY(S_adjoint(ctx, L->u.p, L->v.p, 1));
     }
     if (ctx->cons.valid) TFX_TRY(spmtv_dev(ctx, ctx->cons, L->u.p + L->nrows_data, L->v.p, 1));     // lsqr_solver2.F90:147, :238
     const int g = grid_for(L->ncols);
@@ -306,11 +322,12 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     LsqrState *L = ctx->lsqr;
     hipStream_t s = ctx->stream;
     const bool have_cons = ctx->cons.valid;
-    if (have_cons && ctx->cons.ncols != m.ncols) return fail(TFX_E_STATE, "constraint matrix has %lld columns, S has %lld",
-                                                             (long long)ctx->cons.ncols, (long long)m.ncols);
-    L->nrows_data = m.nrows;
-    L->nrows = m.nrows + (have_cons ? ctx->cons.nrows : 0);
-    L->ncols = m.ncols;
+    const int64_t s_rows = ctx->total_rows(), s_cols = ctx->total_cols();       // both problems of a joint inversion
+    if (have_cons && ctx->cons.ncols != s_cols) return fail(TFX_E_STATE, "constraint matrix has %lld columns, S has %lld",
+                                                            (long long)ctx->cons.ncols, (long long)s_cols);
+    L->nrows_data = s_rows;
+    L->nrows = s_rows + (have_cons ? ctx->cons.nrows : 0);
+    L->ncols = s_cols;
     L->nblocks = nblocks;
     L->rmin = rmin;
     L->gamma = gamma;
@@ -410,9 +427,9 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
             if (ctx->spatial_unknowns) {                                                  // :171-176
                 LAUNCH(k_copy, grid_for(nc), L->tw.p, L->x.p, nc);
                 TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, 1));
-                TFX_TRY(spmv_dev(ctx, L->tw.p, L->sx.p, 0));
+                TFX_TRY(S_forward(ctx, L->tw.p, L->sx.p, 0));
             } else
-            TFX_TRY(spmv_dev(ctx, L->x.p, L->sx.p, 0));
+            TFX_TRY(S_forward(ctx, L->x.p, L->sx.p, 0));
             TFX_TRY(allreduce(ctx, L->sx.p, nd));
             const int g = grid_for(nd);
             LAUNCH(k_misfit, g, L->sx.p, L->b0.p, nd, L->red.p);
@@ -425,9 +442,9 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
         if (ctx->spatial_unknowns) {                                                      // :200-209
             LAUNCH(k_copy, grid_for(nc), L->tw.p, L->v.p, nc);
             TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, 1));
-            TFX_TRY(spmv_dev(ctx, L->tw.p, L->u.p, 1));
+            TFX_TRY(S_forward(ctx, L->tw.p, L->u.p, 1));
         } else {
-            TFX_TRY(spmv_dev(ctx, L->v.p, L->u.p, 1));
+            TFX_TRY(S_forward(ctx, L->v.p, L->u.p, 1));
         }
         if (ctx->cons.valid) TFX_TRY(spmv_dev(ctx, ctx->cons, L->v.p, L->u.p + L->nrows_data, 1));   // :211 (general C rows)
         {                                                                                 // :211 (diagonal blocks, local)
@@ -482,7 +499,7 @@ int tfx_calc_data(tfx_ctx *ctx, const double *xw_local, double problem_weight, c
                   double *data_calc)
 {
     if (!ctx || !xw_local || !data_calc) return fail(TFX_E_ARG, "tfx_calc_data: null argument");
-    TiledMatrix &m = ctx->mat;
+    TiledMatrix &m = ctx->selmat();        // the selected problem: part_mult_vector with its line_start / param_shift
     if (!m.valid) return fail(TFX_E_STATE, "tfx_calc_data: no matrix");
     if (problem_weight == 0.0) return fail(TFX_E_NUMERIC, "Zero problem weight in model_calculate_data!");
     TFX_HIP(hipSetDevice(ctx->device));

@@ -675,13 +675,13 @@ static void prof_end(tfx_ctx *ctx, int which)
     ctx->prof_n[which] += 1;
 }
 
-int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spmv_dev(ctx, ctx->mat, d_x, d_b, add); }
-int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spmtv_dev(ctx, ctx->mat, d_x, d_b, add); }
+int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spmv_dev(ctx, ctx->selmat(), d_x, d_b, add); }
+int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spmtv_dev(ctx, ctx->selmat(), d_x, d_b, add); }
 
 int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add)
 {
     if (!m.valid) return fail(TFX_E_STATE, "spmv: no matrix");
-    const bool prof = (&m == &ctx->mat);
+    const bool prof = (&m == &ctx->mat || &m == &ctx->mat2);
     if (m.is_dense) {
         hipStream_t s = ctx->stream;
         const int nchunks = (int)((m.ncols + DN_CHUNK - 1) / DN_CHUNK);
@@ -713,7 +713,7 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
 int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add)
 {
     if (!m.valid) return fail(TFX_E_STATE, "spmtv: no matrix");
-    const bool prof = (&m == &ctx->mat);
+    const bool prof = (&m == &ctx->mat || &m == &ctx->mat2);
     if (m.is_dense) {
         hipStream_t s = ctx->stream;
         if (!add) TFX_HIP(hipMemsetAsync(d_b, 0, (size_t)m.ncols * sizeof(double), s));

@@ -85,3 +85,58 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
         if log:
             log("it %d: lsqr iters %d r %.6e data cost %.6e" % (it, iters, r, cost))
     return m, d_calc, hist
+
+
+def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e-13, gamma=0.0, target_misfit=0.0, log=None):
+    """Joint inversion of two problems on one grid (gravity + magnetic) without structural coupling: both sensitivity
+    kernels in ONE LSQR system, S = blockdiag(slot 0, slot 1) (src/inversion/joint_inverse_problem.F90:393-573; block layout
+    :712-739, right-hand side :379-387, one damping block per problem :448-463).  Coupling constraints built on the host
+    (cross-gradient, clustering) enter through ctx.cons_upload_csr over both column blocks.
+
+    problems: two dicts(column_weight, data_obs, problem_weight, alpha[, model_start, model_prior]); slot i of ctx holds
+    problem i's kernel, built with its problem_weight.  Returns (models, data_calc, history)."""
+    nx, ny, nz = ctx.dims
+    N = nx * ny * nz
+    P = len(problems)
+    if P != 2:
+        raise ValueError("two problems (gravity, magnetic)")
+    cw = [np.asarray(p["column_weight"], np.float64) for p in problems]
+    pw = [float(p["problem_weight"]) for p in problems]
+    m = [np.zeros(N) if p.get("model_start") is None else np.array(p["model_start"], np.float64) for p in problems]
+    mp = [np.zeros(N) if p.get("model_prior") is None else np.asarray(p["model_prior"], np.float64) for p in problems]
+
+    def to_wavelet(v):
+        return ctx.forward_wavelet(v, nx, ny, nz, compression_type) if compression_type > 0 else v
+
+    def calculate_data(i):                            # model.F90:242-305 on problem i's rows / columns
+        ctx.select_problem(i)
+        try:
+            return ctx.calc_data(to_wavelet(np.where(cw[i] != 0.0, m[i] / cw[i], 0.0)), pw[i], None)
+        finally:
+            ctx.select_problem(0)
+
+    d = [calculate_data(i) for i in range(P)]
+    hist = []
+    for it in range(1, nmajor + 1):
+        b_data = np.concatenate([pw[i] * (np.asarray(problems[i]["data_obs"], np.float64) - d[i]) for i in range(P)])
+        diag, rhs = [], []
+        for i, p in enumerate(problems):
+            if p.get("alpha", 0.0) != 0.0:            # damping block of problem i: its column block only (:448-463)
+                md = to_wavelet((m[i] - mp[i]) / cw[i])
+                blk = np.zeros(P * N, np.float32)
+                blk[i * N:(i + 1) * N] = np.float32(p["alpha"] * pw[i])
+                r = np.zeros(P * N)
+                r[i * N:(i + 1) * N] = -p["alpha"] * pw[i] * md
+                diag.append(blk)
+                rhs.append(r)
+        x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
+        for i in range(P):
+            xi = x[i * N:(i + 1) * N]
+            dm = ctx.inverse_wavelet(xi, nx, ny, nz, compression_type) if compression_type > 0 else xi
+            m[i] = m[i] + dm * cw[i]                  # joint_inverse_problem.F90:559-571
+            d[i] = calculate_data(i)
+        costs = [float(np.linalg.norm(d[i] - problems[i]["data_obs"]) / np.linalg.norm(problems[i]["data_obs"])) for i in range(P)]
+        hist.append(dict(it=it, iters=iters, r=r, costs=costs))
+        if log:
+            log("it %d: lsqr iters %d r %.6e data costs %s" % (it, iters, r, costs))
+    return m, d, hist

@@ -21,7 +21,7 @@ TFX_E = {-1: "TFX_E_ARG", -2: "TFX_E_HIP", -3: "TFX_E_GEOMETRY", -4: "TFX_E_STAT
 SYMBOLS = [
     "tfx_create", "tfx_destroy", "tfx_last_error", "tfx_device_info", "tfx_set_allreduce", "tfx_set_grid",
     "tfx_column_weight_type1", "tfx_column_weight_type2", "tfx_prism_rows_gz", "tfx_prism_rows_mag", "tfx_prism_rows", "tfx_wavelet", "tfx_compress_row",
-    "tfx_build_kernel_grav", "tfx_build_kernel_mag", "tfx_build_kernel",
+    "tfx_build_kernel_grav", "tfx_build_kernel_mag", "tfx_build_kernel", "tfx_select_problem",
     "tfx_matrix_upload_csr", "tfx_matrix_info", "tfx_matrix_download_csr", "tfx_matrix_free",
     "tfx_cons_upload_csr", "tfx_cons_clear", "tfx_rowstore_build", "tfx_rowstore_build_ex", "tfx_rowstore_counts", "tfx_rowstore_pack",
     "tfx_rowstore_free", "tfx_matrix_begin", "tfx_matrix_append_rows", "tfx_matrix_finish",

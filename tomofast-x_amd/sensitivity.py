@@ -185,6 +185,30 @@ class Context:
                                                  C.c_int64(c1), C.byref(nnz), C.byref(err), ptr(hist)))
         return dict(nnz=nnz.value, error_sum=err.value, comp_error=err.value / xd.size, nnz_hist=hist)
 
+    # ---- joint inversion: which of the two problems the matrix-level calls act on (LSQR uses both once slot 1 holds a matrix)
+    def select_problem(self, slot):
+        check(self._lib.tfx_select_problem(self._h, int(slot)))
+        self._slot = int(slot)
+
+    def system_dims(self):
+        """(rows, columns) of the LSQR system matrix S = blockdiag(problem 0, problem 1)."""
+        cur = getattr(self, "_slot", 0)
+        nr = nc = 0
+        try:
+            for slot in (0, 1):
+                self.select_problem(slot)
+                try:
+                    info = self.matrix_info()
+                except TfxError:
+                    if slot == 0:
+                        raise
+                    continue
+                nr += info["nrows"]
+                nc += info["ncols"]
+        finally:
+            self.select_problem(cur)
+        return nr, nc
+
     # ---- row store / piecewise assembly (multi-GPU build, distributed.build_partitioned)
     ROW_BLOCK = 2048
 
@@ -309,12 +333,12 @@ class Context:
         return nb, dp, rp, keep
 
     def lsqr_solve_sensit(self, b_data, niter, rmin=1e-13, gamma=0.0, target_misfit=0.0, diag_blocks=(), rhs_blocks=()):
-        info = self.matrix_info()
+        nrows, ncols = self.system_dims()
         b = f64(b_data)
-        if b.size != info["nrows"]:
+        if b.size != nrows:
             raise ValueError("Wrong matrix sizes in lsqr_solve_sensit!")
-        nb, dp, rp, keep = self._blocks(diag_blocks, rhs_blocks, info["ncols"])
-        x = np.empty(info["ncols"])
+        nb, dp, rp, keep = self._blocks(diag_blocks, rhs_blocks, ncols)
+        x = np.empty(ncols)
         it = C.c_int()
         r = C.c_double()
         check(self._lib.tfx_lsqr_solve(self._h, int(niter), C.c_double(rmin), C.c_double(gamma), C.c_double(target_misfit), ptr(b),
@@ -327,9 +351,8 @@ class Context:
         check(self._lib.tfx_lsqr_set_wavelet_domain(self._h, int(bool(wavelet_domain)), n1, n2, n3, int(wavelet_type)))
 
     def lsqr_begin(self, b_data, rmin=1e-13, gamma=0.0, target_misfit=0.0, diag_blocks=(), rhs_blocks=()):
-        info = self.matrix_info()
         b = f64(b_data)
-        nb, dp, rp, keep = self._blocks(diag_blocks, rhs_blocks, info["ncols"])
+        nb, dp, rp, keep = self._blocks(diag_blocks, rhs_blocks, self.system_dims()[1])
         check(self._lib.tfx_lsqr_begin(self._h, C.c_double(rmin), C.c_double(gamma), C.c_double(target_misfit), ptr(b), nb, dp, rp))
 
     def lsqr_iterate(self, k):
@@ -339,7 +362,7 @@ class Context:
         return done.value, r.value
 
     def lsqr_end(self):
-        x = np.empty(self.matrix_info()["ncols"])
+        x = np.empty(self.system_dims()[1])
         check(self._lib.tfx_lsqr_end(self._h, ptr(x)))
         return x
 
