@@ -136,3 +136,88 @@ def test_row_parallel_build_with_relayout(world):
         p.join(60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def _worker_joint(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tfx = importlib.import_module("tomofast-x_amd")
+        import oracle_lib as orc
+        import multirank_model as mm
+        g = np.load(os.path.join(GOLDEN, "e2e_joint.npz"))
+        dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+        N = int(np.prod(dims))
+        nel = g["np2_nelements_at_cpu"]                       # the reference's joint 2-rank partition (both histograms added)
+        c0 = int(nel[:rank].sum())
+        c1 = c0 + int(nel[rank])
+        nloc = c1 - c0
+        ctx = tfx.Context(0)
+        ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+        hook = tfx.distributed.TorchAllreduce(0)
+        ctx.set_allreduce(hook, rank, world)
+        S = []
+        for i, tag in enumerate(("grav", "magn")):
+            vals = (g["np1_%s_vals" % tag] * np.float32(g["pw"][i])).astype(np.float32)
+            Sf = (g["np1_%s_row_ptr" % tag], g["np1_%s_cols" % tag], vals)
+            S.append(Sf)
+            ctx.select_problem(i)
+            ctx.matrix_upload_csr(Sf[0].size - 1, nloc, *mm.column_slice(Sf, c0, c1))
+        ctx.select_problem(0)
+        nd = [S[0][0].size - 1, S[1][0].size - 1]
+        assert ctx.system_dims() == (nd[0] + nd[1], 2 * nloc)
+        rng = np.random.default_rng(11)
+        b = rng.standard_normal(nd[0] + nd[1])
+        alpha = [np.float32(3e-9), np.float32(7e-10)]
+        rhs_full = rng.standard_normal(2 * N) * 1e-10
+        # local unknowns [m1_loc; m2_loc]; one damping block per problem over its own column block
+        diag, rhs = [], []
+        for i in range(2):
+            dblk = np.zeros(2 * nloc, np.float32)
+            dblk[i * nloc:(i + 1) * nloc] = alpha[i]
+            r = np.zeros(2 * nloc)
+            r[i * nloc:(i + 1) * nloc] = rhs_full[i * N + c0:i * N + c1]
+            diag.append(dblk)
+            rhs.append(r)
+        x_loc, it, r = ctx.lsqr_solve_sensit(b, 12, 1e-13, 0.0, 0.0, diag, rhs)
+        # single-rank oracle on blockdiag(S1, S2) with the same two diagonal blocks
+        rp = np.concatenate([S[0][0], S[1][0][1:] + S[0][0][-1]])
+        Sj = (rp, np.concatenate([S[0][1], S[1][1] + N]).astype(np.int32), np.concatenate([S[0][2], S[1][2]]))
+        d1 = np.zeros(2 * N, np.float32); d1[:N] = alpha[0]
+        d2 = np.zeros(2 * N, np.float32); d2[N:] = alpha[1]
+        c1m, c2m = orc.diag_csr(d1), orc.diag_csr(d2)
+        Cm = (np.concatenate([c1m[0], c2m[0][1:] + c1m[0][-1]]), np.concatenate([c1m[1], c2m[1]]), np.concatenate([c1m[2], c2m[2]]))
+        z = np.zeros(N)                                                # block b has 2N rows, non-empty only in its own column block
+        rhs_rows = np.concatenate([rhs_full[:N], z, z, rhs_full[N:]])
+        x_ref, it_ref, r_ref = orc.lsqr(Sj, Cm, 2 * N, np.concatenate([b, rhs_rows]), 12)
+        want = np.concatenate([x_ref[c0:c1], x_ref[N + c0:N + c1]])
+        assert it == it_ref == 12
+        err = np.linalg.norm(x_loc - want) / np.linalg.norm(x_ref)
+        assert err <= 1e-6, err
+        ctx.close()
+        q.put((rank, "ok"))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_joint_system_two_ranks():
+    """Joint system blockdiag(S_grav, S_magn) column-partitioned over 2 ranks (each rank holds its cell range of BOTH kernels,
+    like the reference's nelements_at_cpu for joint inversion) vs the single-rank oracle."""
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29700 + os.getpid() % 2000
+    procs = [ctxm.Process(target=_worker_joint, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)

@@ -147,6 +147,14 @@ module tfx_binding
       real(c_double), intent(out) :: rows(*)
     end function
 
+    ! joint inversion: slot 0 / 1 = which problem's sensitivity matrix the build / matrix / product / calc_data calls act on;
+    ! LSQR solves with blockdiag(slot 0, slot 1) once slot 1 holds a matrix (src/inversion/joint_inverse_problem.F90:712-739)
+    integer(c_int) function tfx_select_problem(ctx, slot) bind(C, name="tfx_select_problem")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: slot
+    end function
+
     ! t_sparse_matrix add_row/new_row/finalize (src/inversion/sparse_matrix.f90:213-293)
     integer(c_int) function tfx_matrix_upload_csr(ctx, nrows, ncols, rowptr, cols, vals) bind(C, name="tfx_matrix_upload_csr")
       import :: c_int, c_ptr, c_float, c_int64_t, c_int32_t
