@@ -224,6 +224,43 @@ def test_sensit_files_written_like_the_reference_and_reloaded(tmp_path, golden_d
     assert np.linalg.norm(model - refm) <= tol * np.linalg.norm(refm), (np.linalg.norm(model - refm) / np.linalg.norm(refm), self_diff)
 
 
+def test_joint_parfile_matches_reference_outputs(tmp_path, golden_dir):
+    """Joint gravity + magnetic inversion from the Parfile (both problem weights non-zero): two kernels, one LSQR system."""
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    g = np.load(os.path.join(golden_dir, "e2e_joint.npz"))
+    wd = str(tmp_path)
+    n = g["X1"].size
+    nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    with open(os.path.join(wd, "grid.txt"), "w") as f:
+        f.write("%d\n" % n)
+        for p in range(n):
+            f.write("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %d\n" % (g["X1"][p], g["X2"][p], g["Y1"][p], g["Y2"][p], g["Z1"][p],
+                                                                      g["Z2"][p], i.ravel()[p] + 1, j.ravel()[p] + 1, k.ravel()[p] + 1))
+    for tag in ("grav", "magn"):
+        with open(os.path.join(wd, "data_grid_%s.txt" % tag), "w") as f:
+            f.write("%d\n" % g["obs_" + tag].shape[0])
+            for o in g["obs_" + tag]:
+                f.write("%.17g %.17g %.17g 0.0\n" % tuple(o))
+        with open(os.path.join(wd, "model_true_%s.txt" % tag), "w") as f:
+            f.write("%d\n" % n)
+            f.write("\n".join("%.17g" % v for v in g["model_true_" + tag]) + "\n")
+    open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout and "JOINT inversion" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    for tag, sfx in (("grav", "grav"), ("magn", "mag")):
+        model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)[:, 0]
+        ref = g["np1_%s_model_final" % tag]
+        self_diff = np.linalg.norm(g["np2_%s_model_final" % tag] - ref) / np.linalg.norm(ref)
+        tol = max(1e-6, 100.0 * self_diff)
+        assert np.linalg.norm(model - ref) <= tol * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
+        dfin = read_tokens(os.path.join(wd, "out", "data", sfx + "_final.txt"), 4)[:, 3]
+        assert np.linalg.norm(dfin - g["np1_%s_data_final" % tag]) <= 10 * tol * np.linalg.norm(g["np1_%s_data_final" % tag])
+    costs = [l.split() for l in open(os.path.join(wd, "out", "costs.txt")) if l.strip() and not l.lstrip().startswith("#")]
+    assert len(costs) == int(g["nmajor"]) + 1 and len(costs[-1]) == 9            # iteration + 4 columns per problem
+
+
 def test_parfile_errors_like_the_reference(tmp_path):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")

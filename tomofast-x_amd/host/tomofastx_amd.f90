@@ -4,14 +4,15 @@
 !     ./tomofastx_amd -p <Parfile>          (src/program_tomofastx.F90:77-80, src/parameters_init.f90:104-119)
 !
 ! It re-states the control flow of solve_problem_joint_gravmag (src/problem_joint_gravmag.F90:65-613) and
-! joint_inversion_solve (src/inversion/joint_inverse_problem.F90:393-573) for ONE problem (gravity or magnetic,
-! selected by the problem weights like the reference) and hands every O(N), O(N.Ndata) and O(nnz) step to libtfx.so
+! joint_inversion_solve (src/inversion/joint_inverse_problem.F90:393-573) for gravity, magnetic or JOINT gravity + magnetic
+! inversion (selected by the problem weights like the reference) and hands every O(N), O(N.Ndata) and O(nnz) step to libtfx.so
 ! through tfx_binding (iso_c_binding): depth weight, sensitivity kernel, wavelets, LSQR, forward data.
 ! What stays in Fortran is what the reference also does on the host: Parfile parsing, ASCII readers / writers in
 ! the reference's formats, the ADMM projection (src/inversion/admm_method.F90:70-134), residuals and costs.
 !
 ! Supported Parfile subset: gravity (g_z, or gradiometry Gzz / full tensor with forward.data.grav.type = 2) or magnetic
-! (TMI or three-component data; susceptibility or magnetisation-vector model) single inversion, depth weighting types 1 and 2, Haar / D4
+! (TMI or three-component data; susceptibility or magnetisation-vector model) single inversion, or both jointly in one LSQR
+! system (no structural coupling), depth weighting types 1 and 2, Haar / D4
 ! compression or none, model damping (L2), ADMM with global bounds, prior / starting model by value or file, data from
 ! file or from a synthetic model.  Keys of features whose constraint builders are out of scope (cross-gradient,
 ! clustering, gradient damping, local weights) stop with a message when enabled, like the
@@ -45,7 +46,7 @@ module tfx_host_params
     real(dp) :: alpha(2) = (/1.d-11, 1.d-8/), norm_power = 2.d0
     real(dp) :: pw(2) = (/1.d0, 0.d0/), cwm(2) = (/4.d3, 1.d0/)
     integer :: admm = 0, admm_bound_type = 1, nlithos = 1
-    real(dp), allocatable :: bounds(:)
+    real(dp), allocatable :: bounds(:, :)         ! (2*nlithos, problem)
     real(dp) :: rho(2) = 1.d-7, admm_cost_thr = 1.d-4, admm_mult = 1.d0, admm_max = 1.d+10
     ! features that need the out-of-scope constraint builders
     real(dp) :: beta_grad(2) = 0.d0, w_cross = 0.d0, w_clust(2) = 0.d0
@@ -150,9 +151,15 @@ contains
       case ('inversion.admm.nLithologies');        read(val, *) par%nlithos
       case ('inversion.admm.grav.bounds', 'inversion.admm.magn.bounds')
         if (par%admm > 0 .and. par%admm_bound_type == 1) then
-          if (allocated(par%bounds)) deallocate(par%bounds)
-          allocate(par%bounds(2 * par%nlithos))
-          read(val, *) par%bounds
+          if (.not. allocated(par%bounds)) then
+            allocate(par%bounds(2 * par%nlithos, 2))
+            par%bounds = huge(1.d0)
+          endif
+          if (index(key, '.grav.') > 0) then
+            read(val, *) par%bounds(:, 1)
+          else
+            read(val, *) par%bounds(:, 2)
+          endif
         endif
       case ('inversion.admm.grav.weight');         read(val, *) par%rho(1)
       case ('inversion.admm.magn.weight');         read(val, *) par%rho(2)
@@ -468,24 +475,33 @@ program tomofastx_amd
   use tfx_host_sensit
   implicit none
 
+  ! everything one problem (gravity or magnetic) owns; model vectors are component-major, data vectors d-fastest
+  type t_prob
+    logical :: on = .false.
+    integer :: slot = 0, nd = 0, ndc = 1, nc = 1, nm = 0, ndt = 0, dtype = 1, col0 = 0, row0 = 0
+    real(dp) :: pw = 0.d0, rho = 0.d0, cost_data = 0.d0, cost_model = 0.d0, cost_admm = 0.d0
+    real(dp), allocatable :: X1(:), X2(:), Y1(:), Y2(:), Z1(:), Z2(:), cw(:)
+    real(dp), allocatable :: Xd(:), Yd(:), Zd(:), d_meas(:), d_calc(:)
+    real(dp), allocatable :: m(:), m_prior(:), m_synth(:), z_admm(:), u_admm(:), x0(:)
+  end type t_prob
+
   type(t_par) :: par
+  type(t_prob), target :: pr(2)
   character(len=256) :: envv
   integer :: envlen, envstat
   character(len=256) :: arg, parfile
   ! output file prefixes (src/problem_joint_gravmag.F90:340-362, :554-555): 'grav_...' and 'mag_...'
   character(len=4) :: suffix(2) = (/'grav', 'mag '/)
-  integer :: ip, n, nd, it, i, k, nblocks, ucost, narg, nc, ndc, nm, ndt, kadm, dtype
+  integer :: ip, n, it, i, k, nblocks, ucost, narg, kadm, nprob, ntot, ndtot, c0, r0
   real(dp), target :: mag_field(4)
   type(c_ptr) :: mag_ptr
   integer(c_int) :: iters
   integer(c_int64_t) :: nnz
   real(c_double) :: err_sum, r
-  type(c_ptr) :: ctx, dptr(2), rptr(2)
-  real(dp), allocatable, target :: X1(:), X2(:), Y1(:), Y2(:), Z1(:), Z2(:), cw(:)
-  real(dp), allocatable, target :: Xd(:), Yd(:), Zd(:), d_meas(:), d_calc(:), dw(:), res(:), b_data(:)
-  real(dp), allocatable, target :: m(:), m_prior(:), m_synth(:), work(:), x(:), rhs1(:), rhs2(:), z_admm(:), u_admm(:), x0(:)
-  real(c_float), allocatable, target :: diag1(:), diag2(:)
-  real(dp) :: cost_data, cost_model, cost_admm, pw, rho, s1, s2
+  type(c_ptr) :: ctx, dptr(4), rptr(4)
+  real(dp), allocatable, target :: b_data(:), x(:), rhs(:, :), work(:)
+  real(c_float), allocatable, target :: diag(:, :)
+  real(dp) :: s1, s2
 
   ! ---- command line (src/parameters_init.f90:104-119)
   parfile = ''
@@ -504,127 +520,155 @@ program tomofastx_amd
   print *, 'Started Tomofast-x (MI355X host), Parfile = ', trim(parfile)
   call read_parfile(parfile, par)
 
-  ! ---- which problem (src/problem_joint_gravmag.F90:108-112)
-  if (par%pw(1) /= 0.d0 .and. par%pw(2) /= 0.d0) &
-    call stop_msg('Joint inversion needs the coupling-constraint builders (cross-gradient / clustering): not in this host.')
-  ip = merge(1, 2, par%pw(1) /= 0.d0)
-  if (par%pw(ip) == 0.d0) call stop_msg('Both problem weights are zero!')
-  pw = par%pw(ip)
+  ! ---- which problems (src/problem_joint_gravmag.F90:108-112): both weights non-zero = joint inversion
+  pr(1)%on = par%pw(1) /= 0.d0
+  pr(2)%on = par%pw(2) /= 0.d0
+  nprob = count(pr%on)
+  if (nprob == 0) call stop_msg('Both problem weights are zero!')
   if (par%dw_type /= 1 .and. par%dw_type /= 2) call stop_msg('forward.depthWeighting.type must be 1 or 2 in this host.')
-  if (par%beta_grad(ip) /= 0.d0 .or. par%w_cross /= 0.d0 .or. par%w_clust(ip) /= 0.d0) &
-    call stop_msg('Gradient damping / cross-gradient / clustering constraints are not supported by this host.')
-  if (par%apply_local_dw /= 0 .or. par%apply_local_damp /= 0 .or. par%use_error(ip) /= 0) &
-    call stop_msg('Local weights / data errors are not supported by this host yet.')
+  if (par%w_cross /= 0.d0) call stop_msg('Cross-gradient constraints are not supported by this host.')
+  if (par%apply_local_dw /= 0 .or. par%apply_local_damp /= 0) call stop_msg('Local weights are not supported by this host yet.')
   if (par%norm_power /= 2.d0) call stop_msg('inversion.modelDamping.normPower /= 2 is not supported by this host yet.')
   if (par%admm > 0 .and. par%admm_bound_type /= 1) call stop_msg('ADMM with local bounds (boundType 2) is not supported yet.')
   if (par%sensit_read < 0 .or. par%sensit_read > 2) call stop_msg('sensit.readFromFiles must be 0, 1 or 2.')
-  ! components (src/parameters_init.f90:187-197, src/forward/gravmag/sensitivity_gravmag.F90:193-220)
-  nc = 1
-  if (ip == 2) nc = par%nmodel_comp
-  if (ip == 1 .and. par%nmodel_comp > 1) call stop_msg('For the magnetisation inversion the gravity problem should be disabled!')
-  ndc = par%ndata_comp(ip)
-  dtype = 1
-  if (ip == 1) dtype = par%grav_data_type
-  if (ip == 1 .and. dtype == 1 .and. ndc /= 1) call stop_msg('Gravity data (type 1) has one data component!')
-  if (ip == 1 .and. dtype == 2 .and. ndc /= 1 .and. ndc /= 6) call stop_msg('Wrong number of gravity gradiometry data components!')
-  if (ip == 1 .and. dtype /= 1 .and. dtype /= 2) call stop_msg('Unknown gravity data type!')
-  if (ip == 2 .and. .not. ((nc == 1 .or. nc == 3) .and. (ndc == 1 .or. ndc == 3))) &
-    call stop_msg('Wrong number of components in magnetic_field_magprism!')
   if (par%admm > 0 .and. .not. allocated(par%bounds)) call stop_msg('Global bounds are not defined!')
-
   n = par%nx * par%ny * par%nz
-  nd = par%ndata(ip)
-  if (n <= 0 .or. nd <= 0) call stop_msg('Wrong model grid size or number of data!')
-  nm = n * nc              ! model vectors are component-major: m((k-1)*n + cell) = model%val(cell, k)
-  ndt = nd * ndc           ! data vectors are d-fastest: d((i-1)*ndc + d) = data(d, i)
-  allocate(X1(n), X2(n), Y1(n), Y2(n), Z1(n), Z2(n), cw(n), m(nm), m_prior(nm), m_synth(nm), work(nm), x(nm), rhs1(nm), rhs2(nm))
-  allocate(z_admm(n), u_admm(n), x0(n), diag1(nm), diag2(nm))
-  allocate(Xd(nd), Yd(nd), Zd(nd), d_meas(ndt), d_calc(ndt), dw(ndt), res(ndt), b_data(ndt))
+  if (n <= 0) call stop_msg('Wrong model grid size!')
 
-  ! ---- (I) model grid and data (problem_joint_gravmag.F90:140-157)
-  call read_model_grid(par%grid_file(ip), n, X1, X2, Y1, Y2, Z1, Z2)
-  call read_data(par%data_grid_file(ip), nd, ndc, Xd, Yd, Zd, d_meas)
-  d_meas = d_meas * par%data_units_mult(ip)
-  dw = 1.d0
+  ! components (src/parameters_init.f90:187-197, src/forward/gravmag/sensitivity_gravmag.F90:193-220) and sizes
+  ntot = 0
+  ndtot = 0
+  k = 0
+  do ip = 1, 2
+    if (.not. pr(ip)%on) cycle
+    if (par%beta_grad(ip) /= 0.d0 .or. par%w_clust(ip) /= 0.d0) &
+      call stop_msg('Gradient damping / clustering constraints are not supported by this host.')
+    if (par%use_error(ip) /= 0) call stop_msg('Data errors are not supported by this host yet.')
+    pr(ip)%slot = k
+    k = k + 1
+    pr(ip)%pw = par%pw(ip)
+    pr(ip)%rho = par%rho(ip)
+    pr(ip)%nd = par%ndata(ip)
+    if (pr(ip)%nd <= 0) call stop_msg('Wrong number of data!')
+    pr(ip)%nc = 1
+    if (ip == 2) pr(ip)%nc = par%nmodel_comp
+    if (par%nmodel_comp > 1 .and. pr(1)%on) call stop_msg('For the magnetisation inversion the gravity problem should be disabled!')
+    pr(ip)%ndc = par%ndata_comp(ip)
+    pr(ip)%dtype = 1
+    if (ip == 1) pr(ip)%dtype = par%grav_data_type
+    if (ip == 1 .and. pr(ip)%dtype == 1 .and. pr(ip)%ndc /= 1) call stop_msg('Gravity data (type 1) has one data component!')
+    if (ip == 1 .and. pr(ip)%dtype == 2 .and. pr(ip)%ndc /= 1 .and. pr(ip)%ndc /= 6) &
+      call stop_msg('Wrong number of gravity gradiometry data components!')
+    if (ip == 1 .and. pr(ip)%dtype /= 1 .and. pr(ip)%dtype /= 2) call stop_msg('Unknown gravity data type!')
+    if (ip == 2 .and. .not. ((pr(ip)%nc == 1 .or. pr(ip)%nc == 3) .and. (pr(ip)%ndc == 1 .or. pr(ip)%ndc == 3))) &
+      call stop_msg('Wrong number of components in magnetic_field_magprism!')
+    pr(ip)%nm = n * pr(ip)%nc            ! m((k-1)*n + cell) = model%val(cell, k)
+    pr(ip)%ndt = pr(ip)%nd * pr(ip)%ndc  ! d((i-1)*ndc + d) = data(d, i)
+    pr(ip)%col0 = ntot                   ! param_shift / line_start of the joint system (joint_inverse_problem.F90:712-739)
+    pr(ip)%row0 = ndtot
+    ntot = ntot + pr(ip)%nm
+    ndtot = ndtot + pr(ip)%ndt
+    allocate(pr(ip)%X1(n), pr(ip)%X2(n), pr(ip)%Y1(n), pr(ip)%Y2(n), pr(ip)%Z1(n), pr(ip)%Z2(n), pr(ip)%cw(n))
+    allocate(pr(ip)%Xd(pr(ip)%nd), pr(ip)%Yd(pr(ip)%nd), pr(ip)%Zd(pr(ip)%nd), pr(ip)%d_meas(pr(ip)%ndt), pr(ip)%d_calc(pr(ip)%ndt))
+    allocate(pr(ip)%m(pr(ip)%nm), pr(ip)%m_prior(pr(ip)%nm), pr(ip)%m_synth(pr(ip)%nm))
+    allocate(pr(ip)%z_admm(n), pr(ip)%u_admm(n), pr(ip)%x0(n))
+  enddo
+  allocate(b_data(ndtot), x(ntot), rhs(ntot, 4), diag(ntot, 4), work(ntot))
+  if (nprob == 2) print *, 'JOINT inversion: two sensitivity kernels in one system.'
 
   call tfx_check(tfx_create(0_c_int, c_null_ptr, ctx), 'tfx_create')
-  call tfx_check(tfx_set_grid(ctx, par%nx, par%ny, par%nz, X1, X2, Y1, Y2, Z1, Z2), 'tfx_set_grid')
 
-  ! ---- (II) depth weight (:174-178, :189-193): computed, or read from the SENSIT folder
-  if (par%sensit_read == 0) then
-    print *, 'Calculating the depth weight, type = ', par%dw_type
-    if (par%dw_type == 1) then
-      call tfx_check(tfx_column_weight_type1(ctx, par%dw_power(ip), par%dw_Z0(ip), par%cwm(ip), cw), 'calculate_depth_weight')
+  do ip = 1, 2
+    if (.not. pr(ip)%on) cycle
+    call tfx_check(tfx_select_problem(ctx, pr(ip)%slot), 'tfx_select_problem')
+    ! ---- (I) model grid and data (problem_joint_gravmag.F90:140-157)
+    call read_model_grid(par%grid_file(ip), n, pr(ip)%X1, pr(ip)%X2, pr(ip)%Y1, pr(ip)%Y2, pr(ip)%Z1, pr(ip)%Z2)
+    call read_data(par%data_grid_file(ip), pr(ip)%nd, pr(ip)%ndc, pr(ip)%Xd, pr(ip)%Yd, pr(ip)%Zd, pr(ip)%d_meas)
+    pr(ip)%d_meas = pr(ip)%d_meas * par%data_units_mult(ip)
+    call tfx_check(tfx_set_grid(ctx, par%nx, par%ny, par%nz, pr(ip)%X1, pr(ip)%X2, pr(ip)%Y1, pr(ip)%Y2, pr(ip)%Z1, pr(ip)%Z2), &
+                   'tfx_set_grid')
+
+    ! ---- (II) depth weight (:174-178, :189-193): computed, or read from the SENSIT folder
+    if (par%sensit_read == 0) then
+      print *, 'Calculating the depth weight, type = ', par%dw_type
+      if (par%dw_type == 1) then
+        call tfx_check(tfx_column_weight_type1(ctx, par%dw_power(ip), par%dw_Z0(ip), par%cwm(ip), pr(ip)%cw), 'calculate_depth_weight')
+      else
+        call tfx_check(tfx_column_weight_type2(ctx, int(pr(ip)%nd, c_int64_t), pr(ip)%Xd, pr(ip)%Yd, pr(ip)%Zd, par%dw_power(ip), &
+                                               par%dw_beta(ip), par%cwm(ip), pr(ip)%cw), 'calculate_depth_weight')
+      endif
     else
-      call tfx_check(tfx_column_weight_type2(ctx, int(nd, c_int64_t), Xd, Yd, Zd, par%dw_power(ip), par%dw_beta(ip), par%cwm(ip), cw), &
-                     'calculate_depth_weight')
+      call read_weight_file(par%sensit_path, ip, n, pr(ip)%cw)
     endif
-  else
-    call read_weight_file(par%sensit_path, ip, n, cw)
-  endif
 
-  ! ---- (III) sensitivity kernel (:197-248): built on the device, or re-loaded from SENSIT files
-  if (par%sensit_read == 1) then
-    call read_sensit_files(ctx, par%sensit_path, ip, par%nx, par%ny, par%nz, nd, ndc, nc, par%dw_type, par%comp_type, pw, nnz)
-    err_sum = 0.d0
-  else
-  mag_ptr = c_null_ptr
-  if (ip == 1) then
-    print *, 'Calculating GRAVITY sensitivity kernel...'
-  else
-    print *, 'Calculating MAGNETIC sensitivity kernel...'
-    mag_field = (/par%mag_incl, par%mag_decl, par%mag_xaxis_decl, par%mag_intensity/)
-    mag_ptr = c_loc(mag_field)
-  endif
-  call tfx_check(tfx_build_kernel(ctx, ip, dtype, ndc, nc, int(nd, c_int64_t), Xd, Yd, Zd, cw, mag_ptr, par%comp_type, &
-                                  par%comp_rate, pw, c_null_ptr, 0_c_int64_t, int(n, c_int64_t), nnz, err_sum, c_null_ptr), &
-                 'calculate_and_write_sensit')
-  ! the reference always writes the kernel (calculate_and_write_sensit); TFX_WRITE_SENSIT=0 skips the download + write
-  call get_environment_variable('TFX_WRITE_SENSIT', envv, envlen, envstat)
-  if (.not. (envstat == 0 .and. envlen > 0 .and. envv(1:1) == '0')) &
-    call write_sensit_files(ctx, trim(par%path_output)//'/SENSIT', ip, par%nx, par%ny, par%nz, nd, ndc, nc, par%dw_type, &
-                            par%comp_type, err_sum / dble(nd * ndc * nc), pw, cw)
-  endif
-  print *, 'nnz_total = ', nnz
-  print *, 'COMPRESSION RATE = ', dble(nnz) / dble(n) / dble(nd) / dble(nc) / dble(ndc)
-  print *, 'COMPRESSION ERROR, r = ', err_sum / dble(nd * ndc * nc)
+    ! ---- (III) sensitivity kernel (:197-248): built on the device, or re-loaded from SENSIT files
+    if (par%sensit_read == 1) then
+      call read_sensit_files(ctx, par%sensit_path, ip, par%nx, par%ny, par%nz, pr(ip)%nd, pr(ip)%ndc, pr(ip)%nc, par%dw_type, &
+                             par%comp_type, pr(ip)%pw, nnz)
+      err_sum = 0.d0
+    else
+      mag_ptr = c_null_ptr
+      if (ip == 1) then
+        print *, 'Calculating GRAVITY sensitivity kernel...'
+      else
+        print *, 'Calculating MAGNETIC sensitivity kernel...'
+        mag_field = (/par%mag_incl, par%mag_decl, par%mag_xaxis_decl, par%mag_intensity/)
+        mag_ptr = c_loc(mag_field)
+      endif
+      call tfx_check(tfx_build_kernel(ctx, ip, pr(ip)%dtype, pr(ip)%ndc, pr(ip)%nc, int(pr(ip)%nd, c_int64_t), pr(ip)%Xd, pr(ip)%Yd, &
+                                      pr(ip)%Zd, pr(ip)%cw, mag_ptr, par%comp_type, par%comp_rate, pr(ip)%pw, c_null_ptr, &
+                                      0_c_int64_t, int(n, c_int64_t), nnz, err_sum, c_null_ptr), 'calculate_and_write_sensit')
+      ! the reference always writes the kernel (calculate_and_write_sensit); TFX_WRITE_SENSIT=0 skips the download + write
+      call get_environment_variable('TFX_WRITE_SENSIT', envv, envlen, envstat)
+      if (.not. (envstat == 0 .and. envlen > 0 .and. envv(1:1) == '0')) &
+        call write_sensit_files(ctx, trim(par%path_output)//'/SENSIT', ip, par%nx, par%ny, par%nz, pr(ip)%nd, pr(ip)%ndc, pr(ip)%nc, &
+                                par%dw_type, par%comp_type, err_sum / dble(pr(ip)%nd * pr(ip)%ndc * pr(ip)%nc), pr(ip)%pw, pr(ip)%cw)
+    endif
+    print *, 'nnz_total = ', nnz
+    print *, 'COMPRESSION RATE = ', dble(nnz) / dble(n) / dble(pr(ip)%nd) / dble(pr(ip)%nc) / dble(pr(ip)%ndc)
+    print *, 'COMPRESSION ERROR, r = ', err_sum / dble(pr(ip)%nd * pr(ip)%ndc * pr(ip)%nc)
 
-  ! ---- data from the synthetic model (:318-345)
-  if (par%use_synth(ip) > 0) then
-    call read_model_values(par%synth_file(ip), n, nc, m_synth)
-    m_synth = m_synth * par%model_units_mult(ip)
-    call calculate_data(m_synth, d_calc)
-    d_meas = d_calc
-    call write_data(par%path_output, trim(suffix(ip))//'_synthetic', nd, ndc, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
-  endif
-  call write_data(par%path_output, trim(suffix(ip))//'_observed', nd, ndc, Xd, Yd, Zd, d_meas, par%data_units_mult(ip), par%z_axis_dir)
+    ! ---- data from the synthetic model (:318-345)
+    if (par%use_synth(ip) > 0) then
+      call read_model_values(par%synth_file(ip), n, pr(ip)%nc, pr(ip)%m_synth)
+      pr(ip)%m_synth = pr(ip)%m_synth * par%model_units_mult(ip)
+      call calculate_data(ip, pr(ip)%m_synth, pr(ip)%d_calc)
+      pr(ip)%d_meas = pr(ip)%d_calc
+      call write_data(par%path_output, trim(suffix(ip))//'_synthetic', pr(ip)%nd, pr(ip)%ndc, pr(ip)%Xd, pr(ip)%Yd, pr(ip)%Zd, &
+                      pr(ip)%d_calc, par%data_units_mult(ip), par%z_axis_dir)
+    endif
+    call write_data(par%path_output, trim(suffix(ip))//'_observed', pr(ip)%nd, pr(ip)%ndc, pr(ip)%Xd, pr(ip)%Yd, pr(ip)%Zd, &
+                    pr(ip)%d_meas, par%data_units_mult(ip), par%z_axis_dir)
 
-  ! ---- prior and starting models (:350-441)
-  if (par%prior_type == 1) then
-    m_prior = par%prior_val(ip)
-  else
-    call read_model_values(par%prior_file(ip), n, nc, m_prior)
-  endif
-  m_prior = m_prior * par%model_units_mult(ip)
-  if (par%start_type == 1) then
-    m = par%start_val(ip)
-  else
-    call read_model_values(par%start_file(ip), n, nc, m)
-  endif
-  m = m * par%model_units_mult(ip)
-  call calculate_data(m, d_calc)
-  call write_data(par%path_output, trim(suffix(ip))//'_starting', nd, ndc, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
+    ! ---- prior and starting models (:350-441)
+    if (par%prior_type == 1) then
+      pr(ip)%m_prior = par%prior_val(ip)
+    else
+      call read_model_values(par%prior_file(ip), n, pr(ip)%nc, pr(ip)%m_prior)
+    endif
+    pr(ip)%m_prior = pr(ip)%m_prior * par%model_units_mult(ip)
+    if (par%start_type == 1) then
+      pr(ip)%m = par%start_val(ip)
+    else
+      call read_model_values(par%start_file(ip), n, pr(ip)%nc, pr(ip)%m)
+    endif
+    pr(ip)%m = pr(ip)%m * par%model_units_mult(ip)
+    call calculate_data(ip, pr(ip)%m, pr(ip)%d_calc)
+    call write_data(par%path_output, trim(suffix(ip))//'_starting', pr(ip)%nd, pr(ip)%ndc, pr(ip)%Xd, pr(ip)%Yd, pr(ip)%Zd, &
+                    pr(ip)%d_calc, par%data_units_mult(ip), par%z_axis_dir)
 
-  ! ---- costs (:443-470)
-  call model_cost(cost_model)
-  cost_data = norm2(d_calc - d_meas) / norm2(d_meas)
-  cost_admm = 0.d0
+    ! ---- costs (:443-470)
+    call model_cost(ip, pr(ip)%cost_model)
+    pr(ip)%cost_data = norm2(pr(ip)%d_calc - pr(ip)%d_meas) / norm2(pr(ip)%d_meas)
+    pr(ip)%cost_admm = 0.d0
+    pr(ip)%z_admm = 0.d0
+    pr(ip)%u_admm = 0.d0
+  enddo
+  call tfx_check(tfx_select_problem(ctx, 0_c_int), 'tfx_select_problem')
+
   call make_dir(par%path_output)
   open(newunit=ucost, file=trim(par%path_output)//'/costs.txt', status='replace', action='write')
-  write(ucost, *) '# 1:iteration, 2:data_cost, 3:model_cost, 4:ADMM_cost, 5:ADMM_weight'
-  z_admm = 0.d0
-  u_admm = 0.d0
-  rho = par%rho(ip)
+  write(ucost, '(A)') '# 1:iteration, then per active problem: data_cost, model_cost, ADMM_cost, ADMM_weight'
 
   ! ---- (V) major inversion loop (:473-547)
   do it = 1, par%nmajor
@@ -635,101 +679,136 @@ program tomofastx_amd
     print *, '======================================================='
     print *, 'Iteration =', it
     print *, '======================================================='
-    res = dw * (d_meas - d_calc)                                   ! :666-675
-    b_data = pw * res                                              ! joint_inverse_problem.F90:379-387
     nblocks = 0
-    if (par%alpha(ip) /= 0.d0) then                                ! damping.F90:97-234
-      nblocks = nblocks + 1
-      do k = 1, nc                                                 ! one block per component (joint_inverse_problem.F90:456-463)
-        work((k - 1) * n + 1:k * n) = (m((k - 1) * n + 1:k * n) - m_prior((k - 1) * n + 1:k * n)) / cw
-      enddo
-      call to_wavelet(work)
-      diag1 = real(par%alpha(ip) * pw, c_float)
-      rhs1 = -par%alpha(ip) * pw * work
-      dptr(nblocks) = c_loc(diag1)
-      rptr(nblocks) = c_loc(rhs1)
-    endif
-    if (par%admm > 0) then                                         ! joint_inverse_problem.F90:497-527
-      nblocks = nblocks + 1
-      kadm = merge(1, 3, nc == 1)                                  ! vector model: bounds on Mz (:499-506)
-      call iterate_admm_arrays(n, par%nlithos, par%bounds, m((kadm - 1) * n + 1:kadm * n), z_admm, u_admm, x0)
-      work = 0.d0
-      work((kadm - 1) * n + 1:kadm * n) = (m((kadm - 1) * n + 1:kadm * n) - x0) / cw
-      call to_wavelet(work)
-      diag2 = 0.0
-      diag2((kadm - 1) * n + 1:kadm * n) = real(rho * pw, c_float)
-      rhs2 = -rho * pw * work
-      dptr(nblocks) = c_loc(diag2)
-      rptr(nblocks) = c_loc(rhs2)
-      s1 = sum((z_admm - m((kadm - 1) * n + 1:kadm * n))**2)
-      s2 = sum(z_admm**2)
-      cost_admm = 0.d0
-      if (s2 /= 0.d0) cost_admm = sqrt(s1 / s2)                    ! costs.f90:38-69
-      print *, 'ADMM cost |x - z| / |z| =', cost_admm
-    endif
+    do ip = 1, 2
+      if (.not. pr(ip)%on) cycle
+      c0 = pr(ip)%col0
+      r0 = pr(ip)%row0
+      ! residuals (:666-675; data weight 1) and the right-hand side pw * residuals (joint_inverse_problem.F90:379-387)
+      b_data(r0 + 1:r0 + pr(ip)%ndt) = pr(ip)%pw * (pr(ip)%d_meas - pr(ip)%d_calc)
+      if (par%alpha(ip) /= 0.d0) then                              ! damping.F90:97-234, one block per problem and component
+        nblocks = nblocks + 1
+        work(1:pr(ip)%nm) = 0.d0
+        do k = 1, pr(ip)%nc                                        ! (joint_inverse_problem.F90:456-463)
+          work((k - 1) * n + 1:k * n) = (pr(ip)%m((k - 1) * n + 1:k * n) - pr(ip)%m_prior((k - 1) * n + 1:k * n)) / pr(ip)%cw
+        enddo
+        call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
+        diag(:, nblocks) = 0.0
+        diag(c0 + 1:c0 + pr(ip)%nm, nblocks) = real(par%alpha(ip) * pr(ip)%pw, c_float)
+        rhs(:, nblocks) = 0.d0
+        rhs(c0 + 1:c0 + pr(ip)%nm, nblocks) = -par%alpha(ip) * pr(ip)%pw * work(1:pr(ip)%nm)
+        dptr(nblocks) = c_loc(diag(1, nblocks))
+        rptr(nblocks) = c_loc(rhs(1, nblocks))
+      endif
+      if (par%admm > 0) then                                       ! joint_inverse_problem.F90:497-527
+        nblocks = nblocks + 1
+        kadm = merge(1, 3, pr(ip)%nc == 1)                         ! vector model: bounds on Mz (:499-506)
+        call iterate_admm_arrays(n, par%nlithos, par%bounds(:, ip), pr(ip)%m((kadm - 1) * n + 1:kadm * n), pr(ip)%z_admm, &
+                                 pr(ip)%u_admm, pr(ip)%x0)
+        work(1:pr(ip)%nm) = 0.d0
+        work((kadm - 1) * n + 1:kadm * n) = (pr(ip)%m((kadm - 1) * n + 1:kadm * n) - pr(ip)%x0) / pr(ip)%cw
+        call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
+        diag(:, nblocks) = 0.0
+        diag(c0 + (kadm - 1) * n + 1:c0 + kadm * n, nblocks) = real(pr(ip)%rho * pr(ip)%pw, c_float)
+        rhs(:, nblocks) = 0.d0
+        rhs(c0 + 1:c0 + pr(ip)%nm, nblocks) = -pr(ip)%rho * pr(ip)%pw * work(1:pr(ip)%nm)
+        dptr(nblocks) = c_loc(diag(1, nblocks))
+        rptr(nblocks) = c_loc(rhs(1, nblocks))
+        s1 = sum((pr(ip)%z_admm - pr(ip)%m((kadm - 1) * n + 1:kadm * n))**2)
+        s2 = sum(pr(ip)%z_admm**2)
+        pr(ip)%cost_admm = 0.d0
+        if (s2 /= 0.d0) pr(ip)%cost_admm = sqrt(s1 / s2)            ! costs.f90:38-69
+        print *, 'ADMM cost |x - z| / |z| =', pr(ip)%cost_admm
+      endif
+    enddo
     call tfx_check(tfx_lsqr_solve(ctx, par%nminor, par%rmin, par%gamma, par%target_misfit, b_data, nblocks, dptr, rptr, x, &
                                   iters, r), 'lsqr_solve_sensit')
     print *, 'Finished lsqr solver, r =', r, ' iter =', iters
-    if (par%comp_type > 0) &                                       ! :559-567
-      call tfx_check(tfx_wavelet(ctx, x, par%nx, par%ny, par%nz, int(nc, c_int64_t), par%comp_type, 2_c_int), 'inverse_wavelet')
-    do k = 1, nc
-      x((k - 1) * n + 1:k * n) = x((k - 1) * n + 1:k * n) * cw     ! :570
+    call write_costs(it - 1)                                       ! :519-528 (costs of the previous iteration)
+    do ip = 1, 2
+      if (.not. pr(ip)%on) cycle
+      c0 = pr(ip)%col0
+      if (par%comp_type > 0) &                                     ! :559-567
+        call tfx_check(tfx_wavelet(ctx, x(c0 + 1:c0 + pr(ip)%nm), par%nx, par%ny, par%nz, int(pr(ip)%nc, c_int64_t), par%comp_type, &
+                                   2_c_int), 'inverse_wavelet')
+      do k = 1, pr(ip)%nc
+        pr(ip)%m((k - 1) * n + 1:k * n) = pr(ip)%m((k - 1) * n + 1:k * n) + x(c0 + (k - 1) * n + 1:c0 + k * n) * pr(ip)%cw   ! :570, :500
+      enddo
+      call calculate_data(ip, pr(ip)%m, pr(ip)%d_calc)             ! :513
+      call model_cost(ip, pr(ip)%cost_model)
+      pr(ip)%cost_data = norm2(pr(ip)%d_calc - pr(ip)%d_meas) / norm2(pr(ip)%d_meas)   ! data_gravmag.f90:123-129
+      print *, 'data cost (new) =', pr(ip)%cost_data
+      if (par%admm > 0 .and. pr(ip)%cost_data < par%admm_cost_thr .and. pr(ip)%rho < par%admm_max .and. par%admm_mult /= 1.d0) then
+        pr(ip)%rho = par%admm_mult * pr(ip)%rho                    ! :618-638
+        print *, 'Increased the ADMM weight to:', pr(ip)%rho
+      endif
     enddo
-    m = m + x                                                      ! problem_joint_gravmag.F90:500
-    call calculate_data(m, d_calc)                                 ! :513
-    write(ucost, *) it - 1, cost_data, cost_model, cost_admm, rho  ! :519-528 (costs of the previous iteration)
-    flush(ucost)
-    call model_cost(cost_model)
-    cost_data = norm2(d_calc - d_meas) / norm2(d_meas)             ! data_gravmag.f90:123-129
-    print *, 'data cost (new) =', cost_data
-    if (par%admm > 0 .and. cost_data < par%admm_cost_thr .and. rho < par%admm_max .and. par%admm_mult /= 1.d0) then
-      rho = par%admm_mult * rho                                    ! :618-638
-      print *, 'Increased the ADMM weight to:', rho
-    endif
   enddo
-  write(ucost, *) par%nmajor, cost_data, cost_model, cost_admm, rho
+  call write_costs(par%nmajor)
   close(ucost)
 
   ! ---- outputs (:552-600)
-  call write_data(par%path_output, trim(suffix(ip))//'_final', nd, ndc, Xd, Yd, Zd, d_calc, par%data_units_mult(ip), par%z_axis_dir)
-  call write_model(par%path_output, trim(suffix(ip))//'_final_model_full.txt', n, nc, m, par%model_units_mult(ip))
-  print *, 'model min / max =', minval(m), maxval(m)
+  do ip = 1, 2
+    if (.not. pr(ip)%on) cycle
+    call write_data(par%path_output, trim(suffix(ip))//'_final', pr(ip)%nd, pr(ip)%ndc, pr(ip)%Xd, pr(ip)%Yd, pr(ip)%Zd, &
+                    pr(ip)%d_calc, par%data_units_mult(ip), par%z_axis_dir)
+    call write_model(par%path_output, trim(suffix(ip))//'_final_model_full.txt', n, pr(ip)%nc, pr(ip)%m, par%model_units_mult(ip))
+    print *, 'model min / max =', minval(pr(ip)%m), maxval(pr(ip)%m)
+  enddo
   call tfx_check(tfx_destroy(ctx), 'tfx_destroy')
   print *, 'THE END.'
 
 contains
 
-  subroutine to_wavelet(v)
-    real(dp), intent(inout) :: v(nm)
+  subroutine write_costs(iter)
+    integer, intent(in) :: iter
+    integer :: jp
+    write(ucost, '(I8)', advance='no') iter
+    do jp = 1, 2
+      if (pr(jp)%on) write(ucost, '(4(1X,ES24.16))', advance='no') pr(jp)%cost_data, pr(jp)%cost_model, pr(jp)%cost_admm, pr(jp)%rho
+    enddo
+    write(ucost, *)
+    flush(ucost)
+  end subroutine write_costs
+
+  subroutine to_wavelet(v, ncomp)
+    real(dp), intent(inout) :: v(:)
+    integer, intent(in) :: ncomp
     if (par%comp_type > 0) &      ! every model component on its own (src/inversion/wavelet_utils.F90:37-72)
-      call tfx_check(tfx_wavelet(ctx, v, par%nx, par%ny, par%nz, int(nc, c_int64_t), par%comp_type, 1_c_int), 'forward_wavelet')
+      call tfx_check(tfx_wavelet(ctx, v, par%nx, par%ny, par%nz, int(ncomp, c_int64_t), par%comp_type, 1_c_int), 'forward_wavelet')
   end subroutine to_wavelet
 
-  ! model_calculate_data, src/inversion/model.F90:220-307
-  subroutine calculate_data(model, dcalc)
-    real(dp), intent(in) :: model(nm)
-    real(dp), intent(out) :: dcalc(ndt)
+  ! model_calculate_data, src/inversion/model.F90:220-307 (on the problem's own rows / columns: part_mult_vector)
+  subroutine calculate_data(jp, model, dcalc)
+    integer, intent(in) :: jp
+    real(dp), intent(in) :: model(:)
+    real(dp), intent(out) :: dcalc(:)
+    real(dp), allocatable :: w(:)
     integer :: p, kc
-    do kc = 1, nc
+    allocate(w(pr(jp)%nm))
+    do kc = 1, pr(jp)%nc
       do p = 1, n
-        if (cw(p) /= 0.d0) then
-          work((kc - 1) * n + p) = model((kc - 1) * n + p) / cw(p)
+        if (pr(jp)%cw(p) /= 0.d0) then
+          w((kc - 1) * n + p) = model((kc - 1) * n + p) / pr(jp)%cw(p)
         else
-          work((kc - 1) * n + p) = 0.d0
+          w((kc - 1) * n + p) = 0.d0
         endif
       enddo
     enddo
-    call to_wavelet(work)
-    call tfx_check(tfx_calc_data(ctx, work, pw, c_null_ptr, dcalc), 'model_calculate_data')
+    call to_wavelet(w, pr(jp)%nc)
+    call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
+    call tfx_check(tfx_calc_data(ctx, w, pr(jp)%pw, c_null_ptr, dcalc), 'model_calculate_data')
+    call tfx_check(tfx_select_problem(ctx, 0_c_int), 'tfx_select_problem')
   end subroutine calculate_data
 
   ! calculate_cost_model, src/utils/costs.f90:74-113 (first model component only, problem_joint_gravmag.F90:655-657)
-  subroutine model_cost(cost)
+  subroutine model_cost(jp, cost)
+    integer, intent(in) :: jp
     real(dp), intent(out) :: cost
     integer :: p
     cost = 0.d0
     do p = 1, n
-      if (cw(p) /= 0.d0) cost = cost + (abs((m(p) - m_prior(p)) / cw(p)))**par%norm_power
+      if (pr(jp)%cw(p) /= 0.d0) cost = cost + (abs((pr(jp)%m(p) - pr(jp)%m_prior(p)) / pr(jp)%cw(p)))**par%norm_power
     enddo
   end subroutine model_cost
 
