@@ -221,3 +221,52 @@ def test_joint_system_two_ranks():
         p.join(60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def _worker_inversion(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tfx = importlib.import_module("tomofast-x_amd")
+        g = np.load(os.path.join(GOLDEN, "e2e_haar.npz"))
+        dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+        obs = g["obs"]
+        ctx = tfx.Context(0)
+        ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+        ctx.set_allreduce(tfx.distributed.TorchAllreduce(0), rank, world)
+        cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+        part = tfx.distributed.build_partitioned(ctx, rank, world, obs[:, 0], obs[:, 1], obs[:, 2], cw, 1, float(g["rate"]))
+        m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, 1, g["np1_data_observed"], int(g["nmajor"]), int(g["nminor"]),
+                                                         alpha=float(g["alpha"]), col_range=part["col_range"])
+        ref = g["np2_model_final"]                       # the reference's own 2-rank run
+        err = np.linalg.norm(m - ref) / np.linalg.norm(ref)
+        assert err <= 1e-6, err
+        cost_ref = np.linalg.norm(g["np1_data_final"] - g["np1_data_observed"]) / np.linalg.norm(g["np1_data_observed"])
+        assert abs(hist[-1]["cost"] - cost_ref) <= 1e-5 * cost_ref + 1e-16
+        ctx.close()
+        q.put((rank, "ok"))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_whole_inversion_two_ranks():
+    """Major loop on 2 ranks: kernel built per column range, LSQR over the hook, model-update slices gathered and
+    inverse-transformed on every rank, forward data all-reduced - vs the reference's final model of its own 2-rank run."""
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29800 + os.getpid() % 2000
+    procs = [ctxm.Process(target=_worker_inversion, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)

@@ -8,8 +8,10 @@ that drives the hot path, for one gravity problem with WAVELET_DOMAIN = true (or
   model_calculate_data (src/inversion/model.F90:220-307).
 
 All O(N) and O(nnz) work (wavelets, products, LSQR) runs on the device through Context; this file is control flow.
-With a multi-rank Context (distributed.RankContext) the model vectors are the rank-local column slices in the wavelet
-domain, exactly like the reference's nelements_at_cpu partition."""
+Multi-rank (col_range given): every rank keeps the full model (N doubles), the LSQR unknowns are its column slice of the
+wavelet-domain vector exactly like the reference's nelements_at_cpu partition, and the slices of the model update are
+gathered once per major iteration before the inverse transform, which every rank runs redundantly (the
+reference gathers to rank 0, transforms there and scatters: wavelet_utils.F90:37-72)."""
 import numpy as np
 
 
@@ -35,7 +37,7 @@ class AdmmState:
 
 def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor, nminor, alpha=0.0, rmin=1e-13,
                           problem_weight=1.0, data_weight=None, model_start=None, model_prior=None, admm=None,
-                          gamma=0.0, target_misfit=0.0, log=None, nmodel_components=1):
+                          gamma=0.0, target_misfit=0.0, log=None, nmodel_components=1, col_range=None):
     """ctx: Context holding the sensitivity matrix S (already scaled by problem_weight * data_weight) over ALL columns.
     admm: dict(bounds=[...], rho=...) or None.  Returns (model, data_calc, history).
     One problem of either kind (the name is historical).  nmodel_components = 3 (magnetisation vector): model vectors are
@@ -44,7 +46,24 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
     data vectors are [idata*ndata_components + d]."""
     nx, ny, nz = ctx.dims
     ncm = int(nmodel_components)
-    N = nx * ny * nz * ncm
+    N1 = nx * ny * nz
+    N = N1 * ncm
+    if col_range is None:
+        loc = lambda v: v
+        gather = lambda v: v
+    else:
+        from .distributed import allreduce_numpy
+        c0, c1 = col_range
+
+        def loc(v):                                  # this rank's cells of every model component
+            return np.concatenate([v[k * N1 + c0:k * N1 + c1] for k in range(ncm)])
+
+        def gather(v_loc):                           # all slices -> the full vector (disjoint supports: a sum is a gather)
+            full = np.zeros(N)
+            nl = c1 - c0
+            for k in range(ncm):
+                full[k * N1 + c0:k * N1 + c1] = v_loc[k * nl:(k + 1) * nl]
+            return allreduce_numpy(full)
     cw = np.tile(np.asarray(column_weight, np.float64), ncm)
     if admm is not None and ncm != 1:
         raise NotImplementedError("ADMM bounds act on Mz only for vector models (joint_inverse_problem.F90:497-506)")
@@ -58,7 +77,7 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
 
     def calculate_data(model):                       # model.F90:242-305
         scaled = np.where(cw != 0.0, model / cw, 0.0)
-        return ctx.calc_data(to_wavelet(scaled), pw, dw)
+        return ctx.calc_data(loc(to_wavelet(scaled)), pw, dw)
 
     d_calc = calculate_data(m)
     st = AdmmState(N) if admm is not None else None
@@ -68,15 +87,16 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
         b_data = pw * res                            # joint_inverse_problem.F90:379-387
         diag, rhs = [], []
         if alpha != 0.0:                             # damping.F90:97-234 (L2, no local weights)
-            md = to_wavelet((m - mp) / cw)
-            diag.append(np.full(N, np.float32(alpha * pw), np.float32))
+            md = loc(to_wavelet((m - mp) / cw))
+            diag.append(np.full(md.size, np.float32(alpha * pw), np.float32))
             rhs.append(-alpha * pw * md)
         if admm is not None:                         # joint_inverse_problem.F90:497-527
             x0 = st.iterate_admm_arrays(m, admm["bounds"])
-            md = to_wavelet((m - x0) / cw)
-            diag.append(np.full(N, np.float32(admm["rho"] * pw), np.float32))
+            md = loc(to_wavelet((m - x0) / cw))
+            diag.append(np.full(md.size, np.float32(admm["rho"] * pw), np.float32))
             rhs.append(-admm["rho"] * pw * md)
         x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
+        x = gather(x)
         dm = ctx.inverse_wavelet(x, nx, ny, nz, compression_type) if compression_type > 0 else x
         m = m + dm * cw                              # joint_inverse_problem.F90:570, model update :500
         d_calc = calculate_data(m)
