@@ -206,8 +206,13 @@ int tfx_lsqr_solve(tfx_ctx *ctx, int niter, double rmin, double gamma, double ta
 /* WAVELET_DOMAIN switch of the reference (src/inversion/joint_inverse_problem.F90:189-198).  1 (default): the unknowns
  * live in the wavelet domain and S is applied as stored.  0: spatial unknowns (needed by constraints that act in space:
  * cross-gradient, clustering, gradient damping, local bounds) - every product with S goes through the 3-D transform
- * (lsqr_solver2.F90:200-206, :228-234).  Single rank, the whole model (n1*n2*n3 = ncolumns) on this ctx.        */
+ * (lsqr_solver2.F90:200-206, :228-234).  Single rank: ncolumns = ncomponents * n1*n2*n3; multi-rank: see below.    */
 int tfx_lsqr_set_wavelet_domain(tfx_ctx *ctx, int wavelet_domain, int n1, int n2, int n3, int wavelet_type);
+/* Multi-rank WAVELET_DOMAIN = 0: this rank's unknowns are the cells [col_begin, col_begin + ncolumns/ncomponents) of each of
+ * the ncomponents model components (all problems of a joint run counted).  Every product with S then gathers the slices of all
+ * ranks through the all-reduce hook (disjoint supports), transforms the full vector on every rank and keeps its slice
+ * (apply_wavelet_transform, src/inversion/wavelet_utils.F90:37-72: gather to rank 0, transform, scatter).                    */
+int tfx_lsqr_set_partition(tfx_ctx *ctx, int64_t col_begin, int ncomponents);
 
 /* The same solver in three steps, so that a caller (bench.py) can time exactly k iterations with everything
  * resident: begin = lines :120-157 (x=0, normalise u, v = A^T u, ...), iterate = k passes of the loop body

@@ -270,3 +270,68 @@ def test_whole_inversion_two_ranks():
         p.join(60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def _worker_spatial(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tfx = importlib.import_module("tomofast-x_amd")
+        import oracle_lib as orc
+        import multirank_model as mm
+        g = np.load(os.path.join(GOLDEN, "e2e_haar.npz"))       # Haar lifting is orthonormal: S W with spatial unknowns == S with W x
+        dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+        N = int(np.prod(dims))
+        nel = g["np2_nelements_at_cpu"]
+        c0 = int(nel[:rank].sum())
+        c1 = c0 + int(nel[rank])
+        S_full = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+        nd = S_full[0].size - 1
+        ctx = tfx.Context(0)
+        ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+        ctx.set_allreduce(tfx.distributed.TorchAllreduce(0), rank, world)
+        ctx.matrix_upload_csr(nd, c1 - c0, *mm.column_slice(S_full, c0, c1))
+        b = g["np1_data_observed"]
+        alpha = np.float32(1e-7)
+        rng = np.random.default_rng(3)
+        rhs_full = rng.standard_normal(N) * 1e-8
+        # spatial unknowns on 2 ranks ...
+        ctx.lsqr_set_wavelet_domain(False, 1)
+        ctx.lsqr_set_partition(c0, 1)
+        x_loc, it, r = ctx.lsqr_solve_sensit(b, 15, 1e-13, 0.0, 0.0, [np.full(c1 - c0, alpha, np.float32)], [rhs_full[c0:c1]])
+        ctx.lsqr_set_wavelet_domain(True)
+        # ... against the single-rank oracle: x_spatial solves min |S W x - b|^2 + |alpha x - rhs|^2; W orthonormal, so
+        # x_wavelet = W x solves the wavelet-domain system with the transformed right-hand side, iteration by iteration
+        Cm = orc.diag_csr(np.full(N, alpha, np.float32))
+        rhs_w = orc.wavelet(rhs_full, dims[0], dims[1], dims[2], 1)
+        xw_ref, it_ref, r_ref = orc.lsqr(S_full, Cm, N, np.concatenate([b, rhs_w]), 15)
+        x_ref = orc.wavelet(xw_ref, dims[0], dims[1], dims[2], 1, inverse=True)
+        assert it == it_ref == 15
+        err = np.linalg.norm(x_loc - x_ref[c0:c1]) / np.linalg.norm(x_ref)
+        assert err <= 1e-6 and abs(r - r_ref) <= 1e-6 * r_ref, (err, r, r_ref)
+        ctx.close()
+        q.put((rank, "ok"))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spatial_unknowns_two_ranks():
+    """WAVELET_DOMAIN = F on 2 ranks: every product with S gathers the slices, transforms on every rank and keeps its slice."""
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29900 + os.getpid() % 2000
+    procs = [ctxm.Process(target=_worker_spatial, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)

@@ -162,6 +162,8 @@ struct tfx_ctx {
     bool spatial_unknowns = false;
     int wd_n1 = 0, wd_n2 = 0, wd_n3 = 0, wd_type = 0;
     int64_t wd_nvec = 1;      // model components transformed one after the other
+    int64_t wd_col_begin = -1; // multi-rank WAVELET_DOMAIN = F: first cell of this rank's column range (tfx_lsqr_set_partition)
+    int wd_ncomp = 0;          //   and the number of model components (of all problems) in the local unknown vector
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profile = false;

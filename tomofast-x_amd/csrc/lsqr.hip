@@ -32,6 +32,7 @@ struct LsqrState {
     DBuf<float> diag;      // nblocks * ncols
     DBuf<double> b0, sx;   // target-misfit only
     DBuf<double> tw;       // WAVELET_DOMAIN = F: wavelet-domain image of v / x, or S^T u before the inverse transform
+    DBuf<double> twf;      //   multi-rank: the full-length vector (all ranks' slices) the transform runs on
     DBuf<double> red;      // block partial sums
     DBuf<Scalars> sc;
     Scalars *h_sc = nullptr;   // pinned
@@ -268,13 +269,55 @@ static int scale_u(tfx_ctx *ctx, LsqrState *L)
     return 0;
 }
 
+// full[k*N + c0 + i] = loc[k*nloc + i]  /  loc[k*nloc + i] = full[k*N + c0 + i]
+__global__ void k_place_slice(double *__restrict__ full, const double *__restrict__ loc, int ncomp, int64_t N, int64_t c0, int64_t nloc)
+{
+    const int64_t n = (int64_t)ncomp * nloc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = i / nloc, j = i - k * nloc;
+        full[k * N + c0 + j] = loc[i];
+    }
+}
+
+__global__ void k_take_slice(double *__restrict__ loc, const double *__restrict__ full, int ncomp, int64_t N, int64_t c0, int64_t nloc)
+{
+    const int64_t n = (int64_t)ncomp * nloc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = i / nloc, j = i - k * nloc;
+        loc[i] = full[k * N + c0 + j];
+    }
+}
+
+// WAVELET_DOMAIN = F (lsqr_solver2.F90:200-206, :228-234 -> apply_wavelet_transform, wavelet_utils.F90:37-72).
+// L->tw holds this rank's slice of a vector; it is replaced by the same slice of the transformed vector (dir 1 forward,
+// 2 inverse).  Single rank: the slice is the whole vector.  Multi-rank: the slices are gathered into the full vector (disjoint
+// supports, so the sum all-reduce of the hook is a gather), every rank transforms redundantly and keeps its slice (SURVEY 8e;
+// the reference gathers to rank 0, transforms there and scatters).
+static int transform_slice(tfx_ctx *ctx, LsqrState *L, int dir)
+{
+    hipStream_t s = ctx->stream;
+    if (ctx->nranks <= 1)
+        return wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, dir);
+    const int64_t N = (int64_t)ctx->wd_n1 * ctx->wd_n2 * ctx->wd_n3;
+    const int ncomp = ctx->wd_ncomp;
+    const int64_t nloc = L->ncols / ncomp, full = (int64_t)ncomp * N;
+    TFX_HIP(hipMemsetAsync(L->twf.p, 0, (size_t)full * sizeof(double), s));
+    LAUNCH(k_place_slice, grid_for(L->ncols), L->twf.p, L->tw.p, ncomp, N, ctx->wd_col_begin, nloc);
+    TFX_HIP(hipGetLastError());
+    TFX_TRY(allreduce(ctx, L->twf.p, full));
+    TFX_TRY(wavelet_dev(ctx, L->twf.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ncomp, ctx->wd_type, dir));
+    LAUNCH(k_take_slice, grid_for(L->ncols), L->tw.p, L->twf.p, ncomp, N, ctx->wd_col_begin, nloc);
+    TFX_HIP(hipGetLastError());
+    return 0;
+}
+
 // v (+)= S^T u_data + C^T u_cons ; alpha = ||v|| ; v /= alpha
 static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L)
 {
     hipStream_t s = ctx->stream;
     if (ctx->spatial_unknowns) {                                         // lsqr_solver2.F90:137-145, :228-236
         TFX_TRY(S_adjoint(ctx, L->u.p, L->tw.p, 0));
-        TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, 2));
+        TFX_TRY(transform_slice(ctx, L, 2));
         LAUNCH(k_axpy1, grid_for(L->ncols), L->v.p, L->tw.p, L->ncols);
     } else {
         TFX_TRY(S_adjoint(ctx, L->u.p, L->v.p, 1));
@@ -347,10 +390,18 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     TFX_TRY(L->red.ensure(RED_BLOCKS));
     if (ctx->spatial_unknowns) {
         const int64_t n123 = (int64_t)ctx->wd_n1 * ctx->wd_n2 * ctx->wd_n3;
-        if (n123 <= 0 || nc % n123 != 0)       // ncolumns = nmodel_components * nelements (wavelet_utils.F90:37-72 loops the components)
-            return fail(TFX_E_STATE, "WAVELET_DOMAIN = F needs the whole model on this rank (ncolumns %lld is not a multiple of n1*n2*n3)", (long long)nc);
-        ctx->wd_nvec = nc / n123;
-        if (ctx->nranks > 1) return fail(TFX_E_STATE, "WAVELET_DOMAIN = F is single-rank for now");
+        if (ctx->nranks > 1) {
+            // this rank's unknowns are the cells [col_begin, col_begin + nloc) of every model component
+            if (ctx->wd_col_begin < 0 || ctx->wd_ncomp <= 0)
+                return fail(TFX_E_STATE, "multi-rank WAVELET_DOMAIN = F: call tfx_lsqr_set_partition first");
+            if (nc % ctx->wd_ncomp != 0 || ctx->wd_col_begin + nc / ctx->wd_ncomp > n123)
+                return fail(TFX_E_STATE, "the column partition does not match the matrix (%lld local columns, %d components)", (long long)nc, ctx->wd_ncomp);
+            TFX_TRY(L->twf.ensure((size_t)(ctx->wd_ncomp * n123)));
+        } else {
+            if (n123 <= 0 || nc % n123 != 0)   // ncolumns = nmodel_components * nelements (wavelet_utils.F90:37-72 loops the components)
+                return fail(TFX_E_STATE, "WAVELET_DOMAIN = F needs the whole model on this rank (ncolumns %lld is not a multiple of n1*n2*n3)", (long long)nc);
+            ctx->wd_nvec = nc / n123;
+        }
         TFX_TRY(L->tw.ensure((size_t)nc));
     }
     TFX_TRY(L->sc.ensure(1));
@@ -413,6 +464,17 @@ int tfx_lsqr_set_wavelet_domain(tfx_ctx *ctx, int wavelet_domain, int n1, int n2
     return 0;
 }
 
+// Multi-rank WAVELET_DOMAIN = F: where this rank's unknowns sit in the full model (cells [col_begin, col_begin + nloc) of each of
+// the ncomponents model components, all problems counted)
+int tfx_lsqr_set_partition(tfx_ctx *ctx, int64_t col_begin, int ncomponents)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    if (col_begin < 0 || ncomponents < 1) return fail(TFX_E_ARG, "tfx_lsqr_set_partition: bad arguments");
+    ctx->wd_col_begin = col_begin;
+    ctx->wd_ncomp = ncomponents;
+    return 0;
+}
+
 int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
 {
     if (!ctx || !ctx->lsqr || !ctx->lsqr->active) return fail(TFX_E_STATE, "tfx_lsqr_iterate: call tfx_lsqr_begin first");
@@ -426,7 +488,7 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
             const int64_t nd = L->nrows_data;
             if (ctx->spatial_unknowns) {                                                  // :171-176
                 LAUNCH(k_copy, grid_for(nc), L->tw.p, L->x.p, nc);
-                TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, 1));
+                TFX_TRY(transform_slice(ctx, L, 1));
                 TFX_TRY(S_forward(ctx, L->tw.p, L->sx.p, 0));
             } else
             TFX_TRY(S_forward(ctx, L->x.p, L->sx.p, 0));
@@ -441,7 +503,7 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
         LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
         if (ctx->spatial_unknowns) {                                                      // :200-209
             LAUNCH(k_copy, grid_for(nc), L->tw.p, L->v.p, nc);
-            TFX_TRY(wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, 1));
+            TFX_TRY(transform_slice(ctx, L, 1));
             TFX_TRY(S_forward(ctx, L->tw.p, L->u.p, 1));
         } else {
             TFX_TRY(S_forward(ctx, L->v.p, L->u.p, 1));

@@ -147,6 +147,14 @@ module tfx_binding
       real(c_double), intent(out) :: rows(*)
     end function
 
+    ! multi-rank WAVELET_DOMAIN = F: where this rank's unknowns sit in the full model
+    integer(c_int) function tfx_lsqr_set_partition(ctx, col_begin, ncomponents) bind(C, name="tfx_lsqr_set_partition")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: col_begin
+      integer(c_int), value :: ncomponents
+    end function
+
     ! joint inversion: slot 0 / 1 = which problem's sensitivity matrix the build / matrix / product / calc_data calls act on;
     ! LSQR solves with blockdiag(slot 0, slot 1) once slot 1 holds a matrix (src/inversion/joint_inverse_problem.F90:712-739)
     integer(c_int) function tfx_select_problem(ctx, slot) bind(C, name="tfx_select_problem")

@@ -350,6 +350,10 @@ class Context:
         n1, n2, n3 = self.dims if self.dims else (0, 0, 0)
         check(self._lib.tfx_lsqr_set_wavelet_domain(self._h, int(bool(wavelet_domain)), n1, n2, n3, int(wavelet_type)))
 
+    def lsqr_set_partition(self, col_begin, ncomponents=1):
+        """Multi-rank WAVELET_DOMAIN = False: first cell of this rank's column range and the number of model components."""
+        check(self._lib.tfx_lsqr_set_partition(self._h, C.c_int64(col_begin), int(ncomponents)))
+
     def lsqr_begin(self, b_data, rmin=1e-13, gamma=0.0, target_misfit=0.0, diag_blocks=(), rhs_blocks=()):
         b = f64(b_data)
         nb, dp, rp, keep = self._blocks(diag_blocks, rhs_blocks, self.system_dims()[1])
