@@ -50,6 +50,12 @@ const char *tfx_last_error(void);
 /* Library / device facts for logs: fills name[len], returns CU count (or <0). */
 int tfx_device_info(tfx_ctx *ctx, char *name, int len, int64_t *hbm_bytes);
 
+/* HIP devices visible to the process (a host that starts one process per GPU maps rank -> device with it).           */
+int tfx_device_count(void);
+/* Synchronous copy host <-> device (any direction), ordered after the work queued on the ctx stream: lets a host-language
+ * all-reduce hook stage the device buffer through MPI when it has no device-aware collective at hand.                   */
+int tfx_copy(tfx_ctx *ctx, void *dst, const void *src, int64_t bytes);
+
 /* All-reduce hook (sum, fp64, in place on a DEVICE buffer of n doubles, enqueued on `stream`).
  * NULL = single rank.  rank/nranks tell LSQR who adds the -alpha*u term (lsqr_solver2.F90:194-198).         */
 typedef int (*tfx_allreduce_fn)(void *user, double *dev_buf, int64_t n, void *stream);

@@ -261,6 +261,56 @@ def test_joint_parfile_matches_reference_outputs(tmp_path, golden_dir):
     assert len(costs) == int(g["nmajor"]) + 1 and len(costs[-1]) == 9            # iteration + 4 columns per problem
 
 
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+@pytest.mark.parametrize("name", ["e2e_joint", "e2e_mag31"])
+def test_two_ranks_under_mpiexec_match_the_reference_two_rank_run(tmp_path, golden_dir, name):
+    """`mpiexec -n 2 tomofastx_amd -p Parfile`: one process per rank (both on the one GPU of this box), column ranges from the
+    reference's nnz-balancing rule, LSQR reductions through the MPI-staged hook, model-update slices gathered per major
+    iteration - against the reference's own 2-rank run of the same Parfile."""
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    if not os.path.isfile(MPIEXEC):
+        pytest.skip("no mpiexec in this image")
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    wd = str(tmp_path)
+    if name == "e2e_joint":
+        n = g["X1"].size
+        nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
+        k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+        with open(os.path.join(wd, "grid.txt"), "w") as f:
+            f.write("%d\n" % n)
+            for p in range(n):
+                f.write("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %d\n" % (g["X1"][p], g["X2"][p], g["Y1"][p], g["Y2"][p], g["Z1"][p],
+                                                                          g["Z2"][p], i.ravel()[p] + 1, j.ravel()[p] + 1, k.ravel()[p] + 1))
+        for tag in ("grav", "magn"):
+            with open(os.path.join(wd, "data_grid_%s.txt" % tag), "w") as f:
+                f.write("%d\n" % g["obs_" + tag].shape[0])
+                for o in g["obs_" + tag]:
+                    f.write("%.17g %.17g %.17g 0.0\n" % tuple(o))
+            with open(os.path.join(wd, "model_true_%s.txt" % tag), "w") as f:
+                f.write("%d\n" % n)
+                f.write("\n".join("%.17g" % v for v in g["model_true_" + tag]) + "\n")
+        cases = [("grav", "grav", 1), ("magn", "mag", 1)]
+    else:
+        write_case_inputs(wd, g)
+        cases = [(None, "mag", int(g["ncm"]))]
+    open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
+    out = subprocess.run([MPIEXEC, "-n", "2", EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout and "Number of ranks" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    nel = [int(v) for v in out.stdout.split("nelements_at_cpu =")[1].split()[:2]]
+    assert np.all(np.abs(np.array(nel) - g["np2_nelements_at_cpu"]) <= 2)          # a threshold tie may move the cut by a cell
+    for tag, sfx, ncm in cases:
+        key = "np2_%s_model_final" % tag if tag else "np2_model_final"
+        key1 = "np1_%s_model_final" % tag if tag else "np1_model_final"
+        model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), ncm)
+        ref = g[key].reshape(model.shape)
+        self_diff = np.linalg.norm(g[key1].reshape(model.shape) - ref) / np.linalg.norm(ref)
+        tol = max(1e-6, 100.0 * self_diff)
+        assert np.linalg.norm(model - ref) <= tol * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
+
+
 def test_parfile_errors_like_the_reference(tmp_path):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")

@@ -32,6 +32,25 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     return 0;
 }
 
+// number of HIP devices visible to this process (rank -> device mapping of a host that launches one process per GPU)
+int tfx_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+// synchronous copy between host and device memory (either direction), ordered after the work already queued on the ctx stream -
+// what a host-language all-reduce hook needs to stage a device buffer through MPI
+int tfx_copy(tfx_ctx *ctx, void *dst, const void *src, int64_t bytes)
+{
+    if (!ctx || !dst || !src || bytes < 0) return fail(TFX_E_ARG, "tfx_copy: bad arguments");
+    TFX_HIP(hipSetDevice(ctx->device));
+    TFX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, ctx->stream));
+    TFX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int lsqr_free(tfx_ctx *ctx);   // lsqr.hip
 
 int tfx_destroy(tfx_ctx *ctx)

@@ -30,6 +30,17 @@ module tfx_binding
       import :: c_ptr
     end function
 
+    integer(c_int) function tfx_device_count() bind(C, name="tfx_device_count")
+      import :: c_int
+    end function
+
+    ! synchronous copy host <-> device, ordered after the ctx stream (staging for a host-side all-reduce hook)
+    integer(c_int) function tfx_copy(ctx, dst, src, bytes) bind(C, name="tfx_copy")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx, dst, src
+      integer(c_int64_t), value :: bytes
+    end function
+
     integer(c_int) function tfx_set_allreduce(ctx, fn, user, rank, nranks) bind(C, name="tfx_set_allreduce")
       import :: c_int, c_ptr, c_funptr
       type(c_ptr), value :: ctx, user

@@ -21,6 +21,7 @@
 module tfx_host_params
   implicit none
   integer, parameter :: dp = kind(1.d0)
+  logical, save :: io_rank = .true.        ! only rank 0 writes output files (the reference: `if (myrank == 0)` around every writer)
 
   type t_par
     character(len=256) :: path_output = 'output/test/'
@@ -244,6 +245,7 @@ contains
 
   subroutine make_dir(path)
     character(len=*), intent(in) :: path
+    if (.not. io_rank) return
     call execute_command_line('mkdir -p "'//trim(path)//'"')       ! src/utils/file_utils.F90:31-41
   end subroutine make_dir
 
@@ -253,6 +255,7 @@ contains
     integer, intent(in) :: n, ncomp, z_axis_dir
     real(dp), intent(in) :: X(n), Y(n), Z(n), val(ncomp, n), units_mult
     integer :: u, i
+    if (.not. io_rank) return
     call make_dir(trim(path_output)//'/data')
     open(newunit=u, file=trim(path_output)//'/data/'//trim(name)//'.txt', status='replace', action='write')
     write(u, *) n
@@ -268,6 +271,7 @@ contains
     integer, intent(in) :: n, nc
     real(dp), intent(in) :: val(n, nc), units_mult
     integer :: u, p
+    if (.not. io_rank) return
     call make_dir(trim(path_output)//'/model')
     open(newunit=u, file=trim(path_output)//'/model/'//trim(name), status='replace', action='write')
     write(u, *) n
@@ -384,13 +388,15 @@ contains
   end subroutine read_weight_file
 
   ! read_sensitivity_metadata + read_sensitivity_kernel (any number of rank files) -> CSR uploaded to the device
-  subroutine read_sensit_files(ctx, folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, pw, nnz_out)
+  subroutine read_sensit_files(ctx, folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, pw, nnz_out, c0, c1)
     type(c_ptr), intent(in) :: ctx
     character(len=*), intent(in) :: folder
     integer, intent(in) :: ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type
     real(dp), intent(in) :: pw
     integer(c_int64_t), intent(out) :: nnz_out
-    integer :: u, ios, n, rank, nbproc_sensit, precision_read, wtype, ctype, ncm_read, ncd_read, nxr, nyr, nzr, ndr
+    integer, intent(in) :: c0, c1            ! cells (c0, c1] stay on this rank (read_sensitivity_kernel scatters them, :795-830)
+    integer :: u, ios, n, rank, nbproc_sensit, nloc
+    integer(c_int64_t) :: jj, precision_read, wtype, ctype, ncm_read, ncd_read, nxr, nyr, nzr, ndr
     integer :: i, d, k, r, idata_glob
     real(dp) :: comp_error
     integer(c_int64_t) :: nnz_total, pos, j
@@ -401,6 +407,7 @@ contains
     character(len=512) :: fname
     character(len=16) :: s1, s2
     n = nx * ny * nz
+    nloc = c1 - c0
     fname = trim(folder)//'sensit_'//SENSIT_SUFFIX(ip)//'_meta.txt'
     print *, 'Reading the sensitivity metadata file ', trim(fname)
     open(newunit=u, file=trim(fname), form='formatted', status='old', action='read', iostat=ios)
@@ -444,11 +451,14 @@ contains
             if (pos + desc(2) > nnz_total) call stop_msg('Wrong number of elements in read_sensitivity_kernel!')
             if (desc(2) > 0) then
               read(u) cols(pos + 1:pos + desc(2)), vals(pos + 1:pos + desc(2))
+              jj = pos
               do j = pos + 1, pos + desc(2)
-                cols(j) = cols(j) + (k - 1) * n                                                              ! :832
-                vals(j) = vals(j) * real(pw, c_float)                                                        ! :835-843
+                if (cols(j) <= c0 .or. cols(j) > c1) cycle
+                jj = jj + 1
+                cols(jj) = cols(j) - c0 + (k - 1) * nloc                                                     ! :832
+                vals(jj) = vals(j) * real(pw, c_float)                                                       ! :835-843
               enddo
-              pos = pos + desc(2)
+              pos = jj
             endif
           enddo
           rowptr(r + 1) = pos
@@ -456,11 +466,11 @@ contains
       enddo
       close(u)
     enddo
-    if (idata_glob /= nd .or. pos /= nnz_total) call stop_msg('The SENSIT files do not hold the whole kernel!')
+    if (idata_glob /= nd .or. (nloc == n .and. pos /= nnz_total)) call stop_msg('The SENSIT files do not hold the whole kernel!')
     print *, 'nnz_total (of the read kernel)  = ', nnz_total
-    if (tfx_matrix_upload_csr(ctx, int(nd * ndc, c_int64_t), int(n, c_int64_t) * nc, rowptr, cols, vals) /= 0) &
+    if (tfx_matrix_upload_csr(ctx, int(nd * ndc, c_int64_t), int(nloc, c_int64_t) * nc, rowptr, cols, vals) /= 0) &
       call stop_msg('tfx_matrix_upload_csr failed')
-    nnz_out = nnz_total
+    nnz_out = pos
     print *, 'Finished reading the sensitivity kernel.'
   end subroutine read_sensit_files
 
@@ -473,12 +483,14 @@ program tomofastx_amd
   use tfx_host_params
   use tfx_host_io
   use tfx_host_sensit
+  use tfx_host_mpi
   implicit none
 
   ! everything one problem (gravity or magnetic) owns; model vectors are component-major, data vectors d-fastest
   type t_prob
     logical :: on = .false.
     integer :: slot = 0, nd = 0, ndc = 1, nc = 1, nm = 0, ndt = 0, dtype = 1, col0 = 0, row0 = 0
+    integer :: nml = 0                        ! local unknowns: nc * (cells of this rank)
     real(dp) :: pw = 0.d0, rho = 0.d0, cost_data = 0.d0, cost_model = 0.d0, cost_admm = 0.d0
     real(dp), allocatable :: X1(:), X2(:), Y1(:), Y2(:), Z1(:), Z2(:), cw(:)
     real(dp), allocatable :: Xd(:), Yd(:), Zd(:), d_meas(:), d_calc(:)
@@ -492,7 +504,15 @@ program tomofastx_amd
   character(len=256) :: arg, parfile
   ! output file prefixes (src/problem_joint_gravmag.F90:340-362, :554-555): 'grav_...' and 'mag_...'
   character(len=4) :: suffix(2) = (/'grav', 'mag '/)
-  integer :: ip, n, it, i, k, nblocks, ucost, narg, kadm, nprob, ntot, ndtot, c0, r0
+  integer :: ip, n, it, i, k, nblocks, ucost, narg, kadm, nprob, ntot, ndtot, c0, r0, ndev
+  integer :: lc0
+  integer :: cb, ce, nloc, ra, rb                     ! this rank's cells (cb, ce], nloc = ce - cb; its share of the data rows
+  integer(c_int32_t), allocatable, target :: hist(:), hist_all(:), nel_at(:)
+  integer(c_int64_t), allocatable :: nnz_at(:)
+  integer, allocatable :: counts(:), displs(:)
+  real(dp), allocatable, target :: xfull(:)
+  integer(c_int64_t) :: nnz_dummy
+  real(c_double) :: err_loc
   real(dp), target :: mag_field(4)
   type(c_ptr) :: mag_ptr
   integer(c_int) :: iters
@@ -517,7 +537,12 @@ program tomofastx_amd
     i = i + 1
   enddo
   if (len_trim(parfile) == 0) call stop_msg('UNKNOWN Parfile! Use -p <Parfile_path>')
+  ! one process per GPU under `mpiexec -n P`; ranks other than 0 stay silent (the reference prints from rank 0 only)
+  call host_mpi_init()
+  io_rank = myrank == 0
+  if (myrank /= 0) open(unit=6, file='/dev/null', status='old', action='write')
   print *, 'Started Tomofast-x (MI355X host), Parfile = ', trim(parfile)
+  if (nbproc > 1) print *, 'Number of ranks (one GPU each) =', nbproc
   call read_parfile(parfile, par)
 
   ! ---- which problems (src/problem_joint_gravmag.F90:108-112): both weights non-zero = joint inversion
@@ -573,56 +598,86 @@ program tomofastx_amd
     allocate(pr(ip)%m(pr(ip)%nm), pr(ip)%m_prior(pr(ip)%nm), pr(ip)%m_synth(pr(ip)%nm))
     allocate(pr(ip)%z_admm(n), pr(ip)%u_admm(n), pr(ip)%x0(n))
   enddo
-  allocate(b_data(ndtot), x(ntot), rhs(ntot, 4), diag(ntot, 4), work(ntot))
+  allocate(b_data(ndtot), x(ntot), xfull(ntot), rhs(ntot, 4), diag(ntot, 4), work(ntot))
   if (nprob == 2) print *, 'JOINT inversion: two sensitivity kernels in one system.'
 
-  call tfx_check(tfx_create(0_c_int, c_null_ptr, ctx), 'tfx_create')
+  ndev = tfx_device_count()
+  if (ndev <= 0) call stop_msg('No HIP device visible - the MI355X path has no CPU fallback.')
+  call tfx_check(tfx_create(int(mod(myrank, ndev), c_int), c_null_ptr, ctx), 'tfx_create')
+  cb = 0
+  ce = n
+  allocate(counts(nbproc), displs(nbproc))
+  counts = n
+  displs = 0
+  if (nbproc > 1) then
+    hook_ctx = ctx
+    call tfx_check(tfx_set_allreduce(ctx, c_funloc(allreduce_hook), c_null_ptr, int(myrank, c_int), int(nbproc, c_int)), &
+                   'tfx_set_allreduce')
+    if (par%sensit_read == 2) call stop_msg('sensit.readFromFiles = 2 runs single-rank in this host.')
+    ! ---- column partition (calculate_new_partitioning, sensitivity_gravmag.F90:573-640): per-cell non-zero counts of my share
+    ! of the data rows of every kernel, summed over ranks and problems, then the reference's greedy nnz-balancing rule
+    allocate(hist(n), hist_all(n), nel_at(nbproc), nnz_at(nbproc))
+    hist_all = 0
+    if (par%sensit_read == 1) then
+      call read_sensit_nnz_files()
+    else
+      do ip = 1, 2
+        if (.not. pr(ip)%on) cycle
+        call load_inputs(ip)
+        call depth_weight(ip)
+        ra = (pr(ip)%nd / nbproc) * myrank                       ! calculate_nelements_at_cpu (parallel_tools.f90:46-63)
+        rb = ra + pr(ip)%nd / nbproc
+        if (myrank == nbproc - 1) rb = pr(ip)%nd
+        hist = 0
+        if (rb > ra) call build_kernel(ip, ra, rb, 0, 0, nnz_dummy, err_loc, c_loc(hist))
+        hist_all = hist_all + hist
+      enddo
+      call allreduce_sum_i32(hist_all, n)
+    endif
+    call tfx_check(tfx_partition_columns(hist_all, int(n, c_int64_t), int(nbproc, c_int), nel_at, nnz_at), 'calculate_new_partitioning')
+    print *, 'nelements_at_cpu =', nel_at
+    print *, 'nnz_at_cpu =', nnz_at
+    cb = sum(nel_at(1:myrank))
+    ce = cb + nel_at(myrank + 1)
+    counts = nel_at
+    displs(1) = 0
+    do i = 2, nbproc
+      displs(i) = displs(i - 1) + counts(i - 1)
+    enddo
+  endif
+  nloc = ce - cb
+  do ip = 1, 2
+    if (pr(ip)%on) pr(ip)%nml = pr(ip)%nc * nloc
+  enddo
 
   do ip = 1, 2
     if (.not. pr(ip)%on) cycle
     call tfx_check(tfx_select_problem(ctx, pr(ip)%slot), 'tfx_select_problem')
-    ! ---- (I) model grid and data (problem_joint_gravmag.F90:140-157)
-    call read_model_grid(par%grid_file(ip), n, pr(ip)%X1, pr(ip)%X2, pr(ip)%Y1, pr(ip)%Y2, pr(ip)%Z1, pr(ip)%Z2)
-    call read_data(par%data_grid_file(ip), pr(ip)%nd, pr(ip)%ndc, pr(ip)%Xd, pr(ip)%Yd, pr(ip)%Zd, pr(ip)%d_meas)
-    pr(ip)%d_meas = pr(ip)%d_meas * par%data_units_mult(ip)
-    call tfx_check(tfx_set_grid(ctx, par%nx, par%ny, par%nz, pr(ip)%X1, pr(ip)%X2, pr(ip)%Y1, pr(ip)%Y2, pr(ip)%Z1, pr(ip)%Z2), &
-                   'tfx_set_grid')
-
-    ! ---- (II) depth weight (:174-178, :189-193): computed, or read from the SENSIT folder
-    if (par%sensit_read == 0) then
-      print *, 'Calculating the depth weight, type = ', par%dw_type
-      if (par%dw_type == 1) then
-        call tfx_check(tfx_column_weight_type1(ctx, par%dw_power(ip), par%dw_Z0(ip), par%cwm(ip), pr(ip)%cw), 'calculate_depth_weight')
-      else
-        call tfx_check(tfx_column_weight_type2(ctx, int(pr(ip)%nd, c_int64_t), pr(ip)%Xd, pr(ip)%Yd, pr(ip)%Zd, par%dw_power(ip), &
-                                               par%dw_beta(ip), par%cwm(ip), pr(ip)%cw), 'calculate_depth_weight')
-      endif
+    if (nbproc == 1 .or. par%sensit_read == 1) then
+      call load_inputs(ip)
+      call depth_weight(ip)
     else
-      call read_weight_file(par%sensit_path, ip, n, pr(ip)%cw)
+      call tfx_check(tfx_set_grid(ctx, par%nx, par%ny, par%nz, pr(ip)%X1, pr(ip)%X2, pr(ip)%Y1, pr(ip)%Y2, pr(ip)%Z1, pr(ip)%Z2), &
+                     'tfx_set_grid')
     endif
 
-    ! ---- (III) sensitivity kernel (:197-248): built on the device, or re-loaded from SENSIT files
+    ! ---- (III) sensitivity kernel (:197-248): built on the device (this rank's column range), or re-loaded from SENSIT files
     if (par%sensit_read == 1) then
       call read_sensit_files(ctx, par%sensit_path, ip, par%nx, par%ny, par%nz, pr(ip)%nd, pr(ip)%ndc, pr(ip)%nc, par%dw_type, &
-                             par%comp_type, pr(ip)%pw, nnz)
+                             par%comp_type, pr(ip)%pw, nnz, cb, ce)
       err_sum = 0.d0
     else
-      mag_ptr = c_null_ptr
-      if (ip == 1) then
-        print *, 'Calculating GRAVITY sensitivity kernel...'
-      else
-        print *, 'Calculating MAGNETIC sensitivity kernel...'
-        mag_field = (/par%mag_incl, par%mag_decl, par%mag_xaxis_decl, par%mag_intensity/)
-        mag_ptr = c_loc(mag_field)
-      endif
-      call tfx_check(tfx_build_kernel(ctx, ip, pr(ip)%dtype, pr(ip)%ndc, pr(ip)%nc, int(pr(ip)%nd, c_int64_t), pr(ip)%Xd, pr(ip)%Yd, &
-                                      pr(ip)%Zd, pr(ip)%cw, mag_ptr, par%comp_type, par%comp_rate, pr(ip)%pw, c_null_ptr, &
-                                      0_c_int64_t, int(n, c_int64_t), nnz, err_sum, c_null_ptr), 'calculate_and_write_sensit')
+      call build_kernel(ip, 0, pr(ip)%nd, cb, ce, nnz, err_sum, c_null_ptr)
       ! the reference always writes the kernel (calculate_and_write_sensit); TFX_WRITE_SENSIT=0 skips the download + write
       call get_environment_variable('TFX_WRITE_SENSIT', envv, envlen, envstat)
-      if (.not. (envstat == 0 .and. envlen > 0 .and. envv(1:1) == '0')) &
+      if (nbproc == 1 .and. .not. (envstat == 0 .and. envlen > 0 .and. envv(1:1) == '0')) &
         call write_sensit_files(ctx, trim(par%path_output)//'/SENSIT', ip, par%nx, par%ny, par%nz, pr(ip)%nd, pr(ip)%ndc, pr(ip)%nc, &
                                 par%dw_type, par%comp_type, err_sum / dble(pr(ip)%nd * pr(ip)%ndc * pr(ip)%nc), pr(ip)%pw, pr(ip)%cw)
+    endif
+    if (nbproc > 1) then                      ! totals over the column ranges (error sums are per line, the same on every rank)
+      s1 = dble(nnz)
+      call allreduce_sum_dp_scalar(s1)
+      nnz = nint(s1, c_int64_t)
     endif
     print *, 'nnz_total = ', nnz
     print *, 'COMPRESSION RATE = ', dble(nnz) / dble(n) / dble(pr(ip)%nd) / dble(pr(ip)%nc) / dble(pr(ip)%ndc)
@@ -667,7 +722,11 @@ program tomofastx_amd
   call tfx_check(tfx_select_problem(ctx, 0_c_int), 'tfx_select_problem')
 
   call make_dir(par%path_output)
-  open(newunit=ucost, file=trim(par%path_output)//'/costs.txt', status='replace', action='write')
+  if (io_rank) then
+    open(newunit=ucost, file=trim(par%path_output)//'/costs.txt', status='replace', action='write')
+  else
+    open(newunit=ucost, status='scratch', action='readwrite')
+  endif
   write(ucost, '(A)') '# 1:iteration, then per active problem: data_cost, model_cost, ADMM_cost, ADMM_weight'
 
   ! ---- (V) major inversion loop (:473-547)
@@ -684,6 +743,8 @@ program tomofastx_amd
       if (.not. pr(ip)%on) cycle
       c0 = pr(ip)%col0
       r0 = pr(ip)%row0
+      lc0 = 0
+      if (ip == 2 .and. pr(1)%on) lc0 = pr(1)%nml               ! this rank's unknowns: [m1 cells (cb, ce]; m2 cells (cb, ce]]
       ! residuals (:666-675; data weight 1) and the right-hand side pw * residuals (joint_inverse_problem.F90:379-387)
       b_data(r0 + 1:r0 + pr(ip)%ndt) = pr(ip)%pw * (pr(ip)%d_meas - pr(ip)%d_calc)
       if (par%alpha(ip) /= 0.d0) then                              ! damping.F90:97-234, one block per problem and component
@@ -694,9 +755,10 @@ program tomofastx_amd
         enddo
         call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
         diag(:, nblocks) = 0.0
-        diag(c0 + 1:c0 + pr(ip)%nm, nblocks) = real(par%alpha(ip) * pr(ip)%pw, c_float)
+        diag(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = real(par%alpha(ip) * pr(ip)%pw, c_float)
         rhs(:, nblocks) = 0.d0
-        rhs(c0 + 1:c0 + pr(ip)%nm, nblocks) = -par%alpha(ip) * pr(ip)%pw * work(1:pr(ip)%nm)
+        call to_local(ip, work, rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks))
+        rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = -par%alpha(ip) * pr(ip)%pw * rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks)
         dptr(nblocks) = c_loc(diag(1, nblocks))
         rptr(nblocks) = c_loc(rhs(1, nblocks))
       endif
@@ -709,9 +771,10 @@ program tomofastx_amd
         work((kadm - 1) * n + 1:kadm * n) = (pr(ip)%m((kadm - 1) * n + 1:kadm * n) - pr(ip)%x0) / pr(ip)%cw
         call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
         diag(:, nblocks) = 0.0
-        diag(c0 + (kadm - 1) * n + 1:c0 + kadm * n, nblocks) = real(pr(ip)%rho * pr(ip)%pw, c_float)
+        diag(lc0 + (kadm - 1) * nloc + 1:lc0 + kadm * nloc, nblocks) = real(pr(ip)%rho * pr(ip)%pw, c_float)
         rhs(:, nblocks) = 0.d0
-        rhs(c0 + 1:c0 + pr(ip)%nm, nblocks) = -pr(ip)%rho * pr(ip)%pw * work(1:pr(ip)%nm)
+        call to_local(ip, work, rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks))
+        rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = -pr(ip)%rho * pr(ip)%pw * rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks)
         dptr(nblocks) = c_loc(diag(1, nblocks))
         rptr(nblocks) = c_loc(rhs(1, nblocks))
         s1 = sum((pr(ip)%z_admm - pr(ip)%m((kadm - 1) * n + 1:kadm * n))**2)
@@ -728,11 +791,16 @@ program tomofastx_amd
     do ip = 1, 2
       if (.not. pr(ip)%on) cycle
       c0 = pr(ip)%col0
+      lc0 = 0
+      if (ip == 2 .and. pr(1)%on) lc0 = pr(1)%nml
+      do k = 1, pr(ip)%nc                                          ! slices of all ranks -> the full update (wavelet_utils.F90:37-72)
+        call allgather_slices(x(lc0 + (k - 1) * nloc + 1:lc0 + k * nloc), nloc, xfull(c0 + (k - 1) * n + 1:c0 + k * n), counts, displs)
+      enddo
       if (par%comp_type > 0) &                                     ! :559-567
-        call tfx_check(tfx_wavelet(ctx, x(c0 + 1:c0 + pr(ip)%nm), par%nx, par%ny, par%nz, int(pr(ip)%nc, c_int64_t), par%comp_type, &
-                                   2_c_int), 'inverse_wavelet')
+        call tfx_check(tfx_wavelet(ctx, xfull(c0 + 1:c0 + pr(ip)%nm), par%nx, par%ny, par%nz, int(pr(ip)%nc, c_int64_t), &
+                                   par%comp_type, 2_c_int), 'inverse_wavelet')
       do k = 1, pr(ip)%nc
-        pr(ip)%m((k - 1) * n + 1:k * n) = pr(ip)%m((k - 1) * n + 1:k * n) + x(c0 + (k - 1) * n + 1:c0 + k * n) * pr(ip)%cw   ! :570, :500
+        pr(ip)%m((k - 1) * n + 1:k * n) = pr(ip)%m((k - 1) * n + 1:k * n) + xfull(c0 + (k - 1) * n + 1:c0 + k * n) * pr(ip)%cw   ! :570, :500
       enddo
       call calculate_data(ip, pr(ip)%m, pr(ip)%d_calc)             ! :513
       call model_cost(ip, pr(ip)%cost_model)
@@ -757,6 +825,7 @@ program tomofastx_amd
   enddo
   call tfx_check(tfx_destroy(ctx), 'tfx_destroy')
   print *, 'THE END.'
+  call host_mpi_finalize()
 
 contains
 
@@ -771,6 +840,92 @@ contains
     flush(ucost)
   end subroutine write_costs
 
+  ! this rank's cells (cb, ce] of every model component of a full vector
+  subroutine to_local(jp, vfull, vloc)
+    integer, intent(in) :: jp
+    real(dp), intent(in) :: vfull(:)
+    real(dp), intent(out) :: vloc(:)
+    integer :: kc
+    do kc = 1, pr(jp)%nc
+      vloc((kc - 1) * nloc + 1:kc * nloc) = vfull((kc - 1) * n + cb + 1:(kc - 1) * n + ce)
+    enddo
+  end subroutine to_local
+
+  subroutine allreduce_sum_dp_scalar(v)
+    real(dp), intent(inout) :: v
+    real(dp) :: a(1)
+    a(1) = v
+    call allreduce_sum_dp(a, 1)
+    v = a(1)
+  end subroutine allreduce_sum_dp_scalar
+
+  ! (I) model grid and data of problem jp (problem_joint_gravmag.F90:140-157), grid to the device
+  subroutine load_inputs(jp)
+    integer, intent(in) :: jp
+    call read_model_grid(par%grid_file(jp), n, pr(jp)%X1, pr(jp)%X2, pr(jp)%Y1, pr(jp)%Y2, pr(jp)%Z1, pr(jp)%Z2)
+    call read_data(par%data_grid_file(jp), pr(jp)%nd, pr(jp)%ndc, pr(jp)%Xd, pr(jp)%Yd, pr(jp)%Zd, pr(jp)%d_meas)
+    pr(jp)%d_meas = pr(jp)%d_meas * par%data_units_mult(jp)
+    call tfx_check(tfx_set_grid(ctx, par%nx, par%ny, par%nz, pr(jp)%X1, pr(jp)%X2, pr(jp)%Y1, pr(jp)%Y2, pr(jp)%Z1, pr(jp)%Z2), &
+                   'tfx_set_grid')
+  end subroutine load_inputs
+
+  ! (II) depth weight (:174-178, :189-193): computed, or read from the SENSIT folder
+  subroutine depth_weight(jp)
+    integer, intent(in) :: jp
+    if (par%sensit_read == 0) then
+      print *, 'Calculating the depth weight, type = ', par%dw_type
+      if (par%dw_type == 1) then
+        call tfx_check(tfx_column_weight_type1(ctx, par%dw_power(jp), par%dw_Z0(jp), par%cwm(jp), pr(jp)%cw), 'calculate_depth_weight')
+      else
+        call tfx_check(tfx_column_weight_type2(ctx, int(pr(jp)%nd, c_int64_t), pr(jp)%Xd, pr(jp)%Yd, pr(jp)%Zd, par%dw_power(jp), &
+                                               par%dw_beta(jp), par%cwm(jp), pr(jp)%cw), 'calculate_depth_weight')
+      endif
+    else
+      call read_weight_file(par%sensit_path, jp, n, pr(jp)%cw)
+    endif
+  end subroutine depth_weight
+
+  ! the kernel of problem jp for the data rows (row_a, row_b] and the cells (col_a, col_b] into slot pr(jp)%slot
+  ! (col_a = col_b = 0: nothing is stored, only the per-cell non-zero counts are returned in hist_ptr)
+  subroutine build_kernel(jp, row_a, row_b, col_a, col_b, nnz_k, err_k, hist_ptr)
+    integer, intent(in) :: jp, row_a, row_b, col_a, col_b
+    integer(c_int64_t), intent(out) :: nnz_k
+    real(c_double), intent(out) :: err_k
+    type(c_ptr), intent(in) :: hist_ptr
+    type(c_ptr) :: mptr
+    mptr = c_null_ptr
+    if (jp == 1) then
+      print *, 'Calculating GRAVITY sensitivity kernel...'
+    else
+      print *, 'Calculating MAGNETIC sensitivity kernel...'
+      mag_field = (/par%mag_incl, par%mag_decl, par%mag_xaxis_decl, par%mag_intensity/)
+      mptr = c_loc(mag_field)
+    endif
+    call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
+    call tfx_check(tfx_build_kernel(ctx, jp, pr(jp)%dtype, pr(jp)%ndc, pr(jp)%nc, int(row_b - row_a, c_int64_t), &
+                                    pr(jp)%Xd(row_a + 1:row_b), pr(jp)%Yd(row_a + 1:row_b), pr(jp)%Zd(row_a + 1:row_b), pr(jp)%cw, &
+                                    mptr, par%comp_type, par%comp_rate, pr(jp)%pw, c_null_ptr, int(col_a, c_int64_t), &
+                                    int(col_b, c_int64_t), nnz_k, err_k, hist_ptr), 'calculate_and_write_sensit')
+  end subroutine build_kernel
+
+  ! sensit.readFromFiles = 1 on several ranks: the per-cell counts of every kernel from the sensit_*_nnz files
+  ! (read_sensit_nnz, sensitivity_gravmag.F90:530-568)
+  subroutine read_sensit_nnz_files()
+    integer :: jp, u, ios
+    integer(c_int32_t) :: nread
+    do jp = 1, 2
+      if (.not. pr(jp)%on) cycle
+      open(newunit=u, file=trim(par%sensit_path)//'sensit_'//SENSIT_SUFFIX(jp)//'_nnz', status='old', access='stream', &
+           form='unformatted', action='read', convert='big_endian', iostat=ios)
+      if (ios /= 0) call stop_msg('Error in opening the sensit_nnz file!')
+      read(u) nread
+      if (nread /= n) call stop_msg('Wrong file header in calculate_new_partitioning!')
+      read(u) hist
+      close(u)
+      hist_all = hist_all + hist
+    enddo
+  end subroutine read_sensit_nnz_files
+
   subroutine to_wavelet(v, ncomp)
     real(dp), intent(inout) :: v(:)
     integer, intent(in) :: ncomp
@@ -783,7 +938,7 @@ contains
     integer, intent(in) :: jp
     real(dp), intent(in) :: model(:)
     real(dp), intent(out) :: dcalc(:)
-    real(dp), allocatable :: w(:)
+    real(dp), allocatable :: w(:), wl(:)
     integer :: p, kc
     allocate(w(pr(jp)%nm))
     do kc = 1, pr(jp)%nc
@@ -796,8 +951,10 @@ contains
       enddo
     enddo
     call to_wavelet(w, pr(jp)%nc)
+    allocate(wl(max(1, pr(jp)%nml)))
+    call to_local(jp, w, wl)
     call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
-    call tfx_check(tfx_calc_data(ctx, w, pr(jp)%pw, c_null_ptr, dcalc), 'model_calculate_data')
+    call tfx_check(tfx_calc_data(ctx, wl, pr(jp)%pw, c_null_ptr, dcalc), 'model_calculate_data')    ! all-reduced through the hook
     call tfx_check(tfx_select_problem(ctx, 0_c_int), 'tfx_select_problem')
   end subroutine calculate_data
 
