@@ -56,6 +56,10 @@ int tfx_device_count(void);
  * all-reduce hook stage the device buffer through MPI when it has no device-aware collective at hand.                   */
 int tfx_copy(tfx_ctx *ctx, void *dst, const void *src, int64_t bytes);
 
+/* Raw device buffers for a host that moves packed matrix pieces itself (tfx_rowstore_pack -> send -> tfx_matrix_append_rows). */
+int tfx_device_malloc(tfx_ctx *ctx, int64_t bytes, void **ptr_out);
+int tfx_device_free(tfx_ctx *ctx, void *ptr);
+
 /* All-reduce hook (sum, fp64, in place on a DEVICE buffer of n doubles, enqueued on `stream`).
  * NULL = single rank.  rank/nranks tell LSQR who adds the -alpha*u term (lsqr_solver2.F90:194-198).         */
 typedef int (*tfx_allreduce_fn)(void *user, double *dev_buf, int64_t n, void *stream);
@@ -162,6 +166,7 @@ int tfx_cons_clear(tfx_ctx *ctx);
 
 /* ---- multi-GPU build: row-parallel compression + relayout (what the reference does through SENSIT files and a
  * rank-0 MPI_Scatterv per row, sensitivity_gravmag.F90:179-189 and :795-830).
+ * (One row store per problem slot, tfx_select_problem: a joint run partitions on the counts of both kernels first.)
  * tfx_rowstore_build: like tfx_build_kernel_* for THIS rank's share of the observations, but the compressed rows stay
  *   row-major on the device with all their columns (problem_type 1 grav / 2 magn with mag_field = incl, decl, azim, nT).
  * tfx_rowstore_counts: counts_out[r*nparts + d] = entries of local row r with column in [bounds[d], bounds[d+1]).

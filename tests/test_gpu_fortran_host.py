@@ -311,6 +311,82 @@ def test_two_ranks_under_mpiexec_match_the_reference_two_rank_run(tmp_path, gold
         assert np.linalg.norm(model - ref) <= tol * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
 
 
+PAR_BIG = """global.outputFolderPath     = out/
+modelGrid.size                      = 32 24 12
+modelGrid.grav.file                 = grid.txt
+forward.data.grav.nData             = {nd}
+forward.data.grav.dataGridFile      = data_grid.txt
+forward.data.grav.useSyntheticModelForDataValues = 1
+forward.data.grav.syntheticModelFile = model_true.txt
+forward.depthWeighting.type         = 1
+forward.depthWeighting.grav.power   = 2.0d0
+sensit.readFromFiles                = 0
+forward.matrixCompression.type      = 2
+forward.matrixCompression.rate      = 0.05d0
+inversion.priorModel.type           = 1
+inversion.priorModel.grav.value     = 0.d0
+inversion.startingModel.type        = 1
+inversion.startingModel.grav.value  = 0.d0
+inversion.nMajorIterations          = 2
+inversion.nMinorIterations          = 8
+inversion.minResidual               = 1.d-13
+inversion.modelDamping.grav.weight  = 1.d-7
+inversion.joint.grav.problemWeight  = 1.d0
+inversion.joint.magn.problemWeight  = 0.d0
+"""
+
+
+def test_row_parallel_build_with_mpi_relayout(tmp_path):
+    """3 ranks under mpiexec, 4608 data = 3 row blocks: every rank compresses its row block with all columns, the pieces are
+    cut by column range on the GPU and travel over MPI to the owners (read_sensitivity_kernel's relayout without the files).
+    Same final model as the single-rank run and as the scheme where every rank builds all rows for its own columns."""
+    import importlib
+    if not os.path.isfile(EXE) or not os.path.isfile(MPIEXEC):
+        pytest.skip("Fortran host / mpiexec not available")
+    syn = importlib.import_module("tomofast-x_amd").synthetic
+    nx, ny, nz = 32, 24, 12
+    grid = syn.grid(nx, ny, nz)
+    xs, ys, zs = syn.observations(nx, ny, 72, 64)
+    n = nx * ny * nz
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    mtrue = np.where((k.ravel() >= nz // 4) & (k.ravel() < nz // 2) & (j.ravel() >= ny // 3) & (j.ravel() < 2 * ny // 3) &
+                     (i.ravel() >= nx // 3) & (i.ravel() < 2 * nx // 3), 300.0, 0.0)
+    models = {}
+    for tag, cmd, env in (("one", [EXE], {}), ("exchange", [MPIEXEC, "-n", "3", EXE], {}),
+                          ("redundant", [MPIEXEC, "-n", "3", EXE], {"TFX_BUILD_MODE": "redundant"})):
+        wd = os.path.join(str(tmp_path), tag)
+        os.makedirs(wd)
+        with open(os.path.join(wd, "grid.txt"), "w") as f:
+            f.write("%d\n" % n)
+            for p in range(n):
+                f.write("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %d\n" % (grid[0][p], grid[1][p], grid[2][p], grid[3][p], grid[4][p],
+                                                                          grid[5][p], i.ravel()[p] + 1, j.ravel()[p] + 1, k.ravel()[p] + 1))
+        with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+            f.write("%d\n" % xs.size)
+            for o in zip(xs, ys, zs):
+                f.write("%.17g %.17g %.17g 0.0\n" % o)
+        with open(os.path.join(wd, "model_true.txt"), "w") as f:
+            f.write("%d\n" % n)
+            f.write("\n".join("%.17g" % v for v in mtrue) + "\n")
+        open(os.path.join(wd, "Parfile.txt"), "w").write(PAR_BIG.format(nd=xs.size))
+        e = dict(os.environ, TFX_WRITE_SENSIT="0", **env)
+        out = subprocess.run(cmd + ["-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900, env=e)
+        assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+        if tag == "exchange":
+            assert "row-parallel" in out.stdout
+        if tag == "redundant":
+            assert "row-parallel" not in out.stdout
+        nnz = int(out.stdout.split("nnz_total =")[1].split()[0])
+        models[tag] = (read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0], nnz)
+    ref, nnz_ref = models["one"]
+    for tag in ("exchange", "redundant"):
+        m, nnz = models[tag]
+        assert nnz == nnz_ref
+        # 2 x 8 LSQR iterations stop mid-convergence; partial sums are combined in a different order on 3 ranks
+        assert np.linalg.norm(m - ref) <= 1e-6 * np.linalg.norm(ref), (tag, np.linalg.norm(m - ref) / np.linalg.norm(ref))
+    assert np.linalg.norm(models["exchange"][0] - models["redundant"][0]) <= 1e-6 * np.linalg.norm(ref)
+
+
 def test_parfile_errors_like_the_reference(tmp_path):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")

@@ -51,6 +51,29 @@ int tfx_copy(tfx_ctx *ctx, void *dst, const void *src, int64_t bytes)
     return 0;
 }
 
+// raw device buffers for a host that moves packed matrix pieces itself (tfx_rowstore_pack -> send -> tfx_matrix_append_rows)
+int tfx_device_malloc(tfx_ctx *ctx, int64_t bytes, void **ptr_out)
+{
+    if (!ctx || !ptr_out || bytes < 0) return fail(TFX_E_ARG, "tfx_device_malloc: bad arguments");
+    TFX_HIP(hipSetDevice(ctx->device));
+    *ptr_out = nullptr;
+    if (bytes == 0) return 0;
+    hipError_t e = hipMalloc(ptr_out, (size_t)bytes);
+    if (e != hipSuccess) return fail(TFX_E_HIP, "hipMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e));
+    return 0;
+}
+
+int tfx_device_free(tfx_ctx *ctx, void *ptr)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    TFX_HIP(hipSetDevice(ctx->device));
+    if (ptr) {
+        (void)hipStreamSynchronize(ctx->stream);
+        TFX_HIP(hipFree(ptr));
+    }
+    return 0;
+}
+
 int lsqr_free(tfx_ctx *ctx);   // lsqr.hip
 
 int tfx_destroy(tfx_ctx *ctx)

@@ -1809,7 +1809,7 @@ int tfx_rowstore_build(tfx_ctx *ctx, int problem_type, int64_t ndata, const doub
     RowGen gen;
     TFX_TRY(make_rowgen(gen, problem_type, 1, 1, 1, mag_field));
     return build_kernel_any(ctx, gen, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight, 0, 0,
-                            nnz_out, error_sum_out, nnz_hist_out, &ctx->rowstore);
+                            nnz_out, error_sum_out, nnz_hist_out, &ctx->rowstore());
 }
 
 // the same with any data type / data components the reference supports (one model component)
@@ -1822,7 +1822,7 @@ int tfx_rowstore_build_ex(tfx_ctx *ctx, int problem_type, int data_type, int nda
     RowGen gen;
     TFX_TRY(make_rowgen(gen, problem_type, data_type, ndata_components, 1, mag_field));
     return build_kernel_any(ctx, gen, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight, 0, 0,
-                            nnz_out, error_sum_out, nnz_hist_out, &ctx->rowstore);
+                            nnz_out, error_sum_out, nnz_hist_out, &ctx->rowstore());
 }
 
 // first entry of every row with column >= bounds[d] (d = 0..nparts); counts[r*nparts + d] = entries in [bounds[d], bounds[d+1])
@@ -1846,7 +1846,7 @@ __global__ void k_rs_bounds(const int32_t *__restrict__ cols, const int32_t *__r
 int tfx_rowstore_counts(tfx_ctx *ctx, int nparts, const int64_t *bounds, int32_t *counts_out)
 {
     if (!ctx || !bounds || !counts_out) return fail(TFX_E_ARG, "tfx_rowstore_counts: null argument");
-    RowStore &rs = ctx->rowstore;
+    RowStore &rs = ctx->rowstore();
     if (rs.nrows == 0) return fail(TFX_E_STATE, "no row store");
     if (nparts < 1 || nparts > 1024) return fail(TFX_E_ARG, "nparts out of range");
     TFX_HIP(hipSetDevice(ctx->device));
@@ -1904,7 +1904,7 @@ int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t co
                       float *vals_dev_out, int64_t capacity, int64_t *n_out)
 {
     if (!ctx || !n_out) return fail(TFX_E_ARG, "tfx_rowstore_pack: null argument");
-    RowStore &rs = ctx->rowstore;
+    RowStore &rs = ctx->rowstore();
     if (rs.nrows == 0) return fail(TFX_E_STATE, "no row store");
     if (row_begin < 0 || nrows <= 0 || row_begin + nrows > rs.nrows) return fail(TFX_E_ARG, "row range outside the row store");
     TFX_HIP(hipSetDevice(ctx->device));
@@ -1937,10 +1937,10 @@ int tfx_rowstore_free(tfx_ctx *ctx)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     (void)hipStreamSynchronize(ctx->stream);
-    ctx->rowstore.cols.release();
-    ctx->rowstore.vals.release();
-    ctx->rowstore.nel.release();
-    ctx->rowstore.nrows = 0;
+    ctx->rowstore().cols.release();
+    ctx->rowstore().vals.release();
+    ctx->rowstore().nel.release();
+    ctx->rowstore().nrows = 0;
     return 0;
 }
 

@@ -149,7 +149,8 @@ struct tfx_ctx {
     tfx::TiledMatrix cons;
     tfx::DBuf<double> cons_rhs;        // right-hand side of the C rows (replicated)
     tfx::TiledMatrix *target = &mat;   // which matrix matrix_begin / append / finish assemble
-    tfx::RowStore rowstore;
+    tfx::RowStore rowstores[2];        // one per problem slot (a joint run partitions on the counts of both kernels before the relayout)
+    tfx::RowStore &rowstore() { return rowstores[slot]; }
     // scratch vectors for spmv / spmtv with host pointers
     tfx::DBuf<double> vx, vb;
     // comm

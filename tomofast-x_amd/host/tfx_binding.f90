@@ -166,6 +166,78 @@ module tfx_binding
       integer(c_int), value :: ncomponents
     end function
 
+    ! ---- multi-GPU build: row-parallel compression + relayout (sensitivity_gravmag.F90:179-189, :795-830 without the files)
+    integer(c_int) function tfx_rowstore_build_ex(ctx, problem_type, data_type, ndata_components, ndata, xd, yd, zd, column_weight, &
+                                                  mag_field, compression_type, rate, problem_weight, data_weight, nnz, error_sum, &
+                                                  nnz_hist) bind(C, name="tfx_rowstore_build_ex")
+      import :: c_int, c_ptr, c_double, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: problem_type, data_type, ndata_components
+      integer(c_int64_t), value :: ndata
+      real(c_double), intent(in) :: xd(*), yd(*), zd(*), column_weight(*)
+      type(c_ptr), value :: mag_field
+      integer(c_int), value :: compression_type
+      real(c_double), value :: rate, problem_weight
+      type(c_ptr), value :: data_weight
+      integer(c_int64_t), intent(out) :: nnz
+      real(c_double), intent(out) :: error_sum
+      type(c_ptr), value :: nnz_hist
+    end function
+
+    ! counts(d, r) = entries of local row r with column in [bounds(d), bounds(d+1))   (C layout counts[r*nparts + d])
+    integer(c_int) function tfx_rowstore_counts(ctx, nparts, bounds, counts) bind(C, name="tfx_rowstore_counts")
+      import :: c_int, c_ptr, c_int64_t, c_int32_t
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nparts
+      integer(c_int64_t), intent(in) :: bounds(*)
+      integer(c_int32_t), intent(out) :: counts(*)
+    end function
+
+    ! columns [col_begin, col_end) of local rows [row_begin, row_begin + nrows) packed into DEVICE buffers
+    integer(c_int) function tfx_rowstore_pack(ctx, row_begin, nrows, col_begin, col_end, cols_dev, vals_dev, capacity, n_out) &
+        bind(C, name="tfx_rowstore_pack")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx, cols_dev, vals_dev
+      integer(c_int64_t), value :: row_begin, nrows, col_begin, col_end, capacity
+      integer(c_int64_t), intent(out) :: n_out
+    end function
+
+    integer(c_int) function tfx_rowstore_free(ctx) bind(C, name="tfx_rowstore_free")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    integer(c_int) function tfx_matrix_begin(ctx, nrows, ncols, nnz_upper) bind(C, name="tfx_matrix_begin")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: nrows, ncols, nnz_upper
+    end function
+
+    ! rows [row_begin, row_begin + nr) (row_begin a multiple of 2048), packed in DEVICE buffers, nel(r) entries each
+    integer(c_int) function tfx_matrix_append_rows(ctx, row_begin, nr, cols_dev, vals_dev, nel) bind(C, name="tfx_matrix_append_rows")
+      import :: c_int, c_ptr, c_int64_t, c_int32_t
+      type(c_ptr), value :: ctx, cols_dev, vals_dev
+      integer(c_int64_t), value :: row_begin, nr
+      integer(c_int32_t), intent(in) :: nel(*)
+    end function
+
+    integer(c_int) function tfx_matrix_finish(ctx) bind(C, name="tfx_matrix_finish")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    integer(c_int) function tfx_device_malloc(ctx, bytes, ptr) bind(C, name="tfx_device_malloc")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: bytes
+      type(c_ptr), intent(out) :: ptr
+    end function
+
+    integer(c_int) function tfx_device_free(ctx, ptr) bind(C, name="tfx_device_free")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, ptr
+    end function
+
     ! joint inversion: slot 0 / 1 = which problem's sensitivity matrix the build / matrix / product / calc_data calls act on;
     ! LSQR solves with blockdiag(slot 0, slot 1) once slot 1 holds a matrix (src/inversion/joint_inverse_problem.F90:712-739)
     integer(c_int) function tfx_select_problem(ctx, slot) bind(C, name="tfx_select_problem")

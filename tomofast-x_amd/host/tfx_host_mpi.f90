@@ -92,4 +92,32 @@ contains
     endif
   end subroutine allgather_slices
 
+  ! counts of every rank's rows, rank after rank (counts_loc: nparts x nrows_loc, row blocks are dealt out contiguously)
+  subroutine allgather_counts(counts_loc, nparts, nrows_loc, counts_all, rows_at, row_displs)
+    integer, intent(in) :: nparts, nrows_loc, rows_at(:), row_displs(:)
+    integer(c_int32_t), intent(in) :: counts_loc(nparts, *)
+    integer(c_int32_t), intent(out) :: counts_all(nparts, *)
+    integer :: ierr
+    call MPI_Allgatherv(counts_loc, nparts * nrows_loc, MPI_INTEGER4, counts_all, nparts * rows_at, nparts * row_displs, &
+                        MPI_INTEGER4, MPI_COMM_WORLD, ierr)
+  end subroutine allgather_counts
+
+  subroutine send_piece(dest, n, cols, vals, tag)
+    integer, intent(in) :: dest, n, tag
+    integer(c_int32_t), intent(in) :: cols(n)
+    real(c_float), intent(in) :: vals(n)
+    integer :: ierr
+    call MPI_Send(cols, n, MPI_INTEGER4, dest, tag, MPI_COMM_WORLD, ierr)
+    call MPI_Send(vals, n, MPI_REAL4, dest, tag + 1, MPI_COMM_WORLD, ierr)
+  end subroutine send_piece
+
+  subroutine recv_piece(src, n, cols, vals, tag)
+    integer, intent(in) :: src, n, tag
+    integer(c_int32_t), intent(out) :: cols(n)
+    real(c_float), intent(out) :: vals(n)
+    integer :: ierr, st(MPI_STATUS_SIZE)
+    call MPI_Recv(cols, n, MPI_INTEGER4, src, tag, MPI_COMM_WORLD, st, ierr)
+    call MPI_Recv(vals, n, MPI_REAL4, src, tag + 1, MPI_COMM_WORLD, st, ierr)
+  end subroutine recv_piece
+
 end module tfx_host_mpi

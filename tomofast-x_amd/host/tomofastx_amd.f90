@@ -21,6 +21,7 @@
 module tfx_host_params
   implicit none
   integer, parameter :: dp = kind(1.d0)
+  integer, parameter :: ROW_BLOCK = 2048   ! rows per row block of the device matrix (tfx_matrix_append_rows)
   logical, save :: io_rank = .true.        ! only rank 0 writes output files (the reference: `if (myrank == 0)` around every writer)
 
   type t_par
@@ -491,7 +492,7 @@ program tomofastx_amd
     logical :: on = .false.
     integer :: slot = 0, nd = 0, ndc = 1, nc = 1, nm = 0, ndt = 0, dtype = 1, col0 = 0, row0 = 0
     integer :: nml = 0                        ! local unknowns: nc * (cells of this rank)
-    real(dp) :: pw = 0.d0, rho = 0.d0, cost_data = 0.d0, cost_model = 0.d0, cost_admm = 0.d0
+    real(dp) :: pw = 0.d0, rho = 0.d0, cost_data = 0.d0, cost_model = 0.d0, cost_admm = 0.d0, err_rows = 0.d0
     real(dp), allocatable :: X1(:), X2(:), Y1(:), Y2(:), Z1(:), Z2(:), cw(:)
     real(dp), allocatable :: Xd(:), Yd(:), Zd(:), d_meas(:), d_calc(:)
     real(dp), allocatable :: m(:), m_prior(:), m_synth(:), z_admm(:), u_admm(:), x0(:)
@@ -625,11 +626,18 @@ program tomofastx_amd
         if (.not. pr(ip)%on) cycle
         call load_inputs(ip)
         call depth_weight(ip)
-        ra = (pr(ip)%nd / nbproc) * myrank                       ! calculate_nelements_at_cpu (parallel_tools.f90:46-63)
-        rb = ra + pr(ip)%nd / nbproc
-        if (myrank == nbproc - 1) rb = pr(ip)%nd
         hist = 0
-        if (rb > ra) call build_kernel(ip, ra, rb, 0, 0, nnz_dummy, err_loc, c_loc(hist))
+        if (exchange_ok(ip)) then
+          ! row-parallel build: my row blocks (of 2048 data) with ALL their columns stay on the device; relayout after the partition
+          call my_row_blocks(pr(ip)%nd, ra, rb)
+          pr(ip)%err_rows = 0.d0
+          if (rb > ra) call build_rowstore(ip, ra, rb, pr(ip)%err_rows, c_loc(hist))
+        else
+          ra = (pr(ip)%nd / nbproc) * myrank                     ! calculate_nelements_at_cpu (parallel_tools.f90:46-63)
+          rb = ra + pr(ip)%nd / nbproc
+          if (myrank == nbproc - 1) rb = pr(ip)%nd
+          if (rb > ra) call build_kernel(ip, ra, rb, 0, 0, nnz_dummy, err_loc, c_loc(hist))
+        endif
         hist_all = hist_all + hist
       enddo
       call allreduce_sum_i32(hist_all, n)
@@ -667,7 +675,13 @@ program tomofastx_amd
                              par%comp_type, pr(ip)%pw, nnz, cb, ce)
       err_sum = 0.d0
     else
-      call build_kernel(ip, 0, pr(ip)%nd, cb, ce, nnz, err_sum, c_null_ptr)
+      if (nbproc > 1 .and. exchange_ok(ip)) then
+        call relayout_rowstore(ip, nnz)
+        err_sum = pr(ip)%err_rows
+        call allreduce_sum_dp_scalar(err_sum)
+      else
+        call build_kernel(ip, 0, pr(ip)%nd, cb, ce, nnz, err_sum, c_null_ptr)
+      endif
       ! the reference always writes the kernel (calculate_and_write_sensit); TFX_WRITE_SENSIT=0 skips the download + write
       call get_environment_variable('TFX_WRITE_SENSIT', envv, envlen, envstat)
       if (nbproc == 1 .and. .not. (envstat == 0 .and. envlen > 0 .and. envv(1:1) == '0')) &
@@ -907,6 +921,149 @@ contains
                                     mptr, par%comp_type, par%comp_rate, pr(jp)%pw, c_null_ptr, int(col_a, c_int64_t), &
                                     int(col_b, c_int64_t), nnz_k, err_k, hist_ptr), 'calculate_and_write_sensit')
   end subroutine build_kernel
+
+  ! The relayout-based build applies to single-component compressed kernels (row blocks of 2048 matrix rows = whole data);
+  ! TFX_BUILD_MODE=redundant forces the simpler scheme (every rank builds all rows for its own columns).
+  logical function exchange_ok(jp)
+    integer, intent(in) :: jp
+    character(len=32) :: v
+    integer :: l, st
+    call get_environment_variable('TFX_BUILD_MODE', v, l, st)
+    exchange_ok = pr(jp)%nc == 1 .and. pr(jp)%ndc == 1 .and. par%comp_type > 0
+    if (st == 0 .and. l > 0) then
+      if (v(1:l) == 'redundant') exchange_ok = .false.
+    endif
+  end function exchange_ok
+
+  ! row blocks dealt out contiguously: this rank's data (row_a, row_b]
+  subroutine my_row_blocks(ndat, row_a, row_b)
+    integer, intent(in) :: ndat
+    integer, intent(out) :: row_a, row_b
+    integer :: nblk, base, rem, b0, b1
+    nblk = (ndat + ROW_BLOCK - 1) / ROW_BLOCK
+    base = nblk / nbproc
+    rem = mod(nblk, nbproc)
+    b0 = myrank * base + min(myrank, rem)
+    b1 = b0 + base
+    if (myrank < rem) b1 = b1 + 1
+    row_a = min(b0 * ROW_BLOCK, ndat)
+    row_b = min(b1 * ROW_BLOCK, ndat)
+  end subroutine my_row_blocks
+
+  subroutine build_rowstore(jp, row_a, row_b, err_k, hist_ptr)
+    integer, intent(in) :: jp, row_a, row_b
+    real(c_double), intent(out) :: err_k
+    type(c_ptr), intent(in) :: hist_ptr
+    type(c_ptr) :: mptr
+    integer(c_int64_t) :: nnz_k
+    mptr = c_null_ptr
+    if (jp == 1) then
+      print *, 'Calculating GRAVITY sensitivity kernel (row-parallel)...'
+    else
+      print *, 'Calculating MAGNETIC sensitivity kernel (row-parallel)...'
+      mag_field = (/par%mag_incl, par%mag_decl, par%mag_xaxis_decl, par%mag_intensity/)
+      mptr = c_loc(mag_field)
+    endif
+    call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
+    call tfx_check(tfx_rowstore_build_ex(ctx, jp, pr(jp)%dtype, pr(jp)%ndc, int(row_b - row_a, c_int64_t), pr(jp)%Xd(row_a + 1:row_b), &
+                                         pr(jp)%Yd(row_a + 1:row_b), pr(jp)%Zd(row_a + 1:row_b), pr(jp)%cw, mptr, par%comp_type, &
+                                         par%comp_rate, pr(jp)%pw, c_null_ptr, nnz_k, err_k, hist_ptr), 'calculate_and_write_sensit')
+  end subroutine build_rowstore
+
+  ! read_sensitivity_kernel's relayout (sensitivity_gravmag.F90:795-830) without the files: every row block is cut by column range
+  ! on its owner's GPU and the pieces go to the owners of the columns, which lay them out as tiles
+  subroutine relayout_rowstore(jp, nnz_k)
+    integer, intent(in) :: jp
+    integer(c_int64_t), intent(out) :: nnz_k
+    integer :: ndat, row_a, row_b, nrl, nblk, b, ga, gb, o, d, rr, base, rem
+    integer, allocatable :: rows_at(:), row_displs(:), blk_owner(:)
+    integer(c_int64_t), allocatable :: bounds(:)
+    integer(c_int32_t), allocatable, target :: cnt_loc(:, :), cnt_all(:, :), hc(:), nel_blk(:)
+    real(c_float), allocatable, target :: hv(:)
+    integer(c_int64_t) :: n_in, n_out, got, mine
+    type(c_ptr) :: dcols, dvals, scols, svals
+    ndat = pr(jp)%nd
+    call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
+    call my_row_blocks(ndat, row_a, row_b)
+    nrl = row_b - row_a
+    nblk = (ndat + ROW_BLOCK - 1) / ROW_BLOCK
+    allocate(rows_at(nbproc), row_displs(nbproc), blk_owner(nblk), bounds(nbproc + 1))
+    base = nblk / nbproc
+    rem = mod(nblk, nbproc)
+    b = 0
+    do rr = 0, nbproc - 1
+      d = base
+      if (rr < rem) d = d + 1
+      blk_owner(b + 1:b + d) = rr
+      rows_at(rr + 1) = min((b + d) * ROW_BLOCK, ndat) - min(b * ROW_BLOCK, ndat)
+      row_displs(rr + 1) = min(b * ROW_BLOCK, ndat)
+      b = b + d
+    enddo
+    bounds(1) = 0
+    do rr = 1, nbproc
+      bounds(rr + 1) = bounds(rr) + nel_at(rr)
+    enddo
+    allocate(cnt_loc(nbproc, max(nrl, 1)), cnt_all(nbproc, ndat))
+    if (nrl > 0) call tfx_check(tfx_rowstore_counts(ctx, int(nbproc, c_int), bounds, cnt_loc), 'tfx_rowstore_counts')
+    call allgather_counts(cnt_loc, nbproc, nrl, cnt_all, rows_at, row_displs)
+    mine = 0
+    do rr = 1, ndat
+      mine = mine + cnt_all(myrank + 1, rr)
+    enddo
+    call tfx_check(tfx_matrix_begin(ctx, int(ndat, c_int64_t), int(nloc, c_int64_t), max(mine, 1_c_int64_t)), 'tfx_matrix_begin')
+    do b = 1, nblk
+      ga = (b - 1) * ROW_BLOCK
+      gb = min(b * ROW_BLOCK, ndat)
+      o = blk_owner(b)
+      n_in = 0
+      do rr = ga + 1, gb
+        n_in = n_in + cnt_all(myrank + 1, rr)
+      enddo
+      call tfx_check(tfx_device_malloc(ctx, 4 * max(n_in, 1_c_int64_t), dcols), 'tfx_device_malloc')
+      call tfx_check(tfx_device_malloc(ctx, 4 * max(n_in, 1_c_int64_t), dvals), 'tfx_device_malloc')
+      if (o == myrank) then
+        do d = 0, nbproc - 1
+          n_out = 0
+          do rr = ga + 1, gb
+            n_out = n_out + cnt_all(d + 1, rr)
+          enddo
+          if (n_out == 0) cycle
+          if (d == myrank) then
+            call tfx_check(tfx_rowstore_pack(ctx, int(ga - row_a, c_int64_t), int(gb - ga, c_int64_t), bounds(d + 1), bounds(d + 2), &
+                                             dcols, dvals, n_out, got), 'tfx_rowstore_pack')
+          else
+            call tfx_check(tfx_device_malloc(ctx, 4 * n_out, scols), 'tfx_device_malloc')
+            call tfx_check(tfx_device_malloc(ctx, 4 * n_out, svals), 'tfx_device_malloc')
+            call tfx_check(tfx_rowstore_pack(ctx, int(ga - row_a, c_int64_t), int(gb - ga, c_int64_t), bounds(d + 1), bounds(d + 2), &
+                                             scols, svals, n_out, got), 'tfx_rowstore_pack')
+            allocate(hc(n_out), hv(n_out))
+            call tfx_check(tfx_copy(ctx, c_loc(hc), scols, 4 * n_out), 'tfx_copy')
+            call tfx_check(tfx_copy(ctx, c_loc(hv), svals, 4 * n_out), 'tfx_copy')
+            call send_piece(d, int(n_out), hc, hv, 2 * b)
+            deallocate(hc, hv)
+            call tfx_check(tfx_device_free(ctx, scols), 'tfx_device_free')
+            call tfx_check(tfx_device_free(ctx, svals), 'tfx_device_free')
+          endif
+        enddo
+      else if (n_in > 0) then
+        allocate(hc(n_in), hv(n_in))
+        call recv_piece(o, int(n_in), hc, hv, 2 * b)
+        call tfx_check(tfx_copy(ctx, dcols, c_loc(hc), 4 * n_in), 'tfx_copy')
+        call tfx_check(tfx_copy(ctx, dvals, c_loc(hv), 4 * n_in), 'tfx_copy')
+        deallocate(hc, hv)
+      endif
+      allocate(nel_blk(gb - ga))
+      nel_blk = cnt_all(myrank + 1, ga + 1:gb)
+      call tfx_check(tfx_matrix_append_rows(ctx, int(ga, c_int64_t), int(gb - ga, c_int64_t), dcols, dvals, nel_blk), &
+                     'tfx_matrix_append_rows')
+      deallocate(nel_blk)
+      call tfx_check(tfx_device_free(ctx, dcols), 'tfx_device_free')
+      call tfx_check(tfx_device_free(ctx, dvals), 'tfx_device_free')
+    enddo
+    call tfx_check(tfx_matrix_finish(ctx), 'tfx_matrix_finish')
+    call tfx_check(tfx_rowstore_free(ctx), 'tfx_rowstore_free')
+    nnz_k = mine
+  end subroutine relayout_rowstore
 
   ! sensit.readFromFiles = 1 on several ranks: the per-cell counts of every kernel from the sensit_*_nnz files
   ! (read_sensit_nnz, sensitivity_gravmag.F90:530-568)

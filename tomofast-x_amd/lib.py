@@ -19,7 +19,7 @@ TFX_E = {-1: "TFX_E_ARG", -2: "TFX_E_HIP", -3: "TFX_E_GEOMETRY", -4: "TFX_E_STAT
 
 # every symbol include/tfx.h declares (tests check the library exports exactly these)
 SYMBOLS = [
-    "tfx_create", "tfx_destroy", "tfx_last_error", "tfx_device_info", "tfx_device_count", "tfx_copy", "tfx_set_allreduce", "tfx_set_grid",
+    "tfx_create", "tfx_destroy", "tfx_last_error", "tfx_device_info", "tfx_device_count", "tfx_copy", "tfx_device_malloc", "tfx_device_free", "tfx_set_allreduce", "tfx_set_grid",
     "tfx_column_weight_type1", "tfx_column_weight_type2", "tfx_prism_rows_gz", "tfx_prism_rows_mag", "tfx_prism_rows", "tfx_wavelet", "tfx_compress_row",
     "tfx_build_kernel_grav", "tfx_build_kernel_mag", "tfx_build_kernel", "tfx_select_problem",
     "tfx_matrix_upload_csr", "tfx_matrix_info", "tfx_matrix_download_csr", "tfx_matrix_free",
