@@ -778,6 +778,53 @@ def test_joint_products_are_block_diagonal(ctx, golden_dir):
             ctx.select_problem(0)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# degenerate shapes the reference accepts
+def test_build_edge_cases(ctx):
+    """rate 0 (nothing kept), one datum, a 1 x 1 x 1 grid, fewer cells than a wave, a single kept entry per row."""
+    # (1) compression rate 0: K = 0 -> every row empty (sensitivity_gravmag.F90:64-77, :244-256); the matrix is valid and S x = 0
+    nx, ny, nz = 6, 5, 4
+    N = nx * ny * nz
+    grid = tfx.synthetic.grid(nx, ny, nz)
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, 3, 2)
+    ctx.set_grid(nx, ny, nz, *grid)
+    cw = orc.column_weight_type1(grid)
+    res = ctx.calculate_sensit(xs, ys, zs, cw, 1, 0.0, want_hist=True)
+    assert res["nnz"] == 0 and int(res["nnz_hist"].sum()) == 0
+    info = ctx.matrix_info()
+    assert info["nrows"] == xs.size and info["ncols"] == N and info["nnz"] == 0
+    assert np.all(ctx.mult_vector(np.ones(N)) == 0.0) and np.all(ctx.trans_mult_vector(np.ones(xs.size)) == 0.0)
+    rp, cols, vals = ctx.matrix_download_csr()
+    assert int(rp[-1]) == 0
+    with pytest.raises(tfx.TfxError) as e:                      # lsqr_solver2.F90:150-153: v = A^T u = 0
+        ctx.lsqr_solve_sensit(np.ones(xs.size), 5)
+    assert "normalize" in str(e.value)
+    # (2) K = 1: exactly the largest coefficient of every row survives
+    res = ctx.calculate_sensit(xs, ys, zs, cw, 2, 1.0 / N + 1e-12)
+    rp, cols, vals = ctx.matrix_download_csr()
+    assert np.all(np.diff(rp) <= 1) and res["nnz"] == int(rp[-1]) >= xs.size - 1
+    for r in range(xs.size):
+        c_ref, v_ref, _ = orc.build_row_grav(grid, (nx, ny, nz), cw, (xs[r], ys[r], zs[r]), 2, 1)
+        assert np.array_equal(cols[rp[r]:rp[r + 1]], c_ref)
+    # (3) one datum, no compression, then compressed with rate 1 (everything above 1e-30 kept)
+    for ctype, rate in ((0, 1.0), (1, 1.0)):
+        res = ctx.calculate_sensit(xs[:1], ys[:1], zs[:1], cw, ctype, rate)
+        rp, cols, vals = ctx.matrix_download_csr()
+        c_ref, v_ref, _ = orc.build_row_grav(grid, (nx, ny, nz), cw, (xs[0], ys[0], zs[0]), ctype, N)
+        assert rp.size == 2 and abs(int(rp[1]) - c_ref.size) <= 1
+    # (4) a single cell
+    one = [np.array([v], np.float64) for v in (0.0, 100.0, 0.0, 100.0, 0.0, 100.0)]
+    ctx.set_grid(1, 1, 1, *one)
+    cw1 = ctx.calculate_depth_weight(2.0, 0.0, 1.0)
+    assert cw1.shape == (1,) and np.isfinite(cw1[0])
+    res = ctx.calculate_sensit([50.3], [49.2], [-1.0], cw1, 1, 1.0)
+    rp, cols, vals = ctx.matrix_download_csr()
+    ierr, row = orc.graviprism_z(one, 50.3, 49.2, -1.0)
+    assert int(rp[-1]) == 1 and cols[0] == 1 and abs(vals[0] - np.float32(row[0] * cw1[0])) <= 2 * np.spacing(np.float32(vals[0]))
+    x, it, r = ctx.lsqr_solve_sensit(np.array([2.0 * float(vals[0])]), 5)
+    assert abs(x[0] - 2.0) <= 1e-12
+
+
 def test_config1_mansf_end_to_end(ctx, golden_dir):
     """BASELINE config 1 (parfiles/Parfile_mansf_slice.txt: 2x128x32 cells, 256 obs, Haar 0.15, ADMM, 60 x 100 LSQR
     iterations) entirely on the HIP path vs the reference's final model."""
