@@ -106,7 +106,27 @@ def main():
     t0 = time.time()
     # N > 1: row-parallel build + point-to-point relayout (every row computed once); TFX_BUILD_MODE=redundant selects the
     # simpler scheme where every rank rebuilds all rows for its column range (also used for uncompressed kernels)
-    if world > 1 and w["ctype"] > 0 and os.environ.get("TFX_BUILD_MODE", "exchange") == "exchange":
+    use_exchange = world > 1 and w["ctype"] > 0 and os.environ.get("TFX_BUILD_MODE", "exchange") == "exchange"
+    if use_exchange:
+        # the relayout needs point-to-point transfers: try a ring of tiny messages first and agree on the outcome, so that a
+        # backend without working send / recv degrades to the redundant build instead of failing the run
+        import torch
+        import torch.distributed as dist
+        ok = 1
+        try:
+            dev = torch.device("cuda", local_rank)
+            probe = torch.full((4,), float(rank), dtype=torch.float32, device=dev)
+            got = torch.empty(4, dtype=torch.float32, device=dev)
+            tfx.distributed._p2p([((rank + 1) % world, probe)], [((rank - 1) % world, got)], dist.get_backend())
+            torch.cuda.synchronize(dev)
+            ok = int(bool((got == float((rank - 1) % world)).all().item()))
+        except Exception as exc:      # noqa
+            log("point-to-point probe failed (%s): falling back to the redundant build" % exc)
+            ok = 0
+        agreed = int(tfx.distributed.allreduce_numpy(np.array([ok], np.int64))[0])
+        if agreed != world:
+            use_exchange = False
+    if use_exchange:
         part = tfx.distributed.build_partitioned_exchange(ctx, rank, world, xs, ys, zs, cw, w["ctype"], w["rate"], device_index=local_rank)
         build_mode = "row-parallel + relayout"
     else:
