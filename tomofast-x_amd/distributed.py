@@ -45,6 +45,7 @@ class TorchAllreduce:
         self.zero_copy = self._probe_zero_copy()
         self._hip = None
         self._staging = None
+        self._alias = {}          # (ptr, n) -> tensor aliasing the library's buffer (LSQR reduces the same two buffers every iteration)
 
     def _probe_zero_copy(self):
         torch = self.torch
@@ -67,7 +68,11 @@ class TorchAllreduce:
     def __call__(self, ptr, n, stream):
         torch, dist = self.torch, self.dist
         if self.zero_copy:
-            t = torch.as_tensor(_DevArray(ptr, n), device=self.device)
+            t = self._alias.get((ptr, n))
+            if t is None:
+                if len(self._alias) > 64:
+                    self._alias.clear()
+                t = self._alias[(ptr, n)] = torch.as_tensor(_DevArray(ptr, n), device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return
         if self._staging is None or self._staging.numel() < n:
