@@ -523,9 +523,6 @@ __global__ void k_rows_final_sum(const double *__restrict__ red, int n, double *
     if (threadIdx.x == 0) out[row] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-// dmu check: K,L,M in {0,1}; signo(0) = -1, signo(1) = +1; product = (-1)^(number of zeros) = (-1)^(3-(K+L+M));
-// K+L+M odd -> even number of zeros... (3 - odd) is even -> +1.  K+L+M even -> -1.  Matches the expression above.
-
 // =============================================================================================================
 // column weight, depth weighting type 1
 // =============================================================================================================
@@ -1293,22 +1290,6 @@ __global__ void k_merge_nel(const int32_t *__restrict__ nel_sub, int ncm, int nr
     int n = 0;
     for (int k = 0; k < ncm; ++k) n += nel_sub[r * ncm + k];
     out[r] = n;
-}
-
-// sum of squares of each row (cost_full, :234); red: [nrows][gridDim.x]
-__global__ __launch_bounds__(256) void k_row_sumsq(const double *__restrict__ rows, int64_t N, double *__restrict__ red)
-{
-    const int row = blockIdx.y;
-    const double *r = rows + (int64_t)row * N;
-    double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) s = fma(r[i], r[i], s);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
-    __shared__ double sm[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) sm[wave] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) red[(int64_t)row * gridDim.x + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
 // dense store of a batch of rows: out[row][c] = (float)rows[row][col_begin + c] * scale[row]   (:289-295, :841)
