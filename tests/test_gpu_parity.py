@@ -122,6 +122,56 @@ def test_prism_tensor_path_bit_identical_to_general(ctx, golden_dir):
     assert np.all(np.abs(r - ref) <= 8 * 2.3e-16 * prism_term_scale(bent, obs[0]))
 
 
+def test_magprism_tensor_path_bit_identical_to_general(ctx, golden_dir):
+    """Magnetic rows on a tensor-product grid (atan2 terms and corner distances shared through LDS) vs the six-array kernel:
+    same bits for every component combination, observations above, beside and INSIDE cells."""
+    g = load(golden_dir, "magprism")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    cases = [((int(g["nx"]), int(g["ny"]), int(g["nz"])), grid, g["obs"])]
+    xs, ys, zs = tfx.synthetic.observations(37, 21, 3, 2)
+    obs2 = np.stack([xs, ys, zs], 1)
+    obs2 = np.concatenate([obs2, [[1234.5, 987.6, 433.3]]])                    # inside a cell of the uniform 100 m grid
+    cases.append(((37, 21, 19), list(tfx.synthetic.grid(37, 21, 19)), obs2))
+    field = (-62.0, 11.0, 20.0, 57000.0)
+    for dims, gr, obs in cases:
+        ctx.set_grid(*dims, *gr)
+        assert ctx.debug_set("tensor_grid") == 1
+        for ncm, ncd in ((1, 1), (1, 3), (3, 1), (3, 3)):
+            rows_t = ctx.sensit_lines(2, obs[:, 0], obs[:, 1], obs[:, 2], ndata_components=ncd, nmodel_components=ncm, mag_field=field)
+            ctx.debug_set("force_general_prism", 1)
+            rows_g = ctx.sensit_lines(2, obs[:, 0], obs[:, 1], obs[:, 2], ndata_components=ncd, nmodel_components=ncm, mag_field=field)
+            ctx.debug_set("force_general_prism", 0)
+            assert bits_equal(rows_t, rows_g), (dims, ncm, ncd)
+        # and the whole build (cost_full partials differ in order only: same kept entries)
+        cw = orc.column_weight_type1(gr, 3.0, 0.0, 1.0)
+        res_t = ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, 1, 0.2, mag_field=field)
+        A = ctx.matrix_download_csr()
+        ctx.debug_set("force_general_prism", 1)
+        res_g = ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, 1, 0.2, mag_field=field)
+        B = ctx.matrix_download_csr()
+        ctx.debug_set("force_general_prism", 0)
+        assert np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and A[2].tobytes() == B[2].tobytes()
+        assert abs(res_t["comp_error"] - res_g["comp_error"]) <= 1e-12 * res_g["comp_error"]
+
+
+def test_gradiprism_tensor_path_bit_identical_to_general(ctx, golden_dir):
+    """Gzz / full gradient tensor on a tensor-product grid (corner terms shared through LDS) vs the six-array kernel."""
+    g = load(golden_dir, "gradprism")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    cases = [((int(g["nx"]), int(g["ny"]), int(g["nz"])), grid, g["obs"])]
+    xs, ys, zs = tfx.synthetic.observations(70, 37, 3, 2)
+    cases.append(((70, 37, 19), list(tfx.synthetic.grid(70, 37, 19)), np.stack([xs, ys, zs], 1)))
+    for dims, gr, obs in cases:
+        ctx.set_grid(*dims, *gr)
+        assert ctx.debug_set("tensor_grid") == 1
+        for ncd in (1, 6):
+            rows_t = ctx.sensit_lines(1, obs[:, 0], obs[:, 1], obs[:, 2], data_type=2, ndata_components=ncd)
+            ctx.debug_set("force_general_prism", 1)
+            rows_g = ctx.sensit_lines(1, obs[:, 0], obs[:, 1], obs[:, 2], data_type=2, ndata_components=ncd)
+            ctx.debug_set("force_general_prism", 0)
+            assert bits_equal(rows_t, rows_g), (dims, ncd)
+
+
 def mag_term_scale(grid, o, inten):
     """|intensity| / 4 pi times the sum of |atan2| and |log| terms (each O(1..pi)): the tensor entries cancel to O((h/R)^3)."""
     return abs(inten) / (4 * np.pi) * 60.0 * np.ones(grid[0].size)

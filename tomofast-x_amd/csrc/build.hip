@@ -204,6 +204,64 @@ __device__ __forceinline__ void sharmbox_dev(double x0, double y0, double z0, do
     tz[0] = tx[2];
 }
 
+// magnetic tensor of a cell seen from (xo, yo, zo), incl. the 6-sub-box split for an observation strictly inside the cell
+// (magnetic_field.f90:139-240)
+__device__ __forceinline__ void mag_cell_tensor(double x1, double x2, double y1, double y2, double z1, double z2, double xo, double yo,
+                                                double zo, double *tx, double *ty, double *tz, int &bad)
+{
+    if (x1 < xo && x2 > xo && y1 < yo && y2 > yo && z1 < zo && z2 > zo) {                          // :139-141
+        double width = (double)0.1f;                                                               // :144
+        const double min_clr = fmin(fmin(fmin(fabs(xo - x1), fabs(xo - x2)), fmin(fabs(yo - y1), fabs(yo - y2))),
+                                    fmin(fabs(zo - z1), fabs(zo - z2)));
+        if (width > min_clr) width = 0.5 * min_clr;                                                // :153
+        tx[0] = tx[1] = tx[2] = ty[0] = ty[1] = ty[2] = tz[0] = tz[1] = tz[2] = 0.0;
+        for (int j = 0; j < 6; ++j) {                                                              // :157-226
+            double bx1 = x1, bx2 = x2, by1 = y1, by2 = y2, bz1 = zo - width, bz2 = zo + width;
+            if (j == 0) { bz1 = z1; bz2 = zo - width; }
+            else if (j == 1) { bz1 = zo + width; bz2 = z2; }
+            else if (j == 2) { bx2 = xo - width; }
+            else if (j == 3) { bx1 = xo + width; }
+            else if (j == 4) { bx1 = xo - width; bx2 = xo + width; by2 = yo - width; }
+            else { bx1 = xo - width; bx2 = xo + width; by1 = yo + width; }
+            double sx[3], sy[3], sz[3];
+            sharmbox_dev(xo, yo, zo, bx1, by1, bz1, bx2, by2, bz2, sx, sy, sz, bad);
+            for (int k = 0; k < 3; ++k) { tx[k] = tx[k] + sx[k]; ty[k] = ty[k] + sy[k]; tz[k] = tz[k] + sz[k]; }
+        }
+    } else {
+        sharmbox_dev(xo, yo, zo, x1, y1, z1, x2, y2, z2, tx, ty, tz, bad);                         // :230-240
+    }
+}
+
+// projection of the tensor on the field direction / components and the unit scaling (magnetic_field.f90:243-295):
+// out[d][k] = sensit_line(:, k, d) of this cell
+template <int NCM, int NCD>
+__device__ __forceinline__ void mag_project(const double *tx, const double *ty, const double *tz, const MagField &mf, double out[NCD][NCM])
+{
+    const double PI = 3.14159265358979323846;
+    const double mu0 = 4.0 * PI * 1.e-7, T2nT = 1.e+9;                                                     // :31-34
+    if (NCM == 1) {
+        const double mx = (tx[0] * mf.magv[0] + tx[1] * mf.magv[1]) + tx[2] * mf.magv[2];                  // :246-248
+        const double my = (ty[0] * mf.magv[0] + ty[1] * mf.magv[1]) + ty[2] * mf.magv[2];
+        const double mz = (tz[0] * mf.magv[0] + tz[1] * mf.magv[1]) + tz[2] * mf.magv[2];
+        if (NCD == 1) out[0][0] = mx * mf.magv[0] + my * mf.magv[1] + mz * mf.magv[2];                     // :251
+        else { out[0][0] = mx; out[NCD > 1 ? 1 : 0][0] = my; out[NCD > 2 ? 2 : 0][0] = mz; }               // :254-256
+    } else {
+#pragma unroll
+        for (int k = 0; k < NCM; ++k) {
+            if (NCD == 1) out[0][k] = tx[k] * mf.magv[0] + ty[k] * mf.magv[1] + tz[k] * mf.magv[2];        // :268
+            else { out[0][k] = tx[k]; out[NCD > 1 ? 1 : 0][k] = ty[k]; out[NCD > 2 ? 2 : 0][k] = tz[k]; } // :273-275
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < NCD; ++d)
+#pragma unroll
+        for (int k = 0; k < NCM; ++k) {
+            double v = out[d][k];
+            v = (NCM == 1) ? mf.intensity * v : (mu0 * T2nT) * v;                                          // :286-291
+            out[d][k] = v / (4.0 * PI);                                                                    // :295
+        }
+}
+
 // NCM model components (1 susceptibility | 3 magnetisation vector), NCD data components (1 TMI | 3): sub-row
 // (o*NCD + d)*NCM + k of the output holds sensit_line(:, k, d) of observation o (magnetic_field.f90:243-295).
 template <int NCM, int NCD>
@@ -216,8 +274,6 @@ __global__ __launch_bounds__(256) void k_magprism(int64_t N, const double *__res
                                                   double *__restrict__ sumsq)
 {
     constexpr int NSUB = NCM * NCD;
-    const double PI = 3.14159265358979323846;
-    const double mu0 = 4.0 * PI * 1.e-7, T2nT = 1.e+9;                                                     // :31-34
     __shared__ double s_sq[PRISM_MAX_BATCH];
     if (sumsq) {
         for (int o = threadIdx.x; o < nobs * NSUB; o += blockDim.x) s_sq[o] = 0.0;
@@ -233,49 +289,15 @@ __global__ __launch_bounds__(256) void k_magprism(int64_t N, const double *__res
             const double xo = xd[o], yo = yd[o], zo = zd[o];
             double tx[3], ty[3], tz[3];
             int bad = 0;
-            if (x1 < xo && x2 > xo && y1 < yo && y2 > yo && z1 < zo && z2 > zo) {                          // :139-141
-                double width = (double)0.1f;                                                               // :144
-                const double min_clr = fmin(fmin(fmin(fabs(xo - x1), fabs(xo - x2)), fmin(fabs(yo - y1), fabs(yo - y2))),
-                                            fmin(fabs(zo - z1), fabs(zo - z2)));
-                if (width > min_clr) width = 0.5 * min_clr;                                                // :153
-                tx[0] = tx[1] = tx[2] = ty[0] = ty[1] = ty[2] = tz[0] = tz[1] = tz[2] = 0.0;
-                for (int j = 0; j < 6; ++j) {                                                              // :157-226
-                    double bx1 = x1, bx2 = x2, by1 = y1, by2 = y2, bz1 = zo - width, bz2 = zo + width;
-                    if (j == 0) { bz1 = z1; bz2 = zo - width; }
-                    else if (j == 1) { bz1 = zo + width; bz2 = z2; }
-                    else if (j == 2) { bx2 = xo - width; }
-                    else if (j == 3) { bx1 = xo + width; }
-                    else if (j == 4) { bx1 = xo - width; bx2 = xo + width; by2 = yo - width; }
-                    else { bx1 = xo - width; bx2 = xo + width; by1 = yo + width; }
-                    double sx[3], sy[3], sz[3];
-                    sharmbox_dev(xo, yo, zo, bx1, by1, bz1, bx2, by2, bz2, sx, sy, sz, bad);
-                    for (int k = 0; k < 3; ++k) { tx[k] = tx[k] + sx[k]; ty[k] = ty[k] + sy[k]; tz[k] = tz[k] + sz[k]; }
-                }
-            } else {
-                sharmbox_dev(xo, yo, zo, x1, y1, z1, x2, y2, z2, tx, ty, tz, bad);                         // :230-240
-            }
+            mag_cell_tensor(x1, x2, y1, y2, z1, z2, xo, yo, zo, tx, ty, tz, bad);
             double out[NCD][NCM];
-            if (NCM == 1) {
-                const double mx = (tx[0] * mf.magv[0] + tx[1] * mf.magv[1]) + tx[2] * mf.magv[2];          // :246-248
-                const double my = (ty[0] * mf.magv[0] + ty[1] * mf.magv[1]) + ty[2] * mf.magv[2];
-                const double mz = (tz[0] * mf.magv[0] + tz[1] * mf.magv[1]) + tz[2] * mf.magv[2];
-                if (NCD == 1) out[0][0] = mx * mf.magv[0] + my * mf.magv[1] + mz * mf.magv[2];             // :251
-                else { out[0][0] = mx; out[NCD > 1 ? 1 : 0][0] = my; out[NCD > 2 ? 2 : 0][0] = mz; }       // :254-256
-            } else {
-#pragma unroll
-                for (int k = 0; k < NCM; ++k) {
-                    if (NCD == 1) out[0][k] = tx[k] * mf.magv[0] + ty[k] * mf.magv[1] + tz[k] * mf.magv[2];    // :268
-                    else { out[0][k] = tx[k]; out[NCD > 1 ? 1 : 0][k] = ty[k]; out[NCD > 2 ? 2 : 0][k] = tz[k]; }   // :273-275
-                }
-            }
+            mag_project<NCM, NCD>(tx, ty, tz, mf, out);
             if (bad && active) atomicOr(err, bad);
 #pragma unroll
             for (int d = 0; d < NCD; ++d)
 #pragma unroll
                 for (int k = 0; k < NCM; ++k) {
                     double v = out[d][k];
-                    v = (NCM == 1) ? mf.intensity * v : (mu0 * T2nT) * v;                                  // :286-291
-                    v = v / (4.0 * PI);                                                                    // :295
                     if (cw) v = v * w;
                     const int sub = (o * NCD + d) * NCM + k;
                     if (active) rows[(int64_t)sub * N + p] = v;
@@ -292,6 +314,119 @@ __global__ __launch_bounds__(256) void k_magprism(int64_t N, const double *__res
         __syncthreads();
         for (int o = threadIdx.x; o < nobs * NSUB; o += blockDim.x) sumsq[(int64_t)o * gridDim.x + blockIdx.x] = s_sq[o];
     }
+}
+
+// Tensor-product grid: of the 24 atan2 + 12 log + 24 sqrt of a cell's tensor, the two atan2 families and the three distances
+// (one per summation order of the squares, so that the bits are sharmbox's) depend on one NODE only.  A workgroup evaluates them
+// once for the (MT_X+1)(MT_Y+1)(MT_Z+1) nodes of its tile into LDS (1.3 nodes per cell: 2.7 atan2 + 4 sqrt per cell instead of
+// 24 + 24); the 12 logs of corner-pair ratios stay per cell.  Same operations in the same order as sharmbox_dev -> same bits as
+// k_magprism.  A cell that contains the observation takes the general path (6 sub-boxes).
+constexpr int MT_X = 16, MT_Y = 8, MT_Z = 8;
+constexpr int MT_NODES = (MT_X + 1) * (MT_Y + 1) * (MT_Z + 1);
+template <int NCM, int NCD>
+__global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz, const double *__restrict__ xe,
+                                                         const double *__restrict__ ye, const double *__restrict__ ze, int nobs,
+                                                         const double *__restrict__ xd, const double *__restrict__ yd,
+                                                         const double *__restrict__ zd, const double *__restrict__ cw, MagField mf,
+                                                         double *__restrict__ rows, int *__restrict__ err, double *__restrict__ sumsq)
+{
+    constexpr int NSUB = NCM * NCD;
+    __shared__ double Taz[MT_NODES], Tax[MT_NODES], Tay[MT_NODES], TAx[MT_NODES], TAy[MT_NODES];      // 5 x 1377 doubles = 55 KB
+    __shared__ double s_w[4];
+    const double eps = 0.;
+    const int tiles_x = (nx + MT_X - 1) / MT_X, tiles_y = (ny + MT_Y - 1) / MT_Y;
+    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
+    const int i0 = bx * MT_X, j0 = by * MT_Y, k0 = bz * MT_Z;
+    const int cx = min(MT_X, nx - i0), cy = min(MT_Y, ny - j0), cz = min(MT_Z, nz - k0);
+    const int64_t N = (int64_t)nx * ny * nz;
+    const int nnode = (cx + 1) * (cy + 1) * (cz + 1);
+    const int ncell = cx * cy * cz;
+    int bad = 0;
+#define NODE(a, b, c) (((c) * (MT_Y + 1) + (b)) * (MT_X + 1) + (a))
+    for (int o = 0; o < nobs; ++o) {
+        const double xo = xd[o], yo = yd[o], zo = zd[o];
+        __syncthreads();
+        for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
+            const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
+            const double rx = xe[i0 + a] - xo + eps, ry = ye[j0 + b] - yo + eps, rz = ze[k0 + c] - zo + eps;       // :336-341
+            const double rxsq = rx * rx, rysq = ry * ry, rzsq = rz * rz;
+            const double az = sqrt(rzsq + (rysq + rxsq));        // :361-372   a = sqrt(rz^2 + R), R = ry^2 + rx^2
+            const double ax = sqrt(rxsq + (rysq + rzsq));        // :404-415   a = sqrt(rx^2 + R), R = ry^2 + rz^2
+            const double ay = sqrt(rysq + (rxsq + rzsq));        // :424-435   a = sqrt(ry^2 + R), R = rx^2 + rz^2
+            const int id = NODE(a, b, c);
+            Taz[id] = az; Tax[id] = ax; Tay[id] = ay;
+            TAx[id] = atan2(ry * rz, (rx * az + eps));           // the terms of tx(1), :376-383
+            TAy[id] = atan2(rx * rz, (ry * az + eps));           // the terms of ty(2), :392-399
+        }
+        __syncthreads();
+        double sq[NSUB];
+#pragma unroll
+        for (int i = 0; i < NSUB; ++i) sq[i] = 0.0;
+        for (int q = threadIdx.x; q < ncell; q += blockDim.x) {
+            const int a = q % cx, b = (q / cx) % cy, c = q / (cx * cy);
+            const double x1 = xe[i0 + a], x2 = xe[i0 + a + 1], y1 = ye[j0 + b], y2 = ye[j0 + b + 1], z1 = ze[k0 + c], z2 = ze[k0 + c + 1];
+            double tx[3], ty[3], tz[3];
+            if (x1 < xo && x2 > xo && y1 < yo && y2 > yo && z1 < zo && z2 > zo) {
+                mag_cell_tensor(x1, x2, y1, y2, z1, z2, xo, yo, zo, tx, ty, tz, bad);      // observation inside this cell
+            } else {
+                const double rx1 = x1 - xo + eps, rx2 = x2 - xo + eps, ry1 = y1 - yo + eps, ry2 = y2 - yo + eps;
+                const double rz1 = z1 - zo + eps, rz2 = z2 - zo + eps;
+                if (rx1 == 0. || rx2 == 0.) bad |= 4;
+                if (ry1 == 0. || ry2 == 0.) bad |= 8;
+                // corner (i, j, k), i / j / k in {1, 2}: node (a + i - 1, b + j - 1, c + k - 1)
+#define C_(T, i, j, k) T[NODE(a + (i) - 1, b + (j) - 1, c + (k) - 1)]
+                tx[0] = C_(TAx, 2, 1, 2) - C_(TAx, 2, 2, 2) + C_(TAx, 2, 2, 1) - C_(TAx, 2, 1, 1) + C_(TAx, 1, 2, 2) - C_(TAx, 1, 1, 2) +
+                        C_(TAx, 1, 1, 1) - C_(TAx, 1, 2, 1);                                                                  // :376-383
+                ty[0] = log((rz2 + C_(Taz, 2, 2, 2) + eps) / (rz1 + C_(Taz, 2, 2, 1) + eps)) -
+                        log((rz2 + C_(Taz, 1, 2, 2) + eps) / (rz1 + C_(Taz, 1, 2, 1) + eps)) +
+                        log((rz2 + C_(Taz, 1, 1, 2) + eps) / (rz1 + C_(Taz, 1, 1, 1) + eps)) -
+                        log((rz2 + C_(Taz, 2, 1, 2) + eps) / (rz1 + C_(Taz, 2, 1, 1) + eps));                                 // :386-389
+                ty[1] = C_(TAy, 1, 2, 2) - C_(TAy, 2, 2, 2) + C_(TAy, 2, 2, 1) - C_(TAy, 1, 2, 1) + C_(TAy, 2, 1, 2) - C_(TAy, 1, 1, 2) +
+                        C_(TAy, 1, 1, 1) - C_(TAy, 2, 1, 1);                                                                  // :392-399
+                ty[2] = log((rx1 + C_(Tax, 1, 2, 1) + eps) / (rx2 + C_(Tax, 2, 2, 1) + eps)) -
+                        log((rx1 + C_(Tax, 1, 2, 2) + eps) / (rx2 + C_(Tax, 2, 2, 2) + eps)) +
+                        log((rx1 + C_(Tax, 1, 1, 2) + eps) / (rx2 + C_(Tax, 2, 1, 2) + eps)) -
+                        log((rx1 + C_(Tax, 1, 1, 1) + eps) / (rx2 + C_(Tax, 2, 1, 1) + eps));                                 // :419-422
+                tx[2] = log((ry1 + C_(Tay, 2, 1, 1) + eps) / (ry2 + C_(Tay, 2, 2, 1) + eps)) -
+                        log((ry1 + C_(Tay, 2, 1, 2) + eps) / (ry2 + C_(Tay, 2, 2, 2) + eps)) +
+                        log((ry1 + C_(Tay, 1, 1, 2) + eps) / (ry2 + C_(Tay, 1, 2, 2) + eps)) -
+                        log((ry1 + C_(Tay, 1, 1, 1) + eps) / (ry2 + C_(Tay, 1, 2, 1) + eps));                                 // :439-442
+#undef C_
+                tz[2] = -1 * (tx[0] + ty[1]);                                                                                 // :446
+                tz[1] = ty[2];
+                tx[1] = ty[0];
+                tz[0] = tx[2];
+            }
+            double out[NCD][NCM];
+            mag_project<NCM, NCD>(tx, ty, tz, mf, out);
+            const int64_t p = ((int64_t)(k0 + c) * ny + (j0 + b)) * nx + (i0 + a);
+            const double w = cw ? cw[p] : 1.0;
+#pragma unroll
+            for (int d = 0; d < NCD; ++d)
+#pragma unroll
+                for (int k = 0; k < NCM; ++k) {
+                    double v = out[d][k];
+                    if (cw) v = v * w;
+                    const int sub = (o * NCD + d) * NCM + k;
+                    rows[(int64_t)sub * N + p] = v;
+                    sq[d * NCM + k] = fma(v, v, sq[d * NCM + k]);
+                }
+        }
+        if (sumsq) {                                        // cost_full (sensitivity_gravmag.F90:234), fixed order
+#pragma unroll
+            for (int i = 0; i < NSUB; ++i) {
+                double t = sq[i];
+#pragma unroll
+                for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_down(t, dd);
+                __syncthreads();
+                if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+                __syncthreads();
+                if (threadIdx.x == 0) sumsq[(int64_t)(o * NSUB + i) * gridDim.x + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+            }
+        }
+    }
+#undef NODE
+    if (bad) atomicOr(err, bad);
 }
 
 // =============================================================================================================
@@ -383,6 +518,109 @@ __global__ __launch_bounds__(256) void k_gradiprism(int64_t N, const double *__r
     }
 }
 
+// Tensor-product grid: every term of the gradient tensor depends on ONE corner, so a workgroup evaluates the terms once per
+// node of its tile into LDS (1.3 - 1.5 nodes per cell instead of 8 corner evaluations) and each cell sums its 8 nodes in the
+// reference's order (K outer, L, M inner) -> same bits as k_gradiprism.
+template <bool FULL>
+struct GradTile {
+    static constexpr int X = FULL ? 16 : 32, Y = 8, Z = FULL ? 4 : 8, NV = FULL ? 6 : 1;
+    static constexpr int NODES = (X + 1) * (Y + 1) * (Z + 1);
+};
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int nz, const double *__restrict__ xe,
+                                                           const double *__restrict__ ye, const double *__restrict__ ze, int nobs,
+                                                           const double *__restrict__ xd, const double *__restrict__ yd,
+                                                           const double *__restrict__ zd, const double *__restrict__ cw,
+                                                           double *__restrict__ rows, int *__restrict__ err, double *__restrict__ sumsq)
+{
+    using GT = GradTile<FULL>;
+    constexpr int NC = GT::NV;
+    const double twopi = 2.0 * 3.14159265358979323846;
+    __shared__ double T[NC][GT::NODES];
+    __shared__ double s_w[4];
+    const int tiles_x = (nx + GT::X - 1) / GT::X, tiles_y = (ny + GT::Y - 1) / GT::Y;
+    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
+    const int i0 = bx * GT::X, j0 = by * GT::Y, k0 = bz * GT::Z;
+    const int cx = min(GT::X, nx - i0), cy = min(GT::Y, ny - j0), cz = min(GT::Z, nz - k0);
+    const int64_t N = (int64_t)nx * ny * nz;
+    const int nnode = (cx + 1) * (cy + 1) * (cz + 1);
+    const int ncell = cx * cy * cz;
+    int bad = 0;
+#define NODE(a, b, c) (((c) * (GT::Y + 1) + (b)) * (GT::X + 1) + (a))
+    for (int o = 0; o < nobs; ++o) {
+        const double xo = xd[o], yo = yd[o], zo = zd[o];
+        __syncthreads();
+        for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
+            const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
+            const double XX = xo - xe[i0 + a], YY = yo - ye[j0 + b], ZZ = -(zo - ze[k0 + c]);            // gravity_field.f90:232-237
+            const double Rs = sqrt(XX * XX + YY * YY + ZZ * ZZ);                                         // :251
+            double vzz = -atan2(XX * YY, Rs * ZZ);                                                       // :255
+            if (vzz < 0) vzz = vzz + twopi;
+            const int id = NODE(a, b, c);
+            if (FULL) {
+                double vxx = atan2(XX * YY, XX * XX + Rs * ZZ + ZZ * ZZ);                                // :253
+                double vyy = atan2(XX * YY, Rs * Rs + Rs * ZZ - XX * XX);                                // :254
+                if (vxx < 0) vxx = vxx + twopi;
+                if (vyy < 0) vyy = vyy + twopi;
+                const double arg1 = Rs + ZZ;
+                const double arg21 = Rs - YY, arg22 = Rs + YY;
+                const double arg31 = Rs - XX, arg32 = Rs + XX;
+                if (arg22 == 0. || arg32 == 0.) bad |= 16;
+                const double arg2 = arg21 / arg22, arg3 = arg31 / arg32;
+                if (arg1 <= 0. || arg2 <= 0. || arg3 <= 0.) bad |= 32;
+                T[0][id] = vxx;
+                T[NC > 1 ? 1 : 0][id] = vyy;
+                T[NC > 2 ? 2 : 0][id] = vzz;
+                T[NC > 3 ? 3 : 0][id] = log(arg1);                                                       // vxy, :286
+                T[NC > 4 ? 4 : 0][id] = 0.5 * log(arg3);                                                 // vyz, :288
+                T[NC > 5 ? 5 : 0][id] = 0.5 * log(arg2);                                                 // vzx, :287
+            } else {
+                T[0][id] = vzz;
+            }
+        }
+        __syncthreads();
+        double sq[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) sq[i] = 0.0;
+        for (int q = threadIdx.x; q < ncell; q += blockDim.x) {
+            const int a = q % cx, b = (q / cx) % cy, c = q / (cx * cy);
+            const int64_t p = ((int64_t)(k0 + c) * ny + (j0 + b)) * nx + (i0 + a);
+            const double w = cw ? cw[p] : 1.0;
+#pragma unroll
+            for (int comp = 0; comp < NC; ++comp) {
+                double gsum = 0.0;
+#pragma unroll
+                for (int K = 0; K < 2; ++K)
+#pragma unroll
+                    for (int L = 0; L < 2; ++L)
+#pragma unroll
+                        for (int M = 0; M < 2; ++M) {
+                            const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;
+                            gsum = gsum + dmu * T[comp][NODE(a + K, b + L, c + M)];
+                        }
+                double v = g_grav() * gsum;                                                               // :301-306, :358
+                if (cw) v = v * w;
+                rows[(int64_t)(o * NC + comp) * N + p] = v;
+                sq[comp] = fma(v, v, sq[comp]);
+            }
+        }
+        if (sumsq) {                                        // cost_full (sensitivity_gravmag.F90:234), fixed order
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                double t = sq[i];
+#pragma unroll
+                for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_down(t, dd);
+                __syncthreads();
+                if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+                __syncthreads();
+                if (threadIdx.x == 0) sumsq[(int64_t)(o * NC + i) * gridDim.x + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+            }
+        }
+    }
+#undef NODE
+    if (bad) atomicOr(err, bad);
+}
+
 // What produces the lines of one observation (sensitivity_gravmag.F90:193-220): nsub = ncd*ncm lines in (d, k) order.
 enum { GEN_GZ = 0, GEN_GZZ = 1, GEN_FTG = 2, GEN_MAG = 3 };
 struct RowGen {
@@ -464,6 +702,12 @@ int detect_tensor_grid(tfx_ctx *ctx)
     return 0;
 }
 
+static int grad_tiles(tfx_ctx *ctx, bool full)
+{
+    const int X = full ? GradTile<true>::X : GradTile<false>::X, Y = 8, Z = full ? GradTile<true>::Z : GradTile<false>::Z;
+    return ((ctx->nx + X - 1) / X) * ((ctx->ny + Y - 1) / Y) * ((ctx->nz + Z - 1) / Z);
+}
+
 // Lines of a batch of observations already on the device: d_rows[(o*nsub + sub)*N + p]; picks the tensor-grid kernel
 // when it applies.  d_sumsq (optional): [nobs*nsub][*nblk] partial sums of squares per line.
 int prism_rows_dev(tfx_ctx *ctx, const RowGen &gen, int nobs, const double *d_x, const double *d_y, const double *d_z,
@@ -474,13 +718,32 @@ int prism_rows_dev(tfx_ctx *ctx, const RowGen &gen, int nobs, const double *d_x,
     const int64_t N = ctx->N;
     const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
 #define GRID_ARGS N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p, ctx->grid[3].p, ctx->grid[4].p, ctx->grid[5].p, nobs, d_x, d_y, d_z, d_cw
-    if (gen.kind == GEN_MAG) {
+    if (gen.kind == GEN_MAG && ctx->tensor_grid) {
+        const int tiles = ((ctx->nx + MT_X - 1) / MT_X) * ((ctx->ny + MT_Y - 1) / MT_Y) * ((ctx->nz + MT_Z - 1) / MT_Z);
+#define TENSOR_ARGS ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p, ctx->edges[1].p, ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, gen.mf, d_rows, d_err, d_sumsq
+        if (gen.ncm == 1 && gen.ncd == 1) hipLaunchKernelGGL((k_magprism_tensor<1, 1>), dim3(tiles), dim3(256), 0, s, TENSOR_ARGS);
+        else if (gen.ncm == 1 && gen.ncd == 3) hipLaunchKernelGGL((k_magprism_tensor<1, 3>), dim3(tiles), dim3(256), 0, s, TENSOR_ARGS);
+        else if (gen.ncm == 3 && gen.ncd == 1) hipLaunchKernelGGL((k_magprism_tensor<3, 1>), dim3(tiles), dim3(256), 0, s, TENSOR_ARGS);
+        else if (gen.ncm == 3 && gen.ncd == 3) hipLaunchKernelGGL((k_magprism_tensor<3, 3>), dim3(tiles), dim3(256), 0, s, TENSOR_ARGS);
+        else return fail(TFX_E_ARG, "Wrong number of components in magnetic_field_magprism!");
+#undef TENSOR_ARGS
+        if (nblk) *nblk = tiles;
+    } else if (gen.kind == GEN_MAG) {
         if (gen.ncm == 1 && gen.ncd == 1) hipLaunchKernelGGL((k_magprism<1, 1>), dim3(grid), dim3(256), 0, s, GRID_ARGS, gen.mf, d_rows, d_err, d_sumsq);
         else if (gen.ncm == 1 && gen.ncd == 3) hipLaunchKernelGGL((k_magprism<1, 3>), dim3(grid), dim3(256), 0, s, GRID_ARGS, gen.mf, d_rows, d_err, d_sumsq);
         else if (gen.ncm == 3 && gen.ncd == 1) hipLaunchKernelGGL((k_magprism<3, 1>), dim3(grid), dim3(256), 0, s, GRID_ARGS, gen.mf, d_rows, d_err, d_sumsq);
         else if (gen.ncm == 3 && gen.ncd == 3) hipLaunchKernelGGL((k_magprism<3, 3>), dim3(grid), dim3(256), 0, s, GRID_ARGS, gen.mf, d_rows, d_err, d_sumsq);
         else return fail(TFX_E_ARG, "Wrong number of components in magnetic_field_magprism!");            // magnetic_field.f90:258-282
         if (nblk) *nblk = grid;
+    } else if ((gen.kind == GEN_GZZ || gen.kind == GEN_FTG) && ctx->tensor_grid) {
+        const int tiles = grad_tiles(ctx, gen.kind == GEN_FTG);
+        if (gen.kind == GEN_FTG)
+            hipLaunchKernelGGL((k_gradiprism_tensor<true>), dim3(tiles), dim3(256), 0, s, ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p,
+                               ctx->edges[1].p, ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err, d_sumsq);
+        else
+            hipLaunchKernelGGL((k_gradiprism_tensor<false>), dim3(tiles), dim3(256), 0, s, ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p,
+                               ctx->edges[1].p, ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err, d_sumsq);
+        if (nblk) *nblk = tiles;
     } else if (gen.kind == GEN_GZZ) {
         hipLaunchKernelGGL((k_gradiprism<false>), dim3(grid), dim3(256), 0, s, GRID_ARGS, d_rows, d_err, d_sumsq);
         if (nblk) *nblk = grid;
@@ -505,6 +768,8 @@ int prism_rows_dev(tfx_ctx *ctx, const RowGen &gen, int nobs, const double *d_x,
 int prism_partials(tfx_ctx *ctx, const RowGen &gen)
 {
     if (ctx->tensor_grid && gen.kind == GEN_GZ) return ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
+    if (ctx->tensor_grid && (gen.kind == GEN_GZZ || gen.kind == GEN_FTG)) return grad_tiles(ctx, gen.kind == GEN_FTG);
+    if (ctx->tensor_grid && gen.kind == GEN_MAG) return ((ctx->nx + MT_X - 1) / MT_X) * ((ctx->ny + MT_Y - 1) / MT_Y) * ((ctx->nz + MT_Z - 1) / MT_Z);
     return (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->num_cu * 16);
 }
 
