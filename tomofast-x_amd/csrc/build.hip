@@ -893,6 +893,7 @@ struct WaveAxis {
 };
 
 struct WaveConst { double sq2, c0, c1, c2, c3, c4; };
+constexpr int WAVE_FUSE_ITEMS = 8;       // pairs per thread the fused D4 level keeps in registers (L <= 256 at 16 lines per tile)
 
 template <int TYPE, int DIR>
 __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, int64_t vec_stride, WaveAxis ax, WaveConst wc)
@@ -995,6 +996,36 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
                     lo = lo - hi / 2.0;
                     hi = hi + lo;
                     T[a] = lo; T[a + dHI] = hi;
+                }
+                __syncthreads();
+            } else if (TYPE == 2 && DIR == 1 && ng <= WAVE_FUSE_ITEMS * MR) {
+                // Fused D4 level: a thread produces the final (lo, hi) of its pairs from the RAW values of pairs m-1, m, m+1,
+                // recomputing the neighbours' intermediate values with exactly the reference's operations (same bits):
+                //   lo1(m) = lo + hi*c0 (:296-300); hi2(m) = hi - lo1(m)*c1 - lo1(m-1)*c2 (:302-319, m-1 wraps to the last pair);
+                //   lo3(m) = lo1(m) - hi2(m+1) (:321-345, m+1 wraps to pair 0); lo3*c3, hi2*c4 (:347-363).
+                // Two barriers per level instead of four.
+                double olo[WAVE_FUSE_ITEMS], ohi[WAVE_FUSE_ITEMS];
+#pragma unroll
+                for (int i = 0; i < WAVE_FUSE_ITEMS; ++i) {
+                    const int m = mr + i * MR, a = a0 + i * dA;
+                    if (m < ng) {
+                        const int ap = (m == 0) ? ilmax * P + q : a - dS;
+                        const int an = (m == ng - 1) ? q : a + dS;
+                        const double lo = T[a], hi = T[a + dHI], lop = T[ap], hip = T[ap + dHI], lon = T[an], hin = T[an + dHI];
+                        const double lo1 = lo + hi * wc.c0;
+                        const double lo1p = lop + hip * wc.c0;
+                        const double lo1n = lon + hin * wc.c0;
+                        const double hi2 = hi - lo1 * wc.c1 - lo1p * wc.c2;
+                        const double hi2n = hin - lo1n * wc.c1 - lo1 * wc.c2;
+                        olo[i] = (lo1 - hi2n) * wc.c3;
+                        ohi[i] = hi2 * wc.c4;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < WAVE_FUSE_ITEMS; ++i) {
+                    const int m = mr + i * MR, a = a0 + i * dA;
+                    if (m < ng) { T[a] = olo[i]; T[a + dHI] = ohi[i]; }
                 }
                 __syncthreads();
             } else if (TYPE == 2 && DIR == 1) {
