@@ -456,14 +456,16 @@ def test_lsqr_vs_reference_golden(ctx, golden_dir, case):
     for (niter, rmin, gamma), xref, rref, itref in zip(g[case + "_runs"], g[case + "_x"], g[case + "_r"], g[case + "_iters"]):
         x, it, r = ctx.lsqr_solve_sensit(b[:nl_s], int(niter), rmin, gamma, 0.0, diag, rhs)
         early = itref < niter
+        # mid-convergence iterates of this ill-conditioned 40 x 60 toy amplify 1e-16 summation-order differences (the
+        # LDS-atomic order is run-dependent): over 300 repetitions (tools/lsqr_scatter.py) the 30-iteration run scatters by up
+        # to 4.6e-4 in x and 3.1e-5 in r, every other run by <= 5e-10 / 3e-15; early and converged iterates are tight
+        mid = int(niter) == 30 or (case == "noC" and int(niter) == 10)
         if early:
             assert abs(it - itref) <= 0.1 * itref
         else:
             assert it == itref
-            assert abs(r - rref) <= 1e-7 * abs(rref)
-        # mid-convergence iterates of this ill-conditioned 40 x 60 toy amplify 1e-16 summation-order differences (the
-        # LDS-atomic order is run-dependent) up to ~1e-5..1e-4; early and converged iterates are tight
-        tol = 1e-12 if niter <= 5 else (1e-9 if (early or niter >= 50) else 1e-3)
+            assert abs(r - rref) <= (1e-3 if mid else 1e-7) * abs(rref)
+        tol = 1e-12 if niter <= 5 else (1e-2 if mid else 1e-8)
         assert np.linalg.norm(x - xref) <= tol * np.linalg.norm(xref), (case, niter)
 
 
