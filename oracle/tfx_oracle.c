@@ -570,12 +570,24 @@ static int normalize_vec(double *x, int64_t n, double *s)
     return 0;
 }
 
-int orc_lsqr_solve_sensit(int64_t nl_s, int64_t nl_c, int64_t ncols, int niter, double rmin, double gamma,
-                          double target_misfit,
-                          const int64_t *s_rowptr, const int32_t *s_cols, const float *s_vals,
-                          const int64_t *c_rowptr, const int32_t *c_cols, const float *c_vals,
-                          double *u, double *x, double *r_out)
+/* wavelet_type > 0: WAVELET_DOMAIN = false - the unknowns are spatial and every product with S goes through the transform of
+ * each of the ncols / (n1 n2 n3) model components (lsqr_solver2.F90:137-145, :171-176, :200-206, :228-234). */
+static void transform_comps(double *v, int64_t ncols, int n1, int n2, int n3, int type, int inverse)
 {
+    const int64_t n = (int64_t)n1 * n2 * n3;
+    for (int64_t o = 0; o + n <= ncols; o += n) {
+        if (inverse) orc_inverse_wavelet(v + o, n1, n2, n3, type);
+        else orc_forward_wavelet(v + o, n1, n2, n3, type);
+    }
+}
+
+int orc_lsqr_solve_sensit_wd(int64_t nl_s, int64_t nl_c, int64_t ncols, int niter, double rmin, double gamma,
+                             double target_misfit,
+                             const int64_t *s_rowptr, const int32_t *s_cols, const float *s_vals,
+                             const int64_t *c_rowptr, const int32_t *c_cols, const float *c_vals,
+                             double *u, double *x, double *r_out, int wavelet_type, int n1, int n2, int n3)
+{
+    const int spatial = wavelet_type > 0;
     int64_t nlines = nl_s + nl_c;
     double *v = (double *)calloc((size_t)ncols, sizeof(double));
     double *w = (double *)calloc((size_t)ncols, sizeof(double));
@@ -594,6 +606,7 @@ int orc_lsqr_solve_sensit(int64_t nl_s, int64_t nl_c, int64_t ncols, int niter, 
     normalize_vec(u, nlines, &beta);                                             /* :129 */
     b1 = beta;
     orc_spmtv_add(nl_s, s_rowptr, s_cols, s_vals, u, v2);                        /* :137 (v2 starts at 0) */
+    if (spatial) transform_comps(v2, ncols, n1, n2, n3, wavelet_type, 1);        /* :139-143 */
     memcpy(v, v2, (size_t)ncols * sizeof(double));                               /* :145 */
     if (nl_c > 0) orc_spmtv_add(nl_c, c_rowptr, c_cols, c_vals, u + nl_s, v);    /* :147 */
     normalize_vec(v, ncols, &alpha);                                             /* :150 */
@@ -604,18 +617,23 @@ int orc_lsqr_solve_sensit(int64_t nl_s, int64_t nl_c, int64_t ncols, int niter, 
     while (iter <= niter && r > rmin) {                                          /* :163 */
         if (calc_misfit) {                                                       /* :168-189 */
             memset(Sx, 0, (size_t)nl_s * sizeof(double));
-            orc_spmv_add(nl_s, s_rowptr, s_cols, s_vals, x, Sx);
+            memcpy(v2, x, (size_t)ncols * sizeof(double));                       /* :169 */
+            if (spatial) transform_comps(v2, ncols, n1, n2, n3, wavelet_type, 0);/* :171-175 */
+            orc_spmv_add(nl_s, s_rowptr, s_cols, s_vals, v2, Sx);
             double ss = 0.0;
             for (int64_t i = 0; i < nl_s; ++i) ss += (Sx[i] - b0[i]) * (Sx[i] - b0[i]);
             if (sqrt(ss / (double)nl_s) <= target_misfit) break;
         }
         for (int64_t i = 0; i < nlines; ++i) u[i] = -alpha * u[i];               /* :195 */
-        orc_spmv_add(nl_s, s_rowptr, s_cols, s_vals, v, u);                      /* :209 */
+        memcpy(v2, v, (size_t)ncols * sizeof(double));                           /* :200 */
+        if (spatial) transform_comps(v2, ncols, n1, n2, n3, wavelet_type, 0);    /* :202-206 */
+        orc_spmv_add(nl_s, s_rowptr, s_cols, s_vals, v2, u);                     /* :209 */
         if (nl_c > 0) orc_spmv_add(nl_c, c_rowptr, c_cols, c_vals, v, u + nl_s); /* :211 */
         normalize_vec(u, nlines, &beta);                                         /* :218 */
         for (int64_t i = 0; i < ncols; ++i) v[i] = -beta * v[i];                 /* :225 */
         memset(v2, 0, (size_t)ncols * sizeof(double));
         orc_spmtv_add(nl_s, s_rowptr, s_cols, s_vals, u, v2);                    /* :228 */
+        if (spatial) transform_comps(v2, ncols, n1, n2, n3, wavelet_type, 1);    /* :230-234 */
         for (int64_t i = 0; i < ncols; ++i) v[i] = v[i] + v2[i];                 /* :236 */
         if (nl_c > 0) orc_spmtv_add(nl_c, c_rowptr, c_cols, c_vals, u + nl_s, v);/* :238 */
         normalize_vec(v, ncols, &alpha);                                         /* :241 */
@@ -641,6 +659,16 @@ done:
     free(v); free(w); free(v2); free(b0); free(Sx);
     if (r_out) *r_out = r;
     return iter - 1;
+}
+
+int orc_lsqr_solve_sensit(int64_t nl_s, int64_t nl_c, int64_t ncols, int niter, double rmin, double gamma,
+                          double target_misfit,
+                          const int64_t *s_rowptr, const int32_t *s_cols, const float *s_vals,
+                          const int64_t *c_rowptr, const int32_t *c_cols, const float *c_vals,
+                          double *u, double *x, double *r_out)
+{
+    return orc_lsqr_solve_sensit_wd(nl_s, nl_c, ncols, niter, rmin, gamma, target_misfit, s_rowptr, s_cols, s_vals, c_rowptr, c_cols,
+                                    c_vals, u, x, r_out, 0, 0, 0, 0);
 }
 
 int orc_calc_data(int64_t N, int nx, int ny, int nz, int64_t ndata, const double *model, const double *cw,

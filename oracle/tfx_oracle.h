@@ -108,6 +108,14 @@ int orc_lsqr_solve_sensit(int64_t nl_s, int64_t nl_c, int64_t ncols, int niter, 
                           const int64_t *c_rowptr, const int32_t *c_cols, const float *c_vals,
                           double *u, double *x, double *r_out);
 
+/* The same with WAVELET_DOMAIN = false when wavelet_type > 0: spatial unknowns, every product with S goes through the
+ * n1 x n2 x n3 transform of each model component (lsqr_solver2.F90:137-145, :171-176, :200-206, :228-234). */
+int orc_lsqr_solve_sensit_wd(int64_t nl_s, int64_t nl_c, int64_t ncols, int niter, double rmin, double gamma,
+                             double target_misfit,
+                             const int64_t *s_rowptr, const int32_t *s_cols, const float *s_vals,
+                             const int64_t *c_rowptr, const int32_t *c_cols, const float *c_vals,
+                             double *u, double *x, double *r_out, int wavelet_type, int n1, int n2, int n3);
+
 /* src/inversion/lsqr_solver2.F90:478-494 */
 void orc_soft_threshold(double *x, int64_t n, double gamma);
 

@@ -732,6 +732,43 @@ def make_joint_e2e(tmp):
           "self diff grav", np.linalg.norm(a - b) / np.linalg.norm(a))
 
 
+def make_dgrad_e2e(tmp):
+    """Gradient damping (damping_gradient.F90): three blocks of first differences in the general constraint matrix, which
+    switches the solver to WAVELET_DOMAIN = false (spatial unknowns, S applied through the per-iteration transform)."""
+    c = dict(nx=8, ny=6, nz=5, ox=3, oy=3, ctype=1, rate="0.3d0", nmajor=2, nminor=600, alpha="1.d-7", dwtype=1)
+    beta = "2.d-6"
+    g, obs, mtrue = synthetic_problem(c["nx"], c["ny"], c["nz"], c["ox"], c["oy"])
+    nd = obs.shape[0]
+    par = PAR_TMPL.format(nd=nd, **c) + "inversion.dampingGradient.weightType = 1\ninversion.dampingGradient.grav.weight = %s\n" % beta
+    res = {}
+    for nproc in (1, 2):
+        wd = os.path.join(tmp, "dgrad_np%d" % nproc)
+        shutil.rmtree(wd, ignore_errors=True)
+        os.makedirs(wd)
+        write_grid_file(os.path.join(wd, "grid.txt"), g, c["nx"], c["ny"], c["nz"])
+        with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+            f.write("%d\n" % nd)
+            for r in obs:
+                f.write("%.17g %.17g %.17g 0.0\n" % tuple(r))
+        with open(os.path.join(wd, "model_true.txt"), "w") as f:
+            f.write("%d\n" % mtrue.size)
+            for v in mtrue:
+                f.write("%.17g\n" % v)
+        pf = os.path.join(wd, "Parfile.txt")
+        open(pf, "w").write(par)
+        log = run([MPIEXEC, "-n", str(nproc), os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+        assert "WAVELET_DOMAIN = F" in log
+        o = collect_run(wd, log, "out", nproc)
+        for kk, vv in o.items():
+            res["np%d_%s" % (nproc, kk)] = vv
+    res.update(dict(nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=0.3, nmajor=c["nmajor"], nminor=c["nminor"],
+                    alpha=1e-7, beta=float(beta.replace("d", "e")), X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs,
+                    model_true=mtrue, parfile=par))
+    np.savez_compressed(os.path.join(HERE, "e2e_dgrad.npz"), **res)
+    a, b = res["np1_model_final"], res["np2_model_final"]
+    print("e2e_dgrad.npz: lsqr r", res["np1_lsqr_r"], "self diff", np.linalg.norm(a - b) / np.linalg.norm(a))
+
+
 def make_mansf(tmp):
     """BASELINE config 1.  Inputs are the reference's shipped example data (data/gravmag/mansf_slice)."""
     par = open(os.path.join(REFROOT, "parfiles", "Parfile_mansf_slice.txt")).read()

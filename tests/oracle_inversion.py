@@ -162,3 +162,71 @@ def run_joint_inversion(problems, dims, ctype, nmajor, nminor, rmin=1e-13, lsqr=
             d[i] = calc_data(i, m[i])
         hist.append(dict(iters=iters, r=r))
     return m, d, hist
+
+
+def gradient_damping_rows(m, dims, grid, cw, pw, beta):
+    """damping_gradient%add for the three directions (src/inversion/damping_gradient.F90:94-205; forward differences
+    gradient.F90:77-81; spacings grid.F90:371-391): 3 N rows, two entries each (none in the last layer of a direction),
+    values cast to fp32 like sparse_matrix.f90:226.  Returns (rowptr, cols 1-based ascending, vals fp32), rhs."""
+    nx, ny, nz = dims
+    N = nx * ny * nz
+    X1, X2, Y1, Y2, Z1, Z2 = grid
+    idx = np.arange(N).reshape(nz, ny, nx)
+    hx = np.abs(X2 - X1).reshape(nz, ny, nx)[0, 0, :]
+    hy = np.abs(Y2 - Y1).reshape(nz, ny, nx)[0, :, 0]
+    hz = np.abs(Z2 - Z1).reshape(nz, ny, nx)[:, 0, 0]
+    f = np.asarray(m, np.float64).reshape(nz, ny, nx)
+    rp, cols, vals, rhs = [0], [], [], []
+    for direction in (1, 2, 3):
+        for k in range(nz):
+            for j in range(ny):
+                for i in range(nx):
+                    last = (i == nx - 1, j == ny - 1, k == nz - 1)[direction - 1]
+                    if last:
+                        rp.append(rp[-1])
+                        rhs.append(0.0)
+                        continue
+                    delta = (hx[i], hy[j], hz[k])[direction - 1]
+                    nb = (idx[k, j, i + 1] if direction == 1 else idx[k, j + 1, i] if direction == 2 else idx[k + 1, j, i])
+                    me = idx[k, j, i]
+                    gval = (f.ravel()[nb] - f.ravel()[me]) / delta
+                    v1 = (1.0 / delta) * pw * beta * cw[nb]
+                    v2 = -(1.0 / delta) * pw * beta * cw[me]
+                    # ascending columns for the upload (me < nb always)
+                    cols += [me + 1, nb + 1]
+                    vals += [np.float32(v2), np.float32(v1)]
+                    rp.append(rp[-1] + 2)
+                    rhs.append(-pw * beta * gval)
+    return (np.array(rp, np.int64), np.array(cols, np.int32), np.array(vals, np.float32)), np.array(rhs)
+
+
+def run_inversion_gradient_damping(S, cw, dims, grid, ctype, d_obs, nmajor, nminor, alpha, beta, rmin=1e-13, pw=1.0, lsqr=None,
+                                   calc_data=None):
+    """Major loop with model damping + gradient damping: WAVELET_DOMAIN = false (joint_inverse_problem.F90:189-198), i.e. the
+    unknowns are the spatial (depth-weighted) model update and nothing is transformed back after the solve (:559-571)."""
+    N = int(np.prod(dims))
+    m = np.zeros(N)
+    lsqr = lsqr or (lambda Cm, b, niter: orc.lsqr(S, Cm, N, b, niter, rmin, spatial=(ctype, dims[0], dims[1], dims[2]) if ctype > 0 else None)[:3])
+    calc_data = calc_data or (lambda model: orc.calc_data(model, cw, dims, ctype, S, pw, np.ones(d_obs.size)))
+    d = calc_data(m)
+    hist = []
+    for it in range(nmajor):
+        rhs = [pw * (d_obs - d)]
+        blocks = []
+        if alpha != 0.0:                                   # damping.F90:97-234 without the transform
+            blocks.append(orc.diag_csr(np.full(N, np.float32(alpha * pw), np.float32)))
+            rhs.append(-alpha * pw * (m / cw))
+        G, grhs = gradient_damping_rows(m, dims, grid, cw, pw, beta)
+        blocks.append(G)
+        rhs.append(grhs)
+        rp = [np.zeros(1, np.int64)]
+        off = 0
+        for b in blocks:
+            rp.append(b[0][1:] + off)
+            off += int(b[0][-1])
+        Cm = (np.concatenate(rp), np.concatenate([b[1] for b in blocks]), np.concatenate([b[2] for b in blocks]))
+        x, iters, r = lsqr(Cm, np.concatenate(rhs), nminor)
+        m = m + x * cw                                      # joint_inverse_problem.F90:570
+        d = calc_data(m)
+        hist.append(dict(iters=iters, r=r))
+    return m, d, hist

@@ -270,8 +270,9 @@ def spmtv(rowptr, cols, vals, x, ncols, b=None):
     return b
 
 
-def lsqr(S, Cm, ncols, b, niter, rmin=1e-13, gamma=0.0, target_misfit=0.0):
-    """S, Cm: (rowptr, cols, vals) CSR.  Returns x, iters, r."""
+def lsqr(S, Cm, ncols, b, niter, rmin=1e-13, gamma=0.0, target_misfit=0.0, spatial=None):
+    """S, Cm: (rowptr, cols, vals) CSR.  Returns x, iters, r.
+    spatial = (wavelet_type, n1, n2, n3): WAVELET_DOMAIN = false (unknowns spatial, S applied through the transform)."""
     s_rp, s_c, s_v = _csr(*S)
     c_rp, c_c, c_v = _csr(*Cm)
     nl_s, nl_c = s_rp.size - 1, c_rp.size - 1
@@ -279,12 +280,13 @@ def lsqr(S, Cm, ncols, b, niter, rmin=1e-13, gamma=0.0, target_misfit=0.0):
     assert u.size == nl_s + nl_c
     x = np.zeros(ncols)
     r = C.c_double()
-    lib().orc_lsqr_solve_sensit.restype = C.c_int
-    it = lib().orc_lsqr_solve_sensit(C.c_int64(nl_s), C.c_int64(nl_c), C.c_int64(ncols), int(niter),
-                                     C.c_double(rmin), C.c_double(gamma), C.c_double(target_misfit),
-                                     s_rp.ctypes.data_as(c_lp), s_c.ctypes.data_as(c_ip), s_v.ctypes.data_as(c_fp),
-                                     c_rp.ctypes.data_as(c_lp), c_c.ctypes.data_as(c_ip), c_v.ctypes.data_as(c_fp),
-                                     dp(u), dp(x), C.byref(r))
+    lib().orc_lsqr_solve_sensit_wd.restype = C.c_int
+    wt, n1, n2, n3 = spatial if spatial else (0, 0, 0, 0)
+    it = lib().orc_lsqr_solve_sensit_wd(C.c_int64(nl_s), C.c_int64(nl_c), C.c_int64(ncols), int(niter),
+                                        C.c_double(rmin), C.c_double(gamma), C.c_double(target_misfit),
+                                        s_rp.ctypes.data_as(c_lp), s_c.ctypes.data_as(c_ip), s_v.ctypes.data_as(c_fp),
+                                        c_rp.ctypes.data_as(c_lp), c_c.ctypes.data_as(c_ip), c_v.ctypes.data_as(c_fp),
+                                        dp(u), dp(x), C.byref(r), int(wt), int(n1), int(n2), int(n3))
     return x, it, r.value
 
 

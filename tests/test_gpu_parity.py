@@ -877,6 +877,35 @@ def test_build_edge_cases(ctx):
     assert abs(x[0] - 2.0) <= 1e-12
 
 
+@pytest.mark.parametrize("matrix", ["reference", "built"])
+def test_gradient_damping_end_to_end_vs_reference(ctx, golden_dir, matrix):
+    """Gradient damping: 3 N first-difference rows built on the host go into the general constraint matrix (tfx_cons_upload_csr)
+    and LSQR runs with spatial unknowns (WAVELET_DOMAIN = false: S through the per-iteration device transform) - the whole
+    inversion against the reference's final model."""
+    g = load(golden_dir, "e2e_dgrad")
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    N = int(np.prod(dims))
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    ctx.set_grid(*dims, *grid)
+    cw = g["np1_column_weight"]
+    obs = g["obs"]
+    if matrix == "built":
+        ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, int(g["ctype"]), float(g["rate"]))
+    else:
+        ctx.matrix_upload_csr(obs.shape[0], N, g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+    # the host-side builder against the oracle's loop-by-loop restatement
+    mtest = np.random.default_rng(2).standard_normal(N)
+    G1, r1 = tfx.inversion.gradient_damping_rows(mtest, dims, ctx.spacing, cw, 1.0, float(g["beta"]))
+    G2, r2 = oinv.gradient_damping_rows(mtest, dims, grid, cw, 1.0, float(g["beta"]))
+    assert np.array_equal(G1[0], G2[0]) and np.array_equal(G1[1], G2[1]) and bits_equal(G1[2], G2[2]) and bits_equal(r1, r2)
+    m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, int(g["ctype"]), g["np1_data_observed"], int(g["nmajor"]),
+                                                     int(g["nminor"]), alpha=float(g["alpha"]), beta=float(g["beta"]))
+    ref = g["np1_model_final"]
+    tol = 1e-7 if matrix == "reference" else 1e-5
+    assert np.linalg.norm(m - ref) <= tol * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-5)
+
+
 def test_config1_mansf_end_to_end(ctx, golden_dir):
     """BASELINE config 1 (parfiles/Parfile_mansf_slice.txt: 2x128x32 cells, 256 obs, Haar 0.15, ADMM, 60 x 100 LSQR
     iterations) entirely on the HIP path vs the reference's final model."""

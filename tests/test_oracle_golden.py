@@ -334,3 +334,19 @@ def test_joint_inversion_end_to_end(golden_dir):
         dref = g["np1_%s_data_final" % tag]
         assert np.allclose(d[i], dref, rtol=100 * tol, atol=10 * tol * np.abs(dref).max())
     assert np.allclose(hist[0]["r"], g["np1_lsqr_r"][0], rtol=1e-4)
+
+
+def test_gradient_damping_end_to_end(golden_dir):
+    """Gradient damping puts 3 N first-difference rows into the general constraint matrix and switches LSQR to spatial
+    unknowns (WAVELET_DOMAIN = false): whole inversion vs the reference's final model."""
+    g = load(golden_dir, "e2e_dgrad")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    S = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+    m, d, hist = oinv.run_inversion_gradient_damping(S, g["np1_column_weight"], dims, grid, int(g["ctype"]), g["np1_data_observed"],
+                                                     int(g["nmajor"]), int(g["nminor"]), float(g["alpha"]), float(g["beta"]))
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    assert np.allclose(d, g["np1_data_final"], rtol=1e-8, atol=1e-10 * np.abs(g["np1_data_final"]).max())
+    assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
+    assert np.linalg.norm(g["np2_model_final"] - ref) <= 1e-9 * np.linalg.norm(ref)

@@ -35,9 +35,48 @@ class AdmmState:
         return self.z - self.u
 
 
+def gradient_damping_rows(m, dims, spacing, cw, pw, beta):
+    """damping_gradient%add for the three directions (src/inversion/damping_gradient.F90:94-205): forward differences
+    (gradient.F90:77-81) of the model along x, y, z; 3 N rows of two entries (none in the last layer of a direction) with
+    values pw * beta * cw(column) * (+-1 / delta) cast to fp32, right-hand side -pw * beta * gradient.
+    Returns (rowptr, cols 1-based ascending, vals), rhs - what Context.cons_upload_csr takes."""
+    nx, ny, nz = dims
+    N = nx * ny * nz
+    idx = np.arange(N, dtype=np.int64).reshape(nz, ny, nx)
+    f = np.asarray(m, np.float64)
+    cnts, cs, vs, rh = [], [], [], []
+    for axis, h in ((2, spacing[0]), (1, spacing[1]), (0, spacing[2])):       # direction 1 = x (fastest index), 2 = y, 3 = z
+        n_ax = idx.shape[axis]
+        me = np.take(idx, np.arange(n_ax - 1), axis=axis)
+        nb = np.take(idx, np.arange(1, n_ax), axis=axis)
+        shape = [1, 1, 1]
+        shape[axis] = n_ax - 1
+        delta = np.broadcast_to(np.asarray(h, np.float64)[:n_ax - 1].reshape(shape), me.shape)
+        me, nb, delta = me.ravel(), nb.ravel(), delta.ravel()
+        gval = (f[nb] - f[me]) / delta
+        cnt = np.zeros(N, np.int64)
+        cnt[me] = 2
+        order = np.argsort(me, kind="stable")                                   # rows are cells in i-fastest order
+        me, nb, delta, gval = me[order], nb[order], delta[order], gval[order]
+        c = np.empty(2 * me.size, np.int32)
+        v = np.empty(2 * me.size, np.float32)
+        c[0::2] = me + 1
+        c[1::2] = nb + 1
+        v[0::2] = (-(1.0 / delta) * pw * beta * cw[me]).astype(np.float32)
+        v[1::2] = ((1.0 / delta) * pw * beta * cw[nb]).astype(np.float32)
+        r = np.zeros(N)
+        r[me] = -pw * beta * gval
+        cnts.append(cnt)
+        cs.append(c)
+        vs.append(v)
+        rh.append(r)
+    rowptr = np.concatenate([[0], np.cumsum(np.concatenate(cnts))]).astype(np.int64)
+    return (rowptr, np.concatenate(cs), np.concatenate(vs)), np.concatenate(rh)
+
+
 def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor, nminor, alpha=0.0, rmin=1e-13,
                           problem_weight=1.0, data_weight=None, model_start=None, model_prior=None, admm=None,
-                          gamma=0.0, target_misfit=0.0, log=None, nmodel_components=1, col_range=None):
+                          gamma=0.0, target_misfit=0.0, log=None, nmodel_components=1, col_range=None, beta=0.0):
     """ctx: Context holding the sensitivity matrix S (already scaled by problem_weight * data_weight) over ALL columns.
     admm: dict(bounds=[...], rho=...) or None.  Returns (model, data_calc, history).
     One problem of either kind (the name is historical).  nmodel_components = 3 (magnetisation vector): model vectors are
@@ -48,6 +87,12 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
     ncm = int(nmodel_components)
     N1 = nx * ny * nz
     N = N1 * ncm
+    # gradient damping (beta != 0) acts in space: WAVELET_DOMAIN = false (joint_inverse_problem.F90:189-198) - the unknowns
+    # are the spatial depth-weighted update, S is applied through the per-iteration device transform, the damping block is not
+    # transformed (damping.F90:135-150) and nothing is transformed back after the solve (joint_inverse_problem.F90:559-567)
+    spatial = beta != 0.0
+    if spatial and (ncm != 1 or col_range is not None):
+        raise NotImplementedError("gradient damping: one model component, single rank in this host")
     if col_range is None:
         loc = lambda v: v
         gather = lambda v: v
@@ -75,6 +120,9 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
     def to_wavelet(v):
         return ctx.forward_wavelet(v, nx, ny, nz, compression_type) if compression_type > 0 else v
 
+    def to_unknowns(v):                              # the domain of the LSQR unknowns
+        return v if spatial else to_wavelet(v)
+
     def calculate_data(model):                       # model.F90:242-305
         scaled = np.where(cw != 0.0, model / cw, 0.0)
         return ctx.calc_data(loc(to_wavelet(scaled)), pw, dw)
@@ -87,17 +135,26 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
         b_data = pw * res                            # joint_inverse_problem.F90:379-387
         diag, rhs = [], []
         if alpha != 0.0:                             # damping.F90:97-234 (L2, no local weights)
-            md = loc(to_wavelet((m - mp) / cw))
+            md = loc(to_unknowns((m - mp) / cw))
             diag.append(np.full(md.size, np.float32(alpha * pw), np.float32))
             rhs.append(-alpha * pw * md)
         if admm is not None:                         # joint_inverse_problem.F90:497-527
             x0 = st.iterate_admm_arrays(m, admm["bounds"])
-            md = loc(to_wavelet((m - x0) / cw))
+            md = loc(to_unknowns((m - x0) / cw))
             diag.append(np.full(md.size, np.float32(admm["rho"] * pw), np.float32))
             rhs.append(-admm["rho"] * pw * md)
-        x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
+        if spatial:
+            G, grhs = gradient_damping_rows(m, (nx, ny, nz), ctx.spacing, cw, pw, beta)
+            ctx.cons_upload_csr(G[0], G[1], G[2], grhs)
+            ctx.lsqr_set_wavelet_domain(False, compression_type)
+        try:
+            x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
+        finally:
+            if spatial:
+                ctx.lsqr_set_wavelet_domain(True)
+                ctx.cons_clear()
         x = gather(x)
-        dm = ctx.inverse_wavelet(x, nx, ny, nz, compression_type) if compression_type > 0 else x
+        dm = ctx.inverse_wavelet(x, nx, ny, nz, compression_type) if (compression_type > 0 and not spatial) else x
         m = m + dm * cw                              # joint_inverse_problem.F90:570, model update :500
         d_calc = calculate_data(m)
         cost = float(np.linalg.norm(d_calc - data_obs) / np.linalg.norm(data_obs))   # data_gravmag.f90:123-129

@@ -73,6 +73,11 @@ class Context:
                 raise ValueError("grid array size %d != nx*ny*nz = %d" % (a.size, n))
         check(self._lib.tfx_set_grid(self._h, nx, ny, nz, *[ptr(a) for a in arrs]))
         self.dims = (int(nx), int(ny), int(nz))
+        # cell sizes along the axes of the structured grid (t_grad_grid, src/inversion/grid.F90:371-391) for host-side
+        # constraint builders
+        sh = (nz, ny, nx)
+        self.spacing = (np.abs(arrs[1] - arrs[0]).reshape(sh)[0, 0, :].copy(), np.abs(arrs[3] - arrs[2]).reshape(sh)[0, :, 0].copy(),
+                        np.abs(arrs[5] - arrs[4]).reshape(sh)[:, 0, 0].copy())
 
     @property
     def nelements_total(self):
