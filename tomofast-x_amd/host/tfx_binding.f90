@@ -238,6 +238,31 @@ module tfx_binding
       type(c_ptr), value :: ctx, ptr
     end function
 
+    ! matrix_cons built on the host (cross-gradient, clustering, gradient damping, local bounds: joint_inverse_problem.F90:466-544)
+    ! as CSR with its right-hand side; columns span all problems; consumed by the next tfx_lsqr_solve
+    integer(c_int) function tfx_cons_upload_csr(ctx, nrows, rowptr, cols, vals, rhs) bind(C, name="tfx_cons_upload_csr")
+      import :: c_int, c_ptr, c_float, c_double, c_int64_t, c_int32_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: nrows
+      integer(c_int64_t), intent(in) :: rowptr(*)
+      integer(c_int32_t), intent(in) :: cols(*)
+      real(c_float), intent(in) :: vals(*)
+      real(c_double), intent(in) :: rhs(*)
+    end function
+
+    integer(c_int) function tfx_cons_clear(ctx) bind(C, name="tfx_cons_clear")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    ! WAVELET_DOMAIN (joint_inverse_problem.F90:189-198): 0 = spatial unknowns, S applied through the n1 x n2 x n3 transform
+    integer(c_int) function tfx_lsqr_set_wavelet_domain(ctx, wavelet_domain, n1, n2, n3, wavelet_type) &
+        bind(C, name="tfx_lsqr_set_wavelet_domain")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: wavelet_domain, n1, n2, n3, wavelet_type
+    end function
+
     ! joint inversion: slot 0 / 1 = which problem's sensitivity matrix the build / matrix / product / calc_data calls act on;
     ! LSQR solves with blockdiag(slot 0, slot 1) once slot 1 holds a matrix (src/inversion/joint_inverse_problem.F90:712-739)
     integer(c_int) function tfx_select_problem(ctx, slot) bind(C, name="tfx_select_problem")

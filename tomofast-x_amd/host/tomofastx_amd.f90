@@ -507,6 +507,12 @@ program tomofastx_amd
   character(len=4) :: suffix(2) = (/'grav', 'mag '/)
   integer :: ip, n, it, i, k, nblocks, ucost, narg, kadm, nprob, ntot, ndtot, c0, r0, ndev
   integer :: lc0
+  logical :: spatial = .false.      ! gradient damping acts in space: LSQR unknowns are spatial, S goes through the device transform
+  integer(c_int64_t), allocatable, target :: g_rowptr(:)
+  integer(c_int32_t), allocatable, target :: g_cols(:)
+  real(c_float), allocatable, target :: g_vals(:)
+  real(dp), allocatable, target :: g_rhs(:)
+  integer(c_int64_t) :: g_nrows, g_nnz
   integer :: cb, ce, nloc, ra, rb                     ! this rank's cells (cb, ce], nloc = ce - cb; its share of the data rows
   integer(c_int32_t), allocatable, target :: hist(:), hist_all(:), nel_at(:)
   integer(c_int64_t), allocatable :: nnz_at(:)
@@ -567,8 +573,8 @@ program tomofastx_amd
   k = 0
   do ip = 1, 2
     if (.not. pr(ip)%on) cycle
-    if (par%beta_grad(ip) /= 0.d0 .or. par%w_clust(ip) /= 0.d0) &
-      call stop_msg('Gradient damping / clustering constraints are not supported by this host.')
+    if (par%w_clust(ip) /= 0.d0) call stop_msg('Clustering constraints are not supported by this host.')
+    if (par%beta_grad(ip) /= 0.d0) spatial = .true.              ! WAVELET_DOMAIN = .false. (joint_inverse_problem.F90:189-198)
     if (par%use_error(ip) /= 0) call stop_msg('Data errors are not supported by this host yet.')
     pr(ip)%slot = k
     k = k + 1
@@ -601,6 +607,7 @@ program tomofastx_amd
   enddo
   allocate(b_data(ndtot), x(ntot), xfull(ntot), rhs(ntot, 4), diag(ntot, 4), work(ntot))
   if (nprob == 2) print *, 'JOINT inversion: two sensitivity kernels in one system.'
+  print *, 'WAVELET_DOMAIN =', .not. spatial
 
   ndev = tfx_device_count()
   if (ndev <= 0) call stop_msg('No HIP device visible - the MI355X path has no CPU fallback.')
@@ -615,6 +622,7 @@ program tomofastx_amd
     call tfx_check(tfx_set_allreduce(ctx, c_funloc(allreduce_hook), c_null_ptr, int(myrank, c_int), int(nbproc, c_int)), &
                    'tfx_set_allreduce')
     if (par%sensit_read == 2) call stop_msg('sensit.readFromFiles = 2 runs single-rank in this host.')
+    if (spatial) call stop_msg('Gradient damping (WAVELET_DOMAIN = F) runs single-rank in this host.')
     ! ---- column partition (calculate_new_partitioning, sensitivity_gravmag.F90:573-640): per-cell non-zero counts of my share
     ! of the data rows of every kernel, summed over ranks and problems, then the reference's greedy nnz-balancing rule
     allocate(hist(n), hist_all(n), nel_at(nbproc), nnz_at(nbproc))
@@ -767,7 +775,7 @@ program tomofastx_amd
         do k = 1, pr(ip)%nc                                        ! (joint_inverse_problem.F90:456-463)
           work((k - 1) * n + 1:k * n) = (pr(ip)%m((k - 1) * n + 1:k * n) - pr(ip)%m_prior((k - 1) * n + 1:k * n)) / pr(ip)%cw
         enddo
-        call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
+        if (.not. spatial) call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)       ! damping.F90:135-150
         diag(:, nblocks) = 0.0
         diag(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = real(par%alpha(ip) * pr(ip)%pw, c_float)
         rhs(:, nblocks) = 0.d0
@@ -783,7 +791,7 @@ program tomofastx_amd
                                  pr(ip)%u_admm, pr(ip)%x0)
         work(1:pr(ip)%nm) = 0.d0
         work((kadm - 1) * n + 1:kadm * n) = (pr(ip)%m((kadm - 1) * n + 1:kadm * n) - pr(ip)%x0) / pr(ip)%cw
-        call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
+        if (.not. spatial) call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
         diag(:, nblocks) = 0.0
         diag(lc0 + (kadm - 1) * nloc + 1:lc0 + kadm * nloc, nblocks) = real(pr(ip)%rho * pr(ip)%pw, c_float)
         rhs(:, nblocks) = 0.d0
@@ -798,8 +806,17 @@ program tomofastx_amd
         print *, 'ADMM cost |x - z| / |z| =', pr(ip)%cost_admm
       endif
     enddo
+    if (spatial) then
+      call build_gradient_damping()
+      call tfx_check(tfx_cons_upload_csr(ctx, g_nrows, g_rowptr, g_cols, g_vals, g_rhs), 'damping_gradient_add')
+      call tfx_check(tfx_lsqr_set_wavelet_domain(ctx, 0_c_int, par%nx, par%ny, par%nz, par%comp_type), 'WAVELET_DOMAIN')
+    endif
     call tfx_check(tfx_lsqr_solve(ctx, par%nminor, par%rmin, par%gamma, par%target_misfit, b_data, nblocks, dptr, rptr, x, &
                                   iters, r), 'lsqr_solve_sensit')
+    if (spatial) then
+      call tfx_check(tfx_lsqr_set_wavelet_domain(ctx, 1_c_int, par%nx, par%ny, par%nz, par%comp_type), 'WAVELET_DOMAIN')
+      call tfx_check(tfx_cons_clear(ctx), 'tfx_cons_clear')
+    endif
     print *, 'Finished lsqr solver, r =', r, ' iter =', iters
     call write_costs(it - 1)                                       ! :519-528 (costs of the previous iteration)
     do ip = 1, 2
@@ -810,7 +827,7 @@ program tomofastx_amd
       do k = 1, pr(ip)%nc                                          ! slices of all ranks -> the full update (wavelet_utils.F90:37-72)
         call allgather_slices(x(lc0 + (k - 1) * nloc + 1:lc0 + k * nloc), nloc, xfull(c0 + (k - 1) * n + 1:c0 + k * n), counts, displs)
       enddo
-      if (par%comp_type > 0) &                                     ! :559-567
+      if (par%comp_type > 0 .and. .not. spatial) &                 ! :559-567
         call tfx_check(tfx_wavelet(ctx, xfull(c0 + 1:c0 + pr(ip)%nm), par%nx, par%ny, par%nz, int(pr(ip)%nc, c_int64_t), &
                                    par%comp_type, 2_c_int), 'inverse_wavelet')
       do k = 1, pr(ip)%nc
@@ -853,6 +870,65 @@ contains
     write(ucost, *)
     flush(ucost)
   end subroutine write_costs
+
+  ! damping_gradient%add for every active problem, component and direction (src/inversion/damping_gradient.F90:94-205,
+  ! joint_inverse_problem.F90:466-488): forward differences (gradient.F90:77-81) over the structured grid (grid.F90:371-391);
+  ! 3 N rows per component, two entries each except in the last layer of the direction; columns ascending for the upload
+  subroutine build_gradient_damping()
+    integer :: jp, kc, dir, i, j, kk, p, me, nb, cshift
+    integer(c_int64_t) :: row, e
+    real(dp) :: delta, gval, coef
+    g_nrows = 0
+    do jp = 1, 2
+      if (pr(jp)%on .and. par%beta_grad(jp) /= 0.d0) g_nrows = g_nrows + 3_c_int64_t * n * pr(jp)%nc
+    enddo
+    if (.not. allocated(g_rowptr)) allocate(g_rowptr(g_nrows + 1), g_cols(2 * g_nrows), g_vals(2 * g_nrows), g_rhs(g_nrows))
+    row = 0
+    e = 0
+    g_rowptr(1) = 0
+    do jp = 1, 2
+      if (.not. (pr(jp)%on .and. par%beta_grad(jp) /= 0.d0)) cycle
+      coef = pr(jp)%pw * par%beta_grad(jp)
+      do kc = 1, pr(jp)%nc
+        cshift = pr(jp)%col0 + (kc - 1) * n
+        do dir = 1, 3
+          p = 0
+          do kk = 1, par%nz
+            do j = 1, par%ny
+              do i = 1, par%nx
+                p = p + 1
+                row = row + 1
+                g_rhs(row) = 0.d0
+                me = p
+                nb = 0
+                if (dir == 1 .and. i /= par%nx) then
+                  nb = p + 1
+                  delta = abs(pr(jp)%X2(i) - pr(jp)%X1(i))                       ! dX(i): cell (i, 1, 1)
+                else if (dir == 2 .and. j /= par%ny) then
+                  nb = p + par%nx
+                  delta = abs(pr(jp)%Y2((j - 1) * par%nx + 1) - pr(jp)%Y1((j - 1) * par%nx + 1))
+                else if (dir == 3 .and. kk /= par%nz) then
+                  nb = p + par%nx * par%ny
+                  delta = abs(pr(jp)%Z2((kk - 1) * par%nx * par%ny + 1) - pr(jp)%Z1((kk - 1) * par%nx * par%ny + 1))
+                endif
+                if (nb > 0) then
+                  gval = (pr(jp)%m((kc - 1) * n + nb) - pr(jp)%m((kc - 1) * n + me)) / delta
+                  g_cols(e + 1) = cshift + me
+                  g_vals(e + 1) = real(-(1.d0 / delta) * coef * pr(jp)%cw(me), c_float)
+                  g_cols(e + 2) = cshift + nb
+                  g_vals(e + 2) = real((1.d0 / delta) * coef * pr(jp)%cw(nb), c_float)
+                  e = e + 2
+                  g_rhs(row) = -coef * gval
+                endif
+                g_rowptr(row + 1) = e
+              enddo
+            enddo
+          enddo
+        enddo
+      enddo
+    enddo
+    g_nnz = e
+  end subroutine build_gradient_damping
 
   ! this rank's cells (cb, ce] of every model component of a full vector
   subroutine to_local(jp, vfull, vloc)
