@@ -769,6 +769,43 @@ def make_dgrad_e2e(tmp):
     print("e2e_dgrad.npz: lsqr r", res["np1_lsqr_r"], "self diff", np.linalg.norm(a - b) / np.linalg.norm(a))
 
 
+def make_lp_e2e(tmp):
+    """Lp-norm model damping (inversion.modelDamping.normPower = 1.5): the damping block and its right-hand side carry the
+    multiplier |m - m_prior|^(p/2 - 1) (damping.F90:171-175, :250-262) and the solver runs with WAVELET_DOMAIN = false."""
+    c = dict(nx=8, ny=6, nz=5, ox=3, oy=3, ctype=2, rate="0.3d0", nmajor=3, nminor=400, alpha="1.d-6", dwtype=1)
+    g, obs, mtrue = synthetic_problem(c["nx"], c["ny"], c["nz"], c["ox"], c["oy"])
+    nd = obs.shape[0]
+    par = PAR_TMPL.format(nd=nd, **c).replace("inversion.modelDamping.normPower    = 2.0d0", "inversion.modelDamping.normPower    = 1.5d0")
+    assert "1.5d0" in par
+    res = {}
+    for nproc in (1, 2):
+        wd = os.path.join(tmp, "lp_np%d" % nproc)
+        shutil.rmtree(wd, ignore_errors=True)
+        os.makedirs(wd)
+        write_grid_file(os.path.join(wd, "grid.txt"), g, c["nx"], c["ny"], c["nz"])
+        with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+            f.write("%d\n" % nd)
+            for r in obs:
+                f.write("%.17g %.17g %.17g 0.0\n" % tuple(r))
+        with open(os.path.join(wd, "model_true.txt"), "w") as f:
+            f.write("%d\n" % mtrue.size)
+            for v in mtrue:
+                f.write("%.17g\n" % v)
+        pf = os.path.join(wd, "Parfile.txt")
+        open(pf, "w").write(par)
+        log = run([MPIEXEC, "-n", str(nproc), os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+        assert "WAVELET_DOMAIN = F" in log
+        o = collect_run(wd, log, "out", nproc)
+        for kk, vv in o.items():
+            res["np%d_%s" % (nproc, kk)] = vv
+    res.update(dict(nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=0.3, nmajor=c["nmajor"], nminor=c["nminor"],
+                    alpha=1e-6, norm_power=1.5, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs,
+                    model_true=mtrue, parfile=par))
+    np.savez_compressed(os.path.join(HERE, "e2e_lp.npz"), **res)
+    a, b = res["np1_model_final"], res["np2_model_final"]
+    print("e2e_lp.npz: lsqr r", res["np1_lsqr_r"], "self diff", np.linalg.norm(a - b) / np.linalg.norm(a))
+
+
 def make_mansf(tmp):
     """BASELINE config 1.  Inputs are the reference's shipped example data (data/gravmag/mansf_slice)."""
     par = open(os.path.join(REFROOT, "parfiles", "Parfile_mansf_slice.txt")).read()

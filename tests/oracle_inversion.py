@@ -201,7 +201,7 @@ def gradient_damping_rows(m, dims, grid, cw, pw, beta):
 
 
 def run_inversion_gradient_damping(S, cw, dims, grid, ctype, d_obs, nmajor, nminor, alpha, beta, rmin=1e-13, pw=1.0, lsqr=None,
-                                   calc_data=None):
+                                   calc_data=None, norm_power=2.0):
     """Major loop with model damping + gradient damping: WAVELET_DOMAIN = false (joint_inverse_problem.F90:189-198), i.e. the
     unknowns are the spatial (depth-weighted) model update and nothing is transformed back after the solve (:559-571)."""
     N = int(np.prod(dims))
@@ -214,11 +214,17 @@ def run_inversion_gradient_damping(S, cw, dims, grid, ctype, d_obs, nmajor, nmin
         rhs = [pw * (d_obs - d)]
         blocks = []
         if alpha != 0.0:                                   # damping.F90:97-234 without the transform
-            blocks.append(orc.diag_csr(np.full(N, np.float32(alpha * pw), np.float32)))
-            rhs.append(-alpha * pw * (m / cw))
-        G, grhs = gradient_damping_rows(m, dims, grid, cw, pw, beta)
-        blocks.append(G)
-        rhs.append(grhs)
+            md = m / cw
+            mult = np.ones(N)
+            if norm_power != 2.0:                          # Lp norm multiplier, damping.F90:171-175, :250-262
+                nzm = md != 0.0
+                mult[nzm] = np.abs(md[nzm]) ** (norm_power / 2.0 - 1.0)
+            blocks.append(orc.diag_csr((alpha * pw * mult).astype(np.float32)))
+            rhs.append(-alpha * pw * md * mult)
+        if beta != 0.0:
+            G, grhs = gradient_damping_rows(m, dims, grid, cw, pw, beta)
+            blocks.append(G)
+            rhs.append(grhs)
         rp = [np.zeros(1, np.int64)]
         off = 0
         for b in blocks:

@@ -350,3 +350,18 @@ def test_gradient_damping_end_to_end(golden_dir):
     assert np.allclose(d, g["np1_data_final"], rtol=1e-8, atol=1e-10 * np.abs(g["np1_data_final"]).max())
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
     assert np.linalg.norm(g["np2_model_final"] - ref) <= 1e-9 * np.linalg.norm(ref)
+
+
+def test_lp_norm_damping_end_to_end(golden_dir):
+    """Model damping with normPower = 1.5: multiplier |m - m_prior|^(p/2 - 1) on the block and its right-hand side, spatial
+    unknowns (WAVELET_DOMAIN = false), three major iterations vs the reference."""
+    g = load(golden_dir, "e2e_lp")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    S = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+    m, d, hist = oinv.run_inversion_gradient_damping(S, g["np1_column_weight"], dims, grid, int(g["ctype"]), g["np1_data_observed"],
+                                                     int(g["nmajor"]), int(g["nminor"]), float(g["alpha"]), 0.0,
+                                                     norm_power=float(g["norm_power"]))
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)

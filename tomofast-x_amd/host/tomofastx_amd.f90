@@ -560,7 +560,7 @@ program tomofastx_amd
   if (par%dw_type /= 1 .and. par%dw_type /= 2) call stop_msg('forward.depthWeighting.type must be 1 or 2 in this host.')
   if (par%w_cross /= 0.d0) call stop_msg('Cross-gradient constraints are not supported by this host.')
   if (par%apply_local_dw /= 0 .or. par%apply_local_damp /= 0) call stop_msg('Local weights are not supported by this host yet.')
-  if (par%norm_power /= 2.d0) call stop_msg('inversion.modelDamping.normPower /= 2 is not supported by this host yet.')
+  if (par%norm_power /= 2.d0) spatial = .true.                   ! Lp damping acts in space (joint_inverse_problem.F90:189-198)
   if (par%admm > 0 .and. par%admm_bound_type /= 1) call stop_msg('ADMM with local bounds (boundType 2) is not supported yet.')
   if (par%sensit_read < 0 .or. par%sensit_read > 2) call stop_msg('sensit.readFromFiles must be 0, 1 or 2.')
   if (par%admm > 0 .and. .not. allocated(par%bounds)) call stop_msg('Global bounds are not defined!')
@@ -780,6 +780,14 @@ program tomofastx_amd
         diag(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = real(par%alpha(ip) * pr(ip)%pw, c_float)
         rhs(:, nblocks) = 0.d0
         call to_local(ip, work, rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks))
+        if (par%norm_power /= 2.d0) then                             ! Lp norm multiplier (damping.F90:171-175, :250-262)
+          do i = lc0 + 1, lc0 + pr(ip)%nml
+            s1 = 1.d0
+            if (rhs(i, nblocks) /= 0.d0) s1 = (abs(rhs(i, nblocks)))**(par%norm_power / 2.d0 - 1.d0)
+            diag(i, nblocks) = real(par%alpha(ip) * pr(ip)%pw * s1, c_float)
+            rhs(i, nblocks) = rhs(i, nblocks) * s1
+          enddo
+        endif
         rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = -par%alpha(ip) * pr(ip)%pw * rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks)
         dptr(nblocks) = c_loc(diag(1, nblocks))
         rptr(nblocks) = c_loc(rhs(1, nblocks))
@@ -808,7 +816,7 @@ program tomofastx_amd
     enddo
     if (spatial) then
       call build_gradient_damping()
-      call tfx_check(tfx_cons_upload_csr(ctx, g_nrows, g_rowptr, g_cols, g_vals, g_rhs), 'damping_gradient_add')
+      if (g_nrows > 0) call tfx_check(tfx_cons_upload_csr(ctx, g_nrows, g_rowptr, g_cols, g_vals, g_rhs), 'damping_gradient_add')
       call tfx_check(tfx_lsqr_set_wavelet_domain(ctx, 0_c_int, par%nx, par%ny, par%nz, par%comp_type), 'WAVELET_DOMAIN')
     endif
     call tfx_check(tfx_lsqr_solve(ctx, par%nminor, par%rmin, par%gamma, par%target_misfit, b_data, nblocks, dptr, rptr, x, &
@@ -882,6 +890,7 @@ contains
     do jp = 1, 2
       if (pr(jp)%on .and. par%beta_grad(jp) /= 0.d0) g_nrows = g_nrows + 3_c_int64_t * n * pr(jp)%nc
     enddo
+    if (g_nrows == 0) return
     if (.not. allocated(g_rowptr)) allocate(g_rowptr(g_nrows + 1), g_cols(2 * g_nrows), g_vals(2 * g_nrows), g_rhs(g_nrows))
     row = 0
     e = 0

@@ -76,7 +76,8 @@ def gradient_damping_rows(m, dims, spacing, cw, pw, beta):
 
 def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor, nminor, alpha=0.0, rmin=1e-13,
                           problem_weight=1.0, data_weight=None, model_start=None, model_prior=None, admm=None,
-                          gamma=0.0, target_misfit=0.0, log=None, nmodel_components=1, col_range=None, beta=0.0):
+                          gamma=0.0, target_misfit=0.0, log=None, nmodel_components=1, col_range=None, beta=0.0,
+                          norm_power=2.0):
     """ctx: Context holding the sensitivity matrix S (already scaled by problem_weight * data_weight) over ALL columns.
     admm: dict(bounds=[...], rho=...) or None.  Returns (model, data_calc, history).
     One problem of either kind (the name is historical).  nmodel_components = 3 (magnetisation vector): model vectors are
@@ -90,9 +91,10 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
     # gradient damping (beta != 0) acts in space: WAVELET_DOMAIN = false (joint_inverse_problem.F90:189-198) - the unknowns
     # are the spatial depth-weighted update, S is applied through the per-iteration device transform, the damping block is not
     # transformed (damping.F90:135-150) and nothing is transformed back after the solve (joint_inverse_problem.F90:559-567)
-    spatial = beta != 0.0
+    # ... and so does an Lp norm of the model damping (norm_power != 2: multiplier |m - m_prior|^(p/2 - 1), damping.F90:171-175)
+    spatial = beta != 0.0 or norm_power != 2.0
     if spatial and (ncm != 1 or col_range is not None):
-        raise NotImplementedError("gradient damping: one model component, single rank in this host")
+        raise NotImplementedError("gradient / Lp damping: one model component, single rank in this host")
     if col_range is None:
         loc = lambda v: v
         gather = lambda v: v
@@ -136,16 +138,21 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
         diag, rhs = [], []
         if alpha != 0.0:                             # damping.F90:97-234 (L2, no local weights)
             md = loc(to_unknowns((m - mp) / cw))
-            diag.append(np.full(md.size, np.float32(alpha * pw), np.float32))
-            rhs.append(-alpha * pw * md)
+            mult = np.ones(md.size)
+            if norm_power != 2.0:                    # damping.F90:250-262
+                nzm = md != 0.0
+                mult[nzm] = np.abs(md[nzm]) ** (norm_power / 2.0 - 1.0)
+            diag.append((alpha * pw * mult).astype(np.float32))
+            rhs.append(-alpha * pw * md * mult)
         if admm is not None:                         # joint_inverse_problem.F90:497-527
             x0 = st.iterate_admm_arrays(m, admm["bounds"])
             md = loc(to_unknowns((m - x0) / cw))
             diag.append(np.full(md.size, np.float32(admm["rho"] * pw), np.float32))
             rhs.append(-admm["rho"] * pw * md)
         if spatial:
-            G, grhs = gradient_damping_rows(m, (nx, ny, nz), ctx.spacing, cw, pw, beta)
-            ctx.cons_upload_csr(G[0], G[1], G[2], grhs)
+            if beta != 0.0:
+                G, grhs = gradient_damping_rows(m, (nx, ny, nz), ctx.spacing, cw, pw, beta)
+                ctx.cons_upload_csr(G[0], G[1], G[2], grhs)
             ctx.lsqr_set_wavelet_domain(False, compression_type)
         try:
             x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
