@@ -806,6 +806,55 @@ def make_lp_e2e(tmp):
     print("e2e_lp.npz: lsqr r", res["np1_lsqr_r"], "self diff", np.linalg.norm(a - b) / np.linalg.norm(a))
 
 
+def make_admm_local_e2e(tmp):
+    """ADMM with LOCAL bounds (inversion.admm.boundType = 2): per-cell lithology intervals and a per-cell weight from a file
+    (model_IO.F90:311-372); the weight scales the ADMM block and its right-hand side, and the solver runs with
+    WAVELET_DOMAIN = false (joint_inverse_problem.F90:189-198)."""
+    c = dict(nx=8, ny=6, nz=5, ox=3, oy=3, ctype=1, rate="0.3d0", nmajor=4, nminor=300, alpha="1.d-9", dwtype=1)
+    g, obs, mtrue = synthetic_problem(c["nx"], c["ny"], c["nz"], c["ox"], c["oy"])
+    nd = obs.shape[0]
+    N = mtrue.size
+    rng = np.random.default_rng(77)
+    # two lithologies per cell: background around 0 and a body whose interval depends on the cell, plus a weight
+    lo2 = np.where(np.arange(N) % 3 == 0, 250.0, 280.0)
+    bounds = np.stack([np.full(N, -5.0), np.full(N, 5.0), lo2, lo2 + 60.0], 1)
+    weight = rng.uniform(0.5, 2.0, N)
+    par = PAR_TMPL.format(nd=nd, **c).replace("inversion.admm.enableADMM           = 0", "inversion.admm.enableADMM           = 1") + (
+        "inversion.admm.nLithologies         = 2\ninversion.admm.boundType            = 2\n"
+        "inversion.admm.grav.boundsFile      = bounds.txt\ninversion.admm.grav.weight          = 1.d-6\n")
+    res = {}
+    for nproc in (1, 2):
+        wd = os.path.join(tmp, "admml_np%d" % nproc)
+        shutil.rmtree(wd, ignore_errors=True)
+        os.makedirs(wd)
+        write_grid_file(os.path.join(wd, "grid.txt"), g, c["nx"], c["ny"], c["nz"])
+        with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+            f.write("%d\n" % nd)
+            for r in obs:
+                f.write("%.17g %.17g %.17g 0.0\n" % tuple(r))
+        with open(os.path.join(wd, "model_true.txt"), "w") as f:
+            f.write("%d\n" % N)
+            for v in mtrue:
+                f.write("%.17g\n" % v)
+        with open(os.path.join(wd, "bounds.txt"), "w") as f:
+            f.write("%d 2\n" % N)
+            for bnd, w in zip(bounds, weight):
+                f.write("%.17g %.17g %.17g %.17g %.17g\n" % (bnd[0], bnd[1], bnd[2], bnd[3], w))
+        pf = os.path.join(wd, "Parfile.txt")
+        open(pf, "w").write(par)
+        log = run([MPIEXEC, "-n", str(nproc), os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+        assert "WAVELET_DOMAIN = F" in log
+        o = collect_run(wd, log, "out", nproc)
+        for kk, vv in o.items():
+            res["np%d_%s" % (nproc, kk)] = vv
+    res.update(dict(nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=0.3, nmajor=c["nmajor"], nminor=c["nminor"],
+                    alpha=1e-9, rho=1e-6, bounds=bounds, bound_weight=weight, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5],
+                    obs=obs, model_true=mtrue, parfile=par))
+    np.savez_compressed(os.path.join(HERE, "e2e_admm_local.npz"), **res)
+    a, b = res["np1_model_final"], res["np2_model_final"]
+    print("e2e_admm_local.npz: lsqr r", res["np1_lsqr_r"], "self diff", np.linalg.norm(a - b) / np.linalg.norm(a))
+
+
 def make_mansf(tmp):
     """BASELINE config 1.  Inputs are the reference's shipped example data (data/gravmag/mansf_slice)."""
     par = open(os.path.join(REFROOT, "parfiles", "Parfile_mansf_slice.txt")).read()

@@ -200,8 +200,29 @@ def gradient_damping_rows(m, dims, grid, cw, pw, beta):
     return (np.array(rp, np.int64), np.array(cols, np.int32), np.array(vals, np.float32)), np.array(rhs)
 
 
+def admm_iterate_local(z, u, x, bounds):
+    """admm_method.F90:70-134 with per-cell intervals bounds[cell] = [lo1 hi1 lo2 hi2 ...]; plain loops (the checker)."""
+    for p in range(x.size):
+        a = x[p] + u[p]
+        b = bounds[p]
+        inside = False
+        for j in range(0, b.size, 2):
+            if b[j] <= a <= b[j + 1]:
+                inside = True
+                z[p] = a
+                break
+        if not inside:
+            best, mind = a, 1e30
+            for j in range(b.size):
+                if abs(b[j] - a) < mind:
+                    mind, best = abs(b[j] - a), b[j]
+            z[p] = best
+    u[:] = u + x - z
+    return z - u
+
+
 def run_inversion_gradient_damping(S, cw, dims, grid, ctype, d_obs, nmajor, nminor, alpha, beta, rmin=1e-13, pw=1.0, lsqr=None,
-                                   calc_data=None, norm_power=2.0):
+                                   calc_data=None, norm_power=2.0, admm=None):
     """Major loop with model damping + gradient damping: WAVELET_DOMAIN = false (joint_inverse_problem.F90:189-198), i.e. the
     unknowns are the spatial (depth-weighted) model update and nothing is transformed back after the solve (:559-571)."""
     N = int(np.prod(dims))
@@ -225,6 +246,13 @@ def run_inversion_gradient_damping(S, cw, dims, grid, ctype, d_obs, nmajor, nmin
             G, grhs = gradient_damping_rows(m, dims, grid, cw, pw, beta)
             blocks.append(G)
             rhs.append(grhs)
+        if admm is not None:                               # local bounds + local weight (joint_inverse_problem.F90:497-527)
+            if it == 0:
+                az, au = np.zeros(N), np.zeros(N)
+            x0 = admm_iterate_local(az, au, m, admm["bounds"])
+            lw = admm["weight"]
+            blocks.append(orc.diag_csr((admm["rho"] * pw * lw).astype(np.float32)))
+            rhs.append(-admm["rho"] * pw * ((m - x0) / cw) * lw)
         rp = [np.zeros(1, np.int64)]
         off = 0
         for b in blocks:

@@ -419,6 +419,24 @@ def test_lp_norm_damping_parfile_matches_reference(tmp_path, golden_dir):
     assert np.linalg.norm(model - ref) <= 1e-5 * np.linalg.norm(ref), np.linalg.norm(model - ref) / np.linalg.norm(ref)
 
 
+def test_admm_local_bounds_parfile_matches_reference(tmp_path, golden_dir):
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    g = np.load(os.path.join(golden_dir, "e2e_admm_local.npz"))
+    wd = str(tmp_path)
+    write_case_inputs(wd, g)
+    with open(os.path.join(wd, "bounds.txt"), "w") as f:
+        f.write("%d 2\n" % g["bounds"].shape[0])
+        for bnd, w in zip(g["bounds"], g["bound_weight"]):
+            f.write("%.17g %.17g %.17g %.17g %.17g\n" % (bnd[0], bnd[1], bnd[2], bnd[3], w))
+    open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(model - ref) <= 1e-5 * np.linalg.norm(ref), np.linalg.norm(model - ref) / np.linalg.norm(ref)
+
+
 def test_parfile_errors_like_the_reference(tmp_path):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")

@@ -922,6 +922,22 @@ def test_lp_norm_damping_end_to_end_vs_reference(ctx, golden_dir):
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-5)
 
 
+def test_admm_local_bounds_end_to_end_vs_reference(ctx, golden_dir):
+    """ADMM with per-cell intervals and weights (boundType 2): non-constant ADMM block, spatial unknowns."""
+    g = load(golden_dir, "e2e_admm_local")
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    N = int(np.prod(dims))
+    ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    cw = g["np1_column_weight"]
+    ctx.matrix_upload_csr(g["obs"].shape[0], N, g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+    m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, int(g["ctype"]), g["np1_data_observed"], int(g["nmajor"]),
+                                                     int(g["nminor"]), alpha=float(g["alpha"]),
+                                                     admm=dict(bounds=g["bounds"], weight=g["bound_weight"], rho=float(g["rho"])))
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(m - ref) <= 1e-6 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-5)
+
+
 def test_config1_mansf_end_to_end(ctx, golden_dir):
     """BASELINE config 1 (parfiles/Parfile_mansf_slice.txt: 2x128x32 cells, 256 obs, Haar 0.15, ADMM, 60 x 100 LSQR
     iterations) entirely on the HIP path vs the reference's final model."""

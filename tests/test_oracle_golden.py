@@ -365,3 +365,17 @@ def test_lp_norm_damping_end_to_end(golden_dir):
     ref = g["np1_model_final"]
     assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
+
+
+def test_admm_local_bounds_end_to_end(golden_dir):
+    """ADMM with per-cell lithology intervals and per-cell weights (boundType 2) vs the reference: four major iterations."""
+    g = load(golden_dir, "e2e_admm_local")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    S = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+    m, d, hist = oinv.run_inversion_gradient_damping(S, g["np1_column_weight"], dims, grid, int(g["ctype"]), g["np1_data_observed"],
+                                                     int(g["nmajor"]), int(g["nminor"]), float(g["alpha"]), 0.0,
+                                                     admm=dict(bounds=g["bounds"], weight=g["bound_weight"], rho=float(g["rho"])))
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)

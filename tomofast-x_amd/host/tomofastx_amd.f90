@@ -55,6 +55,7 @@ module tfx_host_params
     integer :: apply_local_dw = 0, apply_local_damp = 0, use_error(2) = 0, sensit_read = 0, nmodel_comp = 1, ndata_comp(2) = 1
     integer :: grav_data_type = 1
     character(len=256) :: sensit_path = 'SENSIT/'        ! src/parameters_init.f90:296-297
+    character(len=256) :: bounds_file(2) = 'NILL'        ! inversion.admm.{grav,magn}.boundsFile (boundType 2)
   end type t_par
 
 contains
@@ -163,6 +164,8 @@ contains
             read(val, *) par%bounds(:, 2)
           endif
         endif
+      case ('inversion.admm.grav.boundsFile');     par%bounds_file(1) = trim(val)
+      case ('inversion.admm.magn.boundsFile');     par%bounds_file(2) = trim(val)
       case ('inversion.admm.grav.weight');         read(val, *) par%rho(1)
       case ('inversion.admm.magn.weight');         read(val, *) par%rho(2)
       case ('inversion.admm.dataCostThreshold');   read(val, *) par%admm_cost_thr
@@ -243,6 +246,29 @@ contains
     enddo
     close(u)
   end subroutine read_data
+
+  ! local bound constraints for the ADMM: "nelements nlithos", then per cell min1 max1 ... minL maxL weight
+  ! (src/inversion/model_IO.F90:311-372)
+  subroutine read_bound_constraints(file, n, nlithos, bnd, w)
+    character(len=*), intent(in) :: file
+    integer, intent(in) :: n, nlithos
+    real(dp), intent(out) :: bnd(2 * nlithos, n), w(n)
+    integer :: u, ios, nread, lread, p, j
+    print *, 'Reading local bound constraints from file ', trim(file)
+    open(newunit=u, file=trim(file), status='old', action='read', iostat=ios)
+    if (ios /= 0) call stop_msg('Error in opening the bound constraints file! path='//trim(file))
+    read(u, *, iostat=ios) nread, lread
+    if (ios /= 0) call stop_msg('Problem while reading the bound constraints file!')
+    if (nread /= n .or. lread /= nlithos) call stop_msg('The constraints are not correctly defined!')
+    do p = 1, n
+      read(u, *, iostat=ios) bnd(:, p), w(p)
+      if (ios /= 0) call stop_msg('Problem with reading the bound constraints!')
+      do j = 1, nlithos
+        if (bnd(2 * j - 1, p) > bnd(2 * j, p)) call stop_msg('Wrong admm bounds: define bounds as: min1 max1 ... minN maxN.')
+      enddo
+    enddo
+    close(u)
+  end subroutine read_bound_constraints
 
   subroutine make_dir(path)
     character(len=*), intent(in) :: path
@@ -496,6 +522,7 @@ program tomofastx_amd
     real(dp), allocatable :: X1(:), X2(:), Y1(:), Y2(:), Z1(:), Z2(:), cw(:)
     real(dp), allocatable :: Xd(:), Yd(:), Zd(:), d_meas(:), d_calc(:)
     real(dp), allocatable :: m(:), m_prior(:), m_synth(:), z_admm(:), u_admm(:), x0(:)
+    real(dp), allocatable :: bnd(:, :), bnd_w(:)        ! ADMM intervals (2*nlithos, cell) and per-cell weight (model%bound_weight)
   end type t_prob
 
   type(t_par) :: par
@@ -561,9 +588,10 @@ program tomofastx_amd
   if (par%w_cross /= 0.d0) call stop_msg('Cross-gradient constraints are not supported by this host.')
   if (par%apply_local_dw /= 0 .or. par%apply_local_damp /= 0) call stop_msg('Local weights are not supported by this host yet.')
   if (par%norm_power /= 2.d0) spatial = .true.                   ! Lp damping acts in space (joint_inverse_problem.F90:189-198)
-  if (par%admm > 0 .and. par%admm_bound_type /= 1) call stop_msg('ADMM with local bounds (boundType 2) is not supported yet.')
+  if (par%admm > 0 .and. par%admm_bound_type /= 1 .and. par%admm_bound_type /= 2) call stop_msg('Unknown inversion.admm.boundType!')
+  if (par%admm > 0 .and. par%admm_bound_type == 2) spatial = .true.      ! local bounds / weights (joint_inverse_problem.F90:189-198)
   if (par%sensit_read < 0 .or. par%sensit_read > 2) call stop_msg('sensit.readFromFiles must be 0, 1 or 2.')
-  if (par%admm > 0 .and. .not. allocated(par%bounds)) call stop_msg('Global bounds are not defined!')
+  if (par%admm > 0 .and. par%admm_bound_type == 1 .and. .not. allocated(par%bounds)) call stop_msg('Global bounds are not defined!')
   n = par%nx * par%ny * par%nz
   if (n <= 0) call stop_msg('Wrong model grid size!')
 
@@ -604,6 +632,18 @@ program tomofastx_amd
     allocate(pr(ip)%Xd(pr(ip)%nd), pr(ip)%Yd(pr(ip)%nd), pr(ip)%Zd(pr(ip)%nd), pr(ip)%d_meas(pr(ip)%ndt), pr(ip)%d_calc(pr(ip)%ndt))
     allocate(pr(ip)%m(pr(ip)%nm), pr(ip)%m_prior(pr(ip)%nm), pr(ip)%m_synth(pr(ip)%nm))
     allocate(pr(ip)%z_admm(n), pr(ip)%u_admm(n), pr(ip)%x0(n))
+    if (par%admm > 0) then                                           ! set_model_bounds, src/inversion/model_IO.F90:273-305
+      allocate(pr(ip)%bnd(2 * par%nlithos, n), pr(ip)%bnd_w(n))
+      pr(ip)%bnd_w = 1.d0
+      if (par%admm_bound_type == 1) then
+        do i = 1, n
+          pr(ip)%bnd(:, i) = par%bounds(:, ip)
+        enddo
+      else
+        call read_bound_constraints(par%bounds_file(ip), n, par%nlithos, pr(ip)%bnd, pr(ip)%bnd_w)
+      endif
+      pr(ip)%bnd = pr(ip)%bnd * par%model_units_mult(ip)
+    endif
   enddo
   allocate(b_data(ndtot), x(ntot), xfull(ntot), rhs(ntot, 4), diag(ntot, 4), work(ntot))
   if (nprob == 2) print *, 'JOINT inversion: two sensitivity kernels in one system.'
@@ -795,16 +835,18 @@ program tomofastx_amd
       if (par%admm > 0) then                                       ! joint_inverse_problem.F90:497-527
         nblocks = nblocks + 1
         kadm = merge(1, 3, pr(ip)%nc == 1)                         ! vector model: bounds on Mz (:499-506)
-        call iterate_admm_arrays(n, par%nlithos, par%bounds(:, ip), pr(ip)%m((kadm - 1) * n + 1:kadm * n), pr(ip)%z_admm, &
+        call iterate_admm_arrays(n, par%nlithos, pr(ip)%bnd, pr(ip)%m((kadm - 1) * n + 1:kadm * n), pr(ip)%z_admm, &
                                  pr(ip)%u_admm, pr(ip)%x0)
         work(1:pr(ip)%nm) = 0.d0
         work((kadm - 1) * n + 1:kadm * n) = (pr(ip)%m((kadm - 1) * n + 1:kadm * n) - pr(ip)%x0) / pr(ip)%cw
         if (.not. spatial) call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
         diag(:, nblocks) = 0.0
-        diag(lc0 + (kadm - 1) * nloc + 1:lc0 + kadm * nloc, nblocks) = real(pr(ip)%rho * pr(ip)%pw, c_float)
+        diag(lc0 + (kadm - 1) * nloc + 1:lc0 + kadm * nloc, nblocks) = real(pr(ip)%rho * pr(ip)%pw * pr(ip)%bnd_w(cb + 1:ce), c_float)
         rhs(:, nblocks) = 0.d0
         call to_local(ip, work, rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks))
         rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = -pr(ip)%rho * pr(ip)%pw * rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks)
+        rhs(lc0 + (kadm - 1) * nloc + 1:lc0 + kadm * nloc, nblocks) = rhs(lc0 + (kadm - 1) * nloc + 1:lc0 + kadm * nloc, nblocks) * &
+                                                                      pr(ip)%bnd_w(cb + 1:ce)      ! local weight = local rho (damping.F90:177-180, :264-267)
         dptr(nblocks) = c_loc(diag(1, nblocks))
         rptr(nblocks) = c_loc(rhs(1, nblocks))
         s1 = sum((pr(ip)%z_admm - pr(ip)%m((kadm - 1) * n + 1:kadm * n))**2)
@@ -1217,15 +1259,17 @@ contains
   end function stop_file_exists
 
   ! admm_method_iterate_admm_arrays, src/inversion/admm_method.F90:70-134 (global bounds)
-  subroutine iterate_admm_arrays(nel, nlithos, bounds, xm, z, u, x0out)
+  subroutine iterate_admm_arrays(nel, nlithos, bounds_all, xm, z, u, x0out)
     integer, intent(in) :: nel, nlithos
-    real(dp), intent(in) :: bounds(2 * nlithos), xm(nel)
+    real(dp), intent(in) :: bounds_all(2 * nlithos, nel), xm(nel)
+    real(dp) :: bounds(2 * nlithos)
     real(dp), intent(inout) :: z(nel), u(nel)
     real(dp), intent(out) :: x0out(nel)
     integer :: p, j
     real(dp) :: a, mindist, v, closest
     logical :: inside
     do p = 1, nel
+      bounds = bounds_all(:, p)
       a = xm(p) + u(p)
       inside = .false.
       do j = 1, nlithos

@@ -23,13 +23,17 @@ class AdmmState:
         self.u = np.zeros(n)
 
     def iterate_admm_arrays(self, x, bounds):
-        """admm_method.F90:70-134 with global bounds [lo1 hi1 lo2 hi2 ...] (boundType 1)."""
+        """admm_method.F90:70-134.  bounds: [lo1 hi1 lo2 hi2 ...] for all cells (boundType 1) or an (N, 2 nlithos) array of
+        per-cell intervals (boundType 2, model_IO.F90:311-372)."""
         ends = np.asarray(bounds, np.float64)
-        lo, hi = ends[0::2], ends[1::2]
+        if ends.ndim == 1:
+            ends = ends[None, :]
+        lo, hi = ends[:, 0::2], ends[:, 1::2]
         arg = x + self.u
-        inside = ((lo[None, :] <= arg[:, None]) & (arg[:, None] <= hi[None, :])).any(1)
+        inside = ((lo <= arg[:, None]) & (arg[:, None] <= hi)).any(1)
         # closest boundary; np.argmin returns the first minimum = the strict '<' scan order xmin(1), xmax(1), xmin(2)...
-        closest = ends[np.argmin(np.abs(ends[None, :] - arg[:, None]), axis=1)]
+        ends_b = np.broadcast_to(ends, (arg.size, ends.shape[1]))
+        closest = np.take_along_axis(ends_b, np.argmin(np.abs(ends_b - arg[:, None]), axis=1)[:, None], 1)[:, 0]
         self.z = np.where(inside, arg, closest)
         self.u = self.u + x - self.z
         return self.z - self.u
@@ -92,7 +96,9 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
     # are the spatial depth-weighted update, S is applied through the per-iteration device transform, the damping block is not
     # transformed (damping.F90:135-150) and nothing is transformed back after the solve (joint_inverse_problem.F90:559-567)
     # ... and so does an Lp norm of the model damping (norm_power != 2: multiplier |m - m_prior|^(p/2 - 1), damping.F90:171-175)
-    spatial = beta != 0.0 or norm_power != 2.0
+    # ... and so do local ADMM bounds (admm["bounds"] per cell, optional admm["weight"] per cell = bound_weight)
+    admm_local = admm is not None and (np.ndim(admm["bounds"]) == 2 or admm.get("weight") is not None)
+    spatial = beta != 0.0 or norm_power != 2.0 or admm_local
     if spatial and (ncm != 1 or col_range is not None):
         raise NotImplementedError("gradient / Lp damping: one model component, single rank in this host")
     if col_range is None:
@@ -147,8 +153,9 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
         if admm is not None:                         # joint_inverse_problem.F90:497-527
             x0 = st.iterate_admm_arrays(m, admm["bounds"])
             md = loc(to_unknowns((m - x0) / cw))
-            diag.append(np.full(md.size, np.float32(admm["rho"] * pw), np.float32))
-            rhs.append(-admm["rho"] * pw * md)
+            lw = np.ones(md.size) if admm.get("weight") is None else loc(np.asarray(admm["weight"], np.float64))
+            diag.append((admm["rho"] * pw * lw).astype(np.float32))     # local weight = local rho (damping.F90:177-180, :264-267)
+            rhs.append(-admm["rho"] * pw * md * lw)
         if spatial:
             if beta != 0.0:
                 G, grhs = gradient_damping_rows(m, (nx, ny, nz), ctx.spacing, cw, pw, beta)
