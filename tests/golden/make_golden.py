@@ -855,6 +855,47 @@ def make_admm_local_e2e(tmp):
     print("e2e_admm_local.npz: lsqr r", res["np1_lsqr_r"], "self diff", np.linalg.norm(a - b) / np.linalg.norm(a))
 
 
+def make_err_e2e(tmp):
+    """Data errors (forward.data.grav.useError = 1): data_weight = 1 / error scales the kernel rows on reload
+    (sensitivity_gravmag.F90:834-843), the residuals (problem_joint_gravmag.F90:666-675) and the forward data (model.F90:301)."""
+    c = dict(nx=10, ny=9, nz=6, ox=4, oy=3, ctype=2, rate="0.2d0", nmajor=2, nminor=60, alpha="1.d-7", dwtype=1)
+    g, obs, mtrue = synthetic_problem(c["nx"], c["ny"], c["nz"], c["ox"], c["oy"])
+    nd = obs.shape[0]
+    rng = np.random.default_rng(91)
+    err = rng.uniform(0.5, 3.0, nd) * 1e-6
+    par = PAR_TMPL.format(nd=nd, **c) + "forward.data.grav.useError = 1\nforward.data.grav.errorFile = data_error.txt\n"
+    res = {}
+    for nproc in (1, 2):
+        wd = os.path.join(tmp, "err_np%d" % nproc)
+        shutil.rmtree(wd, ignore_errors=True)
+        os.makedirs(wd)
+        write_grid_file(os.path.join(wd, "grid.txt"), g, c["nx"], c["ny"], c["nz"])
+        with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+            f.write("%d\n" % nd)
+            for r in obs:
+                f.write("%.17g %.17g %.17g 0.0\n" % tuple(r))
+        with open(os.path.join(wd, "data_error.txt"), "w") as f:
+            f.write("%d\n" % nd)
+            for e in err:
+                f.write("%.17g\n" % e)
+        with open(os.path.join(wd, "model_true.txt"), "w") as f:
+            f.write("%d\n" % mtrue.size)
+            for v in mtrue:
+                f.write("%.17g\n" % v)
+        pf = os.path.join(wd, "Parfile.txt")
+        open(pf, "w").write(par)
+        log = run([MPIEXEC, "-n", str(nproc), os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+        o = collect_run(wd, log, "out", nproc)
+        for kk, vv in o.items():
+            res["np%d_%s" % (nproc, kk)] = vv
+    res.update(dict(nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=0.2, nmajor=c["nmajor"], nminor=c["nminor"],
+                    alpha=1e-7, data_error=err, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs,
+                    model_true=mtrue, parfile=par))
+    np.savez_compressed(os.path.join(HERE, "e2e_err.npz"), **res)
+    a, b = res["np1_model_final"], res["np2_model_final"]
+    print("e2e_err.npz: lsqr r", res["np1_lsqr_r"], "self diff", np.linalg.norm(a - b) / np.linalg.norm(a))
+
+
 def make_mansf(tmp):
     """BASELINE config 1.  Inputs are the reference's shipped example data (data/gravmag/mansf_slice)."""
     par = open(os.path.join(REFROOT, "parfiles", "Parfile_mansf_slice.txt")).read()

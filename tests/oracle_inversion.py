@@ -40,7 +40,7 @@ def calc_data_comp(model, cw, dims, ctype, S, pw, dw, ncm):
 
 
 def run_inversion(S, cw, dims, ctype, d_obs, nmajor, nminor, alpha=0.0, rmin=1e-13, pw=1.0, m0=None, m_prior=None,
-                  admm=None, lsqr=None, calc_data=None, ncm=1):
+                  admm=None, lsqr=None, calc_data=None, ncm=1, data_weight=None):
     """S = (rowptr, cols, vals) CSR.  admm = dict(bounds=..., rho=...) or None.
     lsqr / calc_data: replaceable callables (default: oracle) so that tests can run the SAME loop on the HIP path.
     ncm > 1: model vectors are component-major [k*N + cell] (the reference's model%val(:, k) flattened), the data vector is
@@ -60,7 +60,7 @@ def run_inversion(S, cw, dims, ctype, d_obs, nmajor, nminor, alpha=0.0, rmin=1e-
         worc = orc
     N = N1 * ncm
     nd = d_obs.size
-    dw = np.ones(nd)
+    dw = np.ones(nd) if data_weight is None else np.asarray(data_weight, np.float64)   # S must carry float32(pw * dw) per row
     m = np.zeros(N) if m0 is None else np.array(m0, np.float64)
     mp = np.zeros(N) if m_prior is None else np.asarray(m_prior, np.float64)
     lsqr = lsqr or (lambda blocks, b, niter: orc.lsqr(S, _blocks_csr(blocks, N), N, b, niter, rmin)[:3])

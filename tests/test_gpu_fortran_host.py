@@ -437,6 +437,32 @@ def test_admm_local_bounds_parfile_matches_reference(tmp_path, golden_dir):
     assert np.linalg.norm(model - ref) <= 1e-5 * np.linalg.norm(ref), np.linalg.norm(model - ref) / np.linalg.norm(ref)
 
 
+def test_data_errors_parfile_matches_reference(tmp_path, golden_dir):
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    g = np.load(os.path.join(golden_dir, "e2e_err.npz"))
+    wd = str(tmp_path)
+    write_case_inputs(wd, g)
+    with open(os.path.join(wd, "data_error.txt"), "w") as f:
+        f.write("%d\n" % g["data_error"].size)
+        f.write("\n".join("%.17g" % e for e in g["data_error"]) + "\n")
+    open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(model - ref) <= 1e-6 * np.linalg.norm(ref), np.linalg.norm(model - ref) / np.linalg.norm(ref)
+    # the SENSIT file holds the UNSCALED kernel, like the reference's
+    import importlib
+    sio = importlib.import_module("tomofast-x_amd").sensit_io
+    got = sio.read_sensit(os.path.join(wd, "out", "SENSIT"), 1)
+    same = np.intersect1d(got["cols"][:got["rowptr"][1]], g["np1_cols"][:g["np1_row_ptr"][1]]).size
+    assert same >= 0.99 * g["np1_row_ptr"][1]
+    r0 = slice(0, int(min(got["rowptr"][1], g["np1_row_ptr"][1])))
+    common, ia, ib = np.intersect1d(got["cols"][:got["rowptr"][1]], g["np1_cols"][:g["np1_row_ptr"][1]], return_indices=True)
+    assert np.allclose(got["vals"][ia], g["np1_vals"][ib], rtol=1e-6)
+
+
 def test_parfile_errors_like_the_reference(tmp_path):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")

@@ -938,6 +938,23 @@ def test_admm_local_bounds_end_to_end_vs_reference(ctx, golden_dir):
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-5)
 
 
+def test_data_errors_end_to_end_vs_reference(ctx, golden_dir):
+    """forward.data.grav.useError: data_weight = 1 / error goes into the kernel build (row scaling), the residuals and
+    calculate_data."""
+    g = load(golden_dir, "e2e_err")
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    cw = g["np1_column_weight"]
+    obs = g["obs"]
+    dw = 1.0 / g["data_error"]
+    ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, int(g["ctype"]), float(g["rate"]), data_weight=dw)
+    m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, int(g["ctype"]), g["np1_data_observed"], int(g["nmajor"]),
+                                                     int(g["nminor"]), alpha=float(g["alpha"]), data_weight=dw)
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(m - ref) <= 1e-6 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    assert np.allclose(d, g["np1_data_final"], rtol=1e-6, atol=1e-9 * np.abs(g["np1_data_final"]).max())
+
+
 def test_config1_mansf_end_to_end(ctx, golden_dir):
     """BASELINE config 1 (parfiles/Parfile_mansf_slice.txt: 2x128x32 cells, 256 obs, Haar 0.15, ADMM, 60 x 100 LSQR
     iterations) entirely on the HIP path vs the reference's final model."""

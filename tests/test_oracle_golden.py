@@ -379,3 +379,18 @@ def test_admm_local_bounds_end_to_end(golden_dir):
     ref = g["np1_model_final"]
     assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
+
+
+def test_data_errors_end_to_end(golden_dir):
+    """Data errors: data_weight = 1 / error in the kernel rows (as float32(pw * dw), :834-843), the residuals and calculate_data."""
+    g = load(golden_dir, "e2e_err")
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    dw = 1.0 / g["data_error"]
+    rp = g["np1_row_ptr"]
+    scale = np.repeat((1.0 * dw).astype(np.float32), np.diff(rp))
+    S = (rp, g["np1_cols"], (g["np1_vals"] * scale).astype(np.float32))
+    m, d, hist = oinv.run_inversion(S, g["np1_column_weight"], dims, int(g["ctype"]), g["np1_data_observed"], int(g["nmajor"]),
+                                    int(g["nminor"]), alpha=float(g["alpha"]), data_weight=dw)
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    assert np.allclose(d, g["np1_data_final"], rtol=1e-8, atol=1e-10 * np.abs(g["np1_data_final"]).max())

@@ -55,6 +55,7 @@ module tfx_host_params
     integer :: apply_local_dw = 0, apply_local_damp = 0, use_error(2) = 0, sensit_read = 0, nmodel_comp = 1, ndata_comp(2) = 1
     integer :: grav_data_type = 1
     character(len=256) :: sensit_path = 'SENSIT/'        ! src/parameters_init.f90:296-297
+    character(len=256) :: error_file(2) = 'NILL'         ! forward.data.{grav,magn}.errorFile (useError = 1)
     character(len=256) :: bounds_file(2) = 'NILL'        ! inversion.admm.{grav,magn}.boundsFile (boundType 2)
   end type t_par
 
@@ -106,6 +107,8 @@ contains
       case ('forward.data.grav.type');             read(val, *) par%grav_data_type
       case ('forward.data.grav.useError');         read(val, *) par%use_error(1)
       case ('forward.data.magn.useError');         read(val, *) par%use_error(2)
+      case ('forward.data.grav.errorFile');        par%error_file(1) = trim(val)
+      case ('forward.data.magn.errorFile');        par%error_file(2) = trim(val)
       case ('forward.data.grav.useSyntheticModelForDataValues'); read(val, *) par%use_synth(1)
       case ('forward.data.magn.useSyntheticModelForDataValues'); read(val, *) par%use_synth(2)
       case ('forward.data.grav.syntheticModelFile'); par%synth_file(1) = trim(val)
@@ -247,6 +250,27 @@ contains
     close(u)
   end subroutine read_data
 
+  ! data errors -> data weights 1 / (units_mult * error)  (src/forward/gravmag/data_gravmag.f90:243-279)
+  subroutine read_data_error(file, n, ncomp, units_mult, w)
+    character(len=*), intent(in) :: file
+    integer, intent(in) :: n, ncomp
+    real(dp), intent(in) :: units_mult
+    real(dp), intent(out) :: w(ncomp, n)
+    real(dp) :: e(ncomp)
+    integer :: u, ios, nfile, i
+    print *, 'Reading data error from file '//trim(file)
+    open(newunit=u, file=trim(file), status='old', action='read', iostat=ios)
+    if (ios /= 0) call stop_msg('Error in opening the data error file!')
+    read(u, *) nfile
+    if (nfile /= n) call stop_msg('The number of data in Parfile differs from the data file!')
+    do i = 1, n
+      read(u, *, iostat=ios) e
+      if (ios /= 0) call stop_msg('Problem while reading the data error file!')
+      w(:, i) = 1.d0 / (units_mult * e)
+    enddo
+    close(u)
+  end subroutine read_data_error
+
   ! local bound constraints for the ADMM: "nelements nlithos", then per cell min1 max1 ... minL maxL weight
   ! (src/inversion/model_IO.F90:311-372)
   subroutine read_bound_constraints(file, n, nlithos, bnd, w)
@@ -322,11 +346,11 @@ module tfx_host_sensit
 contains
 
   ! The device matrix back as CSR, cut into the (datum, data component, model component) lines of the reference's file.
-  subroutine write_sensit_files(ctx, folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, comp_error, pw, cw)
+  subroutine write_sensit_files(ctx, folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, comp_error, pw, cw, dw)
     type(c_ptr), intent(in) :: ctx
     character(len=*), intent(in) :: folder
     integer, intent(in) :: ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type
-    real(dp), intent(in) :: comp_error, pw, cw(:)
+    real(dp), intent(in) :: comp_error, pw, cw(:), dw(:)
     integer(c_int64_t) :: nrows, ncols, nnz, dbytes
     integer(c_int64_t), allocatable :: rowptr(:)
     integer(c_int32_t), allocatable :: cols(:), hist(:)
@@ -338,7 +362,9 @@ contains
     if (tfx_matrix_info(ctx, nrows, ncols, nnz, dbytes) /= 0) call stop_msg('tfx_matrix_info failed')
     allocate(rowptr(nrows + 1), cols(max(nnz, 1_c_int64_t)), vals(max(nnz, 1_c_int64_t)), hist(n))
     if (tfx_matrix_download_csr(ctx, rowptr, cols, vals) /= 0) call stop_msg('tfx_matrix_download_csr failed')
-    if (pw /= 1.d0) vals = vals / real(pw, c_float)          ! the file holds the unscaled kernel (:834-843 scales on reload)
+    do r = 1, int(nrows)                                      ! the file holds the unscaled kernel (:834-843 scales on reload)
+      if (pw * dw(r) /= 1.d0) vals(rowptr(r) + 1:rowptr(r + 1)) = vals(rowptr(r) + 1:rowptr(r + 1)) / real(pw * dw(r), c_float)
+    enddo
     call execute_command_line('mkdir -p "'//trim(folder)//'"')
     fname = trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_1_0'
     print *, 'Writing the sensitivity to file ', trim(fname)
@@ -415,11 +441,11 @@ contains
   end subroutine read_weight_file
 
   ! read_sensitivity_metadata + read_sensitivity_kernel (any number of rank files) -> CSR uploaded to the device
-  subroutine read_sensit_files(ctx, folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, pw, nnz_out, c0, c1)
+  subroutine read_sensit_files(ctx, folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, pw, nnz_out, c0, c1, dw)
     type(c_ptr), intent(in) :: ctx
     character(len=*), intent(in) :: folder
     integer, intent(in) :: ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type
-    real(dp), intent(in) :: pw
+    real(dp), intent(in) :: pw, dw(:)
     integer(c_int64_t), intent(out) :: nnz_out
     integer, intent(in) :: c0, c1            ! cells (c0, c1] stay on this rank (read_sensitivity_kernel scatters them, :795-830)
     integer :: u, ios, n, rank, nbproc_sensit, nloc
@@ -483,7 +509,7 @@ contains
                 if (cols(j) <= c0 .or. cols(j) > c1) cycle
                 jj = jj + 1
                 cols(jj) = cols(j) - c0 + (k - 1) * nloc                                                     ! :832
-                vals(jj) = vals(j) * real(pw, c_float)                                                       ! :835-843
+                vals(jj) = vals(j) * real(pw * dw(r), c_float)                                               ! :835-843
               enddo
               pos = jj
             endif
@@ -521,6 +547,7 @@ program tomofastx_amd
     real(dp) :: pw = 0.d0, rho = 0.d0, cost_data = 0.d0, cost_model = 0.d0, cost_admm = 0.d0, err_rows = 0.d0
     real(dp), allocatable :: X1(:), X2(:), Y1(:), Y2(:), Z1(:), Z2(:), cw(:)
     real(dp), allocatable :: Xd(:), Yd(:), Zd(:), d_meas(:), d_calc(:)
+    real(dp), allocatable :: dw(:)                      ! data weight (ndc, nd) = 1 / data error, or 1 (data_gravmag.f90:243-279)
     real(dp), allocatable :: m(:), m_prior(:), m_synth(:), z_admm(:), u_admm(:), x0(:)
     real(dp), allocatable :: bnd(:, :), bnd_w(:)        ! ADMM intervals (2*nlithos, cell) and per-cell weight (model%bound_weight)
   end type t_prob
@@ -603,7 +630,6 @@ program tomofastx_amd
     if (.not. pr(ip)%on) cycle
     if (par%w_clust(ip) /= 0.d0) call stop_msg('Clustering constraints are not supported by this host.')
     if (par%beta_grad(ip) /= 0.d0) spatial = .true.              ! WAVELET_DOMAIN = .false. (joint_inverse_problem.F90:189-198)
-    if (par%use_error(ip) /= 0) call stop_msg('Data errors are not supported by this host yet.')
     pr(ip)%slot = k
     k = k + 1
     pr(ip)%pw = par%pw(ip)
@@ -630,6 +656,8 @@ program tomofastx_amd
     ndtot = ndtot + pr(ip)%ndt
     allocate(pr(ip)%X1(n), pr(ip)%X2(n), pr(ip)%Y1(n), pr(ip)%Y2(n), pr(ip)%Z1(n), pr(ip)%Z2(n), pr(ip)%cw(n))
     allocate(pr(ip)%Xd(pr(ip)%nd), pr(ip)%Yd(pr(ip)%nd), pr(ip)%Zd(pr(ip)%nd), pr(ip)%d_meas(pr(ip)%ndt), pr(ip)%d_calc(pr(ip)%ndt))
+    allocate(pr(ip)%dw(pr(ip)%ndt))
+    pr(ip)%dw = 1.d0
     allocate(pr(ip)%m(pr(ip)%nm), pr(ip)%m_prior(pr(ip)%nm), pr(ip)%m_synth(pr(ip)%nm))
     allocate(pr(ip)%z_admm(n), pr(ip)%u_admm(n), pr(ip)%x0(n))
     if (par%admm > 0) then                                           ! set_model_bounds, src/inversion/model_IO.F90:273-305
@@ -720,7 +748,7 @@ program tomofastx_amd
     ! ---- (III) sensitivity kernel (:197-248): built on the device (this rank's column range), or re-loaded from SENSIT files
     if (par%sensit_read == 1) then
       call read_sensit_files(ctx, par%sensit_path, ip, par%nx, par%ny, par%nz, pr(ip)%nd, pr(ip)%ndc, pr(ip)%nc, par%dw_type, &
-                             par%comp_type, pr(ip)%pw, nnz, cb, ce)
+                             par%comp_type, pr(ip)%pw, nnz, cb, ce, pr(ip)%dw)
       err_sum = 0.d0
     else
       if (nbproc > 1 .and. exchange_ok(ip)) then
@@ -734,7 +762,8 @@ program tomofastx_amd
       call get_environment_variable('TFX_WRITE_SENSIT', envv, envlen, envstat)
       if (nbproc == 1 .and. .not. (envstat == 0 .and. envlen > 0 .and. envv(1:1) == '0')) &
         call write_sensit_files(ctx, trim(par%path_output)//'/SENSIT', ip, par%nx, par%ny, par%nz, pr(ip)%nd, pr(ip)%ndc, pr(ip)%nc, &
-                                par%dw_type, par%comp_type, err_sum / dble(pr(ip)%nd * pr(ip)%ndc * pr(ip)%nc), pr(ip)%pw, pr(ip)%cw)
+                                par%dw_type, par%comp_type, err_sum / dble(pr(ip)%nd * pr(ip)%ndc * pr(ip)%nc), pr(ip)%pw, pr(ip)%cw, &
+                                pr(ip)%dw)
     endif
     if (nbproc > 1) then                      ! totals over the column ranges (error sums are per line, the same on every rank)
       s1 = dble(nnz)
@@ -808,7 +837,7 @@ program tomofastx_amd
       lc0 = 0
       if (ip == 2 .and. pr(1)%on) lc0 = pr(1)%nml               ! this rank's unknowns: [m1 cells (cb, ce]; m2 cells (cb, ce]]
       ! residuals (:666-675; data weight 1) and the right-hand side pw * residuals (joint_inverse_problem.F90:379-387)
-      b_data(r0 + 1:r0 + pr(ip)%ndt) = pr(ip)%pw * (pr(ip)%d_meas - pr(ip)%d_calc)
+      b_data(r0 + 1:r0 + pr(ip)%ndt) = pr(ip)%pw * (pr(ip)%dw * (pr(ip)%d_meas - pr(ip)%d_calc))
       if (par%alpha(ip) /= 0.d0) then                              ! damping.F90:97-234, one block per problem and component
         nblocks = nblocks + 1
         work(1:pr(ip)%nm) = 0.d0
@@ -1006,6 +1035,7 @@ contains
     call read_model_grid(par%grid_file(jp), n, pr(jp)%X1, pr(jp)%X2, pr(jp)%Y1, pr(jp)%Y2, pr(jp)%Z1, pr(jp)%Z2)
     call read_data(par%data_grid_file(jp), pr(jp)%nd, pr(jp)%ndc, pr(jp)%Xd, pr(jp)%Yd, pr(jp)%Zd, pr(jp)%d_meas)
     pr(jp)%d_meas = pr(jp)%d_meas * par%data_units_mult(jp)
+    if (par%use_error(jp) == 1) call read_data_error(par%error_file(jp), pr(jp)%nd, pr(jp)%ndc, par%data_units_mult(jp), pr(jp)%dw)
     call tfx_check(tfx_set_grid(ctx, par%nx, par%ny, par%nz, pr(jp)%X1, pr(jp)%X2, pr(jp)%Y1, pr(jp)%Y2, pr(jp)%Z1, pr(jp)%Z2), &
                    'tfx_set_grid')
   end subroutine load_inputs
@@ -1045,8 +1075,8 @@ contains
     call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
     call tfx_check(tfx_build_kernel(ctx, jp, pr(jp)%dtype, pr(jp)%ndc, pr(jp)%nc, int(row_b - row_a, c_int64_t), &
                                     pr(jp)%Xd(row_a + 1:row_b), pr(jp)%Yd(row_a + 1:row_b), pr(jp)%Zd(row_a + 1:row_b), pr(jp)%cw, &
-                                    mptr, par%comp_type, par%comp_rate, pr(jp)%pw, c_null_ptr, int(col_a, c_int64_t), &
-                                    int(col_b, c_int64_t), nnz_k, err_k, hist_ptr), 'calculate_and_write_sensit')
+                                    mptr, par%comp_type, par%comp_rate, pr(jp)%pw, c_loc(pr(jp)%dw(row_a * pr(jp)%ndc + 1)), &
+                                    int(col_a, c_int64_t), int(col_b, c_int64_t), nnz_k, err_k, hist_ptr), 'calculate_and_write_sensit')
   end subroutine build_kernel
 
   ! The relayout-based build applies to single-component compressed kernels (row blocks of 2048 matrix rows = whole data);
@@ -1094,7 +1124,8 @@ contains
     call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
     call tfx_check(tfx_rowstore_build_ex(ctx, jp, pr(jp)%dtype, pr(jp)%ndc, int(row_b - row_a, c_int64_t), pr(jp)%Xd(row_a + 1:row_b), &
                                          pr(jp)%Yd(row_a + 1:row_b), pr(jp)%Zd(row_a + 1:row_b), pr(jp)%cw, mptr, par%comp_type, &
-                                         par%comp_rate, pr(jp)%pw, c_null_ptr, nnz_k, err_k, hist_ptr), 'calculate_and_write_sensit')
+                                         par%comp_rate, pr(jp)%pw, c_loc(pr(jp)%dw(row_a * pr(jp)%ndc + 1)), nnz_k, err_k, hist_ptr), &
+                   'calculate_and_write_sensit')
   end subroutine build_rowstore
 
   ! read_sensitivity_kernel's relayout (sensitivity_gravmag.F90:795-830) without the files: every row block is cut by column range
@@ -1238,7 +1269,7 @@ contains
     allocate(wl(max(1, pr(jp)%nml)))
     call to_local(jp, w, wl)
     call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
-    call tfx_check(tfx_calc_data(ctx, wl, pr(jp)%pw, c_null_ptr, dcalc), 'model_calculate_data')    ! all-reduced through the hook
+    call tfx_check(tfx_calc_data(ctx, wl, pr(jp)%pw, c_loc(pr(jp)%dw), dcalc), 'model_calculate_data')   ! all-reduced through the hook
     call tfx_check(tfx_select_problem(ctx, 0_c_int), 'tfx_select_problem')
   end subroutine calculate_data
 
