@@ -896,6 +896,54 @@ def make_err_e2e(tmp):
     print("e2e_err.npz: lsqr r", res["np1_lsqr_r"], "self diff", np.linalg.norm(a - b) / np.linalg.norm(a))
 
 
+def make_localw_e2e(tmp):
+    """Local depth weights (column_weight /= w, weights_gravmag.f90:255-309) and local model-damping weights (the damping block
+    and its right-hand side *= w, damping.F90:177-180, :264-267; forces WAVELET_DOMAIN = false)."""
+    c = dict(nx=8, ny=6, nz=5, ox=3, oy=3, ctype=1, rate="0.3d0", nmajor=2, nminor=400, alpha="1.d-6", dwtype=1)
+    g, obs, mtrue = synthetic_problem(c["nx"], c["ny"], c["nz"], c["ox"], c["oy"])
+    nd = obs.shape[0]
+    N = mtrue.size
+    rng = np.random.default_rng(55)
+    lw_depth = rng.uniform(0.5, 2.0, N)
+    lw_depth[7] = 0.0                                   # zero local weight -> zero column weight (:298-299)
+    lw_damp = rng.uniform(0.2, 3.0, N)
+    par = PAR_TMPL.format(nd=nd, **c) + ("forward.depthWeighting.applyLocalWeight = 1\nforward.depthWeighting.grav.file = lw_depth.txt\n"
+                                         "inversion.modelDamping.applyLocalWeight = 1\ninversion.modelDamping.grav.file = lw_damp.txt\n")
+    res = {}
+    # one rank only: the reference never closes unit 10 after the local-weight file (weights_gravmag.f90:268-309) and the
+    # flang runtime of this image mis-handles the re-open that follows on 2 ranks (see oracle/ref_build.sh, accommodation 2)
+    for nproc in (1,):
+        wd = os.path.join(tmp, "localw_np%d" % nproc)
+        shutil.rmtree(wd, ignore_errors=True)
+        os.makedirs(wd)
+        write_grid_file(os.path.join(wd, "grid.txt"), g, c["nx"], c["ny"], c["nz"])
+        with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+            f.write("%d\n" % nd)
+            for r in obs:
+                f.write("%.17g %.17g %.17g 0.0\n" % tuple(r))
+        with open(os.path.join(wd, "model_true.txt"), "w") as f:
+            f.write("%d\n" % N)
+            for v in mtrue:
+                f.write("%.17g\n" % v)
+        for name, arr in (("lw_depth.txt", lw_depth), ("lw_damp.txt", lw_damp)):
+            with open(os.path.join(wd, name), "w") as f:
+                f.write("%d\n" % N)
+                for v in arr:
+                    f.write("%.17g\n" % v)
+        pf = os.path.join(wd, "Parfile.txt")
+        open(pf, "w").write(par)
+        log = run([MPIEXEC, "-n", str(nproc), os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+        assert "WAVELET_DOMAIN = F" in log
+        o = collect_run(wd, log, "out", nproc)
+        for kk, vv in o.items():
+            res["np%d_%s" % (nproc, kk)] = vv
+    res.update(dict(nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=0.3, nmajor=c["nmajor"], nminor=c["nminor"],
+                    alpha=1e-6, lw_depth=lw_depth, lw_damp=lw_damp, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs,
+                    model_true=mtrue, parfile=par))
+    np.savez_compressed(os.path.join(HERE, "e2e_localw.npz"), **res)
+    print("e2e_localw.npz: lsqr r", res["np1_lsqr_r"])
+
+
 def make_mansf(tmp):
     """BASELINE config 1.  Inputs are the reference's shipped example data (data/gravmag/mansf_slice)."""
     par = open(os.path.join(REFROOT, "parfiles", "Parfile_mansf_slice.txt")).read()

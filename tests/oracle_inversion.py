@@ -222,7 +222,7 @@ def admm_iterate_local(z, u, x, bounds):
 
 
 def run_inversion_gradient_damping(S, cw, dims, grid, ctype, d_obs, nmajor, nminor, alpha, beta, rmin=1e-13, pw=1.0, lsqr=None,
-                                   calc_data=None, norm_power=2.0, admm=None):
+                                   calc_data=None, norm_power=2.0, admm=None, damping_weight=None):
     """Major loop with model damping + gradient damping: WAVELET_DOMAIN = false (joint_inverse_problem.F90:189-198), i.e. the
     unknowns are the spatial (depth-weighted) model update and nothing is transformed back after the solve (:559-571)."""
     N = int(np.prod(dims))
@@ -235,11 +235,13 @@ def run_inversion_gradient_damping(S, cw, dims, grid, ctype, d_obs, nmajor, nmin
         rhs = [pw * (d_obs - d)]
         blocks = []
         if alpha != 0.0:                                   # damping.F90:97-234 without the transform
-            md = m / cw
+            md = np.where(cw != 0.0, m / np.where(cw != 0.0, cw, 1.0), 0.0)     # damping.F90:129-135
             mult = np.ones(N)
             if norm_power != 2.0:                          # Lp norm multiplier, damping.F90:171-175, :250-262
                 nzm = md != 0.0
                 mult[nzm] = np.abs(md[nzm]) ** (norm_power / 2.0 - 1.0)
+            if damping_weight is not None:                 # local weight = local alpha (damping.F90:177-180, :264-267)
+                mult = mult * damping_weight
             blocks.append(orc.diag_csr((alpha * pw * mult).astype(np.float32)))
             rhs.append(-alpha * pw * md * mult)
         if beta != 0.0:

@@ -463,6 +463,24 @@ def test_data_errors_parfile_matches_reference(tmp_path, golden_dir):
     assert np.allclose(got["vals"][ia], g["np1_vals"][ib], rtol=1e-6)
 
 
+def test_local_weights_parfile_matches_reference(tmp_path, golden_dir):
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    g = np.load(os.path.join(golden_dir, "e2e_localw.npz"))
+    wd = str(tmp_path)
+    write_case_inputs(wd, g)
+    for name, key in (("lw_depth.txt", "lw_depth"), ("lw_damp.txt", "lw_damp")):
+        with open(os.path.join(wd, name), "w") as f:
+            f.write("%d\n" % g[key].size)
+            f.write("\n".join("%.17g" % v for v in g[key]) + "\n")
+    open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(model - ref) <= 1e-5 * np.linalg.norm(ref), np.linalg.norm(model - ref) / np.linalg.norm(ref)
+
+
 def test_parfile_errors_like_the_reference(tmp_path):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")

@@ -955,6 +955,25 @@ def test_data_errors_end_to_end_vs_reference(ctx, golden_dir):
     assert np.allclose(d, g["np1_data_final"], rtol=1e-6, atol=1e-9 * np.abs(g["np1_data_final"]).max())
 
 
+def test_local_weights_end_to_end_vs_reference(ctx, golden_dir):
+    """Local depth weights (a zero among them) and local model-damping weights: kernel, damping block, spatial unknowns."""
+    g = load(golden_dir, "e2e_localw")
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+    lw = g["lw_depth"]
+    cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+    cw = np.where(lw != 0.0, cw / np.where(lw != 0.0, lw, 1.0), 0.0)             # apply_local_depth_weighting
+    ref_cw = g["np1_column_weight"]
+    assert np.all(np.abs(cw - ref_cw) <= 1e-14 * np.abs(ref_cw)) and cw[7] == 0.0
+    obs = g["obs"]
+    ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, int(g["ctype"]), float(g["rate"]))
+    m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, int(g["ctype"]), g["np1_data_observed"], int(g["nmajor"]),
+                                                     int(g["nminor"]), alpha=float(g["alpha"]), damping_weight=g["lw_damp"])
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(m - ref) <= 1e-5 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    assert m[7] == 0.0
+
+
 def test_config1_mansf_end_to_end(ctx, golden_dir):
     """BASELINE config 1 (parfiles/Parfile_mansf_slice.txt: 2x128x32 cells, 256 obs, Haar 0.15, ADMM, 60 x 100 LSQR
     iterations) entirely on the HIP path vs the reference's final model."""

@@ -55,6 +55,8 @@ module tfx_host_params
     integer :: apply_local_dw = 0, apply_local_damp = 0, use_error(2) = 0, sensit_read = 0, nmodel_comp = 1, ndata_comp(2) = 1
     integer :: grav_data_type = 1
     character(len=256) :: sensit_path = 'SENSIT/'        ! src/parameters_init.f90:296-297
+    character(len=256) :: local_dw_file(2) = 'NILL'      ! forward.depthWeighting.{grav,magn}.file
+    character(len=256) :: local_damp_file(2) = 'NILL'    ! inversion.modelDamping.{grav,magn}.file
     character(len=256) :: error_file(2) = 'NILL'         ! forward.data.{grav,magn}.errorFile (useError = 1)
     character(len=256) :: bounds_file(2) = 'NILL'        ! inversion.admm.{grav,magn}.boundsFile (boundType 2)
   end type t_par
@@ -125,6 +127,10 @@ contains
       case ('forward.depthWeighting.grav.Z0');     read(val, *) par%dw_Z0(1)
       case ('forward.depthWeighting.magn.Z0');     read(val, *) par%dw_Z0(2)
       case ('forward.depthWeighting.applyLocalWeight'); read(val, *) par%apply_local_dw
+      case ('forward.depthWeighting.grav.file');   par%local_dw_file(1) = trim(val)
+      case ('forward.depthWeighting.magn.file');   par%local_dw_file(2) = trim(val)
+      case ('inversion.modelDamping.grav.file');   par%local_damp_file(1) = trim(val)
+      case ('inversion.modelDamping.magn.file');   par%local_damp_file(2) = trim(val)
       case ('sensit.readFromFiles');               read(val, *) par%sensit_read
       case ('sensit.folderPath');                  if (len_trim(val) > 0) par%sensit_path = trim(val)
       case ('forward.matrixCompression.type');     read(val, *) par%comp_type
@@ -249,6 +255,24 @@ contains
     enddo
     close(u)
   end subroutine read_data
+
+  ! one value per cell after a count line (local depth weights weights_gravmag.f90:268-309, damping weights model_IO.F90:425-476)
+  subroutine read_cell_values(file, n, w, what)
+    character(len=*), intent(in) :: file, what
+    integer, intent(in) :: n
+    real(dp), intent(out) :: w(n)
+    integer :: u, ios, nfile, p
+    print *, 'Reading '//what//' from file ', trim(file)
+    open(newunit=u, file=trim(file), status='old', action='read', iostat=ios)
+    if (ios /= 0) call stop_msg('Error in opening the '//what//' file! path='//trim(file))
+    read(u, *, iostat=ios) nfile
+    if (ios /= 0 .or. nfile /= n) call stop_msg('The '//what//' are not correctly defined!')
+    do p = 1, n
+      read(u, *, iostat=ios) w(p)
+      if (ios /= 0) call stop_msg('Problem with reading the local weight!')
+    enddo
+    close(u)
+  end subroutine read_cell_values
 
   ! data errors -> data weights 1 / (units_mult * error)  (src/forward/gravmag/data_gravmag.f90:243-279)
   subroutine read_data_error(file, n, ncomp, units_mult, w)
@@ -547,6 +571,7 @@ program tomofastx_amd
     real(dp) :: pw = 0.d0, rho = 0.d0, cost_data = 0.d0, cost_model = 0.d0, cost_admm = 0.d0, err_rows = 0.d0
     real(dp), allocatable :: X1(:), X2(:), Y1(:), Y2(:), Z1(:), Z2(:), cw(:)
     real(dp), allocatable :: Xd(:), Yd(:), Zd(:), d_meas(:), d_calc(:)
+    real(dp), allocatable :: damp_w(:)                  ! local model-damping weight per cell (model%damping_weight)
     real(dp), allocatable :: dw(:)                      ! data weight (ndc, nd) = 1 / data error, or 1 (data_gravmag.f90:243-279)
     real(dp), allocatable :: m(:), m_prior(:), m_synth(:), z_admm(:), u_admm(:), x0(:)
     real(dp), allocatable :: bnd(:, :), bnd_w(:)        ! ADMM intervals (2*nlithos, cell) and per-cell weight (model%bound_weight)
@@ -613,7 +638,7 @@ program tomofastx_amd
   if (nprob == 0) call stop_msg('Both problem weights are zero!')
   if (par%dw_type /= 1 .and. par%dw_type /= 2) call stop_msg('forward.depthWeighting.type must be 1 or 2 in this host.')
   if (par%w_cross /= 0.d0) call stop_msg('Cross-gradient constraints are not supported by this host.')
-  if (par%apply_local_dw /= 0 .or. par%apply_local_damp /= 0) call stop_msg('Local weights are not supported by this host yet.')
+  if (par%apply_local_damp > 0) spatial = .true.                 ! local damping weights act in space (:189-198)
   if (par%norm_power /= 2.d0) spatial = .true.                   ! Lp damping acts in space (joint_inverse_problem.F90:189-198)
   if (par%admm > 0 .and. par%admm_bound_type /= 1 .and. par%admm_bound_type /= 2) call stop_msg('Unknown inversion.admm.boundType!')
   if (par%admm > 0 .and. par%admm_bound_type == 2) spatial = .true.      ! local bounds / weights (joint_inverse_problem.F90:189-198)
@@ -659,7 +684,9 @@ program tomofastx_amd
     allocate(pr(ip)%dw(pr(ip)%ndt))
     pr(ip)%dw = 1.d0
     allocate(pr(ip)%m(pr(ip)%nm), pr(ip)%m_prior(pr(ip)%nm), pr(ip)%m_synth(pr(ip)%nm))
-    allocate(pr(ip)%z_admm(n), pr(ip)%u_admm(n), pr(ip)%x0(n))
+    allocate(pr(ip)%z_admm(n), pr(ip)%u_admm(n), pr(ip)%x0(n), pr(ip)%damp_w(n))
+    pr(ip)%damp_w = 1.d0
+    if (par%apply_local_damp > 0) call read_cell_values(par%local_damp_file(ip), n, pr(ip)%damp_w, 'model damping weights')
     if (par%admm > 0) then                                           ! set_model_bounds, src/inversion/model_IO.F90:273-305
       allocate(pr(ip)%bnd(2 * par%nlithos, n), pr(ip)%bnd_w(n))
       pr(ip)%bnd_w = 1.d0
@@ -842,22 +869,34 @@ program tomofastx_amd
         nblocks = nblocks + 1
         work(1:pr(ip)%nm) = 0.d0
         do k = 1, pr(ip)%nc                                        ! (joint_inverse_problem.F90:456-463)
-          work((k - 1) * n + 1:k * n) = (pr(ip)%m((k - 1) * n + 1:k * n) - pr(ip)%m_prior((k - 1) * n + 1:k * n)) / pr(ip)%cw
+          call unweight(ip, pr(ip)%m((k - 1) * n + 1:k * n) - pr(ip)%m_prior((k - 1) * n + 1:k * n), work((k - 1) * n + 1:k * n))
         enddo
         if (.not. spatial) call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)       ! damping.F90:135-150
         diag(:, nblocks) = 0.0
         diag(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = real(par%alpha(ip) * pr(ip)%pw, c_float)
         rhs(:, nblocks) = 0.d0
         call to_local(ip, work, rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks))
+        if (par%apply_local_damp > 0) then                           ! local weight = local alpha (damping.F90:177-180, :264-267)
+          do k = 1, pr(ip)%nc
+            do i = 1, nloc
+              diag(lc0 + (k - 1) * nloc + i, nblocks) = real(par%alpha(ip) * pr(ip)%pw * pr(ip)%damp_w(cb + i), c_float)
+            enddo
+          enddo
+        endif
         if (par%norm_power /= 2.d0) then                             ! Lp norm multiplier (damping.F90:171-175, :250-262)
           do i = lc0 + 1, lc0 + pr(ip)%nml
             s1 = 1.d0
             if (rhs(i, nblocks) /= 0.d0) s1 = (abs(rhs(i, nblocks)))**(par%norm_power / 2.d0 - 1.d0)
-            diag(i, nblocks) = real(par%alpha(ip) * pr(ip)%pw * s1, c_float)
+            diag(i, nblocks) = diag(i, nblocks) * real(s1, c_float)
             rhs(i, nblocks) = rhs(i, nblocks) * s1
           enddo
         endif
         rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = -par%alpha(ip) * pr(ip)%pw * rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks)
+        if (par%apply_local_damp > 0) then
+          do k = 1, pr(ip)%nc
+            rhs(lc0 + (k - 1) * nloc + 1:lc0 + k * nloc, nblocks) = rhs(lc0 + (k - 1) * nloc + 1:lc0 + k * nloc, nblocks) * pr(ip)%damp_w(cb + 1:ce)
+          enddo
+        endif
         dptr(nblocks) = c_loc(diag(1, nblocks))
         rptr(nblocks) = c_loc(rhs(1, nblocks))
       endif
@@ -867,7 +906,7 @@ program tomofastx_amd
         call iterate_admm_arrays(n, par%nlithos, pr(ip)%bnd, pr(ip)%m((kadm - 1) * n + 1:kadm * n), pr(ip)%z_admm, &
                                  pr(ip)%u_admm, pr(ip)%x0)
         work(1:pr(ip)%nm) = 0.d0
-        work((kadm - 1) * n + 1:kadm * n) = (pr(ip)%m((kadm - 1) * n + 1:kadm * n) - pr(ip)%x0) / pr(ip)%cw
+        call unweight(ip, pr(ip)%m((kadm - 1) * n + 1:kadm * n) - pr(ip)%x0, work((kadm - 1) * n + 1:kadm * n))
         if (.not. spatial) call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
         diag(:, nblocks) = 0.0
         diag(lc0 + (kadm - 1) * nloc + 1:lc0 + kadm * nloc, nblocks) = real(pr(ip)%rho * pr(ip)%pw * pr(ip)%bnd_w(cb + 1:ce), c_float)
@@ -1010,6 +1049,21 @@ contains
     g_nnz = e
   end subroutine build_gradient_damping
 
+  ! v / column_weight with the reference's zero guard (damping.F90:129-135)
+  subroutine unweight(jp, v, res)
+    integer, intent(in) :: jp
+    real(dp), intent(in) :: v(:)
+    real(dp), intent(out) :: res(:)
+    integer :: p
+    do p = 1, n
+      if (pr(jp)%cw(p) /= 0.d0) then
+        res(p) = v(p) / pr(jp)%cw(p)
+      else
+        res(p) = 0.d0
+      endif
+    enddo
+  end subroutine unweight
+
   ! this rank's cells (cb, ce] of every model component of a full vector
   subroutine to_local(jp, vfull, vloc)
     integer, intent(in) :: jp
@@ -1043,6 +1097,8 @@ contains
   ! (II) depth weight (:174-178, :189-193): computed, or read from the SENSIT folder
   subroutine depth_weight(jp)
     integer, intent(in) :: jp
+    real(dp), allocatable :: lw(:)
+    integer :: p
     if (par%sensit_read == 0) then
       print *, 'Calculating the depth weight, type = ', par%dw_type
       if (par%dw_type == 1) then
@@ -1050,6 +1106,18 @@ contains
       else
         call tfx_check(tfx_column_weight_type2(ctx, int(pr(jp)%nd, c_int64_t), pr(jp)%Xd, pr(jp)%Yd, pr(jp)%Zd, par%dw_power(jp), &
                                                par%dw_beta(jp), par%cwm(jp), pr(jp)%cw), 'calculate_depth_weight')
+      endif
+      if (par%apply_local_dw > 0) then                             ! apply_local_depth_weighting, weights_gravmag.f90:255-309
+        allocate(lw(n))
+        call read_cell_values(par%local_dw_file(jp), n, lw, 'local depth weights')
+        do p = 1, n
+          if (lw(p) /= 0.d0) then
+            pr(jp)%cw(p) = pr(jp)%cw(p) / lw(p)
+          else
+            pr(jp)%cw(p) = 0.d0
+          endif
+        enddo
+        deallocate(lw)
       endif
     else
       call read_weight_file(par%sensit_path, jp, n, pr(jp)%cw)

@@ -81,7 +81,7 @@ def gradient_damping_rows(m, dims, spacing, cw, pw, beta):
 def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor, nminor, alpha=0.0, rmin=1e-13,
                           problem_weight=1.0, data_weight=None, model_start=None, model_prior=None, admm=None,
                           gamma=0.0, target_misfit=0.0, log=None, nmodel_components=1, col_range=None, beta=0.0,
-                          norm_power=2.0):
+                          norm_power=2.0, damping_weight=None):
     """ctx: Context holding the sensitivity matrix S (already scaled by problem_weight * data_weight) over ALL columns.
     admm: dict(bounds=[...], rho=...) or None.  Returns (model, data_calc, history).
     One problem of either kind (the name is historical).  nmodel_components = 3 (magnetisation vector): model vectors are
@@ -98,7 +98,11 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
     # ... and so does an Lp norm of the model damping (norm_power != 2: multiplier |m - m_prior|^(p/2 - 1), damping.F90:171-175)
     # ... and so do local ADMM bounds (admm["bounds"] per cell, optional admm["weight"] per cell = bound_weight)
     admm_local = admm is not None and (np.ndim(admm["bounds"]) == 2 or admm.get("weight") is not None)
-    spatial = beta != 0.0 or norm_power != 2.0 or admm_local
+    # ... and local model-damping weights (damping_weight per cell: model%damping_weight, model_IO.F90:425-476)
+    spatial = beta != 0.0 or norm_power != 2.0 or admm_local or damping_weight is not None
+
+    def unweight(v):                                 # v / column_weight with the reference's zero guard (damping.F90:129-135)
+        return np.where(cw != 0.0, v / np.where(cw != 0.0, cw, 1.0), 0.0)
     if spatial and (ncm != 1 or col_range is not None):
         raise NotImplementedError("gradient / Lp damping: one model component, single rank in this host")
     if col_range is None:
@@ -132,7 +136,7 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
         return v if spatial else to_wavelet(v)
 
     def calculate_data(model):                       # model.F90:242-305
-        scaled = np.where(cw != 0.0, model / cw, 0.0)
+        scaled = np.where(cw != 0.0, model / np.where(cw != 0.0, cw, 1.0), 0.0)
         return ctx.calc_data(loc(to_wavelet(scaled)), pw, dw)
 
     d_calc = calculate_data(m)
@@ -143,8 +147,8 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
         b_data = pw * res                            # joint_inverse_problem.F90:379-387
         diag, rhs = [], []
         if alpha != 0.0:                             # damping.F90:97-234 (L2, no local weights)
-            md = loc(to_unknowns((m - mp) / cw))
-            mult = np.ones(md.size)
+            md = loc(to_unknowns(unweight(m - mp)))
+            mult = np.ones(md.size) if damping_weight is None else loc(np.asarray(damping_weight, np.float64)).copy()
             if norm_power != 2.0:                    # damping.F90:250-262
                 nzm = md != 0.0
                 mult[nzm] = np.abs(md[nzm]) ** (norm_power / 2.0 - 1.0)
@@ -152,7 +156,7 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
             rhs.append(-alpha * pw * md * mult)
         if admm is not None:                         # joint_inverse_problem.F90:497-527
             x0 = st.iterate_admm_arrays(m, admm["bounds"])
-            md = loc(to_unknowns((m - x0) / cw))
+            md = loc(to_unknowns(unweight(m - x0)))
             lw = np.ones(md.size) if admm.get("weight") is None else loc(np.asarray(admm["weight"], np.float64))
             diag.append((admm["rho"] * pw * lw).astype(np.float32))     # local weight = local rho (damping.F90:177-180, :264-267)
             rhs.append(-admm["rho"] * pw * md * lw)
