@@ -10,13 +10,14 @@
 ! What stays in Fortran is what the reference also does on the host: Parfile parsing, ASCII readers / writers in
 ! the reference's formats, the ADMM projection (src/inversion/admm_method.F90:70-134), residuals and costs.
 !
-! Supported Parfile subset: gravity (g_z, or gradiometry Gzz / full tensor with forward.data.grav.type = 2) or magnetic
-! (TMI or three-component data; susceptibility or magnetisation-vector model) single inversion, or both jointly in one LSQR
-! system (no structural coupling), depth weighting types 1 and 2, Haar / D4
-! compression or none, model damping (L2), ADMM with global bounds, prior / starting model by value or file, data from
-! file or from a synthetic model.  Keys of features whose constraint builders are out of scope (cross-gradient,
-! clustering, gradient damping, local weights) stop with a message when enabled, like the
-! reference stops on an unknown solver (joint_inverse_problem.F90:547-554); unknown keys only warn (:944-947).
+! Supported Parfile subset: gravity (g_z, or gradiometry Gzz / full tensor with forward.data.grav.type = 2), magnetic (TMI or
+! three-component data; susceptibility or magnetisation-vector model), or both jointly in one LSQR system; depth weighting
+! types 1 and 2 with optional local weights; data errors; Haar / D4 compression or none; SENSIT checkpoint (write, readFromFiles
+! 1 / 2); model damping (L2 or Lp, optional local weights); gradient damping; ADMM with global or per-cell bounds and weights
+! (dynamic weight); prior / starting model by value or file; data from file or from a synthetic model; 1..P ranks under mpiexec.
+! The solver switches to spatial unknowns (WAVELET_DOMAIN = F) by the reference's rule (joint_inverse_problem.F90:189-198).
+! Keys of the structural coupling constraints (cross-gradient, clustering) stop with a message when enabled, like the reference
+! stops on an unknown solver (:547-554); unknown keys only warn (parameters_init.f90:944-947).
 !=========================================================================================================
 module tfx_host_params
   implicit none
