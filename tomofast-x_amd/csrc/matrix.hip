@@ -488,9 +488,12 @@ struct ChunkRegs {
 __device__ __forceinline__ void load_chunk(const uint16_t *__restrict__ codes, const float *__restrict__ vals,
                                            int64_t base, ChunkRegs &c)
 {
-    const uint4 cw = *reinterpret_cast<const uint4 *>(codes + base);
-    const float4 a = *reinterpret_cast<const float4 *>(vals + base);
-    const float4 b = *reinterpret_cast<const float4 *>(vals + base + 4);
+    // the matrix is streamed exactly once per product: non-temporal loads keep it from displacing the x / u tiles in L2
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 cw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(codes + base));
+    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vals + base));
+    const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vals + base + 4));
     c.w[0] = cw.x; c.w[1] = cw.y; c.w[2] = cw.z; c.w[3] = cw.w;
     c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w;
     c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w;
