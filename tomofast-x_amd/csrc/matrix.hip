@@ -209,6 +209,7 @@ int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols)
 }
 
 // forward: workgroup = one column chunk, its x slice in LDS; a wave per row, partial[chunk][row] = dot over the chunk
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(DN_THREADS) void k_dense_fwd(const float *__restrict__ A, int64_t ld, int64_t nrows, int64_t ncols,
                                                            const double *__restrict__ x, double *__restrict__ partial)
 {
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dense_fwd(const float *__restric
         const float *row = A + r * ld + c0;
         double acc = 0.0;
         for (int i = lane * 4; i < nc4; i += 256) {
-            const float4 v = *reinterpret_cast<const float4 *>(row + i);
+            const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(row + i));      // streamed once per product
             acc = fma((double)v.x, xs[i], acc);
             acc = fma((double)v.y, xs[i + 1], acc);
             acc = fma((double)v.z, xs[i + 2], acc);
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dense_adj(const float *__restric
         const double ur = u[r];
         const float *p = A + r * ld + c0;
         if (full) {
-            const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+            const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p + 4));
             acc[0] = fma((double)a.x, ur, acc[0]); acc[1] = fma((double)a.y, ur, acc[1]);
             acc[2] = fma((double)a.z, ur, acc[2]); acc[3] = fma((double)a.w, ur, acc[3]);
             acc[4] = fma((double)b.x, ur, acc[4]); acc[5] = fma((double)b.y, ur, acc[5]);
