@@ -502,6 +502,24 @@ __device__ __forceinline__ void load_chunk(const uint16_t *__restrict__ codes, c
 
 __device__ __forceinline__ uint32_t code_of(const ChunkRegs &c, int k) { return (c.w[k >> 1] >> ((k & 1) * 16)) & 0xffffu; }
 
+// ---- segmented reduction helpers (DPP: data moves between lanes on the VALU, not through the LDS crossbar)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// sum += sum of the lane D positions up inside the same 16-lane row, when that lane ends on the same output row
+template <int D>
+__device__ __forceinline__ void seg_step(double &sum, int cur)
+{
+    constexpr int CTRL = 0x100 + D;                                           // row_shl:D  (lane i reads lane i + D of its row)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(sum), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(sum), CTRL, 0xf, 0xf, false);
+    const int oc = __builtin_amdgcn_update_dpp(-2, cur, CTRL, 0xf, 0xf, false);   // lanes without a source keep -2 (never a row)
+    if (oc == cur) sum += __hiloint2double(hi, lo);
+}
+
 // number of ROWSTART flags in all lanes below this one (all 8 entries of those lanes)
 __device__ __forceinline__ int flags_before_lane(const ChunkRegs &c, bool &any)
 {
@@ -558,16 +576,31 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_fwd(const WorkItem *__res
                 }
                 acc = fma((double)cr.v[k], xs[swz((int)(code & COLMASK))], acc);
             }
-            // merge the tails of lanes that end on the same row (equal rows are contiguous lanes)
+            // merge the tails of lanes that end on the same row (equal rows are contiguous lanes): the first lane of every run
+            // gets the run's total.  Inside a 16-lane DPP row: 4 shift-and-add steps on the VALU (row_shl, no LDS crossbar);
+            // across the four rows: the row heads are read as scalars and carried backwards.
             double sum = acc;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const double o = __shfl_down(sum, d);
-                const int ocur = __shfl_down(cur, d);
-                if (lane + d < 64 && ocur == cur) sum += o;
+            seg_step<1>(sum, cur);
+            seg_step<2>(sum, cur);
+            seg_step<4>(sum, cur);
+            seg_step<8>(sum, cur);
+            {
+                const int tc0 = __builtin_amdgcn_readlane(cur, 15), tc1 = __builtin_amdgcn_readlane(cur, 31),
+                          tc2 = __builtin_amdgcn_readlane(cur, 47);
+                const int hc1 = __builtin_amdgcn_readlane(cur, 16), hc2 = __builtin_amdgcn_readlane(cur, 32),
+                          hc3 = __builtin_amdgcn_readlane(cur, 48);
+                const double hs1 = readlane_f64(sum, 16), hs2 = readlane_f64(sum, 32), hs3 = readlane_f64(sum, 48);
+                // carry[r]: what the lanes of row r whose run reaches the end of the row still miss
+                const double carry2 = (hc3 == tc2) ? hs3 : 0.0;
+                const double carry1 = (hc2 == tc1) ? hs2 + ((hc2 == tc2) ? carry2 : 0.0) : 0.0;
+                const double carry0 = (hc1 == tc0) ? hs1 + ((hc1 == tc1) ? carry1 : 0.0) : 0.0;
+                const int row = lane >> 4;
+                const int tc = row == 0 ? tc0 : (row == 1 ? tc1 : (row == 2 ? tc2 : -2));
+                const double carry = row == 0 ? carry0 : (row == 1 ? carry1 : carry2);
+                if (cur == tc) sum += carry;
             }
-            const int pcur = __shfl_up(cur, 1);
-            if ((lane == 0 || pcur != cur) && cur >= 0 && sum != 0.0) atomicAdd(&outs[cur], sum);
+            const int pcur = __builtin_amdgcn_update_dpp(-3, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            if (pcur != cur && cur >= 0 && sum != 0.0) atomicAdd(&outs[cur], sum);
         }
     }
     __syncthreads();
