@@ -944,6 +944,72 @@ def make_localw_e2e(tmp):
     print("e2e_localw.npz: lsqr r", res["np1_lsqr_r"])
 
 
+def make_xgrad_e2e(tmp):
+    """Joint gravity + magnetic inversion WITH the cross-gradient constraint (structural coupling, cross_gradient.F90): 3 N rows
+    over both models' columns in the general constraint matrix, WAVELET_DOMAIN = false.  Forward (default) and central
+    difference schemes."""
+    # Few LSQR iterations per major iteration: the exactly consistent, under-determined synthetic data are fitted to 1e-9 by a
+    # converged first solve, after which the updates are rounding noise (the reference's 1- and 2-rank runs then differ by tens
+    # of percent); with 10 iterations every major iteration does real work and the two runs agree to 1e-12.
+    base = dict(nx=8, ny=7, nz=5, ctype=1, rate="0.3d0", nmajor=4, nminor=10, alpha_g="1.d-7", alpha_m="1.d-9", pwg="1.d0", pwm="1.d0")
+    g, obs_g, mtrue = synthetic_problem(base["nx"], base["ny"], base["nz"], 4, 3)
+    _, obs_m, _ = synthetic_problem(base["nx"], base["ny"], base["nz"], 3, 3)
+    obs_m = obs_m + np.array([11.0, -7.0, 0.0])
+    # different bodies for the two properties so that the gradients are not parallel everywhere
+    k, j, i = np.meshgrid(np.arange(base["nz"]), np.arange(base["ny"]), np.arange(base["nx"]), indexing="ij")
+    m_mag = np.where((k.ravel() >= 1) & (k.ravel() < 3) & (j.ravel() >= 1) & (j.ravel() < 4) & (i.ravel() >= 3) & (i.ravel() < 7), 0.03, 0.0)
+    mt = [mtrue, m_mag]
+    for name, der, wgt in (("e2e_xgrad", 1, "1.d-3"), ("e2e_xgrad_cnt", 2, "1.d-3")):
+        res = {}
+        for nproc in (1, 2):
+            wd = os.path.join(tmp, name + "_np%d" % nproc)
+            shutil.rmtree(wd, ignore_errors=True)
+            os.makedirs(wd)
+            write_grid_file(os.path.join(wd, "grid.txt"), g, base["nx"], base["ny"], base["nz"])
+            for tag, obs, m in (("grav", obs_g, mt[0]), ("magn", obs_m, mt[1])):
+                with open(os.path.join(wd, "data_grid_%s.txt" % tag), "w") as f:
+                    f.write("%d\n" % obs.shape[0])
+                    for r in obs:
+                        f.write("%.17g %.17g %.17g 0.0\n" % tuple(r))
+                with open(os.path.join(wd, "model_true_%s.txt" % tag), "w") as f:
+                    f.write("%d\n" % m.size)
+                    for v in m:
+                        f.write("%.17g\n" % v)
+            par = PAR_JOINT.format(ndg=obs_g.shape[0], ndm=obs_m.shape[0], **base) + (
+                "inversion.crossGradient.weight = %s\ninversion.crossGradient.derivativeType = %d\n" % (wgt, der))
+            pf = os.path.join(wd, "Parfile.txt")
+            open(pf, "w").write(par)
+            log = run([MPIEXEC, "-n", str(nproc), os.path.join(REFBIN, "tomofastx"), "-p", pf], cwd=wd)
+            assert "WAVELET_DOMAIN = F" in log
+            sd = os.path.join(wd, "out", "SENSIT")
+            o = {}
+            for tag, sfx in (("grav", "grav"), ("magn", "mag")):
+                if nproc == 1:
+                    hdr, rows = parse_sensit(os.path.join(sd, "sensit_%s_1_0" % tag))
+                    o["%s_row_ptr" % tag] = np.concatenate([[0], np.cumsum([r[1].size for r in rows])]).astype(np.int64)
+                    o["%s_cols" % tag] = np.concatenate([r[1] for r in rows])
+                    o["%s_vals" % tag] = np.concatenate([r[2] for r in rows])
+                    o["%s_column_weight" % tag] = np.frombuffer(open(os.path.join(sd, "sensit_%s_weight" % tag), "rb").read(), ">f8", offset=4).astype(np.float64)
+                    dd = os.path.join(wd, "out", "data")
+                    o["%s_data_observed" % tag] = read_tokens(os.path.join(dd, "%s_observed.txt" % sfx), 4)[:, 3]
+                    o["%s_data_final" % tag] = read_tokens(os.path.join(dd, "%s_final.txt" % sfx), 4)[:, 3]
+                o["%s_model_final" % tag] = read_tokens(os.path.join(wd, "out", "model", "%s_final_model_full.txt" % sfx), 1)[:, 0]
+            o["lsqr_r"] = np.array([float(m.group(1)) for m in re.finditer(r"Finished lsqr solver, r =\s*([0-9.eE+-]+)", log)])
+            o["xgrad_cost"] = np.array([[float(v) for v in m.groups()] for m in re.finditer(
+                r"cross-grad cost =\s*([0-9.eE+-]+)\s+([0-9.eE+-]+)\s+([0-9.eE+-]+)", log)])
+            for kk, vv in o.items():
+                res["np%d_%s" % (nproc, kk)] = vv
+        res.update(dict(nx=base["nx"], ny=base["ny"], nz=base["nz"], ctype=base["ctype"], rate=0.3, nmajor=base["nmajor"],
+                        nminor=base["nminor"], alpha=np.array([1e-7, 1e-9]), pw=np.array([1.0, 1.0]), xgrad_weight=float(wgt.replace("d", "e")),
+                        der_type=der, field=np.array([-62.0, 11.0, 0.0, 57000.0]), X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5],
+                        obs_grav=obs_g, obs_magn=obs_m, model_true_grav=mt[0], model_true_magn=mt[1], parfile=par))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+        for tag in ("grav", "magn"):
+            a, b = res["np1_%s_model_final" % tag], res["np2_%s_model_final" % tag]
+            print(name, tag, "self diff", np.linalg.norm(a - b) / np.linalg.norm(a))
+        print(name, "lsqr r", res["np1_lsqr_r"], "xgrad cost", res["np1_xgrad_cost"][:2])
+
+
 def make_mansf(tmp):
     """BASELINE config 1.  Inputs are the reference's shipped example data (data/gravmag/mansf_slice)."""
     par = open(os.path.join(REFROOT, "parfiles", "Parfile_mansf_slice.txt")).read()

@@ -266,3 +266,156 @@ def run_inversion_gradient_damping(S, cw, dims, grid, ctype, d_obs, nmajor, nmin
         d = calc_data(m)
         hist.append(dict(iters=iters, r=r))
     return m, d, hist
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cross-gradient constraint (structural coupling of two models), loop-by-loop restatement
+def _grad(f, dims, h, i, j, k, kind):
+    """get_grad (src/inversion/gradient.F90:68-86) with grad_get_par's zero outside the grid (:196-225); i, j, k 1-based."""
+    nx, ny, nz = dims
+
+    def par(a, b, c):
+        if a == 0 or b == 0 or c == 0 or a == nx + 1 or b == ny + 1 or c == nz + 1:
+            return 0.0
+        return f[((c - 1) * ny + (b - 1)) * nx + (a - 1)]
+    dx, dy, dz = h[0][i - 1], h[1][j - 1], h[2][k - 1]
+    if kind == "BWD":
+        return ((par(i, j, k) - par(i - 1, j, k)) / dx, (par(i, j, k) - par(i, j - 1, k)) / dy, (par(i, j, k) - par(i, j, k - 1)) / dz)
+    if kind == "FWD":
+        return ((par(i + 1, j, k) - par(i, j, k)) / dx, (par(i, j + 1, k) - par(i, j, k)) / dy, (par(i, j, k + 1) - par(i, j, k)) / dz)
+    return ((par(i + 1, j, k) - par(i - 1, j, k)) / 2.0 / dx, (par(i, j + 1, k) - par(i, j - 1, k)) / 2.0 / dy,
+            (par(i, j, k + 1) - par(i, j, k - 1)) / 2.0 / dz)
+
+
+def cross_gradient_rows(m1, m2, dims, grid, cw1, cw2, weight, der_type=1):
+    """cross_gradient_calculate (src/inversion/cross_gradient.F90:220-391) with calculate_tau (:457-577) and
+    calculate_tau_backward (:675-743): 3 rows per cell (x, y, z component of grad m1 x grad m2) over the columns of both models
+    (model 2 at + N), values dm * column_weight * weight cast to fp32, right-hand side -tau * weight.
+    Returns (rowptr, cols 1-based ascending, vals), rhs, cost[3]."""
+    nx, ny, nz = dims
+    N = nx * ny * nz
+    X1, X2, Y1, Y2, Z1, Z2 = grid
+    sh = (nz, ny, nx)
+    h = (np.abs(X2 - X1).reshape(sh)[0, 0, :], np.abs(Y2 - Y1).reshape(sh)[0, :, 0], np.abs(Z2 - Z1).reshape(sh)[:, 0, 0])
+
+    def ind(a, b, c):
+        return ((c - 1) * ny + (b - 1)) * nx + a            # 1-based cell index
+    rp, cols, vals, rhs = [0], [], [], []
+    cost = np.zeros(3)
+    for k in range(1, nz + 1):
+        for j in range(1, ny + 1):
+            for i in range(1, nx + 1):
+                left = i == 1 or j == 1 or k == 1
+                right = i == nx or j == ny or k == nz
+                rows = None
+                if left and right:
+                    tau = (0.0, 0.0, 0.0)
+                elif right or (der_type == 2 and left):
+                    backward = right
+                    kind = "BWD" if backward else "FWD"
+                    g1, g2 = _grad(m1, dims, h, i, j, k, kind), _grad(m2, dims, h, i, j, k, kind)
+                    sx, sy, sz = h[0][i - 1], h[1][j - 1], h[2][k - 1]
+                    if backward:                                  # :700-735
+                        rows = [
+                            [(ind(i, j - 1, k), -g2[2] / sy, g1[2] / sy), (ind(i, j, k - 1), g2[1] / sz, -g1[1] / sz),
+                             (ind(i, j, k), g2[2] / sy - g2[1] / sz, g1[1] / sz - g1[2] / sy)],
+                            [(ind(i - 1, j, k), g2[2] / sx, -g1[2] / sx), (ind(i, j, k - 1), -g2[0] / sz, g1[0] / sz),
+                             (ind(i, j, k), g2[0] / sz - g2[2] / sx, g1[2] / sx - g1[0] / sz)],
+                            [(ind(i - 1, j, k), -g2[1] / sx, g1[1] / sx), (ind(i, j - 1, k), g2[0] / sy, -g1[0] / sy),
+                             (ind(i, j, k), g2[1] / sx - g2[0] / sy, g1[0] / sy - g1[1] / sx)]]
+                    else:                                         # forward scheme on the left boundary of a central run
+                        rows = _tau_rows(g1, g2, (sx, sy, sz), i, j, k, ind, 1)
+                    tau = (g1[1] * g2[2] - g1[2] * g2[1], g1[2] * g2[0] - g1[0] * g2[2], g1[0] * g2[1] - g1[1] * g2[0])
+                else:
+                    kind = "FWD" if der_type == 1 else "CNT"
+                    g1, g2 = _grad(m1, dims, h, i, j, k, kind), _grad(m2, dims, h, i, j, k, kind)
+                    step = (h[0][i - 1], h[1][j - 1], h[2][k - 1])
+                    if der_type != 1:
+                        step = tuple(2.0 * v for v in step)
+                    rows = _tau_rows(g1, g2, step, i, j, k, ind, der_type)
+                    tau = (g1[1] * g2[2] - g1[2] * g2[1], g1[2] * g2[0] - g1[0] * g2[2], g1[0] * g2[1] - g1[1] * g2[0])
+                cost += np.array(tau) ** 2
+                for comp in range(3):
+                    entries = {}
+                    if rows is not None:
+                        for (cell, d1, d2) in rows[comp]:
+                            v1 = np.float32(d1 * cw1[cell - 1] * weight)
+                            v2 = np.float32(d2 * cw2[cell - 1] * weight)
+                            if v1 != 0:
+                                entries[cell] = v1
+                            if v2 != 0:
+                                entries[cell + N] = v2
+                    for c in sorted(entries):
+                        cols.append(c)
+                        vals.append(entries[c])
+                    rp.append(rp[-1] + len(entries))
+                    rhs.append(-tau[comp] * weight)
+    return (np.array(rp, np.int64), np.array(cols, np.int32), np.array(vals, np.float32)), np.array(rhs), cost
+
+
+def _tau_rows(g1, g2, step, i, j, k, ind, der_type):
+    """calculate_tau's derivative table (cross_gradient.F90:485-559): per component a list of (cell, d/dm1, d/dm2)."""
+    sx, sy, sz = step
+    x = [(ind(i, j + 1, k), g2[2] / sy, -g1[2] / sy), (ind(i, j, k + 1), -g2[1] / sz, g1[1] / sz)]
+    y = [(ind(i + 1, j, k), -g2[2] / sx, g1[2] / sx), (ind(i, j, k + 1), g2[0] / sz, -g1[0] / sz)]
+    z = [(ind(i + 1, j, k), g2[1] / sx, -g1[1] / sx), (ind(i, j + 1, k), -g2[0] / sy, g1[0] / sy)]
+    if der_type == 1:
+        x.append((ind(i, j, k), -(g2[2] / sy - g2[1] / sz), -(g1[1] / sz - g1[2] / sy)))
+        y.append((ind(i, j, k), -(g2[0] / sz - g2[2] / sx), -(g1[2] / sx - g1[0] / sz)))
+        z.append((ind(i, j, k), -(g2[1] / sx - g2[0] / sy), -(g1[0] / sy - g1[1] / sx)))
+    else:
+        x += [(ind(i, j - 1, k), -x[0][1], -x[0][2]), (ind(i, j, k - 1), -x[1][1], -x[1][2])]
+        y += [(ind(i - 1, j, k), -y[0][1], -y[0][2]), (ind(i, j, k - 1), -y[1][1], -y[1][2])]
+        z += [(ind(i - 1, j, k), -z[0][1], -z[0][2]), (ind(i, j - 1, k), -z[1][1], -z[1][2])]
+    return [x, y, z]
+
+
+def run_joint_inversion_xgrad(problems, dims, grid, ctype, nmajor, nminor, xgrad_weight, der_type=1, rmin=1e-13, lsqr=None,
+                              calc_data=None, rows_fn=None):
+    """Joint inversion with the cross-gradient constraint: WAVELET_DOMAIN = false, unknowns [x1; x2] spatial
+    (joint_inverse_problem.F90:189-198, :393-573)."""
+    N = int(np.prod(dims))
+    P = 2
+    rows_fn = rows_fn or cross_gradient_rows
+    m = [np.zeros(N), np.zeros(N)]
+    rp = [np.zeros(1, np.int64)]
+    cs, vs = [], []
+    off = 0
+    for i, pr in enumerate(problems):
+        r, c, v = pr["S"]
+        rp.append(np.asarray(r[1:], np.int64) + off)
+        off += int(r[-1])
+        cs.append(np.asarray(c, np.int64) + i * N)
+        vs.append(v)
+    Sj = (np.concatenate(rp), np.concatenate(cs).astype(np.int32), np.concatenate(vs))
+    lsqr = lsqr or (lambda Cm, b, niter: orc.lsqr(Sj, Cm, P * N, b, niter, rmin, spatial=(ctype, dims[0], dims[1], dims[2]) if ctype > 0 else None)[:3])
+    calc_data = calc_data or (lambda i, model: orc.calc_data(model, problems[i]["cw"], dims, ctype, problems[i]["S"], problems[i]["pw"],
+                                                             np.ones(problems[i]["d_obs"].size)))
+    d = [calc_data(i, m[i]) for i in range(P)]
+    hist = []
+    for it in range(nmajor):
+        rhs = [pr["pw"] * (pr["d_obs"] - d[i]) for i, pr in enumerate(problems)]
+        blocks = []
+        for i, pr in enumerate(problems):                  # damping, spatial (damping.F90:135-150)
+            if pr["alpha"] != 0.0:
+                blk = np.zeros(P * N, np.float32)
+                blk[i * N:(i + 1) * N] = np.float32(pr["alpha"] * pr["pw"])
+                blocks.append(orc.diag_csr(blk))
+                r = np.zeros(P * N)
+                r[i * N:(i + 1) * N] = -pr["alpha"] * pr["pw"] * (m[i] / pr["cw"])
+                rhs.append(r)
+        G, grhs, cost = rows_fn(m[0], m[1], dims, grid, problems[0]["cw"], problems[1]["cw"], xgrad_weight, der_type)
+        blocks.append(G)
+        rhs.append(grhs)
+        rpc = [np.zeros(1, np.int64)]
+        off = 0
+        for b in blocks:
+            rpc.append(b[0][1:] + off)
+            off += int(b[0][-1])
+        Cm = (np.concatenate(rpc), np.concatenate([b[1] for b in blocks]), np.concatenate([b[2] for b in blocks]))
+        x, iters, r = lsqr(Cm, np.concatenate(rhs), nminor)
+        for i, pr in enumerate(problems):
+            m[i] = m[i] + x[i * N:(i + 1) * N] * pr["cw"]
+            d[i] = calc_data(i, m[i])
+        hist.append(dict(iters=iters, r=r, xgrad_cost=cost))
+    return m, d, hist

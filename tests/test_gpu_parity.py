@@ -974,6 +974,47 @@ def test_local_weights_end_to_end_vs_reference(ctx, golden_dir):
     assert m[7] == 0.0
 
 
+@pytest.mark.parametrize("name", ["e2e_xgrad", "e2e_xgrad_cnt"])
+def test_joint_inversion_with_cross_gradient_vs_reference(ctx, golden_dir, name):
+    """Joint inversion with structural coupling: the host builds the cross-gradient rows over both models' columns
+    (tfx_cons_upload_csr), LSQR runs over blockdiag(S_grav, S_magn) with spatial unknowns (two components through the device
+    transform per iteration) - four major iterations vs the reference."""
+    g = load(golden_dir, name)
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    N = int(np.prod(dims))
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    ctx.set_grid(*dims, *grid)
+    # the vectorised builder against the oracle's loop-by-loop restatement
+    rng = np.random.default_rng(4)
+    t1, t2 = rng.standard_normal(N), rng.standard_normal(N)
+    cwg, cwm = g["np1_grav_column_weight"], g["np1_magn_column_weight"]
+    for der in (1, 2):
+        A, ra, ca = tfx.inversion.cross_gradient_rows(t1, t2, dims, ctx.spacing, cwg, cwm, 0.37, der)
+        B, rb, cb = oinv.cross_gradient_rows(t1, t2, dims, grid, cwg, cwm, 0.37, der)
+        assert np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and bits_equal(A[2], B[2]) and bits_equal(ra, rb)
+        assert np.allclose(ca, cb, rtol=1e-13)
+    probs = []
+    try:
+        for i, tag in enumerate(("grav", "magn")):
+            ctx.select_problem(i)
+            nd = g["obs_%s" % tag].shape[0]
+            ctx.matrix_upload_csr(nd, N, g["np1_%s_row_ptr" % tag], g["np1_%s_cols" % tag], g["np1_%s_vals" % tag])
+            probs.append(dict(column_weight=g["np1_%s_column_weight" % tag], data_obs=g["np1_%s_data_observed" % tag], problem_weight=1.0,
+                              alpha=float(g["alpha"][i])))
+        ctx.select_problem(0)
+        m, d, hist = tfx.inversion.solve_problem_joint(ctx, probs, int(g["ctype"]), int(g["nmajor"]), int(g["nminor"]),
+                                                       cross_gradient=dict(weight=float(g["xgrad_weight"]), der_type=int(g["der_type"])))
+        for i, tag in enumerate(("grav", "magn")):
+            ref = g["np1_%s_model_final" % tag]
+            assert np.linalg.norm(m[i] - ref) <= 1e-7 * np.linalg.norm(ref), (tag, np.linalg.norm(m[i] - ref) / np.linalg.norm(ref))
+        assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
+        assert np.allclose(np.array([h["xgrad_cost"] for h in hist])[2:], g["np1_xgrad_cost"][2:], rtol=1e-5)
+    finally:
+        ctx.select_problem(1)
+        ctx.matrix_free()
+        ctx.select_problem(0)
+
+
 def test_config1_mansf_end_to_end(ctx, golden_dir):
     """BASELINE config 1 (parfiles/Parfile_mansf_slice.txt: 2x128x32 cells, 256 obs, Haar 0.15, ADMM, 60 x 100 LSQR
     iterations) entirely on the HIP path vs the reference's final model."""

@@ -413,3 +413,25 @@ def test_local_weights_end_to_end(golden_dir):
     ref = g["np1_model_final"]
     assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["e2e_xgrad", "e2e_xgrad_cnt"])
+def test_joint_inversion_with_cross_gradient(golden_dir, name):
+    """Structural coupling: the cross-gradient rows over both models in the general constraint matrix, spatial unknowns; forward
+    and central schemes incl. their boundary rules - four major iterations vs the reference (final models, LSQR residuals and
+    the cross-gradient cost it prints every iteration)."""
+    g = load(golden_dir, name)
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    probs = []
+    for i, tag in enumerate(("grav", "magn")):
+        probs.append(dict(S=(g["np1_%s_row_ptr" % tag], g["np1_%s_cols" % tag], g["np1_%s_vals" % tag]), cw=g["np1_%s_column_weight" % tag],
+                          d_obs=g["np1_%s_data_observed" % tag], pw=1.0, alpha=float(g["alpha"][i])))
+    m, d, hist = oinv.run_joint_inversion_xgrad(probs, dims, grid, int(g["ctype"]), int(g["nmajor"]), int(g["nminor"]),
+                                                float(g["xgrad_weight"]), int(g["der_type"]))
+    for i, tag in enumerate(("grav", "magn")):
+        ref = g["np1_%s_model_final" % tag]
+        assert np.linalg.norm(m[i] - ref) <= 1e-9 * np.linalg.norm(ref), (tag, np.linalg.norm(m[i] - ref) / np.linalg.norm(ref))
+    assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-7)
+    costs = np.array([h["xgrad_cost"] for h in hist])
+    assert np.allclose(costs[2:], g["np1_xgrad_cost"][2:], rtol=1e-6)

@@ -78,6 +78,92 @@ def gradient_damping_rows(m, dims, spacing, cw, pw, beta):
     return (rowptr, np.concatenate(cs), np.concatenate(vs)), np.concatenate(rh)
 
 
+def cross_gradient_rows(m1, m2, dims, spacing, cw1, cw2, weight, der_type=1):
+    """The cross-gradient constraint tau = grad m1 x grad m2 = 0 of a joint inversion (src/inversion/cross_gradient.F90:220-391;
+    derivative tables :457-577 forward / central, :675-743 backward; boundary rules :255-285; gradients gradient.F90:68-86 with
+    zeros outside the grid): 3 rows per cell over the columns of both models (model 2 at + N), values
+    d tau / d m * column_weight * weight cast to fp32, right-hand side -tau * weight.
+    Returns (rowptr, cols 1-based ascending, vals), rhs, cost[3] - what Context.cons_upload_csr takes."""
+    nx, ny, nz = dims
+    N = nx * ny * nz
+    sh = (nz, ny, nx)
+    hx = np.broadcast_to(np.asarray(spacing[0], np.float64)[None, None, :], sh)
+    hy = np.broadcast_to(np.asarray(spacing[1], np.float64)[None, :, None], sh)
+    hz = np.broadcast_to(np.asarray(spacing[2], np.float64)[:, None, None], sh)
+    idx = np.arange(N, dtype=np.int64).reshape(sh)
+    kk, jj, ii = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    left = (ii == 0) | (jj == 0) | (kk == 0)
+    right = (ii == nx - 1) | (jj == ny - 1) | (kk == nz - 1)
+
+    def grads(f):
+        P = np.pad(np.asarray(f, np.float64).reshape(sh), 1)
+        c = P[1:-1, 1:-1, 1:-1]
+        xp, xm = P[1:-1, 1:-1, 2:], P[1:-1, 1:-1, :-2]
+        yp, ym = P[1:-1, 2:, 1:-1], P[1:-1, :-2, 1:-1]
+        zp, zm = P[2:, 1:-1, 1:-1], P[:-2, 1:-1, 1:-1]
+        return dict(F=((xp - c) / hx, (yp - c) / hy, (zp - c) / hz), B=((c - xm) / hx, (c - ym) / hy, (c - zm) / hz),
+                    C=((xp - xm) / 2.0 / hx, (yp - ym) / 2.0 / hy, (zp - zm) / 2.0 / hz))
+    G1, G2 = grads(m1), grads(m2)
+    modes = []                                              # (mask, scheme, gradient kind, step multiplier)
+    if der_type == 1:
+        modes.append((~right, "fwd", "F", 1.0))
+        modes.append((right & ~left, "bwd", "B", 1.0))
+    else:
+        modes.append((~right & ~left, "cnt", "C", 2.0))
+        modes.append((left & ~right, "fwd", "F", 1.0))
+        modes.append((right & ~left, "bwd", "B", 1.0))
+    rows_l, cols_l, vals_l = [], [], []
+    tau = np.zeros((3,) + sh)
+    nbr = {"x+": (0, 0, 1), "x-": (0, 0, -1), "y+": (0, 1, 0), "y-": (0, -1, 0), "z+": (1, 0, 0), "z-": (-1, 0, 0), "0": (0, 0, 0)}
+    for mask, scheme, kind, mult in modes:
+        if not mask.any():
+            continue
+        g1, g2 = G1[kind], G2[kind]
+        sx, sy, sz = mult * hx, mult * hy, mult * hz
+        t = (g1[1] * g2[2] - g1[2] * g2[1], g1[2] * g2[0] - g1[0] * g2[2], g1[0] * g2[1] - g1[1] * g2[0])
+        for comp in range(3):
+            tau[comp][mask] = t[comp][mask]
+        if scheme == "bwd":                                 # :700-735
+            table = [
+                [("y-", -g2[2] / sy, g1[2] / sy), ("z-", g2[1] / sz, -g1[1] / sz), ("0", g2[2] / sy - g2[1] / sz, g1[1] / sz - g1[2] / sy)],
+                [("x-", g2[2] / sx, -g1[2] / sx), ("z-", -g2[0] / sz, g1[0] / sz), ("0", g2[0] / sz - g2[2] / sx, g1[2] / sx - g1[0] / sz)],
+                [("x-", -g2[1] / sx, g1[1] / sx), ("y-", g2[0] / sy, -g1[0] / sy), ("0", g2[1] / sx - g2[0] / sy, g1[0] / sy - g1[1] / sx)]]
+        else:                                               # :485-559
+            tx = [("y+", g2[2] / sy, -g1[2] / sy), ("z+", -g2[1] / sz, g1[1] / sz)]
+            ty = [("x+", -g2[2] / sx, g1[2] / sx), ("z+", g2[0] / sz, -g1[0] / sz)]
+            tz = [("x+", g2[1] / sx, -g1[1] / sx), ("y+", -g2[0] / sy, g1[0] / sy)]
+            if scheme == "fwd":
+                tx.append(("0", -(g2[2] / sy - g2[1] / sz), -(g1[1] / sz - g1[2] / sy)))
+                ty.append(("0", -(g2[0] / sz - g2[2] / sx), -(g1[2] / sx - g1[0] / sz)))
+                tz.append(("0", -(g2[1] / sx - g2[0] / sy), -(g1[0] / sy - g1[1] / sx)))
+            else:
+                tx += [("y-", -tx[0][1], -tx[0][2]), ("z-", -tx[1][1], -tx[1][2])]
+                ty += [("x-", -ty[0][1], -ty[0][2]), ("z-", -ty[1][1], -ty[1][2])]
+                tz += [("x-", -tz[0][1], -tz[0][2]), ("y-", -tz[1][1], -tz[1][2])]
+            table = [tx, ty, tz]
+        p = idx[mask]
+        for comp in range(3):
+            for where, d1, d2 in table[comp]:
+                dk, dj, di = nbr[where]
+                cell = p + (dk * ny + dj) * nx + di
+                for off, dm, cw in ((0, d1, cw1), (N, d2, cw2)):
+                    v = (dm[mask] * cw[cell] * weight).astype(np.float32)
+                    keep = v != 0
+                    rows_l.append((3 * p + comp)[keep])
+                    cols_l.append((cell + off + 1)[keep])
+                    vals_l.append(v[keep])
+    rows = np.concatenate(rows_l) if rows_l else np.zeros(0, np.int64)
+    cols = np.concatenate(cols_l) if cols_l else np.zeros(0, np.int64)
+    vals = np.concatenate(vals_l) if vals_l else np.zeros(0, np.float32)
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=3 * N))]).astype(np.int64)
+    tflat = np.stack([tau[0].ravel(), tau[1].ravel(), tau[2].ravel()], 1)       # (cell, component)
+    rhs = (-tflat * weight).ravel()
+    cost = (tflat ** 2).sum(0)
+    return (rowptr, cols.astype(np.int32), vals), rhs, cost
+
+
 def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor, nminor, alpha=0.0, rmin=1e-13,
                           problem_weight=1.0, data_weight=None, model_start=None, model_prior=None, admm=None,
                           gamma=0.0, target_misfit=0.0, log=None, nmodel_components=1, col_range=None, beta=0.0,
@@ -182,14 +268,17 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
     return m, d_calc, hist
 
 
-def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e-13, gamma=0.0, target_misfit=0.0, log=None):
+def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e-13, gamma=0.0, target_misfit=0.0, log=None,
+                        cross_gradient=None):
     """Joint inversion of two problems on one grid (gravity + magnetic) without structural coupling: both sensitivity
     kernels in ONE LSQR system, S = blockdiag(slot 0, slot 1) (src/inversion/joint_inverse_problem.F90:393-573; block layout
     :712-739, right-hand side :379-387, one damping block per problem :448-463).  Coupling constraints built on the host
     (cross-gradient, clustering) enter through ctx.cons_upload_csr over both column blocks.
 
     problems: two dicts(column_weight, data_obs, problem_weight, alpha[, model_start, model_prior]); slot i of ctx holds
-    problem i's kernel, built with its problem_weight.  Returns (models, data_calc, history)."""
+    problem i's kernel, built with its problem_weight.  cross_gradient = dict(weight, der_type 1 | 2): the structural
+    coupling constraint, which switches the solver to spatial unknowns (WAVELET_DOMAIN = false, :189-198).
+    Returns (models, data_calc, history)."""
     nx, ny, nz = ctx.dims
     N = nx * ny * nz
     P = len(problems)
@@ -202,6 +291,8 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
 
     def to_wavelet(v):
         return ctx.forward_wavelet(v, nx, ny, nz, compression_type) if compression_type > 0 else v
+
+    spatial = cross_gradient is not None
 
     def calculate_data(i):                            # model.F90:242-305 on problem i's rows / columns
         ctx.select_problem(i)
@@ -217,21 +308,34 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
         diag, rhs = [], []
         for i, p in enumerate(problems):
             if p.get("alpha", 0.0) != 0.0:            # damping block of problem i: its column block only (:448-463)
-                md = to_wavelet((m[i] - mp[i]) / cw[i])
+                md = (m[i] - mp[i]) / cw[i]
+                if not spatial:
+                    md = to_wavelet(md)
                 blk = np.zeros(P * N, np.float32)
                 blk[i * N:(i + 1) * N] = np.float32(p["alpha"] * pw[i])
                 r = np.zeros(P * N)
                 r[i * N:(i + 1) * N] = -p["alpha"] * pw[i] * md
                 diag.append(blk)
                 rhs.append(r)
-        x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
+        xcost = None
+        if spatial:
+            G, grhs, xcost = cross_gradient_rows(m[0], m[1], (nx, ny, nz), ctx.spacing, cw[0], cw[1], float(cross_gradient["weight"]),
+                                                 int(cross_gradient.get("der_type", 1)))
+            ctx.cons_upload_csr(G[0], G[1], G[2], grhs)
+            ctx.lsqr_set_wavelet_domain(False, compression_type)
+        try:
+            x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
+        finally:
+            if spatial:
+                ctx.lsqr_set_wavelet_domain(True)
+                ctx.cons_clear()
         for i in range(P):
             xi = x[i * N:(i + 1) * N]
-            dm = ctx.inverse_wavelet(xi, nx, ny, nz, compression_type) if compression_type > 0 else xi
+            dm = ctx.inverse_wavelet(xi, nx, ny, nz, compression_type) if (compression_type > 0 and not spatial) else xi
             m[i] = m[i] + dm * cw[i]                  # joint_inverse_problem.F90:559-571
             d[i] = calculate_data(i)
         costs = [float(np.linalg.norm(d[i] - problems[i]["data_obs"]) / np.linalg.norm(problems[i]["data_obs"])) for i in range(P)]
-        hist.append(dict(it=it, iters=iters, r=r, costs=costs))
+        hist.append(dict(it=it, iters=iters, r=r, costs=costs, xgrad_cost=xcost))
         if log:
             log("it %d: lsqr iters %d r %.6e data costs %s" % (it, iters, r, costs))
     return m, d, hist
