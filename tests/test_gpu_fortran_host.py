@@ -224,12 +224,7 @@ def test_sensit_files_written_like_the_reference_and_reloaded(tmp_path, golden_d
     assert np.linalg.norm(model - refm) <= tol * np.linalg.norm(refm), (np.linalg.norm(model - refm) / np.linalg.norm(refm), self_diff)
 
 
-def test_joint_parfile_matches_reference_outputs(tmp_path, golden_dir):
-    """Joint gravity + magnetic inversion from the Parfile (both problem weights non-zero): two kernels, one LSQR system."""
-    if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, "e2e_joint.npz"))
-    wd = str(tmp_path)
+def write_joint_inputs(wd, g):
     n = g["X1"].size
     nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
     k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
@@ -247,6 +242,15 @@ def test_joint_parfile_matches_reference_outputs(tmp_path, golden_dir):
             f.write("%d\n" % n)
             f.write("\n".join("%.17g" % v for v in g["model_true_" + tag]) + "\n")
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
+
+
+def test_joint_parfile_matches_reference_outputs(tmp_path, golden_dir):
+    """Joint gravity + magnetic inversion from the Parfile (both problem weights non-zero): two kernels, one LSQR system."""
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    g = np.load(os.path.join(golden_dir, "e2e_joint.npz"))
+    wd = str(tmp_path)
+    write_joint_inputs(wd, g)
     out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "THE END." in out.stdout and "JOINT inversion" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     for tag, sfx in (("grav", "grav"), ("magn", "mag")):
@@ -259,6 +263,27 @@ def test_joint_parfile_matches_reference_outputs(tmp_path, golden_dir):
         assert np.linalg.norm(dfin - g["np1_%s_data_final" % tag]) <= 10 * tol * np.linalg.norm(g["np1_%s_data_final" % tag])
     costs = [l.split() for l in open(os.path.join(wd, "out", "costs.txt")) if l.strip() and not l.lstrip().startswith("#")]
     assert len(costs) == int(g["nmajor"]) + 1 and len(costs[-1]) == 9            # iteration + 4 columns per problem
+
+
+@pytest.mark.parametrize("name", ["e2e_xgrad", "e2e_xgrad_cnt"])
+def test_cross_gradient_parfile_matches_reference(tmp_path, golden_dir, name):
+    """inversion.crossGradient.weight /= 0 on a joint run: the host builds the 3 N coupling rows over both models' columns
+    (forward or central differences), uploads them as the general constraint matrix, WAVELET_DOMAIN = F."""
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    wd = str(tmp_path)
+    write_joint_inputs(wd, g)
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    for tag, sfx in (("grav", "grav"), ("magn", "mag")):
+        model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)[:, 0]
+        ref = g["np1_%s_model_final" % tag]
+        assert np.linalg.norm(model - ref) <= 1e-6 * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
+    rs = [float(t.split()[0]) for t in out.stdout.split("Finished lsqr solver, r =")[1:]]
+    assert np.allclose(rs, g["np1_lsqr_r"], rtol=1e-5)
+    xc = np.array([[float(v) for v in t.split()[:3]] for t in out.stdout.split("cross-grad cost =")[1:]])
+    assert np.allclose(xc[2:], g["np1_xgrad_cost"][2:], rtol=1e-4)
 
 
 MPIEXEC = "/opt/conda/bin/mpiexec"

@@ -16,8 +16,9 @@
 ! 1 / 2); model damping (L2 or Lp, optional local weights); gradient damping; ADMM with global or per-cell bounds and weights
 ! (dynamic weight); prior / starting model by value or file; data from file or from a synthetic model; 1..P ranks under mpiexec.
 ! The solver switches to spatial unknowns (WAVELET_DOMAIN = F) by the reference's rule (joint_inverse_problem.F90:189-198).
-! Keys of the structural coupling constraints (cross-gradient, clustering) stop with a message when enabled, like the reference
-! stops on an unknown solver (:547-554); unknown keys only warn (parameters_init.f90:944-947).
+! Joint runs may add the cross-gradient coupling constraint (forward or central differences, keepModelConstant); its rows are built
+! on the host and uploaded as the general constraint matrix like the reference's matrix_cons.  The clustering constraint and the
+! cross-gradient with a given vector field stop with a message; unknown keys only warn (parameters_init.f90:944-947).
 !=========================================================================================================
 module tfx_host_params
   implicit none
@@ -53,6 +54,7 @@ module tfx_host_params
     real(dp) :: rho(2) = 1.d-7, admm_cost_thr = 1.d-4, admm_mult = 1.d0, admm_max = 1.d+10
     ! features that need the out-of-scope constraint builders
     real(dp) :: beta_grad(2) = 0.d0, w_cross = 0.d0, w_clust(2) = 0.d0
+    integer :: der_type = 1, keep_const(2) = 0, vec_field_type = 0   ! inversion.crossGradient.* (parameters_init.f90:368-373)
     integer :: apply_local_dw = 0, apply_local_damp = 0, use_error(2) = 0, sensit_read = 0, nmodel_comp = 1, ndata_comp(2) = 1
     integer :: grav_data_type = 1
     character(len=256) :: sensit_path = 'SENSIT/'        ! src/parameters_init.f90:296-297
@@ -184,6 +186,10 @@ contains
       case ('inversion.dampingGradient.grav.weight'); read(val, *) par%beta_grad(1)
       case ('inversion.dampingGradient.magn.weight'); read(val, *) par%beta_grad(2)
       case ('inversion.crossGradient.weight');     read(val, *) par%w_cross
+      case ('inversion.crossGradient.derivativeType'); read(val, *) par%der_type
+      case ('inversion.crossGradient.grav.keepModelConstant'); read(val, *) par%keep_const(1)
+      case ('inversion.crossGradient.magn.keepModelConstant'); read(val, *) par%keep_const(2)
+      case ('inversion.crossGradient.vectorFieldType'); read(val, *) par%vec_field_type
       case ('inversion.clustering.grav.weight');   read(val, *) par%w_clust(1)
       case ('inversion.clustering.magn.weight');   read(val, *) par%w_clust(2)
       case ('inversion.writeModelEveryNiter', 'inversion.solver', &
@@ -638,7 +644,12 @@ program tomofastx_amd
   nprob = count(pr%on)
   if (nprob == 0) call stop_msg('Both problem weights are zero!')
   if (par%dw_type /= 1 .and. par%dw_type /= 2) call stop_msg('forward.depthWeighting.type must be 1 or 2 in this host.')
-  if (par%w_cross /= 0.d0) call stop_msg('Cross-gradient constraints are not supported by this host.')
+  if (par%w_cross /= 0.d0) then                                   ! structural coupling (joint_inverse_problem.F90:189-198, :529-541)
+    if (par%pw(1) == 0.d0 .or. par%pw(2) == 0.d0) call stop_msg('The cross-gradient constraint needs both problems (joint inversion).')
+    if (par%vec_field_type > 0) call stop_msg('Cross-gradient with a given vector field is not supported by this host.')
+    if (par%nmodel_comp /= 1) call stop_msg('Cross-gradient constraints need scalar models.')
+    spatial = .true.
+  endif
   if (par%apply_local_damp > 0) spatial = .true.                 ! local damping weights act in space (:189-198)
   if (par%norm_power /= 2.d0) spatial = .true.                   ! Lp damping acts in space (joint_inverse_problem.F90:189-198)
   if (par%admm > 0 .and. par%admm_bound_type /= 1 .and. par%admm_bound_type /= 2) call stop_msg('Unknown inversion.admm.boundType!')
@@ -927,6 +938,7 @@ program tomofastx_amd
     enddo
     if (spatial) then
       call build_gradient_damping()
+      if (par%w_cross /= 0.d0) call build_cross_gradient()
       if (g_nrows > 0) call tfx_check(tfx_cons_upload_csr(ctx, g_nrows, g_rowptr, g_cols, g_vals, g_rhs), 'damping_gradient_add')
       call tfx_check(tfx_lsqr_set_wavelet_domain(ctx, 0_c_int, par%nx, par%ny, par%nz, par%comp_type), 'WAVELET_DOMAIN')
     endif
@@ -1001,8 +1013,14 @@ contains
     do jp = 1, 2
       if (pr(jp)%on .and. par%beta_grad(jp) /= 0.d0) g_nrows = g_nrows + 3_c_int64_t * n * pr(jp)%nc
     enddo
+    e = 0
+    if (par%w_cross /= 0.d0) e = 3_c_int64_t * n                  ! the cross-gradient rows follow (up to 8 entries each)
+    if (.not. allocated(g_rowptr)) then
+      allocate(g_rowptr(g_nrows + e + 1), g_cols(2 * g_nrows + 8 * e), g_vals(2 * g_nrows + 8 * e), g_rhs(g_nrows + e))
+      g_rowptr(1) = 0
+    endif
+    g_nnz = 0
     if (g_nrows == 0) return
-    if (.not. allocated(g_rowptr)) allocate(g_rowptr(g_nrows + 1), g_cols(2 * g_nrows), g_vals(2 * g_nrows), g_rhs(g_nrows))
     row = 0
     e = 0
     g_rowptr(1) = 0
@@ -1051,6 +1069,139 @@ contains
   end subroutine build_gradient_damping
 
   ! v / column_weight with the reference's zero guard (damping.F90:129-135)
+  ! cross_gradient_calculate (src/inversion/cross_gradient.F90:220-391): 3 rows per cell, tau = grad m1 x grad m2, over the
+  ! columns of both models; appended after the gradient-damping rows.  Forward differences (or central with forward / backward
+  ! on the boundary layers, :255-285); the derivative tables follow calculate_tau (:457-577) and calculate_tau_backward (:675-743).
+  subroutine build_cross_gradient()
+    integer :: i, j, kk, p, comp, t, ne, scheme, a, b, cmin
+    integer(c_int64_t) :: row, e
+    real(dp) :: g1(3), g2(3), st(3), tau(3), cost(3), d1(4, 3), d2(4, 3)
+    integer :: cell(4, 3), ecol(8)
+    real(c_float) :: eval(8), f
+    logical :: lft, rgt
+    row = g_nrows
+    e = g_nnz
+    cost = 0.d0
+    p = 0
+    do kk = 1, par%nz
+      do j = 1, par%ny
+        do i = 1, par%nx
+          p = p + 1
+          lft = (i == 1 .or. j == 1 .or. kk == 1)
+          rgt = (i == par%nx .or. j == par%ny .or. kk == par%nz)
+          scheme = 0                                              ! 0 none, 1 forward, 2 central, 3 backward
+          if (lft .and. rgt) then
+            scheme = 0
+          else if (rgt) then
+            scheme = 3
+          else if (par%der_type /= 1 .and. .not. lft) then
+            scheme = 2
+          else
+            scheme = 1
+          endif
+          tau = 0.d0
+          ne = 0
+          if (scheme /= 0) then
+            st = (/ abs(pr(1)%X2(i) - pr(1)%X1(i)), abs(pr(1)%Y2((j - 1) * par%nx + 1) - pr(1)%Y1((j - 1) * par%nx + 1)), &
+                    abs(pr(1)%Z2((kk - 1) * par%nx * par%ny + 1) - pr(1)%Z1((kk - 1) * par%nx * par%ny + 1)) /)
+            call cell_gradient(pr(1)%m, i, j, kk, scheme, st, g1)
+            call cell_gradient(pr(2)%m, i, j, kk, scheme, st, g2)
+            if (scheme == 2) st = 2.d0 * st
+            tau = (/ g1(2) * g2(3) - g1(3) * g2(2), g1(3) * g2(1) - g1(1) * g2(3), g1(1) * g2(2) - g1(2) * g2(1) /)
+            a = 1
+            if (scheme == 3) a = -1                               ! neighbours on the + side (forward, central) or - side (backward)
+            ! entries 1, 2: the two neighbours of each component; 3: the cell itself (one-sided) or the opposite neighbours (central)
+            cell(1, 1) = p + a * par%nx;            cell(2, 1) = p + a * par%nx * par%ny
+            cell(1, 2) = p + a;                     cell(2, 2) = p + a * par%nx * par%ny
+            cell(1, 3) = p + a;                     cell(2, 3) = p + a * par%nx
+            d1(1, 1) = g2(3) / st(2);   d2(1, 1) = -g1(3) / st(2);  d1(2, 1) = -g2(2) / st(3);  d2(2, 1) = g1(2) / st(3)
+            d1(1, 2) = -g2(3) / st(1);  d2(1, 2) = g1(3) / st(1);   d1(2, 2) = g2(1) / st(3);   d2(2, 2) = -g1(1) / st(3)
+            d1(1, 3) = g2(2) / st(1);   d2(1, 3) = -g1(2) / st(1);  d1(2, 3) = -g2(1) / st(2);  d2(2, 3) = g1(1) / st(2)
+            if (scheme == 2) then
+              ne = 4
+              cell(3, 1) = p - par%nx;  cell(4, 1) = p - par%nx * par%ny
+              cell(3, 2) = p - 1;       cell(4, 2) = p - par%nx * par%ny
+              cell(3, 3) = p - 1;       cell(4, 3) = p - par%nx
+              d1(3:4, :) = -d1(1:2, :)
+              d2(3:4, :) = -d2(1:2, :)
+            else
+              ne = 3
+              cell(3, :) = p
+              d1(3, 1) = g2(3) / st(2) - g2(2) / st(3);  d2(3, 1) = g1(2) / st(3) - g1(3) / st(2)
+              d1(3, 2) = g2(1) / st(3) - g2(3) / st(1);  d2(3, 2) = g1(3) / st(1) - g1(1) / st(3)
+              d1(3, 3) = g2(2) / st(1) - g2(1) / st(2);  d2(3, 3) = g1(1) / st(2) - g1(2) / st(1)
+              if (scheme == 1) then
+                d1(3, :) = -d1(3, :)
+                d2(3, :) = -d2(3, :)
+              else
+                d1(1:2, :) = -d1(1:2, :)
+                d2(1:2, :) = -d2(1:2, :)
+              endif
+            endif
+            if (par%keep_const(1) > 0) d1 = 0.d0                  ! :294-295
+            if (par%keep_const(2) > 0) d2 = 0.d0
+          endif
+          cost = cost + tau**2
+          do comp = 1, 3
+            row = row + 1
+            b = 0
+            do t = 1, ne                                          ! model 1 columns, then model 2 columns (+ N), zeros dropped
+              f = real(d1(t, comp) * pr(1)%cw(cell(t, comp)) * par%w_cross, c_float)
+              if (f /= 0.0) then
+                b = b + 1;  ecol(b) = pr(1)%col0 + cell(t, comp);  eval(b) = f
+              endif
+            enddo
+            do t = 1, ne
+              f = real(d2(t, comp) * pr(2)%cw(cell(t, comp)) * par%w_cross, c_float)
+              if (f /= 0.0) then
+                b = b + 1;  ecol(b) = pr(2)%col0 + cell(t, comp);  eval(b) = f
+              endif
+            enddo
+            do t = 1, b                                           ! ascending columns for the upload (selection sort, <= 8 entries)
+              cmin = t
+              do a = t + 1, b
+                if (ecol(a) < ecol(cmin)) cmin = a
+              enddo
+              g_cols(e + t) = ecol(cmin);  g_vals(e + t) = eval(cmin)
+              ecol(cmin) = ecol(t);  eval(cmin) = eval(t)
+            enddo
+            e = e + b
+            g_rowptr(row + 1) = e
+            g_rhs(row) = -tau(comp) * par%w_cross
+          enddo
+        enddo
+      enddo
+    enddo
+    g_nrows = row
+    g_nnz = e
+    print *, 'cross-grad cost =', cost
+  end subroutine build_cross_gradient
+
+  ! get_grad (src/inversion/gradient.F90:68-86) with zeros outside the grid (grad_get_par, :196-225)
+  subroutine cell_gradient(f, i, j, kk, scheme, st, g)
+    real(dp), intent(in) :: f(:), st(3)
+    integer, intent(in) :: i, j, kk, scheme
+    real(dp), intent(out) :: g(3)
+    real(dp) :: c
+    c = fpar(f, i, j, kk)
+    if (scheme == 1) then
+      g = (/ (fpar(f, i + 1, j, kk) - c) / st(1), (fpar(f, i, j + 1, kk) - c) / st(2), (fpar(f, i, j, kk + 1) - c) / st(3) /)
+    else if (scheme == 3) then
+      g = (/ (c - fpar(f, i - 1, j, kk)) / st(1), (c - fpar(f, i, j - 1, kk)) / st(2), (c - fpar(f, i, j, kk - 1)) / st(3) /)
+    else
+      g = (/ (fpar(f, i + 1, j, kk) - fpar(f, i - 1, j, kk)) / 2.d0 / st(1), (fpar(f, i, j + 1, kk) - fpar(f, i, j - 1, kk)) / 2.d0 / st(2), &
+             (fpar(f, i, j, kk + 1) - fpar(f, i, j, kk - 1)) / 2.d0 / st(3) /)
+    endif
+  end subroutine cell_gradient
+
+  real(dp) function fpar(f, i, j, kk)
+    real(dp), intent(in) :: f(:)
+    integer, intent(in) :: i, j, kk
+    fpar = 0.d0
+    if (i < 1 .or. j < 1 .or. kk < 1 .or. i > par%nx .or. j > par%ny .or. kk > par%nz) return
+    fpar = f(((kk - 1) * par%ny + (j - 1)) * par%nx + i)
+  end function fpar
+
   subroutine unweight(jp, v, res)
     integer, intent(in) :: jp
     real(dp), intent(in) :: v(:)

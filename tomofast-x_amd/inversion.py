@@ -78,11 +78,12 @@ def gradient_damping_rows(m, dims, spacing, cw, pw, beta):
     return (rowptr, np.concatenate(cs), np.concatenate(vs)), np.concatenate(rh)
 
 
-def cross_gradient_rows(m1, m2, dims, spacing, cw1, cw2, weight, der_type=1):
+def cross_gradient_rows(m1, m2, dims, spacing, cw1, cw2, weight, der_type=1, keep_constant=(False, False)):
     """The cross-gradient constraint tau = grad m1 x grad m2 = 0 of a joint inversion (src/inversion/cross_gradient.F90:220-391;
     derivative tables :457-577 forward / central, :675-743 backward; boundary rules :255-285; gradients gradient.F90:68-86 with
     zeros outside the grid): 3 rows per cell over the columns of both models (model 2 at + N), values
     d tau / d m * column_weight * weight cast to fp32, right-hand side -tau * weight.
+    keep_constant[i]: no derivative entries for model i (:294-295).
     Returns (rowptr, cols 1-based ascending, vals), rhs, cost[3] - what Context.cons_upload_csr takes."""
     nx, ny, nz = dims
     N = nx * ny * nz
@@ -146,7 +147,9 @@ def cross_gradient_rows(m1, m2, dims, spacing, cw1, cw2, weight, der_type=1):
             for where, d1, d2 in table[comp]:
                 dk, dj, di = nbr[where]
                 cell = p + (dk * ny + dj) * nx + di
-                for off, dm, cw in ((0, d1, cw1), (N, d2, cw2)):
+                for off, dm, cw, fixed in ((0, d1, cw1, keep_constant[0]), (N, d2, cw2, keep_constant[1])):
+                    if fixed:
+                        continue
                     v = (dm[mask] * cw[cell] * weight).astype(np.float32)
                     keep = v != 0
                     rows_l.append((3 * p + comp)[keep])
@@ -320,7 +323,7 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
         xcost = None
         if spatial:
             G, grhs, xcost = cross_gradient_rows(m[0], m[1], (nx, ny, nz), ctx.spacing, cw[0], cw[1], float(cross_gradient["weight"]),
-                                                 int(cross_gradient.get("der_type", 1)))
+                                                 int(cross_gradient.get("der_type", 1)), cross_gradient.get("keep_constant", (False, False)))
             ctx.cons_upload_csr(G[0], G[1], G[2], grhs)
             ctx.lsqr_set_wavelet_domain(False, compression_type)
         try:
