@@ -370,8 +370,90 @@ def _tau_rows(g1, g2, step, i, j, k, ind, der_type):
     return [x, y, z]
 
 
+def _gaussian(mu, sigma, wloc, val):
+    """clustering_calculate_Gaussian (src/inversion/clustering.F90:539-584): 2-D Gaussian (:519-533) when both problems carry a
+    clustering weight, else the 1-D one of the active problem (:505-511); clamped to exp(-100) for tiny arguments."""
+    x, y = val
+    mu1, mu2 = mu
+    s11, s22, s12 = sigma
+    if wloc[0] != 0.0 and wloc[1] != 0.0:
+        s12_4 = (s12 * s12) * (s12 * s12)
+        arg = (-((-mu2 + y) * (mu2 * s11**2 - mu1 * s12**2 + s12**2 * x - s11**2 * y)) / (s12_4 - s11**2 * s22**2)
+               - ((-mu1 + x) * (mu2 * s12**2 - mu1 * s22**2 + s22**2 * x - s12**2 * y)) / (-s12_4 + s11**2 * s22**2)) / 2.0
+        norm = 2.0 * np.pi * np.sqrt(-s12_4 + s11**2 * s22**2)
+    elif wloc[1] == 0.0:
+        arg = -(x - mu1)**2 / s11**2 / 2.0
+        norm = np.sqrt(2.0 * np.pi * s11**2)
+    else:
+        arg = -(y - mu2)**2 / s22**2 / 2.0
+        norm = np.sqrt(2.0 * np.pi * s22**2)
+    if arg < -100.0:
+        return np.exp(-100.0)
+    return np.exp(arg) / norm
+
+
+def _mixture(mix, wloc, val, cluster_weight):
+    """clustering_calculate_Gaussian_mixture (:591-642): value and the two partial derivatives."""
+    gauss, deriv = 0.0, [0.0, 0.0]
+    x, y = val
+    for i in range(mix.shape[0]):
+        mu1, s11, mu2, s22, s12 = mix[i, 1], mix[i, 2], mix[i, 3], mix[i, 4], mix[i, 5]
+        gl = cluster_weight[i] * _gaussian((mu1, mu2), (s11, s22, s12), wloc, val)
+        gauss = gauss + gl
+        s12_4 = (s12 * s12) * (s12 * s12)
+        c1 = (s22**2 * (-mu1 + x) + s12**2 * (mu2 - y)) / (s12_4 - s11**2 * s22**2)
+        c2 = (s12**2 * (mu1 - x) + s11**2 * (-mu2 + y)) / (s12_4 - s11**2 * s22**2)
+        deriv[0] = deriv[0] + c1 * gl
+        deriv[1] = deriv[1] + c2 * gl
+    return gauss, deriv
+
+
+def clustering_setup(mixtures, N, cell_weights=None):
+    """clustering_read_mixtures (:159-283): per-cell cluster weights (global ones normalised to sum 1, local ones as read)."""
+    mixtures = np.asarray(mixtures, np.float64)
+    if cell_weights is None:
+        w = mixtures[:, 0] / np.sum(mixtures[:, 0])
+        return np.tile(w[None, :], (N, 1))
+    return np.asarray(cell_weights, np.float64)
+
+
+def clustering_rows(m1, m2, cw1, cw2, weight_glob, mixtures, cell_weight, opt_type=2):
+    """clustering_add for problem 1 then 2 (joint_inverse_problem.F90:613-631, clustering.F90:393-499): 2 N rows, row p of block i
+    holds weight_i * column_weight_i[p] * dP/dm_i (or -dP/dm_i / P for the logarithmic objective) at column p (+ N for i = 2);
+    right-hand side -weight_i * (P - P_max) resp. -weight_i * (log P_max - log P).  Returns CSR, rhs, cost[2]."""
+    N = m1.size
+    mix = np.asarray(mixtures, np.float64)
+    wloc = [0.0 if w == 0.0 else 1.0 for w in weight_glob]
+    cw = (cw1, cw2)
+    rp, cols, vals, rhs = [0], [], [], []
+    cost = np.zeros(2)
+    pmax = np.zeros(N)
+    for p in range(N):                                      # calculate_Gaussian_mixture_max (:647-674): the largest value at a cluster centre
+        for i in range(mix.shape[0]):
+            gval, _ = _mixture(mix, wloc, (mix[i, 1], mix[i, 3]), cell_weight[p])
+            pmax[p] = max(pmax[p], gval)
+    for i in range(2):
+        for p in range(N):
+            gauss, deriv = _mixture(mix, wloc, (m1[p], m2[p]), cell_weight[p])
+            if opt_type == 2:
+                deriv = [-d / gauss for d in deriv] if gauss != 0.0 else [0.0, 0.0]
+            v = np.float32(weight_glob[i] * cw[i][p] * deriv[i] * wloc[i])
+            if v != 0:
+                cols.append(p + 1 + i * N)
+                vals.append(v)
+            rp.append(len(cols))
+            if opt_type == 1:
+                f = gauss - pmax[p]
+            else:
+                f = -np.log(gauss) + np.log(pmax[p]) if gauss > 0.0 else 0.0
+            b = -weight_glob[i] * f * wloc[i]
+            rhs.append(b)
+            cost[i] += b * b
+    return (np.array(rp, np.int64), np.array(cols, np.int32), np.array(vals, np.float32)), np.array(rhs), cost
+
+
 def run_joint_inversion_xgrad(problems, dims, grid, ctype, nmajor, nminor, xgrad_weight, der_type=1, rmin=1e-13, lsqr=None,
-                              calc_data=None, rows_fn=None):
+                              calc_data=None, rows_fn=None, coupling=None):
     """Joint inversion with the cross-gradient constraint: WAVELET_DOMAIN = false, unknowns [x1; x2] spatial
     (joint_inverse_problem.F90:189-198, :393-573)."""
     N = int(np.prod(dims))
@@ -404,7 +486,10 @@ def run_joint_inversion_xgrad(problems, dims, grid, ctype, nmajor, nminor, xgrad
                 r = np.zeros(P * N)
                 r[i * N:(i + 1) * N] = -pr["alpha"] * pr["pw"] * (m[i] / pr["cw"])
                 rhs.append(r)
-        G, grhs, cost = rows_fn(m[0], m[1], dims, grid, problems[0]["cw"], problems[1]["cw"], xgrad_weight, der_type)
+        if coupling is not None:                           # another coupling constraint in place of the cross-gradient (clustering)
+            G, grhs, cost = coupling(m[0], m[1])
+        else:
+            G, grhs, cost = rows_fn(m[0], m[1], dims, grid, problems[0]["cw"], problems[1]["cw"], xgrad_weight, der_type)
         blocks.append(G)
         rhs.append(grhs)
         rpc = [np.zeros(1, np.int64)]

@@ -286,6 +286,34 @@ def test_cross_gradient_parfile_matches_reference(tmp_path, golden_dir, name):
     assert np.allclose(xc[2:], g["np1_xgrad_cost"][2:], rtol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["e2e_clust", "e2e_clust_normal", "e2e_clust_grav"])
+def test_clustering_parfile_matches_reference(tmp_path, golden_dir, name):
+    """inversion.clustering.*.weight /= 0 on a joint run: the host reads the mixture (and per-cell weight) files, builds the 2 N
+    Gaussian-mixture rows each major iteration and uploads them as the general constraint matrix, WAVELET_DOMAIN = F."""
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    wd = str(tmp_path)
+    write_joint_inputs(wd, g)
+    with open(os.path.join(wd, "mixtures.txt"), "w") as f:
+        f.write("%d\n" % g["mixtures"].shape[0])
+        for r in g["mixtures"]:
+            f.write(" ".join("%.17g" % v for v in r) + "\n")
+    with open(os.path.join(wd, "cell_weights.txt"), "w") as f:
+        f.write("%d %d\n" % g["cell_weights"].shape)
+        for r in g["cell_weights"]:
+            f.write(" ".join("%.17g" % v for v in r) + "\n")
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    for tag, sfx in (("grav", "grav"), ("magn", "mag")):
+        model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)[:, 0]
+        ref = g["np1_%s_model_final" % tag]
+        assert np.linalg.norm(model - ref) <= 1e-6 * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
+    rs = [float(t.split()[0]) for t in out.stdout.split("Finished lsqr solver, r =")[1:]]
+    assert np.allclose(rs, g["np1_lsqr_r"], rtol=1e-5)
+    assert np.isclose(float(out.stdout.split("Clustering mixture_max =")[1].split()[0]), float(g["np1_mixture_max"][0]), rtol=1e-7)
+
+
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 

@@ -1015,6 +1015,50 @@ def test_joint_inversion_with_cross_gradient_vs_reference(ctx, golden_dir, name)
         ctx.select_problem(0)
 
 
+@pytest.mark.parametrize("name", ["e2e_clust", "e2e_clust_normal", "e2e_clust_grav"])
+def test_joint_inversion_with_clustering_vs_reference(ctx, golden_dir, name):
+    """Joint inversion with the clustering (Gaussian-mixture) constraint: 2 N single-entry rows built on the host, uploaded as the
+    general constraint matrix, spatial unknowns - four major iterations vs the reference."""
+    g = load(golden_dir, name)
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    N = int(np.prod(dims))
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    ctx.set_grid(*dims, *grid)
+    local = None if int(g["cons_type"]) == 1 else g["cell_weights"]
+    cwg, cwm = g["np1_grav_column_weight"], g["np1_magn_column_weight"]
+    # the vectorised builder against the oracle's cell-by-cell restatement
+    rng = np.random.default_rng(5)
+    t1, t2 = rng.uniform(-100, 400, N), rng.uniform(-0.01, 0.05, N)
+    cellw = tfx.inversion.clustering_cell_weights(g["mixtures"], N, local)
+    assert np.array_equal(cellw, oinv.clustering_setup(g["mixtures"], N, local))
+    for opt in (1, 2):
+        A, ra, ca = tfx.inversion.clustering_rows(t1, t2, cwg, cwm, g["clust_weight"], g["mixtures"], cellw, opt)
+        B, rb, cb = oinv.clustering_rows(t1, t2, cwg, cwm, g["clust_weight"], g["mixtures"], cellw, opt)
+        assert np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1])
+        assert np.allclose(A[2], B[2], rtol=1e-6, atol=0) and np.allclose(ra, rb, rtol=1e-12, atol=1e-300) and np.allclose(ca, cb, rtol=1e-12)
+    probs = []
+    try:
+        for i, tag in enumerate(("grav", "magn")):
+            ctx.select_problem(i)
+            nd = g["obs_%s" % tag].shape[0]
+            ctx.matrix_upload_csr(nd, N, g["np1_%s_row_ptr" % tag], g["np1_%s_cols" % tag], g["np1_%s_vals" % tag])
+            probs.append(dict(column_weight=g["np1_%s_column_weight" % tag], data_obs=g["np1_%s_data_observed" % tag], problem_weight=1.0,
+                              alpha=float(g["alpha"][i])))
+        ctx.select_problem(0)
+        m, d, hist = tfx.inversion.solve_problem_joint(ctx, probs, int(g["ctype"]), int(g["nmajor"]), int(g["nminor"]),
+                                                       clustering=dict(weight=g["clust_weight"], mixtures=g["mixtures"],
+                                                                       opt_type=int(g["opt_type"]), cell_weights=local))
+        for i, tag in enumerate(("grav", "magn")):
+            ref = g["np1_%s_model_final" % tag]
+            assert np.linalg.norm(m[i] - ref) <= 1e-7 * np.linalg.norm(ref), (tag, np.linalg.norm(m[i] - ref) / np.linalg.norm(ref))
+        assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
+        assert np.allclose(np.array([h["clustering_cost"] for h in hist])[2:], g["np1_clust_cost"][2:], rtol=1e-5)
+    finally:
+        ctx.select_problem(1)
+        ctx.matrix_free()
+        ctx.select_problem(0)
+
+
 def test_config1_mansf_end_to_end(ctx, golden_dir):
     """BASELINE config 1 (parfiles/Parfile_mansf_slice.txt: 2x128x32 cells, 256 obs, Haar 0.15, ADMM, 60 x 100 LSQR
     iterations) entirely on the HIP path vs the reference's final model."""

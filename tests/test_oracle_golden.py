@@ -435,3 +435,29 @@ def test_joint_inversion_with_cross_gradient(golden_dir, name):
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-7)
     costs = np.array([h["xgrad_cost"] for h in hist])
     assert np.allclose(costs[2:], g["np1_xgrad_cost"][2:], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["e2e_clust", "e2e_clust_normal", "e2e_clust_grav"])
+def test_joint_inversion_with_clustering(golden_dir, name):
+    """Petrophysical coupling: the Gaussian-mixture clustering rows (2 N rows, one entry each) in the general constraint matrix,
+    spatial unknowns; logarithmic and normal objective, global and per-cell cluster weights, 2-D mixtures and the 1-D ones of a
+    single weighted problem - four major iterations vs the reference (final models, LSQR residuals, printed clustering costs)."""
+    g = load(golden_dir, name)
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    N = int(np.prod(dims))
+    probs = []
+    for i, tag in enumerate(("grav", "magn")):
+        probs.append(dict(S=(g["np1_%s_row_ptr" % tag], g["np1_%s_cols" % tag], g["np1_%s_vals" % tag]), cw=g["np1_%s_column_weight" % tag],
+                          d_obs=g["np1_%s_data_observed" % tag], pw=1.0, alpha=float(g["alpha"][i])))
+    cellw = oinv.clustering_setup(g["mixtures"], N, None if int(g["cons_type"]) == 1 else g["cell_weights"])
+
+    def coupling(m1, m2):
+        return oinv.clustering_rows(m1, m2, probs[0]["cw"], probs[1]["cw"], g["clust_weight"], g["mixtures"], cellw, int(g["opt_type"]))
+    m, d, hist = oinv.run_joint_inversion_xgrad(probs, dims, grid, int(g["ctype"]), int(g["nmajor"]), int(g["nminor"]), 0.0, coupling=coupling)
+    for i, tag in enumerate(("grav", "magn")):
+        ref = g["np1_%s_model_final" % tag]
+        assert np.linalg.norm(m[i] - ref) <= 1e-9 * np.linalg.norm(ref), (tag, np.linalg.norm(m[i] - ref) / np.linalg.norm(ref))
+    assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-7)
+    costs = np.array([h["xgrad_cost"] for h in hist])
+    assert np.allclose(costs[2:], g["np1_clust_cost"][2:], rtol=1e-6)

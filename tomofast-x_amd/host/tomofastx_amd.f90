@@ -17,8 +17,9 @@
 ! (dynamic weight); prior / starting model by value or file; data from file or from a synthetic model; 1..P ranks under mpiexec.
 ! The solver switches to spatial unknowns (WAVELET_DOMAIN = F) by the reference's rule (joint_inverse_problem.F90:189-198).
 ! Joint runs may add the cross-gradient coupling constraint (forward or central differences, keepModelConstant); its rows are built
-! on the host and uploaded as the general constraint matrix like the reference's matrix_cons.  The clustering constraint and the
-! cross-gradient with a given vector field stop with a message; unknown keys only warn (parameters_init.f90:944-947).
+! on the host and uploaded as the general constraint matrix like the reference's matrix_cons; so are the rows of the clustering
+! (Gaussian-mixture) constraint, logarithmic or normal objective, global or per-cell cluster weights.  The cross-gradient with a
+! given vector field stops with a message; unknown keys only warn (parameters_init.f90:944-947).
 !=========================================================================================================
 module tfx_host_params
   implicit none
@@ -55,6 +56,8 @@ module tfx_host_params
     ! features that need the out-of-scope constraint builders
     real(dp) :: beta_grad(2) = 0.d0, w_cross = 0.d0, w_clust(2) = 0.d0
     integer :: der_type = 1, keep_const(2) = 0, vec_field_type = 0   ! inversion.crossGradient.* (parameters_init.f90:368-373)
+    integer :: nclusters = 4, clust_opt = 2, clust_cons = 2          ! inversion.clustering.* (parameters_init.f90:375-381)
+    character(len=256) :: mixture_file = 'NILL', cell_weights_file = 'NILL'
     integer :: apply_local_dw = 0, apply_local_damp = 0, use_error(2) = 0, sensit_read = 0, nmodel_comp = 1, ndata_comp(2) = 1
     integer :: grav_data_type = 1
     character(len=256) :: sensit_path = 'SENSIT/'        ! src/parameters_init.f90:296-297
@@ -192,6 +195,11 @@ contains
       case ('inversion.crossGradient.vectorFieldType'); read(val, *) par%vec_field_type
       case ('inversion.clustering.grav.weight');   read(val, *) par%w_clust(1)
       case ('inversion.clustering.magn.weight');   read(val, *) par%w_clust(2)
+      case ('inversion.clustering.nClusters');     read(val, *) par%nclusters
+      case ('inversion.clustering.mixtureFile');   par%mixture_file = trim(val)
+      case ('inversion.clustering.cellWeightsFile'); par%cell_weights_file = trim(val)
+      case ('inversion.clustering.optimizationType'); read(val, *) par%clust_opt
+      case ('inversion.clustering.constraintsType'); read(val, *) par%clust_cons
       case ('inversion.writeModelEveryNiter', 'inversion.solver', &
             'output.paraview.grav.modelLabel', 'output.paraview.magn.modelLabel', 'inversion.priorModel.nModels')
         continue
@@ -598,6 +606,7 @@ program tomofastx_amd
   integer(c_int32_t), allocatable, target :: g_cols(:)
   real(c_float), allocatable, target :: g_vals(:)
   real(dp), allocatable, target :: g_rhs(:)
+  real(dp), allocatable :: clust_mix(:, :), clust_cellw(:, :), clust_max(:)   ! mixtures (6, cluster), cell weights (cluster, cell), P_max
   integer(c_int64_t) :: g_nrows, g_nnz
   integer :: cb, ce, nloc, ra, rb                     ! this rank's cells (cb, ce], nloc = ce - cb; its share of the data rows
   integer(c_int32_t), allocatable, target :: hist(:), hist_all(:), nel_at(:)
@@ -665,7 +674,7 @@ program tomofastx_amd
   k = 0
   do ip = 1, 2
     if (.not. pr(ip)%on) cycle
-    if (par%w_clust(ip) /= 0.d0) call stop_msg('Clustering constraints are not supported by this host.')
+    if (par%w_clust(ip) /= 0.d0) spatial = .true.
     if (par%beta_grad(ip) /= 0.d0) spatial = .true.              ! WAVELET_DOMAIN = .false. (joint_inverse_problem.F90:189-198)
     pr(ip)%slot = k
     k = k + 1
@@ -939,6 +948,7 @@ program tomofastx_amd
     if (spatial) then
       call build_gradient_damping()
       if (par%w_cross /= 0.d0) call build_cross_gradient()
+      if (any(par%w_clust /= 0.d0)) call build_clustering()
       if (g_nrows > 0) call tfx_check(tfx_cons_upload_csr(ctx, g_nrows, g_rowptr, g_cols, g_vals, g_rhs), 'damping_gradient_add')
       call tfx_check(tfx_lsqr_set_wavelet_domain(ctx, 0_c_int, par%nx, par%ny, par%nz, par%comp_type), 'WAVELET_DOMAIN')
     endif
@@ -1007,16 +1017,18 @@ contains
   ! 3 N rows per component, two entries each except in the last layer of the direction; columns ascending for the upload
   subroutine build_gradient_damping()
     integer :: jp, kc, dir, i, j, kk, p, me, nb, cshift
-    integer(c_int64_t) :: row, e
+    integer(c_int64_t) :: row, e, ec
     real(dp) :: delta, gval, coef
     g_nrows = 0
     do jp = 1, 2
       if (pr(jp)%on .and. par%beta_grad(jp) /= 0.d0) g_nrows = g_nrows + 3_c_int64_t * n * pr(jp)%nc
     enddo
     e = 0
-    if (par%w_cross /= 0.d0) e = 3_c_int64_t * n                  ! the cross-gradient rows follow (up to 8 entries each)
+    if (par%w_cross /= 0.d0) e = 3_c_int64_t * n                  ! the cross-gradient rows follow (up to 8 entries each),
+    ec = 0
+    if (any(par%w_clust /= 0.d0)) ec = 2_c_int64_t * n            ! then the clustering rows (one entry each)
     if (.not. allocated(g_rowptr)) then
-      allocate(g_rowptr(g_nrows + e + 1), g_cols(2 * g_nrows + 8 * e), g_vals(2 * g_nrows + 8 * e), g_rhs(g_nrows + e))
+      allocate(g_rowptr(g_nrows + e + ec + 1), g_cols(2 * g_nrows + 8 * e + ec), g_vals(2 * g_nrows + 8 * e + ec), g_rhs(g_nrows + e + ec))
       g_rowptr(1) = 0
     endif
     g_nnz = 0
@@ -1176,6 +1188,140 @@ contains
     g_nnz = e
     print *, 'cross-grad cost =', cost
   end subroutine build_cross_gradient
+
+  ! clustering_add for problem 1 then 2 (src/inversion/clustering.F90:393-499, joint_inverse_problem.F90:613-631): 2 N rows with one
+  ! entry each - the derivative of the Gaussian mixture P(m1, m2) (or of -log P) times weight and column weight - and the
+  ! right-hand side -weight (P - P_max) resp. -weight (log P_max - log P); appended after the other constraint rows.
+  subroutine build_clustering()
+    integer :: jp, p, i
+    integer(c_int64_t) :: row, e
+    real(dp) :: wloc(2), gauss, deriv(2), func, val(2), gc, dtmp(2), cost
+    real(c_float) :: f
+    if (.not. allocated(clust_mix)) call read_mixtures()
+    wloc = merge(0.d0, 1.d0, par%w_clust == 0.d0)                 ! 1-D Gaussians when one weight is zero (:131-138)
+    if (.not. allocated(clust_max)) then                          ! calculate_Gaussian_mixture_max (:647-674)
+      allocate(clust_max(n))
+      do p = 1, n
+        clust_max(p) = 0.d0
+        do i = 1, par%nclusters
+          call gaussian_mixture((/ clust_mix(2, i), clust_mix(4, i) /), clust_cellw(:, p), wloc, gc, dtmp)
+          if (gc > clust_max(p)) clust_max(p) = gc
+        enddo
+      enddo
+      print *, 'Clustering mixture_max =', maxval(clust_max)
+    endif
+    row = g_nrows
+    e = g_nnz
+    do jp = 1, 2
+      cost = 0.d0
+      do p = 1, n
+        val = (/ pr(1)%m(p), pr(2)%m(p) /)
+        call gaussian_mixture(val, clust_cellw(:, p), wloc, gauss, deriv)
+        if (par%clust_opt == 2) then
+          if (gauss /= 0.d0) then
+            deriv = -deriv / gauss
+          else
+            deriv = 0.d0
+          endif
+        endif
+        row = row + 1
+        f = real(par%w_clust(jp) * pr(jp)%cw(p) * deriv(jp) * wloc(jp), c_float)
+        if (f /= 0.0) then
+          e = e + 1
+          g_cols(e) = pr(jp)%col0 + p
+          g_vals(e) = f
+        endif
+        g_rowptr(row + 1) = e
+        if (par%clust_opt == 1) then
+          func = gauss - clust_max(p)
+        else if (par%clust_opt == 2) then
+          func = 0.d0
+          if (gauss > 0.d0) func = -log(gauss) + log(clust_max(p))
+        else
+          call stop_msg('Wrong optimization type in clustering_add!')
+        endif
+        g_rhs(row) = -par%w_clust(jp) * func * wloc(jp)
+        cost = cost + g_rhs(row)**2
+      enddo
+      print *, 'clustering term', jp, 'cost = ', cost
+    enddo
+    g_nrows = row
+    g_nnz = e
+  end subroutine build_clustering
+
+  ! clustering_calculate_Gaussian_mixture (:591-642) with the Gaussians of :505-584
+  subroutine gaussian_mixture(val, cellw, wloc, gauss, deriv)
+    real(dp), intent(in) :: val(2), cellw(:), wloc(2)
+    real(dp), intent(out) :: gauss, deriv(2)
+    real(dp), parameter :: PI = 3.14159265358979323846264338327950288d0
+    real(dp) :: x, y, mu1, mu2, s11, s22, s12, arg, norm, gl, den
+    integer :: i
+    gauss = 0.d0
+    deriv = 0.d0
+    x = val(1)
+    y = val(2)
+    do i = 1, par%nclusters
+      mu1 = clust_mix(2, i);  s11 = clust_mix(3, i);  mu2 = clust_mix(4, i);  s22 = clust_mix(5, i);  s12 = clust_mix(6, i)
+      if (wloc(1) /= 0.d0 .and. wloc(2) /= 0.d0) then
+        arg = (-((-mu2 + y) * (mu2 * s11**2 - mu1 * s12**2 + s12**2 * x - s11**2 * y)) / (s12**4 - s11**2 * s22**2) &
+               - ((-mu1 + x) * (mu2 * s12**2 - mu1 * s22**2 + s22**2 * x - s12**2 * y)) / (-s12**4 + s11**2 * s22**2)) / 2.d0
+        norm = 2.d0 * PI * sqrt(-s12**4 + s11**2 * s22**2)
+      else if (wloc(2) == 0.d0) then
+        arg = -(x - mu1)**2 / s11**2 / 2.d0
+        norm = sqrt(2.d0 * PI * s11**2)
+      else
+        arg = -(y - mu2)**2 / s22**2 / 2.d0
+        norm = sqrt(2.d0 * PI * s22**2)
+      endif
+      if (norm == 0.d0) call stop_msg('Zero norm in clustering_calculate_Gaussian!')
+      if (arg < -100.d0) then
+        gl = cellw(i) * exp(-100.d0)
+      else
+        gl = cellw(i) * (exp(arg) / norm)
+      endif
+      gauss = gauss + gl
+      den = s12**4 - s11**2 * s22**2
+      deriv(1) = deriv(1) + (s22**2 * (-mu1 + x) + s12**2 * (mu2 - y)) / den * gl
+      deriv(2) = deriv(2) + (s12**2 * (mu1 - x) + s11**2 * (-mu2 + y)) / den * gl
+    enddo
+  end subroutine gaussian_mixture
+
+  ! clustering_read_mixtures (:159-283): "nclusters", then per cluster: weight mu1 sigma1 mu2 sigma2 sigma12; per-cell cluster
+  ! weights "nelements nclusters" + one line per cell (constraintsType 2), else the normalised global weights for every cell
+  subroutine read_mixtures()
+    integer :: u, ios, nread, cread, i, p
+    if (.not. (pr(1)%on .and. pr(2)%on)) call stop_msg('The clustering constraint needs both problems (joint inversion).')
+    if (par%nmodel_comp /= 1) call stop_msg('Clustering constraints need scalar models.')
+    allocate(clust_mix(6, par%nclusters), clust_cellw(par%nclusters, n))
+    print *, 'Reading clustering parameters from file ', trim(par%mixture_file)
+    open(newunit=u, file=trim(par%mixture_file), status='old', action='read', iostat=ios)
+    if (ios /= 0) call stop_msg('Error in opening the mixture file! path='//trim(par%mixture_file))
+    read(u, *, iostat=ios) nread
+    if (ios /= 0 .or. nread /= par%nclusters) call stop_msg('The number of clusters is inconsistent!')
+    do i = 1, par%nclusters
+      read(u, *, iostat=ios) clust_mix(:, i)
+      if (ios /= 0) call stop_msg('Problem while reading the mixture file in clustering_read_mixtures!')
+    enddo
+    close(u)
+    clust_mix(1, :) = clust_mix(1, :) / sum(clust_mix(1, :))
+    if (par%clust_cons /= 1) then
+      print *, 'Reading clustering cell-weights:'
+      open(newunit=u, file=trim(par%cell_weights_file), status='old', action='read', iostat=ios)
+      if (ios /= 0) call stop_msg('Error in opening the cell-weights file! path='//trim(par%cell_weights_file))
+      read(u, *, iostat=ios) nread, cread
+      if (ios /= 0 .or. cread /= par%nclusters) call stop_msg('The number of clusters is inconsistent!')
+      if (nread /= n) call stop_msg('The number of cells is inconsistent!')
+      do p = 1, n
+        read(u, *, iostat=ios) clust_cellw(:, p)
+        if (ios /= 0) call stop_msg('Problem while reading the cell-weights file!')
+      enddo
+      close(u)
+    else
+      do p = 1, n
+        clust_cellw(:, p) = clust_mix(1, :)
+      enddo
+    endif
+  end subroutine read_mixtures
 
   ! get_grad (src/inversion/gradient.F90:68-86) with zeros outside the grid (grad_get_par, :196-225)
   subroutine cell_gradient(f, i, j, kk, scheme, st, g)

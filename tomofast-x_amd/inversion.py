@@ -167,6 +167,77 @@ def cross_gradient_rows(m1, m2, dims, spacing, cw1, cw2, weight, der_type=1, kee
     return (rowptr, cols.astype(np.int32), vals), rhs, cost
 
 
+def clustering_cell_weights(mixtures, N, cell_weights=None):
+    """Per-cell cluster weights (src/inversion/clustering.F90:159-283): the global ones of the mixture file normalised to sum 1
+    (constraintsType 1), or the per-cell table as read (constraintsType 2)."""
+    mixtures = np.asarray(mixtures, np.float64)
+    if cell_weights is None:
+        return np.tile((mixtures[:, 0] / np.sum(mixtures[:, 0]))[None, :], (N, 1))
+    return np.asarray(cell_weights, np.float64)
+
+
+def _gaussian_mixture(mix, wloc, x, y, cell_weight):
+    """Gaussian mixture P(x, y) and its two partial derivatives, vectorised over the cells (clustering.F90:591-642 with the
+    Gaussians of :505-584: 2-D when both problems carry a clustering weight, else 1-D in the weighted one; exp(-100) floor)."""
+    gauss = np.zeros_like(x)
+    d1, d2 = np.zeros_like(x), np.zeros_like(x)
+    for i in range(mix.shape[0]):
+        mu1, s11, mu2, s22, s12 = mix[i, 1], mix[i, 2], mix[i, 3], mix[i, 4], mix[i, 5]
+        s12_4 = (s12 * s12) * (s12 * s12)
+        if wloc[0] != 0.0 and wloc[1] != 0.0:
+            arg = (-((-mu2 + y) * (mu2 * s11**2 - mu1 * s12**2 + s12**2 * x - s11**2 * y)) / (s12_4 - s11**2 * s22**2)
+                   - ((-mu1 + x) * (mu2 * s12**2 - mu1 * s22**2 + s22**2 * x - s12**2 * y)) / (-s12_4 + s11**2 * s22**2)) / 2.0
+            norm = 2.0 * np.pi * np.sqrt(-s12_4 + s11**2 * s22**2)
+        elif wloc[1] == 0.0:
+            arg = -(x - mu1)**2 / s11**2 / 2.0
+            norm = np.sqrt(2.0 * np.pi * s11**2)
+        else:
+            arg = -(y - mu2)**2 / s22**2 / 2.0
+            norm = np.sqrt(2.0 * np.pi * s22**2)
+        if norm == 0.0:
+            raise ValueError("zero norm of a clustering Gaussian (clustering.F90:571-574)")
+        val = np.where(arg < -100.0, np.exp(-100.0), np.exp(np.maximum(arg, -100.0)) / norm)
+        gl = cell_weight[:, i] * val
+        gauss = gauss + gl
+        d1 = d1 + (s22**2 * (-mu1 + x) + s12**2 * (mu2 - y)) / (s12_4 - s11**2 * s22**2) * gl
+        d2 = d2 + (s12**2 * (mu1 - x) + s11**2 * (-mu2 + y)) / (s12_4 - s11**2 * s22**2) * gl
+    return gauss, d1, d2
+
+
+def clustering_rows(m1, m2, cw1, cw2, weight_glob, mixtures, cell_weight, opt_type=2):
+    """The clustering (petrophysical) constraint of a joint inversion (clustering.F90:393-499, called for problem 1 then 2,
+    joint_inverse_problem.F90:613-631): 2 N rows, row p of block i holds weight_i * column_weight_i[p] * dP/dm_i - or
+    -dP/dm_i / P for the logarithmic objective (opt_type 2) - at column p (+ N for i = 2), cast to fp32; right-hand side
+    -weight_i * (P - P_max) resp. -weight_i * (log P_max - log P), P_max = the largest mixture value at a cluster centre
+    (:647-674).  mixtures[c] = (cluster weight, mu1, sigma1, mu2, sigma2, sigma12).
+    Returns (rowptr, cols 1-based, vals), rhs, cost[2] - what Context.cons_upload_csr takes."""
+    N = m1.size
+    mix = np.asarray(mixtures, np.float64)
+    wloc = [0.0 if w == 0.0 else 1.0 for w in weight_glob]
+    pmax = np.zeros(N)
+    for i in range(mix.shape[0]):
+        gc, _, _ = _gaussian_mixture(mix, wloc, np.full(N, mix[i, 1]), np.full(N, mix[i, 3]), cell_weight)
+        pmax = np.maximum(pmax, gc)
+    gauss, d1, d2 = _gaussian_mixture(mix, wloc, np.asarray(m1, np.float64), np.asarray(m2, np.float64), cell_weight)
+    if opt_type == 2:
+        nzm = gauss != 0.0
+        safe = np.where(nzm, gauss, 1.0)
+        d1, d2 = np.where(nzm, -d1 / safe, 0.0), np.where(nzm, -d2 / safe, 0.0)
+        pos = gauss > 0.0
+        func = np.where(pos, -np.log(np.where(pos, gauss, 1.0)) + np.log(pmax), 0.0)
+    elif opt_type == 1:
+        func = gauss - pmax
+    else:
+        raise ValueError("wrong optimization type of the clustering constraint: %r" % (opt_type,))
+    vals = np.concatenate([(weight_glob[0] * cw1 * d1 * wloc[0]).astype(np.float32), (weight_glob[1] * cw2 * d2 * wloc[1]).astype(np.float32)])
+    keep = vals != 0
+    rowptr = np.concatenate([[0], np.cumsum(keep)]).astype(np.int64)
+    cols = (np.nonzero(keep)[0] + 1).astype(np.int32)
+    rhs = np.concatenate([-weight_glob[0] * func * wloc[0], -weight_glob[1] * func * wloc[1]])
+    cost = np.array([np.sum(rhs[:N] ** 2), np.sum(rhs[N:] ** 2)])
+    return (rowptr, cols, vals[keep]), rhs, cost
+
+
 def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor, nminor, alpha=0.0, rmin=1e-13,
                           problem_weight=1.0, data_weight=None, model_start=None, model_prior=None, admm=None,
                           gamma=0.0, target_misfit=0.0, log=None, nmodel_components=1, col_range=None, beta=0.0,
@@ -272,7 +343,7 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
 
 
 def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e-13, gamma=0.0, target_misfit=0.0, log=None,
-                        cross_gradient=None):
+                        cross_gradient=None, clustering=None):
     """Joint inversion of two problems on one grid (gravity + magnetic) without structural coupling: both sensitivity
     kernels in ONE LSQR system, S = blockdiag(slot 0, slot 1) (src/inversion/joint_inverse_problem.F90:393-573; block layout
     :712-739, right-hand side :379-387, one damping block per problem :448-463).  Coupling constraints built on the host
@@ -280,7 +351,8 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
 
     problems: two dicts(column_weight, data_obs, problem_weight, alpha[, model_start, model_prior]); slot i of ctx holds
     problem i's kernel, built with its problem_weight.  cross_gradient = dict(weight, der_type 1 | 2): the structural
-    coupling constraint, which switches the solver to spatial unknowns (WAVELET_DOMAIN = false, :189-198).
+    coupling constraint; clustering = dict(weight (2), mixtures, opt_type 1 | 2[, cell_weights]): the petrophysical one.
+    Either switches the solver to spatial unknowns (WAVELET_DOMAIN = false, :189-198); the rows go cross-gradient first (:529-541).
     Returns (models, data_calc, history)."""
     nx, ny, nz = ctx.dims
     N = nx * ny * nz
@@ -295,7 +367,8 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
     def to_wavelet(v):
         return ctx.forward_wavelet(v, nx, ny, nz, compression_type) if compression_type > 0 else v
 
-    spatial = cross_gradient is not None
+    spatial = cross_gradient is not None or clustering is not None
+    clust_w = clustering_cell_weights(clustering["mixtures"], N, clustering.get("cell_weights")) if clustering is not None else None
 
     def calculate_data(i):                            # model.F90:242-305 on problem i's rows / columns
         ctx.select_problem(i)
@@ -320,11 +393,20 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
                 r[i * N:(i + 1) * N] = -p["alpha"] * pw[i] * md
                 diag.append(blk)
                 rhs.append(r)
-        xcost = None
+        xcost = ccost = None
         if spatial:
-            G, grhs, xcost = cross_gradient_rows(m[0], m[1], (nx, ny, nz), ctx.spacing, cw[0], cw[1], float(cross_gradient["weight"]),
-                                                 int(cross_gradient.get("der_type", 1)), cross_gradient.get("keep_constant", (False, False)))
-            ctx.cons_upload_csr(G[0], G[1], G[2], grhs)
+            blocks = []
+            if cross_gradient is not None:
+                G, grhs, xcost = cross_gradient_rows(m[0], m[1], (nx, ny, nz), ctx.spacing, cw[0], cw[1], float(cross_gradient["weight"]),
+                                                     int(cross_gradient.get("der_type", 1)), cross_gradient.get("keep_constant", (False, False)))
+                blocks.append((G, grhs))
+            if clustering is not None:
+                G, grhs, ccost = clustering_rows(m[0], m[1], cw[0], cw[1], clustering["weight"], clustering["mixtures"], clust_w,
+                                                 int(clustering.get("opt_type", 2)))
+                blocks.append((G, grhs))
+            rp = np.concatenate([[0]] + [b[0][0][1:] + off for b, off in zip(blocks, np.cumsum([0] + [int(b[0][0][-1]) for b in blocks])[:-1])])
+            ctx.cons_upload_csr(rp.astype(np.int64), np.concatenate([b[0][1] for b in blocks]), np.concatenate([b[0][2] for b in blocks]),
+                                np.concatenate([b[1] for b in blocks]))
             ctx.lsqr_set_wavelet_domain(False, compression_type)
         try:
             x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
@@ -338,7 +420,7 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
             m[i] = m[i] + dm * cw[i]                  # joint_inverse_problem.F90:559-571
             d[i] = calculate_data(i)
         costs = [float(np.linalg.norm(d[i] - problems[i]["data_obs"]) / np.linalg.norm(problems[i]["data_obs"])) for i in range(P)]
-        hist.append(dict(it=it, iters=iters, r=r, costs=costs, xgrad_cost=xcost))
+        hist.append(dict(it=it, iters=iters, r=r, costs=costs, xgrad_cost=xcost, clustering_cost=ccost))
         if log:
             log("it %d: lsqr iters %d r %.6e data costs %s" % (it, iters, r, costs))
     return m, d, hist

@@ -1,0 +1,51 @@
+"""Reduces the two rocprofv3 PMC passes of tools/profile_round.sh (FETCH_SIZE, WRITE_SIZE on the k_spmv kernels) to HBM bytes per
+launch -> profiles/rNN_pmc_summary.json, which bench.py reads for roofline.traffic.  Corrections: MI355X_MICROARCH.md, HBM section
+(gfx950: FETCH_SIZE counts half of a wide coalesced streaming read -> x2; both counters are in KiB)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_kernel(folder, counter):
+    out = {}
+    for f in glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = row["Kernel_Name"]
+            key = "k_spmv_fwd" if "k_spmv_fwd" in name else "k_spmv_adj" if "k_spmv_adj" in name else None
+            if key is None:
+                continue
+            disp = row["Dispatch_Id"]
+            out.setdefault(key, {}).setdefault(disp, 0.0)
+            out[key][disp] += float(row["Counter_Value"])
+    return {k: (sum(v.values()) / len(v), len(v)) for k, v in out.items()}
+
+
+def main(src, dst, rnd):
+    fetch = per_kernel(os.path.join(src, "pmc_FETCH_SIZE"), "FETCH_SIZE")
+    write = per_kernel(os.path.join(src, "pmc_WRITE_SIZE"), "WRITE_SIZE")
+    bench = json.loads(open(os.path.join(src, "pmc_FETCH_SIZE.json")).read().strip().splitlines()[-1])
+    res = {"round": rnd, "workload": bench["config"]["workload"].split(":")[0],
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-include-regex k_spmv), "
+                     "bench.py --steps 3 --warmup 1 --no-cpu --no-profile (tools/profile_round.sh)",
+           "correction": "MI355X_MICROARCH.md HBM: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) "
+                         "coalesced streaming read -> doubled; FETCH_SIZE/WRITE_SIZE are in KiB (x1024). WRITE_SIZE is uncalibrated (small here).",
+           "kernels": {}, "nnz": bench["config"]["nnz"]}
+    plain = os.path.join(src, "bench_plain.json")
+    if os.path.isfile(plain):
+        res["stored_bytes"] = json.loads(open(plain).read().strip().splitlines()[-1])["roofline"]["stored_bytes_per_launch"]
+    for k in fetch:
+        rd = fetch[k][0] * 1024.0 * 2.0
+        wr = write.get(k, (0.0, 0))[0] * 1024.0
+        res["kernels"][k] = {"FETCH_SIZE_raw_KiB_avg": fetch[k][0], "FETCH_SIZE_launches": fetch[k][1],
+                             "WRITE_SIZE_raw_KiB_avg": write.get(k, (0.0, 0))[0], "WRITE_SIZE_launches": write.get(k, (0.0, 0))[1],
+                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr}
+    json.dump(res, open(dst, "w"), indent=1)
+    print(json.dumps(res["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 1)
