@@ -1,0 +1,90 @@
+"""Host-side constraint builders (numpy, no GPU): the vectorised product versions in tomofast-x_amd/inversion.py against the
+test oracle's cell-by-cell restatements, which tests/test_oracle_golden.py pins to the reference's own runs."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_inversion as oinv
+
+tfx = importlib.import_module("tomofast-x_amd")
+
+
+def bits_equal(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def case(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    sh = (dims[2], dims[1], dims[0])
+    spacing = (np.abs(grid[1] - grid[0]).reshape(sh)[0, 0, :], np.abs(grid[3] - grid[2]).reshape(sh)[0, :, 0],
+               np.abs(grid[5] - grid[4]).reshape(sh)[:, 0, 0])
+    return g, dims, grid, spacing
+
+
+def test_gradient_damping_rows_match_the_restatement(golden_dir):
+    g, dims, grid, spacing = case(golden_dir, "e2e_dgrad")
+    N = int(np.prod(dims))
+    m = np.random.default_rng(3).standard_normal(N)
+    cw = g["np1_column_weight"]
+    A, ra = tfx.inversion.gradient_damping_rows(m, dims, spacing, cw, 0.7, 1.3e-3)
+    B, rb = oinv.gradient_damping_rows(m, dims, grid, cw, 0.7, 1.3e-3)
+    assert np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and bits_equal(A[2], B[2]) and bits_equal(ra, rb)
+    assert A[0].size == 3 * N + 1 and int(A[0][-1]) == 2 * (3 * N - dims[1] * dims[2] - dims[0] * dims[2] - dims[0] * dims[1])
+
+
+@pytest.mark.parametrize("der_type", [1, 2])
+def test_cross_gradient_rows_match_the_restatement(golden_dir, der_type):
+    g, dims, grid, spacing = case(golden_dir, "e2e_xgrad")
+    N = int(np.prod(dims))
+    rng = np.random.default_rng(4)
+    m1, m2 = rng.standard_normal(N), rng.standard_normal(N)
+    cw1, cw2 = g["np1_grav_column_weight"], g["np1_magn_column_weight"]
+    A, ra, ca = tfx.inversion.cross_gradient_rows(m1, m2, dims, spacing, cw1, cw2, 0.37, der_type)
+    B, rb, cb = oinv.cross_gradient_rows(m1, m2, dims, grid, cw1, cw2, 0.37, der_type)
+    assert np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and bits_equal(A[2], B[2]) and bits_equal(ra, rb)
+    assert np.allclose(ca, cb, rtol=1e-13)
+    # parallel gradients: tau = 0 everywhere, the right-hand side vanishes
+    _, r0, c0 = tfx.inversion.cross_gradient_rows(m1, 3.0 * m1, dims, spacing, cw1, cw2, 0.37, der_type)
+    assert np.abs(r0).max() <= 1e-12 * np.abs(ra).max() and c0.max() <= 1e-24 * ca.max()
+    # keepModelConstant drops exactly the entries of that model's column block
+    K, rk, _ = tfx.inversion.cross_gradient_rows(m1, m2, dims, spacing, cw1, cw2, 0.37, der_type, keep_constant=(False, True))
+    assert bits_equal(rk, ra) and K[1].max() <= N and np.array_equal(K[1], A[1][A[1] <= N]) and bits_equal(K[2], A[2][A[1] <= N])
+
+
+@pytest.mark.parametrize("weights", [(1e-3, 2e-3), (1e-3, 0.0), (0.0, 2e-3)])
+@pytest.mark.parametrize("opt_type", [1, 2])
+@pytest.mark.parametrize("local", [False, True])
+def test_clustering_rows_match_the_restatement(golden_dir, weights, opt_type, local):
+    g, dims, grid, spacing = case(golden_dir, "e2e_clust_normal")
+    N = int(np.prod(dims))
+    rng = np.random.default_rng(5)
+    m1, m2 = rng.uniform(-100, 400, N), rng.uniform(-0.01, 0.05, N)
+    m1[:3] = 1e5                                          # far from every cluster: the exp(-100) floor (clustering.F90:576-582)
+    cw1, cw2 = g["np1_grav_column_weight"], g["np1_magn_column_weight"]
+    cellw = tfx.inversion.clustering_cell_weights(g["mixtures"], N, g["cell_weights"] if local else None)
+    assert bits_equal(cellw, oinv.clustering_setup(g["mixtures"], N, g["cell_weights"] if local else None))
+    A, ra, ca = tfx.inversion.clustering_rows(m1, m2, cw1, cw2, weights, g["mixtures"], cellw, opt_type)
+    B, rb, cb = oinv.clustering_rows(m1, m2, cw1, cw2, weights, g["mixtures"], cellw, opt_type)
+    assert np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1])
+    assert np.allclose(A[2], B[2], rtol=1e-6, atol=0) and np.allclose(ra, rb, rtol=1e-12, atol=1e-300) and np.allclose(ca, cb, rtol=1e-12)
+    assert A[0].size == 2 * N + 1
+    for i in range(2):                                    # a problem without a clustering weight contributes empty rows and zero rhs
+        if weights[i] == 0.0:
+            assert int(A[0][(i + 1) * N] - A[0][i * N]) == 0 and not ra[i * N:(i + 1) * N].any()
+
+
+def test_admm_projection_matches_the_restatement():
+    rng = np.random.default_rng(6)
+    n = 500
+    bounds = np.array([-20.0, 20.0, 90.0, 130.0, 220.0, 260.0])
+    st = tfx.inversion.AdmmState(n)
+    z, u = np.zeros(n), np.zeros(n)
+    for _ in range(4):
+        x = rng.uniform(-60, 300, n)
+        x0 = st.iterate_admm_arrays(x, bounds)
+        r0 = oinv.admm_iterate(z, u, x, bounds)
+        assert bits_equal(x0, r0) and bits_equal(st.z, z) and bits_equal(st.u, u)
