@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the matrix kernels with HIP events")
+    ap.add_argument("--full-select", action="store_true", help="A/B: thresholds by the full radix select instead of the band select")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,6 +95,8 @@ def main():
     xs, ys, zs = tfx.synthetic.observations(nx, ny, w["ox"], w["oy"])
     D = xs.size
     ctx = tfx.Context(local_rank)
+    if args.full_select:
+        ctx.debug_set("band_select_min_cells", -1)
     info = ctx.device_info()
     log("device %s, %d CUs, %.0f GB; workload %s" % (info["name"], info["cus"], info["hbm_bytes"] / 1e9, w["desc"]))
     ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
@@ -219,6 +222,7 @@ def main():
                        "parallelism": "column-partitioned x%d" % world, "damping_alpha": alpha},
             "cell_obs_per_s_solve": round(N * D * value, 1),
             "cell_obs_per_s_build": round(N * D / t_build, 1), "build_s": round(t_build, 2), "build_mode": build_mode,
+            "build_threshold_batches": {"band_select": ctx.debug_set("band_batches"), "fell_back_to_full_select": ctx.debug_set("band_fallbacks")},
             "gpu_ms_per_step_hip_events": round(ms_gpu / args.steps, 4),
             "lsqr_bytes_per_iteration_algorithmic": 16 * int(nnz_total) + 112 * N + 48 * (D + N),
             "adjoint_identity_rel_err": adj_err, "final_r": r,

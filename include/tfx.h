@@ -248,7 +248,10 @@ int tfx_profile_enable(tfx_ctx *ctx, int on);
 int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches);
 
 /* Test / diagnostics switchboard.  key "force_general_prism" (value 0/1): always use the six-array prism kernel even
- * when the grid is a tensor product; key "tensor_grid": returns 1 when the tensor-product fast path is active.       */
+ * when the grid is a tensor product; key "tensor_grid": returns 1 when the tensor-product fast path is active;
+ * key "band_select_min_cells" (value): grids of at least that many cells find the row thresholds by the sample-bracketed
+ * band select instead of the full radix select (default 2^20; < 0: never) - both give the exact order statistic;
+ * keys "band_batches" / "band_fallbacks": return how many row batches used it / fell back to the full select.        */
 int tfx_debug_set(tfx_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

@@ -1110,6 +1110,49 @@ def test_medium_synthetic_build_vs_oracle_and_adjoint_identity(ctx):
     assert np.allclose(Sx, orc.spmv(rp, cols, vals, x), rtol=0, atol=1e-12 * np.abs(Sx).max() * 10)
 
 
+@pytest.mark.parametrize("ctype,rate,expect_fallback", [(1, 0.02, False), (2, 0.1, False), (1, 0.5, False), (2, 0.9995, False),
+                                                        (1, 0.5, True)])
+def test_band_select_gives_the_same_matrix_as_the_full_select(ctx, ctype, rate, expect_fallback):
+    """Rows of >= 2^20 cells find their threshold by the sample-bracketed band select inside the compaction's count pass; it
+    must give exactly the order statistic of the full radix select: same matrix bits, nnz histogram and compression error.
+    Rows that are mostly exact zeros (column weight zero almost everywhere) have the threshold under the 1e-30 floor, which
+    the band cannot represent -> the batch falls back to the full select (same result)."""
+    nx, ny, nz, ox, oy = 64, 64, 32, 7, 6
+    grid = tfx.synthetic.grid(nx, ny, nz)
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, ox, oy)
+    ctx.set_grid(nx, ny, nz, *grid)
+    cw = ctx.calculate_depth_weight()
+    if expect_fallback:
+        cw = np.where(np.arange(cw.size) % 257 == 0, cw, 0.0)
+    out = []
+    try:
+        for min_cells in (-1, 0):
+            ctx.debug_set("band_select_min_cells", min_cells)
+            b0, f0 = ctx.debug_set("band_batches"), ctx.debug_set("band_fallbacks")
+            res = ctx.calculate_sensit(xs, ys, zs, cw, ctype, rate, want_hist=True)
+            used, fell = ctx.debug_set("band_batches") - b0, ctx.debug_set("band_fallbacks") - f0
+            out.append((res, ctx.matrix_download_csr(), used, fell))
+    finally:
+        ctx.debug_set("band_select_min_cells", 1 << 20)
+    (ra, A, used_a, _), (rb, B, used_b, fell_b) = out
+    assert used_a == 0 and used_b > 0 and (fell_b > 0) == expect_fallback
+    assert ra["nnz"] == rb["nnz"] and np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and bits_equal(A[2], B[2])
+    assert np.array_equal(ra["nnz_hist"], rb["nnz_hist"]) and ra["error_sum"] == rb["error_sum"]
+    # and in a column range with the statistics of all columns (the multi-GPU direct build)
+    N = nx * ny * nz
+    try:
+        ctx.debug_set("band_select_min_cells", 0)
+        rc = ctx.calculate_sensit(xs, ys, zs, cw, ctype, rate, col_range=(N // 3, N // 2), want_hist=True)
+        C = ctx.matrix_download_csr()
+    finally:
+        ctx.debug_set("band_select_min_cells", 1 << 20)
+    assert np.array_equal(rc["nnz_hist"], ra["nnz_hist"]) and rc["error_sum"] == ra["error_sum"]
+    for r in (0, 17, xs.size - 1):
+        sel = (A[1][A[0][r]:A[0][r + 1]] > N // 3) & (A[1][A[0][r]:A[0][r + 1]] <= N // 2)
+        assert np.array_equal(C[1][C[0][r]:C[0][r + 1]], A[1][A[0][r]:A[0][r + 1]][sel] - N // 3)
+        assert bits_equal(C[2][C[0][r]:C[0][r + 1]], A[2][A[0][r]:A[0][r + 1]][sel])
+
+
 def test_fortran_host_through_c_abi(ctx):
     """The Fortran host (tomofast-x_amd/host, amdflang + iso_c_binding) drives the same C ABI; its fingerprints must match
     the Python host on the same synthetic problem."""

@@ -143,6 +143,12 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         return 0;
     }
     if (!strcmp(key, "tensor_grid")) return ctx->tensor_grid ? 1 : 0;     // query
+    if (!strcmp(key, "band_select_min_cells")) {                           // value < 0: never use the band select
+        ctx->band_min_n = value < 0 ? INT64_MAX : (int64_t)value;
+        return 0;
+    }
+    if (!strcmp(key, "band_batches")) return (int)std::min<int64_t>(ctx->band_batches, INT32_MAX);       // queries
+    if (!strcmp(key, "band_fallbacks")) return (int)std::min<int64_t>(ctx->band_fallbacks, INT32_MAX);
     return fail(TFX_E_ARG, "unknown debug key %s", key);
 }
 

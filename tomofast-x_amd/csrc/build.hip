@@ -1247,10 +1247,11 @@ struct SelState {
     unsigned int bin, pad;
 };
 
-// digit 0 reads |row| directly; later digits read the candidate key buffer
+// from_rows: the keys are |row| itself (digit 0 of the full select); else the candidate key buffer
 __global__ __launch_bounds__(256) void k_sel_hist(const double *__restrict__ rows, int64_t N,
                                                   const unsigned long long *__restrict__ cand, int64_t cand_stride,
-                                                  const SelState *__restrict__ st, int digit, unsigned int *__restrict__ hist)
+                                                  const SelState *__restrict__ st, int digit, unsigned int *__restrict__ hist,
+                                                  int from_rows)
 {
     __shared__ unsigned int h[SEL_BINS];
     const int row = blockIdx.y;
@@ -1258,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double *__restrict__ row
     __syncthreads();
     const int shift = c_sel_shift[digit];
     const unsigned int mask = (1u << c_sel_bits[digit]) - 1u;
-    if (digit == 0) {
+    if (from_rows) {
         const double *r = rows + (int64_t)row * N;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
             const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(r[i]));
@@ -1309,7 +1310,7 @@ constexpr int SEL_STAGE = 512;
 __global__ __launch_bounds__(256) void k_sel_filter(const double *__restrict__ rows, int64_t N,
                                                     const unsigned long long *__restrict__ cand_in,
                                                     unsigned long long *__restrict__ cand_out, int64_t cand_stride,
-                                                    SelState *__restrict__ st, int digit)
+                                                    SelState *__restrict__ st, int digit, int from_rows)
 {
     __shared__ unsigned long long stage[4][SEL_STAGE];
     const int row = blockIdx.y;
@@ -1317,7 +1318,7 @@ __global__ __launch_bounds__(256) void k_sel_filter(const double *__restrict__ r
     const unsigned int mask = (1u << c_sel_bits[digit]) - 1u;
     const unsigned int bin = st[row].bin;
     unsigned long long *out = cand_out + (int64_t)row * cand_stride;
-    const int64_t n = (digit == 0) ? N : (int64_t)st[row].ncand;
+    const int64_t n = from_rows ? N : (int64_t)st[row].ncand;
     const double *r = rows + (int64_t)row * N;
     const unsigned long long *c = cand_in + (int64_t)row * cand_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1329,7 +1330,7 @@ __global__ __launch_bounds__(256) void k_sel_filter(const double *__restrict__ r
         unsigned long long key = 0;
         bool hit = false;
         if (i < n) {
-            key = (digit == 0) ? (unsigned long long)__double_as_longlong(fabs(r[i])) : c[i];
+            key = from_rows ? (unsigned long long)__double_as_longlong(fabs(r[i])) : c[i];
             hit = ((unsigned int)(key >> shift) & mask) == bin;
         }
         const unsigned long long m = __ballot(hit);
@@ -1372,13 +1373,127 @@ __global__ void k_sel_init(SelState *__restrict__ st, int nrows, unsigned long l
     if (row < nrows) { st[row].prefix = 0; st[row].rank = rank; st[row].ncand = 0; st[row].nnext = 0; st[row].bin = 0; }
 }
 
-__global__ void k_sel_result(const SelState *__restrict__ st, int nrows, double *__restrict__ thr)
+// fail != null (band select): a threshold below the 1e-30 floor means the band's "everything above hi is kept" does not hold
+__global__ void k_sel_result(const SelState *__restrict__ st, int nrows, double *__restrict__ thr, int *__restrict__ fail)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row < nrows) {
         double t = __longlong_as_double((long long)st[row].prefix);
-        if (t < 1.e-30) t = 1.e-30;                        // sensitivity_gravmag.F90:252-256
+        if (t < 1.e-30) {                                  // sensitivity_gravmag.F90:252-256
+            t = 1.e-30;
+            if (fail) atomicOr(fail, 2);
+        }
         thr[row] = t;
+    }
+}
+
+// ---- band select: bracket the order statistic from a sample, then select exactly inside the bracket -------------------------
+// The full select reads every row twice (histogram + filter of digit 0) before the candidate set is small.  Here a
+// hashed-position sample of SMP_N coefficients per row gives two sample order statistics lo <= hi that bracket the wanted
+// one with overwhelming probability; the compaction's count pass - which reads the row anyway - counts the keys above hi
+// and collects the few keys in [lo, hi]; the exact select then runs on that band only.  Rows whose band misses (or
+// overflows its buffer) make the whole batch fall back to the full select, so the result is always the exact order
+// statistic.
+constexpr int SMP_THREADS = 1024, SMP_PER = 16, SMP_N = SMP_THREADS * SMP_PER;
+constexpr int BAND_SLOTS = 2048;  // = CMP_SEG: a segment's slots hold all of it (band candidates cluster: whole planes of coarse-level
+                                  // coefficients sit near the threshold); only the used slots are ever touched
+
+struct BandRow {
+    unsigned long long lo, hi;    // key bounds of the band (inclusive)
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)      // splitmix64 finaliser
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+// one block per row: the rank_lo-th and rank_hi-th smallest of the sampled |c| (1-based; rank_lo < 1 -> lo = 0,
+// rank_hi > SMP_N -> hi = all ones), by an 8-bit radix select on register-resident keys with LDS histograms.  Bounds, not
+// values, are wanted: the select stops after SMP_DIGITS digits (sign, exponent, 20 mantissa bits) and rounds lo down / hi up.
+__global__ __launch_bounds__(SMP_THREADS) void k_sel_sample(const double *__restrict__ rows, int64_t N,
+                                                            int rank_lo, int rank_hi, BandRow *__restrict__ band)
+{
+    __shared__ unsigned int h[2][256];
+    __shared__ unsigned int wsum[2][4];
+    __shared__ unsigned long long s_prefix[2];
+    __shared__ unsigned int s_rank[2];
+    const int row = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const double *r = rows + (int64_t)row * N;
+    unsigned long long key[SMP_PER];
+#pragma unroll
+    for (int j = 0; j < SMP_PER; ++j) {
+        // hashed positions: wavelet coefficients are large on index lattices (multiples of 2^l per axis) that any regular
+        // stride would over- or under-sample
+        const unsigned long long t = (unsigned long long)(threadIdx.x + j * SMP_THREADS);
+        key[j] = (unsigned long long)__double_as_longlong(fabs(r[mix64(t) % (unsigned long long)N]));
+    }
+    if (threadIdx.x < 2) {
+        s_prefix[threadIdx.x] = 0;
+        s_rank[threadIdx.x] = (unsigned int)min(max(threadIdx.x == 0 ? rank_lo : rank_hi, 1), SMP_N);
+    }
+    constexpr int SMP_DIGITS = 4;
+    for (int d = 0; d < SMP_DIGITS; ++d) {
+        const int shift = 56 - 8 * d;
+        if (threadIdx.x < 512) h[threadIdx.x >> 8][threadIdx.x & 255] = 0;
+        __syncthreads();
+        const unsigned long long p0 = s_prefix[0], p1 = s_prefix[1];
+#pragma unroll
+        for (int j = 0; j < SMP_PER; ++j) {
+            const unsigned int dig = (unsigned int)(key[j] >> shift) & 255u;
+            const unsigned long long top = (d == 0) ? 0ull : (key[j] >> (shift + 8));
+            const bool in0 = d == 0 || top == (p0 >> (shift + 8)), in1 = d == 0 || top == (p1 >> (shift + 8));
+            // the leading digits (exponent bits) put most keys of a wave into one or two bins: count those with a ballot
+            // instead of 64 serialised same-address LDS atomics
+            bool todo0 = in0, todo1 = in1;
+            for (int it = 0; it < 2; ++it) {
+                const unsigned long long any = __ballot(todo0 || todo1);
+                if (!any) break;
+                const unsigned int d0 = (unsigned int)__builtin_amdgcn_readlane((int)dig, (int)__builtin_ctzll(any));
+                const unsigned long long m0 = __ballot(todo0 && dig == d0), m1 = __ballot(todo1 && dig == d0);
+                if (lane == 0) {
+                    if (m0) atomicAdd(&h[0][d0], (unsigned int)__popcll(m0));
+                    if (m1) atomicAdd(&h[1][d0], (unsigned int)__popcll(m1));
+                }
+                if (dig == d0) { todo0 = false; todo1 = false; }
+            }
+            if (todo0) atomicAdd(&h[0][dig], 1u);
+            if (todo1) atomicAdd(&h[1][dig], 1u);
+        }
+        __syncthreads();
+        // pick the bin of each chain: inclusive scan of its 256 counts by 256 threads (4 waves)
+        unsigned int cntv = 0, incl = 0, rank = 0;
+        const int c = threadIdx.x >> 8, bin = threadIdx.x & 255;
+        if (threadIdx.x < 512) {
+            rank = s_rank[c];
+            cntv = h[c][bin];
+            incl = cntv;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            if (lane == 63) wsum[c][(threadIdx.x >> 6) & 3] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 512) {
+            const int w = (threadIdx.x >> 6) & 3;
+            for (int i = 0; i < w; ++i) incl += wsum[c][i];
+            if (incl >= rank && incl - cntv < rank) {          // exactly one bin per chain (1 <= rank <= SMP_N)
+                s_rank[c] = rank - (incl - cntv);
+                s_prefix[c] |= ((unsigned long long)bin) << shift;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        BandRow br;
+        br.lo = rank_lo < 1 ? 0ull : s_prefix[0];
+        br.hi = rank_hi > SMP_N ? ~0ull : (s_prefix[1] | ((1ull << (64 - 8 * SMP_DIGITS)) - 1ull));
+        band[row] = br;
     }
 }
 
@@ -1390,6 +1505,18 @@ struct SelectWork {
     int64_t cap_N = 0;
 };
 
+static int select_prepare(SelectWork &wk, int nrows, int64_t N)
+{
+    if (wk.cap_rows >= nrows && wk.cap_N >= N) return 0;
+    TFX_TRY(wk.st.alloc(nrows));
+    TFX_TRY(wk.hist.alloc((size_t)nrows * SEL_BINS));
+    TFX_TRY(wk.candA.alloc((size_t)nrows * N));
+    TFX_TRY(wk.candB.alloc((size_t)nrows * N));
+    wk.cap_rows = nrows;
+    wk.cap_N = N;
+    return 0;
+}
+
 // thr[row] for nrows rows of N coefficients; K = entries to keep
 int select_threshold_dev(tfx_ctx *ctx, SelectWork &wk, const double *d_rows, int nrows, int64_t N, int64_t K, double *d_thr)
 {
@@ -1400,28 +1527,21 @@ int select_threshold_dev(tfx_ctx *ctx, SelectWork &wk, const double *d_rows, int
         TFX_HIP(hipStreamSynchronize(s));
         return 0;
     }
-    if (wk.cap_rows < nrows || wk.cap_N < N) {
-        TFX_TRY(wk.st.alloc(nrows));
-        TFX_TRY(wk.hist.alloc((size_t)nrows * SEL_BINS));
-        TFX_TRY(wk.candA.alloc((size_t)nrows * N));
-        TFX_TRY(wk.candB.alloc((size_t)nrows * N));
-        wk.cap_rows = nrows;
-        wk.cap_N = N;
-    }
+    TFX_TRY(select_prepare(wk, nrows, N));
     TFX_HIP(hipMemsetAsync(wk.hist.p, 0, (size_t)nrows * SEL_BINS * sizeof(unsigned int), s));
     hipLaunchKernelGGL(k_sel_init, dim3((nrows + 63) / 64), dim3(64), 0, s, wk.st.p, nrows, (unsigned long long)(N - K));
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->num_cu * 4 / std::max(1, nrows) + 1, (N + 255) / 256));
     unsigned long long *in = wk.candA.p, *out = wk.candB.p;
     for (int d = 0; d < SEL_NDIG; ++d) {
-        hipLaunchKernelGGL(k_sel_hist, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, wk.cap_N, wk.st.p, d, wk.hist.p);
+        hipLaunchKernelGGL(k_sel_hist, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, wk.cap_N, wk.st.p, d, wk.hist.p, d == 0);
         hipLaunchKernelGGL(k_sel_pick, dim3(nrows), dim3(256), 0, s, wk.st.p, wk.hist.p, d);
         if (d + 1 < SEL_NDIG) {
-            hipLaunchKernelGGL(k_sel_filter, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, out, wk.cap_N, wk.st.p, d);
+            hipLaunchKernelGGL(k_sel_filter, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, out, wk.cap_N, wk.st.p, d, d == 0);
             hipLaunchKernelGGL(k_sel_advance, dim3((nrows + 63) / 64), dim3(64), 0, s, wk.st.p, nrows);
             std::swap(in, out);
         }
     }
-    hipLaunchKernelGGL(k_sel_result, dim3((nrows + 63) / 64), dim3(64), 0, s, wk.st.p, nrows, d_thr);
+    hipLaunchKernelGGL(k_sel_result, dim3((nrows + 63) / 64), dim3(64), 0, s, wk.st.p, nrows, d_thr, (int *)nullptr);
     TFX_HIP(hipGetLastError());
     return 0;
 }
@@ -1444,7 +1564,7 @@ struct CompactArgs {
     int32_t *seg_all;         // [nrows][nseg] kept over all columns
     int32_t *seg_off;         // [nrows][nseg] exclusive scan
     double *seg_cost;         // [nrows][nseg] sum of discarded^2
-    int32_t *out_cols;        // [.. ][stride]
+    int32_t *out_cols;        // [.. ][stride] (null: statistics only)
     float *out_vals;
     int64_t out_stride;
     int32_t *nel;             // [nrows] kept in range, per line
@@ -1454,45 +1574,178 @@ struct CompactArgs {
     double *cost_disc;        // [nrows]
     const float *scale;       // [nrows] (float)(problem_weight*data_weight)   (:841)
     int32_t *hist;            // [N] per-column nnz (sensit_nnz, :267) or null
+    // band select (null band: thr is final when the count pass runs)
+    const BandRow *band;      // [nrows]
+    unsigned long long *slot_keys;    // [nrows][nseg][BAND_SLOTS] keys of the band candidates of each segment
+    uint16_t *slot_pos;       // ... and their position inside the segment
+    int32_t *seg_band;        // [nrows][nseg] band candidates found (> BAND_SLOTS: overflow)
+    int32_t *seg_boff;        // [nrows][nseg] exclusive scan of seg_band
+    unsigned long long *band_keys;    // [nrows][key_stride] dense keys for the select
+    int64_t key_stride;
+    SelState *st;
+    unsigned long long K;
+    int *fail;                // set when a band missed: the write pass leaves everything untouched, the batch is redone
 };
 
 __device__ __forceinline__ bool keep_elem(double v, double thr, int keep_all) { return keep_all || fabs(v) > thr; }
 
 // A block owns CMP_SEG = 8 x 256 consecutive elements; thread t reads elements base + k*256 + t (coalesced).
+// Counts the kept elements of the segment.  With a band (threshold not known yet): counts the keys above band.hi and
+// stores the keys inside [band.lo, band.hi] with their positions in the segment's own slots (no atomics).
 __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
 {
     const int row = blockIdx.y, seg = blockIdx.x;
     const double *r = a.rows + (int64_t)row * a.N;
-    const double thr = a.thr[row];
+    const bool banded = a.band != nullptr;
+    const double thr = banded ? 0.0 : a.thr[row];
+    const unsigned long long lo = banded ? a.band[row].lo : 0ull, hi = banded ? a.band[row].hi : 0ull;
     const int64_t base = (int64_t)seg * CMP_SEG + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = CMP_THREADS / 64;
+    __shared__ int wcnt[CMP_PER_THREAD * NW];
     int cnt = 0, cnt_all = 0;
-    double cost = 0.0;
+    unsigned long long bkey[CMP_PER_THREAD];
+    int lpre[CMP_PER_THREAD];
+    unsigned bandmask = 0;
 #pragma unroll
     for (int k = 0; k < CMP_PER_THREAD; ++k) {
         const int64_t p = base + (int64_t)k * CMP_THREADS;
+        bool inband = false;
+        bkey[k] = 0;
         if (p < a.N) {
             const double v = r[p];
-            if (keep_elem(v, thr, a.keep_all)) {
+            bool keep;
+            if (banded) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(v));
+                keep = key > hi;
+                inband = !keep && key >= lo;
+                bkey[k] = key;
+            } else keep = keep_elem(v, thr, a.keep_all);
+            if (keep) {
                 cnt_all += 1;
                 if (p >= a.col_begin && p < a.col_end) cnt += 1;
-                if (a.hist) atomicAdd(&a.hist[p], 1);
-            } else cost = fma(v, v, cost);
+            }
+        }
+        if (banded) {
+            const unsigned long long m = __ballot(inband);
+            lpre[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (inband) bandmask |= 1u << k;
+            if (lane == 0) wcnt[k * NW + wave] = __popcll(m);
         }
     }
-    __shared__ int s_cnt[CMP_THREADS / 64], s_all[CMP_THREADS / 64];
-    __shared__ double s_cost[CMP_THREADS / 64];
+    __shared__ int s_cnt[NW], s_all[NW];
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); cnt_all += __shfl_down(cnt_all, d); cost += __shfl_down(cost, d); }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { s_cnt[wave] = cnt; s_all[wave] = cnt_all; s_cost[wave] = cost; }
+    for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); cnt_all += __shfl_down(cnt_all, d); }
+    if (lane == 0) { s_cnt[wave] = cnt; s_all[wave] = cnt_all; }
     __syncthreads();
+    const int64_t sg = (int64_t)row * a.nseg + seg;
     if (threadIdx.x == 0) {
         int c = 0, ca = 0;
-        double cs = 0.0;
-        for (int i = 0; i < CMP_THREADS / 64; ++i) { c += s_cnt[i]; ca += s_all[i]; cs += s_cost[i]; }
-        a.seg_cnt[(int64_t)row * a.nseg + seg] = c;
-        a.seg_all[(int64_t)row * a.nseg + seg] = ca;
-        a.seg_cost[(int64_t)row * a.nseg + seg] = cs;
+        for (int i = 0; i < NW; ++i) { c += s_cnt[i]; ca += s_all[i]; }
+        a.seg_cnt[sg] = c;
+        a.seg_all[sg] = ca;
+        if (banded) {
+            int run = 0;
+            for (int i = 0; i < CMP_PER_THREAD * NW; ++i) { const int w = wcnt[i]; wcnt[i] = run; run += w; }
+            a.seg_band[sg] = run;
+        }
+    }
+    if (!banded) return;
+    __syncthreads();
+    if (bandmask) {
+        unsigned long long *bk = a.slot_keys + sg * BAND_SLOTS;
+        uint16_t *bp = a.slot_pos + sg * BAND_SLOTS;
+#pragma unroll
+        for (int k = 0; k < CMP_PER_THREAD; ++k)
+            if (bandmask & (1u << k)) {
+                const int pos = wcnt[k * NW + wave] + lpre[k];
+                if (pos < BAND_SLOTS) {
+                    bk[pos] = bkey[k];
+                    bp[pos] = (uint16_t)(k * CMP_THREADS + threadIdx.x);
+                }
+            }
+    }
+}
+
+// one block per row, after the count pass: band size B and keys above (G); does the band hold the wanted order statistic
+// (and did every segment fit its slots)?  Offsets of the segments' candidates in the dense key list; select state.
+__global__ void k_band_scan(CompactArgs a)
+{
+    const int row = blockIdx.x;
+    __shared__ long long part[256], gpart[256];
+    __shared__ int s_over;
+    const int per = (a.nseg + 255) / 256;
+    const int b = threadIdx.x * per, e = min(b + per, a.nseg);
+    if (threadIdx.x == 0) s_over = 0;
+    __syncthreads();
+    long long sb = 0, sgv = 0;
+    bool over = false;
+    for (int i = b; i < e; ++i) {
+        const int nb = a.seg_band[(int64_t)row * a.nseg + i];
+        over |= nb > BAND_SLOTS;
+        sb += nb;
+        sgv += a.seg_all[(int64_t)row * a.nseg + i];
+    }
+    part[threadIdx.x] = sb;
+    gpart[threadIdx.x] = sgv;
+    if (over) s_over = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0, G = 0;
+        for (int i = 0; i < 256; ++i) { const long long v = part[i]; part[i] = run; run += v; G += gpart[i]; }
+        const unsigned long long B = (unsigned long long)run, N = (unsigned long long)a.N;
+        const unsigned long long below = N - (unsigned long long)G - B, r = N - a.K;    // r: 1-based ascending rank of the threshold (:240-250)
+        const bool ok = !s_over && B <= (unsigned long long)a.key_stride && below < r && r <= below + B;
+        a.st[row].prefix = 0;
+        a.st[row].rank = ok ? r - below : 1;
+        a.st[row].ncand = ok ? B : 0;
+        a.st[row].nnext = 0;
+        a.st[row].bin = 0;
+        if (!ok) atomicOr(a.fail, 1);
+    }
+    __syncthreads();
+    long long run = part[threadIdx.x];
+    for (int i = b; i < e; ++i) {
+        a.seg_boff[(int64_t)row * a.nseg + i] = (int32_t)min(run, (long long)INT32_MAX);
+        run += a.seg_band[(int64_t)row * a.nseg + i];
+    }
+}
+
+// slots -> dense key list of the row (one wave per segment)
+__global__ __launch_bounds__(256) void k_band_gather(CompactArgs a)
+{
+    const int row = blockIdx.y, seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg >= a.nseg || a.st[row].ncand == 0) return;
+    const int64_t sg = (int64_t)row * a.nseg + seg;
+    const int n = a.seg_band[sg];
+    const unsigned long long *bk = a.slot_keys + sg * BAND_SLOTS;
+    unsigned long long *out = a.band_keys + (int64_t)row * a.key_stride + a.seg_boff[sg];
+    for (int i = lane; i < n; i += 64) out[i] = bk[i];
+}
+
+// band candidates above the final threshold join their segment's counts (one wave per segment, owner adds: no atomics)
+__global__ __launch_bounds__(256) void k_band_fix(CompactArgs a)
+{
+    const int row = blockIdx.y, seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg >= a.nseg) return;
+    const int64_t sg = (int64_t)row * a.nseg + seg;
+    const int n = min(a.seg_band[sg], BAND_SLOTS);
+    const double thr = a.thr[row];
+    const unsigned long long *bk = a.slot_keys + sg * BAND_SLOTS;
+    const uint16_t *bp = a.slot_pos + sg * BAND_SLOTS;
+    int cnt = 0, cnt_all = 0;
+    for (int i = lane; i < n; i += 64) {
+        if (__longlong_as_double((long long)bk[i]) > thr) {                 // |v| > thr (keep_elem)
+            const int64_t p = (int64_t)seg * CMP_SEG + bp[i];
+            cnt_all += 1;
+            if (p >= a.col_begin && p < a.col_end) cnt += 1;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); cnt_all += __shfl_down(cnt_all, d); }
+    if (lane == 0 && cnt_all) {
+        a.seg_all[sg] += cnt_all;
+        a.seg_cnt[sg] += cnt;
     }
 }
 
@@ -1501,35 +1754,51 @@ __global__ void k_cmp_scan(CompactArgs a)
 {
     const int row = blockIdx.x;
     __shared__ int part[256], apart[256];
-    __shared__ double cpart[256];
     const int per = (a.nseg + 255) / 256;
     const int b = threadIdx.x * per, e = min(b + per, a.nseg);
     int s = 0, sa = 0;
-    double cs = 0.0;
     for (int i = b; i < e; ++i) {
         s += a.seg_cnt[(int64_t)row * a.nseg + i];
         sa += a.seg_all[(int64_t)row * a.nseg + i];
-        cs += a.seg_cost[(int64_t)row * a.nseg + i];
     }
     part[threadIdx.x] = s;
     apart[threadIdx.x] = sa;
-    cpart[threadIdx.x] = cs;
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0, arun = 0;
-        double crun = 0.0;
-        for (int i = 0; i < 256; ++i) { int v = part[i]; part[i] = run; run += v; arun += apart[i]; crun += cpart[i]; }
+        for (int i = 0; i < 256; ++i) { int v = part[i]; part[i] = run; run += v; arun += apart[i]; }
         a.nel[row] = run;
         a.nel_all[row] = arun;
-        a.cost_disc[row] = crun;
     }
     __syncthreads();
     int run = part[threadIdx.x];
     for (int i = b; i < e; ++i) { a.seg_off[(int64_t)row * a.nseg + i] = run; run += a.seg_cnt[(int64_t)row * a.nseg + i]; }
 }
 
+// one block per row: discarded energy of the row = sum of the segment sums (fixed order)
+__global__ void k_cmp_cost(CompactArgs a)
+{
+    if (a.fail && *a.fail) return;
+    const int row = blockIdx.x;
+    __shared__ double cpart[256];
+    const int per = (a.nseg + 255) / 256;
+    const int b = threadIdx.x * per, e = min(b + per, a.nseg);
+    double cs = 0.0;
+    for (int i = b; i < e; ++i) cs += a.seg_cost[(int64_t)row * a.nseg + i];
+    cpart[threadIdx.x] = cs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double crun = 0.0;
+        for (int i = 0; i < 256; ++i) crun += cpart[i];
+        a.cost_disc[row] = crun;
+    }
+}
+
+// second pass over the row: writes the kept in-range entries at their final positions, adds the kept columns to the nnz
+// histogram and sums the discarded energy of the segment (:258-283)
 __global__ __launch_bounds__(CMP_THREADS) void k_cmp_write(CompactArgs a)
 {
+    if (a.fail && *a.fail) return;
     const int row = blockIdx.y, seg = blockIdx.x;
     const double *r = a.rows + (int64_t)row * a.N;
     const double thr = a.thr[row];
@@ -1538,28 +1807,40 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_write(CompactArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = CMP_THREADS / 64;
     __shared__ int wcnt[CMP_PER_THREAD * NW];           // kept count of (sub-block k, wave w), column order = (k, w, lane)
+    __shared__ double s_cost[NW];
     double v[CMP_PER_THREAD];
     int lpre[CMP_PER_THREAD];
     unsigned keepmask = 0;
+    double cost = 0.0;
 #pragma unroll
     for (int k = 0; k < CMP_PER_THREAD; ++k) {
         const int64_t p = base + (int64_t)k * CMP_THREADS;
         v[k] = 0.0;
         bool keep = false;
-        if (p < a.N && p >= a.col_begin && p < a.col_end) {
+        if (p < a.N) {
             v[k] = r[p];
-            keep = keep_elem(v[k], thr, a.keep_all);
+            if (keep_elem(v[k], thr, a.keep_all)) {
+                if (a.hist) atomicAdd(&a.hist[p], 1);
+                keep = p >= a.col_begin && p < a.col_end;
+            } else cost = fma(v[k], v[k], cost);
         }
         const unsigned long long m = __ballot(keep);
         lpre[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
         if (keep) keepmask |= 1u << k;
         if (lane == 0) wcnt[k * NW + wave] = __popcll(m);
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cost += __shfl_down(cost, d);
+    if (lane == 0) s_cost[wave] = cost;
     __syncthreads();
     if (threadIdx.x == 0) {                              // exclusive scan of the 32 (k, w) counts
         int run = 0;
         for (int i = 0; i < CMP_PER_THREAD * NW; ++i) { const int c = wcnt[i]; wcnt[i] = run; run += c; }
+        double cs = 0.0;
+        for (int i = 0; i < NW; ++i) cs += s_cost[i];
+        a.seg_cost[(int64_t)row * a.nseg + seg] = cs;
     }
+    if (!a.out_cols) return;
     __syncthreads();
     int segoff = a.seg_off[(int64_t)row * a.nseg + seg];
     const int comp = row % a.ncm, mrow = row / a.ncm;
@@ -1609,12 +1890,42 @@ __global__ void k_fill_i32(int32_t *__restrict__ p, int64_t n, int32_t v)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] += v;
 }
 
+// per-line statistics of a batch packed for one device -> host copy: [cost_full, cost_disc] doubles, then [nel_all, nel] ints, fail
+struct BatchStat { double cost_full, cost_disc; int32_t nel_all, nel; };
+__global__ void k_pack_stats(int n, const double *__restrict__ cost_full, const double *__restrict__ cost_disc,
+                             const int32_t *__restrict__ nel_all, const int32_t *__restrict__ nel, const int *__restrict__ fail,
+                             BatchStat *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        BatchStat b;
+        b.cost_full = cost_full ? cost_full[i] : 0.0;
+        b.cost_disc = cost_disc[i];
+        b.nel_all = nel_all[i];
+        b.nel = nel[i];
+        out[i] = b;
+    }
+    if (i == 0) {                                  // the fail flag rides in an extra record
+        BatchStat b;
+        b.cost_full = b.cost_disc = 0.0;
+        b.nel_all = *fail;
+        b.nel = 0;
+        out[n] = b;
+    }
+}
+
 struct CompactWork {
     DBuf<int32_t> seg_cnt, seg_all, seg_off, nel, nel_all;
     DBuf<double> seg_cost, cost_disc, thr, red;
     DBuf<float> scale;
     int cap_rows = 0;
     int nseg = 0;
+    // band select
+    DBuf<BandRow> band;
+    DBuf<unsigned long long> slot_keys;
+    DBuf<uint16_t> slot_pos;
+    DBuf<int32_t> seg_band, seg_boff;
+    DBuf<int> fail;
 };
 
 static int compact_prepare(CompactWork &cw, int nrows, int64_t N)
@@ -1631,16 +1942,42 @@ static int compact_prepare(CompactWork &cw, int nrows, int64_t N)
     TFX_TRY(cw.thr.alloc(nrows));
     TFX_TRY(cw.scale.alloc(nrows));
     TFX_TRY(cw.red.alloc((size_t)nrows * 256));
+    TFX_TRY(cw.fail.alloc(1));
     cw.cap_rows = nrows;
     cw.nseg = nseg;
     return 0;
 }
 
+static int band_prepare(CompactWork &cw, int nrows)
+{
+    const size_t nsl = (size_t)nrows * cw.nseg;
+    if (cw.band.n >= (size_t)nrows && cw.seg_band.n >= nsl) return 0;
+    TFX_TRY(cw.band.alloc(nrows));
+    TFX_TRY(cw.slot_keys.alloc(nsl * BAND_SLOTS));
+    TFX_TRY(cw.slot_pos.alloc(nsl * BAND_SLOTS));
+    TFX_TRY(cw.seg_band.alloc(nsl));
+    TFX_TRY(cw.seg_boff.alloc(nsl));
+    return 0;
+}
+
+// Sample ranks that bracket the (N-K)-th smallest of N with a miss probability of ~1e-5 per row (4.5 sigma of the
+// binomial count of sample points below the threshold, + 2 for the rounding of the ranks).
+static void band_sample_ranks(int64_t N, int64_t K, int *rank_lo, int *rank_hi)
+{
+    const double p = (double)(N - K) / (double)N;
+    const double mid = p * SMP_N, m = 4.5 * std::sqrt(SMP_N * p * (1.0 - p)) + 2.0;
+    *rank_lo = (int)std::floor(mid - m);
+    *rank_hi = (int)std::ceil(mid + m) + 1;
+}
+
 // lines [nrows][N] (device) -> out_cols/out_vals matrix rows (stride; ncm consecutive lines form one row),
-// d_nel_out[nrows/ncm] entries per matrix row; per-line nel / nel_all / cost_disc stay in cw
+// d_nel_out[nrows/ncm] entries per matrix row; per-line nel / nel_all / cost_disc stay in cw.
+// sel == null: cw.thr holds the thresholds.  sel != null (band select, K < N): the thresholds are found on the way - cw.thr
+// is written, and *cw.fail != 0 afterwards means a band missed: nothing was written, redo the batch with the full select.
 static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int nrows, int64_t N, int keep_all,
                        int64_t col_begin, int64_t col_end, int32_t *out_cols, float *out_vals, int64_t out_stride,
-                       int32_t *d_nel_out, const float *d_scale, int32_t *d_hist, int ncm = 1)
+                       int32_t *d_nel_out, const float *d_scale, int32_t *d_hist, int ncm = 1, SelectWork *sel = nullptr,
+                       int64_t K = 0)
 {
     hipStream_t s = ctx->stream;
     CompactArgs a{};
@@ -1648,9 +1985,40 @@ static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int 
     a.nseg = cw.nseg; a.seg_cnt = cw.seg_cnt.p; a.seg_all = cw.seg_all.p; a.seg_off = cw.seg_off.p; a.seg_cost = cw.seg_cost.p;
     a.out_cols = out_cols; a.out_vals = out_vals; a.out_stride = out_stride; a.nel = cw.nel.p; a.nel_all = cw.nel_all.p;
     a.cost_disc = cw.cost_disc.p; a.scale = d_scale; a.hist = d_hist; a.ncm = ncm; a.comp_stride = col_end - col_begin;
-    hipLaunchKernelGGL(k_cmp_count, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+    TFX_HIP(hipMemsetAsync(cw.fail.p, 0, sizeof(int), s));
+    if (sel) {
+        TFX_TRY(select_prepare(*sel, nrows, N));
+        TFX_TRY(band_prepare(cw, nrows));
+        int rank_lo, rank_hi;
+        band_sample_ranks(N, K, &rank_lo, &rank_hi);
+        hipLaunchKernelGGL(k_sel_sample, dim3(nrows), dim3(SMP_THREADS), 0, s, d_rows, N, rank_lo, rank_hi, cw.band.p);
+        a.band = cw.band.p; a.slot_keys = cw.slot_keys.p; a.slot_pos = cw.slot_pos.p; a.seg_band = cw.seg_band.p;
+        a.seg_boff = cw.seg_boff.p; a.band_keys = sel->candA.p; a.key_stride = sel->cap_N; a.st = sel->st.p;
+        a.K = (unsigned long long)K; a.fail = cw.fail.p;
+        hipLaunchKernelGGL(k_cmp_count, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_band_scan, dim3(nrows), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_band_gather, dim3((cw.nseg + 3) / 4, nrows), dim3(256), 0, s, a);
+        // exact select inside the band (dense keys in candA)
+        TFX_HIP(hipMemsetAsync(sel->hist.p, 0, (size_t)nrows * SEL_BINS * sizeof(unsigned int), s));
+        const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->num_cu * 4 / std::max(1, nrows) + 1, (N / 64 + 255) / 256));
+        unsigned long long *in = sel->candA.p, *out = sel->candB.p;
+        for (int d = 0; d < SEL_NDIG; ++d) {
+            hipLaunchKernelGGL(k_sel_hist, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, sel->cap_N, sel->st.p, d, sel->hist.p, 0);
+            hipLaunchKernelGGL(k_sel_pick, dim3(nrows), dim3(256), 0, s, sel->st.p, sel->hist.p, d);
+            if (d + 1 < SEL_NDIG) {
+                hipLaunchKernelGGL(k_sel_filter, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, out, sel->cap_N, sel->st.p, d, 0);
+                hipLaunchKernelGGL(k_sel_advance, dim3((nrows + 63) / 64), dim3(64), 0, s, sel->st.p, nrows);
+                std::swap(in, out);
+            }
+        }
+        hipLaunchKernelGGL(k_sel_result, dim3((nrows + 63) / 64), dim3(64), 0, s, sel->st.p, nrows, cw.thr.p, cw.fail.p);
+        hipLaunchKernelGGL(k_band_fix, dim3((cw.nseg + 3) / 4, nrows), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_cmp_count, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+    }
     hipLaunchKernelGGL(k_cmp_scan, dim3(nrows), dim3(256), 0, s, a);
-    if (out_cols) hipLaunchKernelGGL(k_cmp_write, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_cmp_write, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_cmp_cost, dim3(nrows), dim3(256), 0, s, a);
     if (d_nel_out) hipLaunchKernelGGL(k_merge_nel, dim3((nrows / ncm + 63) / 64), dim3(64), 0, s, cw.nel.p, ncm, nrows / ncm, d_nel_out);
     TFX_HIP(hipGetLastError());
     return 0;
@@ -2004,10 +2372,15 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     TFX_TRY(compact_prepare(cw, lines_max, N));
     double err_sum = 0.0;
     int64_t nnz_total = 0;
-    std::vector<double> h_red(lines_max), h_cd(lines_max);
-    std::vector<int32_t> h_nel(lines_max), h_nel_all(lines_max);
+    DBuf<BatchStat> dstat;
+    TFX_TRY(dstat.alloc(lines_max + 1));
+    BatchStat *h_stat = nullptr;                                    // pinned: one asynchronous copy per batch
+    TFX_HIP(hipHostMalloc((void **)&h_stat, (size_t)(lines_max + 1) * sizeof(BatchStat)));
+    struct PinnedFree { void *p; ~PinnedFree() { (void)hipHostFree(p); } } h_stat_guard{h_stat};
     int fill = 0;                 // finished rows waiting in the staging area
     int64_t r0 = 0;               // first matrix row of the staging area
+    bool band_off = false;
+    const int64_t batches0 = ctx->band_batches, fallbacks0 = ctx->band_fallbacks;
     for (int64_t g = 0; g < ndata;) {
         // just enough observations to complete the current row block (so that with one data component blocks never straddle)
         const int64_t want = ((int64_t)RB - fill + ncd - 1) / ncd;
@@ -2015,33 +2388,46 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         const int nl = nb * nsub;                                   // lines of this batch
         TFX_TRY(prism_rows_dev(ctx, gen, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p,
                                compression_type > 0 ? dred.p : nullptr));
+        // threshold: bracketed from a sample and finished inside the compaction's count pass (band select) for large rows,
+        // else the full radix select up front
+        const bool banded = compression_type > 0 && K < N && K > 0 && N >= ctx->band_min_n && !band_off;
         if (compression_type > 0) {
             hipLaunchKernelGGL(k_rows_final_sum, dim3(nl), dim3(256), 0, s, dred.p, npart, dcf.p);                  // cost_full :234
             TFX_HIP(hipGetLastError());
             TFX_TRY(wavelet_dev(ctx, drows.p, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1));                   // :237
-            TFX_TRY(select_threshold_dev(ctx, sw, drows.p, nl, N, K, cw.thr.p));                                      // :240-256
+            if (!banded) TFX_TRY(select_threshold_dev(ctx, sw, drows.p, nl, N, K, cw.thr.p));                         // :240-256
         }
-        if (to_rs)
-            TFX_TRY(compact_dev(ctx, cw, drows.p, nl, N, 0, 0, N, rs->cols.p + (size_t)(g * ncd) * rs->stride,
-                                rs->vals.p + (size_t)(g * ncd) * rs->stride, rs->stride, rs->nel.p + g * ncd, dscale.p + g * nsub,
-                                nnz_hist_out ? dhist.p : nullptr, 1));
-        else
-            TFX_TRY(compact_dev(ctx, cw, drows.p, nl, N, compression_type == 0, col_begin, col_end,
-                                keep_matrix ? ell_cols.p + (size_t)fill * stride : nullptr,
-                                keep_matrix ? ell_vals.p + (size_t)fill * stride : nullptr, stride, ell_nel.p + fill,
-                                dscale.p + g * nsub, nnz_hist_out ? dhist.p : nullptr, ncm));
-        // per-line statistics
-        TFX_HIP(hipMemcpyAsync(h_nel_all.data(), cw.nel_all.p, nl * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        TFX_HIP(hipMemcpyAsync(h_nel.data(), cw.nel.p, nl * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        if (compression_type > 0) {
-            TFX_HIP(hipMemcpyAsync(h_red.data(), dcf.p, (size_t)nl * sizeof(double), hipMemcpyDeviceToHost, s));
-            TFX_HIP(hipMemcpyAsync(h_cd.data(), cw.cost_disc.p, nl * sizeof(double), hipMemcpyDeviceToHost, s));
+        int h_fail = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            SelectWork *sel = (banded && attempt == 0) ? &sw : nullptr;
+            if (attempt == 1) TFX_TRY(select_threshold_dev(ctx, sw, drows.p, nl, N, K, cw.thr.p));     // a band missed: full select
+            if (to_rs)
+                TFX_TRY(compact_dev(ctx, cw, drows.p, nl, N, 0, 0, N, rs->cols.p + (size_t)(g * ncd) * rs->stride,
+                                    rs->vals.p + (size_t)(g * ncd) * rs->stride, rs->stride, rs->nel.p + g * ncd, dscale.p + g * nsub,
+                                    nnz_hist_out ? dhist.p : nullptr, 1, sel, K));
+            else
+                TFX_TRY(compact_dev(ctx, cw, drows.p, nl, N, compression_type == 0, col_begin, col_end,
+                                    keep_matrix ? ell_cols.p + (size_t)fill * stride : nullptr,
+                                    keep_matrix ? ell_vals.p + (size_t)fill * stride : nullptr, stride, ell_nel.p + fill,
+                                    dscale.p + g * nsub, nnz_hist_out ? dhist.p : nullptr, ncm, sel, K));
+            // per-line statistics
+            hipLaunchKernelGGL(k_pack_stats, dim3((nl + 63) / 64), dim3(64), 0, s, nl, compression_type > 0 ? dcf.p : nullptr,
+                               cw.cost_disc.p, cw.nel_all.p, cw.nel.p, cw.fail.p, dstat.p);
+            TFX_HIP(hipMemcpyAsync(h_stat, dstat.p, (size_t)(nl + 1) * sizeof(BatchStat), hipMemcpyDeviceToHost, s));
+            TFX_HIP(hipStreamSynchronize(s));
+            h_fail = h_stat[nl].nel_all;
+            if (sel) {
+                ctx->band_batches += 1;
+                if (h_fail) ctx->band_fallbacks += 1;
+                // a sample that keeps missing (rows the pseudo-random positions do not represent): stop trying
+                if (ctx->band_batches - batches0 >= 8 && 4 * (ctx->band_fallbacks - fallbacks0) > ctx->band_batches - batches0) band_off = true;
+            }
+            if (!h_fail) break;
         }
-        TFX_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < nl; ++i) {
-            if (h_nel_all[i] > K) return fail(TFX_E_NUMERIC, "Wrong number of elements in calculate_and_write_sensit!");   // :275-277
-            if (compression_type > 0) err_sum += std::sqrt(h_cd[i] / h_red[i]);                                          // :283
-            nnz_total += h_nel[i];
+            if (h_stat[i].nel_all > K) return fail(TFX_E_NUMERIC, "Wrong number of elements in calculate_and_write_sensit!");   // :275-277
+            if (compression_type > 0) err_sum += std::sqrt(h_stat[i].cost_disc / h_stat[i].cost_full);                     // :283
+            nnz_total += h_stat[i].nel;
         }
         g += nb;
         fill += nb * ncd;

@@ -139,6 +139,8 @@ struct tfx_ctx {
     tfx::DBuf<double> edges[3];       // xe[nx+1], ye[ny+1], ze[nz+1] when the grid is a tensor product
     bool tensor_grid = false;
     bool force_general_prism = false; // tests: always use the six-array kernel
+    int64_t band_min_n = 1 << 20;      // rows of at least this many cells find their threshold by the band select (build.hip)
+    int64_t band_batches = 0, band_fallbacks = 0;   // batches that used it / that fell back to the full select
     // matrix S and (optional) general constraint matrix C
     tfx::TiledMatrix mat;
     tfx::TiledMatrix mat2;             // second problem of a joint inversion: S = blockdiag(mat, mat2)  (joint_inverse_problem.F90:712-739)
