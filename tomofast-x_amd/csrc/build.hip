@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
 {
     __shared__ double T[PT_NODES];
     __shared__ double s_w[4];
+    // the node / cell index arithmetic does not depend on the observation: done once per workgroup, kept in LDS
+    __shared__ double s_xe[PT_X + 1], s_ye[PT_Y + 1], s_ze[PT_Z + 1];
+    __shared__ int s_node[PT_NODES];                      // LDS slot | a << 12 | b << 18 | c << 22
     const int tiles_x = (nx + PT_X - 1) / PT_X, tiles_y = (ny + PT_Y - 1) / PT_Y;
     const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
     const int i0 = bx * PT_X, j0 = by * PT_Y, k0 = bz * PT_Z;
@@ -121,18 +124,46 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
     const int64_t N = (int64_t)nx * ny * nz;
     const int nnode = (cx + 1) * (cy + 1) * (cz + 1);
     const int ncell = cx * cy * cz;
+    for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
+        const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
+        s_node[n] = ((c * (PT_Y + 1) + b) * (PT_X + 1) + a) | (a << 12) | (b << 18) | (c << 22);
+    }
+    if (threadIdx.x <= cx) s_xe[threadIdx.x] = xe[i0 + threadIdx.x];
+    if (threadIdx.x <= cy) s_ye[threadIdx.x] = ye[j0 + threadIdx.x];
+    if (threadIdx.x <= cz) s_ze[threadIdx.x] = ze[k0 + threadIdx.x];
+    // cells of this thread: q = threadIdx.x + 256 j; LDS slot of the (0, 0, 0) node and the column, observation-independent
+    constexpr int CPT = PT_X * PT_Y * PT_Z / 256;
+    int c_slot[CPT];
+    int64_t c_col[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int q = threadIdx.x + 256 * j;
+        c_slot[j] = -1;
+        c_col[j] = 0;
+        if (q < ncell) {
+            const int a = q % cx, b = (q / cx) % cy, c = q / (cx * cy);
+            c_slot[j] = (c * (PT_Y + 1) + b) * (PT_X + 1) + a;
+            c_col[j] = ((int64_t)(k0 + c) * ny + (j0 + b)) * nx + (i0 + a);
+        }
+    }
+    double c_w[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) c_w[j] = (cw && c_slot[j] >= 0) ? cw[c_col[j]] : 1.0;
     int bad = 0;
     for (int o = 0; o < nobs; ++o) {
         const double xo = xd[o], yo = yd[o], zo = zd[o];
         __syncthreads();
         for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
-            const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
-            T[(c * (PT_Y + 1) + b) * (PT_X + 1) + a] = corner_term(xo - xe[i0 + a], yo - ye[j0 + b], zo - ze[k0 + c], bad);
+            const int code = s_node[n];
+            T[code & 4095] = corner_term(xo - s_xe[(code >> 12) & 63], yo - s_ye[(code >> 18) & 15], zo - s_ze[code >> 22], bad);
         }
         __syncthreads();
         double sq = 0.0;
-        for (int q = threadIdx.x; q < ncell; q += blockDim.x) {
-            const int a = q % cx, b = (q / cx) % cy, c = q / (cx * cy);
+        double *out = rows + (int64_t)o * N;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            if (c_slot[j] < 0) continue;
+            const double *t0 = T + c_slot[j];
             double gz = 0.0;
 #pragma unroll
             for (int K = 0; K < 2; ++K)
@@ -141,12 +172,11 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
 #pragma unroll
                     for (int M = 0; M < 2; ++M) {
                         const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;
-                        gz = gz + dmu * T[((c + M) * (PT_Y + 1) + (b + L)) * (PT_X + 1) + (a + K)];
+                        gz = gz + dmu * t0[(M * (PT_Y + 1) + L) * (PT_X + 1) + K];
                     }
-            const int64_t p = ((int64_t)(k0 + c) * ny + (j0 + b)) * nx + (i0 + a);
             double v = g_grav() * gz;
-            if (cw) v = v * cw[p];
-            rows[(int64_t)o * N + p] = v;
+            if (cw) v = v * c_w[j];
+            out[c_col[j]] = v;
             sq = fma(v, v, sq);
         }
         if (sumsq) {                                        // cost_full (sensitivity_gravmag.F90:234), fixed order
