@@ -373,17 +373,29 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
     const int ncell = cx * cy * cz;
     int bad = 0;
 #define NODE(a, b, c) (((c) * (MT_Y + 1) + (b)) * (MT_X + 1) + (a))
+    // observation-independent index arithmetic, once per workgroup (as in k_prism_gz_tensor)
+    __shared__ double s_xe[MT_X + 1], s_ye[MT_Y + 1], s_ze[MT_Z + 1];
+    __shared__ int s_node[MT_NODES];                      // LDS slot | a << 12 | b << 18 | c << 22
+    for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
+        const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
+        s_node[n] = NODE(a, b, c) | (a << 12) | (b << 18) | (c << 22);
+    }
+    if (threadIdx.x <= cx) s_xe[threadIdx.x] = xe[i0 + threadIdx.x];
+    if (threadIdx.x <= cy) s_ye[threadIdx.x] = ye[j0 + threadIdx.x];
+    if (threadIdx.x <= cz) s_ze[threadIdx.x] = ze[k0 + threadIdx.x];
+    __shared__ int s_cell[MT_X * MT_Y * MT_Z];            // a | b << 8 | c << 16 of cell q
+    for (int q = threadIdx.x; q < ncell; q += blockDim.x) s_cell[q] = (q % cx) | (((q / cx) % cy) << 8) | ((q / (cx * cy)) << 16);
     for (int o = 0; o < nobs; ++o) {
         const double xo = xd[o], yo = yd[o], zo = zd[o];
         __syncthreads();
         for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
-            const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
-            const double rx = xe[i0 + a] - xo + eps, ry = ye[j0 + b] - yo + eps, rz = ze[k0 + c] - zo + eps;       // :336-341
+            const int code = s_node[n];
+            const double rx = s_xe[(code >> 12) & 63] - xo + eps, ry = s_ye[(code >> 18) & 15] - yo + eps, rz = s_ze[code >> 22] - zo + eps;       // :336-341
             const double rxsq = rx * rx, rysq = ry * ry, rzsq = rz * rz;
             const double az = sqrt(rzsq + (rysq + rxsq));        // :361-372   a = sqrt(rz^2 + R), R = ry^2 + rx^2
             const double ax = sqrt(rxsq + (rysq + rzsq));        // :404-415   a = sqrt(rx^2 + R), R = ry^2 + rz^2
             const double ay = sqrt(rysq + (rxsq + rzsq));        // :424-435   a = sqrt(ry^2 + R), R = rx^2 + rz^2
-            const int id = NODE(a, b, c);
+            const int id = code & 4095;
             Taz[id] = az; Tax[id] = ax; Tay[id] = ay;
             TAx[id] = atan2(ry * rz, (rx * az + eps));           // the terms of tx(1), :376-383
             TAy[id] = atan2(rx * rz, (ry * az + eps));           // the terms of ty(2), :392-399
@@ -393,8 +405,9 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
 #pragma unroll
         for (int i = 0; i < NSUB; ++i) sq[i] = 0.0;
         for (int q = threadIdx.x; q < ncell; q += blockDim.x) {
-            const int a = q % cx, b = (q / cx) % cy, c = q / (cx * cy);
-            const double x1 = xe[i0 + a], x2 = xe[i0 + a + 1], y1 = ye[j0 + b], y2 = ye[j0 + b + 1], z1 = ze[k0 + c], z2 = ze[k0 + c + 1];
+            const int ccode = s_cell[q];
+            const int a = ccode & 255, b = (ccode >> 8) & 255, c = ccode >> 16;
+            const double x1 = s_xe[a], x2 = s_xe[a + 1], y1 = s_ye[b], y2 = s_ye[b + 1], z1 = s_ze[c], z2 = s_ze[c + 1];
             double tx[3], ty[3], tz[3];
             if (x1 < xo && x2 > xo && y1 < yo && y2 > yo && z1 < zo && z2 > zo) {
                 mag_cell_tensor(x1, x2, y1, y2, z1, z2, xo, yo, zo, tx, ty, tz, bad);      // observation inside this cell
@@ -568,6 +581,9 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
     const double twopi = 2.0 * 3.14159265358979323846;
     __shared__ double T[NC][GT::NODES];
     __shared__ double s_w[4];
+    // observation-independent index arithmetic, once per workgroup (as in k_prism_gz_tensor)
+    __shared__ double s_xe[GT::X + 1], s_ye[GT::Y + 1], s_ze[GT::Z + 1];
+    __shared__ int s_node[GT::NODES];                     // LDS slot | a << 12 | b << 18 | c << 22
     const int tiles_x = (nx + GT::X - 1) / GT::X, tiles_y = (ny + GT::Y - 1) / GT::Y;
     const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
     const int i0 = bx * GT::X, j0 = by * GT::Y, k0 = bz * GT::Z;
@@ -577,16 +593,40 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
     const int ncell = cx * cy * cz;
     int bad = 0;
 #define NODE(a, b, c) (((c) * (GT::Y + 1) + (b)) * (GT::X + 1) + (a))
+    for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
+        const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
+        s_node[n] = NODE(a, b, c) | (a << 12) | (b << 18) | (c << 22);
+    }
+    if (threadIdx.x <= cx) s_xe[threadIdx.x] = xe[i0 + threadIdx.x];
+    if (threadIdx.x <= cy) s_ye[threadIdx.x] = ye[j0 + threadIdx.x];
+    if (threadIdx.x <= cz) s_ze[threadIdx.x] = ze[k0 + threadIdx.x];
+    constexpr int CPT = GT::X * GT::Y * GT::Z / 256;      // cells per thread
+    int c_slot[CPT];
+    int64_t c_col[CPT];
+    double c_w[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int q = threadIdx.x + 256 * j;
+        c_slot[j] = -1;
+        c_col[j] = 0;
+        c_w[j] = 1.0;
+        if (q < ncell) {
+            const int a = q % cx, b = (q / cx) % cy, c = q / (cx * cy);
+            c_slot[j] = NODE(a, b, c);
+            c_col[j] = ((int64_t)(k0 + c) * ny + (j0 + b)) * nx + (i0 + a);
+            if (cw) c_w[j] = cw[c_col[j]];
+        }
+    }
     for (int o = 0; o < nobs; ++o) {
         const double xo = xd[o], yo = yd[o], zo = zd[o];
         __syncthreads();
         for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
-            const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
-            const double XX = xo - xe[i0 + a], YY = yo - ye[j0 + b], ZZ = -(zo - ze[k0 + c]);            // gravity_field.f90:232-237
+            const int code = s_node[n];
+            const double XX = xo - s_xe[(code >> 12) & 63], YY = yo - s_ye[(code >> 18) & 15], ZZ = -(zo - s_ze[code >> 22]);   // gravity_field.f90:232-237
             const double Rs = sqrt(XX * XX + YY * YY + ZZ * ZZ);                                         // :251
             double vzz = -atan2(XX * YY, Rs * ZZ);                                                       // :255
             if (vzz < 0) vzz = vzz + twopi;
-            const int id = NODE(a, b, c);
+            const int id = code & 4095;
             if (FULL) {
                 double vxx = atan2(XX * YY, XX * XX + Rs * ZZ + ZZ * ZZ);                                // :253
                 double vyy = atan2(XX * YY, Rs * Rs + Rs * ZZ - XX * XX);                                // :254
@@ -612,12 +652,13 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
         double sq[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) sq[i] = 0.0;
-        for (int q = threadIdx.x; q < ncell; q += blockDim.x) {
-            const int a = q % cx, b = (q / cx) % cy, c = q / (cx * cy);
-            const int64_t p = ((int64_t)(k0 + c) * ny + (j0 + b)) * nx + (i0 + a);
-            const double w = cw ? cw[p] : 1.0;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            if (c_slot[j] < 0) continue;
+            const int64_t p = c_col[j];
 #pragma unroll
             for (int comp = 0; comp < NC; ++comp) {
+                const double *t0 = &T[comp][c_slot[j]];
                 double gsum = 0.0;
 #pragma unroll
                 for (int K = 0; K < 2; ++K)
@@ -626,10 +667,10 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
 #pragma unroll
                         for (int M = 0; M < 2; ++M) {
                             const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;
-                            gsum = gsum + dmu * T[comp][NODE(a + K, b + L, c + M)];
+                            gsum = gsum + dmu * t0[NODE(K, L, M)];
                         }
                 double v = g_grav() * gsum;                                                               // :301-306, :358
-                if (cw) v = v * w;
+                if (cw) v = v * c_w[j];
                 rows[(int64_t)(o * NC + comp) * N + p] = v;
                 sq[comp] = fma(v, v, sq[comp]);
             }
