@@ -1623,6 +1623,7 @@ int select_threshold_dev(tfx_ctx *ctx, SelectWork &wk, const double *d_rows, int
 constexpr int CMP_THREADS = 256;
 constexpr int CMP_PER_THREAD = 8;
 constexpr int CMP_SEG = CMP_THREADS * CMP_PER_THREAD;     // 2048 elements per block
+static_assert(CMP_PER_THREAD * (CMP_THREADS / 64) == 32, "scan32_wave0 scans exactly 32 counts");
 
 struct CompactArgs {
     const double *rows;       // [nrows][N]
@@ -1659,6 +1660,21 @@ struct CompactArgs {
 };
 
 __device__ __forceinline__ bool keep_elem(double v, double thr, int keep_all) { return keep_all || fabs(v) > thr; }
+
+// exclusive scan of the CMP_PER_THREAD * NW = 32 (sub-block, wave) counts in LDS by the first wave; returns the total to
+// every lane of that wave (call from wave 0 only, after a barrier)
+__device__ __forceinline__ int scan32_wave0(int *wcnt, int lane)
+{
+    const int c = lane < 32 ? wcnt[lane] : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane < 32) wcnt[lane] = incl - c;
+    return __shfl(incl, 31);
+}
 
 // A block owns CMP_SEG = 8 x 256 consecutive elements; thread t reads elements base + k*256 + t (coalesced).
 // Counts the kept elements of the segment.  With a band (threshold not known yet): counts the keys above band.hi and
@@ -1710,15 +1726,15 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
     if (lane == 0) { s_cnt[wave] = cnt; s_all[wave] = cnt_all; }
     __syncthreads();
     const int64_t sg = (int64_t)row * a.nseg + seg;
-    if (threadIdx.x == 0) {
-        int c = 0, ca = 0;
-        for (int i = 0; i < NW; ++i) { c += s_cnt[i]; ca += s_all[i]; }
-        a.seg_cnt[sg] = c;
-        a.seg_all[sg] = ca;
-        if (banded) {
-            int run = 0;
-            for (int i = 0; i < CMP_PER_THREAD * NW; ++i) { const int w = wcnt[i]; wcnt[i] = run; run += w; }
-            a.seg_band[sg] = run;
+    if (wave == 0) {
+        int run = 0;
+        if (banded) run = scan32_wave0(wcnt, lane);
+        if (lane == 0) {
+            int c = 0, ca = 0;
+            for (int i = 0; i < NW; ++i) { c += s_cnt[i]; ca += s_all[i]; }
+            a.seg_cnt[sg] = c;
+            a.seg_all[sg] = ca;
+            if (banded) a.seg_band[sg] = run;
         }
     }
     if (!banded) return;
@@ -1904,12 +1920,13 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_write(CompactArgs a)
     for (int d = 32; d > 0; d >>= 1) cost += __shfl_down(cost, d);
     if (lane == 0) s_cost[wave] = cost;
     __syncthreads();
-    if (threadIdx.x == 0) {                              // exclusive scan of the 32 (k, w) counts
-        int run = 0;
-        for (int i = 0; i < CMP_PER_THREAD * NW; ++i) { const int c = wcnt[i]; wcnt[i] = run; run += c; }
-        double cs = 0.0;
-        for (int i = 0; i < NW; ++i) cs += s_cost[i];
-        a.seg_cost[(int64_t)row * a.nseg + seg] = cs;
+    if (wave == 0) {                                     // exclusive scan of the 32 (k, w) counts
+        (void)scan32_wave0(wcnt, lane);
+        if (lane == 0) {
+            double cs = 0.0;
+            for (int i = 0; i < NW; ++i) cs += s_cost[i];
+            a.seg_cost[(int64_t)row * a.nseg + seg] = cs;
+        }
     }
     if (!a.out_cols) return;
     __syncthreads();
