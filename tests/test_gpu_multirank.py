@@ -272,6 +272,60 @@ def test_whole_inversion_two_ranks():
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
+def _worker_inversion_spatial(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tfx = importlib.import_module("tomofast-x_amd")
+        import multirank_model as mm
+        g = np.load(os.path.join(GOLDEN, "e2e_dgrad.npz"))
+        dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+        N = int(np.prod(dims))
+        ctx = tfx.Context(0)
+        ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+        ctx.set_allreduce(tfx.distributed.TorchAllreduce(0), rank, world)
+        nel = g["np2_nelements_at_cpu"]                  # the reference's own 2-rank partition
+        c0 = int(nel[:rank].sum())
+        c1 = c0 + int(nel[rank])
+        S_full = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+        ctx.matrix_upload_csr(S_full[0].size - 1, c1 - c0, *mm.column_slice(S_full, c0, c1))
+        m, d, hist = tfx.inversion.solve_problem_gravity(ctx, g["np1_column_weight"], int(g["ctype"]), g["np1_data_observed"],
+                                                         int(g["nmajor"]), int(g["nminor"]), alpha=float(g["alpha"]), beta=float(g["beta"]),
+                                                         col_range=(c0, c1))
+        ref = g["np2_model_final"]                       # the reference's own 2-rank run
+        err = np.linalg.norm(m - ref) / np.linalg.norm(ref)
+        assert err <= 1e-5, err
+        assert np.allclose([h["r"] for h in hist], g["np2_lsqr_r"], rtol=1e-4)
+        ctx.close()
+        q.put((rank, "ok"))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_whole_inversion_with_gradient_damping_two_ranks():
+    """WAVELET_DOMAIN = F on 2 ranks through the host: spatial unknowns per column range (tfx_lsqr_set_partition), the
+    gradient-damping rows replicated with each rank's own columns (rows that straddle the cut are summed by the LSQR
+    all-reduce), model-update slices gathered - vs the reference's own 2-rank run."""
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29800 + (os.getpid() + 7) % 2000
+    procs = [ctxm.Process(target=_worker_inversion_spatial, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
 def _worker_spatial(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

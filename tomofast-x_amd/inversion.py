@@ -39,6 +39,15 @@ class AdmmState:
         return self.z - self.u
 
 
+def restrict_columns(G, c0, c1):
+    """Rows of a constraint block over the columns (c0, c1] (1-based, as uploaded) of one rank, renumbered from 1: the
+    column-partitioned form of matrix_cons - every rank holds all rows and its own columns; LSQR sums the partial products."""
+    rowptr, cols, vals = G
+    keep = (cols > c0) & (cols <= c1)
+    csum = np.concatenate([[0], np.cumsum(keep)])
+    return csum[rowptr].astype(np.int64), (cols[keep] - c0).astype(np.int32), vals[keep]
+
+
 def gradient_damping_rows(m, dims, spacing, cw, pw, beta):
     """damping_gradient%add for the three directions (src/inversion/damping_gradient.F90:94-205): forward differences
     (gradient.F90:77-81) of the model along x, y, z; 3 N rows of two entries (none in the last layer of a direction) with
@@ -263,8 +272,8 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
 
     def unweight(v):                                 # v / column_weight with the reference's zero guard (damping.F90:129-135)
         return np.where(cw != 0.0, v / np.where(cw != 0.0, cw, 1.0), 0.0)
-    if spatial and (ncm != 1 or col_range is not None):
-        raise NotImplementedError("gradient / Lp damping: one model component, single rank in this host")
+    if spatial and ncm != 1:
+        raise NotImplementedError("gradient / Lp damping: one model component in this host")
     if col_range is None:
         loc = lambda v: v
         gather = lambda v: v
@@ -323,8 +332,12 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
         if spatial:
             if beta != 0.0:
                 G, grhs = gradient_damping_rows(m, (nx, ny, nz), ctx.spacing, cw, pw, beta)
+                if col_range is not None:            # rows replicated, columns of this rank (joint_inverse_problem.F90:332: ncolumns local)
+                    G = restrict_columns(G, col_range[0], col_range[1])
                 ctx.cons_upload_csr(G[0], G[1], G[2], grhs)
             ctx.lsqr_set_wavelet_domain(False, compression_type)
+            if col_range is not None:                # every product with S gathers the slices, transforms, keeps its own
+                ctx.lsqr_set_partition(col_range[0], 1)
         try:
             x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
         finally:
