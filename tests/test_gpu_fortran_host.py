@@ -364,6 +364,44 @@ def test_two_ranks_under_mpiexec_match_the_reference_two_rank_run(tmp_path, gold
         assert np.linalg.norm(model - ref) <= tol * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
 
 
+@pytest.mark.parametrize("name", ["e2e_dgrad", "e2e_xgrad", "e2e_clust"])
+def test_spatial_unknowns_two_ranks_under_mpiexec(tmp_path, golden_dir, name):
+    """WAVELET_DOMAIN = F on 2 ranks (gradient damping; cross-gradient and clustering on joint runs): spatial unknowns per cell
+    range (tfx_lsqr_set_partition), the constraint rows replicated with each rank's own columns - against the reference's own
+    2-rank run of the same Parfile."""
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    if not os.path.isfile(MPIEXEC):
+        pytest.skip("no mpiexec in this image")
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    wd = str(tmp_path)
+    if name == "e2e_dgrad":
+        write_case_inputs(wd, g)
+        open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
+        cases = [(None, "grav")]
+    else:
+        write_joint_inputs(wd, g)
+        cases = [("grav", "grav"), ("magn", "mag")]
+        if name == "e2e_clust":
+            with open(os.path.join(wd, "mixtures.txt"), "w") as f:
+                f.write("%d\n" % g["mixtures"].shape[0])
+                for r in g["mixtures"]:
+                    f.write(" ".join("%.17g" % v for v in r) + "\n")
+            with open(os.path.join(wd, "cell_weights.txt"), "w") as f:
+                f.write("%d %d\n" % g["cell_weights"].shape)
+                for r in g["cell_weights"]:
+                    f.write(" ".join("%.17g" % v for v in r) + "\n")
+    out = subprocess.run([MPIEXEC, "-n", "2", EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout and "Number of ranks" in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, \
+        out.stdout[-3000:] + out.stderr[-2000:]
+    for tag, sfx in cases:
+        model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)[:, 0]
+        ref = g["np2_%s_model_final" % tag if tag else "np2_model_final"]
+        assert np.linalg.norm(model - ref) <= 1e-5 * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
+    rs = [float(t.split()[0]) for t in out.stdout.split("Finished lsqr solver, r =")[1:]]
+    assert np.allclose(rs[:len(g["np2_lsqr_r"])], g["np2_lsqr_r"], rtol=1e-4)
+
+
 PAR_BIG = """global.outputFolderPath     = out/
 modelGrid.size                      = 32 24 12
 modelGrid.grav.file                 = grid.txt

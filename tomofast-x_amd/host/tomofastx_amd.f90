@@ -738,7 +738,6 @@ program tomofastx_amd
     call tfx_check(tfx_set_allreduce(ctx, c_funloc(allreduce_hook), c_null_ptr, int(myrank, c_int), int(nbproc, c_int)), &
                    'tfx_set_allreduce')
     if (par%sensit_read == 2) call stop_msg('sensit.readFromFiles = 2 runs single-rank in this host.')
-    if (spatial) call stop_msg('Gradient damping (WAVELET_DOMAIN = F) runs single-rank in this host.')
     ! ---- column partition (calculate_new_partitioning, sensitivity_gravmag.F90:573-640): per-cell non-zero counts of my share
     ! of the data rows of every kernel, summed over ranks and problems, then the reference's greedy nnz-balancing rule
     allocate(hist(n), hist_all(n), nel_at(nbproc), nnz_at(nbproc))
@@ -951,6 +950,13 @@ program tomofastx_amd
       if (any(par%w_clust /= 0.d0)) call build_clustering()
       if (g_nrows > 0) call tfx_check(tfx_cons_upload_csr(ctx, g_nrows, g_rowptr, g_cols, g_vals, g_rhs), 'damping_gradient_add')
       call tfx_check(tfx_lsqr_set_wavelet_domain(ctx, 0_c_int, par%nx, par%ny, par%nz, par%comp_type), 'WAVELET_DOMAIN')
+      if (nbproc > 1) then                                         ! every product with S gathers the slices of all ranks
+        k = 0
+        do ip = 1, 2
+          if (pr(ip)%on) k = k + pr(ip)%nc
+        enddo
+        call tfx_check(tfx_lsqr_set_partition(ctx, int(cb, c_int64_t), int(k, c_int)), 'tfx_lsqr_set_partition')
+      endif
     endif
     call tfx_check(tfx_lsqr_solve(ctx, par%nminor, par%rmin, par%gamma, par%target_misfit, b_data, nblocks, dptr, rptr, x, &
                                   iters, r), 'lsqr_solve_sensit')
@@ -1016,7 +1022,7 @@ contains
   ! joint_inverse_problem.F90:466-488): forward differences (gradient.F90:77-81) over the structured grid (grid.F90:371-391);
   ! 3 N rows per component, two entries each except in the last layer of the direction; columns ascending for the upload
   subroutine build_gradient_damping()
-    integer :: jp, kc, dir, i, j, kk, p, me, nb, cshift
+    integer :: jp, kc, dir, i, j, kk, p, me, nb
     integer(c_int64_t) :: row, e, ec
     real(dp) :: delta, gval, coef
     g_nrows = 0
@@ -1040,7 +1046,6 @@ contains
       if (.not. (pr(jp)%on .and. par%beta_grad(jp) /= 0.d0)) cycle
       coef = pr(jp)%pw * par%beta_grad(jp)
       do kc = 1, pr(jp)%nc
-        cshift = pr(jp)%col0 + (kc - 1) * n
         do dir = 1, 3
           p = 0
           do kk = 1, par%nz
@@ -1063,11 +1068,16 @@ contains
                 endif
                 if (nb > 0) then
                   gval = (pr(jp)%m((kc - 1) * n + nb) - pr(jp)%m((kc - 1) * n + me)) / delta
-                  g_cols(e + 1) = cshift + me
-                  g_vals(e + 1) = real(-(1.d0 / delta) * coef * pr(jp)%cw(me), c_float)
-                  g_cols(e + 2) = cshift + nb
-                  g_vals(e + 2) = real((1.d0 / delta) * coef * pr(jp)%cw(nb), c_float)
-                  e = e + 2
+                  if (local_column(jp, kc, me) > 0) then           ! rows replicated, columns of this rank only
+                    e = e + 1
+                    g_cols(e) = local_column(jp, kc, me)
+                    g_vals(e) = real(-(1.d0 / delta) * coef * pr(jp)%cw(me), c_float)
+                  endif
+                  if (local_column(jp, kc, nb) > 0) then
+                    e = e + 1
+                    g_cols(e) = local_column(jp, kc, nb)
+                    g_vals(e) = real((1.d0 / delta) * coef * pr(jp)%cw(nb), c_float)
+                  endif
                   g_rhs(row) = -coef * gval
                 endif
                 g_rowptr(row + 1) = e
@@ -1159,14 +1169,14 @@ contains
             b = 0
             do t = 1, ne                                          ! model 1 columns, then model 2 columns (+ N), zeros dropped
               f = real(d1(t, comp) * pr(1)%cw(cell(t, comp)) * par%w_cross, c_float)
-              if (f /= 0.0) then
-                b = b + 1;  ecol(b) = pr(1)%col0 + cell(t, comp);  eval(b) = f
+              if (f /= 0.0 .and. local_column(1, 1, cell(t, comp)) > 0) then
+                b = b + 1;  ecol(b) = local_column(1, 1, cell(t, comp));  eval(b) = f
               endif
             enddo
             do t = 1, ne
               f = real(d2(t, comp) * pr(2)%cw(cell(t, comp)) * par%w_cross, c_float)
-              if (f /= 0.0) then
-                b = b + 1;  ecol(b) = pr(2)%col0 + cell(t, comp);  eval(b) = f
+              if (f /= 0.0 .and. local_column(2, 1, cell(t, comp)) > 0) then
+                b = b + 1;  ecol(b) = local_column(2, 1, cell(t, comp));  eval(b) = f
               endif
             enddo
             do t = 1, b                                           ! ascending columns for the upload (selection sort, <= 8 entries)
@@ -1226,9 +1236,9 @@ contains
         endif
         row = row + 1
         f = real(par%w_clust(jp) * pr(jp)%cw(p) * deriv(jp) * wloc(jp), c_float)
-        if (f /= 0.0) then
+        if (f /= 0.0 .and. local_column(jp, 1, p) > 0) then
           e = e + 1
-          g_cols(e) = pr(jp)%col0 + p
+          g_cols(e) = local_column(jp, 1, p)
           g_vals(e) = f
         endif
         g_rowptr(row + 1) = e
@@ -1347,6 +1357,16 @@ contains
     if (i < 1 .or. j < 1 .or. kk < 1 .or. i > par%nx .or. j > par%ny .or. kk > par%nz) return
     fpar = f(((kk - 1) * par%ny + (j - 1)) * par%nx + i)
   end function fpar
+
+  ! column of (problem jp, model component kc, cell) in this rank's unknown vector [m1 cells (cb, ce]; m2 cells (cb, ce]], 1-based;
+  ! 0: the cell belongs to another rank (constraint rows are replicated, every rank fills its own columns)
+  integer function local_column(jp, kc, cell)
+    integer, intent(in) :: jp, kc, cell
+    local_column = 0
+    if (cell <= cb .or. cell > ce) return
+    local_column = (kc - 1) * nloc + cell - cb
+    if (jp == 2 .and. pr(1)%on) local_column = local_column + pr(1)%nml
+  end function local_column
 
   subroutine unweight(jp, v, res)
     integer, intent(in) :: jp
