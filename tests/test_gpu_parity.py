@@ -1137,7 +1137,7 @@ def test_band_select_gives_the_same_matrix_as_the_full_select(ctx, ctype, rate, 
     (ra, A, used_a, _), (rb, B, used_b, fell_b) = out
     assert used_a == 0 and used_b > 0 and (fell_b > 0) == expect_fallback
     assert ra["nnz"] == rb["nnz"] and np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and bits_equal(A[2], B[2])
-    assert np.array_equal(ra["nnz_hist"], rb["nnz_hist"]) and ra["error_sum"] == rb["error_sum"]
+    assert np.array_equal(ra["nnz_hist"], rb["nnz_hist"]) and abs(ra["error_sum"] - rb["error_sum"]) <= 1e-12 * ra["error_sum"]   # summation order of the discarded energy differs
     # and in a column range with the statistics of all columns (the multi-GPU direct build)
     N = nx * ny * nz
     try:
@@ -1146,7 +1146,7 @@ def test_band_select_gives_the_same_matrix_as_the_full_select(ctx, ctype, rate, 
         C = ctx.matrix_download_csr()
     finally:
         ctx.debug_set("band_select_min_cells", 1 << 20)
-    assert np.array_equal(rc["nnz_hist"], ra["nnz_hist"]) and rc["error_sum"] == ra["error_sum"]
+    assert np.array_equal(rc["nnz_hist"], ra["nnz_hist"]) and abs(rc["error_sum"] - ra["error_sum"]) <= 1e-12 * ra["error_sum"]
     for r in (0, 17, xs.size - 1):
         sel = (A[1][A[0][r]:A[0][r + 1]] > N // 3) & (A[1][A[0][r]:A[0][r + 1]] <= N // 2)
         assert np.array_equal(C[1][C[0][r]:C[0][r + 1]], A[1][A[0][r]:A[0][r + 1]][sel] - N // 3)

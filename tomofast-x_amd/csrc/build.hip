@@ -1648,9 +1648,10 @@ struct CompactArgs {
     int32_t *hist;            // [N] per-column nnz (sensit_nnz, :267) or null
     // band select (null band: thr is final when the count pass runs)
     const BandRow *band;      // [nrows]
-    unsigned long long *slot_keys;    // [nrows][nseg][BAND_SLOTS] keys of the band candidates of each segment
+    double *slot_vals;        // [nrows][nseg][BAND_SLOTS] the coefficients of each segment that may be kept (|c| >= band.lo), in order
     uint16_t *slot_pos;       // ... and their position inside the segment
-    int32_t *seg_band;        // [nrows][nseg] band candidates found (> BAND_SLOTS: overflow)
+    int32_t *seg_slot;        // [nrows][nseg] how many
+    int32_t *seg_band;        // [nrows][nseg] how many of them lie inside the band (<= band.hi)
     int32_t *seg_boff;        // [nrows][nseg] exclusive scan of seg_band
     unsigned long long *band_keys;    // [nrows][key_stride] dense keys for the select
     int64_t key_stride;
@@ -1677,8 +1678,9 @@ __device__ __forceinline__ int scan32_wave0(int *wcnt, int lane)
 }
 
 // A block owns CMP_SEG = 8 x 256 consecutive elements; thread t reads elements base + k*256 + t (coalesced).
-// Counts the kept elements of the segment.  With a band (threshold not known yet): counts the keys above band.hi and
-// stores the keys inside [band.lo, band.hi] with their positions in the segment's own slots (no atomics).
+// Counts the kept elements of the segment.  With a band (threshold not known yet): counts the keys above band.hi and those
+// inside the band, copies every coefficient that may be kept (key >= band.lo, ~2.5 % of the row) with its position into the
+// segment's own slots (no atomics) - the write pass then never reads the row again - and sums the energy of the rest.
 __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
 {
     const int row = blockIdx.y, seg = blockIdx.x;
@@ -1690,66 +1692,72 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = CMP_THREADS / 64;
     __shared__ int wcnt[CMP_PER_THREAD * NW];
-    int cnt = 0, cnt_all = 0;
-    unsigned long long bkey[CMP_PER_THREAD];
+    __shared__ int s_cnt[NW], s_all[NW], s_band[NW];
+    __shared__ double s_cost[NW];
+    int cnt = 0, cnt_all = 0, nband = 0;
+    double v[CMP_PER_THREAD];
     int lpre[CMP_PER_THREAD];
-    unsigned bandmask = 0;
+    unsigned slotmask = 0;
+    double cost = 0.0;
 #pragma unroll
     for (int k = 0; k < CMP_PER_THREAD; ++k) {
         const int64_t p = base + (int64_t)k * CMP_THREADS;
-        bool inband = false;
-        bkey[k] = 0;
+        bool slot = false;
+        v[k] = 0.0;
         if (p < a.N) {
-            const double v = r[p];
+            v[k] = r[p];
             bool keep;
             if (banded) {
-                const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(v));
+                const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(v[k]));
                 keep = key > hi;
-                inband = !keep && key >= lo;
-                bkey[k] = key;
-            } else keep = keep_elem(v, thr, a.keep_all);
+                slot = key >= lo;
+                if (slot && !keep) nband += 1;
+                if (!slot) cost = fma(v[k], v[k], cost);
+            } else keep = keep_elem(v[k], thr, a.keep_all);
             if (keep) {
                 cnt_all += 1;
                 if (p >= a.col_begin && p < a.col_end) cnt += 1;
             }
         }
         if (banded) {
-            const unsigned long long m = __ballot(inband);
+            const unsigned long long m = __ballot(slot);
             lpre[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (inband) bandmask |= 1u << k;
+            if (slot) slotmask |= 1u << k;
             if (lane == 0) wcnt[k * NW + wave] = __popcll(m);
         }
     }
-    __shared__ int s_cnt[NW], s_all[NW];
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_down(cnt, d); cnt_all += __shfl_down(cnt_all, d); }
-    if (lane == 0) { s_cnt[wave] = cnt; s_all[wave] = cnt_all; }
+    for (int d = 32; d > 0; d >>= 1) {
+        cnt += __shfl_down(cnt, d);
+        cnt_all += __shfl_down(cnt_all, d);
+        if (banded) { nband += __shfl_down(nband, d); cost += __shfl_down(cost, d); }
+    }
+    if (lane == 0) { s_cnt[wave] = cnt; s_all[wave] = cnt_all; s_band[wave] = nband; s_cost[wave] = cost; }
     __syncthreads();
     const int64_t sg = (int64_t)row * a.nseg + seg;
     if (wave == 0) {
         int run = 0;
         if (banded) run = scan32_wave0(wcnt, lane);
         if (lane == 0) {
-            int c = 0, ca = 0;
-            for (int i = 0; i < NW; ++i) { c += s_cnt[i]; ca += s_all[i]; }
+            int c = 0, ca = 0, nb = 0;
+            double cs = 0.0;
+            for (int i = 0; i < NW; ++i) { c += s_cnt[i]; ca += s_all[i]; nb += s_band[i]; cs += s_cost[i]; }
             a.seg_cnt[sg] = c;
             a.seg_all[sg] = ca;
-            if (banded) a.seg_band[sg] = run;
+            if (banded) { a.seg_slot[sg] = run; a.seg_band[sg] = nb; a.seg_cost[sg] = cs; }
         }
     }
     if (!banded) return;
     __syncthreads();
-    if (bandmask) {
-        unsigned long long *bk = a.slot_keys + sg * BAND_SLOTS;
+    if (slotmask) {
+        double *bv = a.slot_vals + sg * BAND_SLOTS;
         uint16_t *bp = a.slot_pos + sg * BAND_SLOTS;
 #pragma unroll
         for (int k = 0; k < CMP_PER_THREAD; ++k)
-            if (bandmask & (1u << k)) {
+            if (slotmask & (1u << k)) {
                 const int pos = wcnt[k * NW + wave] + lpre[k];
-                if (pos < BAND_SLOTS) {
-                    bk[pos] = bkey[k];
-                    bp[pos] = (uint16_t)(k * CMP_THREADS + threadIdx.x);
-                }
+                bv[pos] = v[k];
+                bp[pos] = (uint16_t)(k * CMP_THREADS + threadIdx.x);
             }
     }
 }
@@ -1766,16 +1774,12 @@ __global__ void k_band_scan(CompactArgs a)
     if (threadIdx.x == 0) s_over = 0;
     __syncthreads();
     long long sb = 0, sgv = 0;
-    bool over = false;
     for (int i = b; i < e; ++i) {
-        const int nb = a.seg_band[(int64_t)row * a.nseg + i];
-        over |= nb > BAND_SLOTS;
-        sb += nb;
+        sb += a.seg_band[(int64_t)row * a.nseg + i];
         sgv += a.seg_all[(int64_t)row * a.nseg + i];
     }
     part[threadIdx.x] = sb;
     gpart[threadIdx.x] = sgv;
-    if (over) s_over = 1;
     __syncthreads();
     if (threadIdx.x == 0) {
         long long run = 0, G = 0;
@@ -1798,31 +1802,49 @@ __global__ void k_band_scan(CompactArgs a)
     }
 }
 
-// slots -> dense key list of the row (one wave per segment)
+// band members of the slots -> dense key list of the row (one wave per segment)
 __global__ __launch_bounds__(256) void k_band_gather(CompactArgs a)
 {
     const int row = blockIdx.y, seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (seg >= a.nseg || a.st[row].ncand == 0) return;
     const int64_t sg = (int64_t)row * a.nseg + seg;
-    const int n = a.seg_band[sg];
-    const unsigned long long *bk = a.slot_keys + sg * BAND_SLOTS;
+    if (a.seg_band[sg] == 0) return;
+    const int n = a.seg_slot[sg];
+    const unsigned long long hi = a.band[row].hi;
+    const double *bv = a.slot_vals + sg * BAND_SLOTS;
     unsigned long long *out = a.band_keys + (int64_t)row * a.key_stride + a.seg_boff[sg];
-    for (int i = lane; i < n; i += 64) out[i] = bk[i];
+    int run = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        unsigned long long key = 0;
+        bool in = false;
+        if (i < n) {
+            key = (unsigned long long)__double_as_longlong(fabs(bv[i]));
+            in = key <= hi;
+        }
+        const unsigned long long m = __ballot(in);
+        if (in) out[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = key;
+        run += __popcll(m);
+    }
 }
 
-// band candidates above the final threshold join their segment's counts (one wave per segment, owner adds: no atomics)
+// band members above the final threshold join their segment's counts (one wave per segment, owner adds: no atomics)
 __global__ __launch_bounds__(256) void k_band_fix(CompactArgs a)
 {
     const int row = blockIdx.y, seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (seg >= a.nseg) return;
     const int64_t sg = (int64_t)row * a.nseg + seg;
-    const int n = min(a.seg_band[sg], BAND_SLOTS);
+    if (a.seg_band[sg] == 0) return;
+    const int n = a.seg_slot[sg];
     const double thr = a.thr[row];
-    const unsigned long long *bk = a.slot_keys + sg * BAND_SLOTS;
+    const double hi = __longlong_as_double((long long)a.band[row].hi);       // NaN pattern when hi = all ones: no key is above it
+    const bool hi_all = a.band[row].hi == ~0ull;
+    const double *bv = a.slot_vals + sg * BAND_SLOTS;
     const uint16_t *bp = a.slot_pos + sg * BAND_SLOTS;
     int cnt = 0, cnt_all = 0;
     for (int i = lane; i < n; i += 64) {
-        if (__longlong_as_double((long long)bk[i]) > thr) {                 // |v| > thr (keep_elem)
+        const double av = fabs(bv[i]);
+        if ((hi_all || av <= hi) && av > thr) {                              // inside the band (not yet counted) and kept
             const int64_t p = (int64_t)seg * CMP_SEG + bp[i];
             cnt_all += 1;
             if (p >= a.col_begin && p < a.col_end) cnt += 1;
@@ -1834,6 +1856,56 @@ __global__ __launch_bounds__(256) void k_band_fix(CompactArgs a)
         a.seg_all[sg] += cnt_all;
         a.seg_cnt[sg] += cnt;
     }
+}
+
+// write pass of the band path: the kept entries come out of the segment's slots (ascending positions), the row itself is not
+// read again; the band members below the threshold complete the discarded energy (one wave per segment)
+__global__ __launch_bounds__(256) void k_slot_write(CompactArgs a)
+{
+    if (*a.fail) return;
+    const int row = blockIdx.y, seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg >= a.nseg) return;
+    const int64_t sg = (int64_t)row * a.nseg + seg;
+    const int n = a.seg_slot[sg];
+    if (n == 0) return;
+    const double thr = a.thr[row];
+    const float sc = a.scale ? a.scale[row] : 1.0f;
+    const double *bv = a.slot_vals + sg * BAND_SLOTS;
+    const uint16_t *bp = a.slot_pos + sg * BAND_SLOTS;
+    int segoff = a.seg_off[sg];
+    const int comp = row % a.ncm, mrow = row / a.ncm;
+    for (int kk = 0; kk < comp; ++kk) segoff += a.nel[row - comp + kk];
+    const int64_t cshift = (int64_t)comp * a.comp_stride - a.col_begin;
+    int32_t *oc = a.out_cols ? a.out_cols + (int64_t)mrow * a.out_stride : nullptr;
+    float *ov = a.out_cols ? a.out_vals + (int64_t)mrow * a.out_stride : nullptr;
+    double cost = 0.0;
+    int run = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        double v = 0.0;
+        int64_t p = 0;
+        bool keep = false;
+        if (i < n) {
+            v = bv[i];
+            p = (int64_t)seg * CMP_SEG + bp[i];
+            if (keep_elem(v, thr, 0)) {
+                if (a.hist) atomicAdd(&a.hist[p], 1);
+                keep = p >= a.col_begin && p < a.col_end;
+            } else cost = fma(v, v, cost);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep && oc) {
+            const int pos = segoff + run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            oc[pos] = (int32_t)(p + cshift);
+            float f = (float)v;                              // real(x, MATRIX_PRECISION), :265
+            if (a.scale) f = f * sc;                         // :841
+            ov[pos] = f;
+        }
+        run += __popcll(m);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cost += __shfl_down(cost, d);
+    if (lane == 0 && cost != 0.0) a.seg_cost[sg] += cost;
 }
 
 // one block per row: exclusive scan of the segment counts, totals
@@ -2010,9 +2082,9 @@ struct CompactWork {
     int nseg = 0;
     // band select
     DBuf<BandRow> band;
-    DBuf<unsigned long long> slot_keys;
+    DBuf<double> slot_vals;
     DBuf<uint16_t> slot_pos;
-    DBuf<int32_t> seg_band, seg_boff;
+    DBuf<int32_t> seg_slot, seg_band, seg_boff;
     DBuf<int> fail;
 };
 
@@ -2041,8 +2113,9 @@ static int band_prepare(CompactWork &cw, int nrows)
     const size_t nsl = (size_t)nrows * cw.nseg;
     if (cw.band.n >= (size_t)nrows && cw.seg_band.n >= nsl) return 0;
     TFX_TRY(cw.band.alloc(nrows));
-    TFX_TRY(cw.slot_keys.alloc(nsl * BAND_SLOTS));
+    TFX_TRY(cw.slot_vals.alloc(nsl * BAND_SLOTS));
     TFX_TRY(cw.slot_pos.alloc(nsl * BAND_SLOTS));
+    TFX_TRY(cw.seg_slot.alloc(nsl));
     TFX_TRY(cw.seg_band.alloc(nsl));
     TFX_TRY(cw.seg_boff.alloc(nsl));
     return 0;
@@ -2080,7 +2153,7 @@ static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int 
         int rank_lo, rank_hi;
         band_sample_ranks(N, K, &rank_lo, &rank_hi);
         hipLaunchKernelGGL(k_sel_sample, dim3(nrows), dim3(SMP_THREADS), 0, s, d_rows, N, rank_lo, rank_hi, cw.band.p);
-        a.band = cw.band.p; a.slot_keys = cw.slot_keys.p; a.slot_pos = cw.slot_pos.p; a.seg_band = cw.seg_band.p;
+        a.band = cw.band.p; a.slot_vals = cw.slot_vals.p; a.slot_pos = cw.slot_pos.p; a.seg_slot = cw.seg_slot.p; a.seg_band = cw.seg_band.p;
         a.seg_boff = cw.seg_boff.p; a.band_keys = sel->candA.p; a.key_stride = sel->cap_N; a.st = sel->st.p;
         a.K = (unsigned long long)K; a.fail = cw.fail.p;
         hipLaunchKernelGGL(k_cmp_count, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
@@ -2105,7 +2178,8 @@ static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int 
         hipLaunchKernelGGL(k_cmp_count, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
     }
     hipLaunchKernelGGL(k_cmp_scan, dim3(nrows), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_cmp_write, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+    if (sel) hipLaunchKernelGGL(k_slot_write, dim3((cw.nseg + 3) / 4, nrows), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_cmp_write, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_cmp_cost, dim3(nrows), dim3(256), 0, s, a);
     if (d_nel_out) hipLaunchKernelGGL(k_merge_nel, dim3((nrows / ncm + 63) / 64), dim3(64), 0, s, cw.nel.p, ncm, nrows / ncm, d_nel_out);
     TFX_HIP(hipGetLastError());
