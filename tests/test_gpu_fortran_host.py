@@ -473,11 +473,11 @@ def test_row_parallel_build_with_mpi_relayout(tmp_path):
     for tag in ("exchange", "redundant"):
         m, nnz = models[tag]
         assert nnz == nnz_ref
-            # 2 x 8 LSQR iterations stop mid-convergence, where the Golub-Kahan recurrence amplifies the last-bit differences of
-            # a different summation order (3 ranks; LDS atomics): observed scatter up to 6e-6 over repeated runs.  A relayout
-            # error (a row piece on the wrong rank, shifted columns) changes the model at the 1e-1 level.
-            assert np.linalg.norm(m - ref) <= 1e-4 * np.linalg.norm(ref), (tag, np.linalg.norm(m - ref) / np.linalg.norm(ref))
-    assert np.linalg.norm(models["exchange"][0] - models["redundant"][0]) <= 1e-6 * np.linalg.norm(ref)
+        # 2 x 8 LSQR iterations stop mid-convergence, where the Golub-Kahan recurrence amplifies the last-bit differences of
+        # a different summation order (3 ranks; LDS atomics): observed scatter up to 6e-6 over repeated runs.  A relayout
+        # error (a row piece on the wrong rank, shifted columns) changes the model at the 1e-1 level.
+        assert np.linalg.norm(m - ref) <= 1e-4 * np.linalg.norm(ref), (tag, np.linalg.norm(m - ref) / np.linalg.norm(ref))
+    assert np.linalg.norm(models["exchange"][0] - models["redundant"][0]) <= 1e-4 * np.linalg.norm(ref)
 
 
 def test_gradient_damping_parfile_matches_reference(tmp_path, golden_dir):
