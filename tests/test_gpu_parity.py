@@ -1153,6 +1153,52 @@ def test_band_select_gives_the_same_matrix_as_the_full_select(ctx, ctype, rate, 
         assert bits_equal(C[2][C[0][r]:C[0][r + 1]], A[2][A[0][r]:A[0][r + 1]][sel])
 
 
+def test_headline_size_build_properties_and_sampled_rows_vs_oracle(ctx):
+    """BASELINE's headline configuration at full size (256x256x152 cells x 316x316 data, D4 r = 0.02: nnz 1.99e10, 120 GB on the
+    device; ~35 s): every batch goes through the band select; size-independent properties of the whole matrix - entry count,
+    adjoint identity, linearity - and three rows pulled out with S^T e_r against the oracle's rows."""
+    if ctx.device_info()["hbm_bytes"] < 200e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    nx, ny, nz, ox, oy = 256, 256, 152, 316, 316
+    grid = tfx.synthetic.grid(nx, ny, nz)
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, ox, oy)
+    N, D = nx * ny * nz, xs.size
+    K = int(0.02 * N)
+    ctx.set_grid(nx, ny, nz, *grid)
+    cw = ctx.calculate_depth_weight()
+    b0, f0 = ctx.debug_set("band_batches"), ctx.debug_set("band_fallbacks")
+    try:
+        res = ctx.calculate_sensit(xs, ys, zs, cw, 2, 0.02)
+        assert ctx.debug_set("band_batches") - b0 > 3000 and ctx.debug_set("band_fallbacks") - f0 <= 40
+        assert res["nnz"] <= K * D and res["nnz"] >= 0.9999 * K * D          # every row keeps K entries, fewer only on exact ties
+        assert 0.0 < res["comp_error"] < 0.1
+        rng = np.random.default_rng(1)
+        x, x2, y = rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(D)
+        Sx, Sx2, STy = ctx.mult_vector(x), ctx.mult_vector(x2), ctx.trans_mult_vector(y)
+        assert abs(np.dot(Sx, y) - np.dot(x, STy)) <= 1e-11 * np.linalg.norm(Sx) * np.linalg.norm(y)
+        assert np.allclose(ctx.mult_vector(2.0 * x - 3.0 * x2), 2.0 * Sx - 3.0 * Sx2, rtol=0, atol=1e-11 * np.abs(Sx).max())
+        cw_o = orc.column_weight_type1(grid)
+        for r in (0, 50123, D - 1):
+            e = np.zeros(D)
+            e[r] = 1.0
+            row = ctx.trans_mult_vector(e)                                    # row r of S, dense
+            cb = np.nonzero(row)[0] + 1
+            c_ref, v_ref, _ = orc.build_row_grav(grid, (nx, ny, nz), cw_o, (xs[r], ys[r], zs[r]), 2, K)
+            common, ib, ir = np.intersect1d(cb, c_ref, return_indices=True)
+            assert common.size >= 0.999 * c_ref.size and abs(cb.size - c_ref.size) <= 0.001 * c_ref.size
+            vb = row[cb - 1].astype(np.float32)
+            # fp32 values: within 2 ulp, or within 1e-8 of the row's largest entry.  The device libm and the host libm differ in
+            # the last bits of log / atan2; the 8 corner terms of a cell (~1e5 each) cancel to ~1e-3 of their size and the
+            # transform adds 1e7 such cells into a coefficient, so the difference shows at ~1e-9 of the row scale (measured:
+            # 1.2e-9) - far below the fp32 resolution of the large entries, above it for the smallest kept ones.
+            dv = np.abs(vb[ib].astype(np.float64) - v_ref[ir].astype(np.float64))
+            ulp = np.spacing(np.abs(v_ref[ir])).astype(np.float64)
+            assert np.all(dv <= 2.0 * ulp + 1e-8 * float(np.abs(v_ref).max())), float((dv / np.abs(v_ref).max()).max())
+            assert abs(Sx[r] - np.dot(v_ref.astype(np.float64), x[c_ref - 1])) <= 1e-6 * np.abs(v_ref).astype(np.float64) @ np.abs(x[c_ref - 1])
+    finally:
+        ctx.matrix_free()
+
+
 def test_fortran_host_through_c_abi(ctx):
     """The Fortran host (tomofast-x_amd/host, amdflang + iso_c_binding) drives the same C ABI; its fingerprints must match
     the Python host on the same synthetic problem."""
