@@ -1153,6 +1153,48 @@ def test_band_select_gives_the_same_matrix_as_the_full_select(ctx, ctype, rate, 
         assert bits_equal(C[2][C[0][r]:C[0][r + 1]], A[2][A[0][r]:A[0][r + 1]][sel])
 
 
+@pytest.mark.parametrize("kind", ["normal", "lognormal", "ties", "quantised", "mostly_zero", "denormal", "constant", "lattice"])
+def test_band_select_on_adversarial_rows(ctx, kind):
+    """Single rows with awkward value distributions through tfx_compress_row, band select against the full select and against
+    numpy's order statistic: heavy ties at the threshold, few distinct values, zeros, denormals, large values on index lattices
+    (what wavelet coefficients look like).  Whatever the band does (hit, overflow, miss -> fallback), the result is the same."""
+    rng = np.random.default_rng(sum(kind.encode()))
+    N = 300007
+    if kind == "normal":
+        row = rng.standard_normal(N)
+    elif kind == "lognormal":
+        row = np.exp(8.0 * rng.standard_normal(N)) * rng.choice([-1.0, 1.0], N)
+    elif kind == "ties":
+        row = rng.standard_normal(N)
+        row[rng.random(N) < 0.3] = 0.731                       # 30 % of the row on one value, the threshold lands inside the run
+    elif kind == "quantised":
+        row = rng.integers(-6, 7, N).astype(np.float64)
+    elif kind == "mostly_zero":
+        row = np.where(rng.random(N) < 0.01, rng.standard_normal(N), 0.0)
+    elif kind == "denormal":
+        row = rng.standard_normal(N) * 1e-312
+    elif kind == "constant":
+        row = np.full(N, -2.5)
+    else:
+        row = 1e-6 * rng.standard_normal(N)
+        for step, amp in ((8, 1e-3), (64, 1.0), (512, 1e3)):
+            row[::step] = amp * rng.standard_normal(row[::step].size)
+    for K in (1, 700, N // 50, N // 3, N - 5):
+        out = []
+        try:
+            for min_cells in (-1, 0):
+                ctx.debug_set("band_select_min_cells", min_cells)
+                out.append(ctx.compress_row(row, K))
+        finally:
+            ctx.debug_set("band_select_min_cells", 1 << 20)
+        (ca, va, ta, da), (cb, vb, tb, db) = out
+        thr_ref = max(np.partition(np.abs(row), N - K - 1)[N - K - 1], 1e-30)          # sort(|row|)[N - K] 1-based, floored (:240-256)
+        assert ta == tb == thr_ref, (kind, K, ta, tb, thr_ref)
+        keep = np.nonzero(np.abs(row) > thr_ref)[0]
+        assert np.array_equal(ca, cb) and np.array_equal(ca, keep + 1) and bits_equal(va, vb) and bits_equal(va, row[keep].astype(np.float32))
+        assert abs(da - db) <= 1e-12 * max(da, 1e-300)
+
+
 def test_headline_size_build_properties_and_sampled_rows_vs_oracle(ctx):
     """BASELINE's headline configuration at full size (256x256x152 cells x 316x316 data, D4 r = 0.02: nnz 1.99e10, 120 GB on the
     device; ~35 s): every batch goes through the band select; size-independent properties of the whole matrix - entry count,

@@ -2386,8 +2386,20 @@ int tfx_compress_row(tfx_ctx *ctx, const double *row, int64_t N, int64_t K, int3
     SelectWork sw;
     CompactWork cw;
     TFX_TRY(compact_prepare(cw, 1, N));
-    TFX_TRY(select_threshold_dev(ctx, sw, d.p, 1, N, K, cw.thr.p));
-    TFX_TRY(compact_dev(ctx, cw, d.p, 1, N, 0, 0, N, oc.p, ov.p, stride, nullptr, nullptr, nullptr));
+    // same threshold path as the build: band select for large rows, the full select otherwise or when the band missed
+    const bool banded = K > 0 && K < N && N >= ctx->band_min_n;
+    int h_fail = 0;
+    if (banded) {
+        TFX_TRY(compact_dev(ctx, cw, d.p, 1, N, 0, 0, N, oc.p, ov.p, stride, nullptr, nullptr, nullptr, 1, &sw, K));
+        TFX_HIP(hipMemcpyAsync(&h_fail, cw.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        TFX_HIP(hipStreamSynchronize(s));
+        ctx->band_batches += 1;
+        if (h_fail) ctx->band_fallbacks += 1;
+    }
+    if (!banded || h_fail) {
+        TFX_TRY(select_threshold_dev(ctx, sw, d.p, 1, N, K, cw.thr.p));
+        TFX_TRY(compact_dev(ctx, cw, d.p, 1, N, 0, 0, N, oc.p, ov.p, stride, nullptr, nullptr, nullptr));
+    }
     int32_t nel = 0;
     double thr = 0, cd = 0;
     TFX_HIP(hipMemcpyAsync(&nel, cw.nel.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
