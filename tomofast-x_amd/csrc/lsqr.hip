@@ -18,6 +18,7 @@ namespace tfx {
 struct Scalars {
     double alpha, beta, rhobar, phibar, b1, r, t1, t2;
     double sum_u, sum_uc, sum_v, misfit_ss;
+    double inv_alpha;      // 1/alpha kept apart from t2 when the rotation runs in the same launch
     int32_t rho_zero, u_zero, v_zero, pad;
 };
 
@@ -126,21 +127,37 @@ __global__ void k_cons_adjoint(double *__restrict__ v, const float *__restrict__
 }
 
 // beta = sqrt(sum_u + sum_uc); scale factor 1/beta (normalize, lsqr_solver2.F90:501-530)
-__global__ void k_beta(Scalars *sc, const double *uc_total)
+__device__ __forceinline__ void set_beta(Scalars *sc, double uc_total)
 {
-    const double ss = sc->sum_u + *uc_total;
+    const double ss = sc->sum_u + uc_total;
     const double beta = sqrt(ss);
     sc->beta = beta;
     sc->u_zero = (beta == 0.0);
-    sc->t1 = (beta != 0.0) ? 1.0 / beta : 1.0;     // t1 doubles as the scale factor until k_rotate overwrites it
+    sc->t1 = (beta != 0.0) ? 1.0 / beta : 1.0;     // t1 doubles as the scale factor until the rotation overwrites it
 }
 
-__global__ void k_alpha(Scalars *sc)
+__device__ __forceinline__ void set_alpha(Scalars *sc)
 {
     const double alpha = sqrt(sc->sum_v);
     sc->alpha = alpha;
     sc->v_zero = (alpha == 0.0);
     sc->t2 = (alpha != 0.0) ? 1.0 / alpha : 1.0;
+    sc->inv_alpha = sc->t2;
+}
+
+__global__ void k_alpha(Scalars *sc) { set_alpha(sc); }
+
+// sum_u = sum of red[0..n) in index order, then beta: one launch instead of k_final_sum + a scalar kernel (small systems are
+// bound by the launch-to-launch latency of this chain)
+__global__ void k_final_sum_beta(const double *__restrict__ red, int n, Scalars *sc, const double *uc_total)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += red[i];
+    s = block_sum(s);
+    if (threadIdx.x == 0) {
+        sc->sum_u = s;
+        set_beta(sc, *uc_total);
+    }
 }
 
 // first-iteration initialisation (lsqr_solver2.F90:134, :155-157)
@@ -154,7 +171,7 @@ __global__ void k_init_scalars(Scalars *sc)
 }
 
 // plane rotation (lsqr_solver2.F90:248-266, :277-280)
-__global__ void k_rotate(Scalars *sc)
+__device__ __forceinline__ void rotate(Scalars *sc)
 {
     const double alpha = sc->alpha, beta = sc->beta;
     const double rho = sqrt(sc->rhobar * sc->rhobar + beta * beta);
@@ -171,16 +188,44 @@ __global__ void k_rotate(Scalars *sc)
     sc->r = sc->phibar / sc->b1;
 }
 
+__global__ void k_rotate(Scalars *sc) { rotate(sc); }
+
+// single rank: sum_v (index order) -> alpha -> rotation in one launch; 1/alpha stays in sc->inv_alpha for k_update_xw
+__global__ void k_final_sum_alpha_rotate(const double *__restrict__ red, int n, Scalars *sc)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += red[i];
+    s = block_sum(s);
+    if (threadIdx.x == 0) {
+        sc->sum_v = s;
+        set_alpha(sc);
+        rotate(sc);
+    }
+}
+
+// u *= t1 ; u_cons *= t1 ; v = -beta v   (normalisation of u and the first half of the adjoint step, :218-225) in one launch
+__global__ void k_scale_u_uc_v(double *__restrict__ u, int64_t nu, double *__restrict__ uc, int64_t nuc, double *__restrict__ v,
+                               int64_t nv, const Scalars *sc)
+{
+    const double f = sc->t1, beta = sc->beta;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = i0; i < nu; i += st) u[i] = f * u[i];
+    for (int64_t i = i0; i < nuc; i += st) uc[i] = f * uc[i];
+    for (int64_t i = i0; i < nv; i += st) v[i] = -beta * v[i];
+}
+
 // v *= 1/alpha (normalize) ; x = t1*w + x ; w = t2*w + v ; soft threshold            (lsqr_solver2.F90:241, :269-274)
 __global__ void k_update_xw(double *__restrict__ v, double *__restrict__ w, double *__restrict__ x, int64_t n,
                             const Scalars *sc, double inv_alpha_known, double gamma)
 {
-    (void)inv_alpha_known;
-    const double t1 = sc->t1, t2 = sc->t2;
+    // inv_alpha_known != 0: v has not been normalised yet (single-rank fused path): v = (1/alpha) v first, as k_scale would
+    const double t1 = sc->t1, t2 = sc->t2, ia = sc->inv_alpha;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double wi = w[i];
         double xi = t1 * wi + x[i];
-        w[i] = t2 * wi + v[i];
+        double vi = v[i];
+        if (inv_alpha_known != 0.0) { vi = ia * vi; v[i] = vi; }
+        w[i] = t2 * wi + vi;
         if (gamma != 0.0) {                                    // :478-494
             if (fabs(xi) <= gamma) xi = 0.0;
             else if (xi <= -gamma) xi = xi + gamma;
@@ -254,8 +299,7 @@ static int norm_u(tfx_ctx *ctx, LsqrState *L)
     hipStream_t s = ctx->stream;
     const int g = grid_for(L->nrows);
     LAUNCH(k_sumsq, g, L->u.p, L->nrows, L->red.p);
-    LAUNCH(k_final_sum, 1, L->red.p, g, &L->sc.p->sum_u);
-    LAUNCH(k_beta, 1, L->sc.p, L->u.p + L->nrows);
+    LAUNCH(k_final_sum_beta, 1, L->red.p, g, L->sc.p, L->u.p + L->nrows);
     TFX_HIP(hipGetLastError());
     return 0;
 }
@@ -312,7 +356,9 @@ static int transform_slice(tfx_ctx *ctx, LsqrState *L, int dir)
 }
 
 // v (+)= S^T u_data + C^T u_cons ; alpha = ||v|| ; v /= alpha
-static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L)
+// fuse_rotate (iterations on a single rank): alpha and the plane rotation come out of the final-sum launch and the
+// normalisation of v is left to k_update_xw
+static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L, bool fuse_rotate = false)
 {
     hipStream_t s = ctx->stream;
     if (ctx->spatial_unknowns) {                                         // lsqr_solver2.F90:137-145, :228-236
@@ -325,6 +371,11 @@ static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L)
     if (ctx->cons.valid) TFX_TRY(spmtv_dev(ctx, ctx->cons, L->u.p + L->nrows_data, L->v.p, 1));     // lsqr_solver2.F90:147, :238
     const int g = grid_for(L->ncols);
     LAUNCH(k_cons_adjoint, g, L->v.p, L->diag.p, L->uc.p, L->ncols, L->nblocks, L->red.p);
+    if (fuse_rotate) {
+        LAUNCH(k_final_sum_alpha_rotate, 1, L->red.p, g, L->sc.p);
+        TFX_HIP(hipGetLastError());
+        return 0;
+    }
     LAUNCH(k_final_sum, 1, L->red.p, g, &L->sc.p->sum_v);
     TFX_HIP(hipGetLastError());
     TFX_TRY(allreduce(ctx, &L->sc.p->sum_v, 1));
@@ -517,11 +568,14 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
         TFX_HIP(hipGetLastError());
         TFX_TRY(allreduce(ctx, L->u.p, nr + 1));                                          // :214
         TFX_TRY(norm_u(ctx, L));                                                          // :218
-        TFX_TRY(scale_u(ctx, L));
-        LAUNCH(k_scale, grid_for(nc), L->v.p, nc, &L->sc.p->beta, 1);                     // :225  v = -beta v
-        TFX_TRY(adjoint_and_alpha(ctx, L));                                               // :228-241
-        LAUNCH(k_rotate, 1, L->sc.p);                                                     // :248-266
-        LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, 0.0, L->gamma);   // :269-274
+        {                                                                                 // u, u_cons /= beta ; v = -beta v   (:218-225)
+            const int64_t nuc = (int64_t)L->nblocks * nc;
+            LAUNCH(k_scale_u_uc_v, grid_for(std::max(std::max(nr, nuc), nc)), L->u.p, nr, L->uc.p, nuc, L->v.p, nc, L->sc.p);
+        }
+        const bool fused = ctx->nranks <= 1 || !ctx->allreduce;                           // no reduction between sum_v and alpha
+        TFX_TRY(adjoint_and_alpha(ctx, L, fused));                                        // :228-241
+        if (!fused) LAUNCH(k_rotate, 1, L->sc.p);                                         // :248-266
+        LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, fused ? 1.0 : 0.0, L->gamma);   // :241, :269-274
         TFX_HIP(hipGetLastError());
         TFX_TRY(read_scalars(ctx, L));
         if (L->h_sc->rho_zero) { L->finished = true; break; }                             // :251-254 (x, w untouched: t1 = t2 = 0 ... see note)
