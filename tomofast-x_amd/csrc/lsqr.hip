@@ -19,6 +19,8 @@ struct Scalars {
     double alpha, beta, rhobar, phibar, b1, r, t1, t2;
     double sum_u, sum_uc, sum_v, misfit_ss;
     double inv_alpha;      // 1/alpha kept apart from t2 when the rotation runs in the same launch
+    double rmin;           // stop test of the iteration loop, evaluated on the device (lsqr_solver2.F90:163)
+    int32_t stop, skip, iters, pad2;   // stop: no further iteration may change x / the scalars; skip: this iteration is void
     int32_t rho_zero, u_zero, v_zero, pad;
 };
 
@@ -161,21 +163,29 @@ __global__ void k_final_sum_beta(const double *__restrict__ red, int n, Scalars 
 }
 
 // first-iteration initialisation (lsqr_solver2.F90:134, :155-157)
-__global__ void k_init_scalars(Scalars *sc)
+__global__ void k_init_scalars(Scalars *sc, double rmin)
 {
+    sc->rmin = rmin;
     sc->b1 = sc->beta;
     sc->rhobar = sc->alpha;
     sc->phibar = sc->beta;
     sc->r = 1.0;
     sc->rho_zero = 0;
+    sc->stop = 0;
+    sc->skip = 0;
+    sc->iters = 0;
 }
 
 // plane rotation (lsqr_solver2.F90:248-266, :277-280)
 __device__ __forceinline__ void rotate(Scalars *sc)
 {
+    // The host queues several iterations before it looks at the scalars again; an iteration that starts after the loop's exit
+    // condition was met (:163, :251-254, :286-289) must leave x, w and the scalars alone: it is marked void here, k_update_xw obeys.
+    sc->skip = sc->stop;
+    if (sc->stop) return;
     const double alpha = sc->alpha, beta = sc->beta;
     const double rho = sqrt(sc->rhobar * sc->rhobar + beta * beta);
-    if (rho == 0.0) { sc->rho_zero = 1; sc->t1 = 0.0; sc->t2 = 0.0; return; }
+    if (rho == 0.0) { sc->rho_zero = 1; sc->t1 = 0.0; sc->t2 = 0.0; sc->stop = 1; return; }
     const double rho_inv = 1.0 / rho;
     const double c = sc->rhobar * rho_inv;
     const double s = beta * rho_inv;
@@ -186,6 +196,8 @@ __device__ __forceinline__ void rotate(Scalars *sc)
     sc->t1 = phi * rho_inv;
     sc->t2 = -theta * rho_inv;
     sc->r = sc->phibar / sc->b1;
+    sc->iters += 1;
+    if (fabs(sc->rhobar) < 1.e-30 || !(sc->r > sc->rmin)) sc->stop = 1;
 }
 
 __global__ void k_rotate(Scalars *sc) { rotate(sc); }
@@ -219,6 +231,7 @@ __global__ void k_update_xw(double *__restrict__ v, double *__restrict__ w, doub
                             const Scalars *sc, double inv_alpha_known, double gamma)
 {
     // inv_alpha_known != 0: v has not been normalised yet (single-rank fused path): v = (1/alpha) v first, as k_scale would
+    if (sc->skip) return;
     const double t1 = sc->t1, t2 = sc->t2, ia = sc->inv_alpha;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double wi = w[i];
@@ -491,7 +504,7 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     }
     TFX_TRY(scale_u(ctx, L));
     TFX_TRY(adjoint_and_alpha(ctx, L));                                                  // :137-150
-    LAUNCH(k_init_scalars, 1, L->sc.p);                                                  // :134, :155-156
+    LAUNCH(k_init_scalars, 1, L->sc.p, L->rmin);                                         // :134, :155-156
     LAUNCH(k_copy, grid_for(nc), L->w.p, L->v.p, nc);                                    // :157
     TFX_HIP(hipGetLastError());
     TFX_TRY(read_scalars(ctx, L));
@@ -534,7 +547,14 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
     TFX_HIP(hipSetDevice(ctx->device));
     const int64_t nc = L->ncols, nr = L->nrows;
     int done = 0;
+    // Iterations are queued LSQR_CHUNK at a time; the scalars come back to the host once per chunk.  The loop's exit tests
+    // (:163 r <= rmin, :251-254 rho = 0, :286-289 small rhobar) run on the device inside the rotation, and an iteration queued
+    // behind a met exit test leaves x, w and the scalars untouched (Scalars::stop / skip), so the result is the one of the
+    // iteration-by-iteration loop - without a host round trip in every iteration of a launch-bound system.  With a target
+    // misfit (:168-189, a host decision per iteration) the chunk is one iteration.
+    constexpr int LSQR_CHUNK = 16;
     while (done < k && !L->finished && L->r > L->rmin) {                                  // :163
+        const int chunk = L->target_misfit > 0.0 ? 1 : std::min(k - done, LSQR_CHUNK);
         if (L->target_misfit > 0.0) {                                                     // :168-189
             const int64_t nd = L->nrows_data;
             if (ctx->spatial_unknowns) {                                                  // :171-176
@@ -550,39 +570,43 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
             TFX_TRY(read_scalars(ctx, L));
             if (std::sqrt(L->h_sc->misfit_ss / (double)nd) <= L->target_misfit) { L->finished = true; break; }
         }
-        // u = -alpha u (rank 0) | 0 (others), then u += S_loc v                           :194-209
-        LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
-        if (ctx->spatial_unknowns) {                                                      // :200-209
-            LAUNCH(k_copy, grid_for(nc), L->tw.p, L->v.p, nc);
-            TFX_TRY(transform_slice(ctx, L, 1));
-            TFX_TRY(S_forward(ctx, L->tw.p, L->u.p, 1));
-        } else {
-            TFX_TRY(S_forward(ctx, L->v.p, L->u.p, 1));
+        for (int j = 0; j < chunk; ++j) {
+            // u = -alpha u (rank 0) | 0 (others), then u += S_loc v                       :194-209
+            LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
+            if (ctx->spatial_unknowns) {                                                  // :200-209
+                LAUNCH(k_copy, grid_for(nc), L->tw.p, L->v.p, nc);
+                TFX_TRY(transform_slice(ctx, L, 1));
+                TFX_TRY(S_forward(ctx, L->tw.p, L->u.p, 1));
+            } else {
+                TFX_TRY(S_forward(ctx, L->v.p, L->u.p, 1));
+            }
+            if (ctx->cons.valid) TFX_TRY(spmv_dev(ctx, ctx->cons, L->v.p, L->u.p + L->nrows_data, 1));   // :211 (general C rows)
+            {                                                                             // :211 (diagonal blocks, local)
+                const int g = grid_for(nc);
+                LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p);
+                LAUNCH(k_final_sum, 1, L->red.p, g, L->u.p + nr);
+            }
+            TFX_HIP(hipGetLastError());
+            TFX_TRY(allreduce(ctx, L->u.p, nr + 1));                                      // :214
+            TFX_TRY(norm_u(ctx, L));                                                      // :218
+            {                                                                             // u, u_cons /= beta ; v = -beta v   (:218-225)
+                const int64_t nuc = (int64_t)L->nblocks * nc;
+                LAUNCH(k_scale_u_uc_v, grid_for(std::max(std::max(nr, nuc), nc)), L->u.p, nr, L->uc.p, nuc, L->v.p, nc, L->sc.p);
+            }
+            const bool fused = ctx->nranks <= 1 || !ctx->allreduce;                       // no reduction between sum_v and alpha
+            TFX_TRY(adjoint_and_alpha(ctx, L, fused));                                    // :228-241
+            if (!fused) LAUNCH(k_rotate, 1, L->sc.p);                                     // :248-266
+            LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, fused ? 1.0 : 0.0, L->gamma);   // :241, :269-274
+            TFX_HIP(hipGetLastError());
         }
-        if (ctx->cons.valid) TFX_TRY(spmv_dev(ctx, ctx->cons, L->v.p, L->u.p + L->nrows_data, 1));   // :211 (general C rows)
-        {                                                                                 // :211 (diagonal blocks, local)
-            const int g = grid_for(nc);
-            LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p);
-            LAUNCH(k_final_sum, 1, L->red.p, g, L->u.p + nr);
-        }
-        TFX_HIP(hipGetLastError());
-        TFX_TRY(allreduce(ctx, L->u.p, nr + 1));                                          // :214
-        TFX_TRY(norm_u(ctx, L));                                                          // :218
-        {                                                                                 // u, u_cons /= beta ; v = -beta v   (:218-225)
-            const int64_t nuc = (int64_t)L->nblocks * nc;
-            LAUNCH(k_scale_u_uc_v, grid_for(std::max(std::max(nr, nuc), nc)), L->u.p, nr, L->uc.p, nuc, L->v.p, nc, L->sc.p);
-        }
-        const bool fused = ctx->nranks <= 1 || !ctx->allreduce;                           // no reduction between sum_v and alpha
-        TFX_TRY(adjoint_and_alpha(ctx, L, fused));                                        // :228-241
-        if (!fused) LAUNCH(k_rotate, 1, L->sc.p);                                         // :248-266
-        LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, fused ? 1.0 : 0.0, L->gamma);   // :241, :269-274
-        TFX_HIP(hipGetLastError());
         TFX_TRY(read_scalars(ctx, L));
-        if (L->h_sc->rho_zero) { L->finished = true; break; }                             // :251-254 (x, w untouched: t1 = t2 = 0 ... see note)
+        const int did = L->h_sc->iters - L->iter;                                         // iterations that counted
+        L->iter = L->h_sc->iters;
+        done += did;
         L->r = L->h_sc->r;
-        L->iter += 1;
-        done += 1;
+        if (L->h_sc->rho_zero) { L->finished = true; break; }                             // :251-254
         if (std::fabs(L->h_sc->rhobar) < 1.e-30) { L->finished = true; break; }           // :286-289
+        if (did < chunk) break;                                                           // r <= rmin inside the chunk
     }
     if (done_out) *done_out = done;
     if (r_out) *r_out = L->r;
