@@ -2808,7 +2808,14 @@ int tfx_matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const in
     TFX_HIP(hipMemcpyAsync(dn.p, nel_host, (size_t)nr * sizeof(int32_t), hipMemcpyHostToDevice, s));
     TFX_HIP(hipMemcpyAsync(dof.p, ho.data(), (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, s));
     ctx->target = &ctx->selmat();
-    TFX_TRY(matrix_append_rows(ctx, row_begin, nr, cols_dev, vals_dev, dn.p, dof.p, maxlen));
+    // the contract is blocks of up to RB_MAX rows starting at a multiple of RB_MAX; the matrix's own row block may be a smaller
+    // power of two (small matrices get smaller tiles)
+    if (row_begin % RB_MAX != 0 || nr > RB_MAX || nr <= 0)
+        return fail(TFX_E_ARG, "tfx_matrix_append_rows: rows [%lld, +%lld) are not a block of up to %d rows at a multiple of %d",
+                    (long long)row_begin, (long long)nr, RB_MAX, RB_MAX);
+    const int rbm = ctx->selmat().RB;
+    for (int64_t r0 = 0; r0 < nr; r0 += rbm)
+        TFX_TRY(matrix_append_rows(ctx, row_begin + r0, std::min<int64_t>(rbm, nr - r0), cols_dev, vals_dev, dn.p + r0, dof.p + r0, maxlen));
     ctx->selmat().nnz += run;
     return 0;
 }

@@ -37,12 +37,17 @@ struct LsqrState {
     DBuf<double> tw;       // WAVELET_DOMAIN = F: wavelet-domain image of v / x, or S^T u before the inverse transform
     DBuf<double> twf;      //   multi-rank: the full-length vector (all ranks' slices) the transform runs on
     DBuf<double> red;      // block partial sums
+    DBuf<unsigned int> cnt;   // arrival counters of the single-launch reductions (zero between launches)
     DBuf<Scalars> sc;
     Scalars *h_sc = nullptr;   // pinned
     int iter = 0;          // iterations completed
     double r = 1.0;
     bool active = false, exact = false, finished = false;
 };
+
+__device__ __forceinline__ void set_beta(Scalars *sc, double uc_total);
+__device__ __forceinline__ void set_alpha(Scalars *sc);
+__device__ __forceinline__ void rotate(Scalars *sc);
 
 constexpr int RED_BLOCKS = 1024;
 constexpr int RED_THREADS = 256;
@@ -62,6 +67,31 @@ __device__ __forceinline__ double block_sum(double v)
     return s;   // valid in thread 0
 }
 
+// Grid-wide reduction in one launch: every block leaves its partial sum in red[], the block that finishes last adds them up in
+// index order - the same arithmetic as a separate k_final_sum launch, one launch less in a chain that is bound by
+// launch-to-launch latency on small systems.  counter must be zero on entry; it is zero again on exit.
+__device__ __forceinline__ bool last_block_done(unsigned int *counter)
+{
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = atomicAdd(counter, 1u);
+        s_last = (t == gridDim.x - 1);
+        if (s_last) *counter = 0;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+__device__ __forceinline__ double final_sum_dev(const double *red, int n)       // valid in thread 0
+{
+    const volatile double *vr = red;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += vr[i];
+    return block_sum(s);
+}
+
 // red[block] = sum over the block's grid-stride range of x[i]^2
 __global__ void k_sumsq(const double *__restrict__ x, int64_t n, double *__restrict__ red)
 {
@@ -69,6 +99,23 @@ __global__ void k_sumsq(const double *__restrict__ x, int64_t n, double *__restr
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s = fma(x[i], x[i], s);
     s = block_sum(s);
     if (threadIdx.x == 0) red[blockIdx.x] = s;
+}
+
+// ||u||^2 over the rows and beta in one launch (norm_u)
+__global__ void k_sumsq_beta(const double *__restrict__ x, int64_t n, double *red, unsigned int *counter, Scalars *sc,
+                             const double *uc_total)
+{
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s = fma(x[i], x[i], s);
+    s = block_sum(s);
+    if (threadIdx.x == 0) red[blockIdx.x] = s;
+    if (last_block_done(counter)) {
+        const double tot = final_sum_dev(red, (int)gridDim.x);
+        if (threadIdx.x == 0) {
+            sc->sum_u = tot;
+            set_beta(sc, *uc_total);
+        }
+    }
 }
 
 // *dst = sum of red[0..n) in index order (deterministic)
@@ -92,8 +139,9 @@ __global__ void k_scale(double *__restrict__ x, int64_t n, const double *factor_
 }
 
 // u_cons[b] = -alpha * u_cons[b] + diag[b] .* v  ; red[block] = partial ||u_cons||^2      (lsqr_solver2.F90:194-211)
+// dst != null: the last block also writes the total (index-order sum of the partials) to *dst
 __global__ void k_cons_forward(double *__restrict__ uc, const float *__restrict__ diag, const double *__restrict__ v,
-                               int64_t ncols, int nblocks, const Scalars *sc, double *__restrict__ red)
+                               int64_t ncols, int nblocks, const Scalars *sc, double *red, unsigned int *counter, double *dst)
 {
     const double alpha = sc->alpha;
     double s = 0.0;
@@ -108,11 +156,16 @@ __global__ void k_cons_forward(double *__restrict__ uc, const float *__restrict_
     }
     s = block_sum(s);
     if (threadIdx.x == 0) red[blockIdx.x] = s;
+    if (dst && last_block_done(counter)) {
+        const double tot = final_sum_dev(red, (int)gridDim.x);
+        if (threadIdx.x == 0) *dst = tot;
+    }
 }
 
 // v += sum_b diag[b] .* u_cons[b] ; red[block] = partial ||v||^2                          (lsqr_solver2.F90:236-241)
+// mode 0: partials only; 1: the last block writes sum_v; 2: ... and alpha and the plane rotation (single rank)
 __global__ void k_cons_adjoint(double *__restrict__ v, const float *__restrict__ diag, const double *__restrict__ uc,
-                               int64_t ncols, int nblocks, double *__restrict__ red)
+                               int64_t ncols, int nblocks, double *red, unsigned int *counter, Scalars *sc, int mode)
 {
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncols; i += (int64_t)gridDim.x * blockDim.x) {
@@ -126,6 +179,13 @@ __global__ void k_cons_adjoint(double *__restrict__ v, const float *__restrict__
     }
     s = block_sum(s);
     if (threadIdx.x == 0) red[blockIdx.x] = s;
+    if (mode != 0 && last_block_done(counter)) {
+        const double tot = final_sum_dev(red, (int)gridDim.x);
+        if (threadIdx.x == 0) {
+            sc->sum_v = tot;
+            if (mode == 2) { set_alpha(sc); rotate(sc); }
+        }
+    }
 }
 
 // beta = sqrt(sum_u + sum_uc); scale factor 1/beta (normalize, lsqr_solver2.F90:501-530)
@@ -148,19 +208,6 @@ __device__ __forceinline__ void set_alpha(Scalars *sc)
 }
 
 __global__ void k_alpha(Scalars *sc) { set_alpha(sc); }
-
-// sum_u = sum of red[0..n) in index order, then beta: one launch instead of k_final_sum + a scalar kernel (small systems are
-// bound by the launch-to-launch latency of this chain)
-__global__ void k_final_sum_beta(const double *__restrict__ red, int n, Scalars *sc, const double *uc_total)
-{
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s += red[i];
-    s = block_sum(s);
-    if (threadIdx.x == 0) {
-        sc->sum_u = s;
-        set_beta(sc, *uc_total);
-    }
-}
 
 // first-iteration initialisation (lsqr_solver2.F90:134, :155-157)
 __global__ void k_init_scalars(Scalars *sc, double rmin)
@@ -201,19 +248,6 @@ __device__ __forceinline__ void rotate(Scalars *sc)
 }
 
 __global__ void k_rotate(Scalars *sc) { rotate(sc); }
-
-// single rank: sum_v (index order) -> alpha -> rotation in one launch; 1/alpha stays in sc->inv_alpha for k_update_xw
-__global__ void k_final_sum_alpha_rotate(const double *__restrict__ red, int n, Scalars *sc)
-{
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s += red[i];
-    s = block_sum(s);
-    if (threadIdx.x == 0) {
-        sc->sum_v = s;
-        set_alpha(sc);
-        rotate(sc);
-    }
-}
 
 // u *= t1 ; u_cons *= t1 ; v = -beta v   (normalisation of u and the first half of the adjoint step, :218-225) in one launch
 __global__ void k_scale_u_uc_v(double *__restrict__ u, int64_t nu, double *__restrict__ uc, int64_t nuc, double *__restrict__ v,
@@ -311,8 +345,7 @@ static int norm_u(tfx_ctx *ctx, LsqrState *L)
 {
     hipStream_t s = ctx->stream;
     const int g = grid_for(L->nrows);
-    LAUNCH(k_sumsq, g, L->u.p, L->nrows, L->red.p);
-    LAUNCH(k_final_sum_beta, 1, L->red.p, g, L->sc.p, L->u.p + L->nrows);
+    LAUNCH(k_sumsq_beta, g, L->u.p, L->nrows, L->red.p, L->cnt.p, L->sc.p, L->u.p + L->nrows);
     TFX_HIP(hipGetLastError());
     return 0;
 }
@@ -383,14 +416,9 @@ static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L, bool fuse_rotate = fals
     }
     if (ctx->cons.valid) TFX_TRY(spmtv_dev(ctx, ctx->cons, L->u.p + L->nrows_data, L->v.p, 1));     // lsqr_solver2.F90:147, :238
     const int g = grid_for(L->ncols);
-    LAUNCH(k_cons_adjoint, g, L->v.p, L->diag.p, L->uc.p, L->ncols, L->nblocks, L->red.p);
-    if (fuse_rotate) {
-        LAUNCH(k_final_sum_alpha_rotate, 1, L->red.p, g, L->sc.p);
-        TFX_HIP(hipGetLastError());
-        return 0;
-    }
-    LAUNCH(k_final_sum, 1, L->red.p, g, &L->sc.p->sum_v);
+    LAUNCH(k_cons_adjoint, g, L->v.p, L->diag.p, L->uc.p, L->ncols, L->nblocks, L->red.p, L->cnt.p + 1, L->sc.p, fuse_rotate ? 2 : 1);
     TFX_HIP(hipGetLastError());
+    if (fuse_rotate) return 0;
     TFX_TRY(allreduce(ctx, &L->sc.p->sum_v, 1));
     LAUNCH(k_alpha, 1, L->sc.p);
     LAUNCH(k_scale, g, L->v.p, L->ncols, &L->sc.p->t2, 0);
@@ -452,6 +480,8 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     TFX_TRY(L->uc.ensure((size_t)std::max<int64_t>(1, nblocks * nc)));
     TFX_TRY(L->diag.ensure((size_t)std::max<int64_t>(1, nblocks * nc)));
     TFX_TRY(L->red.ensure(RED_BLOCKS));
+    TFX_TRY(L->cnt.ensure(4));
+    TFX_HIP(hipMemsetAsync(L->cnt.p, 0, 4 * sizeof(unsigned int), ctx->stream));
     if (ctx->spatial_unknowns) {
         const int64_t n123 = (int64_t)ctx->wd_n1 * ctx->wd_n2 * ctx->wd_n3;
         if (ctx->nranks > 1) {
@@ -583,8 +613,7 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
             if (ctx->cons.valid) TFX_TRY(spmv_dev(ctx, ctx->cons, L->v.p, L->u.p + L->nrows_data, 1));   // :211 (general C rows)
             {                                                                             // :211 (diagonal blocks, local)
                 const int g = grid_for(nc);
-                LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p);
-                LAUNCH(k_final_sum, 1, L->red.p, g, L->u.p + nr);
+                LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p, L->cnt.p + 2, L->u.p + nr);
             }
             TFX_HIP(hipGetLastError());
             TFX_TRY(allreduce(ctx, L->u.p, nr + 1));                                      // :214

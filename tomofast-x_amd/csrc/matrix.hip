@@ -283,8 +283,26 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
     m.ncols = ncols;
     m.nnz = 0;
     if (nrows <= 0 || ncols <= 0) return fail(TFX_E_ARG, "matrix_begin: empty matrix %lld x %lld", (long long)nrows, (long long)ncols);
-    m.TC = (int)std::min<int64_t>(TC_MAX, (ncols + 63) / 64 * 64);
-    m.RB = (int)std::min<int64_t>(RB_MAX, (nrows + 63) / 64 * 64);
+    // Tile shape.  Large matrices use the largest tile (RB_MAX x TC_MAX: least staging per entry).  A tile is never split
+    // between workgroups, so a small or medium matrix gets smaller tiles - enough of them for ~2 workgroups per CU, but not
+    // finer than 16 chunks of entries (a workgroup's 16 waves): narrower column tiles first (less x staging, less LDS, more
+    // workgroups per CU), then lower row blocks.
+    {
+        // RB is a power of two (64 .. RB_MAX): the public append entry point takes blocks of RB_MAX rows and splits them
+        int64_t rb_full = 64;
+        while (rb_full < RB_MAX && rb_full < nrows) rb_full *= 2;
+        const int64_t tc_full = std::min<int64_t>(TC_MAX, (ncols + 63) / 64 * 64);
+        const double density = std::min(1.0, (double)nnz_upper / ((double)nrows * (double)ncols));
+        const double per_tile = std::max<double>(16.0 * CHUNK, (double)nnz_upper / (2.0 * std::max(1, ctx->num_cu)));
+        const double area = per_tile / std::max(density, 1e-12);
+        int64_t tc = 256;
+        while (tc < tc_full && (double)tc * (double)rb_full < area) tc *= 2;
+        tc = std::min(tc, tc_full);
+        int64_t rb = 64;
+        while (rb < rb_full && (double)rb * (double)tc < area) rb *= 2;
+        m.TC = (int)tc;
+        m.RB = (int)rb;
+    }
     m.ntc = (int)((ncols + m.TC - 1) / m.TC);
     m.nrb = (int)((nrows + m.RB - 1) / m.RB);
     int64_t markers = std::min<int64_t>(nnz_upper, (int64_t)nrows * m.ntc);
