@@ -86,6 +86,7 @@ struct WorkItem {     // one workgroup's work: a run of tiles sharing rb (forwar
     int32_t key;          // rb (forward) / t (adjoint)
     int32_t slot;         // position inside the run of items with the same key
     int32_t pidx;         // partial-sum tile owned by this item (-1: adjoint slot 0 adds straight into y)
+    int32_t cb, ce;       // a heavy tile is shared by several items: this one takes its chunks [cb, ce) (single-tile items; ce < 0: all)
 };
 
 struct TiledMatrix {

@@ -118,6 +118,27 @@ __global__ void k_sumsq_beta(const double *__restrict__ x, int64_t n, double *re
     }
 }
 
+// The same finalisations as separate one-block launches, for grids beyond ONE_LAUNCH_MAX_BLOCKS: there the arrival counter (one
+// same-address atomic per block, ~50 ns each) costs more than the launch it saves.
+constexpr int ONE_LAUNCH_MAX_BLOCKS = 64;
+__global__ void k_final_sum_beta(const double *__restrict__ red, int n, Scalars *sc, const double *uc_total)
+{
+    const double tot = final_sum_dev(red, n);
+    if (threadIdx.x == 0) {
+        sc->sum_u = tot;
+        set_beta(sc, *uc_total);
+    }
+}
+
+__global__ void k_final_sum_v(const double *__restrict__ red, int n, Scalars *sc, int mode)
+{
+    const double tot = final_sum_dev(red, n);
+    if (threadIdx.x == 0) {
+        sc->sum_v = tot;
+        if (mode == 2) { set_alpha(sc); rotate(sc); }
+    }
+}
+
 // *dst = sum of red[0..n) in index order (deterministic)
 __global__ void k_final_sum(const double *__restrict__ red, int n, double *dst)
 {
@@ -345,7 +366,12 @@ static int norm_u(tfx_ctx *ctx, LsqrState *L)
 {
     hipStream_t s = ctx->stream;
     const int g = grid_for(L->nrows);
-    LAUNCH(k_sumsq_beta, g, L->u.p, L->nrows, L->red.p, L->cnt.p, L->sc.p, L->u.p + L->nrows);
+    if (g <= ONE_LAUNCH_MAX_BLOCKS) {
+        LAUNCH(k_sumsq_beta, g, L->u.p, L->nrows, L->red.p, L->cnt.p, L->sc.p, L->u.p + L->nrows);
+    } else {
+        LAUNCH(k_sumsq, g, L->u.p, L->nrows, L->red.p);
+        LAUNCH(k_final_sum_beta, 1, L->red.p, g, L->sc.p, L->u.p + L->nrows);
+    }
     TFX_HIP(hipGetLastError());
     return 0;
 }
@@ -416,7 +442,13 @@ static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L, bool fuse_rotate = fals
     }
     if (ctx->cons.valid) TFX_TRY(spmtv_dev(ctx, ctx->cons, L->u.p + L->nrows_data, L->v.p, 1));     // lsqr_solver2.F90:147, :238
     const int g = grid_for(L->ncols);
-    LAUNCH(k_cons_adjoint, g, L->v.p, L->diag.p, L->uc.p, L->ncols, L->nblocks, L->red.p, L->cnt.p + 1, L->sc.p, fuse_rotate ? 2 : 1);
+    const int vmode = fuse_rotate ? 2 : 1;
+    if (g <= ONE_LAUNCH_MAX_BLOCKS) {
+        LAUNCH(k_cons_adjoint, g, L->v.p, L->diag.p, L->uc.p, L->ncols, L->nblocks, L->red.p, L->cnt.p + 1, L->sc.p, vmode);
+    } else {
+        LAUNCH(k_cons_adjoint, g, L->v.p, L->diag.p, L->uc.p, L->ncols, L->nblocks, L->red.p, L->cnt.p + 1, L->sc.p, 0);
+        LAUNCH(k_final_sum_v, 1, L->red.p, g, L->sc.p, vmode);
+    }
     TFX_HIP(hipGetLastError());
     if (fuse_rotate) return 0;
     TFX_TRY(allreduce(ctx, &L->sc.p->sum_v, 1));
@@ -613,7 +645,12 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
             if (ctx->cons.valid) TFX_TRY(spmv_dev(ctx, ctx->cons, L->v.p, L->u.p + L->nrows_data, 1));   // :211 (general C rows)
             {                                                                             // :211 (diagonal blocks, local)
                 const int g = grid_for(nc);
-                LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p, L->cnt.p + 2, L->u.p + nr);
+                if (g <= ONE_LAUNCH_MAX_BLOCKS) {
+                    LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p, L->cnt.p + 2, L->u.p + nr);
+                } else {
+                    LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p, L->cnt.p + 2, (double *)nullptr);
+                    LAUNCH(k_final_sum, 1, L->red.p, g, L->u.p + nr);
+                }
             }
             TFX_HIP(hipGetLastError());
             TFX_TRY(allreduce(ctx, L->u.p, nr + 1));                                      // :214

@@ -418,6 +418,29 @@ static void build_items(const std::vector<TileMeta> &tiles, bool forward, int64_
         size_t b = i;
         pbase[key] = npartial;
         while (b < j) {
+            const int64_t first = (int64_t)tiles[idx[b]].nchunks * CHUNK;
+            if (first > target + target / 2 && tiles[idx[b]].nchunks >= 32) {
+                // a tile much heavier than an item's share (wavelet-compressed rows put most entries of a small kernel into a
+                // few column tiles): its chunks are dealt to several items - every chunk knows its first row (chunk_row0), and
+                // the items add up through their partial tiles like any other items of the key
+                const int nch = tiles[idx[b]].nchunks;
+                const int nparts = (int)std::min<int64_t>((first + target - 1) / target, nch / 16);
+                for (int q = 0; q < nparts; ++q) {
+                    WorkItem w;
+                    w.begin = (int32_t)b;
+                    w.end = (int32_t)b + 1;
+                    w.key = key;
+                    w.slot = slot;
+                    w.pidx = forward ? npartial++ : (slot == 0 ? -1 : npartial++);
+                    w.cb = (int32_t)((int64_t)nch * q / nparts);
+                    w.ce = (int32_t)((int64_t)nch * (q + 1) / nparts);
+                    ++slot;
+                    items.push_back(w);
+                    item_sz.push_back((int64_t)(w.ce - w.cb) * CHUNK);
+                }
+                b += 1;
+                continue;
+            }
             int64_t acc = 0;
             size_t e = b;
             while (e < j && (acc == 0 || acc + (int64_t)tiles[idx[e]].nchunks * CHUNK <= target)) {
@@ -430,6 +453,8 @@ static void build_items(const std::vector<TileMeta> &tiles, bool forward, int64_
             w.key = key;
             w.slot = slot;
             w.pidx = forward ? npartial++ : (slot == 0 ? -1 : npartial++);
+            w.cb = 0;
+            w.ce = -1;
             ++slot;
             items.push_back(w);
             item_sz.push_back(acc);
@@ -577,7 +602,8 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_fwd(const WorkItem *__res
         for (int i = tid; i < TC; i += SPMV_THREADS) xs[swz(i)] = (i < ncol) ? x[col0 + i] : 0.0;
         __syncthreads();
         const int64_t cbase = tm.off / CHUNK;
-        for (int c = wave; c < tm.nchunks; c += SPMV_WAVES) {
+        const int c_end = it.ce < 0 ? tm.nchunks : it.ce;
+        for (int c = it.cb + wave; c < c_end; c += SPMV_WAVES) {
             ChunkRegs cr;
             load_chunk(codes, vals, tm.off + (int64_t)c * CHUNK + lane * 8, cr);
             int cur = chunk_row0[cbase + c];
@@ -626,17 +652,32 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_fwd(const WorkItem *__res
     for (int i = tid; i < RB; i += SPMV_THREADS) dst[i] = outs[i];
 }
 
-// b[row] = (add ? b[row] : 0) + sum over the partial tiles of the row's block (fixed order: deterministic)
-__global__ void k_fwd_reduce(const double *__restrict__ partial, const int32_t *__restrict__ nslots,
-                             const int32_t *__restrict__ pbase, int RB, int64_t nrows, double *__restrict__ b, int add)
+// b[row] = (add ? b[row] : 0) + sum over the partial tiles of the row's block (fixed order: deterministic).
+// A block takes FR_ROWS rows; its FR_GROUPS thread groups each add every FR_GROUPS-th partial tile (small matrices have
+// hundreds of partial tiles per row block: a single sequential chain per row would be latency-bound), then the group sums are
+// added in group order.
+constexpr int FR_ROWS = 16, FR_GROUPS = 16;
+__global__ __launch_bounds__(FR_ROWS * FR_GROUPS) void k_fwd_reduce(const double *__restrict__ partial, const int32_t *__restrict__ nslots,
+                                                                    const int32_t *__restrict__ pbase, int RB, int64_t nrows,
+                                                                    double *__restrict__ b, int add)
 {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    const int rb = (int)(r / RB), lr = (int)(r - (int64_t)rb * RB);
-    const int ns = nslots[rb], p0 = pbase[rb];
-    double s = add ? b[r] : 0.0;
-    for (int k = 0; k < ns; ++k) s += partial[(int64_t)(p0 + k) * RB + lr];
-    b[r] = s;
+    __shared__ double part[FR_GROUPS][FR_ROWS];
+    const int lr_in = threadIdx.x % FR_ROWS, g = threadIdx.x / FR_ROWS;
+    const int64_t r = (int64_t)blockIdx.x * FR_ROWS + lr_in;
+    double s = 0.0;
+    if (r < nrows) {
+        const int rb = (int)(r / RB), lr = (int)(r - (int64_t)rb * RB);
+        const int ns = nslots[rb], p0 = pbase[rb];
+        for (int k = g; k < ns; k += FR_GROUPS) s += partial[(int64_t)(p0 + k) * RB + lr];
+    }
+    part[g][lr_in] = s;
+    __syncthreads();
+    if (g == 0 && r < nrows) {
+        double t = add ? b[r] : 0.0;
+#pragma unroll
+        for (int q = 0; q < FR_GROUPS; ++q) t += part[q][lr_in];
+        b[r] = t;
+    }
 }
 
 // adjoint: one workgroup = a run of tiles of one column tile; slot 0 adds into y, the others write partials.
@@ -664,7 +705,8 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adj(const WorkItem *__res
         for (int i = tid; i < RB; i += SPMV_THREADS) us[i] = (i < nrow) ? u[row0 + i] : 0.0;
         __syncthreads();
         const int64_t cbase = tm.off / CHUNK;
-        for (int c = wave; c < tm.nchunks; c += SPMV_WAVES) {
+        const int c_end = it.ce < 0 ? tm.nchunks : it.ce;
+        for (int c = it.cb + wave; c < c_end; c += SPMV_WAVES) {
             ChunkRegs cr;
             load_chunk(codes, vals, tm.off + (int64_t)c * CHUNK + lane * 8, cr);
             int cur = chunk_row0[cbase + c];
@@ -759,7 +801,7 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
         if (prof) prof_end(ctx, 0);
         TFX_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_fwd_reduce, dim3((unsigned)((m.nrows + 255) / 256)), dim3(256), 0, s, m.fwd_partial.p,
+    hipLaunchKernelGGL(k_fwd_reduce, dim3((unsigned)((m.nrows + FR_ROWS - 1) / FR_ROWS)), dim3(FR_ROWS * FR_GROUPS), 0, s, m.fwd_partial.p,
                        m.fwd_nslots.p, m.fwd_pbase.p, m.RB, m.nrows, d_b, add);
     TFX_HIP(hipGetLastError());
     return 0;
