@@ -326,6 +326,71 @@ def test_whole_inversion_with_gradient_damping_two_ranks():
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
+def _worker_joint_coupled(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tfx = importlib.import_module("tomofast-x_amd")
+        import multirank_model as mm
+        for name in ("e2e_joint", "e2e_xgrad", "e2e_clust"):
+            g = np.load(os.path.join(GOLDEN, name + ".npz"))
+            dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
+            N = int(np.prod(dims))
+            ctx = tfx.Context(0)
+            ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
+            ctx.set_allreduce(tfx.distributed.TorchAllreduce(0), rank, world)
+            c0, c1 = (0, N // 2 + 3) if rank == 0 else (N // 2 + 3, N)
+            probs = []
+            for i, tag in enumerate(("grav", "magn")):
+                ctx.select_problem(i)
+                S = (g["np1_%s_row_ptr" % tag], g["np1_%s_cols" % tag], g["np1_%s_vals" % tag])
+                ctx.matrix_upload_csr(S[0].size - 1, c1 - c0, *mm.column_slice(S, c0, c1))
+                probs.append(dict(column_weight=g["np1_%s_column_weight" % tag], data_obs=g["np1_%s_data_observed" % tag],
+                                  problem_weight=1.0, alpha=float(g["alpha"][i])))
+            ctx.select_problem(0)
+            kw = {}
+            if name == "e2e_xgrad":
+                kw["cross_gradient"] = dict(weight=float(g["xgrad_weight"]), der_type=int(g["der_type"]))
+            if name == "e2e_clust":
+                kw["clustering"] = dict(weight=g["clust_weight"], mixtures=g["mixtures"], opt_type=int(g["opt_type"]),
+                                        cell_weights=None if int(g["cons_type"]) == 1 else g["cell_weights"])
+            m, d, hist = tfx.inversion.solve_problem_joint(ctx, probs, int(g["ctype"]), int(g["nmajor"]), int(g["nminor"]),
+                                                           col_range=(c0, c1), **kw)
+            for i, tag in enumerate(("grav", "magn")):
+                ref = g["np1_%s_model_final" % tag]
+                self_diff = np.linalg.norm(g["np2_%s_model_final" % tag] - ref) / np.linalg.norm(ref)
+                err = np.linalg.norm(m[i] - ref) / np.linalg.norm(ref)
+                assert err <= max(1e-6, 100.0 * self_diff), (name, tag, err, self_diff)
+            ctx.close()
+        q.put((rank, "ok"))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_joint_inversions_with_coupling_two_ranks():
+    """solve_problem_joint on 2 ranks (each holds a cell range of both kernels): the plain joint system in the wavelet domain,
+    and the cross-gradient / clustering couplings with spatial unknowns (constraint rows replicated, each rank's own columns of
+    both column blocks) - vs the reference's final models."""
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29800 + (os.getpid() + 11) % 2000
+    procs = [ctxm.Process(target=_worker_joint_coupled, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
 def _worker_spatial(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -355,8 +355,19 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
     return m, d_calc, hist
 
 
+def restrict_columns_blocks(G, c0, c1, N, nblocks):
+    """restrict_columns for a constraint block over `nblocks` models of N cells each (joint system): the rank keeps the cells
+    (c0, c1] of every model; its unknown vector is [model 1 slice; model 2 slice; ...]."""
+    rowptr, cols, vals = G
+    cell = (cols - 1) % N + 1
+    blk = (cols - 1) // N
+    keep = (cell > c0) & (cell <= c1)
+    csum = np.concatenate([[0], np.cumsum(keep)])
+    return csum[rowptr].astype(np.int64), (blk[keep] * (c1 - c0) + cell[keep] - c0).astype(np.int32), vals[keep]
+
+
 def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e-13, gamma=0.0, target_misfit=0.0, log=None,
-                        cross_gradient=None, clustering=None):
+                        cross_gradient=None, clustering=None, col_range=None):
     """Joint inversion of two problems on one grid (gravity + magnetic) without structural coupling: both sensitivity
     kernels in ONE LSQR system, S = blockdiag(slot 0, slot 1) (src/inversion/joint_inverse_problem.F90:393-573; block layout
     :712-739, right-hand side :379-387, one damping block per problem :448-463).  Coupling constraints built on the host
@@ -366,6 +377,8 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
     problem i's kernel, built with its problem_weight.  cross_gradient = dict(weight, der_type 1 | 2): the structural
     coupling constraint; clustering = dict(weight (2), mixtures, opt_type 1 | 2[, cell_weights]): the petrophysical one.
     Either switches the solver to spatial unknowns (WAVELET_DOMAIN = false, :189-198); the rows go cross-gradient first (:529-541).
+    col_range = (c0, c1): this rank holds the cells (c0, c1] of both kernels (and the all-reduce hook is set); every rank keeps
+    the full models, the LSQR unknowns are [model 1 slice; model 2 slice].
     Returns (models, data_calc, history)."""
     nx, ny, nz = ctx.dims
     N = nx * ny * nz
@@ -382,11 +395,21 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
 
     spatial = cross_gradient is not None or clustering is not None
     clust_w = clustering_cell_weights(clustering["mixtures"], N, clustering.get("cell_weights")) if clustering is not None else None
+    c0, c1 = (0, N) if col_range is None else col_range
+    nloc = c1 - c0
+
+    def gather(v_loc):                                # slices of all ranks -> full vector (disjoint supports: a sum is a gather)
+        if col_range is None:
+            return v_loc
+        from .distributed import allreduce_numpy
+        full = np.zeros(N)
+        full[c0:c1] = v_loc
+        return allreduce_numpy(full)
 
     def calculate_data(i):                            # model.F90:242-305 on problem i's rows / columns
         ctx.select_problem(i)
         try:
-            return ctx.calc_data(to_wavelet(np.where(cw[i] != 0.0, m[i] / cw[i], 0.0)), pw[i], None)
+            return ctx.calc_data(to_wavelet(np.where(cw[i] != 0.0, m[i] / cw[i], 0.0))[c0:c1], pw[i], None)
         finally:
             ctx.select_problem(0)
 
@@ -400,10 +423,10 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
                 md = (m[i] - mp[i]) / cw[i]
                 if not spatial:
                     md = to_wavelet(md)
-                blk = np.zeros(P * N, np.float32)
-                blk[i * N:(i + 1) * N] = np.float32(p["alpha"] * pw[i])
-                r = np.zeros(P * N)
-                r[i * N:(i + 1) * N] = -p["alpha"] * pw[i] * md
+                blk = np.zeros(P * nloc, np.float32)
+                blk[i * nloc:(i + 1) * nloc] = np.float32(p["alpha"] * pw[i])
+                r = np.zeros(P * nloc)
+                r[i * nloc:(i + 1) * nloc] = -p["alpha"] * pw[i] * md[c0:c1]
                 diag.append(blk)
                 rhs.append(r)
         xcost = ccost = None
@@ -417,10 +440,14 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
                 G, grhs, ccost = clustering_rows(m[0], m[1], cw[0], cw[1], clustering["weight"], clustering["mixtures"], clust_w,
                                                  int(clustering.get("opt_type", 2)))
                 blocks.append((G, grhs))
+            if col_range is not None:                 # rows replicated, every rank fills its own columns
+                blocks = [(restrict_columns_blocks(b[0], c0, c1, N, P), b[1]) for b in blocks]
             rp = np.concatenate([[0]] + [b[0][0][1:] + off for b, off in zip(blocks, np.cumsum([0] + [int(b[0][0][-1]) for b in blocks])[:-1])])
             ctx.cons_upload_csr(rp.astype(np.int64), np.concatenate([b[0][1] for b in blocks]), np.concatenate([b[0][2] for b in blocks]),
                                 np.concatenate([b[1] for b in blocks]))
             ctx.lsqr_set_wavelet_domain(False, compression_type)
+            if col_range is not None:
+                ctx.lsqr_set_partition(c0, P)
         try:
             x, iters, r = ctx.lsqr_solve_sensit(b_data, nminor, rmin, gamma, target_misfit, diag, rhs)
         finally:
@@ -428,7 +455,7 @@ def solve_problem_joint(ctx, problems, compression_type, nmajor, nminor, rmin=1e
                 ctx.lsqr_set_wavelet_domain(True)
                 ctx.cons_clear()
         for i in range(P):
-            xi = x[i * N:(i + 1) * N]
+            xi = gather(x[i * nloc:(i + 1) * nloc])
             dm = ctx.inverse_wavelet(xi, nx, ny, nz, compression_type) if (compression_type > 0 and not spatial) else xi
             m[i] = m[i] + dm * cw[i]                  # joint_inverse_problem.F90:559-571
             d[i] = calculate_data(i)
