@@ -3,6 +3,7 @@ libtfx.so) on the mansf_slice example (2 x 128 x 32 cells, 256 data, Haar 0.15, 
 iterations), reading the reference's ASCII input formats and writing its output files.  Compared with the files the
 reference itself wrote for the same Parfile (tests/golden/mansf.npz)."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -362,6 +363,20 @@ def test_two_ranks_under_mpiexec_match_the_reference_two_rank_run(tmp_path, gold
         self_diff = np.linalg.norm(g[key1].reshape(model.shape) - ref) / np.linalg.norm(ref)
         tol = max(1e-6, 100.0 * self_diff)
         assert np.linalg.norm(model - ref) <= tol * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
+    # sensit.readFromFiles = 2 on 2 ranks: the depth weight comes from the SENSIT folder (written by a single-rank run: the
+    # column-partitioned multi-rank build keeps its kernel on the devices), the kernel is built again
+    # (problem_joint_gravmag.F90:189-202) - same models
+    first = {sfx: read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), ncm) for _, sfx, ncm in cases}
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    par2 = re.sub(r"sensit\.readFromFiles\s*=\s*\d", "sensit.readFromFiles                = 2", str(g["parfile"]))
+    assert par2 != str(g["parfile"])
+    open(os.path.join(wd, "Parfile.txt"), "w").write(par2)
+    out = subprocess.run([MPIEXEC, "-n", "2", EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    for _, sfx, ncm in cases:
+        again = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), ncm)
+        assert np.linalg.norm(again - first[sfx]) <= 1e-6 * np.linalg.norm(first[sfx])
 
 
 @pytest.mark.parametrize("name", ["e2e_dgrad", "e2e_xgrad", "e2e_clust"])

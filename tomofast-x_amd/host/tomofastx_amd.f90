@@ -737,7 +737,6 @@ program tomofastx_amd
     hook_ctx = ctx
     call tfx_check(tfx_set_allreduce(ctx, c_funloc(allreduce_hook), c_null_ptr, int(myrank, c_int), int(nbproc, c_int)), &
                    'tfx_set_allreduce')
-    if (par%sensit_read == 2) call stop_msg('sensit.readFromFiles = 2 runs single-rank in this host.')
     ! ---- column partition (calculate_new_partitioning, sensitivity_gravmag.F90:573-640): per-cell non-zero counts of my share
     ! of the data rows of every kernel, summed over ranks and problems, then the reference's greedy nnz-balancing rule
     allocate(hist(n), hist_all(n), nel_at(nbproc), nnz_at(nbproc))
