@@ -88,3 +88,34 @@ def test_admm_projection_matches_the_restatement():
         x0 = st.iterate_admm_arrays(x, bounds)
         r0 = oinv.admm_iterate(z, u, x, bounds)
         assert bits_equal(x0, r0) and bits_equal(st.z, z) and bits_equal(st.u, u)
+
+
+def test_column_restriction_of_constraint_blocks(golden_dir):
+    """restrict_columns / restrict_columns_blocks: the column-partitioned form of a constraint block (rows replicated, each rank
+    its own cells of every model) - the pieces of all ranks put back together give the block."""
+    g, dims, grid, spacing = case(golden_dir, "e2e_xgrad")
+    N = int(np.prod(dims))
+    rng = np.random.default_rng(8)
+    m1, m2 = rng.standard_normal(N), rng.standard_normal(N)
+    G, rhs, _ = tfx.inversion.cross_gradient_rows(m1, m2, dims, spacing, g["np1_grav_column_weight"], g["np1_magn_column_weight"], 0.5, 2)
+    nrows = G[0].size - 1
+    dense = np.zeros((nrows, 2 * N))
+    for r in range(nrows):
+        dense[r, G[1][G[0][r]:G[0][r + 1]] - 1] = G[2][G[0][r]:G[0][r + 1]]
+    cuts = [0, 37, 150, N]
+    back = np.zeros_like(dense)
+    for c0, c1 in zip(cuts[:-1], cuts[1:]):
+        L = tfx.inversion.restrict_columns_blocks(G, c0, c1, N, 2)
+        nl = c1 - c0
+        assert L[0].size == nrows + 1 and (L[1].size == 0 or (L[1].min() >= 1 and L[1].max() <= 2 * nl))
+        for r in range(nrows):
+            cols = L[1][L[0][r]:L[0][r + 1]] - 1
+            assert np.all(np.diff(cols) > 0)                       # ascending inside a row, as the upload wants
+            blk, cell = cols // nl, cols % nl
+            back[r, blk * N + c0 + cell] = L[2][L[0][r]:L[0][r + 1]]
+    assert np.array_equal(back, dense)
+    # one model: restrict_columns
+    Gd, _ = tfx.inversion.gradient_damping_rows(m1, dims, spacing, g["np1_grav_column_weight"], 1.0, 1e-3)
+    one = tfx.inversion.restrict_columns(Gd, 37, 150)
+    keep = (Gd[1] > 37) & (Gd[1] <= 150)
+    assert np.array_equal(one[1], Gd[1][keep] - 37) and np.array_equal(one[2], Gd[2][keep]) and int(one[0][-1]) == int(keep.sum())
