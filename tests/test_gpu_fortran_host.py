@@ -495,6 +495,58 @@ def test_row_parallel_build_with_mpi_relayout(tmp_path):
     assert np.linalg.norm(models["exchange"][0] - models["redundant"][0]) <= 1e-4 * np.linalg.norm(ref)
 
 
+def test_sensit_files_of_a_multi_rank_run(tmp_path):
+    """3 ranks under mpiexec (row-parallel build): every rank writes the row file of its own row block from the device row
+    store, rank 0 the metadata / counts / weights.  The set reads back as the kernel a single-rank run writes (same bits), and a
+    2-rank run with sensit.readFromFiles = 1 on it gives the same model."""
+    import importlib
+    if not os.path.isfile(EXE) or not os.path.isfile(MPIEXEC):
+        pytest.skip("Fortran host / mpiexec not available")
+    pkg = importlib.import_module("tomofast-x_amd")
+    syn = pkg.synthetic
+    nx, ny, nz = 32, 24, 12
+    grid = syn.grid(nx, ny, nz)
+    xs, ys, zs = syn.observations(nx, ny, 72, 64)
+    n = nx * ny * nz
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    mtrue = np.where((k.ravel() >= nz // 4) & (k.ravel() < nz // 2) & (j.ravel() >= ny // 3) & (j.ravel() < 2 * ny // 3) &
+                     (i.ravel() >= nx // 3) & (i.ravel() < 2 * nx // 3), 300.0, 0.0)
+    models, sets = {}, {}
+    for tag, cmd, par in (("one", [EXE], PAR_BIG), ("three", [MPIEXEC, "-n", "3", EXE], PAR_BIG),
+                          ("reload", [MPIEXEC, "-n", "2", EXE], PAR_BIG.replace("sensit.readFromFiles                = 0", "sensit.readFromFiles                = 1"))):
+        wd = os.path.join(str(tmp_path), "three" if tag == "reload" else tag)
+        if tag != "reload":
+            os.makedirs(wd)
+            with open(os.path.join(wd, "grid.txt"), "w") as f:
+                f.write("%d\n" % n)
+                for p in range(n):
+                    f.write("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %d\n" % (grid[0][p], grid[1][p], grid[2][p], grid[3][p], grid[4][p],
+                                                                              grid[5][p], i.ravel()[p] + 1, j.ravel()[p] + 1, k.ravel()[p] + 1))
+            with open(os.path.join(wd, "data_grid.txt"), "w") as f:
+                f.write("%d\n" % xs.size)
+                for o in zip(xs, ys, zs):
+                    f.write("%.17g %.17g %.17g 0.0\n" % o)
+            with open(os.path.join(wd, "model_true.txt"), "w") as f:
+                f.write("%d\n" % n)
+                f.write("\n".join("%.17g" % v for v in mtrue) + "\n")
+        assert "sensit.readFromFiles" in par
+        open(os.path.join(wd, "Parfile.txt"), "w").write(par.format(nd=xs.size) + "sensit.folderPath                   = out/SENSIT/\n")
+        out = subprocess.run(cmd + ["-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+        models[tag] = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
+        if tag != "reload":
+            sets[tag] = pkg.sensit_io.read_sensit(os.path.join(wd, "out", "SENSIT"), 1)
+    a, b = sets["one"], sets["three"]
+    assert b["meta"]["nbproc"] == 3 and a["meta"]["nbproc"] == 1 and a["meta"]["nnz_total"] == b["meta"]["nnz_total"]
+    assert sorted(f for f in os.listdir(os.path.join(str(tmp_path), "three", "out", "SENSIT")) if f.startswith("sensit_grav_3_")) == \
+        ["sensit_grav_3_0", "sensit_grav_3_1", "sensit_grav_3_2"]
+    assert np.array_equal(a["rowptr"], b["rowptr"]) and np.array_equal(a["cols"], b["cols"]) and a["vals"].tobytes() == b["vals"].tobytes()
+    assert np.array_equal(a["nnz_hist"], b["nnz_hist"]) and a["column_weight"].tobytes() == b["column_weight"].tobytes()
+    assert abs(a["meta"]["comp_error"] - b["meta"]["comp_error"]) <= 1e-12 * a["meta"]["comp_error"]
+    for tag in ("three", "reload"):                   # mid-convergence comparison: see test_row_parallel_build_with_mpi_relayout
+        assert np.linalg.norm(models[tag] - models["one"]) <= 1e-4 * np.linalg.norm(models["one"]), tag
+
+
 def test_gradient_damping_parfile_matches_reference(tmp_path, golden_dir):
     """inversion.dampingGradient.grav.weight /= 0: the host builds the first-difference rows, uploads them as the general
     constraint matrix and solves with WAVELET_DOMAIN = F (spatial unknowns, per-iteration device transform)."""

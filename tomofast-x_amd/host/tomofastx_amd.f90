@@ -464,6 +464,30 @@ contains
     close(u)
   end subroutine write_weight_file
 
+  ! metadata, per-cell counts and depth weight of a kernel whose row files were written by nbproc ranks (:360-392, :415-464)
+  subroutine write_sensit_meta_files(folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, comp_error, nnz, nbproc, hist, cw)
+    character(len=*), intent(in) :: folder
+    integer, intent(in) :: ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, nbproc
+    real(dp), intent(in) :: comp_error, cw(:)
+    integer(c_int64_t), intent(in) :: nnz
+    integer(c_int32_t), intent(in) :: hist(:)
+    integer :: u
+    call execute_command_line('mkdir -p "'//trim(folder)//'"')
+    open(newunit=u, file=trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_meta.txt', form='formatted', status='replace', action='write')
+    write(u, *) nx, ny, nz, nd
+    write(u, *) nbproc, 4, dw_type
+    write(u, *) comp_type, comp_error
+    write(u, *) nc, ndc
+    write(u, *) nnz
+    close(u)
+    open(newunit=u, file=trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_nnz', status='replace', access='stream', form='unformatted', &
+         action='write', convert='big_endian')
+    write(u) int(nx * ny * nz, c_int32_t)
+    write(u) hist
+    close(u)
+    call write_weight_file(folder, ip, nx * ny * nz, cw)
+  end subroutine write_sensit_meta_files
+
   subroutine read_weight_file(folder, ip, n, cw)                                                              ! :920-970
     character(len=*), intent(in) :: folder
     integer, intent(in) :: ip, n
@@ -590,6 +614,7 @@ program tomofastx_amd
     real(dp), allocatable :: dw(:)                      ! data weight (ndc, nd) = 1 / data error, or 1 (data_gravmag.f90:243-279)
     real(dp), allocatable :: m(:), m_prior(:), m_synth(:), z_admm(:), u_admm(:), x0(:)
     real(dp), allocatable :: bnd(:, :), bnd_w(:)        ! ADMM intervals (2*nlithos, cell) and per-cell weight (model%bound_weight)
+    integer(c_int32_t), allocatable :: nnz_hist(:)      ! several ranks: per-cell entry counts of this kernel, all rows (sensit_nnz)
   end type t_prob
 
   type(t_par) :: par
@@ -761,6 +786,9 @@ program tomofastx_amd
           if (rb > ra) call build_kernel(ip, ra, rb, 0, 0, nnz_dummy, err_loc, c_loc(hist))
         endif
         hist_all = hist_all + hist
+        allocate(pr(ip)%nnz_hist(n))
+        pr(ip)%nnz_hist = hist
+        call allreduce_sum_i32(pr(ip)%nnz_hist, n)
       enddo
       call allreduce_sum_i32(hist_all, n)
     endif
@@ -816,6 +844,10 @@ program tomofastx_amd
       call allreduce_sum_dp_scalar(s1)
       nnz = nint(s1, c_int64_t)
     endif
+    if (nbproc > 1 .and. par%sensit_read /= 1 .and. exchange_ok(ip) .and. write_sensit_wanted() .and. io_rank) &
+      call write_sensit_meta_files(trim(par%path_output)//'/SENSIT', ip, par%nx, par%ny, par%nz, pr(ip)%nd, pr(ip)%ndc, pr(ip)%nc, &
+                                   par%dw_type, par%comp_type, err_sum / dble(pr(ip)%nd * pr(ip)%ndc * pr(ip)%nc), nnz, nbproc, &
+                                   pr(ip)%nnz_hist, pr(ip)%cw)
     print *, 'nnz_total = ', nnz
     print *, 'COMPRESSION RATE = ', dble(nnz) / dble(n) / dble(pr(ip)%nd) / dble(pr(ip)%nc) / dble(pr(ip)%ndc)
     print *, 'COMPRESSION ERROR, r = ', err_sum / dble(pr(ip)%nd * pr(ip)%ndc * pr(ip)%nc)
@@ -1604,9 +1636,68 @@ contains
       call tfx_check(tfx_device_free(ctx, dvals), 'tfx_device_free')
     enddo
     call tfx_check(tfx_matrix_finish(ctx), 'tfx_matrix_finish')
+    if (write_sensit_wanted()) call write_my_sensit_rows(jp, row_a, row_b, cnt_loc)
     call tfx_check(tfx_rowstore_free(ctx), 'tfx_rowstore_free')
     nnz_k = mine
   end subroutine relayout_rowstore
+
+  ! TFX_WRITE_SENSIT=0 skips the SENSIT files (the kernel has to cross PCIe for them)
+  logical function write_sensit_wanted()
+    character(len=8) :: v
+    integer :: l, st
+    call get_environment_variable('TFX_WRITE_SENSIT', v, l, st)
+    write_sensit_wanted = .not. (st == 0 .and. l > 0 .and. v(1:1) == '0')
+  end function write_sensit_wanted
+
+  ! The row file of this rank, sensit_{grav|magn}_{nbproc}_{rank} (sensitivity_gravmag.F90:142-153, :183, :306-309), from the row
+  ! store of the row-parallel build: my data rows with all their columns - what the reference's ranks write before its relayout.
+  subroutine write_my_sensit_rows(jp, row_a, row_b, cnt)
+    integer, intent(in) :: jp, row_a, row_b
+    integer(c_int32_t), intent(in) :: cnt(:, :)             ! (destination rank, local row): entries per column range
+    integer, parameter :: RCHUNK = 256
+    integer :: u, r0, r1, r, nel
+    integer(c_int64_t) :: cap, got, a
+    integer(c_int32_t), allocatable, target :: hc(:)
+    real(c_float), allocatable, target :: hv(:)
+    type(c_ptr) :: dc, dv
+    character(len=512) :: fname, tag
+    call execute_command_line('mkdir -p "'//trim(par%path_output)//'/SENSIT"')
+    write(tag, '(I0,A,I0)') nbproc, '_', myrank
+    fname = trim(par%path_output)//'/SENSIT/sensit_'//SENSIT_SUFFIX(jp)//'_'//trim(tag)
+    open(newunit=u, file=trim(fname), status='replace', access='stream', form='unformatted', action='write', convert='big_endian')
+    write(u) int(row_b - row_a, c_int32_t), int(pr(jp)%nd, c_int32_t), int(n, c_int32_t), int(myrank, c_int32_t), int(nbproc, c_int32_t)
+    do r0 = row_a, row_b - 1, RCHUNK
+      r1 = min(r0 + RCHUNK, row_b)
+      cap = 0
+      do r = r0 + 1, r1
+        cap = cap + sum(int(cnt(:, r - row_a), c_int64_t))
+      enddo
+      allocate(hc(max(cap, 1_c_int64_t)), hv(max(cap, 1_c_int64_t)))
+      if (cap > 0) then
+        call tfx_check(tfx_device_malloc(ctx, 4 * cap, dc), 'tfx_device_malloc')
+        call tfx_check(tfx_device_malloc(ctx, 4 * cap, dv), 'tfx_device_malloc')
+        call tfx_check(tfx_rowstore_pack(ctx, int(r0 - row_a, c_int64_t), int(r1 - r0, c_int64_t), 0_c_int64_t, int(n, c_int64_t), &
+                                         dc, dv, cap, got), 'tfx_rowstore_pack')
+        call tfx_check(tfx_copy(ctx, c_loc(hc), dc, 4 * cap), 'tfx_copy')
+        call tfx_check(tfx_copy(ctx, c_loc(hv), dv, 4 * cap), 'tfx_copy')
+        call tfx_check(tfx_device_free(ctx, dc), 'tfx_device_free')
+        call tfx_check(tfx_device_free(ctx, dv), 'tfx_device_free')
+      endif
+      a = 0
+      do r = r0 + 1, r1                                            ! data row r (1-based, global)
+        nel = sum(cnt(:, r - row_a))
+        write(u) int(r, c_int32_t), int(nel, c_int32_t), 1_c_int32_t, 1_c_int32_t
+        if (nel > 0) then
+          hc(a + 1:a + nel) = hc(a + 1:a + nel) + 1                ! the packed columns are 0-based
+          if (pr(jp)%pw * pr(jp)%dw(r) /= 1.d0) hv(a + 1:a + nel) = hv(a + 1:a + nel) / real(pr(jp)%pw * pr(jp)%dw(r), c_float)
+          write(u) hc(a + 1:a + nel), hv(a + 1:a + nel)
+        endif
+        a = a + nel
+      enddo
+      deallocate(hc, hv)
+    enddo
+    close(u)
+  end subroutine write_my_sensit_rows
 
   ! sensit.readFromFiles = 1 on several ranks: the per-cell counts of every kernel from the sensit_*_nnz files
   ! (read_sensit_nnz, sensitivity_gravmag.F90:530-568)
