@@ -202,7 +202,10 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(alg_b) * nnz_loc, "stored_bytes_per_launch": stored_b * nnz_loc,
                 "avg_launch_ms": {"spmv_fwd": round(avg[0], 4), "spmv_adj": round(avg[1], 4)},
-                "achieved_other_GBs": round(alg_b * nnz_loc / (avg[1 - dom] * 1e-3) / 1e9, 1)}
+                "achieved_other_GBs": round(alg_b * nnz_loc / (avg[1 - dom] * 1e-3) / 1e9, 1),
+                # frac can exceed 1: `achieved` prices the 8 B per non-zero the reference's CSR moves, the tiled
+                # matrix stores 6 B.  What actually crossed HBM (PMC traffic) over the same time, as a fraction of the peak:
+                "hbm_frac_on_measured_traffic": None if traffic is None else round(traffic / (avg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same workload
     cpu = None
