@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
                     }
             double v = g_grav() * gz;
             if (cw) v = v * c_w[j];
-            out[c_col[j]] = v;
+            __builtin_nontemporal_store(v, &out[c_col[j]]);       // 2 GB per batch: the next reader (wavelet x pass) finds nothing in L2 anyway
             sq = fma(v, v, sq);
         }
         if (sumsq) {                                        // cost_full (sensitivity_gravmag.F90:234), fixed order
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
                     double v = out[d][k];
                     if (cw) v = v * w;
                     const int sub = (o * NCD + d) * NCM + k;
-                    rows[(int64_t)sub * N + p] = v;
+                    __builtin_nontemporal_store(v, &rows[(int64_t)sub * N + p]);
                     sq[d * NCM + k] = fma(v, v, sq[d * NCM + k]);
                 }
         }
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
                         }
                 double v = g_grav() * gsum;                                                               // :301-306, :358
                 if (cw) v = v * c_w[j];
-                rows[(int64_t)(o * NC + comp) * N + p] = v;
+                __builtin_nontemporal_store(v, &rows[(int64_t)(o * NC + comp) * N + p]);
                 sq[comp] = fma(v, v, sq[comp]);
             }
         }
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
             double tmp[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (ab + k * MR < L) tmp[k] = gp[k * gstep];
+                if (ab + k * MR < L) tmp[k] = __builtin_nontemporal_load(&gp[k * gstep]);
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (ab + k * MR < L) T[la0 + k * lstep] = tmp[k];
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
             const int e = e0 + k * nt;
             la[k] = -1;
             if (e < total) {
-                if (ax.mode == 0) { la[k] = ra * P + rq; tmp[k] = base[g0 + e]; }      // the XT lines of an x tile are contiguous: q*L + a = e
+                if (ax.mode == 0) { la[k] = ra * P + rq; tmp[k] = __builtin_nontemporal_load(&base[g0 + e]); }      // the XT lines of an x tile are contiguous: q*L + a = e
                 else { const int a = DIVQ(e), q = e - a * nq; la[k] = a * P + q; tmp[k] = base[g0 + (int64_t)a * ax.astride + q]; }
             }
             rq += dq; ra += da;
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
         for (int ab = mr; ab < L; ab += MR * 8) {
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (ab + k * MR < L) gp[k * gstep] = T[la0 + k * lstep];
+                if (ab + k * MR < L) __builtin_nontemporal_store(T[la0 + k * lstep], &gp[k * gstep]);
             gp += 8 * gstep;
             la0 += 8 * lstep;
         }
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
         for (int k = 0; k < 8; ++k) {
             const int e = e0 + k * nt;
             if (e < total) {
-                if (ax.mode == 0) { base[g0 + e] = T[ra * P + rq]; }
+                if (ax.mode == 0) { __builtin_nontemporal_store(T[ra * P + rq], &base[g0 + e]); }
                 else { const int a = DIVQ(e), q = e - a * nq; base[g0 + (int64_t)a * ax.astride + q] = T[a * P + q]; }
             }
             rq += dq; ra += da;
@@ -1705,7 +1705,7 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
         bool slot = false;
         v[k] = 0.0;
         if (p < a.N) {
-            v[k] = r[p];
+            v[k] = __builtin_nontemporal_load(&r[p]);
             bool keep;
             if (banded) {
                 const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(v[k]));
