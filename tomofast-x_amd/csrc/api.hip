@@ -330,7 +330,7 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
                 if (pass == 0) cnt[(size_t)row] += 1;
                 else {
                     int64_t p = fill[(size_t)row]++;
-                    if (cols) cols[p] = (int32_t)((int64_t)tm.t * m.TC + (code & COLMASK) + 1);
+                    if (cols) cols[p] = (int32_t)((int64_t)tm.t * m.TC + col_slot(code & COLMASK) + 1);
                     if (vals) vals[p] = v;
                 }
             }

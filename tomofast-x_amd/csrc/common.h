@@ -72,6 +72,11 @@ constexpr int TC_MAX = 16384;         // columns per column tile (14-bit local c
 constexpr int RB_MAX = 2048;          // rows per row block
 constexpr uint16_t ROWSTART = 0x8000; // code bit 15: this entry starts a new row inside the tile
 constexpr uint16_t COLMASK = 0x3fff;
+// The column stored in a code is the LDS slot of that column inside the tile, not the column itself: slot = col ^ f(col >> 4), a
+// bijection inside aligned groups of 16 (an involution) that folds the higher index bits into the four bank bits.  Wavelet
+// coefficients sit on index lattices (multiples of 2^l per axis); without the fold the columns of one LDS instruction are
+// often congruent modulo 16 and pile onto one bank pair.  Stored pre-swizzled, it costs the product kernels nothing.
+__host__ __device__ inline int col_slot(int i) { return i ^ (((i >> 4) ^ (i >> 8) ^ (i >> 12)) & 15); }
 
 struct TileMeta {
     int64_t off;      // first entry (multiple of CHUNK) in codes[] / vals[]

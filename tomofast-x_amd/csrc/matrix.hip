@@ -6,7 +6,8 @@
 // Layout (DESIGN.md "Data layout in HBM").  The reference keeps CSR with 4-byte values + 4-byte columns
 // (8 B per non-zero).  Here S is cut into tiles of (RB <= 2048 rows) x (TC <= 16384 columns).  Inside a tile the
 // entries are in (row, column) order and stored as two streams:
-//     codes[]  uint16 : bit 15 = "first entry of a new row inside this tile", bits 0-13 = column inside the tile
+//     codes[]  uint16 : bit 15 = "first entry of a new row inside this tile", bits 0-13 = LDS slot of the column inside the tile
+//                       (col_slot(column), common.h: the column with its higher bits folded into the four bank bits)
 //     vals[]   float  : the value exactly as the reference stores it
 // i.e. 6 B per non-zero.  A row that is empty inside a tile but lies between two non-empty rows carries one marker
 // entry (ROWSTART, value 0).  A tile is padded to a multiple of 512 entries (one chunk = 64 lanes x 8 entries, so a
@@ -45,12 +46,6 @@ int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s)
 // LDS index swizzle: a lane reads 8 consecutive entries, so for dense column runs lanes L and L+4 would hit the
 // same bank pair (stride 8 doubles).  XOR-ing bits 3..5 into bits 0..2 makes 32 consecutive lanes conflict-free
 // and is a bijection inside every aligned group of 64 indices (TC is a multiple of 64).
-// LDS index swizzles (bijections inside aligned groups of 8 / 16 doubles).  Forward: the x tile, against the 8-entry lane stride of
-// the gathers.  Adjoint: the column accumulators - wavelet coefficients sit on index lattices (multiples of 2^l per axis), so the
-// columns of one ds_add instruction are often congruent modulo 16 and would pile onto one bank pair; folding the higher index
-// bits into the low four spreads them (headline adjoint 21.3 -> 19.5 ms, Haar config 3: 27.2 -> 21.2 ms).
-__device__ __forceinline__ int swz(int i) { return i ^ ((i >> 3) & 7); }
-__device__ __forceinline__ int swz_a(int i) { return i ^ (((i >> 4) ^ (i >> 8) ^ (i >> 12)) & 15); }
 
 // ------------------------------------------------------------------------------------------------------------
 // Conversion: row block in ELL form (cols ascending, 0-based local) -> tiles
@@ -134,7 +129,7 @@ __global__ void k_tile_scatter(const int32_t *__restrict__ cols, const float *__
     int t = c / TC;
     int p0 = pos[(int64_t)r * (ntc + 1) + t];
     int64_t dst = tile_off[t] + segoff[(int64_t)t * (nr + 1) + r] + (j - p0);
-    codes[dst] = (uint16_t)((c - t * TC) | (j == p0 ? ROWSTART : 0));
+    codes[dst] = (uint16_t)(col_slot(c - t * TC) | (j == p0 ? ROWSTART : 0));
     ovals[dst] = vals[src];
 }
 
@@ -604,7 +599,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_fwd(const WorkItem *__res
         __syncthreads();
         const int64_t col0 = (int64_t)tm.t * TC;
         const int ncol = (int)min((int64_t)TC, ncols - col0);
-        for (int i = tid; i < TC; i += SPMV_THREADS) xs[swz(i)] = (i < ncol) ? x[col0 + i] : 0.0;
+        for (int i = tid; i < TC; i += SPMV_THREADS) xs[col_slot(i)] = (i < ncol) ? x[col0 + i] : 0.0;
         __syncthreads();
         const int64_t cbase = tm.off / CHUNK;
         const int c_end = it.ce < 0 ? tm.nchunks : it.ce;
@@ -623,7 +618,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_fwd(const WorkItem *__res
                     cur += 1;
                     acc = 0.0;
                 }
-                acc = fma((double)cr.v[k], xs[swz((int)(code & COLMASK))], acc);
+                acc = fma((double)cr.v[k], xs[code & COLMASK], acc);
             }
             // merge the tails of lanes that end on the same row (equal rows are contiguous lanes): the first lane of every run
             // gets the run's total.  Inside a 16-lane DPP row: 4 shift-and-add steps on the VALU (row_shl, no LDS crossbar);
@@ -726,7 +721,7 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adj(const WorkItem *__res
                     uval = us[cur];
                 }
                 const float v = cr.v[k];
-                if (v != 0.0f) atomicAdd(&acc[swz_a((int)(code & COLMASK))], (double)v * uval);
+                if (v != 0.0f) atomicAdd(&acc[code & COLMASK], (double)v * uval);
             }
         }
     }
@@ -734,10 +729,10 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adj(const WorkItem *__res
     const int64_t col0 = (int64_t)it.key * TC;
     const int ncol = (int)min((int64_t)TC, ncols - col0);
     if (it.slot == 0) {
-        for (int i = tid; i < ncol; i += SPMV_THREADS) y[col0 + i] += acc[swz_a(i)];
+        for (int i = tid; i < ncol; i += SPMV_THREADS) y[col0 + i] += acc[col_slot(i)];
     } else {
         double *dst = partial + (int64_t)it.pidx * TC;
-        for (int i = tid; i < TC; i += SPMV_THREADS) dst[i] = acc[swz_a(i)];
+        for (int i = tid; i < TC; i += SPMV_THREADS) dst[i] = acc[col_slot(i)];
     }
 }
 
