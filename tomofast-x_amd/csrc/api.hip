@@ -86,6 +86,8 @@ int tfx_destroy(tfx_ctx *ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->pev0) (void)hipEventDestroy(ctx->pev0);
     if (ctx->pev1) (void)hipEventDestroy(ctx->pev1);
+    tfx::prof_drain(ctx);
+    for (auto &pp : ctx->prof_free) { (void)hipEventDestroy(pp.a); (void)hipEventDestroy(pp.b); }
     delete ctx;
     return 0;
 }
@@ -468,6 +470,7 @@ int tfx_timer_stop_ms(tfx_ctx *ctx, double *ms_out)
 int tfx_profile_enable(tfx_ctx *ctx, int on)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    tfx::prof_drain(ctx);
     ctx->profile = on != 0;
     ctx->prof_ms[0] = ctx->prof_ms[1] = 0;
     ctx->prof_n[0] = ctx->prof_n[1] = 0;
@@ -477,6 +480,7 @@ int tfx_profile_enable(tfx_ctx *ctx, int on)
 int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches)
 {
     if (!ctx || which < 0 || which > 1) return fail(TFX_E_ARG, "bad argument");
+    tfx::prof_drain(ctx);
     if (total_ms) *total_ms = ctx->prof_ms[which];
     if (launches) *launches = ctx->prof_n[which];
     return 0;

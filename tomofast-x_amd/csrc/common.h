@@ -179,6 +179,9 @@ struct tfx_ctx {
     double prof_ms[2] = {0, 0};
     int64_t prof_n[2] = {0, 0};
     hipEvent_t pev0 = nullptr, pev1 = nullptr;
+    // per-launch event pairs of the profiling mode: recorded without a host round trip, resolved when the totals are read
+    struct ProfPair { hipEvent_t a, b; int which; };
+    std::vector<ProfPair> prof_pending, prof_free;
 };
 
 namespace tfx {
@@ -193,6 +196,7 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
 int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add);
 int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols);
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
+void prof_drain(tfx_ctx *ctx);
 // build.hip
 int detect_tensor_grid(tfx_ctx *ctx);
 int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, int type, int dir);

@@ -757,19 +757,43 @@ static int set_lds_limit(const void *fn, size_t bytes)
     return 0;
 }
 
+// HIP events around every launch of the two product kernels (tfx_profile_enable).  The events are only recorded here - no host
+// synchronisation inside the measured region; prof_drain turns the finished pairs into totals when they are asked for.
 static void prof_begin(tfx_ctx *ctx)
 {
-    if (ctx->profile) (void)hipEventRecord(ctx->pev0, ctx->stream);
+    if (!ctx->profile) return;
+    tfx_ctx::ProfPair pp{nullptr, nullptr, 0};
+    if (!ctx->prof_free.empty()) {
+        pp = ctx->prof_free.back();
+        ctx->prof_free.pop_back();
+    } else {
+        (void)hipEventCreate(&pp.a);
+        (void)hipEventCreate(&pp.b);
+    }
+    (void)hipEventRecord(pp.a, ctx->stream);
+    ctx->prof_pending.push_back(pp);
+}
+void prof_drain(tfx_ctx *ctx)
+{
+    for (auto &pp : ctx->prof_pending) {
+        if (!pp.b) continue;
+        (void)hipEventSynchronize(pp.b);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess) {
+            ctx->prof_ms[pp.which] += ms;
+            ctx->prof_n[pp.which] += 1;
+        }
+        ctx->prof_free.push_back(pp);
+    }
+    ctx->prof_pending.clear();
 }
 static void prof_end(tfx_ctx *ctx, int which)
 {
-    if (!ctx->profile) return;
-    (void)hipEventRecord(ctx->pev1, ctx->stream);
-    (void)hipEventSynchronize(ctx->pev1);
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1);
-    ctx->prof_ms[which] += ms;
-    ctx->prof_n[which] += 1;
+    if (!ctx->profile || ctx->prof_pending.empty()) return;
+    tfx_ctx::ProfPair &pp = ctx->prof_pending.back();
+    pp.which = which;
+    (void)hipEventRecord(pp.b, ctx->stream);
+    if (ctx->prof_pending.size() >= 4096) prof_drain(ctx);       // bound the pool
 }
 
 int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spmv_dev(ctx, ctx->selmat(), d_x, d_b, add); }
