@@ -392,6 +392,26 @@ def test_matrix_edge_shapes(ctx, shape):
         assert np.allclose(ctx.trans_mult_vector(y), orc.spmtv(*S, y, ncols), rtol=1e-12, atol=1e-12)
 
 
+def test_matrix_with_more_row_markers_than_entries(ctx):
+    """Only the first and the last row of a 2048-row block hold entries, in every column tile: each tile carries 2046 marker
+    entries for the empty rows in between - far more than its real entries (found by tools/fuzz_matrix.py: the capacity estimate
+    had bounded the markers by the entry count)."""
+    nr, nc = 2048, 300000
+    cols_row = (np.arange(0, nc, 4099) + 1).astype(np.int32)
+    rowptr = np.zeros(nr + 1, np.int64)
+    rowptr[1:] = cols_row.size
+    rowptr[nr] = 2 * cols_row.size
+    cols = np.concatenate([cols_row, cols_row])
+    vals = np.random.default_rng(2).standard_normal(cols.size).astype(np.float32)
+    ctx.matrix_upload_csr(nr, nc, rowptr, cols, vals)
+    back = ctx.matrix_download_csr()
+    assert np.array_equal(back[0], rowptr) and np.array_equal(back[1], cols) and bits_equal(back[2], vals)
+    rng = np.random.default_rng(3)
+    x, y = rng.standard_normal(nc), rng.standard_normal(nr)
+    assert np.allclose(ctx.mult_vector(x), orc.spmv(rowptr, cols, vals, x), rtol=1e-13, atol=1e-13)
+    assert np.allclose(ctx.trans_mult_vector(y), orc.spmtv(rowptr, cols, vals, y, nc), rtol=1e-13, atol=1e-13)
+
+
 def test_lsqr_two_diagonal_blocks_and_soft_threshold(ctx, golden_dir):
     """Damping AND ADMM block together (two diagonal blocks, joint_inverse_problem.F90:452-527) with soft thresholding
     (lsqr_solver2.F90:478-494) against the oracle on the same [S; a I; b I] system."""

@@ -305,7 +305,9 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
     }
     m.ntc = (int)((ncols + m.TC - 1) / m.TC);
     m.nrb = (int)((nrows + m.RB - 1) / m.RB);
-    int64_t markers = std::min<int64_t>(nnz_upper, (int64_t)nrows * m.ntc);
+    // marker entries: a row that is empty inside a tile between two non-empty rows of that tile.  At most one per (row, column
+    // tile); a tile needs two real entries to have any, and at most RB - 2 of them
+    int64_t markers = std::min<int64_t>((int64_t)nrows * m.ntc, (nnz_upper / 2 + 1) * (int64_t)m.RB);
     int64_t cap = nnz_upper + markers + (int64_t)m.nrb * m.ntc * CHUNK + CHUNK;
     cap = (cap + CHUNK - 1) / CHUNK * CHUNK;
     TFX_TRY(m.codes.alloc((size_t)cap));

@@ -1,0 +1,51 @@
+"""Randomised sweep of the tiled matrix (upload -> download round trip, both products) against the CPU oracle's CSR products:
+random shapes from 1 x 1 to 6000 x 300000, uniform and heavily clustered columns (heavy tiles that several work items share),
+empty rows, the size-adaptive tile shapes.  Test infrastructure; run on a GPU box."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as orc  # noqa: E402
+
+tfx = importlib.import_module("tomofast-x_amd")
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+ctx = tfx.Context(0)
+for case in range(ncases):
+    nr = int(rng.choice([1, 2, 63, 64, 65, 257, 1000, 2048, 2049, 6000]))
+    nc = int(rng.choice([1, 7, 64, 255, 256, 4097, 16384, 16385, 70000, 300000]))
+    mean = float(rng.choice([0.3, 3, 40, 400, 3000]))
+    mean = min(mean, nc)
+    clustered = bool(rng.integers(0, 2))
+    rows_c, rows_v, rp = [], [], [0]
+    for r in range(nr):
+        n = 0 if rng.random() < 0.1 else int(min(nc, rng.poisson(mean)))
+        if n and clustered:                      # most entries in a narrow band of columns + lattice positions
+            band = max(1, nc // 50)
+            c = np.unique(np.concatenate([rng.integers(0, band, n), (rng.integers(0, max(1, nc // 64), max(1, n // 4)) * 64) % nc]))[:n]
+        else:
+            c = np.sort(rng.choice(nc, n, replace=False)) if n else np.zeros(0, np.int64)
+        rows_c.append(c.astype(np.int32) + 1)
+        rows_v.append(rng.standard_normal(c.size).astype(np.float32))
+        rp.append(rp[-1] + c.size)
+    rowptr, cols, vals = np.array(rp, np.int64), np.concatenate(rows_c) if rp[-1] else np.zeros(0, np.int32), np.concatenate(rows_v) if rp[-1] else np.zeros(0, np.float32)
+    if rp[-1] == 0:
+        continue
+    ctx.matrix_upload_csr(nr, nc, rowptr, cols, vals)
+    back = ctx.matrix_download_csr()
+    assert np.array_equal(back[0], rowptr) and np.array_equal(back[1], cols) and back[2].tobytes() == vals.tobytes(), ("roundtrip", case, nr, nc)
+    x, y = rng.standard_normal(nc), rng.standard_normal(nr)
+    Sx, STy = ctx.mult_vector(x), ctx.trans_mult_vector(y)
+    Sx_ref = orc.spmv(rowptr, cols, vals, x)
+    STy_ref = orc.spmtv(rowptr, cols, vals, y, nc)
+    sa = orc.spmv(rowptr, cols, np.abs(vals), np.abs(x))
+    sb = orc.spmtv(rowptr, cols, np.abs(vals), np.abs(y), nc)
+    assert np.all(np.abs(Sx - Sx_ref) <= 1e-13 * (sa + 1e-300)), ("forward", case, nr, nc, float(np.abs(Sx - Sx_ref).max()))
+    assert np.all(np.abs(STy - STy_ref) <= 1e-13 * (sb + 1e-300)), ("adjoint", case, nr, nc, float(np.abs(STy - STy_ref).max()))
+    print("case %2d %5d x %6d nnz %8d %s ok" % (case, nr, nc, rp[-1], "clustered" if clustered else "uniform"))
+print("OK")
