@@ -77,5 +77,68 @@ for case in range(ncases):
     x_ref, it_ref, r_ref = orc.lsqr(S, Cm, nc, bb, nit, 1e-13, gamma)
     assert it == it_ref, (case, it, it_ref)
     scale = max(np.linalg.norm(x_ref), 1e-300)
-    assert np.linalg.norm(x - x_ref) <= 1e-9 * scale and abs(r - r_ref) <= 1e-9 * r_ref + 1e-14, (case, nr, nc, nb, gen, gamma, nit, np.linalg.norm(x - x_ref) / scale, r, r_ref)
+    # tolerance: 1e3 x the oracle's own reaction to a last-bit change of its right-hand side (see below), at least 1e-9
+    x_p, _, r_p = orc.lsqr(S, Cm, nc, bb * (1.0 + 4e-16 * rng.standard_normal(bb.size)), nit, 1e-13, gamma)
+    own = max(np.linalg.norm(x_p - x_ref) / scale, abs(r_p - r_ref) / max(r_ref, 1e-300), 1e-12)
+    err = max(np.linalg.norm(x - x_ref) / scale, abs(r - r_ref) / max(r_ref, 1e-300) if r_ref > 1e-14 else 0.0)
+    assert err <= 1e3 * own, (case, nr, nc, nb, gen, gamma, nit, err, own)
 print("LSQR OK (%d cases)" % ncases)
+
+# spatial unknowns (WAVELET_DOMAIN = F: S acts on the wavelet transform of the unknowns) and the joint two-kernel system
+for case in range(ncases):
+    n1, n2, n3 = (int(rng.integers(2, 14)) for _ in range(3))
+    N = n1 * n2 * n3
+    wt = int(rng.integers(1, 3))
+    joint = bool(rng.integers(0, 2))
+    P = 2 if joint else 1
+    nrs = [int(rng.integers(1, 60)) for _ in range(P)]
+    Ss = [rand_csr(nr, N, float(rng.choice([3, 30]))) for nr in nrs]
+    if any(S[0][-1] == 0 for S in Ss):
+        continue
+    ctx.set_grid(n1, n2, n3, *tfx.synthetic.grid(n1, n2, n3))
+    for i, S in enumerate(Ss):
+        ctx.select_problem(i)
+        ctx.matrix_upload_csr(nrs[i], N, *S)
+    ctx.select_problem(0)
+    spatial = bool(rng.integers(0, 2))
+    nb = int(rng.integers(1, 3))
+    diag = [np.abs(rng.standard_normal(P * N)).astype(np.float32) * np.float32(1e-2) for _ in range(nb)]
+    rhs = [rng.standard_normal(P * N) * 0.1 for _ in range(nb)]
+    b = rng.standard_normal(sum(nrs))
+    nit = int(rng.integers(1, 10))
+    try:
+        if spatial:
+            ctx.lsqr_set_wavelet_domain(False, wt)
+        x, it, r = ctx.lsqr_solve_sensit(b, nit, 1e-13, 0.0, 0.0, diag, rhs)
+    finally:
+        if spatial:
+            ctx.lsqr_set_wavelet_domain(True)
+        if joint:
+            ctx.select_problem(1)
+            ctx.matrix_free()
+            ctx.select_problem(0)
+    rp, cs, vs, off = [np.zeros(1, np.int64)], [], [], 0
+    for i, S in enumerate(Ss):
+        rp.append(S[0][1:] + off)
+        off += int(S[0][-1])
+        cs.append(S[1].astype(np.int64) + i * N)
+        vs.append(S[2])
+    Sj = (np.concatenate(rp), np.concatenate(cs).astype(np.int32), np.concatenate(vs))
+    blocks = [orc.diag_csr(d) for d in diag]
+    rpc, off = [np.zeros(1, np.int64)], 0
+    for blk in blocks:
+        rpc.append(blk[0][1:] + off)
+        off += int(blk[0][-1])
+    Cm = (np.concatenate(rpc), np.concatenate([blk[1] for blk in blocks]), np.concatenate([blk[2] for blk in blocks]))
+    sp = (wt, n1, n2, n3) if spatial else None
+    bb = np.concatenate([b] + rhs)
+    x_ref, it_ref, r_ref = orc.lsqr(Sj, Cm, P * N, bb, nit, 1e-13, 0.0, spatial=sp)
+    assert it == it_ref, (case, it, it_ref)
+    scale = max(np.linalg.norm(x_ref), 1e-300)
+    # how far does the oracle itself move when its right-hand side moves in the last bit?  (Golub-Kahan without
+    # re-orthogonalisation amplifies rounding on ill-conditioned systems; a real discrepancy is far above that.)
+    x_p, _, r_p = orc.lsqr(Sj, Cm, P * N, bb * (1.0 + 4e-16 * rng.standard_normal(bb.size)), nit, 1e-13, 0.0, spatial=sp)
+    own = max(np.linalg.norm(x_p - x_ref) / scale, abs(r_p - r_ref) / max(r_ref, 1e-300), 1e-11)
+    err = max(np.linalg.norm(x - x_ref) / scale, abs(r - r_ref) / max(r_ref, 1e-300))
+    assert err <= 1e3 * own, (case, joint, spatial, nit, err, own)
+print("LSQR spatial / joint OK (%d cases)" % ncases)
