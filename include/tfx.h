@@ -183,6 +183,12 @@ int tfx_rowstore_build_ex(tfx_ctx *ctx, int problem_type, int data_type, int nda
                           const double *yd, const double *zd, const double *column_weight, const double *mag_field,
                           int compression_type, double rate, double problem_weight, const double *data_weight, int64_t *nnz_out,
                           double *error_sum_out, int32_t *nnz_hist_out);
+/* ... and several model components (magnetisation vector): a stored row holds component k at columns k*N + cell; counts / pack
+ * take CELL ranges and cut every component, the packed piece has component k at k*(col_end - col_begin) + cell - col_begin.  */
+int tfx_rowstore_build_comp(tfx_ctx *ctx, int problem_type, int data_type, int ndata_components, int nmodel_components, int64_t ndata,
+                            const double *xd, const double *yd, const double *zd, const double *column_weight,
+                            const double *mag_field, int compression_type, double rate, double problem_weight,
+                            const double *data_weight, int64_t *nnz_out, double *error_sum_out, int32_t *nnz_hist_out);
 int tfx_rowstore_counts(tfx_ctx *ctx, int nparts, const int64_t *bounds, int32_t *counts_out);
 int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t col_begin, int64_t col_end,
                       int32_t *cols_dev_out, float *vals_dev_out, int64_t capacity, int64_t *n_out);

@@ -363,6 +363,21 @@ def test_two_ranks_under_mpiexec_match_the_reference_two_rank_run(tmp_path, gold
         self_diff = np.linalg.norm(g[key1].reshape(model.shape) - ref) / np.linalg.norm(ref)
         tol = max(1e-6, 100.0 * self_diff)
         assert np.linalg.norm(model - ref) <= tol * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
+    if name == "e2e_mag31":
+        # the magnetisation-vector kernel went through the row-parallel build, and the two ranks wrote their row files (one
+        # record per model component): the set reads back as the kernel of the reference's own files
+        assert "row-parallel" in out.stdout
+        import importlib
+        back = importlib.import_module("tomofast-x_amd").sensit_io.read_sensit(os.path.join(wd, "out", "SENSIT"), 2)
+        assert back["meta"]["nbproc"] == 2 and back["meta"]["nmodel_components"] == 3
+        # the fixture keeps the reference's records, one per (datum, model component), with cell columns
+        ncells = g["X1"].size
+        lp = g["np1_row_ptr"]
+        assert np.array_equal(back["rowptr"], lp[::3])
+        gcols = np.concatenate([g["np1_cols"][lp[q]:lp[q + 1]].astype(np.int64) + (q % 3) * ncells for q in range(lp.size - 1)])
+        assert np.array_equal(back["cols"], gcols)
+        assert np.max(np.abs(back["vals"].view(np.int32).astype(np.int64) - g["np1_vals"].view(np.int32).astype(np.int64))) <= 2
+        assert np.array_equal(back["nnz_hist"], g["np1_sensit_nnz"])
     # sensit.readFromFiles = 2 on 2 ranks: the depth weight comes from the SENSIT folder (written by a single-rank run: the
     # column-partitioned multi-rank build keeps its kernel on the devices), the kernel is built again
     # (problem_joint_gravmag.F90:189-202) - same models

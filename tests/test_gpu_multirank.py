@@ -112,6 +112,17 @@ def _worker_exchange(rank, world, port, q):
         ranges = [None] * world
         dist.all_gather_object(ranges, (c0, c1))
         assert ranges[0][0] == 0 and ranges[-1][1] == nx * ny * nz and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+        # magnetisation-vector kernel (3 model components, TMI data): a rank owns its cell range of every component
+        field = (63.0, -11.0, 4.0, 51000.0)
+        nsub = 2100                                       # 2 row blocks
+        part = tfx.distributed.build_partitioned_exchange(ctx, rank, world, xs[:nsub], ys[:nsub], zs[:nsub], cw, 1, 0.03, mag_field=field,
+                                                          nmodel_components=3)
+        c0, c1 = part["col_range"]
+        A = ctx.matrix_download_csr()
+        assert ctx.matrix_info()["ncols"] == 3 * (c1 - c0) and int(A[0][-1]) == int(part["nnz_at_cpu"][rank])
+        ctx.calculate_sensit(xs[:nsub], ys[:nsub], zs[:nsub], cw, 1, 0.03, col_range=(c0, c1), mag_field=field, nmodel_components=3)
+        B = ctx.matrix_download_csr()
+        assert np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and A[2].tobytes() == B[2].tobytes()
         ctx.close()
         q.put((rank, "ok"))
     except Exception:      # noqa

@@ -2431,7 +2431,6 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     const bool to_rs = rs != nullptr;
     if (to_rs) { col_begin = 0; col_end = ctx ? ctx->N : 0; }
     if (to_rs && compression_type == 0) return fail(TFX_E_ARG, "the row store is for compressed kernels (dense kernels are built per column range)");
-    if (to_rs && gen.ncm != 1) return fail(TFX_E_ARG, "the row store holds single-model-component kernels (build magnetisation kernels per column range)");
     if (!ctx || !xd || !yd || !zd || !column_weight) return fail(TFX_E_ARG, "tfx_build_kernel: null argument");
     if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_build_kernel: set the grid first");
     if (compression_type < 0 || compression_type > 2) return fail(TFX_E_ARG, "Unknown wavelet type!");
@@ -2536,7 +2535,9 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     TFX_TRY(ell_nel.alloc(stage_rows));
     if (to_rs) {
         rs->nrows = nrows_m;
-        rs->stride = std::max<int64_t>(1, K);
+        rs->stride = std::max<int64_t>(1, K) * ncm;
+        rs->ncm = ncm;
+        rs->N = N;
         TFX_TRY(rs->cols.alloc((size_t)(nrows_m * rs->stride)));
         TFX_TRY(rs->vals.alloc((size_t)(nrows_m * rs->stride)));
         TFX_TRY(rs->nel.alloc((size_t)nrows_m));
@@ -2578,7 +2579,7 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
             if (to_rs)
                 TFX_TRY(compact_dev(ctx, cw, drows.p, nl, N, 0, 0, N, rs->cols.p + (size_t)(g * ncd) * rs->stride,
                                     rs->vals.p + (size_t)(g * ncd) * rs->stride, rs->stride, rs->nel.p + g * ncd, dscale.p + g * nsub,
-                                    nnz_hist_out ? dhist.p : nullptr, 1, sel, K));
+                                    nnz_hist_out ? dhist.p : nullptr, ncm, sel, K));
             else
                 TFX_TRY(compact_dev(ctx, cw, drows.p, nl, N, compression_type == 0, col_begin, col_end,
                                     keep_matrix ? ell_cols.p + (size_t)fill * stride : nullptr,
@@ -2662,22 +2663,39 @@ int tfx_rowstore_build_ex(tfx_ctx *ctx, int problem_type, int data_type, int nda
                             nnz_out, error_sum_out, nnz_hist_out, &ctx->rowstore());
 }
 
-// first entry of every row with column >= bounds[d] (d = 0..nparts); counts[r*nparts + d] = entries in [bounds[d], bounds[d+1])
+int tfx_rowstore_build_comp(tfx_ctx *ctx, int problem_type, int data_type, int ndata_components, int nmodel_components, int64_t ndata,
+                            const double *xd, const double *yd, const double *zd, const double *column_weight, const double *mag_field,
+                            int compression_type, double rate, double problem_weight, const double *data_weight, int64_t *nnz_out,
+                            double *error_sum_out, int32_t *nnz_hist_out)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    RowGen gen;
+    TFX_TRY(make_rowgen(gen, problem_type, data_type, ndata_components, nmodel_components, mag_field));
+    return build_kernel_any(ctx, gen, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight, 0, 0,
+                            nnz_out, error_sum_out, nnz_hist_out, &ctx->rowstore());
+}
+
+// counts[r*nparts + d] = entries of row r whose CELL lies in [bounds[d], bounds[d+1]), summed over the model components
+// (component k holds its cells at columns k*N + cell)
+__device__ __forceinline__ int rs_lower_bound(const int32_t *c, int n, int64_t key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)c[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
 __global__ void k_rs_bounds(const int32_t *__restrict__ cols, const int32_t *__restrict__ nel, int64_t stride, int64_t nrows,
-                            const int64_t *__restrict__ bounds, int nparts, int32_t *__restrict__ counts)
+                            const int64_t *__restrict__ bounds, int nparts, int ncm, int64_t N, int32_t *__restrict__ counts)
 {
     const int64_t r = blockIdx.x;
     const int32_t *c = cols + r * stride;
     const int n = nel[r];
-    __shared__ int pos[1026];
-    for (int d = threadIdx.x; d <= nparts; d += blockDim.x) {
-        const int64_t key = bounds[d];
-        int lo = 0, hi = n;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)c[mid] < key) lo = mid + 1; else hi = mid; }
-        pos[d] = lo;
+    for (int d = threadIdx.x; d < nparts; d += blockDim.x) {
+        int cnt = 0;
+        for (int k = 0; k < ncm; ++k)
+            cnt += rs_lower_bound(c, n, bounds[d + 1] + k * N) - rs_lower_bound(c, n, bounds[d] + k * N);
+        counts[r * nparts + d] = cnt;
     }
-    __syncthreads();
-    for (int d = threadIdx.x; d < nparts; d += blockDim.x) counts[r * nparts + d] = pos[d + 1] - pos[d];
 }
 
 int tfx_rowstore_counts(tfx_ctx *ctx, int nparts, const int64_t *bounds, int32_t *counts_out)
@@ -2693,27 +2711,26 @@ int tfx_rowstore_counts(tfx_ctx *ctx, int nparts, const int64_t *bounds, int32_t
     TFX_TRY(db.alloc(nparts + 1));
     TFX_TRY(dc.alloc((size_t)(rs.nrows * nparts)));
     TFX_HIP(hipMemcpyAsync(db.p, bounds, (nparts + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_rs_bounds, dim3((unsigned)rs.nrows), dim3(64), 0, s, rs.cols.p, rs.nel.p, rs.stride, rs.nrows, db.p, nparts, dc.p);
+    hipLaunchKernelGGL(k_rs_bounds, dim3((unsigned)rs.nrows), dim3(64), 0, s, rs.cols.p, rs.nel.p, rs.stride, rs.nrows, db.p, nparts, rs.ncm, rs.N, dc.p);
     TFX_HIP(hipGetLastError());
     TFX_TRY(copy_any(counts_out, dc.p, (size_t)(rs.nrows * nparts) * sizeof(int32_t), s));
     return 0;
 }
 
-// segment [col_begin, col_end) of rows [row_begin, row_begin + nrows): offsets by an exclusive scan, then a copy
+// cells [col_begin, col_end) of rows [row_begin, row_begin + nrows), one piece per (row, model component): offsets by an
+// exclusive scan over the pieces (row-major, component inside), then a copy
 __global__ void k_rs_seg(const int32_t *__restrict__ cols, const int32_t *__restrict__ nel, int64_t stride, int64_t row_begin,
-                         int nrows, int64_t col_begin, int64_t col_end, int32_t *__restrict__ p0, int32_t *__restrict__ cnt)
+                         int nrows, int64_t col_begin, int64_t col_end, int ncm, int64_t N, int32_t *__restrict__ p0,
+                         int32_t *__restrict__ cnt)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nrows * ncm) return;
+    const int r = q / ncm, k = q - r * ncm;
     const int32_t *c = cols + (row_begin + r) * stride;
     const int n = nel[row_begin + r];
-    int lo = 0, hi = n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)c[mid] < col_begin) lo = mid + 1; else hi = mid; }
-    const int a = lo;
-    hi = n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)c[mid] < col_end) lo = mid + 1; else hi = mid; }
-    p0[r] = a;
-    cnt[r] = lo - a;
+    const int a = rs_lower_bound(c, n, col_begin + k * N);
+    p0[q] = a;
+    cnt[q] = rs_lower_bound(c, n, col_end + k * N) - a;
 }
 
 __global__ void k_rs_scan(const int32_t *__restrict__ cnt, int nrows, int64_t *__restrict__ off)
@@ -2727,14 +2744,16 @@ __global__ void k_rs_scan(const int32_t *__restrict__ cnt, int nrows, int64_t *_
 
 __global__ void k_rs_copy(const int32_t *__restrict__ cols, const float *__restrict__ vals, int64_t stride, int64_t row_begin,
                           const int32_t *__restrict__ p0, const int32_t *__restrict__ cnt, const int64_t *__restrict__ off,
-                          int64_t col_begin, int32_t *__restrict__ ocols, float *__restrict__ ovals)
+                          int64_t col_begin, int64_t col_end, int ncm, int64_t N, int32_t *__restrict__ ocols, float *__restrict__ ovals)
 {
-    const int r = blockIdx.y;
+    const int q = blockIdx.y;                       // piece (row, component)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cnt[r]) return;
-    const int64_t src = (row_begin + r) * stride + p0[r] + j;
-    ocols[off[r] + j] = (int32_t)(cols[src] - col_begin);
-    ovals[off[r] + j] = vals[src];
+    if (j >= cnt[q]) return;
+    const int r = q / ncm, k = q - r * ncm;
+    const int64_t src = (row_begin + r) * stride + p0[q] + j;
+    // the owner's columns: component k at k*(col_end - col_begin) + (cell - col_begin)
+    ocols[off[q] + j] = (int32_t)(cols[src] - k * N - col_begin + k * (col_end - col_begin));
+    ovals[off[q] + j] = vals[src];
 }
 
 int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t col_begin, int64_t col_end, int32_t *cols_dev_out,
@@ -2746,24 +2765,24 @@ int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t co
     if (row_begin < 0 || nrows <= 0 || row_begin + nrows > rs.nrows) return fail(TFX_E_ARG, "row range outside the row store");
     TFX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const int nr = (int)nrows;
+    const int nr = (int)nrows, np = nr * rs.ncm;      // pieces
     DBuf<int32_t> p0, cnt;
     DBuf<int64_t> off;
-    TFX_TRY(p0.alloc(nr));
-    TFX_TRY(cnt.alloc(nr));
-    TFX_TRY(off.alloc(nr + 1));
-    hipLaunchKernelGGL(k_rs_seg, dim3((nr + 255) / 256), dim3(256), 0, s, rs.cols.p, rs.nel.p, rs.stride, row_begin, nr, col_begin,
-                       col_end, p0.p, cnt.p);
-    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(64), 0, s, cnt.p, nr, off.p);
+    TFX_TRY(p0.alloc(np));
+    TFX_TRY(cnt.alloc(np));
+    TFX_TRY(off.alloc(np + 1));
+    hipLaunchKernelGGL(k_rs_seg, dim3((np + 255) / 256), dim3(256), 0, s, rs.cols.p, rs.nel.p, rs.stride, row_begin, nr, col_begin,
+                       col_end, rs.ncm, rs.N, p0.p, cnt.p);
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(64), 0, s, cnt.p, np, off.p);
     int64_t total = 0;
-    TFX_HIP(hipMemcpyAsync(&total, off.p + nr, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipMemcpyAsync(&total, off.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     TFX_HIP(hipStreamSynchronize(s));
     *n_out = total;
     if (total > capacity) return fail(TFX_E_ARG, "tfx_rowstore_pack: %lld entries do not fit the buffer (%lld)", (long long)total, (long long)capacity);
     if (total > 0) {
         if (!cols_dev_out || !vals_dev_out) return fail(TFX_E_ARG, "null output buffer");
-        hipLaunchKernelGGL(k_rs_copy, dim3((unsigned)((rs.stride + 255) / 256), nr), dim3(256), 0, s, rs.cols.p, rs.vals.p, rs.stride,
-                           row_begin, p0.p, cnt.p, off.p, col_begin, cols_dev_out, vals_dev_out);
+        hipLaunchKernelGGL(k_rs_copy, dim3((unsigned)((rs.stride / rs.ncm + 255) / 256), np), dim3(256), 0, s, rs.cols.p, rs.vals.p,
+                           rs.stride, row_begin, p0.p, cnt.p, off.p, col_begin, col_end, rs.ncm, rs.N, cols_dev_out, vals_dev_out);
         TFX_HIP(hipGetLastError());
     }
     TFX_HIP(hipStreamSynchronize(s));

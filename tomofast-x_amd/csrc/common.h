@@ -128,6 +128,8 @@ struct RowStore {
     DBuf<float> vals;
     DBuf<int32_t> nel;     // [nrows]
     int64_t nrows = 0, stride = 0;
+    int ncm = 1;           // model components: a row holds component k in columns k*N + cell (N cells), ascending
+    int64_t N = 0;
 };
 
 struct LsqrState;

@@ -128,12 +128,15 @@ def _p2p(tensors_to_send, recv_specs, backend):
 
 
 def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate,
-                               problem_weight=1.0, data_weight=None, mag_field=None, get_partition=None, device_index=0):
+                               problem_weight=1.0, data_weight=None, mag_field=None, get_partition=None, device_index=0,
+                               nmodel_components=1):
     """Row-parallel build + relayout: every rank compresses only ITS row blocks (all columns, kept row-major on
     the device), the per-column histogram is all-reduced, the reference's greedy rule gives the column ranges, and each
     row block is then cut into column ranges and sent to the owners, who lay their pieces out as tiles.  Every row is
     computed once; the matrix crosses the links once (the reference does this through SENSIT files and a rank-0
-    MPI_Scatterv per row: sensitivity_gravmag.F90:179-189, :306-309, :795-830)."""
+    MPI_Scatterv per row: sensitivity_gravmag.F90:179-189, :306-309, :795-830).
+    nmodel_components = 3 (magnetisation vector, one data component): a rank owns its cell range of every component; the
+    pieces carry component k at k*(cells of the range) + cell."""
     import torch
     import torch.distributed as dist
     from .sensitivity import get_load_balancing_nelements
@@ -150,7 +153,7 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
     if nloc > 0:
         dw = None if data_weight is None else data_weight[r0:r1]
         res = ctx.rowstore_build(Xdata[r0:r1], Ydata[r0:r1], Zdata[r0:r1], column_weight, compression_type, compression_rate,
-                                 problem_weight, dw, mag_field)
+                                 problem_weight, dw, mag_field, nmodel_components=nmodel_components)
         hist, err = res["nnz_hist"].astype(np.int64), res["error_sum"]
     else:
         hist, err = np.zeros(N, np.int64), 0.0
@@ -174,7 +177,7 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
             counts[a:b] = gathered[r].cpu().numpy()[:b - a]
     assert int(counts[:, rank].sum()) == int(nnz[rank]), (counts[:, rank].sum(), nnz[rank])
     # 4. relayout, row block by row block
-    ctx.matrix_begin(nd, c1 - c0, int(nnz[rank]))
+    ctx.matrix_begin(nd, nmodel_components * (c1 - c0), int(nnz[rank]))
     for b in range(nblocks):
         ga, gb = b * RB, min((b + 1) * RB, nd)
         o = int(owner[b])
@@ -206,7 +209,7 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
         ctx.matrix_append_rows(ga, rc, rv, counts[ga:gb, rank])
     ctx.matrix_finish()
     ctx.rowstore_free()
-    return dict(col_range=(c0, c1), nelements_at_cpu=nel, nnz_at_cpu=nnz, nnz_total=int(hist.sum()), comp_error=err / nd)
+    return dict(col_range=(c0, c1), nelements_at_cpu=nel, nnz_at_cpu=nnz, nnz_total=int(hist.sum()), comp_error=err / (nd * nmodel_components))
 
 
 def build_partitioned(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate,
@@ -242,4 +245,4 @@ def build_partitioned(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, com
     res2 = ctx.calculate_sensit(Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate, problem_weight, data_weight,
                                 col_range=(c0, c1))
     assert res2["nnz"] == int(nnz[rank]), (res2["nnz"], nnz[rank])
-    return dict(col_range=(c0, c1), nelements_at_cpu=nel, nnz_at_cpu=nnz, nnz_total=int(hist.sum()), comp_error=err / nd)
+    return dict(col_range=(c0, c1), nelements_at_cpu=nel, nnz_at_cpu=nnz, nnz_total=int(hist.sum()), comp_error=err / (nd * nmodel_components))

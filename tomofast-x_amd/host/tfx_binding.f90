@@ -185,6 +185,19 @@ module tfx_binding
     end function
 
     ! counts(d, r) = entries of local row r with column in [bounds(d), bounds(d+1))   (C layout counts[r*nparts + d])
+    integer(c_int) function tfx_rowstore_build_comp(ctx, problem_type, data_type, ndata_components, nmodel_components, ndata, xd, yd, zd, &
+                                                    column_weight, mag_field, compression_type, rate, problem_weight, data_weight, &
+                                                    nnz_out, error_sum_out, nnz_hist_out) bind(C, name="tfx_rowstore_build_comp")
+      import :: c_ptr, c_int, c_int64_t, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: problem_type, data_type, ndata_components, nmodel_components, compression_type
+      integer(c_int64_t), value :: ndata
+      real(c_double), intent(in) :: xd(*), yd(*), zd(*), column_weight(*)
+      type(c_ptr), value :: mag_field, data_weight, nnz_hist_out
+      real(c_double), value :: rate, problem_weight
+      integer(c_int64_t), intent(out) :: nnz_out
+      real(c_double), intent(out) :: error_sum_out
+    end function tfx_rowstore_build_comp
     integer(c_int) function tfx_rowstore_counts(ctx, nparts, bounds, counts) bind(C, name="tfx_rowstore_counts")
       import :: c_int, c_ptr, c_int64_t, c_int32_t
       type(c_ptr), value :: ctx

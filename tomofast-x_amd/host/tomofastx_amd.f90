@@ -1503,7 +1503,7 @@ contains
     character(len=32) :: v
     integer :: l, st
     call get_environment_variable('TFX_BUILD_MODE', v, l, st)
-    exchange_ok = pr(jp)%nc == 1 .and. pr(jp)%ndc == 1 .and. par%comp_type > 0
+    exchange_ok = pr(jp)%ndc == 1 .and. par%comp_type > 0        ! any number of model components, one data component
     if (st == 0 .and. l > 0) then
       if (v(1:l) == 'redundant') exchange_ok = .false.
     endif
@@ -1539,7 +1539,7 @@ contains
       mptr = c_loc(mag_field)
     endif
     call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
-    call tfx_check(tfx_rowstore_build_ex(ctx, jp, pr(jp)%dtype, pr(jp)%ndc, int(row_b - row_a, c_int64_t), pr(jp)%Xd(row_a + 1:row_b), &
+    call tfx_check(tfx_rowstore_build_comp(ctx, jp, pr(jp)%dtype, pr(jp)%ndc, pr(jp)%nc, int(row_b - row_a, c_int64_t), pr(jp)%Xd(row_a + 1:row_b), &
                                          pr(jp)%Yd(row_a + 1:row_b), pr(jp)%Zd(row_a + 1:row_b), pr(jp)%cw, mptr, par%comp_type, &
                                          par%comp_rate, pr(jp)%pw, c_loc(pr(jp)%dw(row_a * pr(jp)%ndc + 1)), nnz_k, err_k, hist_ptr), &
                    'calculate_and_write_sensit')
@@ -1585,7 +1585,7 @@ contains
     do rr = 1, ndat
       mine = mine + cnt_all(myrank + 1, rr)
     enddo
-    call tfx_check(tfx_matrix_begin(ctx, int(ndat, c_int64_t), int(nloc, c_int64_t), max(mine, 1_c_int64_t)), 'tfx_matrix_begin')
+    call tfx_check(tfx_matrix_begin(ctx, int(ndat, c_int64_t), int(pr(jp)%nc * nloc, c_int64_t), max(mine, 1_c_int64_t)), 'tfx_matrix_begin')
     do b = 1, nblk
       ga = (b - 1) * ROW_BLOCK
       gb = min(b * ROW_BLOCK, ndat)
@@ -1655,8 +1655,8 @@ contains
     integer, intent(in) :: jp, row_a, row_b
     integer(c_int32_t), intent(in) :: cnt(:, :)             ! (destination rank, local row): entries per column range
     integer, parameter :: RCHUNK = 256
-    integer :: u, r0, r1, r, nel
-    integer(c_int64_t) :: cap, got, a
+    integer :: u, r0, r1, r, nel, kc
+    integer(c_int64_t) :: cap, got, a, e0, e1
     integer(c_int32_t), allocatable, target :: hc(:)
     real(c_float), allocatable, target :: hv(:)
     type(c_ptr) :: dc, dv
@@ -1686,12 +1686,23 @@ contains
       a = 0
       do r = r0 + 1, r1                                            ! data row r (1-based, global)
         nel = sum(cnt(:, r - row_a))
-        write(u) int(r, c_int32_t), int(nel, c_int32_t), 1_c_int32_t, 1_c_int32_t
         if (nel > 0) then
-          hc(a + 1:a + nel) = hc(a + 1:a + nel) + 1                ! the packed columns are 0-based
           if (pr(jp)%pw * pr(jp)%dw(r) /= 1.d0) hv(a + 1:a + nel) = hv(a + 1:a + nel) / real(pr(jp)%pw * pr(jp)%dw(r), c_float)
-          write(u) hc(a + 1:a + nel), hv(a + 1:a + nel)
         endif
+        e0 = a
+        do kc = 1, pr(jp)%nc                                       ! one record per model component (:222-311); the packed row
+          e1 = e0                                                  ! holds component kc at 0-based columns (kc-1)*n + cell
+          do while (e1 < a + nel)
+            if (hc(e1 + 1) >= kc * n) exit
+            e1 = e1 + 1
+          enddo
+          write(u) int(r, c_int32_t), int(e1 - e0, c_int32_t), int(kc, c_int32_t), 1_c_int32_t
+          if (e1 > e0) then
+            hc(e0 + 1:e1) = hc(e0 + 1:e1) - (kc - 1) * n + 1
+            write(u) hc(e0 + 1:e1), hv(e0 + 1:e1)
+          endif
+          e0 = e1
+        enddo
         a = a + nel
       enddo
       deallocate(hc, hv)

@@ -218,12 +218,18 @@ class Context:
     ROW_BLOCK = 2048
 
     def rowstore_build(self, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate, problem_weight=1.0,
-                       data_weight=None, mag_field=None, data_type=1, ndata_components=1):
+                       data_weight=None, mag_field=None, data_type=1, ndata_components=1, nmodel_components=1):
         xd, yd, zd, cw = f64(Xdata), f64(Ydata), f64(Zdata), f64(column_weight)
         dw = None if data_weight is None else f64(data_weight)
         mf = None if mag_field is None else f64(mag_field)
         nnz, err = C.c_int64(), C.c_double()
         hist = np.zeros(self.nelements_total, np.int32)
+        if nmodel_components != 1:
+            check(self._lib.tfx_rowstore_build_comp(self._h, 1 if mag_field is None else 2, int(data_type), int(ndata_components),
+                                                    int(nmodel_components), C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw), ptr(mf),
+                                                    int(compression_type), C.c_double(compression_rate), C.c_double(problem_weight), ptr(dw),
+                                                    C.byref(nnz), C.byref(err), ptr(hist)))
+            return dict(nnz=nnz.value, error_sum=err.value, nnz_hist=hist)
         if data_type != 1 or ndata_components != 1:
             check(self._lib.tfx_rowstore_build_ex(self._h, 1 if mag_field is None else 2, int(data_type), int(ndata_components),
                                                   C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(cw), ptr(mf), int(compression_type),
