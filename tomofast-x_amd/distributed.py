@@ -245,4 +245,4 @@ def build_partitioned(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, com
     res2 = ctx.calculate_sensit(Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate, problem_weight, data_weight,
                                 col_range=(c0, c1))
     assert res2["nnz"] == int(nnz[rank]), (res2["nnz"], nnz[rank])
-    return dict(col_range=(c0, c1), nelements_at_cpu=nel, nnz_at_cpu=nnz, nnz_total=int(hist.sum()), comp_error=err / (nd * nmodel_components))
+    return dict(col_range=(c0, c1), nelements_at_cpu=nel, nnz_at_cpu=nnz, nnz_total=int(hist.sum()), comp_error=err / nd)
