@@ -10,3 +10,4 @@ python $R/tools/fuzz_lsqr_wavelet.py 40 $((S + 4)) | tail -3
 python $R/tools/fuzz_band.py 25 $((S + 5)) | tail -1
 python $R/tools/fuzz_misc.py 40 $((S + 6)) | tail -1
 python $R/tools/fuzz_many_rows.py | tail -1
+python $R/tools/fuzz_hosts.py 20 $((S + 7)) | tail -1
