@@ -46,6 +46,13 @@ for case in range(ncases):
     admm = bool(rng.integers(0, 2))
     rho = 1e-5
     nmajor, nminor = 2, int(rng.integers(2, 6))
+    mag = bool(rng.integers(0, 2))
+    normp = float(rng.choice([2.0, 2.0, 1.5]))
+    beta = float(rng.choice([0.0, 0.0, 1e-6]))
+    field = (float(rng.uniform(40, 80)), float(rng.uniform(-20, 20)), 0.0, 50000.0)
+    tag, sfx = ("magn", "mag") if mag else ("grav", "grav")
+    if mag:
+        mtrue = mtrue * 1e-4
     with tempfile.TemporaryDirectory() as wd:
         with open(os.path.join(wd, "grid.txt"), "w") as f:
             f.write("%d\n" % N)
@@ -61,46 +68,53 @@ for case in range(ncases):
             f.write("\n".join("%.17g" % v for v in mtrue) + "\n")
         par = """global.outputFolderPath     = out/
 modelGrid.size                      = %d %d %d
-modelGrid.grav.file                 = grid.txt
-forward.data.grav.nData             = %d
-forward.data.grav.dataGridFile      = data_grid.txt
-forward.data.grav.useSyntheticModelForDataValues = 1
-forward.data.grav.syntheticModelFile = model_true.txt
+modelGrid.TAG.file                 = grid.txt
+forward.data.TAG.nData             = %d
+forward.data.TAG.dataGridFile      = data_grid.txt
+forward.data.TAG.useSyntheticModelForDataValues = 1
+forward.data.TAG.syntheticModelFile = model_true.txt
 forward.depthWeighting.type         = %d
-forward.depthWeighting.grav.power   = %.17g
-forward.depthWeighting.grav.beta    = 1.0d0
-forward.depthWeighting.grav.Z0      = 0.d0
+forward.depthWeighting.TAG.power   = %.17g
+forward.depthWeighting.TAG.beta    = 1.0d0
+forward.depthWeighting.TAG.Z0      = 0.d0
 sensit.readFromFiles                = 0
 forward.matrixCompression.type      = %d
 forward.matrixCompression.rate      = %.17g
 inversion.priorModel.type           = 1
-inversion.priorModel.grav.value     = %.17g
+inversion.priorModel.TAG.value     = %.17g
 inversion.startingModel.type        = 1
-inversion.startingModel.grav.value  = %.17g
+inversion.startingModel.TAG.value  = %.17g
 inversion.nMajorIterations          = %d
 inversion.nMinorIterations          = %d
 inversion.minResidual               = 1.d-13
-inversion.modelDamping.grav.weight  = %.17g
-inversion.modelDamping.normPower    = 2.0d0
-inversion.joint.grav.problemWeight  = 1.d0
-inversion.joint.magn.problemWeight  = 0.d0
-inversion.joint.grav.columnWeightMultiplier = 4.d+3
-""" % (nx, ny, nz, nd, dwt, power, ctype, rate, prior, start, nmajor, nminor, alpha)
+inversion.modelDamping.TAG.weight  = %.17g
+inversion.modelDamping.normPower    = %.17g
+inversion.dampingGradient.TAG.weight = %.17g
+inversion.joint.grav.problemWeight  = %s
+inversion.joint.magn.problemWeight  = %s
+inversion.joint.TAG.columnWeightMultiplier = 4.d+3
+forward.magneticField.inclination   = %.17g
+forward.magneticField.declination   = %.17g
+forward.magneticField.intensity_nT  = %.17g
+forward.magneticField.XaxisDeclination = 0.d0
+""" % (nx, ny, nz, nd, dwt, power, ctype, rate, prior, start, nmajor, nminor, alpha, normp, beta, "0.d0" if mag else "1.d0",
+       "1.d0" if mag else "0.d0", field[0], field[1], field[3])
+        par = par.replace("TAG", tag)
         if admm:
-            par += "inversion.admm.enableADMM = 1\ninversion.admm.nLithologies = 2\ninversion.admm.grav.bounds = -10. 10. 200. 300.\ninversion.admm.grav.weight = %.17g\n" % rho
+            par += "inversion.admm.enableADMM = 1\ninversion.admm.nLithologies = 2\ninversion.admm.%s.bounds = -10. 10. 200. 300.\ninversion.admm.%s.weight = %.17g\n" % (tag, tag, rho)
         open(os.path.join(wd, "Parfile.txt"), "w").write(par)
         out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=600, env=dict(os.environ, TFX_WRITE_SENSIT="0"))
         assert out.returncode == 0 and "THE END." in out.stdout, (case, out.stdout[-1500:], out.stderr[-1500:])
-        m_f = read_col(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)
-        d_f = read_col(os.path.join(wd, "out", "data", "grav_final.txt"), 4)
+        m_f = read_col(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)
+        d_f = read_col(os.path.join(wd, "out", "data", sfx + "_final.txt"), 4)
     # the same run through the Python host
     ctx.set_grid(nx, ny, nz, *grid)
     cw = ctx.calculate_depth_weight(power, 0.0, 4.0e3) if dwt == 1 else ctx.calculate_distance_weight(xs, ys, zs, power, 1.0, 4.0e3)
-    ctx.calculate_sensit(xs, ys, zs, cw, ctype, rate)
+    ctx.calculate_sensit(xs, ys, zs, cw, ctype, rate, mag_field=field if mag else None)
     scaled = np.where(cw != 0.0, mtrue / np.where(cw != 0.0, cw, 1.0), 0.0)
     d_obs = ctx.calc_data(ctx.forward_wavelet(scaled, nx, ny, nz, ctype) if ctype else scaled, 1.0, None)
     m_p, d_p, hist = tfx.inversion.solve_problem_gravity(ctx, cw, ctype, d_obs, nmajor, nminor, alpha=alpha, model_start=np.full(N, start),
-                                                        model_prior=np.full(N, prior),
+                                                        model_prior=np.full(N, prior), beta=beta, norm_power=normp,
                                                         admm=dict(bounds=[-10.0, 10.0, 200.0, 300.0], rho=rho) if admm else None)
     em = np.linalg.norm(m_f - m_p) / max(np.linalg.norm(m_p), 1e-300)
     ed = np.linalg.norm(d_f - d_p) / max(np.linalg.norm(d_p), 1e-300)
@@ -111,11 +125,11 @@ inversion.joint.grav.columnWeightMultiplier = 4.d+3
         own = 0.0
         for _ in range(3):
             m_q, d_q, _ = tfx.inversion.solve_problem_gravity(ctx, cw, ctype, d_obs, nmajor, nminor, alpha=alpha, model_start=np.full(N, start),
-                                                             model_prior=np.full(N, prior),
+                                                             model_prior=np.full(N, prior), beta=beta, norm_power=normp,
                                                              admm=dict(bounds=[-10.0, 10.0, 200.0, 300.0], rho=rho) if admm else None)
             own = max(own, np.linalg.norm(m_q - m_p) / max(np.linalg.norm(m_p), 1e-300))
         tol = max(tol, 30.0 * own)
     assert em <= tol and ed <= tol, (case, em, ed, tol, (nx, ny, nz), nd, ctype, rate, dwt, alpha, prior, start, admm, nminor)
-    print("case %2d %2dx%2dx%2d nd %2d ctype %d rate %.1f dw %d alpha %.0e prior %g start %g admm %d nminor %d: model %.1e data %.1e" % (
-        case, nx, ny, nz, nd, ctype, rate, dwt, alpha, prior, start, admm, nminor, em, ed))
+    print("case %2d %s %2dx%2dx%2d nd %2d ctype %d rate %.1f dw %d alpha %.0e prior %g start %g admm %d Lp %.1f beta %.0e nminor %d: model %.1e data %.1e" % (
+        case, tag, nx, ny, nz, nd, ctype, rate, dwt, alpha, prior, start, admm, normp, beta, nminor, em, ed))
 print("OK (%d cases)" % ncases)
