@@ -648,7 +648,8 @@ program tomofastx_amd
   type(c_ptr) :: ctx, dptr(4), rptr(4)
   real(dp), allocatable, target :: b_data(:), x(:), rhs(:, :), work(:)
   real(c_float), allocatable, target :: diag(:, :)
-  real(dp) :: s1, s2
+  real(dp) :: s1, s2, s3
+  integer :: cc
 
   ! ---- command line (src/parameters_init.f90:104-119)
   parfile = ''
@@ -923,31 +924,30 @@ program tomofastx_amd
           call unweight(ip, pr(ip)%m((k - 1) * n + 1:k * n) - pr(ip)%m_prior((k - 1) * n + 1:k * n), work((k - 1) * n + 1:k * n))
         enddo
         if (.not. spatial) call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)       ! damping.F90:135-150
+        ! value = alpha * pw [* Lp multiplier] [* local weight] in double, ONE cast to the matrix precision (damping.F90:160-173,
+        ! sparse_matrix.f90:226); right-hand side -alpha * pw * diff [* Lp multiplier] [* local weight] (:218-228)
         diag(:, nblocks) = 0.0
-        diag(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = real(par%alpha(ip) * pr(ip)%pw, c_float)
         rhs(:, nblocks) = 0.d0
         call to_local(ip, work, rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks))
-        if (par%apply_local_damp > 0) then                           ! local weight = local alpha (damping.F90:177-180, :264-267)
-          do k = 1, pr(ip)%nc
-            do i = 1, nloc
-              diag(lc0 + (k - 1) * nloc + i, nblocks) = real(par%alpha(ip) * pr(ip)%pw * pr(ip)%damp_w(cb + i), c_float)
-            enddo
+        do k = 1, pr(ip)%nc
+          do i = 1, nloc
+            cc = lc0 + (k - 1) * nloc + i
+            s1 = par%alpha(ip) * pr(ip)%pw                                ! matrix value
+            s2 = -par%alpha(ip) * pr(ip)%pw * rhs(cc, nblocks)            ! right-hand side
+            if (par%norm_power /= 2.d0) then                             ! Lp norm multiplier (:250-262)
+              s3 = 1.d0
+              if (rhs(cc, nblocks) /= 0.d0) s3 = (abs(rhs(cc, nblocks)))**(par%norm_power / 2.d0 - 1.d0)
+              s1 = s1 * s3
+              s2 = s2 * s3
+            endif
+            if (par%apply_local_damp > 0) then                           ! local weight = local alpha (:168-171, :225-228)
+              s1 = s1 * pr(ip)%damp_w(cb + i)
+              s2 = s2 * pr(ip)%damp_w(cb + i)
+            endif
+            diag(cc, nblocks) = real(s1, c_float)
+            rhs(cc, nblocks) = s2
           enddo
-        endif
-        if (par%norm_power /= 2.d0) then                             ! Lp norm multiplier (damping.F90:171-175, :250-262)
-          do i = lc0 + 1, lc0 + pr(ip)%nml
-            s1 = 1.d0
-            if (rhs(i, nblocks) /= 0.d0) s1 = (abs(rhs(i, nblocks)))**(par%norm_power / 2.d0 - 1.d0)
-            diag(i, nblocks) = diag(i, nblocks) * real(s1, c_float)
-            rhs(i, nblocks) = rhs(i, nblocks) * s1
-          enddo
-        endif
-        rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = -par%alpha(ip) * pr(ip)%pw * rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks)
-        if (par%apply_local_damp > 0) then
-          do k = 1, pr(ip)%nc
-            rhs(lc0 + (k - 1) * nloc + 1:lc0 + k * nloc, nblocks) = rhs(lc0 + (k - 1) * nloc + 1:lc0 + k * nloc, nblocks) * pr(ip)%damp_w(cb + 1:ce)
-          enddo
-        endif
+        enddo
         dptr(nblocks) = c_loc(diag(1, nblocks))
         rptr(nblocks) = c_loc(rhs(1, nblocks))
       endif

@@ -317,12 +317,16 @@ def solve_problem_gravity(ctx, column_weight, compression_type, data_obs, nmajor
         diag, rhs = [], []
         if alpha != 0.0:                             # damping.F90:97-234 (L2, no local weights)
             md = loc(to_unknowns(unweight(m - mp)))
-            mult = np.ones(md.size) if damping_weight is None else loc(np.asarray(damping_weight, np.float64)).copy()
+            lp = np.ones(md.size)
             if norm_power != 2.0:                    # damping.F90:250-262
                 nzm = md != 0.0
-                mult[nzm] = np.abs(md[nzm]) ** (norm_power / 2.0 - 1.0)
-            diag.append((alpha * pw * mult).astype(np.float32))
-            rhs.append(-alpha * pw * md * mult)
+                lp[nzm] = np.abs(md[nzm]) ** (norm_power / 2.0 - 1.0)
+            val, r = alpha * pw * lp, -alpha * pw * md * lp          # :160-166, :218-223: alpha * pw, then the Lp multiplier ...
+            if damping_weight is not None:                           # ... then the local weight (:168-171, :225-228)
+                lw = loc(np.asarray(damping_weight, np.float64))
+                val, r = val * lw, r * lw
+            diag.append(val.astype(np.float32))                      # one cast, like matrix%add(value) (sparse_matrix.f90:226)
+            rhs.append(r)
         if admm is not None:                         # joint_inverse_problem.F90:497-527
             x0 = st.iterate_admm_arrays(m, admm["bounds"])
             md = loc(to_unknowns(unweight(m - x0)))

@@ -129,7 +129,7 @@ forward.magneticField.XaxisDeclination = 0.d0
                                                              admm=dict(bounds=[-10.0, 10.0, 200.0, 300.0], rho=rho) if admm else None)
             own = max(own, np.linalg.norm(m_q - m_p) / max(np.linalg.norm(m_p), 1e-300))
         tol = max(tol, 30.0 * own)
-    assert em <= tol and ed <= tol, (case, em, ed, tol, (nx, ny, nz), nd, ctype, rate, dwt, alpha, prior, start, admm, nminor)
+    assert em <= tol and ed <= tol, (case, em, ed, tol, (nx, ny, nz), nd, ctype, rate, dwt, alpha, prior, start, admm, nminor, tag, normp, beta)
     print("case %2d %s %2dx%2dx%2d nd %2d ctype %d rate %.1f dw %d alpha %.0e prior %g start %g admm %d Lp %.1f beta %.0e nminor %d: model %.1e data %.1e" % (
         case, tag, nx, ny, nz, nd, ctype, rate, dwt, alpha, prior, start, admm, normp, beta, nminor, em, ed))
 print("OK (%d cases)" % ncases)
