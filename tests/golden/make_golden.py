@@ -907,13 +907,29 @@ def make_localw_e2e(tmp):
     lw_depth = rng.uniform(0.5, 2.0, N)
     lw_depth[7] = 0.0                                   # zero local weight -> zero column weight (:298-299)
     lw_damp = rng.uniform(0.2, 3.0, N)
-    par = PAR_TMPL.format(nd=nd, **c) + ("forward.depthWeighting.applyLocalWeight = 1\nforward.depthWeighting.grav.file = lw_depth.txt\n"
-                                         "inversion.modelDamping.applyLocalWeight = 1\ninversion.modelDamping.grav.file = lw_damp.txt\n")
+    par0 = PAR_TMPL.format(nd=nd, **c) + ("forward.depthWeighting.applyLocalWeight = 1\nforward.depthWeighting.grav.file = lw_depth.txt\n"
+                                          "inversion.modelDamping.applyLocalWeight = 1\ninversion.modelDamping.grav.file = lw_damp.txt\n")
+    # second fixture: the local weights together with an Lp norm (value = alpha * pw * Lp multiplier * local weight, damping.F90:160-173)
+    # The Lp variant uses few LSQR iterations and three major iterations.  9 data rows give LSQR a tiny Krylov space: past ~8
+    # iterations it has lost orthogonality and the (unconverged) iterate moves by 1e-4..1e-3 under a 1-ulp change of the inputs,
+    # and with 400 iterations the run only pins the converged solution to ~5e-6 (both measured on the oracle).  With 5 iterations
+    # the oracle's own 1-ulp sensitivity is 2e-14, while dropping the local weight or the Lp factor moves the model by 14-23 %.
+    par_lp = par0.replace("inversion.modelDamping.normPower    = 2.0d0", "inversion.modelDamping.normPower    = 1.5d0")
+    assert par_lp != par0
+    c_lp = dict(c, nminor=5, nmajor=3)
+    par_lp2 = par_lp.replace("inversion.nMinorIterations          = %d" % c["nminor"], "inversion.nMinorIterations          = %d" % c_lp["nminor"])
+    par_lp2 = par_lp2.replace("inversion.nMajorIterations          = %d" % c["nmajor"], "inversion.nMajorIterations          = %d" % c_lp["nmajor"])
+    assert par_lp2.count("= 5\n") >= 1 and par_lp2 != par_lp
+    for fname, par, normp, cc in (("e2e_localw", par0, 2.0, c), ("e2e_localw_lp", par_lp2, 1.5, c_lp)):
+        _make_localw_case(tmp, fname, par, normp, cc, g, obs, mtrue, nd, N, lw_depth, lw_damp)
+
+
+def _make_localw_case(tmp, fname, par, normp, c, g, obs, mtrue, nd, N, lw_depth, lw_damp):
     res = {}
     # one rank only: the reference never closes unit 10 after the local-weight file (weights_gravmag.f90:268-309) and the
     # flang runtime of this image mis-handles the re-open that follows on 2 ranks (see oracle/ref_build.sh, accommodation 2)
     for nproc in (1,):
-        wd = os.path.join(tmp, "localw_np%d" % nproc)
+        wd = os.path.join(tmp, fname + "_np%d" % nproc)
         shutil.rmtree(wd, ignore_errors=True)
         os.makedirs(wd)
         write_grid_file(os.path.join(wd, "grid.txt"), g, c["nx"], c["ny"], c["nz"])
@@ -939,9 +955,9 @@ def make_localw_e2e(tmp):
             res["np%d_%s" % (nproc, kk)] = vv
     res.update(dict(nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=0.3, nmajor=c["nmajor"], nminor=c["nminor"],
                     alpha=1e-6, lw_depth=lw_depth, lw_damp=lw_damp, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs,
-                    model_true=mtrue, parfile=par))
-    np.savez_compressed(os.path.join(HERE, "e2e_localw.npz"), **res)
-    print("e2e_localw.npz: lsqr r", res["np1_lsqr_r"])
+                    model_true=mtrue, parfile=par, norm_power=normp))
+    np.savez_compressed(os.path.join(HERE, fname + ".npz"), **res)
+    print(fname + ".npz: lsqr r", res["np1_lsqr_r"])
 
 
 def make_xgrad_e2e(tmp):

@@ -240,10 +240,11 @@ def run_inversion_gradient_damping(S, cw, dims, grid, ctype, d_obs, nmajor, nmin
             if norm_power != 2.0:                          # Lp norm multiplier, damping.F90:171-175, :250-262
                 nzm = md != 0.0
                 mult[nzm] = np.abs(md[nzm]) ** (norm_power / 2.0 - 1.0)
+            val, r = alpha * pw * mult, -alpha * pw * md * mult   # the reference's order: alpha * pw, Lp multiplier, local weight
             if damping_weight is not None:                 # local weight = local alpha (damping.F90:177-180, :264-267)
-                mult = mult * damping_weight
-            blocks.append(orc.diag_csr((alpha * pw * mult).astype(np.float32)))
-            rhs.append(-alpha * pw * md * mult)
+                val, r = val * damping_weight, r * damping_weight
+            blocks.append(orc.diag_csr(val.astype(np.float32)))
+            rhs.append(r)
         if beta != 0.0:
             G, grhs = gradient_damping_rows(m, dims, grid, cw, pw, beta)
             blocks.append(G)

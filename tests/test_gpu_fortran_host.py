@@ -638,14 +638,15 @@ def test_data_errors_parfile_matches_reference(tmp_path, golden_dir):
     assert np.allclose(got["vals"][ia], g["np1_vals"][ib], rtol=1e-6)
 
 
-def test_local_weights_parfile_matches_reference(tmp_path, golden_dir):
+@pytest.mark.parametrize("name", ["e2e_localw", "e2e_localw_lp"])
+def test_local_weights_parfile_matches_reference(tmp_path, golden_dir, name):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, "e2e_localw.npz"))
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
-    for name, key in (("lw_depth.txt", "lw_depth"), ("lw_damp.txt", "lw_damp")):
-        with open(os.path.join(wd, name), "w") as f:
+    for fname, key in (("lw_depth.txt", "lw_depth"), ("lw_damp.txt", "lw_damp")):
+        with open(os.path.join(wd, fname), "w") as f:
             f.write("%d\n" % g[key].size)
             f.write("\n".join("%.17g" % v for v in g[key]) + "\n")
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
@@ -653,7 +654,10 @@ def test_local_weights_parfile_matches_reference(tmp_path, golden_dir):
     assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
     ref = g["np1_model_final"]
-    assert np.linalg.norm(model - ref) <= 1e-5 * np.linalg.norm(ref), np.linalg.norm(model - ref) / np.linalg.norm(ref)
+    # e2e_localw runs 400 iterations on 9 data rows (converged solution, sensitive at the 5e-6 level); e2e_localw_lp is the
+    # well-conditioned 5-iteration case (oracle 1-ulp sensitivity 2e-14; the model file holds ~1e-16 relative precision)
+    tol = 1e-5 if name == "e2e_localw" else 1e-9
+    assert np.linalg.norm(model - ref) <= tol * np.linalg.norm(ref), np.linalg.norm(model - ref) / np.linalg.norm(ref)
 
 
 def test_parfile_errors_like_the_reference(tmp_path):

@@ -396,9 +396,10 @@ def test_data_errors_end_to_end(golden_dir):
     assert np.allclose(d, g["np1_data_final"], rtol=1e-8, atol=1e-10 * np.abs(g["np1_data_final"]).max())
 
 
-def test_local_weights_end_to_end(golden_dir):
+@pytest.mark.parametrize("name", ["e2e_localw", "e2e_localw_lp"])
+def test_local_weights_end_to_end(golden_dir, name):
     """Local depth weights (column_weight /= w, zero stays zero) and local model-damping weights vs the reference."""
-    g = load(golden_dir, "e2e_localw")
+    g = load(golden_dir, name)
     grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
     dims = (int(g["nx"]), int(g["ny"]), int(g["nz"]))
     cw = orc.column_weight_type1(grid)
@@ -409,7 +410,8 @@ def test_local_weights_end_to_end(golden_dir):
     assert np.array_equal(rp, g["np1_row_ptr"]) and bits_equal(cols, g["np1_cols"]) and bits_equal(vals, g["np1_vals"])
     S = (rp, cols, vals)
     m, d, hist = oinv.run_inversion_gradient_damping(S, cw, dims, grid, int(g["ctype"]), g["np1_data_observed"], int(g["nmajor"]),
-                                                     int(g["nminor"]), float(g["alpha"]), 0.0, damping_weight=g["lw_damp"])
+                                                     int(g["nminor"]), float(g["alpha"]), 0.0, damping_weight=g["lw_damp"],
+                                                     norm_power=float(g["norm_power"]))
     ref = g["np1_model_final"]
     assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
