@@ -1699,13 +1699,17 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
     int lpre[CMP_PER_THREAD];
     unsigned slotmask = 0;
     double cost = 0.0;
+    // all loads of the segment first (independent, in flight together), then the ballots
+#pragma unroll
+    for (int k = 0; k < CMP_PER_THREAD; ++k) {
+        const int64_t p = base + (int64_t)k * CMP_THREADS;
+        v[k] = p < a.N ? __builtin_nontemporal_load(&r[p]) : 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < CMP_PER_THREAD; ++k) {
         const int64_t p = base + (int64_t)k * CMP_THREADS;
         bool slot = false;
-        v[k] = 0.0;
         if (p < a.N) {
-            v[k] = __builtin_nontemporal_load(&r[p]);
             bool keep;
             if (banded) {
                 const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(v[k]));
