@@ -97,6 +97,8 @@ def main():
     ctx = tfx.Context(local_rank)
     if args.full_select:
         ctx.debug_set("band_select_min_cells", -1)
+    if os.environ.get("TFX_FWD_GROUP"):          # tuning knob: row blocks sharing one staged x tile in the forward product
+        ctx.debug_set("fwd_group", int(os.environ["TFX_FWD_GROUP"]))
     info = ctx.device_info()
     log("device %s, %d CUs, %.0f GB; workload %s" % (info["name"], info["cus"], info["hbm_bytes"] / 1e9, w["desc"]))
     ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))

@@ -18,8 +18,8 @@
  *    vectors fp64 (CUSTOM_REAL, :31).  Cell order is i-fastest (src/inversion/grid.F90:409-426).
  *  - Multi-GPU: the ctx of rank r holds a contiguous column range of S (reference: nelements_at_cpu,
  *    src/forward/gravmag/sensitivity_gravmag.F90:470-524).  The two per-iteration reductions of LSQR
- *    (src/inversion/lsqr_solver2.F90:214, :514) go through the all-reduce hook (tfx_set_allreduce); the host
- *    language supplies RCCL (torch.distributed / ncclAllReduce) there.
+ *    (src/inversion/lsqr_solver2.F90:214, :514) are RCCL all-reduces on the ctx stream once the ctx has a communicator
+ *    (tfx_comm_init_rccl); hosts without RCCL (test boxes) supply them through the hook (tfx_set_allreduce).
  */
 #ifndef TFX_H
 #define TFX_H
@@ -64,6 +64,32 @@ int tfx_device_free(tfx_ctx *ctx, void *ptr);
  * NULL = single rank.  rank/nranks tell LSQR who adds the -alpha*u term (lsqr_solver2.F90:194-198).         */
 typedef int (*tfx_allreduce_fn)(void *user, double *dev_buf, int64_t n, void *stream);
 int tfx_set_allreduce(tfx_ctx *ctx, tfx_allreduce_fn fn, void *user, int rank, int nranks);
+/* Optional companion hook with MPI_Allgatherv semantics on DEVICE buffers (same `user` as the all-reduce hook): rank r's nsend =
+ * counts[r] doubles land at dev_recv + displs[r] on every rank.  Used for the column slices of multi-rank WAVELET_DOMAIN = F
+ * (apply_wavelet_transform, src/inversion/wavelet_utils.F90:37-72); without it the slices travel as a zero-padded sum.       */
+typedef int (*tfx_allgatherv_fn)(void *user, const double *dev_send, int64_t nsend, double *dev_recv, const int64_t *counts,
+                                 const int64_t *displs, void *stream);
+int tfx_set_allgatherv(tfx_ctx *ctx, tfx_allgatherv_fn fn);
+
+/* ---- RCCL inside the library (the production multi-GPU path; one process per GPU) -----------------------------------
+ * With a communicator the collectives of the path are ncclAllReduce / grouped ncclBroadcast / ncclSend / ncclRecv on the ctx
+ * stream, queued between the kernels that produce and consume the buffers: no host callback, no stream synchronisation.
+ *   lsqr_solver2.F90:214 and :511-515 (the two reductions of an LSQR iteration), model.F90:288-293 (predicted data),
+ *   wavelet_utils.F90:37-72 (slices of the model vector), sensitivity_gravmag.F90:322 (nnz histogram), :795-830 (relayout).
+ * Rank 0 calls tfx_comm_unique_id, the host language carries the 128 bytes to the other ranks (MPI_Bcast, torch store, file),
+ * every rank calls tfx_comm_init_rccl (collective).  The hooks above remain for hosts / test boxes without RCCL.            */
+#define TFX_COMM_ID_BYTES 128
+int tfx_comm_unique_id(char *id_out /* [TFX_COMM_ID_BYTES] */);
+int tfx_comm_init_rccl(tfx_ctx *ctx, const char *unique_id /* [TFX_COMM_ID_BYTES] */, int rank, int nranks);
+int tfx_comm_destroy(tfx_ctx *ctx);
+/* Collectives for the host's own exchange steps, on DEVICE buffers, queued on the ctx stream.                              */
+enum { TFX_F64 = 0, TFX_I32 = 1, TFX_I64 = 2 };
+int tfx_comm_allreduce(tfx_ctx *ctx, void *dev_buf, int64_t n, int dtype);           /* sum, in place                       */
+int tfx_comm_group_begin(tfx_ctx *ctx);                                               /* ncclGroupStart / End around a set   */
+int tfx_comm_group_end(tfx_ctx *ctx);                                                 /*   of sends and receives             */
+int tfx_comm_send(tfx_ctx *ctx, const void *dev_buf, int64_t bytes, int peer);
+int tfx_comm_recv(tfx_ctx *ctx, void *dev_buf, int64_t bytes, int peer);
+int tfx_comm_barrier(tfx_ctx *ctx);                                                   /* 1-element all-reduce + stream sync  */
 
 /* ---- model grid ------------------------------------------------------------------------------------------
  * Replaces t_grid (src/inversion/grid.F90:30-50): six fp64 arrays of nx*ny*nz cell bounds, uploaded once.   */
@@ -154,6 +180,11 @@ int tfx_matrix_upload_csr(tfx_ctx *ctx, int64_t nrows, int64_t ncols, const int6
 int tfx_matrix_info(tfx_ctx *ctx, int64_t *nrows, int64_t *ncols, int64_t *nnz, int64_t *device_bytes);
 int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float *vals);
 int tfx_matrix_free(tfx_ctx *ctx);
+/* Row scaling of the selected matrix: entry (r, c) *= (float)scale[r], in fp32 - what read_sensitivity_kernel applies when it
+ * re-loads a kernel that was written unscaled (sensit_compressed * real(problem_weight * data_weight(d, i), MATRIX_PRECISION),
+ * sensitivity_gravmag.F90:834-843).  A host that keeps calculate_and_write_sensit and read_sensitivity_kernel as two steps
+ * builds with problem_weight = 1, data_weight = NULL and calls this from the second.  scale: nrows doubles.                */
+int tfx_matrix_scale_rows(tfx_ctx *ctx, const double *scale);
 
 /* General constraint rows: matrix_cons as the cross-gradient / clustering / gradient-damping / local-bound ADMM
  * builders assemble it on the host (src/inversion/joint_inverse_problem.F90:332, :466-544), uploaded as CSR with its
@@ -257,7 +288,12 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * when the grid is a tensor product; key "tensor_grid": returns 1 when the tensor-product fast path is active;
  * key "band_select_min_cells" (value): grids of at least that many cells find the row thresholds by the sample-bracketed
  * band select instead of the full radix select (default 2^20; < 0: never) - both give the exact order statistic;
- * keys "band_batches" / "band_fallbacks": return how many row batches used it / fell back to the full select.        */
+ * keys "band_batches" / "band_fallbacks": return how many row batches used it / fell back to the full select;
+ * key "deterministic" (0/1): the two matrix products run with single-wave workgroups, so the LDS accumulations happen in program
+ * order and a product is bit-reproducible from run to run (slow; for debugging convergence differences);
+ * key "fwd_group" (0 = automatic, 1, 2, 4): row blocks that share one staged x tile in the forward product;
+ * key "force_collectives" (0/1): issue the collectives of the multi-rank path even with one rank - with a world-size-1
+ * communicator this runs the real ncclAllReduce / ncclBroadcast calls on a single-GPU box.                              */
 int tfx_debug_set(tfx_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

@@ -364,9 +364,10 @@ def test_matrix_roundtrip_and_products(ctx, shape):
     assert abs(np.dot(b, y) - np.dot(x, bt)) <= 1e-11 * np.dot(orc.spmv(*absS, np.abs(x)), np.abs(y))
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (1, 16384), (1, 16385), (2048, 3), (2049, 16385), (3, 70000)])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 4096), (1, 4097), (1, 16385), (2048, 3), (2049, 4097), (3, 70000), (8193, 5000)])
 def test_matrix_edge_shapes(ctx, shape):
-    """Tile-boundary sizes (row block 2048, column tile 16384), single rows / columns, dense and nearly empty patterns."""
+    """Tile-boundary sizes (row block 2048, column tile 4096, forward super block 4 x 2048 rows), single rows / columns, dense
+    and nearly empty patterns."""
     nrows, ncols = shape
     rng = np.random.default_rng(nrows * 131 + ncols)
     for pattern in ("dense_row0", "last_col_only", "diag", "empty"):
@@ -410,6 +411,91 @@ def test_matrix_with_more_row_markers_than_entries(ctx):
     x, y = rng.standard_normal(nc), rng.standard_normal(nr)
     assert np.allclose(ctx.mult_vector(x), orc.spmv(rowptr, cols, vals, x), rtol=1e-13, atol=1e-13)
     assert np.allclose(ctx.trans_mult_vector(y), orc.spmtv(rowptr, cols, vals, y, nc), rtol=1e-13, atol=1e-13)
+
+
+def _random_csr(rng, nrows, ncols, per_row):
+    rp, cols, vals = [0], [], []
+    for r in range(nrows):
+        k = int(rng.integers(0, per_row + 1))
+        c = np.sort(rng.choice(ncols, size=min(k, ncols), replace=False))
+        cols.append((c + 1).astype(np.int32))
+        vals.append((rng.standard_normal(c.size) * 10.0 ** rng.uniform(-3, 3, c.size)).astype(np.float32))
+        rp.append(rp[-1] + c.size)
+    return np.array(rp, np.int64), np.concatenate(cols), np.concatenate(vals)
+
+
+@pytest.mark.parametrize("group", [0, 1, 2, 4])
+def test_forward_super_blocks_give_the_same_product(ctx, group):
+    """The forward product shares one staged x tile between `fwd_group` row blocks; every grouping must give the oracle's product
+    (10 000 rows = 5 row blocks: super blocks of 1, 2 (ragged last group) and 4 (ragged) blocks)."""
+    rng = np.random.default_rng(77)
+    nrows, ncols = 10000, 9000
+    S = _random_csr(rng, nrows, ncols, 40)
+    ctx.debug_set("fwd_group", group)
+    try:
+        ctx.matrix_upload_csr(nrows, ncols, *S)
+        x, y = rng.standard_normal(ncols), rng.standard_normal(nrows)
+        ref = orc.spmv(*S, x)
+        assert np.allclose(ctx.mult_vector(x), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+        reft = orc.spmtv(*S, y, ncols)
+        assert np.allclose(ctx.trans_mult_vector(y), reft, rtol=1e-12, atol=1e-12 * np.abs(reft).max())
+    finally:
+        ctx.debug_set("fwd_group", 0)
+
+
+def test_deterministic_products_are_bit_reproducible(ctx):
+    """Debug key "deterministic": single-wave workgroups, so the LDS accumulations of the two products happen in program order -
+    the same bits on every run (the production kernels' atomic order is run-dependent at the 1e-16 level)."""
+    rng = np.random.default_rng(5)
+    nrows, ncols = 3000, 20000
+    S = _random_csr(rng, nrows, ncols, 300)
+    ctx.matrix_upload_csr(nrows, ncols, *S)
+    x, y = rng.standard_normal(ncols), rng.standard_normal(nrows)
+    ctx.debug_set("deterministic", 1)
+    try:
+        f = [ctx.mult_vector(x) for _ in range(4)]
+        a = [ctx.trans_mult_vector(y) for _ in range(4)]
+    finally:
+        ctx.debug_set("deterministic", 0)
+    for k in range(1, 4):
+        assert bits_equal(f[k], f[0]) and bits_equal(a[k], a[0])
+    ref, reft = orc.spmv(*S, x), orc.spmtv(*S, y, ncols)
+    assert np.allclose(f[0], ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    assert np.allclose(a[0], reft, rtol=1e-12, atol=1e-12 * np.abs(reft).max())
+
+
+def test_matrix_scale_rows_is_the_reload_scaling(ctx):
+    """tfx_matrix_scale_rows: value * float32(scale[row]) in fp32, bit for bit what read_sensitivity_kernel does on reload
+    (sensitivity_gravmag.F90:834-843); tiled and dense storage."""
+    rng = np.random.default_rng(9)
+    nrows, ncols = 2500, 9000
+    rp, cols, vals = _random_csr(rng, nrows, ncols, 60)
+    scale = rng.uniform(0.1, 30.0, nrows)
+    ctx.matrix_upload_csr(nrows, ncols, rp, cols, vals)
+    ctx.matrix_scale_rows(scale)
+    back = ctx.matrix_download_csr()
+    want = vals * np.repeat(scale.astype(np.float32), np.diff(rp))
+    assert np.array_equal(back[0], rp) and np.array_equal(back[1], cols) and bits_equal(back[2], want.astype(np.float32))
+
+
+def test_two_contexts_in_one_process(ctx):
+    """A second context in the same process registers the large-LDS product kernels for itself (the attribute bookkeeping is per
+    context, not a process-wide static) - both contexts give the oracle's products on a matrix that needs > 64 KB of LDS."""
+    rng = np.random.default_rng(21)
+    nrows, ncols = 9000, 30000
+    S = _random_csr(rng, nrows, ncols, 120)
+    x, y = rng.standard_normal(ncols), rng.standard_normal(nrows)
+    ref, reft = orc.spmv(*S, x), orc.spmtv(*S, y, ncols)
+    other = tfx.Context(0)
+    try:
+        for c in (other, ctx):
+            c.debug_set("fwd_group", 4)
+            c.matrix_upload_csr(nrows, ncols, *S)
+            c.debug_set("fwd_group", 0)
+            assert np.allclose(c.mult_vector(x), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+            assert np.allclose(c.trans_mult_vector(y), reft, rtol=1e-12, atol=1e-12 * np.abs(reft).max())
+    finally:
+        other.close()
 
 
 def test_lsqr_two_diagonal_blocks_and_soft_threshold(ctx, golden_dir):

@@ -82,6 +82,7 @@ int tfx_destroy(tfx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     lsqr_free(ctx);
+    (void)tfx_comm_destroy(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->pev0) (void)hipEventDestroy(ctx->pev0);
@@ -149,6 +150,29 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         ctx->band_min_n = value < 0 ? INT64_MAX : (int64_t)value;
         return 0;
     }
+    if (!strcmp(key, "deterministic")) {        // single-wave workgroups in the two products: LDS atomics in program order
+        ctx->deterministic = value != 0;
+        return 0;
+    }
+    if (!strcmp(key, "items_per_cu")) {         // work items per CU for matrices finished from now on
+        ctx->items_per_cu = value > 0 ? value : 16;
+        return 0;
+    }
+    if (!strcmp(key, "refinish")) {             // rebuild the work lists of the selected matrix with the current knobs
+        if (!ctx->selmat().valid || ctx->selmat().is_dense) return fail(TFX_E_STATE, "refinish: no tiled matrix");
+        const int64_t nnz = ctx->selmat().nnz;
+        TFX_TRY(matrix_finish(ctx));
+        ctx->selmat().nnz = nnz;
+        return 0;
+    }
+    if (!strcmp(key, "force_collectives")) {    // issue the collectives of the multi-rank path even on one rank
+        ctx->force_collectives = value != 0;
+        return 0;
+    }
+    if (!strcmp(key, "fwd_group")) {            // row blocks per forward super block for matrices finished from now on (0 = automatic)
+        ctx->fwd_group_override = value;
+        return 0;
+    }
     if (!strcmp(key, "band_batches")) return (int)std::min<int64_t>(ctx->band_batches, INT32_MAX);       // queries
     if (!strcmp(key, "band_fallbacks")) return (int)std::min<int64_t>(ctx->band_fallbacks, INT32_MAX);
     return fail(TFX_E_ARG, "unknown debug key %s", key);
@@ -192,12 +216,7 @@ int tfx_cons_clear(tfx_ctx *ctx)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     (void)hipStreamSynchronize(ctx->stream);
-    TiledMatrix &m = ctx->cons;
-    m.codes.release(); m.vals.release(); m.chunk_row0.release(); m.tiles.release(); m.fwd.release(); m.adj.release();
-    m.fwd_order.release(); m.adj_order.release(); m.fwd_partial.release(); m.adj_partial.release();
-    m.fwd_nslots.release(); m.fwd_pbase.release(); m.adj_nslots.release(); m.adj_pbase.release();
-    m.h_tiles.clear(); m.h_fwd.clear(); m.h_adj.clear();
-    m.valid = false;
+    ctx->cons.release_storage();
     return 0;
 }
 
@@ -294,15 +313,32 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
         rowptr[m.nrows] = m.nrows * m.ncols;
         return 0;
     }
-    std::vector<uint16_t> hc((size_t)m.n_entries);
+    const size_t nch = (size_t)(m.n_entries / CHUNK);
+    std::vector<uint32_t> hs(nch * SLOT_WORDS);
+    std::vector<uint64_t> hm(nch * MASK_WORDS);
     std::vector<float> hv((size_t)m.n_entries);
     if (m.n_entries > 0) {
-        TFX_HIP(hipMemcpy(hc.data(), m.codes.p, (size_t)m.n_entries * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        TFX_HIP(hipMemcpy(hs.data(), m.slots.p, hs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        TFX_HIP(hipMemcpy(hm.data(), m.rowmask.p, hm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
         TFX_HIP(hipMemcpy(hv.data(), m.vals.p, (size_t)m.n_entries * sizeof(float), hipMemcpyDeviceToHost));
     }
-    std::vector<int32_t> hrow0((size_t)(m.n_entries / CHUNK));
+    std::vector<int32_t> hrow0(nch);
     if (!hrow0.empty())
         TFX_HIP(hipMemcpy(hrow0.data(), m.chunk_row0.p, hrow0.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // entry e of the streams: its 12-bit slot and its row-start flag (matrix.hip: put_entry)
+    auto slot_at = [&](int64_t e) -> uint32_t {
+        const int64_t chunk = e >> 9;
+        const int i = (int)(e & (CHUNK - 1)), lane = i >> 3, k = i & 7, bit = 12 * k, wi = bit >> 5, sh = bit & 31;
+        const uint32_t *w = hs.data() + chunk * SLOT_WORDS + lane * 3;
+        uint32_t v = w[wi] >> sh;
+        if (sh > 20) v |= w[wi + 1] << (32 - sh);
+        return v & 0xfffu;
+    };
+    auto flag_at = [&](int64_t e) -> bool {
+        const int64_t chunk = e >> 9;
+        const int i = (int)(e & (CHUNK - 1)), lane = i >> 3, k = i & 7;
+        return (hm[(size_t)(chunk * MASK_WORDS + k)] >> lane) & 1ull;
+    };
     // tiles sorted by (rb, t): columns of a row come out ascending
     std::vector<TileMeta> tl = m.h_tiles;
     std::sort(tl.begin(), tl.end(), [](const TileMeta &a, const TileMeta &b) { return a.rb != b.rb ? a.rb < b.rb : a.t < b.t; });
@@ -319,11 +355,11 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
         for (const TileMeta &tm : tl) {
             int cur = hrow0[(size_t)(tm.off / CHUNK)];
             for (int32_t e = 0; e < tm.cnt; ++e) {
-                uint16_t code = hc[(size_t)(tm.off + e)];
-                if (code & ROWSTART) cur += 1;
+                const bool flag = flag_at(tm.off + e);
+                const uint32_t slot = slot_at(tm.off + e);
+                if (flag) cur += 1;
                 float v = hv[(size_t)(tm.off + e)];
-                bool marker = (code & ROWSTART) && v == 0.0f && (code & COLMASK) == 0 &&
-                              (e + 1 == tm.cnt || (hc[(size_t)(tm.off + e + 1)] & ROWSTART));
+                bool marker = flag && v == 0.0f && slot == 0 && (e + 1 == tm.cnt || flag_at(tm.off + e + 1));
                 // a marker is indistinguishable from a stored exact zero in column 0 of the tile that is alone in
                 // its row segment; the reference never stores zeros (sparse_matrix.f90:219, threshold >= 1e-30)
                 if (marker) continue;
@@ -332,7 +368,7 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
                 if (pass == 0) cnt[(size_t)row] += 1;
                 else {
                     int64_t p = fill[(size_t)row]++;
-                    if (cols) cols[p] = (int32_t)((int64_t)tm.t * m.TC + col_slot(code & COLMASK) + 1);
+                    if (cols) cols[p] = (int32_t)((int64_t)tm.t * m.TC + col_slot((int)slot) + 1);
                     if (vals) vals[p] = v;
                 }
             }
@@ -345,13 +381,27 @@ int tfx_matrix_free(tfx_ctx *ctx)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     (void)hipStreamSynchronize(ctx->stream);
+    ctx->selmat().release_storage();
+    return 0;
+}
+
+// Rows of the selected matrix times a per-row factor: entry (r, c) becomes value * (float)scale[r] in fp32 - the scaling
+// read_sensitivity_kernel applies on reload (sensitivity_gravmag.F90:834-843) to a kernel stored unscaled.
+int tfx_matrix_scale_rows(tfx_ctx *ctx, const double *scale)
+{
+    if (!ctx || !scale) return fail(TFX_E_ARG, "tfx_matrix_scale_rows: null argument");
     TiledMatrix &m = ctx->selmat();
-    m.codes.release(); m.vals.release(); m.chunk_row0.release(); m.tiles.release(); m.fwd.release(); m.adj.release();
-    m.fwd_order.release(); m.adj_order.release(); m.fwd_partial.release(); m.adj_partial.release();
-    m.fwd_nslots.release(); m.fwd_pbase.release(); m.adj_nslots.release(); m.adj_pbase.release();
-    m.h_tiles.clear(); m.h_fwd.clear(); m.h_adj.clear();
-    m.dense.release(); m.dense_partial.release(); m.is_dense = false;
-    m.valid = false;
+    if (!m.valid) return fail(TFX_E_STATE, "tfx_matrix_scale_rows: no matrix");
+    TFX_HIP(hipSetDevice(ctx->device));
+    std::vector<double> hs((size_t)m.nrows);
+    TFX_TRY(copy_any(hs.data(), scale, (size_t)m.nrows * sizeof(double), ctx->stream));
+    std::vector<float> hf((size_t)m.nrows);
+    for (int64_t r = 0; r < m.nrows; ++r) hf[(size_t)r] = (float)hs[(size_t)r];
+    DBuf<float> df;
+    TFX_TRY(df.alloc((size_t)m.nrows));
+    TFX_TRY(copy_any(df.p, hf.data(), (size_t)m.nrows * sizeof(float), ctx->stream));
+    TFX_TRY(scale_rows_dev(ctx, m, df.p));
+    TFX_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

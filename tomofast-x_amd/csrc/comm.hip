@@ -1,0 +1,192 @@
+// comm.hip - RCCL inside libtfx.so: the collectives of the multi-GPU path run on the ctx stream, between the kernels that
+// produce and consume their buffers - no host callback, no stream synchronisation, the queued LSQR iterations stay queued.
+//
+// What the reference does with MPI on the host (one rank per model-column range):
+//   lsqr_solver2.F90:214        MPI_Allreduce of u = [S_loc v ; ...]            -> all-reduce #1 (rows + 1 doubles)
+//   lsqr_solver2.F90:511-515    MPI_Allreduce of |v_loc|^2                       -> all-reduce #2 (1 double)
+//   model.F90:288-293           MPI_Allreduce of the predicted data              -> tfx_calc_data
+//   wavelet_utils.F90:37-72     gather to rank 0 / transform / scatter           -> all-gather of the column slices, every GPU transforms
+//   sensitivity_gravmag.F90:322 MPI_Allreduce of sensit_nnz                      -> tfx_comm_allreduce (int32)
+//   sensitivity_gravmag.F90:795-830  rank-0 MPI_Scatterv of every row            -> point-to-point pieces (tfx_comm_send / _recv)
+// One process per GPU; the host language only carries the 128-byte unique id from rank 0 to the others (MPI_Bcast, a file, a
+// torch store - anything).  Without a communicator the ctx falls back to the host-supplied hooks (tfx_set_allreduce): that is
+// how the multi-rank logic is tested on boxes without several GPUs (gloo / MPI staging), never the production path.
+#include "common.h"
+#include <rccl/rccl.h>
+
+namespace tfx {
+
+#define TFX_NCCL(expr)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t r_ = (expr);                                                                               \
+        if (r_ != ncclSuccess)                                                                                  \
+            return tfx::fail(TFX_E_COMM, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(r_)); \
+    } while (0)
+
+static inline ncclComm_t comm_of(tfx_ctx *ctx) { return (ncclComm_t)ctx->comm; }
+
+// sum over ranks, fp64, in place on a device buffer, on the ctx stream
+int comm_allreduce_f64(tfx_ctx *ctx, double *buf, int64_t n)
+{
+    if (!ctx->multi() || n <= 0) return 0;
+    if (ctx->comm) {
+        TFX_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, comm_of(ctx), ctx->stream));
+        return 0;
+    }
+    if (!ctx->allreduce) return fail(TFX_E_COMM, "several ranks but neither a communicator nor an all-reduce hook");
+    int rc = ctx->allreduce(ctx->allreduce_user, buf, n, (void *)ctx->stream);
+    if (rc != 0) return fail(TFX_E_COMM, "all-reduce hook failed (%d)", rc);
+    return 0;
+}
+
+// Gathers the slices of all ranks: rank r contributes counts[r] doubles, they land at recv + displs[r] on every rank.
+// RCCL: one grouped broadcast per rank (the slices are nnz-balanced column ranges, so their lengths differ: ncclAllGather
+// wants equal counts).  Hook fallback: tfx_allgatherv_fn when the host supplied one.  Returns 1 when neither is available
+// (the caller then falls back to the zero-padded all-reduce).
+int comm_allgatherv_f64(tfx_ctx *ctx, const double *send, double *recv, const int64_t *counts, const int64_t *displs)
+{
+    if (ctx->comm) {
+        TFX_NCCL(ncclGroupStart());
+        for (int r = 0; r < ctx->nranks; ++r) {
+            if (counts[r] == 0) continue;
+            ncclResult_t rr = ncclBroadcast(r == ctx->rank ? (const void *)send : (const void *)(recv + displs[r]), recv + displs[r],
+                                            (size_t)counts[r], ncclDouble, r, comm_of(ctx), ctx->stream);
+            if (rr != ncclSuccess) {
+                (void)ncclGroupEnd();
+                return fail(TFX_E_COMM, "ncclBroadcast: %s", ncclGetErrorString(rr));
+            }
+        }
+        TFX_NCCL(ncclGroupEnd());
+        return 0;
+    }
+    if (ctx->allgatherv) {
+        int rc = ctx->allgatherv(ctx->allreduce_user, send, counts[ctx->rank], recv, counts, displs, (void *)ctx->stream);
+        if (rc != 0) return fail(TFX_E_COMM, "all-gather hook failed (%d)", rc);
+        return 0;
+    }
+    return 1;
+}
+
+}  // namespace tfx
+
+using namespace tfx;
+
+extern "C" {
+
+int tfx_comm_unique_id(char *id_out)
+{
+    if (!id_out) return fail(TFX_E_ARG, "tfx_comm_unique_id: null output");
+    static_assert(sizeof(ncclUniqueId) == TFX_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    TFX_NCCL(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int tfx_comm_init_rccl(tfx_ctx *ctx, const char *unique_id, int rank, int nranks)
+{
+    if (!ctx || !unique_id) return fail(TFX_E_ARG, "tfx_comm_init_rccl: null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(TFX_E_ARG, "bad rank %d / %d", rank, nranks);
+    if (ctx->comm) return fail(TFX_E_STATE, "tfx_comm_init_rccl: the context already has a communicator");
+    TFX_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t c = nullptr;
+    TFX_NCCL(ncclCommInitRank(&c, nranks, id, rank));
+    ctx->comm = (void *)c;
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return 0;
+}
+
+int tfx_comm_destroy(tfx_ctx *ctx)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    if (ctx->comm) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        ncclResult_t r = ncclCommDestroy(comm_of(ctx));
+        ctx->comm = nullptr;
+        if (!ctx->allreduce) { ctx->rank = 0; ctx->nranks = 1; }
+        if (r != ncclSuccess) return fail(TFX_E_COMM, "ncclCommDestroy: %s", ncclGetErrorString(r));
+    }
+    return 0;
+}
+
+// ---- collectives on device buffers for the host's own exchange steps (build histogram, relayout), on the ctx stream
+static int need_comm(tfx_ctx *ctx, const char *who)
+{
+    if (!ctx) return fail(TFX_E_ARG, "%s: null ctx", who);
+    if (!ctx->comm) return fail(TFX_E_STATE, "%s: no communicator (tfx_comm_init_rccl)", who);
+    return 0;
+}
+
+int tfx_comm_allreduce(tfx_ctx *ctx, void *dev_buf, int64_t n, int dtype)
+{
+    TFX_TRY(need_comm(ctx, "tfx_comm_allreduce"));
+    if (n < 0 || (n > 0 && !dev_buf)) return fail(TFX_E_ARG, "tfx_comm_allreduce: bad buffer");
+    ncclDataType_t t;
+    switch (dtype) {
+    case TFX_F64: t = ncclDouble; break;
+    case TFX_I32: t = ncclInt32; break;
+    case TFX_I64: t = ncclInt64; break;
+    default: return fail(TFX_E_ARG, "tfx_comm_allreduce: unknown dtype %d", dtype);
+    }
+    if (n == 0) return 0;
+    TFX_HIP(hipSetDevice(ctx->device));
+    TFX_NCCL(ncclAllReduce(dev_buf, dev_buf, (size_t)n, t, ncclSum, comm_of(ctx), ctx->stream));
+    return 0;
+}
+
+int tfx_comm_group_begin(tfx_ctx *ctx)
+{
+    TFX_TRY(need_comm(ctx, "tfx_comm_group_begin"));
+    TFX_HIP(hipSetDevice(ctx->device));
+    TFX_NCCL(ncclGroupStart());
+    return 0;
+}
+
+int tfx_comm_group_end(tfx_ctx *ctx)
+{
+    TFX_TRY(need_comm(ctx, "tfx_comm_group_end"));
+    TFX_NCCL(ncclGroupEnd());
+    return 0;
+}
+
+int tfx_comm_send(tfx_ctx *ctx, const void *dev_buf, int64_t bytes, int peer)
+{
+    TFX_TRY(need_comm(ctx, "tfx_comm_send"));
+    if (bytes < 0 || peer < 0 || peer >= ctx->nranks || peer == ctx->rank) return fail(TFX_E_ARG, "tfx_comm_send: bad arguments");
+    if (bytes == 0) return 0;
+    TFX_NCCL(ncclSend(dev_buf, (size_t)bytes, ncclUint8, peer, comm_of(ctx), ctx->stream));
+    return 0;
+}
+
+int tfx_comm_recv(tfx_ctx *ctx, void *dev_buf, int64_t bytes, int peer)
+{
+    TFX_TRY(need_comm(ctx, "tfx_comm_recv"));
+    if (bytes < 0 || peer < 0 || peer >= ctx->nranks || peer == ctx->rank) return fail(TFX_E_ARG, "tfx_comm_recv: bad arguments");
+    if (bytes == 0) return 0;
+    TFX_NCCL(ncclRecv(dev_buf, (size_t)bytes, ncclUint8, peer, comm_of(ctx), ctx->stream));
+    return 0;
+}
+
+int tfx_comm_barrier(tfx_ctx *ctx)
+{
+    TFX_TRY(need_comm(ctx, "tfx_comm_barrier"));
+    TFX_HIP(hipSetDevice(ctx->device));
+    TFX_TRY(ctx->vb.ensure(1));
+    TFX_HIP(hipMemsetAsync(ctx->vb.p, 0, sizeof(double), ctx->stream));
+    TFX_NCCL(ncclAllReduce(ctx->vb.p, ctx->vb.p, 1, ncclDouble, ncclSum, comm_of(ctx), ctx->stream));
+    TFX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int tfx_set_allgatherv(tfx_ctx *ctx, tfx_allgatherv_fn fn)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    ctx->allgatherv = fn;
+    return 0;
+}
+
+}  // extern "C"

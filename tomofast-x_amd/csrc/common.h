@@ -68,18 +68,19 @@ struct DBuf {
 
 // ---- tiled sensitivity matrix (DESIGN.md "Data layout in HBM") ------------------------------------------
 constexpr int CHUNK = 512;            // entries per chunk = 64 lanes x 8 entries
-constexpr int TC_MAX = 16384;         // columns per column tile (14-bit local column)
-constexpr int RB_MAX = 2048;          // rows per row block
-constexpr uint16_t ROWSTART = 0x8000; // code bit 15: this entry starts a new row inside the tile
-constexpr uint16_t COLMASK = 0x3fff;
-// The column stored in a code is the LDS slot of that column inside the tile, not the column itself: slot = col ^ f(col >> 4), a
+constexpr int SLOT_WORDS = 192;       // dwords of packed 12-bit column slots per chunk (lane L: words 3L..3L+2 = its 8 slots)
+constexpr int MASK_WORDS = 8;         // uint64 row-start masks per chunk: word k, bit L = "entry k of lane L starts a new row"
+constexpr int TC_MAX = 4096;          // columns per column tile (12-bit local column; the x tile is 32 KB of LDS)
+constexpr int RB_MAX = 2048;          // rows per (storage) row block
+constexpr int FWD_GROUP_MAX = 4;      // the forward product walks up to this many row blocks per staged x tile (row sums: 64 KB of LDS)
+// The column stored for an entry is the LDS slot of that column inside the tile, not the column itself: slot = col ^ f(col >> 4), a
 // bijection inside aligned groups of 16 (an involution) that folds the higher index bits into the four bank bits.  Wavelet
 // coefficients sit on index lattices (multiples of 2^l per axis); without the fold the columns of one LDS instruction are
 // often congruent modulo 16 and pile onto one bank pair.  Stored pre-swizzled, it costs the product kernels nothing.
-__host__ __device__ inline int col_slot(int i) { return i ^ (((i >> 4) ^ (i >> 8) ^ (i >> 12)) & 15); }
+__host__ __device__ inline int col_slot(int i) { return i ^ (((i >> 4) ^ (i >> 8)) & 15); }
 
 struct TileMeta {
-    int64_t off;      // first entry (multiple of CHUNK) in codes[] / vals[]
+    int64_t off;      // first entry (multiple of CHUNK) of the tile in the entry streams
     int32_t nchunks;  // padded length / CHUNK
     int32_t cnt;      // real entries (incl. empty-row markers)
     int32_t t;        // column tile
@@ -98,9 +99,12 @@ struct TiledMatrix {
     int64_t nrows = 0, ncols = 0, nnz = 0;
     int TC = TC_MAX, RB = RB_MAX;
     int ntc = 0, nrb = 0;
-    DBuf<uint16_t> codes;
+    int fwd_group = 1;            // row blocks per forward super block (shared x tile)
+    DBuf<uint32_t> slots;         // SLOT_WORDS per chunk
+    DBuf<uint64_t> rowmask;       // MASK_WORDS per chunk
     DBuf<float> vals;
     int64_t n_entries = 0;        // used (padded) entries
+    int64_t cap_entries = 0;      // allocated entries
     DBuf<int32_t> chunk_row0;     // per chunk: local row of the entry preceding the chunk
     std::vector<TileMeta> h_tiles;
     DBuf<TileMeta> tiles;
@@ -108,7 +112,7 @@ struct TiledMatrix {
     std::vector<WorkItem> h_fwd, h_adj;
     DBuf<WorkItem> fwd, adj;
     DBuf<int32_t> fwd_order, adj_order;
-    DBuf<double> fwd_partial;     // one RB-tile of row sums per forward item
+    DBuf<double> fwd_partial;     // fwd_group * RB row sums per forward item
     DBuf<double> adj_partial;     // one TC-tile of column sums per adjoint item with slot >= 1
     DBuf<int32_t> fwd_nslots, fwd_pbase;   // per row block
     DBuf<int32_t> adj_nslots, adj_pbase;   // per column tile
@@ -120,6 +124,7 @@ struct TiledMatrix {
     DBuf<double> dense_partial;   // forward: [nchunks][nrows] partial row sums
     bool valid = false;
     size_t device_bytes() const;
+    void release_storage();       // frees every device buffer and clears the host-side lists
 };
 
 // compressed rows kept row-major on the device (all columns): the row-parallel half of the multi-GPU build
@@ -161,12 +166,23 @@ struct tfx_ctx {
     tfx::TiledMatrix *target = &mat;   // which matrix matrix_begin / append / finish assemble
     tfx::RowStore rowstores[2];        // one per problem slot (a joint run partitions on the counts of both kernels before the relayout)
     tfx::RowStore &rowstore() { return rowstores[slot]; }
+    // scratch of matrix_append_rows (grown on demand, reused by every row block)
+    struct AppendScratch {
+        tfx::DBuf<int32_t> pos, segoff, first_ne, last_ne, tile_nch;
+        tfx::DBuf<int64_t> tile_off;
+        std::vector<int32_t> h_segoff_last, h_nch;
+        std::vector<int64_t> h_off;
+    } append;
     // scratch vectors for spmv / spmtv with host pointers
-    tfx::DBuf<double> vx, vb;
+    tfx::DBuf<double> vx, vb, vw;
     // comm
+    void *comm = nullptr;              // ncclComm_t (comm.hip): when set, every collective of the path is RCCL on the ctx stream
     tfx_allreduce_fn allreduce = nullptr;
+    tfx_allgatherv_fn allgatherv = nullptr;
     void *allreduce_user = nullptr;
     int rank = 0, nranks = 1;
+    bool force_collectives = false;    // debug: issue the collectives even on one rank (a world-size-1 communicator exercises RCCL)
+    bool multi() const { return nranks > 1 || force_collectives; }
     // lsqr
     tfx::LsqrState *lsqr = nullptr;
     // WAVELET_DOMAIN = F (joint_inverse_problem.F90:189-198): LSQR unknowns are spatial, S acts on Wav(v)
@@ -177,6 +193,10 @@ struct tfx_ctx {
     int wd_ncomp = 0;          //   and the number of model components (of all problems) in the local unknown vector
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int items_per_cu = 16;            // debug key "items_per_cu": work items per CU the tile list is cut into
+    int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
+    bool deterministic = false;       // debug: single-wave workgroups in the two products -> LDS atomics in program order
+    size_t lds_attr[4] = {0, 0, 0, 0}; // largest dynamic-LDS size registered for each product kernel variant ON THIS ctx's device
     bool profile = false;
     double prof_ms[2] = {0, 0};
     int64_t prof_n[2] = {0, 0};
@@ -197,8 +217,12 @@ int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);    // b (+
 int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add);
 int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add);
 int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols);
+int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale);
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
 void prof_drain(tfx_ctx *ctx);
+// comm.hip
+int comm_allreduce_f64(tfx_ctx *ctx, double *buf, int64_t n);
+int comm_allgatherv_f64(tfx_ctx *ctx, const double *send, double *recv, const int64_t *counts, const int64_t *displs);   // 1: unavailable
 // build.hip
 int detect_tensor_grid(tfx_ctx *ctx);
 int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, int type, int dir);

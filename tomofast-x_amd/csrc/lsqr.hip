@@ -36,6 +36,7 @@ struct LsqrState {
     DBuf<double> b0, sx;   // target-misfit only
     DBuf<double> tw;       // WAVELET_DOMAIN = F: wavelet-domain image of v / x, or S^T u before the inverse transform
     DBuf<double> twf;      //   multi-rank: the full-length vector (all ranks' slices) the transform runs on
+    std::vector<int64_t> g_counts, g_displs;   //   cells per rank and first cell of every rank (all-gather of the slices)
     DBuf<double> red;      // block partial sums
     DBuf<unsigned int> cnt;   // arrival counters of the single-launch reductions (zero between launches)
     DBuf<Scalars> sc;
@@ -253,7 +254,7 @@ __device__ __forceinline__ void rotate(Scalars *sc)
     if (sc->stop) return;
     const double alpha = sc->alpha, beta = sc->beta;
     const double rho = sqrt(sc->rhobar * sc->rhobar + beta * beta);
-    if (rho == 0.0) { sc->rho_zero = 1; sc->t1 = 0.0; sc->t2 = 0.0; sc->stop = 1; return; }
+    if (rho == 0.0) { sc->rho_zero = 1; sc->t1 = 0.0; sc->t2 = 0.0; sc->stop = 1; sc->skip = 1; return; }   // exits before the x / w update and the soft threshold (:251-254)
     const double rho_inv = 1.0 / rho;
     const double c = sc->rhobar * rho_inv;
     const double s = beta * rho_inv;
@@ -346,12 +347,11 @@ static int S_adjoint(tfx_ctx *ctx, const double *x, double *b, int add)
     return 0;
 }
 
+// sum over the ranks: ncclAllReduce on the ctx stream when the ctx has a communicator, else the host's hook (comm.hip)
 static int allreduce(tfx_ctx *ctx, double *buf, int64_t n)
 {
-    if (ctx->nranks <= 1 || !ctx->allreduce) return 0;
-    int rc = ctx->allreduce(ctx->allreduce_user, buf, n, (void *)ctx->stream);
-    if (rc != 0) return fail(TFX_E_COMM, "all-reduce hook failed (%d)", rc);
-    return 0;
+    if (!ctx->multi()) return 0;
+    return comm_allreduce_f64(ctx, buf, n);
 }
 
 static int read_scalars(tfx_ctx *ctx, LsqrState *L)
@@ -412,15 +412,26 @@ __global__ void k_take_slice(double *__restrict__ loc, const double *__restrict_
 static int transform_slice(tfx_ctx *ctx, LsqrState *L, int dir)
 {
     hipStream_t s = ctx->stream;
-    if (ctx->nranks <= 1)
+    if (!ctx->multi())
         return wavelet_dev(ctx, L->tw.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ctx->wd_nvec, ctx->wd_type, dir);
     const int64_t N = (int64_t)ctx->wd_n1 * ctx->wd_n2 * ctx->wd_n3;
     const int ncomp = ctx->wd_ncomp;
     const int64_t nloc = L->ncols / ncomp, full = (int64_t)ncomp * N;
-    TFX_HIP(hipMemsetAsync(L->twf.p, 0, (size_t)full * sizeof(double), s));
-    LAUNCH(k_place_slice, grid_for(L->ncols), L->twf.p, L->tw.p, ncomp, N, ctx->wd_col_begin, nloc);
-    TFX_HIP(hipGetLastError());
-    TFX_TRY(allreduce(ctx, L->twf.p, full));
+    // all-gather of the slices, one model component after the other (N doubles each land on every rank: the reference moves the
+    // same N doubles to rank 0 and back, wavelet_utils.F90:46-70)
+    bool gathered = true;
+    for (int k = 0; k < ncomp && gathered; ++k) {
+        const int rc = comm_allgatherv_f64(ctx, L->tw.p + (int64_t)k * nloc, L->twf.p + (int64_t)k * N, L->g_counts.data(), L->g_displs.data());
+        if (rc < 0) return rc;
+        if (rc == 1) gathered = false;
+    }
+    if (!gathered) {
+        // a host hook without all-gather: disjoint supports, so the sum all-reduce of the zero-padded full vector is a gather
+        TFX_HIP(hipMemsetAsync(L->twf.p, 0, (size_t)full * sizeof(double), s));
+        LAUNCH(k_place_slice, grid_for(L->ncols), L->twf.p, L->tw.p, ncomp, N, ctx->wd_col_begin, nloc);
+        TFX_HIP(hipGetLastError());
+        TFX_TRY(allreduce(ctx, L->twf.p, full));
+    }
     TFX_TRY(wavelet_dev(ctx, L->twf.p, ctx->wd_n1, ctx->wd_n2, ctx->wd_n3, ncomp, ctx->wd_type, dir));
     LAUNCH(k_take_slice, grid_for(L->ncols), L->tw.p, L->twf.p, ncomp, N, ctx->wd_col_begin, nloc);
     TFX_HIP(hipGetLastError());
@@ -516,13 +527,30 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     TFX_HIP(hipMemsetAsync(L->cnt.p, 0, 4 * sizeof(unsigned int), ctx->stream));
     if (ctx->spatial_unknowns) {
         const int64_t n123 = (int64_t)ctx->wd_n1 * ctx->wd_n2 * ctx->wd_n3;
-        if (ctx->nranks > 1) {
+        if (ctx->multi()) {
             // this rank's unknowns are the cells [col_begin, col_begin + nloc) of every model component
             if (ctx->wd_col_begin < 0 || ctx->wd_ncomp <= 0)
                 return fail(TFX_E_STATE, "multi-rank WAVELET_DOMAIN = F: call tfx_lsqr_set_partition first");
             if (nc % ctx->wd_ncomp != 0 || ctx->wd_col_begin + nc / ctx->wd_ncomp > n123)
                 return fail(TFX_E_STATE, "the column partition does not match the matrix (%lld local columns, %d components)", (long long)nc, ctx->wd_ncomp);
             TFX_TRY(L->twf.ensure((size_t)(ctx->wd_ncomp * n123)));
+            // first cell of every rank: each rank puts its own into a zero vector, the sum is the list (exact: integers < 2^53)
+            TFX_TRY(ctx->vx.ensure((size_t)std::max<int64_t>(ctx->nranks, nc)));
+            std::vector<double> hb((size_t)ctx->nranks, 0.0);
+            hb[(size_t)ctx->rank] = (double)ctx->wd_col_begin;
+            TFX_TRY(copy_any(ctx->vx.p, hb.data(), hb.size() * sizeof(double), s));
+            TFX_TRY(allreduce(ctx, ctx->vx.p, ctx->nranks));
+            TFX_TRY(copy_any(hb.data(), ctx->vx.p, hb.size() * sizeof(double), s));
+            L->g_counts.assign((size_t)ctx->nranks, 0);
+            L->g_displs.assign((size_t)ctx->nranks, 0);
+            for (int r = 0; r < ctx->nranks; ++r) {
+                L->g_displs[(size_t)r] = (int64_t)hb[(size_t)r];
+                const int64_t next = r + 1 < ctx->nranks ? (int64_t)hb[(size_t)r + 1] : n123;
+                L->g_counts[(size_t)r] = next - L->g_displs[(size_t)r];
+            }
+            if (L->g_counts[(size_t)ctx->rank] != nc / ctx->wd_ncomp)
+                return fail(TFX_E_STATE, "the ranks' column ranges do not tile the model (rank %d: %lld cells, range of %lld)", ctx->rank,
+                            (long long)(nc / ctx->wd_ncomp), (long long)L->g_counts[(size_t)ctx->rank]);
         } else {
             if (n123 <= 0 || nc % n123 != 0)   // ncolumns = nmodel_components * nelements (wavelet_utils.F90:37-72 loops the components)
                 return fail(TFX_E_STATE, "WAVELET_DOMAIN = F needs the whole model on this rank (ncolumns %lld is not a multiple of n1*n2*n3)", (long long)nc);
@@ -659,7 +687,7 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
                 const int64_t nuc = (int64_t)L->nblocks * nc;
                 LAUNCH(k_scale_u_uc_v, grid_for(std::max(std::max(nr, nuc), nc)), L->u.p, nr, L->uc.p, nuc, L->v.p, nc, L->sc.p);
             }
-            const bool fused = ctx->nranks <= 1 || !ctx->allreduce;                       // no reduction between sum_v and alpha
+            const bool fused = !ctx->multi();                      // no reduction between sum_v and alpha
             TFX_TRY(adjoint_and_alpha(ctx, L, fused));                                    // :228-241
             if (!fused) LAUNCH(k_rotate, 1, L->sc.p);                                     // :248-266
             LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, fused ? 1.0 : 0.0, L->gamma);   // :241, :269-274
@@ -701,6 +729,16 @@ int tfx_lsqr_solve(tfx_ctx *ctx, int niter, double rmin, double gamma, double ta
     return tfx_lsqr_end(ctx, x_out);
 }
 
+// data_calc = S xw / problem_weight / data_weight, the divisions on the device (model.F90:295-302)
+__global__ void k_calc_data_finish(double *__restrict__ d, int64_t n, double problem_weight, const double *__restrict__ dw)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = d[i] / problem_weight;
+        if (dw) v = v / dw[i];
+        d[i] = v;
+    }
+}
+
 int tfx_calc_data(tfx_ctx *ctx, const double *xw_local, double problem_weight, const double *data_weight,
                   double *data_calc)
 {
@@ -710,29 +748,21 @@ int tfx_calc_data(tfx_ctx *ctx, const double *xw_local, double problem_weight, c
     if (problem_weight == 0.0) return fail(TFX_E_NUMERIC, "Zero problem weight in model_calculate_data!");
     TFX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    DBuf<double> dx, db;
-    TFX_TRY(dx.alloc((size_t)m.ncols));
-    TFX_TRY(db.alloc((size_t)m.nrows));
-    TFX_HIP(hipMemcpyAsync(dx.p, xw_local, (size_t)m.ncols * sizeof(double), hipMemcpyDefault, s));
-    TFX_TRY(spmv_dev(ctx, dx.p, db.p, 0));                                                // model.F90:285-286
-    if (ctx->nranks > 1) {                                                                // model.F90:290
-        int rc = ctx->allreduce(ctx->allreduce_user, db.p, m.nrows, (void *)s);
-        if (rc != 0) return fail(TFX_E_COMM, "all-reduce hook failed (%d)", rc);
-    }
-    std::vector<double> h((size_t)m.nrows);
-    TFX_HIP(hipMemcpyAsync(h.data(), db.p, (size_t)m.nrows * sizeof(double), hipMemcpyDeviceToHost, s));
-    TFX_HIP(hipStreamSynchronize(s));
-    std::vector<double> dw;
+    // scratch kept by the ctx: x, b and the data weights (no allocation per call once they have their size)
+    TFX_TRY(ctx->vx.ensure((size_t)m.ncols));
+    TFX_TRY(ctx->vb.ensure((size_t)m.nrows));
+    TFX_HIP(hipMemcpyAsync(ctx->vx.p, xw_local, (size_t)m.ncols * sizeof(double), hipMemcpyDefault, s));
+    const double *dw = nullptr;
     if (data_weight) {
-        dw.resize((size_t)m.nrows);
-        TFX_TRY(copy_any(dw.data(), data_weight, (size_t)m.nrows * sizeof(double), s));
+        TFX_TRY(ctx->vw.ensure((size_t)m.nrows));
+        TFX_HIP(hipMemcpyAsync(ctx->vw.p, data_weight, (size_t)m.nrows * sizeof(double), hipMemcpyDefault, s));
+        dw = ctx->vw.p;
     }
-    for (int64_t i = 0; i < m.nrows; ++i) {                                               // model.F90:295-302
-        double d = h[(size_t)i] / problem_weight;
-        if (data_weight) d = d / dw[(size_t)i];
-        h[(size_t)i] = d;
-    }
-    TFX_TRY(copy_any(data_calc, h.data(), (size_t)m.nrows * sizeof(double), s));
+    TFX_TRY(spmv_dev(ctx, ctx->vx.p, ctx->vb.p, 0));                                      // model.F90:285-286
+    TFX_TRY(allreduce(ctx, ctx->vb.p, m.nrows));                                          // model.F90:290
+    LAUNCH(k_calc_data_finish, grid_for(m.nrows), ctx->vb.p, m.nrows, problem_weight, dw);
+    TFX_HIP(hipGetLastError());
+    TFX_TRY(copy_any(data_calc, ctx->vb.p, (size_t)m.nrows * sizeof(double), s));
     return 0;
 }
 

@@ -4,21 +4,24 @@
 //   adjoint  b (+)= S^T x  (t_sparse_matrix%add_trans_mult_vector, src/inversion/sparse_matrix.f90:391-405)
 //
 // Layout (DESIGN.md "Data layout in HBM").  The reference keeps CSR with 4-byte values + 4-byte columns
-// (8 B per non-zero).  Here S is cut into tiles of (RB <= 2048 rows) x (TC <= 16384 columns).  Inside a tile the
-// entries are in (row, column) order and stored as two streams:
-//     codes[]  uint16 : bit 15 = "first entry of a new row inside this tile", bits 0-13 = LDS slot of the column inside the tile
-//                       (col_slot(column), common.h: the column with its higher bits folded into the four bank bits)
-//     vals[]   float  : the value exactly as the reference stores it
-// i.e. 6 B per non-zero.  A row that is empty inside a tile but lies between two non-empty rows carries one marker
-// entry (ROWSTART, value 0).  A tile is padded to a multiple of 512 entries (one chunk = 64 lanes x 8 entries, so a
-// lane fetches its 8 codes with one 16-byte load and its 8 values with two).  chunk_row0[] gives each chunk the
-// local row of the entry preceding it, so any wave can start at any chunk.
+// (8 B per non-zero).  Here S is cut into tiles of (RB <= 2048 rows) x (TC <= 4096 columns).  Inside a tile the
+// entries are in (row, column) order, padded to chunks of 512 entries (64 lanes x 8 entries), in three streams:
+//     vals[]    float  : the value exactly as the reference stores it                               4      B / entry
+//     slots[]   12 bit : LDS slot of the column inside the tile (col_slot(column), common.h); a lane's 8 slots are
+//                        three consecutive dwords, so a wave fetches a chunk's slots with one dwordx3 load   1.5    B / entry
+//     rowmask[] 1 bit  : "first entry of a new row inside this tile", stored k-major: word k of a chunk holds the
+//                        flags of entry k of all 64 lanes - exactly the wave mask a ballot would produce, so the
+//                        kernels read it with scalar loads and use it as mbcnt operand / exec mask directly   0.125  B / entry
+// i.e. 5.625 B per non-zero.  A row that is empty inside a tile but lies between two non-empty rows carries one marker
+// entry (flag set, value 0).  chunk_row0[] gives each chunk the local row of the entry preceding it, so any wave can
+// start at any chunk.
 //
 // Both products stream every tile once, coalesced, and keep the vector side of the product in LDS:
-//   forward: the x tile (TC doubles, 128 KB) is staged in LDS, row sums are accumulated in LDS (RB doubles);
+//   forward: the x tile (TC doubles, 32 KB) is staged in LDS once for up to FWD_GROUP_MAX row blocks (a "super block"),
+//            whose row sums are accumulated in LDS (4 x RB doubles, 64 KB);
 //   adjoint: the u rows of the block are staged in LDS, the column sums live in LDS (TC doubles) and are
 //            written once.
-// Row membership is recovered from the ROWSTART bits with ballot + mbcnt prefix counts; short row segments are
+// Row membership comes from the row-start masks with mbcnt prefix counts; short row segments are
 // summed inside a lane, the segment tails are merged across lanes with one segmented wave reduction per chunk.
 #include "common.h"
 #include <algorithm>
@@ -30,9 +33,21 @@ thread_local std::string g_last_error;
 
 size_t TiledMatrix::device_bytes() const
 {
-    return codes.bytes() + vals.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
+    return slots.bytes() + rowmask.bytes() + vals.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
            fwd_order.bytes() + adj_order.bytes() + fwd_partial.bytes() + adj_partial.bytes() + adj_nslots.bytes() +
            adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes() + dense.bytes() + dense_partial.bytes();
+}
+
+void TiledMatrix::release_storage()
+{
+    slots.release(); rowmask.release(); vals.release(); chunk_row0.release(); tiles.release(); fwd.release(); adj.release();
+    fwd_order.release(); adj_order.release(); fwd_partial.release(); adj_partial.release();
+    fwd_nslots.release(); fwd_pbase.release(); adj_nslots.release(); adj_pbase.release();
+    dense.release(); dense_partial.release();
+    h_tiles.clear(); h_fwd.clear(); h_adj.clear();
+    is_dense = false;
+    n_entries = cap_entries = 0;
+    valid = false;
 }
 
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s)
@@ -114,12 +129,28 @@ __global__ void k_tile_scan(const int32_t *__restrict__ pos, int nr, int ntc, in
     if (threadIdx.x == 0) { first_ne[t] = (l >= 0) ? f : -1; last_ne[t] = l; }
 }
 
+// One entry into the three streams (the destination range was zeroed: bits are OR-ed in, neighbours belong to other threads).
+__device__ __forceinline__ void put_entry(uint32_t *__restrict__ slots, unsigned long long *__restrict__ rowmask,
+                                          float *__restrict__ vals, int64_t e, uint32_t slot, bool rowstart, float v)
+{
+    const int64_t chunk = e >> 9;
+    const int i = (int)(e & (CHUNK - 1)), lane = i >> 3, k = i & 7;
+    vals[e] = v;
+    if (slot) {
+        uint32_t *w = slots + chunk * SLOT_WORDS + lane * 3;
+        const int bit = 12 * k, wi = bit >> 5, sh = bit & 31;
+        atomicOr(w + wi, slot << sh);
+        if (sh > 20) atomicOr(w + wi + 1, slot >> (32 - sh));
+    }
+    if (rowstart) atomicOr(rowmask + chunk * MASK_WORDS + k, 1ull << lane);
+}
+
 // Scatter the entries of one row block into their tiles.  grid = (ceil(maxlen/256), nr).
 __global__ void k_tile_scatter(const int32_t *__restrict__ cols, const float *__restrict__ vals,
                                const int32_t *__restrict__ nel, const int64_t *__restrict__ rowoff, int ntc, int TC, int nr,
                                const int32_t *__restrict__ pos, const int32_t *__restrict__ segoff,
-                               const int64_t *__restrict__ tile_off, uint16_t *__restrict__ codes,
-                               float *__restrict__ ovals)
+                               const int64_t *__restrict__ tile_off, uint32_t *__restrict__ slots,
+                               unsigned long long *__restrict__ rowmask, float *__restrict__ ovals)
 {
     int r = blockIdx.y;
     int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,26 +160,21 @@ __global__ void k_tile_scatter(const int32_t *__restrict__ cols, const float *__
     int t = c / TC;
     int p0 = pos[(int64_t)r * (ntc + 1) + t];
     int64_t dst = tile_off[t] + segoff[(int64_t)t * (nr + 1) + r] + (j - p0);
-    codes[dst] = (uint16_t)(col_slot(c - t * TC) | (j == p0 ? ROWSTART : 0));
-    ovals[dst] = vals[src];
+    put_entry(slots, rowmask, ovals, dst, (uint32_t)col_slot(c - t * TC), j == p0, vals[src]);
 }
 
 // Markers for empty rows strictly between the first and last non-empty row of a tile.  grid = (ntc), block 256.
 __global__ void k_tile_markers(const int32_t *__restrict__ pos, int nr, int ntc, const int32_t *__restrict__ segoff,
                                const int32_t *__restrict__ first_ne, const int32_t *__restrict__ last_ne,
-                               const int64_t *__restrict__ tile_off, uint16_t *__restrict__ codes,
-                               float *__restrict__ ovals)
+                               const int64_t *__restrict__ tile_off, uint32_t *__restrict__ slots,
+                               unsigned long long *__restrict__ rowmask, float *__restrict__ ovals)
 {
     int t = blockIdx.x;
     int f = first_ne[t], l = last_ne[t];
     if (f < 0) return;
     for (int r = f + 1 + threadIdx.x; r < l; r += blockDim.x) {
         int cnt = pos[(int64_t)r * (ntc + 1) + t + 1] - pos[(int64_t)r * (ntc + 1) + t];
-        if (cnt == 0) {
-            int64_t dst = tile_off[t] + segoff[(int64_t)t * (nr + 1) + r];
-            codes[dst] = ROWSTART;
-            ovals[dst] = 0.0f;
-        }
+        if (cnt == 0) put_entry(slots, rowmask, ovals, tile_off[t] + segoff[(int64_t)t * (nr + 1) + r], 0u, true, 0.0f);
     }
 }
 
@@ -272,6 +298,14 @@ __global__ __launch_bounds__(DN_THREADS) void k_dense_adj(const float *__restric
     for (int k = 0; k < nmine; ++k) y[c0 + k] += acc[k];
 }
 
+__global__ void k_dense_scale_rows(float *__restrict__ A, int64_t ld, int64_t nrows, int64_t ncols, const float *__restrict__ scale)
+{
+    for (int64_t r = blockIdx.y; r < nrows; r += gridDim.y) {
+        const float f = scale[r];
+        for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * blockDim.x) A[r * ld + c] *= f;
+    }
+}
+
 int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 {
     TiledMatrix &m = *ctx->target;
@@ -310,9 +344,11 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
     int64_t markers = std::min<int64_t>((int64_t)nrows * m.ntc, (nnz_upper / 2 + 1) * (int64_t)m.RB);
     int64_t cap = nnz_upper + markers + (int64_t)m.nrb * m.ntc * CHUNK + CHUNK;
     cap = (cap + CHUNK - 1) / CHUNK * CHUNK;
-    TFX_TRY(m.codes.alloc((size_t)cap));
     TFX_TRY(m.vals.alloc((size_t)cap));
+    TFX_TRY(m.slots.alloc((size_t)(cap / CHUNK) * SLOT_WORDS));
+    TFX_TRY(m.rowmask.alloc((size_t)(cap / CHUNK) * MASK_WORDS));
     TFX_TRY(m.chunk_row0.alloc((size_t)(cap / CHUNK)));
+    m.cap_entries = cap;
     m.n_entries = 0;
     m.h_tiles.clear();
     return 0;
@@ -320,6 +356,7 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 
 // Appends the tiles of one row block.  Row r of the block has d_nel[r] entries starting at d_cols/d_vals +
 // d_rowoff[r] (columns ascending, 0-based local); maxlen >= max d_nel.  row_begin must be a multiple of RB, nr <= RB.
+// Everything is queued on the ctx stream; the inputs may be reused by work queued on that stream afterwards.
 int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int32_t *d_cols, const float *d_vals,
                        const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen)
 {
@@ -330,32 +367,31 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
         return fail(TFX_E_ARG, "matrix_append_rows: rows [%lld, +%d) not aligned to row block %d", (long long)row_begin, nr, m.RB);
     int rb = (int)(row_begin / m.RB);
     int ntc = m.ntc;
-    DBuf<int32_t> pos, segoff, first_ne, last_ne, tile_nch;
-    DBuf<int64_t> tile_off;
-    TFX_TRY(pos.alloc((size_t)nr * (ntc + 1)));
-    TFX_TRY(segoff.alloc((size_t)ntc * (nr + 1)));
-    TFX_TRY(first_ne.alloc(ntc));
-    TFX_TRY(last_ne.alloc(ntc));
-    TFX_TRY(tile_nch.alloc(ntc));
-    TFX_TRY(tile_off.alloc(ntc));
-    hipLaunchKernelGGL(k_tile_pos, dim3(nr), dim3(256), 0, s, d_cols, d_nel, d_rowoff, nr, ntc, m.TC, pos.p);
-    hipLaunchKernelGGL(k_tile_scan, dim3(ntc), dim3(256), (size_t)(nr + 1) * sizeof(int32_t), s, pos.p, nr, ntc,
-                       segoff.p, first_ne.p, last_ne.p);
+    // scratch of the conversion lives in the ctx (no allocation per row block once it has grown to size)
+    tfx_ctx::AppendScratch &sc = ctx->append;
+    TFX_TRY(sc.pos.ensure((size_t)nr * (ntc + 1)));
+    TFX_TRY(sc.segoff.ensure((size_t)ntc * (nr + 1)));
+    TFX_TRY(sc.first_ne.ensure(ntc));
+    TFX_TRY(sc.last_ne.ensure(ntc));
+    TFX_TRY(sc.tile_nch.ensure(ntc));
+    TFX_TRY(sc.tile_off.ensure(ntc));
+    hipLaunchKernelGGL(k_tile_pos, dim3(nr), dim3(256), 0, s, d_cols, d_nel, d_rowoff, nr, ntc, m.TC, sc.pos.p);
+    hipLaunchKernelGGL(k_tile_scan, dim3(ntc), dim3(256), (size_t)(nr + 1) * sizeof(int32_t), s, sc.pos.p, nr, ntc,
+                       sc.segoff.p, sc.first_ne.p, sc.last_ne.p);
     TFX_HIP(hipGetLastError());
     // tile totals -> host
-    std::vector<int32_t> h_segoff_last(ntc), h_first(ntc);
-    TFX_HIP(hipMemcpy2DAsync(h_segoff_last.data(), sizeof(int32_t), segoff.p + nr, (size_t)(nr + 1) * sizeof(int32_t),
+    sc.h_segoff_last.resize(ntc);
+    TFX_HIP(hipMemcpy2DAsync(sc.h_segoff_last.data(), sizeof(int32_t), sc.segoff.p + nr, (size_t)(nr + 1) * sizeof(int32_t),
                              sizeof(int32_t), ntc, hipMemcpyDeviceToHost, s));
     TFX_HIP(hipStreamSynchronize(s));
-    std::vector<int64_t> h_off(ntc);
-    std::vector<int32_t> h_nch(ntc);
+    sc.h_off.resize(ntc);
+    sc.h_nch.resize(ntc);
     int64_t cur = m.n_entries;
-    int64_t nnz_block = 0;
     for (int t = 0; t < ntc; ++t) {
-        int32_t cnt = h_segoff_last[t];
+        int32_t cnt = sc.h_segoff_last[t];
         int32_t nch = (cnt + CHUNK - 1) / CHUNK;
-        h_off[t] = cur;
-        h_nch[t] = nch;
+        sc.h_off[t] = cur;
+        sc.h_nch[t] = nch;
         if (cnt > 0) {
             TileMeta tm;
             tm.off = cur;
@@ -366,43 +402,50 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
             m.h_tiles.push_back(tm);
         }
         cur += (int64_t)nch * CHUNK;
-        nnz_block += cnt;
     }
-    if ((size_t)cur > m.codes.n)
-        return fail(TFX_E_STATE, "tiled matrix capacity exceeded (%lld > %zu entries)", (long long)cur, m.codes.n);
-    // zero the destination range (padding: code 0 / value 0)
-    TFX_HIP(hipMemsetAsync(m.codes.p + m.n_entries, 0, (size_t)(cur - m.n_entries) * sizeof(uint16_t), s));
+    if (cur > m.cap_entries)
+        return fail(TFX_E_STATE, "tiled matrix capacity exceeded (%lld > %lld entries)", (long long)cur, (long long)m.cap_entries);
+    // zero the destination range (padding: slot 0 / no flag / value 0; the scatter ORs its bits in)
+    const int64_t c0 = m.n_entries / CHUNK, c1 = cur / CHUNK;
     TFX_HIP(hipMemsetAsync(m.vals.p + m.n_entries, 0, (size_t)(cur - m.n_entries) * sizeof(float), s));
-    TFX_HIP(hipMemcpyAsync(tile_off.p, h_off.data(), ntc * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    TFX_HIP(hipMemcpyAsync(tile_nch.p, h_nch.data(), ntc * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    TFX_HIP(hipMemsetAsync(m.slots.p + c0 * SLOT_WORDS, 0, (size_t)(c1 - c0) * SLOT_WORDS * sizeof(uint32_t), s));
+    TFX_HIP(hipMemsetAsync(m.rowmask.p + c0 * MASK_WORDS, 0, (size_t)(c1 - c0) * MASK_WORDS * sizeof(uint64_t), s));
+    TFX_HIP(hipMemcpyAsync(sc.tile_off.p, sc.h_off.data(), ntc * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    TFX_HIP(hipMemcpyAsync(sc.tile_nch.p, sc.h_nch.data(), ntc * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    unsigned long long *mask = reinterpret_cast<unsigned long long *>(m.rowmask.p);
     if (maxlen > 0)
         hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((maxlen + 255) / 256), nr), dim3(256), 0, s, d_cols, d_vals,
-                           d_nel, d_rowoff, ntc, m.TC, nr, pos.p, segoff.p, tile_off.p, m.codes.p, m.vals.p);
-    hipLaunchKernelGGL(k_tile_markers, dim3(ntc), dim3(256), 0, s, pos.p, nr, ntc, segoff.p, first_ne.p, last_ne.p,
-                       tile_off.p, m.codes.p, m.vals.p);
-    hipLaunchKernelGGL(k_chunk_row0, dim3(ntc), dim3(256), 0, s, nr, segoff.p, first_ne.p, tile_off.p, tile_nch.p,
+                           d_nel, d_rowoff, ntc, m.TC, nr, sc.pos.p, sc.segoff.p, sc.tile_off.p, m.slots.p, mask, m.vals.p);
+    hipLaunchKernelGGL(k_tile_markers, dim3(ntc), dim3(256), 0, s, sc.pos.p, nr, ntc, sc.segoff.p, sc.first_ne.p, sc.last_ne.p,
+                       sc.tile_off.p, m.slots.p, mask, m.vals.p);
+    hipLaunchKernelGGL(k_chunk_row0, dim3(ntc), dim3(256), 0, s, nr, sc.segoff.p, sc.first_ne.p, sc.tile_off.p, sc.tile_nch.p,
                        m.chunk_row0.p);
     TFX_HIP(hipGetLastError());
-    TFX_HIP(hipStreamSynchronize(s));    // temporaries are freed on return
+    TFX_HIP(hipStreamSynchronize(s));    // the host-side staging vectors above are reused by the next call
     m.n_entries = cur;
-    (void)nnz_block;
     return 0;
 }
 
-// Cuts the tile list into work items.  Forward: every item owns one partial-sum tile (pidx) of RB doubles, the
-// items of row block rb are pbase[rb] .. pbase[rb]+nslots[rb]-1.  Adjoint: slot 0 of a column tile adds straight
-// into y, slots >= 1 own partial tiles pbase[t] .. pbase[t]+nslots[t]-2 of TC doubles.
-static void build_items(const std::vector<TileMeta> &tiles, bool forward, int64_t target, std::vector<WorkItem> &items,
+// Cuts the tile list into work items.  Forward: the key is the super block (fwd_group consecutive row blocks that share the
+// staged x tile); inside a super block the tiles are ordered by (column tile, row block); every item owns one partial-sum
+// tile (pidx) of fwd_group * RB doubles, the items of super block sb are pbase[sb] .. pbase[sb]+nslots[sb]-1.
+// Adjoint: the key is the column tile; slot 0 of a column tile adds straight into y, slots >= 1 own partial tiles
+// pbase[t] .. pbase[t]+nslots[t]-2 of TC doubles.
+static void build_items(const std::vector<TileMeta> &tiles, bool forward, int group, int64_t target, std::vector<WorkItem> &items,
                         std::vector<int32_t> &order, int &npartial, std::vector<int32_t> &nslots,
                         std::vector<int32_t> &pbase, int nkeys)
 {
+    auto key_of = [&](const TileMeta &t) { return forward ? t.rb / group : t.t; };
     std::vector<int32_t> idx(tiles.size());
     std::iota(idx.begin(), idx.end(), 0);
     std::sort(idx.begin(), idx.end(), [&](int a, int b) {
-        int ka = forward ? tiles[a].rb : tiles[a].t, kb = forward ? tiles[b].rb : tiles[b].t;
+        const int ka = key_of(tiles[a]), kb = key_of(tiles[b]);
         if (ka != kb) return ka < kb;
-        int sa = forward ? tiles[a].t : tiles[a].rb, sb = forward ? tiles[b].t : tiles[b].rb;
-        return sa < sb;
+        if (forward) {
+            if (tiles[a].t != tiles[b].t) return tiles[a].t < tiles[b].t;
+            return tiles[a].rb < tiles[b].rb;
+        }
+        return tiles[a].rb < tiles[b].rb;
     });
     order = idx;
     items.clear();
@@ -412,9 +455,9 @@ static void build_items(const std::vector<TileMeta> &tiles, bool forward, int64_
     std::vector<int64_t> item_sz;
     size_t i = 0;
     while (i < idx.size()) {
-        int key = forward ? tiles[idx[i]].rb : tiles[idx[i]].t;
+        int key = key_of(tiles[idx[i]]);
         size_t j = i;
-        while (j < idx.size() && (forward ? tiles[idx[j]].rb : tiles[idx[j]].t) == key) ++j;
+        while (j < idx.size() && key_of(tiles[idx[j]]) == key) ++j;
         // split [i, j) into runs of about `target` entries
         int slot = 0;
         size_t b = i;
@@ -487,12 +530,21 @@ int matrix_finish(tfx_ctx *ctx)
     TFX_TRY(m.tiles.alloc(std::max<size_t>(1, m.h_tiles.size())));
     if (!m.h_tiles.empty())
         TFX_HIP(hipMemcpyAsync(m.tiles.p, m.h_tiles.data(), m.h_tiles.size() * sizeof(TileMeta), hipMemcpyHostToDevice, s));
-    // about 8 work items per CU, but never finer than 16 chunks
-    int64_t target = std::max<int64_t>((int64_t)16 * CHUNK, m.n_entries / std::max(1, ctx->num_cu * 8));
+    // about 16 work items per CU (measured at the headline size: 8 -> 38.1, 16 -> 37.3, 32 -> 38.0 ms per iteration), never finer than 16 chunks
+    int64_t target = std::max<int64_t>((int64_t)16 * CHUNK, m.n_entries / std::max(1, ctx->num_cu * ctx->items_per_cu));
+    // Forward super blocks: one staged x tile serves fwd_group row blocks.  Worth it when the matrix is tall (full-height row
+    // blocks, several of them) and big enough that a super block still splits into many items; small systems keep group 1.
+    m.fwd_group = 1;
+    if (m.RB == RB_MAX && m.nrb >= 2 && m.n_entries >= (int64_t)64 * target) {
+        m.fwd_group = FWD_GROUP_MAX;
+        while (m.fwd_group > m.nrb) m.fwd_group /= 2;
+    }
+    if (ctx->fwd_group_override > 0) m.fwd_group = std::max(1, std::min(ctx->fwd_group_override, FWD_GROUP_MAX));
+    const int nsb = (m.nrb + m.fwd_group - 1) / m.fwd_group;
     std::vector<int32_t> fo, ao, fns, ans, fpb, apb;
     int nfp = 0, nap = 0;
-    build_items(m.h_tiles, true, target, m.h_fwd, fo, nfp, fns, fpb, m.nrb);
-    build_items(m.h_tiles, false, target, m.h_adj, ao, nap, ans, apb, m.ntc);
+    build_items(m.h_tiles, true, m.fwd_group, target, m.h_fwd, fo, nfp, fns, fpb, nsb);
+    build_items(m.h_tiles, false, 1, target, m.h_adj, ao, nap, ans, apb, m.ntc);
     TFX_TRY(m.fwd.alloc(std::max<size_t>(1, m.h_fwd.size())));
     TFX_TRY(m.adj.alloc(std::max<size_t>(1, m.h_adj.size())));
     TFX_TRY(m.fwd_order.alloc(std::max<size_t>(1, fo.size())));
@@ -511,7 +563,7 @@ int matrix_finish(tfx_ctx *ctx)
     TFX_HIP(hipMemcpyAsync(m.adj_pbase.p, apb.data(), apb.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
     TFX_HIP(hipMemcpyAsync(m.fwd_nslots.p, fns.data(), fns.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
     TFX_HIP(hipMemcpyAsync(m.fwd_pbase.p, fpb.data(), fpb.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    TFX_TRY(m.fwd_partial.alloc(std::max<size_t>(1, (size_t)nfp * m.RB)));
+    TFX_TRY(m.fwd_partial.alloc(std::max<size_t>(1, (size_t)nfp * m.fwd_group * m.RB)));
     TFX_TRY(m.adj_partial.alloc(std::max<size_t>(1, (size_t)nap * m.TC)));
     TFX_HIP(hipStreamSynchronize(s));
     m.adj_has_partials = nap > 0;
@@ -524,28 +576,52 @@ int matrix_finish(tfx_ctx *ctx)
 // The two matrix kernels
 // ------------------------------------------------------------------------------------------------------------
 constexpr int SPMV_THREADS = 1024;
-constexpr int SPMV_WAVES = SPMV_THREADS / 64;
 
 struct ChunkRegs {
-    uint32_t w[4];    // 8 codes
+    uint32_t w[3];    // 8 packed 12-bit slots
     float v[8];
 };
 
-__device__ __forceinline__ void load_chunk(const uint16_t *__restrict__ codes, const float *__restrict__ vals,
-                                           int64_t base, ChunkRegs &c)
+__device__ __forceinline__ void load_chunk(const uint32_t *__restrict__ slots, const float *__restrict__ vals,
+                                           int64_t chunk, int lane, ChunkRegs &c)
 {
     // the matrix is streamed exactly once per product: non-temporal loads keep it from displacing the x / u tiles in L2
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 cw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(codes + base));
-    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vals + base));
-    const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vals + base + 4));
-    c.w[0] = cw.x; c.w[1] = cw.y; c.w[2] = cw.z; c.w[3] = cw.w;
+    const uint32_t *sp = slots + chunk * SLOT_WORDS + lane * 3;       // three dword loads, merged into one dwordx3 by the compiler
+    c.w[0] = __builtin_nontemporal_load(sp);
+    c.w[1] = __builtin_nontemporal_load(sp + 1);
+    c.w[2] = __builtin_nontemporal_load(sp + 2);
+    const float *vp = vals + chunk * CHUNK + lane * 8;
+    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vp));
+    const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vp + 4));
     c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w;
     c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w;
 }
 
-__device__ __forceinline__ uint32_t code_of(const ChunkRegs &c, int k) { return (c.w[k >> 1] >> ((k & 1) * 16)) & 0xffffu; }
+// slot k of the lane's eight (12 bits each in three dwords)
+template <int K>
+__device__ __forceinline__ uint32_t slot_of(const ChunkRegs &c)
+{
+    constexpr int bit = 12 * K, wi = bit >> 5, sh = bit & 31;
+    if constexpr (sh <= 20) return (c.w[wi] >> sh) & 0xfffu;
+    else return ((c.w[wi] >> sh) | (c.w[wi + 1] << (32 - sh))) & 0xfffu;
+}
+
+// The eight row-start masks of a chunk (wave-uniform address -> scalar loads), and the number of row starts in all lanes
+// below this one (all 8 entries of those lanes): mbcnt straight on the stored masks, no ballots.
+struct ChunkMasks { uint64_t m[8]; };
+__device__ __forceinline__ int load_masks(const uint64_t *__restrict__ rowmask, int64_t chunk, ChunkMasks &mk)
+{
+    const uint64_t *p = rowmask + chunk * MASK_WORDS;
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mk.m[k] = p[k];
+        acc = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk.m[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk.m[k], acc));
+    }
+    return acc;
+}
+#define ROWSTART_K(mk, k) __builtin_amdgcn_inverse_ballot_w64((mk).m[k])
 
 // ---- segmented reduction helpers (DPP: data moves between lanes on the VALU, not through the LDS crossbar)
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -565,63 +641,119 @@ __device__ __forceinline__ void seg_step(double &sum, int cur)
     if (oc == cur) sum += __hiloint2double(hi, lo);
 }
 
-// number of ROWSTART flags in all lanes below this one (all 8 entries of those lanes)
-__device__ __forceinline__ int flags_before_lane(const ChunkRegs &c, bool &any)
+// A work item walks its tiles in groups of up to FWD_GROUP_MAX tiles that share the LDS-staged vector(s): forward - the tiles of
+// one column tile inside the item's super block (one staged x tile, row sums of all row blocks of the super block in LDS);
+// adjoint - the tiles of consecutive row blocks inside one aligned super block (their u rows staged together).  The waves of the
+// workgroup deal out the chunks of the whole group round-robin, so a barrier and a partly filled last round are paid once per
+// group, not once per tile.  Everything here is wave-uniform (scalar registers).
+struct TileGroup {
+    int ng;                          // tiles in the group
+    int total;                       // chunks in the group
+    int pre[FWD_GROUP_MAX];          // first group-chunk of tile j (INT_MAX beyond ng)
+    int64_t cbase[FWD_GROUP_MAX];    // first chunk of tile j in the streams
+    int lrb[FWD_GROUP_MAX];          // row block of tile j relative to the super block
+};
+
+template <bool FORWARD>
+__device__ __forceinline__ void make_group(const WorkItem &it, const int32_t *__restrict__ order, const TileMeta *__restrict__ tiles,
+                                           int ti, int GROUP, TileGroup &g, TileMeta &first)
 {
-    int acc = 0;
-    unsigned long long all = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        unsigned long long mk = __ballot((code_of(c, k) & ROWSTART) != 0);
-        all |= mk;
-        acc = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, acc));
+    first = tiles[order[ti]];
+    const int sb = first.rb / GROUP;
+    g.ng = 1;
+    g.pre[0] = 0;
+    g.cbase[0] = first.off / CHUNK;
+    g.lrb[0] = first.rb - sb * GROUP;
+    int run = first.nchunks;
+    if (it.ce >= 0) {                  // a heavy tile shared by several items: this one takes its chunks [cb, ce)
+        g.cbase[0] += it.cb;
+        run = it.ce - it.cb;
     }
-    any = all != 0;
-    return acc;
+#pragma unroll
+    for (int j = 1; j < FWD_GROUP_MAX; ++j) {
+        g.pre[j] = 0x7fffffff;
+        g.cbase[j] = 0;
+        g.lrb[j] = 0;
+        if (g.ng == j && ti + j < it.end && it.ce < 0) {
+            const TileMeta tm = tiles[order[ti + j]];
+            const bool same = FORWARD ? (tm.t == first.t) : (tm.rb / GROUP == sb);
+            if (same) {
+                g.ng = j + 1;
+                g.pre[j] = run;
+                g.cbase[j] = tm.off / CHUNK;
+                g.lrb[j] = tm.rb - sb * GROUP;
+                run += tm.nchunks;
+            }
+        }
+    }
+    g.total = run;
 }
 
-// forward: one workgroup = a run of tiles of one row block; partial[slot][row] = sum over the run.
-__global__ __launch_bounds__(SPMV_THREADS) void k_spmv_fwd(const WorkItem *__restrict__ items,
-                                                             const int32_t *__restrict__ order,
-                                                             const TileMeta *__restrict__ tiles,
-                                                             const uint16_t *__restrict__ codes,
-                                                             const float *__restrict__ vals,
-                                                             const int32_t *__restrict__ chunk_row0,
-                                                             const double *__restrict__ x, double *__restrict__ partial,
-                                                             int64_t ncols, int TC, int RB)
+// group-chunk q -> chunk index in the streams and the tile's row block inside the super block
+__device__ __forceinline__ int64_t locate_chunk(const TileGroup &g, int q, int &lrb)
+{
+    int64_t c = g.cbase[0] + q;
+    lrb = g.lrb[0];
+#pragma unroll
+    for (int j = 1; j < FWD_GROUP_MAX; ++j)
+        if (q >= g.pre[j]) { c = g.cbase[j] + (q - g.pre[j]); lrb = g.lrb[j]; }
+    return c;
+}
+
+// forward: one workgroup = a run of tiles of one super block (GROUP row blocks), ordered by column tile so that a staged x tile
+// serves all row blocks of the group; partial[item][row of the super block] = sum over the run.
+// WAVES = 16: the product kernel; WAVES = 1: the deterministic debug variant (a single wave issues its LDS atomics in program
+// order, and no other wave touches the workgroup's sums).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_spmv_fwd(const WorkItem *__restrict__ items,
+                                                           const int32_t *__restrict__ order,
+                                                           const TileMeta *__restrict__ tiles,
+                                                           const uint32_t *__restrict__ slots,
+                                                           const uint64_t *__restrict__ rowmask,
+                                                           const float *__restrict__ vals,
+                                                           const int32_t *__restrict__ chunk_row0,
+                                                           const double *__restrict__ x, double *__restrict__ partial,
+                                                           int64_t ncols, int TC, int RB, int GROUP)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int THREADS = WAVES * 64;
     double *xs = lds;          // TC
-    double *outs = lds + TC;   // RB
+    double *outs = lds + TC;   // GROUP * RB
     const WorkItem it = items[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < RB; i += SPMV_THREADS) outs[i] = 0.0;
-    for (int ti = it.begin; ti < it.end; ++ti) {
-        const TileMeta tm = tiles[order[ti]];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nout = GROUP * RB;
+    for (int i = tid; i < nout; i += THREADS) outs[i] = 0.0;
+    int ti = it.begin;
+    while (ti < it.end) {
+        TileGroup g;
+        TileMeta tm;
+        make_group<true>(it, order, tiles, ti, GROUP, g, tm);
+        ti += g.ng;
         __syncthreads();
-        const int64_t col0 = (int64_t)tm.t * TC;
-        const int ncol = (int)min((int64_t)TC, ncols - col0);
-        for (int i = tid; i < TC; i += SPMV_THREADS) xs[col_slot(i)] = (i < ncol) ? x[col0 + i] : 0.0;
+        {
+            const int64_t col0 = (int64_t)tm.t * TC;
+            const int ncol = (int)min((int64_t)TC, ncols - col0);
+            for (int i = tid; i < TC; i += THREADS) xs[col_slot(i)] = (i < ncol) ? x[col0 + i] : 0.0;
+        }
         __syncthreads();
-        const int64_t cbase = tm.off / CHUNK;
-        const int c_end = it.ce < 0 ? tm.nchunks : it.ce;
-        for (int c = it.cb + wave; c < c_end; c += SPMV_WAVES) {
+        for (int q = wave; q < g.total; q += WAVES) {
+            int lrb;
+            const int64_t ch = locate_chunk(g, q, lrb);
+            double *o = outs + lrb * RB;
             ChunkRegs cr;
-            load_chunk(codes, vals, tm.off + (int64_t)c * CHUNK + lane * 8, cr);
-            int cur = chunk_row0[cbase + c];
-            bool any;
-            cur += flags_before_lane(cr, any);
+            ChunkMasks mk;
+            load_chunk(slots, vals, ch, lane, cr);
+            int cur = chunk_row0[ch] + load_masks(rowmask, ch, mk);
             double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t code = code_of(cr, k);
-                if (code & ROWSTART) {
-                    if (cur >= 0 && acc != 0.0) atomicAdd(&outs[cur], acc);
-                    cur += 1;
-                    acc = 0.0;
-                }
-                acc = fma((double)cr.v[k], xs[code & COLMASK], acc);
-            }
+#define FWD_STEP(K)                                                          \
+            if (ROWSTART_K(mk, K)) {                                         \
+                if (cur >= 0 && acc != 0.0) atomicAdd(&o[cur], acc);         \
+                cur += 1;                                                    \
+                acc = 0.0;                                                   \
+            }                                                                \
+            acc = fma((double)cr.v[K], xs[slot_of<K>(cr)], acc);
+            FWD_STEP(0) FWD_STEP(1) FWD_STEP(2) FWD_STEP(3) FWD_STEP(4) FWD_STEP(5) FWD_STEP(6) FWD_STEP(7)
+#undef FWD_STEP
             // merge the tails of lanes that end on the same row (equal rows are contiguous lanes): the first lane of every run
             // gets the run's total.  Inside a 16-lane DPP row: 4 shift-and-add steps on the VALU (row_shl, no LDS crossbar);
             // across the four rows: the row heads are read as scalars and carried backwards.
@@ -646,21 +778,21 @@ __global__ __launch_bounds__(SPMV_THREADS) void k_spmv_fwd(const WorkItem *__res
                 if (cur == tc) sum += carry;
             }
             const int pcur = __builtin_amdgcn_update_dpp(-3, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            if (pcur != cur && cur >= 0 && sum != 0.0) atomicAdd(&outs[cur], sum);
+            if (pcur != cur && cur >= 0 && sum != 0.0) atomicAdd(&o[cur], sum);
         }
     }
     __syncthreads();
-    double *dst = partial + (int64_t)it.pidx * RB;
-    for (int i = tid; i < RB; i += SPMV_THREADS) dst[i] = outs[i];
+    double *dst = partial + (int64_t)it.pidx * nout;
+    for (int i = tid; i < nout; i += THREADS) dst[i] = outs[i];
 }
 
-// b[row] = (add ? b[row] : 0) + sum over the partial tiles of the row's block (fixed order: deterministic).
+// b[row] = (add ? b[row] : 0) + sum over the partial tiles of the row's super block (fixed order: deterministic).
 // A block takes FR_ROWS rows; its FR_GROUPS thread groups each add every FR_GROUPS-th partial tile (small matrices have
 // hundreds of partial tiles per row block: a single sequential chain per row would be latency-bound), then the group sums are
-// added in group order.
+// added in group order.  SB = rows per super block = fwd_group * RB.
 constexpr int FR_ROWS = 16, FR_GROUPS = 16;
 __global__ __launch_bounds__(FR_ROWS * FR_GROUPS) void k_fwd_reduce(const double *__restrict__ partial, const int32_t *__restrict__ nslots,
-                                                                    const int32_t *__restrict__ pbase, int RB, int64_t nrows,
+                                                                    const int32_t *__restrict__ pbase, int SB, int64_t nrows,
                                                                     double *__restrict__ b, int add)
 {
     __shared__ double part[FR_GROUPS][FR_ROWS];
@@ -668,9 +800,9 @@ __global__ __launch_bounds__(FR_ROWS * FR_GROUPS) void k_fwd_reduce(const double
     const int64_t r = (int64_t)blockIdx.x * FR_ROWS + lr_in;
     double s = 0.0;
     if (r < nrows) {
-        const int rb = (int)(r / RB), lr = (int)(r - (int64_t)rb * RB);
-        const int ns = nslots[rb], p0 = pbase[rb];
-        for (int k = g; k < ns; k += FR_GROUPS) s += partial[(int64_t)(p0 + k) * RB + lr];
+        const int sb = (int)(r / SB), lr = (int)(r - (int64_t)sb * SB);
+        const int ns = nslots[sb], p0 = pbase[sb];
+        for (int k = g; k < ns; k += FR_GROUPS) s += partial[(int64_t)(p0 + k) * SB + lr];
     }
     part[g][lr_in] = s;
     __syncthreads();
@@ -683,58 +815,94 @@ __global__ __launch_bounds__(FR_ROWS * FR_GROUPS) void k_fwd_reduce(const double
 }
 
 // adjoint: one workgroup = a run of tiles of one column tile; slot 0 adds into y, the others write partials.
-__global__ __launch_bounds__(SPMV_THREADS) void k_spmv_adj(const WorkItem *__restrict__ items,
-                                                             const int32_t *__restrict__ order,
-                                                             const TileMeta *__restrict__ tiles,
-                                                             const uint16_t *__restrict__ codes,
-                                                             const float *__restrict__ vals,
-                                                             const int32_t *__restrict__ chunk_row0,
-                                                             const double *__restrict__ u, double *__restrict__ y,
-                                                             double *__restrict__ partial, int64_t nrows, int64_t ncols,
-                                                             int TC, int RB)
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_spmv_adj(const WorkItem *__restrict__ items,
+                                                           const int32_t *__restrict__ order,
+                                                           const TileMeta *__restrict__ tiles,
+                                                           const uint32_t *__restrict__ slots,
+                                                           const uint64_t *__restrict__ rowmask,
+                                                           const float *__restrict__ vals,
+                                                           const int32_t *__restrict__ chunk_row0,
+                                                           const double *__restrict__ u, double *__restrict__ y,
+                                                           double *__restrict__ partial, int64_t nrows, int64_t ncols,
+                                                           int TC, int RB, int GROUP)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int THREADS = WAVES * 64;
     double *acc = lds;        // TC
-    double *us = lds + TC;    // RB
+    double *us = lds + TC;    // GROUP * RB
     const WorkItem it = items[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < TC; i += SPMV_THREADS) acc[i] = 0.0;
-    for (int ti = it.begin; ti < it.end; ++ti) {
-        const TileMeta tm = tiles[order[ti]];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < TC; i += THREADS) acc[i] = 0.0;
+    int ti = it.begin;
+    while (ti < it.end) {
+        TileGroup g;
+        TileMeta tm;
+        make_group<false>(it, order, tiles, ti, GROUP, g, tm);
+        ti += g.ng;
         __syncthreads();
-        const int64_t row0 = (int64_t)tm.rb * RB;
-        const int nrow = (int)min((int64_t)RB, nrows - row0);
-        for (int i = tid; i < RB; i += SPMV_THREADS) us[i] = (i < nrow) ? u[row0 + i] : 0.0;
-        __syncthreads();
-        const int64_t cbase = tm.off / CHUNK;
-        const int c_end = it.ce < 0 ? tm.nchunks : it.ce;
-        for (int c = it.cb + wave; c < c_end; c += SPMV_WAVES) {
-            ChunkRegs cr;
-            load_chunk(codes, vals, tm.off + (int64_t)c * CHUNK + lane * 8, cr);
-            int cur = chunk_row0[cbase + c];
-            bool any;
-            cur += flags_before_lane(cr, any);
-            double uval = us[max(cur, 0)];
+        {
+            // the u rows of the row blocks the group touches: [first tile's block, last tile's block] inside the super block
+            int last = g.lrb[0];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t code = code_of(cr, k);
-                if (code & ROWSTART) {
-                    cur += 1;
-                    uval = us[cur];
-                }
-                const float v = cr.v[k];
-                if (v != 0.0f) atomicAdd(&acc[code & COLMASK], (double)v * uval);
-            }
+            for (int j = 1; j < FWD_GROUP_MAX; ++j)
+                if (j < g.ng) last = g.lrb[j];
+            const int lo = g.lrb[0] * RB, hi = (last + 1) * RB;
+            const int64_t row0 = (int64_t)(tm.rb / GROUP) * GROUP * RB;
+            for (int i = lo + tid; i < hi; i += THREADS) us[i] = (row0 + i < nrows) ? u[row0 + i] : 0.0;
+        }
+        __syncthreads();
+        for (int q = wave; q < g.total; q += WAVES) {
+            int lrb;
+            const int64_t ch = locate_chunk(g, q, lrb);
+            const double *ub = us + lrb * RB;
+            ChunkRegs cr;
+            ChunkMasks mk;
+            load_chunk(slots, vals, ch, lane, cr);
+            int cur = chunk_row0[ch] + load_masks(rowmask, ch, mk);
+            double uval = ub[max(cur, 0)];
+#define ADJ_STEP(K)                                                                      \
+            if (ROWSTART_K(mk, K)) {                                                     \
+                cur += 1;                                                                \
+                uval = ub[cur];                                                          \
+            }                                                                            \
+            if (cr.v[K] != 0.0f) atomicAdd(&acc[slot_of<K>(cr)], (double)cr.v[K] * uval);
+            ADJ_STEP(0) ADJ_STEP(1) ADJ_STEP(2) ADJ_STEP(3) ADJ_STEP(4) ADJ_STEP(5) ADJ_STEP(6) ADJ_STEP(7)
+#undef ADJ_STEP
         }
     }
     __syncthreads();
     const int64_t col0 = (int64_t)it.key * TC;
     const int ncol = (int)min((int64_t)TC, ncols - col0);
     if (it.slot == 0) {
-        for (int i = tid; i < ncol; i += SPMV_THREADS) y[col0 + i] += acc[col_slot(i)];
+        for (int i = tid; i < ncol; i += THREADS) y[col0 + i] += acc[col_slot(i)];
     } else {
         double *dst = partial + (int64_t)it.pidx * TC;
-        for (int i = tid; i < TC; i += SPMV_THREADS) dst[i] = acc[col_slot(i)];
+        for (int i = tid; i < TC; i += THREADS) dst[i] = acc[col_slot(i)];
+    }
+}
+
+// vals[e] *= scale[row of e] for every stored entry: what read_sensitivity_kernel does to a row on reload
+// (sensitivity_gravmag.F90:834-843: the file holds the unscaled kernel, the matrix problem_weight * data_weight(row) times it).
+__global__ __launch_bounds__(256) void k_scale_rows(const TileMeta *__restrict__ tiles, int ntiles, const uint64_t *__restrict__ rowmask,
+                                                     float *__restrict__ vals, const int32_t *__restrict__ chunk_row0,
+                                                     const float *__restrict__ scale, int64_t nrows, int RB)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int ti = blockIdx.y; ti < ntiles; ti += gridDim.y) {
+        const TileMeta tm = tiles[ti];
+        const int64_t cbase = tm.off / CHUNK, row0 = (int64_t)tm.rb * RB;
+        for (int c = blockIdx.x * 4 + wave; c < tm.nchunks; c += gridDim.x * 4) {
+            ChunkMasks mk;
+            int cur = chunk_row0[cbase + c] + load_masks(rowmask, cbase + c, mk);
+            float *vp = vals + (cbase + c) * CHUNK + lane * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if ((mk.m[k] >> lane) & 1ull) cur += 1;
+                const int64_t r = row0 + max(cur, 0);
+                if (r < nrows) vp[k] = vp[k] * scale[r];
+            }
+        }
     }
 }
 
@@ -753,9 +921,13 @@ __global__ void k_adj_reduce(const double *__restrict__ partial, const int32_t *
     y[c] = s;
 }
 
-static int set_lds_limit(const void *fn, size_t bytes)
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: the bookkeeping lives in the ctx (one ctx = one device),
+// not in a process-wide static, so a second ctx on another device registers the kernels for itself.
+static int set_lds_limit(tfx_ctx *ctx, int which, const void *fn, size_t bytes)
 {
+    if (bytes <= ctx->lds_attr[which]) return 0;
     TFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->lds_attr[which] = bytes;
     return 0;
 }
 
@@ -817,18 +989,24 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
         return 0;
     }
     hipStream_t s = ctx->stream;
-    const size_t lds = (size_t)(m.TC + m.RB) * sizeof(double);
+    const int SB = m.fwd_group * m.RB;
+    const size_t lds = (size_t)(m.TC + SB) * sizeof(double);
     if (!m.h_fwd.empty()) {
-        static size_t lds_set = 0;
-        if (lds > lds_set) { TFX_TRY(set_lds_limit((const void *)k_spmv_fwd, lds)); lds_set = lds; }
         if (prof) prof_begin(ctx);
-        hipLaunchKernelGGL(k_spmv_fwd, dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, m.fwd.p, m.fwd_order.p,
-                           m.tiles.p, m.codes.p, m.vals.p, m.chunk_row0.p, d_x, m.fwd_partial.p, m.ncols, m.TC, m.RB);
+        if (ctx->deterministic) {
+            TFX_TRY(set_lds_limit(ctx, 2, (const void *)k_spmv_fwd<1>, lds));
+            hipLaunchKernelGGL(k_spmv_fwd<1>, dim3((unsigned)m.h_fwd.size()), dim3(64), lds, s, m.fwd.p, m.fwd_order.p, m.tiles.p,
+                               m.slots.p, m.rowmask.p, m.vals.p, m.chunk_row0.p, d_x, m.fwd_partial.p, m.ncols, m.TC, m.RB, m.fwd_group);
+        } else {
+            TFX_TRY(set_lds_limit(ctx, 0, (const void *)k_spmv_fwd<16>, lds));
+            hipLaunchKernelGGL(k_spmv_fwd<16>, dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, m.fwd.p, m.fwd_order.p, m.tiles.p,
+                               m.slots.p, m.rowmask.p, m.vals.p, m.chunk_row0.p, d_x, m.fwd_partial.p, m.ncols, m.TC, m.RB, m.fwd_group);
+        }
         if (prof) prof_end(ctx, 0);
         TFX_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(k_fwd_reduce, dim3((unsigned)((m.nrows + FR_ROWS - 1) / FR_ROWS)), dim3(FR_ROWS * FR_GROUPS), 0, s, m.fwd_partial.p,
-                       m.fwd_nslots.p, m.fwd_pbase.p, m.RB, m.nrows, d_b, add);
+                       m.fwd_nslots.p, m.fwd_pbase.p, SB, m.nrows, d_b, add);
     TFX_HIP(hipGetLastError());
     return 0;
 }
@@ -848,15 +1026,19 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
         return 0;
     }
     hipStream_t s = ctx->stream;
-    const size_t lds = (size_t)(m.TC + m.RB) * sizeof(double);
+    const size_t lds = (size_t)(m.TC + m.fwd_group * m.RB) * sizeof(double);
     if (!add) TFX_HIP(hipMemsetAsync(d_b, 0, (size_t)m.ncols * sizeof(double), s));
     if (!m.h_adj.empty()) {
-        static size_t lds_set = 0;
-        if (lds > lds_set) { TFX_TRY(set_lds_limit((const void *)k_spmv_adj, lds)); lds_set = lds; }
         if (prof) prof_begin(ctx);
-        hipLaunchKernelGGL(k_spmv_adj, dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, m.adj.p, m.adj_order.p,
-                           m.tiles.p, m.codes.p, m.vals.p, m.chunk_row0.p, d_x, d_b, m.adj_partial.p, m.nrows, m.ncols,
-                           m.TC, m.RB);
+        if (ctx->deterministic) {
+            TFX_TRY(set_lds_limit(ctx, 3, (const void *)k_spmv_adj<1>, lds));
+            hipLaunchKernelGGL(k_spmv_adj<1>, dim3((unsigned)m.h_adj.size()), dim3(64), lds, s, m.adj.p, m.adj_order.p, m.tiles.p,
+                               m.slots.p, m.rowmask.p, m.vals.p, m.chunk_row0.p, d_x, d_b, m.adj_partial.p, m.nrows, m.ncols, m.TC, m.RB, m.fwd_group);
+        } else {
+            TFX_TRY(set_lds_limit(ctx, 1, (const void *)k_spmv_adj<16>, lds));
+            hipLaunchKernelGGL(k_spmv_adj<16>, dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, m.adj.p, m.adj_order.p, m.tiles.p,
+                               m.slots.p, m.rowmask.p, m.vals.p, m.chunk_row0.p, d_x, d_b, m.adj_partial.p, m.nrows, m.ncols, m.TC, m.RB, m.fwd_group);
+        }
         if (prof) prof_end(ctx, 1);
         TFX_HIP(hipGetLastError());
         if (m.adj_has_partials)
@@ -864,6 +1046,26 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
                                m.adj_nslots.p, m.adj_pbase.p, m.TC, m.ncols, d_b);
         TFX_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+// rows of the selected matrix times a per-row factor (fp32 product of the stored value and the factor, like the reference's
+// sensit_compressed * real(problem_weight * data_weight, MATRIX_PRECISION), sensitivity_gravmag.F90:834-843)
+int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale)
+{
+    if (!m.valid) return fail(TFX_E_STATE, "scale_rows: no matrix");
+    hipStream_t s = ctx->stream;
+    if (m.is_dense) {
+        hipLaunchKernelGGL(k_dense_scale_rows, dim3(256, (unsigned)std::min<int64_t>(m.nrows, 65535)), dim3(256), 0, s, m.dense.p, m.ld,
+                           m.nrows, m.ncols, d_scale);
+        TFX_HIP(hipGetLastError());
+        return 0;
+    }
+    const int nt = (int)m.h_tiles.size();
+    if (nt == 0) return 0;
+    hipLaunchKernelGGL(k_scale_rows, dim3(8, (unsigned)std::min(nt, 32768)), dim3(256), 0, s, m.tiles.p, nt, m.rowmask.p, m.vals.p,
+                       m.chunk_row0.p, d_scale, m.nrows, m.RB);
+    TFX_HIP(hipGetLastError());
     return 0;
 }
 

@@ -4,8 +4,10 @@ The reference's model-cell domain decomposition (MPI, src/forward/gravmag/sensit
 src/inversion/lsqr_solver2.F90:194-241) maps to: rank r owns a contiguous column range of S (nnz-balanced with the
 reference's own greedy rule), x / v / w and the damping rows are rank-local, u_data is replicated, and LSQR needs two
 small all-reduces per iteration, which libtfx.so requests through its all-reduce hook (tfx_set_allreduce).  This module
-supplies that hook from torch.distributed and holds the partition logic, which is pure host code (tested on CPU with
-gloo, world_size 2)."""
+holds the partition logic (pure host code, tested on CPU with gloo, world_size 2) and sets the collectives up:
+`setup_comm` joins the ranks in an RCCL communicator INSIDE libtfx.so (torch.distributed only carries the 128-byte id),
+after which every collective of the path is queued by the library on its own stream; the torch.distributed hooks remain
+for boxes where RCCL cannot connect the ranks (gloo tests, several processes on one GPU)."""
 import ctypes as C
 
 import numpy as np
@@ -30,12 +32,13 @@ def column_ranges(nelements_at_cpu):
 class _DevArray:
     """Exposes a raw device pointer through the CUDA array interface so torch can alias it (zero copy)."""
 
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+    def __init__(self, ptr, n, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
 class TorchAllreduce:
-    """fp64 sum all-reduce of a device buffer through torch.distributed."""
+    """Hook fallback for boxes without RCCL between the ranks (gloo CPU tests, several processes sharing one GPU): the fp64 sum
+    all-reduce and the all-gather of a device buffer through torch.distributed, issued on the stream libtfx.so passes in."""
 
     def __init__(self, device_index):
         import torch
@@ -46,6 +49,7 @@ class TorchAllreduce:
         self._hip = None
         self._staging = None
         self._alias = {}          # (ptr, n) -> tensor aliasing the library's buffer (LSQR reduces the same two buffers every iteration)
+        self._ext = {}            # raw stream handle -> torch.cuda.ExternalStream
 
     def _probe_zero_copy(self):
         torch = self.torch
@@ -58,6 +62,18 @@ class TorchAllreduce:
         except Exception:
             return False
 
+    def _on(self, stream):
+        """Context manager that makes `stream` (the hipStream_t the library launches on) torch's current stream, so that the
+        collective and the staging copies are ordered with the kernels queued before and after them (tfx.h: the hook is
+        'enqueued on `stream`').  The null stream is torch's default stream: nothing to switch."""
+        import contextlib
+        if not stream:
+            return contextlib.nullcontext()
+        ext = self._ext.get(stream)
+        if ext is None:
+            ext = self._ext[stream] = self.torch.cuda.ExternalStream(stream, device=self.device)
+        return self.torch.cuda.stream(ext)
+
     def _copy(self, dst, src, nbytes, stream):
         if self._hip is None:
             self._hip = C.CDLL("libamdhip64.so")
@@ -65,22 +81,143 @@ class TorchAllreduce:
         if rc != 0:
             raise RuntimeError("hipMemcpyAsync failed: %d" % rc)
 
+    def _tensor(self, ptr, n):
+        t = self._alias.get((ptr, n))
+        if t is None:
+            if len(self._alias) > 64:
+                self._alias.clear()
+            t = self._alias[(ptr, n)] = self.torch.as_tensor(_DevArray(ptr, n), device=self.device)
+        return t
+
     def __call__(self, ptr, n, stream):
         torch, dist = self.torch, self.dist
-        if self.zero_copy:
-            t = self._alias.get((ptr, n))
-            if t is None:
-                if len(self._alias) > 64:
-                    self._alias.clear()
-                t = self._alias[(ptr, n)] = torch.as_tensor(_DevArray(ptr, n), device=self.device)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        with self._on(stream):
+            if self.zero_copy:
+                dist.all_reduce(self._tensor(ptr, n), op=dist.ReduceOp.SUM)
+                return
+            if self._staging is None or self._staging.numel() < n:
+                self._staging = torch.empty(max(n, 1 << 16), dtype=torch.float64, device=self.device)
+            st = self._staging[:n]
+            self._copy(st.data_ptr(), ptr, 8 * n, stream)
+            dist.all_reduce(st, op=dist.ReduceOp.SUM)
+            self._copy(ptr, st.data_ptr(), 8 * n, stream)
+
+    def allgatherv(self, send_ptr, nsend, recv_ptr, counts, displs, stream):
+        """MPI_Allgatherv on device buffers: rank r's counts[r] doubles land at recv + displs[r] on every rank."""
+        torch, dist = self.torch, self.dist
+        with self._on(stream):
+            mine = torch.empty(max(nsend, 1), dtype=torch.float64, device=self.device)
+            if nsend:
+                self._copy(mine.data_ptr(), send_ptr, 8 * nsend, stream)
+            pieces = [torch.empty(max(c, 1), dtype=torch.float64, device=self.device) for c in counts]
+            # ragged all-gather as one broadcast per rank (gloo and nccl both take it)
+            for r, c in enumerate(counts):
+                buf = mine if r == dist.get_rank() else pieces[r]
+                dist.broadcast(buf[:max(c, 1)], src=r)
+                if c:
+                    self._copy(recv_ptr + 8 * displs[r], buf.data_ptr(), 8 * c, stream)
+            torch.cuda.current_stream(self.device).synchronize()       # the temporaries die with this frame
+
+
+class HostComm:
+    """The exchange steps the HOST drives around the library (nnz histogram, counts, matrix pieces, barrier, timing):
+    RCCL inside libtfx.so when the ctx has a communicator (`rccl=True`), torch.distributed otherwise."""
+
+    def __init__(self, ctx, rank, nranks, device_index, rccl):
+        import torch
+        self.ctx, self.rank, self.nranks, self.rccl = ctx, rank, nranks, rccl
+        self.torch = torch
+        self.dev = torch.device("cuda", device_index)
+
+    def allreduce_host(self, arr):
+        """Sum over the ranks of a numpy array (int32 / int64 / float64); returns the reduced array."""
+        if self.nranks == 1:
+            return arr
+        torch = self.torch
+        a = np.ascontiguousarray(arr)
+        if not self.rccl:
+            return allreduce_numpy(a)
+        kind = {np.dtype(np.float64): "f64", np.dtype(np.int32): "i32", np.dtype(np.int64): "i64"}[a.dtype]
+        t = torch.from_numpy(a).to(self.dev)
+        torch.cuda.synchronize(self.dev)
+        self.ctx.comm_allreduce(t.data_ptr(), a.size, kind)
+        torch.cuda.synchronize(self.dev)
+        return t.cpu().numpy()
+
+    def allgather_host(self, arr):
+        """Equal-shape numpy arrays of all ranks, as a list."""
+        if self.nranks == 1:
+            return [arr]
+        a = np.ascontiguousarray(arr)
+        if self.rccl:                                   # gather as a sum of disjoint supports (small host-side tables)
+            full = np.zeros((self.nranks,) + a.shape, a.dtype)
+            full[self.rank] = a
+            full = self.allreduce_host(full.reshape(-1)).reshape(full.shape)
+            return [full[r] for r in range(self.nranks)]
+        import torch.distributed as dist
+        torch = self.torch
+        out = [torch.zeros(a.shape, dtype=torch.from_numpy(a).dtype) for _ in range(self.nranks)]
+        dist.all_gather(out, torch.from_numpy(a))
+        return [o.numpy() for o in out]
+
+    def exchange(self, sends, recvs):
+        """sends: [(dst_rank, device tensor)], recvs: [(src_rank, device tensor)] - matched point-to-point transfers."""
+        torch = self.torch
+        if self.rccl:
+            torch.cuda.synchronize(self.dev)
+            self.ctx.comm_group_begin()
+            for dst, t in sends:
+                self.ctx.comm_send(t.data_ptr(), t.numel() * t.element_size(), dst)
+            for src, t in recvs:
+                self.ctx.comm_recv(t.data_ptr(), t.numel() * t.element_size(), src)
+            self.ctx.comm_group_end()
+            torch.cuda.synchronize(self.dev)
             return
-        if self._staging is None or self._staging.numel() < n:
-            self._staging = torch.empty(max(n, 1 << 16), dtype=torch.float64, device=self.device)
-        st = self._staging[:n]
-        self._copy(st.data_ptr(), ptr, 8 * n, stream)
-        dist.all_reduce(st, op=dist.ReduceOp.SUM)
-        self._copy(ptr, st.data_ptr(), 8 * n, stream)
+        import torch.distributed as dist
+        torch.cuda.synchronize(self.dev)
+        _p2p(sends, recvs, dist.get_backend())
+        torch.cuda.synchronize(self.dev)
+
+    def barrier(self):
+        if self.nranks == 1:
+            self.torch.cuda.synchronize(self.dev)
+            return
+        if self.rccl:
+            self.ctx.comm_barrier()
+        else:
+            import torch.distributed as dist
+            dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, value):
+        v = np.zeros(self.nranks)
+        v[self.rank] = value
+        return float(self.allreduce_host(v).max())
+
+
+def setup_comm(ctx, rank, nranks, device_index=0, want_rccl=None):
+    """Gives the ctx its collectives and returns the HostComm for the host-driven exchange steps.
+    RCCL (the production path): rank 0 draws the unique id, torch.distributed only carries its 128 bytes to the other ranks, every
+    rank joins the communicator inside libtfx.so - from then on LSQR's reductions, calc_data and the slices of WAVELET_DOMAIN = F
+    are RCCL calls on the ctx stream.  Without it (gloo tests, ranks sharing one GPU): the hooks through torch.distributed."""
+    import torch
+    import torch.distributed as dist
+    if nranks == 1:
+        return HostComm(ctx, 0, 1, device_index, False)
+    if want_rccl is None:
+        want_rccl = dist.get_backend() == "nccl"
+    if want_rccl:
+        dev = torch.device("cuda", device_index)
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).to(dev)
+        dist.broadcast(idt, src=0)
+        ctx.comm_init_rccl(bytes(idt.cpu().numpy().tobytes()), rank, nranks)
+        return HostComm(ctx, rank, nranks, device_index, True)
+    hook = TorchAllreduce(device_index)
+    ctx.set_allreduce(hook, rank, nranks)
+    ctx.set_allgatherv(hook.allgatherv)
+    return HostComm(ctx, rank, nranks, device_index, False)
 
 
 def allreduce_numpy(arr, op="sum"):
@@ -129,7 +266,7 @@ def _p2p(tensors_to_send, recv_specs, backend):
 
 def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate,
                                problem_weight=1.0, data_weight=None, mag_field=None, get_partition=None, device_index=0,
-                               nmodel_components=1):
+                               nmodel_components=1, comm=None):
     """Row-parallel build + relayout: every rank compresses only ITS row blocks (all columns, kept row-major on
     the device), the per-column histogram is all-reduced, the reference's greedy rule gives the column ranges, and each
     row block is then cut into column ranges and sent to the owners, who lay their pieces out as tiles.  Every row is
@@ -138,9 +275,9 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
     nmodel_components = 3 (magnetisation vector, one data component): a rank owns its cell range of every component; the
     pieces carry component k at k*(cells of the range) + cell."""
     import torch
-    import torch.distributed as dist
     from .sensitivity import get_load_balancing_nelements
-    backend = dist.get_backend()
+    if comm is None:                    # hosts that set the hooks themselves (tests): host-driven steps through torch.distributed
+        comm = HostComm(ctx, rank, nranks, device_index, False)
     dev = torch.device("cuda", device_index)
     N = ctx.nelements_total
     nd = len(Xdata)
@@ -158,8 +295,8 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
     else:
         hist, err = np.zeros(N, np.int64), 0.0
     # 2. partition (sensitivity_gravmag.F90:322, :470-524)
-    hist = allreduce_numpy(hist)
-    err = float(allreduce_numpy(np.array([err]))[0])
+    hist = comm.allreduce_host(hist)
+    err = float(comm.allreduce_host(np.array([err]))[0])
     nel, nnz = (get_partition or get_load_balancing_nelements)(hist.astype(np.int32), nranks)
     bounds = np.concatenate([[0], np.cumsum(np.asarray(nel, np.int64))])
     c0, c1 = int(bounds[rank]), int(bounds[rank + 1])
@@ -168,13 +305,12 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
     maxloc = int(max(np.diff(bstart))) * RB
     pad = np.zeros((maxloc, nranks), np.int32)
     pad[:nloc] = counts_loc
-    gathered = [torch.zeros((maxloc, nranks), dtype=torch.int32, device=dev if backend == "nccl" else "cpu") for _ in range(nranks)]
-    dist.all_gather(gathered, torch.from_numpy(pad).to(gathered[0].device))
+    gathered = comm.allgather_host(pad)
     counts = np.zeros((nd, nranks), np.int32)                       # counts[row, dest]
     for r in range(nranks):
         a, b = int(bstart[r]) * RB, min(int(bstart[r + 1]) * RB, nd)
         if b > a:
-            counts[a:b] = gathered[r].cpu().numpy()[:b - a]
+            counts[a:b] = gathered[r][:b - a]
     assert int(counts[:, rank].sum()) == int(nnz[rank]), (counts[:, rank].sum(), nnz[rank])
     # 4. relayout, row block by row block
     ctx.matrix_begin(nd, nmodel_components * (c1 - c0), int(nnz[rank]))
@@ -202,10 +338,7 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
                 sends += [(d, sc), (d, sv)]
         elif n_in > 0:
             recvs += [(o, rc[:n_in]), (o, rv[:n_in])]
-        if backend == "nccl":
-            torch.cuda.synchronize(dev)                              # pack kernels ran on the ctx stream
-        _p2p(sends, recvs, backend)
-        torch.cuda.synchronize(dev)
+        comm.exchange(sends, recvs)                                  # synchronises before (pack kernels) and after
         ctx.matrix_append_rows(ga, rc, rv, counts[ga:gb, rank])
     ctx.matrix_finish()
     ctx.rowstore_free()
@@ -213,7 +346,7 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
 
 
 def build_partitioned(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate,
-                      problem_weight=1.0, data_weight=None, get_partition=None):
+                      problem_weight=1.0, data_weight=None, get_partition=None, comm=None):
     """Column-partitioned sensitivity build for `nranks` GPUs.
 
     Phase 1 (row-parallel, like the reference's P1 decomposition, sensitivity_gravmag.F90:179-189): every rank compresses
@@ -238,8 +371,10 @@ def build_partitioned(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, com
         hist, err = res1["nnz_hist"].astype(np.int64), res1["error_sum"]
     else:
         hist, err = np.zeros(N, np.int64), 0.0
-    hist = allreduce_numpy(hist)
-    err = float(allreduce_numpy(np.array([err]))[0])
+    if comm is None:
+        comm = HostComm(ctx, rank, nranks, getattr(ctx, "device", 0), False)
+    hist = comm.allreduce_host(hist)
+    err = float(comm.allreduce_host(np.array([err]))[0])
     nel, nnz = (get_partition or get_load_balancing_nelements)(hist.astype(np.int32), nranks)
     c0, c1 = column_ranges(nel)[rank]
     res2 = ctx.calculate_sensit(Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate, problem_weight, data_weight,

@@ -24,7 +24,8 @@ class Context:
         self._h = h
         self.device = int(device)
         self.dims = None
-        self._hook = None          # keeps the ctypes callback alive
+        self._hook = None          # keeps the ctypes callbacks alive
+        self._ghook = None
         self.rank, self.nranks = 0, 1
 
     def close(self):
@@ -63,6 +64,61 @@ class Context:
             self._hook = L.ALLREDUCE_FN(tramp)
             check(self._lib.tfx_set_allreduce(self._h, self._hook, None, int(rank), int(nranks)))
         self.rank, self.nranks = int(rank), int(nranks)
+
+    def set_allgatherv(self, fn):
+        """Companion hook with MPI_Allgatherv semantics on device buffers:
+        fn(send_ptr:int, nsend:int, recv_ptr:int, counts:list, displs:list, stream:int) -> None."""
+        if fn is None:
+            self._ghook = None
+            check(self._lib.tfx_set_allgatherv(self._h, C.cast(None, L.ALLGATHERV_FN)))
+            return
+        nranks = self.nranks
+
+        def tramp(user, send, nsend, recv, counts, displs, stream):
+            try:
+                fn(int(send or 0), int(nsend), int(recv or 0), [int(counts[r]) for r in range(nranks)],
+                   [int(displs[r]) for r in range(nranks)], int(stream or 0))
+                return 0
+            except Exception as e:
+                import sys
+                sys.stderr.write("all-gather hook failed: %r\n" % (e,))
+                return 1
+        self._ghook = L.ALLGATHERV_FN(tramp)
+        check(self._lib.tfx_set_allgatherv(self._h, self._ghook))
+
+    # ---- RCCL inside the library (the production multi-GPU path)
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        check(self._lib.tfx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rccl(self, unique_id, rank, nranks):
+        """Collective: every rank calls it with the 128 bytes rank 0 got from comm_unique_id()."""
+        if len(unique_id) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        check(self._lib.tfx_comm_init_rccl(self._h, C.c_char_p(bytes(unique_id)), int(rank), int(nranks)))
+        self.rank, self.nranks = int(rank), int(nranks)
+
+    def comm_destroy(self):
+        check(self._lib.tfx_comm_destroy(self._h))
+
+    def comm_allreduce(self, dev_buf, n, dtype="f64"):
+        check(self._lib.tfx_comm_allreduce(self._h, ptr(dev_buf), C.c_int64(n), {"f64": 0, "i32": 1, "i64": 2}[dtype]))
+
+    def comm_group_begin(self):
+        check(self._lib.tfx_comm_group_begin(self._h))
+
+    def comm_group_end(self):
+        check(self._lib.tfx_comm_group_end(self._h))
+
+    def comm_send(self, dev_buf, nbytes, peer):
+        check(self._lib.tfx_comm_send(self._h, ptr(dev_buf), C.c_int64(nbytes), int(peer)))
+
+    def comm_recv(self, dev_buf, nbytes, peer):
+        check(self._lib.tfx_comm_recv(self._h, ptr(dev_buf), C.c_int64(nbytes), int(peer)))
+
+    def comm_barrier(self):
+        check(self._lib.tfx_comm_barrier(self._h))
 
     # ---- grid (t_grid, src/inversion/grid.F90:30-50)
     def set_grid(self, nx, ny, nz, X1, X2, Y1, Y2, Z1, Z2):
@@ -303,6 +359,14 @@ class Context:
 
     def matrix_free(self):
         check(self._lib.tfx_matrix_free(self._h))
+
+    def matrix_scale_rows(self, scale):
+        """Row r of the selected matrix times float32(scale[r]) in fp32: the problem_weight * data_weight scaling that
+        read_sensitivity_kernel applies to a kernel stored unscaled (sensitivity_gravmag.F90:834-843)."""
+        sc = f64(scale)
+        if sc.size != self.matrix_info()["nrows"]:
+            raise ValueError("scale size != number of matrix rows")
+        check(self._lib.tfx_matrix_scale_rows(self._h, ptr(sc)))
 
     def mult_vector(self, x, b=None):
         """b = S x (mult_vector) or b += S x when b is given (add_mult_vector)."""
