@@ -8,12 +8,16 @@ A "step" is one LSQR iteration (the loop body of lsqr_solve_sensit, src/inversio
 wavelet-compressed sensitivity matrix, everything resident in HBM.  Setup (not timed, reported separately as build
 cell.obs/s): prism rows -> column weights -> wavelet -> threshold -> tiled matrix, all on the GPU.
 Strong scaling: the same problem on N GPUs, column-partitioned like the reference's MPI decomposition, two RCCL
-all-reduces per iteration through torch.distributed.
+all-reduces per iteration issued by libtfx.so itself on its stream (tfx_comm_init_rccl; torch.distributed only starts the
+ranks and carries the 128-byte communicator id).
 
-One JSON line on rank 0.  `roofline` prices the dominant kernel (compressed SpMV or its adjoint, whichever is slower)
-with SURVEY.md 8(d)'s algorithmic bytes (8 B per non-zero per pass) over its HIP-event duration; `cpu_baseline` is the
-CPU oracle (oracle/, a C restatement of the reference pinned to it bit-for-bit) timed on a bounded sample of the same
-workload on this box's host cores."""
+One JSON line on rank 0.  `roofline` is about the dominant kernel (compressed SpMV or its adjoint, whichever is slower):
+`achieved` = the bytes the kernel's algorithm streams per launch (5.625 B per stored entry + the staged vectors)
+over its HIP-event duration, `traffic` = the HBM bytes rocprofv3's counters saw for the same launch (profiles/), both
+against the 8 TB/s spec; the reference-CSR-equivalent rate (8 B per non-zero) is reported next to it as
+`csr_equivalent_GBs`, not as the fraction.  `cpu_baseline` is the REAL reference (oracle/_ref/tomofastx, compiled from
+/root/reference by oracle/ref_build.sh) under mpiexec on all host cores of this box on the SURVEY-6 synthetic size, with
+the headline-size figure a stated linear extrapolation in nnz."""
 import argparse
 import importlib
 import json
@@ -67,6 +71,7 @@ def main():
     import torch
     tfx = importlib.import_module("tomofast-x_amd")
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         # TFX_BENCH_BACKEND=gloo + TFX_BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a single-GPU box
@@ -78,11 +83,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(local_rank)
 
     def log(msg):
         if rank == 0:
@@ -103,8 +103,13 @@ def main():
     log("device %s, %d CUs, %.0f GB; workload %s" % (info["name"], info["cus"], info["hbm_bytes"] / 1e9, w["desc"]))
     ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
     cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
-    if world > 1:
-        ctx.set_allreduce(tfx.distributed.TorchAllreduce(local_rank), rank, world)
+    # collectives: an RCCL communicator inside libtfx.so (nccl launch) - the library queues its reductions on its own stream;
+    # the gloo rehearsal uses the torch.distributed hooks
+    comm = tfx.distributed.setup_comm(ctx, rank, world, local_rank)
+    log("collectives: %s" % ("RCCL inside libtfx.so (tfx_comm_init_rccl)" if comm.rccl else ("single rank" if world == 1 else "torch.distributed hooks (%s)" % backend)))
+
+    def barrier():
+        comm.barrier()
 
     # ---- build (setup; reported as cell.obs/s)
     barrier()
@@ -115,27 +120,25 @@ def main():
     if use_exchange:
         # the relayout needs point-to-point transfers: try a ring of tiny messages first and agree on the outcome, so that a
         # backend without working send / recv degrades to the redundant build instead of failing the run
-        import torch
-        import torch.distributed as dist
         ok = 1
         try:
             dev = torch.device("cuda", local_rank)
             probe = torch.full((4,), float(rank), dtype=torch.float32, device=dev)
             got = torch.empty(4, dtype=torch.float32, device=dev)
-            tfx.distributed._p2p([((rank + 1) % world, probe)], [((rank - 1) % world, got)], dist.get_backend())
-            torch.cuda.synchronize(dev)
+            comm.exchange([((rank + 1) % world, probe)], [((rank - 1) % world, got)])
             ok = int(bool((got == float((rank - 1) % world)).all().item()))
         except Exception as exc:      # noqa
             log("point-to-point probe failed (%s): falling back to the redundant build" % exc)
             ok = 0
-        agreed = int(tfx.distributed.allreduce_numpy(np.array([ok], np.int64))[0])
+        agreed = int(comm.allreduce_host(np.array([ok], np.int64))[0])
         if agreed != world:
             use_exchange = False
     if use_exchange:
-        part = tfx.distributed.build_partitioned_exchange(ctx, rank, world, xs, ys, zs, cw, w["ctype"], w["rate"], device_index=local_rank)
-        build_mode = "row-parallel + relayout"
+        part = tfx.distributed.build_partitioned_exchange(ctx, rank, world, xs, ys, zs, cw, w["ctype"], w["rate"], device_index=local_rank,
+                                                          comm=comm)
+        build_mode = "row-parallel + relayout" + (" (ncclSend / ncclRecv)" if comm.rccl else "")
     else:
-        part = tfx.distributed.build_partitioned(ctx, rank, world, xs, ys, zs, cw, w["ctype"], w["rate"])
+        part = tfx.distributed.build_partitioned(ctx, rank, world, xs, ys, zs, cw, w["ctype"], w["rate"], comm=comm)
         build_mode = "direct" if world == 1 else "redundant rows per column range"
     barrier()
     t_build = time.time() - t0
@@ -180,10 +183,7 @@ def main():
     prof = [ctx.profile_get(0), ctx.profile_get(1)] if not args.no_profile else [(0.0, 0), (0.0, 0)]
     ctx.profile_enable(False)
     ctx.lsqr_end()
-    if dist is not None:
-        tt = torch.tensor([t_steps], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_steps = float(tt.item())
+    t_steps = comm.max_over_ranks(t_steps) if world > 1 else t_steps
     ms_per_step = 1e3 * t_steps / args.steps
     value = args.steps / t_steps
 
@@ -196,24 +196,35 @@ def main():
     if prof[0][1] and prof[1][1]:
         avg = [prof[0][0] / prof[0][1], prof[1][0] / prof[1][1]]
         dom = 0 if avg[0] >= avg[1] else 1
-        # 8 B per non-zero per pass for the compressed kernel, 4 B per entry for the dense (uncompressed) block
-        alg_b, stored_b = (4.0, 4) if w["ctype"] == 0 else (8.0, 6)
-        achieved = alg_b * nnz_loc / (avg[dom] * 1e-3) / 1e9
+        # Algorithmic bytes of one launch = what the kernel's algorithm has to stream: the stored entry streams
+        # (compressed: 4 B value + 1.5 B column slot + 1 bit row start = 5.625 B per non-zero; dense block: 4 B per entry) plus the
+        # vector on the streaming side once per row-block pass.  The reference's CSR moves 8 B per non-zero: that
+        # rate is reported as csr_equivalent_GBs and is NOT the roofline fraction.
+        if w["ctype"] == 0:
+            alg_bytes = 4.0 * nnz_loc + 8.0 * (ncl + D)
+            csr_b = 4.0
+        else:
+            alg_bytes = 5.625 * nnz_loc + 8.0 * (ncl + D)
+            csr_b = 8.0
+        achieved = alg_bytes / (avg[dom] * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args.workload, "k_spmv_fwd" if dom == 0 else "k_spmv_adj", nnz_loc)
         roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": int(alg_b) * nnz_loc, "stored_bytes_per_launch": stored_b * nnz_loc,
+                "algorithmic_bytes_per_launch": int(alg_bytes), "device_bytes_of_the_matrix": minfo["device_bytes"],
                 "avg_launch_ms": {"spmv_fwd": round(avg[0], 4), "spmv_adj": round(avg[1], 4)},
-                "achieved_other_GBs": round(alg_b * nnz_loc / (avg[1 - dom] * 1e-3) / 1e9, 1),
-                # frac can exceed 1: `achieved` prices the 8 B per non-zero the reference's CSR moves, the tiled
-                # matrix stores 6 B.  What actually crossed HBM (PMC traffic) over the same time, as a fraction of the peak:
-                "hbm_frac_on_measured_traffic": None if traffic is None else round(traffic / (avg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                # the same launch on the bytes that crossed HBM by PMC (>= the algorithmic bytes: tile padding, row markers, staging)
+                "frac_on_traffic": None if traffic is None else round(traffic / (avg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic_over_algorithmic": None if traffic is None else round(traffic / alg_bytes, 4),
+                "streaming_ceiling_GBs": 6290.0,     # MI355X_MICROARCH.md: measured float4 copy
+                "csr_equivalent_GBs": round(csr_b * nnz_loc / (avg[dom] * 1e-3) / 1e9, 1)}
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same workload
     cpu = None
     ref_cfg1 = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(tfx, w, args.cpu_seconds, cw, log)
+        cpu = cpu_baseline_reference(tfx, int(nnz_total), N * D, log)
+        if cpu is None:                     # no compiled reference / launcher on this box: the C port on one core
+            cpu = cpu_baseline(tfx, w, args.cpu_seconds, cw, log)
         ref_cfg1 = reference_config1(log)
 
     if rank == 0:
@@ -235,6 +246,8 @@ def main():
         }
         print(json.dumps(out))
         sys.stdout.flush()
+    if comm.rccl:
+        ctx.comm_destroy()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -278,6 +291,78 @@ def reference_config1(log):
     except Exception as e:      # the baseline leg must never take the benchmark down
         log("reference_config1 skipped: %r" % (e,))
         return None
+
+
+def cpu_baseline_reference(tfx, nnz_headline, pairs_headline, log, nx=64, ny=64, nz=32, ox=32, oy=32, ctype=1, rate=0.1):
+    """The compiled reference itself (oracle/_ref/tomofastx = /root/reference built by oracle/ref_build.sh; it travels to the
+    GPU box as a binary) under `mpiexec -n <all host cores>` on the SURVEY-6 synthetic size (64x64x32 cells x 32x32 data,
+    Haar r = 0.1, the same generator as the GPU workload): run A builds the kernel and does 1 x 1 LSQR iteration, run B
+    re-loads the kernel from A's SENSIT files and does 1 x 101; build rate = N.D / (A - reload part), LSQR time per
+    iteration = (B - B0) / 100 where B0 is B with 1 iteration.  The headline-size figure is a LINEAR EXTRAPOLATION in nnz
+    (LSQR) resp. in cell.obs pairs (build) and is labelled so.  None when the binary or the launcher is missing."""
+    import shutil
+    import subprocess
+    import tempfile
+    ref = os.path.join(ROOT, "oracle", "_ref", "tomofastx")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.isfile(ref) and os.path.isfile(mpiexec)):
+        return None
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    if cores >= 32:            # enough cores for the larger SURVEY-6 size (128x128x32 cells, nnz 2.7e7) inside the time budget
+        nx, ny, rate = 128, 128, 0.05
+    nd = ox * oy
+    N = nx * ny * nz
+    # The build is row-parallel and keeps scaling; the reference's LSQR all-reduces nlines doubles per iteration and its kernel
+    # reload is rank-0-serial, so more ranks are not faster there: the build runs on up to 64 ranks (beyond that the 1024-row
+    # build has < 16 rows per rank and start-up dominates), the LSQR leg is timed at 64 and at 16 ranks and the faster one counts.
+    build_ranks = max(1, min(cores, 64, nd // 4))
+    lsqr_rank_counts = sorted({build_ranks, max(1, min(cores, 16))}, reverse=True)
+    wd = tempfile.mkdtemp(prefix="tfx_refcpu_")
+    try:
+        def run(ranks, nminor, sensit_read):
+            tfx.synthetic.write_parfile_inputs(wd, nx, ny, nz, ox, oy, ctype, rate, nmajor=1, nminor=nminor, sensit_read=sensit_read)
+            t0 = time.time()
+            p = subprocess.run([mpiexec, "-n", str(ranks), ref, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+            dt = time.time() - t0
+            if p.returncode != 0 or "THE END." not in p.stdout:
+                raise RuntimeError("reference run failed: " + p.stdout[-400:] + p.stderr[-400:])
+            return dt, p.stdout
+        tA, outA = run(build_ranks, 1, 0)
+        nnz = int(outA.split("nnz_total =")[1].split()[0])
+        legs = {}
+        for rk in lsqr_rank_counts:
+            t0_, _ = run(rk, 1, 1)
+            t1_, _ = run(rk, 101, 1)
+            legs[rk] = {"reload_and_1_iteration_s": t0_, "reload_and_101_iterations_s": t1_, "ms_per_lsqr_iteration": 1e3 * max(t1_ - t0_, 1e-9) / 100.0}
+        best = min(legs, key=lambda rk: legs[rk]["ms_per_lsqr_iteration"])
+        t_iter = legs[best]["ms_per_lsqr_iteration"] * 1e-3
+        t_build = max(tA - legs[build_ranks]["reload_and_1_iteration_s"], 1e-9)   # A = inputs + build + write + reload + 1 iteration
+        out = {"value": 1.0 / (t_iter * nnz_headline / nnz), "unit": "iterations/s", "cores": build_ranks,
+               "host_cores": cores, "kind": "reference",
+               "sample": "oracle/_ref/tomofastx (the compiled reference) under mpiexec on %dx%dx%d cells x %d data, Haar r = %g "
+                         "(box: %d host cores): kernel build on %d ranks %.3e cell.obs/s; LSQR %.2f ms per iteration at nnz = %d on "
+                         "%d ranks (the faster of %s ranks - the reference's per-iteration MPI_Allreduce of all rows does not scale "
+                         "further); `value` is the LINEAR EXTRAPOLATION in nnz of that iteration time to the headline matrix "
+                         "(the reference cannot hold / finish that size on a host)" %
+                         (nx, ny, nz, nd, rate, cores, build_ranks, N * nd / t_build, 1e3 * t_iter, nnz, best, lsqr_rank_counts),
+               "measured": {"cells": N, "obs": nd, "nnz": nnz, "ms_per_lsqr_iteration": 1e3 * t_iter, "lsqr_ranks": best,
+                            "iterations_per_s": 1.0 / t_iter, "build_s": t_build, "build_ranks": build_ranks,
+                            "build_cell_obs_per_s": N * nd / t_build, "build_and_1_iteration_wall_s": tA,
+                            "lsqr_legs_by_ranks": {str(k): v for k, v in legs.items()}},
+               "extrapolated_headline": {"ms_per_lsqr_iteration": 1e3 * t_iter * nnz_headline / nnz,
+                                         "build_s": pairs_headline / (N * nd / t_build)}}
+        log("cpu baseline (reference; box has %d cores): build %.3e cell.obs/s on %d ranks, %.2f ms / LSQR iteration at nnz %d on %d ranks" %
+            (cores, N * nd / t_build, build_ranks, 1e3 * t_iter, nnz, best))
+        return out
+    except Exception as e:      # the baseline leg must never take the benchmark down
+        log("cpu_baseline_reference skipped: %r" % (e,))
+        return None
+    finally:
+        shutil.rmtree(wd, ignore_errors=True)
 
 
 def pmc_traffic(workload, kernel, nnz_loc):

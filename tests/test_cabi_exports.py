@@ -58,3 +58,35 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".f90", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "tfx_oracle" not in txt and "oracle_lib" not in txt and "oracle/" not in txt.replace("oracle/ ", ""), f
+
+
+def test_library_links_rccl():
+    """The multi-GPU collectives live inside libtfx.so (csrc/comm.hip): librccl is a direct dependency of the library and the
+    ncclAllReduce / ncclBroadcast / ncclSend / ncclRecv it calls are undefined symbols resolved from it."""
+    import subprocess
+    so = os.path.join(ROOT, "tomofast-x_amd", "libtfx.so")
+    dyn = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "librccl.so" in dyn
+    syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+    for name in ("ncclCommInitRank", "ncclAllReduce", "ncclBroadcast", "ncclSend", "ncclRecv", "ncclGroupStart"):
+        assert name in syms, name
+
+
+def test_parfile_host_reaches_the_gpu_only_through_the_reference_named_entry_points():
+    """tomofastx_amd.f90 (Parfile reader + solve_problem_joint_gravmag) must not call the C ABI directly: every hot-path step
+    goes through module tfx_reference_api, whose procedures carry the reference's names and argument orders."""
+    import re
+    host = os.path.join(ROOT, "tomofast-x_amd", "host")
+    src = open(os.path.join(host, "tomofastx_amd.f90")).read()
+    code = "\n".join(l.split("!")[0] for l in src.splitlines())            # comments stripped
+    assert not re.search(r"\btfx_(?!host_|reference_api|api_)[a-z_0-9]+\s*\(", code), re.findall(r"\btfx_(?!host_|reference_api|api_)[a-z_0-9]+\s*\(", code)[:5]
+    assert "use tfx_binding" not in code
+    assert re.search(r"subroutine\s+solve_problem_joint_gravmag\s*\(\s*gpar\s*,\s*mpar\s*,\s*ipar\s*,\s*myrank\s*,\s*nbproc\s*\)", code)
+    api = open(os.path.join(host, "tfx_reference_api.f90")).read()
+    for sig in (r"subroutine calculate_and_write_sensit\(par, grid_full, data, column_weight, memory, myrank_, nbproc_\)",
+                r"subroutine calculate_new_partitioning\(par, nnz, nelements_at_cpu, problem_type, myrank_, nbproc_\)",
+                r"subroutine read_sensitivity_kernel\(par, sensit_matrix, column_weight, problem_weight, data_weight, problem_type, &",
+                r"subroutine model_calculate_data\(this, ndata, ndata_components, matrix_sensit, problem_weight, column_weight, data_weight, &",
+                r"subroutine lsqr_solve_sensit\(nlines, ncolumns, niter, rmin, gamma, target_misfit, matrix_sensit, matrix_cons, u, x, &",
+                r"subroutine forward_wavelet\(s, n1, n2, n3, wavelet_type\)", r"subroutine inverse_wavelet\(s, n1, n2, n3, wavelet_type\)"):
+        assert re.search(sig, api), sig

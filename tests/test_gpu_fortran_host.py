@@ -281,7 +281,7 @@ def test_cross_gradient_parfile_matches_reference(tmp_path, golden_dir, name):
         model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)[:, 0]
         ref = g["np1_%s_model_final" % tag]
         assert np.linalg.norm(model - ref) <= 1e-6 * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
-    rs = [float(t.split()[0]) for t in out.stdout.split("Finished lsqr solver, r =")[1:]]
+    rs = [float(t.split()[0]) for t in out.stdout.split("End of subroutine lsqr_solve_sensit, r =")[1:]]
     assert np.allclose(rs, g["np1_lsqr_r"], rtol=1e-5)
     xc = np.array([[float(v) for v in t.split()[:3]] for t in out.stdout.split("cross-grad cost =")[1:]])
     assert np.allclose(xc[2:], g["np1_xgrad_cost"][2:], rtol=1e-4)
@@ -310,7 +310,7 @@ def test_clustering_parfile_matches_reference(tmp_path, golden_dir, name):
         model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)[:, 0]
         ref = g["np1_%s_model_final" % tag]
         assert np.linalg.norm(model - ref) <= 1e-6 * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
-    rs = [float(t.split()[0]) for t in out.stdout.split("Finished lsqr solver, r =")[1:]]
+    rs = [float(t.split()[0]) for t in out.stdout.split("End of subroutine lsqr_solve_sensit, r =")[1:]]
     assert np.allclose(rs, g["np1_lsqr_r"], rtol=1e-5)
     assert np.isclose(float(out.stdout.split("Clustering mixture_max =")[1].split()[0]), float(g["np1_mixture_max"][0]), rtol=1e-7)
 
@@ -428,7 +428,7 @@ def test_spatial_unknowns_two_ranks_under_mpiexec(tmp_path, golden_dir, name):
         model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)[:, 0]
         ref = g["np2_%s_model_final" % tag if tag else "np2_model_final"]
         assert np.linalg.norm(model - ref) <= 1e-5 * np.linalg.norm(ref), (tag, np.linalg.norm(model - ref) / np.linalg.norm(ref))
-    rs = [float(t.split()[0]) for t in out.stdout.split("Finished lsqr solver, r =")[1:]]
+    rs = [float(t.split()[0]) for t in out.stdout.split("End of subroutine lsqr_solve_sensit, r =")[1:]]
     assert np.allclose(rs[:len(g["np2_lsqr_r"])], g["np2_lsqr_r"], rtol=1e-4)
 
 
@@ -576,7 +576,7 @@ def test_gradient_damping_parfile_matches_reference(tmp_path, golden_dir):
     model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
     ref = g["np1_model_final"]
     assert np.linalg.norm(model - ref) <= 1e-5 * np.linalg.norm(ref), np.linalg.norm(model - ref) / np.linalg.norm(ref)
-    rs = [float(t.split()[0]) for t in out.stdout.split("Finished lsqr solver, r =")[1:]]
+    rs = [float(t.split()[0]) for t in out.stdout.split("End of subroutine lsqr_solve_sensit, r =")[1:]]
     assert np.allclose(rs, g["np1_lsqr_r"], rtol=1e-4)
 
 

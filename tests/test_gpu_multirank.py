@@ -248,7 +248,7 @@ def _worker_inversion(rank, world, port, q):
         obs = g["obs"]
         ctx = tfx.Context(0)
         ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
-        ctx.set_allreduce(tfx.distributed.TorchAllreduce(0), rank, world)
+        tfx.distributed.setup_comm(ctx, rank, world, 0)          # gloo here: all-reduce + all-gather hooks through torch.distributed
         cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
         part = tfx.distributed.build_partitioned(ctx, rank, world, obs[:, 0], obs[:, 1], obs[:, 2], cw, 1, float(g["rate"]))
         m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, 1, g["np1_data_observed"], int(g["nmajor"]), int(g["nminor"]),
@@ -298,7 +298,7 @@ def _worker_inversion_spatial(rank, world, port, q):
         N = int(np.prod(dims))
         ctx = tfx.Context(0)
         ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
-        ctx.set_allreduce(tfx.distributed.TorchAllreduce(0), rank, world)
+        tfx.distributed.setup_comm(ctx, rank, world, 0)          # gloo here: all-reduce + all-gather hooks through torch.distributed
         nel = g["np2_nelements_at_cpu"]                  # the reference's own 2-rank partition
         c0 = int(nel[:rank].sum())
         c1 = c0 + int(nel[rank])
@@ -353,7 +353,7 @@ def _worker_joint_coupled(rank, world, port, q):
             N = int(np.prod(dims))
             ctx = tfx.Context(0)
             ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
-            ctx.set_allreduce(tfx.distributed.TorchAllreduce(0), rank, world)
+            tfx.distributed.setup_comm(ctx, rank, world, 0)          # gloo here: all-reduce + all-gather hooks through torch.distributed
             c0, c1 = (0, N // 2 + 3) if rank == 0 else (N // 2 + 3, N)
             probs = []
             for i, tag in enumerate(("grav", "magn")):
@@ -423,7 +423,7 @@ def _worker_spatial(rank, world, port, q):
         nd = S_full[0].size - 1
         ctx = tfx.Context(0)
         ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
-        ctx.set_allreduce(tfx.distributed.TorchAllreduce(0), rank, world)
+        tfx.distributed.setup_comm(ctx, rank, world, 0)          # gloo here: all-reduce + all-gather hooks through torch.distributed
         ctx.matrix_upload_csr(nd, c1 - c0, *mm.column_slice(S_full, c0, c1))
         b = g["np1_data_observed"]
         alpha = np.float32(1e-7)
@@ -432,7 +432,14 @@ def _worker_spatial(rank, world, port, q):
         # spatial unknowns on 2 ranks ...
         ctx.lsqr_set_wavelet_domain(False, 1)
         ctx.lsqr_set_partition(c0, 1)
+        ctx.debug_set("deterministic", 1)     # fixed accumulation order in the products, so that two solves can be compared tightly
         x_loc, it, r = ctx.lsqr_solve_sensit(b, 15, 1e-13, 0.0, 0.0, [np.full(c1 - c0, alpha, np.float32)], [rhs_full[c0:c1]])
+        # the same solve with the slices travelling as a zero-padded sum (a host that supplies only the all-reduce hook):
+        # same numbers moved differently
+        ctx.set_allgatherv(None)
+        x_sum, it_sum, r_sum = ctx.lsqr_solve_sensit(b, 15, 1e-13, 0.0, 0.0, [np.full(c1 - c0, alpha, np.float32)], [rhs_full[c0:c1]])
+        ctx.debug_set("deterministic", 0)
+        assert it_sum == it and np.linalg.norm(x_sum - x_loc) <= 1e-12 * np.linalg.norm(x_loc) and abs(r_sum - r) <= 1e-12 * r
         ctx.lsqr_set_wavelet_domain(True)
         # ... against the single-rank oracle: x_spatial solves min |S W x - b|^2 + |alpha x - rhs|^2; W orthonormal, so
         # x_wavelet = W x solves the wavelet-domain system with the transformed right-hand side, iteration by iteration

@@ -360,6 +360,73 @@ module tfx_binding
       type(c_ptr), value :: data_weight
       real(c_double), intent(out) :: data_calc(*)
     end function
+
+    ! read_sensitivity_kernel's row scaling (sensitivity_gravmag.F90:834-843): row r *= real(scale(r), 4)
+    integer(c_int) function tfx_matrix_scale_rows(ctx, scale) bind(C, name="tfx_matrix_scale_rows")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(in) :: scale(*)
+    end function
+
+    integer(c_int) function tfx_matrix_free(ctx) bind(C, name="tfx_matrix_free")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    ! ---- RCCL inside libtfx.so (include/tfx.h "RCCL inside the library")
+    integer(c_int) function tfx_comm_unique_id(id) bind(C, name="tfx_comm_unique_id")
+      import :: c_int, c_char
+      character(kind=c_char), intent(out) :: id(128)
+    end function
+
+    integer(c_int) function tfx_comm_init_rccl(ctx, id, rank, nranks) bind(C, name="tfx_comm_init_rccl")
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: ctx
+      character(kind=c_char), intent(in) :: id(128)
+      integer(c_int), value :: rank, nranks
+    end function
+
+    integer(c_int) function tfx_comm_destroy(ctx) bind(C, name="tfx_comm_destroy")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    ! dtype: 0 = real(8), 1 = integer(4), 2 = integer(8); dev_buf is a DEVICE pointer (tfx_device_malloc)
+    integer(c_int) function tfx_comm_allreduce(ctx, dev_buf, n, dtype) bind(C, name="tfx_comm_allreduce")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx, dev_buf
+      integer(c_int64_t), value :: n
+      integer(c_int), value :: dtype
+    end function
+
+    integer(c_int) function tfx_comm_group_begin(ctx) bind(C, name="tfx_comm_group_begin")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    integer(c_int) function tfx_comm_group_end(ctx) bind(C, name="tfx_comm_group_end")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    integer(c_int) function tfx_comm_send(ctx, dev_buf, bytes, peer) bind(C, name="tfx_comm_send")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx, dev_buf
+      integer(c_int64_t), value :: bytes
+      integer(c_int), value :: peer
+    end function
+
+    integer(c_int) function tfx_comm_recv(ctx, dev_buf, bytes, peer) bind(C, name="tfx_comm_recv")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx, dev_buf
+      integer(c_int64_t), value :: bytes
+      integer(c_int), value :: peer
+    end function
+
+    integer(c_int) function tfx_comm_barrier(ctx) bind(C, name="tfx_comm_barrier")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
   end interface
 
 contains

@@ -1,14 +1,16 @@
 !=========================================================================================================
-! One process per GPU for the Fortran host: MPI (the MPICH of this image, the reference's own launcher `mpiexec -n P`) for
-! start-up, the two small LSQR reductions and the gathers of the host-side vectors.  The sensitivity matrix never moves
-! through MPI: every rank builds its own column range on its GPU.
+! One process per GPU for the Fortran host, started by the reference's own launcher (`mpiexec -n P`).
 !
-! The all-reduce hook stages the device buffer through the host (tfx_copy + MPI_Allreduce): 0.8 MB per LSQR iteration at
-! the headline size.  A device-side collective (ncclAllReduce on the ctx stream, the RCCL path the Python host uses through
-! torch.distributed) plugs into the same tfx_set_allreduce slot.
+! Data path: RCCL inside libtfx.so.  host_comm_setup joins the ranks in a communicator (rank 0 draws the unique id, MPI_Bcast
+! carries its 128 bytes); from then on the two LSQR reductions, the predicted-data reduction and the slices of
+! WAVELET_DOMAIN = F are ncclAllReduce / ncclBroadcast calls queued by the library on its own stream, and the pieces of the
+! build relayout travel GPU to GPU with ncclSend / ncclRecv.  MPI keeps only start-up and the small host-side tables
+! (per-cell counts, model slices for the output files).
+! Fallback (fewer GPUs than ranks - e.g. two ranks on the one GPU of a test box - or TFX_COMM=mpi): the all-reduce hook stages
+! the device buffer through the host (tfx_copy + MPI_Allreduce) and the pieces go through MPI_Send / MPI_Recv.
 !
-! MPI is initialised only under a launcher (PMI_RANK / PMI_SIZE in the environment); a plain `./tomofastx_amd -p ...`
-! runs single-rank without touching MPI.
+! MPI is initialised only under a launcher (PMI / PMIx / Open MPI / Slurm variables in the environment); a plain
+! `./tomofastx_amd -p ...` runs single-rank without touching MPI.
 !=========================================================================================================
 module tfx_host_mpi
   use iso_c_binding
@@ -16,6 +18,7 @@ module tfx_host_mpi
   implicit none
   include 'mpif.h'
   logical, save :: mpi_on = .false.
+  logical, save :: rccl_on = .false.       ! the ctx has an RCCL communicator: collectives run inside libtfx.so
   integer, save :: myrank = 0, nbproc = 1
   type(c_ptr), save :: hook_ctx = c_null_ptr
   real(c_double), allocatable, target, save :: hook_buf(:)
@@ -24,10 +27,16 @@ contains
 
   subroutine host_mpi_init()
     character(len=32) :: v
-    integer :: l, st, ierr
-    call get_environment_variable('PMI_RANK', v, l, st)
-    if (st /= 0 .or. l == 0) call get_environment_variable('PMI_SIZE', v, l, st)
-    if (st == 0 .and. l > 0) then
+    character(len=24), parameter :: launcher_vars(6) = [character(len=24) :: 'PMI_RANK', 'PMI_SIZE', 'OMPI_COMM_WORLD_SIZE', &
+                                                        'PMIX_RANK', 'SLURM_PROCID', 'MPI_LOCALRANKID']
+    integer :: l, st, ierr, k
+    logical :: launched
+    launched = .false.
+    do k = 1, size(launcher_vars)            ! MPICH / Hydra, Open MPI, PMIx, srun, Intel MPI
+      call get_environment_variable(trim(launcher_vars(k)), v, l, st)
+      if (st == 0 .and. l > 0) launched = .true.
+    enddo
+    if (launched) then
       call MPI_Init(ierr)
       mpi_on = .true.
       call MPI_Comm_rank(MPI_COMM_WORLD, myrank, ierr)
@@ -44,6 +53,78 @@ contains
     integer :: ierr
     if (mpi_on) call MPI_Abort(MPI_COMM_WORLD, 1, ierr)
   end subroutine host_mpi_abort
+
+  ! The collectives of the path for this ctx: an RCCL communicator inside libtfx.so when every rank has its own GPU, else the
+  ! MPI-staged hook (TFX_COMM=mpi forces the hook; TFX_COMM=rccl insists on RCCL)
+  subroutine host_comm_setup(ctx)
+    type(c_ptr), intent(in) :: ctx
+    character(kind=c_char) :: id(128)
+    character(len=16) :: v
+    integer :: l, st, ierr, ndev
+    logical :: want
+    if (nbproc <= 1) return
+    ndev = tfx_device_count()
+    want = ndev >= nbproc
+    call get_environment_variable('TFX_COMM', v, l, st)
+    if (st == 0 .and. l > 0) then
+      if (v(1:l) == 'mpi') want = .false.
+      if (v(1:l) == 'rccl') want = .true.
+    endif
+    if (want) then
+      id = c_null_char
+      if (myrank == 0) call tfx_check(tfx_comm_unique_id(id), 'tfx_comm_unique_id')
+      call MPI_Bcast(id, 128, MPI_CHARACTER, 0, MPI_COMM_WORLD, ierr)
+      call tfx_check(tfx_comm_init_rccl(ctx, id, int(myrank, c_int), int(nbproc, c_int)), 'tfx_comm_init_rccl')
+      rccl_on = .true.
+      if (myrank == 0) print *, 'Collectives: RCCL inside libtfx.so (one GPU per rank).'
+    else
+      hook_ctx = ctx
+      call tfx_check(tfx_set_allreduce(ctx, c_funloc(allreduce_hook), c_null_ptr, int(myrank, c_int), int(nbproc, c_int)), &
+                     'tfx_set_allreduce')
+      if (myrank == 0) print *, 'Collectives: MPI-staged hook (ranks share GPUs, or TFX_COMM=mpi).'
+    endif
+  end subroutine host_comm_setup
+
+  ! a matrix piece (columns + values, device buffers) to / from another rank: GPU to GPU over RCCL, or staged through MPI
+  subroutine exchange_piece_send(ctx, dest, n, dcols, dvals, tag)
+    type(c_ptr), intent(in) :: ctx, dcols, dvals
+    integer, intent(in) :: dest, tag
+    integer(c_int64_t), intent(in) :: n
+    integer(c_int32_t), allocatable, target :: hc(:)
+    real(c_float), allocatable, target :: hv(:)
+    if (rccl_on) then
+      call tfx_check(tfx_comm_group_begin(ctx), 'tfx_comm_group_begin')
+      call tfx_check(tfx_comm_send(ctx, dcols, 4 * n, int(dest, c_int)), 'tfx_comm_send')
+      call tfx_check(tfx_comm_send(ctx, dvals, 4 * n, int(dest, c_int)), 'tfx_comm_send')
+      call tfx_check(tfx_comm_group_end(ctx), 'tfx_comm_group_end')
+    else
+      allocate(hc(n), hv(n))
+      call tfx_check(tfx_copy(ctx, c_loc(hc), dcols, 4 * n), 'tfx_copy')
+      call tfx_check(tfx_copy(ctx, c_loc(hv), dvals, 4 * n), 'tfx_copy')
+      call send_piece(dest, int(n), hc, hv, tag)
+      deallocate(hc, hv)
+    endif
+  end subroutine exchange_piece_send
+
+  subroutine exchange_piece_recv(ctx, src, n, dcols, dvals, tag)
+    type(c_ptr), intent(in) :: ctx, dcols, dvals
+    integer, intent(in) :: src, tag
+    integer(c_int64_t), intent(in) :: n
+    integer(c_int32_t), allocatable, target :: hc(:)
+    real(c_float), allocatable, target :: hv(:)
+    if (rccl_on) then
+      call tfx_check(tfx_comm_group_begin(ctx), 'tfx_comm_group_begin')
+      call tfx_check(tfx_comm_recv(ctx, dcols, 4 * n, int(src, c_int)), 'tfx_comm_recv')
+      call tfx_check(tfx_comm_recv(ctx, dvals, 4 * n, int(src, c_int)), 'tfx_comm_recv')
+      call tfx_check(tfx_comm_group_end(ctx), 'tfx_comm_group_end')
+    else
+      allocate(hc(n), hv(n))
+      call recv_piece(src, int(n), hc, hv, tag)
+      call tfx_check(tfx_copy(ctx, dcols, c_loc(hc), 4 * n), 'tfx_copy')
+      call tfx_check(tfx_copy(ctx, dvals, c_loc(hv), 4 * n), 'tfx_copy')
+      deallocate(hc, hv)
+    endif
+  end subroutine exchange_piece_recv
 
   ! tfx_allreduce_fn: sum over ranks of n doubles in a DEVICE buffer (lsqr_solver2.F90:214, :511-515; model.F90:290)
   integer(c_int) function allreduce_hook(user, buf, n, stream) bind(C)

@@ -3,10 +3,14 @@
 !
 !     ./tomofastx_amd -p <Parfile>          (src/program_tomofastx.F90:77-80, src/parameters_init.f90:104-119)
 !
-! It re-states the control flow of solve_problem_joint_gravmag (src/problem_joint_gravmag.F90:65-613) and
-! joint_inversion_solve (src/inversion/joint_inverse_problem.F90:393-573) for gravity, magnetic or JOINT gravity + magnetic
-! inversion (selected by the problem weights like the reference) and hands every O(N), O(N.Ndata) and O(nnz) step to libtfx.so
-! through tfx_binding (iso_c_binding): depth weight, sensitivity kernel, wavelets, LSQR, forward data.
+! The main program reads the Parfile and calls solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc) (module
+! problem_joint_gravmag below), which re-states the control flow of the reference's routine of that name
+! (src/problem_joint_gravmag.F90:65-613) and of joint_inversion_solve (src/inversion/joint_inverse_problem.F90:393-573) for
+! gravity, magnetic or JOINT gravity + magnetic inversion (selected by the problem weights like the reference).  Every step on
+! the sensitivity-kernel hot path goes through the reference's own entry points, provided over libtfx.so by module
+! tfx_reference_api: calculate_depth_weight, calculate_and_write_sensit, calculate_new_partitioning, read_sensitivity_kernel,
+! model%calculate_data, lsqr_solve_sensit (with the constraint rows built by add / new_row like damping%add), forward_wavelet /
+! inverse_wavelet.  No other call reaches the GPU library from this file.
 ! What stays in Fortran is what the reference also does on the host: Parfile parsing, ASCII readers / writers in
 ! the reference's formats, the ADMM projection (src/inversion/admm_method.F90:70-134), residuals and costs.
 !
@@ -67,14 +71,29 @@ module tfx_host_params
     character(len=256) :: bounds_file(2) = 'NILL'        ! inversion.admm.{grav,magn}.boundsFile (boundType 2)
   end type t_par
 
+  ! Parfile keys of the callers on either side of the hot path (constraint builders, file names, ADMM schedule): the program sets
+  ! this before it calls solve_problem_joint_gravmag; what the hot path itself reads travels in gpar / mpar / ipar
+  type(t_par), save :: host_par
+
+  ! set by the program to MPI_Abort under a launcher, so that a failure on one rank takes the others down instead of leaving them
+  ! blocked in a collective (src/utils/mpi_tools.F90:29-53: exit_MPI aborts every rank)
+  abstract interface
+    subroutine abort_all_ranks()
+    end subroutine abort_all_ranks
+  end interface
+  procedure(abort_all_ranks), pointer, save :: abort_hook => null()
+
 contains
 
   subroutine stop_msg(msg)
     character(len=*), intent(in) :: msg
     ! src/utils/mpi_tools.F90:29-53: banner + abort
-    print *, '**********************************************'
+    write(0, *) '**********************************************'
+    write(0, *) 'ERROR: ', trim(msg)
+    write(0, *) '**********************************************'
     print *, 'ERROR: ', trim(msg)
-    print *, '**********************************************'
+    flush(6)
+    if (associated(abort_hook)) call abort_hook()
     stop 1
   end subroutine stop_msg
 
@@ -374,257 +393,57 @@ contains
 end module tfx_host_io
 
 !=========================================================================================================
-! Reference-compatible SENSIT files (src/forward/gravmag/sensitivity_gravmag.F90:142-153, :183, :306-309, :360-392,
-! :415-464 written; :648-883, :920-1030 read): big-endian streams like the reference's -fconvert=big-endian build.
-module tfx_host_sensit
+module problem_joint_gravmag
   use iso_c_binding
-  use tfx_binding
-  use tfx_host_params
-  implicit none
-  character(len=4), parameter :: SENSIT_SUFFIX(2) = (/'grav', 'magn'/)
-contains
-
-  ! The device matrix back as CSR, cut into the (datum, data component, model component) lines of the reference's file.
-  subroutine write_sensit_files(ctx, folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, comp_error, pw, cw, dw)
-    type(c_ptr), intent(in) :: ctx
-    character(len=*), intent(in) :: folder
-    integer, intent(in) :: ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type
-    real(dp), intent(in) :: comp_error, pw, cw(:), dw(:)
-    integer(c_int64_t) :: nrows, ncols, nnz, dbytes
-    integer(c_int64_t), allocatable :: rowptr(:)
-    integer(c_int32_t), allocatable :: cols(:), hist(:)
-    real(c_float), allocatable :: vals(:)
-    integer :: u, n, i, d, k, r
-    integer(c_int64_t) :: a, b, e, p
-    character(len=512) :: fname
-    n = nx * ny * nz
-    if (tfx_matrix_info(ctx, nrows, ncols, nnz, dbytes) /= 0) call stop_msg('tfx_matrix_info failed')
-    allocate(rowptr(nrows + 1), cols(max(nnz, 1_c_int64_t)), vals(max(nnz, 1_c_int64_t)), hist(n))
-    if (tfx_matrix_download_csr(ctx, rowptr, cols, vals) /= 0) call stop_msg('tfx_matrix_download_csr failed')
-    do r = 1, int(nrows)                                      ! the file holds the unscaled kernel (:834-843 scales on reload)
-      if (pw * dw(r) /= 1.d0) vals(rowptr(r) + 1:rowptr(r + 1)) = vals(rowptr(r) + 1:rowptr(r + 1)) / real(pw * dw(r), c_float)
-    enddo
-    call execute_command_line('mkdir -p "'//trim(folder)//'"')
-    fname = trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_1_0'
-    print *, 'Writing the sensitivity to file ', trim(fname)
-    open(newunit=u, file=trim(fname), status='replace', access='stream', form='unformatted', action='write', convert='big_endian')
-    write(u) int(nd, c_int32_t), int(nd, c_int32_t), int(n, c_int32_t), 0_c_int32_t, 1_c_int32_t          ! :183
-    hist = 0
-    r = 0
-    do i = 1, nd
-      do d = 1, ndc
-        r = r + 1
-        a = rowptr(r) + 1
-        b = rowptr(r + 1)
-        do k = 1, nc                                            ! columns (k-1)*n + cell, ascending (:829-846)
-          e = a
-          do while (e <= b)
-            if (cols(e) > k * n) exit
-            e = e + 1
-          enddo
-          write(u) int(i, c_int32_t), int(e - a, c_int32_t), int(k, c_int32_t), int(d, c_int32_t)            ! :306
-          if (e > a) then
-            do p = a, e - 1
-              cols(p) = cols(p) - (k - 1) * n
-              hist(cols(p)) = hist(cols(p)) + 1
-            enddo
-            write(u) cols(a:e - 1), vals(a:e - 1)                                                               ! :308
-          endif
-          a = e
-        enddo
-      enddo
-    enddo
-    close(u)
-    fname = trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_meta.txt'                                          ! :360-375
-    open(newunit=u, file=trim(fname), form='formatted', status='replace', action='write')
-    write(u, *) nx, ny, nz, nd
-    write(u, *) 1, 4, dw_type
-    write(u, *) comp_type, comp_error
-    write(u, *) nc, ndc
-    write(u, *) nnz
-    close(u)
-    fname = trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_nnz'                                               ! :380-392
-    open(newunit=u, file=trim(fname), status='replace', access='stream', form='unformatted', action='write', convert='big_endian')
-    write(u) int(n, c_int32_t)
-    write(u) hist
-    close(u)
-    call write_weight_file(folder, ip, n, cw)
-  end subroutine write_sensit_files
-
-  subroutine write_weight_file(folder, ip, n, cw)                                                             ! :415-464
-    character(len=*), intent(in) :: folder
-    integer, intent(in) :: ip, n
-    real(dp), intent(in) :: cw(n)
-    integer :: u
-    call execute_command_line('mkdir -p "'//trim(folder)//'"')
-    open(newunit=u, file=trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_weight', status='replace', access='stream', &
-         form='unformatted', action='write', convert='big_endian')
-    write(u) int(n, c_int32_t)
-    write(u) cw
-    close(u)
-  end subroutine write_weight_file
-
-  ! metadata, per-cell counts and depth weight of a kernel whose row files were written by nbproc ranks (:360-392, :415-464)
-  subroutine write_sensit_meta_files(folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, comp_error, nnz, nbproc, hist, cw)
-    character(len=*), intent(in) :: folder
-    integer, intent(in) :: ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, nbproc
-    real(dp), intent(in) :: comp_error, cw(:)
-    integer(c_int64_t), intent(in) :: nnz
-    integer(c_int32_t), intent(in) :: hist(:)
-    integer :: u
-    call execute_command_line('mkdir -p "'//trim(folder)//'"')
-    open(newunit=u, file=trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_meta.txt', form='formatted', status='replace', action='write')
-    write(u, *) nx, ny, nz, nd
-    write(u, *) nbproc, 4, dw_type
-    write(u, *) comp_type, comp_error
-    write(u, *) nc, ndc
-    write(u, *) nnz
-    close(u)
-    open(newunit=u, file=trim(folder)//'/sensit_'//SENSIT_SUFFIX(ip)//'_nnz', status='replace', access='stream', form='unformatted', &
-         action='write', convert='big_endian')
-    write(u) int(nx * ny * nz, c_int32_t)
-    write(u) hist
-    close(u)
-    call write_weight_file(folder, ip, nx * ny * nz, cw)
-  end subroutine write_sensit_meta_files
-
-  subroutine read_weight_file(folder, ip, n, cw)                                                              ! :920-970
-    character(len=*), intent(in) :: folder
-    integer, intent(in) :: ip, n
-    real(dp), intent(out) :: cw(n)
-    integer :: u, ios
-    integer(c_int32_t) :: nread
-    open(newunit=u, file=trim(folder)//'sensit_'//SENSIT_SUFFIX(ip)//'_weight', status='old', access='stream', &
-         form='unformatted', action='read', convert='big_endian', iostat=ios)
-    if (ios /= 0) call stop_msg('Error in opening the depth weight file! path='//trim(folder))
-    read(u) nread
-    if (nread /= n) call stop_msg('Depth weight file header does not match the Parfile!')
-    read(u) cw
-    close(u)
-  end subroutine read_weight_file
-
-  ! read_sensitivity_metadata + read_sensitivity_kernel (any number of rank files) -> CSR uploaded to the device
-  subroutine read_sensit_files(ctx, folder, ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type, pw, nnz_out, c0, c1, dw)
-    type(c_ptr), intent(in) :: ctx
-    character(len=*), intent(in) :: folder
-    integer, intent(in) :: ip, nx, ny, nz, nd, ndc, nc, dw_type, comp_type
-    real(dp), intent(in) :: pw, dw(:)
-    integer(c_int64_t), intent(out) :: nnz_out
-    integer, intent(in) :: c0, c1            ! cells (c0, c1] stay on this rank (read_sensitivity_kernel scatters them, :795-830)
-    integer :: u, ios, n, rank, nbproc_sensit, nloc
-    integer(c_int64_t) :: jj, precision_read, wtype, ctype, ncm_read, ncd_read, nxr, nyr, nzr, ndr
-    integer :: i, d, k, r, idata_glob
-    real(dp) :: comp_error
-    integer(c_int64_t) :: nnz_total, pos, j
-    integer(c_int32_t) :: hdr(5), desc(4)
-    integer(c_int64_t), allocatable :: rowptr(:)
-    integer(c_int32_t), allocatable :: cols(:)
-    real(c_float), allocatable :: vals(:)
-    character(len=512) :: fname
-    character(len=16) :: s1, s2
-    n = nx * ny * nz
-    nloc = c1 - c0
-    fname = trim(folder)//'sensit_'//SENSIT_SUFFIX(ip)//'_meta.txt'
-    print *, 'Reading the sensitivity metadata file ', trim(fname)
-    open(newunit=u, file=trim(fname), form='formatted', status='old', action='read', iostat=ios)
-    if (ios /= 0) call stop_msg('Error in opening the sensitivity metadata file! path='//trim(fname))
-    read(u, *) nxr, nyr, nzr, ndr
-    read(u, *) nbproc_sensit, precision_read, wtype
-    read(u, *) ctype, comp_error
-    read(u, *) ncm_read, ncd_read
-    read(u, *) nnz_total
-    close(u)
-    print *, 'COMPRESSION ERROR (read) =', comp_error
-    if (nxr /= nx .or. nyr /= ny .or. nzr /= nz .or. ndr /= nd .or. wtype /= dw_type .or. ncm_read /= nc .or. ncd_read /= ndc) &
-      call stop_msg('Sensitivity metadata file info does not match the Parfile!')                            ! :1001-1006
-    if (ctype /= comp_type) call stop_msg('Compression type is inconsistent!')
-    if (precision_read /= 4) call stop_msg('Matrix precision is not consistent!')
-    allocate(rowptr(nd * ndc + 1), cols(max(nnz_total, 1_c_int64_t)), vals(max(nnz_total, 1_c_int64_t)))
-    rowptr(1) = 0
-    pos = 0
-    r = 0
-    idata_glob = 0
-    do rank = 0, nbproc_sensit - 1
-      write(s1, '(I0)') nbproc_sensit
-      write(s2, '(I0)') rank
-      fname = trim(folder)//'sensit_'//SENSIT_SUFFIX(ip)//'_'//trim(s1)//'_'//trim(s2)
-      if (rank == 0) print *, 'Reading the sensitivity file (new) ', trim(fname)
-      open(newunit=u, file=trim(fname), status='old', access='stream', form='unformatted', action='read', convert='big_endian', &
-           iostat=ios)
-      if (ios /= 0) call stop_msg('Error in opening the sensitivity file! path='//trim(fname))
-      read(u) hdr
-      if (hdr(2) /= nd .or. hdr(3) /= n .or. hdr(4) /= rank .or. hdr(5) /= nbproc_sensit) &
-        call stop_msg('Wrong file header in read_sensitivity_kernel!')                                       ! :744-747
-      do i = 1, hdr(1)
-        idata_glob = idata_glob + 1
-        do d = 1, ndc
-          r = r + 1
-          do k = 1, nc
-            read(u) desc
-            if (desc(1) /= idata_glob) call stop_msg('Wrong data index in read_sensitivity_kernel!')
-            if (desc(3) /= k) call stop_msg('Wrong model component index in read_sensitivity_kernel!')
-            if (desc(4) /= d) call stop_msg('Wrong data component index in read_sensitivity_kernel!')
-            if (pos + desc(2) > nnz_total) call stop_msg('Wrong number of elements in read_sensitivity_kernel!')
-            if (desc(2) > 0) then
-              read(u) cols(pos + 1:pos + desc(2)), vals(pos + 1:pos + desc(2))
-              jj = pos
-              do j = pos + 1, pos + desc(2)
-                if (cols(j) <= c0 .or. cols(j) > c1) cycle
-                jj = jj + 1
-                cols(jj) = cols(j) - c0 + (k - 1) * nloc                                                     ! :832
-                vals(jj) = vals(j) * real(pw * dw(r), c_float)                                               ! :835-843
-              enddo
-              pos = jj
-            endif
-          enddo
-          rowptr(r + 1) = pos
-        enddo
-      enddo
-      close(u)
-    enddo
-    if (idata_glob /= nd .or. (nloc == n .and. pos /= nnz_total)) call stop_msg('The SENSIT files do not hold the whole kernel!')
-    print *, 'nnz_total (of the read kernel)  = ', nnz_total
-    if (tfx_matrix_upload_csr(ctx, int(nd * ndc, c_int64_t), int(nloc, c_int64_t) * nc, rowptr, cols, vals) /= 0) &
-      call stop_msg('tfx_matrix_upload_csr failed')
-    nnz_out = pos
-    print *, 'Finished reading the sensitivity kernel.'
-  end subroutine read_sensit_files
-
-end module tfx_host_sensit
-
-!=========================================================================================================
-program tomofastx_amd
-  use iso_c_binding
-  use tfx_binding
   use tfx_host_params
   use tfx_host_io
-  use tfx_host_sensit
-  use tfx_host_mpi
+  use tfx_reference_api
+  use tfx_host_mpi, only: allreduce_sum_dp, allgather_slices
   implicit none
+  private
+  public :: solve_problem_joint_gravmag
+
+contains
+
+!=========================================================================================================
+! Solves gravity AND magnetism joint problem (forward + inversion): src/problem_joint_gravmag.F90:65-613, same arguments.
+!=========================================================================================================
+subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
+  type(t_parameters_grav), intent(inout) :: gpar
+  type(t_parameters_mag), intent(inout) :: mpar
+  type(t_parameters_inversion), intent(inout) :: ipar
+  integer, intent(in) :: myrank, nbproc
 
   ! everything one problem (gravity or magnetic) owns; model vectors are component-major, data vectors d-fastest
   type t_prob
     logical :: on = .false.
     integer :: slot = 0, nd = 0, ndc = 1, nc = 1, nm = 0, ndt = 0, dtype = 1, col0 = 0, row0 = 0
     integer :: nml = 0                        ! local unknowns: nc * (cells of this rank)
-    real(dp) :: pw = 0.d0, rho = 0.d0, cost_data = 0.d0, cost_model = 0.d0, cost_admm = 0.d0, err_rows = 0.d0
+    real(dp) :: pw = 0.d0, rho = 0.d0, cost_data = 0.d0, cost_model = 0.d0, cost_admm = 0.d0
     real(dp), allocatable :: X1(:), X2(:), Y1(:), Y2(:), Z1(:), Z2(:), cw(:)
     real(dp), allocatable :: Xd(:), Yd(:), Zd(:), d_meas(:), d_calc(:)
     real(dp), allocatable :: damp_w(:)                  ! local model-damping weight per cell (model%damping_weight)
     real(dp), allocatable :: dw(:)                      ! data weight (ndc, nd) = 1 / data error, or 1 (data_gravmag.f90:243-279)
     real(dp), allocatable :: m(:), m_prior(:), m_synth(:), z_admm(:), u_admm(:), x0(:)
     real(dp), allocatable :: bnd(:, :), bnd_w(:)        ! ADMM intervals (2*nlithos, cell) and per-cell weight (model%bound_weight)
-    integer(c_int32_t), allocatable :: nnz_hist(:)      ! several ranks: per-cell entry counts of this kernel, all rows (sensit_nnz)
   end type t_prob
 
   type(t_par) :: par
   type(t_prob), target :: pr(2)
-  character(len=256) :: envv
-  integer :: envlen, envstat
-  character(len=256) :: arg, parfile
+  ! the reference's objects of this routine (problem_joint_gravmag.F90:71-77): data with its grid, model with its grid, and the
+  ! joint inversion's two matrices + right-hand side (joint_inverse_problem.F90:60-80)
+  type(t_data) :: data(2)
+  type(t_model) :: model(2)
+  type(t_sparse_matrix) :: matrix_sensit, matrix_cons
+  real(dp), allocatable :: b_RHS(:), delta_model(:), cw_loc(:, :)
+  integer, allocatable :: nelements_at_cpu(:)
+  integer(c_int64_t) :: nnz_part
+  real(dp) :: memory_fwd, memory_inv
+  logical :: SOLVE_PROBLEM(2), WAVELET_DOMAIN
+  integer :: line_start(2), param_shift(2), nl_cons, lc, problem_type_part
   ! output file prefixes (src/problem_joint_gravmag.F90:340-362, :554-555): 'grav_...' and 'mag_...'
   character(len=4) :: suffix(2) = (/'grav', 'mag '/)
-  integer :: ip, n, it, i, k, nblocks, ucost, narg, kadm, nprob, ntot, ndtot, c0, r0, ndev
+  integer :: ip, n, it, i, k, ucost, kadm, nprob, ntot, ndtot, c0, r0
   integer :: lc0
   logical :: spatial = .false.      ! gradient damping acts in space: LSQR unknowns are spatial, S goes through the device transform
   integer(c_int64_t), allocatable, target :: g_rowptr(:)
@@ -632,53 +451,33 @@ program tomofastx_amd
   real(c_float), allocatable, target :: g_vals(:)
   real(dp), allocatable, target :: g_rhs(:)
   real(dp), allocatable :: clust_mix(:, :), clust_cellw(:, :), clust_max(:)   ! mixtures (6, cluster), cell weights (cluster, cell), P_max
-  integer(c_int64_t) :: g_nrows, g_nnz
-  integer :: cb, ce, nloc, ra, rb                     ! this rank's cells (cb, ce], nloc = ce - cb; its share of the data rows
-  integer(c_int32_t), allocatable, target :: hist(:), hist_all(:), nel_at(:)
-  integer(c_int64_t), allocatable :: nnz_at(:)
+  integer(c_int64_t) :: g_nrows, g_nnz, e8
+  integer :: cb, ce, nloc                             ! this rank's cells (cb, ce], nloc = ce - cb
   integer, allocatable :: counts(:), displs(:)
   real(dp), allocatable, target :: xfull(:)
-  integer(c_int64_t) :: nnz_dummy
-  real(c_double) :: err_loc
-  real(dp), target :: mag_field(4)
-  type(c_ptr) :: mag_ptr
-  integer(c_int) :: iters
-  integer(c_int64_t) :: nnz
-  real(c_double) :: err_sum, r
-  type(c_ptr) :: ctx, dptr(4), rptr(4)
-  real(dp), allocatable, target :: b_data(:), x(:), rhs(:, :), work(:)
-  real(c_float), allocatable, target :: diag(:, :)
+  real(dp), allocatable, target :: work(:)
   real(dp) :: s1, s2, s3
-  integer :: cc
+  integer :: cc, row
 
-  ! ---- command line (src/parameters_init.f90:104-119)
-  parfile = ''
-  narg = command_argument_count()
-  i = 1
-  do while (i <= narg)
-    call get_command_argument(i, arg)
-    if (trim(arg) == '-p' .or. trim(arg) == '-j') then
-      if (i + 1 > narg) call stop_msg('UNKNOWN Parfile! Use -p <Parfile_path>')
-      call get_command_argument(i + 1, parfile)
-      i = i + 1
-    endif
-    i = i + 1
-  enddo
-  if (len_trim(parfile) == 0) call stop_msg('UNKNOWN Parfile! Use -p <Parfile_path>')
-  ! one process per GPU under `mpiexec -n P`; ranks other than 0 stay silent (the reference prints from rank 0 only)
-  call host_mpi_init()
+  par = host_par
   io_rank = myrank == 0
-  if (myrank /= 0) open(unit=6, file='/dev/null', status='old', action='write')
-  print *, 'Started Tomofast-x (MI355X host), Parfile = ', trim(parfile)
-  if (nbproc > 1) print *, 'Number of ranks (one GPU each) =', nbproc
-  call read_parfile(parfile, par)
+  if (myrank == 0) print *, 'Solving problem grav/mag.'
+  memory_fwd = 0.d0
+  memory_inv = 0.d0
+  g_nrows = 0
+  g_nnz = 0
 
   ! ---- which problems (src/problem_joint_gravmag.F90:108-112): both weights non-zero = joint inversion
-  pr(1)%on = par%pw(1) /= 0.d0
-  pr(2)%on = par%pw(2) /= 0.d0
+  do i = 1, 2
+    SOLVE_PROBLEM(i) = (ipar%problem_weight(i) /= 0.d0)
+    if (myrank == 0) print *, 'SOLVE_PROBLEM(', i, ') = ', SOLVE_PROBLEM(i)
+  enddo
+  pr(1)%on = SOLVE_PROBLEM(1)
+  pr(2)%on = SOLVE_PROBLEM(2)
   nprob = count(pr%on)
   if (nprob == 0) call stop_msg('Both problem weights are zero!')
-  if (par%dw_type /= 1 .and. par%dw_type /= 2) call stop_msg('forward.depthWeighting.type must be 1 or 2 in this host.')
+  if (par%dw_type /= 1 .and. par%dw_type /= 2) &       ! type 3 (weights_gravmag.f90:140-165) needs the whole kernel on the host
+    call stop_msg('forward.depthWeighting.type must be 1 or 2: type 3 (sensitivity-based) is not offered by this host.')
   if (par%w_cross /= 0.d0) then                                   ! structural coupling (joint_inverse_problem.F90:189-198, :529-541)
     if (par%pw(1) == 0.d0 .or. par%pw(2) == 0.d0) call stop_msg('The cross-gradient constraint needs both problems (joint inversion).')
     if (par%vec_field_type > 0) call stop_msg('Cross-gradient with a given vector field is not supported by this host.')
@@ -688,7 +487,7 @@ program tomofastx_amd
   if (par%apply_local_damp > 0) spatial = .true.                 ! local damping weights act in space (:189-198)
   if (par%norm_power /= 2.d0) spatial = .true.                   ! Lp damping acts in space (joint_inverse_problem.F90:189-198)
   if (par%admm > 0 .and. par%admm_bound_type /= 1 .and. par%admm_bound_type /= 2) call stop_msg('Unknown inversion.admm.boundType!')
-  if (par%admm > 0 .and. par%admm_bound_type == 2) spatial = .true.      ! local bounds / weights (joint_inverse_problem.F90:189-198)
+  if (par%admm_bound_type /= 1) spatial = .true.       ! local bounds / weights, whether ADMM is on or not (joint_inverse_problem.F90:189-198)
   if (par%sensit_read < 0 .or. par%sensit_read > 2) call stop_msg('sensit.readFromFiles must be 0, 1 or 2.')
   if (par%admm > 0 .and. par%admm_bound_type == 1 .and. .not. allocated(par%bounds)) call stop_msg('Global bounds are not defined!')
   n = par%nx * par%ny * par%nz
@@ -747,112 +546,113 @@ program tomofastx_amd
       pr(ip)%bnd = pr(ip)%bnd * par%model_units_mult(ip)
     endif
   enddo
-  allocate(b_data(ndtot), x(ntot), xfull(ntot), rhs(ntot, 4), diag(ntot, 4), work(ntot))
-  if (nprob == 2) print *, 'JOINT inversion: two sensitivity kernels in one system.'
-  print *, 'WAVELET_DOMAIN =', .not. spatial
+  allocate(xfull(ntot), work(ntot))
+  if (nprob == 2 .and. myrank == 0) print *, 'JOINT inversion: two sensitivity kernels in one system.'
+  WAVELET_DOMAIN = .not. spatial
+  if (myrank == 0) print *, 'WAVELET_DOMAIN =', WAVELET_DOMAIN
 
-  ndev = tfx_device_count()
-  if (ndev <= 0) call stop_msg('No HIP device visible - the MI355X path has no CPU fallback.')
-  call tfx_check(tfx_create(int(mod(myrank, ndev), c_int), c_null_ptr, ctx), 'tfx_create')
-  cb = 0
-  ce = n
-  allocate(counts(nbproc), displs(nbproc))
-  counts = n
-  displs = 0
-  if (nbproc > 1) then
-    hook_ctx = ctx
-    call tfx_check(tfx_set_allreduce(ctx, c_funloc(allreduce_hook), c_null_ptr, int(myrank, c_int), int(nbproc, c_int)), &
-                   'tfx_set_allreduce')
-    ! ---- column partition (calculate_new_partitioning, sensitivity_gravmag.F90:573-640): per-cell non-zero counts of my share
-    ! of the data rows of every kernel, summed over ranks and problems, then the reference's greedy nnz-balancing rule
-    allocate(hist(n), hist_all(n), nel_at(nbproc), nnz_at(nbproc))
-    hist_all = 0
-    if (par%sensit_read == 1) then
-      call read_sensit_nnz_files()
-    else
-      do ip = 1, 2
-        if (.not. pr(ip)%on) cycle
-        call load_inputs(ip)
-        call depth_weight(ip)
-        hist = 0
-        if (exchange_ok(ip)) then
-          ! row-parallel build: my row blocks (of 2048 data) with ALL their columns stay on the device; relayout after the partition
-          call my_row_blocks(pr(ip)%nd, ra, rb)
-          pr(ip)%err_rows = 0.d0
-          if (rb > ra) call build_rowstore(ip, ra, rb, pr(ip)%err_rows, c_loc(hist))
-        else
-          ra = (pr(ip)%nd / nbproc) * myrank                     ! calculate_nelements_at_cpu (parallel_tools.f90:46-63)
-          rb = ra + pr(ip)%nd / nbproc
-          if (myrank == nbproc - 1) rb = pr(ip)%nd
-          if (rb > ra) call build_kernel(ip, ra, rb, 0, 0, nnz_dummy, err_loc, c_loc(hist))
-        endif
-        hist_all = hist_all + hist
-        allocate(pr(ip)%nnz_hist(n))
-        pr(ip)%nnz_hist = hist
-        call allreduce_sum_i32(pr(ip)%nnz_hist, n)
-      enddo
-      call allreduce_sum_i32(hist_all, n)
-    endif
-    call tfx_check(tfx_partition_columns(hist_all, int(n, c_int64_t), int(nbproc, c_int), nel_at, nnz_at), 'calculate_new_partitioning')
-    print *, 'nelements_at_cpu =', nel_at
-    print *, 'nnz_at_cpu =', nnz_at
-    cb = sum(nel_at(1:myrank))
-    ce = cb + nel_at(myrank + 1)
-    counts = nel_at
-    displs(1) = 0
-    do i = 2, nbproc
-      displs(i) = displs(i - 1) + counts(i - 1)
+  ! (I) MODEL GRID, (II) DATA (:135-162): the reference's objects, filled from the files
+  if (myrank == 0) print *, '(I) MODEL GRID ALLOCATION.'
+  do ip = 1, 2
+    if (.not. pr(ip)%on) cycle
+    call model(ip)%grid_full%allocate(ipar%nx, ipar%ny, ipar%nz, par%z_axis_dir, myrank)
+    call read_model_grid(par%grid_file(ip), n, model(ip)%grid_full%X1, model(ip)%grid_full%X2, model(ip)%grid_full%Y1, &
+                         model(ip)%grid_full%Y2, model(ip)%grid_full%Z1, model(ip)%grid_full%Z2)
+    pr(ip)%X1 = model(ip)%grid_full%X1; pr(ip)%X2 = model(ip)%grid_full%X2       ! (the constraint builders read the spacings)
+    pr(ip)%Y1 = model(ip)%grid_full%Y1; pr(ip)%Y2 = model(ip)%grid_full%Y2
+    pr(ip)%Z1 = model(ip)%grid_full%Z1; pr(ip)%Z2 = model(ip)%grid_full%Z2
+  enddo
+  if (myrank == 0) print *, '(II) DATA ALLOCATION.'
+  do ip = 1, 2
+    if (.not. pr(ip)%on) cycle
+    call data(ip)%initialize(pr(ip)%nd, pr(ip)%ndc, par%data_units_mult(ip), par%z_axis_dir, myrank)
+    call read_data(par%data_grid_file(ip), pr(ip)%nd, pr(ip)%ndc, data(ip)%X, data(ip)%Y, data(ip)%Z, data(ip)%val_meas)
+    data(ip)%val_meas = data(ip)%val_meas * par%data_units_mult(ip)
+    if (par%use_error(ip) == 1) call read_data_error(par%error_file(ip), pr(ip)%nd, pr(ip)%ndc, par%data_units_mult(ip), data(ip)%weight)
+    pr(ip)%Xd = data(ip)%X; pr(ip)%Yd = data(ip)%Y; pr(ip)%Zd = data(ip)%Z
+    pr(ip)%d_meas = reshape(data(ip)%val_meas, (/pr(ip)%ndt/))
+    pr(ip)%dw = reshape(data(ip)%weight, (/pr(ip)%ndt/))
+  enddo
+
+  ! (III) SENSITIVITY MATRIX CALCULATION (:164-215)
+  if (myrank == 0) print *, '(III) SENSITIVITY MATRIX CALCULATION.'
+  if (gpar%sensit_read == 0) then
+    do ip = 1, 2
+      if (.not. pr(ip)%on) cycle
+      if (ip == 1) then
+        call calculate_depth_weight(gpar, pr(ip)%cw, model(ip)%grid_full, data(ip), myrank, nbproc)
+      else
+        call calculate_depth_weight(mpar, pr(ip)%cw, model(ip)%grid_full, data(ip), myrank, nbproc)
+      endif
+      pr(ip)%cw = ipar%column_weight_multiplier(ip) * pr(ip)%cw                    ! :178
+      call apply_local_depth_weighting(ip)                                         ! :181-182
     enddo
   endif
-  nloc = ce - cb
+  if (gpar%sensit_read == 0 .or. gpar%sensit_read == 2) then
+    do ip = 1, 2
+      if (.not. pr(ip)%on) cycle
+      if (gpar%sensit_read == 2) call read_depth_weight(ip)                         ! :189-193
+      if (ip == 1) then
+        call calculate_and_write_sensit(gpar, model(ip)%grid_full, data(ip), pr(ip)%cw, memory_fwd, myrank, nbproc)
+      else
+        call calculate_and_write_sensit(mpar, model(ip)%grid_full, data(ip), pr(ip)%cw, memory_fwd, myrank, nbproc)
+      endif
+    enddo
+  endif
+  ! new partitioning for the load balancing (:205-221)
+  allocate(nelements_at_cpu(nbproc), counts(nbproc), displs(nbproc))
+  problem_type_part = merge(3, merge(1, 2, pr(1)%on), nprob == 2)
+  if (problem_type_part == 2) then
+    call calculate_new_partitioning(mpar, nnz_part, nelements_at_cpu, problem_type_part, myrank, nbproc)
+  else
+    call calculate_new_partitioning(gpar, nnz_part, nelements_at_cpu, problem_type_part, myrank, nbproc)
+  endif
+  gpar%nelements = nelements_at_cpu(myrank + 1)
+  mpar%nelements = nelements_at_cpu(myrank + 1)
+  ipar%nelements = nelements_at_cpu(myrank + 1)
+  cb = sum(nelements_at_cpu(1:myrank))
+  nloc = nelements_at_cpu(myrank + 1)
+  ce = cb + nloc
+  counts = nelements_at_cpu
+  displs(1) = 0
+  do i = 2, nbproc
+    displs(i) = displs(i - 1) + counts(i - 1)
+  enddo
   do ip = 1, 2
     if (pr(ip)%on) pr(ip)%nml = pr(ip)%nc * nloc
   enddo
+  ! matrix partitioning of the joint system (joint_inverse_problem.F90:712-739): rows of problem 2 follow problem 1's, its
+  ! columns follow problem 1's local unknowns
+  line_start = 0
+  param_shift = 0
+  if (pr(1)%on .and. pr(2)%on) then
+    line_start(2) = pr(1)%ndt
+    param_shift(2) = pr(1)%nml
+  endif
+
+  ! (IV) MATRIX ALLOCATION + READING THE SENSITIVITY KERNEL (:227-248)
+  if (myrank == 0) print *, '(IV) MATRIX ALLOCATION.'
+  allocate(cw_loc(nloc, 2))
+  do ip = 1, 2
+    if (.not. pr(ip)%on) cycle
+    if (ip == 1) then
+      call read_sensitivity_kernel(gpar, matrix_sensit, cw_loc(:, ip), ipar%problem_weight(ip), data(ip)%weight, ip, myrank, nbproc, &
+                                   nelements_at_cpu)
+    else
+      call read_sensitivity_kernel(mpar, matrix_sensit, cw_loc(:, ip), ipar%problem_weight(ip), data(ip)%weight, ip, myrank, nbproc, &
+                                   nelements_at_cpu)
+    endif
+    if (gpar%sensit_read == 1) then                    ! the full weight comes from the SENSIT folder (:920-970)
+      call read_depth_weight(ip)
+    endif
+    call model(ip)%initialize(nloc, pr(ip)%nc, n, myrank)
+    model(ip)%grid_full%nx = ipar%nx; model(ip)%grid_full%ny = ipar%ny; model(ip)%grid_full%nz = ipar%nz
+  enddo
+  call matrix_sensit%finalize(myrank)
+  allocate(delta_model(matrix_sensit%get_ncolumns()))
 
   do ip = 1, 2
     if (.not. pr(ip)%on) cycle
-    call tfx_check(tfx_select_problem(ctx, pr(ip)%slot), 'tfx_select_problem')
-    if (nbproc == 1 .or. par%sensit_read == 1) then
-      call load_inputs(ip)
-      call depth_weight(ip)
-    else
-      call tfx_check(tfx_set_grid(ctx, par%nx, par%ny, par%nz, pr(ip)%X1, pr(ip)%X2, pr(ip)%Y1, pr(ip)%Y2, pr(ip)%Z1, pr(ip)%Z2), &
-                     'tfx_set_grid')
-    endif
-
-    ! ---- (III) sensitivity kernel (:197-248): built on the device (this rank's column range), or re-loaded from SENSIT files
-    if (par%sensit_read == 1) then
-      call read_sensit_files(ctx, par%sensit_path, ip, par%nx, par%ny, par%nz, pr(ip)%nd, pr(ip)%ndc, pr(ip)%nc, par%dw_type, &
-                             par%comp_type, pr(ip)%pw, nnz, cb, ce, pr(ip)%dw)
-      err_sum = 0.d0
-    else
-      if (nbproc > 1 .and. exchange_ok(ip)) then
-        call relayout_rowstore(ip, nnz)
-        err_sum = pr(ip)%err_rows
-        call allreduce_sum_dp_scalar(err_sum)
-      else
-        call build_kernel(ip, 0, pr(ip)%nd, cb, ce, nnz, err_sum, c_null_ptr)
-      endif
-      ! the reference always writes the kernel (calculate_and_write_sensit); TFX_WRITE_SENSIT=0 skips the download + write
-      call get_environment_variable('TFX_WRITE_SENSIT', envv, envlen, envstat)
-      if (nbproc == 1 .and. .not. (envstat == 0 .and. envlen > 0 .and. envv(1:1) == '0')) &
-        call write_sensit_files(ctx, trim(par%path_output)//'/SENSIT', ip, par%nx, par%ny, par%nz, pr(ip)%nd, pr(ip)%ndc, pr(ip)%nc, &
-                                par%dw_type, par%comp_type, err_sum / dble(pr(ip)%nd * pr(ip)%ndc * pr(ip)%nc), pr(ip)%pw, pr(ip)%cw, &
-                                pr(ip)%dw)
-    endif
-    if (nbproc > 1) then                      ! totals over the column ranges (error sums are per line, the same on every rank)
-      s1 = dble(nnz)
-      call allreduce_sum_dp_scalar(s1)
-      nnz = nint(s1, c_int64_t)
-    endif
-    if (nbproc > 1 .and. par%sensit_read /= 1 .and. exchange_ok(ip) .and. write_sensit_wanted() .and. io_rank) &
-      call write_sensit_meta_files(trim(par%path_output)//'/SENSIT', ip, par%nx, par%ny, par%nz, pr(ip)%nd, pr(ip)%ndc, pr(ip)%nc, &
-                                   par%dw_type, par%comp_type, err_sum / dble(pr(ip)%nd * pr(ip)%ndc * pr(ip)%nc), nnz, nbproc, &
-                                   pr(ip)%nnz_hist, pr(ip)%cw)
-    print *, 'nnz_total = ', nnz
-    print *, 'COMPRESSION RATE = ', dble(nnz) / dble(n) / dble(pr(ip)%nd) / dble(pr(ip)%nc) / dble(pr(ip)%ndc)
-    print *, 'COMPRESSION ERROR, r = ', err_sum / dble(pr(ip)%nd * pr(ip)%ndc * pr(ip)%nc)
-
     ! ---- data from the synthetic model (:318-345)
     if (par%use_synth(ip) > 0) then
       call read_model_values(par%synth_file(ip), n, pr(ip)%nc, pr(ip)%m_synth)
@@ -889,8 +689,6 @@ program tomofastx_amd
     pr(ip)%z_admm = 0.d0
     pr(ip)%u_admm = 0.d0
   enddo
-  call tfx_check(tfx_select_problem(ctx, 0_c_int), 'tfx_select_problem')
-
   call make_dir(par%path_output)
   if (io_rank) then
     open(newunit=ucost, file=trim(par%path_output)//'/costs.txt', status='replace', action='write')
@@ -908,106 +706,122 @@ program tomofastx_amd
     print *, '======================================================='
     print *, 'Iteration =', it
     print *, '======================================================='
-    nblocks = 0
+    ! ---- general constraint rows first (their count sizes the system): gradient damping, cross-gradient, clustering
+    g_nrows = 0
+    if (spatial) then
+      call build_gradient_damping()
+      if (par%w_cross /= 0.d0) call build_cross_gradient()
+      if (any(par%w_clust /= 0.d0)) call build_clustering()
+    endif
+    ! ---- the constraint matrix and the right-hand side (joint_inverse_problem.F90:393-545): one diagonal block of
+    ! nelements_total rows per damped model component and per ADMM term, then the general rows
+    nl_cons = int(g_nrows)
+    do ip = 1, 2
+      if (.not. pr(ip)%on) cycle
+      if (par%alpha(ip) /= 0.d0) nl_cons = nl_cons + n * pr(ip)%nc
+      if (par%admm > 0) nl_cons = nl_cons + n
+    enddo
+    if (.not. allocated(b_RHS)) then
+      allocate(b_RHS(ndtot + nl_cons))
+      e8 = int(nl_cons, c_int64_t)
+      if (allocated(g_cols)) e8 = e8 + size(g_cols, kind=c_int64_t)
+      call matrix_cons%initialize(nl_cons, matrix_sensit%get_ncolumns(), e8, myrank)
+    endif
+    if (size(b_RHS) /= ndtot + nl_cons) call stop_msg('The number of constraint rows changed between major iterations!')
+    call matrix_cons%reset()
+    b_RHS = 0.d0
+    lc = ndtot                                                     ! rows of the constraints start after the data rows
     do ip = 1, 2
       if (.not. pr(ip)%on) cycle
       c0 = pr(ip)%col0
       r0 = pr(ip)%row0
-      lc0 = 0
-      if (ip == 2 .and. pr(1)%on) lc0 = pr(1)%nml               ! this rank's unknowns: [m1 cells (cb, ce]; m2 cells (cb, ce]]
+      lc0 = param_shift(ip)                                        ! this rank's unknowns: [m1 cells (cb, ce]; m2 cells (cb, ce]]
       ! residuals (:666-675; data weight 1) and the right-hand side pw * residuals (joint_inverse_problem.F90:379-387)
-      b_data(r0 + 1:r0 + pr(ip)%ndt) = pr(ip)%pw * (pr(ip)%dw * (pr(ip)%d_meas - pr(ip)%d_calc))
-      if (par%alpha(ip) /= 0.d0) then                              ! damping.F90:97-234, one block per problem and component
-        nblocks = nblocks + 1
+      b_RHS(r0 + 1:r0 + pr(ip)%ndt) = pr(ip)%pw * (pr(ip)%dw * (pr(ip)%d_meas - pr(ip)%d_calc))
+      if (par%alpha(ip) /= 0.d0) then                              ! damping%add, damping.F90:97-234, one block per model component
         work(1:pr(ip)%nm) = 0.d0
         do k = 1, pr(ip)%nc                                        ! (joint_inverse_problem.F90:456-463)
           call unweight(ip, pr(ip)%m((k - 1) * n + 1:k * n) - pr(ip)%m_prior((k - 1) * n + 1:k * n), work((k - 1) * n + 1:k * n))
         enddo
         if (.not. spatial) call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)       ! damping.F90:135-150
-        ! value = alpha * pw [* Lp multiplier] [* local weight] in double, ONE cast to the matrix precision (damping.F90:160-173,
+        ! value = alpha * pw [* Lp multiplier] [* local weight] in double, ONE cast to the matrix precision in add (damping.F90:160-173,
         ! sparse_matrix.f90:226); right-hand side -alpha * pw * diff [* Lp multiplier] [* local weight] (:218-228)
-        diag(:, nblocks) = 0.0
-        rhs(:, nblocks) = 0.d0
-        call to_local(ip, work, rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks))
         do k = 1, pr(ip)%nc
-          do i = 1, nloc
-            cc = lc0 + (k - 1) * nloc + i
-            s1 = par%alpha(ip) * pr(ip)%pw                                ! matrix value
-            s2 = -par%alpha(ip) * pr(ip)%pw * rhs(cc, nblocks)            ! right-hand side
-            if (par%norm_power /= 2.d0) then                             ! Lp norm multiplier (:250-262)
-              s3 = 1.d0
-              if (rhs(cc, nblocks) /= 0.d0) s3 = (abs(rhs(cc, nblocks)))**(par%norm_power / 2.d0 - 1.d0)
-              s1 = s1 * s3
-              s2 = s2 * s3
+          do i = 1, n
+            if (i > cb .and. i <= ce) then
+              s3 = work((k - 1) * n + i)
+              s1 = par%alpha(ip) * pr(ip)%pw                              ! matrix value
+              s2 = -par%alpha(ip) * pr(ip)%pw * s3                        ! right-hand side
+              if (par%norm_power /= 2.d0) then                           ! Lp norm multiplier (:250-262)
+                if (s3 /= 0.d0) then
+                  s3 = (abs(s3))**(par%norm_power / 2.d0 - 1.d0)
+                else
+                  s3 = 1.d0
+                endif
+                s1 = s1 * s3
+                s2 = s2 * s3
+              endif
+              if (par%apply_local_damp > 0) then                         ! local weight = local alpha (:168-171, :225-228)
+                s1 = s1 * pr(ip)%damp_w(i)
+                s2 = s2 * pr(ip)%damp_w(i)
+              endif
+              call matrix_cons%add(s1, lc0 + (k - 1) * nloc + (i - cb), myrank)
+              b_RHS(lc + i) = s2
             endif
-            if (par%apply_local_damp > 0) then                           ! local weight = local alpha (:168-171, :225-228)
-              s1 = s1 * pr(ip)%damp_w(cb + i)
-              s2 = s2 * pr(ip)%damp_w(cb + i)
-            endif
-            diag(cc, nblocks) = real(s1, c_float)
-            rhs(cc, nblocks) = s2
+            call matrix_cons%new_row(myrank)
           enddo
+          lc = lc + n
         enddo
-        dptr(nblocks) = c_loc(diag(1, nblocks))
-        rptr(nblocks) = c_loc(rhs(1, nblocks))
       endif
-      if (par%admm > 0) then                                       ! joint_inverse_problem.F90:497-527
-        nblocks = nblocks + 1
+    enddo
+    do ip = 1, 2                                                     ! ***** ADMM method ***** (joint_inverse_problem.F90:490-527)
+      if (.not. pr(ip)%on) cycle
+      lc0 = param_shift(ip)
+      if (par%admm > 0) then
         kadm = merge(1, 3, pr(ip)%nc == 1)                         ! vector model: bounds on Mz (:499-506)
         call iterate_admm_arrays(n, par%nlithos, pr(ip)%bnd, pr(ip)%m((kadm - 1) * n + 1:kadm * n), pr(ip)%z_admm, &
                                  pr(ip)%u_admm, pr(ip)%x0)
         work(1:pr(ip)%nm) = 0.d0
         call unweight(ip, pr(ip)%m((kadm - 1) * n + 1:kadm * n) - pr(ip)%x0, work((kadm - 1) * n + 1:kadm * n))
         if (.not. spatial) call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
-        diag(:, nblocks) = 0.0
-        diag(lc0 + (kadm - 1) * nloc + 1:lc0 + kadm * nloc, nblocks) = real(pr(ip)%rho * pr(ip)%pw * pr(ip)%bnd_w(cb + 1:ce), c_float)
-        rhs(:, nblocks) = 0.d0
-        call to_local(ip, work, rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks))
-        rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks) = -pr(ip)%rho * pr(ip)%pw * rhs(lc0 + 1:lc0 + pr(ip)%nml, nblocks)
-        rhs(lc0 + (kadm - 1) * nloc + 1:lc0 + kadm * nloc, nblocks) = rhs(lc0 + (kadm - 1) * nloc + 1:lc0 + kadm * nloc, nblocks) * &
-                                                                      pr(ip)%bnd_w(cb + 1:ce)      ! local weight = local rho (damping.F90:177-180, :264-267)
-        dptr(nblocks) = c_loc(diag(1, nblocks))
-        rptr(nblocks) = c_loc(rhs(1, nblocks))
+        do i = 1, n
+          if (i > cb .and. i <= ce) then                             ! local weight = local rho (damping.F90:177-180, :264-267)
+            call matrix_cons%add(pr(ip)%rho * pr(ip)%pw * pr(ip)%bnd_w(i), lc0 + (kadm - 1) * nloc + (i - cb), myrank)
+            b_RHS(lc + i) = -pr(ip)%rho * pr(ip)%pw * work((kadm - 1) * n + i) * pr(ip)%bnd_w(i)
+          endif
+          call matrix_cons%new_row(myrank)
+        enddo
+        lc = lc + n
         s1 = sum((pr(ip)%z_admm - pr(ip)%m((kadm - 1) * n + 1:kadm * n))**2)
         s2 = sum(pr(ip)%z_admm**2)
         pr(ip)%cost_admm = 0.d0
         if (s2 /= 0.d0) pr(ip)%cost_admm = sqrt(s1 / s2)            ! costs.f90:38-69
-        print *, 'ADMM cost |x - z| / |z| =', pr(ip)%cost_admm
+        if (myrank == 0) print *, 'ADMM cost |x - z| / |z| =', pr(ip)%cost_admm
       endif
     enddo
-    if (spatial) then
-      call build_gradient_damping()
-      if (par%w_cross /= 0.d0) call build_cross_gradient()
-      if (any(par%w_clust /= 0.d0)) call build_clustering()
-      if (g_nrows > 0) call tfx_check(tfx_cons_upload_csr(ctx, g_nrows, g_rowptr, g_cols, g_vals, g_rhs), 'damping_gradient_add')
-      call tfx_check(tfx_lsqr_set_wavelet_domain(ctx, 0_c_int, par%nx, par%ny, par%nz, par%comp_type), 'WAVELET_DOMAIN')
-      if (nbproc > 1) then                                         ! every product with S gathers the slices of all ranks
-        k = 0
-        do ip = 1, 2
-          if (pr(ip)%on) k = k + pr(ip)%nc
-        enddo
-        call tfx_check(tfx_lsqr_set_partition(ctx, int(cb, c_int64_t), int(k, c_int)), 'tfx_lsqr_set_partition')
-      endif
-    endif
-    call tfx_check(tfx_lsqr_solve(ctx, par%nminor, par%rmin, par%gamma, par%target_misfit, b_data, nblocks, dptr, rptr, x, &
-                                  iters, r), 'lsqr_solve_sensit')
-    if (spatial) then
-      call tfx_check(tfx_lsqr_set_wavelet_domain(ctx, 1_c_int, par%nx, par%ny, par%nz, par%comp_type), 'WAVELET_DOMAIN')
-      call tfx_check(tfx_cons_clear(ctx), 'tfx_cons_clear')
-    endif
-    print *, 'Finished lsqr solver, r =', r, ' iter =', iters
+    do row = 1, int(g_nrows)                                         ! the builders' rows (columns of this rank, rows replicated)
+      do e8 = g_rowptr(row) + 1, g_rowptr(row + 1)
+        call matrix_cons%add(real(g_vals(e8), dp), int(g_cols(e8)), myrank)
+      enddo
+      call matrix_cons%new_row(myrank)
+      b_RHS(lc + row) = g_rhs(row)
+    enddo
+    call matrix_cons%finalize(myrank)
+    ! ---- parallel sparse inversion (joint_inverse_problem.F90:546-552)
+    delta_model = 0.d0
+    call lsqr_solve_sensit(size(b_RHS), size(delta_model), ipar%niter, ipar%rmin, ipar%gamma, ipar%target_misfit, &
+                           matrix_sensit, matrix_cons, b_RHS, delta_model, SOLVE_PROBLEM, ipar%nelements, ipar%nx, ipar%ny, ipar%nz, &
+                           ipar%nmodel_components, ipar%compression_type, WAVELET_DOMAIN, memory_inv, myrank, nbproc)
     call write_costs(it - 1)                                       ! :519-528 (costs of the previous iteration)
     do ip = 1, 2
       if (.not. pr(ip)%on) cycle
       c0 = pr(ip)%col0
-      lc0 = 0
-      if (ip == 2 .and. pr(1)%on) lc0 = pr(1)%nml
+      lc0 = param_shift(ip)
       do k = 1, pr(ip)%nc                                          ! slices of all ranks -> the full update (wavelet_utils.F90:37-72)
-        call allgather_slices(x(lc0 + (k - 1) * nloc + 1:lc0 + k * nloc), nloc, xfull(c0 + (k - 1) * n + 1:c0 + k * n), counts, displs)
+        call allgather_slices(delta_model(lc0 + (k - 1) * nloc + 1:lc0 + k * nloc), nloc, xfull(c0 + (k - 1) * n + 1:c0 + k * n), counts, displs)
+        if (ipar%compression_type > 0 .and. WAVELET_DOMAIN) &      ! :559-567
+          call inverse_wavelet(xfull(c0 + (k - 1) * n + 1:c0 + k * n), ipar%nx, ipar%ny, ipar%nz, ipar%compression_type)
       enddo
-      if (par%comp_type > 0 .and. .not. spatial) &                 ! :559-567
-        call tfx_check(tfx_wavelet(ctx, xfull(c0 + 1:c0 + pr(ip)%nm), par%nx, par%ny, par%nz, int(pr(ip)%nc, c_int64_t), &
-                                   par%comp_type, 2_c_int), 'inverse_wavelet')
       do k = 1, pr(ip)%nc
         pr(ip)%m((k - 1) * n + 1:k * n) = pr(ip)%m((k - 1) * n + 1:k * n) + xfull(c0 + (k - 1) * n + 1:c0 + k * n) * pr(ip)%cw   ! :570, :500
       enddo
@@ -1032,9 +846,8 @@ program tomofastx_amd
     call write_model(par%path_output, trim(suffix(ip))//'_final_model_full.txt', n, pr(ip)%nc, pr(ip)%m, par%model_units_mult(ip))
     print *, 'model min / max =', minval(pr(ip)%m), maxval(pr(ip)%m)
   enddo
-  call tfx_check(tfx_destroy(ctx), 'tfx_destroy')
-  print *, 'THE END.'
-  call host_mpi_finalize()
+  if (myrank == 0) print *, 'MEMORY USED (device matrix) [GB] =', memory_fwd
+  call tfx_api_finalize()
 
 contains
 
@@ -1432,332 +1245,64 @@ contains
     v = a(1)
   end subroutine allreduce_sum_dp_scalar
 
-  ! (I) model grid and data of problem jp (problem_joint_gravmag.F90:140-157), grid to the device
-  subroutine load_inputs(jp)
-    integer, intent(in) :: jp
-    call read_model_grid(par%grid_file(jp), n, pr(jp)%X1, pr(jp)%X2, pr(jp)%Y1, pr(jp)%Y2, pr(jp)%Z1, pr(jp)%Z2)
-    call read_data(par%data_grid_file(jp), pr(jp)%nd, pr(jp)%ndc, pr(jp)%Xd, pr(jp)%Yd, pr(jp)%Zd, pr(jp)%d_meas)
-    pr(jp)%d_meas = pr(jp)%d_meas * par%data_units_mult(jp)
-    if (par%use_error(jp) == 1) call read_data_error(par%error_file(jp), pr(jp)%nd, pr(jp)%ndc, par%data_units_mult(jp), pr(jp)%dw)
-    call tfx_check(tfx_set_grid(ctx, par%nx, par%ny, par%nz, pr(jp)%X1, pr(jp)%X2, pr(jp)%Y1, pr(jp)%Y2, pr(jp)%Z1, pr(jp)%Z2), &
-                   'tfx_set_grid')
-  end subroutine load_inputs
-
-  ! (II) depth weight (:174-178, :189-193): computed, or read from the SENSIT folder
-  subroutine depth_weight(jp)
+  ! apply_local_depth_weighting, weights_gravmag.f90:255-309
+  subroutine apply_local_depth_weighting(jp)
     integer, intent(in) :: jp
     real(dp), allocatable :: lw(:)
     integer :: p
-    if (par%sensit_read == 0) then
-      print *, 'Calculating the depth weight, type = ', par%dw_type
-      if (par%dw_type == 1) then
-        call tfx_check(tfx_column_weight_type1(ctx, par%dw_power(jp), par%dw_Z0(jp), par%cwm(jp), pr(jp)%cw), 'calculate_depth_weight')
+    if (par%apply_local_dw <= 0) return
+    allocate(lw(n))
+    call read_cell_values(par%local_dw_file(jp), n, lw, 'local depth weights')
+    do p = 1, n
+      if (lw(p) /= 0.d0) then
+        pr(jp)%cw(p) = pr(jp)%cw(p) / lw(p)
       else
-        call tfx_check(tfx_column_weight_type2(ctx, int(pr(jp)%nd, c_int64_t), pr(jp)%Xd, pr(jp)%Yd, pr(jp)%Zd, par%dw_power(jp), &
-                                               par%dw_beta(jp), par%cwm(jp), pr(jp)%cw), 'calculate_depth_weight')
+        pr(jp)%cw(p) = 0.d0
       endif
-      if (par%apply_local_dw > 0) then                             ! apply_local_depth_weighting, weights_gravmag.f90:255-309
-        allocate(lw(n))
-        call read_cell_values(par%local_dw_file(jp), n, lw, 'local depth weights')
-        do p = 1, n
-          if (lw(p) /= 0.d0) then
-            pr(jp)%cw(p) = pr(jp)%cw(p) / lw(p)
-          else
-            pr(jp)%cw(p) = 0.d0
-          endif
-        enddo
-        deallocate(lw)
-      endif
-    else
-      call read_weight_file(par%sensit_path, jp, n, pr(jp)%cw)
-    endif
-  end subroutine depth_weight
+    enddo
+    deallocate(lw)
+  end subroutine apply_local_depth_weighting
 
-  ! the kernel of problem jp for the data rows (row_a, row_b] and the cells (col_a, col_b] into slot pr(jp)%slot
-  ! (col_a = col_b = 0: nothing is stored, only the per-cell non-zero counts are returned in hist_ptr)
-  subroutine build_kernel(jp, row_a, row_b, col_a, col_b, nnz_k, err_k, hist_ptr)
-    integer, intent(in) :: jp, row_a, row_b, col_a, col_b
-    integer(c_int64_t), intent(out) :: nnz_k
-    real(c_double), intent(out) :: err_k
-    type(c_ptr), intent(in) :: hist_ptr
-    type(c_ptr) :: mptr
-    mptr = c_null_ptr
-    if (jp == 1) then
-      print *, 'Calculating GRAVITY sensitivity kernel...'
-    else
-      print *, 'Calculating MAGNETIC sensitivity kernel...'
-      mag_field = (/par%mag_incl, par%mag_decl, par%mag_xaxis_decl, par%mag_intensity/)
-      mptr = c_loc(mag_field)
-    endif
-    call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
-    call tfx_check(tfx_build_kernel(ctx, jp, pr(jp)%dtype, pr(jp)%ndc, pr(jp)%nc, int(row_b - row_a, c_int64_t), &
-                                    pr(jp)%Xd(row_a + 1:row_b), pr(jp)%Yd(row_a + 1:row_b), pr(jp)%Zd(row_a + 1:row_b), pr(jp)%cw, &
-                                    mptr, par%comp_type, par%comp_rate, pr(jp)%pw, c_loc(pr(jp)%dw(row_a * pr(jp)%ndc + 1)), &
-                                    int(col_a, c_int64_t), int(col_b, c_int64_t), nnz_k, err_k, hist_ptr), 'calculate_and_write_sensit')
-  end subroutine build_kernel
-
-  ! The relayout-based build applies to single-component compressed kernels (row blocks of 2048 matrix rows = whole data);
-  ! TFX_BUILD_MODE=redundant forces the simpler scheme (every rank builds all rows for its own columns).
-  logical function exchange_ok(jp)
+  ! read_depth_weight, sensitivity_gravmag.F90:920-970: the full column weight from the SENSIT folder (big-endian stream)
+  subroutine read_depth_weight(jp)
     integer, intent(in) :: jp
-    character(len=32) :: v
-    integer :: l, st
-    call get_environment_variable('TFX_BUILD_MODE', v, l, st)
-    exchange_ok = pr(jp)%ndc == 1 .and. par%comp_type > 0        ! any number of model components, one data component
-    if (st == 0 .and. l > 0) then
-      if (v(1:l) == 'redundant') exchange_ok = .false.
-    endif
-  end function exchange_ok
-
-  ! row blocks dealt out contiguously: this rank's data (row_a, row_b]
-  subroutine my_row_blocks(ndat, row_a, row_b)
-    integer, intent(in) :: ndat
-    integer, intent(out) :: row_a, row_b
-    integer :: nblk, base, rem, b0, b1
-    nblk = (ndat + ROW_BLOCK - 1) / ROW_BLOCK
-    base = nblk / nbproc
-    rem = mod(nblk, nbproc)
-    b0 = myrank * base + min(myrank, rem)
-    b1 = b0 + base
-    if (myrank < rem) b1 = b1 + 1
-    row_a = min(b0 * ROW_BLOCK, ndat)
-    row_b = min(b1 * ROW_BLOCK, ndat)
-  end subroutine my_row_blocks
-
-  subroutine build_rowstore(jp, row_a, row_b, err_k, hist_ptr)
-    integer, intent(in) :: jp, row_a, row_b
-    real(c_double), intent(out) :: err_k
-    type(c_ptr), intent(in) :: hist_ptr
-    type(c_ptr) :: mptr
-    integer(c_int64_t) :: nnz_k
-    mptr = c_null_ptr
-    if (jp == 1) then
-      print *, 'Calculating GRAVITY sensitivity kernel (row-parallel)...'
-    else
-      print *, 'Calculating MAGNETIC sensitivity kernel (row-parallel)...'
-      mag_field = (/par%mag_incl, par%mag_decl, par%mag_xaxis_decl, par%mag_intensity/)
-      mptr = c_loc(mag_field)
-    endif
-    call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
-    call tfx_check(tfx_rowstore_build_comp(ctx, jp, pr(jp)%dtype, pr(jp)%ndc, pr(jp)%nc, int(row_b - row_a, c_int64_t), pr(jp)%Xd(row_a + 1:row_b), &
-                                         pr(jp)%Yd(row_a + 1:row_b), pr(jp)%Zd(row_a + 1:row_b), pr(jp)%cw, mptr, par%comp_type, &
-                                         par%comp_rate, pr(jp)%pw, c_loc(pr(jp)%dw(row_a * pr(jp)%ndc + 1)), nnz_k, err_k, hist_ptr), &
-                   'calculate_and_write_sensit')
-  end subroutine build_rowstore
-
-  ! read_sensitivity_kernel's relayout (sensitivity_gravmag.F90:795-830) without the files: every row block is cut by column range
-  ! on its owner's GPU and the pieces go to the owners of the columns, which lay them out as tiles
-  subroutine relayout_rowstore(jp, nnz_k)
-    integer, intent(in) :: jp
-    integer(c_int64_t), intent(out) :: nnz_k
-    integer :: ndat, row_a, row_b, nrl, nblk, b, ga, gb, o, d, rr, base, rem
-    integer, allocatable :: rows_at(:), row_displs(:), blk_owner(:)
-    integer(c_int64_t), allocatable :: bounds(:)
-    integer(c_int32_t), allocatable, target :: cnt_loc(:, :), cnt_all(:, :), hc(:), nel_blk(:)
-    real(c_float), allocatable, target :: hv(:)
-    integer(c_int64_t) :: n_in, n_out, got, mine
-    type(c_ptr) :: dcols, dvals, scols, svals
-    ndat = pr(jp)%nd
-    call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
-    call my_row_blocks(ndat, row_a, row_b)
-    nrl = row_b - row_a
-    nblk = (ndat + ROW_BLOCK - 1) / ROW_BLOCK
-    allocate(rows_at(nbproc), row_displs(nbproc), blk_owner(nblk), bounds(nbproc + 1))
-    base = nblk / nbproc
-    rem = mod(nblk, nbproc)
-    b = 0
-    do rr = 0, nbproc - 1
-      d = base
-      if (rr < rem) d = d + 1
-      blk_owner(b + 1:b + d) = rr
-      rows_at(rr + 1) = min((b + d) * ROW_BLOCK, ndat) - min(b * ROW_BLOCK, ndat)
-      row_displs(rr + 1) = min(b * ROW_BLOCK, ndat)
-      b = b + d
-    enddo
-    bounds(1) = 0
-    do rr = 1, nbproc
-      bounds(rr + 1) = bounds(rr) + nel_at(rr)
-    enddo
-    allocate(cnt_loc(nbproc, max(nrl, 1)), cnt_all(nbproc, ndat))
-    if (nrl > 0) call tfx_check(tfx_rowstore_counts(ctx, int(nbproc, c_int), bounds, cnt_loc), 'tfx_rowstore_counts')
-    call allgather_counts(cnt_loc, nbproc, nrl, cnt_all, rows_at, row_displs)
-    mine = 0
-    do rr = 1, ndat
-      mine = mine + cnt_all(myrank + 1, rr)
-    enddo
-    call tfx_check(tfx_matrix_begin(ctx, int(ndat, c_int64_t), int(pr(jp)%nc * nloc, c_int64_t), max(mine, 1_c_int64_t)), 'tfx_matrix_begin')
-    do b = 1, nblk
-      ga = (b - 1) * ROW_BLOCK
-      gb = min(b * ROW_BLOCK, ndat)
-      o = blk_owner(b)
-      n_in = 0
-      do rr = ga + 1, gb
-        n_in = n_in + cnt_all(myrank + 1, rr)
-      enddo
-      call tfx_check(tfx_device_malloc(ctx, 4 * max(n_in, 1_c_int64_t), dcols), 'tfx_device_malloc')
-      call tfx_check(tfx_device_malloc(ctx, 4 * max(n_in, 1_c_int64_t), dvals), 'tfx_device_malloc')
-      if (o == myrank) then
-        do d = 0, nbproc - 1
-          n_out = 0
-          do rr = ga + 1, gb
-            n_out = n_out + cnt_all(d + 1, rr)
-          enddo
-          if (n_out == 0) cycle
-          if (d == myrank) then
-            call tfx_check(tfx_rowstore_pack(ctx, int(ga - row_a, c_int64_t), int(gb - ga, c_int64_t), bounds(d + 1), bounds(d + 2), &
-                                             dcols, dvals, n_out, got), 'tfx_rowstore_pack')
-          else
-            call tfx_check(tfx_device_malloc(ctx, 4 * n_out, scols), 'tfx_device_malloc')
-            call tfx_check(tfx_device_malloc(ctx, 4 * n_out, svals), 'tfx_device_malloc')
-            call tfx_check(tfx_rowstore_pack(ctx, int(ga - row_a, c_int64_t), int(gb - ga, c_int64_t), bounds(d + 1), bounds(d + 2), &
-                                             scols, svals, n_out, got), 'tfx_rowstore_pack')
-            allocate(hc(n_out), hv(n_out))
-            call tfx_check(tfx_copy(ctx, c_loc(hc), scols, 4 * n_out), 'tfx_copy')
-            call tfx_check(tfx_copy(ctx, c_loc(hv), svals, 4 * n_out), 'tfx_copy')
-            call send_piece(d, int(n_out), hc, hv, 2 * b)
-            deallocate(hc, hv)
-            call tfx_check(tfx_device_free(ctx, scols), 'tfx_device_free')
-            call tfx_check(tfx_device_free(ctx, svals), 'tfx_device_free')
-          endif
-        enddo
-      else if (n_in > 0) then
-        allocate(hc(n_in), hv(n_in))
-        call recv_piece(o, int(n_in), hc, hv, 2 * b)
-        call tfx_check(tfx_copy(ctx, dcols, c_loc(hc), 4 * n_in), 'tfx_copy')
-        call tfx_check(tfx_copy(ctx, dvals, c_loc(hv), 4 * n_in), 'tfx_copy')
-        deallocate(hc, hv)
-      endif
-      allocate(nel_blk(gb - ga))
-      nel_blk = cnt_all(myrank + 1, ga + 1:gb)
-      call tfx_check(tfx_matrix_append_rows(ctx, int(ga, c_int64_t), int(gb - ga, c_int64_t), dcols, dvals, nel_blk), &
-                     'tfx_matrix_append_rows')
-      deallocate(nel_blk)
-      call tfx_check(tfx_device_free(ctx, dcols), 'tfx_device_free')
-      call tfx_check(tfx_device_free(ctx, dvals), 'tfx_device_free')
-    enddo
-    call tfx_check(tfx_matrix_finish(ctx), 'tfx_matrix_finish')
-    if (write_sensit_wanted()) call write_my_sensit_rows(jp, row_a, row_b, cnt_loc)
-    call tfx_check(tfx_rowstore_free(ctx), 'tfx_rowstore_free')
-    nnz_k = mine
-  end subroutine relayout_rowstore
-
-  ! TFX_WRITE_SENSIT=0 skips the SENSIT files (the kernel has to cross PCIe for them)
-  logical function write_sensit_wanted()
-    character(len=8) :: v
-    integer :: l, st
-    call get_environment_variable('TFX_WRITE_SENSIT', v, l, st)
-    write_sensit_wanted = .not. (st == 0 .and. l > 0 .and. v(1:1) == '0')
-  end function write_sensit_wanted
-
-  ! The row file of this rank, sensit_{grav|magn}_{nbproc}_{rank} (sensitivity_gravmag.F90:142-153, :183, :306-309), from the row
-  ! store of the row-parallel build: my data rows with all their columns - what the reference's ranks write before its relayout.
-  subroutine write_my_sensit_rows(jp, row_a, row_b, cnt)
-    integer, intent(in) :: jp, row_a, row_b
-    integer(c_int32_t), intent(in) :: cnt(:, :)             ! (destination rank, local row): entries per column range
-    integer, parameter :: RCHUNK = 256
-    integer :: u, r0, r1, r, nel, kc
-    integer(c_int64_t) :: cap, got, a, e0, e1
-    integer(c_int32_t), allocatable, target :: hc(:)
-    real(c_float), allocatable, target :: hv(:)
-    type(c_ptr) :: dc, dv
-    character(len=512) :: fname, tag
-    call execute_command_line('mkdir -p "'//trim(par%path_output)//'/SENSIT"')
-    write(tag, '(I0,A,I0)') nbproc, '_', myrank
-    fname = trim(par%path_output)//'/SENSIT/sensit_'//SENSIT_SUFFIX(jp)//'_'//trim(tag)
-    open(newunit=u, file=trim(fname), status='replace', access='stream', form='unformatted', action='write', convert='big_endian')
-    write(u) int(row_b - row_a, c_int32_t), int(pr(jp)%nd, c_int32_t), int(n, c_int32_t), int(myrank, c_int32_t), int(nbproc, c_int32_t)
-    do r0 = row_a, row_b - 1, RCHUNK
-      r1 = min(r0 + RCHUNK, row_b)
-      cap = 0
-      do r = r0 + 1, r1
-        cap = cap + sum(int(cnt(:, r - row_a), c_int64_t))
-      enddo
-      allocate(hc(max(cap, 1_c_int64_t)), hv(max(cap, 1_c_int64_t)))
-      if (cap > 0) then
-        call tfx_check(tfx_device_malloc(ctx, 4 * cap, dc), 'tfx_device_malloc')
-        call tfx_check(tfx_device_malloc(ctx, 4 * cap, dv), 'tfx_device_malloc')
-        call tfx_check(tfx_rowstore_pack(ctx, int(r0 - row_a, c_int64_t), int(r1 - r0, c_int64_t), 0_c_int64_t, int(n, c_int64_t), &
-                                         dc, dv, cap, got), 'tfx_rowstore_pack')
-        call tfx_check(tfx_copy(ctx, c_loc(hc), dc, 4 * cap), 'tfx_copy')
-        call tfx_check(tfx_copy(ctx, c_loc(hv), dv, 4 * cap), 'tfx_copy')
-        call tfx_check(tfx_device_free(ctx, dc), 'tfx_device_free')
-        call tfx_check(tfx_device_free(ctx, dv), 'tfx_device_free')
-      endif
-      a = 0
-      do r = r0 + 1, r1                                            ! data row r (1-based, global)
-        nel = sum(cnt(:, r - row_a))
-        if (nel > 0) then
-          if (pr(jp)%pw * pr(jp)%dw(r) /= 1.d0) hv(a + 1:a + nel) = hv(a + 1:a + nel) / real(pr(jp)%pw * pr(jp)%dw(r), c_float)
-        endif
-        e0 = a
-        do kc = 1, pr(jp)%nc                                       ! one record per model component (:222-311); the packed row
-          e1 = e0                                                  ! holds component kc at 0-based columns (kc-1)*n + cell
-          do while (e1 < a + nel)
-            if (hc(e1 + 1) >= kc * n) exit
-            e1 = e1 + 1
-          enddo
-          write(u) int(r, c_int32_t), int(e1 - e0, c_int32_t), int(kc, c_int32_t), 1_c_int32_t
-          if (e1 > e0) then
-            hc(e0 + 1:e1) = hc(e0 + 1:e1) - (kc - 1) * n + 1
-            write(u) hc(e0 + 1:e1), hv(e0 + 1:e1)
-          endif
-          e0 = e1
-        enddo
-        a = a + nel
-      enddo
-      deallocate(hc, hv)
-    enddo
-    close(u)
-  end subroutine write_my_sensit_rows
-
-  ! sensit.readFromFiles = 1 on several ranks: the per-cell counts of every kernel from the sensit_*_nnz files
-  ! (read_sensit_nnz, sensitivity_gravmag.F90:530-568)
-  subroutine read_sensit_nnz_files()
-    integer :: jp, u, ios
+    integer :: u, ios
     integer(c_int32_t) :: nread
-    do jp = 1, 2
-      if (.not. pr(jp)%on) cycle
-      open(newunit=u, file=trim(par%sensit_path)//'sensit_'//SENSIT_SUFFIX(jp)//'_nnz', status='old', access='stream', &
-           form='unformatted', action='read', convert='big_endian', iostat=ios)
-      if (ios /= 0) call stop_msg('Error in opening the sensit_nnz file!')
-      read(u) nread
-      if (nread /= n) call stop_msg('Wrong file header in calculate_new_partitioning!')
-      read(u) hist
-      close(u)
-      hist_all = hist_all + hist
-    enddo
-  end subroutine read_sensit_nnz_files
+    character(len=4), parameter :: sfx(2) = (/'grav', 'magn'/)
+    open(newunit=u, file=trim(par%sensit_path)//'sensit_'//sfx(jp)//'_weight', status='old', access='stream', &
+         form='unformatted', action='read', convert='big_endian', iostat=ios)
+    if (ios /= 0) call stop_msg('Error in opening the depth weight file! path='//trim(par%sensit_path))
+    read(u) nread
+    if (nread /= n) call stop_msg('Depth weight file header does not match the Parfile!')
+    read(u) pr(jp)%cw
+    close(u)
+  end subroutine read_depth_weight
 
   subroutine to_wavelet(v, ncomp)
     real(dp), intent(inout) :: v(:)
     integer, intent(in) :: ncomp
-    if (par%comp_type > 0) &      ! every model component on its own (src/inversion/wavelet_utils.F90:37-72)
-      call tfx_check(tfx_wavelet(ctx, v, par%nx, par%ny, par%nz, int(ncomp, c_int64_t), par%comp_type, 1_c_int), 'forward_wavelet')
+    integer :: kc
+    if (ipar%compression_type <= 0) return
+    do kc = 1, ncomp                ! every model component on its own (src/inversion/wavelet_utils.F90:37-72)
+      call forward_wavelet(v((kc - 1) * n + 1:kc * n), ipar%nx, ipar%ny, ipar%nz, ipar%compression_type)
+    enddo
   end subroutine to_wavelet
 
-  ! model_calculate_data, src/inversion/model.F90:220-307 (on the problem's own rows / columns: part_mult_vector)
-  subroutine calculate_data(jp, model, dcalc)
+  ! model%calculate_data (src/inversion/model.F90:220-307) for the full model vector the host keeps: this rank's cells go into the
+  ! reference's model object, the call is the reference's (problem_joint_gravmag.F90:333, :414, :438, :513)
+  subroutine calculate_data(jp, mfull, dcalc)
     integer, intent(in) :: jp
-    real(dp), intent(in) :: model(:)
+    real(dp), intent(in) :: mfull(:)
     real(dp), intent(out) :: dcalc(:)
-    real(dp), allocatable :: w(:), wl(:)
-    integer :: p, kc
-    allocate(w(pr(jp)%nm))
+    real(dp), allocatable :: dc(:, :)
+    integer :: kc
     do kc = 1, pr(jp)%nc
-      do p = 1, n
-        if (pr(jp)%cw(p) /= 0.d0) then
-          w((kc - 1) * n + p) = model((kc - 1) * n + p) / pr(jp)%cw(p)
-        else
-          w((kc - 1) * n + p) = 0.d0
-        endif
-      enddo
+      model(jp)%val(:, kc) = mfull((kc - 1) * n + cb + 1:(kc - 1) * n + ce)
     enddo
-    call to_wavelet(w, pr(jp)%nc)
-    allocate(wl(max(1, pr(jp)%nml)))
-    call to_local(jp, w, wl)
-    call tfx_check(tfx_select_problem(ctx, pr(jp)%slot), 'tfx_select_problem')
-    call tfx_check(tfx_calc_data(ctx, wl, pr(jp)%pw, c_loc(pr(jp)%dw), dcalc), 'model_calculate_data')   ! all-reduced through the hook
-    call tfx_check(tfx_select_problem(ctx, 0_c_int), 'tfx_select_problem')
+    allocate(dc(pr(jp)%ndc, pr(jp)%nd))
+    call model(jp)%calculate_data(pr(jp)%nd, pr(jp)%ndc, matrix_sensit, ipar%problem_weight(jp), cw_loc(:, jp), data(jp)%weight, dc, &
+                                  ipar%compression_type, line_start(jp), param_shift(jp), myrank, nbproc)
+    dcalc = reshape(dc, (/pr(jp)%ndt/))
   end subroutine calculate_data
 
   ! calculate_cost_model, src/utils/costs.f90:74-113 (first model component only, problem_joint_gravmag.F90:655-657)
@@ -1818,5 +1363,106 @@ contains
     u = u + xm - z
     x0out = z - u
   end subroutine iterate_admm_arrays
+
+end subroutine solve_problem_joint_gravmag
+
+end module problem_joint_gravmag
+
+!=========================================================================================================
+! program_tomofastx (src/program_tomofastx.F90:25-103): command line, MPI start-up, Parfile, then the reference's entry point
+program tomofastx_amd
+  use tfx_host_params
+  use tfx_host_mpi
+  use tfx_reference_api
+  use problem_joint_gravmag
+  implicit none
+  type(t_par) :: par
+  type(t_parameters_grav) :: gpar
+  type(t_parameters_mag) :: mpar
+  type(t_parameters_inversion) :: ipar
+  character(len=256) :: arg, parfile
+  integer :: i, narg
+
+  ! ---- command line (src/parameters_init.f90:104-119)
+  parfile = ''
+  narg = command_argument_count()
+  i = 1
+  do while (i <= narg)
+    call get_command_argument(i, arg)
+    if (trim(arg) == '-p' .or. trim(arg) == '-j') then
+      if (i + 1 > narg) call stop_msg('UNKNOWN Parfile! Use -p <Parfile_path>')
+      call get_command_argument(i + 1, parfile)
+      i = i + 1
+    endif
+    i = i + 1
+  enddo
+  if (len_trim(parfile) == 0) call stop_msg('UNKNOWN Parfile! Use -p <Parfile_path>')
+  ! one process per GPU under `mpiexec -n P`; ranks other than 0 stay silent (the reference prints from rank 0 only)
+  call host_mpi_init()
+  abort_hook => host_mpi_abort
+  io_rank = myrank == 0
+  if (myrank /= 0) open(unit=6, file='/dev/null', status='old', action='write')
+  print *, 'Started Tomofast-x (MI355X host), Parfile = ', trim(parfile)
+  if (nbproc > 1) print *, 'Number of ranks (one GPU each) =', nbproc
+  call read_parfile(parfile, par)
+  if (par%admm > 0 .and. par%admm_bound_type == 1 .and. .not. allocated(par%bounds)) call stop_msg('Global bounds are not defined!')
+
+  ! ---- the reference's three parameter objects (src/parameters_init.f90:412-966 fills them from the same keys)
+  call set_base(gpar, 1)
+  call set_base(mpar, 2)
+  gpar%data_type = par%grav_data_type
+  gpar%nmodel_components = 1
+  mpar%mi = par%mag_incl
+  mpar%md = par%mag_decl
+  mpar%theta = par%mag_xaxis_decl
+  mpar%intensity = par%mag_intensity
+  ipar%nx = par%nx; ipar%ny = par%ny; ipar%nz = par%nz
+  ipar%nelements_total = par%nx * par%ny * par%nz
+  ipar%nelements = ipar%nelements_total
+  ipar%ndata = par%ndata
+  ipar%ndata_components = par%ndata_comp
+  ipar%nmodel_components = par%nmodel_comp
+  ipar%niter = par%nminor
+  ipar%ninversions = par%nmajor
+  ipar%alpha = par%alpha
+  ipar%norm_power = par%norm_power
+  ipar%rmin = par%rmin
+  ipar%target_misfit = par%target_misfit
+  ipar%gamma = par%gamma
+  ipar%compression_type = par%comp_type
+  ipar%problem_weight = par%pw
+  ipar%column_weight_multiplier = par%cwm
+  ipar%admm_type = par%admm
+  ipar%rho_ADMM = par%rho
+  host_par = par
+
+  call solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
+
+  print *, 'THE END.'
+  call host_mpi_finalize()
+
+contains
+
+  subroutine set_base(b, ip)
+    class(t_parameters_base), intent(inout) :: b
+    integer, intent(in) :: ip
+    b%nx = par%nx; b%ny = par%ny; b%nz = par%nz
+    b%nelements = par%nx * par%ny * par%nz
+    b%ndata = par%ndata(ip)
+    b%ndata_components = par%ndata_comp(ip)
+    b%nmodel_components = par%nmodel_comp
+    b%depth_weighting_type = par%dw_type
+    b%depth_weighting_power = par%dw_power(ip)
+    b%depth_weighting_beta = par%dw_beta(ip)
+    b%Z0 = par%dw_Z0(ip)
+    b%compression_type = par%comp_type
+    b%compression_rate = par%comp_rate
+    b%sensit_read = par%sensit_read
+    if (par%sensit_read == 0) then                 ! a fresh kernel is (optionally) written under the output folder (:142-153)
+      b%sensit_path = trim(par%path_output)//'/SENSIT/'
+    else
+      b%sensit_path = par%sensit_path
+    endif
+  end subroutine set_base
 
 end program tomofastx_amd
