@@ -123,6 +123,21 @@ def _worker_exchange(rank, world, port, q):
         ctx.calculate_sensit(xs[:nsub], ys[:nsub], zs[:nsub], cw, 1, 0.03, col_range=(c0, c1), mag_field=field, nmodel_components=3)
         B = ctx.matrix_download_csr()
         assert np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and A[2].tobytes() == B[2].tobytes()
+        # several DATA components: the matrix has ncd rows per datum, data are dealt out in blocks of 2048 (= ncd row blocks):
+        # full gradient tensor (6 lines per observation) and three-component magnetic data with a magnetisation-vector model,
+        # problem weight and per-line data weights fused into the rows on both paths
+        for kw in (dict(data_type=2, ndata_components=6), dict(mag_field=field, ndata_components=3, nmodel_components=3)):
+            nsub = 2100                                   # 2 blocks of data -> 12600 / 6300 matrix rows
+            ncd = kw["ndata_components"]
+            dw = 0.5 + np.random.default_rng(4).random((nsub, ncd))
+            part = tfx.distributed.build_partitioned_exchange(ctx, rank, world, xs[:nsub], ys[:nsub], zs[:nsub], cw, 2, 0.04,
+                                                              problem_weight=1.75, data_weight=dw, **kw)
+            c0, c1 = part["col_range"]
+            A = ctx.matrix_download_csr()
+            assert ctx.matrix_info()["nrows"] == nsub * ncd and int(A[0][-1]) == int(part["nnz_at_cpu"][rank])
+            ctx.calculate_sensit(xs[:nsub], ys[:nsub], zs[:nsub], cw, 2, 0.04, 1.75, dw, col_range=(c0, c1), **kw)
+            B = ctx.matrix_download_csr()
+            assert np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and A[2].tobytes() == B[2].tobytes(), kw
         ctx.close()
         q.put((rank, "ok"))
     except Exception:      # noqa

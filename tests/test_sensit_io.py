@@ -3,6 +3,7 @@ import importlib
 import os
 
 import numpy as np
+import pytest
 
 tfx = importlib.import_module("tomofast-x_amd")
 
@@ -38,19 +39,20 @@ def test_reader_accepts_any_rank_count(tmp_path, golden_dir):
     nd = S[0].size - 1
     folder = str(tmp_path / "S2")
     half = nd // 2
+    hist_total = np.bincount(S[1] - 1, minlength=N).astype(np.int32)        # what the ranks' all-reduce of sensit_nnz gives
     for rank, (a, b) in enumerate([(0, half), (half, nd)]):
-        if rank == 0:      # rank 0 also writes meta / nnz / weight for the WHOLE matrix
-            tfx.sensit_io.write_sensit(folder, 1, S, N, dims, g["np1_column_weight"], 2, float(g["np1_comp_error"]), nbproc=2, rank=0)
-        # write the per-rank row file explicitly (rank files hold only their rows)
-        with open(os.path.join(folder, "sensit_grav_2_%d" % rank), "wb") as f:
-            f.write(np.array([b - a, nd, N, rank, 2], ">i4").tobytes())
-            for r in range(a, b):
-                c0, c1 = int(S[0][r]), int(S[0][r + 1])
-                f.write(np.array([r + 1, c1 - c0, 1, 1], ">i4").tobytes())
-                f.write(S[1][c0:c1].astype(">i4").tobytes() + S[2][c0:c1].astype(">f4").tobytes())
+        e0, e1 = int(S[0][a]), int(S[0][b])
+        part = (S[0][a:b + 1] - e0, S[1][e0:e1], S[2][e0:e1])               # every rank passes ITS rows only
+        tfx.sensit_io.write_sensit(folder, 1, part, N, dims, g["np1_column_weight"], 2, float(g["np1_comp_error"]), nbproc=2, rank=rank,
+                                   row_begin=a, ndata_total=nd, nnz_hist_total=hist_total, nnz_total=int(S[0][-1]))
+    with pytest.raises(ValueError):                                          # rank 0 of several writers needs the totals
+        tfx.sensit_io.write_sensit(str(tmp_path / "bad"), 1, (S[0][:half + 1], S[1][:int(S[0][half])], S[2][:int(S[0][half])]), N, dims,
+                                   g["np1_column_weight"], 2, 0.0, nbproc=2, rank=0, ndata_total=nd)
+    with pytest.raises(ValueError):                                          # a scaled kernel is refused (the files hold the unscaled one)
+        tfx.sensit_io.write_sensit(str(tmp_path / "bad"), 1, S, N, dims, g["np1_column_weight"], 2, 0.0, problem_weight=2.0)
     back = tfx.sensit_io.read_sensit(folder, 1)
-    assert back["meta"]["nbproc"] == 2
-    assert np.array_equal(back["rowptr"], S[0]) and np.array_equal(back["cols"], S[1])
+    assert back["meta"]["nbproc"] == 2 and back["meta"]["nnz_total"] == int(S[0][-1])
+    assert np.array_equal(back["rowptr"], S[0]) and np.array_equal(back["cols"], S[1]) and np.array_equal(back["nnz_hist"], hist_total)
 
 
 def test_multicomponent_lines_roundtrip(tmp_path, golden_dir):

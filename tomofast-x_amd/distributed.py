@@ -266,14 +266,16 @@ def _p2p(tensors_to_send, recv_specs, backend):
 
 def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate,
                                problem_weight=1.0, data_weight=None, mag_field=None, get_partition=None, device_index=0,
-                               nmodel_components=1, comm=None):
-    """Row-parallel build + relayout: every rank compresses only ITS row blocks (all columns, kept row-major on
+                               nmodel_components=1, comm=None, data_type=1, ndata_components=1):
+    """Row-parallel build + relayout: every rank compresses only ITS blocks of data (all columns, kept row-major on
     the device), the per-column histogram is all-reduced, the reference's greedy rule gives the column ranges, and each
     row block is then cut into column ranges and sent to the owners, who lay their pieces out as tiles.  Every row is
     computed once; the matrix crosses the links once (the reference does this through SENSIT files and a rank-0
     MPI_Scatterv per row: sensitivity_gravmag.F90:179-189, :306-309, :795-830).
-    nmodel_components = 3 (magnetisation vector, one data component): a rank owns its cell range of every component; the
-    pieces carry component k at k*(cells of the range) + cell."""
+    Several data components (full gradient tensor, three-component magnetic data): the matrix has ndata_components rows per
+    datum (row = i*ncd + d), data are dealt out in blocks of 2048, so a rank's rows are whole row blocks of the matrix.
+    nmodel_components = 3 (magnetisation vector): a rank owns its cell range of every component; the pieces carry component k
+    at k*(cells of the range) + cell."""
     import torch
     from .sensitivity import get_load_balancing_nelements
     if comm is None:                    # hosts that set the hooks themselves (tests): host-driven steps through torch.distributed
@@ -281,16 +283,19 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
     dev = torch.device("cuda", device_index)
     N = ctx.nelements_total
     nd = len(Xdata)
+    ncd = int(ndata_components)
+    nrows = nd * ncd                                                # matrix rows
     RB = ctx.ROW_BLOCK
-    nblocks, bstart = block_row_partition(nd, nranks, RB)
-    owner = np.repeat(np.arange(nranks), np.diff(bstart))
-    r0, r1 = int(bstart[rank]) * RB, min(int(bstart[rank + 1]) * RB, nd)
+    ndblocks, bstart = block_row_partition(nd, nranks, RB)          # blocks of RB data, dealt out contiguously
+    r0, r1 = int(bstart[rank]) * RB, min(int(bstart[rank + 1]) * RB, nd)      # my data
     nloc = max(0, r1 - r0)
+    m0 = [min(int(bstart[r]) * RB, nd) * ncd for r in range(nranks + 1)]      # first matrix row of every rank (multiples of RB)
     # 1. my rows, all columns
     if nloc > 0:
-        dw = None if data_weight is None else data_weight[r0:r1]
+        dw = None if data_weight is None else np.asarray(data_weight).reshape(-1)[r0 * ncd:r1 * ncd]
         res = ctx.rowstore_build(Xdata[r0:r1], Ydata[r0:r1], Zdata[r0:r1], column_weight, compression_type, compression_rate,
-                                 problem_weight, dw, mag_field, nmodel_components=nmodel_components)
+                                 problem_weight, dw, mag_field, data_type=data_type, ndata_components=ncd,
+                                 nmodel_components=nmodel_components)
         hist, err = res["nnz_hist"].astype(np.int64), res["error_sum"]
     else:
         hist, err = np.zeros(N, np.int64), 0.0
@@ -301,22 +306,23 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
     bounds = np.concatenate([[0], np.cumsum(np.asarray(nel, np.int64))])
     c0, c1 = int(bounds[rank]), int(bounds[rank + 1])
     # 3. who sends how much of which row to whom
-    counts_loc = ctx.rowstore_counts(nloc, bounds) if nloc > 0 else np.zeros((0, nranks), np.int32)
-    maxloc = int(max(np.diff(bstart))) * RB
+    counts_loc = ctx.rowstore_counts(nloc * ncd, bounds) if nloc > 0 else np.zeros((0, nranks), np.int32)
+    maxloc = int(max(np.diff(bstart))) * RB * ncd
     pad = np.zeros((maxloc, nranks), np.int32)
-    pad[:nloc] = counts_loc
+    pad[:nloc * ncd] = counts_loc
     gathered = comm.allgather_host(pad)
-    counts = np.zeros((nd, nranks), np.int32)                       # counts[row, dest]
+    counts = np.zeros((nrows, nranks), np.int32)                    # counts[matrix row, dest]
     for r in range(nranks):
-        a, b = int(bstart[r]) * RB, min(int(bstart[r + 1]) * RB, nd)
+        a, b = m0[r], m0[r + 1]
         if b > a:
             counts[a:b] = gathered[r][:b - a]
     assert int(counts[:, rank].sum()) == int(nnz[rank]), (counts[:, rank].sum(), nnz[rank])
-    # 4. relayout, row block by row block
-    ctx.matrix_begin(nd, nmodel_components * (c1 - c0), int(nnz[rank]))
-    for b in range(nblocks):
-        ga, gb = b * RB, min((b + 1) * RB, nd)
-        o = int(owner[b])
+    # 4. relayout, matrix row block by row block
+    ctx.matrix_begin(nrows, nmodel_components * (c1 - c0), int(nnz[rank]))
+    owner_of_row = np.searchsorted(np.asarray(m0[1:]), np.arange(0, nrows, RB), side="right")
+    for b in range((nrows + RB - 1) // RB):
+        ga, gb = b * RB, min((b + 1) * RB, nrows)
+        o = int(owner_of_row[b])
         n_in = int(counts[ga:gb, rank].sum())
         rc = torch.empty(max(n_in, 1), dtype=torch.int32, device=dev)
         rv = torch.empty(max(n_in, 1), dtype=torch.float32, device=dev)
@@ -327,12 +333,12 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
                 if n_out == 0:
                     continue
                 if d == rank:
-                    got = ctx.rowstore_pack(ga - r0, gb - ga, int(bounds[d]), int(bounds[d + 1]), rc, rv, n_out)
+                    got = ctx.rowstore_pack(ga - m0[rank], gb - ga, int(bounds[d]), int(bounds[d + 1]), rc, rv, n_out)
                     assert got == n_out
                     continue
                 sc = torch.empty(n_out, dtype=torch.int32, device=dev)
                 sv = torch.empty(n_out, dtype=torch.float32, device=dev)
-                got = ctx.rowstore_pack(ga - r0, gb - ga, int(bounds[d]), int(bounds[d + 1]), sc, sv, n_out)
+                got = ctx.rowstore_pack(ga - m0[rank], gb - ga, int(bounds[d]), int(bounds[d + 1]), sc, sv, n_out)
                 assert got == n_out
                 keep += [sc, sv]
                 sends += [(d, sc), (d, sv)]
@@ -342,7 +348,8 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
         ctx.matrix_append_rows(ga, rc, rv, counts[ga:gb, rank])
     ctx.matrix_finish()
     ctx.rowstore_free()
-    return dict(col_range=(c0, c1), nelements_at_cpu=nel, nnz_at_cpu=nnz, nnz_total=int(hist.sum()), comp_error=err / (nd * nmodel_components))
+    return dict(col_range=(c0, c1), nelements_at_cpu=nel, nnz_at_cpu=nnz, nnz_total=int(hist.sum()),
+                comp_error=err / (nd * ncd * nmodel_components))
 
 
 def build_partitioned(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate,

@@ -530,9 +530,9 @@ contains
                                       int(n, c_int64_t), nnz_k, err_k, c_loc(hist)), 'calculate_and_write_sensit', myrank_)
       k%nnz_total = nnz_k
     else
-      ! row-parallel: my row blocks with ALL their columns stay in the device row store until the partition is known
-      ! (one data component; otherwise count now and let every rank build its own columns on reload)
-      exchange = k%ndc == 1 .and. par%compression_type > 0
+      ! row-parallel: my blocks of ROW_BLOCK data (= ndc row blocks of the matrix each) with ALL their columns stay in the device
+      ! row store until the partition is known (compressed kernels; a dense kernel is built per column range on reload)
+      exchange = par%compression_type > 0
       call get_environment_variable('TFX_BUILD_MODE', v, l, st)
       if (st == 0 .and. l > 0) then
         if (v(1:l) == 'redundant') exchange = .false.
@@ -638,12 +638,13 @@ contains
         enddo
       enddo
     else
-      ! several ranks: my rows out of the device row store, RCHUNK rows at a time (one data component)
+      ! several ranks: my rows out of the device row store, RCHUNK matrix rows at a time (local row = (i-1)*ndc + d)
       bounds = (/0_c_int64_t, int(n, c_int64_t)/)
-      allocate(cnt(1, max(nrl, 1)))
-      if (nrl > 0) call api_check(tfx_rowstore_counts(api_ctx, 1_c_int, bounds, cnt), 'tfx_rowstore_counts', myrank_)
-      do r0 = 0, nrl - 1, RCHUNK
-        r1 = min(r0 + RCHUNK, nrl)
+      nrows = int(nrl, c_int64_t) * k%ndc
+      allocate(cnt(1, max(nrows, 1_c_int64_t)))
+      if (nrows > 0) call api_check(tfx_rowstore_counts(api_ctx, 1_c_int, bounds, cnt), 'tfx_rowstore_counts', myrank_)
+      do r0 = 0, int(nrows) - 1, RCHUNK
+        r1 = min(r0 + RCHUNK, int(nrows))
         cap = sum(int(cnt(1, r0 + 1:r1), c_int64_t))
         allocate(cols(max(cap, 1_c_int64_t)), vals(max(cap, 1_c_int64_t)))
         if (cap > 0) then
@@ -666,7 +667,8 @@ contains
               if (cols(p + 1) >= kc * n) exit
               p = p + 1
             enddo
-            write(u) int(k%row_a + r, c_int32_t), int(p - e, c_int32_t), int(kc, c_int32_t), 1_c_int32_t
+            write(u) int(k%row_a + (r - 1) / k%ndc + 1, c_int32_t), int(p - e, c_int32_t), int(kc, c_int32_t), &
+                     int(mod(r - 1, k%ndc) + 1, c_int32_t)
             if (p > e) then
               cols(e + 1:p) = cols(e + 1:p) - (kc - 1) * n + 1
               write(u) cols(e + 1:p), vals(e + 1:p)
@@ -845,27 +847,33 @@ contains
     class(t_parameters_base), intent(in) :: par
     type(t_kernel_state), intent(inout) :: k
     integer, intent(in) :: nel_at(:), myrank_, nbproc_
-    integer :: ndat, row_a, row_b, nrl, nblk, b, ga, gb, o, d, rr, base, rem, nloc
+    integer :: ndat, row_a, row_b, nrl, nblk, b, ga, gb, o, d, rr, base, rem, nloc, ndc, ndblk
     integer, allocatable :: rows_at(:), row_displs(:), blk_owner(:)
     integer(c_int64_t), allocatable :: bounds(:)
     integer(c_int32_t), allocatable, target :: cnt_loc(:, :), cnt_all(:, :), nel_blk(:)
     integer(c_int64_t) :: n_in, n_out, got, mine
     type(c_ptr) :: dcols, dvals, scols, svals
-    ndat = par%ndata
-    row_a = k%row_a; row_b = k%row_b
+    ! matrix rows: ndc per datum (row = (i-1)*ndc + d); a rank's data range is whole blocks of ROW_BLOCK data, so its matrix rows
+    ! are whole row blocks of ROW_BLOCK rows
+    ndc = k%ndc
+    ndat = par%ndata * ndc                       ! matrix rows of the kernel
+    row_a = k%row_a * ndc; row_b = k%row_b * ndc
     nrl = row_b - row_a
     nloc = nel_at(myrank_ + 1)
     nblk = (ndat + ROW_BLOCK - 1) / ROW_BLOCK
     allocate(rows_at(nbproc_), row_displs(nbproc_), blk_owner(nblk), bounds(nbproc_ + 1))
-    base = nblk / nbproc_
-    rem = mod(nblk, nbproc_)
+    ndblk = (par%ndata + ROW_BLOCK - 1) / ROW_BLOCK       ! blocks of data, dealt out contiguously (my_row_blocks)
+    base = ndblk / nbproc_
+    rem = mod(ndblk, nbproc_)
     b = 0
     do rr = 0, nbproc_ - 1
       d = base
       if (rr < rem) d = d + 1
-      blk_owner(b + 1:b + d) = rr
-      rows_at(rr + 1) = min((b + d) * ROW_BLOCK, ndat) - min(b * ROW_BLOCK, ndat)
-      row_displs(rr + 1) = min(b * ROW_BLOCK, ndat)
+      ga = min(b * ROW_BLOCK, par%ndata) * ndc             ! first / one-past-last matrix row of rank rr
+      gb = min((b + d) * ROW_BLOCK, par%ndata) * ndc
+      rows_at(rr + 1) = gb - ga
+      row_displs(rr + 1) = ga
+      if (gb > ga) blk_owner(ga / ROW_BLOCK + 1:(gb + ROW_BLOCK - 1) / ROW_BLOCK) = rr
       b = b + d
     enddo
     bounds(1) = 0

@@ -100,8 +100,9 @@ contains
   subroutine read_parfile(path, par)
     character(len=*), intent(in) :: path
     type(t_par), intent(inout) :: par
-    character(len=512) :: line, key, val
+    character(len=512) :: line, key, val, bounds_text(2)
     integer :: ios, eq, u
+    bounds_text = ''
     open(newunit=u, file=trim(path), status='old', action='read', iostat=ios)
     if (ios /= 0) call stop_msg('Parfile "'//trim(path)//'" cannot be opened!')
     do
@@ -186,18 +187,8 @@ contains
       case ('inversion.admm.enableADMM');          read(val, *) par%admm
       case ('inversion.admm.boundType');           read(val, *) par%admm_bound_type
       case ('inversion.admm.nLithologies');        read(val, *) par%nlithos
-      case ('inversion.admm.grav.bounds', 'inversion.admm.magn.bounds')
-        if (par%admm > 0 .and. par%admm_bound_type == 1) then
-          if (.not. allocated(par%bounds)) then
-            allocate(par%bounds(2 * par%nlithos, 2))
-            par%bounds = huge(1.d0)
-          endif
-          if (index(key, '.grav.') > 0) then
-            read(val, *) par%bounds(:, 1)
-          else
-            read(val, *) par%bounds(:, 2)
-          endif
-        endif
+      case ('inversion.admm.grav.bounds');         bounds_text(1) = val      ! parsed after the whole file: they need nLithologies,
+      case ('inversion.admm.magn.bounds');         bounds_text(2) = val      ! enableADMM and boundType, wherever those keys stand
       case ('inversion.admm.grav.boundsFile');     par%bounds_file(1) = trim(val)
       case ('inversion.admm.magn.boundsFile');     par%bounds_file(2) = trim(val)
       case ('inversion.admm.grav.weight');         read(val, *) par%rho(1)
@@ -227,6 +218,17 @@ contains
       end select
     enddo
     close(u)
+    if (par%admm > 0 .and. par%admm_bound_type == 1) then        ! parameters_init.f90:880-905
+      do eq = 1, 2
+        if (len_trim(bounds_text(eq)) == 0) cycle
+        if (.not. allocated(par%bounds)) then
+          allocate(par%bounds(2 * par%nlithos, 2))
+          par%bounds = huge(1.d0)
+        endif
+        read(bounds_text(eq), *, iostat=ios) par%bounds(:, eq)
+        if (ios /= 0) call stop_msg('Wrong number of ADMM bounds: define bounds as min1 max1 ... minN maxN (nLithologies pairs)!')
+      enddo
+    endif
     print *, 'Finished reading the parameter file.'
   end subroutine read_parfile
 

@@ -19,11 +19,21 @@ SUFFIX = {1: "grav", 2: "magn"}
 
 def write_sensit(folder, problem_type, ctx_csr, nelements_total, grid_dims, column_weight, compression_type, comp_error,
                  depth_weighting_type=1, nbproc=1, rank=0, row_begin=0, ndata_total=None, ndata_components=1,
-                 nmodel_components=1):
+                 nmodel_components=1, problem_weight=1.0, data_weight=None, nnz_hist_total=None, nnz_total=None):
     """ctx_csr = (rowptr, cols, vals) of the matrix rows of the data [row_begin, row_begin + ndata_loc) over ALL columns
     (1-based cols).  With several components the matrix row idata*ndata_components + d holds model component k in columns
-    k*nelements_total + cell; the file stores one line per (idata, d, k) with cell columns (sensitivity_gravmag.F90:222-311)."""
+    k*nelements_total + cell; the file stores one line per (idata, d, k) with cell columns (sensitivity_gravmag.F90:222-311).
+    The files hold the UNSCALED kernel (the reference scales by problem_weight * data_weight on reload, :834-843): a matrix that was
+    built scaled must come with the factors it was built with, and is refused otherwise; the hosts build unscaled and scale
+    afterwards (Context.matrix_scale_rows), which keeps the files bit-identical to the reference's.
+    Several writer ranks (nbproc > 1): every rank passes its own rows; rank 0 also needs the per-cell counts and the entry count of
+    the WHOLE kernel (nnz_hist_total, nnz_total = the all-reduced values) for the metadata files."""
     rp, cols, vals = ctx_csr
+    if problem_weight != 1.0 or data_weight is not None:
+        raise ValueError("write_sensit: pass the unscaled kernel (build with problem_weight 1 and no data weights, scale the device "
+                         "matrix afterwards with matrix_scale_rows) - dividing the factors out again is not bit-exact in fp32")
+    if nbproc > 1 and rank == 0 and (nnz_hist_total is None or nnz_total is None):
+        raise ValueError("write_sensit: with several writer ranks rank 0 needs nnz_hist_total and nnz_total of the whole kernel")
     ncd, ncm, N = int(ndata_components), int(nmodel_components), int(nelements_total)
     nrows = rp.size - 1
     assert nrows % ncd == 0
@@ -45,13 +55,13 @@ def write_sensit(folder, problem_type, ctx_csr, nelements_total, grid_dims, colu
                     f.write(np.asarray(vals)[sel].astype(">f4").tobytes())
     if rank == 0:
         nx, ny, nz = grid_dims
-        hist = np.bincount((cols - 1) % N, minlength=N).astype(np.int32)
+        hist = (np.bincount((cols - 1) % N, minlength=N) if nnz_hist_total is None else np.asarray(nnz_hist_total)).astype(np.int32)
         with open(os.path.join(folder, "sensit_%s_meta.txt" % sfx), "w") as f:
             f.write(" %d %d %d %d\n" % (nx, ny, nz, ndata_total))
             f.write(" %d %d %d\n" % (nbproc, 4, depth_weighting_type))
             f.write(" %d %.17g\n" % (compression_type, comp_error))
             f.write(" %d %d\n" % (ncm, ncd))
-            f.write(" %d\n" % int(rp[-1]))
+            f.write(" %d\n" % int(rp[-1] if nnz_total is None else nnz_total))
         with open(os.path.join(folder, "sensit_%s_nnz" % sfx), "wb") as f:
             f.write(np.array([nelements_total], ">i4").tobytes() + hist.astype(">i4").tobytes())
         with open(os.path.join(folder, "sensit_%s_weight" % sfx), "wb") as f:

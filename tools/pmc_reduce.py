@@ -32,17 +32,23 @@ def main(src, dst, rnd):
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-include-regex k_spmv), "
                      "bench.py --steps 3 --warmup 1 --no-cpu --no-profile (tools/profile_round.sh)",
            "correction": "MI355X_MICROARCH.md HBM: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) "
-                         "coalesced streaming read -> doubled; FETCH_SIZE/WRITE_SIZE are in KiB (x1024). WRITE_SIZE is uncalibrated (small here).",
+                         "coalesced streaming read -> doubled; FETCH_SIZE/WRITE_SIZE are in KiB (x1024). WRITE_SIZE is uncalibrated (small here). "
+                         "The product kernels read 71 % of their bytes with 16 B/lane loads and 27 % with 12 B/lane (dwordx3) loads; the x2 "
+                         "factor is calibrated on this access mix by the device bytes of the matrix (every stored byte is read exactly once "
+                         "per launch): 2 x FETCH_SIZE / device bytes is reported as `fetch_over_device_bytes` and should be ~1.",
            "kernels": {}, "nnz": bench["config"]["nnz"]}
     plain = os.path.join(src, "bench_plain.json")
     if os.path.isfile(plain):
-        res["stored_bytes"] = json.loads(open(plain).read().strip().splitlines()[-1])["roofline"]["stored_bytes_per_launch"]
+        roof = json.loads(open(plain).read().strip().splitlines()[-1])["roofline"]
+        res["algorithmic_bytes"] = roof.get("algorithmic_bytes_per_launch", roof.get("stored_bytes_per_launch"))
+        res["device_bytes_of_the_matrix"] = roof.get("device_bytes_of_the_matrix")
     for k in fetch:
         rd = fetch[k][0] * 1024.0 * 2.0
         wr = write.get(k, (0.0, 0))[0] * 1024.0
         res["kernels"][k] = {"FETCH_SIZE_raw_KiB_avg": fetch[k][0], "FETCH_SIZE_launches": fetch[k][1],
                              "WRITE_SIZE_raw_KiB_avg": write.get(k, (0.0, 0))[0], "WRITE_SIZE_launches": write.get(k, (0.0, 0))[1],
-                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr}
+                             "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr,
+                             "fetch_over_device_bytes": (rd / res["device_bytes_of_the_matrix"]) if res.get("device_bytes_of_the_matrix") else None}
     json.dump(res, open(dst, "w"), indent=1)
     print(json.dumps(res["kernels"], indent=1))
 
