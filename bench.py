@@ -144,6 +144,8 @@ def main():
     t_build = time.time() - t0
     minfo = ctx.matrix_info()
     nnz_total = part["nnz_total"]
+    if os.environ.get("TFX_CHUNK_SPAN"):         # diagnostics: value-exponent span of the stored chunks (printed by the library)
+        log("chunks within %s binades: %d per mille" % (os.environ["TFX_CHUNK_SPAN"], ctx.debug_set("chunk_exponent_span", int(os.environ["TFX_CHUNK_SPAN"]))))
     c0, c1 = part["col_range"]
     log("build %.1f s (%.3e cell.obs/s), nnz %d, compression error %.3e, rank-0 matrix %.2f GB, cols [%d,%d)" %
         (t_build, N * D / t_build, nnz_total, part["comp_error"], minfo["device_bytes"] / 1e9, c0, c1))

@@ -299,9 +299,18 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * keys "hybrid" (0/1, default 0), "hybrid_min_nnz", "hybrid_tau_permille" (values): whether, from which size and from which column
  * density matrices get the bitmap head of the hybrid layout (experimental: fewer bytes, not faster - DESIGN.md);
  * "head_columns", "head_entries_permille": queries of the selected matrix;
+ * key "build_overlap" (0/1, default 1): the kernel build runs its row generator (VALU-bound) on a second stream one batch ahead of
+ * the wavelet / threshold / compaction kernels (HBM-bound) of the main stream; 0 = one stream, one row buffer;
+ * key "chunk_exponent_span" (value): diagnostics - per mille of the stored 512-entry chunks whose non-zero values span at most
+ * `value` binades (prints the histogram on stderr);
  * key "force_collectives" (0/1): issue the collectives of the multi-rank path even with one rank - with a world-size-1
  * communicator this runs the real ncclAllReduce / ncclBroadcast calls on a single-GPU box.                              */
 int tfx_debug_set(tfx_ctx *ctx, const char *key, int value);
+
+/* Diagnostics: evaluates the device build of the prism kernels' fp64 log / atan2 (csrc/fastmath.h: table-reduced replacements of the
+ * device libm calls behind gravity_field.f90:165-186 and magnetic_field.f90:376-399) on host arrays: out_log[i] = log(a[i]),
+ * out_atan2[i] = atan2(a[i], b[i]).  Tests compare them with the host libm.                                                 */
+int tfx_fastmath_eval(tfx_ctx *ctx, int64_t n, const double *a, const double *b, double *out_log, double *out_atan2);
 
 #ifdef __cplusplus
 }

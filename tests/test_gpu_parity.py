@@ -84,6 +84,36 @@ def test_prism_rows_vs_reference(ctx, golden_dir):
         assert np.all(np.abs(r - ref) <= 8 * 2.3e-16 * prism_term_scale(grid, o))
 
 
+def test_fastmath_device(ctx):
+    """The device build of csrc/fastmath.h (log / atan2 of the prism kernels) against the host libm: <= 1 ulp class + the host's own."""
+    rng = np.random.default_rng(5)
+    n = 400000
+    XX = 3e4 * rng.uniform(-1, 1, n)
+    YY = np.where(rng.uniform(size=n) < 0.3, 10.0 ** rng.uniform(-6, 6, n), 3e4 * rng.uniform(-1, 1, n))
+    ZZ = 1e4 * rng.uniform(0, 1, n) + 0.1
+    R = np.sqrt(XX * XX + YY * YY + ZZ * ZZ)
+    spacing = lambda v: np.spacing(np.maximum(np.abs(v), 2.3e-308))
+    # log(R + XX), atan2(XX YY, ZZ R): the arguments of gravity_field.f90:165-181
+    a = R + XX
+    keep = a > 0
+    lg, _ = ctx.fastmath_eval(a[keep], a[keep])
+    ref = np.log(a[keep])
+    assert np.all(np.abs(lg - ref) <= 1.6 * np.maximum(spacing(ref), 2.3e-16))
+    y, x = XX * YY, ZZ * R * np.where(rng.uniform(size=n) < 0.2, -1.0, 1.0)
+    _, at = ctx.fastmath_eval(y, x)
+    ref = np.arctan2(y, x)
+    assert np.all(np.abs(at - ref) <= 2.7 * spacing(ref))
+    assert np.all(np.abs(at - ref) <= 2.0 * np.maximum(spacing(ref), 1.2e-16))
+    # special values take the library path
+    sa = np.array([0.0, -0.0, 1.0, -1.0, 1.0, 0.0, np.inf, 1e-320, 5.0, 1e300, -3.0])
+    sb = np.array([1.0, -1.0, 0.0, -0.0, 1.0, 0.0, 1.0, 1.0, -np.inf, 1e-300, -3.0])
+    lg, at = ctx.fastmath_eval(sa, sb)
+    with np.errstate(all="ignore"):
+        rl, ra = np.log(sa), np.arctan2(sa, sb)
+    assert np.all((lg == rl) | (np.isnan(lg) & np.isnan(rl)) | (np.abs(lg - rl) <= 2 * spacing(rl)))
+    assert np.all((np.abs(at - ra) <= 2 * spacing(ra)) & (np.signbit(at) == np.signbit(ra)))
+
+
 def prism_term_scale(grid, o):
     X1, X2, Y1, Y2, Z1, Z2 = grid
     s = np.zeros(X1.size)

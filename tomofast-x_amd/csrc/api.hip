@@ -28,6 +28,8 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     // test knobs of the hybrid layout (same as the debug keys "hybrid" / "hybrid_min_nnz"): the GPU suite is run a second time
     // with TFX_HYBRID_MIN_NNZ=0 so that every small matrix of the parity tests goes through the bitmap head as well
     if (const char *e = getenv("TFX_HYBRID")) c->hybrid = atoi(e) != 0;
+    if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = atoi(e) != 0;
+    if (const char *e = getenv("TFX_GEN_WGS_PER_CU")) c->gen_wgs_per_cu = atoi(e);
     if (const char *e = getenv("TFX_HYBRID_MIN_NNZ")) c->hybrid_min_nnz = atoll(e);
     if (const char *e = getenv("TFX_HYBRID_TAU")) c->hybrid_tau_permille = std::max(74, std::min(1000, atoi(e)));
     TFX_HIP(hipEventCreate(&c->ev0));
@@ -178,6 +180,23 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         int64_t hv = 0;
         for (const TileMeta &t : mm.h_tiles) hv += t.kind ? t.cnt : 0;
         return mm.nnz > 0 ? (int)(1000.0 * (double)hv / (double)mm.nnz) : 0;
+    }
+    if (!strcmp(key, "chunk_exponent_span")) {  // diagnostics: per mille of the chunks whose non-zero values span <= `value` binades
+        int64_t fit = 0, total = 0;
+        unsigned int hist[34];
+        TFX_TRY(chunk_exponent_stats(ctx, ctx->selmat(), value, &fit, &total, hist));
+        fprintf(stderr, "[tfx] chunk exponent spans (binades: chunks):");
+        for (int i = 0; i < 34; ++i) if (hist[i]) fprintf(stderr, " %d:%u", i, hist[i]);
+        fprintf(stderr, "\n");
+        return total > 0 ? (int)(1000.0 * (double)fit / (double)total) : 0;
+    }
+    if (!strcmp(key, "gen_wgs_per_cu")) {
+        ctx->gen_wgs_per_cu = value;
+        return 0;
+    }
+    if (!strcmp(key, "build_overlap")) {
+        ctx->build_overlap = value != 0;
+        return 0;
     }
     if (!strcmp(key, "items_per_cu")) {         // work items per CU for matrices finished from now on
         ctx->items_per_cu = value > 0 ? value : 16;

@@ -11,6 +11,7 @@
 // operation order (separate multiply / add), so wavelets are bit-identical to the reference and prism rows differ
 // only through the device libm (atan2 / log, <= 2 ulp).
 #include "common.h"
+#include "fastmath.h"
 #include <algorithm>
 #include <cmath>
 
@@ -22,21 +23,38 @@ namespace tfx {
 // gravity_field.f90:26 - `G_grav = 6.674e-11` is a default-real literal: the value used is (double)(float)6.674e-11.
 __device__ __forceinline__ double g_grav() { return (double)6.674e-11f; }
 
+// The reduction tables of fastmath.h live in the workgroup's LDS: one static array shared by every device function of a kernel
+// (init_math_tables() at kernel entry, then a __syncthreads() before the first dlog / datan2).
+__device__ __forceinline__ FastMathTables math_tables()
+{
+    __shared__ double s_math_tab[FASTMATH_TABLE_DOUBLES];
+    return FastMathTables{s_math_tab, s_math_tab + 3 * TFX_LOG_TAB_N};
+}
+__device__ __forceinline__ void init_math_tables()
+{
+    double *lds = const_cast<double *>(math_tables().logt);
+    for (int i = threadIdx.x; i < 3 * TFX_LOG_TAB_N; i += blockDim.x) lds[i] = tfx_log_tab[i];
+    for (int i = threadIdx.x; i < 2 * TFX_ATAN_TAB_N; i += blockDim.x) lds[3 * TFX_LOG_TAB_N + i] = tfx_atan_tab[i];
+}
+__device__ __forceinline__ double dlog(double x) { return fast_log(x, math_tables()); }
+__device__ __forceinline__ double datan2(double y, double x) { return fast_atan2(y, x, math_tables()); }
+
 // One corner of the prism integral (gravity_field.f90:165-186): returns ZZ*atan2'(XX*YY, ZZ*R) - XX*log(R+YY) - YY*log(R+XX)
 // and flags R+XX <= 0 / R+YY <= 0 (:176-181).  Shared by the general and the tensor-grid kernel so both produce the
 // same bits.
+// log / atan2: fastmath.h (table-reduced, <= 1 ulp class like the device libm, a third of its instructions).
 __device__ __forceinline__ double corner_term(double XX, double YY, double ZZ, int &bad)
 {
     const double twopi = 2.0 * 3.14159265358979323846;
     const double Rs = sqrt(XX * XX + YY * YY + ZZ * ZZ);                                            // :165
-    double arg3 = atan2(XX * YY, ZZ * Rs);                                                          // :167
+    double arg3 = datan2(XX * YY, ZZ * Rs);                                                         // :167
     if (arg3 < 0) arg3 = arg3 + twopi;
     double arg4 = Rs + XX;
     double arg5 = Rs + YY;
     if (arg4 <= 0.) bad |= 1;
     if (arg5 <= 0.) bad |= 2;
-    arg4 = log(arg4);
-    arg5 = log(arg5);
+    arg4 = dlog(arg4);
+    arg5 = dlog(arg5);
     return ZZ * arg3 - XX * arg5 - YY * arg4;                                                       // :186
 }
 
@@ -54,10 +72,10 @@ __global__ __launch_bounds__(256) void k_prism_gz(int64_t N, const double *__res
                                                   double *__restrict__ sumsq /* [nobs][gridDim.x] or null */)
 {
     __shared__ double s_sq[PRISM_MAX_BATCH];
-    if (sumsq) {
+    init_math_tables();
+    if (sumsq)
         for (int o = threadIdx.x; o < nobs; o += blockDim.x) s_sq[o] = 0.0;
-        __syncthreads();
-    }
+    __syncthreads();
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < N; p0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = p0 + threadIdx.x;
         const bool active = p < N;
@@ -110,15 +128,21 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
                                                          int nobs, const double *__restrict__ xd,
                                                          const double *__restrict__ yd, const double *__restrict__ zd,
                                                          const double *__restrict__ cw, double *__restrict__ rows,
-                                                         int *__restrict__ err, double *__restrict__ sumsq)
+                                                         int *__restrict__ err, double *__restrict__ sumsq, int ntiles)
 {
     __shared__ double T[PT_NODES];
     __shared__ double s_w[4];
+    init_math_tables();
     // the node / cell index arithmetic does not depend on the observation: done once per workgroup, kept in LDS
     __shared__ double s_xe[PT_X + 1], s_ye[PT_Y + 1], s_ze[PT_Z + 1];
     __shared__ int s_node[PT_NODES];                      // LDS slot | a << 12 | b << 18 | c << 22
     const int tiles_x = (nx + PT_X - 1) / PT_X, tiles_y = (ny + PT_Y - 1) / PT_Y;
-    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
+    int bad = 0;
+    // a launch of fewer workgroups than tiles (the build's overlap mode: two per CU, leaving registers and LDS to the HBM-bound
+    // kernels of the main stream) walks the tiles with the grid's stride
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (tile != (int)blockIdx.x) __syncthreads();           // the previous tile's T / s_node are still being read
+    const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, bz = tile / (tiles_x * tiles_y);
     const int i0 = bx * PT_X, j0 = by * PT_Y, k0 = bz * PT_Z;
     const int cx = min(PT_X, nx - i0), cy = min(PT_Y, ny - j0), cz = min(PT_Z, nz - k0);
     const int64_t N = (int64_t)nx * ny * nz;
@@ -149,7 +173,6 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
     double c_w[CPT];
 #pragma unroll
     for (int j = 0; j < CPT; ++j) c_w[j] = (cw && c_slot[j] >= 0) ? cw[c_col[j]] : 1.0;
-    int bad = 0;
     for (int o = 0; o < nobs; ++o) {
         const double xo = xd[o], yo = yd[o], zo = zd[o];
         __syncthreads();
@@ -184,8 +207,9 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
             for (int d = 32; d > 0; d >>= 1) sq += __shfl_down(sq, d);
             if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sq;
             __syncthreads();
-            if (threadIdx.x == 0) sumsq[(int64_t)o * gridDim.x + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+            if (threadIdx.x == 0) sumsq[(int64_t)o * ntiles + tile] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
         }
+    }
     }
     if (bad) atomicOr(err, bad);
 }
@@ -210,24 +234,24 @@ __device__ __forceinline__ void sharmbox_dev(double x0, double y0, double z0, do
     double R1 = ry2sq + rx2sq, R2 = ry2sq + rx1sq, R3 = ry1sq + rx2sq, R4 = ry1sq + rx1sq;        // :361-364
     double a1 = sqrt(rz2sq + R2), a2 = sqrt(rz2sq + R1), a3 = sqrt(rz1sq + R1), a4 = sqrt(rz1sq + R2);
     double a5 = sqrt(rz2sq + R3), a6 = sqrt(rz2sq + R4), a7 = sqrt(rz1sq + R4), a8 = sqrt(rz1sq + R3);
-    tx[0] = atan2(ry1 * rz2, (rx2 * a5 + eps)) - atan2(ry2 * rz2, (rx2 * a2 + eps)) + atan2(ry2 * rz1, (rx2 * a3 + eps)) -
-            atan2(ry1 * rz1, (rx2 * a8 + eps)) + atan2(ry2 * rz2, (rx1 * a1 + eps)) - atan2(ry1 * rz2, (rx1 * a6 + eps)) +
-            atan2(ry1 * rz1, (rx1 * a7 + eps)) - atan2(ry2 * rz1, (rx1 * a4 + eps));                     // :376-383
-    ty[0] = log((rz2 + a2 + eps) / (rz1 + a3 + eps)) - log((rz2 + a1 + eps) / (rz1 + a4 + eps)) +
-            log((rz2 + a6 + eps) / (rz1 + a7 + eps)) - log((rz2 + a5 + eps) / (rz1 + a8 + eps));        // :386-389
-    ty[1] = atan2(rx1 * rz2, (ry2 * a1 + eps)) - atan2(rx2 * rz2, (ry2 * a2 + eps)) + atan2(rx2 * rz1, (ry2 * a3 + eps)) -
-            atan2(rx1 * rz1, (ry2 * a4 + eps)) + atan2(rx2 * rz2, (ry1 * a5 + eps)) - atan2(rx1 * rz2, (ry1 * a6 + eps)) +
-            atan2(rx1 * rz1, (ry1 * a7 + eps)) - atan2(rx2 * rz1, (ry1 * a8 + eps));                     // :392-399
+    tx[0] = datan2(ry1 * rz2, (rx2 * a5 + eps)) - datan2(ry2 * rz2, (rx2 * a2 + eps)) + datan2(ry2 * rz1, (rx2 * a3 + eps)) -
+            datan2(ry1 * rz1, (rx2 * a8 + eps)) + datan2(ry2 * rz2, (rx1 * a1 + eps)) - datan2(ry1 * rz2, (rx1 * a6 + eps)) +
+            datan2(ry1 * rz1, (rx1 * a7 + eps)) - datan2(ry2 * rz1, (rx1 * a4 + eps));                     // :376-383
+    ty[0] = dlog((rz2 + a2 + eps) / (rz1 + a3 + eps)) - dlog((rz2 + a1 + eps) / (rz1 + a4 + eps)) +
+            dlog((rz2 + a6 + eps) / (rz1 + a7 + eps)) - dlog((rz2 + a5 + eps) / (rz1 + a8 + eps));        // :386-389
+    ty[1] = datan2(rx1 * rz2, (ry2 * a1 + eps)) - datan2(rx2 * rz2, (ry2 * a2 + eps)) + datan2(rx2 * rz1, (ry2 * a3 + eps)) -
+            datan2(rx1 * rz1, (ry2 * a4 + eps)) + datan2(rx2 * rz2, (ry1 * a5 + eps)) - datan2(rx1 * rz2, (ry1 * a6 + eps)) +
+            datan2(rx1 * rz1, (ry1 * a7 + eps)) - datan2(rx2 * rz1, (ry1 * a8 + eps));                     // :392-399
     R1 = ry2sq + rz1sq; R2 = ry2sq + rz2sq; R3 = ry1sq + rz1sq; R4 = ry1sq + rz2sq;                    // :404-407
     a1 = sqrt(rx1sq + R1); a2 = sqrt(rx2sq + R1); a3 = sqrt(rx1sq + R2); a4 = sqrt(rx2sq + R2);
     a5 = sqrt(rx1sq + R3); a6 = sqrt(rx2sq + R3); a7 = sqrt(rx1sq + R4); a8 = sqrt(rx2sq + R4);
-    ty[2] = log((rx1 + a1 + eps) / (rx2 + a2 + eps)) - log((rx1 + a3 + eps) / (rx2 + a4 + eps)) +
-            log((rx1 + a7 + eps) / (rx2 + a8 + eps)) - log((rx1 + a5 + eps) / (rx2 + a6 + eps));        // :419-422
+    ty[2] = dlog((rx1 + a1 + eps) / (rx2 + a2 + eps)) - dlog((rx1 + a3 + eps) / (rx2 + a4 + eps)) +
+            dlog((rx1 + a7 + eps) / (rx2 + a8 + eps)) - dlog((rx1 + a5 + eps) / (rx2 + a6 + eps));        // :419-422
     R1 = rx2sq + rz1sq; R2 = rx2sq + rz2sq; R3 = rx1sq + rz1sq; R4 = rx1sq + rz2sq;                    // :424-427
     a1 = sqrt(ry1sq + R1); a2 = sqrt(ry2sq + R1); a3 = sqrt(ry1sq + R2); a4 = sqrt(ry2sq + R2);
     a5 = sqrt(ry1sq + R3); a6 = sqrt(ry2sq + R3); a7 = sqrt(ry1sq + R4); a8 = sqrt(ry2sq + R4);
-    tx[2] = log((ry1 + a1 + eps) / (ry2 + a2 + eps)) - log((ry1 + a3 + eps) / (ry2 + a4 + eps)) +
-            log((ry1 + a7 + eps) / (ry2 + a8 + eps)) - log((ry1 + a5 + eps) / (ry2 + a6 + eps));        // :439-442
+    tx[2] = dlog((ry1 + a1 + eps) / (ry2 + a2 + eps)) - dlog((ry1 + a3 + eps) / (ry2 + a4 + eps)) +
+            dlog((ry1 + a7 + eps) / (ry2 + a8 + eps)) - dlog((ry1 + a5 + eps) / (ry2 + a6 + eps));        // :439-442
     tz[2] = -1 * (tx[0] + ty[1]);                                                                       // :446
     tz[1] = ty[2];
     tx[1] = ty[0];
@@ -305,10 +329,10 @@ __global__ __launch_bounds__(256) void k_magprism(int64_t N, const double *__res
 {
     constexpr int NSUB = NCM * NCD;
     __shared__ double s_sq[PRISM_MAX_BATCH];
-    if (sumsq) {
+    init_math_tables();
+    if (sumsq)
         for (int o = threadIdx.x; o < nobs * NSUB; o += blockDim.x) s_sq[o] = 0.0;
-        __syncthreads();
-    }
+    __syncthreads();
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < N; p0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = p0 + threadIdx.x;
         const bool active = p < N;
@@ -363,6 +387,7 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
     constexpr int NSUB = NCM * NCD;
     __shared__ double Taz[MT_NODES], Tax[MT_NODES], Tay[MT_NODES], TAx[MT_NODES], TAy[MT_NODES];      // 5 x 1377 doubles = 55 KB
     __shared__ double s_w[4];
+    init_math_tables();                                   // (+ 4 KB; the first __syncthreads() of the observation loop publishes them)
     const double eps = 0.;
     const int tiles_x = (nx + MT_X - 1) / MT_X, tiles_y = (ny + MT_Y - 1) / MT_Y;
     const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
@@ -397,8 +422,8 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
             const double ay = sqrt(rysq + (rxsq + rzsq));        // :424-435   a = sqrt(ry^2 + R), R = rx^2 + rz^2
             const int id = code & 4095;
             Taz[id] = az; Tax[id] = ax; Tay[id] = ay;
-            TAx[id] = atan2(ry * rz, (rx * az + eps));           // the terms of tx(1), :376-383
-            TAy[id] = atan2(rx * rz, (ry * az + eps));           // the terms of ty(2), :392-399
+            TAx[id] = datan2(ry * rz, (rx * az + eps));           // the terms of tx(1), :376-383
+            TAy[id] = datan2(rx * rz, (ry * az + eps));           // the terms of ty(2), :392-399
         }
         __syncthreads();
         double sq[NSUB];
@@ -420,20 +445,20 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
 #define C_(T, i, j, k) T[NODE(a + (i) - 1, b + (j) - 1, c + (k) - 1)]
                 tx[0] = C_(TAx, 2, 1, 2) - C_(TAx, 2, 2, 2) + C_(TAx, 2, 2, 1) - C_(TAx, 2, 1, 1) + C_(TAx, 1, 2, 2) - C_(TAx, 1, 1, 2) +
                         C_(TAx, 1, 1, 1) - C_(TAx, 1, 2, 1);                                                                  // :376-383
-                ty[0] = log((rz2 + C_(Taz, 2, 2, 2) + eps) / (rz1 + C_(Taz, 2, 2, 1) + eps)) -
-                        log((rz2 + C_(Taz, 1, 2, 2) + eps) / (rz1 + C_(Taz, 1, 2, 1) + eps)) +
-                        log((rz2 + C_(Taz, 1, 1, 2) + eps) / (rz1 + C_(Taz, 1, 1, 1) + eps)) -
-                        log((rz2 + C_(Taz, 2, 1, 2) + eps) / (rz1 + C_(Taz, 2, 1, 1) + eps));                                 // :386-389
+                ty[0] = dlog((rz2 + C_(Taz, 2, 2, 2) + eps) / (rz1 + C_(Taz, 2, 2, 1) + eps)) -
+                        dlog((rz2 + C_(Taz, 1, 2, 2) + eps) / (rz1 + C_(Taz, 1, 2, 1) + eps)) +
+                        dlog((rz2 + C_(Taz, 1, 1, 2) + eps) / (rz1 + C_(Taz, 1, 1, 1) + eps)) -
+                        dlog((rz2 + C_(Taz, 2, 1, 2) + eps) / (rz1 + C_(Taz, 2, 1, 1) + eps));                                 // :386-389
                 ty[1] = C_(TAy, 1, 2, 2) - C_(TAy, 2, 2, 2) + C_(TAy, 2, 2, 1) - C_(TAy, 1, 2, 1) + C_(TAy, 2, 1, 2) - C_(TAy, 1, 1, 2) +
                         C_(TAy, 1, 1, 1) - C_(TAy, 2, 1, 1);                                                                  // :392-399
-                ty[2] = log((rx1 + C_(Tax, 1, 2, 1) + eps) / (rx2 + C_(Tax, 2, 2, 1) + eps)) -
-                        log((rx1 + C_(Tax, 1, 2, 2) + eps) / (rx2 + C_(Tax, 2, 2, 2) + eps)) +
-                        log((rx1 + C_(Tax, 1, 1, 2) + eps) / (rx2 + C_(Tax, 2, 1, 2) + eps)) -
-                        log((rx1 + C_(Tax, 1, 1, 1) + eps) / (rx2 + C_(Tax, 2, 1, 1) + eps));                                 // :419-422
-                tx[2] = log((ry1 + C_(Tay, 2, 1, 1) + eps) / (ry2 + C_(Tay, 2, 2, 1) + eps)) -
-                        log((ry1 + C_(Tay, 2, 1, 2) + eps) / (ry2 + C_(Tay, 2, 2, 2) + eps)) +
-                        log((ry1 + C_(Tay, 1, 1, 2) + eps) / (ry2 + C_(Tay, 1, 2, 2) + eps)) -
-                        log((ry1 + C_(Tay, 1, 1, 1) + eps) / (ry2 + C_(Tay, 1, 2, 1) + eps));                                 // :439-442
+                ty[2] = dlog((rx1 + C_(Tax, 1, 2, 1) + eps) / (rx2 + C_(Tax, 2, 2, 1) + eps)) -
+                        dlog((rx1 + C_(Tax, 1, 2, 2) + eps) / (rx2 + C_(Tax, 2, 2, 2) + eps)) +
+                        dlog((rx1 + C_(Tax, 1, 1, 2) + eps) / (rx2 + C_(Tax, 2, 1, 2) + eps)) -
+                        dlog((rx1 + C_(Tax, 1, 1, 1) + eps) / (rx2 + C_(Tax, 2, 1, 1) + eps));                                 // :419-422
+                tx[2] = dlog((ry1 + C_(Tay, 2, 1, 1) + eps) / (ry2 + C_(Tay, 2, 2, 1) + eps)) -
+                        dlog((ry1 + C_(Tay, 2, 1, 2) + eps) / (ry2 + C_(Tay, 2, 2, 2) + eps)) +
+                        dlog((ry1 + C_(Tay, 1, 1, 2) + eps) / (ry2 + C_(Tay, 1, 2, 2) + eps)) -
+                        dlog((ry1 + C_(Tay, 1, 1, 1) + eps) / (ry2 + C_(Tay, 1, 2, 1) + eps));                                 // :439-442
 #undef C_
                 tz[2] = -1 * (tx[0] + ty[1]);                                                                                 // :446
                 tz[1] = ty[2];
@@ -489,10 +514,10 @@ __global__ __launch_bounds__(256) void k_gradiprism(int64_t N, const double *__r
     constexpr int NC = FULL ? 6 : 1;
     const double twopi = 2.0 * 3.14159265358979323846;
     __shared__ double s_sq[PRISM_MAX_BATCH];
-    if (sumsq) {
+    init_math_tables();
+    if (sumsq)
         for (int o = threadIdx.x; o < nobs * NC; o += blockDim.x) s_sq[o] = 0.0;
-        __syncthreads();
-    }
+    __syncthreads();
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < N; p0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = p0 + threadIdx.x;
         const bool active = p < N;
@@ -514,12 +539,12 @@ __global__ __launch_bounds__(256) void k_gradiprism(int64_t N, const double *__r
                     for (int M = 0; M < 2; ++M) {
                         const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;
                         const double Rs = sqrt(XX[K] * XX[K] + YY[L] * YY[L] + ZZ[M] * ZZ[M]);            // :251
-                        double vzz = -atan2(XX[K] * YY[L], Rs * ZZ[M]);                                    // :255
+                        double vzz = -datan2(XX[K] * YY[L], Rs * ZZ[M]);                                    // :255
                         if (vzz < 0) vzz = vzz + twopi;
                         gzz = gzz + dmu * vzz;
                         if (FULL) {
-                            double vxx = atan2(XX[K] * YY[L], XX[K] * XX[K] + Rs * ZZ[M] + ZZ[M] * ZZ[M]);   // :253
-                            double vyy = atan2(XX[K] * YY[L], Rs * Rs + Rs * ZZ[M] - XX[K] * XX[K]);         // :254
+                            double vxx = datan2(XX[K] * YY[L], XX[K] * XX[K] + Rs * ZZ[M] + ZZ[M] * ZZ[M]);   // :253
+                            double vyy = datan2(XX[K] * YY[L], Rs * Rs + Rs * ZZ[M] - XX[K] * XX[K]);         // :254
                             if (vxx < 0) vxx = vxx + twopi;
                             if (vyy < 0) vyy = vyy + twopi;
                             const double arg1 = Rs + ZZ[M];
@@ -528,9 +553,9 @@ __global__ __launch_bounds__(256) void k_gradiprism(int64_t N, const double *__r
                             if (arg22 == 0. || arg32 == 0.) bad |= 16;
                             const double arg2 = arg21 / arg22, arg3 = arg31 / arg32;
                             if (arg1 <= 0. || arg2 <= 0. || arg3 <= 0.) bad |= 32;
-                            const double vxy = log(arg1);
-                            const double vzx = 0.5 * log(arg2);
-                            const double vyz = 0.5 * log(arg3);
+                            const double vxy = dlog(arg1);
+                            const double vzx = 0.5 * dlog(arg2);
+                            const double vyz = 0.5 * dlog(arg3);
                             gxx = gxx + dmu * vxx;
                             gyy = gyy + dmu * vyy;
                             gxy = gxy + dmu * vxy;
@@ -581,6 +606,7 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
     const double twopi = 2.0 * 3.14159265358979323846;
     __shared__ double T[NC][GT::NODES];
     __shared__ double s_w[4];
+    init_math_tables();                                   // (published by the first __syncthreads() of the observation loop)
     // observation-independent index arithmetic, once per workgroup (as in k_prism_gz_tensor)
     __shared__ double s_xe[GT::X + 1], s_ye[GT::Y + 1], s_ze[GT::Z + 1];
     __shared__ int s_node[GT::NODES];                     // LDS slot | a << 12 | b << 18 | c << 22
@@ -624,12 +650,12 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
             const int code = s_node[n];
             const double XX = xo - s_xe[(code >> 12) & 63], YY = yo - s_ye[(code >> 18) & 15], ZZ = -(zo - s_ze[code >> 22]);   // gravity_field.f90:232-237
             const double Rs = sqrt(XX * XX + YY * YY + ZZ * ZZ);                                         // :251
-            double vzz = -atan2(XX * YY, Rs * ZZ);                                                       // :255
+            double vzz = -datan2(XX * YY, Rs * ZZ);                                                       // :255
             if (vzz < 0) vzz = vzz + twopi;
             const int id = code & 4095;
             if (FULL) {
-                double vxx = atan2(XX * YY, XX * XX + Rs * ZZ + ZZ * ZZ);                                // :253
-                double vyy = atan2(XX * YY, Rs * Rs + Rs * ZZ - XX * XX);                                // :254
+                double vxx = datan2(XX * YY, XX * XX + Rs * ZZ + ZZ * ZZ);                                // :253
+                double vyy = datan2(XX * YY, Rs * Rs + Rs * ZZ - XX * XX);                                // :254
                 if (vxx < 0) vxx = vxx + twopi;
                 if (vyy < 0) vyy = vyy + twopi;
                 const double arg1 = Rs + ZZ;
@@ -641,9 +667,9 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
                 T[0][id] = vxx;
                 T[NC > 1 ? 1 : 0][id] = vyy;
                 T[NC > 2 ? 2 : 0][id] = vzz;
-                T[NC > 3 ? 3 : 0][id] = log(arg1);                                                       // vxy, :286
-                T[NC > 4 ? 4 : 0][id] = 0.5 * log(arg3);                                                 // vyz, :288
-                T[NC > 5 ? 5 : 0][id] = 0.5 * log(arg2);                                                 // vzx, :287
+                T[NC > 3 ? 3 : 0][id] = dlog(arg1);                                                       // vxy, :286
+                T[NC > 4 ? 4 : 0][id] = 0.5 * dlog(arg3);                                                 // vyz, :288
+                T[NC > 5 ? 5 : 0][id] = 0.5 * dlog(arg2);                                                 // vzx, :287
             } else {
                 T[0][id] = vzz;
             }
@@ -823,8 +849,10 @@ int prism_rows_dev(tfx_ctx *ctx, const RowGen &gen, int nobs, const double *d_x,
         if (nblk) *nblk = grid;
     } else if (ctx->tensor_grid) {
         const int tiles = ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
-        hipLaunchKernelGGL(k_prism_gz_tensor, dim3(tiles), dim3(256), 0, s, ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p,
-                           ctx->edges[1].p, ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err, d_sumsq);
+        // (gen_grid_limit: the build's overlap mode caps the resident workgroups - see build_kernel_any)
+        const int wgs = ctx->gen_grid_limit > 0 ? std::min(tiles, ctx->gen_grid_limit) : tiles;
+        hipLaunchKernelGGL(k_prism_gz_tensor, dim3(wgs), dim3(256), 0, s, ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p,
+                           ctx->edges[1].p, ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err, d_sumsq, tiles);
         if (nblk) *nblk = tiles;
     } else {
         hipLaunchKernelGGL(k_prism_gz, dim3(grid), dim3(256), 0, s, GRID_ARGS, d_rows, d_err, d_sumsq);
@@ -2350,6 +2378,39 @@ int tfx_column_weight_type2(tfx_ctx *ctx, int64_t ndata, const double *xd, const
     return 0;
 }
 
+// diagnostics: the device build of fastmath.h on host arrays (tests compare it with the host libm)
+__global__ void k_fastmath_eval(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out_log,
+                                double *__restrict__ out_atan2)
+{
+    tfx::init_math_tables();
+    __syncthreads();
+    const tfx::FastMathTables tb = tfx::math_tables();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        out_log[i] = tfx::fast_log(a[i], tb);
+        out_atan2[i] = tfx::fast_atan2(a[i], b[i], tb);
+    }
+}
+
+int tfx_fastmath_eval(tfx_ctx *ctx, int64_t n, const double *a, const double *b, double *out_log, double *out_atan2)
+{
+    using namespace tfx;
+    if (!ctx || !a || !b || !out_log || !out_atan2 || n < 0) return fail(TFX_E_ARG, "tfx_fastmath_eval: bad argument");
+    if (n == 0) return 0;
+    TFX_HIP(hipSetDevice(ctx->device));
+    DBuf<double> da, db, dl, dt;
+    TFX_TRY(da.alloc((size_t)n));
+    TFX_TRY(db.alloc((size_t)n));
+    TFX_TRY(dl.alloc((size_t)n));
+    TFX_TRY(dt.alloc((size_t)n));
+    TFX_TRY(copy_any(da.p, a, (size_t)n * sizeof(double), ctx->stream));
+    TFX_TRY(copy_any(db.p, b, (size_t)n * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_fastmath_eval, dim3((unsigned)std::min<int64_t>(4096, (n + 255) / 256)), dim3(256), 0, ctx->stream, n, da.p, db.p, dl.p, dt.p);
+    TFX_HIP(hipGetLastError());
+    TFX_TRY(copy_any(out_log, dl.p, (size_t)n * sizeof(double), ctx->stream));
+    TFX_TRY(copy_any(out_atan2, dt.p, (size_t)n * sizeof(double), ctx->stream));
+    return 0;
+}
+
 int tfx_wavelet(tfx_ctx *ctx, double *sarr, int n1, int n2, int n3, int64_t nvec, int type, int direction)
 {
     if (!ctx || !sarr) return fail(TFX_E_ARG, "tfx_wavelet: null argument");
@@ -2587,32 +2648,92 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     int64_t r0 = 0;               // first matrix row of the staging area
     bool band_off = false;
     const int64_t batches0 = ctx->band_batches, fallbacks0 = ctx->band_fallbacks;
+    // Two streams: the row generator is VALU-bound (fp64 log / atan2 / sqrt per grid node), everything after it - wavelet passes,
+    // threshold, compaction, tile scatter - is HBM-bound.  The generator of batch b + 1 runs on its own (low-priority) stream into
+    // the second row buffer while the main stream transforms and compacts batch b: their waves share the CUs, one kind waiting on
+    // memory while the other computes.  (ctx->build_overlap = 0: one stream, one buffer - the sequential order of round 1.)
+    const bool overlap = ctx->build_overlap && ndata > 1;
+    DBuf<double> drows2, dred2;
+    double *rows_buf[2] = {drows.p, drows.p}, *red_buf[2] = {dred.p, dred.p};
+    struct GenStream {
+        hipStream_t st = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr}, ev0 = nullptr;
+        ~GenStream()
+        {
+            if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+            for (hipEvent_t e : {ev[0], ev[1], ev0}) if (e) (void)hipEventDestroy(e);
+        }
+    } gs;
+    if (overlap) {
+        TFX_TRY(drows2.alloc((size_t)ob_max * nsub * N));
+        TFX_TRY(dred2.alloc((size_t)lines_max * npart));
+        rows_buf[1] = drows2.p;
+        red_buf[1] = dred2.p;
+        int prio_lo = 0, prio_hi = 0;
+        TFX_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        TFX_HIP(hipStreamCreateWithPriority(&gs.st, hipStreamNonBlocking, prio_lo));
+        for (int i = 0; i < 2; ++i) TFX_HIP(hipEventCreateWithFlags(&gs.ev[i], hipEventDisableTiming));
+        TFX_HIP(hipEventCreateWithFlags(&gs.ev0, hipEventDisableTiming));
+        TFX_HIP(hipEventRecord(gs.ev0, s));                 // the uploads of the observations / weights queued above
+        TFX_HIP(hipStreamWaitEvent(gs.st, gs.ev0, 0));
+    }
+    // observations of the batch that starts at g_ with fill_ rows staged: just enough to complete the current row block (so that
+    // with one data component blocks never straddle)
+    auto batch_obs = [&](int64_t g_, int fill_) -> int {
+        const int64_t want = ((int64_t)RB - fill_ + ncd - 1) / ncd;
+        return (int)std::min<int64_t>(std::min<int64_t>(ob_max, std::max<int64_t>(1, want)), ndata - g_);
+    };
+    auto generate = [&](int64_t g_, int nb_, int slot_) -> int {
+        hipStream_t keep = ctx->stream;
+        if (overlap) {
+            ctx->stream = gs.st;
+            ctx->gen_grid_limit = ctx->gen_wgs_per_cu > 0 ? ctx->gen_wgs_per_cu * ctx->num_cu : 0;
+        }
+        const int rc = prism_rows_dev(ctx, gen, nb_, dobs.p + g_, dobs.p + ndata + g_, dobs.p + 2 * ndata + g_, dcw.p, rows_buf[slot_], derr.p,
+                                      compression_type > 0 ? red_buf[slot_] : nullptr);
+        ctx->stream = keep;
+        ctx->gen_grid_limit = 0;
+        TFX_TRY(rc);
+        if (overlap) TFX_HIP(hipEventRecord(gs.ev[slot_], gs.st));
+        return 0;
+    };
+    int slot = 0;
+    int nb_cur = batch_obs(0, 0);
+    if (overlap) TFX_TRY(generate(0, nb_cur, 0));
     for (int64_t g = 0; g < ndata;) {
-        // just enough observations to complete the current row block (so that with one data component blocks never straddle)
-        const int64_t want = ((int64_t)RB - fill + ncd - 1) / ncd;
-        const int nb = (int)std::min<int64_t>(std::min<int64_t>(ob_max, std::max<int64_t>(1, want)), ndata - g);
+        const int nb = nb_cur;
         const int nl = nb * nsub;                                   // lines of this batch
-        TFX_TRY(prism_rows_dev(ctx, gen, nb, dobs.p + g, dobs.p + ndata + g, dobs.p + 2 * ndata + g, dcw.p, drows.p, derr.p,
-                               compression_type > 0 ? dred.p : nullptr));
+        double *const rows_cur = rows_buf[slot], *const red_cur = red_buf[slot];
+        if (overlap) {
+            // the next batch's generator first: its buffer was last read by the compaction of batch b - 1, which the host has waited for
+            int fill_after = fill + nb * ncd;
+            const int64_t g_after = g + nb;
+            if (fill_after >= RB || g_after >= ndata) fill_after %= RB;
+            nb_cur = g_after < ndata ? batch_obs(g_after, fill_after) : 0;
+            if (nb_cur > 0) TFX_TRY(generate(g_after, nb_cur, slot ^ 1));
+            TFX_HIP(hipStreamWaitEvent(s, gs.ev[slot], 0));
+        } else {
+            TFX_TRY(generate(g, nb, 0));
+        }
         // threshold: bracketed from a sample and finished inside the compaction's count pass (band select) for large rows,
         // else the full radix select up front
         const bool banded = compression_type > 0 && K < N && K > 0 && N >= ctx->band_min_n && !band_off;
         if (compression_type > 0) {
-            hipLaunchKernelGGL(k_rows_final_sum, dim3(nl), dim3(256), 0, s, dred.p, npart, dcf.p);                  // cost_full :234
+            hipLaunchKernelGGL(k_rows_final_sum, dim3(nl), dim3(256), 0, s, red_cur, npart, dcf.p);                  // cost_full :234
             TFX_HIP(hipGetLastError());
-            TFX_TRY(wavelet_dev(ctx, drows.p, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1));                   // :237
-            if (!banded) TFX_TRY(select_threshold_dev(ctx, sw, drows.p, nl, N, K, cw.thr.p));                         // :240-256
+            TFX_TRY(wavelet_dev(ctx, rows_cur, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1));                   // :237
+            if (!banded) TFX_TRY(select_threshold_dev(ctx, sw, rows_cur, nl, N, K, cw.thr.p));                         // :240-256
         }
         int h_fail = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
             SelectWork *sel = (banded && attempt == 0) ? &sw : nullptr;
-            if (attempt == 1) TFX_TRY(select_threshold_dev(ctx, sw, drows.p, nl, N, K, cw.thr.p));     // a band missed: full select
+            if (attempt == 1) TFX_TRY(select_threshold_dev(ctx, sw, rows_cur, nl, N, K, cw.thr.p));     // a band missed: full select
             if (to_rs)
-                TFX_TRY(compact_dev(ctx, cw, drows.p, nl, N, 0, 0, N, rs->cols.p + (size_t)(g * ncd) * rs->stride,
+                TFX_TRY(compact_dev(ctx, cw, rows_cur, nl, N, 0, 0, N, rs->cols.p + (size_t)(g * ncd) * rs->stride,
                                     rs->vals.p + (size_t)(g * ncd) * rs->stride, rs->stride, rs->nel.p + g * ncd, dscale.p + g * nsub,
                                     nnz_hist_out ? dhist.p : nullptr, ncm, sel, K));
             else
-                TFX_TRY(compact_dev(ctx, cw, drows.p, nl, N, compression_type == 0, col_begin, col_end,
+                TFX_TRY(compact_dev(ctx, cw, rows_cur, nl, N, compression_type == 0, col_begin, col_end,
                                     keep_matrix ? ell_cols.p + (size_t)fill * stride : nullptr,
                                     keep_matrix ? ell_vals.p + (size_t)fill * stride : nullptr, stride, ell_nel.p + fill,
                                     dscale.p + g * nsub, nnz_hist_out ? dhist.p : nullptr, ncm, sel, K));
@@ -2657,6 +2778,8 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
                 fill = left;
             }
         }
+        if (overlap) slot ^= 1;
+        else if (g < ndata) nb_cur = batch_obs(g, fill);
     }
     if (keep_matrix) {
         TFX_TRY(matrix_finish(ctx));

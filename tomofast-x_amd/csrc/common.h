@@ -228,6 +228,9 @@ struct tfx_ctx {
     int wd_ncomp = 0;          //   and the number of model components (of all problems) in the local unknown vector
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int gen_wgs_per_cu = 0;           // debug key "gen_wgs_per_cu": resident generator workgroups per CU in overlap mode (0: one per tile)
+    int gen_grid_limit = 0;           // (set around the generator launches of the overlapped build)
+    int build_overlap = 1;            // debug key "build_overlap": row generator on its own stream, one batch ahead of the wavelet / compaction
     int items_per_cu = 16;            // debug key "items_per_cu": work items per CU the tile list is cut into
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
     bool deterministic = false;       // debug: single-wave workgroups in the two products -> LDS atomics in program order
@@ -253,6 +256,7 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
 int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add);
 int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols);
 int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale);
+int chunk_exponent_stats(tfx_ctx *ctx, TiledMatrix &m, int span, int64_t *fit, int64_t *total, unsigned int *hist34);
 void set_column_counts(tfx_ctx *ctx, const int32_t *counts, int64_t ncols, int64_t nrows_counted);
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
 void prof_drain(tfx_ctx *ctx);

@@ -718,7 +718,7 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
     }
     if (cur > m.cap_entries)
         return fail(TFX_E_STATE, "tiled matrix capacity exceeded (%lld > %lld entries)", (long long)cur, (long long)m.cap_entries);
-    if (ntc > 0) {
+    if (ntc > 0 && cur > m.n_entries) {
         // zero the destination range (padding: slot 0 / no flag / value 0; the scatter ORs its bits in)
         const int64_t c0 = m.n_entries / CHUNK, c1 = cur / CHUNK;
         TFX_HIP(hipMemsetAsync(m.vals.p + m.n_entries, 0, (size_t)(cur - m.n_entries) * sizeof(float), s));
@@ -1539,6 +1539,46 @@ static void prof_end(tfx_ctx *ctx, int which)
 
 int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spmv_dev(ctx, ctx->selmat(), d_x, d_b, add); }
 int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spmtv_dev(ctx, ctx->selmat(), d_x, d_b, add); }
+
+// Diagnostics: how many chunks have all their non-zero values within `span` binades (candidates for a shared-exponent value format)
+__global__ void k_chunk_exponent_span(const float *__restrict__ vals, int64_t nchunks, int span, unsigned long long *__restrict__ count,
+                                      unsigned int *__restrict__ hist /* [34] span histogram */)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t c = w; c < nchunks; c += nw) {
+        int emin = 1 << 30, emax = -(1 << 30);
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t b = __float_as_uint(vals[c * CHUNK + lane * 8 + k]);
+            const int e = (int)((b >> 23) & 0xff);
+            if ((b & 0x7fffffffu) != 0) { emin = min(emin, e); emax = max(emax, e); }
+        }
+        for (int d = 32; d > 0; d >>= 1) { emin = min(emin, __shfl_xor(emin, d)); emax = max(emax, __shfl_xor(emax, d)); }
+        if (lane == 0) {
+            const int sp = emax >= emin ? emax - emin : 0;
+            if (sp <= span) atomicAdd(count, 1ull);
+            atomicAdd(&hist[min(sp, 33)], 1u);
+        }
+    }
+}
+
+int chunk_exponent_stats(tfx_ctx *ctx, TiledMatrix &m, int span, int64_t *fit, int64_t *total, unsigned int *hist34)
+{
+    const int64_t nch = m.n_entries / CHUNK;
+    DBuf<unsigned long long> cnt;
+    DBuf<unsigned int> dh;
+    TFX_TRY(cnt.alloc(1));
+    TFX_TRY(dh.alloc(34));
+    TFX_HIP(hipMemsetAsync(cnt.p, 0, 8, ctx->stream));
+    TFX_HIP(hipMemsetAsync(dh.p, 0, 34 * 4, ctx->stream));
+    if (nch > 0) hipLaunchKernelGGL(k_chunk_exponent_span, dim3(4096), dim3(256), 0, ctx->stream, m.vals.p, nch, span, cnt.p, dh.p);
+    unsigned long long h = 0;
+    TFX_TRY(copy_any(&h, cnt.p, 8, ctx->stream));
+    TFX_TRY(copy_any(hist34, dh.p, 34 * 4, ctx->stream));
+    *fit = (int64_t)h;
+    *total = nch;
+    return 0;
+}
 
 static MatPtrs mat_ptrs(const TiledMatrix &m, bool forward)
 {

@@ -31,6 +31,7 @@ SYMBOLS = [
     "tfx_partition_columns", "tfx_spmv", "tfx_spmtv", "tfx_lsqr_solve", "tfx_lsqr_begin", "tfx_lsqr_iterate",
     "tfx_lsqr_end", "tfx_lsqr_set_wavelet_domain", "tfx_lsqr_set_partition", "tfx_calc_data", "tfx_timer_start", "tfx_timer_stop_ms", "tfx_profile_enable", "tfx_profile_get",
     "tfx_debug_set",
+    "tfx_fastmath_eval",
 ]
 
 

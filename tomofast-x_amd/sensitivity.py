@@ -463,6 +463,15 @@ class Context:
         check(self._lib.tfx_calc_data(self._h, ptr(x), C.c_double(problem_weight), ptr(dw), ptr(out)))
         return out
 
+    def fastmath_eval(self, a, b):
+        """Diagnostics: the device log(a) and atan2(a, b) of the prism kernels (csrc/fastmath.h)."""
+        a = f64(a)
+        b = f64(b)
+        out_log = np.empty(a.size)
+        out_atan = np.empty(a.size)
+        check(self._lib.tfx_fastmath_eval(self._h, C.c_int64(a.size), ptr(a), ptr(b), ptr(out_log), ptr(out_atan)))
+        return out_log, out_atan
+
     def debug_set(self, key, value=0):
         rc = self._lib.tfx_debug_set(self._h, key.encode(), int(value))
         if rc < 0:
