@@ -30,6 +30,7 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     if (const char *e = getenv("TFX_HYBRID")) c->hybrid = atoi(e) != 0;
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = atoi(e) != 0;
     if (const char *e = getenv("TFX_GEN_WGS_PER_CU")) c->gen_wgs_per_cu = atoi(e);
+    if (const char *e = getenv("TFX_GEN_AFTER_WAVELET")) c->gen_after_wavelet = atoi(e) != 0;
     if (const char *e = getenv("TFX_HYBRID_MIN_NNZ")) c->hybrid_min_nnz = atoll(e);
     if (const char *e = getenv("TFX_HYBRID_TAU")) c->hybrid_tau_permille = std::max(74, std::min(1000, atoi(e)));
     TFX_HIP(hipEventCreate(&c->ev0));
@@ -189,6 +190,10 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         for (int i = 0; i < 34; ++i) if (hist[i]) fprintf(stderr, " %d:%u", i, hist[i]);
         fprintf(stderr, "\n");
         return total > 0 ? (int)(1000.0 * (double)fit / (double)total) : 0;
+    }
+    if (!strcmp(key, "gen_after_wavelet")) {
+        ctx->gen_after_wavelet = value != 0;
+        return 0;
     }
     if (!strcmp(key, "gen_wgs_per_cu")) {
         ctx->gen_wgs_per_cu = value;

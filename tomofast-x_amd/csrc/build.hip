@@ -13,6 +13,7 @@
 #include "common.h"
 #include "fastmath.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 namespace tfx {
@@ -994,75 +995,14 @@ struct WaveAxis {
 struct WaveConst { double sq2, c0, c1, c2, c3, c4; };
 constexpr int WAVE_FUSE_ITEMS = 8;       // pairs per thread the fused D4 level keeps in registers (L <= 256 at 16 lines per tile)
 
+// All levels of one axis on the LDS tile T (L positions x nq lines, pitch P): the lifting steps of wavelet_transform.F90 with the
+// reference's operations in the reference's order.  Ends with a barrier.
 template <int TYPE, int DIR>
-__global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, int64_t vec_stride, WaveAxis ax, WaveConst wc)
+__device__ __forceinline__ void wave_levels(double *__restrict__ T, const int L, const int P, const int nq, const bool fast, const int q,
+                                            const int mr, const int MR, const bool nq_pow2, const int nq_shift, const int tid, const int nt,
+                                            const WaveConst &wc)
 {
-    extern __shared__ __attribute__((aligned(16))) double T[];
-    const int L = ax.L, XT = ax.XT, P = ax.P;
-    double *base = s + (int64_t)blockIdx.y * vec_stride;
-    // which lines does this tile hold
-    int64_t g0;       // global offset of (line q = 0, position 0)
-    int nq;           // valid lines in the tile
-    if (ax.mode == 0) {
-        const int64_t l0 = (int64_t)blockIdx.x * XT;
-        nq = (int)min((int64_t)XT, ax.nlines - l0);
-        g0 = l0 * L;
-    } else {
-        const int64_t o = blockIdx.x / ax.ntiles_inner, ti = blockIdx.x % ax.ntiles_inner;
-        const int64_t m0 = ti * XT;
-        nq = (int)min((int64_t)XT, ax.inner - m0);
-        g0 = o * ax.outer_stride + m0;
-    }
-    const int tid = threadIdx.x, nt = blockDim.x;
-    // e -> (e / nq, e % nq) without an integer division when nq is a power of two (full tiles)
-    const bool nq_pow2 = (nq & (nq - 1)) == 0;
-    const int nq_shift = 31 - __clz(nq);
 #define DIVQ(e) (nq_pow2 ? ((e) >> nq_shift) : ((e) / nq))
-    const bool fast = nq == XT && nq_pow2 && (nt & (nq - 1)) == 0;
-    const int q = tid & (nq - 1), mr = tid >> nq_shift, MR = nt >> nq_shift;      // fast path: line and first pair of this thread
-    // ---- load: 8 independent global loads in flight per thread, then the LDS writes
-    // (x axis: element e = q*L + a; e advances by nt per step, so (q, a) advance by (nt / L, nt % L) - one integer division
-    // per thread instead of one per element)
-    const int total = nq * L;
-    const int dq = nt / L, da = nt - dq * L;
-    int rq = tid / L, ra = tid - rq * L;
-    if (ax.mode == 1 && fast) {
-        // y / z axis, full tile: thread (q, mr) walks positions a = mr, mr + MR, ... of line q with constant strides
-        const double *gp = base + g0 + (int64_t)mr * ax.astride + q;
-        const int64_t gstep = (int64_t)MR * ax.astride;
-        int la0 = mr * P + q;
-        const int lstep = MR * P;
-        for (int ab = mr; ab < L; ab += MR * 8) {
-            double tmp[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (ab + k * MR < L) tmp[k] = __builtin_nontemporal_load(&gp[k * gstep]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (ab + k * MR < L) T[la0 + k * lstep] = tmp[k];
-            gp += 8 * gstep;
-            la0 += 8 * lstep;
-        }
-    } else
-    for (int e0 = tid; e0 < total; e0 += nt * 8) {
-        double tmp[8];
-        int la[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int e = e0 + k * nt;
-            la[k] = -1;
-            if (e < total) {
-                if (ax.mode == 0) { la[k] = ra * P + rq; tmp[k] = __builtin_nontemporal_load(&base[g0 + e]); }      // the XT lines of an x tile are contiguous: q*L + a = e
-                else { const int a = DIVQ(e), q = e - a * nq; la[k] = a * P + q; tmp[k] = base[g0 + (int64_t)a * ax.astride + q]; }
-            }
-            rq += dq; ra += da;
-            if (ra >= L) { ra -= L; rq += 1; }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (la[k] >= 0) T[la[k]] = tmp[k];
-    }
-    __syncthreads();
     int nscale = 0;
     while ((2 << nscale) <= L) ++nscale;      // = int(log(L)/log(2)) of wavelet_transform.F90:85 for every L < 5000
     for (int lv = 0; lv < nscale; ++lv) {
@@ -1098,33 +1038,45 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
                 }
                 __syncthreads();
             } else if (TYPE == 2 && DIR == 1 && ng <= WAVE_FUSE_ITEMS * MR) {
-                // Fused D4 level: a thread produces the final (lo, hi) of its pairs from the RAW values of pairs m-1, m, m+1,
-                // recomputing the neighbours' intermediate values with exactly the reference's operations (same bits):
+                // Fused D4 level: a thread owns a run of CONSECUTIVE pairs m0 .. m0+cnt-1 of its line and produces their final
+                // (lo, hi) from the RAW values of pairs m0-1 .. m0+cnt, with exactly the reference's operations (same bits):
                 //   lo1(m) = lo + hi*c0 (:296-300); hi2(m) = hi - lo1(m)*c1 - lo1(m-1)*c2 (:302-319, m-1 wraps to the last pair);
                 //   lo3(m) = lo1(m) - hi2(m+1) (:321-345, m+1 wraps to pair 0); lo3*c3, hi2*c4 (:347-363).
-                // Two barriers per level instead of four.
+                // lo1 / hi2 of a pair are computed once per thread and handed down the run (cnt + 2 pairs read for cnt written:
+                // 20 LDS reads and 9 flops per pair at 8 pairs per thread, against 48 and 17 with strided ownership); two barriers
+                // per level instead of four.  Lanes 0-31 of a wave (2 values of mr x 16 lines) read 32 distinct bank pairs.
+                const int ipt = (ng + MR - 1) / MR;
+                const int m0 = mr * ipt;
+                const int cnt = min(ipt, ng - m0);
                 double olo[WAVE_FUSE_ITEMS], ohi[WAVE_FUSE_ITEMS];
+                if (cnt > 0) {
+                    const int apv = ((m0 == 0 ? ng - 1 : m0 - 1) * step) * P + q;
+                    const int av = (m0 * step) * P + q;
+                    const double lo1_prev = T[apv] + T[apv + dHI] * wc.c0;
+                    const double hi0 = T[av + dHI];
+                    double lo1_cur = T[av] + hi0 * wc.c0;
+                    double hi2_cur = hi0 - lo1_cur * wc.c1 - lo1_prev * wc.c2;
 #pragma unroll
-                for (int i = 0; i < WAVE_FUSE_ITEMS; ++i) {
-                    const int m = mr + i * MR, a = a0 + i * dA;
-                    if (m < ng) {
-                        const int ap = (m == 0) ? ilmax * P + q : a - dS;
-                        const int an = (m == ng - 1) ? q : a + dS;
-                        const double lo = T[a], hi = T[a + dHI], lop = T[ap], hip = T[ap + dHI], lon = T[an], hin = T[an + dHI];
-                        const double lo1 = lo + hi * wc.c0;
-                        const double lo1p = lop + hip * wc.c0;
-                        const double lo1n = lon + hin * wc.c0;
-                        const double hi2 = hi - lo1 * wc.c1 - lo1p * wc.c2;
-                        const double hi2n = hin - lo1n * wc.c1 - lo1 * wc.c2;
-                        olo[i] = (lo1 - hi2n) * wc.c3;
-                        ohi[i] = hi2 * wc.c4;
+                    for (int i = 0; i < WAVE_FUSE_ITEMS; ++i) {
+                        if (i < cnt) {
+                            const int an = ((m0 + i == ng - 1 ? 0 : m0 + i + 1) * step) * P + q;
+                            const double hin = T[an + dHI];
+                            const double lo1n = T[an] + hin * wc.c0;
+                            const double hi2n = hin - lo1n * wc.c1 - lo1_cur * wc.c2;
+                            olo[i] = (lo1_cur - hi2n) * wc.c3;
+                            ohi[i] = hi2_cur * wc.c4;
+                            lo1_cur = lo1n;
+                            hi2_cur = hi2n;
+                        }
                     }
                 }
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < WAVE_FUSE_ITEMS; ++i) {
-                    const int m = mr + i * MR, a = a0 + i * dA;
-                    if (m < ng) { T[a] = olo[i]; T[a + dHI] = ohi[i]; }
+                    if (i < cnt) {
+                        const int a = ((m0 + i) * step) * P + q;
+                        T[a] = olo[i]; T[a + dHI] = ohi[i];
+                    }
                 }
                 __syncthreads();
             } else if (TYPE == 2 && DIR == 1) {
@@ -1223,6 +1175,79 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
 #undef LO
 #undef HI
     }
+#undef DIVQ
+}
+
+template <int TYPE, int DIR>
+__global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, int64_t vec_stride, WaveAxis ax, WaveConst wc)
+{
+    extern __shared__ __attribute__((aligned(16))) double T[];
+    const int L = ax.L, XT = ax.XT, P = ax.P;
+    double *base = s + (int64_t)blockIdx.y * vec_stride;
+    // which lines does this tile hold
+    int64_t g0;       // global offset of (line q = 0, position 0)
+    int nq;           // valid lines in the tile
+    if (ax.mode == 0) {
+        const int64_t l0 = (int64_t)blockIdx.x * XT;
+        nq = (int)min((int64_t)XT, ax.nlines - l0);
+        g0 = l0 * L;
+    } else {
+        const int64_t o = blockIdx.x / ax.ntiles_inner, ti = blockIdx.x % ax.ntiles_inner;
+        const int64_t m0 = ti * XT;
+        nq = (int)min((int64_t)XT, ax.inner - m0);
+        g0 = o * ax.outer_stride + m0;
+    }
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // e -> (e / nq, e % nq) without an integer division when nq is a power of two (full tiles)
+    const bool nq_pow2 = (nq & (nq - 1)) == 0;
+    const int nq_shift = 31 - __clz(nq);
+#define DIVQ(e) (nq_pow2 ? ((e) >> nq_shift) : ((e) / nq))
+    const bool fast = nq == XT && nq_pow2 && (nt & (nq - 1)) == 0;
+    const int q = tid & (nq - 1), mr = tid >> nq_shift, MR = nt >> nq_shift;      // fast path: line and first pair of this thread
+    // ---- load: 8 independent global loads in flight per thread, then the LDS writes
+    // (x axis: element e = q*L + a; e advances by nt per step, so (q, a) advance by (nt / L, nt % L) - one integer division
+    // per thread instead of one per element)
+    const int total = nq * L;
+    const int dq = nt / L, da = nt - dq * L;
+    int rq = tid / L, ra = tid - rq * L;
+    if (ax.mode == 1 && fast) {
+        // y / z axis, full tile: thread (q, mr) walks positions a = mr, mr + MR, ... of line q with constant strides
+        const double *gp = base + g0 + (int64_t)mr * ax.astride + q;
+        const int64_t gstep = (int64_t)MR * ax.astride;
+        int la0 = mr * P + q;
+        const int lstep = MR * P;
+        for (int ab = mr; ab < L; ab += MR * 8) {
+            double tmp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ab + k * MR < L) tmp[k] = __builtin_nontemporal_load(&gp[k * gstep]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ab + k * MR < L) T[la0 + k * lstep] = tmp[k];
+            gp += 8 * gstep;
+            la0 += 8 * lstep;
+        }
+    } else
+    for (int e0 = tid; e0 < total; e0 += nt * 8) {
+        double tmp[8];
+        int la[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + k * nt;
+            la[k] = -1;
+            if (e < total) {
+                if (ax.mode == 0) { la[k] = ra * P + rq; tmp[k] = __builtin_nontemporal_load(&base[g0 + e]); }      // the XT lines of an x tile are contiguous: q*L + a = e
+                else { const int a = DIVQ(e), q = e - a * nq; la[k] = a * P + q; tmp[k] = base[g0 + (int64_t)a * ax.astride + q]; }
+            }
+            rq += dq; ra += da;
+            if (ra >= L) { ra -= L; rq += 1; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (la[k] >= 0) T[la[k]] = tmp[k];
+    }
+    __syncthreads();
+    wave_levels<TYPE, DIR>(T, L, P, nq, fast, q, mr, MR, nq_pow2, nq_shift, tid, nt, wc);
     // ---- store
     rq = tid / L; ra = tid - rq * L;
     if (ax.mode == 1 && fast) {
@@ -1300,24 +1325,31 @@ int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, i
     if (dir != 1 && dir != 2) return fail(TFX_E_ARG, "bad wavelet direction");
     if (nvec <= 0) return 0;
     const int64_t N = (int64_t)n1 * n2 * n3;
+    // lines per LDS tile and axis (tuning knob TFX_WAVE_XT="x,y,z"; 16 lines of 256 doubles = 34 KB per workgroup)
+    static int want[3] = {0, 0, 0};
+    if (!want[0]) {
+        int w[3] = {16, 16, 16};
+        if (const char *e = getenv("TFX_WAVE_XT")) sscanf(e, "%d,%d,%d", &w[0], &w[1], &w[2]);
+        for (int i = 0; i < 3; ++i) want[i] = std::max(1, std::min(64, w[i]));
+    }
     for (int axis = 0; axis < 3; ++axis) {             // axis order x -> y -> z for forward AND inverse (:82-93, :165-176)
         WaveAxis ax{};
         unsigned ntiles = 0;
         if (axis == 0) {
             if (n1 < 2) continue;
             ax.L = n1; ax.mode = 0; ax.astride = 1; ax.nlines = (int64_t)n2 * n3;
-            TFX_TRY(pick_xt(n1, ax.nlines, 16, &ax.XT, &ax.P));
+            TFX_TRY(pick_xt(n1, ax.nlines, want[0], &ax.XT, &ax.P));
             ntiles = (unsigned)((ax.nlines + ax.XT - 1) / ax.XT);
         } else if (axis == 1) {
             if (n2 < 2) continue;
             ax.L = n2; ax.mode = 1; ax.astride = n1; ax.inner = n1; ax.outer_stride = (int64_t)n1 * n2;
-            TFX_TRY(pick_xt(n2, n1, 16, &ax.XT, &ax.P));
+            TFX_TRY(pick_xt(n2, n1, want[1], &ax.XT, &ax.P));
             ax.ntiles_inner = (n1 + ax.XT - 1) / ax.XT;
             ntiles = (unsigned)(ax.ntiles_inner * n3);
         } else {
             if (n3 < 2) continue;
             ax.L = n3; ax.mode = 1; ax.astride = (int64_t)n1 * n2; ax.inner = (int64_t)n1 * n2; ax.outer_stride = 0;
-            TFX_TRY(pick_xt(n3, ax.inner, 16, &ax.XT, &ax.P));
+            TFX_TRY(pick_xt(n3, ax.inner, want[2], &ax.XT, &ax.P));
             ax.ntiles_inner = (ax.inner + ax.XT - 1) / ax.XT;
             ntiles = (unsigned)ax.ntiles_inner;
         }
@@ -2505,6 +2537,17 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     if (ndata <= 0) return fail(TFX_E_ARG, "no data");
     TFX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    // TFX_BUILD_TIMING=1: wall-clock phases of the build on stderr (host clock; the loop time includes its per-batch waits)
+    static const bool timing = getenv("TFX_BUILD_TIMING") != nullptr;
+    const auto wall = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_enter = wall();
+    double t_wait = 0.0, t_append = 0.0, t_lap = t_enter;
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const double t = wall();
+        fprintf(stderr, "[tfx] build setup: %-28s %.3f s\n", what, t - t_lap);
+        t_lap = t;
+    };
     const int ncd = gen.ncd, ncm = gen.ncm, nsub = gen.nsub();
     const int64_t ncols = col_end - col_begin;            // cells kept; the matrix has ncm*ncols columns
     const int64_t nrows_m = ndata * ncd;                  // matrix rows
@@ -2544,6 +2587,7 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     DBuf<float> dscale;
     TFX_TRY(dscale.alloc((size_t)nlines));
     TFX_HIP(hipMemcpyAsync(dscale.p, hscale.data(), (size_t)nlines * sizeof(float), hipMemcpyHostToDevice, s));
+    lap("uploads queued");
     // observations per batch: the line buffer + select candidates (2x) stay around 6 GB, at most 32 lines (one observation
     // at least)
     const int64_t lines_cap = std::max<int64_t>(1, std::min<int64_t>(32, (int64_t)(1u << 28) / N));
@@ -2602,7 +2646,9 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         } else {
             set_column_counts(ctx, nullptr, 0, 0);
         }
+        lap("column counts");
         TFX_TRY(matrix_begin(ctx, nrows_m, ncm * ncols, nrows_m * stride));
+        lap("matrix_begin");
     }
     const int RB = keep_matrix ? m.RB : (int)std::min<int64_t>(RB_MAX, (nrows_m + 63) / 64 * 64);
     TFX_TRY(drows.alloc((size_t)ob_max * nsub * N));
@@ -2634,9 +2680,11 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         TFX_TRY(rs->vals.alloc((size_t)(nrows_m * rs->stride)));
         TFX_TRY(rs->nel.alloc((size_t)nrows_m));
     }
+    lap("row / staging buffers");
     SelectWork sw;
     CompactWork cw;
     TFX_TRY(compact_prepare(cw, lines_max, N));
+    lap("compaction work areas");
     double err_sum = 0.0;
     int64_t nnz_total = 0;
     DBuf<BatchStat> dstat;
@@ -2697,6 +2745,8 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         if (overlap) TFX_HIP(hipEventRecord(gs.ev[slot_], gs.st));
         return 0;
     };
+    lap("streams, pinned stats");
+    const double t_loop = wall();
     int slot = 0;
     int nb_cur = batch_obs(0, 0);
     if (overlap) TFX_TRY(generate(0, nb_cur, 0));
@@ -2704,17 +2754,28 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         const int nb = nb_cur;
         const int nl = nb * nsub;                                   // lines of this batch
         double *const rows_cur = rows_buf[slot], *const red_cur = red_buf[slot];
+        int64_t g_after = g + nb;
         if (overlap) {
-            // the next batch's generator first: its buffer was last read by the compaction of batch b - 1, which the host has waited for
             int fill_after = fill + nb * ncd;
-            const int64_t g_after = g + nb;
             if (fill_after >= RB || g_after >= ndata) fill_after %= RB;
             nb_cur = g_after < ndata ? batch_obs(g_after, fill_after) : 0;
-            if (nb_cur > 0) TFX_TRY(generate(g_after, nb_cur, slot ^ 1));
             TFX_HIP(hipStreamWaitEvent(s, gs.ev[slot], 0));
         } else {
             TFX_TRY(generate(g, nb, 0));
         }
+        // The next batch's generator is queued behind this batch's wavelet passes (ctx->gen_after_wavelet, the default): it then
+        // shares the GPU with the count / select / compaction kernels - pure HBM streams, the complement of its fp64 arithmetic -
+        // and runs alone for the rest; beside the wavelet kernels (65 % VALU-busy themselves) both only slow each other down.
+        // Its buffer was last read by the compaction of batch b - 1, which the host has waited for.
+        auto queue_next = [&]() -> int {
+            if (!overlap || nb_cur <= 0) return 0;
+            if (ctx->gen_after_wavelet) {
+                TFX_HIP(hipEventRecord(gs.ev0, s));
+                TFX_HIP(hipStreamWaitEvent(gs.st, gs.ev0, 0));
+            }
+            return generate(g_after, nb_cur, slot ^ 1);
+        };
+        if (!ctx->gen_after_wavelet || compression_type == 0) TFX_TRY(queue_next());
         // threshold: bracketed from a sample and finished inside the compaction's count pass (band select) for large rows,
         // else the full radix select up front
         const bool banded = compression_type > 0 && K < N && K > 0 && N >= ctx->band_min_n && !band_off;
@@ -2722,6 +2783,7 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
             hipLaunchKernelGGL(k_rows_final_sum, dim3(nl), dim3(256), 0, s, red_cur, npart, dcf.p);                  // cost_full :234
             TFX_HIP(hipGetLastError());
             TFX_TRY(wavelet_dev(ctx, rows_cur, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1));                   // :237
+            if (ctx->gen_after_wavelet) TFX_TRY(queue_next());
             if (!banded) TFX_TRY(select_threshold_dev(ctx, sw, rows_cur, nl, N, K, cw.thr.p));                         // :240-256
         }
         int h_fail = 0;
@@ -2741,7 +2803,9 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
             hipLaunchKernelGGL(k_pack_stats, dim3((nl + 63) / 64), dim3(64), 0, s, nl, compression_type > 0 ? dcf.p : nullptr,
                                cw.cost_disc.p, cw.nel_all.p, cw.nel.p, cw.fail.p, dstat.p);
             TFX_HIP(hipMemcpyAsync(h_stat, dstat.p, (size_t)(nl + 1) * sizeof(BatchStat), hipMemcpyDeviceToHost, s));
+            const double tw = timing ? wall() : 0.0;
             TFX_HIP(hipStreamSynchronize(s));
+            if (timing) t_wait += wall() - tw;
             h_fail = h_stat[nl].nel_all;
             if (sel) {
                 ctx->band_batches += 1;
@@ -2765,7 +2829,9 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
             TFX_TRY(geometry_error(herr));
             while (fill >= RB || (g >= ndata && fill > 0)) {
                 const int nr = std::min(fill, RB);
+                const double ta = timing ? wall() : 0.0;
                 if (keep_matrix) TFX_TRY(matrix_append_rows(ctx, r0, nr, ell_cols.p, ell_vals.p, ell_nel.p, ell_off.p, stride));
+                if (timing) t_append += wall() - ta;
                 r0 += nr;
                 const int left = fill - nr;
                 if (left > 0) {        // rows of the straddling observation move to the front (left < ncd <= nr: no overlap)
@@ -2781,10 +2847,14 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         if (overlap) slot ^= 1;
         else if (g < ndata) nb_cur = batch_obs(g, fill);
     }
+    const double t_fin = wall();
     if (keep_matrix) {
         TFX_TRY(matrix_finish(ctx));
         m.nnz = nnz_total;
     }
+    if (timing)
+        fprintf(stderr, "[tfx] build timing: setup %.2f s (allocations, uploads, matrix_begin), loop %.2f s (waiting on the GPU %.2f s, appends %.2f s), "
+                        "finish %.2f s\n", t_loop - t_enter, t_fin - t_loop, t_wait, t_append, wall() - t_fin);
     if (nnz_out) *nnz_out = nnz_total;
     if (error_sum_out) *error_sum_out = err_sum;
     if (nnz_hist_out) TFX_TRY(copy_any(nnz_hist_out, dhist.p, (size_t)N * sizeof(int32_t), s));

@@ -228,6 +228,7 @@ struct tfx_ctx {
     int wd_ncomp = 0;          //   and the number of model components (of all problems) in the local unknown vector
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int gen_after_wavelet = 1;        // debug key: the overlapped generator starts behind the current batch's wavelet passes (0: at the batch start)
     int gen_wgs_per_cu = 0;           // debug key "gen_wgs_per_cu": resident generator workgroups per CU in overlap mode (0: one per tile)
     int gen_grid_limit = 0;           // (set around the generator launches of the overlapped build)
     int build_overlap = 1;            // debug key "build_overlap": row generator on its own stream, one batch ahead of the wavelet / compaction
