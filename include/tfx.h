@@ -105,6 +105,11 @@ int tfx_column_weight_type1(tfx_ctx *ctx, double power, double Z0, double multip
 int tfx_column_weight_type2(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double power,
                             double beta, double multiplier, double *cw_out);
 
+/* calculate_depth_weight type 3, minimum-distance weighting (weights_gravmag.f90:140-162): w = sqrt(1 / (min over the data of the
+ * distance from the cell centre + 0.01)^power), same tail.                                                        */
+int tfx_column_weight_type3(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double power,
+                            double multiplier, double *cw_out);
+
 /* ---- unit-level kernels (also what the parity tests call) ------------------------------------------------ */
 /* graviprism_z (src/forward/gravmag/grav/gravity_field.f90:131-195): ndata rows of N, rows_out[ndata*N].    */
 int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd,

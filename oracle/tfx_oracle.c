@@ -286,6 +286,37 @@ int orc_column_weight_type2(int64_t n, const double *X1, const double *X2, const
     return 0;
 }
 
+/* Minimum-distance weighting (type 3), weights_gravmag.f90:140-162 + the common tail :170-195 and problem_joint_gravmag.F90:178:
+ * w = sqrt(1 / (min_j |cell centre - datum j| + R0)^power). */
+int orc_column_weight_type3(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                            const double *Z1, const double *Z2, int64_t ndata, const double *xd, const double *yd,
+                            const double *zd, double power, double multiplier, double *cw)
+{
+    const double R0 = 0.01;                                              /* :142 */
+    double norm = -HUGE_VAL;
+    for (int64_t p = 0; p < n; ++p) {
+        const double xc = 0.5 * (X1[p] + X2[p]), yc = 0.5 * (Y1[p] + Y2[p]), zc = 0.5 * (Z1[p] + Z2[p]);   /* grid.F90:248-277 */
+        double mindist = 1.e30;                                          /* :149 */
+        for (int64_t j = 0; j < ndata; ++j) {
+            double dist = sqrt(pow(xc - xd[j], 2.0) + pow(yc - yd[j], 2.0) + pow(zc - zd[j], 2.0));         /* :151-153 */
+            if (dist < mindist) mindist = dist;
+        }
+        double w = sqrt(1.0 / pow(mindist + R0, power));                 /* :160 */
+        double vol = fabs((X2[p] - X1[p]) * (Y2[p] - Y1[p]) * (Z2[p] - Z1[p]));
+        w = w * sqrt(vol);                                               /* :174 */
+        cw[p] = w;
+        if (w > norm) norm = w;
+    }
+    if (norm == 0) return -2;
+    for (int64_t i = 0; i < n; ++i) {
+        cw[i] = cw[i] / norm;
+        if (cw[i] == 0.0) return -2;
+        cw[i] = 1.0 / cw[i];
+        cw[i] = cw[i] * multiplier;
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Lifting wavelets, wavelet_transform.F90.  One axis at a time (x, y, z), per axis all levels.
  * idx(a, o) addresses element a (0-based) of a line along the axis; the other two indices are

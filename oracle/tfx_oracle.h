@@ -70,6 +70,11 @@ int orc_column_weight_type2(int64_t n, const double *X1, const double *X2, const
                             const double *Z1, const double *Z2, int64_t ndata, const double *xd, const double *yd,
                             const double *zd, double power, double beta, double multiplier, double *cw);
 
+/* Minimum-distance weighting, type 3 (src/forward/gravmag/weights_gravmag.f90:140-162, then the same tail as type 1). */
+int orc_column_weight_type3(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                            const double *Z1, const double *Z2, int64_t ndata, const double *xd, const double *yd,
+                            const double *zd, double power, double multiplier, double *cw);
+
 /* src/utils/wavelet_transform.F90:37-70. type 1 = Haar (:75-236), 2 = Daubechies D4 (:243-498).
  * s is (n1,n2,n3) with n1 fastest (Fortran order). Returns 0 or -1 (unknown type). */
 int orc_forward_wavelet(double *s, int n1, int n2, int n3, int type);

@@ -395,6 +395,8 @@ def make_e2e(tmp):
         "e2e_full": dict(nx=8, ny=6, nz=5, ox=3, oy=3, ctype=0, rate="1.d0", nmajor=2, nminor=25, alpha="1.d-6"),
         # distance weighting (forward.depthWeighting.type = 2, the reference's default)
         "e2e_dw2": dict(nx=10, ny=9, nz=6, ox=4, oy=3, ctype=1, rate="0.2d0", nmajor=2, nminor=20, alpha="1.d-7", dwtype=2),
+        # minimum-distance weighting (forward.depthWeighting.type = 3, weights_gravmag.f90:140-162)
+        "e2e_dw3": dict(nx=11, ny=8, nz=7, ox=4, oy=3, ctype=2, rate="0.25d0", nmajor=2, nminor=20, alpha="1.d-7", dwtype=3),
     }
     only = os.environ.get("GOLDEN_E2E_ONLY")
     if only:
@@ -424,7 +426,7 @@ def make_e2e(tmp):
             o = collect_run(wd, log, "out", nproc)
             for kk, vv in o.items():
                 res["np%d_%s" % (nproc, kk)] = vv
-        res.update(dict(dwtype=c["dwtype"], nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=float(c["rate"].replace("d", "e")),
+        res.update(dict(parfile=par, dwtype=c["dwtype"], nx=c["nx"], ny=c["ny"], nz=c["nz"], ctype=c["ctype"], rate=float(c["rate"].replace("d", "e")),
                         nmajor=c["nmajor"], nminor=c["nminor"], alpha=float(c["alpha"].replace("d", "e")),
                         X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs, model_true=mtrue))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)

@@ -160,6 +160,18 @@ def column_weight_type2(grid, obs, power=2.0, beta=1.0, multiplier=4.0e3):
     return cw
 
 
+def column_weight_type3(grid, obs, power=2.0, multiplier=4.0e3):
+    X1, X2, Y1, Y2, Z1, Z2 = [f64(g) for g in grid]
+    obs = np.asarray(obs, np.float64)
+    xd, yd, zd = f64(obs[:, 0]), f64(obs[:, 1]), f64(obs[:, 2])
+    n = X1.size
+    cw = np.empty(n)
+    ierr = lib().orc_column_weight_type3(C.c_int64(n), dp(X1), dp(X2), dp(Y1), dp(Y2), dp(Z1), dp(Z2), C.c_int64(xd.size), dp(xd),
+                                         dp(yd), dp(zd), C.c_double(power), C.c_double(multiplier), dp(cw))
+    assert ierr == 0, ierr
+    return cw
+
+
 def wavelet(a, n1, n2, n3, wtype, inverse=False):
     s = f64(a).copy()
     assert s.size == n1 * n2 * n3

@@ -580,6 +580,24 @@ def test_gradient_damping_parfile_matches_reference(tmp_path, golden_dir):
     assert np.allclose(rs, g["np1_lsqr_r"], rtol=1e-4)
 
 
+def test_mindist_depth_weight_parfile_matches_reference(tmp_path, golden_dir):
+    """forward.depthWeighting.type = 3 from the Parfile: calculate_depth_weight -> tfx_column_weight_type3, then the usual run."""
+    if not os.path.isfile(EXE):
+        pytest.skip("Fortran host not built (no amdflang)")
+    g = np.load(os.path.join(golden_dir, "e2e_dw3.npz"))
+    wd = str(tmp_path)
+    write_case_inputs(wd, g)
+    open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
+    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "Calculating the depth weight, type =" in out.stdout
+    model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(model - ref) <= 1e-6 * np.linalg.norm(ref), np.linalg.norm(model - ref) / np.linalg.norm(ref)
+    w = np.frombuffer(open(os.path.join(wd, "out", "SENSIT", "sensit_grav_weight"), "rb").read(), ">f8", offset=4).astype(np.float64)
+    assert np.max(np.abs(w[:ref.size] - g["np1_column_weight"]) / g["np1_column_weight"]) <= 1e-14
+
+
 def test_lp_norm_damping_parfile_matches_reference(tmp_path, golden_dir):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
@@ -666,6 +684,6 @@ def test_parfile_errors_like_the_reference(tmp_path):
     out = subprocess.run([EXE], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "UNKNOWN Parfile" in out.stdout
     open(os.path.join(str(tmp_path), "P.txt"), "w").write("inversion.joint.grav.problemWeight = 1.d0\nfoo.bar = 3\nmodelGrid.size = 2 2 2\n"
-                                                           "forward.data.grav.nData = 3\nforward.depthWeighting.type = 3\n")
+                                                           "forward.data.grav.nData = 3\nforward.depthWeighting.type = 4\n")
     out = subprocess.run([EXE, "-p", "P.txt"], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
-    assert out.returncode != 0 and "Unknown parameter name: foo.bar" in out.stdout and "depthWeighting.type" in out.stdout
+    assert out.returncode != 0 and "Unknown parameter name: foo.bar" in out.stdout and "Not known depth weight type!" in out.stdout     # weights_gravmag.f90:164

@@ -296,6 +296,25 @@ def test_column_weight_vs_reference(ctx, golden_dir):
     assert np.max(np.abs(cw - g["np1_column_weight"]) / g["np1_column_weight"]) <= 1e-14
 
 
+def test_mindist_weight_type3_vs_reference(ctx, golden_dir):
+    """forward.depthWeighting.type = 3 (weights_gravmag.f90:140-162) against the compiled reference's weight file, the oracle, and the
+    inversion that uses it end to end."""
+    g = load(golden_dir, "e2e_dw3")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    ctx.set_grid(int(g["nx"]), int(g["ny"]), int(g["nz"]), *grid)
+    obs = g["obs"]
+    cw = ctx.calculate_mindist_weight(obs[:, 0], obs[:, 1], obs[:, 2], 2.0, 4.0e3)
+    assert np.max(np.abs(cw - g["np1_column_weight"]) / g["np1_column_weight"]) <= 1e-14
+    for power, mult in ((3.0, 1.0), (2.5, 7.0)):              # x*x*x and the general pow path
+        a, b = ctx.calculate_mindist_weight(obs[:, 0], obs[:, 1], obs[:, 2], power, mult), orc.column_weight_type3(grid, obs, power, mult)
+        assert np.allclose(a, b, rtol=1e-13, atol=0)
+    ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, int(g["ctype"]), float(g["rate"]))
+    m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, int(g["ctype"]), g["np1_data_observed"], int(g["nmajor"]),
+                                                     int(g["nminor"]), alpha=float(g["alpha"]))
+    ref = g["np1_model_final"]
+    assert np.linalg.norm(m - ref) <= 1e-6 * np.linalg.norm(ref)
+
+
 def test_distance_weight_type2_vs_reference(ctx, golden_dir):
     g = load(golden_dir, "e2e_dw2")
     ctx.set_grid(int(g["nx"]), int(g["ny"]), int(g["nz"]), *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])

@@ -73,6 +73,13 @@ def test_spmv_lsqr_vs_reference(golden_dir, case):
             assert abs(r - rref) <= 1e-7 * abs(rref)
 
 
+def test_mindist_weight_type3_bit_exact(golden_dir):
+    g = load(golden_dir, "e2e_dw3")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    assert int(g["dwtype"]) == 3
+    assert bits_equal(orc.column_weight_type3(grid, g["obs"]), g["np1_column_weight"])
+
+
 @pytest.mark.parametrize("name", ["e2e_haar", "e2e_d4", "e2e_full"])
 def test_build_rows_weights_partition(golden_dir, name):
     g = load(golden_dir, name)

@@ -977,6 +977,37 @@ __global__ __launch_bounds__(256) void k_distance_weight(int64_t N, const double
     atomicMax(maxbits, (unsigned long long)__double_as_longlong(mx));
 }
 
+// minimum-distance weighting, type 3 (weights_gravmag.f90:140-162): w = sqrt(1 / (min_j |cell centre - datum j| + R0)^power), then
+// sqrt(volume) (:174).  One thread per cell; the data coordinates are wave-uniform scalar loads; the minimum is taken over the
+// distances themselves (the reference compares sqrt values), so ties and rounding behave the same.
+__global__ __launch_bounds__(256) void k_mindist_weight(int64_t N, const double *__restrict__ X1, const double *__restrict__ X2,
+                                                        const double *__restrict__ Y1, const double *__restrict__ Y2,
+                                                        const double *__restrict__ Z1, const double *__restrict__ Z2,
+                                                        int64_t ndata, const double *__restrict__ xd, const double *__restrict__ yd,
+                                                        const double *__restrict__ zd, double power, double *__restrict__ w,
+                                                        unsigned long long *__restrict__ maxbits)
+{
+    const double R0 = 0.01;                                                                  // :142
+    double mx = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
+        const double x1 = X1[p], x2 = X2[p], y1 = Y1[p], y2 = Y2[p], z1 = Z1[p], z2 = Z2[p];
+        const double xc = 0.5 * (x1 + x2), yc = 0.5 * (y1 + y2), zc = 0.5 * (z1 + z2);       // grid.F90:248-277
+        double mind2 = 1.e60;
+        // sqrt is monotone and correctly rounded: min over sqrt(d2) = sqrt(min d2); the 1.d30 start value of :149 caps it below
+        for (int64_t j = 0; j < ndata; ++j) {
+            const double dx = xc - xd[j], dy = yc - yd[j], dz = zc - zd[j];
+            const double d2 = dx * dx + dy * dy + dz * dz;                                   // :151-153
+            mind2 = fmin(mind2, d2);
+        }
+        const double mindist = fmin(sqrt(mind2), 1.e30);
+        double v = sqrt(1.0 / pow_int_or_general(mindist + R0, power));                      // :160
+        v = v * sqrt(fabs((x2 - x1) * (y2 - y1) * (z2 - z1)));                               // :174
+        w[p] = v;
+        mx = fmax(mx, v);
+    }
+    atomicMax(maxbits, (unsigned long long)__double_as_longlong(mx));
+}
+
 // =============================================================================================================
 // lifting wavelets: one LDS tile = XT lines x L positions, all levels of the axis done in LDS
 // =============================================================================================================
@@ -2410,6 +2441,40 @@ int tfx_column_weight_type2(tfx_ctx *ctx, int64_t ndata, const double *xd, const
     return 0;
 }
 
+int tfx_column_weight_type3(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double power,
+                            double multiplier, double *cw_out)
+{
+    if (!ctx || !cw_out || !xd || !yd || !zd) return fail(TFX_E_ARG, "tfx_column_weight_type3: null argument");
+    if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_column_weight_type3: set the grid first");
+    if (ndata <= 0) return fail(TFX_E_ARG, "no data");
+    TFX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int64_t N = ctx->N;
+    DBuf<double> w, dobs;
+    DBuf<unsigned long long> mx;
+    DBuf<int> derr;
+    TFX_TRY(w.alloc((size_t)N));
+    TFX_TRY(dobs.alloc((size_t)3 * ndata));
+    TFX_TRY(mx.alloc(1));
+    TFX_TRY(derr.alloc(1));
+    TFX_HIP(hipMemcpyAsync(dobs.p, xd, ndata * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemcpyAsync(dobs.p + ndata, yd, ndata * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemcpyAsync(dobs.p + 2 * ndata, zd, ndata * sizeof(double), hipMemcpyDefault, s));
+    TFX_HIP(hipMemsetAsync(mx.p, 0, sizeof(unsigned long long), s));
+    TFX_HIP(hipMemsetAsync(derr.p, 0, sizeof(int), s));
+    const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)ctx->num_cu * 16);
+    hipLaunchKernelGGL(k_mindist_weight, dim3(grid), dim3(256), 0, s, N, ctx->grid[0].p, ctx->grid[1].p, ctx->grid[2].p, ctx->grid[3].p,
+                       ctx->grid[4].p, ctx->grid[5].p, ndata, dobs.p, dobs.p + ndata, dobs.p + 2 * ndata, power, w.p, mx.p);
+    hipLaunchKernelGGL(k_depth_weight_finish, dim3(grid), dim3(256), 0, s, N, w.p, mx.p, multiplier, derr.p);
+    TFX_HIP(hipGetLastError());
+    int herr = 0;
+    TFX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipStreamSynchronize(s));
+    if (herr & 2) return fail(TFX_E_NUMERIC, "Zero damping weight! Exiting.");
+    TFX_TRY(copy_any(cw_out, w.p, (size_t)N * sizeof(double), s));
+    return 0;
+}
+
 // diagnostics: the device build of fastmath.h on host arrays (tests compare it with the host libm)
 __global__ void k_fastmath_eval(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out_log,
                                 double *__restrict__ out_atan2)
@@ -2590,7 +2655,10 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     lap("uploads queued");
     // observations per batch: the line buffer + select candidates (2x) stay around 6 GB, at most 32 lines (one observation
     // at least)
-    const int64_t lines_cap = std::max<int64_t>(1, std::min<int64_t>(32, (int64_t)(1u << 28) / N));
+    // (TFX_LINES_CAP / TFX_LINES_BYTES_LOG2: tuning knobs for the batch size)
+    static const int64_t cap_lines = getenv("TFX_LINES_CAP") ? std::max(1, std::min(PRISM_MAX_BATCH, atoi(getenv("TFX_LINES_CAP")))) : 32;
+    static const int cap_log2 = getenv("TFX_LINES_BYTES_LOG2") ? std::max(20, std::min(34, atoi(getenv("TFX_LINES_BYTES_LOG2")))) - 3 : 28;
+    const int64_t lines_cap = std::max<int64_t>(1, std::min<int64_t>(cap_lines, ((int64_t)1 << cap_log2) / N));
     const int ob_max = (int)std::max<int64_t>(1, lines_cap / nsub);
     TiledMatrix &m = ctx->selmat();
     ctx->target = &m;
@@ -2700,7 +2768,7 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     // threshold, compaction, tile scatter - is HBM-bound.  The generator of batch b + 1 runs on its own (low-priority) stream into
     // the second row buffer while the main stream transforms and compacts batch b: their waves share the CUs, one kind waiting on
     // memory while the other computes.  (ctx->build_overlap = 0: one stream, one buffer - the sequential order of round 1.)
-    const bool overlap = ctx->build_overlap && ndata > 1;
+    const bool overlap = ctx->build_overlap && ndata >= 8 * (int64_t)ob_max;      // (short builds: the second buffer and stream cost more than they hide)
     DBuf<double> drows2, dred2;
     double *rows_buf[2] = {drows.p, drows.p}, *red_buf[2] = {dred.p, dred.p};
     struct GenStream {

@@ -75,6 +75,17 @@ module tfx_binding
       real(c_double), intent(out) :: cw(*)
     end function
 
+    ! calculate_depth_weight type 3, minimum-distance weighting (src/forward/gravmag/weights_gravmag.f90:140-162)
+    integer(c_int) function tfx_column_weight_type3(ctx, ndata, xd, yd, zd, power, multiplier, cw) &
+        bind(C, name="tfx_column_weight_type3")
+      import :: c_int, c_ptr, c_double, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: ndata
+      real(c_double), intent(in) :: xd(*), yd(*), zd(*)
+      real(c_double), value :: power, multiplier
+      real(c_double), intent(out) :: cw(*)
+    end function
+
     ! graviprism_z (src/forward/gravmag/grav/gravity_field.f90:131-195)
     integer(c_int) function tfx_prism_rows_gz(ctx, ndata, xd, yd, zd, rows) bind(C, name="tfx_prism_rows_gz")
       import :: c_int, c_ptr, c_double, c_int64_t

@@ -402,7 +402,7 @@ contains
   end subroutine get_full_array
 
   !-------------------------------------------------------------------------------------------------------
-  ! calculate_depth_weight, src/forward/gravmag/weights_gravmag.f90:46-196 (types 1 and 2; the reference's iarr%column_weight is
+  ! calculate_depth_weight, src/forward/gravmag/weights_gravmag.f90:46-196 (types 1, 2 and 3; the reference's iarr%column_weight is
   ! the plain array here).  The multiplier of problem_joint_gravmag.F90:178 is applied by the caller, as in the reference.
   subroutine calculate_depth_weight(par, column_weight, grid_full, data, myrank_, nbproc_)
     class(t_parameters_base), intent(in) :: par
@@ -420,9 +420,12 @@ contains
     else if (par%depth_weighting_type == 2) then
       call api_check(tfx_column_weight_type2(ctx, int(data%ndata, c_int64_t), data%X, data%Y, data%Z, par%depth_weighting_power, &
                                              par%depth_weighting_beta, 1.d0, column_weight), 'calculate_depth_weight', myrank_)
+    else if (par%depth_weighting_type == 3) then
+      call api_check(tfx_column_weight_type3(ctx, int(data%ndata, c_int64_t), data%X, data%Y, data%Z, par%depth_weighting_power, &
+                                             1.d0, column_weight), 'calculate_depth_weight', myrank_)
     else
-      call exit_MPI('Unknown depth weight type!', myrank_, 0)                  ! weights_gravmag.f90:166 (type 3 needs the sensitivity
-    endif                                                                      ! kernel on the host: not offered by this path)
+      call exit_MPI('Not known depth weight type!', myrank_, par%depth_weighting_type)      ! weights_gravmag.f90:164
+    endif
   end subroutine calculate_depth_weight
 
   !-------------------------------------------------------------------------------------------------------

@@ -478,8 +478,7 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
   pr(2)%on = SOLVE_PROBLEM(2)
   nprob = count(pr%on)
   if (nprob == 0) call stop_msg('Both problem weights are zero!')
-  if (par%dw_type /= 1 .and. par%dw_type /= 2) &       ! type 3 (weights_gravmag.f90:140-165) needs the whole kernel on the host
-    call stop_msg('forward.depthWeighting.type must be 1 or 2: type 3 (sensitivity-based) is not offered by this host.')
+  if (par%dw_type < 1 .or. par%dw_type > 3) call stop_msg('Not known depth weight type!')      ! weights_gravmag.f90:164
   if (par%w_cross /= 0.d0) then                                   ! structural coupling (joint_inverse_problem.F90:189-198, :529-541)
     if (par%pw(1) == 0.d0 .or. par%pw(2) == 0.d0) call stop_msg('The cross-gradient constraint needs both problems (joint inversion).')
     if (par%vec_field_type > 0) call stop_msg('Cross-gradient with a given vector field is not supported by this host.')

@@ -153,6 +153,14 @@ class Context:
                                                 C.c_double(beta), C.c_double(multiplier), ptr(cw)))
         return cw
 
+    def calculate_mindist_weight(self, Xdata, Ydata, Zdata, power=2.0, multiplier=4.0e3):
+        """forward.depthWeighting.type = 3 (weights_gravmag.f90:140-162): distance from the cell centre to the nearest datum."""
+        xd, yd, zd = f64(Xdata), f64(Ydata), f64(Zdata)
+        cw = np.empty(self.nelements_total)
+        check(self._lib.tfx_column_weight_type3(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), C.c_double(power),
+                                                C.c_double(multiplier), ptr(cw)))
+        return cw
+
     # ---- graviprism_z
     def graviprism_z(self, Xdata, Ydata, Zdata):
         xd, yd, zd = f64(np.atleast_1d(Xdata)), f64(np.atleast_1d(Ydata)), f64(np.atleast_1d(Zdata))

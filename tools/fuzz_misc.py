@@ -33,6 +33,8 @@ for case in range(ncases):
     beta = float(rng.choice([1.0, 1.5]))
     a, b = ctx.calculate_distance_weight(obs[:, 0], obs[:, 1], obs[:, 2], power, beta, mult), orc.column_weight_type2(grid, obs, power, beta, mult)
     assert np.allclose(a, b, rtol=1e-12, atol=0), ("type2", case, float(np.abs(a / b - 1).max()))
+    a, b = ctx.calculate_mindist_weight(obs[:, 0], obs[:, 1], obs[:, 2], power, mult), orc.column_weight_type3(grid, obs, power, mult)
+    assert np.allclose(a, b, rtol=1e-12, atol=0), ("type3", case, float(np.abs(a / b - 1).max()))
     # partition
     n = int(rng.integers(1, 5000))
     P = int(rng.integers(1, 9))
