@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, own_stream=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -30,7 +30,10 @@ def _worker(rank, world, port, q):
         N = int(np.prod(dims))
         obs = g["obs"]
         cw = g["np1_column_weight"]
-        ctx = tfx.Context(0)
+        # own_stream: the library works on a caller-supplied NON-null stream; the hook has to run its reductions (and staging
+        # copies) on that stream, not on torch's current one (tfx.h: "enqueued on `stream`")
+        side = torch.cuda.Stream(device=0) if own_stream else None
+        ctx = tfx.Context(0, stream=side.cuda_stream) if own_stream else tfx.Context(0)
         ctx.set_grid(*dims, *[g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")])
         hook = tfx.distributed.TorchAllreduce(0)
         ctx.set_allreduce(hook, rank, world)
@@ -68,11 +71,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("own_stream", [False, True])
+def test_two_ranks_on_one_gpu(own_stream):
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctxm.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + os.getpid() % 2000 + (7 if own_stream else 0)
+    procs = [ctxm.Process(target=_worker, args=(r, 2, port, q, own_stream)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
