@@ -1327,7 +1327,8 @@ template <int TYPE, int DIR>
 static int launch_axis(tfx_ctx *ctx, double *d, int64_t vec_stride, int64_t nvec, WaveAxis ax, unsigned ntiles)
 {
     const size_t lds = (size_t)ax.L * ax.P * sizeof(double);
-    static size_t lds_set = 0;
+    // the attribute belongs to the (kernel, device) pair: remembered per ctx, i.e. per device (a process may drive several)
+    size_t &lds_set = ctx->wave_lds_attr[(TYPE - 1) * 2 + (DIR - 1)];
     if (lds > lds_set) {
         TFX_HIP(hipFuncSetAttribute((const void *)k_wavelet_axis<TYPE, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS_BUDGET + 4096));
         lds_set = WAVE_LDS_BUDGET + 4096;

@@ -235,6 +235,7 @@ struct tfx_ctx {
     int items_per_cu = 16;            // debug key "items_per_cu": work items per CU the tile list is cut into
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
     bool deterministic = false;       // debug: single-wave workgroups in the two products -> LDS atomics in program order
+    size_t wave_lds_attr[4] = {0, 0, 0, 0};   // the same for the four wavelet axis kernels (Haar / D4 x forward / inverse)
     size_t lds_attr[4] = {0, 0, 0, 0}; // largest dynamic-LDS size registered for each product kernel variant ON THIS ctx's device
     bool profile = false;
     double prof_ms[2] = {0, 0};
