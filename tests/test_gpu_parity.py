@@ -1481,6 +1481,76 @@ def test_full_size_build_properties_and_sampled_rows_vs_oracle(ctx, name):
         ctx.matrix_free()
 
 
+def test_joint_two_kernels_at_a_single_gpu_size(ctx):
+    """BASELINE config 4's system (a gravity and a magnetic kernel in one LSQR, `joint_inverse_problem.F90:547-554`) at a size one
+    GPU builds in seconds: 192 x 192 x 64 cells (2.36e6), 9216 gravity + 4096 TMI data, Haar r = 0.02 (4.3e8 + 1.9e8 non-zeros).
+    Per kernel: entry count, adjoint identity, two rows pulled out with S^T e_r against the oracle's rows; jointly: the residual
+    LSQR reports after 25 iterations is the residual of the augmented block-diagonal system computed from the products, and the
+    second block of unknowns stays exactly zero while its right-hand side is zero."""
+    nx, ny, nz = 192, 192, 64
+    N = nx * ny * nz
+    grid = tfx.synthetic.grid(nx, ny, nz)
+    field = np.array([-62.0, 11.0, 0.0, 57000.0])
+    obs_sets = [tfx.synthetic.observations(nx, ny, 96, 96), tfx.synthetic.observations(nx, ny, 64, 64)]
+    pws = (1.0, 3.0e-3)
+    K = int(0.02 * N)
+    ctx.set_grid(nx, ny, nz, *grid)
+    cws = [ctx.calculate_depth_weight(2.0, 0.0, 4.0e3), ctx.calculate_depth_weight(3.0, 0.0, 1.0)]
+    rng = np.random.default_rng(3)
+    try:
+        for i, (xs, ys, zs) in enumerate(obs_sets):
+            ctx.select_problem(i)
+            res = ctx.calculate_sensit(xs, ys, zs, cws[i], 1, 0.02, problem_weight=pws[i], mag_field=field if i == 1 else None)
+            D = xs.size
+            assert 0.9999 * K * D <= res["nnz"] <= K * D
+            x, y = rng.standard_normal(N), rng.standard_normal(D)
+            Sx, STy = ctx.mult_vector(x), ctx.trans_mult_vector(y)
+            assert abs(np.dot(Sx, y) - np.dot(x, STy)) <= 1e-11 * np.linalg.norm(Sx) * np.linalg.norm(y)
+            cw_o = orc.column_weight_type1(grid, 2.0 if i == 0 else 3.0, 0.0, 4.0e3 if i == 0 else 1.0)
+            for r in (0, D // 2 + 7):
+                e = np.zeros(D)
+                e[r] = 1.0
+                row = ctx.trans_mult_vector(e)
+                cb = np.nonzero(row)[0] + 1
+                line = orc.rowgen("gz" if i == 0 else "mag", grid, (xs[r], ys[r], zs[r]), field)[0, 0]
+                c_ref, v_ref, _ = orc.compress_line(line, cw_o, (nx, ny, nz), 1, K)
+                v_ref = (v_ref * np.float32(pws[i])).astype(np.float32)
+                common, ib, ir = np.intersect1d(cb, c_ref, return_indices=True)
+                assert common.size >= 0.999 * c_ref.size and abs(cb.size - c_ref.size) <= 0.001 * c_ref.size
+                dv = np.abs(row[cb - 1].astype(np.float32)[ib].astype(np.float64) - v_ref[ir].astype(np.float64))
+                assert np.all(dv <= 2.0 * np.spacing(np.abs(v_ref[ir])).astype(np.float64) + 1e-8 * float(np.abs(v_ref).max()))
+        ctx.select_problem(0)
+        D1, D2 = obs_sets[0][0].size, obs_sets[1][0].size
+        assert ctx.system_dims() == (D1 + D2, 2 * N)
+        xt = [rng.standard_normal(N) * 1e-3, rng.standard_normal(N) * 1e-3]
+        b = []
+        for i in range(2):
+            ctx.select_problem(i)
+            b.append(ctx.mult_vector(xt[i]))
+        ctx.select_problem(0)
+        alpha = np.concatenate([np.full(N, 1e-6, np.float32), np.full(N, 2e-6, np.float32)])
+        rhs = np.concatenate(b)
+        x, it, r = ctx.lsqr_solve_sensit(rhs, 25, 1e-13, 0.0, 0.0, [alpha], [np.zeros(2 * N)])
+        assert it == 25
+        res2 = 0.0
+        for i in range(2):
+            ctx.select_problem(i)
+            res2 += np.sum((b[i] - ctx.mult_vector(x[i * N:(i + 1) * N])) ** 2)
+        ctx.select_problem(0)
+        res2 += np.sum((alpha.astype(np.float64) * x) ** 2)
+        r_true = np.sqrt(res2) / np.linalg.norm(rhs)
+        assert abs(r - r_true) <= 1e-6 * r_true, (r, r_true)
+        x0, it0, r0 = ctx.lsqr_solve_sensit(np.concatenate([b[0], np.zeros(D2)]), 10, 1e-13, 0.0, 0.0, [alpha], [np.zeros(2 * N)])
+        assert np.all(x0[N:] == 0.0) and np.any(x0[:N] != 0.0)
+    finally:
+        ctx.select_problem(1)
+        try:
+            ctx.matrix_free()
+        finally:
+            ctx.select_problem(0)
+            ctx.matrix_free()
+
+
 def test_reference_named_entry_points(ctx):
     """tomofast-x_amd/host/tfx_reference_demo drives the path ONLY through the reference's own procedure names and argument
     orders (module tfx_reference_api: calculate_depth_weight, calculate_and_write_sensit, calculate_new_partitioning,
