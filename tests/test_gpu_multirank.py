@@ -52,6 +52,9 @@ def _worker(rank, world, port, q, own_stream=False):
         rng = np.random.default_rng(5)
         rhs_full = rng.standard_normal(N) * 1e-9
         Cm = orc.diag_csr(np.full(N, alpha, np.float32))
+        # (25 iterations stop mid-convergence: deterministic products, so that the outcome does not hang on the run-dependent order
+        # of the LDS atomics - the difference to the single-rank oracle is then a fixed number)
+        ctx.debug_set("deterministic", 1)
         for niter, tol in ((3, 1e-11), (25, 1e-3)):
             x_loc, it, r = ctx.lsqr_solve_sensit(b, niter, 1e-13, 0.0, 0.0, [np.full(c1 - c0, alpha, np.float32)], [rhs_full[c0:c1]])
             x_ref, it_ref, r_ref = orc.lsqr(S_full, Cm, N, np.concatenate([b, rhs_full]), niter)

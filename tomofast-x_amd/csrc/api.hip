@@ -28,6 +28,7 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     // test knobs of the hybrid layout (same as the debug keys "hybrid" / "hybrid_min_nnz"): the GPU suite is run a second time
     // with TFX_HYBRID_MIN_NNZ=0 so that every small matrix of the parity tests goes through the bitmap head as well
     if (const char *e = getenv("TFX_HYBRID")) c->hybrid = atoi(e) != 0;
+    if (const char *e = getenv("TFX_DETERMINISTIC")) c->deterministic = atoi(e) != 0;     // like tfx_debug_set "deterministic"
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = atoi(e) != 0;
     if (const char *e = getenv("TFX_GEN_WGS_PER_CU")) c->gen_wgs_per_cu = atoi(e);
     if (const char *e = getenv("TFX_GEN_AFTER_WAVELET")) c->gen_after_wavelet = atoi(e) != 0;

@@ -1229,6 +1229,7 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
         g0 = o * ax.outer_stride + m0;
     }
     const int tid = threadIdx.x, nt = blockDim.x;
+    typedef double d2 __attribute__((ext_vector_type(2)));
     // e -> (e / nq, e % nq) without an integer division when nq is a power of two (full tiles)
     const bool nq_pow2 = (nq & (nq - 1)) == 0;
     const int nq_shift = 31 - __clz(nq);
@@ -1240,8 +1241,31 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
     // per thread instead of one per element)
     const int total = nq * L;
     const int dq = nt / L, da = nt - dq * L;
+    const bool wide_x = ax.mode == 0 && (L & 1) == 0 && (vec_stride & 1) == 0;       // (the pairs are 16-byte aligned)
+    const int npair = total / 2;
+    const int dq2 = (2 * nt) / L, da2 = 2 * nt - dq2 * L;
     int rq = tid / L, ra = tid - rq * L;
-    if (ax.mode == 1 && fast) {
+    // y / z axis, full tile, even strides: 16-byte loads / stores - thread (q2, mr2) moves lines 2 q2, 2 q2 + 1 of positions mr2, mr2 + MR2, ...
+    const bool wide_yz = ax.mode == 1 && fast && nq >= 2 && (ax.astride & 1) == 0 && (g0 & 1) == 0 && (vec_stride & 1) == 0;
+    const int sh2 = nq_shift > 0 ? nq_shift - 1 : 0;
+    const int hq = nq >> 1, q2 = tid & (hq - 1), mr2 = tid >> sh2, MR2 = nt >> sh2;
+    if (wide_yz) {
+        const double *gp = base + g0 + (int64_t)mr2 * ax.astride + 2 * q2;
+        const int64_t gstep = (int64_t)MR2 * ax.astride;
+        int la0 = mr2 * P + 2 * q2;
+        const int lstep = MR2 * P;
+        for (int ab = mr2; ab < L; ab += MR2 * 8) {
+            d2 tmp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ab + k * MR2 < L) tmp[k] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(&gp[k * gstep]));
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ab + k * MR2 < L) { T[la0 + k * lstep] = tmp[k].x; T[la0 + k * lstep + 1] = tmp[k].y; }
+            gp += 8 * gstep;
+            la0 += 8 * lstep;
+        }
+    } else if (ax.mode == 1 && fast) {
         // y / z axis, full tile: thread (q, mr) walks positions a = mr, mr + MR, ... of line q with constant strides
         const double *gp = base + g0 + (int64_t)mr * ax.astride + q;
         const int64_t gstep = (int64_t)MR * ax.astride;
@@ -1257,6 +1281,24 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
                 if (ab + k * MR < L) T[la0 + k * lstep] = tmp[k];
             gp += 8 * gstep;
             la0 += 8 * lstep;
+        }
+    } else if (wide_x) {
+        // x axis, even line length: the tile is one contiguous run of nq*L doubles - 16-byte loads, two positions of a line each
+        int rq2 = (2 * tid) / L, ra2 = 2 * tid - rq2 * L;
+        for (int p0 = tid; p0 < npair; p0 += nt * 8) {
+            d2 tmp[8];
+            int la[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int p = p0 + k * nt;
+                la[k] = -1;
+                if (p < npair) { la[k] = ra2 * P + rq2; tmp[k] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(&base[g0 + 2 * (int64_t)p])); }
+                rq2 += dq2; ra2 += da2;
+                if (ra2 >= L) { ra2 -= L; rq2 += 1; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (la[k] >= 0) { T[la[k]] = tmp[k].x; T[la[k] + P] = tmp[k].y; }
         }
     } else
     for (int e0 = tid; e0 < total; e0 += nt * 8) {
@@ -1281,7 +1323,24 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
     wave_levels<TYPE, DIR>(T, L, P, nq, fast, q, mr, MR, nq_pow2, nq_shift, tid, nt, wc);
     // ---- store
     rq = tid / L; ra = tid - rq * L;
-    if (ax.mode == 1 && fast) {
+    if (wide_yz) {
+        double *gp = base + g0 + (int64_t)mr2 * ax.astride + 2 * q2;
+        const int64_t gstep = (int64_t)MR2 * ax.astride;
+        int la0 = mr2 * P + 2 * q2;
+        const int lstep = MR2 * P;
+        for (int ab = mr2; ab < L; ab += MR2 * 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ab + k * MR2 < L) {
+                    d2 v;
+                    v.x = T[la0 + k * lstep];
+                    v.y = T[la0 + k * lstep + 1];
+                    __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(&gp[k * gstep]));
+                }
+            gp += 8 * gstep;
+            la0 += 8 * lstep;
+        }
+    } else if (ax.mode == 1 && fast) {
         double *gp = base + g0 + (int64_t)mr * ax.astride + q;
         const int64_t gstep = (int64_t)MR * ax.astride;
         int la0 = mr * P + q;
@@ -1292,6 +1351,22 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
                 if (ab + k * MR < L) __builtin_nontemporal_store(T[la0 + k * lstep], &gp[k * gstep]);
             gp += 8 * gstep;
             la0 += 8 * lstep;
+        }
+    } else if (wide_x) {
+        int rq2 = (2 * tid) / L, ra2 = 2 * tid - rq2 * L;
+        for (int p0 = tid; p0 < npair; p0 += nt * 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int p = p0 + k * nt;
+                if (p < npair) {
+                    d2 v;
+                    v.x = T[ra2 * P + rq2];
+                    v.y = T[ra2 * P + rq2 + P];
+                    __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(&base[g0 + 2 * (int64_t)p]));
+                }
+                rq2 += dq2; ra2 += da2;
+                if (ra2 >= L) { ra2 -= L; rq2 += 1; }
+            }
         }
     } else
     for (int e0 = tid; e0 < total; e0 += nt * 8) {
