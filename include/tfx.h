@@ -298,7 +298,7 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * key "band_select_min_cells" (value): grids of at least that many cells find the row thresholds by the sample-bracketed
  * band select instead of the full radix select (default 2^20; < 0: never) - both give the exact order statistic;
  * keys "band_batches" / "band_fallbacks": return how many row batches used it / fell back to the full select;
- * key "deterministic" (0/1): the two matrix products run with single-wave workgroups, so the LDS accumulations happen in program
+ * key "deterministic" (0/1; environment TFX_DETERMINISTIC at tfx_create): the two matrix products run with single-wave workgroups, so the LDS accumulations happen in program
  * order and a product is bit-reproducible from run to run (slow; for debugging convergence differences);
  * key "fwd_group" (0 = automatic, 1, 2, 4): row blocks that share one staged x tile in the forward product;
  * keys "hybrid" (0/1, default 0), "hybrid_min_nnz", "hybrid_tau_permille" (values): whether, from which size and from which column
