@@ -99,6 +99,8 @@ def main():
         ctx.debug_set("band_select_min_cells", -1)
     if os.environ.get("TFX_FWD_GROUP"):          # tuning knob: row blocks sharing one staged x tile in the forward product
         ctx.debug_set("fwd_group", int(os.environ["TFX_FWD_GROUP"]))
+    if os.environ.get("TFX_ITEMS_PER_CU"):       # tuning knob: work items per CU the tile list is cut into
+        ctx.debug_set("items_per_cu", int(os.environ["TFX_ITEMS_PER_CU"]))
     info = ctx.device_info()
     log("device %s, %d CUs, %.0f GB; workload %s" % (info["name"], info["cus"], info["hbm_bytes"] / 1e9, w["desc"]))
     ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))

@@ -460,7 +460,7 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
                 const bool flag = flag_at(tm.off + e);
                 const uint32_t slot = slot_at(tm.off + e);
                 if (flag) cur += 1;
-                float v = hv[(size_t)(tm.off + e)];
+                float v = hv[(size_t)val_pos(tm.off + e)];
                 bool marker = flag && v == 0.0f && slot == 0 && (e + 1 == tm.cnt || flag_at(tm.off + e + 1));
                 // a marker is indistinguishable from a stored exact zero in column 0 of the tile that is alone in
                 // its row segment; the reference never stores zeros (sparse_matrix.f90:219, threshold >= 1e-30)

@@ -78,6 +78,14 @@ constexpr int FWD_GROUP_MAX = 4;      // the forward product walks up to this ma
 // coefficients sit on index lattices (multiples of 2^l per axis); without the fold the columns of one LDS instruction are
 // often congruent modulo 16 and pile onto one bank pair.  Stored pre-swizzled, it costs the product kernels nothing.
 __host__ __device__ inline int col_slot(int i) { return i ^ (((i >> 4) ^ (i >> 8)) & 15); }
+// Position of entry e (lane L = (e & 511) >> 3 of its chunk, k = e & 7) in the value stream: the chunk's 2 KB hold k = 0..3 of
+// all lanes first (lane L at byte 16 L), then k = 4..7 - a wave reads its chunk with two loads of 16 bytes per lane at a lane
+// stride of 16 bytes.  (With the lane's 8 values in one 32-byte record both loads touch every cache line of the chunk and the
+// stream tops out at 6.3 TB/s; this order reaches 6.7 in tools/read_bw_probe.hip.)
+__host__ __device__ inline int64_t val_pos(int64_t e)
+{
+    return (e & ~(int64_t)511) | (((e >> 2) & 1) << 8) | (((e >> 3) & 63) << 2) | (e & 3);
+}
 
 constexpr int HGROUP = 64;            // columns per bitmap group of the head part (one 64-bit mask per row and group)
 
@@ -236,7 +244,7 @@ struct tfx_ctx {
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
     bool deterministic = false;       // debug: single-wave workgroups in the two products -> LDS atomics in program order
     size_t wave_lds_attr[4] = {0, 0, 0, 0};   // the same for the four wavelet axis kernels (Haar / D4 x forward / inverse)
-    size_t lds_attr[4] = {0, 0, 0, 0}; // largest dynamic-LDS size registered for each product kernel variant ON THIS ctx's device
+    size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // largest dynamic-LDS size registered for each product kernel variant ON THIS ctx's device
     bool profile = false;
     double prof_ms[2] = {0, 0};
     int64_t prof_n[2] = {0, 0};

@@ -6,7 +6,7 @@
 // Layout (DESIGN.md "Data layout in HBM").  The reference keeps CSR with 4-byte values + 4-byte columns
 // (8 B per non-zero).  Here S is cut into tiles of (RB <= 2048 rows) x (TC <= 4096 columns).  Inside a tile the
 // entries are in (row, column) order, padded to chunks of 512 entries (64 lanes x 8 entries), in three streams:
-//     vals[]    float  : the value exactly as the reference stores it                               4      B / entry
+//     vals[]    float  : the value exactly as the reference stores it (inside a chunk in val_pos() order)     4      B / entry
 //     slots[]   12 bit : LDS slot of the column inside the tile (col_slot(column), common.h); a lane's 8 slots are
 //                        three consecutive dwords, so a wave fetches a chunk's slots with one dwordx3 load   1.5    B / entry
 //     rowmask[] 1 bit  : "first entry of a new row inside this tile", stored k-major: word k of a chunk holds the
@@ -138,7 +138,7 @@ __device__ __forceinline__ void put_entry(uint32_t *__restrict__ slots, unsigned
 {
     const int64_t chunk = e >> 9;
     const int i = (int)(e & (CHUNK - 1)), lane = i >> 3, k = i & 7;
-    vals[e] = v;
+    vals[val_pos(e)] = v;
     if (slot) {
         uint32_t *w = slots + chunk * SLOT_WORDS + lane * 3;
         const int bit = 12 * k, wi = bit >> 5, sh = bit & 31;
@@ -153,7 +153,7 @@ __device__ __forceinline__ void put_entry(uint32_t *__restrict__ slots, unsigned
 __device__ __forceinline__ void put_entry16(uint16_t *__restrict__ tmp16, int64_t base, unsigned long long *__restrict__ rowmask,
                                             float *__restrict__ vals, int64_t e, uint32_t slot, bool rowstart, float v)
 {
-    vals[e] = v;
+    vals[val_pos(e)] = v;
     tmp16[e - base] = (uint16_t)slot;
     if (rowstart) atomicOr(rowmask + (e >> 9) * MASK_WORDS + (e & 7), 1ull << ((e & (CHUNK - 1)) >> 3));
 }
@@ -858,11 +858,12 @@ int matrix_finish(tfx_ctx *ctx)
     int64_t target = std::max<int64_t>((int64_t)16 * CHUNK, (m.n_entries + m.h_entries) / std::max(1, ctx->num_cu * ctx->items_per_cu));
     // Forward super blocks: one staged x tile serves fwd_group row blocks.  Worth it when the matrix is tall (full-height row
     // blocks, several of them) and big enough that a super block still splits into many items; small systems keep group 1.
+    // Two row blocks per group, not four: the x tile (32 KB) plus two row blocks of sums (32 KB) let TWO workgroups of 16 waves share
+    // a CU (the sparse kernels are compiled for 8 waves per SIMD: 28 VGPRs, 72 SGPRs), which the three-stream read pattern needs to
+    // reach its 6.7 TB/s (tools/read_bw_probe.hip); measured per iteration, groups of 4 / 2 / 1: headline 37.9 / 37.8 / 37.7 ms on one
+    // box, 37.7 / 36.3 / 35.9 on another; config 3 (3.4e7 columns, where staging costs most) 43.5 / 42.3 / 42.4 ms.
     m.fwd_group = 1;
-    if (m.RB == RB_MAX && m.nrb >= 2 && m.n_entries + m.h_entries >= (int64_t)64 * target) {
-        m.fwd_group = FWD_GROUP_MAX;
-        while (m.fwd_group > m.nrb) m.fwd_group /= 2;
-    }
+    if (m.RB == RB_MAX && m.nrb >= 2 && m.n_entries + m.h_entries >= (int64_t)64 * target) m.fwd_group = 2;
     if (ctx->fwd_group_override > 0) m.fwd_group = std::max(1, std::min(ctx->fwd_group_override, FWD_GROUP_MAX));
     const int nsb = (m.nrb + m.fwd_group - 1) / m.fwd_group;
     std::vector<int32_t> fo, ao, fns, ans, fpb, apb;
@@ -915,9 +916,9 @@ __device__ __forceinline__ void load_chunk(const uint32_t *__restrict__ slots, c
     c.w[0] = __builtin_nontemporal_load(sp);
     c.w[1] = __builtin_nontemporal_load(sp + 1);
     c.w[2] = __builtin_nontemporal_load(sp + 2);
-    const float *vp = vals + chunk * CHUNK + lane * 8;
+    const float *vp = vals + chunk * CHUNK + lane * 4;                // val_pos(): entries k = 0..3 of all lanes, then k = 4..7
     const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vp));
-    const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vp + 4));
+    const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vp + CHUNK / 2));
     c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w;
     c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w;
 }
@@ -1142,8 +1143,8 @@ __device__ __forceinline__ void bitmap_unit_scatter(const float (&v)[GPT], doubl
     const float *__restrict__ hvals
 #define MAT_ARGS(mp) (mp).items, (mp).order, (mp).tiles, (mp).slots, (mp).rowmask, (mp).vals, (mp).chunk_row0, (mp).hmask, (mp).hrowoff, (mp).hvals
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_spmv_fwd(MAT_PARAMS, const double *__restrict__ x, double *__restrict__ partial,
+template <int WAVES, bool HYB>
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 16 && !HYB) ? 8 : 1) void k_spmv_fwd(MAT_PARAMS, const double *__restrict__ x, double *__restrict__ partial,
                                                            int64_t ncols, int TC, int RB, int GROUP)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1165,14 +1166,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_spmv_fwd(MAT_PARAMS, const doubl
             // sparse tiles read x at the columns' (bank-folded) slots, bitmap tiles at the columns themselves (lane = column)
             const int64_t col0 = (int64_t)tm.t * TC;
             const int ncol = (int)min((int64_t)TC, ncols - col0);
-            if (g.kind) {
+            if (HYB && g.kind) {
                 for (int i = tid; i < TC; i += THREADS) xs[i] = (i < ncol) ? x[col0 + i] : 0.0;
             } else {
                 for (int i = tid; i < TC; i += THREADS) xs[col_slot(i)] = (i < ncol) ? x[col0 + i] : 0.0;
             }
         }
         __syncthreads();
-        if (g.kind) {
+        if (HYB && g.kind) {
             // bitmap tiles: a wave takes a row; lane = column inside the group; the row's sum is one wave reduction per tile
             const int gpt = TC / HGROUP;
             if (gpt == 64) {
@@ -1315,8 +1316,8 @@ __global__ __launch_bounds__(FR_ROWS * FR_GROUPS) void k_fwd_reduce(const double
 }
 
 // adjoint: one workgroup = a run of tiles of one column tile; slot 0 adds into y, the others write partials.
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_spmv_adj(MAT_PARAMS, const double *__restrict__ u, double *__restrict__ y,
+template <int WAVES, bool HYB>
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 16 && !HYB) ? 8 : 1) void k_spmv_adj(MAT_PARAMS, const double *__restrict__ u, double *__restrict__ y,
                                                            double *__restrict__ partial, int64_t nrows, int64_t ncols,
                                                            int TC, int RB, int GROUP)
 {
@@ -1346,7 +1347,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_spmv_adj(MAT_PARAMS, const doubl
             for (int i = lo + tid; i < hi; i += THREADS) us[i] = (row0 + i < nrows) ? u[row0 + i] : 0.0;
         }
         __syncthreads();
-        if (g.kind) {
+        if (HYB && g.kind) {
             // bitmap tiles: a wave takes a row; lane = column inside the group -> the LDS adds of one instruction go to 64 consecutive
             // column sums (no bank conflicts, no slot fold)
             bitmap = true;
@@ -1462,12 +1463,13 @@ __global__ __launch_bounds__(256) void k_scale_rows(const TileMeta *__restrict__
         for (int c = blockIdx.x * 4 + wave; c < tm.nchunks; c += gridDim.x * 4) {
             ChunkMasks mk;
             int cur = chunk_row0[cbase + c] + load_masks(rowmask, cbase + c, mk);
-            float *vp = vals + (cbase + c) * CHUNK + lane * 8;
+            float *vp = vals + (cbase + c) * CHUNK + lane * 4;          // val_pos()
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if ((mk.m[k] >> lane) & 1ull) cur += 1;
                 const int64_t r = row0 + max(cur, 0);
-                if (r < nrows) vp[k] = vp[k] * scale[r];
+                float *v = vp + (k >> 2) * (CHUNK / 2) + (k & 3);
+                if (r < nrows) *v = *v * scale[r];
             }
         }
     }
@@ -1624,15 +1626,19 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
     if (!m.h_fwd.empty()) {
         const MatPtrs mp = mat_ptrs(m, true);
         if (prof) prof_begin(ctx);
-        if (ctx->deterministic) {
-            TFX_TRY(set_lds_limit(ctx, 2, (const void *)k_spmv_fwd<1>, lds));
-            hipLaunchKernelGGL(k_spmv_fwd<1>, dim3((unsigned)m.h_fwd.size()), dim3(64), lds, s, MAT_ARGS(mp), xk, m.fwd_partial.p, m.ncols_p, m.TC, m.RB,
-                               m.fwd_group);
-        } else {
-            TFX_TRY(set_lds_limit(ctx, 0, (const void *)k_spmv_fwd<16>, lds));
-            hipLaunchKernelGGL(k_spmv_fwd<16>, dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), xk, m.fwd_partial.p, m.ncols_p,
-                               m.TC, m.RB, m.fwd_group);
+        // (HYB = false: the purely sparse layout - every default matrix - compiles without the bitmap path's 64-value buffers)
+#define LAUNCH_FWD(W, H, IDX, THREADS)                                                                                                       \
+        {                                                                                                                                    \
+            TFX_TRY(set_lds_limit(ctx, IDX, (const void *)k_spmv_fwd<W, H>, lds));                                                           \
+            hipLaunchKernelGGL((k_spmv_fwd<W, H>), dim3((unsigned)m.h_fwd.size()), dim3(THREADS), lds, s, MAT_ARGS(mp), xk, m.fwd_partial.p, \
+                               m.ncols_p, m.TC, m.RB, m.fwd_group);                                                                          \
         }
+        if (ctx->deterministic) {
+            if (m.NH > 0) LAUNCH_FWD(1, true, 2, 64) else LAUNCH_FWD(1, false, 6, 64)
+        } else {
+            if (m.NH > 0) LAUNCH_FWD(16, true, 0, SPMV_THREADS) else LAUNCH_FWD(16, false, 4, SPMV_THREADS)
+        }
+#undef LAUNCH_FWD
         if (prof) prof_end(ctx, 0);
         TFX_HIP(hipGetLastError());
     }
@@ -1668,15 +1674,18 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
     if (!m.h_adj.empty()) {
         const MatPtrs mp = mat_ptrs(m, false);
         if (prof) prof_begin(ctx);
-        if (ctx->deterministic) {
-            TFX_TRY(set_lds_limit(ctx, 3, (const void *)k_spmv_adj<1>, lds));
-            hipLaunchKernelGGL(k_spmv_adj<1>, dim3((unsigned)m.h_adj.size()), dim3(64), lds, s, MAT_ARGS(mp), d_x, yk, m.adj_partial.p, m.nrows,
-                               m.ncols_p, m.TC, m.RB, m.fwd_group);
-        } else {
-            TFX_TRY(set_lds_limit(ctx, 1, (const void *)k_spmv_adj<16>, lds));
-            hipLaunchKernelGGL(k_spmv_adj<16>, dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), d_x, yk, m.adj_partial.p,
-                               m.nrows, m.ncols_p, m.TC, m.RB, m.fwd_group);
+#define LAUNCH_ADJ(W, H, IDX, THREADS)                                                                                                       \
+        {                                                                                                                                    \
+            TFX_TRY(set_lds_limit(ctx, IDX, (const void *)k_spmv_adj<W, H>, lds));                                                           \
+            hipLaunchKernelGGL((k_spmv_adj<W, H>), dim3((unsigned)m.h_adj.size()), dim3(THREADS), lds, s, MAT_ARGS(mp), d_x, yk,             \
+                               m.adj_partial.p, m.nrows, m.ncols_p, m.TC, m.RB, m.fwd_group);                                                \
         }
+        if (ctx->deterministic) {
+            if (m.NH > 0) LAUNCH_ADJ(1, true, 3, 64) else LAUNCH_ADJ(1, false, 7, 64)
+        } else {
+            if (m.NH > 0) LAUNCH_ADJ(16, true, 1, SPMV_THREADS) else LAUNCH_ADJ(16, false, 5, SPMV_THREADS)
+        }
+#undef LAUNCH_ADJ
         if (prof) prof_end(ctx, 1);
         TFX_HIP(hipGetLastError());
         if (m.adj_has_partials)

@@ -1,0 +1,108 @@
+// read-bandwidth probe: what a pure streaming read reaches on this part (tools probe, not product code)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int NT, int UNROLL>
+__global__ __launch_bounds__(256) void k_read(const f4 *__restrict__ p, size_t n, float *out)
+{
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+        f4 v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) v[k] = NT ? __builtin_nontemporal_load(&p[i + k * stride]) : p[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) acc += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+    for (; i < n; i += stride) { f4 v = p[i]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 1.2345f) out[0] = acc;
+}
+// contiguous chunk per workgroup (like the matrix kernels: a work item streams a contiguous range)
+template <int NT>
+__global__ __launch_bounds__(1024) void k_read_chunked(const f4 *__restrict__ p, size_t n, size_t per_wg, float *out)
+{
+    float acc = 0.f;
+    const size_t b = (size_t)blockIdx.x * per_wg, e = b + per_wg < n ? b + per_wg : n;
+    for (size_t i = b + threadIdx.x; i < e; i += 4 * 1024) {
+        f4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const size_t j = i + (size_t)k * 1024; v[k] = j < e ? (NT ? __builtin_nontemporal_load(&p[j]) : p[j]) : f4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+    if (acc == 1.2345f) out[0] = acc;
+}
+// the matrix kernels' access pattern without their arithmetic: per wave and 512-entry chunk two 16-byte loads per lane of a 32-byte
+// lane record (vals), one 12-byte load per lane (slots) and 64 bytes of scalar loads (masks), from three arrays
+template <int SPLIT, int WHAT>
+__global__ __launch_bounds__(1024) void k_read3(const float *__restrict__ vals, const unsigned *__restrict__ slots, const unsigned long long *__restrict__ masks,
+                                                 size_t nchunks, float *out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    unsigned long long macc = 0;
+    const size_t per = (nchunks + gridDim.x - 1) / gridDim.x, c0 = blockIdx.x * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+    for (size_t c = c0 + wave; c < c1; c += 16) {
+        const float *vp = vals + c * 512;
+        f4 a, b;
+        if (SPLIT) { a = __builtin_nontemporal_load((const f4 *)(vp + lane * 8)); b = __builtin_nontemporal_load((const f4 *)(vp + lane * 8 + 4)); }
+        else { a = __builtin_nontemporal_load((const f4 *)(vp + lane * 4)); b = __builtin_nontemporal_load((const f4 *)(vp + 256 + lane * 4)); }
+        unsigned w0 = 0, w1 = 0, w2 = 0;
+        if (WHAT >= 1) { const unsigned *sp = slots + c * 192 + lane * 3; w0 = __builtin_nontemporal_load(sp); w1 = __builtin_nontemporal_load(sp + 1); w2 = __builtin_nontemporal_load(sp + 2); }
+        if (WHAT >= 2) {
+            const unsigned long long *mp = masks + c * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) macc += mp[k];
+        }
+        acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + (float)(w0 ^ w1 ^ w2);
+    }
+    if (acc == 1.2345f || macc == 77) out[0] = acc;
+}
+__global__ void k_copy(const f4 *__restrict__ a, f4 *__restrict__ b, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+int main()
+{
+    const size_t bytes = (size_t)48 << 30, n = bytes / 16;
+    f4 *p, *q; float *out;
+    CK(hipMalloc(&p, bytes)); CK(hipMalloc(&q, bytes)); CK(hipMalloc(&out, 4));
+    CK(hipMemset(p, 1, bytes)); CK(hipMemset(q, 0, bytes));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](const char *name, auto launch, double nbytes) {
+        launch(); hipDeviceSynchronize();
+        float best = 1e30f;
+        for (int r = 0; r < 5; ++r) { hipEventRecord(e0, 0); launch(); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; }
+        printf("%-46s %8.3f ms  %7.1f GB/s\n", name, best, nbytes / best / 1e6);
+    };
+    for (int g : {1024, 2048, 4096, 8192, 16384}) {
+        char nm[96];
+        snprintf(nm, 96, "read f4 grid-stride x4   grid %5d", g); timeit(nm, [&]() { hipLaunchKernelGGL((k_read<0, 4>), dim3(g), dim3(256), 0, 0, p, n, out); }, (double)bytes);
+        snprintf(nm, 96, "read f4 grid-stride x4 nt grid %5d", g); timeit(nm, [&]() { hipLaunchKernelGGL((k_read<1, 4>), dim3(g), dim3(256), 0, 0, p, n, out); }, (double)bytes);
+        snprintf(nm, 96, "read f4 grid-stride x8 nt grid %5d", g); timeit(nm, [&]() { hipLaunchKernelGGL((k_read<1, 8>), dim3(g), dim3(256), 0, 0, p, n, out); }, (double)bytes);
+    }
+    for (int wgs : {256, 512, 1024, 4096}) {
+        char nm[96];
+        const size_t per = (n + wgs - 1) / wgs;
+        snprintf(nm, 96, "read f4 contiguous per WG nt, %4d WGs x1024", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read_chunked<1>), dim3(wgs), dim3(1024), 0, 0, p, n, per, out); }, (double)bytes);
+    }
+    {
+        const size_t nch = (size_t)16 << 20;        // 16 Mi chunks: 32 GB of values, 12 GB of slots, 1 GB of masks
+        float *v; unsigned *sl; unsigned long long *mk;
+        CK(hipMalloc(&v, nch * 2048)); CK(hipMalloc(&sl, nch * 768)); CK(hipMalloc(&mk, nch * 64));
+        CK(hipMemset(v, 0, nch * 2048)); CK(hipMemset(sl, 0, nch * 768)); CK(hipMemset(mk, 0, nch * 64));
+        const double by = (double)nch * (2048 + 768 + 64);
+        for (int wgs : {256, 512, 4096}) {
+            char nm[96];
+            snprintf(nm, 96, "3 streams, 32-B lane records, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<1, 2>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, by);
+            snprintf(nm, 96, "3 streams, 16-B lane stride, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<0, 2>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, by);
+            snprintf(nm, 96, "values + slots (no masks), %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<0, 1>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, (double)nch * (2048 + 768));
+            snprintf(nm, 96, "values only, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<0, 0>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, (double)nch * 2048);
+        }
+    }
+    timeit("copy f4 (read + write)", [&]() { hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, p, q, n); }, 2.0 * bytes);
+    return 0;
+}
