@@ -219,7 +219,9 @@ def main():
                 # the same launch on the bytes that crossed HBM by PMC (>= the algorithmic bytes: tile padding, row markers, staging)
                 "frac_on_traffic": None if traffic is None else round(traffic / (avg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "traffic_over_algorithmic": None if traffic is None else round(traffic / alg_bytes, 4),
-                "streaming_ceiling_GBs": 6290.0,     # MI355X_MICROARCH.md: measured float4 copy
+                "streaming_ceiling_GBs": 6290.0,     # MI355X_MICROARCH.md: measured float4 copy (read + write)
+                # tools/read_bw_probe.hip on this part: a single contiguous read stream / the kernels' three streams without arithmetic
+                "read_stream_ceiling_GBs": 7000.0, "three_stream_read_ceiling_GBs": 6700.0,
                 "csr_equivalent_GBs": round(csr_b * nnz_loc / (avg[dom] * 1e-3) / 1e9, 1)}
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same workload
