@@ -51,7 +51,8 @@ __global__ __launch_bounds__(1024) void k_read3(const float *__restrict__ vals, 
         if (SPLIT) { a = __builtin_nontemporal_load((const f4 *)(vp + lane * 8)); b = __builtin_nontemporal_load((const f4 *)(vp + lane * 8 + 4)); }
         else { a = __builtin_nontemporal_load((const f4 *)(vp + lane * 4)); b = __builtin_nontemporal_load((const f4 *)(vp + 256 + lane * 4)); }
         unsigned w0 = 0, w1 = 0, w2 = 0;
-        if (WHAT >= 1) { const unsigned *sp = slots + c * 192 + lane * 3; w0 = __builtin_nontemporal_load(sp); w1 = __builtin_nontemporal_load(sp + 1); w2 = __builtin_nontemporal_load(sp + 2); }
+        if (WHAT == 3) { const unsigned *sp = slots + c * 192 + lane; w0 = __builtin_nontemporal_load(sp); w1 = __builtin_nontemporal_load(sp + 64); w2 = __builtin_nontemporal_load(sp + 128); }
+        else if (WHAT >= 1) { const unsigned *sp = slots + c * 192 + lane * 3; w0 = __builtin_nontemporal_load(sp); w1 = __builtin_nontemporal_load(sp + 1); w2 = __builtin_nontemporal_load(sp + 2); }
         if (WHAT >= 2) {
             const unsigned long long *mp = masks + c * 8;
 #pragma unroll
@@ -99,6 +100,7 @@ int main()
             char nm[96];
             snprintf(nm, 96, "3 streams, 32-B lane records, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<1, 2>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, by);
             snprintf(nm, 96, "3 streams, 16-B lane stride, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<0, 2>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, by);
+            snprintf(nm, 96, "3 streams, slots as 3 dword planes, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<0, 3>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, by);
             snprintf(nm, 96, "values + slots (no masks), %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<0, 1>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, (double)nch * (2048 + 768));
             snprintf(nm, 96, "values only, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<0, 0>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, (double)nch * 2048);
         }
