@@ -425,30 +425,35 @@ __global__ void k_dense_fwd_reduce(const double *__restrict__ partial, int nchun
     b[r] = s;
 }
 
-// adjoint: workgroup = one column chunk over all rows; a thread owns 8 columns, u[r] is a wave-uniform scalar load
+// adjoint: workgroup = one column chunk over all rows; a thread owns two runs of 4 columns, one in each half of the chunk (each of
+// its two 16-byte loads is then at a 16-byte lane stride: a 32-byte record per lane makes both loads of a wave touch every cache
+// line of the row piece - tools/read_bw_probe.hip); u[r] is a wave-uniform scalar load
 __global__ __launch_bounds__(DN_THREADS) void k_dense_adj(const float *__restrict__ A, int64_t ld, int64_t nrows, int64_t ncols,
                                                            const double *__restrict__ u, double *__restrict__ y)
 {
-    const int64_t c0 = (int64_t)blockIdx.x * DN_CHUNK + (int64_t)threadIdx.x * 8;
-    if (c0 >= ncols) return;
+    static_assert(DN_CHUNK == 8 * DN_THREADS, "two runs of four columns per thread");
+    const int64_t ca = (int64_t)blockIdx.x * DN_CHUNK + (int64_t)threadIdx.x * 4, cb = ca + 4 * DN_THREADS;
+    if (ca >= ncols) return;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool full = c0 + 8 <= ncols;
-    const int nmine = (int)min((int64_t)8, ncols - c0);
+    const int na = (int)min((int64_t)4, ncols - ca), nb = (int)max((int64_t)0, min((int64_t)4, ncols - cb));
+    const bool full = na == 4 && nb == 4;
 #pragma unroll 4
     for (int64_t r = 0; r < nrows; ++r) {
         const double ur = u[r];
-        const float *p = A + r * ld + c0;
+        const float *p = A + r * ld;
         if (full) {
-            const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p + 4));
+            const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p + ca)), b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p + cb));
             acc[0] = fma((double)a.x, ur, acc[0]); acc[1] = fma((double)a.y, ur, acc[1]);
             acc[2] = fma((double)a.z, ur, acc[2]); acc[3] = fma((double)a.w, ur, acc[3]);
             acc[4] = fma((double)b.x, ur, acc[4]); acc[5] = fma((double)b.y, ur, acc[5]);
             acc[6] = fma((double)b.z, ur, acc[6]); acc[7] = fma((double)b.w, ur, acc[7]);
         } else {
-            for (int k = 0; k < nmine; ++k) acc[k] = fma((double)p[k], ur, acc[k]);
+            for (int k = 0; k < na; ++k) acc[k] = fma((double)p[ca + k], ur, acc[k]);
+            for (int k = 0; k < nb; ++k) acc[4 + k] = fma((double)p[cb + k], ur, acc[4 + k]);
         }
     }
-    for (int k = 0; k < nmine; ++k) y[c0 + k] += acc[k];
+    for (int k = 0; k < na; ++k) y[ca + k] += acc[k];
+    for (int k = 0; k < nb; ++k) y[cb + k] += acc[4 + k];
 }
 
 __global__ void k_dense_scale_rows(float *__restrict__ A, int64_t ld, int64_t nrows, int64_t ncols, const float *__restrict__ scale)
