@@ -2861,9 +2861,15 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         TFX_TRY(dred2.alloc((size_t)lines_max * npart));
         rows_buf[1] = drows2.p;
         red_buf[1] = dred2.p;
+        // lowest priority where the runtime offers priorities (the main stream's kernels get the freed slots first); a plain
+        // non-blocking stream otherwise
         int prio_lo = 0, prio_hi = 0;
-        TFX_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        TFX_HIP(hipStreamCreateWithPriority(&gs.st, hipStreamNonBlocking, prio_lo));
+        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&gs.st, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+            (void)hipGetLastError();
+            gs.st = nullptr;
+            TFX_HIP(hipStreamCreateWithFlags(&gs.st, hipStreamNonBlocking));
+        }
         for (int i = 0; i < 2; ++i) TFX_HIP(hipEventCreateWithFlags(&gs.ev[i], hipEventDisableTiming));
         TFX_HIP(hipEventCreateWithFlags(&gs.ev0, hipEventDisableTiming));
         TFX_HIP(hipEventRecord(gs.ev0, s));                 // the uploads of the observations / weights queued above
