@@ -37,8 +37,13 @@ __device__ __forceinline__ void init_math_tables()
     for (int i = threadIdx.x; i < 3 * TFX_LOG_TAB_N; i += blockDim.x) lds[i] = tfx_log_tab[i];
     for (int i = threadIdx.x; i < 2 * TFX_ATAN_TAB_N; i += blockDim.x) lds[3 * TFX_LOG_TAB_N + i] = tfx_atan_tab[i];
 }
+#ifdef TFX_LIBM_TRANSCENDENTALS          // A/B builds only (make EXTRA=-DTFX_LIBM_TRANSCENDENTALS): the device libm instead of fastmath.h
+__device__ __forceinline__ double dlog(double x) { return log(x); }
+__device__ __forceinline__ double datan2(double y, double x) { return atan2(y, x); }
+#else
 __device__ __forceinline__ double dlog(double x) { return fast_log(x, math_tables()); }
 __device__ __forceinline__ double datan2(double y, double x) { return fast_atan2(y, x, math_tables()); }
+#endif
 
 // One corner of the prism integral (gravity_field.f90:165-186): returns ZZ*atan2'(XX*YY, ZZ*R) - XX*log(R+YY) - YY*log(R+XX)
 // and flags R+XX <= 0 / R+YY <= 0 (:176-181).  Shared by the general and the tensor-grid kernel so both produce the
