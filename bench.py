@@ -355,8 +355,8 @@ def cpu_baseline_reference(tfx, nnz_headline, pairs_headline, log, nx=64, ny=64,
         best = min(usable, key=lambda rk: legs[rk]["ms_per_lsqr_iteration"])
         t_iter = legs[best]["ms_per_lsqr_iteration"] * 1e-3
         t_build = max(tA - legs[build_ranks]["reload_and_1_iteration_s"], 1e-9)   # A = inputs + build + write + reload + 1 iteration
-        out = {"value": 1.0 / (t_iter * nnz_headline / nnz), "unit": "iterations/s", "cores": build_ranks,
-               "host_cores": cores, "kind": "reference",
+        out = {"value": 1.0 / (t_iter * nnz_headline / nnz), "unit": "iterations/s", "cores": best,      # the ranks `value` was measured on
+               "build_cores": build_ranks, "host_cores": cores, "kind": "reference",
                "sample": "oracle/_ref/tomofastx (the compiled reference) under mpiexec on %dx%dx%d cells x %d data, Haar r = %g "
                          "(box: %d host cores): kernel build on %d ranks %.3e cell.obs/s; LSQR %.2f ms per iteration at nnz = %d on "
                          "%d ranks (the faster of the legs at %s ranks whose 100-iteration difference clears the run-to-run spread - the "
