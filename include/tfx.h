@@ -229,10 +229,6 @@ int tfx_rowstore_counts(tfx_ctx *ctx, int nparts, const int64_t *bounds, int32_t
 int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t col_begin, int64_t col_end,
                       int32_t *cols_dev_out, float *vals_dev_out, int64_t capacity, int64_t *n_out);
 int tfx_rowstore_free(tfx_ctx *ctx);
-/* Optional, before tfx_matrix_begin: how many entries each of the ncols local columns will receive, counted over nrows_counted
- * rows (the all-reduced sensit_nnz restricted to this rank's cells - and repeated per model component - is exactly that).  The
- * library then stores the densely populated columns as per-row bitmaps instead of indexed entries (DESIGN.md "Data layout").   */
-int tfx_matrix_set_column_counts(tfx_ctx *ctx, const int32_t *counts, int64_t ncols, int64_t nrows_counted);
 int tfx_matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper);
 int tfx_matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const int32_t *cols_dev, const float *vals_dev,
                            const int32_t *nel_host);
@@ -301,9 +297,6 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * key "deterministic" (0/1; environment TFX_DETERMINISTIC at tfx_create): the two matrix products run with single-wave workgroups, so the LDS accumulations happen in program
  * order and a product is bit-reproducible from run to run (slow; for debugging convergence differences);
  * key "fwd_group" (0 = automatic, 1, 2, 4): row blocks that share one staged x tile in the forward product;
- * keys "hybrid" (0/1, default 0), "hybrid_min_nnz", "hybrid_tau_permille" (values): whether, from which size and from which column
- * density matrices get the bitmap head of the hybrid layout (experimental: fewer bytes, not faster - DESIGN.md);
- * "head_columns", "head_entries_permille": queries of the selected matrix;
  * key "build_overlap" (0/1, default 1): the kernel build runs its row generator (VALU-bound) on a second stream one batch ahead of
  * the wavelet / threshold / compaction kernels (HBM-bound) of the main stream; 0 = one stream, one row buffer;
  * key "chunk_exponent_span" (value): diagnostics - per mille of the stored 512-entry chunks whose non-zero values span at most

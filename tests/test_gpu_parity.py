@@ -562,53 +562,6 @@ def _csr_with_dense_columns(rng, nrows, ncols, ndense, per_row_sparse):
     return np.array(rp, np.int64), np.concatenate(cols), np.concatenate(vals)
 
 
-@pytest.mark.parametrize("shape", [(300, 5000, 700), (2500, 9000, 1500), (5000, 20000, 333)])
-def test_hybrid_layout_bitmap_head(ctx, shape):
-    """Hybrid layout: densely populated columns are permuted to the front and stored as per-row 64-bit masks + values (no column
-    index per entry), the rest as sparse tiles.  Round trip through the layout (bit-identical CSR), both products against the
-    oracle, the reload scaling, bit-reproducible deterministic mode, and the same matrix forced purely sparse."""
-    nrows, ncols, ndense = shape
-    rng = np.random.default_rng(nrows + ncols)
-    S = _csr_with_dense_columns(rng, nrows, ncols, ndense, 30)
-    x, y = rng.standard_normal(ncols), rng.standard_normal(nrows)
-    ref, reft = orc.spmv(*S, x), orc.spmtv(*S, y, ncols)
-    ctx.debug_set("hybrid", 1)
-    ctx.debug_set("hybrid_min_nnz", 0)
-    ctx.debug_set("hybrid_tau_permille", 80)
-    try:
-        ctx.matrix_upload_csr(nrows, ncols, *S)
-        nh = ctx.debug_set("head_columns")
-        assert nh >= 64 * (ndense // 64) and nh <= ndense + 64 * 8, nh                 # the dense columns (rounded to groups of 64)
-        assert ctx.debug_set("head_entries_permille") > 800
-        back = ctx.matrix_download_csr()
-        assert np.array_equal(back[0], S[0]) and np.array_equal(back[1], S[1]) and bits_equal(back[2], S[2])
-        assert np.allclose(ctx.mult_vector(x), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
-        assert np.allclose(ctx.trans_mult_vector(y), reft, rtol=1e-12, atol=1e-12 * np.abs(reft).max())
-        b0 = rng.standard_normal(nrows)
-        assert np.allclose(ctx.mult_vector(x, b0), b0 + ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
-        t0 = rng.standard_normal(ncols)
-        assert np.allclose(ctx.trans_mult_vector(y, t0), t0 + reft, rtol=1e-12, atol=1e-12 * np.abs(reft).max())
-        ctx.debug_set("deterministic", 1)
-        f = [ctx.mult_vector(x) for _ in range(3)]
-        a = [ctx.trans_mult_vector(y) for _ in range(3)]
-        ctx.debug_set("deterministic", 0)
-        assert bits_equal(f[1], f[0]) and bits_equal(f[2], f[0]) and bits_equal(a[1], a[0]) and bits_equal(a[2], a[0])
-        scale = rng.uniform(0.1, 30.0, nrows)
-        ctx.matrix_scale_rows(scale)
-        back = ctx.matrix_download_csr()
-        want = (S[2] * np.repeat(scale.astype(np.float32), np.diff(S[0]))).astype(np.float32)
-        assert np.array_equal(back[1], S[1]) and bits_equal(back[2], want)
-        ctx.debug_set("hybrid", 0)
-        ctx.matrix_upload_csr(nrows, ncols, *S)
-        assert ctx.debug_set("head_columns") == 0
-        assert np.allclose(ctx.mult_vector(x), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
-    finally:
-        ctx.debug_set("hybrid", 0)
-        ctx.debug_set("hybrid_min_nnz", 1 << 24)
-        ctx.debug_set("hybrid_tau_permille", 400)
-        ctx.debug_set("deterministic", 0)
-
-
 def test_lsqr_two_diagonal_blocks_and_soft_threshold(ctx, golden_dir):
     """Damping AND ADMM block together (two diagonal blocks, joint_inverse_problem.F90:452-527) with soft thresholding
     (lsqr_solver2.F90:478-494) against the oracle on the same [S; a I; b I] system."""

@@ -25,15 +25,10 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     c->stream = (hipStream_t)stream;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
-    // test knobs of the hybrid layout (same as the debug keys "hybrid" / "hybrid_min_nnz"): the GPU suite is run a second time
-    // with TFX_HYBRID_MIN_NNZ=0 so that every small matrix of the parity tests goes through the bitmap head as well
-    if (const char *e = getenv("TFX_HYBRID")) c->hybrid = atoi(e) != 0;
     if (const char *e = getenv("TFX_DETERMINISTIC")) c->deterministic = atoi(e) != 0;     // like tfx_debug_set "deterministic"
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = atoi(e) != 0;
     if (const char *e = getenv("TFX_GEN_WGS_PER_CU")) c->gen_wgs_per_cu = atoi(e);
     if (const char *e = getenv("TFX_GEN_AFTER_WAVELET")) c->gen_after_wavelet = atoi(e) != 0;
-    if (const char *e = getenv("TFX_HYBRID_MIN_NNZ")) c->hybrid_min_nnz = atoll(e);
-    if (const char *e = getenv("TFX_HYBRID_TAU")) c->hybrid_tau_permille = std::max(74, std::min(1000, atoi(e)));
     TFX_HIP(hipEventCreate(&c->ev0));
     TFX_HIP(hipEventCreate(&c->ev1));
     TFX_HIP(hipEventCreate(&c->pev0));
@@ -164,25 +159,6 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         ctx->deterministic = value != 0;
         return 0;
     }
-    if (!strcmp(key, "hybrid")) {               // 0: matrices begun from now on stay purely sparse (no bitmap head, no permutation)
-        ctx->hybrid = value != 0;
-        return 0;
-    }
-    if (!strcmp(key, "hybrid_tau_permille")) {  // density (per mille) above which a group of 64 ordered columns is stored as bitmaps
-        ctx->hybrid_tau_permille = std::max(74, std::min(1000, value));
-        return 0;
-    }
-    if (!strcmp(key, "hybrid_min_nnz")) {       // matrices with fewer entries than this stay purely sparse
-        ctx->hybrid_min_nnz = value;
-        return 0;
-    }
-    if (!strcmp(key, "head_columns")) return (int)std::min<int64_t>(ctx->selmat().NH, INT32_MAX);      // queries
-    if (!strcmp(key, "head_entries_permille")) {
-        const TiledMatrix &mm = ctx->selmat();
-        int64_t hv = 0;
-        for (const TileMeta &t : mm.h_tiles) hv += t.kind ? t.cnt : 0;
-        return mm.nnz > 0 ? (int)(1000.0 * (double)hv / (double)mm.nnz) : 0;
-    }
     if (!strcmp(key, "chunk_exponent_span")) {  // diagnostics: per mille of the chunks whose non-zero values span <= `value` binades
         int64_t fit = 0, total = 0;
         unsigned int hist[34];
@@ -211,7 +187,11 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "refinish")) {             // rebuild the work lists of the selected matrix with the current knobs
         if (!ctx->selmat().valid || ctx->selmat().is_dense) return fail(TFX_E_STATE, "refinish: no tiled matrix");
         const int64_t nnz = ctx->selmat().nnz;
-        TFX_TRY(matrix_finish(ctx));
+        TiledMatrix *keep = ctx->target;            // (the target may still be the constraint matrix or the other slot: ADVICE r2)
+        ctx->target = &ctx->selmat();
+        const int rc = matrix_finish(ctx);
+        ctx->target = keep;
+        TFX_TRY(rc);
         ctx->selmat().nnz = nnz;
         return 0;
     }
@@ -294,11 +274,6 @@ static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_
                 return fail(TFX_E_ARG, "columns must ascend within a row (row %lld)", (long long)r);
         }
     }
-    {   // exact per-column counts choose the head of the hybrid layout (matrix.hip: choose_head)
-        std::vector<int32_t> cnt((size_t)ncols, 0);
-        for (int64_t k = 0; k < nnz; ++k) cnt[(size_t)(cols[k] - 1)] += 1;
-        set_column_counts(ctx, cnt.data(), ncols, nrows);
-    }
     TFX_TRY(matrix_begin(ctx, nrows, ncols, nnz));
     TiledMatrix &m = dst;
     hipStream_t s = ctx->stream;
@@ -333,16 +308,6 @@ static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_
     }
     TFX_TRY(matrix_finish(ctx));
     m.nnz = nnz;
-    return 0;
-}
-
-// Per-column entry counts for the matrix the next tfx_matrix_begin (or build / upload) assembles: they choose the densely
-// populated columns that are stored as bitmaps (hybrid layout).  Optional: without counts the matrix stays purely sparse.
-int tfx_matrix_set_column_counts(tfx_ctx *ctx, const int32_t *counts, int64_t ncols, int64_t nrows_counted)
-{
-    if (!ctx) return fail(TFX_E_ARG, "null ctx");
-    if (counts && (ncols <= 0 || nrows_counted <= 0)) return fail(TFX_E_ARG, "tfx_matrix_set_column_counts: bad sizes");
-    set_column_counts(ctx, counts, ncols, nrows_counted);
     return 0;
 }
 
@@ -404,23 +369,7 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
         const int i = (int)(e & (CHUNK - 1)), lane = i >> 3, k = i & 7;
         return (hm[(size_t)(chunk * MASK_WORDS + k)] >> lane) & 1ull;
     };
-    // hybrid layout: the bitmap (head) tiles and the column permutation
-    std::vector<uint64_t> hhm;
-    std::vector<int32_t> hro, hperm;
-    std::vector<float> hhv;
-    if (m.NH > 0) {
-        hhm.resize(m.hmask.n);
-        hro.resize(m.hrowoff.n);
-        hhv.resize((size_t)std::max<int64_t>(1, m.h_entries));
-        hperm.resize((size_t)m.ncols_p);
-        TFX_HIP(hipMemcpy(hhm.data(), m.hmask.p, m.hmask.bytes(), hipMemcpyDeviceToHost));
-        TFX_HIP(hipMemcpy(hro.data(), m.hrowoff.p, m.hrowoff.bytes(), hipMemcpyDeviceToHost));
-        if (m.h_entries > 0) TFX_HIP(hipMemcpy(hhv.data(), m.hvals.p, (size_t)m.h_entries * sizeof(float), hipMemcpyDeviceToHost));
-        TFX_HIP(hipMemcpy(hperm.data(), m.perm.p, m.perm.bytes(), hipMemcpyDeviceToHost));
-    }
-    auto orig_col = [&](int64_t pcol) -> int64_t { return m.NH > 0 ? (int64_t)hperm[(size_t)pcol] : pcol; };
-    const int gpt = m.TC / HGROUP;
-    // tiles sorted by (rb, t); with a permutation the columns of a row are sorted afterwards
+    // tiles sorted by (rb, t)
     std::vector<TileMeta> tl = m.h_tiles;
     std::sort(tl.begin(), tl.end(), [](const TileMeta &a, const TileMeta &b) { return a.rb != b.rb ? a.rb < b.rb : a.t < b.t; });
     // pass 0: counts, pass 1: fill
@@ -434,27 +383,6 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
             fill.assign(rowptr, rowptr + m.nrows);
         }
         for (const TileMeta &tm : tl) {
-            if (tm.kind) {                        // bitmap tile: row r, group g, set bits ascending
-                for (int r = 0; r < tm.nchunks; ++r) {
-                    const int64_t row = (int64_t)tm.rb * m.RB + r;
-                    int64_t vi = tm.off + 1 + hro[(size_t)tm.aux * m.RB + r];      // (element 0 of the tile's run is its reserved zero)
-                    for (int g = 0; g < gpt; ++g) {
-                        uint64_t mk = hhm[((size_t)tm.aux * m.RB + r) * gpt + g];
-                        while (mk) {
-                            const int bit = __builtin_ctzll(mk);
-                            mk &= mk - 1;
-                            if (pass == 0) cnt[(size_t)row] += 1;
-                            else {
-                                const int64_t p = fill[(size_t)row]++;
-                                if (cols) cols[p] = (int32_t)(orig_col((int64_t)tm.t * m.TC + g * HGROUP + bit) + 1);
-                                if (vals) vals[p] = hhv[(size_t)vi];
-                            }
-                            ++vi;
-                        }
-                    }
-                }
-                continue;
-            }
             int cur = hrow0[(size_t)(tm.off / CHUNK)];
             for (int32_t e = 0; e < tm.cnt; ++e) {
                 const bool flag = flag_at(tm.off + e);
@@ -470,21 +398,10 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
                 if (pass == 0) cnt[(size_t)row] += 1;
                 else {
                     int64_t p = fill[(size_t)row]++;
-                    const int64_t pcol = (int64_t)(tm.t - m.nht) * m.TC + col_slot((int)slot) + m.NHpad;
-                    if (cols) cols[p] = (int32_t)(orig_col(pcol) + 1);
+                    if (cols) cols[p] = (int32_t)((int64_t)tm.t * m.TC + col_slot((int)slot) + 1);
                     if (vals) vals[p] = v;
                 }
             }
-        }
-    }
-    if (m.NH > 0 && cols) {                       // ascending original columns inside every row
-        std::vector<std::pair<int32_t, float>> tmp;
-        for (int64_t r = 0; r < m.nrows; ++r) {
-            const int64_t a = rowptr[r], b = rowptr[r + 1];
-            tmp.resize((size_t)(b - a));
-            for (int64_t k = a; k < b; ++k) tmp[(size_t)(k - a)] = {cols[k], vals ? vals[k] : 0.0f};
-            std::sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, float> &x, const std::pair<int32_t, float> &y) { return x.first < y.first; });
-            for (int64_t k = a; k < b; ++k) { cols[k] = tmp[(size_t)(k - a)].first; if (vals) vals[k] = tmp[(size_t)(k - a)].second; }
         }
     }
     return 0;

@@ -2770,32 +2770,6 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         return 0;
     }
     if (keep_matrix) {
-        // Hybrid layout: which columns are densely populated is estimated from a sample of the observations spread over the data
-        // set - the same pipeline in its count-only mode (no matrix is touched), a fraction of a percent of the build.
-        if (ctx->hybrid && nrows_m * stride >= ctx->hybrid_min_nnz && ndata >= 8) {
-            const int64_t S = std::min<int64_t>(ndata, 192);
-            std::vector<double> hx((size_t)ndata), hy((size_t)ndata), hz((size_t)ndata), sx((size_t)S), sy((size_t)S), sz((size_t)S);
-            TFX_TRY(copy_any(hx.data(), xd, (size_t)ndata * sizeof(double), s));
-            TFX_TRY(copy_any(hy.data(), yd, (size_t)ndata * sizeof(double), s));
-            TFX_TRY(copy_any(hz.data(), zd, (size_t)ndata * sizeof(double), s));
-            for (int64_t i = 0; i < S; ++i) {
-                const int64_t j = S > 1 ? i * (ndata - 1) / (S - 1) : 0;
-                sx[(size_t)i] = hx[(size_t)j]; sy[(size_t)i] = hy[(size_t)j]; sz[(size_t)i] = hz[(size_t)j];
-            }
-            std::vector<int32_t> hist((size_t)N), cnt((size_t)(ncm * ncols));
-            int64_t nnz_s = 0;
-            double err_s = 0.0;
-            TiledMatrix *keep_target = ctx->target;
-            TFX_TRY(build_kernel_any(ctx, gen, S, sx.data(), sy.data(), sz.data(), column_weight, compression_type, rate, 1.0, nullptr, 0, 0,
-                                     &nnz_s, &err_s, hist.data(), nullptr));
-            ctx->target = keep_target;
-            for (int k = 0; k < ncm; ++k)
-                for (int64_t j = 0; j < ncols; ++j) cnt[(size_t)(k * ncols + j)] = hist[(size_t)(col_begin + j)] / ncm;   // lines of all components are counted per cell
-            set_column_counts(ctx, cnt.data(), ncm * ncols, S * ncd);
-        } else {
-            set_column_counts(ctx, nullptr, 0, 0);
-        }
-        lap("column counts");
         TFX_TRY(matrix_begin(ctx, nrows_m, ncm * ncols, nrows_m * stride));
         lap("matrix_begin");
     }

@@ -87,16 +87,14 @@ __host__ __device__ inline int64_t val_pos(int64_t e)
     return (e & ~(int64_t)511) | (((e >> 2) & 1) << 8) | (((e >> 3) & 63) << 2) | (e & 3);
 }
 
-constexpr int HGROUP = 64;            // columns per bitmap group of the head part (one 64-bit mask per row and group)
-
 struct TileMeta {
-    int64_t off;      // sparse tile: first entry (multiple of CHUNK) in the entry streams; bitmap tile: first value in hvals[]
-    int32_t nchunks;  // work units of the tile: sparse - chunks (padded length / CHUNK); bitmap - rows
-    int32_t cnt;      // real entries (sparse: incl. empty-row markers)
-    int32_t t;        // column tile (in the permuted column space: bitmap head tiles first, then the sparse tail tiles)
+    int64_t off;      // first entry (multiple of CHUNK) in the entry streams
+    int32_t nchunks;  // chunks of the tile (padded length / CHUNK)
+    int32_t cnt;      // real entries (incl. empty-row markers)
+    int32_t t;        // column tile
     int32_t rb;       // row block
-    int32_t kind;     // 0 sparse (12-bit slots + row-start masks), 1 bitmap (head part)
-    int32_t aux;      // bitmap tile: its slot in hmask[] / hrowoff[]
+    int32_t kind;     // reserved (0)
+    int32_t aux;      // reserved (0)
 };
 
 struct WorkItem {     // one workgroup's work: a run of tiles sharing rb (forward) or t (adjoint)
@@ -118,20 +116,6 @@ struct TiledMatrix {
     int64_t n_entries = 0;        // used (padded) entries
     int64_t cap_entries = 0;      // allocated entries
     DBuf<int32_t> chunk_row0;     // per chunk: local row of the entry preceding the chunk
-    // ---- hybrid layout (DESIGN.md "Data layout"): the columns are permuted so that the densely populated ones (the coarse
-    // wavelet coefficients every row keeps) come first - the HEAD, NH columns in groups of 64 - and the rest - the TAIL - follows
-    // in its original order.  Head tiles store, per row and group, a 64-bit occupancy mask and the values of the set bits, row-major
-    // (no column index per entry: 4 B + 8 B / (64 x fill) per non-zero); tail tiles are the sparse tiles above.
-    int64_t NH = 0;               // head columns (multiple of HGROUP); 0: no head, no permutation
-    int64_t NHpad = 0;            // head padded to whole column tiles; tail column j sits at permuted column NHpad + j
-    int64_t ncols_p = 0;          // size of the permuted column space = NHpad + (ncols - NH)
-    int nht = 0;                  // head (bitmap) column tiles
-    DBuf<int32_t> perm, iperm;    // perm[p] = original column of permuted column p (-1: padding), iperm[c] = permuted column of c
-    DBuf<uint64_t> hmask;         // [slot][RB rows][TC / 64 groups], slot = rb * nht + ht
-    DBuf<int32_t> hrowoff;        // [slot][RB]: offset of the row's first value inside the tile's value run
-    DBuf<float> hvals;            // values of all bitmap tiles
-    int64_t h_entries = 0, h_cap = 0;
-    DBuf<double> xp, yp;          // permuted copies of the vectors of a product
     std::vector<TileMeta> h_tiles;
     DBuf<TileMeta> tiles;
     // work lists
@@ -198,24 +182,8 @@ struct tfx_ctx {
         tfx::DBuf<int64_t> tile_off;
         std::vector<int32_t> h_segoff_last, h_nch;
         std::vector<int64_t> h_off;
-        // hybrid split: the tail entries of the row block (compacted, tail column space), per-row / per-group value prefixes
-        tfx::DBuf<int32_t> tcols, tnel, htot;
-        tfx::DBuf<float> tvals;
-        tfx::DBuf<int64_t> toff, htile_off;
-        tfx::DBuf<uint16_t> gpre, tmp16;
-        std::vector<int32_t> h_htot;
-        std::vector<int64_t> h_htile_off;
+        tfx::DBuf<uint16_t> tmp16;
     } append;
-    // per-column entry counts for the next matrix_begin (tfx_matrix_set_column_counts / the build's sample): they choose the head
-    std::vector<int32_t> col_counts;
-    int64_t col_counts_rows = 0;
-    // The hybrid layout is OFF by default: measured at the headline size it saves 5-10 % of the bytes but does not run faster - the walk
-    // over a group's mask costs the same whatever its fill, and at the fill of a wavelet-compressed kernel's dense columns (0.3 on
-    // average) a bitmap step serves 19 of its 64 lanes, so the bitmap tiles are instruction-issue-bound where the sparse tiles are
-    // HBM-bound ("Hybrid layout").  Kept selectable (debug key "hybrid" / TFX_HYBRID=1) and covered by the tests.
-    int hybrid = 0;                    // debug key "hybrid": 1 use the bitmap head for matrices above hybrid_min_nnz
-    int hybrid_tau_permille = 400;     // debug key "hybrid_tau_permille": groups of 64 ordered columns denser than this join the head
-    int64_t hybrid_min_nnz = 1 << 24;  // debug key "hybrid_min_nnz": matrices below this many entries stay purely sparse
     // scratch vectors for spmv / spmtv with host pointers
     tfx::DBuf<double> vx, vb, vw;
     // comm
@@ -244,7 +212,6 @@ struct tfx_ctx {
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
     bool deterministic = false;       // debug: single-wave workgroups in the two products -> LDS atomics in program order
     size_t wave_lds_attr[4] = {0, 0, 0, 0};   // the same for the four wavelet axis kernels (Haar / D4 x forward / inverse)
-    size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // largest dynamic-LDS size registered for each product kernel variant ON THIS ctx's device
     bool profile = false;
     double prof_ms[2] = {0, 0};
     int64_t prof_n[2] = {0, 0};
@@ -267,7 +234,6 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
 int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols);
 int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale);
 int chunk_exponent_stats(tfx_ctx *ctx, TiledMatrix &m, int span, int64_t *fit, int64_t *total, unsigned int *hist34);
-void set_column_counts(tfx_ctx *ctx, const int32_t *counts, int64_t ncols, int64_t nrows_counted);
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
 void prof_drain(tfx_ctx *ctx);
 // comm.hip

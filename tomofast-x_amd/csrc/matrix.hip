@@ -33,8 +33,7 @@ thread_local std::string g_last_error;
 
 size_t TiledMatrix::device_bytes() const
 {
-    return perm.bytes() + iperm.bytes() + hmask.bytes() + hrowoff.bytes() + hvals.bytes() + xp.bytes() + yp.bytes() +
-           slots.bytes() + rowmask.bytes() + vals.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
+    return slots.bytes() + rowmask.bytes() + vals.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
            fwd_order.bytes() + adj_order.bytes() + fwd_partial.bytes() + adj_partial.bytes() + adj_nslots.bytes() +
            adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes() + dense.bytes() + dense_partial.bytes();
 }
@@ -45,8 +44,6 @@ void TiledMatrix::release_storage()
     fwd_order.release(); adj_order.release(); fwd_partial.release(); adj_partial.release();
     fwd_nslots.release(); fwd_pbase.release(); adj_nslots.release(); adj_pbase.release();
     dense.release(); dense_partial.release();
-    perm.release(); iperm.release(); hmask.release(); hrowoff.release(); hvals.release(); xp.release(); yp.release();
-    NH = NHpad = ncols_p = 0; nht = 0; h_entries = h_cap = 0;
     h_tiles.clear(); h_fwd.clear(); h_adj.clear();
     is_dense = false;
     n_entries = cap_entries = 0;
@@ -238,130 +235,6 @@ __global__ void k_chunk_row0(int nr, const int32_t *__restrict__ segoff, const i
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Hybrid layout: the head (bitmap) part of a row block.  Input rows are in ORIGINAL local columns, ascending.
-// ------------------------------------------------------------------------------------------------------------
-// One wave per row: head entries set their bit in the row's group masks; tail entries are compacted, in order, into the
-// tail ELL (columns in the tail's own column space, still ascending: the tail keeps the original column order).
-__global__ __launch_bounds__(64) void k_hyb_split(const int32_t *__restrict__ cols, const float *__restrict__ vals,
-                                                   const int32_t *__restrict__ nel, const int64_t *__restrict__ rowoff,
-                                                   const int32_t *__restrict__ iperm, int64_t NH, int64_t NHpad, int TC, int RB, int nht,
-                                                   unsigned long long *__restrict__ hmask /* slot 0 of this row block */,
-                                                   int32_t *__restrict__ tcols, float *__restrict__ tvals, int32_t *__restrict__ tnel,
-                                                   int64_t tstride)
-{
-    const int r = blockIdx.x, lane = threadIdx.x;
-    const int n = nel[r];
-    const int gpt = TC / HGROUP;
-    const int32_t *c = cols + rowoff[r];
-    const float *v = vals + rowoff[r];
-    int32_t *tc = tcols + (int64_t)r * tstride;
-    float *tv = tvals + (int64_t)r * tstride;
-    int ntail = 0;
-    for (int e0 = 0; e0 < n; e0 += 64) {
-        const int e = e0 + lane;
-        const bool in = e < n;
-        int64_t p = 0;
-        float val = 0.0f;
-        if (in) { p = iperm[c[e]]; val = v[e]; }
-        const bool head = in && p < NH;
-        const bool tail = in && !head;
-        if (head) {
-            const int ht = (int)(p / TC), g = (int)(p - (int64_t)ht * TC) / HGROUP, bit = (int)(p & (HGROUP - 1));
-            atomicOr(hmask + ((int64_t)ht * RB + r) * gpt + g, 1ull << bit);
-        }
-        const unsigned long long mt = __ballot(tail);
-        if (tail) {
-            const int k = ntail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0));
-            tc[k] = (int32_t)(p - NHpad);
-            tv[k] = val;
-        }
-        ntail += __popcll(mt);
-    }
-    if (lane == 0) tnel[r] = ntail;
-    (void)nht;
-}
-
-// One block per head tile of the row block: per row the number of values (sum of popcounts) and their exclusive scan over the rows
-// -> hrowoff; per (row, group) the prefix inside the row -> gpre (temporary); the tile's total -> htot.
-__global__ void k_hyb_scan(const unsigned long long *__restrict__ hmask /* slot 0 of this row block */, int nr, int RB, int gpt,
-                           int32_t *__restrict__ hrowoff /* slot 0 */, uint16_t *__restrict__ gpre, int32_t *__restrict__ htot)
-{
-    extern __shared__ int32_t sm[];     // nr
-    const int ht = blockIdx.x;
-    const unsigned long long *mk = hmask + (int64_t)ht * RB * gpt;
-    uint16_t *gp = gpre + (int64_t)ht * RB * gpt;
-    for (int r = threadIdx.x; r < nr; r += blockDim.x) {
-        int run = 0;
-        for (int g = 0; g < gpt; ++g) {
-            gp[(int64_t)r * gpt + g] = (uint16_t)run;
-            run += __popcll(mk[(int64_t)r * gpt + g]);
-        }
-        sm[r] = run;
-    }
-    __syncthreads();
-    const int per = (nr + blockDim.x - 1) / blockDim.x;
-    const int b = threadIdx.x * per, e = min(b + per, nr);
-    int sum = 0;
-    for (int r = b; r < e; ++r) sum += sm[r];
-    __shared__ int part[1024];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < (int)blockDim.x; ++i) { int v = part[i]; part[i] = run; run += v; }
-        htot[ht] = run;
-    }
-    __syncthreads();
-    int run = part[threadIdx.x];
-    int32_t *ro = hrowoff + (int64_t)ht * RB;
-    for (int r = b; r < e; ++r) { ro[r] = run; run += sm[r]; }
-}
-
-// One wave per row again: every head entry goes to its place in the value run of its tile:
-// tile offset + row offset + group prefix + rank of its bit inside the group mask.
-__global__ __launch_bounds__(64) void k_hyb_scatter(const int32_t *__restrict__ cols, const float *__restrict__ vals,
-                                                     const int32_t *__restrict__ nel, const int64_t *__restrict__ rowoff,
-                                                     const int32_t *__restrict__ iperm, int64_t NH, int TC, int RB, int nht,
-                                                     const unsigned long long *__restrict__ hmask, const int32_t *__restrict__ hrowoff,
-                                                     const uint16_t *__restrict__ gpre, const int64_t *__restrict__ htile_off,
-                                                     float *__restrict__ hvals)
-{
-    const int r = blockIdx.x, lane = threadIdx.x;
-    const int n = nel[r];
-    const int gpt = TC / HGROUP;
-    const int32_t *c = cols + rowoff[r];
-    const float *v = vals + rowoff[r];
-    for (int e = lane; e < n; e += 64) {
-        const int64_t p = iperm[c[e]];
-        if (p >= NH) continue;
-        const int ht = (int)(p / TC), g = (int)(p - (int64_t)ht * TC) / HGROUP, bit = (int)(p & (HGROUP - 1));
-        const int64_t mi = ((int64_t)ht * RB + r) * gpt + g;
-        const unsigned long long m = hmask[mi];
-        const int rank = __popcll(m & ((1ull << bit) - 1ull));
-        hvals[htile_off[ht] + 1 + hrowoff[(int64_t)ht * RB + r] + gpre[mi] + rank] = v[e];
-    }
-    if (r == 0)                                         // element 0 of every tile's value run: the reserved zero
-        for (int ht = lane; ht < nht; ht += 64) hvals[htile_off[ht]] = 0.0f;
-}
-
-// xp[p] = x[perm[p]] (0 in the padding) / y[perm[p]] += yp[p]
-__global__ void k_perm_gather(const double *__restrict__ x, const int32_t *__restrict__ perm, int64_t np, double *__restrict__ xp)
-{
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t c = perm[p];
-        xp[p] = c >= 0 ? x[c] : 0.0;
-    }
-}
-
-__global__ void k_perm_scatter_add(const double *__restrict__ yp, const int32_t *__restrict__ perm, int64_t np, double *__restrict__ y)
-{
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t c = perm[p];
-        if (c >= 0) y[c] += yp[p];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // Dense storage for an uncompressed kernel (forward.matrixCompression.type = 0): fp32 [nrows][ld], 4 B per entry.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int DN_CHUNK = 8192;          // columns per workgroup (x chunk = 64 KB of LDS)
@@ -464,67 +337,6 @@ __global__ void k_dense_scale_rows(float *__restrict__ A, int64_t ld, int64_t nr
     }
 }
 
-void set_column_counts(tfx_ctx *ctx, const int32_t *counts, int64_t ncols, int64_t nrows_counted)
-{
-    if (!counts || ncols <= 0 || nrows_counted <= 0) {
-        ctx->col_counts.clear();
-        ctx->col_counts_rows = 0;
-        return;
-    }
-    ctx->col_counts.assign(counts, counts + ncols);
-    ctx->col_counts_rows = nrows_counted;
-}
-
-// Chooses the head of the hybrid layout from per-column entry counts over `R` rows (all rows, or a sample spread over them).
-// Columns are ordered by count, descending (stable: ties keep the original order); groups of 64 ordered columns join the head
-// while a bitmap (8 B mask per row + 4 B per entry) is cheaper than the sparse stream (5.625 B per entry + ~1 % markers and
-// padding): 8 + 4 k < 5.7 k  <=>  k > 4.7 entries per row and group  <=>  group density > 0.0735.  The tail keeps the original order.
-// Returns the head's share of the counted entries (capacity estimate); leaves m.NH = 0 when nothing qualifies.
-static double choose_head(tfx_ctx *ctx, TiledMatrix &m, int64_t nnz_upper, std::vector<int32_t> &h_perm, std::vector<int32_t> &h_iperm)
-{
-    m.NH = m.NHpad = 0;
-    m.nht = 0;
-    m.ncols_p = m.ncols;
-    h_perm.clear();
-    h_iperm.clear();
-    const int64_t n = m.ncols, R = ctx->col_counts_rows;
-    if (!ctx->hybrid || (int64_t)ctx->col_counts.size() != n || R <= 0 || nnz_upper < ctx->hybrid_min_nnz || n < HGROUP) return 0.0;
-    const std::vector<int32_t> &cnt = ctx->col_counts;
-    int32_t maxc = 0;
-    int64_t total = 0;
-    for (int64_t c = 0; c < n; ++c) { maxc = std::max(maxc, cnt[(size_t)c]); total += cnt[(size_t)c]; }
-    if (total <= 0) return 0.0;
-    // counting sort, descending by count, ascending by column inside a count
-    std::vector<int64_t> start((size_t)maxc + 2, 0);
-    for (int64_t c = 0; c < n; ++c) start[(size_t)(maxc - cnt[(size_t)c]) + 1] += 1;
-    for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
-    std::vector<int32_t> order((size_t)n);
-    for (int64_t c = 0; c < n; ++c) order[(size_t)start[(size_t)(maxc - cnt[(size_t)c])]++] = (int32_t)c;
-    // break-even on bytes is a group density of 0.0735; the walk over a group's mask costs the same whatever its fill, so thinly
-    // filled groups are cheaper to process as sparse entries: the threshold is a measured compromise (debug key "hybrid_tau_permille")
-    const double tau = 1e-3 * (double)ctx->hybrid_tau_permille;
-    int64_t G = 0, headsum = 0;
-    for (int64_t j = 0; (j + 1) * HGROUP <= n; ++j) {
-        int64_t gsum = 0;
-        for (int k = 0; k < HGROUP; ++k) gsum += cnt[(size_t)order[(size_t)(j * HGROUP + k)]];
-        if ((double)gsum <= tau * (double)HGROUP * (double)R) break;
-        headsum += gsum;
-        G = j + 1;
-    }
-    if (G == 0) return 0.0;
-    m.NH = G * HGROUP;
-    m.NHpad = (m.NH + m.TC - 1) / m.TC * m.TC;
-    m.nht = (int)(m.NHpad / m.TC);
-    m.ncols_p = m.NHpad + (n - m.NH);
-    h_perm.assign((size_t)m.ncols_p, -1);
-    h_iperm.assign((size_t)n, -1);
-    for (int64_t p = 0; p < m.NH; ++p) { h_perm[(size_t)p] = order[(size_t)p]; h_iperm[(size_t)order[(size_t)p]] = (int32_t)p; }
-    int64_t p = m.NHpad;
-    for (int64_t c = 0; c < n; ++c)
-        if (h_iperm[(size_t)c] < 0) { h_perm[(size_t)p] = (int32_t)c; h_iperm[(size_t)c] = (int32_t)p; ++p; }
-    return (double)headsum / (double)total;
-}
-
 int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 {
     TiledMatrix &m = *ctx->target;
@@ -554,43 +366,11 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
         m.RB = (int)rb;
     }
     m.nrb = (int)((nrows + m.RB - 1) / m.RB);
-    // hybrid layout: the head from the column counts the caller (or the build's sample) left in the ctx
-    std::vector<int32_t> h_perm, h_iperm;
-    double head_frac = 0.0;
-    m.ncols_p = ncols;
-    if (m.TC % HGROUP == 0) head_frac = choose_head(ctx, m, nnz_upper, h_perm, h_iperm);
-    ctx->col_counts.clear();
-    ctx->col_counts_rows = 0;
-    const int64_t ncols_tail = ncols - m.NH;
-    const int ntc_tail = (int)((ncols_tail + m.TC - 1) / m.TC);
-    m.ntc = m.nht + ntc_tail;                                   // column tiles of the permuted space: head tiles, then tail tiles
-    int64_t nnz_tail_upper = nnz_upper;
-    if (m.NH > 0) {
-        hipStream_t s = ctx->stream;
-        TFX_TRY(m.perm.alloc((size_t)m.ncols_p));
-        TFX_TRY(m.iperm.alloc((size_t)ncols));
-        TFX_HIP(hipMemcpyAsync(m.perm.p, h_perm.data(), h_perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        TFX_HIP(hipMemcpyAsync(m.iperm.p, h_iperm.data(), h_iperm.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        TFX_HIP(hipStreamSynchronize(s));
-        const int gpt = m.TC / HGROUP;
-        const size_t nslots = (size_t)m.nrb * m.nht;
-        TFX_TRY(m.hmask.alloc(nslots * m.RB * gpt));
-        TFX_TRY(m.hrowoff.alloc(nslots * m.RB));
-        TFX_HIP(hipMemsetAsync(m.hmask.p, 0, m.hmask.bytes(), s));
-        TFX_HIP(hipMemsetAsync(m.hrowoff.p, 0, m.hrowoff.bytes(), s));
-        // capacity split by the counted share (+ margin: the counts may come from a sample)
-        m.h_cap = std::min<int64_t>(nnz_upper, (int64_t)(std::min(1.0, head_frac * 1.06 + 0.01) * (double)nnz_upper) + 1024);
-        nnz_tail_upper = std::min<int64_t>(nnz_upper, (int64_t)(std::min(1.0, (1.0 - head_frac) * 1.06 + 0.01) * (double)nnz_upper) + 1024);
-        m.h_cap += (int64_t)m.nrb * m.nht;                   // one reserved zero per bitmap tile
-        TFX_TRY(m.hvals.alloc((size_t)m.h_cap + 64));     // + slack: lanes whose bit is clear read up to one value past a row's run
-        TFX_TRY(m.xp.alloc((size_t)m.ncols_p));
-        TFX_TRY(m.yp.alloc((size_t)m.ncols_p));
-        m.h_entries = 0;
-    }
+    m.ntc = (int)((ncols + m.TC - 1) / m.TC);
     // marker entries: a row that is empty inside a tile between two non-empty rows of that tile.  At most one per (row, column
     // tile); a tile needs two real entries to have any, and at most RB - 2 of them
-    int64_t markers = std::min<int64_t>((int64_t)nrows * ntc_tail, (nnz_tail_upper / 2 + 1) * (int64_t)m.RB);
-    int64_t cap = nnz_tail_upper + markers + (int64_t)m.nrb * ntc_tail * CHUNK + CHUNK;
+    int64_t markers = std::min<int64_t>((int64_t)nrows * m.ntc, (nnz_upper / 2 + 1) * (int64_t)m.RB);
+    int64_t cap = nnz_upper + markers + (int64_t)m.nrb * m.ntc * CHUNK + CHUNK;
     cap = (cap + CHUNK - 1) / CHUNK * CHUNK;
     TFX_TRY(m.vals.alloc((size_t)cap));
     TFX_TRY(m.slots.alloc((size_t)(cap / CHUNK) * SLOT_WORDS));
@@ -605,8 +385,6 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 // Appends the tiles of one row block.  Row r of the block has d_nel[r] entries starting at d_cols/d_vals +
 // d_rowoff[r] (columns ascending, 0-based local); maxlen >= max d_nel.  row_begin must be a multiple of RB, nr <= RB.
 // Everything is queued on the ctx stream; the inputs may be reused by work queued on that stream afterwards.
-// Hybrid layout: the rows are first split - head entries into the bitmap tiles of the row block, tail entries (compacted, in the
-// tail's column space) into the sparse tiles.
 int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int32_t *d_cols, const float *d_vals,
                        const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen)
 {
@@ -616,41 +394,13 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
     if (row_begin % m.RB != 0 || nr > m.RB || nr <= 0)
         return fail(TFX_E_ARG, "matrix_append_rows: rows [%lld, +%d) not aligned to row block %d", (long long)row_begin, nr, m.RB);
     int rb = (int)(row_begin / m.RB);
-    const bool hyb = m.NH > 0;
-    const int nht = m.nht;
-    const int ntc = m.ntc - nht;                       // sparse (tail) column tiles
-    const int gpt = m.TC / HGROUP;
+    const int ntc = m.ntc;
     // scratch of the conversion lives in the ctx (no allocation per row block once it has grown to size)
     tfx_ctx::AppendScratch &sc = ctx->append;
-    unsigned long long *hmask0 = nullptr;
-    int32_t *hrowoff0 = nullptr;
-    if (hyb) {
-        // 1. split: head bits + compacted tail rows
-        const int64_t tstride = std::max<int64_t>(1, maxlen);
-        TFX_TRY(sc.tcols.ensure((size_t)nr * tstride));
-        TFX_TRY(sc.tvals.ensure((size_t)nr * tstride));
-        TFX_TRY(sc.tnel.ensure(m.RB));
-        TFX_TRY(sc.toff.ensure(m.RB));
-        TFX_TRY(sc.htot.ensure(std::max(1, nht)));
-        TFX_TRY(sc.htile_off.ensure(std::max(1, nht)));
-        TFX_TRY(sc.gpre.ensure((size_t)nht * m.RB * gpt));
-        hmask0 = reinterpret_cast<unsigned long long *>(m.hmask.p) + (size_t)rb * nht * m.RB * gpt;
-        hrowoff0 = m.hrowoff.p + (size_t)rb * nht * m.RB;
-        hipLaunchKernelGGL(k_hyb_split, dim3(nr), dim3(64), 0, s, d_cols, d_vals, d_nel, d_rowoff, m.iperm.p, m.NH, m.NHpad, m.TC, m.RB,
-                           nht, hmask0, sc.tcols.p, sc.tvals.p, sc.tnel.p, tstride);
-        hipLaunchKernelGGL(k_hyb_scan, dim3(nht), dim3(256), (size_t)nr * sizeof(int32_t), s, hmask0, nr, m.RB, gpt, hrowoff0, sc.gpre.p,
-                           sc.htot.p);
-        TFX_HIP(hipGetLastError());
-        std::vector<int64_t> ho((size_t)nr);
-        for (int r = 0; r < nr; ++r) ho[(size_t)r] = (int64_t)r * tstride;
-        TFX_HIP(hipMemcpyAsync(sc.toff.p, ho.data(), (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, s));
-        TFX_HIP(hipStreamSynchronize(s));
-    }
-    // the sparse tiles: of the whole rows, or of their tail part
-    const int32_t *s_cols = hyb ? sc.tcols.p : d_cols;
-    const float *s_vals = hyb ? sc.tvals.p : d_vals;
-    const int32_t *s_nel = hyb ? sc.tnel.p : d_nel;
-    const int64_t *s_off = hyb ? sc.toff.p : d_rowoff;
+    const int32_t *s_cols = d_cols;
+    const float *s_vals = d_vals;
+    const int32_t *s_nel = d_nel;
+    const int64_t *s_off = d_rowoff;
     TFX_TRY(sc.pos.ensure((size_t)nr * (ntc + 1)));
     TFX_TRY(sc.segoff.ensure((size_t)std::max(1, ntc) * (nr + 1)));
     TFX_TRY(sc.first_ne.ensure(std::max(1, ntc)));
@@ -668,38 +418,7 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
     if (ntc > 0)
         TFX_HIP(hipMemcpy2DAsync(sc.h_segoff_last.data(), sizeof(int32_t), sc.segoff.p + nr, (size_t)(nr + 1) * sizeof(int32_t),
                                  sizeof(int32_t), ntc, hipMemcpyDeviceToHost, s));
-    sc.h_htot.assign((size_t)std::max(1, nht), 0);
-    if (hyb) TFX_HIP(hipMemcpyAsync(sc.h_htot.data(), sc.htot.p, (size_t)nht * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     TFX_HIP(hipStreamSynchronize(s));
-    // bitmap tiles of the row block
-    if (hyb) {
-        sc.h_htile_off.assign((size_t)nht, 0);
-        int64_t hcur = m.h_entries;
-        for (int ht = 0; ht < nht; ++ht) {
-            sc.h_htile_off[(size_t)ht] = hcur;               // (element 0 of the run is the tile's reserved zero)
-            const int32_t cnt = sc.h_htot[(size_t)ht];
-            if (cnt > 0) {
-                TileMeta tm;
-                tm.off = hcur;
-                tm.nchunks = nr;                    // units of a bitmap tile = its rows
-                tm.cnt = cnt;
-                tm.t = ht;
-                tm.rb = rb;
-                tm.kind = 1;
-                tm.aux = rb * nht + ht;
-                m.h_tiles.push_back(tm);
-            }
-            hcur += cnt + 1;
-        }
-        if (hcur > m.h_cap)
-            return fail(TFX_E_STATE, "hybrid matrix: head capacity exceeded (%lld > %lld values) - the column counts underestimated the head",
-                        (long long)hcur, (long long)m.h_cap);
-        TFX_HIP(hipMemcpyAsync(sc.htile_off.p, sc.h_htile_off.data(), (size_t)nht * sizeof(int64_t), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_hyb_scatter, dim3(nr), dim3(64), 0, s, d_cols, d_vals, d_nel, d_rowoff, m.iperm.p, m.NH, m.TC, m.RB, nht,
-                           hmask0, hrowoff0, sc.gpre.p, sc.htile_off.p, m.hvals.p);
-        TFX_HIP(hipGetLastError());
-        m.h_entries = hcur;
-    }
     sc.h_off.resize((size_t)std::max(1, ntc));
     sc.h_nch.resize((size_t)std::max(1, ntc));
     int64_t cur = m.n_entries;
@@ -713,7 +432,7 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
             tm.off = cur;
             tm.nchunks = nch;
             tm.cnt = cnt;
-            tm.t = nht + t;
+            tm.t = t;
             tm.rb = rb;
             tm.kind = 0;
             tm.aux = 0;
@@ -733,7 +452,7 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
         TFX_HIP(hipMemcpyAsync(sc.tile_off.p, sc.h_off.data(), ntc * sizeof(int64_t), hipMemcpyHostToDevice, s));
         TFX_HIP(hipMemcpyAsync(sc.tile_nch.p, sc.h_nch.data(), ntc * sizeof(int32_t), hipMemcpyHostToDevice, s));
         unsigned long long *mask = reinterpret_cast<unsigned long long *>(m.rowmask.p);
-        const int64_t smax = hyb ? std::max<int64_t>(1, maxlen) : maxlen;
+        const int64_t smax = maxlen;
         if (smax > 0)
             hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((smax + 255) / 256), nr), dim3(256), 0, s, s_cols, s_vals,
                                s_nel, s_off, ntc, m.TC, nr, sc.pos.p, sc.segoff.p, sc.tile_off.p, sc.tmp16.p, m.n_entries, mask, m.vals.p);
@@ -757,14 +476,10 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
 // pbase[t] .. pbase[t]+nslots[t]-2 of TC doubles.
 static void build_items(const std::vector<TileMeta> &tiles, bool forward, int group, int64_t target, std::vector<WorkItem> &items,
                         std::vector<int32_t> &order, int &npartial, std::vector<int32_t> &nslots,
-                        std::vector<int32_t> &pbase, int nkeys, int groups_per_tile)
+                        std::vector<int32_t> &pbase, int nkeys)
 {
     auto key_of = [&](const TileMeta &t) { return forward ? t.rb / group : t.t; };
-    // work of a tile in entry-equivalents: sparse - its padded entries; bitmap - its values plus the per-(row, group) overhead of the
-    // mask walk (a group step costs about as much as 8 entries of a sparse chunk)
-    auto size_of = [&](const TileMeta &t) -> int64_t {
-        return t.kind ? (int64_t)t.cnt + (int64_t)t.nchunks * 8 * groups_per_tile : (int64_t)t.nchunks * CHUNK;
-    };
+    auto size_of = [&](const TileMeta &t) -> int64_t { return (int64_t)t.nchunks * CHUNK; };
     std::vector<int32_t> idx(tiles.size());
     std::iota(idx.begin(), idx.end(), 0);
     std::sort(idx.begin(), idx.end(), [&](int a, int b) {
@@ -860,7 +575,7 @@ int matrix_finish(tfx_ctx *ctx)
     if (!m.h_tiles.empty())
         TFX_HIP(hipMemcpyAsync(m.tiles.p, m.h_tiles.data(), m.h_tiles.size() * sizeof(TileMeta), hipMemcpyHostToDevice, s));
     // about 16 work items per CU (measured at the headline size: 8 -> 38.1, 16 -> 37.3, 32 -> 38.0 ms per iteration), never finer than 16 chunks
-    int64_t target = std::max<int64_t>((int64_t)16 * CHUNK, (m.n_entries + m.h_entries) / std::max(1, ctx->num_cu * ctx->items_per_cu));
+    int64_t target = std::max<int64_t>((int64_t)16 * CHUNK, m.n_entries / std::max(1, ctx->num_cu * ctx->items_per_cu));
     // Forward super blocks: one staged x tile serves fwd_group row blocks.  Worth it when the matrix is tall (full-height row
     // blocks, several of them) and big enough that a super block still splits into many items; small systems keep group 1.
     // Two row blocks per group, not four: the x tile (32 KB) plus two row blocks of sums (32 KB) let TWO workgroups of 16 waves share
@@ -868,13 +583,13 @@ int matrix_finish(tfx_ctx *ctx)
     // reach its 6.7 TB/s (tools/read_bw_probe.hip); measured per iteration, groups of 4 / 2 / 1: headline 37.9 / 37.8 / 37.7 ms on one
     // box, 37.7 / 36.3 / 35.9 on another; config 3 (3.4e7 columns, where staging costs most) 43.5 / 42.3 / 42.4 ms.
     m.fwd_group = 1;
-    if (m.RB == RB_MAX && m.nrb >= 2 && m.n_entries + m.h_entries >= (int64_t)64 * target) m.fwd_group = 2;
+    if (m.RB == RB_MAX && m.nrb >= 2 && m.n_entries >= (int64_t)64 * target) m.fwd_group = 2;
     if (ctx->fwd_group_override > 0) m.fwd_group = std::max(1, std::min(ctx->fwd_group_override, FWD_GROUP_MAX));
     const int nsb = (m.nrb + m.fwd_group - 1) / m.fwd_group;
     std::vector<int32_t> fo, ao, fns, ans, fpb, apb;
     int nfp = 0, nap = 0;
-    build_items(m.h_tiles, true, m.fwd_group, target, m.h_fwd, fo, nfp, fns, fpb, nsb, m.TC / HGROUP);
-    build_items(m.h_tiles, false, 1, target, m.h_adj, ao, nap, ans, apb, m.ntc, m.TC / HGROUP);
+    build_items(m.h_tiles, true, m.fwd_group, target, m.h_fwd, fo, nfp, fns, fpb, nsb);
+    build_items(m.h_tiles, false, 1, target, m.h_adj, ao, nap, ans, apb, m.ntc);
     TFX_TRY(m.fwd.alloc(std::max<size_t>(1, m.h_fwd.size())));
     TFX_TRY(m.adj.alloc(std::max<size_t>(1, m.h_adj.size())));
     TFX_TRY(m.fwd_order.alloc(std::max<size_t>(1, fo.size())));
@@ -978,12 +693,9 @@ __device__ __forceinline__ void seg_step(double &sum, int cur)
 // group, not once per tile.  Everything here is wave-uniform (scalar registers).
 struct TileGroup {
     int ng;                          // tiles in the group
-    int total;                       // work units in the group (sparse tiles: chunks; bitmap tiles: rows)
-    int kind;                        // 0 sparse / 1 bitmap: the same for all tiles of a group (they share the column tile)
-    int pre[FWD_GROUP_MAX];          // first group-unit of tile j (INT_MAX beyond ng)
-    int64_t cbase[FWD_GROUP_MAX];    // sparse: first chunk of tile j in the streams (+ cb); bitmap: first row of the item's range in tile j
-    int64_t voff[FWD_GROUP_MAX];     // bitmap: first value of tile j in hvals[]
-    int aux[FWD_GROUP_MAX];          // bitmap: slot of tile j in hmask[] / hrowoff[]
+    int total;                       // chunks in the group
+    int pre[FWD_GROUP_MAX];          // first group-chunk of tile j (INT_MAX beyond ng)
+    int64_t cbase[FWD_GROUP_MAX];    // first chunk of tile j in the streams (+ cb)
     int lrb[FWD_GROUP_MAX];          // row block of tile j relative to the super block
 };
 
@@ -994,11 +706,8 @@ __device__ __forceinline__ void make_group(const WorkItem &it, const int32_t *__
     first = tiles[order[ti]];
     const int sb = first.rb / GROUP;
     g.ng = 1;
-    g.kind = first.kind;
     g.pre[0] = 0;
-    g.cbase[0] = first.kind ? 0 : first.off / CHUNK;
-    g.voff[0] = first.off;
-    g.aux[0] = first.aux;
+    g.cbase[0] = first.off / CHUNK;
     g.lrb[0] = first.rb - sb * GROUP;
     int run = first.nchunks;
     if (it.ce >= 0) {                  // a heavy tile shared by several items: this one takes its units [cb, ce)
@@ -1009,8 +718,6 @@ __device__ __forceinline__ void make_group(const WorkItem &it, const int32_t *__
     for (int j = 1; j < FWD_GROUP_MAX; ++j) {
         g.pre[j] = 0x7fffffff;
         g.cbase[j] = 0;
-        g.voff[j] = 0;
-        g.aux[j] = 0;
         g.lrb[j] = 0;
         if (g.ng == j && ti + j < it.end && it.ce < 0) {
             const TileMeta tm = tiles[order[ti + j]];
@@ -1018,9 +725,7 @@ __device__ __forceinline__ void make_group(const WorkItem &it, const int32_t *__
             if (same) {
                 g.ng = j + 1;
                 g.pre[j] = run;
-                g.cbase[j] = tm.kind ? 0 : tm.off / CHUNK;
-                g.voff[j] = tm.off;
-                g.aux[j] = tm.aux;
+                g.cbase[j] = tm.off / CHUNK;
                 g.lrb[j] = tm.rb - sb * GROUP;
                 run += tm.nchunks;
             }
@@ -1029,7 +734,7 @@ __device__ __forceinline__ void make_group(const WorkItem &it, const int32_t *__
     g.total = run;
 }
 
-// group-unit q -> unit index inside its tile's streams (sparse: chunk; bitmap: row) and the tile's row block in the super block
+// group-chunk q -> chunk index in the streams and the tile's row block in the super block
 __device__ __forceinline__ int64_t locate_chunk(const TileGroup &g, int q, int &lrb)
 {
     int64_t c = g.cbase[0] + q;
@@ -1040,54 +745,10 @@ __device__ __forceinline__ int64_t locate_chunk(const TileGroup &g, int q, int &
     return c;
 }
 
-// ... and for a bitmap tile also its slot and value offset
-__device__ __forceinline__ int locate_row(const TileGroup &g, int q, int &lrb, int &aux, int64_t &voff)
-{
-    int r = (int)g.cbase[0] + q;
-    lrb = g.lrb[0];
-    aux = g.aux[0];
-    voff = g.voff[0];
-#pragma unroll
-    for (int j = 1; j < FWD_GROUP_MAX; ++j)
-        if (q >= g.pre[j]) { r = (int)g.cbase[j] + (q - g.pre[j]); lrb = g.lrb[j]; aux = g.aux[j]; voff = g.voff[j]; }
-    return r;
-}
-
-// Bitmap tile, one row: the row's group masks (lane g <- mask of group g), the exclusive prefix of their popcounts (where each
-// group's values start in the row's value run).
-__device__ __forceinline__ void load_row_masks(const uint64_t *__restrict__ hmask, int aux, int r, int RB, int gpt, int lane,
-                                               uint64_t &m, int &pre)
-{
-    m = lane < gpt ? hmask[((int64_t)aux * RB + r) * gpt + lane] : 0ull;
-    const int pc = __popcll(m);
-    int x = pc;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    pre = x - pc;
-}
-
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane)
-{
-    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane), hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-
 // forward: one workgroup = a run of tiles of one super block (GROUP row blocks), ordered by column tile so that a staged x tile
 // serves all row blocks of the group; partial[item][row of the super block] = sum over the run.
 // WAVES = 16: the product kernel; WAVES = 1: the deterministic debug variant (a single wave issues its LDS atomics in program
 // order, and no other wave touches the workgroup's sums).
-constexpr int HB = 16;      // bitmap tiles: groups per batch of independent value loads
-
 // pointers of the matrix streams (passed by value to the product kernels)
 struct MatPtrs {
     const WorkItem *items;
@@ -1097,59 +758,18 @@ struct MatPtrs {
     const uint64_t *rowmask;
     const float *vals;
     const int32_t *chunk_row0;
-    const uint64_t *hmask;      // bitmap (head) tiles
-    const int32_t *hrowoff;
-    const float *hvals;
 };
-
-// ---- bitmap tiles: one (row, tile) unit -----------------------------------------------------------------------------------
-// The row's GPT group masks arrive as ONE coalesced vector load (lane g <- mask of group g), requested one unit ahead by the
-// caller.  Every group's mask is then broadcast to scalars (readlane), the running value offset lives on the scalar unit
-// (s_bcnt1), the lane's value index comes straight out of mbcnt, and ALL value loads of the unit are issued before the first is
-// used (a lane whose bit is clear loads a neighbouring value of the same run and drops it): one memory latency per unit.
-template <int GPT>
-__device__ __forceinline__ void bitmap_unit_loads(uint64_t m, const float *__restrict__ tvals, int vbase, float (&v)[GPT])
-{
-    // tvals = the tile's value run, whose element 0 is a reserved 0.0f; vbase = index of the row's first value in it.  A lane whose
-    // bit is clear loads that zero, so the consumers need no mask at all (v * x = 0, v * u = 0)
-    int og = vbase;
-#pragma unroll
-    for (int g = 0; g < GPT; ++g) {
-        const uint64_t mg = readlane_u64(m, g);
-        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mg, og));
-        const int idx = __builtin_amdgcn_inverse_ballot_w64(mg) ? rank : 0;
-        v[g] = __builtin_nontemporal_load(tvals + idx);
-        og += __popcll(mg);
-    }
-}
-
-template <int GPT>
-__device__ __forceinline__ double bitmap_unit_dot(const float (&v)[GPT], const double *__restrict__ xs, int lane)
-{
-    double acc = 0.0;
-#pragma unroll
-    for (int g = 0; g < GPT; ++g) acc = fma((double)v[g], xs[g * HGROUP + lane], acc);
-    return acc;
-}
-
-template <int GPT>
-__device__ __forceinline__ void bitmap_unit_scatter(const float (&v)[GPT], double ur, double *__restrict__ acc, int lane)
-{
-#pragma unroll
-    for (int g = 0; g < GPT; ++g) atomicAdd(&acc[g * HGROUP + lane], (double)v[g] * ur);     // lanes with a clear bit add 0
-}
 
 // (the streams are separate `const __restrict__` kernel arguments, not members of a struct: only then does the compiler know that
 // nothing in the kernel writes them and reads the wave-uniform ones - masks, offsets, tile records - with scalar loads)
 #define MAT_PARAMS                                                                                                         \
     const WorkItem *__restrict__ items, const int32_t *__restrict__ order, const TileMeta *__restrict__ tiles,             \
     const uint32_t *__restrict__ slots, const uint64_t *__restrict__ rowmask, const float *__restrict__ vals,              \
-    const int32_t *__restrict__ chunk_row0, const uint64_t *__restrict__ hmask, const int32_t *__restrict__ hrowoff,       \
-    const float *__restrict__ hvals
-#define MAT_ARGS(mp) (mp).items, (mp).order, (mp).tiles, (mp).slots, (mp).rowmask, (mp).vals, (mp).chunk_row0, (mp).hmask, (mp).hrowoff, (mp).hvals
+    const int32_t *__restrict__ chunk_row0
+#define MAT_ARGS(mp) (mp).items, (mp).order, (mp).tiles, (mp).slots, (mp).rowmask, (mp).vals, (mp).chunk_row0
 
-template <int WAVES, bool HYB>
-__global__ __launch_bounds__(WAVES * 64, (WAVES == 16 && !HYB) ? 8 : 1) void k_spmv_fwd(MAT_PARAMS, const double *__restrict__ x, double *__restrict__ partial,
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_fwd(MAT_PARAMS, const double *__restrict__ x, double *__restrict__ partial,
                                                            int64_t ncols, int TC, int RB, int GROUP)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1168,80 +788,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 16 && !HYB) ? 8 : 1) void k_s
         ti += g.ng;
         __syncthreads();
         {
-            // sparse tiles read x at the columns' (bank-folded) slots, bitmap tiles at the columns themselves (lane = column)
+            // x is read at the columns' (bank-folded) slots
             const int64_t col0 = (int64_t)tm.t * TC;
             const int ncol = (int)min((int64_t)TC, ncols - col0);
-            if (HYB && g.kind) {
-                for (int i = tid; i < TC; i += THREADS) xs[i] = (i < ncol) ? x[col0 + i] : 0.0;
-            } else {
-                for (int i = tid; i < TC; i += THREADS) xs[col_slot(i)] = (i < ncol) ? x[col0 + i] : 0.0;
-            }
+            for (int i = tid; i < TC; i += THREADS) xs[col_slot(i)] = (i < ncol) ? x[col0 + i] : 0.0;
         }
         __syncthreads();
-        if (HYB && g.kind) {
-            // bitmap tiles: a wave takes a row; lane = column inside the group; the row's sum is one wave reduction per tile
-            const int gpt = TC / HGROUP;
-            if (gpt == 64) {
-                // full-width tiles (every large matrix): the unit-at-a-time scheme above, masks of the next unit requested first
-                int lrb, aux;
-                int64_t voff;
-                int q = wave;
-                uint64_t m_next = 0;
-                if (q < g.total) {
-                    const int r = locate_row(g, q, lrb, aux, voff);
-                    m_next = hmask[((int64_t)aux * RB + r) * 64 + lane];
-                }
-                for (; q < g.total; q += WAVES) {
-                    const int r = locate_row(g, q, lrb, aux, voff);
-                    const uint64_t m = m_next;
-                    const int vbase = 1 + hrowoff[(int64_t)aux * RB + r];
-                    if (q + WAVES < g.total) {
-                        int lrb2, aux2;
-                        int64_t voff2;
-                        const int r2 = locate_row(g, q + WAVES, lrb2, aux2, voff2);
-                        m_next = hmask[((int64_t)aux2 * RB + r2) * 64 + lane];
-                    }
-                    float v[64];
-                    bitmap_unit_loads<64>(m, hvals + voff, vbase, v);
-                    const double tot = wave_sum(bitmap_unit_dot<64>(v, xs, lane));
-                    if (lane == 0 && tot != 0.0) atomicAdd(&outs[lrb * RB + r], tot);
-                }
-                continue;
-            }
-            for (int q = wave; q < g.total; q += WAVES) {
-                int lrb, aux;
-                int64_t voff;
-                const int r = locate_row(g, q, lrb, aux, voff);
-                // narrower tiles (small matrices): the row's group masks are wave-uniform: scalar loads, the running value offset `og` on the scalar unit
-                // (s_bcnt1), and the lane's value index straight out of mbcnt with og as its start value.  Groups in batches of
-                // HB: the HB value loads of a batch are independent and all issued before the first use (a lane whose bit is clear
-                // loads a neighbouring value of the same run and drops it) - one memory latency per batch, not per group.
-                const uint64_t *mrow = hmask + ((int64_t)aux * RB + r) * gpt;
-                const float *vb = hvals + voff + 1 + hrowoff[(int64_t)aux * RB + r];        // (+ 1: the tile's reserved zero)
-                double acc = 0.0;
-                int og = 0;
-                for (int g0 = 0; g0 < gpt; g0 += HB) {
-                    uint64_t mg[HB];
-                    float v[HB];
-#pragma unroll
-                    for (int k = 0; k < HB; ++k) mg[k] = g0 + k < gpt ? mrow[g0 + k] : 0ull;
-#pragma unroll
-                    for (int k = 0; k < HB; ++k) {
-                        const int idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(mg[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mg[k], og));
-                        v[k] = __builtin_nontemporal_load(vb + idx);
-                        og += __popcll(mg[k]);
-                    }
-#pragma unroll
-                    for (int k = 0; k < HB; ++k) {
-                        const float t = __builtin_amdgcn_inverse_ballot_w64(mg[k]) ? v[k] : 0.0f;
-                        acc = fma((double)t, xs[(g0 + k) * HGROUP + lane], acc);
-                    }
-                }
-                const double tot = wave_sum(acc);
-                if (lane == 0 && tot != 0.0) atomicAdd(&outs[lrb * RB + r], tot);
-            }
-            continue;
-        }
         for (int q = wave; q < g.total; q += WAVES) {
             int lrb;
             const int64_t ch = locate_chunk(g, q, lrb);
@@ -1321,8 +873,8 @@ __global__ __launch_bounds__(FR_ROWS * FR_GROUPS) void k_fwd_reduce(const double
 }
 
 // adjoint: one workgroup = a run of tiles of one column tile; slot 0 adds into y, the others write partials.
-template <int WAVES, bool HYB>
-__global__ __launch_bounds__(WAVES * 64, (WAVES == 16 && !HYB) ? 8 : 1) void k_spmv_adj(MAT_PARAMS, const double *__restrict__ u, double *__restrict__ y,
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_adj(MAT_PARAMS, const double *__restrict__ u, double *__restrict__ y,
                                                            double *__restrict__ partial, int64_t nrows, int64_t ncols,
                                                            int TC, int RB, int GROUP)
 {
@@ -1333,7 +885,6 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 16 && !HYB) ? 8 : 1) void k_s
     const WorkItem it = items[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < TC; i += THREADS) acc[i] = 0.0;
-    bool bitmap = false;          // an item's tiles share the column tile, hence the kind
     int ti = it.begin;
     while (ti < it.end) {
         TileGroup g;
@@ -1352,64 +903,6 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 16 && !HYB) ? 8 : 1) void k_s
             for (int i = lo + tid; i < hi; i += THREADS) us[i] = (row0 + i < nrows) ? u[row0 + i] : 0.0;
         }
         __syncthreads();
-        if (HYB && g.kind) {
-            // bitmap tiles: a wave takes a row; lane = column inside the group -> the LDS adds of one instruction go to 64 consecutive
-            // column sums (no bank conflicts, no slot fold)
-            bitmap = true;
-            const int gpt = TC / HGROUP;
-            if (gpt == 64) {                      // full-width tiles: unit-at-a-time scheme of the forward kernel
-                int lrb, aux;
-                int64_t voff;
-                int q = wave;
-                uint64_t m_next = 0;
-                if (q < g.total) {
-                    const int r = locate_row(g, q, lrb, aux, voff);
-                    m_next = hmask[((int64_t)aux * RB + r) * 64 + lane];
-                }
-                for (; q < g.total; q += WAVES) {
-                    const int r = locate_row(g, q, lrb, aux, voff);
-                    const uint64_t m = m_next;
-                    const int vbase = 1 + hrowoff[(int64_t)aux * RB + r];
-                    const double ur = us[lrb * RB + r];
-                    if (q + WAVES < g.total) {
-                        int lrb2, aux2;
-                        int64_t voff2;
-                        const int r2 = locate_row(g, q + WAVES, lrb2, aux2, voff2);
-                        m_next = hmask[((int64_t)aux2 * RB + r2) * 64 + lane];
-                    }
-                    float v[64];
-                    bitmap_unit_loads<64>(m, hvals + voff, vbase, v);
-                    bitmap_unit_scatter<64>(v, ur, acc, lane);
-                }
-                continue;
-            }
-            for (int q = wave; q < g.total; q += WAVES) {
-                int lrb, aux;
-                int64_t voff;
-                const int r = locate_row(g, q, lrb, aux, voff);
-                const uint64_t *mrow = hmask + ((int64_t)aux * RB + r) * gpt;       // scalar masks and offsets as in the forward kernel
-                const float *vb = hvals + voff + 1 + hrowoff[(int64_t)aux * RB + r];
-                const double ur = us[lrb * RB + r];
-                if (ur == 0.0) continue;
-                int og = 0;
-                for (int g0 = 0; g0 < gpt; g0 += HB) {
-                    uint64_t mg[HB];
-                    float v[HB];
-#pragma unroll
-                    for (int k = 0; k < HB; ++k) mg[k] = g0 + k < gpt ? mrow[g0 + k] : 0ull;
-#pragma unroll
-                    for (int k = 0; k < HB; ++k) {
-                        const int idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(mg[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mg[k], og));
-                        v[k] = __builtin_nontemporal_load(vb + idx);
-                        og += __popcll(mg[k]);
-                    }
-#pragma unroll
-                    for (int k = 0; k < HB; ++k)
-                        if (__builtin_amdgcn_inverse_ballot_w64(mg[k])) atomicAdd(&acc[(g0 + k) * HGROUP + lane], (double)v[k] * ur);
-                }
-            }
-            continue;
-        }
         for (int q = wave; q < g.total; q += WAVES) {
             int lrb;
             const int64_t ch = locate_chunk(g, q, lrb);
@@ -1433,10 +926,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 16 && !HYB) ? 8 : 1) void k_s
     const int64_t col0 = (int64_t)it.key * TC;
     const int ncol = (int)min((int64_t)TC, ncols - col0);
     if (it.slot == 0) {
-        for (int i = tid; i < ncol; i += THREADS) y[col0 + i] += acc[bitmap ? i : col_slot(i)];
+        for (int i = tid; i < ncol; i += THREADS) y[col0 + i] += acc[col_slot(i)];
     } else {
         double *dst = partial + (int64_t)it.pidx * TC;
-        for (int i = tid; i < TC; i += THREADS) dst[i] = acc[bitmap ? i : col_slot(i)];
+        for (int i = tid; i < TC; i += THREADS) dst[i] = acc[col_slot(i)];
     }
 }
 
@@ -1444,26 +937,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 16 && !HYB) ? 8 : 1) void k_s
 // (sensitivity_gravmag.F90:834-843: the file holds the unscaled kernel, the matrix problem_weight * data_weight(row) times it).
 __global__ __launch_bounds__(256) void k_scale_rows(const TileMeta *__restrict__ tiles, int ntiles, const uint64_t *__restrict__ rowmask,
                                                      float *__restrict__ vals, const int32_t *__restrict__ chunk_row0,
-                                                     const uint64_t *__restrict__ hmask, const int32_t *__restrict__ hrowoff,
-                                                     float *__restrict__ hvals, const float *__restrict__ scale, int64_t nrows, int RB, int TC)
+                                                     const float *__restrict__ scale, int64_t nrows, int RB)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int ti = blockIdx.y; ti < ntiles; ti += gridDim.y) {
         const TileMeta tm = tiles[ti];
         const int64_t row0 = (int64_t)tm.rb * RB;
-        if (tm.kind) {                                   // bitmap tile: the values of a row are one contiguous run
-            const int gpt = TC / HGROUP;
-            for (int r = blockIdx.x * 4 + wave; r < tm.nchunks; r += gridDim.x * 4) {
-                uint64_t m;
-                int pre;
-                load_row_masks(hmask, tm.aux, r, RB, gpt, lane, m, pre);
-                const int total = __builtin_amdgcn_readlane(pre + __popcll(m), 63);
-                float *vb = hvals + tm.off + 1 + hrowoff[(int64_t)tm.aux * RB + r];
-                const float f = scale[row0 + r];
-                for (int i = lane; i < total; i += 64) vb[i] = vb[i] * f;
-            }
-            continue;
-        }
         const int64_t cbase = tm.off / CHUNK;
         for (int c = blockIdx.x * 4 + wave; c < tm.nchunks; c += gridDim.x * 4) {
             ChunkMasks mk;
@@ -1495,13 +974,18 @@ __global__ void k_adj_reduce(const double *__restrict__ partial, const int32_t *
     y[c] = s;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: the bookkeeping lives in the ctx (one ctx = one device),
-// not in a process-wide static, so a second ctx on another device registers the kernels for itself.
+// hipFuncAttributeMaxDynamicSharedMemorySize applies per (kernel, device) for the whole process, so the bookkeeping is process-wide and
+// keyed by (device, kernel variant): it holds the running maximum, and the attribute is only ever raised - a second ctx on the same
+// device with smaller tiles can not lower what an older ctx relies on, and another device registers for itself.
+constexpr int LDS_MAX_DEVICES = 64, LDS_VARIANTS = 4;
+static size_t g_lds_attr[LDS_MAX_DEVICES][LDS_VARIANTS];
 static int set_lds_limit(tfx_ctx *ctx, int which, const void *fn, size_t bytes)
 {
-    if (bytes <= ctx->lds_attr[which]) return 0;
+    const int dev = ctx->device;
+    if (dev < 0 || dev >= LDS_MAX_DEVICES) return fail(TFX_E_ARG, "device %d out of range", dev);
+    if (bytes <= g_lds_attr[dev][which]) return 0;
     TFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    ctx->lds_attr[which] = bytes;
+    g_lds_attr[dev][which] = bytes;
     return 0;
 }
 
@@ -1597,9 +1081,6 @@ static MatPtrs mat_ptrs(const TiledMatrix &m, bool forward)
     p.rowmask = m.rowmask.p;
     p.vals = m.vals.p;
     p.chunk_row0 = m.chunk_row0.p;
-    p.hmask = m.hmask.p;
-    p.hrowoff = m.hrowoff.p;
-    p.hvals = m.hvals.p;
     return p;
 }
 
@@ -1607,8 +1088,8 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
 {
     if (!m.valid) return fail(TFX_E_STATE, "spmv: no matrix");
     const bool prof = (&m == &ctx->mat || &m == &ctx->mat2);
+    hipStream_t s = ctx->stream;
     if (m.is_dense) {
-        hipStream_t s = ctx->stream;
         const int nchunks = (int)((m.ncols + DN_CHUNK - 1) / DN_CHUNK);
         if (prof) prof_begin(ctx);
         hipLaunchKernelGGL(k_dense_fwd, dim3(nchunks), dim3(DN_THREADS), 0, s, m.dense.p, m.ld, m.nrows, m.ncols, d_x, m.dense_partial.p);
@@ -1618,32 +1099,20 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
         TFX_HIP(hipGetLastError());
         return 0;
     }
-    hipStream_t s = ctx->stream;
     const int SB = m.fwd_group * m.RB;
     const size_t lds = (size_t)(m.TC + SB) * sizeof(double);
-    // hybrid layout: the kernels work in the permuted column space
-    const double *xk = d_x;
-    if (m.NH > 0) {
-        hipLaunchKernelGGL(k_perm_gather, dim3((unsigned)std::min<int64_t>(4096, (m.ncols_p + 255) / 256)), dim3(256), 0, s, d_x, m.perm.p,
-                           m.ncols_p, m.xp.p);
-        xk = m.xp.p;
-    }
     if (!m.h_fwd.empty()) {
         const MatPtrs mp = mat_ptrs(m, true);
         if (prof) prof_begin(ctx);
-        // (HYB = false: the purely sparse layout - every default matrix - compiles without the bitmap path's 64-value buffers)
-#define LAUNCH_FWD(W, H, IDX, THREADS)                                                                                                       \
-        {                                                                                                                                    \
-            TFX_TRY(set_lds_limit(ctx, IDX, (const void *)k_spmv_fwd<W, H>, lds));                                                           \
-            hipLaunchKernelGGL((k_spmv_fwd<W, H>), dim3((unsigned)m.h_fwd.size()), dim3(THREADS), lds, s, MAT_ARGS(mp), xk, m.fwd_partial.p, \
-                               m.ncols_p, m.TC, m.RB, m.fwd_group);                                                                          \
-        }
         if (ctx->deterministic) {
-            if (m.NH > 0) LAUNCH_FWD(1, true, 2, 64) else LAUNCH_FWD(1, false, 6, 64)
+            TFX_TRY(set_lds_limit(ctx, 1, (const void *)k_spmv_fwd<1>, lds));
+            hipLaunchKernelGGL((k_spmv_fwd<1>), dim3((unsigned)m.h_fwd.size()), dim3(64), lds, s, MAT_ARGS(mp), d_x, m.fwd_partial.p,
+                               m.ncols, m.TC, m.RB, m.fwd_group);
         } else {
-            if (m.NH > 0) LAUNCH_FWD(16, true, 0, SPMV_THREADS) else LAUNCH_FWD(16, false, 4, SPMV_THREADS)
+            TFX_TRY(set_lds_limit(ctx, 0, (const void *)k_spmv_fwd<16>, lds));
+            hipLaunchKernelGGL((k_spmv_fwd<16>), dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), d_x,
+                               m.fwd_partial.p, m.ncols, m.TC, m.RB, m.fwd_group);
         }
-#undef LAUNCH_FWD
         if (prof) prof_end(ctx, 0);
         TFX_HIP(hipGetLastError());
     }
@@ -1657,9 +1126,9 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
 {
     if (!m.valid) return fail(TFX_E_STATE, "spmtv: no matrix");
     const bool prof = (&m == &ctx->mat || &m == &ctx->mat2);
+    hipStream_t s = ctx->stream;
+    if (!add) TFX_HIP(hipMemsetAsync(d_b, 0, (size_t)m.ncols * sizeof(double), s));
     if (m.is_dense) {
-        hipStream_t s = ctx->stream;
-        if (!add) TFX_HIP(hipMemsetAsync(d_b, 0, (size_t)m.ncols * sizeof(double), s));
         const int nchunks = (int)((m.ncols + DN_CHUNK - 1) / DN_CHUNK);
         if (prof) prof_begin(ctx);
         hipLaunchKernelGGL(k_dense_adj, dim3(nchunks), dim3(DN_THREADS), 0, s, m.dense.p, m.ld, m.nrows, m.ncols, d_x, d_b);
@@ -1667,40 +1136,24 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
         TFX_HIP(hipGetLastError());
         return 0;
     }
-    hipStream_t s = ctx->stream;
     const size_t lds = (size_t)(m.TC + m.fwd_group * m.RB) * sizeof(double);
-    if (!add) TFX_HIP(hipMemsetAsync(d_b, 0, (size_t)m.ncols * sizeof(double), s));
-    // hybrid layout: the column sums come out in the permuted space and are added to b through the permutation
-    double *yk = d_b;
-    if (m.NH > 0) {
-        yk = m.yp.p;
-        TFX_HIP(hipMemsetAsync(yk, 0, (size_t)m.ncols_p * sizeof(double), s));
-    }
     if (!m.h_adj.empty()) {
         const MatPtrs mp = mat_ptrs(m, false);
         if (prof) prof_begin(ctx);
-#define LAUNCH_ADJ(W, H, IDX, THREADS)                                                                                                       \
-        {                                                                                                                                    \
-            TFX_TRY(set_lds_limit(ctx, IDX, (const void *)k_spmv_adj<W, H>, lds));                                                           \
-            hipLaunchKernelGGL((k_spmv_adj<W, H>), dim3((unsigned)m.h_adj.size()), dim3(THREADS), lds, s, MAT_ARGS(mp), d_x, yk,             \
-                               m.adj_partial.p, m.nrows, m.ncols_p, m.TC, m.RB, m.fwd_group);                                                \
-        }
         if (ctx->deterministic) {
-            if (m.NH > 0) LAUNCH_ADJ(1, true, 3, 64) else LAUNCH_ADJ(1, false, 7, 64)
+            TFX_TRY(set_lds_limit(ctx, 3, (const void *)k_spmv_adj<1>, lds));
+            hipLaunchKernelGGL((k_spmv_adj<1>), dim3((unsigned)m.h_adj.size()), dim3(64), lds, s, MAT_ARGS(mp), d_x, d_b, m.adj_partial.p,
+                               m.nrows, m.ncols, m.TC, m.RB, m.fwd_group);
         } else {
-            if (m.NH > 0) LAUNCH_ADJ(16, true, 1, SPMV_THREADS) else LAUNCH_ADJ(16, false, 5, SPMV_THREADS)
+            TFX_TRY(set_lds_limit(ctx, 2, (const void *)k_spmv_adj<16>, lds));
+            hipLaunchKernelGGL((k_spmv_adj<16>), dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), d_x, d_b,
+                               m.adj_partial.p, m.nrows, m.ncols, m.TC, m.RB, m.fwd_group);
         }
-#undef LAUNCH_ADJ
         if (prof) prof_end(ctx, 1);
         TFX_HIP(hipGetLastError());
         if (m.adj_has_partials)
-            hipLaunchKernelGGL(k_adj_reduce, dim3((unsigned)((m.ncols_p + 255) / 256)), dim3(256), 0, s, m.adj_partial.p,
-                               m.adj_nslots.p, m.adj_pbase.p, m.TC, m.ncols_p, yk);
-        TFX_HIP(hipGetLastError());
-    }
-    if (m.NH > 0) {
-        hipLaunchKernelGGL(k_perm_scatter_add, dim3((unsigned)std::min<int64_t>(4096, (m.ncols_p + 255) / 256)), dim3(256), 0, s, yk,
-                           m.perm.p, m.ncols_p, d_b);
+            hipLaunchKernelGGL(k_adj_reduce, dim3((unsigned)((m.ncols + 255) / 256)), dim3(256), 0, s, m.adj_partial.p, m.adj_nslots.p,
+                               m.adj_pbase.p, m.TC, m.ncols, d_b);
         TFX_HIP(hipGetLastError());
     }
     return 0;
@@ -1721,7 +1174,7 @@ int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale)
     const int nt = (int)m.h_tiles.size();
     if (nt == 0) return 0;
     hipLaunchKernelGGL(k_scale_rows, dim3(8, (unsigned)std::min(nt, 32768)), dim3(256), 0, s, m.tiles.p, nt, m.rowmask.p, m.vals.p,
-                       m.chunk_row0.p, m.hmask.p, m.hrowoff.p, m.hvals.p, d_scale, m.nrows, m.RB, m.TC);
+                       m.chunk_row0.p, d_scale, m.nrows, m.RB);
     TFX_HIP(hipGetLastError());
     return 0;
 }

@@ -317,9 +317,7 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
         if b > a:
             counts[a:b] = gathered[r][:b - a]
     assert int(counts[:, rank].sum()) == int(nnz[rank]), (counts[:, rank].sum(), nnz[rank])
-    # 4. relayout, matrix row block by row block.  The all-reduced counts of this rank's cells tell the library which columns are
-    # densely populated (hybrid layout); the histogram counts the lines of every model component per cell
-    ctx.matrix_set_column_counts(np.tile(hist[c0:c1] // nmodel_components, nmodel_components), nrows)
+    # 4. relayout, matrix row block by row block
     ctx.matrix_begin(nrows, nmodel_components * (c1 - c0), int(nnz[rank]))
     owner_of_row = np.searchsorted(np.asarray(m0[1:]), np.arange(0, nrows, RB), side="right")
     for b in range((nrows + RB - 1) // RB):

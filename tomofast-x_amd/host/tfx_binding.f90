@@ -379,14 +379,6 @@ module tfx_binding
       real(c_double), intent(in) :: scale(*)
     end function
 
-    ! per-column entry counts of the matrix the next tfx_matrix_begin assembles (hybrid layout: dense columns as bitmaps)
-    integer(c_int) function tfx_matrix_set_column_counts(ctx, counts, ncols, nrows_counted) bind(C, name="tfx_matrix_set_column_counts")
-      import :: c_int, c_ptr, c_int32_t, c_int64_t
-      type(c_ptr), value :: ctx
-      integer(c_int32_t), intent(in) :: counts(*)
-      integer(c_int64_t), value :: ncols, nrows_counted
-    end function
-
     integer(c_int) function tfx_matrix_free(ctx) bind(C, name="tfx_matrix_free")
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx

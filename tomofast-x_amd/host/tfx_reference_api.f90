@@ -853,7 +853,7 @@ contains
     integer :: ndat, row_a, row_b, nrl, nblk, b, ga, gb, o, d, rr, base, rem, nloc, ndc, ndblk
     integer, allocatable :: rows_at(:), row_displs(:), blk_owner(:)
     integer(c_int64_t), allocatable :: bounds(:)
-    integer(c_int32_t), allocatable, target :: cnt_loc(:, :), cnt_all(:, :), nel_blk(:), colcnt(:)
+    integer(c_int32_t), allocatable, target :: cnt_loc(:, :), cnt_all(:, :), nel_blk(:)
     integer(c_int64_t) :: n_in, n_out, got, mine
     type(c_ptr) :: dcols, dvals, scols, svals
     ! matrix rows: ndc per datum (row = (i-1)*ndc + d); a rank's data range is whole blocks of ROW_BLOCK data, so its matrix rows
@@ -890,14 +890,6 @@ contains
     do rr = 1, ndat
       mine = mine + cnt_all(myrank_ + 1, rr)
     enddo
-    ! the all-reduced per-cell counts of my cells: which of my columns are densely populated (hybrid layout of the device matrix)
-    allocate(colcnt(max(1, k%ncm * nloc)))
-    do d = 1, k%ncm
-      colcnt((d - 1) * nloc + 1:d * nloc) = k%nnz_hist(bounds(myrank_ + 1) + 1:bounds(myrank_ + 2)) / k%ncm
-    enddo
-    call api_check(tfx_matrix_set_column_counts(api_ctx, colcnt, int(k%ncm * nloc, c_int64_t), int(ndat, c_int64_t)), &
-                   'tfx_matrix_set_column_counts', myrank_)
-    deallocate(colcnt)
     call api_check(tfx_matrix_begin(api_ctx, int(ndat, c_int64_t), int(k%ncm * nloc, c_int64_t), max(mine, 1_c_int64_t)), 'tfx_matrix_begin', myrank_)
     do b = 1, nblk
       ga = (b - 1) * ROW_BLOCK

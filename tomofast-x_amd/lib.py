@@ -27,7 +27,7 @@ SYMBOLS = [
     "tfx_build_kernel_grav", "tfx_build_kernel_mag", "tfx_build_kernel", "tfx_select_problem",
     "tfx_matrix_upload_csr", "tfx_matrix_info", "tfx_matrix_download_csr", "tfx_matrix_free", "tfx_matrix_scale_rows",
     "tfx_cons_upload_csr", "tfx_cons_clear", "tfx_rowstore_build", "tfx_rowstore_build_ex", "tfx_rowstore_build_comp", "tfx_rowstore_counts", "tfx_rowstore_pack",
-    "tfx_rowstore_free", "tfx_matrix_set_column_counts", "tfx_matrix_begin", "tfx_matrix_append_rows", "tfx_matrix_finish",
+    "tfx_rowstore_free", "tfx_matrix_begin", "tfx_matrix_append_rows", "tfx_matrix_finish",
     "tfx_partition_columns", "tfx_spmv", "tfx_spmtv", "tfx_lsqr_solve", "tfx_lsqr_begin", "tfx_lsqr_iterate",
     "tfx_lsqr_end", "tfx_lsqr_set_wavelet_domain", "tfx_lsqr_set_partition", "tfx_calc_data", "tfx_timer_start", "tfx_timer_stop_ms", "tfx_profile_enable", "tfx_profile_get",
     "tfx_debug_set",

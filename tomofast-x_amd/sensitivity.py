@@ -320,15 +320,6 @@ class Context:
     def rowstore_free(self):
         check(self._lib.tfx_rowstore_free(self._h))
 
-    def matrix_set_column_counts(self, counts, nrows_counted):
-        """Entries every local column of the matrix about to be assembled will receive (over nrows_counted rows): lets the library
-        store the densely populated columns as per-row bitmaps (hybrid layout).  None clears."""
-        if counts is None:
-            check(self._lib.tfx_matrix_set_column_counts(self._h, None, C.c_int64(0), C.c_int64(0)))
-            return
-        c = np.ascontiguousarray(counts, np.int32)
-        check(self._lib.tfx_matrix_set_column_counts(self._h, ptr(c), C.c_int64(c.size), C.c_int64(nrows_counted)))
-
     def matrix_begin(self, nrows, ncols, nnz_upper):
         check(self._lib.tfx_matrix_begin(self._h, C.c_int64(nrows), C.c_int64(ncols), C.c_int64(nnz_upper)))
 

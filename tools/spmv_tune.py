@@ -27,18 +27,23 @@ cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
 d = np.random.default_rng(0).standard_normal(xs.size)
 diag = [np.full(N, np.float32(1e-7), np.float32)]
 rhs = [np.zeros(N)]
-settings = [(4, 16)]
+settings = [(0, 16)]
 if os.environ.get("TFX_TUNE_SETTINGS"):
     settings = [tuple(int(v) for v in s.split(":")) for s in os.environ["TFX_TUNE_SETTINGS"].split(",")]
-taus = [int(v) for v in os.environ.get("TFX_TUNE_TAUS", "250").split(",")]       # 0 = purely sparse
-for tau in taus:
-    ctx.debug_set("hybrid", 1 if tau > 0 else 0)
-    if tau > 0:
-        ctx.debug_set("hybrid_tau_permille", tau)
+# TFX_TUNE_KEYS="key=v1:v2,key2=v" : extra debug keys applied before each (re)build, one build per combination of the FIRST key's values
+build_keys = {}
+if os.environ.get("TFX_TUNE_KEYS"):
+    for kv in os.environ["TFX_TUNE_KEYS"].split(","):
+        k, v = kv.split("=")
+        build_keys[k] = [int(x) for x in v.split(":")]
+first = next(iter(build_keys), None)
+for val in (build_keys[first] if first else [None]):
+    for k, vs in build_keys.items():
+        ctx.debug_set(k, val if k == first else vs[0])
     t0 = time.time()
     res = ctx.calculate_sensit(xs, ys, zs, cw, w["ctype"], w["rate"])
-    print("tau %d: build %.1f s nnz %d head columns %d head entries %.1f %% device bytes %.2f GB" % (tau, time.time() - t0, res["nnz"],
-          ctx.debug_set("head_columns"), 0.1 * ctx.debug_set("head_entries_permille"), ctx.matrix_info()["device_bytes"] / 1e9), flush=True)
+    print("%s=%s: build %.1f s nnz %d device bytes %.2f GB" % (first, val, time.time() - t0, res["nnz"],
+          ctx.matrix_info()["device_bytes"] / 1e9), flush=True)
     for group, ipc in settings:
         ctx.debug_set("fwd_group", group)
         ctx.debug_set("items_per_cu", ipc)
@@ -52,8 +57,8 @@ for tau in taus:
         f, a = ctx.profile_get(0), ctx.profile_get(1)
         ctx.profile_enable(False)
         ctx.lsqr_end()
-        rec = dict(tau=tau, group=group, items_per_cu=ipc, ms_per_iter=ms / steps, fwd_ms=f[0] / max(f[1], 1), adj_ms=a[0] / max(a[1], 1),
-                   device_bytes=ctx.matrix_info()["device_bytes"])
+        rec = dict(key=first, value=val, group=group, items_per_cu=ipc, ms_per_iter=ms / steps, fwd_ms=f[0] / max(f[1], 1),
+                   adj_ms=a[0] / max(a[1], 1), device_bytes=ctx.matrix_info()["device_bytes"])
         print(json.dumps(rec), flush=True)
     ctx.matrix_free()
 ctx.close()
