@@ -8,11 +8,13 @@ A "step" is one LSQR iteration (the loop body of lsqr_solve_sensit, src/inversio
 wavelet-compressed sensitivity matrix, everything resident in HBM.  Setup (not timed, reported separately as build
 cell.obs/s): prism rows -> column weights -> wavelet -> threshold -> tiled matrix, all on the GPU.
 Strong scaling: the same problem on N GPUs, column-partitioned like the reference's MPI decomposition, two RCCL
-all-reduces per iteration issued by libtfx.so itself on its stream (tfx_comm_init_rccl; torch.distributed only starts the
-ranks and carries the 128-byte communicator id).
+all-reduces per iteration issued by libtfx.so itself on its stream (tfx_comm_init_rccl).  torch.distributed is the CONTROL
+channel only - a gloo group that starts the ranks, carries the 128-byte communicator id, the agreement flags of the start-up
+ladder and the timing reduction - so exactly one RCCL user lives in the process; if the library's communicator can not be
+set up on every rank, all ranks fall back to the torch.distributed hooks together and the line says so (`comm`).
 
 One JSON line on rank 0.  `roofline` is about the dominant kernel (compressed SpMV or its adjoint, whichever is slower):
-`achieved` = the bytes the kernel's algorithm streams per launch (5.625 B per stored entry + the staged vectors)
+`achieved` = the bytes the kernel's algorithm streams per launch (the stored entry streams + the staged vectors)
 over its HIP-event duration, `traffic` = the HBM bytes rocprofv3's counters saw for the same launch (profiles/), both
 against the 8 TB/s spec; the reference-CSR-equivalent rate (8 B per non-zero) is reported next to it as
 `csr_equivalent_GBs`, not as the fraction.  `cpu_baseline` is the REAL reference (oracle/_ref/tomofastx, compiled from
@@ -72,13 +74,24 @@ def main():
     tfx = importlib.import_module("tomofast-x_amd")
     dist = None
     backend = None
-    if world > 1:
+    force_comm = os.environ.get("TFX_BENCH_FORCE_COMM") == "1"      # world size 1 through the whole multi-rank start-up (tests)
+    if world > 1 or force_comm:
         import torch.distributed as dist
-        # TFX_BENCH_BACKEND=gloo + TFX_BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a single-GPU box
-        backend = os.environ.get("TFX_BENCH_BACKEND", "nccl")
+        # The process group is the control channel (gloo): the data path's collectives are RCCL inside libtfx.so.
+        # TFX_BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a single-GPU box (all ranks on GPU 0 -> the ladder's hook rung);
+        # TFX_BENCH_BACKEND=nccl: torch's own NCCL group as the default group (a second RCCL communicator in the process).
+        backend = os.environ.get("TFX_BENCH_BACKEND", "gloo")
         if os.environ.get("TFX_BENCH_SHARE_GPU") == "1":
             local_rank = 0
+        if local_rank >= torch.cuda.device_count():
+            sys.stderr.write("[bench] rank %d: LOCAL_RANK %d but %d GPUs visible - sharing GPU %d\n" %
+                             (rank, local_rank, torch.cuda.device_count(), local_rank % max(1, torch.cuda.device_count())))
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):      # one node: the control channel needs no routable interface
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")            # (the container's hostname may not resolve)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -107,8 +120,8 @@ def main():
     cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
     # collectives: an RCCL communicator inside libtfx.so (nccl launch) - the library queues its reductions on its own stream;
     # the gloo rehearsal uses the torch.distributed hooks
-    comm = tfx.distributed.setup_comm(ctx, rank, world, local_rank)
-    log("collectives: %s" % ("RCCL inside libtfx.so (tfx_comm_init_rccl)" if comm.rccl else ("single rank" if world == 1 else "torch.distributed hooks (%s)" % backend)))
+    comm = tfx.distributed.setup_comm(ctx, rank, world, local_rank, log=log, force=force_comm)
+    log("collectives: %s" % json.dumps(comm.report))
 
     def barrier():
         comm.barrier()
@@ -184,9 +197,10 @@ def main():
     barrier()
     t_steps = time.perf_counter() - t0
     assert done == args.steps, "LSQR stopped early (%d of %d)" % (done, args.steps)
-    prof = [ctx.profile_get(0), ctx.profile_get(1)] if not args.no_profile else [(0.0, 0), (0.0, 0)]
+    prof = [ctx.profile_get(0), ctx.profile_get(1), ctx.profile_get(2)] if not args.no_profile else [(0.0, 0), (0.0, 0), (0.0, 0)]
     ctx.profile_enable(False)
     ctx.lsqr_end()
+    t_steps_local = t_steps
     t_steps = comm.max_over_ranks(t_steps) if world > 1 else t_steps
     ms_per_step = 1e3 * t_steps / args.steps
     value = args.steps / t_steps
@@ -197,6 +211,10 @@ def main():
     if w["ctype"] == 0:
         names = ["k_dense_fwd (dense fp32 block, b += S x)", "k_dense_adj (dense fp32 block, b += S^T x)"]
     roof = None
+    # bytes per stored entry of the compressed layout: value + column stream + row-start bit (what tfx_matrix_info's stream sizes say;
+    # DESIGN.md 3).  The kernel that runs the adjoint may stream a second, transposed copy of the same size.
+    fmt = ctx.matrix_format() if w["ctype"] > 0 else {}
+    bytes_per_entry = fmt.get("bytes_per_entry", 4.0)
     if prof[0][1] and prof[1][1]:
         avg = [prof[0][0] / prof[0][1], prof[1][0] / prof[1][1]]
         dom = 0 if avg[0] >= avg[1] else 1
@@ -208,13 +226,14 @@ def main():
             alg_bytes = 4.0 * nnz_loc + 8.0 * (ncl + D)
             csr_b = 4.0
         else:
-            alg_bytes = 5.625 * nnz_loc + 8.0 * (ncl + D)
+            alg_bytes = bytes_per_entry * nnz_loc + 8.0 * (ncl + D)
             csr_b = 8.0
         achieved = alg_bytes / (avg[dom] * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args.workload, "k_spmv_fwd" if dom == 0 else "k_spmv_adj", nnz_loc)
+        traffic, traffic_src = pmc_traffic(args.workload, "k_spmv_fwd" if dom == 0 else "k_spmv_adj", nnz_loc, minfo["device_bytes"])
         roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "device_bytes_of_the_matrix": minfo["device_bytes"],
+                "stored_bytes_per_entry": bytes_per_entry, "matrix_format": fmt,
                 "avg_launch_ms": {"spmv_fwd": round(avg[0], 4), "spmv_adj": round(avg[1], 4)},
                 # the same launch on the bytes that crossed HBM by PMC (>= the algorithmic bytes: tile padding, row markers, staging)
                 "frac_on_traffic": None if traffic is None else round(traffic / (avg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -233,6 +252,13 @@ def main():
             cpu = cpu_baseline(tfx, w, args.cpu_seconds, cw, log)
         ref_cfg1 = reference_config1(log)
 
+    # ---- per-rank facts (N > 1): product times, the event-timed all-reduces, matrix share, wall clock of the timed region
+    mine = np.array([prof[0][0] / max(prof[0][1], 1), prof[1][0] / max(prof[1][1], 1), prof[2][0] / max(prof[2][1], 1), float(prof[2][1]),
+                     float(nnz_loc), 1e3 * t_steps_local / args.steps, float(ms_gpu / args.steps)])
+    per_rank = comm.allgather_host(mine) if world > 1 else [mine]
+    stored_iter = None
+    if w["ctype"] > 0:
+        stored_iter = int(2 * bytes_per_entry * int(nnz_total) + 112 * N + 48 * (D + N))
     if rank == 0:
         out = {
             "metric": "LSQR iterations/s, synthetic gravity inversion (wavelet-compressed sensitivity kernel)",
@@ -246,7 +272,17 @@ def main():
             "cell_obs_per_s_build": round(N * D / t_build, 1), "build_s": round(t_build, 2), "build_mode": build_mode,
             "build_threshold_batches": {"band_select": ctx.debug_set("band_batches"), "fell_back_to_full_select": ctx.debug_set("band_fallbacks")},
             "gpu_ms_per_step_hip_events": round(ms_gpu / args.steps, 4),
-            "lsqr_bytes_per_iteration_algorithmic": 16 * int(nnz_total) + 112 * N + 48 * (D + N),
+            # SURVEY 8d's formula on the REFERENCE's CSR (8 B per non-zero and pass): a CSR-equivalent figure like csr_equivalent_GBs, not
+            # what this layout streams; `_stored` is (2 passes over the stored streams + the vector sweeps) and must stay below
+            # 8 TB/s x ms_per_step x n_gpus
+            "lsqr_bytes_per_iteration_csr_equivalent": 16 * int(nnz_total) + 112 * N + 48 * (D + N),
+            "lsqr_bytes_per_iteration_stored": stored_iter,
+            "lsqr_stored_GBs": None if stored_iter is None else round(stored_iter / (ms_per_step * 1e-3) / 1e9, 1),
+            "comm": comm.report,
+            "per_rank": [{"rank": r, "spmv_fwd_ms": round(float(v[0]), 4), "spmv_adj_ms": round(float(v[1]), 4),
+                          "allreduce_ms": round(float(v[2]), 4), "allreduces_timed": int(v[3]), "nnz": int(v[4]),
+                          "ms_per_step_wall": round(float(v[5]), 4), "ms_per_step_hip_events": round(float(v[6]), 4)}
+                         for r, v in enumerate(per_rank)],
             "adjoint_identity_rel_err": adj_err, "final_r": r,
             "roofline": roof, "cpu_baseline": cpu, "reference_config1": ref_cfg1,
         }
@@ -379,15 +415,18 @@ def cpu_baseline_reference(tfx, nnz_headline, pairs_headline, log, nx=64, ny=64,
         shutil.rmtree(wd, ignore_errors=True)
 
 
-def pmc_traffic(workload, kernel, nnz_loc):
+def pmc_traffic(workload, kernel, nnz_loc, device_bytes):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_summary.json:
     FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc passes) for this workload and matrix; None when there is none.
-    PMC counters cannot be read from inside the benchmark process, so this is the value measured on the same command."""
+    PMC counters cannot be read from inside the benchmark process, so this is the value measured on the same command.  A summary
+    is only accepted for the SAME matrix: workload, nnz and the device bytes of the matrix must all match the run's - a layout
+    change without a re-profile then reports traffic = null instead of a stale number."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
         try:
             d = json.load(open(f))
-            if d.get("workload") == workload and int(d.get("nnz", -1)) == int(nnz_loc) and kernel in d.get("kernels", {}):
+            if (d.get("workload") == workload and int(d.get("nnz", -1)) == int(nnz_loc) and kernel in d.get("kernels", {})
+                    and int(d.get("device_bytes_of_the_matrix", -1)) == int(device_bytes)):
                 return d["kernels"][kernel]["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
         except Exception:
             continue

@@ -82,6 +82,14 @@ int tfx_set_allgatherv(tfx_ctx *ctx, tfx_allgatherv_fn fn);
 int tfx_comm_unique_id(char *id_out /* [TFX_COMM_ID_BYTES] */);
 int tfx_comm_init_rccl(tfx_ctx *ctx, const char *unique_id /* [TFX_COMM_ID_BYTES] */, int rank, int nranks);
 int tfx_comm_destroy(tfx_ctx *ctx);
+/* Start-up that can not strand a rank: the hosts wrap tfx_comm_init_rccl in "try - agree over the control channel (MPI / gloo) -
+ * fall back to the hooks"; a rank whose own call succeeded while another rank's failed drops its half-open communicator with
+ * tfx_comm_abort (ncclCommAbort: no hand-shake with the peers).                                                              */
+int tfx_comm_abort(tfx_ctx *ctx);
+/* Facts for the bench line / logs: ranks the communicator itself counts (ncclCommCount; 0 without a communicator), this rank's
+ * index and device in it, ncclGetVersion, and the file the nccl* symbols come from (libtfx.so depends on librccl.so.1: a process
+ * that has already mapped an RCCL of that soname - PyTorch bundles one - keeps that single copy, otherwise /opt/rocm/lib's).   */
+int tfx_comm_info(tfx_ctx *ctx, int *nranks_seen, int *rank_seen, int *device_seen, int *version, char *path, int path_len);
 /* Collectives for the host's own exchange steps, on DEVICE buffers, queued on the ctx stream.                              */
 enum { TFX_F64 = 0, TFX_I32 = 1, TFX_I64 = 2 };
 int tfx_comm_allreduce(tfx_ctx *ctx, void *dev_buf, int64_t n, int dtype);           /* sum, in place                       */
@@ -229,6 +237,9 @@ int tfx_rowstore_counts(tfx_ctx *ctx, int nparts, const int64_t *bounds, int32_t
 int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t col_begin, int64_t col_end,
                       int32_t *cols_dev_out, float *vals_dev_out, int64_t capacity, int64_t *n_out);
 int tfx_rowstore_free(tfx_ctx *ctx);
+/* How the selected matrix is stored: bytes of the entry streams per stored entry (what one product streams per entry), stored
+ * entries (non-zeros + empty-row markers + pad entries), bytes of those streams, adjoint on a transposed copy (0 / 1).        */
+int tfx_matrix_format(tfx_ctx *ctx, double *bytes_per_entry, int64_t *stored_entries, int64_t *stream_bytes, int *adjoint_copy);
 int tfx_matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper);
 int tfx_matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const int32_t *cols_dev, const float *vals_dev,
                            const int32_t *nel_host);
@@ -285,7 +296,7 @@ int tfx_calc_data(tfx_ctx *ctx, const double *xw_local, double problem_weight, c
 int tfx_timer_start(tfx_ctx *ctx);
 int tfx_timer_stop_ms(tfx_ctx *ctx, double *ms_out);       /* synchronises                                  */
 /* Per-kernel accumulated GPU time (HIP events around every launch of the two matrix kernels) since the last
- * reset: which = 0 SpMV, 1 SpMtV.  Enabled with tfx_profile_enable(ctx, 1).                                 */
+ * reset: which = 0 SpMV, 1 SpMtV, 2 the in-stream all-reduces (RCCL or hook).  Enabled with tfx_profile_enable(ctx, 1). */
 int tfx_profile_enable(tfx_ctx *ctx, int on);
 int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches);
 

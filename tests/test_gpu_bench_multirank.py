@@ -1,0 +1,86 @@
+"""bench.py's N > 1 path on the ONE GPU of the test box - everything about `--gpus N` that does not need a second GPU.
+
+* world size 1 through the whole multi-rank start-up (TFX_BENCH_FORCE_COMM=1 under torch.distributed.run): the gloo control group
+  carries the 128-byte id, the ladder of distributed.setup_comm runs (pre-flight -> tfx_comm_init_rccl -> first collectives), the
+  communicator counts 1 rank, LSQR's reductions are real ncclAllReduce calls in-stream - and the residual has the bits of the
+  plain single-rank run (deterministic product mode).
+* 2 and 8 ranks launched exactly as the driver launches them (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+  --gpus N`), all on GPU 0: the pre-flight sees that the ranks share a GPU, every rank takes the hook rung TOGETHER, the
+  row-parallel build with balanced data ranges + relayout, the partition, the N-rank LSQR and the per-rank report all run, and
+  the result agrees with the single-rank run.  What it can not prove: RCCL between several GPUs (the driver's scaling run does).
+Reference: lsqr_solver2.F90:214, 511-515 (the two reductions), sensitivity_gravmag.F90:179-189, 470-524, 795-830 (row-parallel
+build, partition, relayout), parallel_tools.f90:46-63 (how the data are dealt out)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run_bench(nranks, workload, extra_env=None, steps=12, warmup=2, port=29640, launcher=True, timeout=900):
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.update(extra_env or {})
+    args = ["bench.py", "--gpus", str(nranks), "--steps", str(steps), "--warmup", str(warmup), "--workload", workload, "--no-cpu"]
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, "bench.py exited %d\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line expected on rank 0:\n" + p.stdout[-2000:]
+    return json.loads(lines[0]), p.stderr
+
+
+@pytest.fixture(scope="module")
+def plain_small():
+    out, _ = _run_bench(1, "small", {"TFX_DETERMINISTIC": "1"}, launcher=False)
+    assert out["comm"]["path"] == "single rank"
+    return out
+
+
+def test_world_size_1_through_the_rccl_startup_has_the_bits_of_the_plain_run(plain_small):
+    out, err = _run_bench(1, "small", {"TFX_DETERMINISTIC": "1", "TFX_BENCH_FORCE_COMM": "1"}, port=29641)
+    comm = out["comm"]
+    assert comm["path"].startswith("RCCL inside libtfx.so"), comm
+    assert [s["ok"] for s in comm["ladder"]] == [True, True, True], comm
+    assert comm["rccl_ranks"] == 1 and comm["rccl_rank"] == 0 and "librccl" in comm["librccl"], comm
+    assert out["per_rank"][0]["allreduces_timed"] >= 2 * out["steps"], out["per_rank"]       # both reductions of every iteration, event-timed
+    assert out["final_r"] == plain_small["final_r"], (out["final_r"], plain_small["final_r"])
+    assert out["config"]["nnz"] == plain_small["config"]["nnz"]
+
+
+@pytest.mark.parametrize("nranks,workload", [(2, "medium"), (8, "small")])
+def test_ranks_launched_like_the_driver_does_share_the_gpu_and_fall_back_together(nranks, workload, plain_small):
+    out, err = _run_bench(nranks, workload, {"TFX_DETERMINISTIC": "1"}, port=29650 + nranks)
+    comm = out["comm"]
+    assert out["n_gpus"] == nranks and out["scaling"] == "strong"
+    assert comm["path"].startswith("torch.distributed hooks"), comm
+    assert comm["ladder"][0]["stage"] == "pre-flight" and comm["ladder"][0]["ok"] is False and "share a GPU" in comm["ladder"][0]["why"], comm
+    assert comm["rccl_ranks"] == 0
+    assert out["build_mode"].startswith("row-parallel + relayout"), out["build_mode"]
+    per = out["per_rank"]
+    assert len(per) == nranks and sum(p["nnz"] for p in per) == out["config"]["nnz"]
+    assert max(p["nnz"] for p in per) <= 1.02 * out["config"]["nnz"] / nranks + 4096           # the reference's greedy rule balances the non-zeros
+    assert all(p["allreduces_timed"] >= 2 * out["steps"] for p in per)
+    assert out["adjoint_identity_rel_err"] < 1e-12
+    if workload == "small":           # the same problem as the single-rank run: same matrix, same residual after the same iterations
+        assert out["config"]["nnz"] == plain_small["config"]["nnz"]
+        assert abs(out["final_r"] - plain_small["final_r"]) <= 1e-9 * abs(plain_small["final_r"]), (out["final_r"], plain_small["final_r"])
+
+
+def test_tfx_comm_rccl_insists_and_fails_loudly_when_ranks_share_a_gpu():
+    """TFX_COMM=rccl on ranks that share a GPU must not hang and must not silently use the hooks: every rank stops with the reason."""
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "TFX_COMM": "rccl"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29671",
+           "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "small", "--no-cpu"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "TFX_COMM=rccl but the communicator could not be set up" in p.stderr, p.stderr[-3000:]

@@ -311,6 +311,26 @@ static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_
     return 0;
 }
 
+// How the selected matrix is stored: bytes the entry streams (values, column stream, row-start masks) hold per stored entry - what a
+// product streams per entry and launch -, the number of stored entries (non-zeros + empty-row markers + pad entries), the bytes of
+// those streams, and whether the adjoint product runs on a transposed copy of the tiles (then it streams that copy instead).
+int tfx_matrix_format(tfx_ctx *ctx, double *bytes_per_entry, int64_t *stored_entries, int64_t *stream_bytes, int *adjoint_copy)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    const TiledMatrix &m = ctx->selmat();
+    if (!m.valid) return fail(TFX_E_STATE, "no matrix");
+    int64_t stored = 0;
+    for (const TileMeta &t : m.h_tiles) stored += t.cnt;
+    const int64_t bytes = m.is_dense ? (int64_t)m.dense.bytes()
+                                     : m.n_entries * 4 + (m.n_entries / CHUNK) * (int64_t)(SLOT_WORDS * 4 + MASK_WORDS * 8);
+    if (m.is_dense) stored = m.nrows * m.ncols;
+    if (bytes_per_entry) *bytes_per_entry = m.is_dense ? 4.0 : 4.0 + 4.0 * SLOT_WORDS / CHUNK + 8.0 * MASK_WORDS / CHUNK;
+    if (stored_entries) *stored_entries = stored;
+    if (stream_bytes) *stream_bytes = bytes;
+    if (adjoint_copy) *adjoint_copy = 0;
+    return 0;
+}
+
 int tfx_matrix_info(tfx_ctx *ctx, int64_t *nrows, int64_t *ncols, int64_t *nnz, int64_t *device_bytes)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
@@ -552,14 +572,14 @@ int tfx_profile_enable(tfx_ctx *ctx, int on)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     tfx::prof_drain(ctx);
     ctx->profile = on != 0;
-    ctx->prof_ms[0] = ctx->prof_ms[1] = 0;
-    ctx->prof_n[0] = ctx->prof_n[1] = 0;
+    ctx->prof_ms[0] = ctx->prof_ms[1] = ctx->prof_ms[2] = 0;
+    ctx->prof_n[0] = ctx->prof_n[1] = ctx->prof_n[2] = 0;
     return 0;
 }
 
 int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches)
 {
-    if (!ctx || which < 0 || which > 1) return fail(TFX_E_ARG, "bad argument");
+    if (!ctx || which < 0 || which > 2) return fail(TFX_E_ARG, "bad argument");
     tfx::prof_drain(ctx);
     if (total_ms) *total_ms = ctx->prof_ms[which];
     if (launches) *launches = ctx->prof_n[which];

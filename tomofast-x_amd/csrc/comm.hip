@@ -13,6 +13,7 @@
 // how the multi-rank logic is tested on boxes without several GPUs (gloo / MPI staging), never the production path.
 #include "common.h"
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 
 namespace tfx {
 
@@ -29,12 +30,18 @@ static inline ncclComm_t comm_of(tfx_ctx *ctx) { return (ncclComm_t)ctx->comm; }
 int comm_allreduce_f64(tfx_ctx *ctx, double *buf, int64_t n)
 {
     if (!ctx->multi() || n <= 0) return 0;
+    // tfx_profile_enable: HIP events around the reduction on the ctx stream (slot 2) - what bench.py reports as the all-reduce time
     if (ctx->comm) {
-        TFX_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, comm_of(ctx), ctx->stream));
+        prof_begin(ctx);
+        const ncclResult_t r = ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, comm_of(ctx), ctx->stream);
+        prof_end(ctx, 2);
+        if (r != ncclSuccess) return fail(TFX_E_COMM, "ncclAllReduce: %s", ncclGetErrorString(r));
         return 0;
     }
     if (!ctx->allreduce) return fail(TFX_E_COMM, "several ranks but neither a communicator nor an all-reduce hook");
+    prof_begin(ctx);
     int rc = ctx->allreduce(ctx->allreduce_user, buf, n, (void *)ctx->stream);
+    prof_end(ctx, 2);
     if (rc != 0) return fail(TFX_E_COMM, "all-reduce hook failed (%d)", rc);
     return 0;
 }
@@ -92,7 +99,12 @@ int tfx_comm_init_rccl(tfx_ctx *ctx, const char *unique_id, int rank, int nranks
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     ncclComm_t c = nullptr;
+    ctx->comm_cancelled = false;
     TFX_NCCL(ncclCommInitRank(&c, nranks, id, rank));
+    if (ctx->comm_cancelled) {          // the host gave up on this rendezvous (timeout) while it was in flight and moved on to the hooks
+        (void)ncclCommAbort(c);
+        return fail(TFX_E_COMM, "tfx_comm_init_rccl: cancelled by tfx_comm_abort while the rendezvous was in flight");
+    }
     ctx->comm = (void *)c;
     ctx->rank = rank;
     ctx->nranks = nranks;
@@ -109,6 +121,51 @@ int tfx_comm_destroy(tfx_ctx *ctx)
         ctx->comm = nullptr;
         if (!ctx->allreduce) { ctx->rank = 0; ctx->nranks = 1; }
         if (r != ncclSuccess) return fail(TFX_E_COMM, "ncclCommDestroy: %s", ncclGetErrorString(r));
+    }
+    return 0;
+}
+
+// Aborts the communicator without the orderly hand-shake of ncclCommDestroy: what a rank does when the other ranks reported a failed
+// start-up (the fallback ladder of the hosts: every rank agrees on the outcome of tfx_comm_init_rccl over its control channel, and
+// the ranks whose own call succeeded drop their half-open communicator with this).
+int tfx_comm_abort(tfx_ctx *ctx)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    if (ctx->comm) {
+        (void)hipSetDevice(ctx->device);
+        ncclResult_t r = ncclCommAbort(comm_of(ctx));
+        ctx->comm = nullptr;
+        if (!ctx->allreduce) { ctx->rank = 0; ctx->nranks = 1; }
+        if (r != ncclSuccess) return fail(TFX_E_COMM, "ncclCommAbort: %s", ncclGetErrorString(r));
+    } else {
+        ctx->comm_cancelled = true;     // a tfx_comm_init_rccl still in flight on another thread must not install its communicator
+    }
+    return 0;
+}
+
+// Facts about the communicator and the RCCL build that serves it: ranks the communicator itself counts (ncclCommCount - the
+// "ranks seen by RCCL" of the bench line), this rank's index and device in it, the library version (ncclGetVersion) and the file
+// the nccl* symbols were resolved from (libtfx.so names librccl.so.1 as a dependency; a process that has already mapped an RCCL of
+// that soname - PyTorch bundles one - keeps using that one copy, otherwise the loader takes /opt/rocm/lib's).  Without a
+// communicator the counts are 0 and only version / path are filled.
+int tfx_comm_info(tfx_ctx *ctx, int *nranks_seen, int *rank_seen, int *device_seen, int *version, char *path, int path_len)
+{
+    if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    int n = 0, r = -1, d = -1, v = 0;
+    if (ctx->comm) {
+        TFX_NCCL(ncclCommCount(comm_of(ctx), &n));
+        TFX_NCCL(ncclCommUserRank(comm_of(ctx), &r));
+        TFX_NCCL(ncclCommCuDevice(comm_of(ctx), &d));
+    }
+    (void)ncclGetVersion(&v);
+    if (nranks_seen) *nranks_seen = n;
+    if (rank_seen) *rank_seen = r;
+    if (device_seen) *device_seen = d;
+    if (version) *version = v;
+    if (path && path_len > 0) {
+        path[0] = 0;
+        Dl_info di;
+        if (dladdr((void *)&ncclGetVersion, &di) && di.dli_fname) snprintf(path, (size_t)path_len, "%s", di.dli_fname);
     }
     return 0;
 }

@@ -187,6 +187,7 @@ struct tfx_ctx {
     // scratch vectors for spmv / spmtv with host pointers
     tfx::DBuf<double> vx, vb, vw;
     // comm
+    volatile bool comm_cancelled = false;  // tfx_comm_abort while tfx_comm_init_rccl is in flight (start-up ladder of the hosts)
     void *comm = nullptr;              // ncclComm_t (comm.hip): when set, every collective of the path is RCCL on the ctx stream
     tfx_allreduce_fn allreduce = nullptr;
     tfx_allgatherv_fn allgatherv = nullptr;
@@ -213,8 +214,8 @@ struct tfx_ctx {
     bool deterministic = false;       // debug: single-wave workgroups in the two products -> LDS atomics in program order
     size_t wave_lds_attr[4] = {0, 0, 0, 0};   // the same for the four wavelet axis kernels (Haar / D4 x forward / inverse)
     bool profile = false;
-    double prof_ms[2] = {0, 0};
-    int64_t prof_n[2] = {0, 0};
+    double prof_ms[3] = {0, 0, 0};     // 0 forward product, 1 adjoint product, 2 in-stream all-reduce (comm.hip)
+    int64_t prof_n[3] = {0, 0, 0};
     hipEvent_t pev0 = nullptr, pev1 = nullptr;
     // per-launch event pairs of the profiling mode: recorded without a host round trip, resolved when the totals are read
     struct ProfPair { hipEvent_t a, b; int which; };
@@ -236,6 +237,8 @@ int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale);
 int chunk_exponent_stats(tfx_ctx *ctx, TiledMatrix &m, int span, int64_t *fit, int64_t *total, unsigned int *hist34);
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
 void prof_drain(tfx_ctx *ctx);
+void prof_begin(tfx_ctx *ctx);
+void prof_end(tfx_ctx *ctx, int which);
 // comm.hip
 int comm_allreduce_f64(tfx_ctx *ctx, double *buf, int64_t n);
 int comm_allgatherv_f64(tfx_ctx *ctx, const double *send, double *recv, const int64_t *counts, const int64_t *displs);   // 1: unavailable

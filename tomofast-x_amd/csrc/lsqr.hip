@@ -534,23 +534,31 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
             if (nc % ctx->wd_ncomp != 0 || ctx->wd_col_begin + nc / ctx->wd_ncomp > n123)
                 return fail(TFX_E_STATE, "the column partition does not match the matrix (%lld local columns, %d components)", (long long)nc, ctx->wd_ncomp);
             TFX_TRY(L->twf.ensure((size_t)(ctx->wd_ncomp * n123)));
-            // first cell of every rank: each rank puts its own into a zero vector, the sum is the list (exact: integers < 2^53)
-            TFX_TRY(ctx->vx.ensure((size_t)std::max<int64_t>(ctx->nranks, nc)));
-            std::vector<double> hb((size_t)ctx->nranks, 0.0);
+            // first cell and cell count of every rank: each rank puts its own pair into a zero vector, the sum is the table (exact:
+            // integers < 2^53).  EVERY rank validates the WHOLE table - the same data on all of them, so a range that is out of order,
+            // overlapping or does not tile the model makes all ranks fail together instead of leaving some inside a collective with a
+            // negative length
+            const int P = ctx->nranks;
+            TFX_TRY(ctx->vx.ensure((size_t)std::max<int64_t>(2 * P, nc)));
+            std::vector<double> hb((size_t)(2 * P), 0.0);
             hb[(size_t)ctx->rank] = (double)ctx->wd_col_begin;
+            hb[(size_t)(P + ctx->rank)] = (double)(nc / ctx->wd_ncomp);
             TFX_TRY(copy_any(ctx->vx.p, hb.data(), hb.size() * sizeof(double), s));
-            TFX_TRY(allreduce(ctx, ctx->vx.p, ctx->nranks));
+            TFX_TRY(allreduce(ctx, ctx->vx.p, 2 * P));
             TFX_TRY(copy_any(hb.data(), ctx->vx.p, hb.size() * sizeof(double), s));
-            L->g_counts.assign((size_t)ctx->nranks, 0);
-            L->g_displs.assign((size_t)ctx->nranks, 0);
-            for (int r = 0; r < ctx->nranks; ++r) {
+            L->g_counts.assign((size_t)P, 0);
+            L->g_displs.assign((size_t)P, 0);
+            int64_t expect = 0;
+            for (int r = 0; r < P; ++r) {
                 L->g_displs[(size_t)r] = (int64_t)hb[(size_t)r];
-                const int64_t next = r + 1 < ctx->nranks ? (int64_t)hb[(size_t)r + 1] : n123;
-                L->g_counts[(size_t)r] = next - L->g_displs[(size_t)r];
+                L->g_counts[(size_t)r] = (int64_t)hb[(size_t)(P + r)];
+                if (L->g_counts[(size_t)r] < 0 || L->g_displs[(size_t)r] != expect)
+                    return fail(TFX_E_STATE, "the ranks' column ranges do not tile the model: rank %d starts at cell %lld with %lld cells, expected start %lld",
+                                r, (long long)L->g_displs[(size_t)r], (long long)L->g_counts[(size_t)r], (long long)expect);
+                expect += L->g_counts[(size_t)r];
             }
-            if (L->g_counts[(size_t)ctx->rank] != nc / ctx->wd_ncomp)
-                return fail(TFX_E_STATE, "the ranks' column ranges do not tile the model (rank %d: %lld cells, range of %lld)", ctx->rank,
-                            (long long)(nc / ctx->wd_ncomp), (long long)L->g_counts[(size_t)ctx->rank]);
+            if (expect != n123)
+                return fail(TFX_E_STATE, "the ranks' column ranges cover %lld of %lld cells", (long long)expect, (long long)n123);
         } else {
             if (n123 <= 0 || nc % n123 != 0)   // ncolumns = nmodel_components * nelements (wavelet_utils.F90:37-72 loops the components)
                 return fail(TFX_E_STATE, "WAVELET_DOMAIN = F needs the whole model on this rank (ncolumns %lld is not a multiple of n1*n2*n3)", (long long)nc);

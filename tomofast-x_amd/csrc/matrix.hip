@@ -991,7 +991,7 @@ static int set_lds_limit(tfx_ctx *ctx, int which, const void *fn, size_t bytes)
 
 // HIP events around every launch of the two product kernels (tfx_profile_enable).  The events are only recorded here - no host
 // synchronisation inside the measured region; prof_drain turns the finished pairs into totals when they are asked for.
-static void prof_begin(tfx_ctx *ctx)
+void prof_begin(tfx_ctx *ctx)
 {
     if (!ctx->profile) return;
     tfx_ctx::ProfPair pp{nullptr, nullptr, 0};
@@ -1019,7 +1019,7 @@ void prof_drain(tfx_ctx *ctx)
     }
     ctx->prof_pending.clear();
 }
-static void prof_end(tfx_ctx *ctx, int which)
+void prof_end(tfx_ctx *ctx, int which)
 {
     if (!ctx->profile || ctx->prof_pending.empty()) return;
     tfx_ctx::ProfPair &pp = ctx->prof_pending.back();

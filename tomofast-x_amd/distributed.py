@@ -157,7 +157,7 @@ class HostComm:
         import torch.distributed as dist
         torch = self.torch
         out = [torch.zeros(a.shape, dtype=torch.from_numpy(a).dtype) for _ in range(self.nranks)]
-        dist.all_gather(out, torch.from_numpy(a))
+        dist.all_gather(out, torch.from_numpy(a), group=control_group())
         return [o.numpy() for o in out]
 
     def exchange(self, sends, recvs):
@@ -195,29 +195,178 @@ class HostComm:
         return float(self.allreduce_host(v).max())
 
 
-def setup_comm(ctx, rank, nranks, device_index=0, want_rccl=None):
-    """Gives the ctx its collectives and returns the HostComm for the host-driven exchange steps.
-    RCCL (the production path): rank 0 draws the unique id, torch.distributed only carries its 128 bytes to the other ranks, every
-    rank joins the communicator inside libtfx.so - from then on LSQR's reductions, calc_data and the slices of WAVELET_DOMAIN = F
-    are RCCL calls on the ctx stream.  Without it (gloo tests, ranks sharing one GPU): the hooks through torch.distributed."""
+_CONTROL = {"group": None}
+
+
+def control_group():
+    """The control channel of the ranks: a gloo group (CPU tensors over TCP on 127.0.0.1) that exists independently of every GPU
+    communicator.  It carries the 128-byte RCCL id, the agreement flags of the start-up ladder and the host-side tables; the data
+    path never touches it when the library's own communicator is up.  The default group itself when that is gloo."""
+    import torch.distributed as dist
+    if _CONTROL["group"] is None:
+        _CONTROL["group"] = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _CONTROL["group"]
+
+
+def agree(ok):
+    """True only when EVERY rank reports ok (min over the control channel): the ranks take the same branch of a fallback."""
     import torch
     import torch.distributed as dist
-    if nranks == 1:
-        return HostComm(ctx, 0, 1, device_index, False)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=control_group())
+    return bool(int(t[0]) == 1)
+
+
+def _call_with_timeout(fn, seconds):
+    """Runs fn() in a helper thread (the ctypes calls release the GIL); returns (finished, exception or None).  A collective that
+    never returns - a peer that died inside the rendezvous - then costs `seconds`, not the whole run."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            fn()
+        except BaseException as e:      # noqa
+            box["exc"] = e
+        box["done"] = True
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    return bool(box.get("done")), box.get("exc")
+
+
+def setup_comm(ctx, rank, nranks, device_index=0, want_rccl=None, log=None, init_timeout=None, force=False):
+    """Gives the ctx its collectives and returns the HostComm for the host-driven exchange steps.
+
+    The start-up is a ladder that every rank climbs in lock-step - after each rung the ranks AGREE on the outcome over the gloo
+    control channel, so a failure on one rank moves all of them to the next rung instead of stranding the others in a collective:
+      1. RCCL inside libtfx.so (the production path): pre-flight (one GPU per rank, a unique id) -> agree -> tfx_comm_init_rccl
+         under a timeout -> agree -> a one-element all-reduce and a ring send / recv through the new communicator -> agree;
+         the communicator must count `nranks` members itself (ncclCommCount).  From then on LSQR's reductions, calc_data, the
+         slices of WAVELET_DOMAIN = F and the relayout are RCCL calls on the ctx stream; torch.distributed only carried 128 bytes.
+      2. hooks over torch.distributed (gloo stages through the host): slower, but it completes - ranks sharing one GPU in the
+         tests, or a node on which RCCL can not connect the ranks.
+    `comm.report` says which rung ran and why (bench.py prints it).  TFX_COMM=hooks skips rung 1, TFX_COMM=rccl insists on it.
+    force=True takes a single rank through the same start-up (a world-size-1 communicator with the collectives forced on): what a
+    one-GPU box can prove about the production path."""
+    import os
+    import torch
+    import torch.distributed as dist
+    if log is None:
+        log = lambda msg: None      # noqa
+    if nranks == 1 and not force:
+        comm = HostComm(ctx, 0, 1, device_index, False)
+        comm.report = {"path": "single rank", "ladder": []}
+        return comm
+    mode = os.environ.get("TFX_COMM", "")
     if want_rccl is None:
-        want_rccl = dist.get_backend() == "nccl"
+        want_rccl = mode != "hooks" and (mode == "rccl" or dist.get_backend() in ("nccl", "gloo") and torch.cuda.device_count() >= 1
+                                         and os.environ.get("TFX_BENCH_SHARE_GPU") != "1")
+    if init_timeout is None:
+        init_timeout = float(os.environ.get("TFX_COMM_INIT_TIMEOUT", "240"))
+    report = {"path": None, "ladder": []}
     if want_rccl:
-        dev = torch.device("cuda", device_index)
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).to(dev)
-        dist.broadcast(idt, src=0)
-        ctx.comm_init_rccl(bytes(idt.cpu().numpy().tobytes()), rank, nranks)
-        return HostComm(ctx, rank, nranks, device_index, True)
+        why = _try_rccl(ctx, rank, nranks, device_index, init_timeout, report)
+        if why is None:
+            info = ctx.comm_info()
+            report.update(path="RCCL inside libtfx.so (tfx_comm_init_rccl)", **info)
+            if nranks == 1:
+                ctx.debug_set("force_collectives", 1)
+            comm = HostComm(ctx, rank, nranks, device_index, True)
+            comm.report = report
+            return comm
+        log("RCCL start-up did not complete on every rank (%s): all ranks fall back to the torch.distributed hooks" % why)
+        if mode == "rccl":
+            raise RuntimeError("TFX_COMM=rccl but the communicator could not be set up: %s" % why)
     hook = TorchAllreduce(device_index)
     ctx.set_allreduce(hook, rank, nranks)
     ctx.set_allgatherv(hook.allgatherv)
-    return HostComm(ctx, rank, nranks, device_index, False)
+    report["path"] = "torch.distributed hooks (%s)" % dist.get_backend()
+    try:
+        report.update({k: v for k, v in ctx.comm_info().items() if k in ("rccl_version", "librccl")}, rccl_ranks=0)
+    except Exception:      # noqa
+        pass
+    comm = HostComm(ctx, rank, nranks, device_index, False)
+    comm.report = report
+    return comm
+
+
+def _try_rccl(ctx, rank, nranks, device_index, timeout, report):
+    """Rung 1 of setup_comm.  Returns None when every rank holds a working communicator, else the reason (the same decision on all
+    ranks); on failure no rank is left with a communicator."""
+    import torch
+    import torch.distributed as dist
+    grp = control_group()
+    step = report["ladder"]
+
+    def fail_all(stage, local_reason):
+        # collect the first reason any rank has (for the log), then make sure nobody keeps a half-open communicator
+        reasons = [None] * nranks
+        dist.all_gather_object(reasons, local_reason, group=grp)
+        try:
+            ctx.comm_abort()
+        except Exception:      # noqa
+            pass
+        why = "%s: %s" % (stage, next((("rank %d: %s" % (r, x)) for r, x in enumerate(reasons) if x), "unknown"))
+        step.append({"stage": stage, "ok": False, "why": why})
+        return why
+
+    # -- pre-flight: every rank on a GPU of its own (bus ids over the control channel), rank 0 can draw an id
+    mine, err, uid = None, None, b"\0" * 128
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bus = tuple(getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        mine = "pci %s:%s:%s" % bus if None not in bus else "uuid %s" % (getattr(props, "uuid", None),)
+        if rank == 0:
+            uid = ctx.comm_unique_id()
+    except Exception as e:      # noqa
+        err = repr(e)
+    ids = [None] * nranks
+    dist.all_gather_object(ids, (mine, err), group=grp)
+    dup = len({i[0] for i in ids}) != nranks
+    local = err or ("ranks share a GPU (%s)" % ", ".join(str(i[0]) for i in ids) if dup else None)
+    if not agree(local is None):
+        return fail_all("pre-flight", local)
+    step.append({"stage": "pre-flight", "ok": True})
+    # -- the id travels as 128 bytes over gloo; the rendezvous itself under a timeout
+    box = [uid]
+    dist.broadcast_object_list(box, src=0, group=grp)
+    uid = box[0]
+    done, exc = _call_with_timeout(lambda: ctx.comm_init_rccl(uid, rank, nranks), timeout)
+    local = None if (done and exc is None) else ("tfx_comm_init_rccl %s" % ("timed out after %.0f s" % timeout if not done else repr(exc)))
+    if not agree(local is None):
+        return fail_all("tfx_comm_init_rccl", local)
+    step.append({"stage": "tfx_comm_init_rccl", "ok": True})
+    # -- first contact: the communicator counts its members, a sum travels through it, every rank reaches both ring neighbours
+    def probe():
+        dev = torch.device("cuda", device_index)
+        info = ctx.comm_info()
+        if info["rccl_ranks"] != nranks or info["rccl_rank"] != rank:
+            raise RuntimeError("the communicator reports rank %d of %d, expected %d of %d" % (info["rccl_rank"], info["rccl_ranks"], rank, nranks))
+        one = torch.full((3,), float(rank + 1), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        ctx.comm_allreduce(one.data_ptr(), 3, "f64")
+        ctx.comm_barrier()
+        if abs(float(one[0].item()) - nranks * (nranks + 1) / 2.0) > 0:
+            raise RuntimeError("all-reduce through the communicator gave %r" % (one.tolist(),))
+        if nranks == 1:
+            return
+        sendb = torch.full((1024,), float(rank), dtype=torch.float32, device=dev)
+        recvb = torch.full((1024,), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        ctx.comm_group_begin()
+        ctx.comm_send(sendb.data_ptr(), 4096, (rank + 1) % nranks)
+        ctx.comm_recv(recvb.data_ptr(), 4096, (rank - 1) % nranks)
+        ctx.comm_group_end()
+        ctx.comm_barrier()
+        if not bool((recvb == float((rank - 1) % nranks)).all().item()):
+            raise RuntimeError("ring send / recv delivered the wrong data")
+    done, exc = _call_with_timeout(probe, timeout)
+    local = None if (done and exc is None) else ("first collectives %s" % ("timed out after %.0f s" % timeout if not done else repr(exc)))
+    if not agree(local is None):
+        return fail_all("first collectives", local)
+    step.append({"stage": "first collectives (all-reduce, ring send / recv, ncclCommCount)", "ok": True})
+    return None
 
 
 def allreduce_numpy(arr, op="sum"):
@@ -226,20 +375,17 @@ def allreduce_numpy(arr, op="sum"):
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return arr
-    t = torch.from_numpy(np.ascontiguousarray(arr))
-    if dist.get_backend() == "nccl":
-        t = t.cuda()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
-    return t.cpu().numpy()
+    t = torch.from_numpy(np.ascontiguousarray(arr).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=control_group())
+    return t.numpy()
 
 
-def block_row_partition(ndata, nranks, row_block):
-    """Row blocks (of `row_block` observations) dealt out contiguously: rank r builds blocks [b[r], b[r+1])."""
-    nblocks = (ndata + row_block - 1) // row_block
-    base, rem = divmod(nblocks, nranks)
-    counts = [base + (1 if r < rem else 0) for r in range(nranks)]
-    starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    return nblocks, starts
+def data_row_partition(ndata, nranks):
+    """Data dealt out for the row-parallel build by the reference's own rule (calculate_nelements_at_cpu,
+    src/utils/parallel_tools.f90:46-63; used for the data in sensitivity_gravmag.F90:179-189): contiguous ranges of ndata / nranks
+    data, the remainder to the last rank - the ranks build within (nranks - 1) rows of each other (round 2 dealt whole 2048-row
+    blocks: 7 vs 6 blocks on 8 ranks at the headline size, a 14 % imbalance).  Returns the nranks + 1 range starts."""
+    return np.array([row_range(ndata, r, nranks)[0] for r in range(nranks)] + [ndata], np.int64)
 
 
 def _p2p(tensors_to_send, recv_specs, backend):
@@ -286,10 +432,10 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
     ncd = int(ndata_components)
     nrows = nd * ncd                                                # matrix rows
     RB = ctx.ROW_BLOCK
-    ndblocks, bstart = block_row_partition(nd, nranks, RB)          # blocks of RB data, dealt out contiguously
-    r0, r1 = int(bstart[rank]) * RB, min(int(bstart[rank + 1]) * RB, nd)      # my data
+    dstart = data_row_partition(nd, nranks)                         # my data: [dstart[rank], dstart[rank + 1])
+    r0, r1 = int(dstart[rank]), int(dstart[rank + 1])
     nloc = max(0, r1 - r0)
-    m0 = [min(int(bstart[r]) * RB, nd) * ncd for r in range(nranks + 1)]      # first matrix row of every rank (multiples of RB)
+    m0 = [int(d) * ncd for d in dstart]                             # first matrix row of every rank
     # 1. my rows, all columns
     if nloc > 0:
         dw = None if data_weight is None else np.asarray(data_weight).reshape(-1)[r0 * ncd:r1 * ncd]
@@ -307,7 +453,7 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
     c0, c1 = int(bounds[rank]), int(bounds[rank + 1])
     # 3. who sends how much of which row to whom
     counts_loc = ctx.rowstore_counts(nloc * ncd, bounds) if nloc > 0 else np.zeros((0, nranks), np.int32)
-    maxloc = int(max(np.diff(bstart))) * RB * ncd
+    maxloc = int(max(np.diff(dstart))) * ncd
     pad = np.zeros((maxloc, nranks), np.int32)
     pad[:nloc * ncd] = counts_loc
     gathered = comm.allgather_host(pad)
@@ -317,33 +463,46 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
         if b > a:
             counts[a:b] = gathered[r][:b - a]
     assert int(counts[:, rank].sum()) == int(nnz[rank]), (counts[:, rank].sum(), nnz[rank])
-    # 4. relayout, matrix row block by row block
+    # 4. relayout, matrix row block by row block.  The rows of a block come from the rank(s) that built them - a block that
+    # straddles a boundary of the data partition has two (rarely more) contributors, whose pieces are contiguous row sub-ranges in
+    # rank order, so they land one behind the other in the receive buffer and form the packed row block.
     ctx.matrix_begin(nrows, nmodel_components * (c1 - c0), int(nnz[rank]))
-    owner_of_row = np.searchsorted(np.asarray(m0[1:]), np.arange(0, nrows, RB), side="right")
+    m0a = np.asarray(m0, np.int64)
     for b in range((nrows + RB - 1) // RB):
         ga, gb = b * RB, min((b + 1) * RB, nrows)
-        o = int(owner_of_row[b])
         n_in = int(counts[ga:gb, rank].sum())
         rc = torch.empty(max(n_in, 1), dtype=torch.int32, device=dev)
         rv = torch.empty(max(n_in, 1), dtype=torch.float32, device=dev)
         sends, recvs, keep = [], [], []
-        if o == rank:
-            for d in range(nranks):
-                n_out = int(counts[ga:gb, d].sum())
-                if n_out == 0:
-                    continue
-                if d == rank:
-                    got = ctx.rowstore_pack(ga - m0[rank], gb - ga, int(bounds[d]), int(bounds[d + 1]), rc, rv, n_out)
+        off = 0
+        first = int(np.searchsorted(m0a[1:], ga, side="right"))
+        for o in range(first, nranks):
+            sa, sb = max(ga, m0[o]), min(gb, m0[o + 1])
+            if sb <= sa:
+                if m0[o] >= gb:
+                    break
+                continue
+            n_piece = int(counts[sa:sb, rank].sum())                 # what I receive of owner o's rows
+            if o == rank:
+                for d in range(nranks):
+                    n_out = int(counts[sa:sb, d].sum())
+                    if n_out == 0:
+                        continue
+                    if d == rank:
+                        got = ctx.rowstore_pack(sa - m0[rank], sb - sa, int(bounds[d]), int(bounds[d + 1]), rc[off:off + n_out],
+                                                rv[off:off + n_out], n_out)
+                        assert got == n_out
+                        continue
+                    sc = torch.empty(n_out, dtype=torch.int32, device=dev)
+                    sv = torch.empty(n_out, dtype=torch.float32, device=dev)
+                    got = ctx.rowstore_pack(sa - m0[rank], sb - sa, int(bounds[d]), int(bounds[d + 1]), sc, sv, n_out)
                     assert got == n_out
-                    continue
-                sc = torch.empty(n_out, dtype=torch.int32, device=dev)
-                sv = torch.empty(n_out, dtype=torch.float32, device=dev)
-                got = ctx.rowstore_pack(ga - m0[rank], gb - ga, int(bounds[d]), int(bounds[d + 1]), sc, sv, n_out)
-                assert got == n_out
-                keep += [sc, sv]
-                sends += [(d, sc), (d, sv)]
-        elif n_in > 0:
-            recvs += [(o, rc[:n_in]), (o, rv[:n_in])]
+                    keep += [sc, sv]
+                    sends += [(d, sc), (d, sv)]
+            elif n_piece > 0:
+                recvs += [(o, rc[off:off + n_piece]), (o, rv[off:off + n_piece])]
+            off += n_piece
+        assert off == n_in, (off, n_in)
         comm.exchange(sends, recvs)                                  # synchronises before (pack kernels) and after
         ctx.matrix_append_rows(ga, rc, rv, counts[ga:gb, rank])
     ctx.matrix_finish()

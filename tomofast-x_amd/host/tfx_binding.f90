@@ -385,6 +385,19 @@ module tfx_binding
     end function
 
     ! ---- RCCL inside libtfx.so (include/tfx.h "RCCL inside the library")
+    integer(c_int) function tfx_comm_abort(ctx) bind(C, name="tfx_comm_abort")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+
+    integer(c_int) function tfx_comm_info(ctx, nranks_seen, rank_seen, device_seen, version, path, path_len) bind(C, name="tfx_comm_info")
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: ctx
+      integer(c_int), intent(out) :: nranks_seen, rank_seen, device_seen, version
+      character(kind=c_char), intent(out) :: path(*)
+      integer(c_int), value :: path_len
+    end function
+
     integer(c_int) function tfx_comm_unique_id(id) bind(C, name="tfx_comm_unique_id")
       import :: c_int, c_char
       character(kind=c_char), intent(out) :: id(128)

@@ -54,35 +54,99 @@ contains
     if (mpi_on) call MPI_Abort(MPI_COMM_WORLD, 1, ierr)
   end subroutine host_mpi_abort
 
-  ! The collectives of the path for this ctx: an RCCL communicator inside libtfx.so when every rank has its own GPU, else the
-  ! MPI-staged hook (TFX_COMM=mpi forces the hook; TFX_COMM=rccl insists on RCCL)
+  ! This rank's place on its node: index among the ranks that share the node's memory (MPI_Comm_split_type SHARED) and their count.
+  ! The GPU a rank drives is its NODE-LOCAL index, so a multi-node job with one GPU per rank gets RCCL (ADVICE r2: the choice used
+  ! to compare MPI_COMM_WORLD's size with the GPUs of one node).
+  subroutine host_local_rank(local_rank, local_size)
+    integer, intent(out) :: local_rank, local_size
+    integer :: node_comm, ierr
+    local_rank = 0
+    local_size = 1
+    if (.not. mpi_on) return
+    call MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, myrank, MPI_INFO_NULL, node_comm, ierr)
+    if (ierr /= 0) then
+      local_rank = myrank; local_size = nbproc
+      return
+    endif
+    call MPI_Comm_rank(node_comm, local_rank, ierr)
+    call MPI_Comm_size(node_comm, local_size, ierr)
+    call MPI_Comm_free(node_comm, ierr)
+  end subroutine host_local_rank
+
+  integer function host_device_for_rank()
+    integer :: lr, ls, ndev
+    call host_local_rank(lr, ls)
+    ndev = max(1, tfx_device_count())
+    host_device_for_rank = mod(lr, ndev)
+  end function host_device_for_rank
+
+  ! The collectives of the path for this ctx, as a ladder every rank climbs in lock-step (the outcome of each rung is agreed with an
+  ! MPI_Allreduce(MIN), so a failure on one rank moves all of them on instead of stranding the others inside a collective):
+  !   1. RCCL inside libtfx.so when every rank of every node has a GPU of its own (TFX_COMM=rccl insists, TFX_COMM=mpi skips):
+  !      tfx_comm_init_rccl, then the communicator must count nbproc members and pass a barrier;
+  !   2. the MPI-staged hook (ranks sharing a GPU on a test box, or RCCL unable to connect the ranks).
   subroutine host_comm_setup(ctx)
     type(c_ptr), intent(in) :: ctx
-    character(kind=c_char) :: id(128)
+    character(kind=c_char) :: id(128), path(512)
     character(len=16) :: v
-    integer :: l, st, ierr, ndev
-    logical :: want
+    integer :: l, st, ierr, ndev, lr, ls, ok, ok_all, rc
+    integer(c_int) :: nseen, rseen, dseen, ver
+    logical :: want, insist
     if (nbproc <= 1) return
     ndev = tfx_device_count()
-    want = ndev >= nbproc
+    call host_local_rank(lr, ls)
+    ok = 0
+    if (ls <= ndev) ok = 1
+    call MPI_Allreduce(ok, ok_all, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)     ! every node must have a GPU per local rank
+    want = ok_all == 1
+    insist = .false.
     call get_environment_variable('TFX_COMM', v, l, st)
     if (st == 0 .and. l > 0) then
       if (v(1:l) == 'mpi') want = .false.
-      if (v(1:l) == 'rccl') want = .true.
+      if (v(1:l) == 'rccl') then
+        if (.not. want .and. myrank == 0) print *, 'TFX_COMM=rccl, but some ranks share a GPU: RCCL can not join them; using the MPI-staged hook.'
+        insist = want
+      endif
     endif
     if (want) then
       id = c_null_char
-      if (myrank == 0) call tfx_check(tfx_comm_unique_id(id), 'tfx_comm_unique_id')
-      call MPI_Bcast(id, 128, MPI_CHARACTER, 0, MPI_COMM_WORLD, ierr)
-      call tfx_check(tfx_comm_init_rccl(ctx, id, int(myrank, c_int), int(nbproc, c_int)), 'tfx_comm_init_rccl')
-      rccl_on = .true.
-      if (myrank == 0) print *, 'Collectives: RCCL inside libtfx.so (one GPU per rank).'
-    else
-      hook_ctx = ctx
-      call tfx_check(tfx_set_allreduce(ctx, c_funloc(allreduce_hook), c_null_ptr, int(myrank, c_int), int(nbproc, c_int)), &
-                     'tfx_set_allreduce')
-      if (myrank == 0) print *, 'Collectives: MPI-staged hook (ranks share GPUs, or TFX_COMM=mpi).'
+      ok = 1
+      if (myrank == 0) then
+        if (tfx_comm_unique_id(id) /= 0) ok = 0
+      endif
+      call MPI_Bcast(ok, 1, MPI_INTEGER, 0, MPI_COMM_WORLD, ierr)
+      if (ok == 1) then
+        call MPI_Bcast(id, 128, MPI_CHARACTER, 0, MPI_COMM_WORLD, ierr)
+        rc = tfx_comm_init_rccl(ctx, id, int(myrank, c_int), int(nbproc, c_int))
+        if (rc /= 0) ok = 0
+        call MPI_Allreduce(ok, ok_all, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+        ok = ok_all
+        if (ok == 1) then                      ! first contact: the communicator counts its members, a barrier passes through it
+          if (tfx_comm_info(ctx, nseen, rseen, dseen, ver, path, 512_c_int) /= 0) ok = 0
+          if (ok == 1) then
+            if (nseen /= nbproc .or. rseen /= myrank) ok = 0
+          endif
+          if (ok == 1) then
+            if (tfx_comm_barrier(ctx) /= 0) ok = 0
+          endif
+          call MPI_Allreduce(ok, ok_all, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+          ok = ok_all
+        endif
+        if (ok /= 1) rc = tfx_comm_abort(ctx)    ! nobody keeps a half-open communicator
+      endif
+      if (ok == 1) then
+        rccl_on = .true.
+        if (myrank == 0) print '(a,i0,a,i0,a)', ' Collectives: RCCL inside libtfx.so (one GPU per rank; the communicator counts ', nseen, &
+                                                 ' ranks, RCCL ', ver, ').'
+        return
+      endif
+      if (myrank == 0) print *, 'RCCL start-up did not complete on every rank: all ranks fall back to the MPI-staged hook.'
+      if (insist) call tfx_check(1_c_int, 'TFX_COMM=rccl but the communicator could not be set up')
     endif
+    hook_ctx = ctx
+    call tfx_check(tfx_set_allreduce(ctx, c_funloc(allreduce_hook), c_null_ptr, int(myrank, c_int), int(nbproc, c_int)), &
+                   'tfx_set_allreduce')
+    if (myrank == 0) print *, 'Collectives: MPI-staged hook (ranks share GPUs, TFX_COMM=mpi, or RCCL could not connect the ranks).'
   end subroutine host_comm_setup
 
   ! a matrix piece (columns + values, device buffers) to / from another rank: GPU to GPU over RCCL, or staged through MPI

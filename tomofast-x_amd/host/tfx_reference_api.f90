@@ -207,7 +207,7 @@ contains
     if (.not. c_associated(api_ctx)) then
       ndev = tfx_device_count()
       if (ndev <= 0) call exit_MPI('No HIP device visible - the MI355X path has no CPU fallback.', rank, 0)
-      call api_check(tfx_create(int(mod(rank, ndev), c_int), c_null_ptr, api_ctx), 'tfx_create', rank)
+      call api_check(tfx_create(int(host_device_for_rank(), c_int), c_null_ptr, api_ctx), 'tfx_create', rank)
       if (nranks > 1) call host_comm_setup(api_ctx)
     endif
     ctx = api_ctx
@@ -438,20 +438,25 @@ contains
     end select
   end function problem_of
 
-  ! rows dealt out in blocks of ROW_BLOCK data, contiguously: this rank's data (row_a, row_b]
+  ! the data are dealt out by the reference's own rule (calculate_nelements_at_cpu, src/utils/parallel_tools.f90:46-63, used for the
+  ! rows in sensitivity_gravmag.F90:179-189): contiguous ranges of ndat / nbproc data, the remainder to the last rank - this
+  ! rank's data (row_a, row_b].  (Round 2 dealt whole 2048-row blocks: 7 vs 6 blocks on 8 ranks at the headline size.)
   subroutine my_row_blocks(ndat, myrank_, nbproc_, row_a, row_b)
     integer, intent(in) :: ndat, myrank_, nbproc_
     integer, intent(out) :: row_a, row_b
-    integer :: nblk, base, rem, b0, b1
-    nblk = (ndat + ROW_BLOCK - 1) / ROW_BLOCK
-    base = nblk / nbproc_
-    rem = mod(nblk, nbproc_)
-    b0 = myrank_ * base + min(myrank_, rem)
-    b1 = b0 + base
-    if (myrank_ < rem) b1 = b1 + 1
-    row_a = min(b0 * ROW_BLOCK, ndat)
-    row_b = min(b1 * ROW_BLOCK, ndat)
+    integer :: base
+    base = ndat / nbproc_
+    row_a = myrank_ * base
+    row_b = row_a + base
+    if (myrank_ == nbproc_ - 1) row_b = ndat
   end subroutine my_row_blocks
+
+  ! device pointer + byte offset
+  type(c_ptr) function ptr_plus(p, bytes)
+    type(c_ptr), intent(in) :: p
+    integer(c_int64_t), intent(in) :: bytes
+    ptr_plus = transfer(transfer(p, 0_c_intptr_t) + int(bytes, c_intptr_t), ptr_plus)
+  end function ptr_plus
 
   logical function write_sensit_rank_file_enabled(par, nnz_total)
     class(t_parameters_base), intent(in) :: par
@@ -850,34 +855,26 @@ contains
     class(t_parameters_base), intent(in) :: par
     type(t_kernel_state), intent(inout) :: k
     integer, intent(in) :: nel_at(:), myrank_, nbproc_
-    integer :: ndat, row_a, row_b, nrl, nblk, b, ga, gb, o, d, rr, base, rem, nloc, ndc, ndblk
-    integer, allocatable :: rows_at(:), row_displs(:), blk_owner(:)
+    integer :: ndat, row_a, row_b, nrl, nblk, b, ga, gb, sa, sb, o, d, rr, nloc, ndc, ra, rb
+    integer, allocatable :: rows_at(:), row_displs(:)
     integer(c_int64_t), allocatable :: bounds(:)
     integer(c_int32_t), allocatable, target :: cnt_loc(:, :), cnt_all(:, :), nel_blk(:)
-    integer(c_int64_t) :: n_in, n_out, got, mine
+    integer(c_int64_t) :: n_in, n_out, n_piece, off, got, mine
     type(c_ptr) :: dcols, dvals, scols, svals
-    ! matrix rows: ndc per datum (row = (i-1)*ndc + d); a rank's data range is whole blocks of ROW_BLOCK data, so its matrix rows
-    ! are whole row blocks of ROW_BLOCK rows
+    ! matrix rows: ndc per datum (row = (i-1)*ndc + d); rank rr built the rows [row_displs(rr+1), +rows_at(rr+1)) - any contiguous
+    ! range (my_row_blocks), so a row block of the matrix may have two (rarely more) contributors: their pieces are contiguous row
+    ! sub-ranges in rank order and land one behind the other in the receive buffer, which then holds the packed row block
     ndc = k%ndc
     ndat = par%ndata * ndc                       ! matrix rows of the kernel
     row_a = k%row_a * ndc; row_b = k%row_b * ndc
     nrl = row_b - row_a
     nloc = nel_at(myrank_ + 1)
     nblk = (ndat + ROW_BLOCK - 1) / ROW_BLOCK
-    allocate(rows_at(nbproc_), row_displs(nbproc_), blk_owner(nblk), bounds(nbproc_ + 1))
-    ndblk = (par%ndata + ROW_BLOCK - 1) / ROW_BLOCK       ! blocks of data, dealt out contiguously (my_row_blocks)
-    base = ndblk / nbproc_
-    rem = mod(ndblk, nbproc_)
-    b = 0
+    allocate(rows_at(nbproc_), row_displs(nbproc_), bounds(nbproc_ + 1))
     do rr = 0, nbproc_ - 1
-      d = base
-      if (rr < rem) d = d + 1
-      ga = min(b * ROW_BLOCK, par%ndata) * ndc             ! first / one-past-last matrix row of rank rr
-      gb = min((b + d) * ROW_BLOCK, par%ndata) * ndc
-      rows_at(rr + 1) = gb - ga
-      row_displs(rr + 1) = ga
-      if (gb > ga) blk_owner(ga / ROW_BLOCK + 1:(gb + ROW_BLOCK - 1) / ROW_BLOCK) = rr
-      b = b + d
+      call my_row_blocks(par%ndata, rr, nbproc_, ra, rb)
+      rows_at(rr + 1) = (rb - ra) * ndc
+      row_displs(rr + 1) = ra * ndc
     enddo
     bounds(1) = 0
     do rr = 1, nbproc_
@@ -894,36 +891,46 @@ contains
     do b = 1, nblk
       ga = (b - 1) * ROW_BLOCK
       gb = min(b * ROW_BLOCK, ndat)
-      o = blk_owner(b)
       n_in = 0
       do rr = ga + 1, gb
         n_in = n_in + cnt_all(myrank_ + 1, rr)
       enddo
       call api_check(tfx_device_malloc(api_ctx, 4 * max(n_in, 1_c_int64_t), dcols), 'tfx_device_malloc', myrank_)
       call api_check(tfx_device_malloc(api_ctx, 4 * max(n_in, 1_c_int64_t), dvals), 'tfx_device_malloc', myrank_)
-      if (o == myrank_) then
-        do d = 0, nbproc_ - 1
-          n_out = 0
-          do rr = ga + 1, gb
-            n_out = n_out + cnt_all(d + 1, rr)
-          enddo
-          if (n_out == 0) cycle
-          if (d == myrank_) then
-            call api_check(tfx_rowstore_pack(api_ctx, int(ga - row_a, c_int64_t), int(gb - ga, c_int64_t), bounds(d + 1), bounds(d + 2), &
-                                             dcols, dvals, n_out, got), 'tfx_rowstore_pack', myrank_)
-          else
-            call api_check(tfx_device_malloc(api_ctx, 4 * n_out, scols), 'tfx_device_malloc', myrank_)
-            call api_check(tfx_device_malloc(api_ctx, 4 * n_out, svals), 'tfx_device_malloc', myrank_)
-            call api_check(tfx_rowstore_pack(api_ctx, int(ga - row_a, c_int64_t), int(gb - ga, c_int64_t), bounds(d + 1), bounds(d + 2), &
-                                             scols, svals, n_out, got), 'tfx_rowstore_pack', myrank_)
-            call exchange_piece_send(api_ctx, d, n_out, scols, svals, 2 * b)
-            call api_check(tfx_device_free(api_ctx, scols), 'tfx_device_free', myrank_)
-            call api_check(tfx_device_free(api_ctx, svals), 'tfx_device_free', myrank_)
-          endif
+      off = 0
+      do o = 0, nbproc_ - 1
+        sa = max(ga, row_displs(o + 1))
+        sb = min(gb, row_displs(o + 1) + rows_at(o + 1))
+        if (sb <= sa) cycle
+        n_piece = 0                                              ! what I receive of rank o's rows of this block
+        do rr = sa + 1, sb
+          n_piece = n_piece + cnt_all(myrank_ + 1, rr)
         enddo
-      else if (n_in > 0) then
-        call exchange_piece_recv(api_ctx, o, n_in, dcols, dvals, 2 * b)
-      endif
+        if (o == myrank_) then
+          do d = 0, nbproc_ - 1
+            n_out = 0
+            do rr = sa + 1, sb
+              n_out = n_out + cnt_all(d + 1, rr)
+            enddo
+            if (n_out == 0) cycle
+            if (d == myrank_) then
+              call api_check(tfx_rowstore_pack(api_ctx, int(sa - row_a, c_int64_t), int(sb - sa, c_int64_t), bounds(d + 1), bounds(d + 2), &
+                                               ptr_plus(dcols, 4 * off), ptr_plus(dvals, 4 * off), n_out, got), 'tfx_rowstore_pack', myrank_)
+            else
+              call api_check(tfx_device_malloc(api_ctx, 4 * n_out, scols), 'tfx_device_malloc', myrank_)
+              call api_check(tfx_device_malloc(api_ctx, 4 * n_out, svals), 'tfx_device_malloc', myrank_)
+              call api_check(tfx_rowstore_pack(api_ctx, int(sa - row_a, c_int64_t), int(sb - sa, c_int64_t), bounds(d + 1), bounds(d + 2), &
+                                               scols, svals, n_out, got), 'tfx_rowstore_pack', myrank_)
+              call exchange_piece_send(api_ctx, d, n_out, scols, svals, 2 * b)
+              call api_check(tfx_device_free(api_ctx, scols), 'tfx_device_free', myrank_)
+              call api_check(tfx_device_free(api_ctx, svals), 'tfx_device_free', myrank_)
+            endif
+          enddo
+        else if (n_piece > 0) then
+          call exchange_piece_recv(api_ctx, o, n_piece, ptr_plus(dcols, 4 * off), ptr_plus(dvals, 4 * off), 2 * b)
+        endif
+        off = off + n_piece
+      enddo
       allocate(nel_blk(gb - ga))
       nel_blk = cnt_all(myrank_ + 1, ga + 1:gb)
       call api_check(tfx_matrix_append_rows(api_ctx, int(ga, c_int64_t), int(gb - ga, c_int64_t), dcols, dvals, nel_blk), &

@@ -21,11 +21,11 @@ TFX_E = {-1: "TFX_E_ARG", -2: "TFX_E_HIP", -3: "TFX_E_GEOMETRY", -4: "TFX_E_STAT
 # every symbol include/tfx.h declares (tests check the library exports exactly these)
 SYMBOLS = [
     "tfx_create", "tfx_destroy", "tfx_last_error", "tfx_device_info", "tfx_device_count", "tfx_copy", "tfx_device_malloc", "tfx_device_free", "tfx_set_allreduce", "tfx_set_allgatherv", "tfx_set_grid",
-    "tfx_comm_unique_id", "tfx_comm_init_rccl", "tfx_comm_destroy", "tfx_comm_allreduce", "tfx_comm_group_begin", "tfx_comm_group_end",
+    "tfx_comm_unique_id", "tfx_comm_init_rccl", "tfx_comm_destroy", "tfx_comm_abort", "tfx_comm_info", "tfx_comm_allreduce", "tfx_comm_group_begin", "tfx_comm_group_end",
     "tfx_comm_send", "tfx_comm_recv", "tfx_comm_barrier",
     "tfx_column_weight_type1", "tfx_column_weight_type2", "tfx_column_weight_type3", "tfx_prism_rows_gz", "tfx_prism_rows_mag", "tfx_prism_rows", "tfx_wavelet", "tfx_compress_row",
     "tfx_build_kernel_grav", "tfx_build_kernel_mag", "tfx_build_kernel", "tfx_select_problem",
-    "tfx_matrix_upload_csr", "tfx_matrix_info", "tfx_matrix_download_csr", "tfx_matrix_free", "tfx_matrix_scale_rows",
+    "tfx_matrix_upload_csr", "tfx_matrix_info", "tfx_matrix_format", "tfx_matrix_download_csr", "tfx_matrix_free", "tfx_matrix_scale_rows",
     "tfx_cons_upload_csr", "tfx_cons_clear", "tfx_rowstore_build", "tfx_rowstore_build_ex", "tfx_rowstore_build_comp", "tfx_rowstore_counts", "tfx_rowstore_pack",
     "tfx_rowstore_free", "tfx_matrix_begin", "tfx_matrix_append_rows", "tfx_matrix_finish",
     "tfx_partition_columns", "tfx_spmv", "tfx_spmtv", "tfx_lsqr_solve", "tfx_lsqr_begin", "tfx_lsqr_iterate",

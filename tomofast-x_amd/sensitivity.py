@@ -72,10 +72,9 @@ class Context:
             self._ghook = None
             check(self._lib.tfx_set_allgatherv(self._h, C.cast(None, L.ALLGATHERV_FN)))
             return
-        nranks = self.nranks
-
         def tramp(user, send, nsend, recv, counts, displs, stream):
             try:
+                nranks = self.nranks            # read at call time: the hook may be set before the rank count is known
                 fn(int(send or 0), int(nsend), int(recv or 0), [int(counts[r]) for r in range(nranks)],
                    [int(displs[r]) for r in range(nranks)], int(stream or 0))
                 return 0
@@ -101,6 +100,21 @@ class Context:
 
     def comm_destroy(self):
         check(self._lib.tfx_comm_destroy(self._h))
+        if self._hook is None:
+            self.rank, self.nranks = 0, 1
+
+    def comm_abort(self):
+        """Drops a (possibly half-open) communicator without the peers' hand-shake: the failure leg of the start-up ladder."""
+        check(self._lib.tfx_comm_abort(self._h))
+        if self._hook is None:
+            self.rank, self.nranks = 0, 1
+
+    def comm_info(self):
+        """dict(rccl_ranks, rccl_rank, rccl_device, rccl_version, librccl): what the communicator itself reports + which RCCL serves it."""
+        n, r, d, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        path = C.create_string_buffer(1024)
+        check(self._lib.tfx_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d), C.byref(v), path, 1024))
+        return dict(rccl_ranks=n.value, rccl_rank=r.value, rccl_device=d.value, rccl_version=v.value, librccl=path.value.decode())
 
     def comm_allreduce(self, dev_buf, n, dtype="f64"):
         check(self._lib.tfx_comm_allreduce(self._h, ptr(dev_buf), C.c_int64(n), {"f64": 0, "i32": 1, "i64": 2}[dtype]))
@@ -343,6 +357,11 @@ class Context:
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         check(self._lib.tfx_matrix_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(nrows=a.value, ncols=b.value, nnz=c.value, device_bytes=d.value)
+
+    def matrix_format(self):
+        b, n, sb, adj = C.c_double(), C.c_int64(), C.c_int64(), C.c_int()
+        check(self._lib.tfx_matrix_format(self._h, C.byref(b), C.byref(n), C.byref(sb), C.byref(adj)))
+        return dict(bytes_per_entry=b.value, stored_entries=n.value, stream_bytes=sb.value, adjoint_copy=bool(adj.value))
 
     def matrix_download_csr(self):
         info = self.matrix_info()

@@ -4,7 +4,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-export TFX_BENCH_BACKEND=gloo TFX_BENCH_SHARE_GPU=1
+# (ranks whose LOCAL_RANK exceeds the visible GPUs share GPU 0: the start-up ladder's pre-flight sends every rank to the hook rung)
 for n in 2 4 8; do
 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29700+n)) bench.py --gpus $n --steps 10 --warmup 2 --workload medium --no-cpu 2> /tmp/reh_$n.err | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('n', d['n_gpus'], 'it/s', d['value'], 'build', d['build_s'], d['config'].get('build_mode'), d.get('scaling'))"
 tail -2 /tmp/reh_$n.err | cut -c1-200
