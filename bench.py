@@ -114,6 +114,7 @@ def main():
         ctx.debug_set("fwd_group", int(os.environ["TFX_FWD_GROUP"]))
     if os.environ.get("TFX_ITEMS_PER_CU"):       # tuning knob: work items per CU the tile list is cut into
         ctx.debug_set("items_per_cu", int(os.environ["TFX_ITEMS_PER_CU"]))
+    # (TFX_ADJ_COPY=0/1/2 is read by the library itself: transposed copy of the tiles for the adjoint product - never / always / when it fits)
     info = ctx.device_info()
     log("device %s, %d CUs, %.0f GB; workload %s" % (info["name"], info["cus"], info["hbm_bytes"] / 1e9, w["desc"]))
     ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
@@ -208,6 +209,8 @@ def main():
     # ---- roofline of the dominant kernel (rank 0's share of the matrix)
     nnz_loc = minfo["nnz"]
     names = ["k_spmv_fwd (compressed SpMV, b += S x)", "k_spmv_adj (compressed SpMtV, b += S^T x)"]
+    if w["ctype"] > 0 and ctx.matrix_format().get("adjoint_copy"):
+        names[1] = "k_spmv_fwd on the transposed copy of the tiles (compressed SpMtV, b += S^T x)"
     if w["ctype"] == 0:
         names = ["k_dense_fwd (dense fp32 block, b += S x)", "k_dense_adj (dense fp32 block, b += S^T x)"]
     roof = None

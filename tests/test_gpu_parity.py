@@ -527,6 +527,79 @@ def test_matrix_scale_rows_is_the_reload_scaling(ctx):
     assert np.array_equal(back[0], rp) and np.array_equal(back[1], cols) and bits_equal(back[2], want.astype(np.float32))
 
 
+@pytest.mark.parametrize("shape", CSR_SHAPES + [(2049, 4097, 40, False), (1, 16385, 900, False), (9000, 70, 5, False)])
+def test_adjoint_on_the_transposed_copy(ctx, shape):
+    """Debug key "adj_copy" = 1: the matrix gets a transposed copy of its tiles (built on the device from the tiles themselves) and
+    b (+)= S^T x runs as the FORWARD kernel on that copy - no LDS atomic per non-zero (add_trans_mult_vector,
+    sparse_matrix.f90:391-405).  Same results as the one-copy adjoint kernel and the oracle: overwrite and accumulate forms, the
+    adjoint identity, bit-reproducible in deterministic mode, the reload scaling applied to both copies, explicit zeros dropped."""
+    nrows, ncols, mean_nnz, clustered = shape
+    rng = np.random.default_rng(nrows * 11 + ncols)
+    S = random_csr(rng, nrows, ncols, mean_nnz, clustered=clustered)
+    x, y = rng.standard_normal(ncols), rng.standard_normal(nrows)
+    absS = (S[0], S[1], np.abs(S[2]))
+    reft = orc.spmtv(*S, y, ncols)
+    tol = 1e-12 * orc.spmtv(*absS, np.abs(y), ncols) + 1e-300
+    ctx.debug_set("adj_copy", 0)
+    ctx.matrix_upload_csr(nrows, ncols, *S)
+    assert ctx.debug_set("has_adj_copy") == 0 and not ctx.matrix_format()["adjoint_copy"]
+    one_copy = ctx.trans_mult_vector(y)
+    bytes_one = ctx.matrix_info()["device_bytes"]
+    ctx.debug_set("adj_copy", 1)
+    try:
+        ctx.matrix_upload_csr(nrows, ncols, *S)
+        assert ctx.debug_set("has_adj_copy") == 1 and ctx.matrix_format()["adjoint_copy"]
+        assert ctx.matrix_info()["device_bytes"] > 1.5 * bytes_one
+        back = ctx.matrix_download_csr()
+        assert np.array_equal(back[0], S[0]) and np.array_equal(back[1], S[1]) and bits_equal(back[2], S[2])
+        bt = ctx.trans_mult_vector(y)
+        assert np.all(np.abs(bt - reft) <= tol) and np.all(np.abs(bt - one_copy) <= 2 * tol)
+        t0 = rng.standard_normal(ncols)
+        assert np.all(np.abs(ctx.trans_mult_vector(y, t0) - (t0 + reft)) <= tol + 1e-15 * np.abs(t0))
+        b = ctx.mult_vector(x)
+        assert np.all(np.abs(b - orc.spmv(*S, x)) <= 1e-12 * orc.spmv(*absS, np.abs(x)) + 1e-300)
+        assert abs(np.dot(b, y) - np.dot(x, bt)) <= 1e-11 * np.dot(orc.spmv(*absS, np.abs(x)), np.abs(y))
+        ctx.debug_set("deterministic", 1)
+        a = [ctx.trans_mult_vector(y) for _ in range(3)]
+        ctx.debug_set("deterministic", 0)
+        assert bits_equal(a[1], a[0]) and bits_equal(a[2], a[0]) and np.all(np.abs(a[0] - reft) <= tol)
+        scale = rng.uniform(0.1, 30.0, nrows)
+        ctx.matrix_scale_rows(scale)
+        Ss = (S[0], S[1], (S[2] * np.repeat(scale.astype(np.float32), np.diff(S[0]))).astype(np.float32))
+        back = ctx.matrix_download_csr()
+        assert bits_equal(back[2], Ss[2])
+        refs = orc.spmtv(*Ss, y, ncols)
+        assert np.all(np.abs(ctx.trans_mult_vector(y) - refs) <= 1e-12 * orc.spmtv(Ss[0], Ss[1], np.abs(Ss[2]), np.abs(y), ncols) + 1e-300)
+        # explicit zeros are stored in S (and come back on download) but not in the copy: the product does not change
+        Sz = (S[0], S[1], S[2].copy())
+        Sz[2][::3] = 0.0
+        ctx.matrix_upload_csr(nrows, ncols, *Sz)
+        assert np.all(np.abs(ctx.trans_mult_vector(y) - orc.spmtv(*Sz, y, ncols)) <= tol)
+    finally:
+        ctx.debug_set("adj_copy", 2)
+        ctx.debug_set("deterministic", 0)
+
+
+def test_lsqr_with_the_adjoint_copy_matches_the_one_copy_solver(ctx, golden_dir):
+    """The solver sees no difference: same iterates (to the products' rounding) with the adjoint on the transposed copy, also for the
+    general constraint matrix C (it gets a copy too) - lsqr_solver2.F90:230-241."""
+    g = np.load(os.path.join(golden_dir, "e2e_haar.npz"))
+    N = int(g["nx"]) * int(g["ny"]) * int(g["nz"])
+    S = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
+    nd = S[0].size - 1
+    b = g["np1_data_observed"]
+    rng = np.random.default_rng(3)
+    diag, rhs = [np.full(N, np.float32(1e-7), np.float32)], [rng.standard_normal(N) * 1e-8]
+    out = {}
+    for mode in (0, 1):
+        ctx.debug_set("adj_copy", mode)
+        ctx.matrix_upload_csr(nd, N, *S)
+        out[mode] = ctx.lsqr_solve_sensit(b, 12, 1e-13, 0.0, 0.0, diag, rhs)
+    ctx.debug_set("adj_copy", 2)
+    assert out[0][1] == out[1][1] == 12
+    assert np.linalg.norm(out[0][0] - out[1][0]) <= 1e-10 * np.linalg.norm(out[0][0]) and abs(out[0][2] - out[1][2]) <= 1e-10 * out[0][2]
+
+
 def test_two_contexts_in_one_process(ctx):
     """A second context in the same process registers the large-LDS product kernels for itself (the attribute bookkeeping is per
     context, not a process-wide static) - both contexts give the oracle's products on a matrix that needs > 64 KB of LDS."""

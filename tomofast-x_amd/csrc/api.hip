@@ -26,6 +26,8 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (const char *e = getenv("TFX_DETERMINISTIC")) c->deterministic = atoi(e) != 0;     // like tfx_debug_set "deterministic"
+    if (const char *e = getenv("TFX_ADJ_COPY")) c->adj_copy = std::max(0, std::min(2, atoi(e)));   // like tfx_debug_set "adj_copy"
+    if (const char *e = getenv("TFX_ADJ_COPY_MIN_NNZ")) c->adj_copy_min_nnz = atoll(e);
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = atoi(e) != 0;
     if (const char *e = getenv("TFX_GEN_WGS_PER_CU")) c->gen_wgs_per_cu = atoi(e);
     if (const char *e = getenv("TFX_GEN_AFTER_WAVELET")) c->gen_after_wavelet = atoi(e) != 0;
@@ -159,6 +161,15 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         ctx->deterministic = value != 0;
         return 0;
     }
+    if (!strcmp(key, "adj_copy")) {             // transposed copy for the adjoint of matrices finished from now on: 0 never, 1 always, 2 automatic
+        ctx->adj_copy = std::max(0, std::min(2, value));
+        return 0;
+    }
+    if (!strcmp(key, "adj_copy_min_nnz")) {     // automatic mode: matrices of at least this many stored entries get the copy
+        ctx->adj_copy_min_nnz = value;
+        return 0;
+    }
+    if (!strcmp(key, "has_adj_copy")) return (ctx->selmat().T && ctx->selmat().T->valid) ? 1 : 0;     // query
     if (!strcmp(key, "chunk_exponent_span")) {  // diagnostics: per mille of the chunks whose non-zero values span <= `value` binades
         int64_t fit = 0, total = 0;
         unsigned int hist[34];
@@ -322,12 +333,12 @@ int tfx_matrix_format(tfx_ctx *ctx, double *bytes_per_entry, int64_t *stored_ent
     int64_t stored = 0;
     for (const TileMeta &t : m.h_tiles) stored += t.cnt;
     const int64_t bytes = m.is_dense ? (int64_t)m.dense.bytes()
-                                     : m.n_entries * 4 + (m.n_entries / CHUNK) * (int64_t)(SLOT_WORDS * 4 + MASK_WORDS * 8);
+                                     : (m.n_entries / CHUNK) * (int64_t)REC_BYTES;
     if (m.is_dense) stored = m.nrows * m.ncols;
     if (bytes_per_entry) *bytes_per_entry = m.is_dense ? 4.0 : 4.0 + 4.0 * SLOT_WORDS / CHUNK + 8.0 * MASK_WORDS / CHUNK;
     if (stored_entries) *stored_entries = stored;
     if (stream_bytes) *stream_bytes = bytes;
-    if (adjoint_copy) *adjoint_copy = 0;
+    if (adjoint_copy) *adjoint_copy = (m.T && m.T->valid) ? 1 : 0;
     return 0;
 }
 
@@ -364,14 +375,8 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
         return 0;
     }
     const size_t nch = (size_t)(m.n_entries / CHUNK);
-    std::vector<uint32_t> hs(nch * SLOT_WORDS);
-    std::vector<uint64_t> hm(nch * MASK_WORDS);
-    std::vector<float> hv((size_t)m.n_entries);
-    if (m.n_entries > 0) {
-        TFX_HIP(hipMemcpy(hs.data(), m.slots.p, hs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        TFX_HIP(hipMemcpy(hm.data(), m.rowmask.p, hm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        TFX_HIP(hipMemcpy(hv.data(), m.vals.p, (size_t)m.n_entries * sizeof(float), hipMemcpyDeviceToHost));
-    }
+    std::vector<char> hrec(nch * REC_BYTES);            // the chunk records: values, 12-bit slots, row-start masks (common.h)
+    if (m.n_entries > 0) TFX_HIP(hipMemcpy(hrec.data(), m.rec.p, hrec.size(), hipMemcpyDeviceToHost));
     std::vector<int32_t> hrow0(nch);
     if (!hrow0.empty())
         TFX_HIP(hipMemcpy(hrow0.data(), m.chunk_row0.p, hrow0.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -379,7 +384,7 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
     auto slot_at = [&](int64_t e) -> uint32_t {
         const int64_t chunk = e >> 9;
         const int i = (int)(e & (CHUNK - 1)), lane = i >> 3, k = i & 7, bit = 12 * k, wi = bit >> 5, sh = bit & 31;
-        const uint32_t *w = hs.data() + chunk * SLOT_WORDS + lane * 3;
+        const uint32_t *w = chunk_slots((const char *)hrec.data(), chunk) + lane * 3;
         uint32_t v = w[wi] >> sh;
         if (sh > 20) v |= w[wi + 1] << (32 - sh);
         return v & 0xfffu;
@@ -387,7 +392,7 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
     auto flag_at = [&](int64_t e) -> bool {
         const int64_t chunk = e >> 9;
         const int i = (int)(e & (CHUNK - 1)), lane = i >> 3, k = i & 7;
-        return (hm[(size_t)(chunk * MASK_WORDS + k)] >> lane) & 1ull;
+        return (chunk_masks((const char *)hrec.data(), chunk)[k] >> lane) & 1ull;
     };
     // tiles sorted by (rb, t)
     std::vector<TileMeta> tl = m.h_tiles;
@@ -408,7 +413,7 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
                 const bool flag = flag_at(tm.off + e);
                 const uint32_t slot = slot_at(tm.off + e);
                 if (flag) cur += 1;
-                float v = hv[(size_t)val_pos(tm.off + e)];
+                float v = chunk_vals((const char *)hrec.data(), (tm.off + e) >> 9)[val_pos(tm.off + e) & (CHUNK - 1)];
                 bool marker = flag && v == 0.0f && slot == 0 && (e + 1 == tm.cnt || flag_at(tm.off + e + 1));
                 // a marker is indistinguishable from a stored exact zero in column 0 of the tile that is alone in
                 // its row segment; the reference never stores zeros (sparse_matrix.f90:219, threshold >= 1e-30)

@@ -70,6 +70,19 @@ struct DBuf {
 constexpr int CHUNK = 512;            // entries per chunk = 64 lanes x 8 entries
 constexpr int SLOT_WORDS = 192;       // dwords of packed 12-bit column slots per chunk (lane L: words 3L..3L+2 = its 8 slots)
 constexpr int MASK_WORDS = 8;         // uint64 row-start masks per chunk: word k, bit L = "entry k of lane L starts a new row"
+// The three per-entry streams of a chunk are stored as ONE contiguous record [512 values | 192 slot words | 8 mask words] = 2880 bytes:
+// a product reads a single sequential stream (tools/read_bw_probe.hip on this part: three separate arrays 6.71-6.78 TB/s, the same
+// loads from interleaved records 6.89-6.93 TB/s).
+constexpr int REC_SLOT_OFF = CHUNK * 4;                       // byte offset of the slot words inside a record
+constexpr int REC_MASK_OFF = REC_SLOT_OFF + SLOT_WORDS * 4;   // byte offset of the row-start masks
+constexpr int REC_BYTES = REC_MASK_OFF + MASK_WORDS * 8;      // 2880
+static_assert(REC_BYTES % 64 == 0, "records keep the 16-byte value loads and the 64-byte mask block aligned");
+__host__ __device__ inline float *chunk_vals(char *rec, int64_t chunk) { return reinterpret_cast<float *>(rec + chunk * REC_BYTES); }
+__host__ __device__ inline uint32_t *chunk_slots(char *rec, int64_t chunk) { return reinterpret_cast<uint32_t *>(rec + chunk * REC_BYTES + REC_SLOT_OFF); }
+__host__ __device__ inline unsigned long long *chunk_masks(char *rec, int64_t chunk) { return reinterpret_cast<unsigned long long *>(rec + chunk * REC_BYTES + REC_MASK_OFF); }
+__host__ __device__ inline const float *chunk_vals(const char *rec, int64_t chunk) { return reinterpret_cast<const float *>(rec + chunk * REC_BYTES); }
+__host__ __device__ inline const uint32_t *chunk_slots(const char *rec, int64_t chunk) { return reinterpret_cast<const uint32_t *>(rec + chunk * REC_BYTES + REC_SLOT_OFF); }
+__host__ __device__ inline const uint64_t *chunk_masks(const char *rec, int64_t chunk) { return reinterpret_cast<const uint64_t *>(rec + chunk * REC_BYTES + REC_MASK_OFF); }
 constexpr int TC_MAX = 4096;          // columns per column tile (12-bit local column; the x tile is 32 KB of LDS)
 constexpr int RB_MAX = 2048;          // rows per (storage) row block
 constexpr int FWD_GROUP_MAX = 4;      // the forward product walks up to this many row blocks per staged x tile (row sums: 64 KB of LDS)
@@ -78,7 +91,7 @@ constexpr int FWD_GROUP_MAX = 4;      // the forward product walks up to this ma
 // coefficients sit on index lattices (multiples of 2^l per axis); without the fold the columns of one LDS instruction are
 // often congruent modulo 16 and pile onto one bank pair.  Stored pre-swizzled, it costs the product kernels nothing.
 __host__ __device__ inline int col_slot(int i) { return i ^ (((i >> 4) ^ (i >> 8)) & 15); }
-// Position of entry e (lane L = (e & 511) >> 3 of its chunk, k = e & 7) in the value stream: the chunk's 2 KB hold k = 0..3 of
+// Position of entry e (lane L = (e & 511) >> 3 of its chunk, k = e & 7) among the values (val_pos(e) & 511 inside its chunk's record): the chunk's 2 KB hold k = 0..3 of
 // all lanes first (lane L at byte 16 L), then k = 4..7 - a wave reads its chunk with two loads of 16 bytes per lane at a lane
 // stride of 16 bytes.  (With the lane's 8 values in one 32-byte record both loads touch every cache line of the chunk and the
 // stream tops out at 6.3 TB/s; this order reaches 6.7 in tools/read_bw_probe.hip.)
@@ -110,9 +123,7 @@ struct TiledMatrix {
     int TC = TC_MAX, RB = RB_MAX;
     int ntc = 0, nrb = 0;
     int fwd_group = 1;            // row blocks per forward super block (shared x tile)
-    DBuf<uint32_t> slots;         // SLOT_WORDS per chunk
-    DBuf<uint64_t> rowmask;       // MASK_WORDS per chunk
-    DBuf<float> vals;
+    DBuf<char> rec;               // REC_BYTES per chunk: values, packed 12-bit slots, row-start masks
     int64_t n_entries = 0;        // used (padded) entries
     int64_t cap_entries = 0;      // allocated entries
     DBuf<int32_t> chunk_row0;     // per chunk: local row of the entry preceding the chunk
@@ -133,6 +144,15 @@ struct TiledMatrix {
     DBuf<float> dense;
     DBuf<double> dense_partial;   // forward: [nchunks][nrows] partial row sums
     bool valid = false;
+    // Transposed copy for the adjoint product ("adjoint copy"): S^T in the same tiled layout, so b += S^T x is the
+    // FORWARD kernel on it - u rows gathered from LDS, column sums merged in registers and by the segmented wave reduction - instead
+    // of one LDS fp64 atomic per non-zero.  Optional (it doubles the matrix memory): ctx->adj_copy.
+    TiledMatrix *T = nullptr;
+    bool is_transpose_copy = false;
+    ~TiledMatrix() { delete T; }
+    TiledMatrix() = default;
+    TiledMatrix(const TiledMatrix &) = delete;
+    TiledMatrix &operator=(const TiledMatrix &) = delete;
     size_t device_bytes() const;
     void release_storage();       // frees every device buffer and clears the host-side lists
 };
@@ -210,6 +230,15 @@ struct tfx_ctx {
     int gen_grid_limit = 0;           // (set around the generator launches of the overlapped build)
     int build_overlap = 1;            // debug key "build_overlap": row generator on its own stream, one batch ahead of the wavelet / compaction
     int items_per_cu = 16;            // debug key "items_per_cu": work items per CU the tile list is cut into
+    // Adjoint on a transposed copy of the tiles: 0 never, 1 always (any size: tests), 2 automatic = for matrices of at least
+    // adj_copy_min_nnz stored entries when the device has room for the second copy (debug key "adj_copy" / TFX_ADJ_COPY)
+    int adj_copy = 2;
+    int64_t adj_copy_min_nnz = (int64_t)1 << 26;
+    struct TransposeScratch {
+        tfx::DBuf<int32_t> cnt, nel, tcols, tids, toff;
+        tfx::DBuf<int64_t> rowoff, totals;
+        tfx::DBuf<float> tvals;
+    } trs;
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
     bool deterministic = false;       // debug: single-wave workgroups in the two products -> LDS atomics in program order
     size_t wave_lds_attr[4] = {0, 0, 0, 0};   // the same for the four wavelet axis kernels (Haar / D4 x forward / inverse)
@@ -225,7 +254,7 @@ struct tfx_ctx {
 namespace tfx {
 // matrix.hip
 int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const int32_t *d_cols, const float *d_vals,
-                       const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen);
+                       const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen, int64_t packed_total = 0);
 int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper);
 int matrix_finish(tfx_ctx *ctx);
 int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);     // b (+)= S x   (device pointers)
@@ -234,6 +263,7 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
 int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add);
 int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols);
 int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale);
+int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m);    // (no-op unless ctx->adj_copy asks for it and the copy fits)
 int chunk_exponent_stats(tfx_ctx *ctx, TiledMatrix &m, int span, int64_t *fit, int64_t *total, unsigned int *hist34);
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);
 void prof_drain(tfx_ctx *ctx);

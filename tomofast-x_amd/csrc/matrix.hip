@@ -33,17 +33,20 @@ thread_local std::string g_last_error;
 
 size_t TiledMatrix::device_bytes() const
 {
-    return slots.bytes() + rowmask.bytes() + vals.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
+    return rec.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
            fwd_order.bytes() + adj_order.bytes() + fwd_partial.bytes() + adj_partial.bytes() + adj_nslots.bytes() +
-           adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes() + dense.bytes() + dense_partial.bytes();
+           adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes() + dense.bytes() + dense_partial.bytes() +
+           (T ? T->device_bytes() : 0);
 }
 
 void TiledMatrix::release_storage()
 {
-    slots.release(); rowmask.release(); vals.release(); chunk_row0.release(); tiles.release(); fwd.release(); adj.release();
+    rec.release(); chunk_row0.release(); tiles.release(); fwd.release(); adj.release();
     fwd_order.release(); adj_order.release(); fwd_partial.release(); adj_partial.release();
     fwd_nslots.release(); fwd_pbase.release(); adj_nslots.release(); adj_pbase.release();
     dense.release(); dense_partial.release();
+    delete T;
+    T = nullptr;
     h_tiles.clear(); h_fwd.clear(); h_adj.clear();
     is_dense = false;
     n_entries = cap_entries = 0;
@@ -130,33 +133,32 @@ __global__ void k_tile_scan(const int32_t *__restrict__ pos, int nr, int ntc, in
 }
 
 // One entry into the three streams (the destination range was zeroed: bits are OR-ed in, neighbours belong to other threads).
-__device__ __forceinline__ void put_entry(uint32_t *__restrict__ slots, unsigned long long *__restrict__ rowmask,
-                                          float *__restrict__ vals, int64_t e, uint32_t slot, bool rowstart, float v)
+__device__ __forceinline__ void put_entry(char *__restrict__ rec, int64_t e, uint32_t slot, bool rowstart, float v)
 {
     const int64_t chunk = e >> 9;
     const int i = (int)(e & (CHUNK - 1)), lane = i >> 3, k = i & 7;
-    vals[val_pos(e)] = v;
+    chunk_vals(rec, chunk)[val_pos(e) & (CHUNK - 1)] = v;
     if (slot) {
-        uint32_t *w = slots + chunk * SLOT_WORDS + lane * 3;
+        uint32_t *w = chunk_slots(rec, chunk) + lane * 3;
         const int bit = 12 * k, wi = bit >> 5, sh = bit & 31;
         atomicOr(w + wi, slot << sh);
         if (sh > 20) atomicOr(w + wi + 1, slot >> (32 - sh));
     }
-    if (rowstart) atomicOr(rowmask + chunk * MASK_WORDS + k, 1ull << lane);
+    if (rowstart) atomicOr(chunk_masks(rec, chunk) + k, 1ull << lane);
 }
 
 // The same through a 16-bit staging array (one plain store per entry; k_pack_slots packs it afterwards): the row block's scatter
 // writes every slot exactly once, so no atomics are needed for the slots - only the (rare) row-start bits stay atomic.
-__device__ __forceinline__ void put_entry16(uint16_t *__restrict__ tmp16, int64_t base, unsigned long long *__restrict__ rowmask,
-                                            float *__restrict__ vals, int64_t e, uint32_t slot, bool rowstart, float v)
+__device__ __forceinline__ void put_entry16(uint16_t *__restrict__ tmp16, int64_t base, char *__restrict__ rec, int64_t e, uint32_t slot,
+                                            bool rowstart, float v)
 {
-    vals[val_pos(e)] = v;
+    chunk_vals(rec, e >> 9)[val_pos(e) & (CHUNK - 1)] = v;
     tmp16[e - base] = (uint16_t)slot;
-    if (rowstart) atomicOr(rowmask + (e >> 9) * MASK_WORDS + (e & 7), 1ull << ((e & (CHUNK - 1)) >> 3));
+    if (rowstart) atomicOr(chunk_masks(rec, e >> 9) + (e & 7), 1ull << ((e & (CHUNK - 1)) >> 3));
 }
 
 // 8 staged 16-bit slots of a lane -> its three dwords of 12-bit slots
-__global__ void k_pack_slots(const uint16_t *__restrict__ tmp16, int64_t base, int64_t nlanes, uint32_t *__restrict__ slots)
+__global__ void k_pack_slots(const uint16_t *__restrict__ tmp16, int64_t base, int64_t nlanes, char *__restrict__ rec)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nlanes; i += (int64_t)gridDim.x * blockDim.x) {
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -164,7 +166,7 @@ __global__ void k_pack_slots(const uint16_t *__restrict__ tmp16, int64_t base, i
         const uint32_t s0 = w.x & 0xfffu, s1 = (w.x >> 16) & 0xfffu, s2 = w.y & 0xfffu, s3 = (w.y >> 16) & 0xfffu;
         const uint32_t s4 = w.z & 0xfffu, s5 = (w.z >> 16) & 0xfffu, s6 = w.w & 0xfffu, s7 = (w.w >> 16) & 0xfffu;
         const int64_t e = base + i * 8;
-        uint32_t *o = slots + (e >> 9) * SLOT_WORDS + ((e & (CHUNK - 1)) >> 3) * 3;
+        uint32_t *o = chunk_slots(rec, e >> 9) + ((e & (CHUNK - 1)) >> 3) * 3;
         o[0] = s0 | (s1 << 12) | (s2 << 24);
         o[1] = (s2 >> 8) | (s3 << 4) | (s4 << 16) | (s5 << 28);
         o[2] = (s5 >> 4) | (s6 << 8) | (s7 << 20);
@@ -175,8 +177,7 @@ __global__ void k_pack_slots(const uint16_t *__restrict__ tmp16, int64_t base, i
 __global__ void k_tile_scatter(const int32_t *__restrict__ cols, const float *__restrict__ vals,
                                const int32_t *__restrict__ nel, const int64_t *__restrict__ rowoff, int ntc, int TC, int nr,
                                const int32_t *__restrict__ pos, const int32_t *__restrict__ segoff,
-                               const int64_t *__restrict__ tile_off, uint16_t *__restrict__ tmp16, int64_t base,
-                               unsigned long long *__restrict__ rowmask, float *__restrict__ ovals)
+                               const int64_t *__restrict__ tile_off, uint16_t *__restrict__ tmp16, int64_t base, char *__restrict__ rec)
 {
     int r = blockIdx.y;
     int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,21 +187,45 @@ __global__ void k_tile_scatter(const int32_t *__restrict__ cols, const float *__
     int t = c / TC;
     int p0 = pos[(int64_t)r * (ntc + 1) + t];
     int64_t dst = tile_off[t] + segoff[(int64_t)t * (nr + 1) + r] + (j - p0);
-    put_entry16(tmp16, base, rowmask, ovals, dst, (uint32_t)col_slot(c - t * TC), j == p0, vals[src]);
+    put_entry16(tmp16, base, rec, dst, (uint32_t)col_slot(c - t * TC), j == p0, vals[src]);
+}
+
+// The same for rows that are PACKED one behind the other (rowoff[r + 1] = rowoff[r] + nel[r]; the rows of a transposed block have
+// lengths from 0 to the whole data set, so a grid over (longest row x rows) would be almost empty): one thread per entry of the
+// packed buffer, its row by binary search in rowoff[].
+__global__ void k_tile_scatter_packed(const int32_t *__restrict__ cols, const float *__restrict__ vals, const int64_t *__restrict__ rowoff,
+                                      int64_t total, int ntc, int TC, int nr, const int32_t *__restrict__ pos,
+                                      const int32_t *__restrict__ segoff, const int64_t *__restrict__ tile_off,
+                                      uint16_t *__restrict__ tmp16, int64_t base, char *__restrict__ rec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = nr - 1;                    // largest r with rowoff[r] <= i (empty rows share their offset with the next row: take the last)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rowoff[mid] <= i) lo = mid;
+        else hi = mid - 1;
+    }
+    const int r = lo;
+    const int j = (int)(i - rowoff[r]);
+    const int32_t c = cols[i];
+    const int t = c / TC;
+    const int p0 = pos[(int64_t)r * (ntc + 1) + t];
+    const int64_t dst = tile_off[t] + segoff[(int64_t)t * (nr + 1) + r] + (j - p0);
+    put_entry16(tmp16, base, rec, dst, (uint32_t)col_slot(c - t * TC), j == p0, vals[i]);
 }
 
 // Markers for empty rows strictly between the first and last non-empty row of a tile.  grid = (ntc), block 256.
 __global__ void k_tile_markers(const int32_t *__restrict__ pos, int nr, int ntc, const int32_t *__restrict__ segoff,
                                const int32_t *__restrict__ first_ne, const int32_t *__restrict__ last_ne,
-                               const int64_t *__restrict__ tile_off, uint32_t *__restrict__ slots,
-                               unsigned long long *__restrict__ rowmask, float *__restrict__ ovals)
+                               const int64_t *__restrict__ tile_off, char *__restrict__ rec)
 {
     int t = blockIdx.x;
     int f = first_ne[t], l = last_ne[t];
     if (f < 0) return;
     for (int r = f + 1 + threadIdx.x; r < l; r += blockDim.x) {
         int cnt = pos[(int64_t)r * (ntc + 1) + t + 1] - pos[(int64_t)r * (ntc + 1) + t];
-        if (cnt == 0) put_entry(slots, rowmask, ovals, tile_off[t] + segoff[(int64_t)t * (nr + 1) + r], 0u, true, 0.0f);
+        if (cnt == 0) put_entry(rec, tile_off[t] + segoff[(int64_t)t * (nr + 1) + r], 0u, true, 0.0f);
     }
 }
 
@@ -372,9 +397,7 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
     int64_t markers = std::min<int64_t>((int64_t)nrows * m.ntc, (nnz_upper / 2 + 1) * (int64_t)m.RB);
     int64_t cap = nnz_upper + markers + (int64_t)m.nrb * m.ntc * CHUNK + CHUNK;
     cap = (cap + CHUNK - 1) / CHUNK * CHUNK;
-    TFX_TRY(m.vals.alloc((size_t)cap));
-    TFX_TRY(m.slots.alloc((size_t)(cap / CHUNK) * SLOT_WORDS));
-    TFX_TRY(m.rowmask.alloc((size_t)(cap / CHUNK) * MASK_WORDS));
+    TFX_TRY(m.rec.alloc((size_t)(cap / CHUNK) * REC_BYTES));
     TFX_TRY(m.chunk_row0.alloc((size_t)(cap / CHUNK)));
     m.cap_entries = cap;
     m.n_entries = 0;
@@ -385,8 +408,9 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 // Appends the tiles of one row block.  Row r of the block has d_nel[r] entries starting at d_cols/d_vals +
 // d_rowoff[r] (columns ascending, 0-based local); maxlen >= max d_nel.  row_begin must be a multiple of RB, nr <= RB.
 // Everything is queued on the ctx stream; the inputs may be reused by work queued on that stream afterwards.
+// packed_total > 0: the rows lie packed one behind the other (d_rowoff[r + 1] = d_rowoff[r] + d_nel[r]) and hold that many entries.
 int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int32_t *d_cols, const float *d_vals,
-                       const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen)
+                       const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen, int64_t packed_total)
 {
     TiledMatrix &m = *ctx->target;
     hipStream_t s = ctx->stream;
@@ -445,21 +469,22 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
     if (ntc > 0 && cur > m.n_entries) {
         // zero the destination range (padding: slot 0 / no flag / value 0; the scatter ORs its bits in)
         const int64_t c0 = m.n_entries / CHUNK, c1 = cur / CHUNK;
-        TFX_HIP(hipMemsetAsync(m.vals.p + m.n_entries, 0, (size_t)(cur - m.n_entries) * sizeof(float), s));
+        TFX_HIP(hipMemsetAsync(m.rec.p + c0 * REC_BYTES, 0, (size_t)(c1 - c0) * REC_BYTES, s));
         TFX_TRY(sc.tmp16.ensure((size_t)(cur - m.n_entries)));
         TFX_HIP(hipMemsetAsync(sc.tmp16.p, 0, (size_t)(cur - m.n_entries) * sizeof(uint16_t), s));
-        TFX_HIP(hipMemsetAsync(m.rowmask.p + c0 * MASK_WORDS, 0, (size_t)(c1 - c0) * MASK_WORDS * sizeof(uint64_t), s));
         TFX_HIP(hipMemcpyAsync(sc.tile_off.p, sc.h_off.data(), ntc * sizeof(int64_t), hipMemcpyHostToDevice, s));
         TFX_HIP(hipMemcpyAsync(sc.tile_nch.p, sc.h_nch.data(), ntc * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        unsigned long long *mask = reinterpret_cast<unsigned long long *>(m.rowmask.p);
         const int64_t smax = maxlen;
-        if (smax > 0)
+        if (packed_total > 0)
+            hipLaunchKernelGGL(k_tile_scatter_packed, dim3((unsigned)((packed_total + 255) / 256)), dim3(256), 0, s, s_cols, s_vals, s_off,
+                               packed_total, ntc, m.TC, nr, sc.pos.p, sc.segoff.p, sc.tile_off.p, sc.tmp16.p, m.n_entries, m.rec.p);
+        else if (smax > 0)
             hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((smax + 255) / 256), nr), dim3(256), 0, s, s_cols, s_vals,
-                               s_nel, s_off, ntc, m.TC, nr, sc.pos.p, sc.segoff.p, sc.tile_off.p, sc.tmp16.p, m.n_entries, mask, m.vals.p);
+                               s_nel, s_off, ntc, m.TC, nr, sc.pos.p, sc.segoff.p, sc.tile_off.p, sc.tmp16.p, m.n_entries, m.rec.p);
         hipLaunchKernelGGL(k_pack_slots, dim3((unsigned)std::min<int64_t>(8192, ((cur - m.n_entries) / 8 + 255) / 256)), dim3(256), 0, s,
-                           sc.tmp16.p, m.n_entries, (cur - m.n_entries) / 8, m.slots.p);
+                           sc.tmp16.p, m.n_entries, (cur - m.n_entries) / 8, m.rec.p);
         hipLaunchKernelGGL(k_tile_markers, dim3(ntc), dim3(256), 0, s, sc.pos.p, nr, ntc, sc.segoff.p, sc.first_ne.p, sc.last_ne.p,
-                           sc.tile_off.p, m.slots.p, mask, m.vals.p);
+                           sc.tile_off.p, m.rec.p);
         hipLaunchKernelGGL(k_chunk_row0, dim3(ntc), dim3(256), 0, s, nr, sc.segoff.p, sc.first_ne.p, sc.tile_off.p, sc.tile_nch.p,
                            m.chunk_row0.p);
         TFX_HIP(hipGetLastError());
@@ -614,6 +639,17 @@ int matrix_finish(tfx_ctx *ctx)
     m.adj_has_partials = nap > 0;
     m.nnz = real;
     m.valid = true;
+    if (!m.is_transpose_copy) {
+        if (m.T) {                       // "refinish": the copy keeps its tiles, its work lists follow the current knobs
+            TiledMatrix *keep = ctx->target;
+            ctx->target = m.T;
+            const int rc = matrix_finish(ctx);
+            ctx->target = keep;
+            TFX_TRY(rc);
+        } else {
+            TFX_TRY(matrix_build_transpose(ctx, m));
+        }
+    }
     return 0;
 }
 
@@ -627,16 +663,15 @@ struct ChunkRegs {
     float v[8];
 };
 
-__device__ __forceinline__ void load_chunk(const uint32_t *__restrict__ slots, const float *__restrict__ vals,
-                                           int64_t chunk, int lane, ChunkRegs &c)
+__device__ __forceinline__ void load_chunk(const char *__restrict__ rec, int64_t chunk, int lane, ChunkRegs &c)
 {
     // the matrix is streamed exactly once per product: non-temporal loads keep it from displacing the x / u tiles in L2
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t *sp = slots + chunk * SLOT_WORDS + lane * 3;       // three dword loads, merged into one dwordx3 by the compiler
+    const uint32_t *sp = chunk_slots(rec, chunk) + lane * 3;          // three dword loads, merged into one dwordx3 by the compiler
     c.w[0] = __builtin_nontemporal_load(sp);
     c.w[1] = __builtin_nontemporal_load(sp + 1);
     c.w[2] = __builtin_nontemporal_load(sp + 2);
-    const float *vp = vals + chunk * CHUNK + lane * 4;                // val_pos(): entries k = 0..3 of all lanes, then k = 4..7
+    const float *vp = chunk_vals(rec, chunk) + lane * 4;              // val_pos(): entries k = 0..3 of all lanes, then k = 4..7
     const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vp));
     const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vp + CHUNK / 2));
     c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w;
@@ -655,9 +690,9 @@ __device__ __forceinline__ uint32_t slot_of(const ChunkRegs &c)
 // The eight row-start masks of a chunk (wave-uniform address -> scalar loads), and the number of row starts in all lanes
 // below this one (all 8 entries of those lanes): mbcnt straight on the stored masks, no ballots.
 struct ChunkMasks { uint64_t m[8]; };
-__device__ __forceinline__ int load_masks(const uint64_t *__restrict__ rowmask, int64_t chunk, ChunkMasks &mk)
+__device__ __forceinline__ int load_masks(const char *__restrict__ rec, int64_t chunk, ChunkMasks &mk)
 {
-    const uint64_t *p = rowmask + chunk * MASK_WORDS;
+    const uint64_t *p = chunk_masks(rec, chunk);
     int acc = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -754,9 +789,7 @@ struct MatPtrs {
     const WorkItem *items;
     const int32_t *order;
     const TileMeta *tiles;
-    const uint32_t *slots;
-    const uint64_t *rowmask;
-    const float *vals;
+    const char *rec;
     const int32_t *chunk_row0;
 };
 
@@ -764,9 +797,8 @@ struct MatPtrs {
 // nothing in the kernel writes them and reads the wave-uniform ones - masks, offsets, tile records - with scalar loads)
 #define MAT_PARAMS                                                                                                         \
     const WorkItem *__restrict__ items, const int32_t *__restrict__ order, const TileMeta *__restrict__ tiles,             \
-    const uint32_t *__restrict__ slots, const uint64_t *__restrict__ rowmask, const float *__restrict__ vals,              \
-    const int32_t *__restrict__ chunk_row0
-#define MAT_ARGS(mp) (mp).items, (mp).order, (mp).tiles, (mp).slots, (mp).rowmask, (mp).vals, (mp).chunk_row0
+    const char *__restrict__ rec, const int32_t *__restrict__ chunk_row0
+#define MAT_ARGS(mp) (mp).items, (mp).order, (mp).tiles, (mp).rec, (mp).chunk_row0
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_fwd(MAT_PARAMS, const double *__restrict__ x, double *__restrict__ partial,
@@ -800,8 +832,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_fwd(MA
             double *o = outs + lrb * RB;
             ChunkRegs cr;
             ChunkMasks mk;
-            load_chunk(slots, vals, ch, lane, cr);
-            int cur = chunk_row0[ch] + load_masks(rowmask, ch, mk);
+            load_chunk(rec, ch, lane, cr);
+            int cur = chunk_row0[ch] + load_masks(rec, ch, mk);
             double acc = 0.0;
 #define FWD_STEP(K)                                                          \
             if (ROWSTART_K(mk, K)) {                                         \
@@ -909,8 +941,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_adj(MA
             const double *ub = us + lrb * RB;
             ChunkRegs cr;
             ChunkMasks mk;
-            load_chunk(slots, vals, ch, lane, cr);
-            int cur = chunk_row0[ch] + load_masks(rowmask, ch, mk);
+            load_chunk(rec, ch, lane, cr);
+            int cur = chunk_row0[ch] + load_masks(rec, ch, mk);
             double uval = ub[max(cur, 0)];
 #define ADJ_STEP(K)                                                                      \
             if (ROWSTART_K(mk, K)) {                                                     \
@@ -935,8 +967,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_adj(MA
 
 // vals[e] *= scale[row of e] for every stored entry: what read_sensitivity_kernel does to a row on reload
 // (sensitivity_gravmag.F90:834-843: the file holds the unscaled kernel, the matrix problem_weight * data_weight(row) times it).
-__global__ __launch_bounds__(256) void k_scale_rows(const TileMeta *__restrict__ tiles, int ntiles, const uint64_t *__restrict__ rowmask,
-                                                     float *__restrict__ vals, const int32_t *__restrict__ chunk_row0,
+__global__ __launch_bounds__(256) void k_scale_rows(const TileMeta *__restrict__ tiles, int ntiles, char *__restrict__ rec,
+                                                     const int32_t *__restrict__ chunk_row0,
                                                      const float *__restrict__ scale, int64_t nrows, int RB)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -946,8 +978,8 @@ __global__ __launch_bounds__(256) void k_scale_rows(const TileMeta *__restrict__
         const int64_t cbase = tm.off / CHUNK;
         for (int c = blockIdx.x * 4 + wave; c < tm.nchunks; c += gridDim.x * 4) {
             ChunkMasks mk;
-            int cur = chunk_row0[cbase + c] + load_masks(rowmask, cbase + c, mk);
-            float *vp = vals + (cbase + c) * CHUNK + lane * 4;          // val_pos()
+            int cur = chunk_row0[cbase + c] + load_masks(rec, cbase + c, mk);
+            float *vp = chunk_vals(rec, cbase + c) + lane * 4;          // val_pos()
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if ((mk.m[k] >> lane) & 1ull) cur += 1;
@@ -1032,7 +1064,7 @@ int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spm
 int spmtv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add) { return spmtv_dev(ctx, ctx->selmat(), d_x, d_b, add); }
 
 // Diagnostics: how many chunks have all their non-zero values within `span` binades (candidates for a shared-exponent value format)
-__global__ void k_chunk_exponent_span(const float *__restrict__ vals, int64_t nchunks, int span, unsigned long long *__restrict__ count,
+__global__ void k_chunk_exponent_span(const char *__restrict__ rec, int64_t nchunks, int span, unsigned long long *__restrict__ count,
                                       unsigned int *__restrict__ hist /* [34] span histogram */)
 {
     const int lane = threadIdx.x & 63;
@@ -1040,7 +1072,7 @@ __global__ void k_chunk_exponent_span(const float *__restrict__ vals, int64_t nc
     for (int64_t c = w; c < nchunks; c += nw) {
         int emin = 1 << 30, emax = -(1 << 30);
         for (int k = 0; k < 8; ++k) {
-            const uint32_t b = __float_as_uint(vals[c * CHUNK + lane * 8 + k]);
+            const uint32_t b = __float_as_uint(chunk_vals(rec, c)[lane * 8 + k]);
             const int e = (int)((b >> 23) & 0xff);
             if ((b & 0x7fffffffu) != 0) { emin = min(emin, e); emax = max(emax, e); }
         }
@@ -1062,7 +1094,7 @@ int chunk_exponent_stats(tfx_ctx *ctx, TiledMatrix &m, int span, int64_t *fit, i
     TFX_TRY(dh.alloc(34));
     TFX_HIP(hipMemsetAsync(cnt.p, 0, 8, ctx->stream));
     TFX_HIP(hipMemsetAsync(dh.p, 0, 34 * 4, ctx->stream));
-    if (nch > 0) hipLaunchKernelGGL(k_chunk_exponent_span, dim3(4096), dim3(256), 0, ctx->stream, m.vals.p, nch, span, cnt.p, dh.p);
+    if (nch > 0) hipLaunchKernelGGL(k_chunk_exponent_span, dim3(4096), dim3(256), 0, ctx->stream, m.rec.p, nch, span, cnt.p, dh.p);
     unsigned long long h = 0;
     TFX_TRY(copy_any(&h, cnt.p, 8, ctx->stream));
     TFX_TRY(copy_any(hist34, dh.p, 34 * 4, ctx->stream));
@@ -1077,11 +1109,38 @@ static MatPtrs mat_ptrs(const TiledMatrix &m, bool forward)
     p.items = forward ? m.fwd.p : m.adj.p;
     p.order = forward ? m.fwd_order.p : m.adj_order.p;
     p.tiles = m.tiles.p;
-    p.slots = m.slots.p;
-    p.rowmask = m.rowmask.p;
-    p.vals = m.vals.p;
+    p.rec = m.rec.p;
     p.chunk_row0 = m.chunk_row0.p;
     return p;
+}
+
+// b (+)= M x with the forward kernel on the tiles of M (M = S for the forward product, M = the transposed copy for the adjoint);
+// prof_slot: which profiling slot the launch is timed in (-1: none)
+static int forward_product(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add, int prof_slot)
+{
+    hipStream_t s = ctx->stream;
+    const bool prof = prof_slot >= 0;
+    const int SB = m.fwd_group * m.RB;
+    const size_t lds = (size_t)(m.TC + SB) * sizeof(double);
+    if (!m.h_fwd.empty()) {
+        const MatPtrs mp = mat_ptrs(m, true);
+        if (prof) prof_begin(ctx);
+        if (ctx->deterministic) {
+            TFX_TRY(set_lds_limit(ctx, 1, (const void *)k_spmv_fwd<1>, lds));
+            hipLaunchKernelGGL((k_spmv_fwd<1>), dim3((unsigned)m.h_fwd.size()), dim3(64), lds, s, MAT_ARGS(mp), d_x, m.fwd_partial.p,
+                               m.ncols, m.TC, m.RB, m.fwd_group);
+        } else {
+            TFX_TRY(set_lds_limit(ctx, 0, (const void *)k_spmv_fwd<16>, lds));
+            hipLaunchKernelGGL((k_spmv_fwd<16>), dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), d_x,
+                               m.fwd_partial.p, m.ncols, m.TC, m.RB, m.fwd_group);
+        }
+        if (prof) prof_end(ctx, prof_slot);
+        TFX_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_fwd_reduce, dim3((unsigned)((m.nrows + FR_ROWS - 1) / FR_ROWS)), dim3(FR_ROWS * FR_GROUPS), 0, s, m.fwd_partial.p,
+                       m.fwd_nslots.p, m.fwd_pbase.p, SB, m.nrows, d_b, add);
+    TFX_HIP(hipGetLastError());
+    return 0;
 }
 
 int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add)
@@ -1099,27 +1158,7 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
         TFX_HIP(hipGetLastError());
         return 0;
     }
-    const int SB = m.fwd_group * m.RB;
-    const size_t lds = (size_t)(m.TC + SB) * sizeof(double);
-    if (!m.h_fwd.empty()) {
-        const MatPtrs mp = mat_ptrs(m, true);
-        if (prof) prof_begin(ctx);
-        if (ctx->deterministic) {
-            TFX_TRY(set_lds_limit(ctx, 1, (const void *)k_spmv_fwd<1>, lds));
-            hipLaunchKernelGGL((k_spmv_fwd<1>), dim3((unsigned)m.h_fwd.size()), dim3(64), lds, s, MAT_ARGS(mp), d_x, m.fwd_partial.p,
-                               m.ncols, m.TC, m.RB, m.fwd_group);
-        } else {
-            TFX_TRY(set_lds_limit(ctx, 0, (const void *)k_spmv_fwd<16>, lds));
-            hipLaunchKernelGGL((k_spmv_fwd<16>), dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), d_x,
-                               m.fwd_partial.p, m.ncols, m.TC, m.RB, m.fwd_group);
-        }
-        if (prof) prof_end(ctx, 0);
-        TFX_HIP(hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_fwd_reduce, dim3((unsigned)((m.nrows + FR_ROWS - 1) / FR_ROWS)), dim3(FR_ROWS * FR_GROUPS), 0, s, m.fwd_partial.p,
-                       m.fwd_nslots.p, m.fwd_pbase.p, SB, m.nrows, d_b, add);
-    TFX_HIP(hipGetLastError());
-    return 0;
+    return forward_product(ctx, m, d_x, d_b, add, prof ? 0 : -1);
 }
 
 int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add)
@@ -1127,6 +1166,7 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
     if (!m.valid) return fail(TFX_E_STATE, "spmtv: no matrix");
     const bool prof = (&m == &ctx->mat || &m == &ctx->mat2);
     hipStream_t s = ctx->stream;
+    if (m.T && m.T->valid) return forward_product(ctx, *m.T, d_x, d_b, add, prof ? 1 : -1);      // the adjoint as a forward product on S^T
     if (!add) TFX_HIP(hipMemsetAsync(d_b, 0, (size_t)m.ncols * sizeof(double), s));
     if (m.is_dense) {
         const int nchunks = (int)((m.ncols + DN_CHUNK - 1) / DN_CHUNK);
@@ -1159,6 +1199,242 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
     return 0;
 }
 
+// vals[e] *= scale[column of e]: tfx_matrix_scale_rows on the transposed copy (its columns are the rows of S)
+__global__ __launch_bounds__(256) void k_scale_cols(const TileMeta *__restrict__ tiles, int ntiles, char *__restrict__ rec,
+                                                     const float *__restrict__ scale, int64_t ncols, int TC)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int ti = blockIdx.y; ti < ntiles; ti += gridDim.y) {
+        const TileMeta tm = tiles[ti];
+        const int64_t cbase = tm.off / CHUNK, col0 = (int64_t)tm.t * TC;
+        for (int c = blockIdx.x * 4 + wave; c < tm.nchunks; c += gridDim.x * 4) {
+            ChunkRegs cr;
+            load_chunk(rec, cbase + c, lane, cr);
+            float *vp = chunk_vals(rec, cbase + c) + lane * 4;
+            const uint32_t sl[8] = {slot_of<0>(cr), slot_of<1>(cr), slot_of<2>(cr), slot_of<3>(cr), slot_of<4>(cr), slot_of<5>(cr), slot_of<6>(cr), slot_of<7>(cr)};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t col = col0 + col_slot((int)sl[k]);
+                if (cr.v[k] != 0.0f && col < ncols) vp[(k >> 2) * (CHUNK / 2) + (k & 3)] = cr.v[k] * scale[col];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Transposed copy of a tiled matrix (the adjoint product as a forward product on S^T)
+// ------------------------------------------------------------------------------------------------------------
+// One block of RBt columns of S = one row block of S^T at a time.  The tiles that hold those columns (all row blocks of one or
+// two column tiles) are walked three times: (1) per-column entry counts per row block of S; after a scan over the row blocks and
+// over the columns every (column, row block of S) knows where its run starts in the column's row of S^T; (2, 3) the fill - a
+// workgroup takes one tile and one strip of TR_STRIP columns, marks (column, row) in an LDS bitmap, and the rank of an entry
+// inside its (column, row block) run is the number of marked rows below it: the rows of S^T come out with ascending column
+// indices without a sort.  Zero-valued entries (markers, padding, stored zeros) are dropped: they add nothing to S^T x.
+constexpr int TR_STRIP = 256;
+
+// every entry of a chunk as (local row, global column, value): the same decode as the product kernels
+template <typename F>
+__device__ __forceinline__ void walk_chunk(const char *__restrict__ rec, const int32_t *__restrict__ chunk_row0, int64_t ch, int lane,
+                                           int64_t col0, F &&f)
+{
+    ChunkRegs cr;
+    ChunkMasks mk;
+    load_chunk(rec, ch, lane, cr);
+    int cur = chunk_row0[ch] + load_masks(rec, ch, mk);
+    const uint32_t sl[8] = {slot_of<0>(cr), slot_of<1>(cr), slot_of<2>(cr), slot_of<3>(cr), slot_of<4>(cr), slot_of<5>(cr), slot_of<6>(cr), slot_of<7>(cr)};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if ((mk.m[k] >> lane) & 1ull) cur += 1;
+        f(cur, col0 + col_slot((int)sl[k]), cr.v[k]);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_tr_count(const TileMeta *__restrict__ tiles, const int32_t *__restrict__ tids, const char *__restrict__ rec,
+                                                    const int32_t *__restrict__ chunk_row0, int TC, int64_t c0, int64_t c1, int RBt,
+                                                    int32_t *__restrict__ cnt /* [row blocks of S][RBt] */)
+{
+    extern __shared__ int32_t hist[];
+    const TileMeta tm = tiles[tids[blockIdx.x]];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < RBt; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int64_t cbase = tm.off / CHUNK, col0 = (int64_t)tm.t * TC;
+    for (int q = wave; q < tm.nchunks; q += 16) {
+        walk_chunk(rec, chunk_row0, cbase + q, lane, col0, [&](int, int64_t col, float val) {
+            if (val != 0.0f && col >= c0 && col < c1) atomicAdd(&hist[(int)(col - c0)], 1);
+        });
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RBt; i += blockDim.x)
+        if (hist[i]) atomicAdd(&cnt[(int64_t)tm.rb * RBt + i], hist[i]);
+}
+
+// cnt[rb][j] -> exclusive prefix over rb (in place), nel[j], rowoff[j] (exclusive scan over j), totals = {entries, longest row}
+__global__ __launch_bounds__(1024) void k_tr_scan(int32_t *__restrict__ cnt, int nrb, int RBt, int nr, int32_t *__restrict__ nel,
+                                                   int64_t *__restrict__ rowoff, int64_t *__restrict__ totals)
+{
+    __shared__ long long part[1024];
+    __shared__ int maxl[1024];
+    const int per = (RBt + 1023) / 1024;
+    const int j0 = threadIdx.x * per;
+    long long sum = 0;
+    int mx = 0;
+    for (int j = j0; j < j0 + per && j < RBt; ++j) {
+        int run = 0;
+        for (int rb = 0; rb < nrb; ++rb) {
+            const int v = cnt[(int64_t)rb * RBt + j];
+            cnt[(int64_t)rb * RBt + j] = run;
+            run += v;
+        }
+        if (j < nr) nel[j] = run;
+        sum += run;
+        mx = max(mx, run);
+    }
+    part[threadIdx.x] = sum;
+    maxl[threadIdx.x] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        int m = 0;
+        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; m = max(m, maxl[i]); }
+        totals[0] = run;
+        totals[1] = m;
+    }
+    __syncthreads();
+    long long run = part[threadIdx.x];
+    for (int j = j0; j < j0 + per && j < RBt; ++j) {
+        if (j < nr) rowoff[j] = run;
+        run += (j < nr) ? nel[j] : 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_tr_fill(const TileMeta *__restrict__ tiles, const int32_t *__restrict__ tids, const char *__restrict__ rec,
+                                                   const int32_t *__restrict__ chunk_row0, int TC, int RB, int64_t c0blk, int64_t c1blk, int RBt,
+                                                   const int32_t *__restrict__ base /* [row blocks of S][RBt] */, const int64_t *__restrict__ rowoff,
+                                                   int32_t *__restrict__ tcols, float *__restrict__ tvals)
+{
+    extern __shared__ unsigned long long bm[];         // [TR_STRIP][WPR] bitmap, then [TR_STRIP][WPR] uint16 prefixes
+    const int WPR = (RB + 63) / 64;
+    uint16_t *pre = reinterpret_cast<uint16_t *>(bm + (size_t)TR_STRIP * WPR);
+    const TileMeta tm = tiles[tids[blockIdx.x]];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t c0 = c0blk + (int64_t)blockIdx.y * TR_STRIP, c1 = min(c1blk, c0 + TR_STRIP);
+    const int64_t cbase = tm.off / CHUNK, col0 = (int64_t)tm.t * TC;
+    if (c0 >= c1 || col0 >= c1 || col0 + TC <= c0) return;          // (uniform) the tile does not reach into this strip
+    for (int i = threadIdx.x; i < TR_STRIP * WPR; i += blockDim.x) bm[i] = 0ull;
+    __syncthreads();
+    for (int q = wave; q < tm.nchunks; q += 16) {
+        walk_chunk(rec, chunk_row0, cbase + q, lane, col0, [&](int lrow, int64_t col, float val) {
+            if (val != 0.0f && col >= c0 && col < c1) atomicOr(&bm[(int)(col - c0) * WPR + (lrow >> 6)], 1ull << (lrow & 63));
+        });
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < TR_STRIP; j += blockDim.x) {
+        int run = 0;
+        for (int w = 0; w < WPR; ++w) { pre[j * WPR + w] = (uint16_t)run; run += __popcll(bm[j * WPR + w]); }
+    }
+    __syncthreads();
+    for (int q = wave; q < tm.nchunks; q += 16) {
+        walk_chunk(rec, chunk_row0, cbase + q, lane, col0, [&](int lrow, int64_t col, float val) {
+            if (val == 0.0f || col < c0 || col >= c1) return;
+            const int j = (int)(col - c0), w = lrow >> 6;
+            const int rank = pre[j * WPR + w] + __popcll(bm[j * WPR + w] & ((1ull << (lrow & 63)) - 1ull));
+            const int jb = (int)(col - c0blk);
+            const int64_t dst = rowoff[jb] + base[(int64_t)tm.rb * RBt + jb] + rank;
+            tcols[dst] = tm.rb * RB + lrow;
+            tvals[dst] = val;
+        });
+    }
+}
+
+int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
+{
+    if (m.is_dense || m.is_transpose_copy || m.h_tiles.empty() || ctx->adj_copy == 0) return 0;
+    hipStream_t s = ctx->stream;
+    if (ctx->adj_copy == 2) {
+        if (m.n_entries < ctx->adj_copy_min_nnz) return 0;
+        size_t free_b = 0, total_b = 0;
+        TFX_HIP(hipStreamSynchronize(s));
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        // the copy (a little larger than the original: its own padding and markers) + the conversion scratch
+        if ((double)free_b < 1.06 * (double)m.rec.bytes() + 8e9) return 0;
+    }
+    TiledMatrix *T = new TiledMatrix();
+    T->is_transpose_copy = true;
+    TiledMatrix *keep = ctx->target;
+    auto give_up = [&](int rc) {
+        // the copy is an optimisation: when the device has no room for it after all, the adjoint stays on the atomic kernel
+        ctx->target = keep;
+        delete T;
+        (void)hipGetLastError();
+        if (ctx->adj_copy == 1) return rc;
+        fprintf(stderr, "[tfx] no transposed copy for the adjoint (%s): using the one-copy adjoint kernel\n", g_last_error.c_str());
+        return 0;
+    };
+    ctx->target = T;
+    int rc = matrix_begin(ctx, m.ncols, m.nrows, std::max<int64_t>(1, m.nnz));
+    if (rc) return give_up(rc);
+    // tiles of S by column tile, row blocks ascending
+    std::vector<int32_t> toff((size_t)m.ntc + 1, 0), tids(m.h_tiles.size());
+    for (const TileMeta &t : m.h_tiles) toff[(size_t)t.t + 1] += 1;
+    for (int t = 0; t < m.ntc; ++t) toff[(size_t)t + 1] += toff[(size_t)t];
+    {
+        std::vector<int32_t> fill(toff.begin(), toff.end() - 1);
+        std::vector<int32_t> order(m.h_tiles.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return m.h_tiles[a].rb < m.h_tiles[b].rb; });
+        for (int32_t i : order) tids[(size_t)fill[(size_t)m.h_tiles[i].t]++] = i;
+    }
+    tfx_ctx::TransposeScratch &sc = ctx->trs;
+    const int RBt = T->RB;
+    const int WPR = (m.RB + 63) / 64;
+    const size_t fill_lds = (size_t)TR_STRIP * WPR * (sizeof(unsigned long long) + sizeof(uint16_t));
+    rc = [&]() -> int {
+        TFX_TRY(sc.tids.ensure(std::max<size_t>(1, tids.size())));
+        TFX_HIP(hipMemcpyAsync(sc.tids.p, tids.data(), tids.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        TFX_TRY(sc.cnt.ensure((size_t)m.nrb * RBt));
+        TFX_TRY(sc.nel.ensure((size_t)RBt));
+        TFX_TRY(sc.rowoff.ensure((size_t)RBt));
+        TFX_TRY(sc.totals.ensure(2));
+        TFX_HIP(hipFuncSetAttribute((const void *)k_tr_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fill_lds));
+        for (int b = 0; b < T->nrb; ++b) {
+            const int64_t c0 = (int64_t)b * RBt, c1 = std::min<int64_t>(m.ncols, c0 + RBt);
+            const int nr = (int)(c1 - c0);
+            const int t_lo = (int)(c0 / m.TC), t_hi = (int)((c1 - 1) / m.TC);
+            const int ntl = toff[(size_t)t_hi + 1] - toff[(size_t)t_lo];
+            std::vector<int32_t> h_nel((size_t)nr, 0);
+            int64_t totals[2] = {0, 0};
+            if (ntl > 0) {
+                const int32_t *tl = sc.tids.p + toff[(size_t)t_lo];
+                TFX_HIP(hipMemsetAsync(sc.cnt.p, 0, (size_t)m.nrb * RBt * sizeof(int32_t), s));
+                hipLaunchKernelGGL(k_tr_count, dim3(ntl), dim3(1024), (size_t)RBt * sizeof(int32_t), s, m.tiles.p, tl, m.rec.p, m.chunk_row0.p,
+                                   m.TC, c0, c1, RBt, sc.cnt.p);
+                hipLaunchKernelGGL(k_tr_scan, dim3(1), dim3(1024), 0, s, sc.cnt.p, m.nrb, RBt, nr, sc.nel.p, sc.rowoff.p, sc.totals.p);
+                TFX_HIP(hipGetLastError());
+                TFX_HIP(hipMemcpyAsync(totals, sc.totals.p, sizeof(totals), hipMemcpyDeviceToHost, s));
+                TFX_HIP(hipMemcpyAsync(h_nel.data(), sc.nel.p, (size_t)nr * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                TFX_HIP(hipStreamSynchronize(s));
+            }
+            if (totals[0] == 0) continue;                  // an empty row block of S^T has no tiles
+            TFX_TRY(sc.tcols.ensure((size_t)totals[0]));
+            TFX_TRY(sc.tvals.ensure((size_t)totals[0]));
+            const int nstrips = (nr + TR_STRIP - 1) / TR_STRIP;
+            hipLaunchKernelGGL(k_tr_fill, dim3(ntl, nstrips), dim3(1024), fill_lds, s, m.tiles.p, sc.tids.p + toff[(size_t)t_lo], m.rec.p,
+                               m.chunk_row0.p, m.TC, m.RB, c0, c1, RBt, sc.cnt.p, sc.rowoff.p, sc.tcols.p, sc.tvals.p);
+            TFX_HIP(hipGetLastError());
+            TFX_TRY(matrix_append_rows(ctx, c0, nr, sc.tcols.p, sc.tvals.p, sc.nel.p, sc.rowoff.p, totals[1], totals[0]));
+        }
+        TFX_TRY(matrix_finish(ctx));
+        return 0;
+    }();
+    // the conversion scratch is as large as the densest block of columns: give it back
+    sc.tcols.release(); sc.tvals.release(); sc.cnt.release();
+    if (rc) return give_up(rc);
+    ctx->target = keep;
+    m.T = T;
+    return 0;
+}
+
 // rows of the selected matrix times a per-row factor (fp32 product of the stored value and the factor, like the reference's
 // sensit_compressed * real(problem_weight * data_weight, MATRIX_PRECISION), sensitivity_gravmag.F90:834-843)
 int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale)
@@ -1173,9 +1449,15 @@ int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale)
     }
     const int nt = (int)m.h_tiles.size();
     if (nt == 0) return 0;
-    hipLaunchKernelGGL(k_scale_rows, dim3(8, (unsigned)std::min(nt, 32768)), dim3(256), 0, s, m.tiles.p, nt, m.rowmask.p, m.vals.p,
+    hipLaunchKernelGGL(k_scale_rows, dim3(8, (unsigned)std::min(nt, 32768)), dim3(256), 0, s, m.tiles.p, nt, m.rec.p,
                        m.chunk_row0.p, d_scale, m.nrows, m.RB);
     TFX_HIP(hipGetLastError());
+    if (m.T && m.T->valid && !m.T->h_tiles.empty()) {        // the same factors, by column, on the transposed copy (same fp32 products)
+        TiledMatrix &t = *m.T;
+        hipLaunchKernelGGL(k_scale_cols, dim3(8, (unsigned)std::min((int)t.h_tiles.size(), 32768)), dim3(256), 0, s, t.tiles.p,
+                           (int)t.h_tiles.size(), t.rec.p, d_scale, t.ncols, t.TC);
+        TFX_HIP(hipGetLastError());
+    }
     return 0;
 }
 

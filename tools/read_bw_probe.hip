@@ -62,6 +62,45 @@ __global__ __launch_bounds__(1024) void k_read3(const float *__restrict__ vals, 
     }
     if (acc == 1.2345f || macc == 77) out[0] = acc;
 }
+// ONE interleaved stream: a chunk is a contiguous record [values 2048 B | slot stream SB bytes | masks 64 B]; the wave reads its record with
+// the same instructions as k_read3 (two 16-byte loads per lane at a 16-byte lane stride, the slot stream as dwordx3 (SB = 768) or as
+// dwordx2 + one byte per lane (SB = 576: 16-bit base + seven 8-bit deltas), masks by scalar loads)
+template <int SB, int UNR>
+__global__ __launch_bounds__(1024) void k_read_rec(const char *__restrict__ base, size_t nchunks, float *out)
+{
+    constexpr size_t REC = 2048 + (SB == 577 ? 576 : SB) + 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    unsigned long long macc = 0;
+    const size_t per = (nchunks + gridDim.x - 1) / gridDim.x, c0 = blockIdx.x * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+#pragma unroll UNR
+    for (size_t c = c0 + wave; c < c1; c += 16) {
+        const char *r = base + c * REC;
+        const float *vp = (const float *)r;
+        const f4 a = __builtin_nontemporal_load((const f4 *)(vp + lane * 4)), b = __builtin_nontemporal_load((const f4 *)(vp + 256 + lane * 4));
+        unsigned w0 = 0, w1 = 0, w2 = 0;
+        if (SB == 768) {
+            const unsigned *sp = (const unsigned *)(r + 2048) + lane * 3;
+            w0 = __builtin_nontemporal_load(sp); w1 = __builtin_nontemporal_load(sp + 1); w2 = __builtin_nontemporal_load(sp + 2);
+        } else if (SB == 576) {
+            const unsigned *sp = (const unsigned *)(r + 2048) + lane * 2;
+            w0 = __builtin_nontemporal_load(sp); w1 = __builtin_nontemporal_load(sp + 1);
+            w2 = __builtin_nontemporal_load((const unsigned char *)(r + 2048 + 512) + lane);
+        } else if (SB == 577) {      // (576 bytes; the seventh delta as a dword shared by four lanes)
+            const unsigned *sp = (const unsigned *)(r + 2048) + lane * 2;
+            w0 = __builtin_nontemporal_load(sp); w1 = __builtin_nontemporal_load(sp + 1);
+            w2 = (__builtin_nontemporal_load((const unsigned *)(r + 2048 + 512) + (lane >> 2)) >> ((lane & 3) * 8)) & 0xffu;
+        } else {                     // 512: exactly 8 bytes per lane
+            const unsigned *sp = (const unsigned *)(r + 2048) + lane * 2;
+            w0 = __builtin_nontemporal_load(sp); w1 = __builtin_nontemporal_load(sp + 1);
+        }
+        const unsigned long long *mp = (const unsigned long long *)(r + 2048 + SB);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) macc += mp[k];
+        acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + (float)(w0 ^ w1 ^ w2);
+    }
+    if (acc == 1.2345f || macc == 77) out[0] = acc;
+}
 __global__ void k_copy(const f4 *__restrict__ a, f4 *__restrict__ b, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
@@ -103,6 +142,21 @@ int main()
             snprintf(nm, 96, "3 streams, slots as 3 dword planes, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<0, 3>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, by);
             snprintf(nm, 96, "values + slots (no masks), %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<0, 1>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, (double)nch * (2048 + 768));
             snprintf(nm, 96, "values only, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read3<0, 0>), dim3(wgs), dim3(1024), 0, 0, v, sl, mk, nch, out); }, (double)nch * 2048);
+        }
+    }
+    {
+        const size_t nch = (size_t)16 << 20;
+        char *rec;
+        CK(hipMalloc(&rec, nch * 2880)); CK(hipMemset(rec, 0, nch * 2880));
+        for (int wgs : {512, 4096}) {
+            char nm[96];
+            snprintf(nm, 96, "1 interleaved stream, 2880-B records, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read_rec<768, 1>), dim3(wgs), dim3(1024), 0, 0, rec, nch, out); }, (double)nch * 2880);
+            snprintf(nm, 96, "  same, 2 chunks in flight per wave, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read_rec<768, 2>), dim3(wgs), dim3(1024), 0, 0, rec, nch, out); }, (double)nch * 2880);
+            snprintf(nm, 96, "1 interleaved stream, 2688-B records, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read_rec<576, 1>), dim3(wgs), dim3(1024), 0, 0, rec, nch, out); }, (double)nch * 2688);
+            snprintf(nm, 96, "  same, 2 chunks in flight per wave, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read_rec<576, 2>), dim3(wgs), dim3(1024), 0, 0, rec, nch, out); }, (double)nch * 2688);
+            snprintf(nm, 96, "2688-B records, d7 as shared dword, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read_rec<577, 1>), dim3(wgs), dim3(1024), 0, 0, rec, nch, out); }, (double)nch * 2688);
+            snprintf(nm, 96, "2624-B records (8 B slots per lane), %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read_rec<512, 1>), dim3(wgs), dim3(1024), 0, 0, rec, nch, out); }, (double)nch * 2624);
+            snprintf(nm, 96, "  same, 4 chunks in flight per wave, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read_rec<576, 4>), dim3(wgs), dim3(1024), 0, 0, rec, nch, out); }, (double)nch * 2688);
         }
     }
     timeit("copy f4 (read + write)", [&]() { hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, p, q, n); }, 2.0 * bytes);
