@@ -42,6 +42,12 @@ WORKLOADS = {
     # BASELINE.json configs[1]: dense (uncompressed) sensitivity
     "dense_256": dict(nx=256, ny=256, nz=64, ox=64, oy=64, ctype=0, rate=1.0,
                       desc="synthetic gravity 256x256x64 cells, 64x64 obs, dense (uncompressed) sensitivity"),
+    # BASELINE.json configs[3] at its stated size on ONE GPU: a gravity and a magnetic (TMI) kernel on 512x512x128 cells, 256x256 data
+    # each, in one LSQR (joint_inverse_problem.F90:547-554, :712-739); 2 x 2.2e10 non-zeros = 2 x 124 GB resident
+    "joint_512": dict(nx=512, ny=512, nz=128, ox=256, oy=256, ctype=1, rate=0.01, joint=True,
+                      desc="joint gravity + magnetic (TMI): 512x512x128 cells, 2 x 256x256 obs, Haar r=0.01, two kernels in one LSQR"),
+    "joint_small": dict(nx=96, ny=96, nz=32, ox=48, oy=48, ctype=1, rate=0.02, joint=True,
+                        desc="joint gravity + magnetic (TMI): 96x96x32 cells, 2 x 48x48 obs, Haar r=0.02 (reduced)"),
     # reduced sizes for quick checks (NOT the headline; bench prints which one ran)
     "medium": dict(nx=128, ny=128, nz=64, ox=64, oy=64, ctype=2, rate=0.02,
                    desc="synthetic gravity 128x128x64 cells, 64x64 obs, D4 r=0.02 (reduced)"),
@@ -118,6 +124,10 @@ def main():
     info = ctx.device_info()
     log("device %s, %d CUs, %.0f GB; workload %s" % (info["name"], info["cus"], info["hbm_bytes"] / 1e9, w["desc"]))
     ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
+    if w.get("joint"):
+        if world > 1:
+            sys.exit("the joint workloads run on one GPU")
+        return bench_joint(args, w, ctx, tfx, log)
     cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
     # collectives: an RCCL communicator inside libtfx.so (nccl launch) - the library queues its reductions on its own stream;
     # the gloo rehearsal uses the torch.distributed hooks
@@ -296,6 +306,80 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_joint(args, w, ctx, tfx, log):
+    """BASELINE configs[3]: two sensitivity kernels (gravity g_z and magnetic TMI) on one grid inside one LSQR - S = blockdiag(S_grav,
+    S_mag), unknowns [m_grav ; m_mag], one damping block spanning both (joint_inverse_problem.F90:547-554, :712-739).  A step is one
+    LSQR iteration of the joint system: two launches per product.  Oracle-free properties here (entry counts, adjoint identity,
+    LSQR residual against the products); rows against the oracle: tests/test_gpu_parity.py::test_joint_two_kernels_*."""
+    nx, ny, nz = w["nx"], w["ny"], w["nz"]
+    N = nx * ny * nz
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, w["ox"], w["oy"])
+    D = xs.size
+    K = int(w["rate"] * N)
+    field = np.array([-62.0, 11.0, 0.0, 57000.0])
+    pws = (1.0, 3.0e-3)
+    cws = [ctx.calculate_depth_weight(2.0, 0.0, 4.0e3), ctx.calculate_depth_weight(3.0, 0.0, 1.0)]
+    rng = np.random.default_rng(3)
+    kern, b, t_build = [], [], 0.0
+    for i in range(2):
+        ctx.select_problem(i)
+        t0 = time.time()
+        res = ctx.calculate_sensit(xs, ys, zs, cws[i], w["ctype"], w["rate"], problem_weight=pws[i], mag_field=field if i == 1 else None)
+        dt = time.time() - t0
+        t_build += dt
+        assert 0.9999 * K * D <= res["nnz"] <= K * D, (res["nnz"], K * D)
+        x, y = rng.standard_normal(N), rng.standard_normal(D)
+        Sx, STy = ctx.mult_vector(x), ctx.trans_mult_vector(y)
+        adj = abs(np.dot(Sx, y) - np.dot(x, STy)) / (np.linalg.norm(Sx) * np.linalg.norm(y))
+        info, fmt = ctx.matrix_info(), ctx.matrix_format()
+        kern.append({"problem": "gravity g_z" if i == 0 else "magnetic TMI", "nnz": int(res["nnz"]), "build_s": round(dt, 2),
+                     "cell_obs_per_s_build": N * D / dt, "device_bytes": int(info["device_bytes"]), "adjoint_identity_rel_err": float(adj),
+                     "bytes_per_entry": fmt["bytes_per_entry"], "adjoint_copy": fmt["adjoint_copy"]})
+        log("kernel %d (%s): build %.1f s, nnz %d, %.1f GB, adjoint identity %.1e" % (i, kern[-1]["problem"], dt, res["nnz"], info["device_bytes"] / 1e9, adj))
+        b.append(ctx.mult_vector(rng.standard_normal(N) * 1e-3))
+    ctx.select_problem(0)
+    assert ctx.system_dims() == (2 * D, 2 * N)
+    alpha = np.concatenate([np.full(N, 1e-6, np.float32), np.full(N, 2e-6, np.float32)])
+    rhs = np.concatenate(b)
+    ctx.lsqr_begin(rhs, 1e-300, 0.0, 0.0, [alpha], [np.zeros(2 * N)])
+    done, r = ctx.lsqr_iterate(args.warmup)
+    assert done == args.warmup
+    ctx.profile_enable(True)
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    done, r = ctx.lsqr_iterate(args.steps)
+    ms_gpu = ctx.timer_stop_ms()
+    torch.cuda.synchronize()
+    t_steps = time.perf_counter() - t0
+    assert done == args.steps
+    prof = [ctx.profile_get(0), ctx.profile_get(1)]
+    ctx.profile_enable(False)
+    ctx.lsqr_end()
+    per_it = [prof[0][0] / args.steps, prof[1][0] / args.steps]          # both kernels' launches of a product, per iteration
+    dom = 0 if per_it[0] >= per_it[1] else 1
+    nnz = sum(k["nnz"] for k in kern)
+    alg_bytes = kern[0]["bytes_per_entry"] * nnz + 8.0 * 2 * (N + D)
+    achieved = alg_bytes / (per_it[dom] * 1e-3) / 1e9
+    value = args.steps / t_steps
+    out = {"metric": "LSQR iterations/s, joint gravity + magnetic inversion (two wavelet-compressed sensitivity kernels in one system)",
+           "value": round(value, 4), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * t_steps / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64 (fp32-stored matrix values, fp64 vectors and accumulation)", "data": "synthetic",
+           "config": {"workload": args.workload + ": " + w["desc"], "cells": N, "obs": [D, D], "nnz": nnz, "compression": "haar", "rate": w["rate"],
+                      "parallelism": "both kernels on one GPU"},
+           "cell_obs_per_s_solve": round(2.0 * N * D * value, 1), "cell_obs_per_s_build": round(2.0 * N * D / t_build, 1), "build_s": round(t_build, 2),
+           "gpu_ms_per_step_hip_events": round(ms_gpu / args.steps, 4), "final_r": r, "kernels": kern,
+           "roofline": {"bound": "hbm", "kernel": ["k_spmv_fwd", "k_spmv_adj"][dom] + " (the two kernels' launches of one product)",
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": int(alg_bytes), "ms_per_iteration": {"spmv_fwd": round(per_it[0], 4), "spmv_adj": round(per_it[1], 4)}},
+           "cpu_baseline": None}
+    print(json.dumps(out))
+    sys.stdout.flush()
+    ctx.close()
 
 
 def reference_config1(log):

@@ -308,9 +308,10 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * key "deterministic" (0/1; environment TFX_DETERMINISTIC at tfx_create): the two matrix products run with single-wave workgroups, so the LDS accumulations happen in program
  * order and a product is bit-reproducible from run to run (slow; for debugging convergence differences);
  * key "fwd_group" (0 = automatic, 1, 2, 4): row blocks that share one staged x tile in the forward product;
- * key "adj_copy" (0 never / 1 always / 2 automatic, default 2; environment TFX_ADJ_COPY): matrices finished from now on get a
+ * key "adj_copy" (0 never / 1 always / 2 automatic, default 0; environment TFX_ADJ_COPY): matrices finished from now on get a
  * transposed copy of their tiles so that the adjoint product runs as a forward product (no LDS atomic per non-zero; twice the
- * matrix memory); automatic = matrices of at least "adj_copy_min_nnz" stored entries (2^26) when the device has room;
+ * matrix memory, a longer build: it pays for very long solves on one matrix - DESIGN.md 3); automatic = matrices of at least
+ * "adj_copy_min_nnz" stored entries (2^26) when the device has room;
  * "has_adj_copy" queries the selected matrix;
  * key "build_overlap" (0/1, default 1): the kernel build runs its row generator (VALU-bound) on a second stream one batch ahead of
  * the wavelet / threshold / compaction kernels (HBM-bound) of the main stream; 0 = one stream, one row buffer;

@@ -230,9 +230,11 @@ struct tfx_ctx {
     int gen_grid_limit = 0;           // (set around the generator launches of the overlapped build)
     int build_overlap = 1;            // debug key "build_overlap": row generator on its own stream, one batch ahead of the wavelet / compaction
     int items_per_cu = 16;            // debug key "items_per_cu": work items per CU the tile list is cut into
-    // Adjoint on a transposed copy of the tiles: 0 never, 1 always (any size: tests), 2 automatic = for matrices of at least
-    // adj_copy_min_nnz stored entries when the device has room for the second copy (debug key "adj_copy" / TFX_ADJ_COPY)
-    int adj_copy = 2;
+    // Adjoint on a transposed copy of the tiles: 0 never (default), 1 always, 2 automatic = for matrices of at least adj_copy_min_nnz
+    // stored entries when the device has room for the second copy (debug key "adj_copy" / TFX_ADJ_COPY).  Off by default: measured at
+    // the headline size the adjoint drops from 18.39 to 18.05 ms per launch (the forward product: 17.8), for 6.5 s more build and
+    // twice the matrix memory - it pays only beyond ~20 000 iterations on one matrix.
+    int adj_copy = 0;
     int64_t adj_copy_min_nnz = (int64_t)1 << 26;
     struct TransposeScratch {
         tfx::DBuf<int32_t> cnt, nel, tcols, tids, toff;
