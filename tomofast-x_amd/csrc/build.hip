@@ -2779,7 +2779,7 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     const int lines_max = ob_max * nsub;
     DBuf<double> dcf;
     TFX_TRY(dred.alloc((size_t)lines_max * npart));
-    TFX_TRY(dcf.alloc(lines_max));
+    TFX_TRY(dcf.alloc((size_t)2 * lines_max));        // cost_full of the lines of a batch: one set per statistics slot (a redone batch needs its own)
     // staging area of finished matrix rows: a row block (RB rows) plus the rows of one observation that may straddle it
     const int stage_rows = RB + ncd;
     DBuf<int32_t> ell_cols, ell_nel;
@@ -2812,9 +2812,17 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     int64_t nnz_total = 0;
     DBuf<BatchStat> dstat;
     TFX_TRY(dstat.alloc(lines_max + 1));
-    BatchStat *h_stat = nullptr;                                    // pinned: one asynchronous copy per batch
-    TFX_HIP(hipHostMalloc((void **)&h_stat, (size_t)(lines_max + 1) * sizeof(BatchStat)));
-    struct PinnedFree { void *p; ~PinnedFree() { (void)hipHostFree(p); } } h_stat_guard{h_stat};
+    // pinned, two of them: the statistics of batch b are read one batch later, when batch b + 1 is already queued (the GPU never waits
+    // for the host's round trip: 3852 batches x ~0.2 ms at the headline size), so its copy must not land on top of batch b's
+    BatchStat *h_stat_all = nullptr;
+    TFX_HIP(hipHostMalloc((void **)&h_stat_all, (size_t)2 * (lines_max + 1) * sizeof(BatchStat)));
+    struct PinnedFree { void *p; ~PinnedFree() { (void)hipHostFree(p); } } h_stat_guard{h_stat_all};
+    BatchStat *h_stat2[2] = {h_stat_all, h_stat_all + (lines_max + 1)};
+    struct StatEvents {
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        ~StatEvents() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+    } se;
+    for (int i = 0; i < 2; ++i) TFX_HIP(hipEventCreateWithFlags(&se.ev[i], hipEventDisableTiming));
     int fill = 0;                 // finished rows waiting in the staging area
     int64_t r0 = 0;               // first matrix row of the staging area
     bool band_off = false;
@@ -2824,22 +2832,29 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     // the second row buffer while the main stream transforms and compacts batch b: their waves share the CUs, one kind waiting on
     // memory while the other computes.  (ctx->build_overlap = 0: one stream, one buffer - the sequential order of round 1.)
     const bool overlap = ctx->build_overlap && ndata >= 8 * (int64_t)ob_max;      // (short builds: the second buffer and stream cost more than they hide)
-    DBuf<double> drows2, dred2;
-    double *rows_buf[2] = {drows.p, drows.p}, *red_buf[2] = {dred.p, dred.p};
+    // Three row buffers in overlap mode: batch b + 1 is generated while batch b is transformed, and batch b - 1's transformed rows stay
+    // until its statistics are confirmed (a band that missed redoes the batch from them with the full select)
+    const int nbuf = overlap ? 3 : 1;
+    DBuf<double> drows2, dred2, drows3, dred3;
+    double *rows_buf[3] = {drows.p, drows.p, drows.p}, *red_buf[3] = {dred.p, dred.p, dred.p};
     struct GenStream {
         hipStream_t st = nullptr;
-        hipEvent_t ev[2] = {nullptr, nullptr}, ev0 = nullptr;
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr}, ev0 = nullptr;
         ~GenStream()
         {
             if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-            for (hipEvent_t e : {ev[0], ev[1], ev0}) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : {ev[0], ev[1], ev[2], ev0}) if (e) (void)hipEventDestroy(e);
         }
     } gs;
     if (overlap) {
         TFX_TRY(drows2.alloc((size_t)ob_max * nsub * N));
         TFX_TRY(dred2.alloc((size_t)lines_max * npart));
+        TFX_TRY(drows3.alloc((size_t)ob_max * nsub * N));
+        TFX_TRY(dred3.alloc((size_t)lines_max * npart));
         rows_buf[1] = drows2.p;
         red_buf[1] = dred2.p;
+        rows_buf[2] = drows3.p;
+        red_buf[2] = dred3.p;
         // lowest priority where the runtime offers priorities (the main stream's kernels get the freed slots first); a plain
         // non-blocking stream otherwise
         int prio_lo = 0, prio_hi = 0;
@@ -2849,7 +2864,7 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
             gs.st = nullptr;
             TFX_HIP(hipStreamCreateWithFlags(&gs.st, hipStreamNonBlocking));
         }
-        for (int i = 0; i < 2; ++i) TFX_HIP(hipEventCreateWithFlags(&gs.ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) TFX_HIP(hipEventCreateWithFlags(&gs.ev[i], hipEventDisableTiming));
         TFX_HIP(hipEventCreateWithFlags(&gs.ev0, hipEventDisableTiming));
         TFX_HIP(hipEventRecord(gs.ev0, s));                 // the uploads of the observations / weights queued above
         TFX_HIP(hipStreamWaitEvent(gs.st, gs.ev0, 0));
@@ -2876,12 +2891,75 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     };
     lap("streams, pinned stats");
     const double t_loop = wall();
+    // A batch in flight: queued on the GPU, its statistics not yet read
+    struct Pending {
+        bool active = false, banded = false;
+        int64_t g = 0;
+        int nb = 0, nl = 0, slot = 0, fill_at = 0, hs = 0;
+    };
+    // threshold (full select when asked, else already known / bracketed by the band) + compaction + the statistics copy of a batch
+    auto compact_batch = [&](const Pending &b, bool full_select) -> int {
+        double *const rows = rows_buf[b.slot];
+        if (full_select) TFX_TRY(select_threshold_dev(ctx, sw, rows, b.nl, N, K, cw.thr.p));              // :240-256
+        SelectWork *sel = (b.banded && !full_select) ? &sw : nullptr;
+        if (to_rs)
+            TFX_TRY(compact_dev(ctx, cw, rows, b.nl, N, 0, 0, N, rs->cols.p + (size_t)(b.g * ncd) * rs->stride,
+                                rs->vals.p + (size_t)(b.g * ncd) * rs->stride, rs->stride, rs->nel.p + b.g * ncd, dscale.p + b.g * nsub,
+                                nnz_hist_out ? dhist.p : nullptr, ncm, sel, K));
+        else
+            TFX_TRY(compact_dev(ctx, cw, rows, b.nl, N, compression_type == 0, col_begin, col_end,
+                                keep_matrix ? ell_cols.p + (size_t)b.fill_at * stride : nullptr,
+                                keep_matrix ? ell_vals.p + (size_t)b.fill_at * stride : nullptr, stride, ell_nel.p + b.fill_at,
+                                dscale.p + b.g * nsub, nnz_hist_out ? dhist.p : nullptr, ncm, sel, K));
+        // per-line statistics
+        hipLaunchKernelGGL(k_pack_stats, dim3((b.nl + 63) / 64), dim3(64), 0, s, b.nl, compression_type > 0 ? dcf.p + (size_t)b.hs * lines_max : nullptr,
+                           cw.cost_disc.p, cw.nel_all.p, cw.nel.p, cw.fail.p, dstat.p);
+        TFX_HIP(hipMemcpyAsync(h_stat2[b.hs], dstat.p, (size_t)(b.nl + 1) * sizeof(BatchStat), hipMemcpyDeviceToHost, s));
+        TFX_HIP(hipEventRecord(se.ev[b.hs], s));
+        return 0;
+    };
+    // reads a batch's statistics (waits for them); a band that missed redoes the batch from its transformed rows with the full
+    // radix select - out of order behind whatever has been queued since: the rows of a batch have their own place in the staging area
+    auto confirm = [&](Pending &b) -> int {
+        if (!b.active) return 0;
+        const BatchStat *hs = h_stat2[b.hs];
+        const double tw = timing ? wall() : 0.0;
+        TFX_HIP(hipEventSynchronize(se.ev[b.hs]));
+        if (b.banded) {
+            ctx->band_batches += 1;
+            if (hs[b.nl].nel_all) {
+                ctx->band_fallbacks += 1;
+                TFX_TRY(compact_batch(b, true));
+                TFX_HIP(hipEventSynchronize(se.ev[b.hs]));
+            }
+            // a sample that keeps missing (rows the pseudo-random positions do not represent): stop trying
+            if (ctx->band_batches - batches0 >= 8 && 4 * (ctx->band_fallbacks - fallbacks0) > ctx->band_batches - batches0) band_off = true;
+        }
+        if (timing) t_wait += wall() - tw;
+        for (int i = 0; i < b.nl; ++i) {
+            if (hs[i].nel_all > K) return fail(TFX_E_NUMERIC, "Wrong number of elements in calculate_and_write_sensit!");   // :275-277
+            if (compression_type > 0) err_sum += std::sqrt(hs[i].cost_disc / hs[i].cost_full);                        // :283
+            nnz_total += hs[i].nel;
+        }
+        b.active = false;
+        return 0;
+    };
     int slot = 0;
     int nb_cur = batch_obs(0, 0);
+    int64_t nbatch = 0;
+    Pending pend;
     if (overlap) TFX_TRY(generate(0, nb_cur, 0));
     for (int64_t g = 0; g < ndata;) {
-        const int nb = nb_cur;
-        const int nl = nb * nsub;                                   // lines of this batch
+        Pending cur;
+        cur.active = true;
+        cur.g = g;
+        cur.nb = nb_cur;
+        cur.nl = nb_cur * nsub;                                     // lines of this batch
+        cur.slot = slot;
+        cur.fill_at = fill;
+        cur.hs = (int)(nbatch & 1);
+        const int nb = cur.nb, nl = cur.nl;
+        const int slot_next = (slot + 1) % nbuf;
         double *const rows_cur = rows_buf[slot], *const red_cur = red_buf[slot];
         int64_t g_after = g + nb;
         if (overlap) {
@@ -2895,63 +2973,34 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         // The next batch's generator is queued behind this batch's wavelet passes (ctx->gen_after_wavelet, the default): it then
         // shares the GPU with the count / select / compaction kernels - pure HBM streams, the complement of its fp64 arithmetic -
         // and runs alone for the rest; beside the wavelet kernels (65 % VALU-busy themselves) both only slow each other down.
-        // Its buffer was last read by the compaction of batch b - 1, which the host has waited for.
+        // Its buffer was last read by the compaction of batch b - 2, whose statistics the host has confirmed.
         auto queue_next = [&]() -> int {
             if (!overlap || nb_cur <= 0) return 0;
             if (ctx->gen_after_wavelet) {
                 TFX_HIP(hipEventRecord(gs.ev0, s));
                 TFX_HIP(hipStreamWaitEvent(gs.st, gs.ev0, 0));
             }
-            return generate(g_after, nb_cur, slot ^ 1);
+            return generate(g_after, nb_cur, slot_next);
         };
         if (!ctx->gen_after_wavelet || compression_type == 0) TFX_TRY(queue_next());
         // threshold: bracketed from a sample and finished inside the compaction's count pass (band select) for large rows,
         // else the full radix select up front
-        const bool banded = compression_type > 0 && K < N && K > 0 && N >= ctx->band_min_n && !band_off;
+        cur.banded = compression_type > 0 && K < N && K > 0 && N >= ctx->band_min_n && !band_off;
         if (compression_type > 0) {
-            hipLaunchKernelGGL(k_rows_final_sum, dim3(nl), dim3(256), 0, s, red_cur, npart, dcf.p);                  // cost_full :234
+            hipLaunchKernelGGL(k_rows_final_sum, dim3(nl), dim3(256), 0, s, red_cur, npart, dcf.p + (size_t)cur.hs * lines_max);   // cost_full :234
             TFX_HIP(hipGetLastError());
             TFX_TRY(wavelet_dev(ctx, rows_cur, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1));                   // :237
             if (ctx->gen_after_wavelet) TFX_TRY(queue_next());
-            if (!banded) TFX_TRY(select_threshold_dev(ctx, sw, rows_cur, nl, N, K, cw.thr.p));                         // :240-256
         }
-        int h_fail = 0;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            SelectWork *sel = (banded && attempt == 0) ? &sw : nullptr;
-            if (attempt == 1) TFX_TRY(select_threshold_dev(ctx, sw, rows_cur, nl, N, K, cw.thr.p));     // a band missed: full select
-            if (to_rs)
-                TFX_TRY(compact_dev(ctx, cw, rows_cur, nl, N, 0, 0, N, rs->cols.p + (size_t)(g * ncd) * rs->stride,
-                                    rs->vals.p + (size_t)(g * ncd) * rs->stride, rs->stride, rs->nel.p + g * ncd, dscale.p + g * nsub,
-                                    nnz_hist_out ? dhist.p : nullptr, ncm, sel, K));
-            else
-                TFX_TRY(compact_dev(ctx, cw, rows_cur, nl, N, compression_type == 0, col_begin, col_end,
-                                    keep_matrix ? ell_cols.p + (size_t)fill * stride : nullptr,
-                                    keep_matrix ? ell_vals.p + (size_t)fill * stride : nullptr, stride, ell_nel.p + fill,
-                                    dscale.p + g * nsub, nnz_hist_out ? dhist.p : nullptr, ncm, sel, K));
-            // per-line statistics
-            hipLaunchKernelGGL(k_pack_stats, dim3((nl + 63) / 64), dim3(64), 0, s, nl, compression_type > 0 ? dcf.p : nullptr,
-                               cw.cost_disc.p, cw.nel_all.p, cw.nel.p, cw.fail.p, dstat.p);
-            TFX_HIP(hipMemcpyAsync(h_stat, dstat.p, (size_t)(nl + 1) * sizeof(BatchStat), hipMemcpyDeviceToHost, s));
-            const double tw = timing ? wall() : 0.0;
-            TFX_HIP(hipStreamSynchronize(s));
-            if (timing) t_wait += wall() - tw;
-            h_fail = h_stat[nl].nel_all;
-            if (sel) {
-                ctx->band_batches += 1;
-                if (h_fail) ctx->band_fallbacks += 1;
-                // a sample that keeps missing (rows the pseudo-random positions do not represent): stop trying
-                if (ctx->band_batches - batches0 >= 8 && 4 * (ctx->band_fallbacks - fallbacks0) > ctx->band_batches - batches0) band_off = true;
-            }
-            if (!h_fail) break;
-        }
-        for (int i = 0; i < nl; ++i) {
-            if (h_stat[i].nel_all > K) return fail(TFX_E_NUMERIC, "Wrong number of elements in calculate_and_write_sensit!");   // :275-277
-            if (compression_type > 0) err_sum += std::sqrt(h_stat[i].cost_disc / h_stat[i].cost_full);                     // :283
-            nnz_total += h_stat[i].nel;
-        }
+        TFX_TRY(compact_batch(cur, compression_type > 0 && !cur.banded));
+        // the previous batch ran while this one was being queued: its statistics are there (or nearly)
+        TFX_TRY(confirm(pend));
         g += nb;
         fill += nb * ncd;
-        if (fill >= RB || g >= ndata) {
+        nbatch += 1;
+        if (fill >= RB || g >= ndata || !overlap) {
+            // a row block is complete (or the build is): everything staged must be final before it is laid out as tiles
+            TFX_TRY(confirm(cur));
             int herr = 0;
             TFX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, s));
             TFX_HIP(hipStreamSynchronize(s));
@@ -2972,8 +3021,10 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
                 }
                 fill = left;
             }
+        } else {
+            pend = cur;
         }
-        if (overlap) slot ^= 1;
+        if (overlap) slot = slot_next;
         else if (g < ndata) nb_cur = batch_obs(g, fill);
     }
     const double t_fin = wall();

@@ -460,8 +460,16 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
   real(dp), allocatable, target :: work(:)
   real(dp) :: s1, s2, s3
   integer :: cc, row
+  ! wall clock per phase of the run (printed at the end and written to <output>/phase_timing.json on rank 0)
+  integer, parameter :: NPHASE = 9
+  character(len=40), parameter :: phase_name(NPHASE) = [character(len=40) :: 'read inputs (ASCII)', 'column weights', &
+    'kernel build (calculate_and_write_sensit)', 'partition + relayout (read_sensitivity_kernel)', 'constraint assembly', &
+    'LSQR (lsqr_solve_sensit)', 'forward data (calculate_data)', 'model update + costs', 'write outputs']
+  real(dp) :: phase_t(NPHASE), tph, t_run
 
   par = host_par
+  phase_t = 0.d0
+  t_run = wall()
   io_rank = myrank == 0
   if (myrank == 0) print *, 'Solving problem grav/mag.'
   memory_fwd = 0.d0
@@ -554,6 +562,7 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
 
   ! (I) MODEL GRID, (II) DATA (:135-162): the reference's objects, filled from the files
   if (myrank == 0) print *, '(I) MODEL GRID ALLOCATION.'
+  tph = wall()
   do ip = 1, 2
     if (.not. pr(ip)%on) cycle
     call model(ip)%grid_full%allocate(ipar%nx, ipar%ny, ipar%nz, par%z_axis_dir, myrank)
@@ -574,9 +583,11 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
     pr(ip)%d_meas = reshape(data(ip)%val_meas, (/pr(ip)%ndt/))
     pr(ip)%dw = reshape(data(ip)%weight, (/pr(ip)%ndt/))
   enddo
+  call lap(1, tph)
 
   ! (III) SENSITIVITY MATRIX CALCULATION (:164-215)
   if (myrank == 0) print *, '(III) SENSITIVITY MATRIX CALCULATION.'
+  tph = wall()
   if (gpar%sensit_read == 0) then
     do ip = 1, 2
       if (.not. pr(ip)%on) cycle
@@ -589,6 +600,8 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
       call apply_local_depth_weighting(ip)                                         ! :181-182
     enddo
   endif
+  call lap(2, tph)
+  tph = wall()
   if (gpar%sensit_read == 0 .or. gpar%sensit_read == 2) then
     do ip = 1, 2
       if (.not. pr(ip)%on) cycle
@@ -600,6 +613,8 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
       endif
     enddo
   endif
+  call lap(3, tph)
+  tph = wall()
   ! new partitioning for the load balancing (:205-221)
   allocate(nelements_at_cpu(nbproc), counts(nbproc), displs(nbproc))
   problem_type_part = merge(3, merge(1, 2, pr(1)%on), nprob == 2)
@@ -651,6 +666,7 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
   enddo
   call matrix_sensit%finalize(myrank)
   allocate(delta_model(matrix_sensit%get_ncolumns()))
+  call lap(4, tph)
 
   do ip = 1, 2
     if (.not. pr(ip)%on) cycle
@@ -708,6 +724,7 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
     print *, 'Iteration =', it
     print *, '======================================================='
     ! ---- general constraint rows first (their count sizes the system): gradient damping, cross-gradient, clustering
+    tph = wall()
     g_nrows = 0
     if (spatial) then
       call build_gradient_damping()
@@ -808,11 +825,15 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
       b_RHS(lc + row) = g_rhs(row)
     enddo
     call matrix_cons%finalize(myrank)
+    call lap(5, tph)
+    tph = wall()
     ! ---- parallel sparse inversion (joint_inverse_problem.F90:546-552)
     delta_model = 0.d0
     call lsqr_solve_sensit(size(b_RHS), size(delta_model), ipar%niter, ipar%rmin, ipar%gamma, ipar%target_misfit, &
                            matrix_sensit, matrix_cons, b_RHS, delta_model, SOLVE_PROBLEM, ipar%nelements, ipar%nx, ipar%ny, ipar%nz, &
                            ipar%nmodel_components, ipar%compression_type, WAVELET_DOMAIN, memory_inv, myrank, nbproc)
+    call lap(6, tph)
+    tph = wall()
     call write_costs(it - 1)                                       ! :519-528 (costs of the previous iteration)
     do ip = 1, 2
       if (.not. pr(ip)%on) cycle
@@ -835,9 +856,11 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
         print *, 'Increased the ADMM weight to:', pr(ip)%rho
       endif
     enddo
+    call lap(8, tph)
   enddo
   call write_costs(par%nmajor)
   close(ucost)
+  tph = wall()
 
   ! ---- outputs (:552-600)
   do ip = 1, 2
@@ -847,10 +870,48 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
     call write_model(par%path_output, trim(suffix(ip))//'_final_model_full.txt', n, pr(ip)%nc, pr(ip)%m, par%model_units_mult(ip))
     print *, 'model min / max =', minval(pr(ip)%m), maxval(pr(ip)%m)
   enddo
+  call lap(9, tph)
+  call report_phases()
   if (myrank == 0) print *, 'MEMORY USED (device matrix) [GB] =', memory_fwd
   call tfx_api_finalize()
 
 contains
+
+  real(dp) function wall()
+    integer(c_int64_t) :: c, rate
+    call system_clock(c, rate)
+    wall = real(c, dp) / real(rate, dp)
+  end function wall
+
+  subroutine lap(idx, t0)                       ! phase idx += time since t0
+    integer, intent(in) :: idx
+    real(dp), intent(in) :: t0
+    phase_t(idx) = phase_t(idx) + (wall() - t0)
+  end subroutine lap
+
+  ! (calculate_data runs inside other phases: its time is reported on its own line AND stays inside the enclosing phase)
+  subroutine report_phases()
+    integer :: q, u
+    real(dp) :: total
+    if (myrank /= 0) return
+    total = wall() - t_run
+    print *, 'PHASE TIMING [s] (rank 0 wall clock):'
+    do q = 1, NPHASE
+      print '(a,a44,f12.3)', '   ', phase_name(q), phase_t(q)
+    enddo
+    print '(a,a44,f12.3)', '   ', 'whole run', total
+    open(newunit=u, file=trim(par%path_output)//'/phase_timing.json', status='replace', action='write')
+    write(u, '(a)') '{'
+    do q = 1, NPHASE
+      write(u, '(a,a,a,es14.6,a)') '  "', trim(phase_name(q)), '": ', phase_t(q), ','
+    enddo
+    write(u, '(a,i0,a)') '  "ranks": ', nbproc, ','
+    write(u, '(a,i0,a)') '  "cells": ', n, ','
+    write(u, '(a,i0,a)') '  "major_iterations": ', par%nmajor, ','
+    write(u, '(a,es14.6)') '  "whole run": ', total
+    write(u, '(a)') '}'
+    close(u)
+  end subroutine report_phases
 
   subroutine write_costs(iter)
     integer, intent(in) :: iter
@@ -1296,7 +1357,9 @@ contains
     real(dp), intent(in) :: mfull(:)
     real(dp), intent(out) :: dcalc(:)
     real(dp), allocatable :: dc(:, :)
+    real(dp) :: t0
     integer :: kc
+    t0 = wall()
     do kc = 1, pr(jp)%nc
       model(jp)%val(:, kc) = mfull((kc - 1) * n + cb + 1:(kc - 1) * n + ce)
     enddo
@@ -1304,6 +1367,7 @@ contains
     call model(jp)%calculate_data(pr(jp)%nd, pr(jp)%ndc, matrix_sensit, ipar%problem_weight(jp), cw_loc(:, jp), data(jp)%weight, dc, &
                                   ipar%compression_type, line_start(jp), param_shift(jp), myrank, nbproc)
     dcalc = reshape(dc, (/pr(jp)%ndt/))
+    call lap(7, t0)
   end subroutine calculate_data
 
   ! calculate_cost_model, src/utils/costs.f90:74-113 (first model component only, problem_joint_gravmag.F90:655-657)

@@ -61,15 +61,24 @@ def write_parfile_inputs(wd, nx, ny, nz, ox, oy, ctype, rate, nmajor=1, nminor=1
     X1, X2, Y1, Y2, Z1, Z2 = grid(nx, ny, nz)
     k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
     n = nx * ny * nz
-    cols = np.column_stack([X1, X2, Y1, Y2, Z1, Z2])
-    idx = np.column_stack([i.ravel() + 1, j.ravel() + 1, k.ravel() + 1])
-    with open(os.path.join(wd, "grid.txt"), "w") as f:
-        f.write("%d\n" % n)
-        for p in range(n):
-            f.write("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %d\n" % (tuple(cols[p]) + tuple(idx[p])))
-    with open(os.path.join(wd, "model_true.txt"), "w") as f:
-        f.write("%d\n" % n)
-        f.write("\n".join("%.17g" % v for v in true_model(nx, ny, nz)) + "\n")
+    # (vectorised: a 1e7-cell grid file is 10 columns x 1e7 lines; %.17g of these coordinates is exact)
+    try:
+        import pandas as pd
+        df = pd.DataFrame({"a": X1, "b": X2, "c": Y1, "d": Y2, "e": Z1, "f": Z2, "g": i.ravel() + 1, "h": j.ravel() + 1, "i": k.ravel() + 1})
+        with open(os.path.join(wd, "grid.txt"), "w") as f:
+            f.write("%d\n" % n)
+            df.to_csv(f, sep=" ", header=False, index=False, float_format="%.17g")
+        with open(os.path.join(wd, "model_true.txt"), "w") as f:
+            f.write("%d\n" % n)
+            pd.DataFrame({"v": true_model(nx, ny, nz)}).to_csv(f, header=False, index=False, float_format="%.17g")
+    except ImportError:
+        cols = np.column_stack([X1, X2, Y1, Y2, Z1, Z2, i.ravel() + 1, j.ravel() + 1, k.ravel() + 1])
+        with open(os.path.join(wd, "grid.txt"), "w") as f:
+            f.write("%d\n" % n)
+            np.savetxt(f, cols, fmt=["%.17g"] * 6 + ["%d"] * 3)
+        with open(os.path.join(wd, "model_true.txt"), "w") as f:
+            f.write("%d\n" % n)
+            np.savetxt(f, true_model(nx, ny, nz), fmt="%.17g")
     xs, ys, zs = observations(nx, ny, ox, oy)
     with open(os.path.join(wd, "data_grid.txt"), "w") as f:
         f.write("%d\n" % xs.size)

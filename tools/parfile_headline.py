@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Parfile -> result at the headline scale through the Fortran host: writes the synthetic problem (256x256x152 cells, 316x316 data,
+D4 r = 0.02) as the files a `tomofastx -p Parfile` run reads, runs `tomofastx_amd -p Parfile.txt` (2 major x 100 minor iterations,
+TFX_WRITE_SENSIT=0), collects its per-phase wall clock (phase_timing.json: ASCII read, weights, build, relayout, constraint
+assembly, LSQR, calculate_data, outputs), then runs the same inversion through the Python host over the same libtfx.so and compares
+the data costs and the final data.  Matches src/problem_joint_gravmag.F90:420-560 and src/inversion/damping.F90:97-201.
+  python tools/parfile_headline.py [nx ny nz ox oy ctype rate nmajor nminor] > gpurun_out/r03_parfile_hamersley.json"""
+import importlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tfx = importlib.import_module("tomofast-x_amd")
+EXE = os.path.join(ROOT, "tomofast-x_amd", "host", "tomofastx_amd")
+a = sys.argv[1:]
+nx, ny, nz, ox, oy, ctype = [int(v) for v in a[:6]] if len(a) >= 6 else (256, 256, 152, 316, 316, 2)
+rate = float(a[6]) if len(a) >= 7 else 0.02
+nmajor, nminor = (int(a[7]), int(a[8])) if len(a) >= 9 else (2, 100)
+N = nx * ny * nz
+
+
+def log(msg):
+    sys.stderr.write("[parfile] %s\n" % msg)
+    sys.stderr.flush()
+
+
+def read_col(path, ntok):
+    tok = open(path).read().split()
+    return np.array(tok[1:], np.float64).reshape(-1, ntok)[:, -1]
+
+
+wd = tempfile.mkdtemp(prefix="tfx_parfile_")
+out = {"cells": N, "data": ox * oy, "compression": {0: "none", 1: "haar", 2: "d4"}[ctype], "rate": rate, "nmajor": nmajor, "nminor": nminor}
+try:
+    t0 = time.time()
+    tfx.synthetic.write_parfile_inputs(wd, nx, ny, nz, ox, oy, ctype, rate, nmajor=nmajor, nminor=nminor)
+    out["write_inputs_s (python, not part of the run)"] = round(time.time() - t0, 2)
+    out["input_bytes"] = {f: os.path.getsize(os.path.join(wd, f)) for f in ("grid.txt", "model_true.txt", "data_grid.txt")}
+    log("inputs written in %.1f s: %s" % (time.time() - t0, out["input_bytes"]))
+    t0 = time.time()
+    p = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=3000, env=dict(os.environ, TFX_WRITE_SENSIT="0"))
+    out["fortran_host_wall_s"] = round(time.time() - t0, 2)
+    assert p.returncode == 0 and "THE END." in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+    odir = os.path.join(wd, "output", "synth")
+    out["phase_timing_s"] = json.load(open(os.path.join(odir, "phase_timing.json")))
+    costs = np.loadtxt(os.path.join(odir, "costs.txt"), comments="#", ndmin=2)
+    out["fortran_host_data_cost_per_major_iteration"] = [float(v) for v in costs[:, 1]]
+    d_f = read_col(os.path.join(odir, "data", "grav_final.txt"), 4)
+    m_f = read_col(os.path.join(odir, "model", "grav_final_model_full.txt"), 1)
+    log("Fortran host: %.1f s, phases %s" % (out["fortran_host_wall_s"], out["phase_timing_s"]))
+    # ---- the same run through the Python host
+    ctx = tfx.Context(0)
+    ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
+    cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, ox, oy)
+    t0 = time.time()
+    ctx.calculate_sensit(xs, ys, zs, cw, ctype, rate)
+    t_build = time.time() - t0
+    mtrue = tfx.synthetic.true_model(nx, ny, nz)
+    scaled = mtrue / cw
+    d_obs = ctx.calc_data(ctx.forward_wavelet(scaled, nx, ny, nz, ctype) if ctype else scaled, 1.0, None)
+    t0 = time.time()
+    m_p, d_p, hist = tfx.inversion.solve_problem_gravity(ctx, cw, ctype, d_obs, nmajor, nminor, alpha=1e-7)
+    out["python_host"] = {"build_s": round(t_build, 2), "inversion_s": round(time.time() - t0, 2)}
+    cost_p = float(np.linalg.norm(d_p - d_obs) / np.linalg.norm(d_obs))
+    cost_f = float(np.linalg.norm(d_f - d_obs) / np.linalg.norm(d_obs))
+    out["final_data_cost"] = {"fortran_host": cost_f, "python_host": cost_p, "abs_difference": abs(cost_f - cost_p),
+                              "fortran_costs_txt_last": out["fortran_host_data_cost_per_major_iteration"][-1]}
+    out["final_data_rel_l2_between_hosts"] = float(np.linalg.norm(d_f - d_p) / np.linalg.norm(d_p))
+    out["final_model_rel_l2_between_hosts"] = float(np.linalg.norm(m_f - m_p) / np.linalg.norm(m_p))
+    out["model_min_max"] = [float(m_f.min()), float(m_f.max())]
+    ctx.close()
+    print(json.dumps(out))
+    ok = abs(cost_f - cost_p) <= 1e-9 + 1e-6 * cost_p
+    log("data cost: Fortran host %.12e, Python host %.12e, |difference| %.2e; data rel-L2 between hosts %.2e -> %s" %
+        (cost_f, cost_p, abs(cost_f - cost_p), out["final_data_rel_l2_between_hosts"], "OK" if ok else "MISMATCH"))
+    sys.exit(0 if ok else 1)
+finally:
+    shutil.rmtree(wd, ignore_errors=True)
