@@ -9,6 +9,7 @@
 !
 !   reference call site (src/problem_joint_gravmag.F90)                     reference procedure replaced
 !   :174   calculate_depth_weight(par, iarr, grid_full, data, myrank, nbproc)         weights_gravmag.f90:46-196
+!          (iarr: t_inversion_arrays with column_weight / residuals and allocate_aux / reallocate_aux, inversion_arrays.f90:30-44)
 !   :197   calculate_and_write_sensit(par, grid_full, data, column_weight, memory, myrank, nbproc)
 !                                                                                sensitivity_gravmag.F90:82-410
 !   :207   calculate_new_partitioning(par, nnz, nelements_at_cpu, problem_type, myrank, nbproc)     :573-640
@@ -160,6 +161,21 @@ module tfx_reference_api
   integer, save :: part_cb = 0, part_ce = 0          ! this rank's cells (part_cb, part_ce] after calculate_new_partitioning
   integer, allocatable, save :: part_nel(:)
   logical, save :: partitioned = .false.
+
+  ! ---- src/inversion/inversion_arrays.f90:30-44: the auxiliary arrays of the inversion, same field and procedure names
+  type, public :: t_inversion_arrays
+    real(dp), allocatable :: residuals(:, :)       ! (ndata_components, ndata): data measured - data calculated
+    real(dp), allocatable :: column_weight(:)      ! weights that scale the sensitivity matrix columns (here over ALL cells)
+  contains
+    procedure, public, pass :: allocate_aux => inversion_arrays_allocate_aux
+    procedure, public, pass :: reallocate_aux => inversion_arrays_reallocate_aux
+  end type t_inversion_arrays
+
+  ! calculate_depth_weight(par, iarr, grid_full, data, myrank, nbproc) is the reference's form (weights_gravmag.f90:46); the form with
+  ! the plain array in iarr's place is kept for callers that hold no t_inversion_arrays
+  interface calculate_depth_weight
+    module procedure calculate_depth_weight_iarr, calculate_depth_weight_array
+  end interface calculate_depth_weight
 
   public :: tfx_api_context, tfx_api_finalize, exit_MPI
   public :: calculate_depth_weight, calculate_and_write_sensit, calculate_new_partitioning, read_sensitivity_kernel
@@ -402,9 +418,55 @@ contains
   end subroutine get_full_array
 
   !-------------------------------------------------------------------------------------------------------
-  ! calculate_depth_weight, src/forward/gravmag/weights_gravmag.f90:46-196 (types 1, 2 and 3; the reference's iarr%column_weight is
-  ! the plain array here).  The multiplier of problem_joint_gravmag.F90:178 is applied by the caller, as in the reference.
-  subroutine calculate_depth_weight(par, column_weight, grid_full, data, myrank_, nbproc_)
+  ! inversion_arrays_allocate_aux / _reallocate_aux, src/inversion/inversion_arrays.f90:50-95.  The reference sizes column_weight
+  ! by the cells of the rank; here the weight is kept for ALL cells on every rank (the row generators need the whole vector, the
+  ! reference gathers it inside calculate_and_write_sensit), so `nelements` only sizes what a caller asks for explicitly and a later
+  ! reallocation with the new partition's count keeps the full vector.
+  subroutine inversion_arrays_allocate_aux(this, nelements, ndata, ndata_components, myrank_)
+    class(t_inversion_arrays), intent(inout) :: this
+    integer, intent(in) :: nelements, ndata, ndata_components, myrank_
+    if (myrank_ == 0) print *, 'Allocating auxiliarily inversion arrays...'
+    if (ndata <= 0 .or. nelements <= 0) call exit_MPI('Wrong dimensions in inversion_arrays_allocate_aux!', myrank_, 0)
+    if (allocated(this%residuals)) deallocate(this%residuals)
+    if (allocated(this%column_weight)) deallocate(this%column_weight)
+    allocate(this%residuals(ndata_components, ndata), this%column_weight(nelements))
+    this%residuals = 0.d0
+    this%column_weight = 1.d0
+  end subroutine inversion_arrays_allocate_aux
+
+  subroutine inversion_arrays_reallocate_aux(this, nelements, ndata, ndata_components, myrank_)
+    class(t_inversion_arrays), intent(inout) :: this
+    integer, intent(in) :: nelements, ndata, ndata_components, myrank_
+    if (.not. allocated(this%residuals)) then
+      call this%allocate_aux(nelements, ndata, ndata_components, myrank_)
+    else if (size(this%residuals, 1) /= ndata_components .or. size(this%residuals, 2) /= ndata) then
+      deallocate(this%residuals)
+      allocate(this%residuals(ndata_components, ndata))
+      this%residuals = 0.d0
+    endif
+    ! (the column weight stays: it is the full vector, which read_sensitivity_kernel slices by the new partition)
+  end subroutine inversion_arrays_reallocate_aux
+
+  !-------------------------------------------------------------------------------------------------------
+  ! calculate_depth_weight, src/forward/gravmag/weights_gravmag.f90:46-196 (types 1, 2 and 3), the reference's argument list:
+  ! the result goes to iarr%column_weight, (re)sized to all cells.
+  subroutine calculate_depth_weight_iarr(par, iarr, grid_full, data, myrank_, nbproc_)
+    class(t_parameters_base), intent(in) :: par
+    type(t_inversion_arrays), intent(inout) :: iarr
+    type(t_grid), intent(in) :: grid_full
+    type(t_data), intent(in) :: data
+    integer, intent(in) :: myrank_, nbproc_
+    integer :: ntot
+    ntot = par%nx * par%ny * par%nz
+    if (allocated(iarr%column_weight)) then
+      if (size(iarr%column_weight) /= ntot) deallocate(iarr%column_weight)
+    endif
+    if (.not. allocated(iarr%column_weight)) allocate(iarr%column_weight(ntot))
+    call calculate_depth_weight_array(par, iarr%column_weight, grid_full, data, myrank_, nbproc_)
+  end subroutine calculate_depth_weight_iarr
+
+  ! The same with the plain array.  The multiplier of problem_joint_gravmag.F90:178 is applied by the caller, as in the reference.
+  subroutine calculate_depth_weight_array(par, column_weight, grid_full, data, myrank_, nbproc_)
     class(t_parameters_base), intent(in) :: par
     real(dp), intent(out) :: column_weight(:)
     type(t_grid), intent(in) :: grid_full
@@ -426,7 +488,7 @@ contains
     else
       call exit_MPI('Not known depth weight type!', myrank_, par%depth_weighting_type)      ! weights_gravmag.f90:164
     endif
-  end subroutine calculate_depth_weight
+  end subroutine calculate_depth_weight_array
 
   !-------------------------------------------------------------------------------------------------------
   integer function problem_of(par)

@@ -436,6 +436,7 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
   ! joint inversion's two matrices + right-hand side (joint_inverse_problem.F90:60-80)
   type(t_data) :: data(2)
   type(t_model) :: model(2)
+  type(t_inversion_arrays) :: iarr(2)                                               ! :73
   type(t_sparse_matrix) :: matrix_sensit, matrix_cons
   real(dp), allocatable :: b_RHS(:), delta_model(:), cw_loc(:, :)
   integer, allocatable :: nelements_at_cpu(:)
@@ -592,11 +593,12 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
     do ip = 1, 2
       if (.not. pr(ip)%on) cycle
       if (ip == 1) then
-        call calculate_depth_weight(gpar, pr(ip)%cw, model(ip)%grid_full, data(ip), myrank, nbproc)
+        call calculate_depth_weight(gpar, iarr(ip), model(ip)%grid_full, data(ip), myrank, nbproc)          ! :174-175
       else
-        call calculate_depth_weight(mpar, pr(ip)%cw, model(ip)%grid_full, data(ip), myrank, nbproc)
+        call calculate_depth_weight(mpar, iarr(ip), model(ip)%grid_full, data(ip), myrank, nbproc)
       endif
-      pr(ip)%cw = ipar%column_weight_multiplier(ip) * pr(ip)%cw                    ! :178
+      iarr(ip)%column_weight = ipar%column_weight_multiplier(ip) * iarr(ip)%column_weight                  ! :178-179
+      pr(ip)%cw = iarr(ip)%column_weight
       call apply_local_depth_weighting(ip)                                         ! :181-182
     enddo
   endif

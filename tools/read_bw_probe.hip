@@ -101,6 +101,28 @@ __global__ __launch_bounds__(1024) void k_read_rec(const char *__restrict__ base
     }
     if (acc == 1.2345f || macc == 77) out[0] = acc;
 }
+// record-size sweep: [values 2048 B | slot stream as dwordx2 per lane (512 B) + optional dwordx1 per lane (256 B) | masks 64 B], padded to REC bytes
+template <int REC, int THIRD>
+__global__ __launch_bounds__(1024) void k_read_sweep(const char *__restrict__ base, size_t nchunks, float *out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    unsigned long long macc = 0;
+    const size_t per = (nchunks + gridDim.x - 1) / gridDim.x, c0 = blockIdx.x * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+    for (size_t c = c0 + wave; c < c1; c += 16) {
+        const char *r = base + c * (size_t)REC;
+        const float *vp = (const float *)r;
+        const f4 a = __builtin_nontemporal_load((const f4 *)(vp + lane * 4)), b = __builtin_nontemporal_load((const f4 *)(vp + 256 + lane * 4));
+        const unsigned *sp = (const unsigned *)(r + 2048) + lane * 2;
+        unsigned w0 = __builtin_nontemporal_load(sp), w1 = __builtin_nontemporal_load(sp + 1), w2 = 0;
+        if (THIRD) w2 = __builtin_nontemporal_load((const unsigned *)(r + 2048 + 512) + lane);
+        const unsigned long long *mp = (const unsigned long long *)(r + 2048 + 512 + (THIRD ? 256 : 0));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) macc += mp[k];
+        acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + (float)(w0 ^ w1 ^ w2);
+    }
+    if (acc == 1.2345f || macc == 77) out[0] = acc;
+}
 __global__ void k_copy(const f4 *__restrict__ a, f4 *__restrict__ b, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
@@ -158,6 +180,18 @@ int main()
             snprintf(nm, 96, "2624-B records (8 B slots per lane), %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read_rec<512, 1>), dim3(wgs), dim3(1024), 0, 0, rec, nch, out); }, (double)nch * 2624);
             snprintf(nm, 96, "  same, 4 chunks in flight per wave, %4d WGs", wgs); timeit(nm, [&]() { hipLaunchKernelGGL((k_read_rec<576, 4>), dim3(wgs), dim3(1024), 0, 0, rec, nch, out); }, (double)nch * 2688);
         }
+    }
+    {
+        const size_t nch = (size_t)16 << 20;
+        char *rec;
+        CK(hipMalloc(&rec, nch * 3072)); CK(hipMemset(rec, 0, nch * 3072));
+        const int wgs = 4096;
+        char nm[96];
+#define SWEEP(REC, THIRD) snprintf(nm, 96, "sweep: %d-B records, %s", REC, THIRD ? "x4 x4 x2 x1 + masks" : "x4 x4 x2 + masks"); \
+        timeit(nm, [&]() { hipLaunchKernelGGL((k_read_sweep<REC, THIRD>), dim3(wgs), dim3(1024), 0, 0, rec, nch, out); }, (double)nch * REC);
+        SWEEP(2624, 0) SWEEP(2688, 0) SWEEP(2752, 0) SWEEP(2816, 0) SWEEP(2880, 0) SWEEP(3072, 0)
+        SWEEP(2880, 1) SWEEP(2944, 1) SWEEP(3072, 1)
+#undef SWEEP
     }
     timeit("copy f4 (read + write)", [&]() { hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, p, q, n); }, 2.0 * bytes);
     return 0;
