@@ -70,6 +70,14 @@ try:
     t0 = time.time()
     m_p, d_p, hist = tfx.inversion.solve_problem_gravity(ctx, cw, ctype, d_obs, nmajor, nminor, alpha=1e-7)
     out["python_host"] = {"build_s": round(t_build, 2), "inversion_s": round(time.time() - t0, 2)}
+    out["deterministic_products"] = os.environ.get("TFX_DETERMINISTIC") == "1"
+    if os.environ.get("PARFILE_SCATTER") == "1":
+        # the SAME host, the same matrix, a second run: how far the run-dependent summation order of the LDS atomics moves an
+        # unconverged 2 x 100-iteration solve (0 with TFX_DETERMINISTIC=1)
+        m_q, d_q, _ = tfx.inversion.solve_problem_gravity(ctx, cw, ctype, d_obs, nmajor, nminor, alpha=1e-7)
+        out["python_host_run_to_run"] = {"data_rel_l2": float(np.linalg.norm(d_q - d_p) / np.linalg.norm(d_p)),
+                                         "model_rel_l2": float(np.linalg.norm(m_q - m_p) / np.linalg.norm(m_p)),
+                                         "data_cost_abs_difference": abs(float(np.linalg.norm(d_q - d_obs) / np.linalg.norm(d_obs)) - float(np.linalg.norm(d_p - d_obs) / np.linalg.norm(d_obs)))}
     cost_p = float(np.linalg.norm(d_p - d_obs) / np.linalg.norm(d_obs))
     cost_f = float(np.linalg.norm(d_f - d_obs) / np.linalg.norm(d_obs))
     out["final_data_cost"] = {"fortran_host": cost_f, "python_host": cost_p, "abs_difference": abs(cost_f - cost_p),
@@ -79,7 +87,15 @@ try:
     out["model_min_max"] = [float(m_f.min()), float(m_f.max())]
     ctx.close()
     print(json.dumps(out))
-    ok = abs(cost_f - cost_p) <= 1e-9 + 1e-6 * cost_p
+    # agreement bar: 1e-9 on the data cost when the products are deterministic; otherwise within 3 x the Python host's own run-to-run
+    # scatter (the summation order of the LDS atomics is run-dependent and an unconverged LSQR amplifies it)
+    tol = 1e-9
+    if "python_host_run_to_run" in out:
+        tol = max(tol, 3.0 * out["python_host_run_to_run"]["data_cost_abs_difference"])
+    out["data_cost_tolerance"] = tol
+    ok = abs(cost_f - cost_p) <= tol
+    out["hosts_agree"] = bool(ok)
+    print(json.dumps(out))
     log("data cost: Fortran host %.12e, Python host %.12e, |difference| %.2e; data rel-L2 between hosts %.2e -> %s" %
         (cost_f, cost_p, abs(cost_f - cost_p), out["final_data_rel_l2_between_hosts"], "OK" if ok else "MISMATCH"))
     sys.exit(0 if ok else 1)
