@@ -294,6 +294,7 @@ def setup_comm(ctx, rank, nranks, device_index=0, want_rccl=None, log=None, init
 def _try_rccl(ctx, rank, nranks, device_index, timeout, report):
     """Rung 1 of setup_comm.  Returns None when every rank holds a working communicator, else the reason (the same decision on all
     ranks); on failure no rank is left with a communicator."""
+    import os
     import torch
     import torch.distributed as dist
     grp = control_group()
@@ -314,17 +315,23 @@ def _try_rccl(ctx, rank, nranks, device_index, timeout, report):
     # -- pre-flight: every rank on a GPU of its own (bus ids over the control channel), rank 0 can draw an id
     mine, err, uid = None, None, b"\0" * 128
     try:
+        import socket
         props = torch.cuda.get_device_properties(device_index)
         bus = tuple(getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
-        mine = "pci %s:%s:%s" % bus if None not in bus else "uuid %s" % (getattr(props, "uuid", None),)
+        # two ranks share a GPU when they sit on the same host AND drive the same device index (the PCI address rides along for the
+        # log; it is not trusted on its own - a virtualised box may report the same address for every device)
+        vis = "|".join(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        mine = (socket.gethostname(), int(device_index), vis, "pci %s:%s:%s" % bus if None not in bus else "uuid %s" % (getattr(props, "uuid", None),))
         if rank == 0:
             uid = ctx.comm_unique_id()
     except Exception as e:      # noqa
         err = repr(e)
     ids = [None] * nranks
     dist.all_gather_object(ids, (mine, err), group=grp)
+    # (every field must coincide: when in doubt the rendezvous is tried - RCCL itself refuses two ranks on one GPU, and the ladder
+    # then moves all ranks to the hooks)
     dup = len({i[0] for i in ids}) != nranks
-    local = err or ("ranks share a GPU (%s)" % ", ".join(str(i[0]) for i in ids) if dup else None)
+    local = err or ("ranks share a GPU (%s)" % ", ".join("%s gpu %s [%s] %s" % i[0] if i[0] else "?" for i in ids) if dup else None)
     if not agree(local is None):
         return fail_all("pre-flight", local)
     step.append({"stage": "pre-flight", "ok": True})

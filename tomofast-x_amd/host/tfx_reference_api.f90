@@ -81,6 +81,10 @@ module tfx_reference_api
     real(dp) :: problem_weight(2) = (/1.d0, 0.d0/), column_weight_multiplier(2) = 1.d0
     integer :: admm_type = 0
     real(dp) :: rho_ADMM(2) = 1.d-7
+    ! what decides WAVELET_DOMAIN (joint_inverse_problem.F90:189-198) and the shape of the damping / ADMM blocks; same names
+    integer :: admm_bound_type = 1, nlithos = 1
+    integer :: apply_local_damping_weight = 0
+    real(dp) :: beta(2) = 0.d0, cross_grad_weight = 0.d0, clustering_weight_glob(2) = 0.d0
   end type t_parameters_inversion
 
   ! ---- src/inversion/grid.F90:30-50 (plain allocatables instead of shared-memory windows: one process per GPU)
@@ -133,9 +137,16 @@ module tfx_reference_api
   type, public :: t_model
     integer :: nelements = 0, nelements_total = 0, ncomponents = 1
     real(dp), allocatable :: val(:, :)               ! (nelements, ncomponents): this rank's cells
+    real(dp), allocatable :: val_prior(:, :)         ! prior model (local), same shape
+    integer :: nlithos = 1                           ! data arrays for the ADMM constraints (local cells)
+    real(dp), allocatable :: min_bound(:, :), max_bound(:, :)      ! (nlithos, nelements)
+    real(dp), allocatable :: bound_weight(:)
+    real(dp), allocatable :: damping_weight(:)       ! local damping weights (for the prior model term)
     type(t_grid) :: grid_full
   contains
     procedure, public, pass :: initialize => model_initialize
+    procedure, public, pass :: allocate_bound_arrays => model_allocate_bound_arrays
+    procedure, public, pass :: update => model_update
     procedure, public, pass :: calculate_data => model_calculate_data
   end type t_model
 
@@ -176,6 +187,44 @@ module tfx_reference_api
   interface calculate_depth_weight
     module procedure calculate_depth_weight_iarr, calculate_depth_weight_array
   end interface calculate_depth_weight
+
+  ! ---- src/inversion/joint_inverse_problem.F90:42-123: the joint inversion (also used for single inversions) - the two matrices
+  ! of the system, its right-hand side, the ADMM state.  Same procedure names and argument lists as the reference:
+  !   problem_joint_gravmag.F90:236  call jinv%initialize(ipar, nnz, myrank)
+  !                            :263  call jinv%initialize2(ipar, iarr, model, myrank, nbproc)
+  !                            :327  call jinv%calculate_matrix_partitioning(ipar, line_start, line_end, param_shift)
+  !                       :393, :494  call jinv%reset(myrank)
+  !                            :497  call jinv%solve(ipar, iarr, model, delta_model, memory_inv, myrank, nbproc)
+  ! solve assembles b_RHS = [problem_weight * residuals ; constraint right-hand sides] and the constraint rows - the damping block
+  ! (damping.F90:97-234: L2 or Lp, optional local weights) and the ADMM block (admm_method.F90:70-134) of every active problem,
+  ! then the general rows the caller registered - and hands the system to lsqr_solve_sensit, i.e. to the GPU; the update comes back
+  ! in model space (inverse transform when WAVELET_DOMAIN, times the column weight: joint_inverse_problem.F90:556-571).
+  ! The builders of gradient damping, cross-gradient and clustering rows live with the caller (they are outside the hot path): it
+  ! passes their rows in with set_general_rows before solve, where the reference builds them inside solve.
+  type, public :: t_joint_inversion
+    type(t_sparse_matrix), public :: matrix_sensit          ! the (device-resident) sensitivity kernel(s)
+    type(t_sparse_matrix), public :: matrix_cons            ! the constraint rows of the current major iteration
+    real(dp), allocatable :: b_RHS(:)
+    integer :: nelements_total = 0, ndata_lines = 0
+    logical :: add_damping(2) = .false., add_damping_gradient(2) = .false., add_admm(2) = .false.
+    logical, public :: add_cross_grad = .false., add_clustering = .false.
+    real(dp) :: admm_cost(2) = 0.d0
+    logical, public :: WAVELET_DOMAIN = .true.
+    real(dp), allocatable :: z_admm(:, :), u_admm(:, :), x0_ADMM(:, :)      ! (nelements, problem): admm_method's arrays
+    integer(c_int64_t) :: g_nrows = 0                        ! general rows of the next solve (set_general_rows)
+    integer(c_int64_t), allocatable :: g_rowptr(:)
+    integer(c_int32_t), allocatable :: g_cols(:)
+    real(c_float), allocatable :: g_vals(:)
+    real(dp), allocatable :: g_rhs(:)
+  contains
+    procedure, public, pass :: initialize => joint_inversion_initialize
+    procedure, public, pass :: initialize2 => joint_inversion_initialize2
+    procedure, public, pass :: reset => joint_inversion_reset
+    procedure, public, pass :: solve => joint_inversion_solve
+    procedure, public, pass :: get_admm_cost => joint_inversion_get_admm_cost
+    procedure, public, pass :: set_general_rows => joint_inversion_set_general_rows
+    procedure, public, nopass :: calculate_matrix_partitioning => joint_inversion_calculate_matrix_partitioning
+  end type t_joint_inversion
 
   public :: tfx_api_context, tfx_api_finalize, exit_MPI
   public :: calculate_depth_weight, calculate_and_write_sensit, calculate_new_partitioning, read_sensitivity_kernel
@@ -283,9 +332,32 @@ contains
     integer :: ierr
     this%nelements = nelements; this%ncomponents = ncomponents; this%nelements_total = nelements_total
     if (allocated(this%val)) deallocate(this%val)
+    if (allocated(this%val_prior)) deallocate(this%val_prior)
+    if (allocated(this%damping_weight)) deallocate(this%damping_weight)
     allocate(this%val(nelements, ncomponents), source=0.d0, stat=ierr)
     if (ierr /= 0) call exit_MPI('Dynamic memory allocation error in model_initialize!', myrank, ierr)
+    allocate(this%val_prior(nelements, ncomponents), source=0.d0, stat=ierr)
+    if (ierr /= 0) call exit_MPI('Dynamic memory allocation error in model_initialize!', myrank, ierr)
+    allocate(this%damping_weight(nelements), source=1.d0, stat=ierr)
+    if (ierr /= 0) call exit_MPI('Dynamic memory allocation error in model_initialize!', myrank, ierr)
   end subroutine model_initialize
+
+  subroutine model_allocate_bound_arrays(this, nlithos, myrank)                   ! model.F90:150-170
+    class(t_model), intent(inout) :: this
+    integer, intent(in) :: nlithos, myrank
+    integer :: ierr
+    this%nlithos = nlithos
+    if (allocated(this%min_bound)) deallocate(this%min_bound, this%max_bound, this%bound_weight)
+    allocate(this%min_bound(nlithos, this%nelements), this%max_bound(nlithos, this%nelements), this%bound_weight(this%nelements), stat=ierr)
+    if (ierr /= 0) call exit_MPI('Dynamic memory allocation error in model_allocate_bound_arrays!', myrank, ierr)
+    this%min_bound = 0.d0; this%max_bound = 0.d0; this%bound_weight = 1.d0
+  end subroutine model_allocate_bound_arrays
+
+  subroutine model_update(this, delta_model)                                      ! model.F90:194-200
+    class(t_model), intent(inout) :: this
+    real(dp), intent(in) :: delta_model(this%nelements, this%ncomponents)
+    this%val = this%val + delta_model
+  end subroutine model_update
 
   !-------------------------------------------------------------------------------------------------------
   ! t_sparse_matrix as a row builder for the constraint matrix (sparse_matrix.f90:107-293)
@@ -418,10 +490,9 @@ contains
   end subroutine get_full_array
 
   !-------------------------------------------------------------------------------------------------------
-  ! inversion_arrays_allocate_aux / _reallocate_aux, src/inversion/inversion_arrays.f90:50-95.  The reference sizes column_weight
-  ! by the cells of the rank; here the weight is kept for ALL cells on every rank (the row generators need the whole vector, the
-  ! reference gathers it inside calculate_and_write_sensit), so `nelements` only sizes what a caller asks for explicitly and a later
-  ! reallocation with the new partition's count keeps the full vector.
+  ! inversion_arrays_allocate_aux / _reallocate_aux, src/inversion/inversion_arrays.f90:50-95.  Before calculate_new_partitioning
+  ! every rank holds the whole model (par%nelements = all cells), so column_weight is the full vector the row generators need;
+  ! reallocate_aux re-sizes it to the cells of the new partition like the reference.
   subroutine inversion_arrays_allocate_aux(this, nelements, ndata, ndata_components, myrank_)
     class(t_inversion_arrays), intent(inout) :: this
     integer, intent(in) :: nelements, ndata, ndata_components, myrank_
@@ -439,12 +510,22 @@ contains
     integer, intent(in) :: nelements, ndata, ndata_components, myrank_
     if (.not. allocated(this%residuals)) then
       call this%allocate_aux(nelements, ndata, ndata_components, myrank_)
-    else if (size(this%residuals, 1) /= ndata_components .or. size(this%residuals, 2) /= ndata) then
+      return
+    endif
+    if (size(this%residuals, 1) /= ndata_components .or. size(this%residuals, 2) /= ndata) then
       deallocate(this%residuals)
       allocate(this%residuals(ndata_components, ndata))
       this%residuals = 0.d0
     endif
-    ! (the column weight stays: it is the full vector, which read_sensitivity_kernel slices by the new partition)
+    ! like the reference (inversion_arrays.f90:78-95): the column weight is re-sized to the cells of the new partition;
+    ! read_sensitivity_kernel fills it (the library keeps the full vector the kernel was built with)
+    if (allocated(this%column_weight)) then
+      if (size(this%column_weight) /= nelements) deallocate(this%column_weight)
+    endif
+    if (.not. allocated(this%column_weight)) then
+      allocate(this%column_weight(nelements))
+      this%column_weight = 1.d0
+    endif
   end subroutine inversion_arrays_reallocate_aux
 
   !-------------------------------------------------------------------------------------------------------
@@ -1316,5 +1397,307 @@ contains
     u = 0.d0                                                ! consumed, like the reference's in-place use of the right-hand side
     if (myrank_ == 0) print *, 'End of subroutine lsqr_solve_sensit, r =', rr, ' iter =', iters          ! :300-305
   end subroutine lsqr_solve_sensit
+
+  !=======================================================================================================
+  ! t_joint_inversion - src/inversion/joint_inverse_problem.F90
+  !=======================================================================================================
+  ! joint_inversion_initialize, :124-216: which terms the system has, and the WAVELET_DOMAIN rule (:189-198): the unknowns are wavelet
+  ! coefficients unless a constraint acts in space (cross-gradient, clustering, gradient damping, Lp damping, local ADMM bounds,
+  ! local damping weights).  The sensitivity matrix itself is allocated by read_sensitivity_kernel (it lives on the device).
+  subroutine joint_inversion_initialize(this, par, nnz_sensit, myrank)
+    class(t_joint_inversion), intent(inout) :: this
+    type(t_parameters_inversion), intent(in) :: par
+    integer(c_int64_t), intent(in) :: nnz_sensit
+    integer, intent(in) :: myrank
+    integer :: i
+    this%nelements_total = par%nelements_total
+    do i = 1, 2
+      this%add_damping(i) = par%problem_weight(i) /= 0.d0 .and. par%alpha(i) /= 0.d0
+      this%add_damping_gradient(i) = par%problem_weight(i) /= 0.d0 .and. par%beta(i) /= 0.d0
+      this%add_admm(i) = par%problem_weight(i) /= 0.d0 .and. par%admm_type > 0
+    enddo
+    this%add_cross_grad = par%cross_grad_weight /= 0.d0
+    this%add_clustering = any(par%clustering_weight_glob /= 0.d0 .and. par%problem_weight /= 0.d0)
+    this%admm_cost = 0.d0
+    this%WAVELET_DOMAIN = .true.
+    if (this%add_cross_grad .or. this%add_clustering .or. this%add_damping_gradient(1) .or. this%add_damping_gradient(2) .or. &
+        par%norm_power /= 2.d0 .or. par%admm_bound_type /= 1 .or. par%apply_local_damping_weight > 0) this%WAVELET_DOMAIN = .false.
+    if (myrank == 0) print *, 'WAVELET_DOMAIN =', this%WAVELET_DOMAIN
+    if (myrank == 0) print *, 'nnz of the sensitivity kernel =', nnz_sensit
+  end subroutine joint_inversion_initialize
+
+  ! joint_inversion_initialize2, :223-359: the remaining allocations, after the kernel has been read (the constraint matrix and the
+  ! right-hand side are sized by the first solve, when the general rows of the caller are known)
+  subroutine joint_inversion_initialize2(this, par, arr, model, myrank, nbproc)
+    class(t_joint_inversion), intent(inout) :: this
+    type(t_parameters_inversion), intent(in) :: par
+    type(t_inversion_arrays), intent(in) :: arr(2)
+    type(t_model), intent(in) :: model(2)
+    integer, intent(in) :: myrank, nbproc
+    integer :: i
+    this%ndata_lines = 0
+    do i = 1, 2
+      if (par%problem_weight(i) /= 0.d0) this%ndata_lines = this%ndata_lines + par%ndata(i) * par%ndata_components(i)
+    enddo
+    if (allocated(this%z_admm)) deallocate(this%z_admm, this%u_admm, this%x0_ADMM)
+    allocate(this%z_admm(par%nelements, 2), this%u_admm(par%nelements, 2), this%x0_ADMM(par%nelements, 2))
+    this%z_admm = 0.d0; this%u_admm = 0.d0; this%x0_ADMM = 0.d0
+    if (myrank == 0 .and. nbproc > 1) print *, 'joint inversion: data rows =', this%ndata_lines, ', cells of rank 0 =', model(1)%nelements + model(2)%nelements, &
+                                               size(arr(1)%column_weight) + size(arr(2)%column_weight)
+  end subroutine joint_inversion_initialize2
+
+  subroutine joint_inversion_reset(this, myrank)                                   ! :366-380
+    class(t_joint_inversion), intent(inout) :: this
+    integer, intent(in) :: myrank
+    if (allocated(this%b_RHS)) this%b_RHS = 0.d0
+    if (allocated(this%matrix_cons%ijl)) call this%matrix_cons%reset()
+    if (myrank < 0) return
+  end subroutine joint_inversion_reset
+
+  pure function joint_inversion_get_admm_cost(this) result(res)                    ! :585-590
+    class(t_joint_inversion), intent(in) :: this
+    real(dp) :: res(2)
+    res = this%admm_cost
+  end function joint_inversion_get_admm_cost
+
+  ! Rows of the constraints that are built outside this module (gradient damping, cross-gradient, clustering), for the NEXT solve:
+  ! CSR with 1-based local columns of this rank's unknowns, rows replicated on all ranks, and their right-hand side.
+  subroutine joint_inversion_set_general_rows(this, nrows, rowptr, cols, vals, rhs)
+    class(t_joint_inversion), intent(inout) :: this
+    integer(c_int64_t), intent(in) :: nrows
+    integer(c_int64_t), intent(in), optional :: rowptr(:)
+    integer(c_int32_t), intent(in), optional :: cols(:)
+    real(c_float), intent(in), optional :: vals(:)
+    real(dp), intent(in), optional :: rhs(:)
+    integer(c_int64_t) :: nnz
+    this%g_nrows = nrows
+    if (allocated(this%g_rowptr)) deallocate(this%g_rowptr, this%g_cols, this%g_vals, this%g_rhs)
+    if (nrows <= 0) return
+    nnz = rowptr(nrows + 1)
+    allocate(this%g_rowptr(nrows + 1), this%g_cols(max(nnz, 1_c_int64_t)), this%g_vals(max(nnz, 1_c_int64_t)), this%g_rhs(nrows))
+    this%g_rowptr = rowptr(1:nrows + 1)
+    if (nnz > 0) then
+      this%g_cols(1:nnz) = cols(1:nnz)
+      this%g_vals(1:nnz) = vals(1:nnz)
+    endif
+    this%g_rhs = rhs(1:nrows)
+  end subroutine joint_inversion_set_general_rows
+
+  ! joint_inversion_calculate_matrix_partitioning, :712-739: rows of problem 2 follow problem 1's data rows, its columns follow
+  ! problem 1's local unknowns
+  subroutine joint_inversion_calculate_matrix_partitioning(par, line_start, line_end, param_shift)
+    type(t_parameters_inversion), intent(in) :: par
+    integer, intent(out) :: line_start(2), line_end(2), param_shift(2)
+    line_start = 0; line_end = 0; param_shift = 0
+    if (par%problem_weight(1) /= 0.d0) line_end(1) = par%ndata(1) * par%ndata_components(1)
+    if (par%problem_weight(2) /= 0.d0) then
+      line_start(2) = line_end(1)
+      line_end(2) = line_start(2) + par%ndata(2) * par%ndata_components(2)
+      if (par%problem_weight(1) /= 0.d0) param_shift(2) = par%nelements          ! (gravity has one model component)
+    endif
+  end subroutine joint_inversion_calculate_matrix_partitioning
+
+  ! admm_method_iterate_admm_arrays, src/inversion/admm_method.F90:70-134: projection of x + u onto the union of the cell's intervals
+  subroutine iterate_admm_arrays(nel, nlithos, min_bound, max_bound, xm, z, u, x0out)
+    integer, intent(in) :: nel, nlithos
+    real(dp), intent(in) :: min_bound(nlithos, nel), max_bound(nlithos, nel), xm(nel)
+    real(dp), intent(inout) :: z(nel), u(nel)
+    real(dp), intent(out) :: x0out(nel)
+    integer :: p, j
+    real(dp) :: a, mindist, v, closest
+    logical :: inside
+    do p = 1, nel
+      a = xm(p) + u(p)
+      inside = .false.
+      do j = 1, nlithos
+        if (min_bound(j, p) <= a .and. a <= max_bound(j, p)) then
+          inside = .true.
+          z(p) = a
+          exit
+        endif
+      enddo
+      if (.not. inside) then
+        mindist = 1.d30
+        closest = a
+        do j = 1, nlithos
+          v = dabs(min_bound(j, p) - a)
+          if (v < mindist) then
+            mindist = v
+            closest = min_bound(j, p)
+          endif
+          v = dabs(max_bound(j, p) - a)
+          if (v < mindist) then
+            mindist = v
+            closest = max_bound(j, p)
+          endif
+        enddo
+        z(p) = closest
+      endif
+    enddo
+    u = u + xm - z
+    x0out = z - u
+  end subroutine iterate_admm_arrays
+
+  ! this rank's slice of a model-sized quantity, divided by the FULL column weight (zero guard of damping.F90:129-135), gathered from all
+  ! ranks and - in the wavelet domain - transformed (damping.F90:135-150, wavelet_utils.F90:37-72)
+  subroutine scaled_full_vector(ip, loc, nloc, full, par, wavelet, myrank, nbproc)
+    integer, intent(in) :: ip, nloc, myrank, nbproc
+    real(dp), intent(in) :: loc(nloc)
+    real(dp), intent(out) :: full(:)
+    type(t_parameters_inversion), intent(in) :: par
+    logical, intent(in) :: wavelet
+    integer :: p
+    call get_full_array(loc, nloc, full, myrank, nbproc)
+    do p = 1, size(full)
+      if (kst(ip)%cw_full(p) /= 0.d0) then
+        full(p) = full(p) / kst(ip)%cw_full(p)
+      else
+        full(p) = 0.d0
+      endif
+    enddo
+    if (wavelet .and. par%compression_type > 0) call forward_wavelet(full, par%nx, par%ny, par%nz, par%compression_type)
+  end subroutine scaled_full_vector
+
+  !-------------------------------------------------------------------------------------------------------
+  ! joint_inversion_solve, :393-573.  delta_model(nelements, nmodel_components, 2): the update of this rank's cells in model space.
+  subroutine joint_inversion_solve(this, par, arr, model, delta_model, memory, myrank, nbproc)
+    class(t_joint_inversion), intent(inout) :: this
+    type(t_parameters_inversion), intent(in) :: par
+    type(t_inversion_arrays), intent(in) :: arr(2)
+    type(t_model), intent(inout) :: model(2)
+    integer, intent(in) :: myrank, nbproc
+    real(dp), intent(out) :: memory
+    real(dp), intent(out) :: delta_model(par%nelements, par%nmodel_components, 2)
+    logical :: SOLVE_PROBLEM(2)
+    integer :: line_start(2), line_end(2), param_shift(2)
+    integer :: i, k, p, ntot, nloc, cb, ce, nl_cons, lc, lc0, nc, ndt, kadm, ncols, row
+    integer(c_int64_t) :: e8, nnz_cons
+    real(dp), allocatable :: full(:), x(:), loc(:)
+    real(dp) :: s1, s2, s3, sums(2)
+
+    SOLVE_PROBLEM = par%problem_weight /= 0.d0
+    ntot = par%nelements_total
+    nloc = par%nelements
+    cb = merge(part_cb, 0, partitioned .and. nbproc > 1)
+    ce = cb + nloc
+    call joint_inversion_calculate_matrix_partitioning(par, line_start, line_end, param_shift)
+    ncols = this%matrix_sensit%get_ncolumns()
+    ! ---- size of the system (joint_inverse_problem.F90:223-330): one diagonal block of nelements_total rows per damped model
+    ! component and per ADMM term, then the caller's general rows
+    nl_cons = int(this%g_nrows)
+    do i = 1, 2
+      if (.not. SOLVE_PROBLEM(i)) cycle
+      if (par%alpha(i) /= 0.d0) nl_cons = nl_cons + ntot * model(i)%ncomponents
+      if (par%admm_type > 0) nl_cons = nl_cons + ntot
+    enddo
+    if (.not. allocated(this%b_RHS)) then
+      allocate(this%b_RHS(this%ndata_lines + nl_cons))
+      nnz_cons = int(nl_cons, c_int64_t)
+      if (allocated(this%g_cols)) nnz_cons = nnz_cons + size(this%g_cols, kind=c_int64_t)
+      call this%matrix_cons%initialize(nl_cons, ncols, nnz_cons, myrank)
+    endif
+    if (size(this%b_RHS) /= this%ndata_lines + nl_cons) &
+      call exit_MPI('The number of constraint rows changed between major iterations!', myrank, nl_cons)
+    call this%matrix_cons%reset()
+    this%b_RHS = 0.d0
+    allocate(full(ntot))
+    lc = this%ndata_lines                                            ! rows of the constraints start after the data rows
+    do i = 1, 2
+      if (.not. SOLVE_PROBLEM(i)) cycle
+      nc = model(i)%ncomponents
+      ndt = par%ndata(i) * par%ndata_components(i)
+      lc0 = param_shift(i)                                           ! this rank's unknowns: [m1 cells (cb, ce]; m2 cells (cb, ce]]
+      ! the right-hand side of the data rows: problem_weight * residuals (:379-387, :448-455)
+      this%b_RHS(line_start(i) + 1:line_start(i) + ndt) = par%problem_weight(i) * reshape(arr(i)%residuals, (/ndt/))
+      if (par%alpha(i) /= 0.d0) then                                 ! damping%add, damping.F90:97-234, one block per model component (:456-463)
+        do k = 1, nc
+          call scaled_full_vector(i, model(i)%val(:, k) - model(i)%val_prior(:, k), nloc, full, par, this%WAVELET_DOMAIN, myrank, nbproc)
+          ! value = alpha * pw [* Lp multiplier] [* local weight] in double, ONE cast to the matrix precision in add (damping.F90:160-173,
+          ! sparse_matrix.f90:226); right-hand side -alpha * pw * diff [* Lp multiplier] [* local weight] (:218-228)
+          do p = 1, ntot
+            if (p > cb .and. p <= ce) then
+              s3 = full(p)
+              s1 = par%alpha(i) * par%problem_weight(i)                  ! matrix value
+              s2 = -par%alpha(i) * par%problem_weight(i) * s3            ! right-hand side
+              if (par%norm_power /= 2.d0) then                           ! Lp norm multiplier (:250-262)
+                if (s3 /= 0.d0) then
+                  s3 = (abs(s3))**(par%norm_power / 2.d0 - 1.d0)
+                else
+                  s3 = 1.d0
+                endif
+                s1 = s1 * s3
+                s2 = s2 * s3
+              endif
+              if (par%apply_local_damping_weight > 0) then               ! local weight = local alpha (:168-171, :225-228)
+                s1 = s1 * model(i)%damping_weight(p - cb)
+                s2 = s2 * model(i)%damping_weight(p - cb)
+              endif
+              call this%matrix_cons%add(s1, lc0 + (k - 1) * nloc + (p - cb), myrank)
+              this%b_RHS(lc + p) = s2
+            endif
+            call this%matrix_cons%new_row(myrank)
+          enddo
+          lc = lc + ntot
+        enddo
+      endif
+    enddo
+    do i = 1, 2                                                      ! ***** ADMM method ***** (:490-527)
+      if (.not. SOLVE_PROBLEM(i)) cycle
+      if (par%admm_type <= 0) cycle
+      nc = model(i)%ncomponents
+      lc0 = param_shift(i)
+      kadm = merge(1, 3, nc == 1)                                    ! vector model: bounds on Mz (:499-506)
+      call iterate_admm_arrays(nloc, model(i)%nlithos, model(i)%min_bound, model(i)%max_bound, model(i)%val(:, kadm), &
+                               this%z_admm(:, i), this%u_admm(:, i), this%x0_ADMM(:, i))
+      call scaled_full_vector(i, model(i)%val(:, kadm) - this%x0_ADMM(:, i), nloc, full, par, this%WAVELET_DOMAIN, myrank, nbproc)
+      do p = 1, ntot
+        if (p > cb .and. p <= ce) then                               ! local weight = local rho (damping.F90:177-180, :264-267)
+          call this%matrix_cons%add(par%rho_ADMM(i) * par%problem_weight(i) * model(i)%bound_weight(p - cb), &
+                                    lc0 + (kadm - 1) * nloc + (p - cb), myrank)
+          this%b_RHS(lc + p) = -par%rho_ADMM(i) * par%problem_weight(i) * full(p) * model(i)%bound_weight(p - cb)
+        endif
+        call this%matrix_cons%new_row(myrank)
+      enddo
+      lc = lc + ntot
+      sums(1) = sum((this%z_admm(:, i) - model(i)%val(:, kadm))**2)       ! costs.f90:38-69, over the cells of all ranks
+      sums(2) = sum(this%z_admm(:, i)**2)
+      if (nbproc > 1) call allreduce_sum_dp(sums, 2)
+      this%admm_cost(i) = 0.d0
+      if (sums(2) /= 0.d0) this%admm_cost(i) = sqrt(sums(1) / sums(2))
+      if (myrank == 0) print *, 'ADMM cost |x - z| / |z| =', this%admm_cost(i)
+    enddo
+    do row = 1, int(this%g_nrows)                                    ! the caller's rows (columns of this rank, rows replicated)
+      do e8 = this%g_rowptr(row) + 1, this%g_rowptr(row + 1)
+        call this%matrix_cons%add(real(this%g_vals(e8), dp), int(this%g_cols(e8)), myrank)
+      enddo
+      call this%matrix_cons%new_row(myrank)
+      this%b_RHS(lc + row) = this%g_rhs(row)
+    enddo
+    call this%matrix_cons%finalize(myrank)
+    ! ---- parallel sparse inversion (:546-552)
+    allocate(x(ncols))
+    x = 0.d0
+    call lsqr_solve_sensit(size(this%b_RHS), ncols, par%niter, par%rmin, par%gamma, par%target_misfit, this%matrix_sensit, &
+                           this%matrix_cons, this%b_RHS, x, SOLVE_PROBLEM, par%nelements, par%nx, par%ny, par%nz, &
+                           par%nmodel_components, par%compression_type, this%WAVELET_DOMAIN, memory, myrank, nbproc)
+    ! ---- back to model space (:556-571): inverse transform of the gathered slices when the unknowns were wavelet coefficients,
+    ! then times the column weight (rescale_model, model.F90:312-324)
+    delta_model = 0.d0
+    allocate(loc(nloc))
+    do i = 1, 2
+      if (.not. SOLVE_PROBLEM(i)) cycle
+      lc0 = param_shift(i)
+      do k = 1, model(i)%ncomponents
+        loc = x(lc0 + (k - 1) * nloc + 1:lc0 + k * nloc)
+        if (par%compression_type > 0 .and. this%WAVELET_DOMAIN) then
+          call get_full_array(loc, nloc, full, myrank, nbproc)
+          call inverse_wavelet(full, par%nx, par%ny, par%nz, par%compression_type)
+          loc = full(cb + 1:ce)
+        endif
+        delta_model(:, k, i) = loc * arr(i)%column_weight
+      enddo
+    enddo
+    deallocate(full, x, loc)
+  end subroutine joint_inversion_solve
 
 end module tfx_reference_api

@@ -426,7 +426,7 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
     real(dp), allocatable :: Xd(:), Yd(:), Zd(:), d_meas(:), d_calc(:)
     real(dp), allocatable :: damp_w(:)                  ! local model-damping weight per cell (model%damping_weight)
     real(dp), allocatable :: dw(:)                      ! data weight (ndc, nd) = 1 / data error, or 1 (data_gravmag.f90:243-279)
-    real(dp), allocatable :: m(:), m_prior(:), m_synth(:), z_admm(:), u_admm(:), x0(:)
+    real(dp), allocatable :: m(:), m_prior(:), m_synth(:)
     real(dp), allocatable :: bnd(:, :), bnd_w(:)        ! ADMM intervals (2*nlithos, cell) and per-cell weight (model%bound_weight)
   end type t_prob
 
@@ -437,13 +437,13 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
   type(t_data) :: data(2)
   type(t_model) :: model(2)
   type(t_inversion_arrays) :: iarr(2)                                               ! :73
-  type(t_sparse_matrix) :: matrix_sensit, matrix_cons
-  real(dp), allocatable :: b_RHS(:), delta_model(:), cw_loc(:, :)
+  type(t_joint_inversion) :: jinv                                                   ! :77
+  real(dp), allocatable :: delta_model(:, :, :), cw_loc(:, :)
   integer, allocatable :: nelements_at_cpu(:)
   integer(c_int64_t) :: nnz_part
   real(dp) :: memory_fwd, memory_inv
   logical :: SOLVE_PROBLEM(2), WAVELET_DOMAIN
-  integer :: line_start(2), param_shift(2), nl_cons, lc, problem_type_part
+  integer :: line_start(2), line_end(2), param_shift(2), problem_type_part
   ! output file prefixes (src/problem_joint_gravmag.F90:340-362, :554-555): 'grav_...' and 'mag_...'
   character(len=4) :: suffix(2) = (/'grav', 'mag '/)
   integer :: ip, n, it, i, k, ucost, kadm, nprob, ntot, ndtot, c0, r0
@@ -459,7 +459,7 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
   integer, allocatable :: counts(:), displs(:)
   real(dp), allocatable, target :: xfull(:)
   real(dp), allocatable, target :: work(:)
-  real(dp) :: s1, s2, s3
+  real(dp) :: s1, s2, s3, admm_costs(2)
   integer :: cc, row
   ! wall clock per phase of the run (printed at the end and written to <output>/phase_timing.json on rank 0)
   integer, parameter :: NPHASE = 9
@@ -540,7 +540,7 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
     allocate(pr(ip)%dw(pr(ip)%ndt))
     pr(ip)%dw = 1.d0
     allocate(pr(ip)%m(pr(ip)%nm), pr(ip)%m_prior(pr(ip)%nm), pr(ip)%m_synth(pr(ip)%nm))
-    allocate(pr(ip)%z_admm(n), pr(ip)%u_admm(n), pr(ip)%x0(n), pr(ip)%damp_w(n))
+    allocate(pr(ip)%damp_w(n))
     pr(ip)%damp_w = 1.d0
     if (par%apply_local_damp > 0) call read_cell_values(par%local_damp_file(ip), n, pr(ip)%damp_w, 'model damping weights')
     if (par%admm > 0) then                                           ! set_model_bounds, src/inversion/model_IO.F90:273-305
@@ -639,35 +639,32 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
   do ip = 1, 2
     if (pr(ip)%on) pr(ip)%nml = pr(ip)%nc * nloc
   enddo
-  ! matrix partitioning of the joint system (joint_inverse_problem.F90:712-739): rows of problem 2 follow problem 1's, its
-  ! columns follow problem 1's local unknowns
-  line_start = 0
-  param_shift = 0
-  if (pr(1)%on .and. pr(2)%on) then
-    line_start(2) = pr(1)%ndt
-    param_shift(2) = pr(1)%nml
-  endif
-
   ! (IV) MATRIX ALLOCATION + READING THE SENSITIVITY KERNEL (:227-248)
   if (myrank == 0) print *, '(IV) MATRIX ALLOCATION.'
   allocate(cw_loc(nloc, 2))
+  call jinv%initialize(ipar, nnz_part, myrank)                                       ! :236
+  if (jinv%WAVELET_DOMAIN .neqv. WAVELET_DOMAIN) call stop_msg('WAVELET_DOMAIN of the joint inversion differs from the Parfile rule!')
   do ip = 1, 2
     if (.not. pr(ip)%on) cycle
+    call iarr(ip)%reallocate_aux(ipar%nelements, pr(ip)%nd, pr(ip)%ndc, myrank)     ! :221-222
     if (ip == 1) then
-      call read_sensitivity_kernel(gpar, matrix_sensit, cw_loc(:, ip), ipar%problem_weight(ip), data(ip)%weight, ip, myrank, nbproc, &
-                                   nelements_at_cpu)
+      call read_sensitivity_kernel(gpar, jinv%matrix_sensit, iarr(ip)%column_weight, ipar%problem_weight(ip), data(ip)%weight, ip, &
+                                   myrank, nbproc, nelements_at_cpu)                  ! :241-246
     else
-      call read_sensitivity_kernel(mpar, matrix_sensit, cw_loc(:, ip), ipar%problem_weight(ip), data(ip)%weight, ip, myrank, nbproc, &
-                                   nelements_at_cpu)
+      call read_sensitivity_kernel(mpar, jinv%matrix_sensit, iarr(ip)%column_weight, ipar%problem_weight(ip), data(ip)%weight, ip, &
+                                   myrank, nbproc, nelements_at_cpu)
     endif
+    cw_loc(:, ip) = iarr(ip)%column_weight
     if (gpar%sensit_read == 1) then                    ! the full weight comes from the SENSIT folder (:920-970)
       call read_depth_weight(ip)
     endif
     call model(ip)%initialize(nloc, pr(ip)%nc, n, myrank)
     model(ip)%grid_full%nx = ipar%nx; model(ip)%grid_full%ny = ipar%ny; model(ip)%grid_full%nz = ipar%nz
   enddo
-  call matrix_sensit%finalize(myrank)
-  allocate(delta_model(matrix_sensit%get_ncolumns()))
+  call jinv%matrix_sensit%finalize(myrank)                                          ! :248
+  call jinv%initialize2(ipar, iarr, model, myrank, nbproc)                           ! :263
+  call jinv%calculate_matrix_partitioning(ipar, line_start, line_end, param_shift)   ! :327
+  allocate(delta_model(ipar%nelements, ipar%nmodel_components, 2))
   call lap(4, tph)
 
   do ip = 1, 2
@@ -701,12 +698,27 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
     call write_data(par%path_output, trim(suffix(ip))//'_starting', pr(ip)%nd, pr(ip)%ndc, pr(ip)%Xd, pr(ip)%Yd, pr(ip)%Zd, &
                     pr(ip)%d_calc, par%data_units_mult(ip), par%z_axis_dir)
 
+    ! ---- this rank's cells of the prior, the local weights and the ADMM intervals: what jinv%solve reads from the model object
+    ! (model.F90:33-70: val_prior, damping_weight, min_bound / max_bound / bound_weight)
+    do k = 1, pr(ip)%nc
+      model(ip)%val_prior(:, k) = pr(ip)%m_prior((k - 1) * n + cb + 1:(k - 1) * n + ce)
+    enddo
+    model(ip)%damping_weight = pr(ip)%damp_w(cb + 1:ce)
+    if (par%admm > 0) then
+      call model(ip)%allocate_bound_arrays(par%nlithos, myrank)
+      do i = 1, nloc
+        do k = 1, par%nlithos
+          model(ip)%min_bound(k, i) = pr(ip)%bnd(2 * k - 1, cb + i)
+          model(ip)%max_bound(k, i) = pr(ip)%bnd(2 * k, cb + i)
+        enddo
+      enddo
+      model(ip)%bound_weight = pr(ip)%bnd_w(cb + 1:ce)
+    endif
+
     ! ---- costs (:443-470)
     call model_cost(ip, pr(ip)%cost_model)
     pr(ip)%cost_data = norm2(pr(ip)%d_calc - pr(ip)%d_meas) / norm2(pr(ip)%d_meas)
     pr(ip)%cost_admm = 0.d0
-    pr(ip)%z_admm = 0.d0
-    pr(ip)%u_admm = 0.d0
   enddo
   call make_dir(par%path_output)
   if (io_rank) then
@@ -733,121 +745,38 @@ subroutine solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
       if (par%w_cross /= 0.d0) call build_cross_gradient()
       if (any(par%w_clust /= 0.d0)) call build_clustering()
     endif
-    ! ---- the constraint matrix and the right-hand side (joint_inverse_problem.F90:393-545): one diagonal block of
-    ! nelements_total rows per damped model component and per ADMM term, then the general rows
-    nl_cons = int(g_nrows)
-    do ip = 1, 2
-      if (.not. pr(ip)%on) cycle
-      if (par%alpha(ip) /= 0.d0) nl_cons = nl_cons + n * pr(ip)%nc
-      if (par%admm > 0) nl_cons = nl_cons + n
-    enddo
-    if (.not. allocated(b_RHS)) then
-      allocate(b_RHS(ndtot + nl_cons))
-      e8 = int(nl_cons, c_int64_t)
-      if (allocated(g_cols)) e8 = e8 + size(g_cols, kind=c_int64_t)
-      call matrix_cons%initialize(nl_cons, matrix_sensit%get_ncolumns(), e8, myrank)
+    ! ---- the builders' rows go to the joint inversion, which assembles the rest of the system (damping and ADMM blocks, right-hand
+    ! side) and solves it on the GPU: joint_inversion_solve, joint_inverse_problem.F90:393-573
+    if (g_nrows > 0) then
+      call jinv%set_general_rows(g_nrows, g_rowptr, g_cols, g_vals, g_rhs)
+    else
+      call jinv%set_general_rows(0_c_int64_t)
     endif
-    if (size(b_RHS) /= ndtot + nl_cons) call stop_msg('The number of constraint rows changed between major iterations!')
-    call matrix_cons%reset()
-    b_RHS = 0.d0
-    lc = ndtot                                                     ! rows of the constraints start after the data rows
     do ip = 1, 2
       if (.not. pr(ip)%on) cycle
-      c0 = pr(ip)%col0
-      r0 = pr(ip)%row0
-      lc0 = param_shift(ip)                                        ! this rank's unknowns: [m1 cells (cb, ce]; m2 cells (cb, ce]]
-      ! residuals (:666-675; data weight 1) and the right-hand side pw * residuals (joint_inverse_problem.F90:379-387)
-      b_RHS(r0 + 1:r0 + pr(ip)%ndt) = pr(ip)%pw * (pr(ip)%dw * (pr(ip)%d_meas - pr(ip)%d_calc))
-      if (par%alpha(ip) /= 0.d0) then                              ! damping%add, damping.F90:97-234, one block per model component
-        work(1:pr(ip)%nm) = 0.d0
-        do k = 1, pr(ip)%nc                                        ! (joint_inverse_problem.F90:456-463)
-          call unweight(ip, pr(ip)%m((k - 1) * n + 1:k * n) - pr(ip)%m_prior((k - 1) * n + 1:k * n), work((k - 1) * n + 1:k * n))
-        enddo
-        if (.not. spatial) call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)       ! damping.F90:135-150
-        ! value = alpha * pw [* Lp multiplier] [* local weight] in double, ONE cast to the matrix precision in add (damping.F90:160-173,
-        ! sparse_matrix.f90:226); right-hand side -alpha * pw * diff [* Lp multiplier] [* local weight] (:218-228)
-        do k = 1, pr(ip)%nc
-          do i = 1, n
-            if (i > cb .and. i <= ce) then
-              s3 = work((k - 1) * n + i)
-              s1 = par%alpha(ip) * pr(ip)%pw                              ! matrix value
-              s2 = -par%alpha(ip) * pr(ip)%pw * s3                        ! right-hand side
-              if (par%norm_power /= 2.d0) then                           ! Lp norm multiplier (:250-262)
-                if (s3 /= 0.d0) then
-                  s3 = (abs(s3))**(par%norm_power / 2.d0 - 1.d0)
-                else
-                  s3 = 1.d0
-                endif
-                s1 = s1 * s3
-                s2 = s2 * s3
-              endif
-              if (par%apply_local_damp > 0) then                         ! local weight = local alpha (:168-171, :225-228)
-                s1 = s1 * pr(ip)%damp_w(i)
-                s2 = s2 * pr(ip)%damp_w(i)
-              endif
-              call matrix_cons%add(s1, lc0 + (k - 1) * nloc + (i - cb), myrank)
-              b_RHS(lc + i) = s2
-            endif
-            call matrix_cons%new_row(myrank)
-          enddo
-          lc = lc + n
-        enddo
-      endif
-    enddo
-    do ip = 1, 2                                                     ! ***** ADMM method ***** (joint_inverse_problem.F90:490-527)
-      if (.not. pr(ip)%on) cycle
-      lc0 = param_shift(ip)
-      if (par%admm > 0) then
-        kadm = merge(1, 3, pr(ip)%nc == 1)                         ! vector model: bounds on Mz (:499-506)
-        call iterate_admm_arrays(n, par%nlithos, pr(ip)%bnd, pr(ip)%m((kadm - 1) * n + 1:kadm * n), pr(ip)%z_admm, &
-                                 pr(ip)%u_admm, pr(ip)%x0)
-        work(1:pr(ip)%nm) = 0.d0
-        call unweight(ip, pr(ip)%m((kadm - 1) * n + 1:kadm * n) - pr(ip)%x0, work((kadm - 1) * n + 1:kadm * n))
-        if (.not. spatial) call to_wavelet(work(1:pr(ip)%nm), pr(ip)%nc)
-        do i = 1, n
-          if (i > cb .and. i <= ce) then                             ! local weight = local rho (damping.F90:177-180, :264-267)
-            call matrix_cons%add(pr(ip)%rho * pr(ip)%pw * pr(ip)%bnd_w(i), lc0 + (kadm - 1) * nloc + (i - cb), myrank)
-            b_RHS(lc + i) = -pr(ip)%rho * pr(ip)%pw * work((kadm - 1) * n + i) * pr(ip)%bnd_w(i)
-          endif
-          call matrix_cons%new_row(myrank)
-        enddo
-        lc = lc + n
-        s1 = sum((pr(ip)%z_admm - pr(ip)%m((kadm - 1) * n + 1:kadm * n))**2)
-        s2 = sum(pr(ip)%z_admm**2)
-        pr(ip)%cost_admm = 0.d0
-        if (s2 /= 0.d0) pr(ip)%cost_admm = sqrt(s1 / s2)            ! costs.f90:38-69
-        if (myrank == 0) print *, 'ADMM cost |x - z| / |z| =', pr(ip)%cost_admm
-      endif
-    enddo
-    do row = 1, int(g_nrows)                                         ! the builders' rows (columns of this rank, rows replicated)
-      do e8 = g_rowptr(row) + 1, g_rowptr(row + 1)
-        call matrix_cons%add(real(g_vals(e8), dp), int(g_cols(e8)), myrank)
+      ! residuals (:486-491; calculate_residuals: data weight * (measured - calculated)) and the current model of this rank's cells
+      iarr(ip)%residuals = reshape(pr(ip)%dw * (pr(ip)%d_meas - pr(ip)%d_calc), (/pr(ip)%ndc, pr(ip)%nd/))
+      do k = 1, pr(ip)%nc
+        model(ip)%val(:, k) = pr(ip)%m((k - 1) * n + cb + 1:(k - 1) * n + ce)
       enddo
-      call matrix_cons%new_row(myrank)
-      b_RHS(lc + row) = g_rhs(row)
+      ipar%rho_ADMM(ip) = pr(ip)%rho                                 ! (dynamic ADMM weight, :618-638)
     enddo
-    call matrix_cons%finalize(myrank)
     call lap(5, tph)
     tph = wall()
-    ! ---- parallel sparse inversion (joint_inverse_problem.F90:546-552)
-    delta_model = 0.d0
-    call lsqr_solve_sensit(size(b_RHS), size(delta_model), ipar%niter, ipar%rmin, ipar%gamma, ipar%target_misfit, &
-                           matrix_sensit, matrix_cons, b_RHS, delta_model, SOLVE_PROBLEM, ipar%nelements, ipar%nx, ipar%ny, ipar%nz, &
-                           ipar%nmodel_components, ipar%compression_type, WAVELET_DOMAIN, memory_inv, myrank, nbproc)
+    if (it > 1) call jinv%reset(myrank)                              ! :494
+    call jinv%solve(ipar, iarr, model, delta_model, memory_inv, myrank, nbproc)        ! :497
     call lap(6, tph)
     tph = wall()
     call write_costs(it - 1)                                       ! :519-528 (costs of the previous iteration)
     do ip = 1, 2
       if (.not. pr(ip)%on) cycle
-      c0 = pr(ip)%col0
-      lc0 = param_shift(ip)
-      do k = 1, pr(ip)%nc                                          ! slices of all ranks -> the full update (wavelet_utils.F90:37-72)
-        call allgather_slices(delta_model(lc0 + (k - 1) * nloc + 1:lc0 + k * nloc), nloc, xfull(c0 + (k - 1) * n + 1:c0 + k * n), counts, displs)
-        if (ipar%compression_type > 0 .and. WAVELET_DOMAIN) &      ! :559-567
-          call inverse_wavelet(xfull(c0 + (k - 1) * n + 1:c0 + k * n), ipar%nx, ipar%ny, ipar%nz, ipar%compression_type)
-      enddo
-      do k = 1, pr(ip)%nc
-        pr(ip)%m((k - 1) * n + 1:k * n) = pr(ip)%m((k - 1) * n + 1:k * n) + xfull(c0 + (k - 1) * n + 1:c0 + k * n) * pr(ip)%cw   ! :570, :500
+      if (par%admm > 0) then
+        admm_costs = jinv%get_admm_cost()                          ! :520-528
+        pr(ip)%cost_admm = admm_costs(ip)
+      endif
+      call model(ip)%update(delta_model(:, 1:pr(ip)%nc, ip))         ! :500
+      do k = 1, pr(ip)%nc                                          ! the full model from its local parts (model_update_full)
+        call get_full_array(model(ip)%val(:, k), nloc, pr(ip)%m((k - 1) * n + 1:k * n), myrank, nbproc)
       enddo
       call calculate_data(ip, pr(ip)%m, pr(ip)%d_calc)             ! :513
       call model_cost(ip, pr(ip)%cost_model)
@@ -1366,7 +1295,7 @@ contains
       model(jp)%val(:, kc) = mfull((kc - 1) * n + cb + 1:(kc - 1) * n + ce)
     enddo
     allocate(dc(pr(jp)%ndc, pr(jp)%nd))
-    call model(jp)%calculate_data(pr(jp)%nd, pr(jp)%ndc, matrix_sensit, ipar%problem_weight(jp), cw_loc(:, jp), data(jp)%weight, dc, &
+    call model(jp)%calculate_data(pr(jp)%nd, pr(jp)%ndc, jinv%matrix_sensit, ipar%problem_weight(jp), cw_loc(:, jp), data(jp)%weight, dc, &
                                   ipar%compression_type, line_start(jp), param_shift(jp), myrank, nbproc)
     dcalc = reshape(dc, (/pr(jp)%ndt/))
     call lap(7, t0)
@@ -1387,49 +1316,6 @@ contains
   logical function stop_file_exists()
     inquire(file='stop', exist=stop_file_exists)
   end function stop_file_exists
-
-  ! admm_method_iterate_admm_arrays, src/inversion/admm_method.F90:70-134 (global bounds)
-  subroutine iterate_admm_arrays(nel, nlithos, bounds_all, xm, z, u, x0out)
-    integer, intent(in) :: nel, nlithos
-    real(dp), intent(in) :: bounds_all(2 * nlithos, nel), xm(nel)
-    real(dp) :: bounds(2 * nlithos)
-    real(dp), intent(inout) :: z(nel), u(nel)
-    real(dp), intent(out) :: x0out(nel)
-    integer :: p, j
-    real(dp) :: a, mindist, v, closest
-    logical :: inside
-    do p = 1, nel
-      bounds = bounds_all(:, p)
-      a = xm(p) + u(p)
-      inside = .false.
-      do j = 1, nlithos
-        if (bounds(2 * j - 1) <= a .and. a <= bounds(2 * j)) then
-          inside = .true.
-          z(p) = a
-          exit
-        endif
-      enddo
-      if (.not. inside) then
-        mindist = 1.d30
-        closest = a
-        do j = 1, nlithos
-          v = dabs(bounds(2 * j - 1) - a)
-          if (v < mindist) then
-            mindist = v
-            closest = bounds(2 * j - 1)
-          endif
-          v = dabs(bounds(2 * j) - a)
-          if (v < mindist) then
-            mindist = v
-            closest = bounds(2 * j)
-          endif
-        enddo
-        z(p) = closest
-      endif
-    enddo
-    u = u + xm - z
-    x0out = z - u
-  end subroutine iterate_admm_arrays
 
 end subroutine solve_problem_joint_gravmag
 
@@ -1501,6 +1387,12 @@ program tomofastx_amd
   ipar%column_weight_multiplier = par%cwm
   ipar%admm_type = par%admm
   ipar%rho_ADMM = par%rho
+  ipar%admm_bound_type = par%admm_bound_type
+  ipar%nlithos = par%nlithos
+  ipar%apply_local_damping_weight = par%apply_local_damp
+  ipar%beta = par%beta_grad
+  ipar%cross_grad_weight = par%w_cross
+  ipar%clustering_weight_glob = par%w_clust
   host_par = par
 
   call solve_problem_joint_gravmag(gpar, mpar, ipar, myrank, nbproc)
