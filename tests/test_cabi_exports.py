@@ -88,5 +88,19 @@ def test_parfile_host_reaches_the_gpu_only_through_the_reference_named_entry_poi
                 r"subroutine read_sensitivity_kernel\(par, sensit_matrix, column_weight, problem_weight, data_weight, problem_type, &",
                 r"subroutine model_calculate_data\(this, ndata, ndata_components, matrix_sensit, problem_weight, column_weight, data_weight, &",
                 r"subroutine lsqr_solve_sensit\(nlines, ncolumns, niter, rmin, gamma, target_misfit, matrix_sensit, matrix_cons, u, x, &",
-                r"subroutine forward_wavelet\(s, n1, n2, n3, wavelet_type\)", r"subroutine inverse_wavelet\(s, n1, n2, n3, wavelet_type\)"):
+                r"subroutine forward_wavelet\(s, n1, n2, n3, wavelet_type\)", r"subroutine inverse_wavelet\(s, n1, n2, n3, wavelet_type\)",
+                # weights_gravmag.f90:46, inversion_arrays.f90:30-44, joint_inverse_problem.F90:124, :223, :366, :393, :712
+                r"subroutine calculate_depth_weight_iarr\(par, iarr, grid_full, data, myrank_, nbproc_\)",
+                r"subroutine inversion_arrays_allocate_aux\(this, nelements, ndata, ndata_components, myrank_\)",
+                r"subroutine joint_inversion_initialize\(this, par, nnz_sensit, myrank\)",
+                r"subroutine joint_inversion_initialize2\(this, par, arr, model, myrank, nbproc\)",
+                r"subroutine joint_inversion_reset\(this, myrank\)",
+                r"subroutine joint_inversion_solve\(this, par, arr, model, delta_model, memory, myrank, nbproc\)",
+                r"subroutine joint_inversion_calculate_matrix_partitioning\(par, line_start, line_end, param_shift\)"):
         assert re.search(sig, api), sig
+    # ... and the Parfile host uses them at the reference's call sites (problem_joint_gravmag.F90:174, :236, :263, :327, :497)
+    for call in (r"call calculate_depth_weight\(gpar, iarr\(ip\), model\(ip\)%grid_full, data\(ip\), myrank, nbproc\)",
+                 r"call jinv%initialize\(ipar, nnz_part, myrank\)", r"call jinv%initialize2\(ipar, iarr, model, myrank, nbproc\)",
+                 r"call jinv%calculate_matrix_partitioning\(ipar, line_start, line_end, param_shift\)",
+                 r"call jinv%solve\(ipar, iarr, model, delta_model, memory_inv, myrank, nbproc\)"):
+        assert re.search(call, code), call

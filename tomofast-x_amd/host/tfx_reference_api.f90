@@ -1590,14 +1590,18 @@ contains
       if (par%alpha(i) /= 0.d0) nl_cons = nl_cons + ntot * model(i)%ncomponents
       if (par%admm_type > 0) nl_cons = nl_cons + ntot
     enddo
-    if (.not. allocated(this%b_RHS)) then
-      allocate(this%b_RHS(this%ndata_lines + nl_cons))
-      nnz_cons = int(nl_cons, c_int64_t)
-      if (allocated(this%g_cols)) nnz_cons = nnz_cons + size(this%g_cols, kind=c_int64_t)
-      call this%matrix_cons%initialize(nl_cons, ncols, nnz_cons, myrank)
-    endif
+    ! (entries: at most one per row of the diagonal blocks + the caller's rows, whose count may change from one major iteration to
+    ! the next - the cross-gradient's does - so the row builder grows when it has to)
+    nnz_cons = int(nl_cons, c_int64_t)
+    if (this%g_nrows > 0) nnz_cons = nnz_cons + this%g_rowptr(this%g_nrows + 1)
+    if (.not. allocated(this%b_RHS)) allocate(this%b_RHS(this%ndata_lines + nl_cons))
     if (size(this%b_RHS) /= this%ndata_lines + nl_cons) &
       call exit_MPI('The number of constraint rows changed between major iterations!', myrank, nl_cons)
+    if (.not. allocated(this%matrix_cons%ija)) then
+      call this%matrix_cons%initialize(nl_cons, ncols, nnz_cons, myrank)
+    else if (size(this%matrix_cons%ija, kind=c_int64_t) < nnz_cons) then
+      call this%matrix_cons%initialize(nl_cons, ncols, nnz_cons + nnz_cons / 4, myrank)
+    endif
     call this%matrix_cons%reset()
     this%b_RHS = 0.d0
     allocate(full(ntot))
