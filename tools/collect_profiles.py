@@ -51,10 +51,10 @@ def main(rnd):
     import pmc_reduce
     pmc_reduce.main(SRC, os.path.join(DST, tag + "_pmc_summary.json"), rnd)
     if os.path.isdir(FIN):
-        for src, dst in (("gpu_tests.log", tag + "_gpu_tests.log"), ("fuzz.log", tag + "_fuzz_seed202.log")):
+        for src, dst in (("gpu_tests.log", tag + "_gpu_tests.log"), ("fuzz.log", tag + "_fuzz.log")):
             if os.path.isfile(os.path.join(FIN, src)):
                 shutil.copy(os.path.join(FIN, src), os.path.join(DST, dst))
-        for w in ("haar_512", "dense_256"):
+        for w in ("haar_512", "dense_256", "medium", "small"):
             p = os.path.join(FIN, "bench_%s.json" % w)
             if os.path.isfile(p):
                 last_json_line(p, os.path.join(DST, "%s_bench_%s.json" % (tag, w)))
