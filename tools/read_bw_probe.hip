@@ -123,6 +123,20 @@ __global__ __launch_bounds__(1024) void k_read_sweep(const char *__restrict__ ba
     }
     if (acc == 1.2345f || macc == 77) out[0] = acc;
 }
+// one launch that reads the same buffer `reps` times (no launch ramp between the passes)
+__global__ __launch_bounds__(256) void k_read_loop(const f4 *__restrict__ p, size_t n, int reps, float *out)
+{
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (int r = 0; r < reps; ++r) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+            const f4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+            acc += a.x + b.y + c.z + d.w;
+        }
+        __syncthreads();
+    }
+    if (acc == 1.2345f) out[0] = acc;
+}
 __global__ void k_copy(const f4 *__restrict__ a, f4 *__restrict__ b, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
@@ -192,6 +206,40 @@ int main()
         SWEEP(2624, 0) SWEEP(2688, 0) SWEEP(2752, 0) SWEEP(2816, 0) SWEEP(2880, 0) SWEEP(3072, 0)
         SWEEP(2880, 1) SWEEP(2944, 1) SWEEP(3072, 1)
 #undef SWEEP
+    }
+    // Infinity Cache (256 MiB): the same buffer read again and again - how fast is a re-read that can come from the memory-side cache?
+    for (size_t mb : {32, 64, 96, 128, 160, 192, 256, 384, 1024}) {
+        const size_t nb = mb << 20, ne = nb / 16;
+        char nm[96];
+        snprintf(nm, 96, "re-read of a %4zu MB buffer, plain loads", mb); timeit(nm, [&]() { hipLaunchKernelGGL((k_read<0, 8>), dim3(4096), dim3(256), 0, 0, p, ne, out); }, (double)nb);
+        snprintf(nm, 96, "re-read of a %4zu MB buffer, nt loads", mb); timeit(nm, [&]() { hipLaunchKernelGGL((k_read<1, 8>), dim3(4096), dim3(256), 0, 0, p, ne, out); }, (double)nb);
+    }
+    for (size_t mb : {16, 64, 128, 192, 256, 512, 4096}) {
+        const size_t nb = mb << 20, ne = nb / 16;
+        const int reps = mb >= 4096 ? 4 : 40;
+        char nm[96];
+        snprintf(nm, 96, "one launch, %d passes over %zu MB", reps, mb);
+        timeit(nm, [&]() { hipLaunchKernelGGL(k_read_loop, dim3(2048), dim3(256), 0, 0, p, ne, reps, out); }, (double)nb * reps);
+    }
+    // ... and a slab read once by one kernel (nt or plain), then by a second kernel: what the second reader sees
+    for (size_t mb : {64, 128}) {
+        const size_t nb = mb << 20, ne = nb / 16;
+        char nm[96];
+        for (int first_nt = 0; first_nt < 2; ++first_nt) {
+            // walk through 8 GB so that every slab is cold for its first reader
+            float best = 1e30f;
+            for (int r = 0; r < 5; ++r) {
+                const f4 *slab = p + (size_t)(r * 7 + first_nt * 3 + 1) * (ne * 4);
+                if (first_nt) hipLaunchKernelGGL((k_read<1, 8>), dim3(4096), dim3(256), 0, 0, slab, ne, out);
+                else hipLaunchKernelGGL((k_read<0, 8>), dim3(4096), dim3(256), 0, 0, slab, ne, out);
+                hipEventRecord(e0, 0);
+                hipLaunchKernelGGL((k_read<0, 8>), dim3(4096), dim3(256), 0, 0, slab, ne, out);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+            }
+            snprintf(nm, 96, "second reader of a %zu MB slab (first: %s)", mb, first_nt ? "nt" : "plain");
+            printf("%-46s %8.3f ms  %7.1f GB/s\n", nm, best, (double)nb / best / 1e6);
+        }
     }
     timeit("copy f4 (read + write)", [&]() { hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, p, q, n); }, 2.0 * bytes);
     return 0;
