@@ -45,8 +45,13 @@ def plain_small():
     return out
 
 
-def test_world_size_1_through_the_rccl_startup_has_the_bits_of_the_plain_run(plain_small):
-    out, err = _run_bench(1, "small", {"TFX_DETERMINISTIC": "1", "TFX_BENCH_FORCE_COMM": "1"}, port=29641)
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_world_size_1_through_the_rccl_startup_has_the_bits_of_the_plain_run(plain_small, backend):
+    """backend = the default torch.distributed group: gloo (the bench's default: the only RCCL user in the process is libtfx.so) or
+    nccl (torch opens its own RCCL communicator eagerly next to the library's: both live in one process and share the one mapped
+    librccl)."""
+    out, err = _run_bench(1, "small", {"TFX_DETERMINISTIC": "1", "TFX_BENCH_FORCE_COMM": "1", "TFX_BENCH_BACKEND": backend},
+                          port=29641 + (backend == "nccl"))
     comm = out["comm"]
     assert comm["path"].startswith("RCCL inside libtfx.so"), comm
     assert [s["ok"] for s in comm["ladder"]] == [True, True, True], comm
