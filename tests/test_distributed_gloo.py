@@ -117,3 +117,97 @@ def test_block_partition_helpers():
     assert [d.calculate_nelements_at_cpu(10, r, 3) for r in range(3)] == [3, 3, 4]
     assert [d.row_range(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
     assert d.column_ranges([3, 5, 2]) == [(0, 3), (3, 8), (8, 10)]
+
+
+# ---- the start-up ladder of distributed.setup_comm, with a scripted stand-in for the GPU context -------------------------------
+class LadderCtx:
+    """Records what the ladder does to the context; `init` scripts what tfx_comm_init_rccl does on this rank."""
+
+    def __init__(self, init):
+        self.init, self.calls, self.has_comm = init, [], False
+        self.rank, self.nranks = 0, 1
+
+    def comm_unique_id(self):
+        self.calls.append("unique_id")
+        return bytes(range(128))
+
+    def comm_init_rccl(self, uid, rank, nranks):
+        self.calls.append("init")
+        assert uid == bytes(range(128))                      # the 128 bytes of rank 0 arrived over the control channel
+        if self.init == "raise":
+            raise RuntimeError("scripted ncclCommInitRank failure")
+        if self.init == "hang":
+            import time
+            time.sleep(30.0)
+        self.has_comm = True
+
+    def comm_abort(self):
+        self.calls.append("abort")
+        self.has_comm = False
+
+    def comm_info(self):
+        return dict(rccl_ranks=0, rccl_rank=-1, rccl_device=-1, rccl_version=0, librccl="scripted")
+
+    def set_allreduce(self, hook, rank, nranks):
+        self.calls.append("set_allreduce")
+        self.rank, self.nranks = rank, nranks
+
+    def set_allgatherv(self, fn):
+        self.calls.append("set_allgatherv")
+
+
+def _ladder_worker(rank, world, port, q, scenario):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    import time
+    import types
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tfx = importlib.import_module("tomofast-x_amd")
+        # no GPU here: every rank "drives" its own device (a distinct PCI address per rank), or all the same one
+        shared = scenario == "shared_gpu"
+        torch.cuda.get_device_properties = lambda i: types.SimpleNamespace(pci_domain_id=0, pci_bus_id=7 if shared else 10 + rank, pci_device_id=0, uuid="x")
+        init = {"one_rank_fails": "raise" if rank == 1 else "ok", "one_rank_hangs": "hang" if rank == 0 else "ok"}.get(scenario, "ok")
+        ctx = LadderCtx(init)
+        t0 = time.time()
+        comm = tfx.distributed.setup_comm(ctx, rank, world, device_index=0 if shared else rank, want_rccl=True, init_timeout=3.0)
+        q.put((rank, comm.rccl, comm.report, ctx.calls, ctx.has_comm, time.time() - t0))
+    except Exception as e:      # noqa
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), [], False, 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["shared_gpu", "one_rank_fails", "one_rank_hangs"])
+def test_startup_ladder_moves_all_ranks_to_the_hooks_together(scenario):
+    """distributed.setup_comm on 2 ranks over gloo with a scripted context: whatever goes wrong on ONE rank - the ranks share a GPU,
+    tfx_comm_init_rccl raises, or it never returns - EVERY rank ends on the hook rung, no rank keeps a communicator (the rank whose
+    own rendezvous succeeded aborts it), the reason is in the report, and a hang costs the timeout, not the run."""
+    world, port = 2, 29581 + ["shared_gpu", "one_rank_fails", "one_rank_hangs"].index(scenario)
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_ladder_worker, args=(r, world, port, q, scenario)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    for rank, rccl, report, calls, has_comm, dt in res:
+        assert rccl is False, (rank, rccl, report)
+        assert report["path"].startswith("torch.distributed hooks"), report
+        assert not has_comm and "set_allreduce" in calls and "set_allgatherv" in calls, calls
+        assert report["ladder"][-1]["ok"] is False
+        assert dt < 25.0, dt
+    ladder = [r[2]["ladder"] for r in res]
+    assert ladder[0] == ladder[1]                                   # the same story on every rank
+    if scenario == "shared_gpu":
+        assert ladder[0][0]["stage"] == "pre-flight" and "share a GPU" in ladder[0][0]["why"]
+        assert all("init" not in r[3] for r in res)                 # nobody entered the rendezvous
+    else:
+        assert ladder[0][0] == {"stage": "pre-flight", "ok": True} and ladder[0][1]["stage"] == "tfx_comm_init_rccl"
+        assert ("scripted ncclCommInitRank failure" in ladder[0][1]["why"]) == (scenario == "one_rank_fails")
+        assert ("timed out" in ladder[0][1]["why"]) == (scenario == "one_rank_hangs")
+        assert all("abort" in r[3] for r in res)                    # also the rank whose own call succeeded drops its communicator

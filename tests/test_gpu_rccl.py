@@ -90,3 +90,23 @@ def test_host_driven_collectives_over_the_communicator(ctx):
     ctx.comm_destroy()
     with pytest.raises(tfx.TfxError):
         ctx.comm_barrier()                          # no communicator any more
+
+
+def test_comm_info_and_abort(ctx):
+    """tfx_comm_info: what the communicator itself reports (ncclCommCount / UserRank / CuDevice), the RCCL version and the file that
+    serves the nccl* symbols; tfx_comm_abort: drops the communicator without a hand-shake (the failure leg of the start-up ladder), and -
+    called while no communicator exists - cancels a rendezvous that is still in flight: the next tfx_comm_init_rccl starts clean."""
+    info = ctx.comm_info()
+    assert info["rccl_ranks"] == 0 and info["rccl_rank"] == -1 and info["rccl_version"] > 20000 and "librccl" in info["librccl"]
+    ctx.comm_init_rccl(ctx.comm_unique_id(), 0, 1)
+    info = ctx.comm_info()
+    assert (info["rccl_ranks"], info["rccl_rank"], info["rccl_device"]) == (1, 0, 0)
+    ctx.comm_abort()
+    assert ctx.comm_info()["rccl_ranks"] == 0
+    with pytest.raises(tfx.TfxError):
+        ctx.comm_barrier()
+    ctx.comm_abort()                                # nothing to abort: marks any in-flight rendezvous as cancelled ...
+    ctx.comm_init_rccl(ctx.comm_unique_id(), 0, 1)  # ... and a fresh one resets the mark
+    assert ctx.comm_info()["rccl_ranks"] == 1
+    ctx.comm_barrier()
+    ctx.comm_destroy()
