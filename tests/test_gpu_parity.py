@@ -1549,7 +1549,10 @@ def test_reference_named_entry_points(ctx):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout + out.stderr
     assert "Entered subroutine lsqr_solve_sensit" in out.stdout and "End of subroutine lsqr_solve_sensit" in out.stdout
-    f = {k: float(v) for k, v in re.findall(r"(nnz_total|model min|max|data cost|u consumed) =\s*([-+0-9.Ee]+)", out.stdout)}
+    f = {k: float(v) for k, v in re.findall(r"(nnz_total|model min|max|data cost|u consumed|jinv vs direct) =\s*([-+0-9.Ee]+)", out.stdout)}
+    # the same major iteration through t_joint_inversion%solve (b_RHS, damping rows, lsqr_solve_sensit, inverse transform, rescaling
+    # assembled inside) gives the model of the hand-written call sequence, up to the products' run-to-run rounding
+    assert f["jinv vs direct"] <= 1e-6, f["jinv vs direct"]
     nx, ny, nz = 16, 12, 8
     N = nx * ny * nz
     pw = 2.5

@@ -26,6 +26,12 @@ program tfx_reference_demo
   integer(c_int64_t) :: nnz
   logical :: SOLVE_PROBLEM(2)
   integer :: i, j, k, p, a, b
+  ! the same major iteration once more through the joint-inversion object (problem_joint_gravmag.F90:236, :263, :497, :500)
+  type(t_parameters_inversion) :: ipar
+  type(t_inversion_arrays) :: iarr(2)
+  type(t_joint_inversion) :: jinv
+  type(t_model) :: model2(2)
+  real(CUSTOM_REAL), allocatable :: delta3(:, :, :), direct(:)
 
   gpar%nx = nx; gpar%ny = ny; gpar%nz = nz
   gpar%nelements = N
@@ -98,6 +104,29 @@ program tfx_reference_demo
   print '(a,es23.16,a,es23.16)', 'model min = ', minval(model%val), '  max = ', maxval(model%val)
   print '(a,es23.16)', 'data cost = ', norm2(d_calc - d_obs) / norm2(d_obs)
   print '(a,es23.16)', 'u consumed = ', maxval(abs(b_RHS))
+
+  ! ---- the same system assembled and solved by jinv%solve: residuals and column weight in iarr, model and prior in the model object
+  allocate(direct(N))
+  direct = model%val(:, 1)
+  ipar%nx = nx; ipar%ny = ny; ipar%nz = nz
+  ipar%nelements = gpar%nelements; ipar%nelements_total = N
+  ipar%ndata = (/nd, 0/); ipar%ndata_components = 1; ipar%nmodel_components = 1
+  ipar%niter = 20; ipar%rmin = 1.d-13; ipar%gamma = 0.d0; ipar%target_misfit = 0.d0
+  ipar%alpha = (/alpha, 0.d0/); ipar%norm_power = 2.d0
+  ipar%problem_weight = (/problem_weight, 0.d0/)
+  ipar%compression_type = gpar%compression_type
+  call iarr(1)%allocate_aux(gpar%nelements, nd, 1, myrank)
+  iarr(1)%column_weight = column_weight
+  iarr(1)%residuals(1, :) = data%weight(1, :) * (d_obs(1, :) - 0.d0)                       ! :486-491, zero starting model
+  call model2(1)%initialize(gpar%nelements, 1, N, myrank)
+  call model2(2)%initialize(gpar%nelements, 1, N, myrank)
+  call jinv%initialize(ipar, nnz, myrank)
+  jinv%matrix_sensit = matrix_sensit                                                       ! (read_sensitivity_kernel filled this handle above)
+  call jinv%initialize2(ipar, iarr, model2, myrank, nbproc)
+  allocate(delta3(gpar%nelements, 1, 2))
+  call jinv%solve(ipar, iarr, model2, delta3, memory, myrank, nbproc)
+  call model2(1)%update(delta3(:, :, 1))
+  print '(a,es23.16)', 'jinv vs direct = ', norm2(model2(1)%val(:, 1) - direct) / norm2(direct)
   call tfx_api_finalize()
   print '(a)', 'THE END.'
 end program tfx_reference_demo
