@@ -1,4 +1,4 @@
-"""Multi-GPU glue: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
+"""Multi-GPU glue: one process per GPU; the data path's collectives are RCCL inside libtfx.so, torch.distributed (gloo) is the control channel.
 
 The reference's model-cell domain decomposition (MPI, src/forward/gravmag/sensitivity_gravmag.F90:470-524 and
 src/inversion/lsqr_solver2.F90:194-241) maps to: rank r owns a contiguous column range of S (nnz-balanced with the
@@ -426,7 +426,8 @@ def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_we
     computed once; the matrix crosses the links once (the reference does this through SENSIT files and a rank-0
     MPI_Scatterv per row: sensitivity_gravmag.F90:179-189, :306-309, :795-830).
     Several data components (full gradient tensor, three-component magnetic data): the matrix has ndata_components rows per
-    datum (row = i*ncd + d), data are dealt out in blocks of 2048, so a rank's rows are whole row blocks of the matrix.
+    datum (row = i*ncd + d); data are dealt out in equal contiguous ranges (data_row_partition), a row block of the matrix may have
+    several contributors.
     nmodel_components = 3 (magnetisation vector): a rank owns its cell range of every component; the pieces carry component k
     at k*(cells of the range) + cell."""
     import torch
