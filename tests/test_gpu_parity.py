@@ -570,6 +570,17 @@ def test_adjoint_on_the_transposed_copy(ctx, shape):
         assert bits_equal(back[2], Ss[2])
         refs = orc.spmtv(*Ss, y, ncols)
         assert np.all(np.abs(ctx.trans_mult_vector(y) - refs) <= 1e-12 * orc.spmtv(Ss[0], Ss[1], np.abs(Ss[2]), np.abs(y), ncols) + 1e-300)
+        # a dense (uncompressed) kernel built into the same slot afterwards must not keep using the sparse matrix's copy
+        # (found by the randomised host sweep with TFX_ADJ_COPY=1: matrix_begin_dense did not release the slot)
+        if nrows * ncols <= 4_000_000:
+            ctx.matrix_upload_csr(nrows, ncols, *S)
+            assert ctx.debug_set("has_adj_copy") == 1
+            ctx.set_grid(ncols, 1, 1, *[np.arange(ncols, dtype=np.float64) + o for o in (0.0, 1.0)], *[np.full(ncols, v) for v in (0.0, 1.0, 0.0, 1.0)])
+            xs_, ys_, zs_ = np.linspace(0.3, ncols - 0.7, nrows), np.full(nrows, 0.5), np.full(nrows, -1.0)
+            ctx.calculate_sensit(xs_, ys_, zs_, np.ones(ncols), 0, 1.0)              # ctype 0: dense storage in the slot
+            assert ctx.debug_set("has_adj_copy") == 0
+            Sd = ctx.matrix_download_csr()
+            assert np.allclose(ctx.trans_mult_vector(y), orc.spmtv(*Sd, y, ncols), rtol=1e-10, atol=1e-10 * np.abs(Sd[2]).max() * np.abs(y).sum())
         # explicit zeros are stored in S (and come back on download) but not in the copy: the product does not change
         Sz = (S[0], S[1], S[2].copy())
         Sz[2][::3] = 0.0

@@ -268,7 +268,7 @@ constexpr int DN_THREADS = 1024;
 int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols)
 {
     TiledMatrix &m = *ctx->target;
-    m.valid = false;
+    m.release_storage();            // (whatever the slot held before: tiles, work lists, a transposed copy)
     if (nrows <= 0 || ncols <= 0) return fail(TFX_E_ARG, "matrix_begin_dense: empty matrix");
     m.nrows = nrows;
     m.ncols = ncols;
