@@ -1419,6 +1419,35 @@ def test_band_select_gives_the_same_matrix_as_the_full_select(ctx, ctype, rate, 
         assert bits_equal(C[2][C[0][r]:C[0][r + 1]], A[2][A[0][r]:A[0][r + 1]][sel])
 
 
+@pytest.mark.parametrize("expect_fallback", [False, True])
+def test_overlapped_build_reads_batch_statistics_late_and_redoes_band_misses_out_of_order(ctx, expect_fallback):
+    """The overlapped build (debug key "build_overlap" = 2 forces it on a build of a few batches) queues batch b + 1 before it reads
+    batch b's statistics; a batch whose band missed is redone afterwards - out of order - from its kept rows with the full select.
+    Same matrix bits, histogram and compression error as the one-stream build, whether no batch or every batch misses."""
+    nx, ny, nz, ox, oy = 64, 64, 32, 13, 11                      # 143 observations = 5 batches of up to 32 lines
+    grid = tfx.synthetic.grid(nx, ny, nz)
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, ox, oy)
+    ctx.set_grid(nx, ny, nz, *grid)
+    cw = ctx.calculate_depth_weight()
+    if expect_fallback:
+        cw = np.where(np.arange(cw.size) % 257 == 0, cw, 0.0)     # thresholds under the 1e-30 floor: every band misses
+    out = []
+    try:
+        ctx.debug_set("band_select_min_cells", 0)
+        for mode in (0, 2):
+            ctx.debug_set("build_overlap", mode)
+            b0, f0 = ctx.debug_set("band_batches"), ctx.debug_set("band_fallbacks")
+            res = ctx.calculate_sensit(xs, ys, zs, cw, 1, 0.5 if expect_fallback else 0.05, want_hist=True)   # (Haar r = 0.5 on 1/257 of the cells: the kept count exceeds the non-zeros)
+            out.append((res, ctx.matrix_download_csr(), ctx.debug_set("band_batches") - b0, ctx.debug_set("band_fallbacks") - f0))
+    finally:
+        ctx.debug_set("band_select_min_cells", 1 << 20)
+        ctx.debug_set("build_overlap", 1)
+    (ra, A, used_a, fell_a), (rb, B, used_b, fell_b) = out
+    assert used_a == used_b >= 5 and fell_a == fell_b and (fell_b > 0) == expect_fallback
+    assert ra["nnz"] == rb["nnz"] and np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and bits_equal(A[2], B[2])
+    assert np.array_equal(ra["nnz_hist"], rb["nnz_hist"]) and abs(ra["error_sum"] - rb["error_sum"]) <= 1e-12 * abs(ra["error_sum"])
+
+
 @pytest.mark.parametrize("kind", ["normal", "lognormal", "ties", "quantised", "mostly_zero", "denormal", "constant", "lattice"])
 def test_band_select_on_adversarial_rows(ctx, kind):
     """Single rows with awkward value distributions through tfx_compress_row, band select against the full select and against

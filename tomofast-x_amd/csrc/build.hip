@@ -2831,7 +2831,8 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     // threshold, compaction, tile scatter - is HBM-bound.  The generator of batch b + 1 runs on its own (low-priority) stream into
     // the second row buffer while the main stream transforms and compacts batch b: their waves share the CUs, one kind waiting on
     // memory while the other computes.  (ctx->build_overlap = 0: one stream, one buffer - the sequential order of round 1.)
-    const bool overlap = ctx->build_overlap && ndata >= 8 * (int64_t)ob_max;      // (short builds: the second buffer and stream cost more than they hide)
+    // (short builds: the extra buffers and the stream cost more than they hide; build_overlap = 2 forces the overlapped form: tests)
+    const bool overlap = ctx->build_overlap == 2 || (ctx->build_overlap && ndata >= 8 * (int64_t)ob_max);
     // Three row buffers in overlap mode: batch b + 1 is generated while batch b is transformed, and batch b - 1's transformed rows stay
     // until its statistics are confirmed (a band that missed redoes the batch from them with the full select)
     const int nbuf = overlap ? 3 : 1;
