@@ -313,8 +313,10 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * matrix memory, a longer build: it pays for very long solves on one matrix - DESIGN.md 3); automatic = matrices of at least
  * "adj_copy_min_nnz" stored entries (2^26) when the device has room;
  * "has_adj_copy" queries the selected matrix;
- * key "build_overlap" (0/1, default 1): the kernel build runs its row generator (VALU-bound) on a second stream one batch ahead of
- * the wavelet / threshold / compaction kernels (HBM-bound) of the main stream; 0 = one stream, one row buffer;
+ * key "build_overlap" (0/1/2, default 1): the kernel build runs its row generator (VALU-bound) on a second stream one batch ahead of
+ * the wavelet / threshold / compaction kernels (HBM-bound) of the main stream and reads each batch's statistics one batch late
+ * (three row buffers); 0 = one stream, one row buffer; 1 = overlapped when the kernel has at least 8 batches of rows; 2 = overlapped
+ * always (what the tests use to drive the deferred-statistics path on small kernels) - the three give the same bits;
  * key "chunk_exponent_span" (value): diagnostics - per mille of the stored 512-entry chunks whose non-zero values span at most
  * `value` binades (prints the histogram on stderr);
  * key "force_collectives" (0/1): issue the collectives of the multi-rank path even with one rank - with a world-size-1
