@@ -30,7 +30,7 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     if (const char *e = getenv("TFX_ADJ_COPY_MIN_NNZ")) c->adj_copy_min_nnz = atoll(e);
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("TFX_GEN_WGS_PER_CU")) c->gen_wgs_per_cu = atoi(e);
-    if (const char *e = getenv("TFX_GEN_AFTER_WAVELET")) c->gen_after_wavelet = atoi(e) != 0;
+    if (const char *e = getenv("TFX_GEN_AFTER_WAVELET")) c->gen_after_wavelet = std::max(0, std::min(3, atoi(e)));
     TFX_HIP(hipEventCreate(&c->ev0));
     TFX_HIP(hipEventCreate(&c->ev1));
     TFX_HIP(hipEventCreate(&c->pev0));
@@ -180,7 +180,7 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         return total > 0 ? (int)(1000.0 * (double)fit / (double)total) : 0;
     }
     if (!strcmp(key, "gen_after_wavelet")) {
-        ctx->gen_after_wavelet = value != 0;
+        ctx->gen_after_wavelet = std::max(0, std::min(3, value));        // axis passes of the wavelet transform ahead of the next generator
         return 0;
     }
     if (!strcmp(key, "gen_wgs_per_cu")) {

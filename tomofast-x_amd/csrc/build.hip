@@ -1431,7 +1431,7 @@ static int pick_xt(int L, int64_t avail, int want, int *XT, int *P)
 }
 
 // in place on nvec device arrays of n1*n2*n3 doubles, back to back (vec_stride = n1*n2*n3)
-int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, int type, int dir)
+int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, int type, int dir, int axis_from, int axis_to)
 {
     if (type != 1 && type != 2) return fail(TFX_E_ARG, "Unknown wavelet type!");      // wavelet_transform.F90:46-48
     if (dir != 1 && dir != 2) return fail(TFX_E_ARG, "bad wavelet direction");
@@ -1444,7 +1444,7 @@ int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, i
         if (const char *e = getenv("TFX_WAVE_XT")) sscanf(e, "%d,%d,%d", &w[0], &w[1], &w[2]);
         for (int i = 0; i < 3; ++i) want[i] = std::max(1, std::min(64, w[i]));
     }
-    for (int axis = 0; axis < 3; ++axis) {             // axis order x -> y -> z for forward AND inverse (:82-93, :165-176)
+    for (int axis = axis_from; axis < axis_to; ++axis) {    // axis order x -> y -> z for forward AND inverse (:82-93, :165-176)
         WaveAxis ax{};
         unsigned ntiles = 0;
         if (axis == 0) {
@@ -1478,17 +1478,27 @@ int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, i
 // radix select on the 63-bit pattern of |x| (non-negative doubles order like unsigned integers)
 // =============================================================================================================
 constexpr int SEL_BINS = 4096;
+constexpr int SEL_DIGIT_BITS = 12;
 constexpr int SEL_NDIG = 6;
-__constant__ int c_sel_shift[SEL_NDIG] = {52, 40, 28, 16, 4, 0};
-__constant__ int c_sel_bits[SEL_NDIG] = {12, 12, 12, 12, 12, 4};
 
 struct SelState {
     unsigned long long prefix;    // selected high bits so far (already shifted into place)
     unsigned long long rank;      // 1-based rank (ascending) inside the candidate set
     unsigned long long ncand;     // candidates in the current buffer
     unsigned long long nnext;     // append counter for the next buffer
-    unsigned int bin, pad;
+    unsigned long long base;      // the keys of the row are stored minus this (0: full select; band.lo: band select)
+    unsigned int bin;
+    int top;                      // the keys of the row are < 2^top (64: full select; bit length of hi - lo: band select)
 };
+
+// digit d of a row whose keys are below 2^top: bits [max(top - 12 (d + 1), 0), top - 12 d) - for top = 64 the windows are
+// 52 / 40 / 28 / 16 / 4 / 0 (the last one 4 bits wide); a window below bit 0 is empty (mask 0: every key in bin 0)
+__device__ __forceinline__ void sel_window(int top, int digit, int &shift, unsigned int &mask)
+{
+    const int hi = max(top - SEL_DIGIT_BITS * digit, 0);
+    shift = max(hi - SEL_DIGIT_BITS, 0);
+    mask = (1u << (hi - shift)) - 1u;
+}
 
 // from_rows: the keys are |row| itself (digit 0 of the full select); else the candidate key buffer
 __global__ __launch_bounds__(256) void k_sel_hist(const double *__restrict__ rows, int64_t N,
@@ -1500,8 +1510,9 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double *__restrict__ row
     const int row = blockIdx.y;
     for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    const int shift = c_sel_shift[digit];
-    const unsigned int mask = (1u << c_sel_bits[digit]) - 1u;
+    int shift;
+    unsigned int mask;
+    sel_window(st[row].top, digit, shift, mask);
     if (from_rows) {
         const double *r = rows + (int64_t)row * N;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1540,7 +1551,10 @@ __global__ void k_sel_pick(SelState *__restrict__ st, unsigned int *__restrict__
         while (b < SEL_BINS - 1 && run + g[b] < rank) { run += g[b]; ++b; }
         st[row].bin = (unsigned int)b;
         st[row].rank = rank - run;
-        st[row].prefix |= ((unsigned long long)b) << c_sel_shift[digit];
+        int shift;
+        unsigned int mask;
+        sel_window(st[row].top, digit, shift, mask);
+        st[row].prefix |= ((unsigned long long)b) << shift;
         st[row].nnext = 0;
     }
     __syncthreads();
@@ -1557,8 +1571,9 @@ __global__ __launch_bounds__(256) void k_sel_filter(const double *__restrict__ r
 {
     __shared__ unsigned long long stage[4][SEL_STAGE];
     const int row = blockIdx.y;
-    const int shift = c_sel_shift[digit];
-    const unsigned int mask = (1u << c_sel_bits[digit]) - 1u;
+    int shift;
+    unsigned int mask;
+    sel_window(st[row].top, digit, shift, mask);
     const unsigned int bin = st[row].bin;
     unsigned long long *out = cand_out + (int64_t)row * cand_stride;
     const int64_t n = from_rows ? N : (int64_t)st[row].ncand;
@@ -1613,7 +1628,74 @@ __global__ void k_sel_advance(SelState *__restrict__ st, int nrows)
 __global__ void k_sel_init(SelState *__restrict__ st, int nrows, unsigned long long rank)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row < nrows) { st[row].prefix = 0; st[row].rank = rank; st[row].ncand = 0; st[row].nnext = 0; st[row].bin = 0; }
+    if (row < nrows) { st[row].prefix = 0; st[row].rank = rank; st[row].ncand = 0; st[row].nnext = 0; st[row].base = 0; st[row].bin = 0; st[row].top = 64; }
+}
+
+// one block per row, after the filter of digit `first_digit - 1` (its output: st.nnext keys in cand): the remaining digits in one
+// launch.  Few candidates (the normal case of the band select: the first digit spreads the band over >= 2048 bins): ranks by
+// counting in LDS.  Many (keys piled up on few values): the digit loop over the candidate list with an LDS histogram.
+constexpr int FIN_CAP = 1024;
+__global__ __launch_bounds__(256) void k_sel_finish(SelState *__restrict__ st, const unsigned long long *__restrict__ cand, int64_t cand_stride,
+                                                    int first_digit)
+{
+    __shared__ unsigned long long keys[FIN_CAP];
+    __shared__ unsigned int h[SEL_BINS];
+    __shared__ unsigned long long part[256];
+    __shared__ unsigned long long s_prefix, s_rank;
+    const int row = blockIdx.x;
+    const unsigned long long n = st[row].nnext;
+    if (n == 0) return;                                        // a band that missed: the batch is redone
+    const unsigned long long *c = cand + (int64_t)row * cand_stride;
+    const unsigned long long rank = st[row].rank;
+    if (n <= (unsigned long long)FIN_CAP) {
+        const int m = (int)n;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) keys[i] = c[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            const unsigned long long k = keys[i];
+            unsigned int less = 0, eq = 0;
+            for (int j = 0; j < m; ++j) {
+                const unsigned long long o = keys[j];
+                less += o < k;
+                eq += o == k;
+            }
+            if ((unsigned long long)less < rank && rank <= (unsigned long long)less + eq) st[row].prefix = k;   // equal keys write the same value
+        }
+        return;
+    }
+    const int top = st[row].top;
+    if (threadIdx.x == 0) { s_prefix = st[row].prefix; s_rank = rank; }
+    for (int d = first_digit; d < SEL_NDIG; ++d) {
+        int shift;
+        unsigned int mask;
+        sel_window(top, d, shift, mask);
+        const int above = max(top - SEL_DIGIT_BITS * d, 0);     // the bits from here up are decided (d >= 1: above <= 52)
+        for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) h[i] = 0;
+        __syncthreads();
+        const unsigned long long pfx = s_prefix >> above;
+        for (unsigned long long i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned long long k = c[i];
+            if ((k >> above) == pfx) atomicAdd(&h[(unsigned int)(k >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        constexpr int per = SEL_BINS / 256;
+        unsigned long long sum = 0;
+        for (int i = 0; i < per; ++i) sum += h[threadIdx.x * per + i];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long r = s_rank;
+            unsigned long long run = 0;
+            int t = 0;
+            while (t < 255 && run + part[t] < r) { run += part[t]; ++t; }
+            int b = t * per;
+            while (b < SEL_BINS - 1 && run + h[b] < r) { run += h[b]; ++b; }
+            s_rank = r - run;
+            s_prefix |= ((unsigned long long)b) << shift;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st[row].prefix = s_prefix;
 }
 
 // fail != null (band select): a threshold below the 1e-30 floor means the band's "everything above hi is kept" does not hold
@@ -1621,7 +1703,7 @@ __global__ void k_sel_result(const SelState *__restrict__ st, int nrows, double 
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row < nrows) {
-        double t = __longlong_as_double((long long)st[row].prefix);
+        double t = __longlong_as_double((long long)(st[row].prefix + st[row].base));
         if (t < 1.e-30) {                                  // sensitivity_gravmag.F90:252-256
             t = 1.e-30;
             if (fail) atomicOr(fail, 2);
@@ -1795,7 +1877,7 @@ int select_threshold_dev(tfx_ctx *ctx, SelectWork &wk, const double *d_rows, int
 constexpr int CMP_THREADS = 256;
 constexpr int CMP_PER_THREAD = 8;
 constexpr int CMP_SEG = CMP_THREADS * CMP_PER_THREAD;     // 2048 elements per block
-static_assert(CMP_PER_THREAD * (CMP_THREADS / 64) == 32, "scan32_wave0 scans exactly 32 counts");
+static_assert(CMP_PER_THREAD * (CMP_THREADS / 64) <= 64 && CMP_PER_THREAD % 2 == 0, "one wave scans the (sub-block, wave) counts");
 
 struct CompactArgs {
     const double *rows;       // [nrows][N]
@@ -1834,107 +1916,143 @@ struct CompactArgs {
 
 __device__ __forceinline__ bool keep_elem(double v, double thr, int keep_all) { return keep_all || fabs(v) > thr; }
 
-// exclusive scan of the CMP_PER_THREAD * NW = 32 (sub-block, wave) counts in LDS by the first wave; returns the total to
-// every lane of that wave (call from wave 0 only, after a barrier)
-__device__ __forceinline__ int scan32_wave0(int *wcnt, int lane)
+// exclusive scan of NCNT <= 64 (sub-block, wave) counts in LDS by the first wave; returns the total to every lane of that wave
+// (call from wave 0 only, after a barrier)
+template <int NCNT>
+__device__ __forceinline__ int scan_wave0(int *wcnt, int lane)
 {
-    const int c = lane < 32 ? wcnt[lane] : 0;
+    const int c = lane < NCNT ? wcnt[lane] : 0;
     int incl = c;
 #pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
+    for (int o = 1; o < NCNT; o <<= 1) {
         const int up = __shfl_up(incl, o);
         if (lane >= o) incl += up;
     }
-    if (lane < 32) wcnt[lane] = incl - c;
-    return __shfl(incl, 31);
+    if (lane < NCNT) wcnt[lane] = incl - c;
+    return __shfl(incl, NCNT - 1);
 }
 
-// A block owns CMP_SEG = 8 x 256 consecutive elements; thread t reads elements base + k*256 + t (coalesced).
-// Counts the kept elements of the segment.  With a band (threshold not known yet): counts the keys above band.hi and those
-// inside the band, copies every coefficient that may be kept (key >= band.lo, ~2.5 % of the row) with its position into the
-// segment's own slots (no atomics) - the write pass then never reads the row again - and sums the energy of the rest.
+// Count pass.  A block walks CNT_SEGS consecutive segments of CMP_SEG = 2048 elements; thread t holds the elements
+// k*512 + 2t, k*512 + 2t + 1 (k = 0..3) of a segment (16-byte loads where the row start allows) and has the loads of the next
+// segment in flight while it counts this one.  Counts the kept elements of each segment.  With a band (threshold not known yet):
+// counts the keys above band.hi and those inside the band, copies every coefficient that may be kept (key >= band.lo, ~2.5 % of
+// the row) with its position into the segment's own slots in ascending position (no atomics) - the write pass then never reads
+// the row again - and sums the energy of the rest.
+constexpr int CNT_SEGS = 4;
+constexpr int CNT_LOADS = CMP_PER_THREAD / 2;
+
+__device__ __forceinline__ void cnt_load(const double *__restrict__ r, int64_t N, int64_t b, bool vec, double *dst)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k < CNT_LOADS; ++k) {
+        const int64_t p = b + (int64_t)k * (2 * CMP_THREADS);
+        if (vec && p + 1 < N) {
+            const d2 t = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(&r[p]));
+            dst[2 * k] = t.x;
+            dst[2 * k + 1] = t.y;
+        } else {
+            dst[2 * k] = p < N ? __builtin_nontemporal_load(&r[p]) : 0.0;
+            dst[2 * k + 1] = p + 1 < N ? __builtin_nontemporal_load(&r[p + 1]) : 0.0;
+        }
+    }
+}
+
 __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
 {
-    const int row = blockIdx.y, seg = blockIdx.x;
+    const int row = blockIdx.y;
+    const int seg_begin = blockIdx.x * CNT_SEGS, seg_end = min(seg_begin + CNT_SEGS, a.nseg);
     const double *r = a.rows + (int64_t)row * a.N;
+    const bool vec = (reinterpret_cast<uintptr_t>(r) & 15) == 0;
     const bool banded = a.band != nullptr;
     const double thr = banded ? 0.0 : a.thr[row];
     const unsigned long long lo = banded ? a.band[row].lo : 0ull, hi = banded ? a.band[row].hi : 0ull;
-    const int64_t base = (int64_t)seg * CMP_SEG + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = CMP_THREADS / 64;
-    __shared__ int wcnt[CMP_PER_THREAD * NW];
-    __shared__ int s_cnt[NW], s_all[NW], s_band[NW];
-    __shared__ double s_cost[NW];
-    int cnt = 0, cnt_all = 0, nband = 0;
-    double v[CMP_PER_THREAD];
-    int lpre[CMP_PER_THREAD];
-    unsigned slotmask = 0;
-    double cost = 0.0;
-    // all loads of the segment first (independent, in flight together), then the ballots
+    // LDS by segment parity: a fast wave may start the next segment while a slow one still reads this one's scan
+    __shared__ int wcnt[2][CNT_LOADS * NW];                 // slot count of (load k, wave w): slot order = (k, w, lane, half)
+    __shared__ int s_cnt[2][NW], s_all[2][NW], s_band[2][NW];
+    __shared__ double s_cost[2][NW];
+    double v[CMP_PER_THREAD], nx[CMP_PER_THREAD];
+    cnt_load(r, a.N, (int64_t)seg_begin * CMP_SEG + 2 * threadIdx.x, vec, v);
+    for (int seg = seg_begin; seg < seg_end; ++seg) {
+        const int par = (seg - seg_begin) & 1;
+        if (seg + 1 < seg_end) cnt_load(r, a.N, (int64_t)(seg + 1) * CMP_SEG + 2 * threadIdx.x, vec, nx);
+        const int64_t base = (int64_t)seg * CMP_SEG + 2 * threadIdx.x;
+        int cnt = 0, cnt_all = 0, nband = 0;
+        int lpre[CMP_PER_THREAD];
+        unsigned slotmask = 0;
+        double cost = 0.0;
 #pragma unroll
-    for (int k = 0; k < CMP_PER_THREAD; ++k) {
-        const int64_t p = base + (int64_t)k * CMP_THREADS;
-        v[k] = p < a.N ? __builtin_nontemporal_load(&r[p]) : 0.0;
-    }
+        for (int k = 0; k < CNT_LOADS; ++k) {
+            bool sl[2] = {false, false};
 #pragma unroll
-    for (int k = 0; k < CMP_PER_THREAD; ++k) {
-        const int64_t p = base + (int64_t)k * CMP_THREADS;
-        bool slot = false;
-        if (p < a.N) {
-            bool keep;
+            for (int h = 0; h < 2; ++h) {
+                const int64_t p = base + (int64_t)k * (2 * CMP_THREADS) + h;
+                const double x = v[2 * k + h];
+                if (p < a.N) {
+                    bool keep;
+                    if (banded) {
+                        const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(x));
+                        keep = key > hi;
+                        sl[h] = key >= lo;
+                        if (sl[h] && !keep) nband += 1;
+                        if (!sl[h]) cost = fma(x, x, cost);
+                    } else keep = keep_elem(x, thr, a.keep_all);
+                    if (keep) {
+                        cnt_all += 1;
+                        if (p >= a.col_begin && p < a.col_end) cnt += 1;
+                    }
+                }
+            }
             if (banded) {
-                const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(v[k]));
-                keep = key > hi;
-                slot = key >= lo;
-                if (slot && !keep) nband += 1;
-                if (!slot) cost = fma(v[k], v[k], cost);
-            } else keep = keep_elem(v[k], thr, a.keep_all);
-            if (keep) {
-                cnt_all += 1;
-                if (p >= a.col_begin && p < a.col_end) cnt += 1;
+                const unsigned long long m0 = __ballot(sl[0]), m1 = __ballot(sl[1]);
+                const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0)) +
+                                __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0));
+                lpre[2 * k] = pre;
+                lpre[2 * k + 1] = pre + (sl[0] ? 1 : 0);
+                if (sl[0]) slotmask |= 1u << (2 * k);
+                if (sl[1]) slotmask |= 1u << (2 * k + 1);
+                if (lane == 0) wcnt[par][k * NW + wave] = __popcll(m0) + __popcll(m1);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            cnt += __shfl_down(cnt, d);
+            cnt_all += __shfl_down(cnt_all, d);
+            if (banded) { nband += __shfl_down(nband, d); cost += __shfl_down(cost, d); }
+        }
+        if (lane == 0) { s_cnt[par][wave] = cnt; s_all[par][wave] = cnt_all; s_band[par][wave] = nband; s_cost[par][wave] = cost; }
+        __syncthreads();
+        const int64_t sg = (int64_t)row * a.nseg + seg;
+        if (wave == 0) {
+            int run = 0;
+            if (banded) run = scan_wave0<CNT_LOADS * NW>(wcnt[par], lane);
+            if (lane == 0) {
+                int c = 0, ca = 0, nb = 0;
+                double cs = 0.0;
+                for (int i = 0; i < NW; ++i) { c += s_cnt[par][i]; ca += s_all[par][i]; nb += s_band[par][i]; cs += s_cost[par][i]; }
+                a.seg_cnt[sg] = c;
+                a.seg_all[sg] = ca;
+                if (banded) { a.seg_slot[sg] = run; a.seg_band[sg] = nb; a.seg_cost[sg] = cs; }
             }
         }
         if (banded) {
-            const unsigned long long m = __ballot(slot);
-            lpre[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (slot) slotmask |= 1u << k;
-            if (lane == 0) wcnt[k * NW + wave] = __popcll(m);
-        }
-    }
+            __syncthreads();
+            if (slotmask) {
+                double *bv = a.slot_vals + sg * BAND_SLOTS;
+                uint16_t *bp = a.slot_pos + sg * BAND_SLOTS;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        cnt += __shfl_down(cnt, d);
-        cnt_all += __shfl_down(cnt_all, d);
-        if (banded) { nband += __shfl_down(nband, d); cost += __shfl_down(cost, d); }
-    }
-    if (lane == 0) { s_cnt[wave] = cnt; s_all[wave] = cnt_all; s_band[wave] = nband; s_cost[wave] = cost; }
-    __syncthreads();
-    const int64_t sg = (int64_t)row * a.nseg + seg;
-    if (wave == 0) {
-        int run = 0;
-        if (banded) run = scan32_wave0(wcnt, lane);
-        if (lane == 0) {
-            int c = 0, ca = 0, nb = 0;
-            double cs = 0.0;
-            for (int i = 0; i < NW; ++i) { c += s_cnt[i]; ca += s_all[i]; nb += s_band[i]; cs += s_cost[i]; }
-            a.seg_cnt[sg] = c;
-            a.seg_all[sg] = ca;
-            if (banded) { a.seg_slot[sg] = run; a.seg_band[sg] = nb; a.seg_cost[sg] = cs; }
-        }
-    }
-    if (!banded) return;
-    __syncthreads();
-    if (slotmask) {
-        double *bv = a.slot_vals + sg * BAND_SLOTS;
-        uint16_t *bp = a.slot_pos + sg * BAND_SLOTS;
-#pragma unroll
-        for (int k = 0; k < CMP_PER_THREAD; ++k)
-            if (slotmask & (1u << k)) {
-                const int pos = wcnt[k * NW + wave] + lpre[k];
-                bv[pos] = v[k];
-                bp[pos] = (uint16_t)(k * CMP_THREADS + threadIdx.x);
+                for (int j = 0; j < CMP_PER_THREAD; ++j)
+                    if (slotmask & (1u << j)) {
+                        const int pos = wcnt[par][(j >> 1) * NW + wave] + lpre[j];
+                        bv[pos] = v[j];
+                        bp[pos] = (uint16_t)((j >> 1) * (2 * CMP_THREADS) + 2 * threadIdx.x + (j & 1));
+                    }
             }
+        }
+#pragma unroll
+        for (int j = 0; j < CMP_PER_THREAD; ++j) v[j] = nx[j];
     }
 }
 
@@ -1963,11 +2081,15 @@ __global__ void k_band_scan(CompactArgs a)
         const unsigned long long B = (unsigned long long)run, N = (unsigned long long)a.N;
         const unsigned long long below = N - (unsigned long long)G - B, r = N - a.K;    // r: 1-based ascending rank of the threshold (:240-250)
         const bool ok = !s_over && B <= (unsigned long long)a.key_stride && below < r && r <= below + B;
+        // the exact select runs on key - lo: its first 12-bit digit splits the band's key range [0, hi - lo] into >= 2048 bins
+        const unsigned long long span = a.band[row].hi - a.band[row].lo;
         a.st[row].prefix = 0;
         a.st[row].rank = ok ? r - below : 1;
         a.st[row].ncand = ok ? B : 0;
         a.st[row].nnext = 0;
+        a.st[row].base = a.band[row].lo;
         a.st[row].bin = 0;
+        a.st[row].top = span ? 64 - __clzll((long long)span) : 0;
         if (!ok) atomicOr(a.fail, 1);
     }
     __syncthreads();
@@ -1978,28 +2100,31 @@ __global__ void k_band_scan(CompactArgs a)
     }
 }
 
-// band members of the slots -> dense key list of the row (one wave per segment)
+// band members of the slots -> dense key list of the row, stored minus band.lo (one wave per segment).  In the three slot kernels
+// every load whose address does not depend on another load is issued before the first test (the first 64 slots speculatively: a
+// segment owns BAND_SLOTS >= 64 of them whether it uses them or not): one memory latency per wave instead of a chain of four.
 __global__ __launch_bounds__(256) void k_band_gather(CompactArgs a)
 {
     const int row = blockIdx.y, seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (seg >= a.nseg || a.st[row].ncand == 0) return;
+    if (seg >= a.nseg) return;
     const int64_t sg = (int64_t)row * a.nseg + seg;
-    if (a.seg_band[sg] == 0) return;
-    const int n = a.seg_slot[sg];
-    const unsigned long long hi = a.band[row].hi;
     const double *bv = a.slot_vals + sg * BAND_SLOTS;
-    unsigned long long *out = a.band_keys + (int64_t)row * a.key_stride + a.seg_boff[sg];
+    const double v0 = bv[lane];
+    const int nb = a.seg_band[sg], n = a.seg_slot[sg], boff = a.seg_boff[sg];
+    const unsigned long long lo = a.band[row].lo, hi = a.band[row].hi, ncand = a.st[row].ncand;
+    if (ncand == 0 || nb == 0) return;
+    unsigned long long *out = a.band_keys + (int64_t)row * a.key_stride + boff;
     int run = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
         unsigned long long key = 0;
         bool in = false;
         if (i < n) {
-            key = (unsigned long long)__double_as_longlong(fabs(bv[i]));
+            key = (unsigned long long)__double_as_longlong(fabs(i0 == 0 ? v0 : bv[i]));
             in = key <= hi;
         }
         const unsigned long long m = __ballot(in);
-        if (in) out[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = key;
+        if (in) out[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = key - lo;
         run += __popcll(m);
     }
 }
@@ -2010,18 +2135,21 @@ __global__ __launch_bounds__(256) void k_band_fix(CompactArgs a)
     const int row = blockIdx.y, seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (seg >= a.nseg) return;
     const int64_t sg = (int64_t)row * a.nseg + seg;
-    if (a.seg_band[sg] == 0) return;
-    const int n = a.seg_slot[sg];
-    const double thr = a.thr[row];
-    const double hi = __longlong_as_double((long long)a.band[row].hi);       // NaN pattern when hi = all ones: no key is above it
-    const bool hi_all = a.band[row].hi == ~0ull;
     const double *bv = a.slot_vals + sg * BAND_SLOTS;
     const uint16_t *bp = a.slot_pos + sg * BAND_SLOTS;
+    const double v0 = bv[lane];
+    const uint16_t p0 = bp[lane];
+    const int nb = a.seg_band[sg], n = a.seg_slot[sg];
+    const double thr = a.thr[row];
+    const unsigned long long hikey = a.band[row].hi;
+    if (nb == 0) return;
+    const double hi = __longlong_as_double((long long)hikey);                // NaN pattern when hi = all ones: no key is above it
+    const bool hi_all = hikey == ~0ull;
     int cnt = 0, cnt_all = 0;
     for (int i = lane; i < n; i += 64) {
-        const double av = fabs(bv[i]);
+        const double av = fabs(i < 64 ? v0 : bv[i]);
         if ((hi_all || av <= hi) && av > thr) {                              // inside the band (not yet counted) and kept
-            const int64_t p = (int64_t)seg * CMP_SEG + bp[i];
+            const int64_t p = (int64_t)seg * CMP_SEG + (i < 64 ? p0 : bp[i]);
             cnt_all += 1;
             if (p >= a.col_begin && p < a.col_end) cnt += 1;
         }
@@ -2042,13 +2170,15 @@ __global__ __launch_bounds__(256) void k_slot_write(CompactArgs a)
     const int row = blockIdx.y, seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (seg >= a.nseg) return;
     const int64_t sg = (int64_t)row * a.nseg + seg;
-    const int n = a.seg_slot[sg];
-    if (n == 0) return;
-    const double thr = a.thr[row];
-    const float sc = a.scale ? a.scale[row] : 1.0f;
     const double *bv = a.slot_vals + sg * BAND_SLOTS;
     const uint16_t *bp = a.slot_pos + sg * BAND_SLOTS;
+    const double v0 = bv[lane];
+    const uint16_t p0 = bp[lane];
+    const int n = a.seg_slot[sg];
+    const double thr = a.thr[row];
+    const float sc = a.scale ? a.scale[row] : 1.0f;
     int segoff = a.seg_off[sg];
+    if (n == 0) return;
     const int comp = row % a.ncm, mrow = row / a.ncm;
     for (int kk = 0; kk < comp; ++kk) segoff += a.nel[row - comp + kk];
     const int64_t cshift = (int64_t)comp * a.comp_stride - a.col_begin;
@@ -2062,8 +2192,8 @@ __global__ __launch_bounds__(256) void k_slot_write(CompactArgs a)
         int64_t p = 0;
         bool keep = false;
         if (i < n) {
-            v = bv[i];
-            p = (int64_t)seg * CMP_SEG + bp[i];
+            v = i0 == 0 ? v0 : bv[i];
+            p = (int64_t)seg * CMP_SEG + (i0 == 0 ? p0 : bp[i]);
             if (keep_elem(v, thr, 0)) {
                 if (a.hist) atomicAdd(&a.hist[p], 1);
                 keep = p >= a.col_begin && p < a.col_end;
@@ -2169,7 +2299,7 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_write(CompactArgs a)
     if (lane == 0) s_cost[wave] = cost;
     __syncthreads();
     if (wave == 0) {                                     // exclusive scan of the 32 (k, w) counts
-        (void)scan32_wave0(wcnt, lane);
+        (void)scan_wave0<CMP_PER_THREAD * NW>(wcnt, lane);
         if (lane == 0) {
             double cs = 0.0;
             for (int i = 0; i < NW; ++i) cs += s_cost[i];
@@ -2332,26 +2462,22 @@ static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int 
         a.band = cw.band.p; a.slot_vals = cw.slot_vals.p; a.slot_pos = cw.slot_pos.p; a.seg_slot = cw.seg_slot.p; a.seg_band = cw.seg_band.p;
         a.seg_boff = cw.seg_boff.p; a.band_keys = sel->candA.p; a.key_stride = sel->cap_N; a.st = sel->st.p;
         a.K = (unsigned long long)K; a.fail = cw.fail.p;
-        hipLaunchKernelGGL(k_cmp_count, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_cmp_count, dim3((cw.nseg + CNT_SEGS - 1) / CNT_SEGS, nrows), dim3(CMP_THREADS), 0, s, a);
         hipLaunchKernelGGL(k_band_scan, dim3(nrows), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_band_gather, dim3((cw.nseg + 3) / 4, nrows), dim3(256), 0, s, a);
         // exact select inside the band (dense keys in candA)
         TFX_HIP(hipMemsetAsync(sel->hist.p, 0, (size_t)nrows * SEL_BINS * sizeof(unsigned int), s));
         const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->num_cu * 4 / std::max(1, nrows) + 1, (N / 64 + 255) / 256));
         unsigned long long *in = sel->candA.p, *out = sel->candB.p;
-        for (int d = 0; d < SEL_NDIG; ++d) {
-            hipLaunchKernelGGL(k_sel_hist, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, sel->cap_N, sel->st.p, d, sel->hist.p, 0);
-            hipLaunchKernelGGL(k_sel_pick, dim3(nrows), dim3(256), 0, s, sel->st.p, sel->hist.p, d);
-            if (d + 1 < SEL_NDIG) {
-                hipLaunchKernelGGL(k_sel_filter, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, out, sel->cap_N, sel->st.p, d, 0);
-                hipLaunchKernelGGL(k_sel_advance, dim3((nrows + 63) / 64), dim3(64), 0, s, sel->st.p, nrows);
-                std::swap(in, out);
-            }
-        }
+        // digit 0 over all blocks (it spreads the band's key range over >= 2048 bins), the rest by one block per row
+        hipLaunchKernelGGL(k_sel_hist, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, sel->cap_N, sel->st.p, 0, sel->hist.p, 0);
+        hipLaunchKernelGGL(k_sel_pick, dim3(nrows), dim3(256), 0, s, sel->st.p, sel->hist.p, 0);
+        hipLaunchKernelGGL(k_sel_filter, dim3(gx, nrows), dim3(256), 0, s, d_rows, N, in, out, sel->cap_N, sel->st.p, 0, 0);
+        hipLaunchKernelGGL(k_sel_finish, dim3(nrows), dim3(256), 0, s, sel->st.p, out, sel->cap_N, 1);
         hipLaunchKernelGGL(k_sel_result, dim3((nrows + 63) / 64), dim3(64), 0, s, sel->st.p, nrows, cw.thr.p, cw.fail.p);
         hipLaunchKernelGGL(k_band_fix, dim3((cw.nseg + 3) / 4, nrows), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL(k_cmp_count, dim3(cw.nseg, nrows), dim3(CMP_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_cmp_count, dim3((cw.nseg + CNT_SEGS - 1) / CNT_SEGS, nrows), dim3(CMP_THREADS), 0, s, a);
     }
     hipLaunchKernelGGL(k_cmp_scan, dim3(nrows), dim3(256), 0, s, a);
     if (sel) hipLaunchKernelGGL(k_slot_write, dim3((cw.nseg + 3) / 4, nrows), dim3(256), 0, s, a);
@@ -2977,21 +3103,23 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         // Its buffer was last read by the compaction of batch b - 2, whose statistics the host has confirmed.
         auto queue_next = [&]() -> int {
             if (!overlap || nb_cur <= 0) return 0;
-            if (ctx->gen_after_wavelet) {
+            if (ctx->gen_after_wavelet > 0) {
                 TFX_HIP(hipEventRecord(gs.ev0, s));
                 TFX_HIP(hipStreamWaitEvent(gs.st, gs.ev0, 0));
             }
             return generate(g_after, nb_cur, slot_next);
         };
-        if (!ctx->gen_after_wavelet || compression_type == 0) TFX_TRY(queue_next());
+        const int gen_at = compression_type == 0 ? 0 : std::max(0, std::min(3, ctx->gen_after_wavelet));
+        if (gen_at == 0) TFX_TRY(queue_next());
         // threshold: bracketed from a sample and finished inside the compaction's count pass (band select) for large rows,
         // else the full radix select up front
         cur.banded = compression_type > 0 && K < N && K > 0 && N >= ctx->band_min_n && !band_off;
         if (compression_type > 0) {
             hipLaunchKernelGGL(k_rows_final_sum, dim3(nl), dim3(256), 0, s, red_cur, npart, dcf.p + (size_t)cur.hs * lines_max);   // cost_full :234
             TFX_HIP(hipGetLastError());
-            TFX_TRY(wavelet_dev(ctx, rows_cur, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1));                   // :237
-            if (ctx->gen_after_wavelet) TFX_TRY(queue_next());
+            TFX_TRY(wavelet_dev(ctx, rows_cur, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1, 0, gen_at));       // :237
+            if (gen_at > 0) TFX_TRY(queue_next());
+            TFX_TRY(wavelet_dev(ctx, rows_cur, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1, gen_at, 3));
         }
         TFX_TRY(compact_batch(cur, compression_type > 0 && !cur.banded));
         // the previous batch ran while this one was being queued: its statistics are there (or nearly)

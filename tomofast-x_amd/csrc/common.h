@@ -225,7 +225,7 @@ struct tfx_ctx {
     int wd_ncomp = 0;          //   and the number of model components (of all problems) in the local unknown vector
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int gen_after_wavelet = 1;        // debug key: the overlapped generator starts behind the current batch's wavelet passes (0: at the batch start)
+    int gen_after_wavelet = 3;        // debug key: the overlapped generator of the next batch starts behind this many axis passes of the current batch's wavelet transform (0: at the batch start, 3: behind all of them)
     int gen_wgs_per_cu = 0;           // debug key "gen_wgs_per_cu": resident generator workgroups per CU in overlap mode (0: one per tile)
     int gen_grid_limit = 0;           // (set around the generator launches of the overlapped build)
     int build_overlap = 1;            // debug key "build_overlap": row generator on its own stream, one batch ahead of the wavelet / compaction
@@ -276,5 +276,5 @@ int comm_allreduce_f64(tfx_ctx *ctx, double *buf, int64_t n);
 int comm_allgatherv_f64(tfx_ctx *ctx, const double *send, double *recv, const int64_t *counts, const int64_t *displs);   // 1: unavailable
 // build.hip
 int detect_tensor_grid(tfx_ctx *ctx);
-int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, int type, int dir);
+int wavelet_dev(tfx_ctx *ctx, double *d, int n1, int n2, int n3, int64_t nvec, int type, int dir, int axis_from = 0, int axis_to = 3);
 }  // namespace tfx
