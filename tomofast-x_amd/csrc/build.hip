@@ -1886,6 +1886,7 @@ struct CompactArgs {
     int keep_all;             // compression off: every column is stored (:289-295)
     int64_t col_begin, col_end;   // columns kept by this rank, output column = p - col_begin
     int nseg;                 // segments per row
+    int cnt_segs;             // consecutive segments a block of the count pass walks
     int32_t *seg_cnt;         // [nrows][nseg] kept-in-range counts
     int32_t *seg_all;         // [nrows][nseg] kept over all columns
     int32_t *seg_off;         // [nrows][nseg] exclusive scan
@@ -1961,7 +1962,7 @@ __device__ __forceinline__ void cnt_load(const double *__restrict__ r, int64_t N
 __global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(CompactArgs a)
 {
     const int row = blockIdx.y;
-    const int seg_begin = blockIdx.x * CNT_SEGS, seg_end = min(seg_begin + CNT_SEGS, a.nseg);
+    const int seg_begin = blockIdx.x * a.cnt_segs, seg_end = min(seg_begin + a.cnt_segs, a.nseg);
     const double *r = a.rows + (int64_t)row * a.N;
     const bool vec = (reinterpret_cast<uintptr_t>(r) & 15) == 0;
     const bool banded = a.band != nullptr;
@@ -2453,6 +2454,8 @@ static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int 
     a.out_cols = out_cols; a.out_vals = out_vals; a.out_stride = out_stride; a.nel = cw.nel.p; a.nel_all = cw.nel_all.p;
     a.cost_disc = cw.cost_disc.p; a.scale = d_scale; a.hist = d_hist; a.ncm = ncm; a.comp_stride = col_end - col_begin;
     TFX_HIP(hipMemsetAsync(cw.fail.p, 0, sizeof(int), s));
+    a.cnt_segs = CNT_SEGS;
+    const unsigned cnt_gx = (unsigned)((cw.nseg + a.cnt_segs - 1) / a.cnt_segs);
     if (sel) {
         TFX_TRY(select_prepare(*sel, nrows, N));
         TFX_TRY(band_prepare(cw, nrows));
@@ -2462,7 +2465,7 @@ static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int 
         a.band = cw.band.p; a.slot_vals = cw.slot_vals.p; a.slot_pos = cw.slot_pos.p; a.seg_slot = cw.seg_slot.p; a.seg_band = cw.seg_band.p;
         a.seg_boff = cw.seg_boff.p; a.band_keys = sel->candA.p; a.key_stride = sel->cap_N; a.st = sel->st.p;
         a.K = (unsigned long long)K; a.fail = cw.fail.p;
-        hipLaunchKernelGGL(k_cmp_count, dim3((cw.nseg + CNT_SEGS - 1) / CNT_SEGS, nrows), dim3(CMP_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_cmp_count, dim3(cnt_gx, nrows), dim3(CMP_THREADS), 0, s, a);
         hipLaunchKernelGGL(k_band_scan, dim3(nrows), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_band_gather, dim3((cw.nseg + 3) / 4, nrows), dim3(256), 0, s, a);
         // exact select inside the band (dense keys in candA)
@@ -2477,7 +2480,7 @@ static int compact_dev(tfx_ctx *ctx, CompactWork &cw, const double *d_rows, int 
         hipLaunchKernelGGL(k_sel_result, dim3((nrows + 63) / 64), dim3(64), 0, s, sel->st.p, nrows, cw.thr.p, cw.fail.p);
         hipLaunchKernelGGL(k_band_fix, dim3((cw.nseg + 3) / 4, nrows), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL(k_cmp_count, dim3((cw.nseg + CNT_SEGS - 1) / CNT_SEGS, nrows), dim3(CMP_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_cmp_count, dim3(cnt_gx, nrows), dim3(CMP_THREADS), 0, s, a);
     }
     hipLaunchKernelGGL(k_cmp_scan, dim3(nrows), dim3(256), 0, s, a);
     if (sel) hipLaunchKernelGGL(k_slot_write, dim3((cw.nseg + 3) / 4, nrows), dim3(256), 0, s, a);
