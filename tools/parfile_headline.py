@@ -74,10 +74,14 @@ try:
     if os.environ.get("PARFILE_SCATTER") == "1":
         # the SAME host, the same matrix, a second run: how far the run-dependent summation order of the LDS atomics moves an
         # unconverged 2 x 100-iteration solve (0 with TFX_DETERMINISTIC=1)
-        m_q, d_q, _ = tfx.inversion.solve_problem_gravity(ctx, cw, ctype, d_obs, nmajor, nminor, alpha=1e-7)
-        out["python_host_run_to_run"] = {"data_rel_l2": float(np.linalg.norm(d_q - d_p) / np.linalg.norm(d_p)),
-                                         "model_rel_l2": float(np.linalg.norm(m_q - m_p) / np.linalg.norm(m_p)),
-                                         "data_cost_abs_difference": abs(float(np.linalg.norm(d_q - d_obs) / np.linalg.norm(d_obs)) - float(np.linalg.norm(d_p - d_obs) / np.linalg.norm(d_obs)))}
+        sc = {"data_rel_l2": 0.0, "model_rel_l2": 0.0, "data_cost_abs_difference": 0.0, "repeats": 3}
+        for _ in range(sc["repeats"]):
+            m_q, d_q, _h = tfx.inversion.solve_problem_gravity(ctx, cw, ctype, d_obs, nmajor, nminor, alpha=1e-7)
+            sc["data_rel_l2"] = max(sc["data_rel_l2"], float(np.linalg.norm(d_q - d_p) / np.linalg.norm(d_p)))
+            sc["model_rel_l2"] = max(sc["model_rel_l2"], float(np.linalg.norm(m_q - m_p) / np.linalg.norm(m_p)))
+            sc["data_cost_abs_difference"] = max(sc["data_cost_abs_difference"],
+                                                 abs(float(np.linalg.norm(d_q - d_obs) / np.linalg.norm(d_obs)) - float(np.linalg.norm(d_p - d_obs) / np.linalg.norm(d_obs))))
+        out["python_host_run_to_run"] = sc          # the largest distance of three repeats from the first run
     cost_p = float(np.linalg.norm(d_p - d_obs) / np.linalg.norm(d_obs))
     cost_f = float(np.linalg.norm(d_f - d_obs) / np.linalg.norm(d_obs))
     out["final_data_cost"] = {"fortran_host": cost_f, "python_host": cost_p, "abs_difference": abs(cost_f - cost_p),
