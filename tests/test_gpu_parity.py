@@ -1448,11 +1448,11 @@ def test_overlapped_build_reads_batch_statistics_late_and_redoes_band_misses_out
     assert np.array_equal(ra["nnz_hist"], rb["nnz_hist"]) and abs(ra["error_sum"] - rb["error_sum"]) <= 1e-12 * abs(ra["error_sum"])
 
 
-@pytest.mark.parametrize("kind", ["normal", "lognormal", "ties", "quantised", "mostly_zero", "denormal", "constant", "lattice"])
+@pytest.mark.parametrize("kind", ["normal", "lognormal", "ties", "quantised", "mostly_zero", "denormal", "constant", "lattice", "binade", "two_runs"])
 def test_band_select_on_adversarial_rows(ctx, kind):
     """Single rows with awkward value distributions through tfx_compress_row, band select against the full select and against
     numpy's order statistic: heavy ties at the threshold, few distinct values, zeros, denormals, large values on index lattices
-    (what wavelet coefficients look like).  Whatever the band does (hit, overflow, miss -> fallback), the result is the same."""
+    (what wavelet coefficients look like), a threshold on a binade boundary, long runs of values one ulp apart.  Whatever the band does (hit, overflow, miss -> fallback), the result is the same."""
     rng = np.random.default_rng(sum(kind.encode()))
     N = 300007
     if kind == "normal":
@@ -1470,6 +1470,13 @@ def test_band_select_on_adversarial_rows(ctx, kind):
         row = rng.standard_normal(N) * 1e-312
     elif kind == "constant":
         row = np.full(N, -2.5)
+    elif kind == "binade":
+        row = rng.uniform(0.75, 1.125, N) * rng.choice([-1.0, 1.0], N)      # K = N // 3: the threshold sits at 1.0, the band straddles the binade boundary
+    elif kind == "two_runs":
+        row = rng.standard_normal(N)                                       # two long runs of equal values one ulp apart around the threshold:
+        m = rng.random(N)                                                  # the band select's first digit cannot separate them, the finishing
+        row[m < 0.25] = 0.5                                                # block walks a long candidate list digit by digit
+        row[(m >= 0.25) & (m < 0.5)] = -np.nextafter(0.5, 1.0)
     else:
         row = 1e-6 * rng.standard_normal(N)
         for step, amp in ((8, 1e-3), (64, 1.0), (512, 1e3)):
