@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_prism_gz(int64_t N, const double *__res
 // order (K outer, L, M inner), so the result is bit-identical to k_prism_gz.
 constexpr int PT_X = 32, PT_Y = 8, PT_Z = 8;
 constexpr int PT_NODES = (PT_X + 1) * (PT_Y + 1) * (PT_Z + 1);
-__global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz, const double *__restrict__ xe,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_prism_gz_tensor(int nx, int ny, int nz, const double *__restrict__ xe,
                                                          const double *__restrict__ ye, const double *__restrict__ ze,
                                                          int nobs, const double *__restrict__ xd,
                                                          const double *__restrict__ yd, const double *__restrict__ zd,
@@ -153,7 +153,6 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
     const int cx = min(PT_X, nx - i0), cy = min(PT_Y, ny - j0), cz = min(PT_Z, nz - k0);
     const int64_t N = (int64_t)nx * ny * nz;
     const int nnode = (cx + 1) * (cy + 1) * (cz + 1);
-    const int ncell = cx * cy * cz;
     for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
         const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
         s_node[n] = ((c * (PT_Y + 1) + b) * (PT_X + 1) + a) | (a << 12) | (b << 18) | (c << 22);
@@ -161,24 +160,15 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
     if (threadIdx.x <= cx) s_xe[threadIdx.x] = xe[i0 + threadIdx.x];
     if (threadIdx.x <= cy) s_ye[threadIdx.x] = ye[j0 + threadIdx.x];
     if (threadIdx.x <= cz) s_ze[threadIdx.x] = ze[k0 + threadIdx.x];
-    // cells of this thread: q = threadIdx.x + 256 j; LDS slot of the (0, 0, 0) node and the column, observation-independent
-    constexpr int CPT = PT_X * PT_Y * PT_Z / 256;
-    int c_slot[CPT];
-    int64_t c_col[CPT];
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-        const int q = threadIdx.x + 256 * j;
-        c_slot[j] = -1;
-        c_col[j] = 0;
-        if (q < ncell) {
-            const int a = q % cx, b = (q / cx) % cy, c = q / (cx * cy);
-            c_slot[j] = (c * (PT_Y + 1) + b) * (PT_X + 1) + a;
-            c_col[j] = ((int64_t)(k0 + c) * ny + (j0 + b)) * nx + (i0 + a);
-        }
-    }
-    double c_w[CPT];
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) c_w[j] = (cw && c_slot[j] >= 0) ? cw[c_col[j]] : 1.0;
+    // cells of this thread: the column (ta, tb) of the tile, one cell per z layer - the LDS slot of a cell's (0, 0, 0) node and its
+    // matrix column are affine in the layer, so nothing per cell stays in registers over the observation loop (the kernel's
+    // occupancy is set by its VGPRs: 4 waves per SIMD at <= 128)
+    static_assert(PT_X * PT_Y == 256, "one thread per (x, y) column of the tile");
+    constexpr int LAYER = (PT_Y + 1) * (PT_X + 1);
+    const int ta = threadIdx.x % PT_X, tb = threadIdx.x / PT_X;
+    const bool col_ok = ta < cx && tb < cy;
+    const int slot0 = tb * (PT_X + 1) + ta;
+    const int64_t col0 = ((int64_t)k0 * ny + (j0 + tb)) * nx + (i0 + ta), lay = (int64_t)ny * nx;
     for (int o = 0; o < nobs; ++o) {
         const double xo = xd[o], yo = yd[o], zo = zd[o];
         __syncthreads();
@@ -189,24 +179,29 @@ __global__ __launch_bounds__(256) void k_prism_gz_tensor(int nx, int ny, int nz,
         __syncthreads();
         double sq = 0.0;
         double *out = rows + (int64_t)o * N;
+        const double *cwo = cw;
+        asm volatile("" : "+s"(cwo));       // the weights are re-read per observation (L2 hits) instead of held in 16 VGPRs over the node loop
+        if (col_ok) {
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            if (c_slot[j] < 0) continue;
-            const double *t0 = T + c_slot[j];
-            double gz = 0.0;
+            for (int j = 0; j < PT_Z; ++j) {
+                if (j >= cz) break;
+                const double *t0 = T + slot0 + j * LAYER;
+                double gz = 0.0;
 #pragma unroll
-            for (int K = 0; K < 2; ++K)
+                for (int K = 0; K < 2; ++K)
 #pragma unroll
-                for (int L = 0; L < 2; ++L)
+                    for (int L = 0; L < 2; ++L)
 #pragma unroll
-                    for (int M = 0; M < 2; ++M) {
-                        const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;
-                        gz = gz + dmu * t0[(M * (PT_Y + 1) + L) * (PT_X + 1) + K];
-                    }
-            double v = g_grav() * gz;
-            if (cw) v = v * c_w[j];
-            __builtin_nontemporal_store(v, &out[c_col[j]]);       // 2 GB per batch: the next reader (wavelet x pass) finds nothing in L2 anyway
-            sq = fma(v, v, sq);
+                        for (int M = 0; M < 2; ++M) {
+                            const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;
+                            gz = gz + dmu * t0[(M * (PT_Y + 1) + L) * (PT_X + 1) + K];
+                        }
+                double v = g_grav() * gz;
+                const int64_t col = col0 + j * lay;
+                if (cw) v = v * cwo[col];
+                __builtin_nontemporal_store(v, &out[col]);       // 2 GB per batch: the next reader (wavelet x pass) finds nothing in L2 anyway
+                sq = fma(v, v, sq);
+            }
         }
         if (sumsq) {                                        // cost_full (sensitivity_gravmag.F90:234), fixed order
 #pragma unroll
