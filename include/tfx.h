@@ -317,6 +317,8 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * the wavelet / threshold / compaction kernels (HBM-bound) of the main stream and reads each batch's statistics one batch late
  * (three row buffers); 0 = one stream, one row buffer; 1 = overlapped when the kernel has at least 8 batches of rows; 2 = overlapped
  * always (what the tests use to drive the deferred-statistics path on small kernels) - the three give the same bits;
+ * key "chain_under_wavelet" (0/1, default 1): overlapped build - the threshold / compaction chain of a batch runs on a third stream
+ * beside the wavelet passes of the next batch (the generator leaves no registers for it); 0 = on the main stream; same bits;
  * key "chunk_exponent_span" (value): diagnostics - per mille of the stored 512-entry chunks whose non-zero values span at most
  * `value` binades (prints the histogram on stderr);
  * key "force_collectives" (0/1): issue the collectives of the multi-rank path even with one rank - with a world-size-1

@@ -28,6 +28,7 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     if (const char *e = getenv("TFX_DETERMINISTIC")) c->deterministic = atoi(e) != 0;     // like tfx_debug_set "deterministic"
     if (const char *e = getenv("TFX_ADJ_COPY")) c->adj_copy = std::max(0, std::min(2, atoi(e)));   // like tfx_debug_set "adj_copy"
     if (const char *e = getenv("TFX_ADJ_COPY_MIN_NNZ")) c->adj_copy_min_nnz = atoll(e);
+    if (const char *e = getenv("TFX_CHAIN_UNDER_WAVELET")) c->chain_under_wavelet = atoi(e) != 0;
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("TFX_GEN_WGS_PER_CU")) c->gen_wgs_per_cu = atoi(e);
     if (const char *e = getenv("TFX_GEN_AFTER_WAVELET")) c->gen_after_wavelet = std::max(0, std::min(3, atoi(e)));
@@ -185,6 +186,10 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
     }
     if (!strcmp(key, "gen_wgs_per_cu")) {
         ctx->gen_wgs_per_cu = value;
+        return 0;
+    }
+    if (!strcmp(key, "chain_under_wavelet")) {
+        ctx->chain_under_wavelet = value != 0;
         return 0;
     }
     if (!strcmp(key, "build_overlap")) {        // 0 one stream; 1 overlapped for builds of at least 8 batches; 2 always overlapped

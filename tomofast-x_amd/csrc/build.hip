@@ -2994,6 +2994,33 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         TFX_HIP(hipEventRecord(gs.ev0, s));                 // the uploads of the observations / weights queued above
         TFX_HIP(hipStreamWaitEvent(gs.st, gs.ev0, 0));
     }
+    // Third stream: the generator holds every VGPR of the SIMDs it runs on, so nothing runs beside it; the wavelet passes leave
+    // registers, wave slots and 21 KB of LDS per CU free.  The threshold / compaction chain of batch b (one read of the rows, then
+    // latency-bound work on the few candidates) therefore waits for the generator of batch b + 1 and runs beside the wavelet passes
+    // of batch b + 1: per batch the device does generator, then (wavelet || chain).  Ordering between the streams: the chain waits
+    // for its batch's wavelet event (recorded on the main stream, i.e. behind every earlier append of staged rows as well) and for
+    // the next generator's event; the main stream meets the chain only through the host (confirm waits for the statistics event).
+    struct ChainStream {
+        hipStream_t st = nullptr;
+        hipEvent_t evw[3] = {nullptr, nullptr, nullptr};
+        ~ChainStream()
+        {
+            if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+            for (hipEvent_t e : evw) if (e) (void)hipEventDestroy(e);
+        }
+    } chs;
+    const bool chain_late = overlap && compression_type > 0 && ctx->chain_under_wavelet;
+    if (chain_late) {
+        TFX_HIP(hipStreamCreateWithFlags(&chs.st, hipStreamNonBlocking));
+        for (int i = 0; i < 3; ++i) TFX_HIP(hipEventCreateWithFlags(&chs.evw[i], hipEventDisableTiming));
+    }
+    hipStream_t const chain_s = chain_late ? chs.st : s;
+    struct StreamSwap {           // the compaction helpers launch on ctx->stream
+        tfx_ctx *c;
+        hipStream_t keep;
+        StreamSwap(tfx_ctx *c_, hipStream_t t) : c(c_), keep(c_->stream) { c->stream = t; }
+        ~StreamSwap() { c->stream = keep; }
+    };
     // observations of the batch that starts at g_ with fill_ rows staged: just enough to complete the current row block (so that
     // with one data component blocks never straddle)
     auto batch_obs = [&](int64_t g_, int fill_) -> int {
@@ -3025,6 +3052,7 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     // threshold (full select when asked, else already known / bracketed by the band) + compaction + the statistics copy of a batch
     auto compact_batch = [&](const Pending &b, bool full_select) -> int {
         double *const rows = rows_buf[b.slot];
+        StreamSwap on_chain(ctx, chain_s);
         if (full_select) TFX_TRY(select_threshold_dev(ctx, sw, rows, b.nl, N, K, cw.thr.p));              // :240-256
         SelectWork *sel = (b.banded && !full_select) ? &sw : nullptr;
         if (to_rs)
@@ -3037,10 +3065,10 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
                                 keep_matrix ? ell_vals.p + (size_t)b.fill_at * stride : nullptr, stride, ell_nel.p + b.fill_at,
                                 dscale.p + b.g * nsub, nnz_hist_out ? dhist.p : nullptr, ncm, sel, K));
         // per-line statistics
-        hipLaunchKernelGGL(k_pack_stats, dim3((b.nl + 63) / 64), dim3(64), 0, s, b.nl, compression_type > 0 ? dcf.p + (size_t)b.hs * lines_max : nullptr,
+        hipLaunchKernelGGL(k_pack_stats, dim3((b.nl + 63) / 64), dim3(64), 0, chain_s, b.nl, compression_type > 0 ? dcf.p + (size_t)b.hs * lines_max : nullptr,
                            cw.cost_disc.p, cw.nel_all.p, cw.nel.p, cw.fail.p, dstat.p);
-        TFX_HIP(hipMemcpyAsync(h_stat2[b.hs], dstat.p, (size_t)(b.nl + 1) * sizeof(BatchStat), hipMemcpyDeviceToHost, s));
-        TFX_HIP(hipEventRecord(se.ev[b.hs], s));
+        TFX_HIP(hipMemcpyAsync(h_stat2[b.hs], dstat.p, (size_t)(b.nl + 1) * sizeof(BatchStat), hipMemcpyDeviceToHost, chain_s));
+        TFX_HIP(hipEventRecord(se.ev[b.hs], chain_s));
         return 0;
     };
     // reads a batch's statistics (waits for them); a band that missed redoes the batch from its transformed rows with the full
@@ -3118,6 +3146,11 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
             TFX_TRY(wavelet_dev(ctx, rows_cur, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1, 0, gen_at));       // :237
             if (gen_at > 0) TFX_TRY(queue_next());
             TFX_TRY(wavelet_dev(ctx, rows_cur, ctx->nx, ctx->ny, ctx->nz, nl, compression_type, 1, gen_at, 3));
+        }
+        if (chain_late) {
+            TFX_HIP(hipEventRecord(chs.evw[slot], s));
+            TFX_HIP(hipStreamWaitEvent(chs.st, chs.evw[slot], 0));
+            if (nb_cur > 0) TFX_HIP(hipStreamWaitEvent(chs.st, gs.ev[slot_next], 0));
         }
         TFX_TRY(compact_batch(cur, compression_type > 0 && !cur.banded));
         // the previous batch ran while this one was being queued: its statistics are there (or nearly)

@@ -228,6 +228,7 @@ struct tfx_ctx {
     int gen_after_wavelet = 3;        // debug key: the overlapped generator of the next batch starts behind this many axis passes of the current batch's wavelet transform (0: at the batch start, 3: behind all of them)
     int gen_wgs_per_cu = 0;           // debug key "gen_wgs_per_cu": resident generator workgroups per CU in overlap mode (0: one per tile)
     int gen_grid_limit = 0;           // (set around the generator launches of the overlapped build)
+    int chain_under_wavelet = 1;      // debug key "chain_under_wavelet": overlapped build - the threshold / compaction chain of batch b runs on a third stream beside the wavelet passes of batch b + 1
     int build_overlap = 1;            // debug key "build_overlap": row generator on its own stream, one batch ahead of the wavelet / compaction
     int items_per_cu = 16;            // debug key "items_per_cu": work items per CU the tile list is cut into
     // Adjoint on a transposed copy of the tiles: 0 never (default), 1 always, 2 automatic = for matrices of at least adj_copy_min_nnz
