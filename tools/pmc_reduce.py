@@ -10,7 +10,9 @@ import sys
 
 def per_kernel(folder, counter):
     out = {}
-    for f in glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
+    # gpurun merges every call's files into gpurun_out/: only the newest pass counts (dispatch ids repeat from run to run)
+    files = glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True)
+    for f in sorted(files, key=os.path.getmtime)[-1:]:
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
                 continue
@@ -49,6 +51,12 @@ def main(src, dst, rnd):
                              "WRITE_SIZE_raw_KiB_avg": write.get(k, (0.0, 0))[0], "WRITE_SIZE_launches": write.get(k, (0.0, 0))[1],
                              "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr,
                              "fetch_over_device_bytes": (rd / res["device_bytes_of_the_matrix"]) if res.get("device_bytes_of_the_matrix") else None}
+    # every stored byte of the matrix is read exactly once per launch: a reduction that is not within a few per cent of that is a
+    # bookkeeping error (e.g. passes of several runs summed), not traffic - do not write it where bench.py would pick it up
+    for k, v in res["kernels"].items():
+        r = v["fetch_over_device_bytes"]
+        if r is not None and not 0.9 < r < 1.2:
+            raise SystemExit("pmc_reduce: %s reads %.3f x the device bytes of the matrix - not written" % (k, r))
     json.dump(res, open(dst, "w"), indent=1)
     print(json.dumps(res["kernels"], indent=1))
 
