@@ -1434,18 +1434,22 @@ def test_overlapped_build_reads_batch_statistics_late_and_redoes_band_misses_out
     out = []
     try:
         ctx.debug_set("band_select_min_cells", 0)
-        for mode in (0, 2):
+        # one stream / three streams (the chain of a batch beside the wavelet passes of the next) / two streams (chain on the main stream)
+        for mode, chain_late in ((0, 1), (2, 1), (2, 0)):
             ctx.debug_set("build_overlap", mode)
+            ctx.debug_set("chain_under_wavelet", chain_late)
             b0, f0 = ctx.debug_set("band_batches"), ctx.debug_set("band_fallbacks")
             res = ctx.calculate_sensit(xs, ys, zs, cw, 1, 0.5 if expect_fallback else 0.05, want_hist=True)   # (Haar r = 0.5 on 1/257 of the cells: the kept count exceeds the non-zeros)
             out.append((res, ctx.matrix_download_csr(), ctx.debug_set("band_batches") - b0, ctx.debug_set("band_fallbacks") - f0))
     finally:
         ctx.debug_set("band_select_min_cells", 1 << 20)
         ctx.debug_set("build_overlap", 1)
-    (ra, A, used_a, fell_a), (rb, B, used_b, fell_b) = out
-    assert used_a == used_b >= 5 and fell_a == fell_b and (fell_b > 0) == expect_fallback
-    assert ra["nnz"] == rb["nnz"] and np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and bits_equal(A[2], B[2])
-    assert np.array_equal(ra["nnz_hist"], rb["nnz_hist"]) and abs(ra["error_sum"] - rb["error_sum"]) <= 1e-12 * abs(ra["error_sum"])
+        ctx.debug_set("chain_under_wavelet", 1)
+    ra, A, used_a, fell_a = out[0]
+    for rb, B, used_b, fell_b in out[1:]:
+        assert used_a == used_b >= 5 and fell_a == fell_b and (fell_b > 0) == expect_fallback
+        assert ra["nnz"] == rb["nnz"] and np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and bits_equal(A[2], B[2])
+        assert np.array_equal(ra["nnz_hist"], rb["nnz_hist"]) and abs(ra["error_sum"] - rb["error_sum"]) <= 1e-12 * abs(ra["error_sum"])
 
 
 @pytest.mark.parametrize("kind", ["normal", "lognormal", "ties", "quantised", "mostly_zero", "denormal", "constant", "lattice", "binade", "two_runs"])
