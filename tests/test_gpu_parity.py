@@ -1503,8 +1503,9 @@ def test_band_select_on_adversarial_rows(ctx, kind):
 
 FULL_SIZE = {
     # BASELINE.json configs[4] (the configuration the metric is quoted on), configs[2] and configs[1] at their full sizes
-    "config5_hamersley_d4": dict(nx=256, ny=256, nz=152, ox=316, oy=316, ctype=2, rate=0.02, rows=(0, 50123, -1)),
-    "config3_haar_512": dict(nx=512, ny=512, nz=128, ox=256, oy=256, ctype=1, rate=0.01, rows=(0, 33001, -1)),
+    # rows checked against the oracle: corners, centre and interior rows of the observation lattice, first / last rows of row blocks
+    "config5_hamersley_d4": dict(nx=256, ny=256, nz=152, ox=316, oy=316, ctype=2, rate=0.02, rows=(0, 2047, 2048, 31337, 50123, 77777, -1)),
+    "config3_haar_512": dict(nx=512, ny=512, nz=128, ox=256, oy=256, ctype=1, rate=0.01, rows=(0, 4095, 33001, 49999, -1)),
     "config2_dense_256": dict(nx=256, ny=256, nz=64, ox=64, oy=64, ctype=0, rate=1.0, rows=(0, 2077, -1)),
 }
 
