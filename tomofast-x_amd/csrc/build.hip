@@ -2951,10 +2951,11 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     int64_t r0 = 0;               // first matrix row of the staging area
     bool band_off = false;
     const int64_t batches0 = ctx->band_batches, fallbacks0 = ctx->band_fallbacks;
-    // Two streams: the row generator is VALU-bound (fp64 log / atan2 / sqrt per grid node), everything after it - wavelet passes,
-    // threshold, compaction, tile scatter - is HBM-bound.  The generator of batch b + 1 runs on its own (low-priority) stream into
-    // the second row buffer while the main stream transforms and compacts batch b: their waves share the CUs, one kind waiting on
-    // memory while the other computes.  (ctx->build_overlap = 0: one stream, one buffer - the sequential order of round 1.)
+    // Overlapped build: the row generator is VALU-bound (fp64 log / atan2 / sqrt per grid node), everything after it - wavelet
+    // passes, threshold, compaction, tile scatter - is HBM-bound.  The generator of batch b + 1 runs on its own (low-priority) stream
+    // into the next row buffer, queued behind the wavelet passes of batch b (the two exclude each other through the LDS); the
+    // threshold / compaction chain of batch b runs on a third stream beside the wavelet passes of batch b + 1 (below).
+    // (ctx->build_overlap = 0: one stream, one buffer - the sequential order of round 1.)
     // (short builds: the extra buffers and the stream cost more than they hide; build_overlap = 2 forces the overlapped form: tests)
     const bool overlap = ctx->build_overlap == 2 || (ctx->build_overlap && ndata >= 8 * (int64_t)ob_max);
     // Three row buffers in overlap mode: batch b + 1 is generated while batch b is transformed, and batch b - 1's transformed rows stay
