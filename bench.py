@@ -474,6 +474,13 @@ def cpu_baseline_reference(tfx, nnz_headline, pairs_headline, log, nx=64, ny=64,
             diff = t1_ - base
             legs[rk] = {"reload_and_1_iteration_s": base, "reload_and_1_iteration_repeat_spread_s": noise, "reload_and_101_iterations_s": t1_,
                         "ms_per_lsqr_iteration": 1e3 * max(diff, 1e-9) / 100.0, "resolved": bool(diff > 3.0 * noise and diff > 0.02 * base)}
+            if not legs[rk]["resolved"] and base < 6.0:
+                # a noisy host (the box is shared): four times the iterations on the leg that is cheap to repeat, instead of falling
+                # back to a leg that is ten times slower per iteration
+                t4_, _ = run(rk, 401, 1)
+                diff4 = t4_ - base
+                legs[rk].update({"reload_and_401_iterations_s": t4_, "ms_per_lsqr_iteration": 1e3 * max(diff4, 1e-9) / 400.0,
+                                 "resolved": bool(diff4 > 3.0 * noise and diff4 > 0.02 * base)})
         usable = [rk for rk in legs if legs[rk]["resolved"]] or list(legs)
         best = min(usable, key=lambda rk: legs[rk]["ms_per_lsqr_iteration"])
         t_iter = legs[best]["ms_per_lsqr_iteration"] * 1e-3
@@ -482,7 +489,7 @@ def cpu_baseline_reference(tfx, nnz_headline, pairs_headline, log, nx=64, ny=64,
                "build_cores": build_ranks, "host_cores": cores, "kind": "reference",
                "sample": "oracle/_ref/tomofastx (the compiled reference) under mpiexec on %dx%dx%d cells x %d data, Haar r = %g "
                          "(box: %d host cores): kernel build on %d ranks %.3e cell.obs/s; LSQR %.2f ms per iteration at nnz = %d on "
-                         "%d ranks (the faster of the legs at %s ranks whose 100-iteration difference clears the run-to-run spread - the "
+                         "%d ranks (the faster of the legs at %s ranks whose 100- (or 400-) iteration difference clears the run-to-run spread - the "
                          "reference's per-iteration MPI_Allreduce of all rows does not scale further); `value` is the LINEAR EXTRAPOLATION in nnz of that iteration time to the headline matrix "
                          "(the reference cannot hold / finish that size on a host)" %
                          (nx, ny, nz, nd, rate, cores, build_ranks, N * nd / t_build, 1e3 * t_iter, nnz, best, lsqr_rank_counts),
