@@ -374,8 +374,8 @@ __global__ __launch_bounds__(256) void k_magprism(int64_t N, const double *__res
 // Tensor-product grid: of the 24 atan2 + 12 log + 24 sqrt of a cell's tensor, the two atan2 families and the three distances
 // (one per summation order of the squares, so that the bits are sharmbox's) depend on one NODE only.  A workgroup evaluates them
 // once for the (MT_X+1)(MT_Y+1)(MT_Z+1) nodes of its tile into LDS (1.3 nodes per cell: 2.7 atan2 + 4 sqrt per cell instead of
-// 24 + 24); the 12 logs of corner-pair ratios stay per cell.  Same operations in the same order as sharmbox_dev -> same bits as
-// k_magprism.  A cell that contains the observation takes the general path (6 sub-boxes).
+// 24 + 24); the 12 logs of corner-pair ratios belong to the EDGES of the node lattice (3.7 per cell, evaluated in a second phase).
+// Same operations in the same order as sharmbox_dev -> same bits as k_magprism.  A cell that contains the observation takes the general path (6 sub-boxes).
 constexpr int MT_X = 16, MT_Y = 8, MT_Z = 8;
 constexpr int MT_NODES = (MT_X + 1) * (MT_Y + 1) * (MT_Z + 1);
 template <int NCM, int NCD>
@@ -427,6 +427,44 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
             TAy[id] = datan2(rx * rz, (ry * az + eps));           // the terms of ty(2), :392-399
         }
         __syncthreads();
+        // edge phase: the 12 logs of a cell's tensor are logs of corner-pair ratios along one axis - each belongs to an EDGE of the
+        // node lattice and is shared by the (up to) 4 cells around that edge.  Evaluated once per edge (3.7 logs + divisions per
+        // cell instead of 12), in place: the edge that starts at a node replaces the node's distance (all reads, barrier, writes).
+        {
+            constexpr int NPT = (MT_NODES + 255) / 256, DY = MT_X + 1, DZ = (MT_Y + 1) * (MT_X + 1);
+            double ez[NPT], ex[NPT], ey[NPT];
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                const int n = threadIdx.x + 256 * k;
+                ez[k] = ex[k] = ey[k] = 0.0;
+                if (n < nnode) {
+                    const int code = s_node[n];
+                    const int id = code & 4095, a = (code >> 12) & 63, b = (code >> 18) & 15, c = code >> 22;
+                    if (c < cz) {                                             // ty(1): (rz2 + a(k = 2)) / (rz1 + a(k = 1)), :386-389
+                        const double rz1 = s_ze[c] - zo + eps, rz2 = s_ze[c + 1] - zo + eps;
+                        ez[k] = dlog((rz2 + Taz[id + DZ] + eps) / (rz1 + Taz[id] + eps));
+                    }
+                    if (a < cx) {                                             // ty(3): (rx1 + a(i = 1)) / (rx2 + a(i = 2)), :419-422
+                        const double rx1 = s_xe[a] - xo + eps, rx2 = s_xe[a + 1] - xo + eps;
+                        ex[k] = dlog((rx1 + Tax[id] + eps) / (rx2 + Tax[id + 1] + eps));
+                    }
+                    if (b < cy) {                                             // tx(3): (ry1 + a(j = 1)) / (ry2 + a(j = 2)), :439-442
+                        const double ry1 = s_ye[b] - yo + eps, ry2 = s_ye[b + 1] - yo + eps;
+                        ey[k] = dlog((ry1 + Tay[id] + eps) / (ry2 + Tay[id + DY] + eps));
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                const int n = threadIdx.x + 256 * k;
+                if (n < nnode) {
+                    const int id = s_node[n] & 4095;
+                    Taz[id] = ez[k]; Tax[id] = ex[k]; Tay[id] = ey[k];
+                }
+            }
+        }
+        __syncthreads();
         double sq[NSUB];
 #pragma unroll
         for (int i = 0; i < NSUB; ++i) sq[i] = 0.0;
@@ -439,27 +477,17 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
                 mag_cell_tensor(x1, x2, y1, y2, z1, z2, xo, yo, zo, tx, ty, tz, bad);      // observation inside this cell
             } else {
                 const double rx1 = x1 - xo + eps, rx2 = x2 - xo + eps, ry1 = y1 - yo + eps, ry2 = y2 - yo + eps;
-                const double rz1 = z1 - zo + eps, rz2 = z2 - zo + eps;
                 if (rx1 == 0. || rx2 == 0.) bad |= 4;
                 if (ry1 == 0. || ry2 == 0.) bad |= 8;
-                // corner (i, j, k), i / j / k in {1, 2}: node (a + i - 1, b + j - 1, c + k - 1)
+                // corner (i, j, k), i / j / k in {1, 2}: node (a + i - 1, b + j - 1, c + k - 1); an edge sits at its lower node
 #define C_(T, i, j, k) T[NODE(a + (i) - 1, b + (j) - 1, c + (k) - 1)]
                 tx[0] = C_(TAx, 2, 1, 2) - C_(TAx, 2, 2, 2) + C_(TAx, 2, 2, 1) - C_(TAx, 2, 1, 1) + C_(TAx, 1, 2, 2) - C_(TAx, 1, 1, 2) +
                         C_(TAx, 1, 1, 1) - C_(TAx, 1, 2, 1);                                                                  // :376-383
-                ty[0] = dlog((rz2 + C_(Taz, 2, 2, 2) + eps) / (rz1 + C_(Taz, 2, 2, 1) + eps)) -
-                        dlog((rz2 + C_(Taz, 1, 2, 2) + eps) / (rz1 + C_(Taz, 1, 2, 1) + eps)) +
-                        dlog((rz2 + C_(Taz, 1, 1, 2) + eps) / (rz1 + C_(Taz, 1, 1, 1) + eps)) -
-                        dlog((rz2 + C_(Taz, 2, 1, 2) + eps) / (rz1 + C_(Taz, 2, 1, 1) + eps));                                 // :386-389
+                ty[0] = C_(Taz, 2, 2, 1) - C_(Taz, 1, 2, 1) + C_(Taz, 1, 1, 1) - C_(Taz, 2, 1, 1);                                // z edges, :386-389
                 ty[1] = C_(TAy, 1, 2, 2) - C_(TAy, 2, 2, 2) + C_(TAy, 2, 2, 1) - C_(TAy, 1, 2, 1) + C_(TAy, 2, 1, 2) - C_(TAy, 1, 1, 2) +
                         C_(TAy, 1, 1, 1) - C_(TAy, 2, 1, 1);                                                                  // :392-399
-                ty[2] = dlog((rx1 + C_(Tax, 1, 2, 1) + eps) / (rx2 + C_(Tax, 2, 2, 1) + eps)) -
-                        dlog((rx1 + C_(Tax, 1, 2, 2) + eps) / (rx2 + C_(Tax, 2, 2, 2) + eps)) +
-                        dlog((rx1 + C_(Tax, 1, 1, 2) + eps) / (rx2 + C_(Tax, 2, 1, 2) + eps)) -
-                        dlog((rx1 + C_(Tax, 1, 1, 1) + eps) / (rx2 + C_(Tax, 2, 1, 1) + eps));                                 // :419-422
-                tx[2] = dlog((ry1 + C_(Tay, 2, 1, 1) + eps) / (ry2 + C_(Tay, 2, 2, 1) + eps)) -
-                        dlog((ry1 + C_(Tay, 2, 1, 2) + eps) / (ry2 + C_(Tay, 2, 2, 2) + eps)) +
-                        dlog((ry1 + C_(Tay, 1, 1, 2) + eps) / (ry2 + C_(Tay, 1, 2, 2) + eps)) -
-                        dlog((ry1 + C_(Tay, 1, 1, 1) + eps) / (ry2 + C_(Tay, 1, 2, 1) + eps));                                 // :439-442
+                ty[2] = C_(Tax, 1, 2, 1) - C_(Tax, 1, 2, 2) + C_(Tax, 1, 1, 2) - C_(Tax, 1, 1, 1);                                // x edges, :419-422
+                tx[2] = C_(Tay, 2, 1, 1) - C_(Tay, 2, 1, 2) + C_(Tay, 1, 1, 2) - C_(Tay, 1, 1, 1);                                // y edges, :439-442
 #undef C_
                 tz[2] = -1 * (tx[0] + ty[1]);                                                                                 // :446
                 tz[1] = ty[2];
