@@ -373,20 +373,23 @@ __global__ __launch_bounds__(256) void k_magprism(int64_t N, const double *__res
 
 // Tensor-product grid: of the 24 atan2 + 12 log + 24 sqrt of a cell's tensor, the two atan2 families and the three distances
 // (one per summation order of the squares, so that the bits are sharmbox's) depend on one NODE only.  A workgroup evaluates them
-// once for the (MT_X+1)(MT_Y+1)(MT_Z+1) nodes of its tile into LDS (1.3 nodes per cell: 2.7 atan2 + 4 sqrt per cell instead of
+// once for the (MT_X+1)(MT_Y+1)(MT_Z+1) nodes of its tile into LDS (1.4 nodes per cell: 2.8 atan2 + 4 sqrt per cell instead of
 // 24 + 24); the 12 logs of corner-pair ratios belong to the EDGES of the node lattice (3.7 per cell, evaluated in a second phase).
-// Same operations in the same order as sharmbox_dev -> same bits as k_magprism.  A cell that contains the observation takes the general path (6 sub-boxes).
-constexpr int MT_X = 16, MT_Y = 8, MT_Z = 8;
+// Same operations in the same order as sharmbox_dev -> same bits as k_magprism.  The one cell per observation that may CONTAIN
+// the observation (6 sub-boxes, a different and register-hungry code path) is left at zero here and written by
+// k_magprism_inside_fix afterwards: without it the kernel needs 141 VGPRs instead of 240, and with a tile of 16 x 8 x 6 cells
+// (43 KB of node arrays, a thread owning one (x, y) column of the tile) three workgroups fit a CU.
+constexpr int MT_X = 16, MT_Y = 8, MT_Z = 6;
 constexpr int MT_NODES = (MT_X + 1) * (MT_Y + 1) * (MT_Z + 1);
 template <int NCM, int NCD>
-__global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz, const double *__restrict__ xe,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_magprism_tensor(int nx, int ny, int nz, const double *__restrict__ xe,
                                                          const double *__restrict__ ye, const double *__restrict__ ze, int nobs,
                                                          const double *__restrict__ xd, const double *__restrict__ yd,
                                                          const double *__restrict__ zd, const double *__restrict__ cw, MagField mf,
                                                          double *__restrict__ rows, int *__restrict__ err, double *__restrict__ sumsq)
 {
     constexpr int NSUB = NCM * NCD;
-    __shared__ double Taz[MT_NODES], Tax[MT_NODES], Tay[MT_NODES], TAx[MT_NODES], TAy[MT_NODES];      // 5 x 1377 doubles = 55 KB
+    __shared__ double Taz[MT_NODES], Tax[MT_NODES], Tay[MT_NODES], TAx[MT_NODES], TAy[MT_NODES];      // 5 x 1071 doubles = 43 KB
     __shared__ double s_w[4];
     init_math_tables();                                   // (+ 4 KB; the first __syncthreads() of the observation loop publishes them)
     const double eps = 0.;
@@ -396,12 +399,13 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
     const int cx = min(MT_X, nx - i0), cy = min(MT_Y, ny - j0), cz = min(MT_Z, nz - k0);
     const int64_t N = (int64_t)nx * ny * nz;
     const int nnode = (cx + 1) * (cy + 1) * (cz + 1);
-    const int ncell = cx * cy * cz;
     int bad = 0;
 #define NODE(a, b, c) (((c) * (MT_Y + 1) + (b)) * (MT_X + 1) + (a))
-    // observation-independent index arithmetic, once per workgroup (as in k_prism_gz_tensor)
+    // observation-independent index arithmetic, once per workgroup: the node codes (LDS slot | a << 12 | b << 18 | c << 22) in LDS,
+    // the cells of a thread are the column (ta, tb) of the tile in the layers tc0, tc0 + 2, ...
     __shared__ double s_xe[MT_X + 1], s_ye[MT_Y + 1], s_ze[MT_Z + 1];
-    __shared__ int s_node[MT_NODES];                      // LDS slot | a << 12 | b << 18 | c << 22
+    constexpr int NPT = (MT_NODES + 255) / 256, DY = MT_X + 1, DZ = (MT_Y + 1) * (MT_X + 1);
+    __shared__ int s_node[MT_NODES];
     for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
         const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
         s_node[n] = NODE(a, b, c) | (a << 12) | (b << 18) | (c << 22);
@@ -409,8 +413,10 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
     if (threadIdx.x <= cx) s_xe[threadIdx.x] = xe[i0 + threadIdx.x];
     if (threadIdx.x <= cy) s_ye[threadIdx.x] = ye[j0 + threadIdx.x];
     if (threadIdx.x <= cz) s_ze[threadIdx.x] = ze[k0 + threadIdx.x];
-    __shared__ int s_cell[MT_X * MT_Y * MT_Z];            // a | b << 8 | c << 16 of cell q
-    for (int q = threadIdx.x; q < ncell; q += blockDim.x) s_cell[q] = (q % cx) | (((q / cx) % cy) << 8) | ((q / (cx * cy)) << 16);
+    static_assert(MT_X * MT_Y * 2 == 256 && MT_Z % 2 == 0, "two (x, y) planes of threads walk the layers of the tile");
+    constexpr int CPT = MT_Z / 2;
+    const int ta = threadIdx.x % MT_X, tb = (threadIdx.x / MT_X) % MT_Y, tc0 = threadIdx.x / (MT_X * MT_Y);
+    const bool col_ok = ta < cx && tb < cy;
     for (int o = 0; o < nobs; ++o) {
         const double xo = xd[o], yo = yd[o], zo = zd[o];
         __syncthreads();
@@ -431,14 +437,13 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
         // node lattice and is shared by the (up to) 4 cells around that edge.  Evaluated once per edge (3.7 logs + divisions per
         // cell instead of 12), in place: the edge that starts at a node replaces the node's distance (all reads, barrier, writes).
         {
-            constexpr int NPT = (MT_NODES + 255) / 256, DY = MT_X + 1, DZ = (MT_Y + 1) * (MT_X + 1);
             double ez[NPT], ex[NPT], ey[NPT];
 #pragma unroll
             for (int k = 0; k < NPT; ++k) {
                 const int n = threadIdx.x + 256 * k;
+                const int code = n < nnode ? s_node[n] : -1;
                 ez[k] = ex[k] = ey[k] = 0.0;
-                if (n < nnode) {
-                    const int code = s_node[n];
+                if (code >= 0) {
                     const int id = code & 4095, a = (code >> 12) & 63, b = (code >> 18) & 15, c = code >> 22;
                     if (c < cz) {                                             // ty(1): (rz2 + a(k = 2)) / (rz1 + a(k = 1)), :386-389
                         const double rz1 = s_ze[c] - zo + eps, rz2 = s_ze[c + 1] - zo + eps;
@@ -453,6 +458,7 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
                         ey[k] = dlog((ry1 + Tay[id] + eps) / (ry2 + Tay[id + DY] + eps));
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);          // one node's three logs at a time: interleaved, the five iterations cost 100 VGPRs more
             }
             __syncthreads();
 #pragma unroll
@@ -468,17 +474,23 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
         double sq[NSUB];
 #pragma unroll
         for (int i = 0; i < NSUB; ++i) sq[i] = 0.0;
-        for (int q = threadIdx.x; q < ncell; q += blockDim.x) {
-            const int ccode = s_cell[q];
-            const int a = ccode & 255, b = (ccode >> 8) & 255, c = ccode >> 16;
-            const double x1 = s_xe[a], x2 = s_xe[a + 1], y1 = s_ye[b], y2 = s_ye[b + 1], z1 = s_ze[c], z2 = s_ze[c + 1];
-            double tx[3], ty[3], tz[3];
-            if (x1 < xo && x2 > xo && y1 < yo && y2 > yo && z1 < zo && z2 > zo) {
-                mag_cell_tensor(x1, x2, y1, y2, z1, z2, xo, yo, zo, tx, ty, tz, bad);      // observation inside this cell
-            } else {
-                const double rx1 = x1 - xo + eps, rx2 = x2 - xo + eps, ry1 = y1 - yo + eps, ry2 = y2 - yo + eps;
-                if (rx1 == 0. || rx2 == 0.) bad |= 4;
-                if (ry1 == 0. || ry2 == 0.) bad |= 8;
+        const double *cwo = cw;
+        asm volatile("" : "+s"(cwo));                 // the weights are re-read per observation, not held over the node / edge phases
+        if (col_ok) {
+            const int a = ta, b = tb;
+            const double x1 = s_xe[a], x2 = s_xe[a + 1], y1 = s_ye[b], y2 = s_ye[b + 1];
+            const double rx1 = x1 - xo + eps, rx2 = x2 - xo + eps, ry1 = y1 - yo + eps, ry2 = y2 - yo + eps;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int c = tc0 + 2 * j;
+                if (c >= cz) break;
+                const double z1 = s_ze[c], z2 = s_ze[c + 1];
+                double tx[3], ty[3], tz[3];
+                const bool inside = x1 < xo && x2 > xo && y1 < yo && y2 > yo && z1 < zo && z2 > zo;       // :139-141: k_magprism_inside_fix writes this cell
+                if (!inside) {
+                    if (rx1 == 0. || rx2 == 0.) bad |= 4;
+                    if (ry1 == 0. || ry2 == 0.) bad |= 8;
+                }
                 // corner (i, j, k), i / j / k in {1, 2}: node (a + i - 1, b + j - 1, c + k - 1); an edge sits at its lower node
 #define C_(T, i, j, k) T[NODE(a + (i) - 1, b + (j) - 1, c + (k) - 1)]
                 tx[0] = C_(TAx, 2, 1, 2) - C_(TAx, 2, 2, 2) + C_(TAx, 2, 2, 1) - C_(TAx, 2, 1, 1) + C_(TAx, 1, 2, 2) - C_(TAx, 1, 1, 2) +
@@ -493,21 +505,22 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
                 tz[1] = ty[2];
                 tx[1] = ty[0];
                 tz[0] = tx[2];
+                double out[NCD][NCM];
+                mag_project<NCM, NCD>(tx, ty, tz, mf, out);
+                const int64_t p = ((int64_t)(k0 + c) * ny + (j0 + b)) * nx + (i0 + a);
+                const double w = cw ? cwo[p] : 1.0;
+#pragma unroll
+                for (int d = 0; d < NCD; ++d)
+#pragma unroll
+                    for (int k = 0; k < NCM; ++k) {
+                        double v = out[d][k];
+                        if (cw) v = v * w;
+                        if (inside) v = 0.0;
+                        const int sub = (o * NCD + d) * NCM + k;
+                        __builtin_nontemporal_store(v, &rows[(int64_t)sub * N + p]);
+                        sq[d * NCM + k] = fma(v, v, sq[d * NCM + k]);
+                    }
             }
-            double out[NCD][NCM];
-            mag_project<NCM, NCD>(tx, ty, tz, mf, out);
-            const int64_t p = ((int64_t)(k0 + c) * ny + (j0 + b)) * nx + (i0 + a);
-            const double w = cw ? cw[p] : 1.0;
-#pragma unroll
-            for (int d = 0; d < NCD; ++d)
-#pragma unroll
-                for (int k = 0; k < NCM; ++k) {
-                    double v = out[d][k];
-                    if (cw) v = v * w;
-                    const int sub = (o * NCD + d) * NCM + k;
-                    __builtin_nontemporal_store(v, &rows[(int64_t)sub * N + p]);
-                    sq[d * NCM + k] = fma(v, v, sq[d * NCM + k]);
-                }
         }
         if (sumsq) {                                        // cost_full (sensitivity_gravmag.F90:234), fixed order
 #pragma unroll
@@ -523,6 +536,52 @@ __global__ __launch_bounds__(256) void k_magprism_tensor(int nx, int ny, int nz,
         }
     }
 #undef NODE
+    if (bad) atomicOr(err, bad);
+}
+
+// The cell that contains an observation (strictly: magnetic_field.f90:139-141), if any: the 6-sub-box tensor of mag_cell_tensor,
+// written over the zero k_magprism_tensor left there; its squares join the tile's cost_full partial.  One workgroup per
+// observation; the threads look for the cell along each axis (at most one per axis on a tensor grid), thread 0 does the rest.
+template <int NCM, int NCD>
+__global__ __launch_bounds__(64) void k_magprism_inside_fix(int nx, int ny, int nz, const double *__restrict__ xe,
+                                                            const double *__restrict__ ye, const double *__restrict__ ze,
+                                                            const double *__restrict__ xd, const double *__restrict__ yd,
+                                                            const double *__restrict__ zd, const double *__restrict__ cw, MagField mf,
+                                                            double *__restrict__ rows, int *__restrict__ err, double *__restrict__ sumsq,
+                                                            int ntiles)
+{
+    constexpr int NSUB = NCM * NCD;
+    __shared__ int s_cell[3];
+    init_math_tables();
+    const int o = blockIdx.x;
+    const double xo = xd[o], yo = yd[o], zo = zd[o];
+    if (threadIdx.x < 3) s_cell[threadIdx.x] = -1;
+    __syncthreads();
+    for (int a = threadIdx.x; a < nx; a += blockDim.x) if (xe[a] < xo && xe[a + 1] > xo) s_cell[0] = a;
+    for (int b = threadIdx.x; b < ny; b += blockDim.x) if (ye[b] < yo && ye[b + 1] > yo) s_cell[1] = b;
+    for (int c = threadIdx.x; c < nz; c += blockDim.x) if (ze[c] < zo && ze[c + 1] > zo) s_cell[2] = c;
+    __syncthreads();
+    const int a = s_cell[0], b = s_cell[1], c = s_cell[2];
+    if (threadIdx.x != 0 || a < 0 || b < 0 || c < 0) return;
+    int bad = 0;
+    double tx[3], ty[3], tz[3];
+    mag_cell_tensor(xe[a], xe[a + 1], ye[b], ye[b + 1], ze[c], ze[c + 1], xo, yo, zo, tx, ty, tz, bad);
+    double out[NCD][NCM];
+    mag_project<NCM, NCD>(tx, ty, tz, mf, out);
+    const int64_t N = (int64_t)nx * ny * nz, p = ((int64_t)c * ny + b) * nx + a;
+    const double w = cw ? cw[p] : 1.0;
+    const int tiles_x = (nx + MT_X - 1) / MT_X, tiles_y = (ny + MT_Y - 1) / MT_Y;
+    const int tile = ((c / MT_Z) * tiles_y + b / MT_Y) * tiles_x + a / MT_X;
+#pragma unroll
+    for (int d = 0; d < NCD; ++d)
+#pragma unroll
+        for (int k = 0; k < NCM; ++k) {
+            double v = out[d][k];
+            if (cw) v = v * w;
+            const int sub = (o * NCD + d) * NCM + k;
+            rows[(int64_t)sub * N + p] = v;
+            if (sumsq) sumsq[(int64_t)(o * NSUB + d * NCM + k) * ntiles + tile] += v * v;
+        }
     if (bad) atomicOr(err, bad);
 }
 
@@ -847,11 +906,19 @@ int prism_rows_dev(tfx_ctx *ctx, const RowGen &gen, int nobs, const double *d_x,
     if (gen.kind == GEN_MAG && ctx->tensor_grid) {
         const int tiles = ((ctx->nx + MT_X - 1) / MT_X) * ((ctx->ny + MT_Y - 1) / MT_Y) * ((ctx->nz + MT_Z - 1) / MT_Z);
 #define TENSOR_ARGS ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p, ctx->edges[1].p, ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, gen.mf, d_rows, d_err, d_sumsq
-        if (gen.ncm == 1 && gen.ncd == 1) hipLaunchKernelGGL((k_magprism_tensor<1, 1>), dim3(tiles), dim3(256), 0, s, TENSOR_ARGS);
-        else if (gen.ncm == 1 && gen.ncd == 3) hipLaunchKernelGGL((k_magprism_tensor<1, 3>), dim3(tiles), dim3(256), 0, s, TENSOR_ARGS);
-        else if (gen.ncm == 3 && gen.ncd == 1) hipLaunchKernelGGL((k_magprism_tensor<3, 1>), dim3(tiles), dim3(256), 0, s, TENSOR_ARGS);
-        else if (gen.ncm == 3 && gen.ncd == 3) hipLaunchKernelGGL((k_magprism_tensor<3, 3>), dim3(tiles), dim3(256), 0, s, TENSOR_ARGS);
+#define FIX_ARGS ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p, ctx->edges[1].p, ctx->edges[2].p, d_x, d_y, d_z, d_cw, gen.mf, d_rows, d_err, d_sumsq, tiles
+#define MAG_TENSOR(M, D)                                                                                      \
+    do {                                                                                                      \
+        hipLaunchKernelGGL((k_magprism_tensor<M, D>), dim3(tiles), dim3(256), 0, s, TENSOR_ARGS);              \
+        hipLaunchKernelGGL((k_magprism_inside_fix<M, D>), dim3(nobs), dim3(64), 0, s, FIX_ARGS);               \
+    } while (0)
+        if (gen.ncm == 1 && gen.ncd == 1) MAG_TENSOR(1, 1);
+        else if (gen.ncm == 1 && gen.ncd == 3) MAG_TENSOR(1, 3);
+        else if (gen.ncm == 3 && gen.ncd == 1) MAG_TENSOR(3, 1);
+        else if (gen.ncm == 3 && gen.ncd == 3) MAG_TENSOR(3, 3);
         else return fail(TFX_E_ARG, "Wrong number of components in magnetic_field_magprism!");
+#undef MAG_TENSOR
+#undef FIX_ARGS
 #undef TENSOR_ARGS
         if (nblk) *nblk = tiles;
     } else if (gen.kind == GEN_MAG) {
