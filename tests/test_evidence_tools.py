@@ -1,0 +1,58 @@
+"""The reducers behind profiles/: tools/pmc_reduce.py must count only the newest PMC pass of a folder (gpurun merges the files of
+every call into gpurun_out/, and dispatch ids repeat from run to run) and must refuse a reduction that is not ~1 x the device
+bytes of the matrix (bench.py would otherwise report it as roofline.traffic)."""
+import json
+import os
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+HEAD = '"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\n'
+
+
+def _pass(folder, name, counter, kib, launches=3):
+    os.makedirs(folder, exist_ok=True)
+    with open(os.path.join(folder, name), "w") as f:
+        f.write(HEAD)
+        for i in range(launches):
+            f.write('%d,"void tfx::k_spmv_fwd<16>(...)","%s",%f\n' % (100 + 2 * i, counter, kib))
+            f.write('%d,"void tfx::k_spmv_adj<16>(...)","%s",%f\n' % (101 + 2 * i, counter, kib))
+
+
+def _bench_lines(src, device_bytes):
+    line = json.dumps({"config": {"workload": "hamersley_1e7: test", "nnz": 123},
+                       "roofline": {"algorithmic_bytes_per_launch": device_bytes, "device_bytes_of_the_matrix": device_bytes}})
+    for name in ("pmc_FETCH_SIZE.json", "bench_plain.json"):
+        open(os.path.join(src, name), "w").write(line + "\n")
+
+
+def test_pmc_reduce_counts_only_the_newest_pass_and_refuses_nonsense(tmp_path):
+    import pmc_reduce
+    src = str(tmp_path)
+    device_bytes = 2.0 * 1024.0 * 1000.0            # FETCH_SIZE 1000 KiB x 2 (gfx950 correction) = exactly the device bytes
+    _bench_lines(src, device_bytes)
+    _pass(os.path.join(src, "pmc_FETCH_SIZE", "runc"), "1_counter_collection.csv", "FETCH_SIZE", 5000.0)     # an older run: same dispatch ids
+    _pass(os.path.join(src, "pmc_WRITE_SIZE", "runc"), "1_counter_collection.csv", "WRITE_SIZE", 7.0)
+    time.sleep(0.05)
+    _pass(os.path.join(src, "pmc_FETCH_SIZE", "runc"), "2_counter_collection.csv", "FETCH_SIZE", 1000.0)
+    _pass(os.path.join(src, "pmc_WRITE_SIZE", "runc"), "2_counter_collection.csv", "WRITE_SIZE", 3.0)
+    now = time.time()
+    for n, t in (("1_counter_collection.csv", now - 100), ("2_counter_collection.csv", now)):
+        for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE"):
+            os.utime(os.path.join(src, sub, "runc", n), (t, t))
+    dst = os.path.join(src, "summary.json")
+    pmc_reduce.main(src, dst, 3)
+    d = json.load(open(dst))
+    k = d["kernels"]["k_spmv_adj"]
+    assert k["FETCH_SIZE_launches"] == 3 and k["FETCH_SIZE_raw_KiB_avg"] == 1000.0 and k["WRITE_SIZE_raw_KiB_avg"] == 3.0
+    assert abs(k["fetch_over_device_bytes"] - 1.0) < 1e-12 and d["workload"] == "hamersley_1e7"
+    # a pass that reads 5 x the matrix is a bookkeeping error: nothing is written
+    os.remove(dst)
+    t = time.time() + 10
+    os.utime(os.path.join(src, "pmc_FETCH_SIZE", "runc", "1_counter_collection.csv"), (t, t))
+    with pytest.raises(SystemExit):
+        pmc_reduce.main(src, dst, 3)
+    assert not os.path.exists(dst)
