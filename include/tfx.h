@@ -305,13 +305,13 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * key "band_select_min_cells" (value): grids of at least that many cells find the row thresholds by the sample-bracketed
  * band select instead of the full radix select (default 2^20; < 0: never) - both give the exact order statistic;
  * keys "band_batches" / "band_fallbacks": return how many row batches used it / fell back to the full select;
- * key "deterministic" (0/1; environment TFX_DETERMINISTIC at tfx_create): the two matrix products run with single-wave workgroups, so the LDS accumulations happen in program
- * order and a product is bit-reproducible from run to run (slow; for debugging convergence differences);
+ * key "deterministic": accepted and ignored (older hosts set it) - the two matrix products are always reproducible: every fp64 sum
+ * is formed in an order fixed by the matrix and its work lists (forward kernel), or exactly in integers (adjoint without a copy);
  * key "fwd_group" (0 = automatic, 1, 2, 4): row blocks that share one staged x tile in the forward product;
- * key "adj_copy" (0 never / 1 always / 2 automatic, default 0; environment TFX_ADJ_COPY): matrices finished from now on get a
- * transposed copy of their tiles so that the adjoint product runs as a forward product (no LDS atomic per non-zero; twice the
- * matrix memory, a longer build: it pays for very long solves on one matrix - DESIGN.md 3); automatic = matrices of at least
- * "adj_copy_min_nnz" stored entries (2^26) when the device has room;
+ * key "adj_copy" (0 never / 1 always / 2 automatic, default 2; environment TFX_ADJ_COPY): matrices finished from now on get a
+ * transposed copy of their tiles so that the adjoint product runs as the forward kernel on S^T (twice the matrix memory, a longer
+ * build - DESIGN.md 3); automatic = matrices of at least "adj_copy_min_nnz" stored entries (default 0) whenever the device has
+ * room; 1 = a copy that does not fit is an error; without a copy the adjoint runs on the tiles of S (exact integer accumulation);
  * "has_adj_copy" queries the selected matrix;
  * key "build_overlap" (0/1/2, default 1): the kernel build runs its row generator (VALU-bound) on a second stream one batch ahead of
  * the wavelet / threshold / compaction kernels (HBM-bound) of the main stream and reads each batch's statistics one batch late

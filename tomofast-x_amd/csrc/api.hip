@@ -25,8 +25,8 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     c->stream = (hipStream_t)stream;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
-    if (const char *e = getenv("TFX_DETERMINISTIC")) c->deterministic = atoi(e) != 0;     // like tfx_debug_set "deterministic"
     if (const char *e = getenv("TFX_ADJ_COPY")) c->adj_copy = std::max(0, std::min(2, atoi(e)));   // like tfx_debug_set "adj_copy"
+    if (const char *e = getenv("TFX_FWD_RUN")) c->fwd_run = std::max(1, atoi(e));
     if (const char *e = getenv("TFX_ADJ_COPY_MIN_NNZ")) c->adj_copy_min_nnz = atoll(e);
     if (const char *e = getenv("TFX_CHAIN_UNDER_WAVELET")) c->chain_under_wavelet = atoi(e) != 0;
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = std::max(0, std::min(2, atoi(e)));
@@ -158,10 +158,7 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         ctx->band_min_n = value < 0 ? INT64_MAX : (int64_t)value;
         return 0;
     }
-    if (!strcmp(key, "deterministic")) {        // single-wave workgroups in the two products: LDS atomics in program order
-        ctx->deterministic = value != 0;
-        return 0;
-    }
+    if (!strcmp(key, "deterministic")) return 0;   // (kept for older hosts) the two products are always reproducible: matrix.hip k_spmv_fwd / k_spmv_adj
     if (!strcmp(key, "adj_copy")) {             // transposed copy for the adjoint of matrices finished from now on: 0 never, 1 always, 2 automatic
         ctx->adj_copy = std::max(0, std::min(2, value));
         return 0;
@@ -213,6 +210,10 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
     }
     if (!strcmp(key, "force_collectives")) {    // issue the collectives of the multi-rank path even on one rank
         ctx->force_collectives = value != 0;
+        return 0;
+    }
+    if (!strcmp(key, "fwd_run")) {              // chunks per run of the forward kernel (>= 1); the sums stay reproducible for a fixed value
+        ctx->fwd_run = std::max(1, value);
         return 0;
     }
     if (!strcmp(key, "fwd_group")) {            // row blocks per forward super block for matrices finished from now on (0 = automatic)

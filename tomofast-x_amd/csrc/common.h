@@ -138,6 +138,8 @@ struct TiledMatrix {
     DBuf<int32_t> fwd_nslots, fwd_pbase;   // per row block
     DBuf<int32_t> adj_nslots, adj_pbase;   // per column tile
     bool adj_has_partials = false;
+    DBuf<float> tile_vmax;        // max |value| per tile: the product bound of the adjoint kernel on the tiles of S (matrix.hip k_spmv_adj);
+    bool vmax_stale = true;       //   computed when that kernel is first used and again after the values changed (scale_rows)
     // dense storage (compression off): fp32 [nrows][ld], no index stream (4 B per entry)
     bool is_dense = false;
     int64_t ld = 0;
@@ -231,19 +233,20 @@ struct tfx_ctx {
     int chain_under_wavelet = 1;      // debug key "chain_under_wavelet": overlapped build - the threshold / compaction chain of batch b runs on a third stream beside the wavelet passes of batch b + 1
     int build_overlap = 1;            // debug key "build_overlap": row generator on its own stream, one batch ahead of the wavelet / compaction
     int items_per_cu = 16;            // debug key "items_per_cu": work items per CU the tile list is cut into
-    // Adjoint on a transposed copy of the tiles: 0 never (default), 1 always, 2 automatic = for matrices of at least adj_copy_min_nnz
-    // stored entries when the device has room for the second copy (debug key "adj_copy" / TFX_ADJ_COPY).  Off by default: measured at
-    // the headline size the adjoint drops from 18.39 to 18.05 ms per launch (the forward product: 17.8), for 6.5 s more build and
-    // twice the matrix memory - it pays only beyond ~20 000 iterations on one matrix.
-    int adj_copy = 0;
-    int64_t adj_copy_min_nnz = (int64_t)1 << 26;
+    // Adjoint on a transposed copy of the tiles: 0 never, 1 always (a copy that does not fit is an error), 2 (default) automatic = for
+    // matrices of at least adj_copy_min_nnz stored entries whenever the device has room for the second copy (debug key "adj_copy" /
+    // TFX_ADJ_COPY).  With the copy b += S^T x is the forward kernel on S^T: fp64 sums in a fixed order, no LDS atomic per non-zero
+    // (headline size: 18.05 ms per launch against 18.39, for 6.5 s of build and twice the matrix memory).  Without it the adjoint
+    // runs on the tiles of S with exact integer accumulation (matrix.hip k_spmv_adj).  Both are reproducible run to run.
+    int adj_copy = 2;
+    int64_t adj_copy_min_nnz = 0;
     struct TransposeScratch {
         tfx::DBuf<int32_t> cnt, nel, tcols, tids, toff;
         tfx::DBuf<int64_t> rowoff, totals;
         tfx::DBuf<float> tvals;
     } trs;
+    int fwd_run = 2;                  // debug key "fwd_run": consecutive chunks a wave of the forward kernel takes at a time (matrix.hip k_spmv_fwd)
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
-    bool deterministic = false;       // debug: single-wave workgroups in the two products -> LDS atomics in program order
     size_t wave_lds_attr[4] = {0, 0, 0, 0};   // the same for the four wavelet axis kernels (Haar / D4 x forward / inverse)
     bool profile = false;
     double prof_ms[3] = {0, 0, 0};     // 0 forward product, 1 adjoint product, 2 in-stream all-reduce (comm.hip)

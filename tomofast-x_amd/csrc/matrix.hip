@@ -35,7 +35,7 @@ size_t TiledMatrix::device_bytes() const
 {
     return rec.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
            fwd_order.bytes() + adj_order.bytes() + fwd_partial.bytes() + adj_partial.bytes() + adj_nslots.bytes() +
-           adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes() + dense.bytes() + dense_partial.bytes() +
+           adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes() + dense.bytes() + dense_partial.bytes() + tile_vmax.bytes() +
            (T ? T->device_bytes() : 0);
 }
 
@@ -44,7 +44,8 @@ void TiledMatrix::release_storage()
     rec.release(); chunk_row0.release(); tiles.release(); fwd.release(); adj.release();
     fwd_order.release(); adj_order.release(); fwd_partial.release(); adj_partial.release();
     fwd_nslots.release(); fwd_pbase.release(); adj_nslots.release(); adj_pbase.release();
-    dense.release(); dense_partial.release();
+    dense.release(); dense_partial.release(); tile_vmax.release();
+    vmax_stale = true;
     delete T;
     T = nullptr;
     h_tiles.clear(); h_fwd.clear(); h_adj.clear();
@@ -637,6 +638,7 @@ int matrix_finish(tfx_ctx *ctx)
     TFX_TRY(m.adj_partial.alloc(std::max<size_t>(1, (size_t)nap * m.TC)));
     TFX_HIP(hipStreamSynchronize(s));
     m.adj_has_partials = nap > 0;
+    m.vmax_stale = true;
     m.nnz = real;
     m.valid = true;
     if (!m.is_transpose_copy) {
@@ -780,10 +782,6 @@ __device__ __forceinline__ int64_t locate_chunk(const TileGroup &g, int q, int &
     return c;
 }
 
-// forward: one workgroup = a run of tiles of one super block (GROUP row blocks), ordered by column tile so that a staged x tile
-// serves all row blocks of the group; partial[item][row of the super block] = sum over the run.
-// WAVES = 16: the product kernel; WAVES = 1: the deterministic debug variant (a single wave issues its LDS atomics in program
-// order, and no other wave touches the workgroup's sums).
 // pointers of the matrix streams (passed by value to the product kernels)
 struct MatPtrs {
     const WorkItem *items;
@@ -800,11 +798,88 @@ struct MatPtrs {
     const char *__restrict__ rec, const int32_t *__restrict__ chunk_row0
 #define MAT_ARGS(mp) (mp).items, (mp).order, (mp).tiles, (mp).rec, (mp).chunk_row0
 
+// Segmented sum over the lanes of a wave: lanes with equal keys are contiguous; on return the FIRST lane of every run of equal keys
+// holds the run's total (the other lanes partial sums), *first says whether the lane is such a first lane.  Inside a 16-lane DPP row:
+// 4 shift-and-add steps on the VALU (row_shl, no LDS crossbar); across the four rows: the row heads are read as scalars and carried
+// backwards.  The association order is fixed (by lane), so the result is reproducible.
+__device__ __forceinline__ double seg_reduce(double sum, int cur, int lane, bool *first)
+{
+    seg_step<1>(sum, cur);
+    seg_step<2>(sum, cur);
+    seg_step<4>(sum, cur);
+    seg_step<8>(sum, cur);
+    {
+        const int tc0 = __builtin_amdgcn_readlane(cur, 15), tc1 = __builtin_amdgcn_readlane(cur, 31),
+                  tc2 = __builtin_amdgcn_readlane(cur, 47);
+        const int hc1 = __builtin_amdgcn_readlane(cur, 16), hc2 = __builtin_amdgcn_readlane(cur, 32),
+                  hc3 = __builtin_amdgcn_readlane(cur, 48);
+        const double hs1 = readlane_f64(sum, 16), hs2 = readlane_f64(sum, 32), hs3 = readlane_f64(sum, 48);
+        // carry[r]: what the lanes of row r whose run reaches the end of the row still miss
+        const double carry2 = (hc3 == tc2) ? hs3 : 0.0;
+        const double carry1 = (hc2 == tc1) ? hs2 + ((hc2 == tc2) ? carry2 : 0.0) : 0.0;
+        const double carry0 = (hc1 == tc0) ? hs1 + ((hc1 == tc1) ? carry1 : 0.0) : 0.0;
+        const int row = lane >> 4;
+        const int tc = row == 0 ? tc0 : (row == 1 ? tc1 : (row == 2 ? tc2 : -2));
+        const double carry = row == 0 ? carry0 : (row == 1 ? carry1 : carry2);
+        if (cur == tc) sum += carry;
+    }
+    const int pcur = __builtin_amdgcn_update_dpp(-3, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    *first = pcur != cur;
+    return sum;
+}
+
+// One chunk of the forward product: row segments summed inside a lane, the segment tails merged across lanes, one LDS add per
+// (row, chunk) piece into o[row].  HEAD: the pieces of row `hr` - the row this wave's run of chunks starts in the middle of, whose
+// earlier part belongs to another wave - go to the run's own slot *hp instead (see k_spmv_fwd).  Returns (HEAD only) whether
+// the chunk holds a row start, i.e. whether row hr ends here.
+template <bool HEAD>
+__device__ __forceinline__ bool fwd_chunk(const char *__restrict__ rec, const int32_t *__restrict__ chunk_row0, int64_t ch, int lane,
+                                          const double *xs, double *o, int hr, double *hp)
+{
+    ChunkRegs cr;
+    ChunkMasks mk;
+    load_chunk(rec, ch, lane, cr);
+    int cur = chunk_row0[ch] + load_masks(rec, ch, mk);
+    double acc = 0.0;
+#define FWD_DST(row) ((HEAD && (row) == hr) ? hp : &o[row])
+#define FWD_STEP(K)                                                          \
+    if (ROWSTART_K(mk, K)) {                                                 \
+        if (cur >= 0 && acc != 0.0) atomicAdd(FWD_DST(cur), acc);            \
+        cur += 1;                                                            \
+        acc = 0.0;                                                           \
+    }                                                                        \
+    acc = fma((double)cr.v[K], xs[slot_of<K>(cr)], acc);
+    FWD_STEP(0) FWD_STEP(1) FWD_STEP(2) FWD_STEP(3) FWD_STEP(4) FWD_STEP(5) FWD_STEP(6) FWD_STEP(7)
+#undef FWD_STEP
+    // merge the tails of lanes that end on the same row (equal rows are contiguous lanes): the first lane of every run adds the total
+    bool first;
+    const double sum = seg_reduce(acc, cur, lane, &first);
+    if (first && cur >= 0 && sum != 0.0) atomicAdd(FWD_DST(cur), sum);
+#undef FWD_DST
+    if constexpr (HEAD) return (mk.m[0] | mk.m[1] | mk.m[2] | mk.m[3] | mk.m[4] | mk.m[5] | mk.m[6] | mk.m[7]) != 0ull;
+    return false;
+}
+
+// forward: one workgroup = a run of tiles of one super block (GROUP row blocks), ordered by column tile so that a staged x tile
+// serves all row blocks of the group; partial[item][row of the super block] = sum over the run.
+//
+// The sums are REPRODUCIBLE: every floating-point addition happens in an order fixed by the matrix and its work lists, never by the
+// timing of the waves (the reference's sums are sequential loops, sparse_matrix.f90:316-329).  The chunks of a tile group are cut into
+// RUNS of `RUN` consecutive chunks, dealt to the waves round-robin (the 16 waves of a workgroup read inside one window of 16 RUN
+// chunks at a time).  A row whose entries lie inside one run is only ever added to by that run's wave, and a wave's LDS adds are
+// performed in program order.  A row that straddles the start of a run is the run's "head row": its pieces inside the run are summed
+// in the run's own LDS slot, the run (of another wave) in which the row starts adds its pieces to the row directly, and after the
+// group's barrier one wave adds the head sums to their rows in run order (a segmented sum over the lanes in a fixed association).
+// (Run 0 has no head row inside the workgroup: when it starts inside a row - an item that owns a range of a heavy tile's chunks -
+// the earlier part of the row belongs to another work item, and the items meet in k_fwd_reduce in fixed order.)
+constexpr int FWD_MAX_RUNS = 256;       // head slots per tile group (3 KB of LDS); longer groups get longer runs
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_fwd(MAT_PARAMS, const double *__restrict__ x, double *__restrict__ partial,
-                                                           int64_t ncols, int TC, int RB, int GROUP)
+                                                           int64_t ncols, int TC, int RB, int GROUP, int RUN)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double s_head[FWD_MAX_RUNS];
+    __shared__ int s_hrow[FWD_MAX_RUNS];
     constexpr int THREADS = WAVES * 64;
     double *xs = lds;          // TC
     double *outs = lds + TC;   // GROUP * RB
@@ -812,13 +887,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_fwd(MA
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nout = GROUP * RB;
     for (int i = tid; i < nout; i += THREADS) outs[i] = 0.0;
+    int nruns_prev = 0;        // runs of the tile group before: their head sums are still to be added
     int ti = it.begin;
-    while (ti < it.end) {
+    while (true) {
+        __syncthreads();
+        if (wave == 0) {
+            for (int base = 0; base < nruns_prev; base += 64) {
+                const int i = base + lane;
+                const bool in = i > 0 && i < nruns_prev;
+                const int r = in ? s_hrow[i] : -1;
+                bool first;
+                const double sum = seg_reduce(in ? s_head[i] : 0.0, r, lane, &first);
+                if (first && r >= 0 && sum != 0.0) atomicAdd(&outs[r], sum);
+            }
+        }
+        if (ti >= it.end) break;
         TileGroup g;
         TileMeta tm;
         make_group<true>(it, order, tiles, ti, GROUP, g, tm);
         ti += g.ng;
-        __syncthreads();
         {
             // x is read at the columns' (bank-folded) slots
             const int64_t col0 = (int64_t)tm.t * TC;
@@ -826,49 +913,31 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_fwd(MA
             for (int i = tid; i < TC; i += THREADS) xs[col_slot(i)] = (i < ncol) ? x[col0 + i] : 0.0;
         }
         __syncthreads();
-        for (int q = wave; q < g.total; q += WAVES) {
-            int lrb;
-            const int64_t ch = locate_chunk(g, q, lrb);
-            double *o = outs + lrb * RB;
-            ChunkRegs cr;
-            ChunkMasks mk;
-            load_chunk(rec, ch, lane, cr);
-            int cur = chunk_row0[ch] + load_masks(rec, ch, mk);
-            double acc = 0.0;
-#define FWD_STEP(K)                                                          \
-            if (ROWSTART_K(mk, K)) {                                         \
-                if (cur >= 0 && acc != 0.0) atomicAdd(&o[cur], acc);         \
-                cur += 1;                                                    \
-                acc = 0.0;                                                   \
-            }                                                                \
-            acc = fma((double)cr.v[K], xs[slot_of<K>(cr)], acc);
-            FWD_STEP(0) FWD_STEP(1) FWD_STEP(2) FWD_STEP(3) FWD_STEP(4) FWD_STEP(5) FWD_STEP(6) FWD_STEP(7)
-#undef FWD_STEP
-            // merge the tails of lanes that end on the same row (equal rows are contiguous lanes): the first lane of every run
-            // gets the run's total.  Inside a 16-lane DPP row: 4 shift-and-add steps on the VALU (row_shl, no LDS crossbar);
-            // across the four rows: the row heads are read as scalars and carried backwards.
-            double sum = acc;
-            seg_step<1>(sum, cur);
-            seg_step<2>(sum, cur);
-            seg_step<4>(sum, cur);
-            seg_step<8>(sum, cur);
-            {
-                const int tc0 = __builtin_amdgcn_readlane(cur, 15), tc1 = __builtin_amdgcn_readlane(cur, 31),
-                          tc2 = __builtin_amdgcn_readlane(cur, 47);
-                const int hc1 = __builtin_amdgcn_readlane(cur, 16), hc2 = __builtin_amdgcn_readlane(cur, 32),
-                          hc3 = __builtin_amdgcn_readlane(cur, 48);
-                const double hs1 = readlane_f64(sum, 16), hs2 = readlane_f64(sum, 32), hs3 = readlane_f64(sum, 48);
-                // carry[r]: what the lanes of row r whose run reaches the end of the row still miss
-                const double carry2 = (hc3 == tc2) ? hs3 : 0.0;
-                const double carry1 = (hc2 == tc1) ? hs2 + ((hc2 == tc2) ? carry2 : 0.0) : 0.0;
-                const double carry0 = (hc1 == tc0) ? hs1 + ((hc1 == tc1) ? carry1 : 0.0) : 0.0;
-                const int row = lane >> 4;
-                const int tc = row == 0 ? tc0 : (row == 1 ? tc1 : (row == 2 ? tc2 : -2));
-                const double carry = row == 0 ? carry0 : (row == 1 ? carry1 : carry2);
-                if (cur == tc) sum += carry;
+        const int run_len = max(RUN, (g.total + FWD_MAX_RUNS - 1) / FWD_MAX_RUNS);
+        const int nruns = (g.total + run_len - 1) / run_len;
+        nruns_prev = nruns;
+        for (int run = wave; run < nruns; run += WAVES) {
+            int q = run * run_len;
+            const int q1 = min(q + run_len, g.total);
+            if (run > 0) {
+                int lrb0;
+                const int64_t ch0 = locate_chunk(g, q, lrb0);
+                const int hr = chunk_row0[ch0];
+                if (lane == 0) { s_hrow[run] = hr >= 0 ? lrb0 * RB + hr : -1; s_head[run] = 0.0; }
+                // chunks up to and including the first one with a row start: the only ones that can hold pieces of the head row
+                bool open = true;
+                while (open && q < q1) {
+                    int lrb;
+                    const int64_t ch = locate_chunk(g, q, lrb);
+                    open = !fwd_chunk<true>(rec, chunk_row0, ch, lane, xs, outs + lrb * RB, lrb == lrb0 ? hr : -5, &s_head[run]);
+                    ++q;
+                }
             }
-            const int pcur = __builtin_amdgcn_update_dpp(-3, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            if (pcur != cur && cur >= 0 && sum != 0.0) atomicAdd(&o[cur], sum);
+            for (; q < q1; ++q) {
+                int lrb;
+                const int64_t ch = locate_chunk(g, q, lrb);
+                fwd_chunk<false>(rec, chunk_row0, ch, lane, xs, outs + lrb * RB, -5, nullptr);
+            }
         }
     }
     __syncthreads();
@@ -904,37 +973,103 @@ __global__ __launch_bounds__(FR_ROWS * FR_GROUPS) void k_fwd_reduce(const double
     }
 }
 
-// adjoint: one workgroup = a run of tiles of one column tile; slot 0 adds into y, the others write partials.
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_adj(MAT_PARAMS, const double *__restrict__ u, double *__restrict__ y,
-                                                           double *__restrict__ partial, int64_t nrows, int64_t ncols,
-                                                           int TC, int RB, int GROUP)
+// adjoint on the tiles of S themselves (no transposed copy: the matrix did not fit twice): one workgroup = a run of tiles of one
+// column tile; slot 0 adds into y, the others write partials.
+//
+// The column sums of a tile group are accumulated in LDS by all 16 waves at once, so an fp64 accumulation would depend on the order
+// in which the waves' adds arrive.  They are therefore accumulated EXACTLY: the group's u rows are staged times 2^k, with k chosen
+// from max|u| of those rows and max|value| of the group's tiles (tile_vmax[], kept with the matrix) such that every product is below
+// 2^(62 - ceil(log2 rows)) in magnitude; fma(value, u * 2^k, 1.5 * 2^52) rounds the product to an integer (ties to even) and leaves
+// it in the low bits of the result, and the integers are added with 64-bit LDS integer atomics - associative, so the sums do not
+// depend on any order and can not overflow.  One rounding per product, at 2^-49 .. 2^-50 of the largest product of the group (for a
+// two-row-block group; an fp64 accumulation rounds every partial sum to 2^-53 of itself).  At the end of the group every thread
+// converts its own columns back (int64 -> fp64, one rounding) and adds them to its running fp64 column sums, in group order.
+constexpr double ADJ_MAGIC = 6755399441055744.0;       // 1.5 * 2^52: fp64 numbers in [2^52, 2^53) have unit spacing
+constexpr int ADJ_COLS_PER_THREAD = TC_MAX / 1024;
+__global__ __launch_bounds__(1024, 8) void k_spmv_adj(MAT_PARAMS, const float *__restrict__ tile_vmax, const double *__restrict__ u,
+                                                       double *__restrict__ y, double *__restrict__ partial, int64_t nrows, int64_t ncols,
+                                                       int TC, int RB, int GROUP)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int THREADS = WAVES * 64;
-    double *acc = lds;        // TC
-    double *us = lds + TC;    // GROUP * RB
+    __shared__ unsigned long long s_umax[16];
+    constexpr int THREADS = 1024, WAVES = 16;
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(lds);        // TC
+    double *us = lds + TC;                                                         // GROUP * RB
     const WorkItem it = items[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < TC; i += THREADS) acc[i] = 0.0;
+    for (int i = tid; i < TC; i += THREADS) acc[i] = 0ull;
+    double colsum[ADJ_COLS_PER_THREAD];          // fp64 sums of this thread's slots tid, tid + 1024, ...
+#pragma unroll
+    for (int j = 0; j < ADJ_COLS_PER_THREAD; ++j) colsum[j] = 0.0;
+    int kprev = 0;                               // scale exponent of the group whose integer sums are still in acc[]
+    bool pending = false;
+    // the headroom of the integer sums: a column collects at most GROUP * RB products per group
+    int hb = 0;
+    while ((1 << hb) < GROUP * RB) ++hb;
+    const int pbits = min(50, 62 - hb);          // |product * 2^k| < 2^pbits  (<= 2^50 keeps fma(..., ADJ_MAGIC) inside its binade)
     int ti = it.begin;
     while (ti < it.end) {
         TileGroup g;
         TileMeta tm;
         make_group<false>(it, order, tiles, ti, GROUP, g, tm);
+        uint32_t vmb = __float_as_uint(tile_vmax[order[ti]]);     // (bit patterns of non-negative floats order like the values; NaN on top)
+#pragma unroll
+        for (int j = 1; j < FWD_GROUP_MAX; ++j)
+            if (j < g.ng) vmb = max(vmb, __float_as_uint(tile_vmax[order[ti + j]]));
+        const float vmax = __uint_as_float(vmb);
         ti += g.ng;
         __syncthreads();
-        {
-            // the u rows of the row blocks the group touches: [first tile's block, last tile's block] inside the super block
-            int last = g.lrb[0];
+        if (pending) {
+            // integer sums of the group before -> this thread's fp64 column sums
 #pragma unroll
-            for (int j = 1; j < FWD_GROUP_MAX; ++j)
-                if (j < g.ng) last = g.lrb[j];
-            const int lo = g.lrb[0] * RB, hi = (last + 1) * RB;
-            const int64_t row0 = (int64_t)(tm.rb / GROUP) * GROUP * RB;
-            for (int i = lo + tid; i < hi; i += THREADS) us[i] = (row0 + i < nrows) ? u[row0 + i] : 0.0;
+            for (int j = 0; j < ADJ_COLS_PER_THREAD; ++j) {
+                const int i = tid + j * THREADS;
+                if (i < TC) {
+                    const long long v = (long long)acc[i];
+                    if (v != 0) {
+                        colsum[j] += ldexp((double)v, -kprev);
+                        acc[i] = 0ull;
+                    }
+                }
+            }
         }
+        // the u rows of the row blocks the group touches: [first tile's block, last tile's block] inside the super block
+        int last = g.lrb[0];
+#pragma unroll
+        for (int j = 1; j < FWD_GROUP_MAX; ++j)
+            if (j < g.ng) last = g.lrb[j];
+        const int lo = g.lrb[0] * RB, hi = (last + 1) * RB;
+        const int64_t row0 = (int64_t)(tm.rb / GROUP) * GROUP * RB;
+        // max |u| of the staged rows, as the largest bit pattern of |u|: ordered like the values, and a NaN sorts above everything
+        unsigned long long umb = 0ull;
+        for (int i = lo + tid; i < hi; i += THREADS) {
+            const double v = (row0 + i < nrows) ? u[row0 + i] : 0.0;
+            us[i] = v;
+            umb = max(umb, (unsigned long long)__double_as_longlong(fabs(v)));
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) umb = max(umb, (unsigned long long)__shfl_xor((long long)umb, d));
+        if (lane == 0) s_umax[wave] = umb;
         __syncthreads();
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) umb = max(umb, s_umax[w]);
+        const double umax = __longlong_as_double((long long)umb);
+        const double bound = umax * (double)vmax;                 // >= |value * u| of every entry of the group
+        const bool finite = bound < __builtin_huge_val();         // false for inf and NaN
+        if (!finite) {
+            // u holds an inf / NaN (or the bound overflows): the sums are poisoned like the fp64 sums would be
+#pragma unroll
+            for (int j = 0; j < ADJ_COLS_PER_THREAD; ++j) colsum[j] = __builtin_nan("");
+        }
+        pending = finite && bound > 0.0;
+        int k = 0;
+        if (pending) {
+            k = pbits - (ilogb(bound) + 1);                        // bound < 2^(ilogb + 1)
+            for (int i = lo + tid; i < hi; i += THREADS) us[i] = ldexp(us[i], k);
+        }
+        kprev = k;
+        __syncthreads();
+        if (!pending) continue;                                    // (wave-uniform) every product of the group is zero
         for (int q = wave; q < g.total; q += WAVES) {
             int lrb;
             const int64_t ch = locate_chunk(g, q, lrb);
@@ -944,12 +1079,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_adj(MA
             load_chunk(rec, ch, lane, cr);
             int cur = chunk_row0[ch] + load_masks(rec, ch, mk);
             double uval = ub[max(cur, 0)];
-#define ADJ_STEP(K)                                                                      \
-            if (ROWSTART_K(mk, K)) {                                                     \
-                cur += 1;                                                                \
-                uval = ub[cur];                                                          \
-            }                                                                            \
-            if (cr.v[K] != 0.0f) atomicAdd(&acc[slot_of<K>(cr)], (double)cr.v[K] * uval);
+#define ADJ_STEP(K)                                                                                          \
+            if (ROWSTART_K(mk, K)) {                                                                         \
+                cur += 1;                                                                                    \
+                uval = ub[cur];                                                                              \
+            }                                                                                                \
+            if (cr.v[K] != 0.0f) {                                                                           \
+                const double t = fma((double)cr.v[K], uval, ADJ_MAGIC);                                      \
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(t) - 0x4338000000000000ull; \
+                atomicAdd(&acc[slot_of<K>(cr)], bits);                                                       \
+            }
             ADJ_STEP(0) ADJ_STEP(1) ADJ_STEP(2) ADJ_STEP(3) ADJ_STEP(4) ADJ_STEP(5) ADJ_STEP(6) ADJ_STEP(7)
 #undef ADJ_STEP
         }
@@ -957,11 +1096,45 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_adj(MA
     __syncthreads();
     const int64_t col0 = (int64_t)it.key * TC;
     const int ncol = (int)min((int64_t)TC, ncols - col0);
-    if (it.slot == 0) {
-        for (int i = tid; i < ncol; i += THREADS) y[col0 + i] += acc[col_slot(i)];
-    } else {
-        double *dst = partial + (int64_t)it.pidx * TC;
-        for (int i = tid; i < TC; i += THREADS) dst[i] = acc[col_slot(i)];
+#pragma unroll
+    for (int j = 0; j < ADJ_COLS_PER_THREAD; ++j) {
+        const int i = tid + j * THREADS;           // slot i holds column col_slot(i) (an involution)
+        if (i < TC) {
+            double sum = colsum[j];
+            if (pending) {
+                const long long v = (long long)acc[i];
+                if (v != 0) sum += ldexp((double)v, -kprev);
+            }
+            const int c = col_slot(i);
+            if (it.slot == 0) {
+                if (c < ncol) y[col0 + c] += sum;
+            } else {
+                partial[(int64_t)it.pidx * TC + c] = sum;
+            }
+        }
+    }
+}
+
+// tile_vmax[tile] = max |value| of the tile (the bound the adjoint kernel scales its products by)
+__global__ __launch_bounds__(256) void k_tile_vmax(const TileMeta *__restrict__ tiles, int ntiles, const char *__restrict__ rec,
+                                                    float *__restrict__ tile_vmax)
+{
+    __shared__ uint32_t part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const TileMeta tm = tiles[ti];
+        const int64_t cbase = tm.off / CHUNK;
+        uint32_t m = 0u;                            // bit pattern of |value|: ordered like the values, a NaN sorts above everything
+        for (int c = wave; c < tm.nchunks; c += 4) {
+            const float *v = chunk_vals(rec, cbase + c);
+            for (int i = lane; i < CHUNK; i += 64) m = max(m, __float_as_uint(v[i]) & 0x7fffffffu);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+        if (lane == 0) part[wave] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_vmax[ti] = __uint_as_float(max(max(part[0], part[1]), max(part[2], part[3])));
+        __syncthreads();
     }
 }
 
@@ -1125,15 +1298,9 @@ static int forward_product(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, doub
     if (!m.h_fwd.empty()) {
         const MatPtrs mp = mat_ptrs(m, true);
         if (prof) prof_begin(ctx);
-        if (ctx->deterministic) {
-            TFX_TRY(set_lds_limit(ctx, 1, (const void *)k_spmv_fwd<1>, lds));
-            hipLaunchKernelGGL((k_spmv_fwd<1>), dim3((unsigned)m.h_fwd.size()), dim3(64), lds, s, MAT_ARGS(mp), d_x, m.fwd_partial.p,
-                               m.ncols, m.TC, m.RB, m.fwd_group);
-        } else {
-            TFX_TRY(set_lds_limit(ctx, 0, (const void *)k_spmv_fwd<16>, lds));
-            hipLaunchKernelGGL((k_spmv_fwd<16>), dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), d_x,
-                               m.fwd_partial.p, m.ncols, m.TC, m.RB, m.fwd_group);
-        }
+        TFX_TRY(set_lds_limit(ctx, 0, (const void *)k_spmv_fwd<16>, lds));
+        hipLaunchKernelGGL((k_spmv_fwd<16>), dim3((unsigned)m.h_fwd.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), d_x,
+                           m.fwd_partial.p, m.ncols, m.TC, m.RB, m.fwd_group, ctx->fwd_run);
         if (prof) prof_end(ctx, prof_slot);
         TFX_HIP(hipGetLastError());
     }
@@ -1179,16 +1346,17 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
     const size_t lds = (size_t)(m.TC + m.fwd_group * m.RB) * sizeof(double);
     if (!m.h_adj.empty()) {
         const MatPtrs mp = mat_ptrs(m, false);
-        if (prof) prof_begin(ctx);
-        if (ctx->deterministic) {
-            TFX_TRY(set_lds_limit(ctx, 3, (const void *)k_spmv_adj<1>, lds));
-            hipLaunchKernelGGL((k_spmv_adj<1>), dim3((unsigned)m.h_adj.size()), dim3(64), lds, s, MAT_ARGS(mp), d_x, d_b, m.adj_partial.p,
-                               m.nrows, m.ncols, m.TC, m.RB, m.fwd_group);
-        } else {
-            TFX_TRY(set_lds_limit(ctx, 2, (const void *)k_spmv_adj<16>, lds));
-            hipLaunchKernelGGL((k_spmv_adj<16>), dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), d_x, d_b,
-                               m.adj_partial.p, m.nrows, m.ncols, m.TC, m.RB, m.fwd_group);
+        if (m.vmax_stale) {
+            const int nt = (int)m.h_tiles.size();
+            TFX_TRY(m.tile_vmax.ensure((size_t)nt));
+            hipLaunchKernelGGL(k_tile_vmax, dim3((unsigned)std::min(nt, 65536)), dim3(256), 0, s, m.tiles.p, nt, m.rec.p, m.tile_vmax.p);
+            TFX_HIP(hipGetLastError());
+            m.vmax_stale = false;
         }
+        if (prof) prof_begin(ctx);
+        TFX_TRY(set_lds_limit(ctx, 2, (const void *)k_spmv_adj, lds));
+        hipLaunchKernelGGL(k_spmv_adj, dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), m.tile_vmax.p, d_x, d_b,
+                           m.adj_partial.p, m.nrows, m.ncols, m.TC, m.RB, m.fwd_group);
         if (prof) prof_end(ctx, 1);
         TFX_HIP(hipGetLastError());
         if (m.adj_has_partials)
@@ -1449,6 +1617,7 @@ int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale)
     }
     const int nt = (int)m.h_tiles.size();
     if (nt == 0) return 0;
+    m.vmax_stale = true;
     hipLaunchKernelGGL(k_scale_rows, dim3(8, (unsigned)std::min(nt, 32768)), dim3(256), 0, s, m.tiles.p, nt, m.rec.p,
                        m.chunk_row0.p, d_scale, m.nrows, m.RB);
     TFX_HIP(hipGetLastError());

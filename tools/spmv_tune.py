@@ -44,7 +44,10 @@ for val in (build_keys[first] if first else [None]):
     res = ctx.calculate_sensit(xs, ys, zs, cw, w["ctype"], w["rate"])
     print("%s=%s: build %.1f s nnz %d device bytes %.2f GB" % (first, val, time.time() - t0, res["nnz"],
           ctx.matrix_info()["device_bytes"] / 1e9), flush=True)
-    for group, ipc in settings:
+    for setting in settings:
+        group, ipc = setting[0], setting[1]
+        if len(setting) > 2:
+            ctx.debug_set("fwd_run", setting[2])          # TFX_TUNE_SETTINGS="group:items_per_cu:fwd_run,..."
         ctx.debug_set("fwd_group", group)
         ctx.debug_set("items_per_cu", ipc)
         ctx.debug_set("refinish", 0)
@@ -57,7 +60,7 @@ for val in (build_keys[first] if first else [None]):
         f, a = ctx.profile_get(0), ctx.profile_get(1)
         ctx.profile_enable(False)
         ctx.lsqr_end()
-        rec = dict(key=first, value=val, group=group, items_per_cu=ipc, ms_per_iter=ms / steps, fwd_ms=f[0] / max(f[1], 1),
+        rec = dict(key=first, value=val, group=group, items_per_cu=ipc, fwd_run=setting[2] if len(setting) > 2 else None, ms_per_iter=ms / steps, fwd_ms=f[0] / max(f[1], 1),
                    adj_ms=a[0] / max(a[1], 1), device_bytes=ctx.matrix_info()["device_bytes"])
         print(json.dumps(rec), flush=True)
     ctx.matrix_free()
