@@ -87,6 +87,7 @@ int lsqr_free(tfx_ctx *ctx);   // lsqr.hip
 int tfx_destroy(tfx_ctx *ctx)
 {
     if (!ctx) return 0;
+    if (tfx::g_alloc_ctx == ctx) tfx::g_alloc_ctx = nullptr;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     lsqr_free(ctx);

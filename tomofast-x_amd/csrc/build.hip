@@ -2888,6 +2888,7 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
                             const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
                             double *error_sum_out, int32_t *nnz_hist_out, RowStore *rs = nullptr)
 {
+    g_alloc_ctx = ctx;
     // rs != null: keep the compressed rows (all columns, global 0-based column indices) row-major on the device instead of
     // laying them out as this rank's tiled matrix - the row-parallel half of the multi-GPU build
     const bool to_rs = rs != nullptr;

@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../include/tfx.h"
 
+struct tfx_ctx;
 namespace tfx {
 
 extern thread_local std::string g_last_error;
@@ -37,6 +38,12 @@ inline int fail(int code, const char *fmt, ...)
         if (rc_ != 0) return rc_;     \
     } while (0)
 
+// An allocation that fails for lack of memory first gives up the transposed copies the matrices of the calling thread's context got
+// in automatic mode (TiledMatrix::T: an optimisation, the adjoint then runs on the tiles of S) and tries once more - e.g. the second
+// kernel of a joint inversion that does not fit beside the first one's copy.  g_alloc_ctx is set by the entry points that allocate.
+extern thread_local tfx_ctx *g_alloc_ctx;
+bool evict_adjoint_copies(tfx_ctx *ctx);      // matrix.hip; true when something was freed
+
 // Owning device allocation.
 template <typename T>
 struct DBuf {
@@ -57,6 +64,10 @@ struct DBuf {
         release();
         if (count == 0) return 0;
         hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipErrorOutOfMemory && g_alloc_ctx && evict_adjoint_copies(g_alloc_ctx)) {
+            (void)hipGetLastError();
+            e = hipMalloc((void **)&p, count * sizeof(T));
+        }
         if (e != hipSuccess)
             return fail(TFX_E_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
         n = count;
@@ -151,6 +162,7 @@ struct TiledMatrix {
     // of one LDS fp64 atomic per non-zero.  Optional (it doubles the matrix memory): ctx->adj_copy.
     TiledMatrix *T = nullptr;
     bool is_transpose_copy = false;
+    bool evictable = false;       // (of a copy) made in automatic mode: given up when another allocation needs the memory
     ~TiledMatrix() { delete T; }
     TiledMatrix() = default;
     TiledMatrix(const TiledMatrix &) = delete;

@@ -488,6 +488,7 @@ extern "C" {
 int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit, const double *b_data, int nblocks,
                    const float *const *diag, const double *const *rhs_blocks)
 {
+    if (ctx) tfx::g_alloc_ctx = ctx;
     if (!ctx || !b_data) return fail(TFX_E_ARG, "tfx_lsqr_begin: null argument");
     TiledMatrix &m = ctx->mat;
     if (!m.valid) return fail(TFX_E_STATE, "tfx_lsqr_begin: no matrix");

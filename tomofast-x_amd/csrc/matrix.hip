@@ -30,6 +30,25 @@
 namespace tfx {
 
 thread_local std::string g_last_error;
+thread_local tfx_ctx *g_alloc_ctx = nullptr;
+
+bool evict_adjoint_copies(tfx_ctx *ctx)
+{
+    bool freed = false;
+    for (TiledMatrix *m : {&ctx->mat, &ctx->mat2, &ctx->cons}) {
+        if (m->T && m->T->evictable) {
+            if (!freed) (void)hipDeviceSynchronize();      // (nothing may still be reading a copy)
+            const size_t bytes = m->T->device_bytes();
+            delete m->T;
+            m->T = nullptr;
+            m->vmax_stale = true;
+            freed = true;
+            fprintf(stderr, "[tfx] out of device memory: gave up the transposed copy of a matrix (%.1f GB); its adjoint runs on the tiles of S\n",
+                    (double)bytes / 1e9);
+        }
+    }
+    return freed;
+}
 
 size_t TiledMatrix::device_bytes() const
 {
@@ -268,6 +287,7 @@ constexpr int DN_THREADS = 1024;
 
 int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols)
 {
+    g_alloc_ctx = ctx;
     TiledMatrix &m = *ctx->target;
     m.release_storage();            // (whatever the slot held before: tiles, work lists, a transposed copy)
     if (nrows <= 0 || ncols <= 0) return fail(TFX_E_ARG, "matrix_begin_dense: empty matrix");
@@ -365,6 +385,7 @@ __global__ void k_dense_scale_rows(float *__restrict__ A, int64_t ld, int64_t nr
 
 int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 {
+    g_alloc_ctx = ctx;
     TiledMatrix &m = *ctx->target;
     m.release_storage();
     m.nrows = nrows;
@@ -1529,6 +1550,7 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
     }
     TiledMatrix *T = new TiledMatrix();
     T->is_transpose_copy = true;
+    T->evictable = ctx->adj_copy == 2;
     TiledMatrix *keep = ctx->target;
     auto give_up = [&](int rc) {
         // the copy is an optimisation: when the device has no room for it after all, the adjoint stays on the atomic kernel
