@@ -670,7 +670,11 @@ int matrix_finish(tfx_ctx *ctx)
             ctx->target = keep;
             TFX_TRY(rc);
         } else {
-            TFX_TRY(matrix_build_transpose(ctx, m));
+            const int rc = matrix_build_transpose(ctx, m);
+            if (rc) {                    // (only adj_copy = 1: the copy was demanded and does not fit) - the finish failed as a whole
+                m.valid = false;
+                return rc;
+            }
         }
     }
     return 0;
@@ -1592,7 +1596,6 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
             const int nr = (int)(c1 - c0);
             const int t_lo = (int)(c0 / m.TC), t_hi = (int)((c1 - 1) / m.TC);
             const int ntl = toff[(size_t)t_hi + 1] - toff[(size_t)t_lo];
-            std::vector<int32_t> h_nel((size_t)nr, 0);
             int64_t totals[2] = {0, 0};
             if (ntl > 0) {
                 const int32_t *tl = sc.tids.p + toff[(size_t)t_lo];
@@ -1602,7 +1605,6 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
                 hipLaunchKernelGGL(k_tr_scan, dim3(1), dim3(1024), 0, s, sc.cnt.p, m.nrb, RBt, nr, sc.nel.p, sc.rowoff.p, sc.totals.p);
                 TFX_HIP(hipGetLastError());
                 TFX_HIP(hipMemcpyAsync(totals, sc.totals.p, sizeof(totals), hipMemcpyDeviceToHost, s));
-                TFX_HIP(hipMemcpyAsync(h_nel.data(), sc.nel.p, (size_t)nr * sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 TFX_HIP(hipStreamSynchronize(s));
             }
             if (totals[0] == 0) continue;                  // an empty row block of S^T has no tiles
