@@ -15,6 +15,7 @@ Files written:
   lsqr.npz       S.x, S^T.y and lsqr_solve_sensit solutions for [S; C] systems        [gold_lsqr driver]
   e2e_*.npz      full `tomofastx -p Parfile` runs: SENSIT rows, weights, nnz, partition, models, data
   mansf.npz      BASELINE config 1 (parfiles/Parfile_mansf_slice.txt), trimmed
+  e2e_medium_*.npz  64x64x32 cells x 1024 data at 1 / 2 / 4 / 8 ranks (the reference's own cross-rank scatter)  [make_golden.py medium_e2e]
 """
 import os
 import re
@@ -431,6 +432,59 @@ def make_e2e(tmp):
                         X1=g[0], X2=g[1], Y1=g[2], Y2=g[3], Z1=g[4], Z2=g[5], obs=obs, model_true=mtrue))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
         print(name + ".npz: nnz", res["np1_nnz_total"], "partition np2", res["np2_nelements_at_cpu"])
+
+
+def make_medium_e2e(tmp):
+    """Mid-scale runs of the reference: 64x64x32 cells (131 072) x 32x32 data (1 024), Haar and D4 at r = 0.05,
+    2 x 100 LSQR iterations, at 1, 2, 4 and 8 MPI ranks - so that the reference's OWN scatter between rank counts at this size and
+    conditioning is a number next to which the HIP path's distance can be stated.  Kept: the 1-rank final model and data, the
+    per-column nnz histogram, 8 full SENSIT rows spread over the data, the costs; of the other rank counts the final model's
+    distance from the 1-rank one (and the 8-rank model itself as fp32 deltas would add nothing: only the distances are kept)."""
+    nx, ny, nz, ox, oy = 64, 64, 32, 32, 32
+    g, obs, mtrue = synthetic_problem(nx, ny, nz, ox, oy)
+    nd = obs.shape[0]
+    inp = os.path.join(tmp, "medium_inputs")
+    os.makedirs(inp, exist_ok=True)
+    write_grid_file(os.path.join(inp, "grid.txt"), g, nx, ny, nz)
+    with open(os.path.join(inp, "data_grid.txt"), "w") as f:
+        f.write("%d\n" % nd)
+        for r in obs:
+            f.write("%.17g %.17g %.17g 0.0\n" % tuple(r))
+    with open(os.path.join(inp, "model_true.txt"), "w") as f:
+        f.write("%d\n" % mtrue.size)
+        for v in mtrue:
+            f.write("%.17g\n" % v)
+    links = [(os.path.join(inp, n), n) for n in ("grid.txt", "data_grid.txt", "model_true.txt")]
+    keep_rows = np.linspace(0, nd - 1, 8).astype(int)
+    for name, ctype in (("e2e_medium_haar", 1), ("e2e_medium_d4", 2)):
+        c = dict(nx=nx, ny=ny, nz=nz, ctype=ctype, rate="0.05d0", nmajor=2, nminor=100, alpha="1.d-7", dwtype=1)
+        par = PAR_TMPL.format(nd=nd, **c)
+        res, models = {}, {}
+        for nproc in (1, 2, 4, 8):
+            wd, log = run_parfile(tmp, name, par, nproc, workdir_links=links)
+            o = collect_run(wd, log, "out", nproc)
+            models[nproc] = o["model_final"]
+            if nproc == 1:
+                rp = o["row_ptr"]
+                res.update(dict(model_final=o["model_final"], data_final=o["data_final"], data_observed=o["data_observed"], costs=o["costs"],
+                                sensit_nnz=o["sensit_nnz"], column_weight=o["column_weight"], comp_error=o["comp_error"],
+                                nnz_total=o["nnz_total"], row_nel=o["row_nel"], lsqr_r=o["lsqr_r"], rows_kept=keep_rows.astype(np.int64),
+                                row_ptr=np.concatenate([[0], np.cumsum([rp[r + 1] - rp[r] for r in keep_rows])]).astype(np.int64),
+                                cols=np.concatenate([o["cols"][rp[r]:rp[r + 1]] for r in keep_rows]),
+                                vals=np.concatenate([o["vals"][rp[r]:rp[r + 1]] for r in keep_rows])))
+            else:
+                res["np%d_nelements_at_cpu" % nproc] = o["nelements_at_cpu"]
+                res["np%d_nnz_total" % nproc] = o["nnz_total"]
+                res["np%d_costs" % nproc] = o["costs"]
+                res["np%d_lsqr_r" % nproc] = o["lsqr_r"]
+                res["np%d_model_rel_l2_vs_np1" % nproc] = np.linalg.norm(o["model_final"] - models[1]) / np.linalg.norm(models[1])
+                res["np%d_model_max_abs_vs_np1" % nproc] = np.abs(o["model_final"] - models[1]).max()
+                res["np%d_data_rel_l2_vs_np1" % nproc] = np.linalg.norm(o["data_final"] - res["data_final"]) / np.linalg.norm(res["data_final"])
+            shutil.rmtree(wd, ignore_errors=True)
+        res.update(dict(parfile=par, nx=nx, ny=ny, nz=nz, ox=ox, oy=oy, ctype=ctype, rate=0.05, nmajor=2, nminor=100, alpha=1e-7))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+        print(name + ".npz: nnz", res["nnz_total"], "comp error", res["comp_error"], "model scatter vs np1:",
+              {k: float(res["np%d_model_rel_l2_vs_np1" % k]) for k in (2, 4, 8)}, "lsqr r", res["lsqr_r"])
 
 
 PAR_MAG = """global.outputFolderPath     = out/

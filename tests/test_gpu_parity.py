@@ -932,6 +932,79 @@ def test_end_to_end_inversion_vs_reference(ctx, golden_dir, name):
     assert abs(hist[-1]["cost"] - cost_ref) <= 1e-5 * cost_ref + 1e-16
 
 
+@pytest.mark.parametrize("name", ["e2e_medium_haar", "e2e_medium_d4"])
+def test_medium_scale_end_to_end_vs_reference(ctx, golden_dir, name):
+    """Mid-scale parity against the REFERENCE'S OWN OUTPUT (tests/golden/e2e_medium_*.npz: 64x64x32 cells x 1024 data, r = 0.05,
+    2 x 100 LSQR iterations, run by oracle/_ref/tomofastx at 1, 2, 4 and 8 ranks): the kernel (nnz, per-column histogram, 8 full
+    SENSIT rows, compression error), the final model, the data and the LSQR residuals.  The reference's own scatter between its
+    rank counts on these runs is 6e-10 .. 1.4e-9 in the final model (stored in the fixture); the HIP path differs from the
+    1-rank run by the same reordering of the sums PLUS last-bit differences of device log / atan2 in the kernel values (a
+    1-ulp-of-fp32 perturbation of a few entries of S) - its distance is asserted against a stated tolerance and
+    written to gpurun_out/ so that profiles/ can carry the measured number."""
+    import json
+    g = load(golden_dir, name)
+    nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
+    N, ctype, rate = nx * ny * nz, int(g["ctype"]), float(g["rate"])
+    grid = tfx.synthetic.grid(nx, ny, nz)
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, int(g["ox"]), int(g["oy"]))
+    nd = xs.size
+    ctx.set_grid(nx, ny, nz, *grid)
+    cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+    assert np.max(np.abs(cw - g["column_weight"]) / g["column_weight"]) <= 1e-14
+    res = ctx.calculate_sensit(xs, ys, zs, cw, ctype, rate, want_hist=True)
+    # ---- the kernel
+    assert abs(res["nnz"] - int(g["nnz_total"])) <= 2 * nd
+    assert abs(res["comp_error"] - float(g["comp_error"])) <= 1e-9 * float(g["comp_error"])
+    hist_same = float(np.mean(res["nnz_hist"] == g["sensit_nnz"]))
+    assert hist_same >= 0.9999, hist_same
+    for k in (2, 4, 8):     # the reference's partition at 2 / 4 / 8 ranks from the histogram built here (exact unless a tie flipped)
+        nel, _ = tfx.get_load_balancing_nelements(res["nnz_hist"], k)
+        assert np.all(np.abs(nel - g["np%d_nelements_at_cpu" % k]) <= 2)
+    rp, cols, vals = ctx.matrix_download_csr()
+    same = total = 0
+    worst_ulp, worst_rel_scale = 0, 0.0
+    for i, r in enumerate(g["rows_kept"]):
+        cb, vb = cols[rp[r]:rp[r + 1]], vals[rp[r]:rp[r + 1]]
+        cr, vr = g["cols"][g["row_ptr"][i]:g["row_ptr"][i + 1]], g["vals"][g["row_ptr"][i]:g["row_ptr"][i + 1]]
+        common, ib, ir = np.intersect1d(cb, cr, return_indices=True)
+        same += common.size
+        total += max(cb.size, cr.size)
+        ulp = np.abs(vb[ib].view(np.int32).astype(np.int64) - vr[ir].view(np.int32).astype(np.int64))
+        worst_ulp = max(worst_ulp, int(ulp.max()))
+        worst_rel_scale = max(worst_rel_scale, float(np.abs(vb[ib].astype(np.float64) - vr[ir]).max() / np.abs(vr).max()))
+    frac = same / total
+    assert frac >= 0.9999, frac
+    assert worst_rel_scale <= 1e-8, (worst_ulp, worst_rel_scale)
+    # ---- the inversion
+    m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, ctype, g["data_observed"], int(g["nmajor"]), int(g["nminor"]), alpha=float(g["alpha"]))
+    ref = g["model_final"]
+    model_rel = float(np.linalg.norm(m - ref) / np.linalg.norm(ref))
+    data_rel = float(np.linalg.norm(d - g["data_final"]) / np.linalg.norm(g["data_final"]))
+    cost_ref = float(np.linalg.norm(g["data_final"] - g["data_observed"]) / np.linalg.norm(g["data_observed"]))
+    cost_rel = abs(hist[-1]["cost"] - cost_ref) / cost_ref
+    ref_scatter = max(float(g["np%d_model_rel_l2_vs_np1" % k]) for k in (2, 4, 8))
+    out = {"fixture": name, "cells": N, "data": nd, "nnz": int(res["nnz"]), "nnz_reference": int(g["nnz_total"]),
+           "column_histogram_identical": hist_same, "rows_identical_sparsity": frac, "rows_worst_fp32_ulp": worst_ulp,
+           "rows_worst_diff_over_row_max": worst_rel_scale, "model_rel_l2_vs_reference_np1": model_rel,
+           "reference_own_scatter_np2_4_8_vs_np1": ref_scatter, "data_rel_l2": data_rel, "data_cost_rel_diff": cost_rel,
+           "data_cost": hist[-1]["cost"], "data_cost_reference": cost_ref}
+    print(json.dumps(out))
+    try:
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+        json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "medium_parity_%s.json" % name), "w"), indent=1)
+    except OSError:
+        pass
+    # Stated tolerance at this scale (DESIGN.md 4): final model 5e-8 (measured 4.7e-9 = 7 x the reference's own rank-count
+    # scatter), calculated data 1e-8 (measured 8.5e-10).  The data cost |d_calc - d_obs| / |d_obs| of these converged runs is 2.8e-9,
+    # i.e. of the size of the data tolerance itself: it is bounded in absolute terms (1e-8 of |d_obs|), its relative difference is
+    # recorded, not asserted.
+    assert model_rel <= 5e-8, out
+    assert data_rel <= 1e-8 and abs(hist[-1]["cost"] - cost_ref) <= 1e-8, out
+    # a second solve gives the same bits (reproducible products, fixed-order reductions)
+    m2, d2, _ = tfx.inversion.solve_problem_gravity(ctx, cw, ctype, g["data_observed"], int(g["nmajor"]), int(g["nminor"]), alpha=float(g["alpha"]))
+    assert bits_equal(m2, m) and bits_equal(d2, d)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # gradiometry / multi-component kernels (SURVEY 8f-4)
 def test_gradiprism_rows_vs_reference(ctx, golden_dir):
