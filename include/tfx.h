@@ -82,9 +82,13 @@ int tfx_set_allgatherv(tfx_ctx *ctx, tfx_allgatherv_fn fn);
 int tfx_comm_unique_id(char *id_out /* [TFX_COMM_ID_BYTES] */);
 int tfx_comm_init_rccl(tfx_ctx *ctx, const char *unique_id /* [TFX_COMM_ID_BYTES] */, int rank, int nranks);
 int tfx_comm_destroy(tfx_ctx *ctx);
-/* Start-up that can not strand a rank: the hosts wrap tfx_comm_init_rccl in "try - agree over the control channel (MPI / gloo) -
- * fall back to the hooks"; a rank whose own call succeeded while another rank's failed drops its half-open communicator with
- * tfx_comm_abort (ncclCommAbort: no hand-shake with the peers).                                                              */
+/* Start-up that can not strand a rank.  (i) tfx_comm_init_rccl itself gives up: the blocking rendezvous (ncclCommInitRank) runs
+ * on a helper thread inside the library and the call returns TFX_E_COMM when it has not completed within the timeout (120 s;
+ * environment TFX_COMM_INIT_TIMEOUT or tfx_debug_set "comm_init_timeout_s"; <= 0 waits for ever) - a peer that died BEFORE the
+ * rendezvous costs the timeout, in every host language.  (ii) The hosts wrap the call in "try - agree over the control channel
+ * (MPI / gloo) - fall back to the hooks"; a rank whose own call succeeded while another rank's failed drops its half-open
+ * communicator with tfx_comm_abort (ncclCommAbort: no hand-shake with the peers).  tfx_comm_abort from another thread while a
+ * rendezvous of the ctx is in flight cancels exactly that attempt (it never installs its communicator).                        */
 int tfx_comm_abort(tfx_ctx *ctx);
 /* Facts for the bench line / logs: ranks the communicator itself counts (ncclCommCount; 0 without a communicator), this rank's
  * index and device in it, ncclGetVersion, and the file the nccl* symbols come from (libtfx.so depends on librccl.so.1: a process

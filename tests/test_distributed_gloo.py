@@ -145,6 +145,10 @@ class LadderCtx:
         self.calls.append("abort")
         self.has_comm = False
 
+    def debug_set(self, key, value=0):
+        self.calls.append("debug_set %s=%s" % (key, value))
+        return 0
+
     def comm_info(self):
         return dict(rccl_ranks=0, rccl_rank=-1, rccl_device=-1, rccl_version=0, librccl="scripted")
 

@@ -3,7 +3,7 @@
 * world size 1 through the whole multi-rank start-up (TFX_BENCH_FORCE_COMM=1 under torch.distributed.run): the gloo control group
   carries the 128-byte id, the ladder of distributed.setup_comm runs (pre-flight -> tfx_comm_init_rccl -> first collectives), the
   communicator counts 1 rank, LSQR's reductions are real ncclAllReduce calls in-stream - and the residual has the bits of the
-  plain single-rank run (deterministic product mode).
+  plain single-rank run (the products are reproducible: fixed summation order / exact integer accumulation).
 * 2 and 8 ranks launched exactly as the driver launches them (`python -m torch.distributed.run --nproc-per-node N ... bench.py
   --gpus N`), all on GPU 0: the pre-flight sees that the ranks share a GPU, every rank takes the hook rung TOGETHER, the
   row-parallel build with balanced data ranges + relayout, the partition, the N-rank LSQR and the per-rank report all run, and
@@ -40,7 +40,7 @@ def _run_bench(nranks, workload, extra_env=None, steps=12, warmup=2, port=29640,
 
 @pytest.fixture(scope="module")
 def plain_small():
-    out, _ = _run_bench(1, "small", {"TFX_DETERMINISTIC": "1"}, launcher=False)
+    out, _ = _run_bench(1, "small", {}, launcher=False)
     assert out["comm"]["path"] == "single rank"
     return out
 
@@ -50,7 +50,7 @@ def test_world_size_1_through_the_rccl_startup_has_the_bits_of_the_plain_run(pla
     """backend = the default torch.distributed group: gloo (the bench's default: the only RCCL user in the process is libtfx.so) or
     nccl (torch opens its own RCCL communicator eagerly next to the library's: both live in one process and share the one mapped
     librccl)."""
-    out, err = _run_bench(1, "small", {"TFX_DETERMINISTIC": "1", "TFX_BENCH_FORCE_COMM": "1", "TFX_BENCH_BACKEND": backend},
+    out, err = _run_bench(1, "small", {"TFX_BENCH_FORCE_COMM": "1", "TFX_BENCH_BACKEND": backend},
                           port=29641 + (backend == "nccl"))
     comm = out["comm"]
     assert comm["path"].startswith("RCCL inside libtfx.so"), comm
@@ -63,7 +63,7 @@ def test_world_size_1_through_the_rccl_startup_has_the_bits_of_the_plain_run(pla
 
 @pytest.mark.parametrize("nranks,workload", [(2, "medium"), (8, "small")])
 def test_ranks_launched_like_the_driver_does_share_the_gpu_and_fall_back_together(nranks, workload, plain_small):
-    out, err = _run_bench(nranks, workload, {"TFX_DETERMINISTIC": "1"}, port=29650 + nranks)
+    out, err = _run_bench(nranks, workload, {}, port=29650 + nranks)
     comm = out["comm"]
     assert out["n_gpus"] == nranks and out["scaling"] == "strong"
     assert comm["path"].startswith("torch.distributed hooks"), comm
@@ -78,6 +78,22 @@ def test_ranks_launched_like_the_driver_does_share_the_gpu_and_fall_back_togethe
     if workload == "small":           # the same problem as the single-rank run: same matrix, same residual after the same iterations
         assert out["config"]["nnz"] == plain_small["config"]["nnz"]
         assert abs(out["final_r"] - plain_small["final_r"]) <= 1e-9 * abs(plain_small["final_r"]), (out["final_r"], plain_small["final_r"])
+
+
+def test_plain_python_bench_gpus_2_launches_its_own_ranks(plain_small):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (no WORLD_SIZE in the environment): bench.py re-runs itself under the
+    launcher (free port on 127.0.0.1) instead of exiting - one JSON line with n_gpus = 2, the same result as the launched form."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "12", "--warmup", "2", "--workload", "small", "--no-cpu"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["per_rank"]) == 2 and out["timed_repeats"] == 3 and len(out["ms_per_step_runs"]) == 3
+    assert "without a launcher" in p.stderr
+    assert out["config"]["nnz"] == plain_small["config"]["nnz"]
+    assert abs(out["final_r"] - plain_small["final_r"]) <= 1e-9 * abs(plain_small["final_r"])
 
 
 def test_tfx_comm_rccl_insists_and_fails_loudly_when_ranks_share_a_gpu():

@@ -514,9 +514,9 @@ def test_row_parallel_build_with_mpi_relayout(tmp_path):
             f.write("%d\n" % n)
             f.write("\n".join("%.17g" % v for v in mtrue) + "\n")
         open(os.path.join(wd, "Parfile.txt"), "w").write(PAR_BIG.format(nd=xs.size))
-        # deterministic products (single-wave workgroups, fixed LDS accumulation order): the comparison below is between runs
-        # that stop mid-convergence, where run-to-run atomics order would otherwise decide the outcome now and then
-        e = dict(os.environ, TFX_WRITE_SENSIT="0", TFX_DETERMINISTIC="1", **env)
+        # (the products are reproducible - fixed summation order / exact integer accumulation - so runs that stop mid-convergence
+        # can be compared: nothing run-dependent decides the outcome)
+        e = dict(os.environ, TFX_WRITE_SENSIT="0", **env)
         out = subprocess.run(cmd + ["-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900, env=e)
         assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
         if tag == "exchange":
@@ -530,9 +530,8 @@ def test_row_parallel_build_with_mpi_relayout(tmp_path):
         m, nnz = models[tag]
         assert nnz == nnz_ref
         # 2 x 8 LSQR iterations stop mid-convergence, where the Golub-Kahan recurrence amplifies the last-bit differences of
-        # a different summation order (3 ranks instead of 1): typically 1e-6, once in ~25 runs 3e-3 with the run-dependent order
-        # of the LDS atomics - hence TFX_DETERMINISTIC above.  A relayout error (a row piece on the wrong rank, shifted
-        # columns) changes the model at the 1e-1 level.
+        # a different summation order (3 ranks instead of 1): typically 1e-6.  A relayout error (a row piece on the wrong rank,
+        # shifted columns) changes the model at the 1e-1 level.
         assert np.linalg.norm(m - ref) <= 1e-4 * np.linalg.norm(ref), (tag, np.linalg.norm(m - ref) / np.linalg.norm(ref))
     assert np.linalg.norm(models["exchange"][0] - models["redundant"][0]) <= 1e-4 * np.linalg.norm(ref)
 
@@ -574,7 +573,7 @@ def test_sensit_files_of_a_multi_rank_run(tmp_path):
         assert "sensit.readFromFiles" in par
         open(os.path.join(wd, "Parfile.txt"), "w").write(par.format(nd=xs.size) + "sensit.folderPath                   = out/SENSIT/\n")
         out = subprocess.run(cmd + ["-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900,
-                             env=dict(os.environ, TFX_DETERMINISTIC="1"))          # (mid-convergence comparison below)
+                             env=dict(os.environ))
         assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
         models[tag] = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
         if tag != "reload":

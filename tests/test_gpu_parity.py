@@ -905,7 +905,7 @@ def test_build_kernel_vs_reference_sensit(ctx, golden_dir, name):
     built = ctx.matrix_download_csr()
     ref = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
     frac, maxulp = compare_built_matrix(built, ref, obs.shape[0])
-    assert frac >= 0.999 and maxulp <= 2, (frac, maxulp)
+    assert frac >= 0.9999 and maxulp <= 2, (frac, maxulp)          # >= 99.99 % identical sparsity (measured: 1.0)
     assert abs(res["nnz"] - int(g["np1_nnz_total"])) <= 2 * obs.shape[0]
     assert int(res["nnz_hist"].sum()) == res["nnz"]
     if int(g["ctype"]) > 0:
@@ -1079,7 +1079,7 @@ def test_build_multicomponent_kernel_vs_reference_sensit(ctx, golden_dir, name):
     ref = (sub_rp[::ncm], (g["np1_cols"] + kk * N).astype(np.int32), g["np1_vals"])
     frac, maxulp = compare_built_matrix(built, ref, obs.shape[0] * ncd)
     # magnetic tensor entries cancel heavily: fp32 values of small coefficients may move by more than 2 ulp
-    assert frac >= 0.995 and (maxulp <= 2 or int(g["prob"]) == 2), (frac, maxulp)
+    assert frac >= 0.9999 and (maxulp <= 2 or int(g["prob"]) == 2), (frac, maxulp)
     assert abs(res["nnz"] - int(g["np1_nnz_total"])) <= 2 * obs.shape[0] * ncd * ncm
     assert int(res["nnz_hist"].sum()) == res["nnz"]
     if int(g["ctype"]) > 0:
@@ -1465,7 +1465,7 @@ def test_config1_mansf_end_to_end(ctx, golden_dir):
     built = ctx.matrix_download_csr()
     n8 = int(g["row_ptr"][-1])
     frac, maxulp = compare_built_matrix((built[0][:9], built[1], built[2]), (g["row_ptr"], g["cols"][:n8], g["vals"][:n8]), 8)
-    assert frac >= 0.999 and maxulp <= 2
+    assert frac >= 0.9999 and maxulp <= 2
     m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, 1, g["data_observed"], 60, 100, alpha=0.0,
                                                      admm=dict(bounds=g["admm_bounds"], rho=float(g["admm_weight"])))
     ref = g["model_final"]
@@ -1492,7 +1492,7 @@ def test_medium_synthetic_build_vs_oracle_and_adjoint_identity(ctx):
         c_ref, v_ref, _ = orc.build_row_grav(grid, (nx, ny, nz), cw_o, (xs[r], ys[r], zs[r]), 1, K)
         cb, vb = cols[rp[r]:rp[r + 1]], vals[rp[r]:rp[r + 1]]
         common, ib, ir = np.intersect1d(cb, c_ref, return_indices=True)
-        assert common.size >= 0.999 * c_ref.size
+        assert common.size >= 0.9999 * c_ref.size
         assert np.max(np.abs(vb[ib].view(np.int32).astype(np.int64) - v_ref[ir].view(np.int32).astype(np.int64))) <= 2
     rng = np.random.default_rng(0)
     x, x2, y = rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(xs.size)
@@ -1678,7 +1678,7 @@ def test_full_size_build_properties_and_sampled_rows_vs_oracle(ctx, name):
             cb = np.nonzero(row)[0] + 1
             c_ref, v_ref, _ = orc.build_row_grav(grid, (nx, ny, nz), cw_o, (xs[r], ys[r], zs[r]), c["ctype"], K)
             common, ib, ir = np.intersect1d(cb, c_ref, return_indices=True)
-            assert common.size >= 0.999 * c_ref.size and abs(cb.size - c_ref.size) <= 0.001 * c_ref.size
+            assert common.size >= 0.9999 * c_ref.size and abs(cb.size - c_ref.size) <= 0.0001 * c_ref.size + 2
             vb = row[cb - 1].astype(np.float32)
             # fp32 values: within 2 ulp, or within 1e-8 of the row's largest entry.  The device libm and the host libm differ in
             # the last bits of log / atan2; the 8 corner terms of a cell (~1e5 each) cancel to ~1e-3 of their size and the

@@ -26,6 +26,7 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (const char *e = getenv("TFX_ADJ_COPY")) c->adj_copy = std::max(0, std::min(2, atoi(e)));   // like tfx_debug_set "adj_copy"
+    if (const char *e = getenv("TFX_COMM_INIT_TIMEOUT")) c->comm_init_timeout_s = atof(e);
     if (const char *e = getenv("TFX_FWD_RUN")) c->fwd_run = std::max(1, atoi(e));
     if (const char *e = getenv("TFX_ADJ_COPY_MIN_NNZ")) c->adj_copy_min_nnz = atoll(e);
     if (const char *e = getenv("TFX_CHAIN_UNDER_WAVELET")) c->chain_under_wavelet = atoi(e) != 0;
@@ -211,6 +212,10 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
     }
     if (!strcmp(key, "force_collectives")) {    // issue the collectives of the multi-rank path even on one rank
         ctx->force_collectives = value != 0;
+        return 0;
+    }
+    if (!strcmp(key, "comm_init_timeout_s")) {  // how long tfx_comm_init_rccl waits for the rendezvous (<= 0: for ever)
+        ctx->comm_init_timeout_s = (double)value;
         return 0;
     }
     if (!strcmp(key, "fwd_run")) {              // chunks per run of the forward kernel (>= 1); the sums stay reproducible for a fixed value

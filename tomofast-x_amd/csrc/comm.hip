@@ -14,6 +14,9 @@
 #include "common.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
+#include <thread>
 
 namespace tfx {
 
@@ -90,22 +93,76 @@ int tfx_comm_unique_id(char *id_out)
     return 0;
 }
 
+// One rendezvous attempt.  ncclCommInitRank blocks until every rank has arrived; a peer that died before the rendezvous would hold
+// the caller for ever, so the call runs on a helper thread and the caller waits for it with a timeout.  The state is shared between
+// the two and owned by neither (the helper may outlive the ctx): an abandoned or cancelled attempt that still completes aborts its
+// own communicator.
+struct InitAttempt {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;        // the helper has a result
+    bool orphaned = false;    // the caller stopped waiting (timeout) or the attempt was cancelled (tfx_comm_abort): nobody will take the result
+    ncclResult_t res = ncclSuccess;
+    ncclComm_t comm = nullptr;
+};
+
 int tfx_comm_init_rccl(tfx_ctx *ctx, const char *unique_id, int rank, int nranks)
 {
     if (!ctx || !unique_id) return fail(TFX_E_ARG, "tfx_comm_init_rccl: null argument");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(TFX_E_ARG, "bad rank %d / %d", rank, nranks);
-    if (ctx->comm) return fail(TFX_E_STATE, "tfx_comm_init_rccl: the context already has a communicator");
-    TFX_HIP(hipSetDevice(ctx->device));
+    auto at = std::make_shared<InitAttempt>();
+    {
+        std::lock_guard<std::mutex> g(ctx->comm_mu);
+        if (ctx->comm) return fail(TFX_E_STATE, "tfx_comm_init_rccl: the context already has a communicator");
+        if (ctx->comm_pending) return fail(TFX_E_STATE, "tfx_comm_init_rccl: another rendezvous of this context is still in flight");
+        ctx->comm_pending = at;                 // from here on tfx_comm_abort cancels THIS attempt
+    }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
-    ncclComm_t c = nullptr;
-    ctx->comm_cancelled = false;
-    TFX_NCCL(ncclCommInitRank(&c, nranks, id, rank));
-    if (ctx->comm_cancelled) {          // the host gave up on this rendezvous (timeout) while it was in flight and moved on to the hooks
-        (void)ncclCommAbort(c);
-        return fail(TFX_E_COMM, "tfx_comm_init_rccl: cancelled by tfx_comm_abort while the rendezvous was in flight");
+    const int device = ctx->device;
+    std::thread([at, id, rank, nranks, device]() {
+        ncclComm_t c = nullptr;
+        ncclResult_t r = hipSetDevice(device) == hipSuccess ? ncclCommInitRank(&c, nranks, id, rank) : ncclUnhandledCudaError;
+        std::unique_lock<std::mutex> lk(at->mu);
+        if (at->orphaned) {
+            lk.unlock();
+            if (r == ncclSuccess && c) (void)ncclCommAbort(c);
+            return;
+        }
+        at->res = r;
+        at->comm = c;
+        at->done = true;
+        at->cv.notify_all();
+    }).detach();
+    bool timed_out = false, cancelled = false;
+    {
+        std::unique_lock<std::mutex> lk(at->mu);
+        auto ready = [&] { return at->done || at->orphaned; };
+        if (ctx->comm_init_timeout_s > 0) {
+            if (!at->cv.wait_for(lk, std::chrono::duration<double>(ctx->comm_init_timeout_s), ready)) {
+                at->orphaned = true;
+                timed_out = true;
+            }
+        } else {
+            at->cv.wait(lk, ready);
+        }
+        cancelled = at->orphaned && !timed_out;
     }
-    ctx->comm = (void *)c;
+    std::lock_guard<std::mutex> g(ctx->comm_mu);
+    if (ctx->comm_pending == std::static_pointer_cast<void>(at)) ctx->comm_pending.reset();
+    if (timed_out)
+        return fail(TFX_E_COMM, "tfx_comm_init_rccl: the rendezvous did not complete within %.0f s (a peer that never arrived?)", ctx->comm_init_timeout_s);
+    {
+        // (a cancel that arrived between the helper's result and this point: the flag is re-read under both locks)
+        std::lock_guard<std::mutex> la(at->mu);
+        if (at->orphaned) cancelled = true;
+        if (cancelled) {
+            if (at->done && at->res == ncclSuccess && at->comm) (void)ncclCommAbort(at->comm);
+            return fail(TFX_E_COMM, "tfx_comm_init_rccl: cancelled by tfx_comm_abort while the rendezvous was in flight");
+        }
+    }
+    if (at->res != ncclSuccess) return fail(TFX_E_COMM, "ncclCommInitRank: %s", ncclGetErrorString(at->res));
+    ctx->comm = (void *)at->comm;
     ctx->rank = rank;
     ctx->nranks = nranks;
     return 0;
@@ -114,6 +171,7 @@ int tfx_comm_init_rccl(tfx_ctx *ctx, const char *unique_id, int rank, int nranks
 int tfx_comm_destroy(tfx_ctx *ctx)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    std::lock_guard<std::mutex> g(ctx->comm_mu);
     if (ctx->comm) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
@@ -131,14 +189,20 @@ int tfx_comm_destroy(tfx_ctx *ctx)
 int tfx_comm_abort(tfx_ctx *ctx)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
+    std::lock_guard<std::mutex> g(ctx->comm_mu);
     if (ctx->comm) {
         (void)hipSetDevice(ctx->device);
         ncclResult_t r = ncclCommAbort(comm_of(ctx));
         ctx->comm = nullptr;
         if (!ctx->allreduce) { ctx->rank = 0; ctx->nranks = 1; }
         if (r != ncclSuccess) return fail(TFX_E_COMM, "ncclCommAbort: %s", ncclGetErrorString(r));
-    } else {
-        ctx->comm_cancelled = true;     // a tfx_comm_init_rccl still in flight on another thread must not install its communicator
+    } else if (ctx->comm_pending) {
+        // a tfx_comm_init_rccl in flight on another thread: that attempt must not install its communicator (whoever finishes last -
+        // the waiting caller or the helper thread - aborts it)
+        InitAttempt *at = static_cast<InitAttempt *>(ctx->comm_pending.get());
+        std::lock_guard<std::mutex> la(at->mu);
+        at->orphaned = true;
+        at->cv.notify_all();
     }
     return 0;
 }

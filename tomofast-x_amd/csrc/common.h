@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/tfx.h"
@@ -221,7 +223,11 @@ struct tfx_ctx {
     // scratch vectors for spmv / spmtv with host pointers
     tfx::DBuf<double> vx, vb, vw;
     // comm
-    volatile bool comm_cancelled = false;  // tfx_comm_abort while tfx_comm_init_rccl is in flight (start-up ladder of the hosts)
+    // comm.hip.  comm_mu guards `comm` and `comm_pending` (check-and-install of tfx_comm_init_rccl against tfx_comm_abort from another
+    // thread); comm_pending is the rendezvous that is in flight, so that an abort can cancel exactly that attempt.
+    std::mutex comm_mu;
+    std::shared_ptr<void> comm_pending;
+    double comm_init_timeout_s = 120.0; // tfx_comm_init_rccl gives up after this long (TFX_COMM_INIT_TIMEOUT / debug key "comm_init_timeout_s"; <= 0: waits for ever)
     void *comm = nullptr;              // ncclComm_t (comm.hip): when set, every collective of the path is RCCL on the ctx stream
     tfx_allreduce_fn allreduce = nullptr;
     tfx_allgatherv_fn allgatherv = nullptr;

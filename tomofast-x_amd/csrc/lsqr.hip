@@ -529,24 +529,32 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     if (ctx->spatial_unknowns) {
         const int64_t n123 = (int64_t)ctx->wd_n1 * ctx->wd_n2 * ctx->wd_n3;
         if (ctx->multi()) {
-            // this rank's unknowns are the cells [col_begin, col_begin + nloc) of every model component
-            if (ctx->wd_col_begin < 0 || ctx->wd_ncomp <= 0)
-                return fail(TFX_E_STATE, "multi-rank WAVELET_DOMAIN = F: call tfx_lsqr_set_partition first");
-            if (nc % ctx->wd_ncomp != 0 || ctx->wd_col_begin + nc / ctx->wd_ncomp > n123)
-                return fail(TFX_E_STATE, "the column partition does not match the matrix (%lld local columns, %d components)", (long long)nc, ctx->wd_ncomp);
-            TFX_TRY(L->twf.ensure((size_t)(ctx->wd_ncomp * n123)));
+            // this rank's unknowns are the cells [col_begin, col_begin + nloc) of every model component.  A partition that is wrong on
+            // THIS rank only (not set, not matching the local matrix) is not an early return: the rank publishes a "bad" flag in the
+            // same all-reduce that builds the table, and all ranks fail together after it - nobody is left inside the collective
+            const bool local_bad = ctx->wd_col_begin < 0 || ctx->wd_ncomp <= 0 || nc % std::max(1, ctx->wd_ncomp) != 0 ||
+                                   ctx->wd_col_begin + nc / std::max(1, ctx->wd_ncomp) > n123;
             // first cell and cell count of every rank: each rank puts its own pair into a zero vector, the sum is the table (exact:
             // integers < 2^53).  EVERY rank validates the WHOLE table - the same data on all of them, so a range that is out of order,
             // overlapping or does not tile the model makes all ranks fail together instead of leaving some inside a collective with a
-            // negative length (ADVICE r2)
+            // negative length (ADVICE r2, r3)
             const int P = ctx->nranks;
-            TFX_TRY(ctx->vx.ensure((size_t)std::max<int64_t>(2 * P, nc)));
-            std::vector<double> hb((size_t)(2 * P), 0.0);
-            hb[(size_t)ctx->rank] = (double)ctx->wd_col_begin;
-            hb[(size_t)(P + ctx->rank)] = (double)(nc / ctx->wd_ncomp);
+            TFX_TRY(ctx->vx.ensure((size_t)std::max<int64_t>(3 * P, nc)));
+            std::vector<double> hb((size_t)(3 * P), 0.0);
+            if (!local_bad) {
+                hb[(size_t)ctx->rank] = (double)ctx->wd_col_begin;
+                hb[(size_t)(P + ctx->rank)] = (double)(nc / ctx->wd_ncomp);
+            }
+            hb[(size_t)(2 * P + ctx->rank)] = local_bad ? 1.0 : 0.0;
             TFX_TRY(copy_any(ctx->vx.p, hb.data(), hb.size() * sizeof(double), s));
-            TFX_TRY(allreduce(ctx, ctx->vx.p, 2 * P));
+            TFX_TRY(allreduce(ctx, ctx->vx.p, 3 * P));
             TFX_TRY(copy_any(hb.data(), ctx->vx.p, hb.size() * sizeof(double), s));
+            for (int r = 0; r < P; ++r)
+                if (hb[(size_t)(2 * P + r)] != 0.0)
+                    return fail(TFX_E_STATE, "multi-rank WAVELET_DOMAIN = F: rank %d has no column partition that matches its matrix "
+                                "(tfx_lsqr_set_partition not called, or %lld local columns do not divide into its components / exceed the grid)",
+                                r, (long long)nc);
+            TFX_TRY(L->twf.ensure((size_t)(ctx->wd_ncomp * n123)));
             L->g_counts.assign((size_t)P, 0);
             L->g_displs.assign((size_t)P, 0);
             int64_t expect = 0;

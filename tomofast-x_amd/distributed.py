@@ -232,7 +232,12 @@ def _call_with_timeout(fn, seconds):
     th = threading.Thread(target=run, daemon=True)
     th.start()
     th.join(seconds)
+    if th.is_alive():
+        _stragglers.append(th)          # still inside a collective: fail_all aborts the communicator and then waits for it
     return bool(box.get("done")), box.get("exc")
+
+
+_stragglers = []
 
 
 def setup_comm(ctx, rank, nranks, device_index=0, want_rccl=None, log=None, init_timeout=None, force=False):
@@ -308,6 +313,13 @@ def _try_rccl(ctx, rank, nranks, device_index, timeout, report):
             ctx.comm_abort()
         except Exception:      # noqa
             pass
+        # a helper thread that timed out inside a collective returns once its communicator is aborted: wait for it, so that nothing
+        # still drives the ctx when the hooks are installed (a thread that does not come back leaves the ctx unusable for RCCL)
+        while _stragglers:
+            th = _stragglers.pop()
+            th.join(5.0)
+            if th.is_alive():
+                ctx._rccl_poisoned = True
         why = "%s: %s" % (stage, next((("rank %d: %s" % (r, x)) for r, x in enumerate(reasons) if x), "unknown"))
         step.append({"stage": stage, "ok": False, "why": why})
         return why
@@ -339,7 +351,10 @@ def _try_rccl(ctx, rank, nranks, device_index, timeout, report):
     box = [uid]
     dist.broadcast_object_list(box, src=0, group=grp)
     uid = box[0]
-    done, exc = _call_with_timeout(lambda: ctx.comm_init_rccl(uid, rank, nranks), timeout)
+    # the rendezvous gives up by itself after `timeout` (a helper thread inside libtfx.so, tfx_comm_init_rccl); the wrapper here is
+    # the belt to those braces
+    ctx.debug_set("comm_init_timeout_s", max(1, int(timeout)))
+    done, exc = _call_with_timeout(lambda: ctx.comm_init_rccl(uid, rank, nranks), timeout + min(15.0, 0.5 * timeout + 2.0))
     local = None if (done and exc is None) else ("tfx_comm_init_rccl %s" % ("timed out after %.0f s" % timeout if not done else repr(exc)))
     if not agree(local is None):
         return fail_all("tfx_comm_init_rccl", local)

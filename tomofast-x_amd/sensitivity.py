@@ -95,6 +95,8 @@ class Context:
         """Collective: every rank calls it with the 128 bytes rank 0 got from comm_unique_id()."""
         if len(unique_id) != 128:
             raise ValueError("unique id must be 128 bytes")
+        if getattr(self, "_rccl_poisoned", False):
+            raise RuntimeError("a thread that timed out inside an RCCL call of this context never returned: no further RCCL start-up on it")
         check(self._lib.tfx_comm_init_rccl(self._h, C.c_char_p(bytes(unique_id)), int(rank), int(nranks)))
         self.rank, self.nranks = int(rank), int(nranks)
 

@@ -16,7 +16,7 @@ tfx = importlib.import_module("tomofast-x_amd")
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 ctx = tfx.Context(0)
-worst = (1.0, 0)
+worst = (1.0, 0, 0.0)
 for case in range(ncases):
     nx, ny, nz = (int(rng.integers(2, 23)) for _ in range(3))
     ex = np.concatenate([[0.0], np.cumsum(rng.uniform(20.0, 180.0, nx))])
@@ -45,7 +45,7 @@ for case in range(ncases):
         ref = orc.build_matrix_mag(grid, (nx, ny, nz), cw, obs, field, ctype, rate)[:3]
     else:
         ref = orc.build_matrix_grav(grid, (nx, ny, nz), cw, obs, ctype, rate)[:3]
-    same, total, maxulp = 0, 0, 0
+    same, total, maxulp, maxrel = 0, 0, 0, 0.0
     for r in range(nd):
         cb, vb = built[1][built[0][r]:built[0][r + 1]], built[2][built[0][r]:built[0][r + 1]]
         cr, vr = ref[1][ref[0][r]:ref[0][r + 1]], ref[2][ref[0][r]:ref[0][r + 1]]
@@ -60,8 +60,11 @@ for case in range(ncases):
             bad = dv > 2.0 * ulp + 1e-9 * scale
             assert not bad.any(), (case, r, float((dv / scale).max()))
             maxulp = max(maxulp, int((dv / ulp).max()))
+            maxrel = max(maxrel, float((dv / scale).max()))
     frac = same / max(total, 1)
-    worst = (min(worst[0], frac), max(worst[1], maxulp))
-    assert frac >= 0.99, (case, frac, (nx, ny, nz), ctype, rate, mag)
+    worst = (min(worst[0], frac), max(worst[1], maxulp), max(worst[2], maxrel))
+    assert frac >= 0.9999, (case, frac, (nx, ny, nz), ctype, rate, mag)
     print("case %2d %2dx%2dx%2d nd %d %s ctype %d rate %.2f: sparsity %.4f max ulp %d" % (case, nx, ny, nz, nd, "mag " if mag else "grav", ctype, rate, frac, maxulp))
-print("OK: worst sparsity agreement %.4f, worst ulp distance %d" % worst)
+# the ulp distance of the smallest kept coefficients is large by construction (cancellation); what is bounded is the
+# distance in units of the row's largest entry: asserted <= 1e-9 above, the run's worst is printed
+print("OK: worst sparsity agreement %.6f, worst fp32-ulp distance %d, worst |difference| / row maximum %.3e (bound 1e-9 + 2 ulp)" % worst)
