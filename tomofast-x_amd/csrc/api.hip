@@ -169,6 +169,7 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         ctx->adj_copy_min_nnz = value;
         return 0;
     }
+    if (!strcmp(key, "adj_copy_build_ms")) return (int)(1e3 * ctx->selmat().copy_build_s);     // query: wall clock of the selected matrix's copy
     if (!strcmp(key, "has_adj_copy")) return (ctx->selmat().T && ctx->selmat().T->valid) ? 1 : 0;     // query
     if (!strcmp(key, "chunk_exponent_span")) {  // diagnostics: per mille of the chunks whose non-zero values span <= `value` binades
         int64_t fit = 0, total = 0;
@@ -335,8 +336,8 @@ static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_
 }
 
 // How the selected matrix is stored: bytes the entry streams (values, column stream, row-start masks) hold per stored entry - what a
-// product streams per entry and launch -, the number of stored entries (non-zeros + empty-row markers + pad entries), the bytes of
-// those streams, and whether the adjoint product runs on a transposed copy of the tiles (then it streams that copy instead).
+// product streams per entry and launch -, the number of stored entries (non-zeros + empty-row markers; the pad entries that fill a
+// tile's last chunk are part of `stream_bytes` only), the bytes of those streams, and whether the adjoint product runs on a transposed copy of the tiles (then it streams that copy instead).
 int tfx_matrix_format(tfx_ctx *ctx, double *bytes_per_entry, int64_t *stored_entries, int64_t *stream_bytes, int *adjoint_copy)
 {
     if (!ctx) return fail(TFX_E_ARG, "null ctx");

@@ -164,6 +164,7 @@ struct TiledMatrix {
     // of one LDS fp64 atomic per non-zero.  Optional (it doubles the matrix memory): ctx->adj_copy.
     TiledMatrix *T = nullptr;
     bool is_transpose_copy = false;
+    double copy_build_s = 0.0;    // (of the original) wall clock matrix_build_transpose took: reported beside the kernel build time
     bool evictable = false;       // (of a copy) made in automatic mode: given up when another allocation needs the memory
     ~TiledMatrix() { delete T; }
     TiledMatrix() = default;

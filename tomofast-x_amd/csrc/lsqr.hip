@@ -270,6 +270,9 @@ __device__ __forceinline__ void rotate(Scalars *sc)
 }
 
 __global__ void k_rotate(Scalars *sc) { rotate(sc); }
+// alpha from the all-reduced |v|^2 and the plane rotation in one launch (multi-rank iterations: the normalisation of v is left to
+// k_update_xw, like on a single rank)
+__global__ void k_alpha_rotate(Scalars *sc) { set_alpha(sc); rotate(sc); }
 
 // u *= t1 ; u_cons *= t1 ; v = -beta v   (normalisation of u and the first half of the adjoint step, :218-225) in one launch
 __global__ void k_scale_u_uc_v(double *__restrict__ u, int64_t nu, double *__restrict__ uc, int64_t nuc, double *__restrict__ v,
@@ -441,7 +444,8 @@ static int transform_slice(tfx_ctx *ctx, LsqrState *L, int dir)
 // v (+)= S^T u_data + C^T u_cons ; alpha = ||v|| ; v /= alpha
 // fuse_rotate (iterations on a single rank): alpha and the plane rotation come out of the final-sum launch and the
 // normalisation of v is left to k_update_xw
-static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L, bool fuse_rotate = false)
+// defer_scale (iterations on several ranks): after the all-reduce of |v|^2 one launch sets alpha and rotates; v / alpha again in k_update_xw
+static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L, bool fuse_rotate = false, bool defer_scale = false)
 {
     hipStream_t s = ctx->stream;
     if (ctx->spatial_unknowns) {                                         // lsqr_solver2.F90:137-145, :228-236
@@ -463,8 +467,12 @@ static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L, bool fuse_rotate = fals
     TFX_HIP(hipGetLastError());
     if (fuse_rotate) return 0;
     TFX_TRY(allreduce(ctx, &L->sc.p->sum_v, 1));
-    LAUNCH(k_alpha, 1, L->sc.p);
-    LAUNCH(k_scale, g, L->v.p, L->ncols, &L->sc.p->t2, 0);
+    if (defer_scale) {
+        LAUNCH(k_alpha_rotate, 1, L->sc.p);
+    } else {
+        LAUNCH(k_alpha, 1, L->sc.p);
+        LAUNCH(k_scale, g, L->v.p, L->ncols, &L->sc.p->t2, 0);
+    }
     TFX_HIP(hipGetLastError());
     return 0;
 }
@@ -705,9 +713,8 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
                 LAUNCH(k_scale_u_uc_v, grid_for(std::max(std::max(nr, nuc), nc)), L->u.p, nr, L->uc.p, nuc, L->v.p, nc, L->sc.p);
             }
             const bool fused = !ctx->multi();                      // no reduction between sum_v and alpha
-            TFX_TRY(adjoint_and_alpha(ctx, L, fused));                                    // :228-241
-            if (!fused) LAUNCH(k_rotate, 1, L->sc.p);                                     // :248-266
-            LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, fused ? 1.0 : 0.0, L->gamma);   // :241, :269-274
+            TFX_TRY(adjoint_and_alpha(ctx, L, fused, !fused));                            // :228-241, :248-266 (alpha and the rotation)
+            LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, 1.0, L->gamma);   // v / alpha, :241, :269-274
             TFX_HIP(hipGetLastError());
         }
         TFX_TRY(read_scalars(ctx, L));

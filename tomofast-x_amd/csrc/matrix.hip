@@ -25,6 +25,7 @@
 // summed inside a lane, the segment tails are merged across lanes with one segmented wave reduction per chunk.
 #include "common.h"
 #include <algorithm>
+#include <chrono>
 #include <numeric>
 
 namespace tfx {
@@ -1552,6 +1553,7 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
         // the copy (a little larger than the original: its own padding and markers) + the conversion scratch
         if ((double)free_b < 1.06 * (double)m.rec.bytes() + 8e9) return 0;
     }
+    const auto t_begin = std::chrono::steady_clock::now();
     TiledMatrix *T = new TiledMatrix();
     T->is_transpose_copy = true;
     T->evictable = ctx->adj_copy == 2;
@@ -1624,6 +1626,8 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
     if (rc) return give_up(rc);
     ctx->target = keep;
     m.T = T;
+    (void)hipStreamSynchronize(s);
+    m.copy_build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return 0;
 }
 
