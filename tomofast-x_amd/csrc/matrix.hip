@@ -1593,7 +1593,12 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
         TFX_TRY(sc.rowoff.ensure((size_t)RBt));
         TFX_TRY(sc.totals.ensure(2));
         TFX_HIP(hipFuncSetAttribute((const void *)k_tr_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fill_lds));
+        const bool timing = getenv("TFX_BUILD_TIMING") != nullptr;
+        double t_count = 0, t_fill = 0, t_append = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         for (int b = 0; b < T->nrb; ++b) {
+            const auto t0 = now();
             const int64_t c0 = (int64_t)b * RBt, c1 = std::min<int64_t>(m.ncols, c0 + RBt);
             const int nr = (int)(c1 - c0);
             const int t_lo = (int)(c0 / m.TC), t_hi = (int)((c1 - 1) / m.TC);
@@ -1609,6 +1614,8 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
                 TFX_HIP(hipMemcpyAsync(totals, sc.totals.p, sizeof(totals), hipMemcpyDeviceToHost, s));
                 TFX_HIP(hipStreamSynchronize(s));
             }
+            const auto t1 = now();
+            t_count += secs(t0, t1);
             if (totals[0] == 0) continue;                  // an empty row block of S^T has no tiles
             TFX_TRY(sc.tcols.ensure((size_t)totals[0]));
             TFX_TRY(sc.tvals.ensure((size_t)totals[0]));
@@ -1616,9 +1623,17 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
             hipLaunchKernelGGL(k_tr_fill, dim3(ntl, nstrips), dim3(1024), fill_lds, s, m.tiles.p, sc.tids.p + toff[(size_t)t_lo], m.rec.p,
                                m.chunk_row0.p, m.TC, m.RB, c0, c1, RBt, sc.cnt.p, sc.rowoff.p, sc.tcols.p, sc.tvals.p);
             TFX_HIP(hipGetLastError());
+            if (timing) (void)hipStreamSynchronize(s);
+            const auto t2 = now();
+            t_fill += secs(t1, t2);
             TFX_TRY(matrix_append_rows(ctx, c0, nr, sc.tcols.p, sc.tvals.p, sc.nel.p, sc.rowoff.p, totals[1], totals[0]));
+            t_append += secs(t2, now());
         }
+        const auto t3 = now();
         TFX_TRY(matrix_finish(ctx));
+        if (timing)
+            fprintf(stderr, "[tfx] transposed copy: %d row blocks; count + scan %.2f s, fill %.2f s, tile conversion %.2f s, finish %.2f s\n", T->nrb,
+                    t_count, t_fill, t_append, secs(t3, now()));
         return 0;
     }();
     // the conversion scratch is as large as the densest block of columns: give it back
