@@ -215,7 +215,7 @@ struct tfx_ctx {
     tfx::RowStore &rowstore() { return rowstores[slot]; }
     // scratch of matrix_append_rows (grown on demand, reused by every row block)
     struct AppendScratch {
-        tfx::DBuf<int32_t> pos, segoff, first_ne, last_ne, tile_nch;
+        tfx::DBuf<int32_t> pos, segoff, first_ne, last_ne, tile_nch, tile_total;
         tfx::DBuf<int64_t> tile_off;
         std::vector<int32_t> h_segoff_last, h_nch;
         std::vector<int64_t> h_off;
@@ -260,8 +260,8 @@ struct tfx_ctx {
     int adj_copy = 2;
     int64_t adj_copy_min_nnz = 0;
     struct TransposeScratch {
-        tfx::DBuf<int32_t> cnt, nel, tcols, tids, toff;
-        tfx::DBuf<int64_t> rowoff, totals;
+        tfx::DBuf<int32_t> cnt, nel, tcols, tids, toff, bmax;
+        tfx::DBuf<int64_t> rowoff, totals, bsum;
         tfx::DBuf<float> tvals;
     } trs;
     int fwd_run = 2;                  // debug key "fwd_run": consecutive chunks a wave of the forward kernel takes at a time (matrix.hip k_spmv_fwd)

@@ -1418,13 +1418,18 @@ __global__ __launch_bounds__(256) void k_scale_cols(const TileMeta *__restrict__
 // ------------------------------------------------------------------------------------------------------------
 // Transposed copy of a tiled matrix (the adjoint product as a forward product on S^T)
 // ------------------------------------------------------------------------------------------------------------
-// One block of RBt columns of S = one row block of S^T at a time.  The tiles that hold those columns (all row blocks of one or
-// two column tiles) are walked three times: (1) per-column entry counts per row block of S; after a scan over the row blocks and
-// over the columns every (column, row block of S) knows where its run starts in the column's row of S^T; (2, 3) the fill - a
-// workgroup takes one tile and one strip of TR_STRIP columns, marks (column, row) in an LDS bitmap, and the rank of an entry
-// inside its (column, row block) run is the number of marked rows below it: the rows of S^T come out with ascending column
-// indices without a sort.  Zero-valued entries (markers, padding, stored zeros) are dropped: they add nothing to S^T x.
-constexpr int TR_STRIP = 256;
+// S^T is made PANEL by panel: a panel is a range of rows of S^T (= columns of S, whole row blocks of S^T) times a range of column
+// tiles of S^T (= a range of rows of S).  For a wide kernel (10^7 columns, 10^5 rows) a panel is ALL rows of S^T times one column
+// tile - 25 panels of ~8e8 entries at the headline size, each a handful of launches over thousands of tiles (round 3 walked the
+// 4864 row blocks of S^T one at a time: 60 000 small launches, 15 000 host synchronisations, 6.5 s).  Per panel:
+//   (1) count: per tile of S that reaches into the panel, the entries per column (LDS histogram), by row block of S;
+//   (2) prefix over the row blocks of S and scan over the columns: every (column, row block of S) knows where its run starts in the
+//       column's row of S^T;
+//   (3) fill: a workgroup takes one tile, slice of 64 rows by slice, marks (column, row) in an LDS bitmap; the rank of an entry inside
+//       its (column, row block) run is the number of marked rows below it - the rows of S^T come out with ascending column indices
+//       without a sort;
+//   (4) the packed rows become tiles of S^T (matrix_append_panel: the tile conversion of matrix_append_rows for many row blocks at once).
+// Zero-valued entries (markers, padding, stored zeros) are dropped: they add nothing to S^T x.
 
 // every entry of a chunk as (local row, global column, value): the same decode as the product kernels
 template <typename F>
@@ -1443,102 +1448,408 @@ __device__ __forceinline__ void walk_chunk(const char *__restrict__ rec, const i
     }
 }
 
+// a panel of the transposition: columns [c0, c1) and rows [R0, R1) of S; rb_lo = first row block of S that reaches into it
+struct TrPanel {
+    int64_t c0, c1, R0, R1;
+    int rb_lo;
+    int64_t npc;          // c1 - c0
+};
+
+// (1) cnt[(rb - rb_lo) * npc + (col - c0)] = entries of the tile in that column (one tile owns its (row block, columns): plain stores)
 __global__ __launch_bounds__(1024) void k_tr_count(const TileMeta *__restrict__ tiles, const int32_t *__restrict__ tids, const char *__restrict__ rec,
-                                                    const int32_t *__restrict__ chunk_row0, int TC, int64_t c0, int64_t c1, int RBt,
-                                                    int32_t *__restrict__ cnt /* [row blocks of S][RBt] */)
+                                                    const int32_t *__restrict__ chunk_row0, int TC, int RB, TrPanel pn, int32_t *__restrict__ cnt)
 {
     extern __shared__ int32_t hist[];
     const TileMeta tm = tiles[tids[blockIdx.x]];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < RBt; i += blockDim.x) hist[i] = 0;
+    for (int i = threadIdx.x; i < TC; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    const int64_t cbase = tm.off / CHUNK, col0 = (int64_t)tm.t * TC;
+    const int64_t cbase = tm.off / CHUNK, col0 = (int64_t)tm.t * TC, row0 = (int64_t)tm.rb * RB;
     for (int q = wave; q < tm.nchunks; q += 16) {
-        walk_chunk(rec, chunk_row0, cbase + q, lane, col0, [&](int, int64_t col, float val) {
-            if (val != 0.0f && col >= c0 && col < c1) atomicAdd(&hist[(int)(col - c0)], 1);
+        walk_chunk(rec, chunk_row0, cbase + q, lane, col0, [&](int lrow, int64_t col, float val) {
+            const int64_t row = row0 + lrow;
+            if (val != 0.0f && col >= pn.c0 && col < pn.c1 && row >= pn.R0 && row < pn.R1) atomicAdd(&hist[(int)(col - col0)], 1);
         });
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < RBt; i += blockDim.x)
-        if (hist[i]) atomicAdd(&cnt[(int64_t)tm.rb * RBt + i], hist[i]);
+    for (int i = threadIdx.x; i < TC; i += blockDim.x) {
+        const int64_t col = col0 + i;
+        if (hist[i] && col >= pn.c0 && col < pn.c1) cnt[(int64_t)(tm.rb - pn.rb_lo) * pn.npc + (col - pn.c0)] = hist[i];
+    }
 }
 
-// cnt[rb][j] -> exclusive prefix over rb (in place), nel[j], rowoff[j] (exclusive scan over j), totals = {entries, longest row}
-__global__ __launch_bounds__(1024) void k_tr_scan(int32_t *__restrict__ cnt, int nrb, int RBt, int nr, int32_t *__restrict__ nel,
-                                                   int64_t *__restrict__ rowoff, int64_t *__restrict__ totals)
+// (2a) per column: exclusive prefix of the counts over the row blocks of S (in place), nel[j] = the column's total
+__global__ __launch_bounds__(256) void k_tr_prefix(int32_t *__restrict__ cnt, int nsub, int64_t npc, int32_t *__restrict__ nel)
 {
-    __shared__ long long part[1024];
-    __shared__ int maxl[1024];
-    const int per = (RBt + 1023) / 1024;
-    const int j0 = threadIdx.x * per;
-    long long sum = 0;
-    int mx = 0;
-    for (int j = j0; j < j0 + per && j < RBt; ++j) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npc; j += (int64_t)gridDim.x * blockDim.x) {
         int run = 0;
-        for (int rb = 0; rb < nrb; ++rb) {
-            const int v = cnt[(int64_t)rb * RBt + j];
-            cnt[(int64_t)rb * RBt + j] = run;
+        for (int sb = 0; sb < nsub; ++sb) {
+            const int v = cnt[(int64_t)sb * npc + j];
+            cnt[(int64_t)sb * npc + j] = run;
             run += v;
         }
-        if (j < nr) nel[j] = run;
-        sum += run;
-        mx = max(mx, run);
+        nel[j] = run;
     }
-    part[threadIdx.x] = sum;
-    maxl[threadIdx.x] = mx;
+}
+
+// (2b) exclusive scan of nel[0..n) into off[0..n] (64-bit) in three launches: block sums, scan of the block sums, offsets
+constexpr int SCAN_BLOCK = 4096;      // elements per block of 1024 threads
+__global__ __launch_bounds__(1024) void k_scan_sums(const int32_t *__restrict__ v, int64_t n, int64_t *__restrict__ bsum, int32_t *__restrict__ bmax)
+{
+    __shared__ long long part[1024];
+    __shared__ int pmax[1024];
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    long long s = 0;
+    int mx = 0;
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) { s += v[i0 + k]; mx = max(mx, v[i0 + k]); }
+    part[threadIdx.x] = s;
+    pmax[threadIdx.x] = mx;
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) { part[threadIdx.x] += part[threadIdx.x + d]; pmax[threadIdx.x] = max(pmax[threadIdx.x], pmax[threadIdx.x + d]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { bsum[blockIdx.x] = part[0]; bmax[blockIdx.x] = pmax[0]; }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_top(int64_t *__restrict__ bsum, const int32_t *__restrict__ bmax, int nb, int64_t *__restrict__ totals)
+{
+    // one block: exclusive scan of the block sums in place (nb is a few thousand), totals = {sum, largest element}
+    __shared__ long long part[1024];
+    __shared__ int pmax[1024];
+    const int per = (nb + 1023) / 1024;
+    const int b0 = threadIdx.x * per;
+    long long s = 0;
+    int mx = 0;
+    for (int b = b0; b < b0 + per && b < nb; ++b) { s += bsum[b]; mx = max(mx, bmax[b]); }
+    part[threadIdx.x] = s;
+    pmax[threadIdx.x] = mx;
     __syncthreads();
     if (threadIdx.x == 0) {
         long long run = 0;
         int m = 0;
-        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; m = max(m, maxl[i]); }
+        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; m = max(m, pmax[i]); }
         totals[0] = run;
         totals[1] = m;
     }
     __syncthreads();
     long long run = part[threadIdx.x];
-    for (int j = j0; j < j0 + per && j < RBt; ++j) {
-        if (j < nr) rowoff[j] = run;
-        run += (j < nr) ? nel[j] : 0;
+    for (int b = b0; b < b0 + per && b < nb; ++b) { const long long v = bsum[b]; bsum[b] = run; run += v; }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_apply(const int32_t *__restrict__ v, int64_t n, const int64_t *__restrict__ bsum, int64_t *__restrict__ off)
+{
+    __shared__ long long part[1024];
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    int e[4];
+    long long s = 0;
+    for (int k = 0; k < 4; ++k) { e[k] = (i0 + k < n) ? v[i0 + k] : 0; s += e[k]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 thread sums
+    for (int d = 1; d < 1024; d <<= 1) {
+        const long long add = ((int)threadIdx.x >= d) ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    long long run = bsum[blockIdx.x] + part[threadIdx.x] - s;
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k < n) off[i0 + k] = run;
+        run += e[k];
+        if (i0 + k == n - 1) off[n] = run;
     }
 }
 
-__global__ __launch_bounds__(1024) void k_tr_fill(const TileMeta *__restrict__ tiles, const int32_t *__restrict__ tids, const char *__restrict__ rec,
-                                                   const int32_t *__restrict__ chunk_row0, int TC, int RB, int64_t c0blk, int64_t c1blk, int RBt,
-                                                   const int32_t *__restrict__ base /* [row blocks of S][RBt] */, const int64_t *__restrict__ rowoff,
-                                                   int32_t *__restrict__ tcols, float *__restrict__ tvals)
+// (3) one workgroup (4 waves) per tile of S.  The tile is walked in slices of 64 rows (its entries are in (row, column) order, so a
+// slice is a range of chunks): the entries of the slice mark (column, row) in bm[column] - one 64-bit word per column of the tile -,
+// then every entry reads its rank inside its column: the entries of the column in earlier slices (colcnt[column]) + the marked rows
+// below it in this slice.  The tile is read about twice (round 3 / the first panel version read it 16 times, one 256-column strip of
+// a [256][2048]-bit map at a time: 1.3 s of the 3.7 s the copy took at the headline size).
+constexpr int TRF_THREADS = 256;
+__global__ __launch_bounds__(TRF_THREADS) void k_tr_fill(const TileMeta *__restrict__ tiles, const int32_t *__restrict__ tids, const char *__restrict__ rec,
+                                                         const int32_t *__restrict__ chunk_row0, int TC, int RB, TrPanel pn,
+                                                         const int32_t *__restrict__ base /* [row blocks of S in the panel][npc] */,
+                                                         const int64_t *__restrict__ rowoff, int32_t *__restrict__ tcols, float *__restrict__ tvals)
 {
-    extern __shared__ unsigned long long bm[];         // [TR_STRIP][WPR] bitmap, then [TR_STRIP][WPR] uint16 prefixes
-    const int WPR = (RB + 63) / 64;
-    uint16_t *pre = reinterpret_cast<uint16_t *>(bm + (size_t)TR_STRIP * WPR);
+    extern __shared__ unsigned long long bm[];         // [TC] row bitmaps of the current slice, then [TC] uint32 column counts
+    uint32_t *colcnt = reinterpret_cast<uint32_t *>(bm + TC);
     const TileMeta tm = tiles[tids[blockIdx.x]];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t c0 = c0blk + (int64_t)blockIdx.y * TR_STRIP, c1 = min(c1blk, c0 + TR_STRIP);
-    const int64_t cbase = tm.off / CHUNK, col0 = (int64_t)tm.t * TC;
-    if (c0 >= c1 || col0 >= c1 || col0 + TC <= c0) return;          // (uniform) the tile does not reach into this strip
-    for (int i = threadIdx.x; i < TR_STRIP * WPR; i += blockDim.x) bm[i] = 0ull;
+    constexpr int WAVES = TRF_THREADS / 64;
+    const int64_t cbase = tm.off / CHUNK, col0 = (int64_t)tm.t * TC, row0 = (int64_t)tm.rb * RB;
+    const int32_t *A = chunk_row0 + cbase;              // A[q] = local row of the entry before chunk q (non-decreasing)
+    const int n = tm.nchunks;
+    for (int i = threadIdx.x; i < TC; i += TRF_THREADS) { bm[i] = 0ull; colcnt[i] = 0u; }
     __syncthreads();
-    for (int q = wave; q < tm.nchunks; q += 16) {
-        walk_chunk(rec, chunk_row0, cbase + q, lane, col0, [&](int lrow, int64_t col, float val) {
-            if (val != 0.0f && col >= c0 && col < c1) atomicOr(&bm[(int)(col - c0) * WPR + (lrow >> 6)], 1ull << (lrow & 63));
-        });
+    const int first_row = max(A[0], 0);
+    for (int lo = (first_row >> 6) << 6; lo < RB; lo += 64) {
+        const int hi = lo + 63;
+        // chunks that hold rows of [lo, hi]: from the first chunk whose last row is >= lo (the row before chunk q + 1) to the last
+        // chunk whose first possible row (the row before it) is <= hi
+        int qa, qb;
+        {
+            int l = 0, h = n - 1;                       // first q with (q == n - 1 or A[q + 1] >= lo)
+            while (l < h) {
+                const int mid = (l + h) >> 1;
+                if (A[mid + 1] >= lo) h = mid;
+                else l = mid + 1;
+            }
+            qa = l;
+            l = qa; h = n;                              // first q with A[q] > hi
+            while (l < h) {
+                const int mid = (l + h) >> 1;
+                if (A[mid] > hi) h = mid;
+                else l = mid + 1;
+            }
+            qb = l;
+        }
+        if (qa >= qb) continue;                         // (uniform) no chunk reaches into this slice
+        auto in_panel = [&](int lrow, int64_t col, float val) {
+            const int64_t row = row0 + lrow;
+            return val != 0.0f && lrow >= lo && lrow <= hi && col >= pn.c0 && col < pn.c1 && row >= pn.R0 && row < pn.R1;
+        };
+        for (int q = qa + wave; q < qb; q += WAVES)
+            walk_chunk(rec, chunk_row0, cbase + q, lane, col0, [&](int lrow, int64_t col, float val) {
+                if (in_panel(lrow, col, val)) atomicOr(&bm[(int)(col - col0)], 1ull << (lrow & 63));
+            });
+        __syncthreads();
+        for (int q = qa + wave; q < qb; q += WAVES)
+            walk_chunk(rec, chunk_row0, cbase + q, lane, col0, [&](int lrow, int64_t col, float val) {
+                if (!in_panel(lrow, col, val)) return;
+                const int c = (int)(col - col0);
+                const int rank = (int)colcnt[c] + __popcll(bm[c] & ((1ull << (lrow & 63)) - 1ull));
+                const int64_t jb = col - pn.c0;
+                const int64_t dst = rowoff[jb] + base[(int64_t)(tm.rb - pn.rb_lo) * pn.npc + jb] + rank;
+                tcols[dst] = (int32_t)(row0 + lrow);
+                tvals[dst] = val;
+            });
+        __syncthreads();
+        for (int i = threadIdx.x; i < TC; i += TRF_THREADS) {
+            const unsigned long long w = bm[i];
+            if (w) { colcnt[i] += (uint32_t)__popcll(w); bm[i] = 0ull; }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- (4) tile conversion of a panel: rows [r0, r0 + nrp) (nbp row blocks) x column tiles [t0, t0 + nt) -----------------------
+// pos[r][k] (k = 0..nt) = first entry of packed row r with column >= (t0 + k) * TC; one wave per row
+__global__ __launch_bounds__(256) void k_panel_pos(const int32_t *__restrict__ cols, const int32_t *__restrict__ nel, const int64_t *__restrict__ rowoff,
+                                                    int64_t nrp, int t0, int nt, int TC, int32_t *__restrict__ pos)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = w; r < nrp; r += nw) {
+        const int32_t *c = cols + rowoff[r];
+        const int n = nel[r];
+        for (int k = lane; k <= nt; k += 64) {
+            int lo = 0;
+            if (k == nt) lo = n;
+            else if (k > 0) {
+                const int64_t key = (int64_t)(t0 + k) * TC;
+                int hi = n;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int64_t)c[mid] < key) lo = mid + 1;
+                    else hi = mid;
+                }
+            }
+            pos[r * (nt + 1) + k] = lo;
+        }
+    }
+}
+
+// grid = (nt, nbp): segment lengths (with empty-row markers) of tile (row block b, column tile k) and their exclusive scan over the
+// rows of the block -> segoff[(b * nt + k) * (RB + 1) + r], first / last non-empty row, total
+__global__ __launch_bounds__(256) void k_panel_scan(const int32_t *__restrict__ pos, int64_t nrp, int nt, int RB, int32_t *__restrict__ segoff,
+                                                     int32_t *__restrict__ first_ne, int32_t *__restrict__ last_ne, int32_t *__restrict__ total)
+{
+    extern __shared__ int32_t sm[];     // RB ints
+    __shared__ int s_first, s_last;
+    __shared__ int part[256];
+    const int k = blockIdx.x, b = blockIdx.y;
+    const int64_t rbase = (int64_t)b * RB;
+    const int nr = (int)min((int64_t)RB, nrp - rbase);
+    if (threadIdx.x == 0) { s_first = 0x7fffffff; s_last = -1; }
+    __syncthreads();
+    for (int r = threadIdx.x; r < nr; r += blockDim.x) {
+        const int32_t *pr = pos + (rbase + r) * (nt + 1) + k;
+        const int cnt = pr[1] - pr[0];
+        sm[r] = cnt;
+        if (cnt > 0) { atomicMin(&s_first, r); atomicMax(&s_last, r); }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < TR_STRIP; j += blockDim.x) {
+    const int f = s_first, l = s_last;
+    const int per = (nr + blockDim.x - 1) / blockDim.x;
+    const int rb0 = threadIdx.x * per, re = min(rb0 + per, nr);
+    int sum = 0;
+    for (int r = rb0; r < re; ++r) {
+        int len = sm[r];
+        if (len == 0 && r > f && r < l) len = 1;      // marker for an empty row between non-empty ones
+        sm[r] = len;
+        sum += len;
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
         int run = 0;
-        for (int w = 0; w < WPR; ++w) { pre[j * WPR + w] = (uint16_t)run; run += __popcll(bm[j * WPR + w]); }
+        for (int i = 0; i < (int)blockDim.x; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        total[b * nt + k] = run;
     }
     __syncthreads();
-    for (int q = wave; q < tm.nchunks; q += 16) {
-        walk_chunk(rec, chunk_row0, cbase + q, lane, col0, [&](int lrow, int64_t col, float val) {
-            if (val == 0.0f || col < c0 || col >= c1) return;
-            const int j = (int)(col - c0), w = lrow >> 6;
-            const int rank = pre[j * WPR + w] + __popcll(bm[j * WPR + w] & ((1ull << (lrow & 63)) - 1ull));
-            const int jb = (int)(col - c0blk);
-            const int64_t dst = rowoff[jb] + base[(int64_t)tm.rb * RBt + jb] + rank;
-            tcols[dst] = tm.rb * RB + lrow;
-            tvals[dst] = val;
-        });
+    int run = part[threadIdx.x];
+    int32_t *so = segoff + (int64_t)(b * nt + k) * (RB + 1);
+    for (int r = rb0; r < re; ++r) { so[r] = run; run += sm[r]; }
+    if (re == nr && rb0 < nr) so[nr] = run;
+    if (nr == 0 && threadIdx.x == 0) so[0] = 0;
+    if (threadIdx.x == 0) { first_ne[b * nt + k] = (l >= 0) ? f : -1; last_ne[b * nt + k] = l; }
+}
+
+// one wave per packed row: its entries go to their tiles
+__global__ __launch_bounds__(256) void k_panel_scatter(const int32_t *__restrict__ cols, const float *__restrict__ vals, const int32_t *__restrict__ nel,
+                                                        const int64_t *__restrict__ rowoff, int64_t nrp, int t0, int nt, int TC, int RB,
+                                                        const int32_t *__restrict__ pos, const int32_t *__restrict__ segoff,
+                                                        const int64_t *__restrict__ tile_off, uint16_t *__restrict__ tmp16, int64_t base, char *__restrict__ rec)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = w; r < nrp; r += nw) {
+        const int n = nel[r];
+        if (n == 0) continue;
+        const int64_t o = rowoff[r];
+        const int b = (int)(r / RB), rl = (int)(r - (int64_t)b * RB);
+        const int32_t *pr = pos + r * (nt + 1);
+        for (int j = lane; j < n; j += 64) {
+            const int32_t c = cols[o + j];
+            const int t = c / TC, k = t - t0;
+            const int p0 = pr[k];
+            const int64_t dst = tile_off[b * nt + k] + segoff[(int64_t)(b * nt + k) * (RB + 1) + rl] + (j - p0);
+            put_entry16(tmp16, base, rec, dst, (uint32_t)col_slot(c - t * TC), j == p0, vals[o + j]);
+        }
     }
+}
+
+// grid = (nt, nbp): markers for empty rows strictly between the first and last non-empty row of a tile
+__global__ __launch_bounds__(256) void k_panel_markers(const int32_t *__restrict__ pos, int64_t nrp, int nt, int RB, const int32_t *__restrict__ segoff,
+                                                        const int32_t *__restrict__ first_ne, const int32_t *__restrict__ last_ne,
+                                                        const int64_t *__restrict__ tile_off, char *__restrict__ rec)
+{
+    const int k = blockIdx.x, b = blockIdx.y, id = b * nt + k;
+    const int f = first_ne[id], l = last_ne[id];
+    if (f < 0) return;
+    const int64_t rbase = (int64_t)b * RB;
+    for (int r = f + 1 + threadIdx.x; r < l; r += blockDim.x) {
+        const int32_t *pr = pos + (rbase + r) * (nt + 1) + k;
+        if (pr[1] - pr[0] == 0) put_entry(rec, tile_off[id] + segoff[(int64_t)id * (RB + 1) + r], 0u, true, 0.0f);
+    }
+}
+
+// grid = (nt, nbp): chunk_row0[chunk] = local row of the entry just before the chunk (first chunk: first_ne - 1)
+__global__ __launch_bounds__(256) void k_panel_chunk_row0(int64_t nrp, int nt, int RB, const int32_t *__restrict__ segoff, const int32_t *__restrict__ first_ne,
+                                                           const int64_t *__restrict__ tile_off, const int32_t *__restrict__ tile_nchunks,
+                                                           int32_t *__restrict__ chunk_row0)
+{
+    const int k = blockIdx.x, b = blockIdx.y, id = b * nt + k;
+    const int nch = tile_nchunks[id];
+    if (nch == 0) return;
+    const int nr = (int)min((int64_t)RB, nrp - (int64_t)b * RB);
+    const int32_t *so = segoff + (int64_t)id * (RB + 1);
+    const int total = so[nr];
+    const int64_t cbase = tile_off[id] / CHUNK;
+    for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+        int row;
+        if (c == 0) row = first_ne[id] - 1;
+        else {
+            int q = c * CHUNK - 1;              // entry before the chunk
+            if (q >= total) q = total - 1;      // padding region: stay on the last row
+            int lo = 0, hi = nr;                // largest r with so[r] <= q and segment r non-empty
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (so[mid + 1] <= q) lo = mid + 1;
+                else hi = mid;
+            }
+            row = lo;
+        }
+        chunk_row0[cbase + c] = row;
+    }
+}
+
+// Appends the tiles of rows [r0, r0 + nrp) (r0 a multiple of RB) restricted to the column tiles [t0, t0 + nt): the rows lie packed one
+// behind the other (d_rowoff[r + 1] = d_rowoff[r] + d_nel[r]; columns ascending, all inside the column tiles of the panel), `total`
+// entries in all.  The tiles are stored row block by row block, column tile by column tile.
+static int matrix_append_panel(tfx_ctx *ctx, int64_t r0, int64_t nrp, int t0, int nt, const int32_t *d_cols, const float *d_vals,
+                               const int32_t *d_nel, const int64_t *d_rowoff, int64_t total)
+{
+    TiledMatrix &m = *ctx->target;
+    hipStream_t s = ctx->stream;
+    if (r0 % m.RB != 0 || nrp <= 0 || nt <= 0 || t0 < 0 || t0 + nt > m.ntc)
+        return fail(TFX_E_ARG, "matrix_append_panel: bad panel (rows %lld + %lld, column tiles %d + %d)", (long long)r0, (long long)nrp, t0, nt);
+    const int RB = m.RB, nbp = (int)((nrp + RB - 1) / RB), rb0 = (int)(r0 / RB);
+    const int64_t ntl = (int64_t)nbp * nt;
+    tfx_ctx::AppendScratch &sc = ctx->append;
+    TFX_TRY(sc.pos.ensure((size_t)(nrp * (nt + 1))));
+    TFX_TRY(sc.segoff.ensure((size_t)(ntl * (RB + 1))));
+    TFX_TRY(sc.first_ne.ensure((size_t)ntl));
+    TFX_TRY(sc.last_ne.ensure((size_t)ntl));
+    TFX_TRY(sc.tile_nch.ensure((size_t)ntl));
+    TFX_TRY(sc.tile_off.ensure((size_t)ntl));
+    TFX_TRY(sc.tile_total.ensure((size_t)ntl));
+    const unsigned row_grid = (unsigned)std::min<int64_t>((nrp + 3) / 4, (int64_t)ctx->num_cu * 64);
+    hipLaunchKernelGGL(k_panel_pos, dim3(row_grid), dim3(256), 0, s, d_cols, d_nel, d_rowoff, nrp, t0, nt, m.TC, sc.pos.p);
+    hipLaunchKernelGGL(k_panel_scan, dim3(nt, nbp), dim3(256), (size_t)RB * sizeof(int32_t), s, sc.pos.p, nrp, nt, RB, sc.segoff.p, sc.first_ne.p,
+                       sc.last_ne.p, sc.tile_total.p);
+    TFX_HIP(hipGetLastError());
+    sc.h_segoff_last.assign((size_t)ntl, 0);
+    TFX_HIP(hipMemcpyAsync(sc.h_segoff_last.data(), sc.tile_total.p, (size_t)ntl * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    TFX_HIP(hipStreamSynchronize(s));
+    sc.h_off.resize((size_t)ntl);
+    sc.h_nch.resize((size_t)ntl);
+    int64_t cur = m.n_entries;
+    for (int b = 0; b < nbp; ++b)
+        for (int k = 0; k < nt; ++k) {
+            const size_t id = (size_t)b * nt + k;
+            const int32_t cnt = sc.h_segoff_last[id];
+            const int32_t nch = (cnt + CHUNK - 1) / CHUNK;
+            sc.h_off[id] = cur;
+            sc.h_nch[id] = nch;
+            if (cnt > 0) {
+                TileMeta tm;
+                tm.off = cur;
+                tm.nchunks = nch;
+                tm.cnt = cnt;
+                tm.t = t0 + k;
+                tm.rb = rb0 + b;
+                tm.kind = 0;
+                tm.aux = 0;
+                m.h_tiles.push_back(tm);
+            }
+            cur += (int64_t)nch * CHUNK;
+        }
+    if (cur > m.cap_entries)
+        return fail(TFX_E_STATE, "tiled matrix capacity exceeded (%lld > %lld entries)", (long long)cur, (long long)m.cap_entries);
+    if (cur > m.n_entries) {
+        const int64_t ch0 = m.n_entries / CHUNK, ch1 = cur / CHUNK;
+        TFX_HIP(hipMemsetAsync(m.rec.p + ch0 * REC_BYTES, 0, (size_t)(ch1 - ch0) * REC_BYTES, s));
+        TFX_TRY(sc.tmp16.ensure((size_t)(cur - m.n_entries)));
+        TFX_HIP(hipMemsetAsync(sc.tmp16.p, 0, (size_t)(cur - m.n_entries) * sizeof(uint16_t), s));
+        TFX_HIP(hipMemcpyAsync(sc.tile_off.p, sc.h_off.data(), (size_t)ntl * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        TFX_HIP(hipMemcpyAsync(sc.tile_nch.p, sc.h_nch.data(), (size_t)ntl * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        if (total > 0)
+            hipLaunchKernelGGL(k_panel_scatter, dim3(row_grid), dim3(256), 0, s, d_cols, d_vals, d_nel, d_rowoff, nrp, t0, nt, m.TC, RB, sc.pos.p,
+                               sc.segoff.p, sc.tile_off.p, sc.tmp16.p, m.n_entries, m.rec.p);
+        hipLaunchKernelGGL(k_pack_slots, dim3((unsigned)std::min<int64_t>(65536, ((cur - m.n_entries) / 8 + 255) / 256)), dim3(256), 0, s,
+                           sc.tmp16.p, m.n_entries, (cur - m.n_entries) / 8, m.rec.p);
+        hipLaunchKernelGGL(k_panel_markers, dim3(nt, nbp), dim3(256), 0, s, sc.pos.p, nrp, nt, RB, sc.segoff.p, sc.first_ne.p, sc.last_ne.p,
+                           sc.tile_off.p, m.rec.p);
+        hipLaunchKernelGGL(k_panel_chunk_row0, dim3(nt, nbp), dim3(256), 0, s, nrp, nt, RB, sc.segoff.p, sc.first_ne.p, sc.tile_off.p, sc.tile_nch.p,
+                           m.chunk_row0.p);
+        TFX_HIP(hipGetLastError());
+    }
+    TFX_HIP(hipStreamSynchronize(s));    // the host-side staging vectors above are reused by the next call
+    m.n_entries = cur;
+    return 0;
 }
 
 int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
@@ -1550,8 +1861,8 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
         size_t free_b = 0, total_b = 0;
         TFX_HIP(hipStreamSynchronize(s));
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
-        // the copy (a little larger than the original: its own padding and markers) + the conversion scratch
-        if ((double)free_b < 1.06 * (double)m.rec.bytes() + 8e9) return 0;
+        // the copy (a little larger than the original: its own padding and markers) + the conversion scratch of a panel
+        if ((double)free_b < 1.06 * (double)m.rec.bytes() + std::min(16e9, 0.2 * (double)m.rec.bytes() + 1e8)) return 0;
     }
     const auto t_begin = std::chrono::steady_clock::now();
     TiledMatrix *T = new TiledMatrix();
@@ -1559,85 +1870,120 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
     T->evictable = ctx->adj_copy == 2;
     TiledMatrix *keep = ctx->target;
     auto give_up = [&](int rc) {
-        // the copy is an optimisation: when the device has no room for it after all, the adjoint stays on the atomic kernel
+        // the copy is an optimisation: when the device has no room for it after all, the adjoint stays on the tiles of S
         ctx->target = keep;
         delete T;
         (void)hipGetLastError();
         if (ctx->adj_copy == 1) return rc;
-        fprintf(stderr, "[tfx] no transposed copy for the adjoint (%s): using the one-copy adjoint kernel\n", g_last_error.c_str());
+        fprintf(stderr, "[tfx] no transposed copy for the adjoint (%s): the adjoint runs on the tiles of S\n", g_last_error.c_str());
         return 0;
     };
     ctx->target = T;
     int rc = matrix_begin(ctx, m.ncols, m.nrows, std::max<int64_t>(1, m.nnz));
     if (rc) return give_up(rc);
-    // tiles of S by column tile, row blocks ascending
-    std::vector<int32_t> toff((size_t)m.ntc + 1, 0), tids(m.h_tiles.size());
-    for (const TileMeta &t : m.h_tiles) toff[(size_t)t.t + 1] += 1;
-    for (int t = 0; t < m.ntc; ++t) toff[(size_t)t + 1] += toff[(size_t)t];
-    {
-        std::vector<int32_t> fill(toff.begin(), toff.end() - 1);
-        std::vector<int32_t> order(m.h_tiles.size());
-        for (size_t i = 0; i < order.size(); ++i) order[i] = (int32_t)i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return m.h_tiles[a].rb < m.h_tiles[b].rb; });
-        for (int32_t i : order) tids[(size_t)fill[(size_t)m.h_tiles[i].t]++] = i;
+    const double t_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    // Panels.  Full height (all rows of S^T) x nt column tiles when the per-row tile index fits the budget, otherwise bands of row
+    // blocks x all column tiles; nt / the band height are cut so that a panel holds about PANEL_ENTRIES entries (estimated from the
+    // mean density; the scratch grows to what a panel really holds).
+    constexpr double PANEL_ENTRIES = 9.0e8, POS_BUDGET = 1.5e8;      // entries (8 B each of scratch + 2 B) ; ints of pos[] / segoff[]
+    const int RBt = T->RB, TCt = T->TC;
+    const int64_t nrt = m.ncols;                                          // rows of S^T
+    const double per_tile_col = (double)std::max<int64_t>(1, m.nnz) / (double)T->ntc;     // entries per column tile of S^T, all rows
+    int nt_panel;
+    int64_t band_rows;                                                    // rows of S^T per panel (multiple of RBt)
+    if ((double)nrt * 2.0 <= POS_BUDGET) {
+        band_rows = ((nrt + RBt - 1) / RBt) * RBt;
+        nt_panel = (int)std::max(1.0, std::min({(double)T->ntc, POS_BUDGET / (double)nrt - 1.0, PANEL_ENTRIES / per_tile_col}));
+        if (nt_panel == 1 && per_tile_col > 1.5 * PANEL_ENTRIES) {       // even one column tile is too much at full height: bands
+            const int64_t nb = (int64_t)std::ceil(per_tile_col / PANEL_ENTRIES);
+            band_rows = std::max<int64_t>(RBt, ((nrt / nb + RBt - 1) / RBt) * RBt);
+        }
+    } else {
+        nt_panel = 1;
+        band_rows = std::max<int64_t>(RBt, (int64_t)(POS_BUDGET / 2.0) / RBt * RBt);
     }
+    // tiles of S by row block (the panels of one band of columns walk them row range by row range)
+    std::vector<std::vector<int32_t>> by_rb((size_t)m.nrb);
+    for (size_t i = 0; i < m.h_tiles.size(); ++i) by_rb[(size_t)m.h_tiles[i].rb].push_back((int32_t)i);
     tfx_ctx::TransposeScratch &sc = ctx->trs;
-    const int RBt = T->RB;
-    const int WPR = (m.RB + 63) / 64;
-    const size_t fill_lds = (size_t)TR_STRIP * WPR * (sizeof(unsigned long long) + sizeof(uint16_t));
+    const size_t fill_lds = (size_t)m.TC * (sizeof(unsigned long long) + sizeof(uint32_t));
+    const bool timing = getenv("TFX_BUILD_TIMING") != nullptr;
+    double t_count = 0, t_fill = 0, t_append = 0;
+    int npanels = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     rc = [&]() -> int {
-        TFX_TRY(sc.tids.ensure(std::max<size_t>(1, tids.size())));
-        TFX_HIP(hipMemcpyAsync(sc.tids.p, tids.data(), tids.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        TFX_TRY(sc.cnt.ensure((size_t)m.nrb * RBt));
-        TFX_TRY(sc.nel.ensure((size_t)RBt));
-        TFX_TRY(sc.rowoff.ensure((size_t)RBt));
         TFX_TRY(sc.totals.ensure(2));
         TFX_HIP(hipFuncSetAttribute((const void *)k_tr_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fill_lds));
-        const bool timing = getenv("TFX_BUILD_TIMING") != nullptr;
-        double t_count = 0, t_fill = 0, t_append = 0;
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-        for (int b = 0; b < T->nrb; ++b) {
-            const auto t0 = now();
-            const int64_t c0 = (int64_t)b * RBt, c1 = std::min<int64_t>(m.ncols, c0 + RBt);
-            const int nr = (int)(c1 - c0);
-            const int t_lo = (int)(c0 / m.TC), t_hi = (int)((c1 - 1) / m.TC);
-            const int ntl = toff[(size_t)t_hi + 1] - toff[(size_t)t_lo];
-            int64_t totals[2] = {0, 0};
-            if (ntl > 0) {
-                const int32_t *tl = sc.tids.p + toff[(size_t)t_lo];
-                TFX_HIP(hipMemsetAsync(sc.cnt.p, 0, (size_t)m.nrb * RBt * sizeof(int32_t), s));
-                hipLaunchKernelGGL(k_tr_count, dim3(ntl), dim3(1024), (size_t)RBt * sizeof(int32_t), s, m.tiles.p, tl, m.rec.p, m.chunk_row0.p,
-                                   m.TC, c0, c1, RBt, sc.cnt.p);
-                hipLaunchKernelGGL(k_tr_scan, dim3(1), dim3(1024), 0, s, sc.cnt.p, m.nrb, RBt, nr, sc.nel.p, sc.rowoff.p, sc.totals.p);
+        std::vector<int32_t> tids;
+        // Tiles must be appended row block by row block of S^T... not so: their order in the streams is free (every tile carries its
+        // offset), so the panels are walked column tile by column tile of S^T inside a band of rows.
+        for (int64_t r0 = 0; r0 < nrt; r0 += band_rows) {
+            const int64_t r1 = std::min(nrt, r0 + band_rows), npc = r1 - r0;
+            const int ct_lo = (int)(r0 / m.TC), ct_hi = (int)((r1 - 1) / m.TC);              // column tiles of S the band touches
+            for (int t0 = 0; t0 < T->ntc; t0 += nt_panel) {
+                const auto tp0 = now();
+                const int nt = std::min(nt_panel, T->ntc - t0);
+                TrPanel pn;
+                pn.c0 = r0; pn.c1 = r1; pn.npc = npc;
+                pn.R0 = (int64_t)t0 * TCt; pn.R1 = std::min<int64_t>(m.nrows, (int64_t)(t0 + nt) * TCt);
+                pn.rb_lo = (int)(pn.R0 / m.RB);
+                const int rb_hi = (int)((pn.R1 - 1) / m.RB), nsub = rb_hi - pn.rb_lo + 1;
+                tids.clear();
+                for (int rb = pn.rb_lo; rb <= rb_hi; ++rb)
+                    for (int32_t i : by_rb[(size_t)rb])
+                        if (m.h_tiles[(size_t)i].t >= ct_lo && m.h_tiles[(size_t)i].t <= ct_hi) tids.push_back(i);
+                if (tids.empty()) continue;
+                ++npanels;
+                TFX_TRY(sc.tids.ensure(tids.size()));
+                TFX_HIP(hipMemcpyAsync(sc.tids.p, tids.data(), tids.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+                TFX_TRY(sc.cnt.ensure((size_t)(nsub * npc)));
+                TFX_TRY(sc.nel.ensure((size_t)npc));
+                TFX_TRY(sc.rowoff.ensure((size_t)npc + 1));
+                const int nsb = (int)((npc + SCAN_BLOCK - 1) / SCAN_BLOCK);
+                TFX_TRY(sc.bsum.ensure((size_t)nsb));
+                TFX_TRY(sc.bmax.ensure((size_t)nsb));
+                TFX_HIP(hipMemsetAsync(sc.cnt.p, 0, (size_t)(nsub * npc) * sizeof(int32_t), s));
+                hipLaunchKernelGGL(k_tr_count, dim3((unsigned)tids.size()), dim3(1024), (size_t)m.TC * sizeof(int32_t), s, m.tiles.p, sc.tids.p, m.rec.p,
+                                   m.chunk_row0.p, m.TC, m.RB, pn, sc.cnt.p);
+                hipLaunchKernelGGL(k_tr_prefix, dim3((unsigned)std::min<int64_t>((npc + 255) / 256, 16384)), dim3(256), 0, s, sc.cnt.p, nsub, npc, sc.nel.p);
+                hipLaunchKernelGGL(k_scan_sums, dim3(nsb), dim3(1024), 0, s, sc.nel.p, npc, sc.bsum.p, sc.bmax.p);
+                hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, sc.bsum.p, sc.bmax.p, nsb, sc.totals.p);
+                hipLaunchKernelGGL(k_scan_apply, dim3(nsb), dim3(1024), 0, s, sc.nel.p, npc, sc.bsum.p, sc.rowoff.p);
                 TFX_HIP(hipGetLastError());
+                int64_t totals[2] = {0, 0};
                 TFX_HIP(hipMemcpyAsync(totals, sc.totals.p, sizeof(totals), hipMemcpyDeviceToHost, s));
                 TFX_HIP(hipStreamSynchronize(s));
+                const auto tp1 = now();
+                t_count += secs(tp0, tp1);
+                if (totals[0] == 0) continue;                  // nothing of S in this panel
+                if ((size_t)totals[0] > sc.tcols.n) {          // (grown with head room: the panels differ in density, and a re-allocation of GBs costs 0.1 s)
+                    const size_t want = (size_t)((double)totals[0] * 1.25) + 1024;
+                    TFX_TRY(sc.tcols.ensure(want));
+                    TFX_TRY(sc.tvals.ensure(want));
+                }
+                hipLaunchKernelGGL(k_tr_fill, dim3((unsigned)tids.size()), dim3(TRF_THREADS), fill_lds, s, m.tiles.p,
+                                   sc.tids.p, m.rec.p, m.chunk_row0.p, m.TC, m.RB, pn, sc.cnt.p, sc.rowoff.p, sc.tcols.p, sc.tvals.p);
+                TFX_HIP(hipGetLastError());
+                if (timing) (void)hipStreamSynchronize(s);
+                const auto tp2 = now();
+                t_fill += secs(tp1, tp2);
+                TFX_TRY(matrix_append_panel(ctx, r0, npc, t0, nt, sc.tcols.p, sc.tvals.p, sc.nel.p, sc.rowoff.p, totals[0]));
+                t_append += secs(tp2, now());
             }
-            const auto t1 = now();
-            t_count += secs(t0, t1);
-            if (totals[0] == 0) continue;                  // an empty row block of S^T has no tiles
-            TFX_TRY(sc.tcols.ensure((size_t)totals[0]));
-            TFX_TRY(sc.tvals.ensure((size_t)totals[0]));
-            const int nstrips = (nr + TR_STRIP - 1) / TR_STRIP;
-            hipLaunchKernelGGL(k_tr_fill, dim3(ntl, nstrips), dim3(1024), fill_lds, s, m.tiles.p, sc.tids.p + toff[(size_t)t_lo], m.rec.p,
-                               m.chunk_row0.p, m.TC, m.RB, c0, c1, RBt, sc.cnt.p, sc.rowoff.p, sc.tcols.p, sc.tvals.p);
-            TFX_HIP(hipGetLastError());
-            if (timing) (void)hipStreamSynchronize(s);
-            const auto t2 = now();
-            t_fill += secs(t1, t2);
-            TFX_TRY(matrix_append_rows(ctx, c0, nr, sc.tcols.p, sc.tvals.p, sc.nel.p, sc.rowoff.p, totals[1], totals[0]));
-            t_append += secs(t2, now());
         }
         const auto t3 = now();
         TFX_TRY(matrix_finish(ctx));
         if (timing)
-            fprintf(stderr, "[tfx] transposed copy: %d row blocks; count + scan %.2f s, fill %.2f s, tile conversion %.2f s, finish %.2f s\n", T->nrb,
-                    t_count, t_fill, t_append, secs(t3, now()));
+            fprintf(stderr, "[tfx] transposed copy: allocation %.2f s; %d panels (%lld rows x %d column tiles each): count + scan %.2f s, fill %.2f s, tile conversion %.2f s; work lists %.2f s\n",
+                    t_alloc, npanels, (long long)band_rows, nt_panel, t_count, t_fill, t_append, secs(t3, now()));
         return 0;
     }();
-    // the conversion scratch is as large as the densest block of columns: give it back
-    sc.tcols.release(); sc.tvals.release(); sc.cnt.release();
+    // the conversion scratch is as large as the densest panel: give it back
+    const auto t_rel = std::chrono::steady_clock::now();
+    sc.tcols.release(); sc.tvals.release(); sc.cnt.release(); sc.nel.release(); sc.rowoff.release();
+    ctx->append.pos.release(); ctx->append.segoff.release(); ctx->append.tmp16.release();
+    if (timing) fprintf(stderr, "[tfx] transposed copy: scratch released in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rel).count());
     if (rc) return give_up(rc);
     ctx->target = keep;
     m.T = T;
