@@ -164,6 +164,15 @@ struct TiledMatrix {
     // of one LDS fp64 atomic per non-zero.  Optional (it doubles the matrix memory): ctx->adj_copy.
     TiledMatrix *T = nullptr;
     bool is_transpose_copy = false;
+    // Storage of the transposed copy, set aside by matrix_begin together with the storage of S for large matrices whose copy will fit
+    // (one early allocation of 100+ GB takes 0.5 s; the same allocation after the build, next to 130 GB in use, was measured at 1.6 s);
+    // matrix_build_transpose takes it over.
+    struct Prealloc {
+        DBuf<char> rec;
+        DBuf<int32_t> row0;
+    };
+    std::unique_ptr<Prealloc> pre;
+    void drop_prealloc() { pre.reset(); }
     double copy_build_s = 0.0;    // (of the original) wall clock matrix_build_transpose took: reported beside the kernel build time
     bool evictable = false;       // (of a copy) made in automatic mode: given up when another allocation needs the memory
     ~TiledMatrix() { delete T; }
@@ -211,6 +220,7 @@ struct tfx_ctx {
     tfx::TiledMatrix cons;
     tfx::DBuf<double> cons_rhs;        // right-hand side of the C rows (replicated)
     tfx::TiledMatrix *target = &mat;   // which matrix matrix_begin / append / finish assemble
+    tfx::TiledMatrix::Prealloc *pre_take = nullptr;   // (matrix_build_transpose -> matrix_begin) storage to take over instead of allocating
     tfx::RowStore rowstores[2];        // one per problem slot (a joint run partitions on the counts of both kernels before the relayout)
     tfx::RowStore &rowstore() { return rowstores[slot]; }
     // scratch of matrix_append_rows (grown on demand, reused by every row block)

@@ -37,6 +37,10 @@ bool evict_adjoint_copies(tfx_ctx *ctx)
 {
     bool freed = false;
     for (TiledMatrix *m : {&ctx->mat, &ctx->mat2, &ctx->cons}) {
+        if (m->pre && ctx->adj_copy != 1 && ctx->pre_take != m->pre.get()) {      // storage set aside for a copy that does not exist yet
+            m->drop_prealloc();
+            freed = true;
+        }
         if (m->T && m->T->evictable) {
             if (!freed) (void)hipDeviceSynchronize();      // (nothing may still be reading a copy)
             const size_t bytes = m->T->device_bytes();
@@ -66,6 +70,7 @@ void TiledMatrix::release_storage()
     fwd_nslots.release(); fwd_pbase.release(); adj_nslots.release(); adj_pbase.release();
     dense.release(); dense_partial.release(); tile_vmax.release();
     vmax_stale = true;
+    drop_prealloc();
     delete T;
     T = nullptr;
     h_tiles.clear(); h_fwd.clear(); h_adj.clear();
@@ -384,6 +389,35 @@ __global__ void k_dense_scale_rows(float *__restrict__ A, int64_t ld, int64_t nr
     }
 }
 
+// Tile shape and capacity (in entries) of a tiled matrix.  Large matrices use the largest tile (RB_MAX x TC_MAX: least staging per
+// entry).  A tile is never split between workgroups, so a small or medium matrix gets smaller tiles - enough of them for ~2
+// workgroups per CU, but not finer than 16 chunks of entries (a workgroup's 16 waves): narrower column tiles first (less x staging,
+// less LDS, more workgroups per CU), then lower row blocks.
+static void tile_shape(const tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper, int &TC, int &RB, int &nrb, int &ntc, int64_t &cap)
+{
+    // RB is a power of two (64 .. RB_MAX): the public append entry point takes blocks of RB_MAX rows and splits them
+    int64_t rb_full = 64;
+    while (rb_full < RB_MAX && rb_full < nrows) rb_full *= 2;
+    const int64_t tc_full = std::min<int64_t>(TC_MAX, (ncols + 63) / 64 * 64);
+    const double density = std::min(1.0, (double)nnz_upper / ((double)nrows * (double)ncols));
+    const double per_tile = std::max<double>(16.0 * CHUNK, (double)nnz_upper / (2.0 * std::max(1, ctx->num_cu)));
+    const double area = per_tile / std::max(density, 1e-12);
+    int64_t tc = 256;
+    while (tc < tc_full && (double)tc * (double)rb_full < area) tc *= 2;
+    tc = std::min(tc, tc_full);
+    int64_t rb = 64;
+    while (rb < rb_full && (double)rb * (double)tc < area) rb *= 2;
+    TC = (int)tc;
+    RB = (int)rb;
+    nrb = (int)((nrows + RB - 1) / RB);
+    ntc = (int)((ncols + TC - 1) / TC);
+    // marker entries: a row that is empty inside a tile between two non-empty rows of that tile.  At most one per (row, column
+    // tile); a tile needs two real entries to have any, and at most RB - 2 of them
+    const int64_t markers = std::min<int64_t>((int64_t)nrows * ntc, (nnz_upper / 2 + 1) * (int64_t)RB);
+    cap = nnz_upper + markers + (int64_t)nrb * ntc * CHUNK + CHUNK;
+    cap = (cap + CHUNK - 1) / CHUNK * CHUNK;
+}
+
 int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 {
     g_alloc_ctx = ctx;
@@ -393,38 +427,43 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
     m.ncols = ncols;
     m.nnz = 0;
     if (nrows <= 0 || ncols <= 0) return fail(TFX_E_ARG, "matrix_begin: empty matrix %lld x %lld", (long long)nrows, (long long)ncols);
-    // Tile shape.  Large matrices use the largest tile (RB_MAX x TC_MAX: least staging per entry).  A tile is never split
-    // between workgroups, so a small or medium matrix gets smaller tiles - enough of them for ~2 workgroups per CU, but not
-    // finer than 16 chunks of entries (a workgroup's 16 waves): narrower column tiles first (less x staging, less LDS, more
-    // workgroups per CU), then lower row blocks.
-    {
-        // RB is a power of two (64 .. RB_MAX): the public append entry point takes blocks of RB_MAX rows and splits them
-        int64_t rb_full = 64;
-        while (rb_full < RB_MAX && rb_full < nrows) rb_full *= 2;
-        const int64_t tc_full = std::min<int64_t>(TC_MAX, (ncols + 63) / 64 * 64);
-        const double density = std::min(1.0, (double)nnz_upper / ((double)nrows * (double)ncols));
-        const double per_tile = std::max<double>(16.0 * CHUNK, (double)nnz_upper / (2.0 * std::max(1, ctx->num_cu)));
-        const double area = per_tile / std::max(density, 1e-12);
-        int64_t tc = 256;
-        while (tc < tc_full && (double)tc * (double)rb_full < area) tc *= 2;
-        tc = std::min(tc, tc_full);
-        int64_t rb = 64;
-        while (rb < rb_full && (double)rb * (double)tc < area) rb *= 2;
-        m.TC = (int)tc;
-        m.RB = (int)rb;
+    int64_t cap = 0;
+    tile_shape(ctx, nrows, ncols, nnz_upper, m.TC, m.RB, m.nrb, m.ntc, cap);
+    if (ctx->pre_take) {
+        // the transposed copy: its storage was set aside when S was begun - take it over when it is large enough
+        TiledMatrix::Prealloc *pre = ctx->pre_take;
+        ctx->pre_take = nullptr;
+        // (`cap` here counts the empty-row markers of S as entries, which the copy drops: the storage was sized on the kernel's entry
+        // bound with 2 % head room; matrix_append_panel checks the capacity as it goes, and a copy that does not fit after all is given up)
+        if ((double)pre->rec.n >= 0.97 * (double)(cap / CHUNK) * REC_BYTES && (double)pre->row0.n >= 0.97 * (double)(cap / CHUNK)) {
+            std::swap(m.rec.p, pre->rec.p); std::swap(m.rec.n, pre->rec.n);
+            std::swap(m.chunk_row0.p, pre->row0.p); std::swap(m.chunk_row0.n, pre->row0.n);
+            m.cap_entries = std::min<int64_t>((int64_t)(m.rec.n / REC_BYTES), (int64_t)m.chunk_row0.n) * CHUNK;
+            m.n_entries = 0;
+            m.h_tiles.clear();
+            return 0;
+        }
+        pre->rec.release();
+        pre->row0.release();
     }
-    m.nrb = (int)((nrows + m.RB - 1) / m.RB);
-    m.ntc = (int)((ncols + m.TC - 1) / m.TC);
-    // marker entries: a row that is empty inside a tile between two non-empty rows of that tile.  At most one per (row, column
-    // tile); a tile needs two real entries to have any, and at most RB - 2 of them
-    int64_t markers = std::min<int64_t>((int64_t)nrows * m.ntc, (nnz_upper / 2 + 1) * (int64_t)m.RB);
-    int64_t cap = nnz_upper + markers + (int64_t)m.nrb * m.ntc * CHUNK + CHUNK;
-    cap = (cap + CHUNK - 1) / CHUNK * CHUNK;
     TFX_TRY(m.rec.alloc((size_t)(cap / CHUNK) * REC_BYTES));
     TFX_TRY(m.chunk_row0.alloc((size_t)(cap / CHUNK)));
     m.cap_entries = cap;
     m.n_entries = 0;
     m.h_tiles.clear();
+    // A large sparse kernel whose transposed copy will fit: the copy's storage is set aside now
+    if (!m.is_transpose_copy && ctx->adj_copy != 0 && m.rec.bytes() >= ((size_t)1 << 30) && (&m == &ctx->mat || &m == &ctx->mat2)) {
+        int tc, rb, nrb, ntc;
+        int64_t capT = 0;
+        tile_shape(ctx, ncols, nrows, nnz_upper + nnz_upper / 50, tc, rb, nrb, ntc, capT);
+        const size_t need = (size_t)(capT / CHUNK) * (REC_BYTES + sizeof(int32_t));
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > (double)need + 40e9) {      // (40 GB: the build's own buffers and the copy's panel scratch)
+            m.pre.reset(new TiledMatrix::Prealloc());
+            if (m.pre->rec.alloc((size_t)(capT / CHUNK) * REC_BYTES) != 0 || m.pre->row0.alloc((size_t)(capT / CHUNK)) != 0) m.pre.reset();
+        }
+        (void)hipGetLastError();
+    }
     return 0;
 }
 
@@ -672,6 +711,7 @@ int matrix_finish(tfx_ctx *ctx)
             TFX_TRY(rc);
         } else {
             const int rc = matrix_build_transpose(ctx, m);
+            m.drop_prealloc();           // (storage set aside for a copy that was not made after all)
             if (rc) {                    // (only adj_copy = 1: the copy was demanded and does not fit) - the finish failed as a whole
                 m.valid = false;
                 return rc;
@@ -1856,7 +1896,8 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
 {
     if (m.is_dense || m.is_transpose_copy || m.h_tiles.empty() || ctx->adj_copy == 0) return 0;
     hipStream_t s = ctx->stream;
-    if (ctx->adj_copy == 2) {
+    const bool have_storage = m.pre && m.pre->rec.p && m.pre->row0.p;       // set aside by matrix_begin
+    if (ctx->adj_copy == 2 && !have_storage) {
         if (m.n_entries < ctx->adj_copy_min_nnz) return 0;
         size_t free_b = 0, total_b = 0;
         TFX_HIP(hipStreamSynchronize(s));
@@ -1879,7 +1920,10 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
         return 0;
     };
     ctx->target = T;
+    ctx->pre_take = have_storage ? m.pre.get() : nullptr;
     int rc = matrix_begin(ctx, m.ncols, m.nrows, std::max<int64_t>(1, m.nnz));
+    ctx->pre_take = nullptr;
+    m.drop_prealloc();
     if (rc) return give_up(rc);
     const double t_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     // Panels.  Full height (all rows of S^T) x nt column tiles when the per-row tile index fits the budget, otherwise bands of row
