@@ -170,6 +170,16 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         return 0;
     }
     if (!strcmp(key, "adj_copy_build_ms")) return (int)(1e3 * ctx->selmat().copy_build_s);     // query: wall clock of the selected matrix's copy
+    if (!strcmp(key, "drop_adj_copy")) {        // gives up the transposed copy of the selected matrix (the adjoint then runs on the tiles of S)
+        TiledMatrix &m = ctx->selmat();
+        if (m.T) {
+            (void)hipDeviceSynchronize();
+            delete m.T;
+            m.T = nullptr;
+            m.vmax_stale = true;
+        }
+        return 0;
+    }
     if (!strcmp(key, "has_adj_copy")) return (ctx->selmat().T && ctx->selmat().T->valid) ? 1 : 0;     // query
     if (!strcmp(key, "chunk_exponent_span")) {  // diagnostics: per mille of the chunks whose non-zero values span <= `value` binades
         int64_t fit = 0, total = 0;

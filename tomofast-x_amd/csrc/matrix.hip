@@ -1459,9 +1459,9 @@ __global__ __launch_bounds__(256) void k_scale_cols(const TileMeta *__restrict__
 // Transposed copy of a tiled matrix (the adjoint product as a forward product on S^T)
 // ------------------------------------------------------------------------------------------------------------
 // S^T is made PANEL by panel: a panel is a range of rows of S^T (= columns of S, whole row blocks of S^T) times a range of column
-// tiles of S^T (= a range of rows of S).  For a wide kernel (10^7 columns, 10^5 rows) a panel is ALL rows of S^T times one column
-// tile - 25 panels of ~8e8 entries at the headline size, each a handful of launches over thousands of tiles (round 3 walked the
-// 4864 row blocks of S^T one at a time: 60 000 small launches, 15 000 host synchronisations, 6.5 s).  Per panel:
+// tiles of S^T (= a range of rows of S).  For a wide kernel (10^7 columns, 10^5 rows) a panel is a band of ~4.5e5 rows of S^T times
+// all its 25 column tiles - 23 panels of ~9e8 entries at the headline size, each a handful of launches over thousands of tiles (round
+// 3 walked the 4864 row blocks of S^T one at a time: 60 000 small launches, 15 000 host synchronisations, 6.5 s).  Per panel:
 //   (1) count: per tile of S that reaches into the panel, the entries per column (LDS histogram), by row block of S;
 //   (2) prefix over the row blocks of S and scan over the columns: every (column, row block of S) knows where its run starts in the
 //       column's row of S^T;
@@ -1935,7 +1935,17 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
     const double per_tile_col = (double)std::max<int64_t>(1, m.nnz) / (double)T->ntc;     // entries per column tile of S^T, all rows
     int nt_panel;
     int64_t band_rows;                                                    // rows of S^T per panel (multiple of RBt)
-    if ((double)nrt * 2.0 <= POS_BUDGET) {
+    const int64_t align = std::max<int64_t>(RBt, m.TC);                   // (powers of two) a band holds whole column tiles of S: every tile of S is read by one band
+    if ((double)(T->ntc + 1) * (double)align <= POS_BUDGET) {
+        // Bands of rows of S^T x ALL its column tiles: the tiles of S^T are then stored row block by row block like those of S (a
+        // work item of the forward kernel walks the column tiles of one super block: with column-tile-major storage its tiles lay
+        // 4.6 GB apart at the headline size, and the product on the copy ran 2 % behind the product on S)
+        nt_panel = T->ntc;
+        const double per_row = (double)std::max<int64_t>(1, m.nnz) / (double)nrt;
+        int64_t rows = (int64_t)std::min(PANEL_ENTRIES / per_row, POS_BUDGET / (double)(T->ntc + 1));
+        rows = std::max<int64_t>(align, rows / align * align);
+        band_rows = std::min<int64_t>(rows, (nrt + align - 1) / align * align);
+    } else if ((double)nrt * 2.0 <= POS_BUDGET) {
         band_rows = ((nrt + RBt - 1) / RBt) * RBt;
         nt_panel = (int)std::max(1.0, std::min({(double)T->ntc, POS_BUDGET / (double)nrt - 1.0, PANEL_ENTRIES / per_tile_col}));
         if (nt_panel == 1 && per_tile_col > 1.5 * PANEL_ENTRIES) {       // even one column tile is too much at full height: bands

@@ -50,6 +50,15 @@ def main(rnd):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_reduce
     pmc_reduce.main(SRC, os.path.join(DST, tag + "_pmc_summary.json"), rnd)
+    # the same workload without the transposed copy (TFX_ADJ_COPY=0: the adjoint on the tiles of S, k_spmv_adj)
+    if os.path.isfile(os.path.join(SRC, "bench_plain_nocopy.json")):
+        last_json_line(os.path.join(SRC, "bench_plain_nocopy.json"), os.path.join(DST, tag + "_bench_hamersley_1e7_nocopy.json"))
+        for sub, name in (("pmc0_FETCH_SIZE", "nocopy_pmc_FETCH_SIZE_k_spmv"), ("pmc0_WRITE_SIZE", "nocopy_pmc_WRITE_SIZE_k_spmv"),
+                          ("pmc0_SQ1", "nocopy_pmc_SQ_pass1_k_spmv"), ("pmc0_SQ2", "nocopy_pmc_SQ_pass2_k_spmv")):
+            f = newest(os.path.join(SRC, sub, "**", "*counter_collection.csv"))
+            if f:
+                shutil.copy(f, os.path.join(DST, "%s_%s.csv" % (tag, name)))
+        pmc_reduce.main(SRC, os.path.join(DST, tag + "_nocopy_pmc_summary.json"), rnd, "pmc0", "bench_plain_nocopy.json")
     if os.path.isdir(FIN):
         for src, dst in (("gpu_tests.log", tag + "_gpu_tests.log"), ("fuzz.log", tag + "_fuzz.log")):
             if os.path.isfile(os.path.join(FIN, src)):
