@@ -98,7 +98,7 @@ __host__ __device__ inline const uint32_t *chunk_slots(const char *rec, int64_t 
 __host__ __device__ inline const uint64_t *chunk_masks(const char *rec, int64_t chunk) { return reinterpret_cast<const uint64_t *>(rec + chunk * REC_BYTES + REC_MASK_OFF); }
 constexpr int TC_MAX = 4096;          // columns per column tile (12-bit local column; the x tile is 32 KB of LDS)
 constexpr int RB_MAX = 2048;          // rows per (storage) row block
-constexpr int FWD_GROUP_MAX = 4;      // the forward product walks up to this many row blocks per staged x tile (row sums: 64 KB of LDS)
+constexpr int FWD_GROUP_MAX = 2;      // the forward product walks up to this many row blocks per staged x tile (row sums: 32 KB of LDS; groups of 4 measured slower in rounds 2-3 and cost scalar registers and compares per chunk)
 // The column stored for an entry is the LDS slot of that column inside the tile, not the column itself: slot = col ^ f(col >> 4), a
 // bijection inside aligned groups of 16 (an involution) that folds the higher index bits into the four bank bits.  Wavelet
 // coefficients sit on index lattices (multiples of 2^l per axis); without the fold the columns of one LDS instruction are
