@@ -151,7 +151,7 @@ struct TiledMatrix {
     DBuf<int32_t> fwd_nslots, fwd_pbase;   // per row block
     DBuf<int32_t> adj_nslots, adj_pbase;   // per column tile
     bool adj_has_partials = false;
-    DBuf<float> tile_vmax;        // max |value| per tile: the product bound of the adjoint kernel on the tiles of S (matrix.hip k_spmv_adj);
+    DBuf<double> tile_bound;      // largest column sum of |value| per tile: the bound the adjoint kernel on the tiles of S scales by (matrix.hip k_spmv_adj);
     bool vmax_stale = true;       //   computed when that kernel is first used and again after the values changed (scale_rows)
     // dense storage (compression off): fp32 [nrows][ld], no index stream (4 B per entry)
     bool is_dense = false;

@@ -59,7 +59,7 @@ size_t TiledMatrix::device_bytes() const
 {
     return rec.bytes() + chunk_row0.bytes() + tiles.bytes() + fwd.bytes() + adj.bytes() +
            fwd_order.bytes() + adj_order.bytes() + fwd_partial.bytes() + adj_partial.bytes() + adj_nslots.bytes() +
-           adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes() + dense.bytes() + dense_partial.bytes() + tile_vmax.bytes() +
+           adj_pbase.bytes() + fwd_nslots.bytes() + fwd_pbase.bytes() + dense.bytes() + dense_partial.bytes() + tile_bound.bytes() +
            (T ? T->device_bytes() : 0);
 }
 
@@ -68,7 +68,7 @@ void TiledMatrix::release_storage()
     rec.release(); chunk_row0.release(); tiles.release(); fwd.release(); adj.release();
     fwd_order.release(); adj_order.release(); fwd_partial.release(); adj_partial.release();
     fwd_nslots.release(); fwd_pbase.release(); adj_nslots.release(); adj_pbase.release();
-    dense.release(); dense_partial.release(); tile_vmax.release();
+    dense.release(); dense_partial.release(); tile_bound.release();
     vmax_stale = true;
     drop_prealloc();
     delete T;
@@ -1043,16 +1043,20 @@ __global__ __launch_bounds__(FR_ROWS * FR_GROUPS) void k_fwd_reduce(const double
 // column tile; slot 0 adds into y, the others write partials.
 //
 // The column sums of a tile group are accumulated in LDS by all 16 waves at once, so an fp64 accumulation would depend on the order
-// in which the waves' adds arrive.  They are therefore accumulated EXACTLY: the group's u rows are staged times 2^k, with k chosen
-// from max|u| of those rows and max|value| of the group's tiles (tile_vmax[], kept with the matrix) such that every product is below
-// 2^(62 - ceil(log2 rows)) in magnitude; fma(value, u * 2^k, 1.5 * 2^52) rounds the product to an integer (ties to even) and leaves
-// it in the low bits of the result, and the integers are added with 64-bit LDS integer atomics - associative, so the sums do not
-// depend on any order and can not overflow.  One rounding per product, at 2^-49 .. 2^-50 of the largest product of the group (for a
-// two-row-block group; an fp64 accumulation rounds every partial sum to 2^-53 of itself).  At the end of the group every thread
-// converts its own columns back (int64 -> fp64, one rounding) and adds them to its running fp64 column sums, in group order.
-constexpr double ADJ_MAGIC = 6755399441055744.0;       // 1.5 * 2^52: fp64 numbers in [2^52, 2^53) have unit spacing
+// in which the waves' adds arrive.  They are therefore accumulated EXACTLY, in 64-bit integers: the group's u rows are staged times
+// 2^k, with k chosen such that no column sum of the group can reach 2^61 in magnitude - the bound is max|u| of the staged rows times
+// the largest column sum of |value| of the group's tiles (tile_bound[], computed once per matrix, exactly, in integers: the same
+// bits on every run).  Every product value * (u * 2^k) is rounded ONCE to an integer (the fp64 product has 77 significant bits; it
+// is split into a multiple of 2^32 and a remainder by two fma's against 1.5 * 2^84 and 1.5 * 2^52, whose low mantissa bits then
+// hold the two halves) and the integers are added with 64-bit LDS integer atomics - associative, so the sums do not depend on any
+// order and can not overflow.  The grid of that one rounding is 2^-60 .. 2^-61 of the bound, i.e. of (largest column sum of |value|
+// x max|u|): for the ~50 entries per column of a tile of a wavelet-compressed kernel about 2^-56 of the largest product, finer than
+// the 2^-53 an fp64 accumulation rounds every partial sum to.  At the end of the group every thread converts its own columns back
+// (int64 -> fp64, one rounding) and adds them to its running fp64 column sums, in group order.
+constexpr double ADJ_MAGIC_LO = 6755399441055744.0;                       // 1.5 * 2^52: unit spacing
+constexpr double ADJ_MAGIC_HI = 6755399441055744.0 * 4294967296.0;        // 1.5 * 2^84: spacing 2^32
 constexpr int ADJ_COLS_PER_THREAD = TC_MAX / 1024;
-__global__ __launch_bounds__(1024, 8) void k_spmv_adj(MAT_PARAMS, const float *__restrict__ tile_vmax, const double *__restrict__ u,
+__global__ __launch_bounds__(1024, 8) void k_spmv_adj(MAT_PARAMS, const double *__restrict__ tile_bound, const double *__restrict__ u,
                                                        double *__restrict__ y, double *__restrict__ partial, int64_t nrows, int64_t ncols,
                                                        int TC, int RB, int GROUP)
 {
@@ -1069,20 +1073,15 @@ __global__ __launch_bounds__(1024, 8) void k_spmv_adj(MAT_PARAMS, const float *_
     for (int j = 0; j < ADJ_COLS_PER_THREAD; ++j) colsum[j] = 0.0;
     int kprev = 0;                               // scale exponent of the group whose integer sums are still in acc[]
     bool pending = false;
-    // the headroom of the integer sums: a column collects at most GROUP * RB products per group
-    int hb = 0;
-    while ((1 << hb) < GROUP * RB) ++hb;
-    const int pbits = min(50, 62 - hb);          // |product * 2^k| < 2^pbits  (<= 2^50 keeps fma(..., ADJ_MAGIC) inside its binade)
     int ti = it.begin;
     while (ti < it.end) {
         TileGroup g;
         TileMeta tm;
         make_group<false>(it, order, tiles, ti, GROUP, g, tm);
-        uint32_t vmb = __float_as_uint(tile_vmax[order[ti]]);     // (bit patterns of non-negative floats order like the values; NaN on top)
+        double csum = tile_bound[order[ti]];      // a column of the group collects at most the sum of the tiles' largest column sums
 #pragma unroll
         for (int j = 1; j < FWD_GROUP_MAX; ++j)
-            if (j < g.ng) vmb = max(vmb, __float_as_uint(tile_vmax[order[ti + j]]));
-        const float vmax = __uint_as_float(vmb);
+            if (j < g.ng) csum = csum + tile_bound[order[ti + j]];
         ti += g.ng;
         __syncthreads();
         if (pending) {
@@ -1120,8 +1119,8 @@ __global__ __launch_bounds__(1024, 8) void k_spmv_adj(MAT_PARAMS, const float *_
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) umb = max(umb, s_umax[w]);
         const double umax = __longlong_as_double((long long)umb);
-        const double bound = umax * (double)vmax;                 // >= |value * u| of every entry of the group
-        const bool finite = bound < __builtin_huge_val();         // false for inf and NaN
+        const double bound = umax * csum;                          // >= |any column sum of the group| (and >= every single product)
+        const bool finite = bound < __builtin_huge_val();          // false for inf and NaN (tile_bound is NaN when a value is)
         if (!finite) {
             // u holds an inf / NaN (or the bound overflows): the sums are poisoned like the fp64 sums would be
 #pragma unroll
@@ -1130,7 +1129,7 @@ __global__ __launch_bounds__(1024, 8) void k_spmv_adj(MAT_PARAMS, const float *_
         pending = finite && bound > 0.0;
         int k = 0;
         if (pending) {
-            k = pbits - (ilogb(bound) + 1);                        // bound < 2^(ilogb + 1)
+            k = 60 - ilogb(bound);                                 // bound < 2^(ilogb + 1)  ->  |sums| < 2^61 (+ the roundings of <= 8192 products)
             for (int i = lo + tid; i < hi; i += THREADS) us[i] = ldexp(us[i], k);
         }
         kprev = k;
@@ -1145,15 +1144,23 @@ __global__ __launch_bounds__(1024, 8) void k_spmv_adj(MAT_PARAMS, const float *_
             load_chunk(rec, ch, lane, cr);
             int cur = chunk_row0[ch] + load_masks(rec, ch, mk);
             double uval = ub[max(cur, 0)];
+            // p = value * uval (|p| < 2^61): s1 = p + 1.5 * 2^84 rounds p to a multiple th of 2^32 and holds th / 2^32 in its low
+            // mantissa bits; p - th is exact to 2^-22 (fma) and |p - th| <= 2^31, s3 = (p - th) + 1.5 * 2^52 rounds it to an integer
+            // held in ITS low mantissa bits; the 64-bit integer is th + that: low dword = low dword of s3, high dword = low dword of
+            // s1 + the (sign-extending) high dword of s3's integer
 #define ADJ_STEP(K)                                                                                          \
             if (ROWSTART_K(mk, K)) {                                                                         \
                 cur += 1;                                                                                    \
                 uval = ub[cur];                                                                              \
             }                                                                                                \
             if (cr.v[K] != 0.0f) {                                                                           \
-                const double t = fma((double)cr.v[K], uval, ADJ_MAGIC);                                      \
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(t) - 0x4338000000000000ull; \
-                atomicAdd(&acc[slot_of<K>(cr)], bits);                                                       \
+                const double vd = (double)cr.v[K];                                                           \
+                const double s1 = fma(vd, uval, ADJ_MAGIC_HI);                                               \
+                const double th = s1 - ADJ_MAGIC_HI;                                                         \
+                const double s3 = fma(vd, uval, -th) + ADJ_MAGIC_LO;                                         \
+                const uint32_t qlo = (uint32_t)__double2loint(s3);                                           \
+                const uint32_t qhi = (uint32_t)__double2loint(s1) + ((uint32_t)__double2hiint(s3) - 0x43380000u); \
+                atomicAdd(&acc[slot_of<K>(cr)], ((unsigned long long)qhi << 32) | qlo);                      \
             }
             ADJ_STEP(0) ADJ_STEP(1) ADJ_STEP(2) ADJ_STEP(3) ADJ_STEP(4) ADJ_STEP(5) ADJ_STEP(6) ADJ_STEP(7)
 #undef ADJ_STEP
@@ -1181,11 +1188,15 @@ __global__ __launch_bounds__(1024, 8) void k_spmv_adj(MAT_PARAMS, const float *_
     }
 }
 
-// tile_vmax[tile] = max |value| of the tile (the bound the adjoint kernel scales its products by)
-__global__ __launch_bounds__(256) void k_tile_vmax(const TileMeta *__restrict__ tiles, int ntiles, const char *__restrict__ rec,
-                                                    float *__restrict__ tile_vmax)
+// tile_bound[tile] = the largest column sum of |value| inside the tile, rounded up - what a column of the adjoint product can collect
+// from the tile per unit of max|u|.  Exact integer arithmetic (|value| scaled to 30 bits below the tile's largest, rounded up, summed in
+// 64-bit LDS integers), so the bound - and with it the scale of the adjoint's integer sums - has the same bits on every run.  NaN when
+// a value is NaN / inf.
+__global__ __launch_bounds__(256) void k_tile_bound(const TileMeta *__restrict__ tiles, int ntiles, const char *__restrict__ rec, int TC,
+                                                     double *__restrict__ tile_bound)
 {
-    __shared__ uint32_t part[4];
+    extern __shared__ unsigned long long cs[];      // TC column sums
+    __shared__ unsigned long long part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
         const TileMeta tm = tiles[ti];
@@ -1198,8 +1209,37 @@ __global__ __launch_bounds__(256) void k_tile_vmax(const TileMeta *__restrict__ 
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
         if (lane == 0) part[wave] = m;
+        for (int i = threadIdx.x; i < TC; i += blockDim.x) cs[i] = 0ull;
         __syncthreads();
-        if (threadIdx.x == 0) tile_vmax[ti] = __uint_as_float(max(max(part[0], part[1]), max(part[2], part[3])));
+        const uint32_t vmb = (uint32_t)max(max(part[0], part[1]), max(part[2], part[3]));
+        __syncthreads();
+        const float vmax = __uint_as_float(vmb);
+        if (!(vmax < __builtin_huge_valf())) {       // NaN or inf among the values
+            if (threadIdx.x == 0) tile_bound[ti] = __builtin_nan("");
+            continue;
+        }
+        if (vmax == 0.0f) {
+            if (threadIdx.x == 0) tile_bound[ti] = 0.0;
+            continue;
+        }
+        const int ev = ilogbf(vmax) + 1;             // |value| < 2^ev
+        for (int c = wave; c < tm.nchunks; c += 4) {
+            ChunkRegs cr;
+            load_chunk(rec, cbase + c, lane, cr);
+            const uint32_t sl[8] = {slot_of<0>(cr), slot_of<1>(cr), slot_of<2>(cr), slot_of<3>(cr), slot_of<4>(cr), slot_of<5>(cr), slot_of<6>(cr), slot_of<7>(cr)};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (cr.v[k] != 0.0f) atomicAdd(&cs[sl[k]], (unsigned long long)ceil(ldexp((double)fabsf(cr.v[k]), 30 - ev)));
+        }
+        __syncthreads();
+        unsigned long long mx = 0ull;
+        for (int i = threadIdx.x; i < TC; i += blockDim.x) mx = max(mx, cs[i]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mx = max(mx, (unsigned long long)__shfl_xor((long long)mx, d));
+        __syncthreads();
+        if (lane == 0) part[wave] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_bound[ti] = ldexp((double)max(max(part[0], part[1]), max(part[2], part[3])), ev - 30);
         __syncthreads();
     }
 }
@@ -1414,14 +1454,15 @@ int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int 
         const MatPtrs mp = mat_ptrs(m, false);
         if (m.vmax_stale) {
             const int nt = (int)m.h_tiles.size();
-            TFX_TRY(m.tile_vmax.ensure((size_t)nt));
-            hipLaunchKernelGGL(k_tile_vmax, dim3((unsigned)std::min(nt, 65536)), dim3(256), 0, s, m.tiles.p, nt, m.rec.p, m.tile_vmax.p);
+            TFX_TRY(m.tile_bound.ensure((size_t)nt));
+            hipLaunchKernelGGL(k_tile_bound, dim3((unsigned)std::min(nt, 65536)), dim3(256), (size_t)m.TC * sizeof(unsigned long long), s, m.tiles.p, nt,
+                               m.rec.p, m.TC, m.tile_bound.p);
             TFX_HIP(hipGetLastError());
             m.vmax_stale = false;
         }
         if (prof) prof_begin(ctx);
         TFX_TRY(set_lds_limit(ctx, 2, (const void *)k_spmv_adj, lds));
-        hipLaunchKernelGGL(k_spmv_adj, dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), m.tile_vmax.p, d_x, d_b,
+        hipLaunchKernelGGL(k_spmv_adj, dim3((unsigned)m.h_adj.size()), dim3(SPMV_THREADS), lds, s, MAT_ARGS(mp), m.tile_bound.p, d_x, d_b,
                            m.adj_partial.p, m.nrows, m.ncols, m.TC, m.RB, m.fwd_group);
         if (prof) prof_end(ctx, 1);
         TFX_HIP(hipGetLastError());
