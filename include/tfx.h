@@ -316,6 +316,8 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * transposed copy of their tiles so that the adjoint product runs as the forward kernel on S^T (twice the matrix memory, a longer
  * build - DESIGN.md 3); automatic = matrices of at least "adj_copy_min_nnz" stored entries (default 0) whenever the device has
  * room; 1 = a copy that does not fit is an error; without a copy the adjoint runs on the tiles of S (exact integer accumulation);
+ * "tr_panel_entries" / "tr_pos_budget" (0 = default) size the panels the copy is built in (tests force many small panels of either
+ * shape), "drop_adj_copy" gives the copy of the selected matrix up;
  * "has_adj_copy" queries the selected matrix, "adj_copy_build_ms" returns the wall clock its copy took to build (ms);
  * key "build_overlap" (0/1/2, default 1): the kernel build runs its row generator (VALU-bound) on a second stream one batch ahead of
  * the wavelet / threshold / compaction kernels (HBM-bound) of the main stream and reads each batch's statistics one batch late

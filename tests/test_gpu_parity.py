@@ -649,6 +649,35 @@ def test_adjoint_on_the_transposed_copy(ctx, shape):
         ctx.debug_set("adj_copy", 2)
 
 
+@pytest.mark.parametrize("shape", [(3000, 40000, 300), (20000, 3000, 40), (9000, 9000, 60)])
+def test_transposed_copy_is_the_same_whatever_the_panels(ctx, shape):
+    """matrix_build_transpose makes S^T panel by panel; the panel shape follows the matrix and two budgets (entries per panel, ints
+    of per-row tile index).  Whatever the cut - one panel, many bands of rows x all column tiles, full height x one column tile, bands
+    of single column tiles - the copy holds the same rows, so the adjoint product has the same bits (the forward kernel on S^T
+    adds in an order fixed by the rows of S^T, not by where its tiles are stored)."""
+    nrows, ncols, per_row = shape
+    rng = np.random.default_rng(nrows + 3 * ncols)
+    S = _random_csr(rng, nrows, ncols, per_row)
+    y = rng.standard_normal(nrows)
+    reft = orc.spmtv(*S, y, ncols)
+    tol = 1e-12 * orc.spmtv(S[0], S[1], np.abs(S[2]), np.abs(y), ncols) + 1e-300
+    out = []
+    try:
+        for entries, budget in ((0, 0), (200000, 0), (50000, 0), (200000, 3 * ncols), (50000, 2 * ncols + 2), (50000, 5000)):
+            ctx.debug_set("tr_panel_entries", entries)
+            ctx.debug_set("tr_pos_budget", budget)
+            ctx.matrix_upload_csr(nrows, ncols, *S)
+            assert ctx.debug_set("has_adj_copy") == 1
+            bt = ctx.trans_mult_vector(y)
+            assert np.all(np.abs(bt - reft) <= tol), (entries, budget)
+            out.append(bt)
+        for bt in out[1:]:
+            assert bits_equal(bt, out[0])
+    finally:
+        ctx.debug_set("tr_panel_entries", 0)
+        ctx.debug_set("tr_pos_budget", 0)
+
+
 def test_lsqr_with_the_adjoint_copy_matches_the_one_copy_solver(ctx, golden_dir):
     """The solver sees no difference: same iterates (to the products' rounding) with the adjoint on the transposed copy, also for the
     general constraint matrix C (it gets a copy too) - lsqr_solver2.F90:230-241."""

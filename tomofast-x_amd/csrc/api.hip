@@ -170,6 +170,14 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         return 0;
     }
     if (!strcmp(key, "adj_copy_build_ms")) return (int)(1e3 * ctx->selmat().copy_build_s);     // query: wall clock of the selected matrix's copy
+    if (!strcmp(key, "tr_panel_entries")) {     // entries per panel of the transposition (0 = default)
+        ctx->tr_panel_entries = value > 0 ? (double)value : 9.0e8;
+        return 0;
+    }
+    if (!strcmp(key, "tr_pos_budget")) {        // ints of per-row tile index a panel may use (0 = default): small values force full-height / banded panels
+        ctx->tr_pos_budget = value > 0 ? (double)value : 1.5e8;
+        return 0;
+    }
     if (!strcmp(key, "drop_adj_copy")) {        // gives up the transposed copy of the selected matrix (the adjoint then runs on the tiles of S)
         TiledMatrix &m = ctx->selmat();
         if (m.T) {

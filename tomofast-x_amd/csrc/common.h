@@ -151,6 +151,7 @@ struct TiledMatrix {
     DBuf<int32_t> fwd_nslots, fwd_pbase;   // per row block
     DBuf<int32_t> adj_nslots, adj_pbase;   // per column tile
     bool adj_has_partials = false;
+    double fwd_avg_nslots = 0.0;  // partial tiles per forward super block on average (picks the reduction kernel)
     DBuf<double> tile_bound;      // largest column sum of |value| per tile: the bound the adjoint kernel on the tiles of S scales by (matrix.hip k_spmv_adj);
     bool vmax_stale = true;       //   computed when that kernel is first used and again after the values changed (scale_rows)
     // dense storage (compression off): fp32 [nrows][ld], no index stream (4 B per entry)
@@ -274,6 +275,7 @@ struct tfx_ctx {
         tfx::DBuf<int64_t> rowoff, totals, bsum;
         tfx::DBuf<float> tvals;
     } trs;
+    double tr_panel_entries = 9.0e8, tr_pos_budget = 1.5e8;   // panel size of the transposition (debug keys "tr_panel_entries" / "tr_pos_budget": tests force many small panels of either shape)
     int fwd_run = 2;                  // debug key "fwd_run": consecutive chunks a wave of the forward kernel takes at a time (matrix.hip k_spmv_fwd)
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
     size_t wave_lds_attr[4] = {0, 0, 0, 0};   // the same for the four wavelet axis kernels (Haar / D4 x forward / inverse)

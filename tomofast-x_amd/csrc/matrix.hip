@@ -699,6 +699,7 @@ int matrix_finish(tfx_ctx *ctx)
     TFX_TRY(m.adj_partial.alloc(std::max<size_t>(1, (size_t)nap * m.TC)));
     TFX_HIP(hipStreamSynchronize(s));
     m.adj_has_partials = nap > 0;
+    m.fwd_avg_nslots = nsb > 0 ? (double)nfp / (double)nsb : 0.0;
     m.vmax_stale = true;
     m.nnz = real;
     m.valid = true;
@@ -1035,6 +1036,27 @@ __global__ __launch_bounds__(FR_ROWS * FR_GROUPS) void k_fwd_reduce(const double
         double t = add ? b[r] : 0.0;
 #pragma unroll
         for (int q = 0; q < FR_GROUPS; ++q) t += part[q][lr_in];
+        b[r] = t;
+    }
+}
+
+// The same sums in the same association (hence the same bits) with one thread per row, consecutive threads on consecutive rows: for
+// matrices with many rows and few partial tiles per super block - the transposed copy of a wide kernel has 10^7 rows and mostly one
+// or two partial tiles per super block, and the blocked kernel above spent 0.28 ms per product there (16 rows per workgroup, most
+// of its 16 thread groups idle).
+__global__ __launch_bounds__(256) void k_fwd_reduce_flat(const double *__restrict__ partial, const int32_t *__restrict__ nslots,
+                                                          const int32_t *__restrict__ pbase, int SB, int64_t nrows, double *__restrict__ b, int add)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int sb = (int)(r / SB), lr = (int)(r - (int64_t)sb * SB);
+        const int ns = nslots[sb], p0 = pbase[sb];
+        double t = add ? b[r] : 0.0;
+#pragma unroll 4
+        for (int q = 0; q < FR_GROUPS; ++q) {
+            double s = 0.0;                                   // (thread group q of k_fwd_reduce: every FR_GROUPS-th partial tile, in order)
+            for (int k = q; k < ns; k += FR_GROUPS) s += partial[(int64_t)(p0 + k) * SB + lr];
+            t += s;
+        }
         b[r] = t;
     }
 }
@@ -1410,8 +1432,12 @@ static int forward_product(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, doub
         if (prof) prof_end(ctx, prof_slot);
         TFX_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_fwd_reduce, dim3((unsigned)((m.nrows + FR_ROWS - 1) / FR_ROWS)), dim3(FR_ROWS * FR_GROUPS), 0, s, m.fwd_partial.p,
-                       m.fwd_nslots.p, m.fwd_pbase.p, SB, m.nrows, d_b, add);
+    if (m.nrows >= 65536 && m.fwd_avg_nslots <= 8.0)
+        hipLaunchKernelGGL(k_fwd_reduce_flat, dim3((unsigned)std::min<int64_t>((m.nrows + 255) / 256, (int64_t)ctx->num_cu * 32)), dim3(256), 0, s,
+                           m.fwd_partial.p, m.fwd_nslots.p, m.fwd_pbase.p, SB, m.nrows, d_b, add);
+    else
+        hipLaunchKernelGGL(k_fwd_reduce, dim3((unsigned)((m.nrows + FR_ROWS - 1) / FR_ROWS)), dim3(FR_ROWS * FR_GROUPS), 0, s, m.fwd_partial.p,
+                           m.fwd_nslots.p, m.fwd_pbase.p, SB, m.nrows, d_b, add);
     TFX_HIP(hipGetLastError());
     return 0;
 }
@@ -1970,7 +1996,7 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
     // Panels.  Full height (all rows of S^T) x nt column tiles when the per-row tile index fits the budget, otherwise bands of row
     // blocks x all column tiles; nt / the band height are cut so that a panel holds about PANEL_ENTRIES entries (estimated from the
     // mean density; the scratch grows to what a panel really holds).
-    constexpr double PANEL_ENTRIES = 9.0e8, POS_BUDGET = 1.5e8;      // entries (8 B each of scratch + 2 B) ; ints of pos[] / segoff[]
+    const double PANEL_ENTRIES = ctx->tr_panel_entries, POS_BUDGET = ctx->tr_pos_budget;      // entries (8 B each of scratch + 2 B) ; ints of pos[] / segoff[]
     const int RBt = T->RB, TCt = T->TC;
     const int64_t nrt = m.ncols;                                          // rows of S^T
     const double per_tile_col = (double)std::max<int64_t>(1, m.nnz) / (double)T->ntc;     // entries per column tile of S^T, all rows
