@@ -271,7 +271,7 @@ struct tfx_ctx {
     int adj_copy = 2;
     int64_t adj_copy_min_nnz = 0;
     struct TransposeScratch {
-        tfx::DBuf<int32_t> cnt, nel, tcols, tids, toff, bmax;
+        tfx::DBuf<int32_t> cnt, nel, tcols, tids, bmax;
         tfx::DBuf<int64_t> rowoff, totals, bsum;
         tfx::DBuf<float> tvals;
     } trs;
@@ -291,7 +291,7 @@ struct tfx_ctx {
 namespace tfx {
 // matrix.hip
 int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const int32_t *d_cols, const float *d_vals,
-                       const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen, int64_t packed_total = 0);
+                       const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen);
 int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper);
 int matrix_finish(tfx_ctx *ctx);
 int spmv_dev(tfx_ctx *ctx, const double *d_x, double *d_b, int add);     // b (+)= S x   (device pointers)

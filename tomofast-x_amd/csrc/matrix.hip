@@ -18,11 +18,12 @@
 //
 // Both products stream every tile once, coalesced, and keep the vector side of the product in LDS:
 //   forward: the x tile (TC doubles, 32 KB) is staged in LDS once for up to FWD_GROUP_MAX row blocks (a "super block"),
-//            whose row sums are accumulated in LDS (4 x RB doubles, 64 KB);
-//   adjoint: the u rows of the block are staged in LDS, the column sums live in LDS (TC doubles) and are
-//            written once.
+//            whose row sums are accumulated in LDS (2 x RB doubles, 32 KB);
+//   adjoint: by default the forward kernel on a transposed copy of the tiles (matrix_build_transpose); without the copy the u rows of
+//            the block are staged in LDS and the column sums are accumulated there exactly, in 64-bit integers (k_spmv_adj).
 // Row membership comes from the row-start masks with mbcnt prefix counts; short row segments are
 // summed inside a lane, the segment tails are merged across lanes with one segmented wave reduction per chunk.
+// Both products give the same bits on every run (DESIGN.md 4 "Reproducibility").
 #include "common.h"
 #include <algorithm>
 #include <chrono>
@@ -214,31 +215,6 @@ __global__ void k_tile_scatter(const int32_t *__restrict__ cols, const float *__
     int p0 = pos[(int64_t)r * (ntc + 1) + t];
     int64_t dst = tile_off[t] + segoff[(int64_t)t * (nr + 1) + r] + (j - p0);
     put_entry16(tmp16, base, rec, dst, (uint32_t)col_slot(c - t * TC), j == p0, vals[src]);
-}
-
-// The same for rows that are PACKED one behind the other (rowoff[r + 1] = rowoff[r] + nel[r]; the rows of a transposed block have
-// lengths from 0 to the whole data set, so a grid over (longest row x rows) would be almost empty): one thread per entry of the
-// packed buffer, its row by binary search in rowoff[].
-__global__ void k_tile_scatter_packed(const int32_t *__restrict__ cols, const float *__restrict__ vals, const int64_t *__restrict__ rowoff,
-                                      int64_t total, int ntc, int TC, int nr, const int32_t *__restrict__ pos,
-                                      const int32_t *__restrict__ segoff, const int64_t *__restrict__ tile_off,
-                                      uint16_t *__restrict__ tmp16, int64_t base, char *__restrict__ rec)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int lo = 0, hi = nr - 1;                    // largest r with rowoff[r] <= i (empty rows share their offset with the next row: take the last)
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (rowoff[mid] <= i) lo = mid;
-        else hi = mid - 1;
-    }
-    const int r = lo;
-    const int j = (int)(i - rowoff[r]);
-    const int32_t c = cols[i];
-    const int t = c / TC;
-    const int p0 = pos[(int64_t)r * (ntc + 1) + t];
-    const int64_t dst = tile_off[t] + segoff[(int64_t)t * (nr + 1) + r] + (j - p0);
-    put_entry16(tmp16, base, rec, dst, (uint32_t)col_slot(c - t * TC), j == p0, vals[i]);
 }
 
 // Markers for empty rows strictly between the first and last non-empty row of a tile.  grid = (ntc), block 256.
@@ -470,9 +446,8 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 // Appends the tiles of one row block.  Row r of the block has d_nel[r] entries starting at d_cols/d_vals +
 // d_rowoff[r] (columns ascending, 0-based local); maxlen >= max d_nel.  row_begin must be a multiple of RB, nr <= RB.
 // Everything is queued on the ctx stream; the inputs may be reused by work queued on that stream afterwards.
-// packed_total > 0: the rows lie packed one behind the other (d_rowoff[r + 1] = d_rowoff[r] + d_nel[r]) and hold that many entries.
 int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int32_t *d_cols, const float *d_vals,
-                       const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen, int64_t packed_total)
+                       const int32_t *d_nel, const int64_t *d_rowoff, int64_t maxlen)
 {
     TiledMatrix &m = *ctx->target;
     hipStream_t s = ctx->stream;
@@ -537,10 +512,7 @@ int matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr64, const int3
         TFX_HIP(hipMemcpyAsync(sc.tile_off.p, sc.h_off.data(), ntc * sizeof(int64_t), hipMemcpyHostToDevice, s));
         TFX_HIP(hipMemcpyAsync(sc.tile_nch.p, sc.h_nch.data(), ntc * sizeof(int32_t), hipMemcpyHostToDevice, s));
         const int64_t smax = maxlen;
-        if (packed_total > 0)
-            hipLaunchKernelGGL(k_tile_scatter_packed, dim3((unsigned)((packed_total + 255) / 256)), dim3(256), 0, s, s_cols, s_vals, s_off,
-                               packed_total, ntc, m.TC, nr, sc.pos.p, sc.segoff.p, sc.tile_off.p, sc.tmp16.p, m.n_entries, m.rec.p);
-        else if (smax > 0)
+        if (smax > 0)
             hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((smax + 255) / 256), nr), dim3(256), 0, s, s_cols, s_vals,
                                s_nel, s_off, ntc, m.TC, nr, sc.pos.p, sc.segoff.p, sc.tile_off.p, sc.tmp16.p, m.n_entries, m.rec.p);
         hipLaunchKernelGGL(k_pack_slots, dim3((unsigned)std::min<int64_t>(8192, ((cur - m.n_entries) / 8 + 255) / 256)), dim3(256), 0, s,
