@@ -56,3 +56,56 @@ def test_pmc_reduce_counts_only_the_newest_pass_and_refuses_nonsense(tmp_path):
     with pytest.raises(SystemExit):
         pmc_reduce.main(src, dst, 3)
     assert not os.path.exists(dst)
+
+
+def test_pmc_reduce_tells_the_two_forward_launches_apart_by_grid_size(tmp_path):
+    """With the transposed copy the adjoint product is k_spmv_fwd on S^T: the launches differ in grid size (the two work lists), the
+    first launch of a run is a forward product on S; a launch streams one of the two copies."""
+    import pmc_reduce
+    src = str(tmp_path)
+    one_copy = 2.0 * 1024.0 * 1000.0
+    _bench_lines(src, 2.0 * one_copy)                  # the device bytes count both copies
+    head = '"Dispatch_Id","Grid_Size","Kernel_Name","Counter_Name","Counter_Value"\n'
+    for sub, counter, kib_s, kib_t in (("pmc_FETCH_SIZE", "FETCH_SIZE", 1000.0, 1010.0), ("pmc_WRITE_SIZE", "WRITE_SIZE", 2.0, 5.0)):
+        os.makedirs(os.path.join(src, sub, "runc"))
+        with open(os.path.join(src, sub, "runc", "1_counter_collection.csv"), "w") as f:
+            f.write(head)
+            for i in range(4):
+                f.write('%d,4194304,"void tfx::k_spmv_fwd<16>(...)","%s",%f\n' % (10 + 2 * i, counter, kib_s))
+                f.write('%d,5000192,"void tfx::k_spmv_fwd<16>(...)","%s",%f\n' % (11 + 2 * i, counter, kib_t))
+    dst = os.path.join(src, "summary.json")
+    pmc_reduce.main(src, dst, 4)
+    d = json.load(open(dst))
+    assert d["copies_of_the_tiles"] == 2 and set(d["kernels"]) == {"k_spmv_fwd", "k_spmv_fwd_on_copy"}
+    assert d["kernels"]["k_spmv_fwd"]["FETCH_SIZE_raw_KiB_avg"] == 1000.0 and d["kernels"]["k_spmv_fwd_on_copy"]["FETCH_SIZE_raw_KiB_avg"] == 1010.0
+    assert abs(d["kernels"]["k_spmv_fwd"]["fetch_over_device_bytes"] - 1.0) < 1e-12
+    assert d["kernels"]["k_spmv_fwd_on_copy"]["WRITE_SIZE_raw_KiB_avg"] == 5.0
+
+
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 4` with no WORLD_SIZE in the environment re-runs itself under torch.distributed.run on 127.0.0.1 at a
+    free port with the same arguments, and exits with that run's status - it must never die on a missing launcher."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, *a, **k):
+        seen["cmd"] = cmd
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--workload", "small"])
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(4)
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--workload", "small"] and cmd[-7].endswith("bench.py")
+    # main() takes that route exactly when WORLD_SIZE is absent and N > 1
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    called = []
+    monkeypatch.setattr(bench, "self_launch", lambda n: called.append(n) or (_ for _ in ()).throw(SystemExit(0)))
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert called == [4]
