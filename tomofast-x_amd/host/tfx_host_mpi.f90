@@ -83,7 +83,9 @@ contains
   ! The collectives of the path for this ctx, as a ladder every rank climbs in lock-step (the outcome of each rung is agreed with an
   ! MPI_Allreduce(MIN), so a failure on one rank moves all of them on instead of stranding the others inside a collective):
   !   1. RCCL inside libtfx.so when every rank of every node has a GPU of its own (TFX_COMM=rccl insists, TFX_COMM=mpi skips):
-  !      tfx_comm_init_rccl, then the communicator must count nbproc members and pass a barrier;
+  !      tfx_comm_init_rccl (it gives up by itself after TFX_COMM_INIT_TIMEOUT seconds - 120 by default - when a peer never reaches the
+  !      rendezvous: the wait is inside the library, so a rank that died before the rendezvous costs the timeout, not the run), then the
+  !      communicator must count nbproc members and pass a barrier;
   !   2. the MPI-staged hook (ranks sharing a GPU on a test box, or RCCL unable to connect the ranks).
   subroutine host_comm_setup(ctx)
     type(c_ptr), intent(in) :: ctx
