@@ -647,7 +647,17 @@ int matrix_finish(tfx_ctx *ctx)
     const int nsb = (m.nrb + m.fwd_group - 1) / m.fwd_group;
     std::vector<int32_t> fo, ao, fns, ans, fpb, apb;
     int nfp = 0, nap = 0;
-    build_items(m.h_tiles, true, m.fwd_group, target, m.h_fwd, fo, nfp, fns, fpb, nsb);
+    // Every forward item writes a partial tile of fwd_group * RB row sums that k_fwd_reduce reads back: for a matrix with few rows
+    // per entry that traffic rivals the matrix itself (1e6 cells x 4096 data: 4096 items x 32 KB = 134 MB written and read per
+    // product against 480 MB of tiles).  The forward list is therefore cut no finer than keeps the partial tiles at ~10 % of the
+    // matrix bytes (never coarser than 2 items per CU).
+    int64_t target_fwd = target;
+    {
+        const double part_bytes = (double)m.fwd_group * m.RB * sizeof(double);
+        const double max_items = std::max(2.0 * std::max(1, ctx->num_cu), 0.1 * ((double)m.n_entries / CHUNK * REC_BYTES) / part_bytes);
+        target_fwd = std::max<int64_t>(target, (int64_t)((double)m.n_entries / max_items));
+    }
+    build_items(m.h_tiles, true, m.fwd_group, target_fwd, m.h_fwd, fo, nfp, fns, fpb, nsb);
     build_items(m.h_tiles, false, 1, target, m.h_adj, ao, nap, ans, apb, m.ntc);
     TFX_TRY(m.fwd.alloc(std::max<size_t>(1, m.h_fwd.size())));
     TFX_TRY(m.adj.alloc(std::max<size_t>(1, m.h_adj.size())));
@@ -952,7 +962,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_fwd(MA
             for (int i = tid; i < TC; i += THREADS) xs[col_slot(i)] = (i < ncol) ? x[col0 + i] : 0.0;
         }
         __syncthreads();
-        const int run_len = max(RUN, (g.total + FWD_MAX_RUNS - 1) / FWD_MAX_RUNS);
+        // (a short group - small matrices have tiles of a few dozen chunks - is dealt chunk by chunk: runs of RUN would leave waves idle)
+        const int run_len = g.total < 4 * WAVES * RUN ? 1 : max(RUN, (g.total + FWD_MAX_RUNS - 1) / FWD_MAX_RUNS);
         const int nruns = (g.total + run_len - 1) / run_len;
         nruns_prev = nruns;
         for (int run = wave; run < nruns; run += WAVES) {
@@ -1404,7 +1415,7 @@ static int forward_product(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, doub
         if (prof) prof_end(ctx, prof_slot);
         TFX_HIP(hipGetLastError());
     }
-    if (m.nrows >= 65536 && m.fwd_avg_nslots <= 8.0)
+    if (m.nrows >= 65536 || (m.nrows >= 8192 && m.fwd_avg_nslots <= 16.0))
         hipLaunchKernelGGL(k_fwd_reduce_flat, dim3((unsigned)std::min<int64_t>((m.nrows + 255) / 256, (int64_t)ctx->num_cu * 32)), dim3(256), 0, s,
                            m.fwd_partial.p, m.fwd_nslots.p, m.fwd_pbase.p, SB, m.nrows, d_b, add);
     else
