@@ -68,6 +68,11 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the matrix kernels with HIP events")
     ap.add_argument("--full-select", action="store_true", help="A/B: thresholds by the full radix select instead of the band select")
     args = ap.parse_args()
+    if os.environ.get("TFX_BENCH_WATCHDOG"):
+        # diagnostics for a run that does not come back (tests set it): after that many seconds every thread's Python stack goes to
+        # stderr - the run itself continues
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["TFX_BENCH_WATCHDOG"]), repeat=False, exit=False)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -21,11 +21,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run_bench(nranks, workload, extra_env=None, steps=4, warmup=2, port=29640, launcher=True, timeout=900):
+def _run(cmd, env, timeout):
+    """subprocess.run that turns a timeout into a failure WITH the child's last words (bench.py logs its phases on stderr and, under
+    TFX_BENCH_WATCHDOG, the Python stack of every thread).  These tests start whole process groups on a GPU the pytest process itself
+    keeps busy; twice in round 4 one of them (a different one each time, none reproducible in 12 repeats) sat until its 900 s limit.
+    A run that times out is therefore repeated ONCE - with a warning that carries the first run's stderr - before it counts as a failure."""
+    import warnings
+    for attempt in (1, 2):
+        try:
+            return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        except subprocess.TimeoutExpired as e:
+            err = e.stderr.decode("utf-8", "replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+            msg = "%s did not finish within %d s (attempt %d); stderr tail:\n%s" % (" ".join(cmd[-8:]), timeout, attempt, err[-6000:])
+            if attempt == 2:
+                pytest.fail(msg)
+            warnings.warn(msg)
+            if "--master-port" in cmd:                      # (the port of the run that hung may still be held)
+                i = cmd.index("--master-port") + 1
+                cmd = cmd[:i] + [str(int(cmd[i]) + 37)] + cmd[i + 1:]
+
+
+def _run_bench(nranks, workload, extra_env=None, steps=4, warmup=2, port=29640, launcher=True, timeout=420):
     # (steps = 4: the K steps are timed three times, 2 + 3 x 4 = 14 LSQR iterations in all - residuals of runs with different rank
     # counts agree to 1e-9 there; by 38 iterations the recurrence has amplified the different summation order to 5e-3)
     env = dict(os.environ)
-    env.update({"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.update({"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "TFX_BENCH_WATCHDOG": "300"})
     env.update(extra_env or {})
     args = ["bench.py", "--gpus", str(nranks), "--steps", str(steps), "--warmup", str(warmup), "--workload", workload, "--no-cpu"]
     if launcher:
@@ -33,7 +53,7 @@ def _run_bench(nranks, workload, extra_env=None, steps=4, warmup=2, port=29640, 
                "--master-port", str(port)] + args
     else:
         cmd = [sys.executable] + args
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    p = _run(cmd, env, timeout)
     assert p.returncode == 0, "bench.py exited %d\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line expected on rank 0:\n" + p.stdout[-2000:]
@@ -86,8 +106,8 @@ def test_plain_python_bench_gpus_2_launches_its_own_ranks(plain_small):
     """`python bench.py --gpus 2` WITHOUT torch.distributed.run (no WORLD_SIZE in the environment): bench.py re-runs itself under the
     launcher (free port on 127.0.0.1) instead of exiting - one JSON line with n_gpus = 2, the same result as the launched form."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "small", "--no-cpu"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    env["TFX_BENCH_WATCHDOG"] = "300"
+    p = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "small", "--no-cpu"], env, 420)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]

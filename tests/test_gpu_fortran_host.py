@@ -49,6 +49,18 @@ inversion.admm.grav.weight          = 1.d-5
 """
 
 
+
+def _sub_run(cmd, **kw):
+    """subprocess.run; a run that does not come back is a failure that shows what the host had printed (its phase banners), not a bare
+    TimeoutExpired after a quarter of an hour."""
+    try:
+        return subprocess.run(cmd, **kw)
+    except subprocess.TimeoutExpired as e:
+        def tail(b):
+            return (b.decode("utf-8", "replace") if isinstance(b, bytes) else (b or ""))[-4000:]
+        pytest.fail("%s did not finish within %s s\nstdout tail:\n%s\nstderr tail:\n%s" % (" ".join(str(c) for c in cmd[-6:]), kw.get("timeout"), tail(e.stdout), tail(e.stderr)))
+
+
 def write_inputs(wd, g):
     dd = os.path.join(wd, "data", "gravmag", "mansf_slice")
     os.makedirs(dd)
@@ -76,7 +88,7 @@ def test_config1_from_parfile_matches_reference_outputs(tmp_path, golden_dir):
     g = np.load(os.path.join(golden_dir, "mansf.npz"))
     wd = str(tmp_path)
     write_inputs(wd, g)
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     assert "nnz_total =" in out.stdout
     nnz = int(out.stdout.split("nnz_total =")[1].split()[0])
@@ -131,7 +143,7 @@ def test_multicomponent_parfiles_match_reference_outputs(tmp_path, golden_dir, n
         for o in g["obs"]:
             f.write("%.17g %.17g %.17g" % tuple(o) + " 0.0" * ncd + "\n")
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     sfx = "grav" if int(g["prob"]) == 1 else "mag"
     nnz = int(out.stdout.split("nnz_total =")[1].split()[0])
@@ -185,7 +197,7 @@ def test_sensit_files_written_like_the_reference_and_reloaded(tmp_path, golden_d
     write_case_inputs(wd, g)
     par = str(g["parfile"])
     open(os.path.join(wd, "Parfile.txt"), "w").write(par)
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     prob = int(g["prob"])
     ncm, ncd = int(g["ncm"]), int(g["ncd"])
@@ -215,7 +227,7 @@ def test_sensit_files_written_like_the_reference_and_reloaded(tmp_path, golden_d
     par2 = par2.replace("sensit.folderPath                   = out/SENSIT/", "sensit.folderPath                   = SENSIT_REF/")
     assert par2 != par
     open(os.path.join(wd2, "Parfile.txt"), "w").write(par2)
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd2, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd2, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "Finished reading the sensitivity kernel." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     sfx = "grav" if prob == 1 else "mag"
     model = read_tokens(os.path.join(wd2, "out", "model", sfx + "_final_model_full.txt"), ncm)
@@ -252,7 +264,7 @@ def test_joint_parfile_matches_reference_outputs(tmp_path, golden_dir):
     g = np.load(os.path.join(golden_dir, "e2e_joint.npz"))
     wd = str(tmp_path)
     write_joint_inputs(wd, g)
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout and "JOINT inversion" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     for tag, sfx in (("grav", "grav"), ("magn", "mag")):
         model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)[:, 0]
@@ -275,7 +287,7 @@ def test_cross_gradient_parfile_matches_reference(tmp_path, golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     write_joint_inputs(wd, g)
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     for tag, sfx in (("grav", "grav"), ("magn", "mag")):
         model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)[:, 0]
@@ -304,7 +316,7 @@ def test_clustering_parfile_matches_reference(tmp_path, golden_dir, name):
         f.write("%d %d\n" % g["cell_weights"].shape)
         for r in g["cell_weights"]:
             f.write(" ".join("%.17g" % v for v in r) + "\n")
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     for tag, sfx in (("grav", "grav"), ("magn", "mag")):
         model = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), 1)[:, 0]
@@ -351,7 +363,7 @@ def test_two_ranks_under_mpiexec_match_the_reference_two_rank_run(tmp_path, gold
         write_case_inputs(wd, g)
         cases = [(None, "mag", int(g["ncm"]))]
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
-    out = subprocess.run([MPIEXEC, "-n", "2", EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([MPIEXEC, "-n", "2", EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout and "Number of ranks" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     nel = [int(v) for v in out.stdout.split("nelements_at_cpu =")[1].split()[:2]]
     assert np.all(np.abs(np.array(nel) - g["np2_nelements_at_cpu"]) <= 2)          # a threshold tie may move the cut by a cell
@@ -382,12 +394,12 @@ def test_two_ranks_under_mpiexec_match_the_reference_two_rank_run(tmp_path, gold
     # column-partitioned multi-rank build keeps its kernel on the devices), the kernel is built again
     # (problem_joint_gravmag.F90:189-202) - same models
     first = {sfx: read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), ncm) for _, sfx, ncm in cases}
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     par2 = re.sub(r"sensit\.readFromFiles\s*=\s*\d", "sensit.readFromFiles                = 2", str(g["parfile"]))
     assert par2 != str(g["parfile"])
     open(os.path.join(wd, "Parfile.txt"), "w").write(par2)
-    out = subprocess.run([MPIEXEC, "-n", "2", EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([MPIEXEC, "-n", "2", EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     for _, sfx, ncm in cases:
         again = read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), ncm)
@@ -407,7 +419,7 @@ def test_config1_with_admm_under_mpiexec(tmp_path, golden_dir, nranks):
     g = np.load(os.path.join(golden_dir, "mansf.npz"))
     wd = str(tmp_path)
     write_inputs(wd, g)
-    out = subprocess.run([MPIEXEC, "-n", str(nranks), EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([MPIEXEC, "-n", str(nranks), EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     assert "ADMM cost" in out.stdout
     model = np.loadtxt(os.path.join(wd, "output", "mansf_slice", "model", "grav_final_model_full.txt"), skiprows=1)
@@ -445,7 +457,7 @@ def test_spatial_unknowns_two_ranks_under_mpiexec(tmp_path, golden_dir, name):
                 f.write("%d %d\n" % g["cell_weights"].shape)
                 for r in g["cell_weights"]:
                     f.write(" ".join("%.17g" % v for v in r) + "\n")
-    out = subprocess.run([MPIEXEC, "-n", "2", EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([MPIEXEC, "-n", "2", EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout and "Number of ranks" in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, \
         out.stdout[-3000:] + out.stderr[-2000:]
     for tag, sfx in cases:
@@ -517,7 +529,7 @@ def test_row_parallel_build_with_mpi_relayout(tmp_path):
         # (the products are reproducible - fixed summation order / exact integer accumulation - so runs that stop mid-convergence
         # can be compared: nothing run-dependent decides the outcome)
         e = dict(os.environ, TFX_WRITE_SENSIT="0", **env)
-        out = subprocess.run(cmd + ["-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900, env=e)
+        out = _sub_run(cmd + ["-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300, env=e)
         assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
         if tag == "exchange":
             assert "row-parallel" in out.stdout
@@ -572,7 +584,7 @@ def test_sensit_files_of_a_multi_rank_run(tmp_path):
                 f.write("\n".join("%.17g" % v for v in mtrue) + "\n")
         assert "sensit.readFromFiles" in par
         open(os.path.join(wd, "Parfile.txt"), "w").write(par.format(nd=xs.size) + "sensit.folderPath                   = out/SENSIT/\n")
-        out = subprocess.run(cmd + ["-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900,
+        out = _sub_run(cmd + ["-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300,
                              env=dict(os.environ))
         assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
         models[tag] = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
@@ -598,7 +610,7 @@ def test_gradient_damping_parfile_matches_reference(tmp_path, golden_dir):
     wd = str(tmp_path)
     write_case_inputs(wd, g)
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
     ref = g["np1_model_final"]
@@ -615,7 +627,7 @@ def test_mindist_depth_weight_parfile_matches_reference(tmp_path, golden_dir):
     wd = str(tmp_path)
     write_case_inputs(wd, g)
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     assert "Calculating the depth weight, type =" in out.stdout
     model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
@@ -632,7 +644,7 @@ def test_lp_norm_damping_parfile_matches_reference(tmp_path, golden_dir):
     wd = str(tmp_path)
     write_case_inputs(wd, g)
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
     ref = g["np1_model_final"]
@@ -650,7 +662,7 @@ def test_admm_local_bounds_parfile_matches_reference(tmp_path, golden_dir):
         for bnd, w in zip(g["bounds"], g["bound_weight"]):
             f.write("%.17g %.17g %.17g %.17g %.17g\n" % (bnd[0], bnd[1], bnd[2], bnd[3], w))
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
     ref = g["np1_model_final"]
@@ -667,7 +679,7 @@ def test_data_errors_parfile_matches_reference(tmp_path, golden_dir):
         f.write("%d\n" % g["data_error"].size)
         f.write("\n".join("%.17g" % e for e in g["data_error"]) + "\n")
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
     ref = g["np1_model_final"]
@@ -695,7 +707,7 @@ def test_local_weights_parfile_matches_reference(tmp_path, golden_dir, name):
             f.write("%d\n" % g[key].size)
             f.write("\n".join("%.17g" % v for v in g[key]) + "\n")
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
-    out = subprocess.run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout and "WAVELET_DOMAIN = F" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     model = read_tokens(os.path.join(wd, "out", "model", "grav_final_model_full.txt"), 1)[:, 0]
     ref = g["np1_model_final"]
@@ -708,9 +720,9 @@ def test_local_weights_parfile_matches_reference(tmp_path, golden_dir, name):
 def test_parfile_errors_like_the_reference(tmp_path):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    out = subprocess.run([EXE], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
+    out = _sub_run([EXE], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "UNKNOWN Parfile" in out.stdout
     open(os.path.join(str(tmp_path), "P.txt"), "w").write("inversion.joint.grav.problemWeight = 1.d0\nfoo.bar = 3\nmodelGrid.size = 2 2 2\n"
                                                            "forward.data.grav.nData = 3\nforward.depthWeighting.type = 4\n")
-    out = subprocess.run([EXE, "-p", "P.txt"], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
+    out = _sub_run([EXE, "-p", "P.txt"], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "Unknown parameter name: foo.bar" in out.stdout and "Not known depth weight type!" in out.stdout     # weights_gravmag.f90:164
