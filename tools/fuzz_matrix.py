@@ -46,6 +46,9 @@ for case in range(ncases):
     sa = orc.spmv(rowptr, cols, np.abs(vals), np.abs(x))
     sb = orc.spmtv(rowptr, cols, np.abs(vals), np.abs(y), nc)
     assert np.all(np.abs(Sx - Sx_ref) <= 1e-13 * (sa + 1e-300)), ("forward", case, nr, nc, float(np.abs(Sx - Sx_ref).max()))
-    assert np.all(np.abs(STy - STy_ref) <= 1e-13 * (sb + 1e-300)), ("adjoint", case, nr, nc, float(np.abs(STy - STy_ref).max()))
+    # without a transposed copy (TFX_ADJ_COPY=0) the adjoint rounds every product to a grid that is absolute inside a tile group (2^-60 of
+    # the group's largest column sum of |value| x max|u|, matrix.hip k_spmv_adj): per column at most (entries) * 2^-50 * max|S| * max|u|
+    slack = 0.0 if ctx.debug_set("has_adj_copy") else np.bincount(cols - 1, minlength=nc) * 2.0 ** -50 * float(np.abs(vals).max()) * float(np.abs(y).max())
+    assert np.all(np.abs(STy - STy_ref) <= 1e-13 * (sb + 1e-300) + slack), ("adjoint", case, nr, nc, float(np.abs(STy - STy_ref).max()))
     print("case %2d %5d x %6d nnz %8d %s ok" % (case, nr, nc, rp[-1], "clustered" if clustered else "uniform"))
 print("OK")
