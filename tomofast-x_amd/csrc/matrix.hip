@@ -1976,9 +1976,10 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
     m.drop_prealloc();
     if (rc) return give_up(rc);
     const double t_alloc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    // Panels.  Full height (all rows of S^T) x nt column tiles when the per-row tile index fits the budget, otherwise bands of row
-    // blocks x all column tiles; nt / the band height are cut so that a panel holds about PANEL_ENTRIES entries (estimated from the
-    // mean density; the scratch grows to what a panel really holds).
+    // Panels: bands of rows of S^T x all its column tiles when a band's per-row tile index (rows x (column tiles + 1) ints) fits the
+    // budget - the usual case -, otherwise full height x a few column tiles, otherwise bands x single column tiles.  The band height /
+    // the number of column tiles are cut so that a panel holds about PANEL_ENTRIES entries (estimated from the mean density; the scratch
+    // grows to what a panel really holds).
     const double PANEL_ENTRIES = ctx->tr_panel_entries, POS_BUDGET = ctx->tr_pos_budget;      // entries (8 B each of scratch + 2 B) ; ints of pos[] / segoff[]
     const int RBt = T->RB, TCt = T->TC;
     const int64_t nrt = m.ncols;                                          // rows of S^T
@@ -2020,8 +2021,7 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
         TFX_TRY(sc.totals.ensure(2));
         TFX_HIP(hipFuncSetAttribute((const void *)k_tr_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fill_lds));
         std::vector<int32_t> tids;
-        // Tiles must be appended row block by row block of S^T... not so: their order in the streams is free (every tile carries its
-        // offset), so the panels are walked column tile by column tile of S^T inside a band of rows.
+        // (the order of the tiles in the streams is free - every tile carries its offset -, so any panel order gives the same matrix)
         for (int64_t r0 = 0; r0 < nrt; r0 += band_rows) {
             const int64_t r1 = std::min(nrt, r0 + band_rows), npc = r1 - r0;
             const int ct_lo = (int)(r0 / m.TC), ct_hi = (int)((r1 - 1) / m.TC);              // column tiles of S the band touches
