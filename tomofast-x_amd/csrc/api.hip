@@ -27,6 +27,8 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (const char *e = getenv("TFX_ADJ_COPY")) c->adj_copy = std::max(0, std::min(2, atoi(e)));   // like tfx_debug_set "adj_copy"
     if (const char *e = getenv("TFX_COMM_INIT_TIMEOUT")) c->comm_init_timeout_s = atof(e);
+    if (const char *e = getenv("TFX_TR_PANEL_ENTRIES")) { if (atof(e) > 0) c->tr_panel_entries = atof(e); }     // like the debug keys "tr_panel_entries" /
+    if (const char *e = getenv("TFX_TR_POS_BUDGET")) { if (atof(e) > 0) c->tr_pos_budget = atof(e); }           //   "tr_pos_budget": sweeps force many small panels
     if (const char *e = getenv("TFX_FWD_RUN")) c->fwd_run = std::max(1, atoi(e));
     if (const char *e = getenv("TFX_ADJ_COPY_MIN_NNZ")) c->adj_copy_min_nnz = atoll(e);
     if (const char *e = getenv("TFX_CHAIN_UNDER_WAVELET")) c->chain_under_wavelet = atoi(e) != 0;
