@@ -3126,10 +3126,8 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     };
     auto generate = [&](int64_t g_, int nb_, int slot_) -> int {
         hipStream_t keep = ctx->stream;
-        if (overlap) {
-            ctx->stream = gs.st;
-            ctx->gen_grid_limit = ctx->gen_wgs_per_cu > 0 ? ctx->gen_wgs_per_cu * ctx->num_cu : 0;
-        }
+        if (overlap) ctx->stream = gs.st;
+        ctx->gen_grid_limit = ctx->gen_wgs_per_cu > 0 ? ctx->gen_wgs_per_cu * ctx->num_cu : 0;      // (debug key: resident generator workgroups per CU)
         const int rc = prism_rows_dev(ctx, gen, nb_, dobs.p + g_, dobs.p + ndata + g_, dobs.p + 2 * ndata + g_, dcw.p, rows_buf[slot_], derr.p,
                                       compression_type > 0 ? red_buf[slot_] : nullptr);
         ctx->stream = keep;

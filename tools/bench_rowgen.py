@@ -33,7 +33,10 @@ def main():
         ("mag_3x3", dict(mag_field=field, ndata_components=3, nmodel_components=3)),
     ]
     out = {}
+    only = os.environ.get("TFX_ROWGEN_ONLY")          # e.g. "gz": one generator only (tools/gen_occupancy_probe.sh)
     for name, kw in cases:
+        if only and name not in only.split(","):
+            continue
         t0 = time.time()
         res = ctx.calculate_sensit(xs[:nobs], ys[:nobs], zs[:nobs], cw, 2, 0.02, **kw)
         dt = time.time() - t0
