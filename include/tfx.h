@@ -202,6 +202,11 @@ int tfx_matrix_free(tfx_ctx *ctx);
  * sensitivity_gravmag.F90:834-843).  A host that keeps calculate_and_write_sensit and read_sensitivity_kernel as two steps
  * builds with problem_weight = 1, data_weight = NULL and calls this from the second.  scale: nrows doubles.                */
 int tfx_matrix_scale_rows(tfx_ctx *ctx, const double *scale);
+/* t_sparse_matrix%normalize_columns (src/inversion/sparse_matrix.f90:414-443): column_norm_out[j] = sqrt(sum of the fp32 squares of
+ * column j, added in fp64) and every entry of a column with a non-zero norm becomes (float)(value / column_norm[j]); zero columns stay.
+ * The column sums are formed exactly (integer accumulation), i.e. with the same bits on every run; they differ from the reference's
+ * sequential fp64 sums by at most nrows * 2^-53 relative.  Acts on the selected matrix (and its transposed copy).  ncols doubles.   */
+int tfx_matrix_normalize_columns(tfx_ctx *ctx, double *column_norm_out);
 
 /* General constraint rows: matrix_cons as the cross-gradient / clustering / gradient-damping / local-bound ADMM
  * builders assemble it on the host (src/inversion/joint_inverse_problem.F90:332, :466-544), uploaded as CSR with its
@@ -255,7 +260,12 @@ int tfx_partition_columns(const int32_t *nnz_hist, int64_t N, int nparts, int32_
 
 /* t_sparse_matrix%mult_vector / add_mult_vector (sparse_matrix.f90:298-329): b (+)= S x.  x: ncols, b: nrows. */
 int tfx_spmv(tfx_ctx *ctx, const double *x, double *b, int add);
-/* trans_mult_vector / add_trans_mult_vector (sparse_matrix.f90:373-405): b (+)= S^T x.  x: nrows, b: ncols.  */
+/* trans_mult_vector / add_trans_mult_vector (sparse_matrix.f90:373-405): b (+)= S^T x.  x: nrows, b: ncols.
+ * With a transposed copy (the default when it fits) the sums are fp64 like the forward product's.  Without one the products of a
+ * tile group are rounded to a fixed-point grid of 2^-60..2^-61 x (largest column sum of |value| in the group's tiles x max |x| of the
+ * group's rows) and added exactly in 64-bit integers: the error bound is NORM-WISE per tile group (a column whose sum is 2^-k of the
+ * group's largest keeps 2^-(60-k) relative accuracy), not component-wise like an fp64 sum; a non-finite x poisons every column of the
+ * tile group.  tfx_matrix_format's adjoint_copy output says which of the two a matrix uses.                                      */
 int tfx_spmtv(tfx_ctx *ctx, const double *x, double *b, int add);
 
 /* ---- LSQR ------------------------------------------------------------------------------------------------
@@ -311,7 +321,8 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * keys "band_batches" / "band_fallbacks": return how many row batches used it / fell back to the full select;
  * key "deterministic": accepted and ignored (older hosts set it) - the two matrix products are always reproducible: every fp64 sum
  * is formed in an order fixed by the matrix and its work lists (forward kernel), or exactly in integers (adjoint without a copy);
- * key "fwd_group" (0 = automatic, 1, 2, 4): row blocks that share one staged x tile in the forward product;
+ * key "fwd_group" (0 = automatic, 1, 2; larger values are clamped to 2): row blocks that share one staged x tile in the forward product;
+ * key "fwd_run" (1..16, default 2; environment TFX_FWD_RUN): consecutive chunks a wave of the forward kernel takes at a time;
  * key "adj_copy" (0 never / 1 always / 2 automatic, default 2; environment TFX_ADJ_COPY): matrices finished from now on get a
  * transposed copy of their tiles so that the adjoint product runs as the forward kernel on S^T (twice the matrix memory, a longer
  * build - DESIGN.md 3); automatic = matrices of at least "adj_copy_min_nnz" stored entries (default 0) whenever the device has

@@ -575,6 +575,25 @@ void orc_spmtv_add(int64_t nrows, const int64_t *rowptr, const int32_t *cols, co
         }
 }
 
+/* t_sparse_matrix%normalize_columns, src/inversion/sparse_matrix.f90:414-443: the square in MATRIX_PRECISION (sa is real(4)),
+ * the sum in CUSTOM_REAL in row order, the quotient rounded back to MATRIX_PRECISION; zero columns stay.  vals is modified. */
+void orc_normalize_columns(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, float *vals, double *column_norm)
+{
+    for (int64_t j = 0; j < ncols; ++j) column_norm[j] = 0.0;                    /* :420 */
+    for (int64_t i = 0; i < nrows; ++i)                                          /* :423-428 */
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            int64_t j = cols[k] - 1;
+            float sq = vals[k] * vals[k];
+            column_norm[j] = column_norm[j] + (double)sq;
+        }
+    for (int64_t j = 0; j < ncols; ++j) column_norm[j] = sqrt(column_norm[j]);   /* :430 */
+    for (int64_t i = 0; i < nrows; ++i)                                          /* :433-441 */
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            int64_t j = cols[k] - 1;
+            if (column_norm[j] != 0.0) vals[k] = (float)((double)vals[k] / column_norm[j]);
+        }
+}
+
 void orc_soft_threshold(double *x, int64_t n, double gamma)
 {
     for (int64_t i = 0; i < n; ++i) {                                            /* lsqr_solver2.F90:485-493 */

@@ -122,6 +122,7 @@ int orc_lsqr_solve_sensit_wd(int64_t nl_s, int64_t nl_c, int64_t ncols, int nite
                              double *u, double *x, double *r_out, int wavelet_type, int n1, int n2, int n3);
 
 /* src/inversion/lsqr_solver2.F90:478-494 */
+void orc_normalize_columns(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, float *vals, double *column_norm);
 void orc_soft_threshold(double *x, int64_t n, double gamma);
 
 /* src/inversion/model.F90:220-307 (model_calculate_data), single rank, one model component.

@@ -282,6 +282,16 @@ def spmtv(rowptr, cols, vals, x, ncols, b=None):
     return b
 
 
+def normalize_columns(rowptr, cols, vals, ncols):
+    """sparse_matrix.f90:414-443.  Returns (column_norm, normalised fp32 values)."""
+    rowptr, cols, vals = _csr(rowptr, cols, vals)
+    vals = vals.copy()
+    norm = np.zeros(ncols)
+    lib().orc_normalize_columns(C.c_int64(rowptr.size - 1), C.c_int64(ncols), rowptr.ctypes.data_as(c_lp), cols.ctypes.data_as(c_ip),
+                                vals.ctypes.data_as(c_fp), dp(norm))
+    return norm, vals
+
+
 def lsqr(S, Cm, ncols, b, niter, rmin=1e-13, gamma=0.0, target_misfit=0.0, spatial=None):
     """S, Cm: (rowptr, cols, vals) CSR.  Returns x, iters, r.
     spatial = (wavelet_type, n1, n2, n3): WAVELET_DOMAIN = false (unknowns spatial, S applied through the transform)."""

@@ -588,6 +588,64 @@ def test_matrix_scale_rows_is_the_reload_scaling(ctx):
     assert np.array_equal(back[0], rp) and np.array_equal(back[1], cols) and bits_equal(back[2], want.astype(np.float32))
 
 
+@pytest.mark.parametrize("adj_copy", [0, 1])
+def test_normalize_columns_vs_reference(ctx, adj_copy):
+    """tfx_matrix_normalize_columns = t_sparse_matrix%normalize_columns (sparse_matrix.f90:414-443): the reference's own unit test
+    (tests_sparse_matrix.f90:39-104) and a random kernel with empty columns and values over 12 decades; norms within n * 2^-53 of the
+    oracle's sequential sums (the sums here are exact), the fp32 quotients identical except where the norms differ in the last bit,
+    the transposed copy normalised with the same bits, two runs identical to the bit; dense storage: bit-identical to the oracle."""
+    ctx.debug_set("adj_copy", adj_copy)
+    try:
+        # the reference's unit test
+        A = np.zeros((30, 10))
+        A[:, :5] = (np.arange(300).reshape(30, 10) + 1.0)[:, :5]
+        S = kat_cases.dense_to_csr(A)
+        ctx.matrix_upload_csr(30, 10, *S)
+        norm = ctx.normalize_columns()
+        assert np.allclose(norm, np.linalg.norm(A, axis=0), rtol=1e-15, atol=0) and np.all(norm[5:] == 0.0)
+        for i in range(10):
+            col = ctx.mult_vector(np.eye(10)[i])
+            assert abs(np.linalg.norm(col) - (1.0 if i < 5 else 0.0)) <= kat_cases.TOL
+        # a random kernel
+        rng = np.random.default_rng(77)
+        nrows, ncols = 3000, 20000
+        rp, cols, vals = _random_csr(rng, nrows, ncols, 80)
+        vals = (vals * np.float32(10.0) ** rng.integers(-6, 7, vals.size).astype(np.float32)).astype(np.float32)
+        dead = rng.choice(ncols, 500, replace=False) + 1
+        vals[np.isin(cols, dead)] = 0.0
+        norm_o, vals_o = orc.normalize_columns(rp, cols, vals, ncols)
+        y = rng.standard_normal(nrows)
+        runs = []
+        for _ in range(2):
+            ctx.matrix_upload_csr(nrows, ncols, rp, cols, vals)
+            assert ctx.debug_set("has_adj_copy") == adj_copy
+            norm_g = ctx.normalize_columns()
+            runs.append((norm_g, ctx.matrix_download_csr()[2], ctx.trans_mult_vector(y)))
+        norm_g, vals_g, sty = runs[0]
+        assert bits_equal(runs[1][0], norm_g) and bits_equal(runs[1][1], vals_g) and bits_equal(runs[1][2], sty)
+        assert np.all(np.abs(norm_g - norm_o) <= nrows * 2.0 ** -53 * norm_o)
+        assert np.all(norm_g[dead - 1] == 0.0) and np.count_nonzero(norm_g) >= ncols - 500 - 50
+        same_norm = (norm_g == norm_o)[cols - 1]
+        print("normalize_columns: %d of %d norms identical to the sequential sums, worst relative distance %.2e" %
+              (np.count_nonzero(norm_g == norm_o), ncols, np.max(np.abs(norm_g - norm_o) / np.maximum(norm_o, 1e-300))))
+        assert vals_g.size == vals_o.size and bits_equal(vals_g[same_norm], vals_o[same_norm])
+        assert np.all(np.abs(vals_g.astype(np.float64) - vals_o) <= 2.0 ** -23 * np.abs(vals_o))
+        # the adjoint (on the copy when there is one) sees the normalised values
+        ref = orc.spmtv(rp, cols, vals_g, y, ncols)
+        assert np.all(np.abs(sty - ref) <= 1e-12 * orc.spmtv(rp, cols, np.abs(vals_g), np.abs(y), ncols) + 1e-300)
+        # dense storage (an uncompressed kernel): the same sequential sums as the reference -> identical bits
+        nc, nr = 600, 40
+        ctx.set_grid(nc, 1, 1, *[np.arange(nc, dtype=np.float64) + o for o in (0.0, 1.0)], *[np.full(nc, v) for v in (0.0, 1.0, 0.0, 1.0)])
+        xs_, ys_, zs_ = np.linspace(0.3, nc - 0.7, nr), np.full(nr, 0.5), np.full(nr, -1.0)
+        ctx.calculate_sensit(xs_, ys_, zs_, np.ones(nc), 0, 1.0)
+        Sd = ctx.matrix_download_csr()
+        nd_o, vd_o = orc.normalize_columns(*Sd, nc)
+        nd = ctx.normalize_columns()
+        assert bits_equal(nd, nd_o) and bits_equal(ctx.matrix_download_csr()[2], vd_o)
+    finally:
+        ctx.debug_set("adj_copy", 2)
+
+
 @pytest.mark.parametrize("shape", CSR_SHAPES + [(2049, 4097, 40, False), (1, 16385, 900, False), (9000, 70, 5, False)])
 def test_adjoint_on_the_transposed_copy(ctx, shape):
     """Debug key "adj_copy" = 1: the matrix gets a transposed copy of its tiles (built on the device from the tiles themselves) and

@@ -70,3 +70,29 @@ def test_sparse_matrix_column_extraction():
         e[j] = 1.0
         assert np.array_equal(orc.spmv(*S, e), A.astype(np.float32)[:, j].astype(np.float64))
         assert np.array_equal(orc.spmtv(*S, np.eye(7)[min(j, 6)], 9), A.astype(np.float32)[min(j, 6)].astype(np.float64))
+
+
+def test_normalize_columns_like_the_reference_unit_test():
+    """tests_sparse_matrix.f90:39-104 (test_normalize_columns): 30 x 10 matrix, entry = running counter in the first five columns,
+    zero columns after; column_norm = norm2 of the dense column, normalised non-zero columns have unit length, zero columns stay."""
+    nrows, ncols = 30, 10
+    A = np.zeros((nrows, ncols))
+    counter = 0
+    for j in range(nrows):
+        for i in range(ncols):
+            counter += 1
+            if i < ncols // 2:
+                A[j, i] = float(counter)
+    S = kat_cases.dense_to_csr(A)
+    norm, vals = orc.normalize_columns(*S, ncols)
+    tol = kat_cases.TOL
+    for i in range(ncols):
+        want = np.linalg.norm(A[:, i])
+        assert abs(norm[i] - want) <= 0.5 * tol * (abs(norm[i]) + abs(want))
+        e = np.zeros(ncols)
+        e[i] = 1.0
+        col = orc.spmv(S[0], S[1], vals, e)
+        got = np.linalg.norm(col)
+        want1 = 1.0 if want != 0.0 else 0.0
+        assert abs(got - want1) <= 0.5 * tol * (abs(got) + want1)
+

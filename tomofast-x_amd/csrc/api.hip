@@ -29,7 +29,7 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     if (const char *e = getenv("TFX_COMM_INIT_TIMEOUT")) c->comm_init_timeout_s = atof(e);
     if (const char *e = getenv("TFX_TR_PANEL_ENTRIES")) { if (atof(e) > 0) c->tr_panel_entries = atof(e); }     // like the debug keys "tr_panel_entries" /
     if (const char *e = getenv("TFX_TR_POS_BUDGET")) { if (atof(e) > 0) c->tr_pos_budget = atof(e); }           //   "tr_pos_budget": sweeps force many small panels
-    if (const char *e = getenv("TFX_FWD_RUN")) c->fwd_run = std::max(1, atoi(e));
+    if (const char *e = getenv("TFX_FWD_RUN")) c->fwd_run = std::min(16, std::max(1, atoi(e)));
     if (const char *e = getenv("TFX_ADJ_COPY_MIN_NNZ")) c->adj_copy_min_nnz = atoll(e);
     if (const char *e = getenv("TFX_CHAIN_UNDER_WAVELET")) c->chain_under_wavelet = atoi(e) != 0;
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = std::max(0, std::min(2, atoi(e)));
@@ -55,6 +55,7 @@ int tfx_device_count(void)
 // what a host-language all-reduce hook needs to stage a device buffer through MPI
 int tfx_copy(tfx_ctx *ctx, void *dst, const void *src, int64_t bytes)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !dst || !src || bytes < 0) return fail(TFX_E_ARG, "tfx_copy: bad arguments");
     TFX_HIP(hipSetDevice(ctx->device));
     TFX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, ctx->stream));
@@ -65,6 +66,7 @@ int tfx_copy(tfx_ctx *ctx, void *dst, const void *src, int64_t bytes)
 // raw device buffers for a host that moves packed matrix pieces itself (tfx_rowstore_pack -> send -> tfx_matrix_append_rows)
 int tfx_device_malloc(tfx_ctx *ctx, int64_t bytes, void **ptr_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !ptr_out || bytes < 0) return fail(TFX_E_ARG, "tfx_device_malloc: bad arguments");
     TFX_HIP(hipSetDevice(ctx->device));
     *ptr_out = nullptr;
@@ -76,6 +78,7 @@ int tfx_device_malloc(tfx_ctx *ctx, int64_t bytes, void **ptr_out)
 
 int tfx_device_free(tfx_ctx *ctx, void *ptr)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     TFX_HIP(hipSetDevice(ctx->device));
     if (ptr) {
@@ -90,7 +93,6 @@ int lsqr_free(tfx_ctx *ctx);   // lsqr.hip
 int tfx_destroy(tfx_ctx *ctx)
 {
     if (!ctx) return 0;
-    if (tfx::g_alloc_ctx == ctx) tfx::g_alloc_ctx = nullptr;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     lsqr_free(ctx);
@@ -107,6 +109,7 @@ int tfx_destroy(tfx_ctx *ctx)
 
 int tfx_device_info(tfx_ctx *ctx, char *name, int len, int64_t *hbm_bytes)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     hipDeviceProp_t prop;
     TFX_HIP(hipGetDeviceProperties(&prop, ctx->device));
@@ -119,6 +122,7 @@ int tfx_device_info(tfx_ctx *ctx, char *name, int len, int64_t *hbm_bytes)
 
 int tfx_set_allreduce(tfx_ctx *ctx, tfx_allreduce_fn fn, void *user, int rank, int nranks)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(TFX_E_ARG, "bad rank %d / %d", rank, nranks);
     if (nranks > 1 && !fn) return fail(TFX_E_ARG, "nranks > 1 needs an all-reduce hook");
@@ -132,6 +136,7 @@ int tfx_set_allreduce(tfx_ctx *ctx, tfx_allreduce_fn fn, void *user, int rank, i
 int tfx_set_grid(tfx_ctx *ctx, int nx, int ny, int nz, const double *X1, const double *X2, const double *Y1,
                  const double *Y2, const double *Z1, const double *Z2)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     if (nx <= 0 || ny <= 0 || nz <= 0) return fail(TFX_E_ARG, "bad grid size %d %d %d", nx, ny, nz);
     TFX_HIP(hipSetDevice(ctx->device));
@@ -151,6 +156,7 @@ int tfx_set_grid(tfx_ctx *ctx, int nx, int ny, int nz, const double *X1, const d
 
 int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !key) return fail(TFX_E_ARG, "null argument");
     if (!strcmp(key, "force_general_prism")) {
         ctx->force_general_prism = value != 0;
@@ -240,7 +246,7 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
         return 0;
     }
     if (!strcmp(key, "fwd_run")) {              // chunks per run of the forward kernel (>= 1); the sums stay reproducible for a fixed value
-        ctx->fwd_run = std::max(1, value);
+        ctx->fwd_run = std::min(16, std::max(1, value));
         return 0;
     }
     if (!strcmp(key, "fwd_group")) {            // row blocks per forward super block for matrices finished from now on (0 = automatic)
@@ -256,6 +262,7 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
 // free / product / calc_data entry points act on; LSQR solves with S = blockdiag(slot 0, slot 1) when slot 1 holds a matrix.
 int tfx_select_problem(tfx_ctx *ctx, int slot)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     if (slot != 0 && slot != 1) return fail(TFX_E_ARG, "tfx_select_problem: slot must be 0 or 1");
     ctx->slot = slot;
@@ -270,6 +277,7 @@ static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_
 int tfx_matrix_upload_csr(tfx_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
                           const float *vals)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !rowptr) return fail(TFX_E_ARG, "tfx_matrix_upload_csr: null argument");
     return upload_csr_into(ctx, ctx->selmat(), nrows, ncols, rowptr, cols, vals, true);
 }
@@ -278,6 +286,7 @@ int tfx_matrix_upload_csr(tfx_ctx *ctx, int64_t nrows, int64_t ncols, const int6
 int tfx_cons_upload_csr(tfx_ctx *ctx, int64_t nrows, const int64_t *rowptr, const int32_t *cols, const float *vals,
                         const double *rhs)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !rowptr || !rhs) return fail(TFX_E_ARG, "tfx_cons_upload_csr: null argument");
     if (!ctx->mat.valid) return fail(TFX_E_STATE, "tfx_cons_upload_csr: upload / build S first (it defines ncolumns)");
     TFX_TRY(upload_csr_into(ctx, ctx->cons, nrows, ctx->total_cols(), rowptr, cols, vals, true));
@@ -288,6 +297,7 @@ int tfx_cons_upload_csr(tfx_ctx *ctx, int64_t nrows, const int64_t *rowptr, cons
 
 int tfx_cons_clear(tfx_ctx *ctx)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     (void)hipStreamSynchronize(ctx->stream);
     ctx->cons.release_storage();
@@ -360,6 +370,7 @@ static int upload_csr_into(tfx_ctx *ctx, TiledMatrix &dst, int64_t nrows, int64_
 // tile's last chunk are part of `stream_bytes` only), the bytes of those streams, and whether the adjoint product runs on a transposed copy of the tiles (then it streams that copy instead).
 int tfx_matrix_format(tfx_ctx *ctx, double *bytes_per_entry, int64_t *stored_entries, int64_t *stream_bytes, int *adjoint_copy)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     const TiledMatrix &m = ctx->selmat();
     if (!m.valid) return fail(TFX_E_STATE, "no matrix");
@@ -377,6 +388,7 @@ int tfx_matrix_format(tfx_ctx *ctx, double *bytes_per_entry, int64_t *stored_ent
 
 int tfx_matrix_info(tfx_ctx *ctx, int64_t *nrows, int64_t *ncols, int64_t *nnz, int64_t *device_bytes)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     const TiledMatrix &m = ctx->selmat();
     if (!m.valid) return fail(TFX_E_STATE, "no matrix");
@@ -390,6 +402,7 @@ int tfx_matrix_info(tfx_ctx *ctx, int64_t *nrows, int64_t *ncols, int64_t *nnz, 
 // Host-side decode of the tiled layout back to CSR (tests, SENSIT-format writers; not on the hot path).
 int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float *vals)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !rowptr) return fail(TFX_E_ARG, "null argument");
     TiledMatrix &m = ctx->selmat();
     if (!m.valid) return fail(TFX_E_STATE, "no matrix");
@@ -467,6 +480,7 @@ int tfx_matrix_download_csr(tfx_ctx *ctx, int64_t *rowptr, int32_t *cols, float 
 
 int tfx_matrix_free(tfx_ctx *ctx)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     (void)hipStreamSynchronize(ctx->stream);
     ctx->selmat().release_storage();
@@ -477,6 +491,7 @@ int tfx_matrix_free(tfx_ctx *ctx)
 // read_sensitivity_kernel applies on reload (sensitivity_gravmag.F90:834-843) to a kernel stored unscaled.
 int tfx_matrix_scale_rows(tfx_ctx *ctx, const double *scale)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !scale) return fail(TFX_E_ARG, "tfx_matrix_scale_rows: null argument");
     TiledMatrix &m = ctx->selmat();
     if (!m.valid) return fail(TFX_E_STATE, "tfx_matrix_scale_rows: no matrix");
@@ -490,6 +505,21 @@ int tfx_matrix_scale_rows(tfx_ctx *ctx, const double *scale)
     TFX_TRY(copy_any(df.p, hf.data(), (size_t)m.nrows * sizeof(float), ctx->stream));
     TFX_TRY(scale_rows_dev(ctx, m, df.p));
     TFX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// t_sparse_matrix%normalize_columns, src/inversion/sparse_matrix.f90:414-443
+int tfx_matrix_normalize_columns(tfx_ctx *ctx, double *column_norm_out)
+{
+    tfx::AllocScope alloc_scope_(ctx);
+    if (!ctx || !column_norm_out) return fail(TFX_E_ARG, "tfx_matrix_normalize_columns: null argument");
+    TiledMatrix &m = ctx->selmat();
+    if (!m.valid) return fail(TFX_E_STATE, "tfx_matrix_normalize_columns: no matrix");
+    TFX_HIP(hipSetDevice(ctx->device));
+    DBuf<double> dn;
+    TFX_TRY(dn.alloc((size_t)m.ncols));
+    TFX_TRY(normalize_columns_dev(ctx, m, dn.p));
+    TFX_TRY(copy_any(column_norm_out, dn.p, (size_t)m.ncols * sizeof(double), ctx->stream));
     return 0;
 }
 
@@ -540,6 +570,7 @@ static bool is_device_ptr(const void *p)
 
 int tfx_spmv(tfx_ctx *ctx, const double *x, double *b, int add)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !x || !b) return fail(TFX_E_ARG, "tfx_spmv: null argument");
     TiledMatrix &m = ctx->selmat();
     if (!m.valid) return fail(TFX_E_STATE, "tfx_spmv: no matrix");
@@ -564,6 +595,7 @@ int tfx_spmv(tfx_ctx *ctx, const double *x, double *b, int add)
 
 int tfx_spmtv(tfx_ctx *ctx, const double *x, double *b, int add)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !x || !b) return fail(TFX_E_ARG, "tfx_spmtv: null argument");
     TiledMatrix &m = ctx->selmat();
     if (!m.valid) return fail(TFX_E_STATE, "tfx_spmtv: no matrix");
@@ -589,6 +621,7 @@ int tfx_spmtv(tfx_ctx *ctx, const double *x, double *b, int add)
 // ---- timers ------------------------------------------------------------------------------------------------
 int tfx_timer_start(tfx_ctx *ctx)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     TFX_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     return 0;
@@ -596,6 +629,7 @@ int tfx_timer_start(tfx_ctx *ctx)
 
 int tfx_timer_stop_ms(tfx_ctx *ctx, double *ms_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !ms_out) return fail(TFX_E_ARG, "null argument");
     TFX_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     TFX_HIP(hipEventSynchronize(ctx->ev1));
@@ -607,6 +641,7 @@ int tfx_timer_stop_ms(tfx_ctx *ctx, double *ms_out)
 
 int tfx_profile_enable(tfx_ctx *ctx, int on)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     tfx::prof_drain(ctx);
     ctx->profile = on != 0;
@@ -617,6 +652,7 @@ int tfx_profile_enable(tfx_ctx *ctx, int on)
 
 int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || which < 0 || which > 2) return fail(TFX_E_ARG, "bad argument");
     tfx::prof_drain(ctx);
     if (total_ms) *total_ms = ctx->prof_ms[which];

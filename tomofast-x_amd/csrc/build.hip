@@ -2657,12 +2657,14 @@ static int prism_rows_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, const 
 
 int tfx_prism_rows_gz(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double *rows_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     return prism_rows_any(ctx, RowGen{}, ndata, xd, yd, zd, rows_out);
 }
 
 int tfx_prism_rows_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double incl,
                        double decl, double azim, double intensity, double *rows_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     RowGen gen;
     gen.kind = GEN_MAG;
     gen.mf = make_mag_field(incl, decl, azim, intensity);
@@ -2672,6 +2674,7 @@ int tfx_prism_rows_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const doub
 int tfx_prism_rows(tfx_ctx *ctx, int problem_type, int data_type, int ndata_components, int nmodel_components, int64_t ndata,
                    const double *xd, const double *yd, const double *zd, const double *mag_field, double *rows_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     RowGen gen;
     TFX_TRY(make_rowgen(gen, problem_type, data_type, ndata_components, nmodel_components, mag_field));
     return prism_rows_any(ctx, gen, ndata, xd, yd, zd, rows_out);
@@ -2679,6 +2682,7 @@ int tfx_prism_rows(tfx_ctx *ctx, int problem_type, int data_type, int ndata_comp
 
 int tfx_column_weight_type1(tfx_ctx *ctx, double power, double Z0, double multiplier, double *cw_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !cw_out) return fail(TFX_E_ARG, "tfx_column_weight_type1: null argument");
     if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_column_weight_type1: set the grid first");
     TFX_HIP(hipSetDevice(ctx->device));
@@ -2709,6 +2713,7 @@ int tfx_column_weight_type1(tfx_ctx *ctx, double power, double Z0, double multip
 int tfx_column_weight_type2(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double power,
                             double beta, double multiplier, double *cw_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !cw_out || !xd || !yd || !zd) return fail(TFX_E_ARG, "tfx_column_weight_type2: null argument");
     if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_column_weight_type2: set the grid first");
     if (ndata <= 0) return fail(TFX_E_ARG, "no data");
@@ -2744,6 +2749,7 @@ int tfx_column_weight_type2(tfx_ctx *ctx, int64_t ndata, const double *xd, const
 int tfx_column_weight_type3(tfx_ctx *ctx, int64_t ndata, const double *xd, const double *yd, const double *zd, double power,
                             double multiplier, double *cw_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !cw_out || !xd || !yd || !zd) return fail(TFX_E_ARG, "tfx_column_weight_type3: null argument");
     if (ctx->N == 0) return fail(TFX_E_STATE, "tfx_column_weight_type3: set the grid first");
     if (ndata <= 0) return fail(TFX_E_ARG, "no data");
@@ -2790,6 +2796,7 @@ __global__ void k_fastmath_eval(int64_t n, const double *__restrict__ a, const d
 
 int tfx_fastmath_eval(tfx_ctx *ctx, int64_t n, const double *a, const double *b, double *out_log, double *out_atan2)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     using namespace tfx;
     if (!ctx || !a || !b || !out_log || !out_atan2 || n < 0) return fail(TFX_E_ARG, "tfx_fastmath_eval: bad argument");
     if (n == 0) return 0;
@@ -2810,6 +2817,7 @@ int tfx_fastmath_eval(tfx_ctx *ctx, int64_t n, const double *a, const double *b,
 
 int tfx_wavelet(tfx_ctx *ctx, double *sarr, int n1, int n2, int n3, int64_t nvec, int type, int direction)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !sarr) return fail(TFX_E_ARG, "tfx_wavelet: null argument");
     if (n1 <= 0 || n2 <= 0 || n3 <= 0 || nvec < 0) return fail(TFX_E_ARG, "tfx_wavelet: bad size");
     TFX_HIP(hipSetDevice(ctx->device));
@@ -2833,6 +2841,7 @@ int tfx_wavelet(tfx_ctx *ctx, double *sarr, int n1, int n2, int n3, int64_t nvec
 int tfx_compress_row(tfx_ctx *ctx, const double *row, int64_t N, int64_t K, int32_t *cols_out, float *vals_out,
                      int64_t *nel_out, double *thr_out, double *cost_discarded_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !row || !cols_out || !vals_out || !nel_out) return fail(TFX_E_ARG, "tfx_compress_row: null argument");
     if (N <= 0 || K < 0) return fail(TFX_E_ARG, "tfx_compress_row: bad size");
     TFX_HIP(hipSetDevice(ctx->device));
@@ -2888,7 +2897,6 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
                             const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
                             double *error_sum_out, int32_t *nnz_hist_out, RowStore *rs = nullptr)
 {
-    g_alloc_ctx = ctx;
     // rs != null: keep the compressed rows (all columns, global 0-based column indices) row-major on the device instead of
     // laying them out as this rank's tiled matrix - the row-parallel half of the multi-GPU build
     const bool to_rs = rs != nullptr;
@@ -3302,6 +3310,7 @@ int tfx_rowstore_build(tfx_ctx *ctx, int problem_type, int64_t ndata, const doub
                        double problem_weight, const double *data_weight, int64_t *nnz_out, double *error_sum_out,
                        int32_t *nnz_hist_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     RowGen gen;
     TFX_TRY(make_rowgen(gen, problem_type, 1, 1, 1, mag_field));
@@ -3315,6 +3324,7 @@ int tfx_rowstore_build_ex(tfx_ctx *ctx, int problem_type, int data_type, int nda
                           int compression_type, double rate, double problem_weight, const double *data_weight, int64_t *nnz_out,
                           double *error_sum_out, int32_t *nnz_hist_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     RowGen gen;
     TFX_TRY(make_rowgen(gen, problem_type, data_type, ndata_components, 1, mag_field));
@@ -3327,6 +3337,7 @@ int tfx_rowstore_build_comp(tfx_ctx *ctx, int problem_type, int data_type, int n
                             int compression_type, double rate, double problem_weight, const double *data_weight, int64_t *nnz_out,
                             double *error_sum_out, int32_t *nnz_hist_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     RowGen gen;
     TFX_TRY(make_rowgen(gen, problem_type, data_type, ndata_components, nmodel_components, mag_field));
@@ -3359,6 +3370,7 @@ __global__ void k_rs_bounds(const int32_t *__restrict__ cols, const int32_t *__r
 
 int tfx_rowstore_counts(tfx_ctx *ctx, int nparts, const int64_t *bounds, int32_t *counts_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !bounds || !counts_out) return fail(TFX_E_ARG, "tfx_rowstore_counts: null argument");
     RowStore &rs = ctx->rowstore();
     if (rs.nrows == 0) return fail(TFX_E_STATE, "no row store");
@@ -3418,6 +3430,7 @@ __global__ void k_rs_copy(const int32_t *__restrict__ cols, const float *__restr
 int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t col_begin, int64_t col_end, int32_t *cols_dev_out,
                       float *vals_dev_out, int64_t capacity, int64_t *n_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !n_out) return fail(TFX_E_ARG, "tfx_rowstore_pack: null argument");
     RowStore &rs = ctx->rowstore();
     if (rs.nrows == 0) return fail(TFX_E_STATE, "no row store");
@@ -3450,6 +3463,7 @@ int tfx_rowstore_pack(tfx_ctx *ctx, int64_t row_begin, int64_t nrows, int64_t co
 
 int tfx_rowstore_free(tfx_ctx *ctx)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     (void)hipStreamSynchronize(ctx->stream);
     ctx->rowstore().cols.release();
@@ -3462,6 +3476,7 @@ int tfx_rowstore_free(tfx_ctx *ctx)
 // ---- assembling this rank's matrix from row pieces that arrive from other ranks ------------------------------------
 int tfx_matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     TFX_HIP(hipSetDevice(ctx->device));
     ctx->target = &ctx->selmat();
@@ -3473,6 +3488,7 @@ int tfx_matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upp
 int tfx_matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const int32_t *cols_dev, const float *vals_dev,
                            const int32_t *nel_host)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !nel_host) return fail(TFX_E_ARG, "tfx_matrix_append_rows: null argument");
     TFX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -3500,6 +3516,7 @@ int tfx_matrix_append_rows(tfx_ctx *ctx, int64_t row_begin, int64_t nr, const in
 
 int tfx_matrix_finish(tfx_ctx *ctx)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     ctx->target = &ctx->selmat();
     const int64_t nnz = ctx->selmat().nnz;
@@ -3513,6 +3530,7 @@ int tfx_build_kernel_grav(tfx_ctx *ctx, int64_t ndata, const double *xd, const d
                           const double *data_weight, int64_t col_begin, int64_t col_end, int64_t *nnz_out,
                           double *error_sum_out, int32_t *nnz_hist_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     return build_kernel_any(ctx, RowGen{}, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight,
                             col_begin, col_end, nnz_out, error_sum_out, nnz_hist_out);
 }
@@ -3522,6 +3540,7 @@ int tfx_build_kernel_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const do
                          int compression_type, double rate, double problem_weight, const double *data_weight,
                          int64_t col_begin, int64_t col_end, int64_t *nnz_out, double *error_sum_out, int32_t *nnz_hist_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     RowGen gen;
     gen.kind = GEN_MAG;
     gen.mf = make_mag_field(incl, decl, azim, intensity);
@@ -3534,6 +3553,7 @@ int tfx_build_kernel(tfx_ctx *ctx, int problem_type, int data_type, int ndata_co
                      int compression_type, double rate, double problem_weight, const double *data_weight, int64_t col_begin,
                      int64_t col_end, int64_t *nnz_out, double *error_sum_out, int32_t *nnz_hist_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     RowGen gen;
     TFX_TRY(make_rowgen(gen, problem_type, data_type, ndata_components, nmodel_components, mag_field));
     return build_kernel_any(ctx, gen, ndata, xd, yd, zd, column_weight, compression_type, rate, problem_weight, data_weight,

@@ -108,6 +108,7 @@ struct InitAttempt {
 
 int tfx_comm_init_rccl(tfx_ctx *ctx, const char *unique_id, int rank, int nranks)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !unique_id) return fail(TFX_E_ARG, "tfx_comm_init_rccl: null argument");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(TFX_E_ARG, "bad rank %d / %d", rank, nranks);
     auto at = std::make_shared<InitAttempt>();
@@ -170,6 +171,7 @@ int tfx_comm_init_rccl(tfx_ctx *ctx, const char *unique_id, int rank, int nranks
 
 int tfx_comm_destroy(tfx_ctx *ctx)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     std::lock_guard<std::mutex> g(ctx->comm_mu);
     if (ctx->comm) {
@@ -188,6 +190,7 @@ int tfx_comm_destroy(tfx_ctx *ctx)
 // the ranks whose own call succeeded drop their half-open communicator with this).
 int tfx_comm_abort(tfx_ctx *ctx)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     std::lock_guard<std::mutex> g(ctx->comm_mu);
     if (ctx->comm) {
@@ -214,6 +217,7 @@ int tfx_comm_abort(tfx_ctx *ctx)
 // communicator the counts are 0 and only version / path are filled.
 int tfx_comm_info(tfx_ctx *ctx, int *nranks_seen, int *rank_seen, int *device_seen, int *version, char *path, int path_len)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     int n = 0, r = -1, d = -1, v = 0;
     if (ctx->comm) {
@@ -244,6 +248,7 @@ static int need_comm(tfx_ctx *ctx, const char *who)
 
 int tfx_comm_allreduce(tfx_ctx *ctx, void *dev_buf, int64_t n, int dtype)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     TFX_TRY(need_comm(ctx, "tfx_comm_allreduce"));
     if (n < 0 || (n > 0 && !dev_buf)) return fail(TFX_E_ARG, "tfx_comm_allreduce: bad buffer");
     ncclDataType_t t;
@@ -261,6 +266,7 @@ int tfx_comm_allreduce(tfx_ctx *ctx, void *dev_buf, int64_t n, int dtype)
 
 int tfx_comm_group_begin(tfx_ctx *ctx)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     TFX_TRY(need_comm(ctx, "tfx_comm_group_begin"));
     TFX_HIP(hipSetDevice(ctx->device));
     TFX_NCCL(ncclGroupStart());
@@ -269,6 +275,7 @@ int tfx_comm_group_begin(tfx_ctx *ctx)
 
 int tfx_comm_group_end(tfx_ctx *ctx)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     TFX_TRY(need_comm(ctx, "tfx_comm_group_end"));
     TFX_NCCL(ncclGroupEnd());
     return 0;
@@ -276,6 +283,7 @@ int tfx_comm_group_end(tfx_ctx *ctx)
 
 int tfx_comm_send(tfx_ctx *ctx, const void *dev_buf, int64_t bytes, int peer)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     TFX_TRY(need_comm(ctx, "tfx_comm_send"));
     if (bytes < 0 || peer < 0 || peer >= ctx->nranks || peer == ctx->rank) return fail(TFX_E_ARG, "tfx_comm_send: bad arguments");
     if (bytes == 0) return 0;
@@ -285,6 +293,7 @@ int tfx_comm_send(tfx_ctx *ctx, const void *dev_buf, int64_t bytes, int peer)
 
 int tfx_comm_recv(tfx_ctx *ctx, void *dev_buf, int64_t bytes, int peer)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     TFX_TRY(need_comm(ctx, "tfx_comm_recv"));
     if (bytes < 0 || peer < 0 || peer >= ctx->nranks || peer == ctx->rank) return fail(TFX_E_ARG, "tfx_comm_recv: bad arguments");
     if (bytes == 0) return 0;
@@ -294,6 +303,7 @@ int tfx_comm_recv(tfx_ctx *ctx, void *dev_buf, int64_t bytes, int peer)
 
 int tfx_comm_barrier(tfx_ctx *ctx)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     TFX_TRY(need_comm(ctx, "tfx_comm_barrier"));
     TFX_HIP(hipSetDevice(ctx->device));
     TFX_TRY(ctx->vb.ensure(1));
@@ -305,6 +315,7 @@ int tfx_comm_barrier(tfx_ctx *ctx)
 
 int tfx_set_allgatherv(tfx_ctx *ctx, tfx_allgatherv_fn fn)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     ctx->allgatherv = fn;
     return 0;

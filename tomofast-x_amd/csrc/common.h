@@ -42,9 +42,26 @@ inline int fail(int code, const char *fmt, ...)
 
 // An allocation that fails for lack of memory first gives up the transposed copies the matrices of the calling thread's context got
 // in automatic mode (TiledMatrix::T: an optimisation, the adjoint then runs on the tiles of S) and tries once more - e.g. the second
-// kernel of a joint inversion that does not fit beside the first one's copy.  g_alloc_ctx is set by the entry points that allocate.
+// kernel of a joint inversion that does not fit beside the first one's copy.  g_alloc_ctx is the context of the extern "C" entry point
+// the thread is inside (AllocScope, first statement of every entry point that takes a context; null outside), so an eviction can only
+// touch the caller's own context and never a destroyed one.  NoEvict switches the retry off for allocations that are themselves
+// optional and owned by an object an eviction would free (the storage matrix_begin sets aside for a copy).
 extern thread_local tfx_ctx *g_alloc_ctx;
+extern thread_local int g_no_evict;
 bool evict_adjoint_copies(tfx_ctx *ctx);      // matrix.hip; true when something was freed
+struct AllocScope {
+    tfx_ctx *prev;
+    explicit AllocScope(tfx_ctx *c) : prev(g_alloc_ctx) { g_alloc_ctx = c; }
+    ~AllocScope() { g_alloc_ctx = prev; }
+    AllocScope(const AllocScope &) = delete;
+    AllocScope &operator=(const AllocScope &) = delete;
+};
+struct NoEvict {
+    NoEvict() { ++g_no_evict; }
+    ~NoEvict() { --g_no_evict; }
+    NoEvict(const NoEvict &) = delete;
+    NoEvict &operator=(const NoEvict &) = delete;
+};
 
 // Owning device allocation.
 template <typename T>
@@ -66,7 +83,7 @@ struct DBuf {
         release();
         if (count == 0) return 0;
         hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-        if (e == hipErrorOutOfMemory && g_alloc_ctx && evict_adjoint_copies(g_alloc_ctx)) {
+        if (e == hipErrorOutOfMemory && g_alloc_ctx && g_no_evict == 0 && evict_adjoint_copies(g_alloc_ctx)) {
             (void)hipGetLastError();
             e = hipMalloc((void **)&p, count * sizeof(T));
         }
@@ -300,6 +317,7 @@ int spmv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int a
 int spmtv_dev(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, double *d_b, int add);
 int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols);
 int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale);
+int normalize_columns_dev(tfx_ctx *ctx, TiledMatrix &m, double *d_norm);      // matrix.hip; synchronises the ctx stream
 int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m);    // (no-op unless ctx->adj_copy asks for it and the copy fits)
 int chunk_exponent_stats(tfx_ctx *ctx, TiledMatrix &m, int span, int64_t *fit, int64_t *total, unsigned int *hist34);
 int copy_any(void *dst, const void *src, size_t bytes, hipStream_t s);

@@ -496,7 +496,7 @@ extern "C" {
 int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit, const double *b_data, int nblocks,
                    const float *const *diag, const double *const *rhs_blocks)
 {
-    if (ctx) tfx::g_alloc_ctx = ctx;
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !b_data) return fail(TFX_E_ARG, "tfx_lsqr_begin: null argument");
     TiledMatrix &m = ctx->mat;
     if (!m.valid) return fail(TFX_E_STATE, "tfx_lsqr_begin: no matrix");
@@ -631,6 +631,7 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
 // 0 = spatial unknowns: every product with S goes through the 3-D wavelet transform (lsqr_solver2.F90:200-206, :228-234)
 int tfx_lsqr_set_wavelet_domain(tfx_ctx *ctx, int wavelet_domain, int n1, int n2, int n3, int wavelet_type)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     if (wavelet_domain || wavelet_type == 0) {
         ctx->spatial_unknowns = false;
@@ -647,6 +648,7 @@ int tfx_lsqr_set_wavelet_domain(tfx_ctx *ctx, int wavelet_domain, int n1, int n2
 // the ncomponents model components, all problems counted)
 int tfx_lsqr_set_partition(tfx_ctx *ctx, int64_t col_begin, int ncomponents)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx) return fail(TFX_E_ARG, "null ctx");
     if (col_begin < 0 || ncomponents < 1) return fail(TFX_E_ARG, "tfx_lsqr_set_partition: bad arguments");
     ctx->wd_col_begin = col_begin;
@@ -656,6 +658,7 @@ int tfx_lsqr_set_partition(tfx_ctx *ctx, int64_t col_begin, int ncomponents)
 
 int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !ctx->lsqr || !ctx->lsqr->active) return fail(TFX_E_STATE, "tfx_lsqr_iterate: call tfx_lsqr_begin first");
     LsqrState *L = ctx->lsqr;
     hipStream_t s = ctx->stream;
@@ -733,6 +736,7 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
 
 int tfx_lsqr_end(tfx_ctx *ctx, double *x_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !ctx->lsqr || !ctx->lsqr->active) return fail(TFX_E_STATE, "tfx_lsqr_end: no solve in progress");
     LsqrState *L = ctx->lsqr;
     if (x_out) TFX_TRY(copy_any(x_out, L->x.p, (size_t)L->ncols * sizeof(double), ctx->stream));
@@ -744,6 +748,7 @@ int tfx_lsqr_solve(tfx_ctx *ctx, int niter, double rmin, double gamma, double ta
                    int nblocks, const float *const *diag, const double *const *rhs_blocks, double *x_out, int *iters_out,
                    double *r_out)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     TFX_TRY(tfx_lsqr_begin(ctx, rmin, gamma, target_misfit, b_data, nblocks, diag, rhs_blocks));
     int done = 0;
     double r = 1.0;
@@ -766,6 +771,7 @@ __global__ void k_calc_data_finish(double *__restrict__ d, int64_t n, double pro
 int tfx_calc_data(tfx_ctx *ctx, const double *xw_local, double problem_weight, const double *data_weight,
                   double *data_calc)
 {
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
     if (!ctx || !xw_local || !data_calc) return fail(TFX_E_ARG, "tfx_calc_data: null argument");
     TiledMatrix &m = ctx->selmat();        // the selected problem: part_mult_vector with its line_start / param_shift
     if (!m.valid) return fail(TFX_E_STATE, "tfx_calc_data: no matrix");

@@ -33,16 +33,19 @@ namespace tfx {
 
 thread_local std::string g_last_error;
 thread_local tfx_ctx *g_alloc_ctx = nullptr;
+thread_local int g_no_evict = 0;
 
 bool evict_adjoint_copies(tfx_ctx *ctx)
 {
     bool freed = false;
+    (void)hipSetDevice(ctx->device);
     for (TiledMatrix *m : {&ctx->mat, &ctx->mat2, &ctx->cons}) {
         if (m->pre && ctx->adj_copy != 1 && ctx->pre_take != m->pre.get()) {      // storage set aside for a copy that does not exist yet
             m->drop_prealloc();
             freed = true;
         }
-        if (m->T && m->T->evictable) {
+        // (never the object an allocation is being made FOR: a copy whose work lists matrix_finish is rebuilding is ctx->target)
+        if (m->T && m->T->evictable && m->T != ctx->target) {
             if (!freed) (void)hipDeviceSynchronize();      // (nothing may still be reading a copy)
             const size_t bytes = m->T->device_bytes();
             delete m->T;
@@ -269,7 +272,6 @@ constexpr int DN_THREADS = 1024;
 
 int matrix_begin_dense(tfx_ctx *ctx, int64_t nrows, int64_t ncols)
 {
-    g_alloc_ctx = ctx;
     TiledMatrix &m = *ctx->target;
     m.release_storage();            // (whatever the slot held before: tiles, work lists, a transposed copy)
     if (nrows <= 0 || ncols <= 0) return fail(TFX_E_ARG, "matrix_begin_dense: empty matrix");
@@ -396,7 +398,6 @@ static void tile_shape(const tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t
 
 int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
 {
-    g_alloc_ctx = ctx;
     TiledMatrix &m = *ctx->target;
     m.release_storage();
     m.nrows = nrows;
@@ -435,6 +436,7 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
         const size_t need = (size_t)(capT / CHUNK) * (REC_BYTES + sizeof(int32_t));
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > (double)need + 40e9) {      // (40 GB: the build's own buffers and the copy's panel scratch)
+            NoEvict optional;       // (an eviction would free the very Prealloc whose buffer is being allocated)
             m.pre.reset(new TiledMatrix::Prealloc());
             if (m.pre->rec.alloc((size_t)(capT / CHUNK) * REC_BYTES) != 0 || m.pre->row0.alloc((size_t)(capT / CHUNK)) != 0) m.pre.reset();
         }
@@ -963,7 +965,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 16 ? 8 : 1) void k_spmv_fwd(MA
         }
         __syncthreads();
         // (a short group - small matrices have tiles of a few dozen chunks - is dealt chunk by chunk: runs of RUN would leave waves idle)
-        const int run_len = g.total < 4 * WAVES * RUN ? 1 : max(RUN, (g.total + FWD_MAX_RUNS - 1) / FWD_MAX_RUNS);
+        const int run_len = max(g.total < 4 * WAVES * RUN ? 1 : RUN, (g.total + FWD_MAX_RUNS - 1) / FWD_MAX_RUNS);      // (never more than FWD_MAX_RUNS head slots, whatever RUN is)
         const int nruns = (g.total + run_len - 1) / run_len;
         nruns_prev = nruns;
         for (int run = wave; run < nruns; run += WAVES) {
@@ -2122,5 +2124,167 @@ int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale)
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// t_sparse_matrix%normalize_columns (src/inversion/sparse_matrix.f90:414-443): column_norm(j) = sqrt(sum_k sa(k)**2) with the square
+// formed in fp32 and added in fp64, then sa(k) = real(sa(k) / column_norm(j), 4) for the columns whose norm is not zero.
+// The sum is formed EXACTLY here (so it has the same bits on every run whatever order the entries arrive in): pass 1 finds the largest
+// square of a column, pass 2 adds every square as two 64-bit integers on a grid fixed by that maximum (units of 2^-40 and 2^-85 of the
+// maximum's binade: 2^17 rows can not overflow either word, bits below 2^-85 of the largest square are dropped), pass 3 rounds once.
+// The reference's sequential fp64 sum differs from the exact one by at most nrows * 2^-53 relative.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colsq_max(const TileMeta *__restrict__ tiles, int ntiles, const char *__restrict__ rec, int TC, int64_t ncols,
+                                                    uint32_t *__restrict__ qmax)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int ti = blockIdx.y; ti < ntiles; ti += gridDim.y) {
+        const TileMeta tm = tiles[ti];
+        const int64_t cbase = tm.off / CHUNK, col0 = (int64_t)tm.t * TC;
+        for (int c = blockIdx.x * 4 + wave; c < tm.nchunks; c += gridDim.x * 4) {
+            ChunkRegs cr;
+            load_chunk(rec, cbase + c, lane, cr);
+            const uint32_t sl[8] = {slot_of<0>(cr), slot_of<1>(cr), slot_of<2>(cr), slot_of<3>(cr), slot_of<4>(cr), slot_of<5>(cr), slot_of<6>(cr), slot_of<7>(cr)};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t col = col0 + col_slot((int)sl[k]);
+                const float q = cr.v[k] * cr.v[k];                       // sa(k)**2 in MATRIX_PRECISION (:427)
+                if (q > 0.0f && col < ncols) atomicMax(qmax + col, __float_as_uint(q));      // (non-negative floats order like their bit patterns)
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void colsq_split(float q, uint32_t qmax_bits, unsigned long long &hi, unsigned long long &lo)
+{
+    const int e = (int)((qmax_bits >> 23) & 0xffu) - 127;            // binade of the column's largest square (denormal: -127, still a valid grid)
+    const double t = ldexp((double)q, 40 - e);                       // exact; < 2^41
+    const double th = floor(t);
+    hi = (unsigned long long)th;
+    lo = (unsigned long long)floor(ldexp(t - th, 45));               // (t - th is exact, < 1)
+}
+
+__global__ __launch_bounds__(256) void k_colsq_sum(const TileMeta *__restrict__ tiles, int ntiles, const char *__restrict__ rec, int TC, int64_t ncols,
+                                                    const uint32_t *__restrict__ qmax, unsigned long long *__restrict__ acc)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int ti = blockIdx.y; ti < ntiles; ti += gridDim.y) {
+        const TileMeta tm = tiles[ti];
+        const int64_t cbase = tm.off / CHUNK, col0 = (int64_t)tm.t * TC;
+        for (int c = blockIdx.x * 4 + wave; c < tm.nchunks; c += gridDim.x * 4) {
+            ChunkRegs cr;
+            load_chunk(rec, cbase + c, lane, cr);
+            const uint32_t sl[8] = {slot_of<0>(cr), slot_of<1>(cr), slot_of<2>(cr), slot_of<3>(cr), slot_of<4>(cr), slot_of<5>(cr), slot_of<6>(cr), slot_of<7>(cr)};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t col = col0 + col_slot((int)sl[k]);
+                const float q = cr.v[k] * cr.v[k];
+                if (q > 0.0f && col < ncols) {
+                    unsigned long long hi, lo;
+                    colsq_split(q, qmax[col], hi, lo);
+                    if (hi) atomicAdd(acc + 2 * col, hi);
+                    if (lo) atomicAdd(acc + 2 * col + 1, lo);
+                }
+            }
+        }
+    }
+}
+
+__global__ void k_colsq_finish(const uint32_t *__restrict__ qmax, const unsigned long long *__restrict__ acc, int64_t ncols, double *__restrict__ norm)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    const uint32_t qb = qmax[j];
+    if (qb == 0u) { norm[j] = 0.0; return; }
+    const int e = (int)((qb >> 23) & 0xffu) - 127;
+    // hi < 2^58, lo < 2^62 in units 2^-45 of hi's: one fp64 sum of the two words, one rounding each for the conversions
+    const double sum = ldexp((double)acc[2 * j] + ldexp((double)acc[2 * j + 1], -45), e - 40);
+    norm[j] = sqrt(sum);                                                                    // :432
+}
+
+// sa(k) = real(sa(k) / column_norm(j), MATRIX_PRECISION) (:439); BY_ROW: the transposed copy, whose rows are the columns of S
+template <bool BY_ROW>
+__global__ __launch_bounds__(256) void k_div_by_norm(const TileMeta *__restrict__ tiles, int ntiles, char *__restrict__ rec,
+                                                      const int32_t *__restrict__ chunk_row0, int TC, int RB, int64_t nlimit,
+                                                      const double *__restrict__ norm)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int ti = blockIdx.y; ti < ntiles; ti += gridDim.y) {
+        const TileMeta tm = tiles[ti];
+        const int64_t cbase = tm.off / CHUNK, col0 = (int64_t)tm.t * TC, row0 = (int64_t)tm.rb * RB;
+        for (int c = blockIdx.x * 4 + wave; c < tm.nchunks; c += gridDim.x * 4) {
+            ChunkRegs cr;
+            ChunkMasks mk;
+            load_chunk(rec, cbase + c, lane, cr);
+            int cur = chunk_row0[cbase + c] + load_masks(rec, cbase + c, mk);
+            float *vp = chunk_vals(rec, cbase + c) + lane * 4;
+            const uint32_t sl[8] = {slot_of<0>(cr), slot_of<1>(cr), slot_of<2>(cr), slot_of<3>(cr), slot_of<4>(cr), slot_of<5>(cr), slot_of<6>(cr), slot_of<7>(cr)};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if ((mk.m[k] >> lane) & 1ull) cur += 1;
+                const int64_t j = BY_ROW ? row0 + max(cur, 0) : col0 + col_slot((int)sl[k]);
+                if (cr.v[k] != 0.0f && j < nlimit) {
+                    const double nj = norm[j];
+                    if (nj != 0.0) vp[(k >> 2) * (CHUNK / 2) + (k & 3)] = (float)((double)cr.v[k] / nj);
+                }
+            }
+        }
+    }
+}
+
+// dense storage: one thread per column, rows in the reference's order (the same sequential fp64 sum)
+__global__ void k_dense_normalize_columns(float *__restrict__ A, int64_t ld, int64_t nrows, int64_t ncols, double *__restrict__ norm)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    double sum = 0.0;
+    for (int64_t r = 0; r < nrows; ++r) {
+        const float v = A[r * ld + j];
+        sum += (double)(v * v);
+    }
+    const double nj = sqrt(sum);
+    norm[j] = nj;
+    if (nj != 0.0)
+        for (int64_t r = 0; r < nrows; ++r) A[r * ld + j] = (float)((double)A[r * ld + j] / nj);
+}
+
+int normalize_columns_dev(tfx_ctx *ctx, TiledMatrix &m, double *d_norm)
+{
+    if (!m.valid) return fail(TFX_E_STATE, "normalize_columns: no matrix");
+    hipStream_t s = ctx->stream;
+    if (m.is_dense) {
+        hipLaunchKernelGGL(k_dense_normalize_columns, dim3((unsigned)((m.ncols + 255) / 256)), dim3(256), 0, s, m.dense.p, m.ld, m.nrows, m.ncols, d_norm);
+        TFX_HIP(hipGetLastError());
+        return 0;
+    }
+    if (m.nrows > ((int64_t)1 << 17)) return fail(TFX_E_ARG, "normalize_columns: more than 2^17 rows (the exact column sums are sized for that)");
+    const int nt = (int)m.h_tiles.size();
+    DBuf<uint32_t> qmax;
+    DBuf<unsigned long long> acc;
+    TFX_TRY(qmax.alloc((size_t)m.ncols));
+    TFX_TRY(acc.alloc((size_t)m.ncols * 2));
+    TFX_HIP(hipMemsetAsync(qmax.p, 0, qmax.bytes(), s));
+    TFX_HIP(hipMemsetAsync(acc.p, 0, acc.bytes(), s));
+    const dim3 grid(8, (unsigned)std::max(1, std::min(nt, 32768)));
+    if (nt > 0) {
+        hipLaunchKernelGGL(k_colsq_max, grid, dim3(256), 0, s, m.tiles.p, nt, m.rec.p, m.TC, m.ncols, qmax.p);
+        hipLaunchKernelGGL(k_colsq_sum, grid, dim3(256), 0, s, m.tiles.p, nt, m.rec.p, m.TC, m.ncols, qmax.p, acc.p);
+    }
+    hipLaunchKernelGGL(k_colsq_finish, dim3((unsigned)((m.ncols + 255) / 256)), dim3(256), 0, s, qmax.p, acc.p, m.ncols, d_norm);
+    if (nt > 0)
+        hipLaunchKernelGGL(k_div_by_norm<false>, grid, dim3(256), 0, s, m.tiles.p, nt, m.rec.p, m.chunk_row0.p, m.TC, m.RB, m.ncols, d_norm);
+    TFX_HIP(hipGetLastError());
+    m.vmax_stale = true;
+    if (m.T && m.T->valid && !m.T->h_tiles.empty()) {        // the same quotients on the transposed copy: its rows are the columns of S
+        TiledMatrix &t = *m.T;
+        const int ntt = (int)t.h_tiles.size();
+        hipLaunchKernelGGL(k_div_by_norm<true>, dim3(8, (unsigned)std::min(ntt, 32768)), dim3(256), 0, s, t.tiles.p, ntt, t.rec.p, t.chunk_row0.p, t.TC,
+                           t.RB, t.nrows, d_norm);
+        TFX_HIP(hipGetLastError());
+        t.vmax_stale = true;
+    }
+    TFX_HIP(hipStreamSynchronize(s));        // (qmax / acc are freed on return)
+    return 0;
+}
+
 
 }  // namespace tfx

@@ -379,6 +379,13 @@ module tfx_binding
       real(c_double), intent(in) :: scale(*)
     end function
 
+    ! t_sparse_matrix%normalize_columns (sparse_matrix.f90:414-443)
+    integer(c_int) function tfx_matrix_normalize_columns(ctx, column_norm) bind(C, name="tfx_matrix_normalize_columns")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(out) :: column_norm(*)
+    end function
+
     integer(c_int) function tfx_matrix_free(ctx) bind(C, name="tfx_matrix_free")
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx

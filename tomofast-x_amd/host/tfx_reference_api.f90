@@ -131,6 +131,7 @@ module tfx_reference_api
     procedure, public, pass :: get_number_elements => sparse_matrix_get_number_elements
     procedure, public, pass :: mult_vector => sparse_matrix_mult_vector
     procedure, public, pass :: trans_mult_vector => sparse_matrix_trans_mult_vector
+    procedure, public, pass :: normalize_columns => sparse_matrix_normalize_columns
   end type t_sparse_matrix
 
   ! ---- src/inversion/model.F90:33-110 (the fields model_calculate_data reads)
@@ -446,6 +447,15 @@ contains
     call api_check(tfx_select_problem(api_ctx, 0_c_int), 'tfx_select_problem', myrank)
     call api_check(tfx_spmtv(api_ctx, x, b, 0_c_int), 'trans_mult_vector', myrank)
   end subroutine sparse_matrix_trans_mult_vector
+
+  ! sparse_matrix.f90:414-443: unit-length columns, returns the original norms (device-resident kernel only)
+  subroutine sparse_matrix_normalize_columns(this, column_norm)
+    class(t_sparse_matrix), intent(inout) :: this
+    real(dp), intent(out) :: column_norm(:)
+    if (.not. this%on_device) call exit_MPI('normalize_columns: only the device-resident sensitivity kernel is normalised.', 0, 0)
+    call api_check(tfx_select_problem(api_ctx, 0_c_int), 'tfx_select_problem', 0)
+    call api_check(tfx_matrix_normalize_columns(api_ctx, column_norm), 'normalize_columns', 0)
+  end subroutine sparse_matrix_normalize_columns
 
   !-------------------------------------------------------------------------------------------------------
   ! forward_wavelet / inverse_wavelet, src/utils/wavelet_transform.F90:37-70: in place on s(n1*n2*n3)

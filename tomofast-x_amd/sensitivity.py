@@ -397,6 +397,13 @@ class Context:
             raise ValueError("scale size != number of matrix rows")
         check(self._lib.tfx_matrix_scale_rows(self._h, ptr(sc)))
 
+    def normalize_columns(self):
+        """t_sparse_matrix%normalize_columns (sparse_matrix.f90:414-443): scales the columns of the selected matrix to unit length
+        (zero columns stay) and returns their original norms."""
+        norm = np.empty(self.matrix_info()["ncols"], np.float64)
+        check(self._lib.tfx_matrix_normalize_columns(self._h, ptr(norm)))
+        return norm
+
     def mult_vector(self, x, b=None):
         """b = S x (mult_vector) or b += S x when b is given (add_mult_vector)."""
         info = self.matrix_info()
