@@ -307,13 +307,16 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "ms_per_step_runs": [round(1e3 * t / args.steps, 4) for t in runs], "timed_repeats": REPEATS,
             "ms_per_step_spread": round(1e3 * (max(runs) - min(runs)) / args.steps, 4),
-            "dtype": "f64 (fp32-stored matrix values, fp64 vectors and accumulation)", "data": "synthetic",
+            "dtype": dtype_line(w, fmt), "data": "synthetic",
             "config": {"workload": args.workload + ": " + w["desc"], "cells": N, "obs": D, "nnz": int(nnz_total),
                        "compression": {0: "none", 1: "haar", 2: "d4"}[w["ctype"]], "rate": w["rate"],
                        "parallelism": "column-partitioned x%d" % world, "damping_alpha": alpha},
             "cell_obs_per_s_solve": round(N * D * value, 1),
-            "cell_obs_per_s_build": round(N * D / t_build, 1), "build_s": round(t_build, 2), "build_mode": build_mode,
-            "adjoint_copy_build_s": round(t_copy, 2), "build_with_adjoint_copy_s": round(t_build_total, 2),
+            # the build as a default run pays it: wall clock from the first row to a matrix ready for both products, INCLUDING the transposed
+            # copy the default adjoint runs on; the copy's share (timed by the library) and the remainder are secondary fields
+            "cell_obs_per_s_build": round(N * D / t_build_total, 1), "build_s": round(t_build_total, 2), "build_mode": build_mode,
+            "adjoint_copy_build_s": round(t_copy, 2), "build_without_adjoint_copy_s": round(t_build, 2),
+            "cell_obs_per_s_build_without_adjoint_copy": round(N * D / t_build, 1),
             "build_threshold_batches": {"band_select": ctx.debug_set("band_batches"), "fell_back_to_full_select": ctx.debug_set("band_fallbacks")},
             "gpu_ms_per_step_hip_events": round(ms_gpu / args.steps, 4),
             # SURVEY 8d's formula on the REFERENCE's CSR (8 B per non-zero and pass): a CSR-equivalent figure like csr_equivalent_GBs, not
@@ -386,6 +389,9 @@ def bench_joint(args, w, ctx, tfx, log):
                      "bytes_per_entry": fmt["bytes_per_entry"], "adjoint_copy": fmt["adjoint_copy"]})
         log("kernel %d (%s): build %.1f s, nnz %d, %.1f GB, adjoint identity %.1e" % (i, kern[-1]["problem"], dt, res["nnz"], info["device_bytes"] / 1e9, adj))
         b.append(ctx.mult_vector(rng.standard_normal(N) * 1e-3))
+    for i in range(2):                     # (the first kernel's automatic copy may have been given up for the second kernel's storage)
+        ctx.select_problem(i)
+        kern[i]["adjoint_copy"] = ctx.matrix_format()["adjoint_copy"]
     ctx.select_problem(0)
     assert ctx.system_dims() == (2 * D, 2 * N)
     alpha = np.concatenate([np.full(N, 1e-6, np.float32), np.full(N, 2e-6, np.float32)])
@@ -415,7 +421,7 @@ def bench_joint(args, w, ctx, tfx, log):
     out = {"metric": "LSQR iterations/s, joint gravity + magnetic inversion (two wavelet-compressed sensitivity kernels in one system)",
            "value": round(value, 4), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * t_steps / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "f64 (fp32-stored matrix values, fp64 vectors and accumulation)", "data": "synthetic",
+           "dtype": dtype_line(w, {"adjoint_copy": all(k["adjoint_copy"] for k in kern)}), "data": "synthetic",
            "config": {"workload": args.workload + ": " + w["desc"], "cells": N, "obs": [D, D], "nnz": nnz, "compression": "haar", "rate": w["rate"],
                       "parallelism": "both kernels on one GPU"},
            "cell_obs_per_s_solve": round(2.0 * N * D * value, 1), "cell_obs_per_s_build": round(2.0 * N * D / t_build, 1), "build_s": round(t_build, 2),
@@ -469,6 +475,20 @@ def reference_config1(log):
         return None
 
 
+CONV_MAJOR = 3        # major iterations of the converged parity leg of cpu_baseline.reference_medium
+
+
+def dtype_line(w, fmt):
+    """The arithmetic of the path: fp32-stored matrix values, fp64 vectors; fp64 sums in both products when the adjoint runs on the
+    transposed copy, 61-bit fixed-point column sums (exact integer accumulation per tile group) when it runs on the tiles of S."""
+    if w["ctype"] == 0:
+        return "f64 (fp32-stored dense block, fp64 vectors and accumulation)"
+    if fmt.get("adjoint_copy"):
+        return "f64 (fp32-stored matrix values, fp64 vectors; fp64 accumulation in both products: the adjoint is the forward kernel on the transposed copy)"
+    return ("f64 (fp32-stored matrix values, fp64 vectors; forward product: fp64 accumulation; adjoint WITHOUT a transposed copy: 61-bit fixed-point "
+            "column sums per tile group - every product rounded once to a 2^-60 grid of the group's bound, added exactly in 64-bit integers)")
+
+
 def cpu_baseline_reference(tfx, nnz_headline, pairs_headline, log, nx=64, ny=64, nz=32, ox=32, oy=32, ctype=1, rate=0.1):
     """The compiled reference itself (oracle/_ref/tomofastx = /root/reference built by oracle/ref_build.sh; it travels to the
     GPU box as a binary) under `mpiexec -n <all host cores>` on the SURVEY-6 synthetic size (64x64x32 cells x 32x32 data,
@@ -500,8 +520,8 @@ def cpu_baseline_reference(tfx, nnz_headline, pairs_headline, log, nx=64, ny=64,
     lsqr_rank_counts = [lsqr_ranks]
     wd = tempfile.mkdtemp(prefix="tfx_refcpu_")
     try:
-        def run(ranks, nminor, sensit_read):
-            tfx.synthetic.write_parfile_inputs(wd, nx, ny, nz, ox, oy, ctype, rate, nmajor=1, nminor=nminor, sensit_read=sensit_read)
+        def run(ranks, nminor, sensit_read, nmajor=1):
+            tfx.synthetic.write_parfile_inputs(wd, nx, ny, nz, ox, oy, ctype, rate, nmajor=nmajor, nminor=nminor, sensit_read=sensit_read)
             t0 = time.time()
             p = subprocess.run([mpiexec, "-n", str(ranks), ref, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
             dt = time.time() - t0
@@ -520,16 +540,23 @@ def cpu_baseline_reference(tfx, nnz_headline, pairs_headline, log, nx=64, ny=64,
             t0a, _ = run(rk, 1, 1)
             t0b, _ = run(rk, 1, 1)
             t1_, _ = run(rk, 101, 1)
-            ref_medium = collect_parfile_outputs(wd)          # the reference's 1 x 101-iteration inversion: kept for reference_medium
+            ref_timing_leg = collect_parfile_outputs(wd)      # the reference's 1 x 101-iteration run (the timing leg; NOT converged)
+            # The parity leg: a CONVERGED inversion (CONV_MAJOR x 100 iterations on the same kernel files).  After one major iteration both
+            # costs still sit near 1e-7 and last-bit differences of the sums are amplified by the Golub-Kahan recurrence; three major
+            # iterations re-start LSQR from the updated residual and the solutions contract onto each other.
+            run(rk, 100, 1, nmajor=CONV_MAJOR)
+            ref_medium = collect_parfile_outputs(wd)
+            ref_medium["timing_leg"] = ref_timing_leg
             if rk > 1:
                 # the same inversion on half the ranks: the reference's OWN distance between two rank counts on this problem (the sums of
                 # its products and norms are ordered differently) - the yardstick for the GPU host's distance in reference_medium
-                run(max(1, rk // 2), 101, 1)
+                run(max(1, rk // 2), 100, 1, nmajor=CONV_MAJOR)
                 other = collect_parfile_outputs(wd)
                 ref_medium["own_scatter"] = {
                     "ranks": [rk, max(1, rk // 2)],
                     "model_rel_l2": float(np.linalg.norm(other["model"] - ref_medium["model"]) / np.linalg.norm(ref_medium["model"])),
-                    "data_cost": [ref_medium["data_cost"], other["data_cost"]]}
+                    "data_cost": [ref_medium["data_cost"], other["data_cost"]],
+                    "data_cost_ratio": other["data_cost"] / ref_medium["data_cost"]}
             base, noise = min(t0a, t0b), abs(t0a - t0b)
             diff = t1_ - base
             legs[rk] = {"reload_and_1_iteration_s": base, "reload_and_1_iteration_repeat_spread_s": noise, "reload_and_101_iterations_s": t1_,
@@ -547,6 +574,9 @@ def cpu_baseline_reference(tfx, nnz_headline, pairs_headline, log, nx=64, ny=64,
         t_iter = legs[best]["ms_per_lsqr_iteration"] * 1e-3
         t_build = max(tA - t_reload_build_ranks, 1e-9)   # A = inputs + build + write + reload + 1 iteration
         out = {"value": 1.0 / (t_iter * nnz_headline / nnz), "unit": "iterations/s", "cores": best,      # the ranks `value` was measured on
+               # `value` is an EXTRAPOLATION (linear in nnz) to the headline matrix; what was measured, at the size it was measured on:
+               "value_is": "linear extrapolation in nnz of value_measured to the headline matrix (nnz %d)" % nnz_headline,
+               "value_measured": 1.0 / t_iter, "value_measured_at": {"nnz": nnz, "cells": N, "obs": nd, "ranks": best},
                "build_cores": build_ranks, "host_cores": cores, "kind": "reference",
                "sample": "oracle/_ref/tomofastx (the compiled reference) under mpiexec on %dx%dx%d cells x %d data, Haar r = %g "
                          "(box: %d host cores): kernel build on %d ranks %.3e cell.obs/s; LSQR %.2f ms per iteration at nnz = %d on "
@@ -597,12 +627,28 @@ def collect_parfile_outputs(wd, out="output/synth"):
 
 
 def reference_medium(tfx, wd, ref_out, cfg, log):
-    """Mid-scale parity, live on the GPU box: the compiled reference's 1 x 101-iteration inversion of the cpu_baseline leg (128x128x32
-    cells x 1024 data, Haar r = 0.05 on a >= 32-core box) against this repo's Parfile host on the GPU, same Parfile and inputs."""
+    """Mid-scale parity, live on the GPU box: the compiled reference's CONVERGED inversion of the cpu_baseline leg's problem (128x128x32
+    cells x 1024 data, Haar r = 0.05 on a >= 32-core box; CONV_MAJOR x 100 LSQR iterations) against this repo's Parfile host on the GPU,
+    same Parfile and inputs; reported next to the reference's own distance between two rank counts.  The 1 x 101-iteration run that
+    times the reference's LSQR is compared too, as `timing_leg_1x101` (not converged: see DESIGN.md 4)."""
     import subprocess
     ours = os.path.join(ROOT, "tomofast-x_amd", "host", "tomofastx_amd")
     if not os.path.isfile(ours) or ref_out is None:
         return None
+
+    def gpu_host(nmajor, nminor, sensit_read, env=None):
+        tfx.synthetic.write_parfile_inputs(wd, nx, ny, nz, ox, oy, ctype, rate, nmajor=nmajor, nminor=nminor, sensit_read=sensit_read)
+        t0 = time.time()
+        p = subprocess.run([ours, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=600, env=env)
+        if p.returncode != 0 or "THE END." not in p.stdout:
+            raise RuntimeError("the GPU host failed: " + p.stdout[-300:] + p.stderr[-300:])
+        return collect_parfile_outputs(wd), time.time() - t0
+
+    def distance(got, ref):
+        rm, gm = ref["model"], got["model"]
+        return {"model_rel_l2": float(np.linalg.norm(gm - rm) / np.linalg.norm(rm)), "model_max_abs_diff": float(np.abs(gm - rm).max()),
+                "data_cost": {"reference": ref["data_cost"], "gpu": got["data_cost"], "ratio_gpu_over_reference": got["data_cost"] / ref["data_cost"]}}
+
     try:
         nx, ny, nz, ox, oy, ctype, rate = cfg
         # (1) the GPU host on the REFERENCE'S OWN kernel: it reads the SENSIT files the reference's build left in the work directory
@@ -610,44 +656,37 @@ def reference_medium(tfx, wd, ref_out, cfg, log):
         # the norms.  Run first: the host's own build (2) rewrites that folder.
         on_ref_kernel = None
         try:
-            tfx.synthetic.write_parfile_inputs(wd, nx, ny, nz, ox, oy, ctype, rate, nmajor=1, nminor=101, sensit_read=1)
-            p = subprocess.run([ours, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=600, env=dict(os.environ, TFX_WRITE_SENSIT="0"))
-            if p.returncode == 0 and "THE END." in p.stdout:
-                t = open(os.path.join(wd, "output/synth", "model", "grav_final_model_full.txt")).read().split()
-                gm1 = np.array([float(v) for v in t[1:1 + int(t[0])]])
-                on_ref_kernel = {"model_rel_l2": float(np.linalg.norm(gm1 - ref_out["model"]) / np.linalg.norm(ref_out["model"])),
-                                 "model_max_abs_diff": float(np.abs(gm1 - ref_out["model"]).max())}
-            else:
-                log("reference_medium: the GPU host on the reference's SENSIT files failed: " + p.stdout[-300:] + p.stderr[-300:])
+            got1, _ = gpu_host(CONV_MAJOR, 100, 1, env=dict(os.environ, TFX_WRITE_SENSIT="0"))
+            on_ref_kernel = distance(got1, ref_out)
         except Exception as e:      # noqa
             log("reference_medium: reload leg skipped: %r" % (e,))
-        # (2) the GPU host building its own kernel
-        tfx.synthetic.write_parfile_inputs(wd, nx, ny, nz, ox, oy, ctype, rate, nmajor=1, nminor=101, sensit_read=0)
-        t0 = time.time()
-        p = subprocess.run([ours, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=600)
-        dt = time.time() - t0
-        if p.returncode != 0 or "THE END." not in p.stdout:
-            log("reference_medium: the GPU host failed: " + p.stdout[-300:] + p.stderr[-300:])
-            return None
-        got = collect_parfile_outputs(wd)
-        rm, gm = ref_out["model"], got["model"]
+        # (2) the GPU host building its own kernel: the converged leg, then the timing leg's 1 x 101 iterations
+        got, dt = gpu_host(CONV_MAJOR, 100, 0)
         hist_same = float(np.mean(ref_out["nnz_hist"] == got["nnz_hist"]))
-        out = {"config": "%dx%dx%d cells x %d data, %s r = %g, 1 x 101 LSQR iterations" % (nx, ny, nz, ox * oy, {1: "Haar", 2: "D4"}[ctype], rate),
-               "gpu_host_wall_s": round(dt, 2),
-               "model_rel_l2": float(np.linalg.norm(gm - rm) / np.linalg.norm(rm)), "model_max_abs_diff": float(np.abs(gm - rm).max()),
-               "model_max_abs": float(np.abs(rm).max()),
-               # data cost = |d_calc - d_obs| / |d_obs| (data_gravmag.f90:123-129): after 101 iterations it is itself ~1e-7, so the
-               # difference of two costs is a data-space distance of that order, not a relative error of the cost
-               "data_cost": {"reference": ref_out["data_cost"], "gpu": got["data_cost"], "abs_diff": abs(got["data_cost"] - ref_out["data_cost"])},
-               "reference_own_scatter_between_rank_counts": ref_out.get("own_scatter"),
-               # the same inversion by the GPU host on the reference's own SENSIT files (identical matrix bits: the solver alone)
-               "gpu_host_on_the_reference_kernel": on_ref_kernel,
-               "nnz_total": {"reference": ref_out["nnz_total"], "gpu": got["nnz_total"]},
-               "compression_error": {"reference": ref_out["comp_error"], "gpu": got["comp_error"]},
-               "nnz_histogram": {"columns": int(rm.size), "columns_with_identical_count": hist_same,
-                                 "sum_abs_count_diff": int(np.abs(ref_out["nnz_hist"] - got["nnz_hist"]).sum())}}
-        log("reference_medium: model rel-L2 %.2e (on the reference's own kernel: %s), data cost %.6e vs %.6e, nnz %d vs %d, identical column counts %.6f" %
-            (out["model_rel_l2"], "%.2e" % on_ref_kernel["model_rel_l2"] if on_ref_kernel else "n/a", got["data_cost"], ref_out["data_cost"],
+        out = {"config": "%dx%dx%d cells x %d data, %s r = %g, %d x 100 LSQR iterations (converged)" %
+                         (nx, ny, nz, ox * oy, {1: "Haar", 2: "D4"}[ctype], rate, CONV_MAJOR),
+               "gpu_host_wall_s": round(dt, 2), "model_max_abs": float(np.abs(ref_out["model"]).max())}
+        out.update(distance(got, ref_out))
+        out.update({"reference_own_scatter_between_rank_counts": ref_out.get("own_scatter"),
+                    # the same inversion by the GPU host on the reference's own SENSIT files (identical matrix bits: the solver alone)
+                    "gpu_host_on_the_reference_kernel": on_ref_kernel,
+                    "nnz_total": {"reference": ref_out["nnz_total"], "gpu": got["nnz_total"]},
+                    "compression_error": {"reference": ref_out["comp_error"], "gpu": got["comp_error"]},
+                    "nnz_histogram": {"columns": int(ref_out["model"].size), "columns_with_identical_count": hist_same,
+                                      "sum_abs_count_diff": int(np.abs(ref_out["nnz_hist"] - got["nnz_hist"]).sum())}})
+        if ref_out.get("timing_leg") is not None:
+            try:
+                got_t, _ = gpu_host(1, 101, 0)
+                out["timing_leg_1x101"] = dict(distance(got_t, ref_out["timing_leg"]),
+                                               note="NOT converged (both costs ~1e-7): an unconverged Golub-Kahan recurrence amplifies last-bit "
+                                                    "differences of the sums; kept because this run times the reference's LSQR")
+            except Exception as e:      # noqa
+                log("reference_medium: timing-leg comparison skipped: %r" % (e,))
+        own = ref_out.get("own_scatter") or {}
+        log("reference_medium (%d x 100, converged): model rel-L2 %.2e (on the reference's own kernel: %s; the reference's own %s-rank scatter: %s), "
+            "data cost %.6e vs %.6e (ratio %.6f), nnz %d vs %d, identical column counts %.6f" %
+            (CONV_MAJOR, out["model_rel_l2"], "%.2e" % on_ref_kernel["model_rel_l2"] if on_ref_kernel else "n/a", own.get("ranks"),
+             "%.2e" % own["model_rel_l2"] if own else "n/a", got["data_cost"], ref_out["data_cost"], got["data_cost"] / ref_out["data_cost"],
              got["nnz_total"], ref_out["nnz_total"], hist_same))
         return out
     except Exception as e:      # never take the benchmark down

@@ -105,7 +105,10 @@ def test_config1_from_parfile_matches_reference_outputs(tmp_path, golden_dir):
     assert np.allclose(dobs[:, 3], g["data_observed"], rtol=1e-9, atol=1e-12 * np.abs(g["data_observed"]).max())
     costs = [l.split() for l in open(os.path.join(wd, "output", "mansf_slice", "costs.txt")) if not l.lstrip().startswith("#")]
     assert len(costs) == 61 and int(costs[-1][0]) == 60
-    assert abs(float(costs[-1][1]) - 9.339172972115141e-11) <= 1e-2 * 9.339172972115141e-11        # final data cost
+    # final data cost: SURVEY 8d asks for <= 1e-5 relative; the reference's own 1 / 2 / 4-rank runs scatter by 1.5e-6
+    dcost = abs(float(costs[-1][1]) - 9.339172972115141e-11) / 9.339172972115141e-11
+    print("config 1 (Fortran host): final model rel-L2 %.3e, final data cost %s (relative distance %.3e)" % (rel, costs[-1][1], dcost))
+    assert dcost <= 5e-6, dcost          # measured 1.9-2.0e-6 on either host
     assert abs(float(costs[-1][2]) - 0.22595168071843558) <= 1e-5 * 0.22595168071843558            # final model cost
 
 

@@ -624,7 +624,7 @@ def test_normalize_columns_vs_reference(ctx, adj_copy):
         norm_g, vals_g, sty = runs[0]
         assert bits_equal(runs[1][0], norm_g) and bits_equal(runs[1][1], vals_g) and bits_equal(runs[1][2], sty)
         assert np.all(np.abs(norm_g - norm_o) <= nrows * 2.0 ** -53 * norm_o)
-        assert np.all(norm_g[dead - 1] == 0.0) and np.count_nonzero(norm_g) >= ncols - 500 - 50
+        assert np.all(norm_g[dead - 1] == 0.0) and np.array_equal(norm_g == 0.0, norm_o == 0.0)
         same_norm = (norm_g == norm_o)[cols - 1]
         print("normalize_columns: %d of %d norms identical to the sequential sums, worst relative distance %.2e" %
               (np.count_nonzero(norm_g == norm_o), ncols, np.max(np.abs(norm_g - norm_o) / np.maximum(norm_o, 1e-300))))
@@ -1021,6 +1021,88 @@ def test_end_to_end_inversion_vs_reference(ctx, golden_dir, name):
     assert np.linalg.norm(m - ref) <= 1e-6 * np.linalg.norm(ref)
     cost_ref = np.linalg.norm(g["np1_data_final"] - g["np1_data_observed"]) / np.linalg.norm(g["np1_data_observed"])
     assert abs(hist[-1]["cost"] - cost_ref) <= 1e-5 * cost_ref + 1e-16
+
+
+def _lsqr_long_double(rp, cols, vals, alpha, d, N, K):
+    """lsqr_solve_sensit's recurrence (lsqr_solver2.F90:115-290) on [S; alpha I] x = [d; 0] with every product and sum in numpy long
+    double (64-bit mantissa): the reference trajectory of an UNCONVERGED run, against which two fp64 arithmetics can be ranked."""
+    LD = np.longdouble
+    c0 = cols.astype(np.int64) - 1
+    rows = np.repeat(np.arange(rp.size - 1), np.diff(rp))
+    order = np.argsort(c0, kind="stable")
+    cT, rT, vT = c0[order], rows[order], vals[order].astype(LD)
+    colptr = np.concatenate([[0], np.cumsum(np.bincount(cT, minlength=N))])
+    v64 = vals.astype(LD)
+    ne_r, ne_c = np.diff(rp) > 0, np.diff(colptr) > 0
+
+    def seg(prod, ptr, ne, n):
+        out = np.zeros(n, LD)
+        out[ne] = np.add.reduceat(prod, ptr[:-1][ne])
+        return out
+
+    def A(x):
+        return np.concatenate([seg(v64 * x[c0], rp, ne_r, rp.size - 1), LD(alpha) * x])
+
+    def AT(u):
+        nd = rp.size - 1
+        return seg(vT * u[:nd][rT], colptr, ne_c, N) + LD(alpha) * u[nd:]
+
+    def norm(v):
+        return np.sqrt(np.sum(v * v))
+
+    u = np.concatenate([d, np.zeros(N)]).astype(LD)
+    beta = norm(u); u /= beta; b1 = beta
+    v = AT(u); al = norm(v); v /= al
+    w = v.copy(); x = np.zeros(N, LD); phibar = beta; rhobar = al
+    for _ in range(K):
+        u = A(v) - al * u; beta = norm(u); u /= beta
+        v = AT(u) - beta * v; al = norm(v); v /= al
+        rho = np.sqrt(rhobar * rhobar + beta * beta)
+        c, s_ = rhobar / rho, beta / rho
+        theta = s_ * al; rhobar = -c * al; phi = c * phibar; phibar = s_ * phibar
+        x = x + (phi / rho) * w
+        w = v - (theta / rho) * w
+    return x.astype(np.float64), float(phibar / b1)
+
+
+@pytest.mark.parametrize("adj_copy", [2, 0])
+def test_unconverged_lsqr_is_closer_to_extended_precision_than_sequential_fp64(ctx, adj_copy):
+    """Why the GPU host's 1 x 101-iteration run of bench.py's mid-scale problem sits 2.5e-7 from the reference's model (15 x the
+    reference's own rank scatter) with a LOWER data cost: 101 iterations of lsqr_solve_sensit (lsqr_solver2.F90:47-308) on the same
+    128x128x32-cell x 1024-data system in three arithmetics - fp64 with the reference's sequential sums (sparse_matrix.f90:316-329,
+    :391-405: the C oracle), the HIP path (tile / tree order, fused multiply-adds), and 80-bit long double.  The recurrence is not
+    converged, so rounding differences of the sums are amplified by orders of magnitude; the HIP path must be the one NEARER the
+    long-double trajectory - in the solution and in the residual - i.e. its distance to the reference is the reference's rounding.
+    Both adjoints: on the transposed copy (fp64 sums) and on the tiles of S (61-bit fixed-point sums)."""
+    nx, ny, nz, ox, oy, rate, K = 128, 128, 32, 32, 32, 0.05, 101
+    N = nx * ny * nz
+    ctx.debug_set("adj_copy", adj_copy)
+    try:
+        ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
+        cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+        xs, ys, zs = tfx.synthetic.observations(nx, ny, ox, oy)
+        ctx.calculate_sensit(xs, ys, zs, cw, 1, rate)
+        assert bool(ctx.matrix_format()["adjoint_copy"]) == (adj_copy != 0)
+        mtrue = tfx.synthetic.true_model(nx, ny, nz)
+        d = ctx.calc_data(ctx.forward_wavelet(mtrue / cw, nx, ny, nz, 1), 1.0, None)
+        alpha = np.float32(1e-7)
+        x_gpu, it, r_gpu = ctx.lsqr_solve_sensit(d, K, 1e-300, 0.0, 0.0, [np.full(N, alpha, np.float32)], [np.zeros(N)])
+        rp, cols, vals = ctx.matrix_download_csr()
+    finally:
+        ctx.debug_set("adj_copy", 2)
+    x_seq, it2, r_seq = orc.lsqr((rp, cols, vals), orc.diag_csr(np.full(N, alpha, np.float32)), N, np.concatenate([d, np.zeros(N)]), K)
+    x_ext, r_ext = _lsqr_long_double(rp, cols, vals, alpha, d, N, K)
+    assert it == it2 == K
+
+    def rel(p, q):
+        return float(np.linalg.norm(p - q) / np.linalg.norm(q))
+
+    g_e, s_e, g_s = rel(x_gpu, x_ext), rel(x_seq, x_ext), rel(x_gpu, x_seq)
+    print("LSQR x %d, adj_copy %d: residual seq64 %.9e / gpu %.9e / ext80 %.9e; model rel-L2 gpu-ext80 %.2e, seq64-ext80 %.2e, gpu-seq64 %.2e" %
+          (K, adj_copy, r_seq, r_gpu, r_ext, g_e, s_e, g_s))
+    assert g_e <= s_e, (g_e, s_e)                                   # the solution: nearer the long-double trajectory than the reference's arithmetic
+    assert abs(r_gpu - r_ext) <= abs(r_seq - r_ext), (r_gpu, r_seq, r_ext)      # and so is the residual
+    assert g_s <= 2.0 * (g_e + s_e)                                 # (triangle: nothing else separates the two fp64 runs)
 
 
 @pytest.mark.parametrize("name", ["e2e_medium_haar", "e2e_medium_d4"])
@@ -1563,7 +1645,11 @@ def test_config1_mansf_end_to_end(ctx, golden_dir):
     rel = np.linalg.norm(m - ref) / np.linalg.norm(ref)
     assert rel <= 1e-6, rel
     assert abs(m.min() - (-19.951562372333093)) < 1e-4 and abs(m.max() - 259.9972445968676) < 1e-4
-    assert abs(hist[-1]["cost"] - 9.339172972115141e-11) <= 1e-2 * 9.339172972115141e-11
+    # final data cost: SURVEY 8d asks for <= 1e-5 relative; the reference's own 1 / 2 / 4-rank runs scatter by 1.5e-6
+    dcost = abs(hist[-1]["cost"] - 9.339172972115141e-11) / 9.339172972115141e-11
+    print("config 1: final model rel-L2 %.3e, final data cost %.15e (relative distance %.3e; reference rank scatter 1.5e-6)" %
+          (rel, hist[-1]["cost"], dcost))
+    assert dcost <= 5e-6, dcost          # measured 1.9-2.0e-6 on either host
 
 
 def test_medium_synthetic_build_vs_oracle_and_adjoint_identity(ctx):
