@@ -120,18 +120,29 @@ module tfx_reference_api
     integer(c_int64_t), allocatable :: ijl(:)       ! row offsets (0-based), nl + 1
     integer(c_int32_t), allocatable :: ija(:)       ! 1-based local columns
     real(c_float), allocatable :: sa(:)
+    integer(c_int64_t) :: nnz = 0                   ! predicted number of elements (initialize)
+    real(dp), allocatable, public :: lsqr_var(:)    ! sparse_matrix.f90:67 (auxiliary array of the solution variance)
+    integer, public :: tag = 0                      ! sparse_matrix.f90:70
   contains
+    ! the reference's public interface, same names and argument lists (sparse_matrix.f90:72-98)
     procedure, public, pass :: initialize => sparse_matrix_initialize
     procedure, public, pass :: reset => sparse_matrix_reset
-    procedure, public, pass :: add => sparse_matrix_add
-    procedure, public, pass :: new_row => sparse_matrix_new_row
     procedure, public, pass :: finalize => sparse_matrix_finalize
+    procedure, public, pass :: add => sparse_matrix_add
+    procedure, public, pass :: add_row => sparse_matrix_add_row
+    procedure, public, pass :: new_row => sparse_matrix_new_row
+    procedure, public, pass :: add_empty_rows => sparse_matrix_add_empty_rows
+    procedure, public, pass :: mult_vector => sparse_matrix_mult_vector
+    procedure, public, pass :: add_mult_vector => sparse_matrix_add_mult_vector
+    procedure, public, pass :: part_mult_vector => sparse_matrix_part_mult_vector
+    procedure, public, pass :: trans_mult_vector => sparse_matrix_trans_mult_vector
+    procedure, public, pass :: add_trans_mult_vector => sparse_matrix_add_trans_mult_vector
+    procedure, public, pass :: normalize_columns => sparse_matrix_normalize_columns
     procedure, public, pass :: get_total_row_number => sparse_matrix_get_total_row_number
+    procedure, public, pass :: get_current_row_number => sparse_matrix_get_current_row_number
     procedure, public, pass :: get_ncolumns => sparse_matrix_get_ncolumns
     procedure, public, pass :: get_number_elements => sparse_matrix_get_number_elements
-    procedure, public, pass :: mult_vector => sparse_matrix_mult_vector
-    procedure, public, pass :: trans_mult_vector => sparse_matrix_trans_mult_vector
-    procedure, public, pass :: normalize_columns => sparse_matrix_normalize_columns
+    procedure, public, pass :: get_nnz => sparse_matrix_get_nnz
   end type t_sparse_matrix
 
   ! ---- src/inversion/model.F90:33-110 (the fields model_calculate_data reads)
@@ -231,6 +242,7 @@ module tfx_reference_api
   public :: calculate_depth_weight, calculate_and_write_sensit, calculate_new_partitioning, read_sensitivity_kernel
   public :: model_calculate_data, lsqr_solve_sensit, forward_wavelet, inverse_wavelet
   public :: get_full_array, write_sensit_rank_file_enabled
+  public :: tfx_api_kernel_slot
 
 contains
 
@@ -278,6 +290,15 @@ contains
     endif
     ctx = api_ctx
   end function tfx_api_context
+
+  ! tfx_select_problem slot of the kernel of problem ip (1 gravity, 2 magnetic) once it has been built or loaded; -1 before
+  integer function tfx_api_kernel_slot(ip)
+    integer, intent(in) :: ip
+    tfx_api_kernel_slot = -1
+    if (ip >= 1 .and. ip <= 2) then
+      if (kst(ip)%built) tfx_api_kernel_slot = kst(ip)%slot
+    endif
+  end function tfx_api_kernel_slot
 
   subroutine tfx_api_finalize()
     integer :: ip
@@ -362,12 +383,13 @@ contains
 
   !-------------------------------------------------------------------------------------------------------
   ! t_sparse_matrix as a row builder for the constraint matrix (sparse_matrix.f90:107-293)
-  subroutine sparse_matrix_initialize(this, nl, ncolumns, nnz, myrank)
+  subroutine sparse_matrix_initialize(this, nl, ncolumns, nnz, myrank, nl_empty)
     class(t_sparse_matrix), intent(inout) :: this
     integer, intent(in) :: nl, ncolumns, myrank
+    integer, intent(in), optional :: nl_empty       ! (the reference sizes its non-empty-row index by it; every row has an offset here)
     integer(c_int64_t), intent(in) :: nnz
     integer :: ierr
-    this%nl = nl; this%ncolumns = ncolumns
+    this%nl = nl; this%ncolumns = ncolumns; this%nnz = nnz
     this%nl_current = 0; this%nel = 0
     if (allocated(this%ijl)) deallocate(this%ijl, this%ija, this%sa)
     allocate(this%ijl(nl + 1), this%ija(max(nnz, 1_c_int64_t)), this%sa(max(nnz, 1_c_int64_t)), stat=ierr)
@@ -393,6 +415,30 @@ contains
     this%ija(this%nel) = column
   end subroutine sparse_matrix_add
 
+  subroutine sparse_matrix_add_row(this, nel_add, values, columns, myrank)      ! sparse_matrix.f90:234-248 (values already in matrix precision)
+    class(t_sparse_matrix), intent(inout) :: this
+    integer, intent(in) :: nel_add
+    real(c_float), intent(in) :: values(nel_add)
+    integer, intent(in) :: columns(nel_add)
+    integer, intent(in) :: myrank
+    if (this%nel + nel_add > size(this%sa, kind=c_int64_t)) &
+      call exit_MPI('Error in total number of elements in sparse_matrix_add_row!', myrank, 0)
+    this%sa(this%nel + 1:this%nel + nel_add) = values
+    this%ija(this%nel + 1:this%nel + nel_add) = columns
+    this%nel = this%nel + nel_add
+  end subroutine sparse_matrix_add_row
+
+  subroutine sparse_matrix_add_empty_rows(this, nrows, myrank)                  ! sparse_matrix.f90:281-293
+    class(t_sparse_matrix), intent(inout) :: this
+    integer, intent(in) :: nrows, myrank
+    integer :: i
+    if (this%nl_current + nrows > this%nl) call exit_MPI('Error in number of rows in sparse_matrix_add_empty_rows!', myrank, 0)
+    do i = 1, nrows
+      this%nl_current = this%nl_current + 1
+      this%ijl(this%nl_current + 1) = this%nel
+    enddo
+  end subroutine sparse_matrix_add_empty_rows
+
   subroutine sparse_matrix_new_row(this, myrank)                                ! sparse_matrix.f90:242-276
     class(t_sparse_matrix), intent(inout) :: this
     integer, intent(in) :: myrank
@@ -414,6 +460,18 @@ contains
     res = merge(this%nl_device, this%nl, this%on_device)
   end function sparse_matrix_get_total_row_number
 
+  pure function sparse_matrix_get_current_row_number(this) result(res)            ! sparse_matrix.f90:458-463
+    class(t_sparse_matrix), intent(in) :: this
+    integer :: res
+    res = this%nl_current
+  end function sparse_matrix_get_current_row_number
+
+  pure function sparse_matrix_get_nnz(this) result(res)                           ! sparse_matrix.f90:488-493
+    class(t_sparse_matrix), intent(in) :: this
+    integer(c_int64_t) :: res
+    res = this%nnz
+  end function sparse_matrix_get_nnz
+
   pure function sparse_matrix_get_ncolumns(this) result(res)
     class(t_sparse_matrix), intent(in) :: this
     integer :: res
@@ -426,27 +484,63 @@ contains
     res = this%nel
   end function sparse_matrix_get_number_elements
 
-  ! b = S x / b = S^T x with the device-resident kernel (sparse_matrix.f90:298-329, :373-405); single kernel (slot 0) only -
-  ! the joint system is applied by lsqr_solve_sensit.  There is no host-side product: a host matrix aborts.
-  subroutine sparse_matrix_mult_vector(this, x, b, myrank)
+  ! b (+)= S x / b (+)= S^T x with the device-resident kernel (sparse_matrix.f90:298-329, :373-405), the reference's argument lists;
+  ! single kernel (slot 0) only - the joint system is applied by lsqr_solve_sensit.  There is no host-side product: a host matrix aborts.
+  subroutine sparse_matrix_mult_vector(this, x, b)
     class(t_sparse_matrix), intent(in) :: this
     real(dp), intent(in) :: x(:)
     real(dp), intent(out) :: b(:)
-    integer, intent(in) :: myrank
-    if (.not. this%on_device) call exit_MPI('mult_vector: only the device-resident sensitivity kernel has products.', myrank, 0)
-    call api_check(tfx_select_problem(api_ctx, 0_c_int), 'tfx_select_problem', myrank)
-    call api_check(tfx_spmv(api_ctx, x, b, 0_c_int), 'mult_vector', myrank)
+    if (.not. this%on_device) call exit_MPI('mult_vector: only the device-resident sensitivity kernel has products.', 0, 0)
+    call api_check(tfx_select_problem(api_ctx, 0_c_int), 'tfx_select_problem', 0)
+    call api_check(tfx_spmv(api_ctx, x, b, 0_c_int), 'mult_vector', 0)
   end subroutine sparse_matrix_mult_vector
 
-  subroutine sparse_matrix_trans_mult_vector(this, x, b, myrank)
+  subroutine sparse_matrix_add_mult_vector(this, x, b)
+    class(t_sparse_matrix), intent(in) :: this
+    real(dp), intent(in) :: x(:)
+    real(dp), intent(inout) :: b(:)
+    if (.not. this%on_device) call exit_MPI('add_mult_vector: only the device-resident sensitivity kernel has products.', 0, 0)
+    call api_check(tfx_select_problem(api_ctx, 0_c_int), 'tfx_select_problem', 0)
+    call api_check(tfx_spmv(api_ctx, x, b, 1_c_int), 'add_mult_vector', 0)
+  end subroutine sparse_matrix_add_mult_vector
+
+  ! sparse_matrix.f90:335-367: rows [line_start, line_start + ndata) of the joint matrix times x, columns shifted by param_shift - the
+  ! block of ONE kernel: the kernel in the slot whose rows start there (0 / 1 in load order)
+  subroutine sparse_matrix_part_mult_vector(this, nelements, x, ndata, b, line_start, param_shift, myrank)
+    class(t_sparse_matrix), intent(in) :: this
+    integer, intent(in) :: nelements, ndata
+    real(dp), intent(in) :: x(nelements)
+    integer, intent(in) :: line_start, param_shift
+    integer, intent(in) :: myrank
+    real(dp), intent(out) :: b(ndata)
+    integer :: slot
+    integer(c_int64_t) :: nr, nc, nz, dbytes
+    if (.not. this%on_device) call exit_MPI('part_mult_vector: only the device-resident sensitivity kernel has products.', myrank, 0)
+    slot = merge(0, 1, line_start <= 1 .and. param_shift == 0)
+    call api_check(tfx_select_problem(api_ctx, int(slot, c_int)), 'tfx_select_problem', myrank)
+    call api_check(tfx_matrix_info(api_ctx, nr, nc, nz, dbytes), 'tfx_matrix_info', myrank)
+    if (nr /= ndata .or. nc /= nelements) call exit_MPI('Wrong line index in sparse_matrix_part_mult_vector!', myrank, 0)
+    call api_check(tfx_spmv(api_ctx, x, b, 0_c_int), 'part_mult_vector', myrank)
+    call api_check(tfx_select_problem(api_ctx, 0_c_int), 'tfx_select_problem', myrank)
+  end subroutine sparse_matrix_part_mult_vector
+
+  subroutine sparse_matrix_trans_mult_vector(this, x, b)
     class(t_sparse_matrix), intent(in) :: this
     real(dp), intent(in) :: x(:)
     real(dp), intent(out) :: b(:)
-    integer, intent(in) :: myrank
-    if (.not. this%on_device) call exit_MPI('trans_mult_vector: only the device-resident sensitivity kernel has products.', myrank, 0)
-    call api_check(tfx_select_problem(api_ctx, 0_c_int), 'tfx_select_problem', myrank)
-    call api_check(tfx_spmtv(api_ctx, x, b, 0_c_int), 'trans_mult_vector', myrank)
+    if (.not. this%on_device) call exit_MPI('trans_mult_vector: only the device-resident sensitivity kernel has products.', 0, 0)
+    call api_check(tfx_select_problem(api_ctx, 0_c_int), 'tfx_select_problem', 0)
+    call api_check(tfx_spmtv(api_ctx, x, b, 0_c_int), 'trans_mult_vector', 0)
   end subroutine sparse_matrix_trans_mult_vector
+
+  subroutine sparse_matrix_add_trans_mult_vector(this, x, b)
+    class(t_sparse_matrix), intent(in) :: this
+    real(dp), intent(in) :: x(:)
+    real(dp), intent(inout) :: b(:)
+    if (.not. this%on_device) call exit_MPI('add_trans_mult_vector: only the device-resident sensitivity kernel has products.', 0, 0)
+    call api_check(tfx_select_problem(api_ctx, 0_c_int), 'tfx_select_problem', 0)
+    call api_check(tfx_spmtv(api_ctx, x, b, 1_c_int), 'add_trans_mult_vector', 0)
+  end subroutine sparse_matrix_add_trans_mult_vector
 
   ! sparse_matrix.f90:414-443: unit-length columns, returns the original norms (device-resident kernel only)
   subroutine sparse_matrix_normalize_columns(this, column_norm)
