@@ -242,7 +242,7 @@ module tfx_reference_api
   public :: calculate_depth_weight, calculate_and_write_sensit, calculate_new_partitioning, read_sensitivity_kernel
   public :: model_calculate_data, lsqr_solve_sensit, forward_wavelet, inverse_wavelet
   public :: get_full_array, write_sensit_rank_file_enabled
-  public :: tfx_api_kernel_slot
+  public :: tfx_api_kernel_slot, api_check
 
 contains
 
