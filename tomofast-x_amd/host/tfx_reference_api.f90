@@ -1473,6 +1473,9 @@ contains
           if (e > 0) then
             g_cols(pos + 1:pos + e) = matrix_cons%ija(matrix_cons%ijl(r0 + col) + 1:matrix_cons%ijl(r0 + col + 1))
             g_vals(pos + 1:pos + e) = matrix_cons%sa(matrix_cons%ijl(r0 + col) + 1:matrix_cons%ijl(r0 + col + 1))
+            ! the device layout wants ascending columns; the reference's builders add them in stencil order (damping_gradient.F90:190,
+            ! cross_gradient.F90:322-369: both problems' columns interleaved)
+            call sort_row(g_cols(pos + 1:pos + e), g_vals(pos + 1:pos + e), e)
             pos = pos + e
           endif
           r = r + 1
@@ -1501,6 +1504,37 @@ contains
     u = 0.d0                                                ! consumed, like the reference's in-place use of the right-hand side
     if (myrank_ == 0) print *, 'End of subroutine lsqr_solve_sensit, r =', rr, ' iter =', iters          ! :300-305
   end subroutine lsqr_solve_sensit
+
+  ! Ascending columns inside one constraint row (rows are a handful of entries: insertion sort).  Two entries of one row in the same
+  ! column - the reference's format allows them, its products simply add both - become one entry with the fp32 sum of the two.
+  subroutine sort_row(c, v, n)
+    integer(c_int64_t), intent(inout) :: n
+    integer(c_int32_t), intent(inout) :: c(n)
+    real(c_float), intent(inout) :: v(n)
+    integer(c_int64_t) :: i, j, m
+    integer(c_int32_t) :: ck
+    real(c_float) :: vk
+    do i = 2, n
+      ck = c(i); vk = v(i)
+      j = i - 1
+      do while (j >= 1)
+        if (c(j) <= ck) exit
+        c(j + 1) = c(j); v(j + 1) = v(j)
+        j = j - 1
+      enddo
+      c(j + 1) = ck; v(j + 1) = vk
+    enddo
+    m = 1
+    do i = 2, n
+      if (c(i) == c(m)) then
+        v(m) = v(m) + v(i)
+      else
+        m = m + 1
+        c(m) = c(i); v(m) = v(i)
+      endif
+    enddo
+    n = m
+  end subroutine sort_row
 
   !=======================================================================================================
   ! t_joint_inversion - src/inversion/joint_inverse_problem.F90
