@@ -187,3 +187,39 @@ def test_medium_scale_on_the_reference_program_with_the_dropin(tmp_path, golden_
           (name, nnz, int(g["nnz_total"]), rel, own))
     assert nnz == int(g["nnz_total"])
     assert rel <= 5e-8, rel
+
+
+@pytest.mark.parametrize("name", ["e2e_joint", "e2e_mag31", "e2e_xgrad"])
+def test_two_ranks_of_the_reference_program_with_the_dropin(tmp_path, golden_dir, name):
+    """`mpiexec -n 2 tomofastx_dropin -p Parfile` (both ranks on the one GPU of the box): the reference's own MPI decomposition -
+    its partition bookkeeping, its gathers / scatters of the model slices, its all-reduce of the predicted data - around the drop-in
+    modules, against the reference's own 2-rank run of the same Parfile."""
+    _need_exe()
+    if not os.path.isfile(MPIEXEC):
+        pytest.skip("no mpiexec in this image")
+    kind, extra, tol = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    wd = str(tmp_path)
+    if kind == "joint":
+        fh.write_joint_inputs(wd, g)
+        cases = [("grav", "grav", 1), ("magn", "mag", 1)]
+    else:
+        fh.write_case_inputs(wd, g)
+        open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
+        cases = [(None, "mag", int(g["ncm"]))]
+    extra(wd, g)
+    out = fh._sub_run([MPIEXEC, "-n", "2", EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "THE END" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    nel = [int(v) for v in out.stdout.split("nelements_at_cpu =")[1].split()[:2]]
+    if "np2_nelements_at_cpu" in g.files:
+        assert np.all(np.abs(np.array(nel) - g["np2_nelements_at_cpu"]) <= 2)      # a threshold tie may move the cut by a cell
+    for tag, sfx, ncm in cases:
+        key = "np2_%s_model_final" % tag if tag else "np2_model_final"
+        key1 = "np1_%s_model_final" % tag if tag else "np1_model_final"
+        model = fh.read_tokens(os.path.join(wd, "out", "model", sfx + "_final_model_full.txt"), ncm)
+        ref = g[key].reshape(model.shape)
+        self_diff = np.linalg.norm(g[key1].reshape(model.shape) - ref) / np.linalg.norm(ref)
+        rel = np.linalg.norm(model - ref) / np.linalg.norm(ref)
+        print("%s, 2 ranks of the reference's own program + drop-in: %s final model rel-L2 %.2e from the reference's 2-rank run (its 1- vs 2-rank: %.1e)" %
+              (name, sfx, rel, self_diff))
+        assert rel <= max(1e-6, 100.0 * self_diff), (tag, rel)

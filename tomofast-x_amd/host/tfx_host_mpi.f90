@@ -44,6 +44,19 @@ contains
     endif
   end subroutine host_mpi_init
 
+  ! A host program that initialised MPI itself (the reference's own program_tomofastx.F90 with the drop-in modules): adopt its
+  ! MPI_COMM_WORLD instead of starting MPI.  MPI_Initialized is one of the calls the standard allows before MPI_Init.
+  subroutine host_mpi_attach()
+    logical :: started
+    integer :: ierr
+    if (mpi_on) return
+    call MPI_Initialized(started, ierr)
+    if (ierr /= 0 .or. .not. started) return
+    mpi_on = .true.
+    call MPI_Comm_rank(MPI_COMM_WORLD, myrank, ierr)
+    call MPI_Comm_size(MPI_COMM_WORLD, nbproc, ierr)
+  end subroutine host_mpi_attach
+
   subroutine host_mpi_finalize()
     integer :: ierr
     if (mpi_on) call MPI_Finalize(ierr)

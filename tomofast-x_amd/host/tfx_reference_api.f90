@@ -283,6 +283,7 @@ contains
     type(c_ptr) :: ctx
     integer :: ndev
     if (.not. c_associated(api_ctx)) then
+      call host_mpi_attach()          ! (a caller that started MPI itself: the reference's program with the drop-in modules)
       ndev = tfx_device_count()
       if (ndev <= 0) call exit_MPI('No HIP device visible - the MI355X path has no CPU fallback.', rank, 0)
       call api_check(tfx_create(int(host_device_for_rank(), c_int), c_null_ptr, api_ctx), 'tfx_create', rank)
