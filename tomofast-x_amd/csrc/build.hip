@@ -37,6 +37,14 @@ __device__ __forceinline__ void init_math_tables()
     for (int i = threadIdx.x; i < 3 * TFX_LOG_TAB_N; i += blockDim.x) lds[i] = tfx_log_tab[i];
     for (int i = threadIdx.x; i < 2 * TFX_ATAN_TAB_N; i += blockDim.x) lds[3 * TFX_LOG_TAB_N + i] = tfx_atan_tab[i];
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also makes the workgroup's GLOBAL stores visible, i.e. it waits for
+// every outstanding store (s_waitcnt vmcnt(0)): in the row generators that drained the non-temporal stores of an observation's rows -
+// which nothing in the kernel ever reads back - at the first barrier of the next observation, so the HBM write latency of each cell phase
+// was exposed instead of running under the next node phase.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 #ifdef TFX_LIBM_TRANSCENDENTALS          // A/B builds only (make EXTRA=-DTFX_LIBM_TRANSCENDENTALS): the device libm instead of fastmath.h
 __device__ __forceinline__ double dlog(double x) { return log(x); }
 __device__ __forceinline__ double datan2(double y, double x) { return atan2(y, x); }
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // a launch of fewer workgroups than tiles (the build's overlap mode: two per CU, leaving registers and LDS to the HBM-bound
     // kernels of the main stream) walks the tiles with the grid's stride
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (tile != (int)blockIdx.x) __syncthreads();           // the previous tile's T / s_node are still being read
+    if (tile != (int)blockIdx.x) lds_barrier();           // the previous tile's T / s_node are still being read
     const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, bz = tile / (tiles_x * tiles_y);
     const int i0 = bx * PT_X, j0 = by * PT_Y, k0 = bz * PT_Z;
     const int cx = min(PT_X, nx - i0), cy = min(PT_Y, ny - j0), cz = min(PT_Z, nz - k0);
@@ -171,12 +179,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int64_t col0 = ((int64_t)k0 * ny + (j0 + tb)) * nx + (i0 + ta), lay = (int64_t)ny * nx;
     for (int o = 0; o < nobs; ++o) {
         const double xo = xd[o], yo = yd[o], zo = zd[o];
-        __syncthreads();
+        lds_barrier();
         for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
             const int code = s_node[n];
             T[code & 4095] = corner_term(xo - s_xe[(code >> 12) & 63], yo - s_ye[(code >> 18) & 15], zo - s_ze[code >> 22], bad);
         }
-        __syncthreads();
+        lds_barrier();
         double sq = 0.0;
         double *out = rows + (int64_t)o * N;
         const double *cwo = cw;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) sq += __shfl_down(sq, d);
             if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sq;
-            __syncthreads();
+            lds_barrier();
             if (threadIdx.x == 0) sumsq[(int64_t)o * ntiles + tile] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
         }
     }
@@ -373,13 +381,22 @@ __global__ __launch_bounds__(256) void k_magprism(int64_t N, const double *__res
 
 // Tensor-product grid: of the 24 atan2 + 12 log + 24 sqrt of a cell's tensor, the two atan2 families and the three distances
 // (one per summation order of the squares, so that the bits are sharmbox's) depend on one NODE only.  A workgroup evaluates them
-// once for the (MT_X+1)(MT_Y+1)(MT_Z+1) nodes of its tile into LDS (1.4 nodes per cell: 2.8 atan2 + 4 sqrt per cell instead of
+// once for the (MT_X+1)(MT_Y+1)(MT_Z+1) nodes of its tile into LDS (1.4 nodes per cell: 2.8 atan2 + 4.2 sqrt per cell instead of
 // 24 + 24); the 12 logs of corner-pair ratios belong to the EDGES of the node lattice (3.7 per cell, evaluated in a second phase).
 // Same operations in the same order as sharmbox_dev -> same bits as k_magprism.  The one cell per observation that may CONTAIN
 // the observation (6 sub-boxes, a different and register-hungry code path) is left at zero here and written by
-// k_magprism_inside_fix afterwards: without it the kernel needs 141 VGPRs instead of 240, and with a tile of 16 x 8 x 6 cells
-// (43 KB of node arrays, a thread owning one (x, y) column of the tile) three workgroups fit a CU.
-constexpr int MT_X = 16, MT_Y = 8, MT_Z = 6;
+// k_magprism_inside_fix afterwards.
+// Tile: 16 x 7 x 6 cells = 17 x 8 x 7 = 952 nodes - FOUR passes of the 256 threads over the nodes, 93 % full (the 16 x 8 x 6 tile of rounds
+// 2-4 had 1071 nodes: five passes, the fifth 16 % full) in 38 KB of node arrays: three workgroups per CU.  The x extent stays 16 cells:
+// a thread row stores 128 contiguous, 128-byte-aligned bytes of an output row (a 15-cell tile, 1008 nodes in four FULL passes, was
+// measured: the magnetisation-vector kernel with nine output rows per observation ran at half speed on its 120-byte segments).
+// What a node keeps for the edge phase is the corner quantity the logs are taken of, r + a (sharmbox's rz2 + a2, rx1 + a1, ...: the
+// sum is the node's own), so an edge is one division and one log of two LDS values.  The edge value replaces the node's in place; the
+// passes walk the nodes in ascending slot order and an edge only reads slots >= its own, so ONE barrier per pass is enough (a pass
+// writes its slots after the barrier that ended its reads; later passes never read them) and three doubles are live per thread
+// (rounds 2-4 held all five passes' fifteen values over one barrier: 168 VGPRs and 4-13 spilled).
+constexpr int MT_X = 16, MT_Y = 7, MT_Z = 6;
+constexpr int MT_TX = 16, MT_TY = 8;                       // thread columns / rows of the cell phase (one row idle when the tile is full)
 constexpr int MT_NODES = (MT_X + 1) * (MT_Y + 1) * (MT_Z + 1);
 template <int NCM, int NCD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_magprism_tensor(int nx, int ny, int nz, const double *__restrict__ xe,
@@ -389,7 +406,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                          double *__restrict__ rows, int *__restrict__ err, double *__restrict__ sumsq)
 {
     constexpr int NSUB = NCM * NCD;
-    __shared__ double Taz[MT_NODES], Tax[MT_NODES], Tay[MT_NODES], TAx[MT_NODES], TAy[MT_NODES];      // 5 x 1071 doubles = 43 KB
+    // Tz / Tx / Ty: r + a of the node (node phase), then the log of the edge that starts at the node (edge phase)
+    __shared__ double Tz[MT_NODES], Tx[MT_NODES], Ty[MT_NODES], TAx[MT_NODES], TAy[MT_NODES];      // 5 x 952 doubles = 38 KB
     __shared__ double s_w[4];
     init_math_tables();                                   // (+ 4 KB; the first __syncthreads() of the observation loop publishes them)
     const double eps = 0.;
@@ -402,9 +420,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int bad = 0;
 #define NODE(a, b, c) (((c) * (MT_Y + 1) + (b)) * (MT_X + 1) + (a))
     // observation-independent index arithmetic, once per workgroup: the node codes (LDS slot | a << 12 | b << 18 | c << 22) in LDS,
-    // the cells of a thread are the column (ta, tb) of the tile in the layers tc0, tc0 + 2, ...
+    // ascending in the slot; the cells of a thread are the column (ta, tb) of the tile in the layers tc0, tc0 + 2, ...
     __shared__ double s_xe[MT_X + 1], s_ye[MT_Y + 1], s_ze[MT_Z + 1];
     constexpr int NPT = (MT_NODES + 255) / 256, DY = MT_X + 1, DZ = (MT_Y + 1) * (MT_X + 1);
+    static_assert(MT_NODES <= 4096 && MT_X + 1 <= 64 && MT_Y + 1 <= 16, "node code fields");
     __shared__ int s_node[MT_NODES];
     for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
         const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
@@ -413,13 +432,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (threadIdx.x <= cx) s_xe[threadIdx.x] = xe[i0 + threadIdx.x];
     if (threadIdx.x <= cy) s_ye[threadIdx.x] = ye[j0 + threadIdx.x];
     if (threadIdx.x <= cz) s_ze[threadIdx.x] = ze[k0 + threadIdx.x];
-    static_assert(MT_X * MT_Y * 2 == 256 && MT_Z % 2 == 0, "two (x, y) planes of threads walk the layers of the tile");
-    constexpr int CPT = MT_Z / 2;
-    const int ta = threadIdx.x % MT_X, tb = (threadIdx.x / MT_X) % MT_Y, tc0 = threadIdx.x / (MT_X * MT_Y);
+    static_assert(MT_TX * MT_TY * 2 == 256 && MT_TX >= MT_X && MT_TY >= MT_Y && MT_Z % 2 == 0, "two (x, y) planes of threads walk the layers of the tile");
+    constexpr int CPT = MT_Z / 2, CELL_UNROLL = NSUB == 3 ? 1 : CPT;
+    const int ta = threadIdx.x % MT_TX, tb = (threadIdx.x / MT_TX) % MT_TY, tc0 = threadIdx.x / (MT_TX * MT_TY);
     const bool col_ok = ta < cx && tb < cy;
     for (int o = 0; o < nobs; ++o) {
         const double xo = xd[o], yo = yd[o], zo = zd[o];
-        __syncthreads();
+        lds_barrier();
+        // node phase
         for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
             const int code = s_node[n];
             const double rx = s_xe[(code >> 12) & 63] - xo + eps, ry = s_ye[(code >> 18) & 15] - yo + eps, rz = s_ze[code >> 22] - zo + eps;       // :336-341
@@ -428,66 +448,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const double ax = sqrt(rxsq + (rysq + rzsq));        // :404-415   a = sqrt(rx^2 + R), R = ry^2 + rz^2
             const double ay = sqrt(rysq + (rxsq + rzsq));        // :424-435   a = sqrt(ry^2 + R), R = rx^2 + rz^2
             const int id = code & 4095;
-            Taz[id] = az; Tax[id] = ax; Tay[id] = ay;
+            Tz[id] = rz + az + eps;                               // the node's operand of ty(1)'s logs, :386-389
+            Tx[id] = rx + ax + eps;                               //                      ty(3)'s,      :419-422
+            Ty[id] = ry + ay + eps;                               //                      tx(3)'s,      :439-442
             TAx[id] = datan2(ry * rz, (rx * az + eps));           // the terms of tx(1), :376-383
             TAy[id] = datan2(rx * rz, (ry * az + eps));           // the terms of ty(2), :392-399
         }
-        __syncthreads();
+        lds_barrier();
         // edge phase: the 12 logs of a cell's tensor are logs of corner-pair ratios along one axis - each belongs to an EDGE of the
-        // node lattice and is shared by the (up to) 4 cells around that edge.  Evaluated once per edge (3.7 logs + divisions per
-        // cell instead of 12), in place: the edge that starts at a node replaces the node's distance (all reads, barrier, writes).
-        {
-            double ez[NPT], ex[NPT], ey[NPT];
-#pragma unroll
-            for (int k = 0; k < NPT; ++k) {
-                const int n = threadIdx.x + 256 * k;
-                const int code = n < nnode ? s_node[n] : -1;
-                ez[k] = ex[k] = ey[k] = 0.0;
-                if (code >= 0) {
-                    const int id = code & 4095, a = (code >> 12) & 63, b = (code >> 18) & 15, c = code >> 22;
-                    if (c < cz) {                                             // ty(1): (rz2 + a(k = 2)) / (rz1 + a(k = 1)), :386-389
-                        const double rz1 = s_ze[c] - zo + eps, rz2 = s_ze[c + 1] - zo + eps;
-                        ez[k] = dlog((rz2 + Taz[id + DZ] + eps) / (rz1 + Taz[id] + eps));
-                    }
-                    if (a < cx) {                                             // ty(3): (rx1 + a(i = 1)) / (rx2 + a(i = 2)), :419-422
-                        const double rx1 = s_xe[a] - xo + eps, rx2 = s_xe[a + 1] - xo + eps;
-                        ex[k] = dlog((rx1 + Tax[id] + eps) / (rx2 + Tax[id + 1] + eps));
-                    }
-                    if (b < cy) {                                             // tx(3): (ry1 + a(j = 1)) / (ry2 + a(j = 2)), :439-442
-                        const double ry1 = s_ye[b] - yo + eps, ry2 = s_ye[b + 1] - yo + eps;
-                        ey[k] = dlog((ry1 + Tay[id] + eps) / (ry2 + Tay[id + DY] + eps));
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);          // one node's three logs at a time: interleaved, the five iterations cost 100 VGPRs more
+        // node lattice and is shared by the (up to) 4 cells around that edge: once per edge, 3.7 logs + divisions per cell instead of 12
+#pragma unroll 1
+        for (int k = 0; k < NPT; ++k) {
+            const int n = threadIdx.x + 256 * k;
+            const int code = n < nnode ? s_node[n] : -1;
+            const int id = code & 4095;
+            double ez = 0.0, ex = 0.0, ey = 0.0;
+            if (code >= 0) {
+                const int a = (code >> 12) & 63, b = (code >> 18) & 15, c = code >> 22;
+                if (c < cz) ez = dlog(Tz[id + DZ] / Tz[id]);              // ty(1): (rz2 + a(k = 2)) / (rz1 + a(k = 1)), :386-389
+                if (a < cx) ex = dlog(Tx[id] / Tx[id + 1]);               // ty(3): (rx1 + a(i = 1)) / (rx2 + a(i = 2)), :419-422
+                if (b < cy) ey = dlog(Ty[id] / Ty[id + DY]);              // tx(3): (ry1 + a(j = 1)) / (ry2 + a(j = 2)), :439-442
             }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < NPT; ++k) {
-                const int n = threadIdx.x + 256 * k;
-                if (n < nnode) {
-                    const int id = s_node[n] & 4095;
-                    Taz[id] = ez[k]; Tax[id] = ex[k]; Tay[id] = ey[k];
-                }
-            }
+            lds_barrier();                    // every read of this pass is done; the passes to come read higher slots only
+            if (code >= 0) { Tz[id] = ez; Tx[id] = ex; Ty[id] = ey; }
         }
-        __syncthreads();
+        lds_barrier();
+        const double *cwo = cw;
+        asm volatile("" : "+s"(cwo));                 // the weights are re-read per observation, not held over the node / edge phases
+        // cell phase.  Nine outputs per cell (magnetisation vector x three data components) go in THREE passes, one data component =
+        // one row of the tensor each: a pass reads the 16-24 LDS operands its row needs and keeps three sums of squares, where one pass
+        // over all nine kept 32 operands x 3 unrolled cells + 9 values + 9 sums live and spilled 13 registers.
+        constexpr int NG = NSUB == 9 ? 3 : 1;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
         double sq[NSUB];
 #pragma unroll
         for (int i = 0; i < NSUB; ++i) sq[i] = 0.0;
-        const double *cwo = cw;
-        asm volatile("" : "+s"(cwo));                 // the weights are re-read per observation, not held over the node / edge phases
         if (col_ok) {
             const int a = ta, b = tb;
             const double x1 = s_xe[a], x2 = s_xe[a + 1], y1 = s_ye[b], y2 = s_ye[b + 1];
             const double rx1 = x1 - xo + eps, rx2 = x2 - xo + eps, ry1 = y1 - yo + eps, ry2 = y2 - yo + eps;
-#pragma unroll
+            // (one cell at a time with three outputs per cell: three cells' 32 LDS operands each in flight spilled registers)
+#pragma unroll CELL_UNROLL
             for (int j = 0; j < CPT; ++j) {
                 const int c = tc0 + 2 * j;
                 if (c >= cz) break;
                 const double z1 = s_ze[c], z2 = s_ze[c + 1];
                 double tx[3], ty[3], tz[3];
                 const bool inside = x1 < xo && x2 > xo && y1 < yo && y2 > yo && z1 < zo && z2 > zo;       // :139-141: k_magprism_inside_fix writes this cell
-                if (!inside) {
+                if (!inside && g == 0) {
                     if (rx1 == 0. || rx2 == 0.) bad |= 4;
                     if (ry1 == 0. || ry2 == 0.) bad |= 8;
                 }
@@ -495,11 +504,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #define C_(T, i, j, k) T[NODE(a + (i) - 1, b + (j) - 1, c + (k) - 1)]
                 tx[0] = C_(TAx, 2, 1, 2) - C_(TAx, 2, 2, 2) + C_(TAx, 2, 2, 1) - C_(TAx, 2, 1, 1) + C_(TAx, 1, 2, 2) - C_(TAx, 1, 1, 2) +
                         C_(TAx, 1, 1, 1) - C_(TAx, 1, 2, 1);                                                                  // :376-383
-                ty[0] = C_(Taz, 2, 2, 1) - C_(Taz, 1, 2, 1) + C_(Taz, 1, 1, 1) - C_(Taz, 2, 1, 1);                                // z edges, :386-389
+                ty[0] = C_(Tz, 2, 2, 1) - C_(Tz, 1, 2, 1) + C_(Tz, 1, 1, 1) - C_(Tz, 2, 1, 1);                                    // z edges, :386-389
                 ty[1] = C_(TAy, 1, 2, 2) - C_(TAy, 2, 2, 2) + C_(TAy, 2, 2, 1) - C_(TAy, 1, 2, 1) + C_(TAy, 2, 1, 2) - C_(TAy, 1, 1, 2) +
                         C_(TAy, 1, 1, 1) - C_(TAy, 2, 1, 1);                                                                  // :392-399
-                ty[2] = C_(Tax, 1, 2, 1) - C_(Tax, 1, 2, 2) + C_(Tax, 1, 1, 2) - C_(Tax, 1, 1, 1);                                // x edges, :419-422
-                tx[2] = C_(Tay, 2, 1, 1) - C_(Tay, 2, 1, 2) + C_(Tay, 1, 1, 2) - C_(Tay, 1, 1, 1);                                // y edges, :439-442
+                ty[2] = C_(Tx, 1, 2, 1) - C_(Tx, 1, 2, 2) + C_(Tx, 1, 1, 2) - C_(Tx, 1, 1, 1);                                    // x edges, :419-422
+                tx[2] = C_(Ty, 2, 1, 1) - C_(Ty, 2, 1, 2) + C_(Ty, 1, 1, 2) - C_(Ty, 1, 1, 1);                                    // y edges, :439-442
 #undef C_
                 tz[2] = -1 * (tx[0] + ty[1]);                                                                                 // :446
                 tz[1] = ty[2];
@@ -513,6 +522,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 for (int d = 0; d < NCD; ++d)
 #pragma unroll
                     for (int k = 0; k < NCM; ++k) {
+                        if (NG > 1 && d != g) continue;      // (this pass's tensor row; what the other rows need is dead code here)
                         double v = out[d][k];
                         if (cw) v = v * w;
                         if (inside) v = 0.0;
@@ -525,14 +535,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (sumsq) {                                        // cost_full (sensitivity_gravmag.F90:234), fixed order
 #pragma unroll
             for (int i = 0; i < NSUB; ++i) {
+                if (NG > 1 && i / NCM != g) continue;
                 double t = sq[i];
 #pragma unroll
                 for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_down(t, dd);
-                __syncthreads();
+                lds_barrier();
                 if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
-                __syncthreads();
+                lds_barrier();
                 if (threadIdx.x == 0) sumsq[(int64_t)(o * NSUB + i) * gridDim.x + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
             }
+        }
         }
     }
 #undef NODE
@@ -733,7 +745,7 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
     }
     for (int o = 0; o < nobs; ++o) {
         const double xo = xd[o], yo = yd[o], zo = zd[o];
-        __syncthreads();
+        lds_barrier();
         for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
             const int code = s_node[n];
             const double XX = xo - s_xe[(code >> 12) & 63], YY = yo - s_ye[(code >> 18) & 15], ZZ = -(zo - s_ze[code >> 22]);   // gravity_field.f90:232-237
@@ -762,7 +774,7 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
                 T[0][id] = vzz;
             }
         }
-        __syncthreads();
+        lds_barrier();
         double sq[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) sq[i] = 0.0;
@@ -795,9 +807,9 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
                 double t = sq[i];
 #pragma unroll
                 for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_down(t, dd);
-                __syncthreads();
+                lds_barrier();
                 if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
-                __syncthreads();
+                lds_barrier();
                 if (threadIdx.x == 0) sumsq[(int64_t)(o * NC + i) * gridDim.x + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
             }
         }

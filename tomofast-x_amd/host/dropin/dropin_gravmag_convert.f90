@@ -1,5 +1,5 @@
 !=========================================================================================================
-! Helper of the drop-in modules (oracle/dropin_build.sh): the reference's own parameter / grid / data objects (its modules
+! Helper of the drop-in modules (build recipe: INTEGRATION.md 0): the reference's own parameter / grid / data objects (its modules
 ! parameters_gravmag, parameters_grav, parameters_mag, grid, data_gravmag - compiled unmodified) -> the plain copies the C-ABI
 ! layer tfx_reference_api works on.  Field by field, so the compiler checks every name against the reference's definitions
 ! (parameters_gravmag.f90:30-108, parameters_mag.f90:30-48, grid.F90:30-50, data_gravmag.f90:30-52).  The repository's own code.

@@ -1,5 +1,5 @@
 !=========================================================================================================
-! DROP-IN module `lsqr_solver` for the UNMODIFIED Tomofast-x sources (oracle/dropin_build.sh).
+! DROP-IN module `lsqr_solver` for the UNMODIFIED Tomofast-x sources (build recipe: INTEGRATION.md 0).
 ! Replaces src/inversion/lsqr_solver2.F90: lsqr_solve_sensit (:47-63) and lsqr_solve (:321-329) with the reference's argument lists;
 ! the solve runs on the GPU (tfx_lsqr_solve of libtfx.so through tfx_reference_api's lsqr_solve_sensit).  The repository's own code.
 !

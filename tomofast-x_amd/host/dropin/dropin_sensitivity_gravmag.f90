@@ -1,5 +1,5 @@
 !=========================================================================================================
-! DROP-IN module `sensitivity_gravmag` for the UNMODIFIED Tomofast-x sources (oracle/dropin_build.sh).
+! DROP-IN module `sensitivity_gravmag` for the UNMODIFIED Tomofast-x sources (build recipe: INTEGRATION.md 0).
 ! Replaces src/forward/gravmag/sensitivity_gravmag.F90 (and with it gravity_field.f90 / magnetic_field.f90, which only it uses):
 ! the six public procedures (:44-49) with the reference's argument lists over the reference's own types.  The kernel is calculated,
 ! wavelet-transformed, thresholded and compacted on the GPU (tfx_build_kernel of libtfx.so) and STAYS there; the SENSIT files are

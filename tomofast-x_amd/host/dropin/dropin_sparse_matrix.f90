@@ -1,5 +1,5 @@
 !=========================================================================================================
-! DROP-IN module `sparse_matrix` for the UNMODIFIED Tomofast-x sources (build recipe: oracle/dropin_build.sh).
+! DROP-IN module `sparse_matrix` for the UNMODIFIED Tomofast-x sources (build recipe: INTEGRATION.md 0).
 !
 ! Replaces src/inversion/sparse_matrix.f90 of the reference: same module name, same public type t_sparse_matrix, same
 ! type-bound procedures with the same argument lists (sparse_matrix.f90:72-98), so that the reference's own

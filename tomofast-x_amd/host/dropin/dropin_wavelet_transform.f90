@@ -1,5 +1,5 @@
 !=========================================================================================================
-! DROP-IN module `wavelet_transform` for the UNMODIFIED Tomofast-x sources (oracle/dropin_build.sh).
+! DROP-IN module `wavelet_transform` for the UNMODIFIED Tomofast-x sources (build recipe: INTEGRATION.md 0).
 ! Replaces src/utils/wavelet_transform.F90: same public names and argument lists (:23-30, :37-39, :56-58, :75-77, :158-160,
 ! :243-245, :374-376); every transform is tfx_wavelet of libtfx.so (HIP kernel k_wavelet_axis), in place, bit-identical to the
 ! reference's lifting scheme (tests/test_gpu_parity.py::test_wavelets_bit_exact_*).  The repository's own code.

@@ -1,5 +1,5 @@
 !=========================================================================================================
-! DROP-IN module `weights_gravmag` for the UNMODIFIED Tomofast-x sources (oracle/dropin_build.sh).
+! DROP-IN module `weights_gravmag` for the UNMODIFIED Tomofast-x sources (build recipe: INTEGRATION.md 0).
 ! Replaces src/forward/gravmag/weights_gravmag.f90: calculate_depth_weight (:46-196; types 1, 2, 3 on the GPU: k_depth_weight,
 ! k_distance_weight, k_mindist_weight of libtfx.so) and apply_local_depth_weighting (:255-310; a file read and a division per cell:
 ! host control plane, restated here because it lives in the replaced module).  Same argument lists.  The repository's own code.

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libtfx.so")
+SO_PATH = os.environ.get("TFX_LIBTFX") or os.path.join(HERE, "libtfx.so")      # (TFX_LIBTFX: another build of the same library, for A/B measurements by tools/)
 
 c_dp = C.POINTER(C.c_double)
 c_fp = C.POINTER(C.c_float)
