@@ -25,8 +25,8 @@ def test_fastmath_host_accuracy(tmp_path):
     # log: error against 1 ulp of max(|log x|, 1) (the kernels multiply it by a coordinate: its absolute error is what counts);
     # atan2: ulps of the result; the largest ones sit at results near 1/128 (table node 1 minus a correction of half its size)
     assert log_ulp <= 0.6
-    assert atan_ulp <= 1.7
-    assert atan_abs <= 1.1
+    assert atan_ulp <= 1.2          # (rounds 2-4: 1.57 - two reflections with a rounding each and an uncompensated denominator)
+    assert atan_abs <= 0.55
     assert bad == 0
 
 

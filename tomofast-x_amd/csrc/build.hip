@@ -35,7 +35,7 @@ __device__ __forceinline__ void init_math_tables()
 {
     double *lds = const_cast<double *>(math_tables().logt);
     for (int i = threadIdx.x; i < 3 * TFX_LOG_TAB_N; i += blockDim.x) lds[i] = tfx_log_tab[i];
-    for (int i = threadIdx.x; i < 2 * TFX_ATAN_TAB_N; i += blockDim.x) lds[3 * TFX_LOG_TAB_N + i] = tfx_atan_tab[i];
+    for (int i = threadIdx.x; i < 8 * TFX_ATAN_TAB_N; i += blockDim.x) lds[3 * TFX_LOG_TAB_N + i] = tfx_atan_tab[i];
 }
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also makes the workgroup's GLOBAL stores visible, i.e. it waits for
 // every outstanding store (s_waitcnt vmcnt(0)): in the row generators that drained the non-temporal stores of an observation's rows -

@@ -6,12 +6,13 @@
 //
 //   log x    x = 2^e m, m in [1, 2); i = top 7 mantissa bits; r = fma(m, c_i, -1) with c_i ~ 1 / (1 + (i + 1/2) / 128), |r| <= 2^-8;
 //            log x = e ln2 + (-log c_i) + log1p(r), log1p by a degree-7 Taylor polynomial (truncation < 2^-67).
-//   atan2    t = min(|y|, |x|) / max(|y|, |x|) is never formed: with t_i = i / 64 the nearest node to a float estimate of t,
-//            u = (mn - t_i mx) / (mx + t_i mn) (one division by Newton iterations on v_rcp_f64), |u| < 2^-6.9;
-//            atan t = atan(t_i) + u - u^3/3 + u^5/5 - u^7/7 + u^9/9, then the quadrant of (y, x).
+//   atan2    t = min(|y|, |x|) / max(|y|, |x|) is never formed: with t_i = i / 64 the node below a float estimate of t,
+//            u = (mn - t_i mx) / (mx + t_i mn) (one division by Newton iterations on v_rcp_f64), |u| < 2^-6;
+//            atan t = atan(t_i) + u - u^3/3 + u^5/5 - u^7/7 + u^9/9; the octant of (y, x) picks one of four tabulated constants
+//            (atan(t_i), pi/2 -+ atan(t_i), pi - atan(t_i) as hi + lo) so that no reflection rounds.
 //
 // Accuracy (tests/test_fastmath.py, host build of this header against the host libm on 1e7 random arguments of the prism
-// kernels' ranges): log <= 1.0 ulp of max(|result|, 1 ulp at 1), atan2 <= 1.0 ulp - the class of the device libm they replace
+// kernels' ranges): log <= 0.51 ulp of max(|result|, 1 ulp at 1), atan2 <= 1.14 ulp of the result (0.52 ulp of pi/4) - the device libm they replace:
 // (<= 1-2 ulp); arguments outside the fast range (zero, denormal, inf, nan, |.| beyond 1e+-30 for atan2) take the libm call.
 // tables: math_tables.h (tools/gen_math_tables.py), copied into LDS by the kernels (`FastMathTables`).
 #pragma once
@@ -32,9 +33,9 @@ namespace tfx {
 
 struct FastMathTables {
     const double *logt;    // 3 * TFX_LOG_TAB_N: c_i, -log(c_i) as hi + lo
-    const double *atant;   // 2 * TFX_ATAN_TAB_N: atan(i / 64) as hi + lo
+    const double *atant;   // 8 * TFX_ATAN_TAB_N: the octant-pair constant of node i = i / 64 as hi + lo, four cases (math_tables.h)
 };
-constexpr int FASTMATH_TABLE_DOUBLES = 3 * TFX_LOG_TAB_N + 2 * TFX_ATAN_TAB_N;
+constexpr int FASTMATH_TABLE_DOUBLES = 3 * TFX_LOG_TAB_N + 8 * TFX_ATAN_TAB_N;
 
 TFX_HD uint64_t fm_bits(double x)
 {
@@ -107,20 +108,31 @@ TFX_HD double fast_atan2(double y, double x, const FastMathTables &tb)
 #else
     const float tq = (float)mn / (float)mx;
 #endif
-    int i = (int)std::rint(tq * 64.0f);
+    // the node BELOW t (not the nearest): q >= 0, so the small results next to a node (t ~ 1/128 against node 1/64) are not the
+    // difference of two numbers twice their size - the last addition rounds in ulps of the result (|u| < 2^-6: u^11 / 11 < 2^-69)
+    int i = (int)(tq * 64.0f);
     i = i < 0 ? 0 : (i > 64 ? 64 : i);
     const double ti = (double)i * 0.015625;
     const double num = std::fma(-ti, mx, mn), den = std::fma(ti, mn, mx);
+    // den + den_lo = mx + ti mn exactly (mx - den is exact: den lies in [mx, 2 mx]); the quotient is corrected against the exact
+    // denominator, so u carries the rounding of num (none when mn - ti mx cancels) and of the last fma only
+    const double den_lo = std::fma(ti, mn, mx - den);
     const double rd = fm_rcp(den);
     double u = num * rd;
-    u = std::fma(std::fma(-den, u, num), rd, u);
+    u = std::fma(std::fma(-den_lo, u, std::fma(-den, u, num)), rd, u);
     const double u2 = u * u;
     double p = std::fma(u2, 1.0 / 9.0, -1.0 / 7.0);
     p = std::fma(u2, p, 1.0 / 5.0);
     p = std::fma(u2, p, -1.0 / 3.0);
-    double r = tb.atant[2 * i] + (std::fma(u * u2, p, u) + tb.atant[2 * i + 1]);
-    if (a > bb) r = TFX_PI_2 - r;
-    if (fm_bits(x) >> 63) r = TFX_PI - r;
+    // atan(mn / mx) = atan(t_i) + q, q = u - u^3/3 + ...; the octant of (y, x) selects the constant q is added to or subtracted from
+    // (atan(t_i), pi/2 - atan(t_i), pi/2 + atan(t_i), pi - atan(t_i), each as hi + lo): the reflections of rounds 2-4
+    // (pi/2 - r, pi - r) cost a rounding each - up to 1.6 ulp - this form has ONE rounding that counts, the last addition
+    const bool swap = a > bb, xneg = (fm_bits(x) >> 63) != 0;
+    const int k = xneg ? (swap ? 2 : 3) : (swap ? 1 : 0);
+    double q = std::fma(u * u2, p, u);
+    if (k & 1) q = -q;
+    const double *c = tb.atant + 2 * (k * TFX_ATAN_TAB_N + i);
+    const double r = c[0] + (q + c[1]);
     return (fm_bits(y) >> 63) ? -r : r;
 }
 
