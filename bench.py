@@ -129,11 +129,25 @@ def main():
     # (TFX_ADJ_COPY=0/1/2 is read by the library itself: transposed copy of the tiles for the adjoint product - never / always / when it fits)
     info = ctx.device_info()
     log("device %s, %d CUs, %.0f GB; workload %s" % (info["name"], info["cus"], info["hbm_bytes"] / 1e9, w["desc"]))
+    # ---- the memory plan of one rank, BEFORE anything large is allocated: what the build, the relayout, the transposed copy and the
+    # solve will need per phase (tomofast-x_amd/distributed.py::memory_plan); a run that can not fit stops here with the numbers
+    # instead of dying inside a hipMalloc on one rank while the others wait in a collective
+    adj_copy_env = os.environ.get("TFX_ADJ_COPY", "2")
+    plan = tfx.distributed.memory_plan(N, D, w["rate"], world, nkernels=2 if w.get("joint") else 1, dense=w["ctype"] == 0,
+                                       adjoint_copy=adj_copy_env != "0", hbm_bytes=info["hbm_bytes"],
+                                       exchange=os.environ.get("TFX_BUILD_MODE", "exchange") == "exchange")
+    log("memory plan per rank (x%d): %s GB per phase, peak %.1f of %.1f GB%s" %
+        (world, json.dumps(plan["phases_GB"]), plan["peak_GB"], plan["hbm_GB"],
+         "" if plan["adjoint_copy_fits"] or w["ctype"] == 0 or adj_copy_env == "0" else
+         " (WITHOUT the transposed copy: with it %.1f GB - the adjoint will run on the tiles of S)" % plan["peak_with_adjoint_copy_GB"]))
+    if not plan["fits"]:
+        sys.exit("bench.py: %s does not fit %d x %.0f GB (peak %.1f GB per rank even without the transposed copy): use more GPUs" %
+                 (args.workload, world, plan["hbm_GB"], plan["peak_GB"]))
     ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
     if w.get("joint"):
         if world > 1:
             sys.exit("the joint workloads run on one GPU")
-        return bench_joint(args, w, ctx, tfx, log)
+        return bench_joint(args, w, ctx, tfx, log, plan)
     cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
     # collectives: an RCCL communicator inside libtfx.so (nccl launch) - the library queues its reductions on its own stream;
     # the gloo rehearsal uses the torch.distributed hooks
@@ -180,6 +194,8 @@ def main():
     t_copy = comm.max_over_ranks(t_copy) if world > 1 else t_copy
     t_build = max(t_build_total - t_copy, 1e-9)
     minfo = ctx.matrix_info()
+    free_b, total_b = torch.cuda.mem_get_info(local_rank)
+    used_after_build = total_b - free_b                   # (matrix + copy + grid + whatever the allocator keeps: compare with the plan's `solve`)
     nnz_total = part["nnz_total"]
     if os.environ.get("TFX_CHUNK_SPAN"):         # diagnostics: value-exponent span of the stored chunks (printed by the library)
         log("chunks within %s binades: %d per mille" % (os.environ["TFX_CHUNK_SPAN"], ctx.debug_set("chunk_exponent_span", int(os.environ["TFX_CHUNK_SPAN"]))))
@@ -325,7 +341,8 @@ def main():
             "lsqr_bytes_per_iteration_csr_equivalent": 16 * int(nnz_total) + 112 * N + 48 * (D + N),
             "lsqr_bytes_per_iteration_stored": stored_iter,
             "lsqr_stored_GBs": None if stored_iter is None else round(stored_iter / (ms_per_step * 1e-3) / 1e9, 1),
-            "comm": comm.report,
+            "comm": comm.report, "memory_plan": plan,
+            "device_memory_used_after_build_GB": round(used_after_build / 1e9, 2),
             "per_rank": [{"rank": r, "spmv_fwd_ms": round(float(v[0]), 4), "spmv_adj_ms": round(float(v[1]), 4),
                           "allreduce_ms": round(float(v[2]), 4), "allreduces_timed": int(v[3]), "nnz": int(v[4]),
                           "ms_per_step_wall": round(float(v[5]), 4), "ms_per_step_hip_events": round(float(v[6]), 4)}
@@ -358,7 +375,7 @@ def self_launch(nproc):
     sys.exit(subprocess.call(cmd))
 
 
-def bench_joint(args, w, ctx, tfx, log):
+def bench_joint(args, w, ctx, tfx, log, plan=None):
     """BASELINE configs[3]: two sensitivity kernels (gravity g_z and magnetic TMI) on one grid inside one LSQR - S = blockdiag(S_grav,
     S_mag), unknowns [m_grav ; m_mag], one damping block spanning both (joint_inverse_problem.F90:547-554, :712-739).  A step is one
     LSQR iteration of the joint system: two launches per product.  Oracle-free properties here (entry counts, adjoint identity,
@@ -429,7 +446,7 @@ def bench_joint(args, w, ctx, tfx, log):
            "roofline": {"bound": "hbm", "kernel": ["k_spmv_fwd", "k_spmv_adj"][dom] + " (the two kernels' launches of one product)",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                         "algorithmic_bytes_per_launch": int(alg_bytes), "ms_per_iteration": {"spmv_fwd": round(per_it[0], 4), "spmv_adj": round(per_it[1], 4)}},
-           "cpu_baseline": None}
+           "memory_plan": plan, "cpu_baseline": None}
     print(json.dumps(out))
     sys.stdout.flush()
     ctx.close()

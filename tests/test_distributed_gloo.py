@@ -215,3 +215,34 @@ def test_startup_ladder_moves_all_ranks_to_the_hooks_together(scenario):
         assert ("scripted ncclCommInitRank failure" in ladder[0][1]["why"]) == (scenario == "one_rank_fails")
         assert ("timed out" in ladder[0][1]["why"]) == (scenario == "one_rank_hangs")
         assert all("abort" in r[3] for r in res)                    # also the rank whose own call succeeded drops its communicator
+
+
+def test_memory_plan_of_the_baseline_configurations():
+    """tomofast-x_amd/distributed.py::memory_plan (what bench.py prints and checks before it allocates): BASELINE config 5 on 8 GPUs
+    and config 4 (two kernels) on 4 GPUs fit a 288 GB MI355X with the transposed copies; the headline on ONE GPU fits with its copy
+    (measured: 230 GB resident); config 3 and config 4 on one GPU fit only without the copy (what the automatic mode does there);
+    a run that can not fit is refused."""
+    tfx = importlib.import_module("tomofast-x_amd")
+    mp = tfx.distributed.memory_plan
+    c5 = dict(ncells=256 * 256 * 152, ndata=316 * 316, compression_rate=0.02)
+    c4 = dict(ncells=512 * 512 * 128, ndata=256 * 256, compression_rate=0.01)
+    peaks = []
+    for P in (1, 2, 4, 8):
+        r = mp(nranks=P, **c5)
+        assert r["fits"] and r["adjoint_copy_fits"], r
+        peaks.append(r["peak_GB"])
+        if P > 1:
+            assert set(r["phases_GB"]) == {"build", "relayout", "adjoint_copy", "solve"}
+            assert r["bytes"]["row_store"] == -(-99856 // P) * int(0.02 * 9961472) * 8
+    assert peaks == sorted(peaks, reverse=True) and peaks[-1] < 70.0             # 8 GPUs: a fifth of the device
+    assert 225.0 <= mp(nranks=1, **c5)["phases_GB"]["solve"] <= 260.0             # one GPU, both copies resident (measured 230 GB)
+    r = mp(nranks=4, nkernels=2, **c4)
+    assert r["fits"] and r["adjoint_copy_fits"] and r["peak_GB"] < 220.0, r
+    assert "relayout_kernel2" in r["phases_GB"]
+    r = mp(nranks=1, **c4)                                                        # config 3
+    assert r["fits"] and not r["adjoint_copy_fits"] and r["peak_with_adjoint_copy_GB"] > 0.97 * 288.0
+    r = mp(nranks=1, nkernels=2, **c4)                                            # config 4 on one GPU: ran in round 3 (256 GB resident)
+    assert r["fits"] and not r["adjoint_copy_fits"] and 250.0 < r["peak_GB"] < 279.5
+    assert not mp(nranks=1, nkernels=2, ncells=512 * 512 * 128, ndata=256 * 256, compression_rate=0.02)["fits"]
+    r = mp(nranks=1, dense=True, ncells=256 * 256 * 64, ndata=4096, compression_rate=1.0)     # config 2
+    assert r["fits"] and 68.0 < r["phases_GB"]["solve"] < 75.0

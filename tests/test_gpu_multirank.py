@@ -494,3 +494,85 @@ def test_spatial_unknowns_two_ranks():
         p.join(60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def test_one_rank_of_2_4_8_at_the_headline_size_stays_inside_its_memory_plan():
+    """What ONE rank of a P-GPU run of BASELINE config 5 (9.96e6 cells x 99 856 data, D4 r = 0.02) holds, built at FULL size on the one
+    GPU of this box: its row store (its ndata / P data x all columns, the row-parallel half of the build), then - the row store still
+    resident, as during the relayout - the tiles of its column range with their transposed copy, then the solve state.  A sampler
+    thread reads the device's used memory every 20 ms; every phase must stay inside tomofast-x_amd/distributed.py::memory_plan (what
+    bench.py --gpus P checks before it allocates) and the plan must not be loose by more than a third."""
+    import threading
+    import time
+    import torch
+    tfx = importlib.import_module("tomofast-x_amd")
+    nx, ny, nz, ox, oy, ctype, rate = 256, 256, 152, 316, 316, 2, 0.02
+    N = nx * ny * nz
+    xs, ys, zs = tfx.synthetic.observations(nx, ny, ox, oy)
+    D = xs.size
+    ctx = tfx.Context(0)
+    hbm = ctx.device_info()["hbm_bytes"]
+
+    def used():
+        free_b, total_b = torch.cuda.mem_get_info(0)
+        return total_b - free_b
+
+    class Peak:
+        def __enter__(self):
+            self.peak, self.stop = used(), False
+            self.t = threading.Thread(target=self.run, daemon=True)
+            self.t.start()
+            return self
+
+        def run(self):
+            while not self.stop:
+                self.peak = max(self.peak, used())
+                time.sleep(0.02)
+
+        def __exit__(self, *a):
+            self.stop = True
+            self.t.join()
+            self.peak = max(self.peak, used())
+
+    try:
+        base = used()
+        ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
+        cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+        for P in (8, 4, 2):
+            plan = tfx.distributed.memory_plan(N, D, rate, P, hbm_bytes=hbm)
+            assert plan["fits"] and plan["adjoint_copy_fits"]
+            ph = {k: v * 1e9 for k, v in plan["phases_GB"].items()}
+            dstart = tfx.distributed.data_row_partition(D, P)
+            r0, r1 = int(dstart[0]), int(dstart[1])
+            with Peak() as pk:
+                res = ctx.rowstore_build(xs[r0:r1], ys[r0:r1], zs[r0:r1], cw, ctype, rate, 1.0, None, None)
+            peak_build = pk.peak - base
+            hist = res["nnz_hist"].astype(np.int32)               # this rank's rows: a fair stand-in for the all-rows histogram's balance
+            nel, nnz = tfx.sensitivity.get_load_balancing_nelements(hist, P)
+            c0, c1 = 0, int(nel[0])
+            with Peak() as pk:
+                got = ctx.calculate_sensit(xs, ys, zs, cw, ctype, rate, col_range=(c0, c1))
+            peak_share = pk.peak - base
+            assert ctx.matrix_format()["adjoint_copy"]
+            resident = used() - base                              # row store + share + copy
+            ctx.rowstore_free()
+            ncl = c1 - c0
+            ctx.lsqr_begin(np.ones(D), 1e-300, 0.0, 0.0, [np.full(ncl, np.float32(1e-7), np.float32)], [np.zeros(ncl)])
+            ctx.lsqr_iterate(2)
+            solve = used() - base
+            ctx.lsqr_end()
+            ctx.matrix_free()
+            share_frac = got["nnz"] / (float(D) * int(rate * N))
+            print("P = %d, one rank at full size: row store phase %.1f GB (plan %.1f), share + copy built beside it %.1f GB (plan: relayout %.1f, "
+                  "adjoint copy %.1f), resident with the row store %.1f GB, solve %.1f GB (plan %.1f); share of the entries %.4f (1 / P = %.4f)" %
+                  (P, peak_build / 1e9, ph["build"] / 1e9, peak_share / 1e9, ph["relayout"] / 1e9, ph["adjoint_copy"] / 1e9, resident / 1e9,
+                   solve / 1e9, ph["solve"] / 1e9, share_frac, 1.0 / P))
+            assert abs(share_frac - 1.0 / P) <= 0.02 / P
+            assert peak_build <= ph["build"], (peak_build, ph["build"])
+            # (this emulation builds the share with the direct kernel build beside the row store: its work buffers stand where the relayout's
+            # receive / send buffers would - both are in the plan)
+            assert peak_share <= max(ph["relayout"], ph["adjoint_copy"]) + plan["bytes"]["build_work"], (peak_share, ph)
+            assert resident <= ph["adjoint_copy"] and solve <= ph["solve"], (resident, solve, ph)
+            assert solve >= 0.66 * ph["solve"] and peak_build >= 0.5 * ph["build"], (solve, peak_build, ph)
+    finally:
+        ctx.close()

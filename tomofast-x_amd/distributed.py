@@ -432,6 +432,68 @@ def _p2p(tensors_to_send, recv_specs, backend):
             item[0].copy_(item[1])
 
 
+HBM_BYTES_MI355X = 288 * 10 ** 9        # what a plan is checked against when no device is at hand (the tests on CPU)
+
+
+def memory_plan(ncells, ndata, compression_rate, nranks, nkernels=1, ndata_components=1, nmodel_components=1, dense=False,
+                adjoint_copy=True, hbm_bytes=HBM_BYTES_MI355X, exchange=True):
+    """Device memory ONE rank of an `nranks`-GPU run needs, phase by phase, BEFORE anything is allocated (bench.py prints it and refuses
+    to start a run whose plan does not fit; tests/test_gpu_multirank.py builds one rank's share at full size and checks the measured peak
+    against it).  Upper bounds in bytes, from the sizes the library allocates (csrc/build.hip, csrc/matrix.hip):
+      grid          six coordinate arrays + the column weight + the per-column histogram                         60 B per cell
+      build_work    three line buffers of <= 32 lines / 2 GiB (generator, wavelet, statistics in flight), the two candidate
+                    buffers of the full radix select (the band select's fallback), one row block in ELL form (2048 rows x K x 8 B)
+      row_store     (row-parallel build) this rank's ndata / nranks data x all columns: K entries x 8 B per line, until the relayout is done
+      share         the tiles of this rank's column range: 5.625 B per stored entry + 3 % for padding, row markers and the chunk table
+      relayout      per row block the received pieces and the packed pieces to send: <= 2 x 2048 rows x K x 8 B
+      copy          the transposed copy of the share (the adjoint as the forward kernel) + the scratch of one panel of its build
+      lsqr          u (replicated), v, w, x, damping rows and right-hand side of the local columns
+    `peak` is the largest phase; joint inversions (nkernels = 2) keep the first kernel's share + copy while the second is built."""
+    N, D, P = int(ncells), int(ndata), int(nranks)
+    ncd, ncm = int(ndata_components), int(nmodel_components)
+    nlines = D * ncd
+    K = N if dense else max(1, int(compression_rate * N))
+    nnz_kernel = float(nlines) * K * ncm
+    grid = 60 * N
+    lines = max(1, min(32, (1 << 31) // (8 * N)))
+    build_work = (1 if dense else 5) * lines * N * 8 + (0 if dense else (2048 + ncd) * K * ncm * 8) + (64 << 20)
+    rows_loc = -(-D // P) * ncd
+    row_store = rows_loc * K * ncm * 8 if (exchange and P > 1 and not dense) else 0
+    share = (4.0 * nnz_kernel / P) if dense else (5.625 * 1.03 * nnz_kernel / P + (64 << 20))
+    relayout = 2 * 2048 * K * ncm * 8 if row_store else 0
+    ncl = -(-N // P) * ncm
+    lsqr = 8 * (3 * (nlines * nkernels + 1) + nkernels * ncl * 8) + (32 << 20)
+    runtime = 1.5e9                     # HIP / RCCL context, kernel code, the allocator's slack
+
+    def phases_with(copy):
+        scratch = 0 if not copy else min(16e9, 0.2 * share + 1e8)
+        resident, ph = 0.0, {}          # resident: kernels finished earlier (joint inversion)
+        for k in range(nkernels):
+            tag = "" if nkernels == 1 else "_kernel%d" % (k + 1)
+            ph["build" + tag] = grid + runtime + resident + build_work + row_store + (0 if row_store else share + copy)
+            if row_store:
+                ph["relayout" + tag] = grid + runtime + resident + row_store + share + copy + relayout
+            if copy:
+                ph["adjoint_copy" + tag] = grid + runtime + resident + row_store + share + copy + scratch
+            resident += share + copy
+        ph["solve"] = grid + runtime + resident + lsqr
+        return ph
+
+    copy = 0 if (dense or not adjoint_copy) else 1.08 * share
+    with_copy, without = phases_with(copy), phases_with(0)
+    limit = 0.97 * hbm_bytes
+    copy_fits = bool(copy) and max(with_copy.values()) <= limit
+    chosen = with_copy if copy_fits else without
+    return {"ranks": P, "cells": N, "data": D, "kernels": nkernels, "entries_per_line": K, "nnz_per_kernel": nnz_kernel,
+            "bytes": {"grid": grid, "build_work": build_work, "row_store": row_store, "share": share, "relayout": relayout, "copy": copy,
+                      "lsqr": lsqr, "runtime": runtime},
+            # the transposed copy is optional (automatic mode gives it up when it does not fit: the adjoint then runs on the tiles of S)
+            "adjoint_copy_fits": copy_fits,
+            "phases_GB": {k: round(v / 1e9, 2) for k, v in chosen.items()}, "peak_GB": round(max(chosen.values()) / 1e9, 2),
+            "peak_with_adjoint_copy_GB": round(max(with_copy.values()) / 1e9, 2) if copy else None,
+            "hbm_GB": round(hbm_bytes / 1e9, 1), "fits": bool(max(without.values()) <= limit)}
+
+
 def build_partitioned_exchange(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate,
                                problem_weight=1.0, data_weight=None, mag_field=None, get_partition=None, device_index=0,
                                nmodel_components=1, comm=None, data_type=1, ndata_components=1):
