@@ -170,6 +170,12 @@ int tfx_build_kernel_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const do
                          int64_t col_begin, int64_t col_end, int64_t *nnz_out, double *error_sum_out,
                          int32_t *nnz_hist_out);
 
+/* Storage bound of the NEXT tfx_build_kernel* into the selected slot: at most nnz_upper entries will be kept (0 = no bound given: rows x K,
+ * K = int(rate * N), sensitivity_gravmag.F90:64-77).  For a build restricted to a column range [col_begin, col_end) whose entry count is
+ * known from a counting pass (the sum of nnz_hist over the range - what a rank of the column-partitioned system holds): without it the
+ * range is given the storage of the whole kernel.  A build that finds more entries than reserved fails ("capacity exceeded").        */
+int tfx_matrix_reserve(tfx_ctx *ctx, int64_t nnz_upper);
+
 /* General form: any data type / component counts the reference's build loop handles (:193-311).  The matrix has
  * ndata*ndata_components rows (row = idata*ndata_components + d, like read_sensitivity_kernel's new_row per (i, d), :855)
  * and nmodel_components*(col_end - col_begin) columns: model component k occupies columns

@@ -550,6 +550,8 @@ def test_one_rank_of_2_4_8_at_the_headline_size_stays_inside_its_memory_plan():
             hist = res["nnz_hist"].astype(np.int32)               # this rank's rows: a fair stand-in for the all-rows histogram's balance
             nel, nnz = tfx.sensitivity.get_load_balancing_nelements(hist, P)
             c0, c1 = 0, int(nel[0])
+            # (the rank knows from the all-reduced histogram what its columns hold; here: its own rows' count scaled to all rows)
+            ctx.matrix_reserve(int(1.03 * P * int(hist[c0:c1].astype(np.int64).sum())) + D)
             with Peak() as pk:
                 got = ctx.calculate_sensit(xs, ys, zs, cw, ctype, rate, col_range=(c0, c1))
             peak_share = pk.peak - base
@@ -569,10 +571,13 @@ def test_one_rank_of_2_4_8_at_the_headline_size_stays_inside_its_memory_plan():
                    solve / 1e9, ph["solve"] / 1e9, share_frac, 1.0 / P))
             assert abs(share_frac - 1.0 / P) <= 0.02 / P
             assert peak_build <= ph["build"], (peak_build, ph["build"])
-            # (this emulation builds the share with the direct kernel build beside the row store: its work buffers stand where the relayout's
-            # receive / send buffers would - both are in the plan)
-            assert peak_share <= max(ph["relayout"], ph["adjoint_copy"]) + plan["bytes"]["build_work"], (peak_share, ph)
+            # this emulation builds the share with the direct kernel build beside the row store, so its work buffers and the scratch of the
+            # transposition are alive together (in a P-rank run the relayout's buffers stand in the work buffers' place): the same terms
+            b = plan["bytes"]
+            together = b["grid"] + b["runtime"] + b["row_store"] + b["share"] + b["copy"] + b["build_work"] + b["copy_scratch"]
+            # (+ the 3 % by which this emulation over-reserves its share: it only has its own rows' histogram to scale)
+            assert peak_share <= together + 0.03 * (b["share"] + b["copy"]), (peak_share, together)
             assert resident <= ph["adjoint_copy"] and solve <= ph["solve"], (resident, solve, ph)
-            assert solve >= 0.66 * ph["solve"] and peak_build >= 0.5 * ph["build"], (solve, peak_build, ph)
+            assert solve >= 0.66 * ph["solve"] and peak_build >= 0.5 * ph["build"] and peak_share >= 0.66 * together, (solve, peak_build, peak_share, ph)
     finally:
         ctx.close()

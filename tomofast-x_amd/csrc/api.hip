@@ -508,6 +508,13 @@ int tfx_matrix_scale_rows(tfx_ctx *ctx, const double *scale)
     return 0;
 }
 
+int tfx_matrix_reserve(tfx_ctx *ctx, int64_t nnz_upper)
+{
+    if (!ctx || nnz_upper < 0) return fail(TFX_E_ARG, "tfx_matrix_reserve: bad arguments");
+    ctx->reserve_nnz = nnz_upper;
+    return 0;
+}
+
 // t_sparse_matrix%normalize_columns, src/inversion/sparse_matrix.f90:414-443
 int tfx_matrix_normalize_columns(tfx_ctx *ctx, double *column_norm_out)
 {

@@ -3010,7 +3010,12 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         return 0;
     }
     if (keep_matrix) {
-        TFX_TRY(matrix_begin(ctx, nrows_m, ncm * ncols, nrows_m * stride));
+        // (a caller that knows how many entries the column range will hold - it has the per-column histogram of a counting pass - says so
+        // with tfx_matrix_reserve: a range of a rank-partitioned kernel holds 1 / P of the rows x K bound used otherwise)
+        int64_t upper = nrows_m * stride;
+        if (ctx->reserve_nnz > 0) upper = std::min(upper, ctx->reserve_nnz);
+        ctx->reserve_nnz = 0;
+        TFX_TRY(matrix_begin(ctx, nrows_m, ncm * ncols, upper));
         lap("matrix_begin");
     }
     const int RB = keep_matrix ? m.RB : (int)std::min<int64_t>(RB_MAX, (nrows_m + 63) / 64 * 64);

@@ -90,6 +90,8 @@ struct DBuf {
         if (e != hipSuccess)
             return fail(TFX_E_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
         n = count;
+        static const bool log_big = getenv("TFX_ALLOC_LOG") != nullptr;       // (memory planning: every allocation of 256 MB and more)
+        if (log_big && count * sizeof(T) >= ((size_t)1 << 28)) fprintf(stderr, "[tfx alloc] %.2f GB\n", (double)(count * sizeof(T)) / 1e9);
         return 0;
     }
     int ensure(size_t count) { return count <= n ? 0 : alloc(count); }
@@ -293,6 +295,7 @@ struct tfx_ctx {
         tfx::DBuf<float> tvals;
     } trs;
     double tr_panel_entries = 9.0e8, tr_pos_budget = 1.5e8;   // panel size of the transposition (debug keys "tr_panel_entries" / "tr_pos_budget": tests force many small panels of either shape)
+    int64_t reserve_nnz = 0;          // tfx_matrix_reserve: entry bound of the next kernel build into the selected slot (0 = rows x K)
     int fwd_run = 2;                  // debug key "fwd_run": consecutive chunks a wave of the forward kernel takes at a time (matrix.hip k_spmv_fwd)
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
     size_t wave_lds_attr[4] = {0, 0, 0, 0};   // the same for the four wavelet axis kernels (Haar / D4 x forward / inverse)

@@ -441,12 +441,12 @@ def memory_plan(ncells, ndata, compression_rate, nranks, nkernels=1, ndata_compo
     to start a run whose plan does not fit; tests/test_gpu_multirank.py builds one rank's share at full size and checks the measured peak
     against it).  Upper bounds in bytes, from the sizes the library allocates (csrc/build.hip, csrc/matrix.hip):
       grid          six coordinate arrays + the column weight + the per-column histogram                         60 B per cell
-      build_work    three line buffers of <= 32 lines / 2 GiB (generator, wavelet, statistics in flight), the two candidate
-                    buffers of the full radix select (the band select's fallback), one row block in ELL form (2048 rows x K x 8 B)
+      build_work    six line buffers of <= 32 lines / 2 GiB (three batches in flight: generator, wavelet passes, statistics; the select's
+                    candidates and the compaction's slots), one row block in ELL form (2048 rows x K x 8 B)
       row_store     (row-parallel build) this rank's ndata / nranks data x all columns: K entries x 8 B per line, until the relayout is done
       share         the tiles of this rank's column range: 5.625 B per stored entry + 3 % for padding, row markers and the chunk table
       relayout      per row block the received pieces and the packed pieces to send: <= 2 x 2048 rows x K x 8 B
-      copy          the transposed copy of the share (the adjoint as the forward kernel) + the scratch of one panel of its build
+      copy          the transposed copy of the share (the adjoint as the forward kernel) + the scratch of one panel of its build (<= 15 GB)
       lsqr          u (replicated), v, w, x, damping rows and right-hand side of the local columns
     `peak` is the largest phase; joint inversions (nkernels = 2) keep the first kernel's share + copy while the second is built."""
     N, D, P = int(ncells), int(ndata), int(nranks)
@@ -456,21 +456,23 @@ def memory_plan(ncells, ndata, compression_rate, nranks, nkernels=1, ndata_compo
     nnz_kernel = float(nlines) * K * ncm
     grid = 60 * N
     lines = max(1, min(32, (1 << 31) // (8 * N)))
-    build_work = (1 if dense else 5) * lines * N * 8 + (0 if dense else (2048 + ncd) * K * ncm * 8) + (64 << 20)
+    build_work = (1 if dense else 6.25) * lines * N * 8 + (0 if dense else (2048 + ncd) * K * ncm * 8) + (64 << 20)
     rows_loc = -(-D // P) * ncd
     row_store = rows_loc * K * ncm * 8 if (exchange and P > 1 and not dense) else 0
     share = (4.0 * nnz_kernel / P) if dense else (5.625 * 1.03 * nnz_kernel / P + (64 << 20))
     relayout = 2 * 2048 * K * ncm * 8 if row_store else 0
     ncl = -(-N // P) * ncm
     lsqr = 8 * (3 * (nlines * nkernels + 1) + nkernels * ncl * 8) + (32 << 20)
-    runtime = 1.5e9                     # HIP / RCCL context, kernel code, the allocator's slack
+    runtime = 3.0e9                     # HIP / RCCL context, kernel code, the allocators' slack
 
     def phases_with(copy):
-        scratch = 0 if not copy else min(16e9, 0.2 * share + 1e8)
+        # panels of ~9e8 entries by the mean density (a dense band of columns holds up to half as many again): (column, value) pairs 8 B +
+        # 2 B of slot scratch per entry, the per-row tile index, the counts
+        scratch = 0 if not copy else min(nnz_kernel / P, 9.0e8) * 15.0 + 1.5e9
         resident, ph = 0.0, {}          # resident: kernels finished earlier (joint inversion)
         for k in range(nkernels):
             tag = "" if nkernels == 1 else "_kernel%d" % (k + 1)
-            ph["build" + tag] = grid + runtime + resident + build_work + row_store + (0 if row_store else share + copy)
+            ph["build" + tag] = grid + runtime + resident + build_work + row_store + (0 if row_store else share + copy + scratch)
             if row_store:
                 ph["relayout" + tag] = grid + runtime + resident + row_store + share + copy + relayout
             if copy:
@@ -485,7 +487,7 @@ def memory_plan(ncells, ndata, compression_rate, nranks, nkernels=1, ndata_compo
     copy_fits = bool(copy) and max(with_copy.values()) <= limit
     chosen = with_copy if copy_fits else without
     return {"ranks": P, "cells": N, "data": D, "kernels": nkernels, "entries_per_line": K, "nnz_per_kernel": nnz_kernel,
-            "bytes": {"grid": grid, "build_work": build_work, "row_store": row_store, "share": share, "relayout": relayout, "copy": copy,
+            "bytes": {"grid": grid, "build_work": build_work, "row_store": row_store, "share": share, "relayout": relayout, "copy": copy, "copy_scratch": (min(nnz_kernel / P, 9.0e8) * 15.0 + 1.5e9) if copy else 0,
                       "lsqr": lsqr, "runtime": runtime},
             # the transposed copy is optional (automatic mode gives it up when it does not fit: the adjoint then runs on the tiles of S)
             "adjoint_copy_fits": copy_fits,
@@ -628,6 +630,7 @@ def build_partitioned(ctx, rank, nranks, Xdata, Ydata, Zdata, column_weight, com
     err = float(comm.allreduce_host(np.array([err]))[0])
     nel, nnz = (get_partition or get_load_balancing_nelements)(hist.astype(np.int32), nranks)
     c0, c1 = column_ranges(nel)[rank]
+    ctx.matrix_reserve(int(nnz[rank]))          # (the histogram says what the range holds: not the rows x K of a whole kernel)
     res2 = ctx.calculate_sensit(Xdata, Ydata, Zdata, column_weight, compression_type, compression_rate, problem_weight, data_weight,
                                 col_range=(c0, c1))
     assert res2["nnz"] == int(nnz[rank]), (res2["nnz"], nnz[rank])

@@ -379,6 +379,13 @@ module tfx_binding
       real(c_double), intent(in) :: scale(*)
     end function
 
+    ! entry bound of the next kernel build into the selected slot (a column range whose count is known from the histogram)
+    integer(c_int) function tfx_matrix_reserve(ctx, nnz_upper) bind(C, name="tfx_matrix_reserve")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: nnz_upper
+    end function
+
     ! t_sparse_matrix%normalize_columns (sparse_matrix.f90:414-443)
     integer(c_int) function tfx_matrix_normalize_columns(ctx, column_norm) bind(C, name="tfx_matrix_normalize_columns")
       import :: c_int, c_ptr, c_double

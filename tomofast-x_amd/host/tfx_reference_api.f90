@@ -1082,6 +1082,8 @@ contains
         if (ip == 2) mptr = c_loc(mag_field)
         allocate(dwflat(par%ndata * par%ndata_components))
         dwflat = reshape(data_weight, (/par%ndata * par%ndata_components/))
+        ! (the histogram of the counting pass says what this rank's columns hold: not the rows x K of a whole kernel)
+        call api_check(tfx_matrix_reserve(ctx, sum(int(k%nnz_hist(cb + 1:ce), c_int64_t))), 'tfx_matrix_reserve', myrank_)
         call api_check(tfx_build_kernel(ctx, ip, k%data_type, k%ndc, k%ncm, int(par%ndata, c_int64_t), k%Xd, k%Yd, k%Zd, k%cw_full, mptr, &
                                         par%compression_type, par%compression_rate, problem_weight, c_loc(dwflat), int(cb, c_int64_t), &
                                         int(ce, c_int64_t), nnz_k, err_k, c_null_ptr), 'read_sensitivity_kernel', myrank_)

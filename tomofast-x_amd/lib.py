@@ -25,7 +25,7 @@ SYMBOLS = [
     "tfx_comm_send", "tfx_comm_recv", "tfx_comm_barrier",
     "tfx_column_weight_type1", "tfx_column_weight_type2", "tfx_column_weight_type3", "tfx_prism_rows_gz", "tfx_prism_rows_mag", "tfx_prism_rows", "tfx_wavelet", "tfx_compress_row",
     "tfx_build_kernel_grav", "tfx_build_kernel_mag", "tfx_build_kernel", "tfx_select_problem",
-    "tfx_matrix_upload_csr", "tfx_matrix_info", "tfx_matrix_format", "tfx_matrix_download_csr", "tfx_matrix_free", "tfx_matrix_scale_rows", "tfx_matrix_normalize_columns",
+    "tfx_matrix_upload_csr", "tfx_matrix_info", "tfx_matrix_format", "tfx_matrix_download_csr", "tfx_matrix_free", "tfx_matrix_scale_rows", "tfx_matrix_normalize_columns", "tfx_matrix_reserve",
     "tfx_cons_upload_csr", "tfx_cons_clear", "tfx_rowstore_build", "tfx_rowstore_build_ex", "tfx_rowstore_build_comp", "tfx_rowstore_counts", "tfx_rowstore_pack",
     "tfx_rowstore_free", "tfx_matrix_begin", "tfx_matrix_append_rows", "tfx_matrix_finish",
     "tfx_partition_columns", "tfx_spmv", "tfx_spmtv", "tfx_lsqr_solve", "tfx_lsqr_begin", "tfx_lsqr_iterate",

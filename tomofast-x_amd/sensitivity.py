@@ -397,6 +397,11 @@ class Context:
             raise ValueError("scale size != number of matrix rows")
         check(self._lib.tfx_matrix_scale_rows(self._h, ptr(sc)))
 
+    def matrix_reserve(self, nnz_upper):
+        """Entry bound of the next kernel build into the selected slot (tfx_matrix_reserve): the sum of the per-column histogram over
+        the column range a rank builds."""
+        check(self._lib.tfx_matrix_reserve(self._h, C.c_int64(int(nnz_upper))))
+
     def normalize_columns(self):
         """t_sparse_matrix%normalize_columns (sparse_matrix.f90:414-443): scales the columns of the selected matrix to unit length
         (zero columns stay) and returns their original norms."""
