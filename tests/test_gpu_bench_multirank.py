@@ -102,6 +102,25 @@ def test_ranks_launched_like_the_driver_does_share_the_gpu_and_fall_back_togethe
         assert abs(out["final_r"] - plain_small["final_r"]) <= 1e-9 * abs(plain_small["final_r"]), (out["final_r"], plain_small["final_r"])
 
 
+def test_eight_ranks_on_the_medium_workload_finish_in_time_on_the_hooks():
+    """The driver's N = 8 launch on a box where the ranks do NOT get a GPU each (here: all eight on one): the pre-flight rung refuses RCCL
+    on every rank together, the hook rung is taken, and the whole `medium` run (1e6 cells x 4096 data: row-parallel build, relayout,
+    2 + 3 x 4 iterations) is over well inside the driver's per-run time limit - the wall clock is asserted, start-up of eight torch
+    processes included."""
+    import time
+    t0 = time.time()
+    out, err = _run_bench(8, "medium", {}, port=29671, timeout=400)
+    wall = time.time() - t0
+    comm = out["comm"]
+    print("8 ranks sharing the GPU, medium workload: %.0f s wall, %.1f it/s, path %s" % (wall, out["value"], comm["path"]))
+    assert wall <= 120.0, wall            # measured: 7 s
+    assert comm["path"].startswith("torch.distributed hooks") and comm["rccl_ranks"] == 0, comm
+    assert comm["ladder"][0]["stage"] == "pre-flight" and comm["ladder"][0]["ok"] is False, comm
+    assert out["n_gpus"] == 8 and len(out["per_rank"]) == 8 and sum(p["nnz"] for p in out["per_rank"]) == out["config"]["nnz"]
+    assert out["memory_plan"]["ranks"] == 8 and out["memory_plan"]["fits"]
+    assert out["adjoint_identity_rel_err"] < 1e-12
+
+
 def test_plain_python_bench_gpus_2_launches_its_own_ranks(plain_small):
     """`python bench.py --gpus 2` WITHOUT torch.distributed.run (no WORLD_SIZE in the environment): bench.py re-runs itself under the
     launcher (free port on 127.0.0.1) instead of exiting - one JSON line with n_gpus = 2, the same result as the launched form."""
