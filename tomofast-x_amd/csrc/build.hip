@@ -3105,6 +3105,8 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         // lowest priority where the runtime offers priorities (the main stream's kernels get the freed slots first); a plain
         // non-blocking stream otherwise
         int prio_lo = 0, prio_hi = 0;
+        // (the generator on a CU-masked stream of its own - 64 / 96 / 128 / 160 of the 256 CUs, started with the batch - was measured in
+        // round 5: 27.9 / 24.9 / 21.4 / 21.0 s of loop against 18.9 s, profiles/r05_gen_cumask_probe.txt; not kept)
         if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
             hipStreamCreateWithPriority(&gs.st, hipStreamNonBlocking, prio_lo) != hipSuccess) {
             (void)hipGetLastError();
