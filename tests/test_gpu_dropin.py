@@ -223,3 +223,31 @@ def test_two_ranks_of_the_reference_program_with_the_dropin(tmp_path, golden_dir
         print("%s, 2 ranks of the reference's own program + drop-in: %s final model rel-L2 %.2e from the reference's 2-rank run (its 1- vs 2-rank: %.1e)" %
               (name, sfx, rel, self_diff))
         assert rel <= max(1e-6, 100.0 * self_diff), (tag, rel)
+
+
+def test_dropin_reloads_the_kernel_files_it_wrote(tmp_path, golden_dir):
+    """sensit.readFromFiles = 1 / 2 through the reference's own program with the drop-in modules (problem_joint_gravmag.F90:170-203): a
+    first run calculates the kernel and writes the SENSIT folder in the reference's format; a second run reads kernel and depth weight
+    back from it (1), a third reads the depth weight only and calculates the kernel again (2) - the same final model each time."""
+    import re
+    _need_exe()
+    g = np.load(os.path.join(golden_dir, "e2e_mag31.npz"))
+    wd = str(tmp_path)
+    fh.write_case_inputs(wd, g)
+    par = str(g["parfile"])
+    models = []
+    for mode in (0, 1, 2):
+        p2 = re.sub(r"sensit\.readFromFiles\s*=\s*\d", "sensit.readFromFiles                = %d" % mode, par)
+        assert mode == 0 or p2 != par
+        open(os.path.join(wd, "Parfile.txt"), "w").write(p2)
+        out = fh._sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "THE END" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+        models.append(fh.read_tokens(os.path.join(wd, "out", "model", "mag_final_model_full.txt"), int(g["ncm"])))
+        if mode == 0:
+            assert os.path.isfile(os.path.join(wd, "out", "SENSIT", "sensit_magn_1_0")) and os.path.isfile(os.path.join(wd, "out", "SENSIT", "sensit_magn_weight"))
+    ref = g["np1_model_final"].reshape(models[0].shape)
+    for mode, m in enumerate(models):
+        rel = float(np.linalg.norm(m - ref) / np.linalg.norm(ref))
+        print("drop-in, sensit.readFromFiles = %d: final model rel-L2 %.2e from the reference" % (mode, rel))
+        assert rel <= 3e-5
+    assert np.array_equal(models[0], models[1]) and np.array_equal(models[0], models[2])
