@@ -996,7 +996,7 @@ def test_build_kernel_vs_reference_sensit(ctx, golden_dir, name):
     built = ctx.matrix_download_csr()
     ref = (g["np1_row_ptr"], g["np1_cols"], g["np1_vals"])
     frac, maxulp = compare_built_matrix(built, ref, obs.shape[0])
-    assert frac >= 0.9999 and maxulp <= 2, (frac, maxulp)          # >= 99.99 % identical sparsity (measured: 1.0)
+    assert frac >= 0.9999 and maxulp <= 1, (frac, maxulp)          # >= 99.99 % identical sparsity (measured: 1.0), values within 1 fp32 ulp
     assert abs(res["nnz"] - int(g["np1_nnz_total"])) <= 2 * obs.shape[0]
     assert int(res["nnz_hist"].sum()) == res["nnz"]
     if int(g["ctype"]) > 0:
@@ -1065,8 +1065,7 @@ def _lsqr_long_double(rp, cols, vals, alpha, d, N, K):
     return x.astype(np.float64), float(phibar / b1)
 
 
-@pytest.mark.parametrize("adj_copy", [2, 0])
-def test_unconverged_lsqr_is_closer_to_extended_precision_than_sequential_fp64(ctx, adj_copy):
+def test_unconverged_lsqr_is_closer_to_extended_precision_than_sequential_fp64(ctx):
     """Why the GPU host's 1 x 101-iteration run of bench.py's mid-scale problem sits 2.5e-7 from the reference's model (15 x the
     reference's own rank scatter) with a LOWER data cost: 101 iterations of lsqr_solve_sensit (lsqr_solver2.F90:47-308) on the same
     128x128x32-cell x 1024-data system in three arithmetics - fp64 with the reference's sequential sums (sparse_matrix.f90:316-329,
@@ -1076,33 +1075,44 @@ def test_unconverged_lsqr_is_closer_to_extended_precision_than_sequential_fp64(c
     Both adjoints: on the transposed copy (fp64 sums) and on the tiles of S (61-bit fixed-point sums)."""
     nx, ny, nz, ox, oy, rate, K = 128, 128, 32, 32, 32, 0.05, 101
     N = nx * ny * nz
-    ctx.debug_set("adj_copy", adj_copy)
+    alpha = np.float32(1e-7)
+    gpu = {}
     try:
-        ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
-        cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
-        xs, ys, zs = tfx.synthetic.observations(nx, ny, ox, oy)
-        ctx.calculate_sensit(xs, ys, zs, cw, 1, rate)
-        assert bool(ctx.matrix_format()["adjoint_copy"]) == (adj_copy != 0)
-        mtrue = tfx.synthetic.true_model(nx, ny, nz)
-        d = ctx.calc_data(ctx.forward_wavelet(mtrue / cw, nx, ny, nz, 1), 1.0, None)
-        alpha = np.float32(1e-7)
-        x_gpu, it, r_gpu = ctx.lsqr_solve_sensit(d, K, 1e-300, 0.0, 0.0, [np.full(N, alpha, np.float32)], [np.zeros(N)])
-        rp, cols, vals = ctx.matrix_download_csr()
+        for adj_copy in (2, 0):
+            ctx.debug_set("adj_copy", adj_copy)
+            ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
+            cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+            xs, ys, zs = tfx.synthetic.observations(nx, ny, ox, oy)
+            ctx.calculate_sensit(xs, ys, zs, cw, 1, rate)
+            assert bool(ctx.matrix_format()["adjoint_copy"]) == (adj_copy != 0)
+            mtrue = tfx.synthetic.true_model(nx, ny, nz)
+            d = ctx.calc_data(ctx.forward_wavelet(mtrue / cw, nx, ny, nz, 1), 1.0, None)
+            x_gpu, it, r_gpu = ctx.lsqr_solve_sensit(d, K, 1e-300, 0.0, 0.0, [np.full(N, alpha, np.float32)], [np.zeros(N)])
+            assert it == K
+            csr = ctx.matrix_download_csr()
+            if gpu:
+                assert all(np.array_equal(p, q) for p, q in zip(csr, gpu[2][3])) and np.array_equal(d, gpu[2][2])    # the same system
+            gpu[adj_copy] = (x_gpu, r_gpu, d, csr)
     finally:
         ctx.debug_set("adj_copy", 2)
+    rp, cols, vals = gpu[2][3]
+    d = gpu[2][2]
     x_seq, it2, r_seq = orc.lsqr((rp, cols, vals), orc.diag_csr(np.full(N, alpha, np.float32)), N, np.concatenate([d, np.zeros(N)]), K)
     x_ext, r_ext = _lsqr_long_double(rp, cols, vals, alpha, d, N, K)
-    assert it == it2 == K
+    assert it2 == K
 
     def rel(p, q):
         return float(np.linalg.norm(p - q) / np.linalg.norm(q))
 
-    g_e, s_e, g_s = rel(x_gpu, x_ext), rel(x_seq, x_ext), rel(x_gpu, x_seq)
-    print("LSQR x %d, adj_copy %d: residual seq64 %.9e / gpu %.9e / ext80 %.9e; model rel-L2 gpu-ext80 %.2e, seq64-ext80 %.2e, gpu-seq64 %.2e" %
-          (K, adj_copy, r_seq, r_gpu, r_ext, g_e, s_e, g_s))
-    assert g_e <= s_e, (g_e, s_e)                                   # the solution: nearer the long-double trajectory than the reference's arithmetic
-    assert abs(r_gpu - r_ext) <= abs(r_seq - r_ext), (r_gpu, r_seq, r_ext)      # and so is the residual
-    assert g_s <= 2.0 * (g_e + s_e)                                 # (triangle: nothing else separates the two fp64 runs)
+    s_e = rel(x_seq, x_ext)
+    for adj_copy in (2, 0):
+        x_gpu, r_gpu = gpu[adj_copy][:2]
+        g_e, g_s = rel(x_gpu, x_ext), rel(x_gpu, x_seq)
+        print("LSQR x %d, adj_copy %d: residual seq64 %.9e / gpu %.9e / ext80 %.9e; model rel-L2 gpu-ext80 %.2e, seq64-ext80 %.2e, gpu-seq64 %.2e" %
+              (K, adj_copy, r_seq, r_gpu, r_ext, g_e, s_e, g_s))
+        assert g_e <= s_e, (g_e, s_e)                                   # the solution: nearer the long-double trajectory than the reference's arithmetic
+        assert abs(r_gpu - r_ext) <= abs(r_seq - r_ext), (r_gpu, r_seq, r_ext)      # and so is the residual
+        assert g_s <= 2.0 * (g_e + s_e)                                 # (triangle: nothing else separates the two fp64 runs)
 
 
 @pytest.mark.parametrize("name", ["e2e_medium_haar", "e2e_medium_d4"])
@@ -1252,7 +1262,7 @@ def test_build_multicomponent_kernel_vs_reference_sensit(ctx, golden_dir, name):
     ref = (sub_rp[::ncm], (g["np1_cols"] + kk * N).astype(np.int32), g["np1_vals"])
     frac, maxulp = compare_built_matrix(built, ref, obs.shape[0] * ncd)
     # magnetic tensor entries cancel heavily: fp32 values of small coefficients may move by more than 2 ulp
-    assert frac >= 0.9999 and (maxulp <= 2 or int(g["prob"]) == 2), (frac, maxulp)
+    assert frac >= 0.9999 and (maxulp <= 1 or int(g["prob"]) == 2), (frac, maxulp)
     assert abs(res["nnz"] - int(g["np1_nnz_total"])) <= 2 * obs.shape[0] * ncd * ncm
     assert int(res["nnz_hist"].sum()) == res["nnz"]
     if int(g["ctype"]) > 0:
@@ -1638,7 +1648,7 @@ def test_config1_mansf_end_to_end(ctx, golden_dir):
     built = ctx.matrix_download_csr()
     n8 = int(g["row_ptr"][-1])
     frac, maxulp = compare_built_matrix((built[0][:9], built[1], built[2]), (g["row_ptr"], g["cols"][:n8], g["vals"][:n8]), 8)
-    assert frac >= 0.9999 and maxulp <= 2
+    assert frac >= 0.9999 and maxulp <= 1, (frac, maxulp)       # values within 1 fp32 ulp
     m, d, hist = tfx.inversion.solve_problem_gravity(ctx, cw, 1, g["data_observed"], 60, 100, alpha=0.0,
                                                      admm=dict(bounds=g["admm_bounds"], rho=float(g["admm_weight"])))
     ref = g["model_final"]
@@ -1863,7 +1873,11 @@ def test_full_size_build_properties_and_sampled_rows_vs_oracle(ctx, name):
             # 1.2e-9) - far below the fp32 resolution of the large entries, above it for the smallest kept ones.
             dv = np.abs(vb[ib].astype(np.float64) - v_ref[ir].astype(np.float64))
             ulp = np.spacing(np.abs(v_ref[ir])).astype(np.float64)
-            assert np.all(dv <= 2.0 * ulp + 1e-8 * float(np.abs(v_ref).max())), float((dv / np.abs(v_ref).max()).max())
+            worst_row = float((dv / np.abs(v_ref).max()).max())
+            print("%s row %d: %d of %d kept values identical in fp32, worst |difference| / row maximum %.2e, worst distance %.1f fp32 ulp" %
+                  (name, r, int(np.count_nonzero(dv == 0.0)), dv.size, worst_row, float((dv / ulp).max())))
+            # (rounds 1-4 asserted 2 ulp + 1e-8 of the row maximum: the round-5 atan2 halves the per-term error)
+            assert np.all(dv <= 1.0 * ulp + 4e-9 * float(np.abs(v_ref).max())), worst_row
             assert abs(Sx[r] - np.dot(v_ref.astype(np.float64), x[c_ref - 1])) <= 1e-6 * np.abs(v_ref).astype(np.float64) @ np.abs(x[c_ref - 1])
     finally:
         ctx.matrix_free()

@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (threadIdx.x <= cx) s_xe[threadIdx.x] = xe[i0 + threadIdx.x];
     if (threadIdx.x <= cy) s_ye[threadIdx.x] = ye[j0 + threadIdx.x];
     if (threadIdx.x <= cz) s_ze[threadIdx.x] = ze[k0 + threadIdx.x];
-    static_assert(MT_TX * MT_TY * 2 == 256 && MT_TX >= MT_X && MT_TY >= MT_Y && MT_Z % 2 == 0, "two (x, y) planes of threads walk the layers of the tile");
-    constexpr int CPT = MT_Z / 2, CELL_UNROLL = NSUB == 3 ? 1 : CPT;
+    static_assert(MT_TX * MT_TY * 2 == 256 && MT_TX >= MT_X && MT_TY >= MT_Y && MT_Z % 2 == 0, "two (x, y) planes of threads, each the lower / upper half of the tile's layers");
+    constexpr int CPT = MT_Z / 2;
     const int ta = threadIdx.x % MT_TX, tb = (threadIdx.x / MT_TX) % MT_TY, tc0 = threadIdx.x / (MT_TX * MT_TY);
     const bool col_ok = ta < cx && tb < cy;
     for (int o = 0; o < nobs; ++o) {
@@ -488,10 +488,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const int a = ta, b = tb;
             const double x1 = s_xe[a], x2 = s_xe[a + 1], y1 = s_ye[b], y2 = s_ye[b + 1];
             const double rx1 = x1 - xo + eps, rx2 = x2 - xo + eps, ry1 = y1 - yo + eps, ry2 = y2 - yo + eps;
-            // (one cell at a time with three outputs per cell: three cells' 32 LDS operands each in flight spilled registers)
-#pragma unroll CELL_UNROLL
+            // The thread's cells are ADJACENT layers of one (x, y) column: the node and edge values of a cell's upper face are the next
+            // cell's lower face and stay in registers - 12 + 16 LDS operands per cell instead of 32 (the cell phase was 27 % of the kernel).
+            // corner (i, j, k), i / j / k in {1, 2}: node (a + i - 1, b + j - 1, c + k - 1); an edge sits at its lower node
+#define C_(T, i, j, k) T[NODE(a + (i) - 1, b + (j) - 1, c + (k) - 1)]
+            double fx[2][2], fy[2][2], gx[2], gy[2];           // lower face: TAx / TAy at (i, j), the x edges at j, the y edges at i
+            {
+                const int c = tc0 * CPT;
+                if (c < cz) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) { fx[i][jj] = C_(TAx, i + 1, jj + 1, 1); fy[i][jj] = C_(TAy, i + 1, jj + 1, 1); }
+                    gx[0] = C_(Tx, 1, 1, 1); gx[1] = C_(Tx, 1, 2, 1);
+                    gy[0] = C_(Ty, 1, 1, 1); gy[1] = C_(Ty, 2, 1, 1);
+                }
+            }
+#pragma unroll 1
             for (int j = 0; j < CPT; ++j) {
-                const int c = tc0 + 2 * j;
+                const int c = tc0 * CPT + j;
                 if (c >= cz) break;
                 const double z1 = s_ze[c], z2 = s_ze[c + 1];
                 double tx[3], ty[3], tz[3];
@@ -500,15 +515,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     if (rx1 == 0. || rx2 == 0.) bad |= 4;
                     if (ry1 == 0. || ry2 == 0.) bad |= 8;
                 }
-                // corner (i, j, k), i / j / k in {1, 2}: node (a + i - 1, b + j - 1, c + k - 1); an edge sits at its lower node
-#define C_(T, i, j, k) T[NODE(a + (i) - 1, b + (j) - 1, c + (k) - 1)]
-                tx[0] = C_(TAx, 2, 1, 2) - C_(TAx, 2, 2, 2) + C_(TAx, 2, 2, 1) - C_(TAx, 2, 1, 1) + C_(TAx, 1, 2, 2) - C_(TAx, 1, 1, 2) +
-                        C_(TAx, 1, 1, 1) - C_(TAx, 1, 2, 1);                                                                  // :376-383
+                double ux[2][2], uy[2][2], hx[2], hy[2];       // upper face
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) { ux[i][jj] = C_(TAx, i + 1, jj + 1, 2); uy[i][jj] = C_(TAy, i + 1, jj + 1, 2); }
+                hx[0] = C_(Tx, 1, 1, 2); hx[1] = C_(Tx, 1, 2, 2);
+                hy[0] = C_(Ty, 1, 1, 2); hy[1] = C_(Ty, 2, 1, 2);
+                // (index [i - 1][j - 1]; f = k 1, u = k 2)
+                tx[0] = ux[1][0] - ux[1][1] + fx[1][1] - fx[1][0] + ux[0][1] - ux[0][0] + fx[0][0] - fx[0][1];                  // :376-383
                 ty[0] = C_(Tz, 2, 2, 1) - C_(Tz, 1, 2, 1) + C_(Tz, 1, 1, 1) - C_(Tz, 2, 1, 1);                                    // z edges, :386-389
-                ty[1] = C_(TAy, 1, 2, 2) - C_(TAy, 2, 2, 2) + C_(TAy, 2, 2, 1) - C_(TAy, 1, 2, 1) + C_(TAy, 2, 1, 2) - C_(TAy, 1, 1, 2) +
-                        C_(TAy, 1, 1, 1) - C_(TAy, 2, 1, 1);                                                                  // :392-399
-                ty[2] = C_(Tx, 1, 2, 1) - C_(Tx, 1, 2, 2) + C_(Tx, 1, 1, 2) - C_(Tx, 1, 1, 1);                                    // x edges, :419-422
-                tx[2] = C_(Ty, 2, 1, 1) - C_(Ty, 2, 1, 2) + C_(Ty, 1, 1, 2) - C_(Ty, 1, 1, 1);                                    // y edges, :439-442
+                ty[1] = uy[0][1] - uy[1][1] + fy[1][1] - fy[0][1] + uy[1][0] - uy[0][0] + fy[0][0] - fy[1][0];                  // :392-399
+                ty[2] = gx[1] - hx[1] + hx[0] - gx[0];                                                                           // x edges, :419-422
+                tx[2] = gy[1] - hy[1] + hy[0] - gy[0];                                                                           // y edges, :439-442
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    gx[i] = hx[i]; gy[i] = hy[i];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) { fx[i][jj] = ux[i][jj]; fy[i][jj] = uy[i][jj]; }
+                }
 #undef C_
                 tz[2] = -1 * (tx[0] + ty[1]);                                                                                 // :446
                 tz[1] = ty[2];

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <future>
 #include <cstdarg>
 #include <cstring>
 #include <memory>
@@ -190,6 +191,11 @@ struct TiledMatrix {
     struct Prealloc {
         DBuf<char> rec;
         DBuf<int32_t> row0;
+        // the two allocations (100+ GB: seconds) run on a helper thread while the build's first row blocks are computed; whoever looks at
+        // rec / row0 - or destroys the object - waits for it first
+        std::future<void> pending;
+        void wait() { if (pending.valid()) pending.get(); }
+        ~Prealloc() { wait(); }
     };
     std::unique_ptr<Prealloc> pre;
     void drop_prealloc() { pre.reset(); }

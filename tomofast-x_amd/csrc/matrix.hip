@@ -436,9 +436,20 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
         const size_t need = (size_t)(capT / CHUNK) * (REC_BYTES + sizeof(int32_t));
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > (double)need + 40e9) {      // (40 GB: the build's own buffers and the copy's panel scratch)
-            NoEvict optional;       // (an eviction would free the very Prealloc whose buffer is being allocated)
+            // on a helper thread (its thread-local allocation context is empty: no eviction can be triggered from there, and an
+            // eviction on this thread waits for it in ~Prealloc): the build computes its first row blocks meanwhile
             m.pre.reset(new TiledMatrix::Prealloc());
-            if (m.pre->rec.alloc((size_t)(capT / CHUNK) * REC_BYTES) != 0 || m.pre->row0.alloc((size_t)(capT / CHUNK)) != 0) m.pre.reset();
+            TiledMatrix::Prealloc *pre = m.pre.get();
+            const int dev = ctx->device;
+            const size_t nrec = (size_t)(capT / CHUNK) * REC_BYTES, nrow0 = (size_t)(capT / CHUNK);
+            pre->pending = std::async(std::launch::async, [pre, dev, nrec, nrow0] {
+                (void)hipSetDevice(dev);
+                if (pre->rec.alloc(nrec) != 0 || pre->row0.alloc(nrow0) != 0) {
+                    pre->rec.release();
+                    pre->row0.release();
+                }
+                (void)hipGetLastError();
+            });
         }
         (void)hipGetLastError();
     }
@@ -1948,6 +1959,7 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
 {
     if (m.is_dense || m.is_transpose_copy || m.h_tiles.empty() || ctx->adj_copy == 0) return 0;
     hipStream_t s = ctx->stream;
+    if (m.pre) m.pre->wait();
     const bool have_storage = m.pre && m.pre->rec.p && m.pre->row0.p;       // set aside by matrix_begin
     if (ctx->adj_copy == 2 && !have_storage) {
         if (m.n_entries < ctx->adj_copy_min_nnz) return 0;
