@@ -1876,8 +1876,11 @@ def test_full_size_build_properties_and_sampled_rows_vs_oracle(ctx, name):
             worst_row = float((dv / np.abs(v_ref).max()).max())
             print("%s row %d: %d of %d kept values identical in fp32, worst |difference| / row maximum %.2e, worst distance %.1f fp32 ulp" %
                   (name, r, int(np.count_nonzero(dv == 0.0)), dv.size, worst_row, float((dv / ulp).max())))
-            # (rounds 1-4 asserted 2 ulp + 1e-8 of the row maximum: the round-5 atan2 halves the per-term error)
-            assert np.all(dv <= 1.0 * ulp + 4e-9 * float(np.abs(v_ref).max())), worst_row
+            # (rounds 1-4 asserted 2 ulp + 1e-8 of the row maximum.  Measured in round 5: compressed kernels <= 1.2e-10 of the row maximum,
+            # 86-99 % of the kept values identical in fp32; the dense rows of config 2 - no transform between the prism sums and the
+            # comparison, entries over seven decades - 4.3e-9)
+            slack = 8e-9 if c["ctype"] == 0 else 5e-10
+            assert np.all(dv <= 1.0 * ulp + slack * float(np.abs(v_ref).max())), worst_row
             assert abs(Sx[r] - np.dot(v_ref.astype(np.float64), x[c_ref - 1])) <= 1e-6 * np.abs(v_ref).astype(np.float64) @ np.abs(x[c_ref - 1])
     finally:
         ctx.matrix_free()
