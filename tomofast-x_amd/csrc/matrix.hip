@@ -435,7 +435,8 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
         tile_shape(ctx, ncols, nrows, nnz_upper + nnz_upper / 50, tc, rb, nrb, ntc, capT);
         const size_t need = (size_t)(capT / CHUNK) * (REC_BYTES + sizeof(int32_t));
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > (double)need + 40e9) {      // (40 GB: the build's own buffers and the copy's panel scratch)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > (double)need + 60e9) {      // (60 GB: the build's own buffers, 16 GB, and the copy's panel scratch - a panel of a
+                                                                                                              // kernel with a dense band of columns was seen to need 30 GB)
             // on a helper thread (its thread-local allocation context is empty: no eviction can be triggered from there, and an
             // eviction on this thread waits for it in ~Prealloc): the build computes its first row blocks meanwhile
             m.pre.reset(new TiledMatrix::Prealloc());
@@ -1968,6 +1969,20 @@ int matrix_build_transpose(tfx_ctx *ctx, TiledMatrix &m)
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
         // the copy (a little larger than the original: its own padding and markers) + the conversion scratch of a panel
         if ((double)free_b < 1.06 * (double)m.rec.bytes() + std::min(16e9, 0.2 * (double)m.rec.bytes() + 1e8)) return 0;
+    }
+    if (ctx->adj_copy == 2 && have_storage) {
+        // the storage is there, but a panel of the transposition needs its scratch as well ((column, value) pairs + slots of up to three
+        // nominal panels' worth of entries: a dense band of columns): without room for it the copy is given up NOW, not after the panel's allocation has failed
+        size_t free_b = 0, total_b = 0;
+        TFX_HIP(hipStreamSynchronize(s));
+        const double scratch = std::min((double)m.n_entries, 3.0 * ctx->tr_panel_entries) * 10.0 + 1.0e9;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < scratch) {
+            (void)hipGetLastError();
+            fprintf(stderr, "[tfx] no transposed copy for the adjoint (%.1f GB free, the transposition needs %.1f GB of scratch): the adjoint runs on the tiles of S\n",
+                    (double)free_b / 1e9, scratch / 1e9);
+            m.drop_prealloc();
+            return 0;
+        }
     }
     const auto t_begin = std::chrono::steady_clock::now();
     TiledMatrix *T = new TiledMatrix();
