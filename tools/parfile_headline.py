@@ -56,6 +56,25 @@ try:
     d_f = read_col(os.path.join(odir, "data", "grav_final.txt"), 4)
     m_f = read_col(os.path.join(odir, "model", "grav_final_model_full.txt"), 1)
     log("Fortran host: %.1f s, phases %s" % (out["fortran_host_wall_s"], out["phase_timing_s"]))
+    # ---- the same Parfile through the REFERENCE'S OWN program with the drop-in modules (oracle/_ref/dropin/tomofastx_dropin, where it was built)
+    DROPIN = os.path.join(ROOT, "oracle", "_ref", "dropin", "tomofastx_dropin")
+    if os.path.isfile(DROPIN) and os.environ.get("PARFILE_DROPIN", "1") != "0":
+        shutil.rmtree(os.path.join(wd, "output"), ignore_errors=True)
+        t0 = time.time()
+        q = subprocess.run([DROPIN, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=3000, env=dict(os.environ, TFX_WRITE_SENSIT="0"))
+        dt = time.time() - t0
+        if q.returncode == 0 and "THE END" in q.stdout:
+            m_d = read_col(os.path.join(odir, "model", "grav_final_model_full.txt"), 1)
+            d_d = read_col(os.path.join(odir, "data", "grav_final.txt"), 4)
+            out["reference_program_with_dropin"] = {
+                "wall_s": round(dt, 2), "final_model_rel_l2_vs_fortran_host": float(np.linalg.norm(m_d - m_f) / np.linalg.norm(m_f)),
+                "final_data_rel_l2_vs_fortran_host": float(np.linalg.norm(d_d - d_f) / np.linalg.norm(d_f)),
+                "lsqr_r": [float(t.split()[0]) for t in q.stdout.split("End of subroutine lsqr_solve_sensit, r =")[1:]],
+                "nnz_total": int(q.stdout.split("nnz_total =")[1].split()[0])}
+            log("the reference's own program + drop-in: %.1f s, %s" % (dt, out["reference_program_with_dropin"]))
+        else:
+            out["reference_program_with_dropin"] = {"failed": (q.stdout[-1500:] + q.stderr[-1500:])}
+            log("drop-in run failed: " + q.stdout[-1500:] + q.stderr[-800:])
     # ---- the same run through the Python host
     ctx = tfx.Context(0)
     ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
