@@ -443,14 +443,20 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
             TiledMatrix::Prealloc *pre = m.pre.get();
             const int dev = ctx->device;
             const size_t nrec = (size_t)(capT / CHUNK) * REC_BYTES, nrow0 = (size_t)(capT / CHUNK);
-            pre->pending = std::async(std::launch::async, [pre, dev, nrec, nrow0] {
+            auto set_aside = [pre, dev, nrec, nrow0] {
                 (void)hipSetDevice(dev);
                 if (pre->rec.alloc(nrec) != 0 || pre->row0.alloc(nrow0) != 0) {
                     pre->rec.release();
                     pre->row0.release();
                 }
                 (void)hipGetLastError();
-            });
+            };
+            try {
+                pre->pending = std::async(std::launch::async, set_aside);
+            } catch (const std::exception &) {      // (no thread to be had: allocate here and now, without the eviction retry)
+                NoEvict optional;
+                set_aside();
+            }
         }
         (void)hipGetLastError();
     }
