@@ -30,10 +30,11 @@ F="-O2 -fconvert=big-endian -DUSE_FLUSH6 -I$MPI_INC"
 S=$REF/src
 D=$HOST/dropin
 
-compile() {   # source -> object in the build directory, when out of date
-  local f=$1 o
+DIRTY=0
+compile() {   # source -> object in the build directory, when out of date - or when anything before it in the order was recompiled
+  local f=$1 o     # (a module file carries the checksums of the modules it uses: a stale dependant is a compile error, not a warning)
   o=$(basename "${f%.*}").o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ]; then $FC $F -c "$f" -o "$o"; fi
+  if [ $DIRTY = 1 ] || [ ! -f "$o" ] || [ "$f" -nt "$o" ]; then DIRTY=1; $FC $F -c "$f" -o "$o"; fi
 }
 
 printf 'module mpi\n  implicit none\n  include "mpif.h"\nend module mpi\n' > mpi.f90
@@ -63,7 +64,7 @@ compile $D/dropin_sensitivity_gravmag.f90
 awk '{ if ($0 ~ /Finished reading the parameter file|Finished reading/ && !done) { print "  close(10)"; done=1 } print }' \
     $S/parameters_init.f90 > parameters_init_patched.f90
 grep -q 'close(10)' parameters_init_patched.f90 || { echo "patch point not found"; exit 1; }
-[ -f parameters_init.o ] && [ parameters_init.o -nt $S/parameters_init.f90 ] || $FC $F -c parameters_init_patched.f90 -o parameters_init.o
+{ [ $DIRTY = 0 ] && [ -f parameters_init.o ] && [ parameters_init.o -nt $S/parameters_init.f90 ]; } || { DIRTY=1; $FC $F -c parameters_init_patched.f90 -o parameters_init.o; }
 # reference, unmodified: the callers of the boundary, the unit tests, the program
 for f in $S/problem_joint_gravmag.F90 $S/tests/tests_inversion.f90 $S/tests/tests_lsqr.f90 $S/tests/tests_parallel_tools.f90 \
          $S/tests/tests_sparse_matrix.f90 $S/tests/tests_wavelet_compression.f90 $S/tests/unit_tests.f90 $S/program_tomofastx.F90; do compile "$f"; done

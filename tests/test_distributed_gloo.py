@@ -21,6 +21,9 @@ class OracleCtx:
         self.nelements_total = int(np.prod(dims))
         self.S = None
 
+    def matrix_reserve(self, nnz_upper):
+        self.reserved = int(nnz_upper)          # (what the next column-range build may hold: checked below)
+
     def calculate_sensit(self, X, Y, Z, cw, ctype, rate, pw=1.0, dw=None, col_range=None, want_hist=False):
         import oracle_lib as orc
         import multirank_model as mm
