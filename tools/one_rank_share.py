@@ -43,6 +43,7 @@ for P in Ps:
     for r in sorted({0, P - 1}):
         c0, c1 = int(bounds[r]), int(bounds[r + 1])
         t0 = time.time()
+        ctx.matrix_reserve(int(nnz[r]))               # what the all-reduced histogram says the range holds (tfx_matrix_reserve)
         got = ctx.calculate_sensit(xs, ys, zs, cw, w["ctype"], w["rate"], col_range=(c0, c1))
         t_build = time.time() - t0
         assert got["nnz"] == int(nnz[r]), (got["nnz"], nnz[r])
