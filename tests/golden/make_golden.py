@@ -23,6 +23,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import time
 
 import numpy as np
 
@@ -1188,6 +1189,40 @@ def make_mansf(tmp):
                     rate=0.15, nmajor=60, nminor=100))
     np.savez_compressed(os.path.join(HERE, "mansf.npz"), **res)
     print("mansf.npz: nnz", res["nnz_total"], "err", res["comp_error"], "P2", res["np2_nelements_at_cpu"], "P4", res["np4_nelements_at_cpu"])
+
+
+def make_hamersley(tmp):
+    """The reference's shipped REAL-DATA examples (parfiles/hamersley/: gravity and magnetic field data over the Hamersley province on a
+    13 x 133 x 33 grid, 113 data each, uncompressed kernels): gravity alone with model + gradient damping, magnetic alone, and the joint
+    inversion with the cross-gradient constraint, run by the reference at 1 and 2 ranks.  Inputs (grid, data) and outputs as arrays; the
+    Parfile keys / values (section banners and comments dropped) with the paths as the tests lay the files out."""
+    dd = os.path.join(REFROOT, "data", "gravmag", "hamersley")
+    grid = np.loadtxt(os.path.join(dd, "grav_grid.txt"), skiprows=1)
+    assert np.array_equal(grid, np.loadtxt(os.path.join(dd, "mag_grid.txt"), skiprows=1))
+    res = dict(nx=13, ny=133, nz=33, X1=grid[:, 0], X2=grid[:, 1], Y1=grid[:, 2], Y2=grid[:, 3], Z1=grid[:, 4], Z2=grid[:, 5],
+               grid_ijk=grid[:, 6:9].astype(np.int32),
+               data_grav=np.loadtxt(os.path.join(dd, "grav_observed_data.txt"), skiprows=1),
+               data_magn=np.loadtxt(os.path.join(dd, "mag_observed_data.txt"), skiprows=1))
+    for case, fname, tags in (("grav", "Parfile_hamersley_grav.txt", ("grav",)), ("magn", "Parfile_hamersley_mag.txt", ("mag",)),
+                              ("xgrad", "Parfile_hamersley_xgrad_joint.txt", ("grav", "mag"))):
+        text = open(os.path.join(REFROOT, "parfiles", "hamersley", fname)).read()
+        keys = [ln.strip() for ln in text.splitlines() if "=" in ln and not ln.lstrip().startswith("#") and not ln.lstrip().startswith("=")]
+        par = "\n".join(keys) + "\n"
+        outdir = [k.split("=", 1)[1].strip() for k in keys if k.startswith("global.outputFolderPath")][0]
+        res[case + "_parfile"] = par
+        res[case + "_outdir"] = outdir
+        for nproc in (1, 2):
+            t0 = time.time()
+            wd, log = run_parfile(tmp, "hamersley_" + case, par, nproc, workdir_links=[(os.path.join(REFROOT, "data"), "data")])
+            od = os.path.join(wd, outdir)
+            for tag in tags:
+                res["%s_np%d_%s_model_final" % (case, nproc, tag)] = read_col(os.path.join(od, "model", tag + "_final_model_full.txt"), 0)
+                res["%s_np%d_%s_data_final" % (case, nproc, tag)] = read_tokens(os.path.join(od, "data", tag + "_final.txt"), 4)[:, 3]
+            res["%s_np%d_lsqr_r" % (case, nproc)] = np.array([float(m.group(1)) for m in re.finditer(r"Finished lsqr solver, r =\s*([0-9.eE+-]+)", log)])
+            txt = open(os.path.join(od, "costs.txt")).read()
+            res["%s_np%d_costs_tokens" % (case, nproc)] = np.array([float(v) for v in txt[txt.index("clustering_cost_mag") + len("clustering_cost_mag"):].split()])
+            print("hamersley %s np%d: %.0f s, final r %.6e" % (case, nproc, time.time() - t0, res["%s_np%d_lsqr_r" % (case, nproc)][-1]))
+    np.savez_compressed(os.path.join(HERE, "hamersley.npz"), **res)
 
 
 if __name__ == "__main__":

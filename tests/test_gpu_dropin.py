@@ -251,3 +251,52 @@ def test_dropin_reloads_the_kernel_files_it_wrote(tmp_path, golden_dir):
         print("drop-in, sensit.readFromFiles = %d: final model rel-L2 %.2e from the reference" % (mode, rel))
         assert rel <= 3e-5
     assert np.array_equal(models[0], models[1]) and np.array_equal(models[0], models[2])
+
+
+def _write_hamersley_inputs(wd, g):
+    dd = os.path.join(wd, "data", "gravmag", "hamersley")
+    os.makedirs(dd)
+    n = g["X1"].size
+    ijk = g["grid_ijk"]
+    for name in ("grav_grid.txt", "mag_grid.txt"):
+        with open(os.path.join(dd, name), "w") as f:
+            f.write("%d\n" % n)
+            for p in range(n):
+                f.write("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %d\n" % (g["X1"][p], g["X2"][p], g["Y1"][p], g["Y2"][p], g["Z1"][p], g["Z2"][p],
+                                                                          ijk[p, 0], ijk[p, 1], ijk[p, 2]))
+    for name, key in (("grav_observed_data.txt", "data_grav"), ("mag_observed_data.txt", "data_magn")):
+        with open(os.path.join(dd, name), "w") as f:
+            f.write("%d\n" % g[key].shape[0])
+            for r in g[key]:
+                f.write(" ".join("%.17g" % v for v in r) + "\n")
+
+
+@pytest.mark.parametrize("host", ["reference program + drop-in", "shipping Fortran host"])
+@pytest.mark.parametrize("case", ["grav", "magn", "xgrad"])
+def test_hamersley_field_data_examples_of_the_reference(tmp_path, golden_dir, case, host):
+    """The reference's shipped real-data examples (parfiles/hamersley/: gravity and magnetic field data of the Hamersley province, 13 x 133
+    x 33 cells, 113 data each, uncompressed kernels; gravity with model + gradient damping, magnetic likewise, the joint inversion with the
+    cross-gradient constraint, 10-15 x 100 iterations) through the reference's own program with the drop-in modules and through the
+    shipping host, against the all-CPU reference's 1-rank run (tests/golden/hamersley.npz); yardstick: its own 1- vs 2-rank distance."""
+    exe = EXE if host.startswith("reference") else fh.EXE
+    if not os.path.isfile(exe):
+        pytest.skip("%s not built" % exe)
+    g = np.load(os.path.join(golden_dir, "hamersley.npz"))
+    wd = str(tmp_path)
+    _write_hamersley_inputs(wd, g)
+    open(os.path.join(wd, "Parfile.txt"), "w").write(str(g[case + "_parfile"]))
+    out = fh._sub_run([exe, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "THE END" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    od = os.path.join(wd, str(g[case + "_outdir"]))
+    for tag in (("grav",) if case == "grav" else ("mag",) if case == "magn" else ("grav", "mag")):
+        ref = g["%s_np1_%s_model_final" % (case, tag)]
+        own = float(np.linalg.norm(g["%s_np2_%s_model_final" % (case, tag)] - ref) / np.linalg.norm(ref))
+        model = fh.read_tokens(os.path.join(od, "model", tag + "_final_model_full.txt"), 1)[:, 0]
+        rel = float(np.linalg.norm(model - ref) / np.linalg.norm(ref))
+        dref = g["%s_np1_%s_data_final" % (case, tag)]
+        dfin = fh.read_tokens(os.path.join(od, "data", tag + "_final.txt"), 4)[:, 3]
+        drel = float(np.linalg.norm(dfin - dref) / np.linalg.norm(dref))
+        print("hamersley %s, %s, %s: final model rel-L2 %.2e, final data rel-L2 %.2e from the reference's 1-rank run (its own 1- vs 2-rank: %.1e)" %
+              (case, tag, host, rel, drel, own))
+        assert rel <= max(1e-6, 20.0 * own), (rel, own)
+        assert drel <= max(1e-6, 20.0 * own), (drel, own)
