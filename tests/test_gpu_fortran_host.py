@@ -50,6 +50,18 @@ inversion.admm.grav.weight          = 1.d-5
 
 
 
+class _Members(dict):
+    files = property(lambda self: list(self))
+
+
+def _load_npz(path):
+    """The members of an .npz as a dict of arrays: indexing an NpzFile decompresses the member on every access, and the input writers
+    below index the grid arrays cell by cell."""
+    with np.load(path) as z:
+        return _Members({k: z[k] for k in z.files})
+
+
+
 def _sub_run(cmd, **kw):
     """subprocess.run; a run that does not come back is a failure that shows what the host had printed (its phase banners), not a bare
     TimeoutExpired after a quarter of an hour."""
@@ -85,7 +97,7 @@ def write_inputs(wd, g):
 def test_config1_from_parfile_matches_reference_outputs(tmp_path, golden_dir):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, "mansf.npz"))
+    g = _load_npz(os.path.join(golden_dir, "mansf.npz"))
     wd = str(tmp_path)
     write_inputs(wd, g)
     out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
@@ -126,7 +138,7 @@ def test_multicomponent_parfiles_match_reference_outputs(tmp_path, golden_dir, n
     files, same output files."""
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     n = g["X1"].size
     nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
@@ -195,7 +207,7 @@ def test_sensit_files_written_like_the_reference_and_reloaded(tmp_path, golden_d
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
     sio = importlib.import_module("tomofast-x_amd").sensit_io
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
     par = str(g["parfile"])
@@ -264,7 +276,7 @@ def test_joint_parfile_matches_reference_outputs(tmp_path, golden_dir):
     """Joint gravity + magnetic inversion from the Parfile (both problem weights non-zero): two kernels, one LSQR system."""
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, "e2e_joint.npz"))
+    g = _load_npz(os.path.join(golden_dir, "e2e_joint.npz"))
     wd = str(tmp_path)
     write_joint_inputs(wd, g)
     out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
@@ -287,7 +299,7 @@ def test_cross_gradient_parfile_matches_reference(tmp_path, golden_dir, name):
     (forward or central differences), uploads them as the general constraint matrix, WAVELET_DOMAIN = F."""
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     write_joint_inputs(wd, g)
     out = _sub_run([EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
@@ -308,7 +320,7 @@ def test_clustering_parfile_matches_reference(tmp_path, golden_dir, name):
     Gaussian-mixture rows each major iteration and uploads them as the general constraint matrix, WAVELET_DOMAIN = F."""
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     write_joint_inputs(wd, g)
     with open(os.path.join(wd, "mixtures.txt"), "w") as f:
@@ -342,7 +354,7 @@ def test_two_ranks_under_mpiexec_match_the_reference_two_rank_run(tmp_path, gold
         pytest.skip("Fortran host not built (no amdflang)")
     if not os.path.isfile(MPIEXEC):
         pytest.skip("no mpiexec in this image")
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     if name == "e2e_joint":
         n = g["X1"].size
@@ -419,7 +431,7 @@ def test_config1_with_admm_under_mpiexec(tmp_path, golden_dir, nranks):
         pytest.skip("Fortran host not built (no amdflang)")
     if not os.path.isfile(MPIEXEC):
         pytest.skip("no mpiexec in this image")
-    g = np.load(os.path.join(golden_dir, "mansf.npz"))
+    g = _load_npz(os.path.join(golden_dir, "mansf.npz"))
     wd = str(tmp_path)
     write_inputs(wd, g)
     out = _sub_run([MPIEXEC, "-n", str(nranks), EXE, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=300)
@@ -442,7 +454,7 @@ def test_spatial_unknowns_two_ranks_under_mpiexec(tmp_path, golden_dir, name):
         pytest.skip("Fortran host not built (no amdflang)")
     if not os.path.isfile(MPIEXEC):
         pytest.skip("no mpiexec in this image")
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     if name == "e2e_dgrad":
         write_case_inputs(wd, g)
@@ -609,7 +621,7 @@ def test_gradient_damping_parfile_matches_reference(tmp_path, golden_dir):
     constraint matrix and solves with WAVELET_DOMAIN = F (spatial unknowns, per-iteration device transform)."""
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, "e2e_dgrad.npz"))
+    g = _load_npz(os.path.join(golden_dir, "e2e_dgrad.npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
@@ -626,7 +638,7 @@ def test_mindist_depth_weight_parfile_matches_reference(tmp_path, golden_dir):
     """forward.depthWeighting.type = 3 from the Parfile: calculate_depth_weight -> tfx_column_weight_type3, then the usual run."""
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, "e2e_dw3.npz"))
+    g = _load_npz(os.path.join(golden_dir, "e2e_dw3.npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
@@ -643,7 +655,7 @@ def test_mindist_depth_weight_parfile_matches_reference(tmp_path, golden_dir):
 def test_lp_norm_damping_parfile_matches_reference(tmp_path, golden_dir):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, "e2e_lp.npz"))
+    g = _load_npz(os.path.join(golden_dir, "e2e_lp.npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
@@ -657,7 +669,7 @@ def test_lp_norm_damping_parfile_matches_reference(tmp_path, golden_dir):
 def test_admm_local_bounds_parfile_matches_reference(tmp_path, golden_dir):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, "e2e_admm_local.npz"))
+    g = _load_npz(os.path.join(golden_dir, "e2e_admm_local.npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
     with open(os.path.join(wd, "bounds.txt"), "w") as f:
@@ -675,7 +687,7 @@ def test_admm_local_bounds_parfile_matches_reference(tmp_path, golden_dir):
 def test_data_errors_parfile_matches_reference(tmp_path, golden_dir):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, "e2e_err.npz"))
+    g = _load_npz(os.path.join(golden_dir, "e2e_err.npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
     with open(os.path.join(wd, "data_error.txt"), "w") as f:
@@ -702,7 +714,7 @@ def test_data_errors_parfile_matches_reference(tmp_path, golden_dir):
 def test_local_weights_parfile_matches_reference(tmp_path, golden_dir, name):
     if not os.path.isfile(EXE):
         pytest.skip("Fortran host not built (no amdflang)")
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
     for fname, key in (("lw_depth.txt", "lw_depth"), ("lw_damp.txt", "lw_damp")):
