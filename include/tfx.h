@@ -327,11 +327,6 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * keys "band_batches" / "band_fallbacks": return how many row batches used it / fell back to the full select;
  * key "deterministic": accepted and ignored (older hosts set it) - the two matrix products are always reproducible: every fp64 sum
  * is formed in an order fixed by the matrix and its work lists (forward kernel), or exactly in integers (adjoint without a copy);
- * key "lsqr_phased" (0 / 1, default 1; environment TFX_LSQR_PHASED): 1 = the vector work of an LSQR iteration runs as two phase
- *     kernels with a grid barrier each (six launches per single-rank iteration instead of ten to thirteen; solves whose ranks reduce
- *     through host hooks always take the separate launches); 0 = separate launches.  Both forms give identical bits.
- * key "lsqr_phase_grid" (0 = automatic): cap of the phase kernels' grid (tests: a small grid makes every workgroup play several of
- *     the separate kernels' blocks); any value gives the same bits;
  * key "fwd_group" (0 = automatic, 1, 2; larger values are clamped to 2): row blocks that share one staged x tile in the forward product;
  * key "fwd_run" (1..16, default 2; environment TFX_FWD_RUN): consecutive chunks a wave of the forward kernel takes at a time;
  * key "adj_copy" (0 never / 1 always / 2 automatic, default 2; environment TFX_ADJ_COPY): matrices finished from now on get a

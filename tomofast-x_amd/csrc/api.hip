@@ -30,9 +30,6 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     if (const char *e = getenv("TFX_TR_PANEL_ENTRIES")) { if (atof(e) > 0) c->tr_panel_entries = atof(e); }     // like the debug keys "tr_panel_entries" /
     if (const char *e = getenv("TFX_TR_POS_BUDGET")) { if (atof(e) > 0) c->tr_pos_budget = atof(e); }           //   "tr_pos_budget": sweeps force many small panels
     if (const char *e = getenv("TFX_FWD_RUN")) c->fwd_run = std::min(16, std::max(1, atoi(e)));
-    if (const char *e = getenv("TFX_LSQR_PHASED")) c->lsqr_phased = atoi(e) != 0;
-    if (const char *e = getenv("TFX_LSQR_PHASE_GRID")) c->lsqr_phase_grid = std::max(0, atoi(e));
-    if (const char *e = getenv("TFX_LSQR_PHASE_NAP")) c->lsqr_phase_nap = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("TFX_ADJ_COPY_MIN_NNZ")) c->adj_copy_min_nnz = atoll(e);
     if (const char *e = getenv("TFX_CHAIN_UNDER_WAVELET")) c->chain_under_wavelet = atoi(e) != 0;
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = std::max(0, std::min(2, atoi(e)));
@@ -250,18 +247,6 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
     }
     if (!strcmp(key, "fwd_run")) {              // chunks per run of the forward kernel (>= 1); the sums stay reproducible for a fixed value
         ctx->fwd_run = std::min(16, std::max(1, value));
-        return 0;
-    }
-    if (!strcmp(key, "lsqr_phased")) {          // 1: the vector work of an LSQR iteration as two phase kernels (default), 0: separate launches; same bits
-        ctx->lsqr_phased = value != 0;
-        return 0;
-    }
-    if (!strcmp(key, "lsqr_phase_nap")) {
-        ctx->lsqr_phase_nap = std::max(0, std::min(64, value));
-        return 0;
-    }
-    if (!strcmp(key, "lsqr_phase_grid")) {      // cap of the phase kernels' grid (0: automatic); any value gives the same bits
-        ctx->lsqr_phase_grid = std::max(0, value);
         return 0;
     }
     if (!strcmp(key, "fwd_group")) {            // row blocks per forward super block for matrices finished from now on (0 = automatic)

@@ -302,9 +302,6 @@ struct tfx_ctx {
     } trs;
     double tr_panel_entries = 9.0e8, tr_pos_budget = 1.5e8;   // panel size of the transposition (debug keys "tr_panel_entries" / "tr_pos_budget": tests force many small panels of either shape)
     int64_t reserve_nnz = 0;          // tfx_matrix_reserve: entry bound of the next kernel build into the selected slot (0 = rows x K)
-    int lsqr_phased = 0;              // debug key "lsqr_phased" / TFX_LSQR_PHASED: the vector work of an LSQR iteration as two phase kernels with a grid barrier (lsqr.hip); 0: separate launches, same bits
-    int lsqr_phase_nap = 1;           // debug key "lsqr_phase_nap" / TFX_LSQR_PHASE_NAP: s_sleep(16) periods between two polls of the barrier's release word
-    int lsqr_phase_grid = 0;          // debug key "lsqr_phase_grid": cap of the phase kernels' grid (0: what fits the device); tests drive the virtual-block loops with it
     int fwd_run = 2;                  // debug key "fwd_run": consecutive chunks a wave of the forward kernel takes at a time (matrix.hip k_spmv_fwd)
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
     size_t wave_lds_attr[4] = {0, 0, 0, 0};   // the same for the four wavelet axis kernels (Haar / D4 x forward / inverse)

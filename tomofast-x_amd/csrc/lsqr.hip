@@ -20,8 +20,7 @@ struct Scalars {
     double sum_u, sum_uc, sum_v, misfit_ss;
     double inv_alpha;      // 1/alpha kept apart from t2 when the rotation runs in the same launch
     double rmin;           // stop test of the iteration loop, evaluated on the device (lsqr_solver2.F90:163)
-    int32_t stop, skip, iters, bar_fail;   // stop: no further iteration may change x / the scalars; skip: this iteration is void;
-                                           // bar_fail: a workgroup of a phase kernel gave up waiting at the grid barrier
+    int32_t stop, skip, iters, pad2;   // stop: no further iteration may change x / the scalars; skip: this iteration is void
     int32_t rho_zero, u_zero, v_zero, pad;
 };
 
@@ -40,11 +39,6 @@ struct LsqrState {
     std::vector<int64_t> g_counts, g_displs;   //   cells per rank and first cell of every rank (all-gather of the slices)
     DBuf<double> red;      // block partial sums
     DBuf<unsigned int> cnt;   // arrival counters of the single-launch reductions (zero between launches)
-    DBuf<double> red2;     // second set of block partial sums (the phase kernels reduce two norms in one launch)
-    DBuf<unsigned int> bar;   // grid barrier of the phase kernels: 32 group counters, root counter, release word
-    unsigned int bar_gen = 0; //   value the next release writes (one barrier per launch)
-    bool phased = false;      // this solve runs the vector work of an iteration as two phase kernels (k_lsqr_mid / k_lsqr_end)
-    int phase_grid = 0;       //   their grid: every workgroup resident at once
     DBuf<Scalars> sc;
     Scalars *h_sc = nullptr;   // pinned
     int iter = 0;          // iterations completed
@@ -336,219 +330,6 @@ __global__ void k_misfit(const double *__restrict__ sx, const double *__restrict
     if (threadIdx.x == 0) red[blockIdx.x] = s;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Phase kernels: the vector work between the two products of an iteration in ONE launch each.
-//
-// An iteration of a small or medium system (and a rank's share of a large one on 8 GPUs) is bound by the latency between dependent
-// launches, not by bytes: ten launches, six of them vector kernels of a few microseconds each (profiles/README.md, "LSQR launch
-// chain"; replaying the same chain from a HIP graph changed nothing - the gaps are on the device).  k_lsqr_mid is
-// [constraint forward step + |u|^2] -> beta -> [u, u_cons /= beta ; v = -beta v]; k_lsqr_end is [constraint adjoint step + |v|^2] ->
-// alpha, plane rotation -> [v /= alpha ; x, w update ; soft threshold ; u = -alpha u for the NEXT iteration].  The "->" is a grid
-// barrier: every workgroup leaves its partial sums, the one that arrives last adds them up in index order, sets the scalars and
-// releases the others.  The arithmetic is the one of the separate kernels, partial sum by partial sum: a workgroup plays the
-// "virtual blocks" vb = blockIdx.x, blockIdx.x + gridDim.x, ... of the grid the separate kernel would have been launched with, so the
-// bits of a solve do not depend on which of the two forms ran (tests/test_gpu_parity.py::test_lsqr_phase_kernels_same_bits).
-//
-// The barrier needs every workgroup resident at once: the grid is capped at what the occupancy query says fits the device
-// (tfx_lsqr_begin).  A wait that lasts longer than BAR_TIMEOUT_TICKS (another process holding the CUs with a barrier of its own)
-// gives up: the workgroup sets Scalars::bar_fail and returns, the host turns the flag into an error - a rank can fail, it can not hang
-// the GPU.  bar[0..31]: arrival counters of groups of 32 workgroups (1024 same-address atomics in a row would cost more than the
-// launches saved), bar[32]: arrivals of the groups, bar[33]: release word (the launch's generation number).
-constexpr unsigned long long BAR_TIMEOUT_TICKS = 400000000ull;     // 4 s of the 100 MHz wall clock
-
-// What crosses workgroups inside a phase kernel are the partial sums, the scalars and the barrier words - never the vectors: phase 2 gives
-// every element to the thread that touched it in phase 1.  So the barrier needs no device-wide cache write-back / invalidate per workgroup
-// (a __threadfence() in each of 1024 workgroups made the launch ten times slower than the launches it replaced): the partial sums are
-// stored and read with agent-scope accesses that go through to memory, a workgroup waits for its own stores before it arrives, and only the
-// workgroup that arrives last - it writes the scalars with plain stores - fences once before the release.
-__device__ __forceinline__ void put(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double get(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// value of a scalar another workgroup of this launch has just written
-__device__ __forceinline__ double fresh(const double *p) { return *(const volatile double *)p; }
-__device__ __forceinline__ int fresh(const int32_t *p) { return *(const volatile int32_t *)p; }
-
-__device__ __forceinline__ bool grid_arrive(unsigned int *bar)         // true in every thread of the workgroup that arrived last
-{
-    __shared__ int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // thread 0's partial sums (agent-scope stores) are complete before its
-        __builtin_amdgcn_s_waitcnt(0);                                  //   arrival shows: compiler order + every counter of the wave at zero
-        const unsigned int G = gridDim.x, ngroups = (G + 31u) >> 5, g = blockIdx.x >> 5;
-        const unsigned int gsize = min(32u, G - (g << 5));
-        int last = 0;
-        if (__hip_atomic_fetch_add(&bar[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
-            __hip_atomic_store(&bar[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(&bar[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u) {
-                __hip_atomic_store(&bar[32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = 1;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        s_last = last;
-    }
-    __syncthreads();
-    return s_last != 0;
-}
-
-__device__ __forceinline__ void grid_release(unsigned int *bar, unsigned int gen)
-{
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();                                                // the scalars (plain stores of this thread) reach memory first
-        __hip_atomic_store(&bar[33], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-__device__ __forceinline__ bool grid_wait(unsigned int *bar, unsigned int gen, Scalars *sc, int nap)      // false: gave up
-{
-    __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();
-        int ok = 1;
-        while (__hip_atomic_load(&bar[33], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
-            for (int k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(16);
-            if (wall_clock64() - t0 > BAR_TIMEOUT_TICKS) {
-                ok = 0;
-                __hip_atomic_store(&sc->bar_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        s_ok = ok;
-    }
-    __syncthreads();
-    return s_ok != 0;
-}
-
-// the sum of n partial sums in the association of final_sum_dev / k_final_sum (valid in thread 0)
-__device__ __forceinline__ double final_sum_get(const double *red, int n)
-{
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s += get(&red[i]);
-    return block_sum(s);
-}
-
-// CONS_FWD (single rank): k_cons_forward + k_sumsq_beta + k_scale_u_uc_v.  Several ranks: the constraint step and the all-reduce
-// of [u ; |u_cons|^2] come first as before, the launch is k_sumsq_beta + k_scale_u_uc_v.           (lsqr_solver2.F90:211-225)
-template <bool CONS_FWD>
-__global__ __launch_bounds__(RED_THREADS) void k_lsqr_mid(double *__restrict__ u, int64_t nr, double *__restrict__ uc,
-                                                          const float *__restrict__ diag, double *__restrict__ v, int64_t nc, int nblocks,
-                                                          Scalars *sc, double *red_u, int g_u, double *red_uc, int g_c,
-                                                          unsigned int *bar, unsigned int gen, int nap)
-{
-    if (CONS_FWD) {
-        const double alpha = sc->alpha;
-        for (int vb = blockIdx.x; vb < g_c; vb += gridDim.x) {
-            double s = 0.0;
-            for (int64_t i = (int64_t)vb * RED_THREADS + threadIdx.x; i < nc; i += (int64_t)g_c * RED_THREADS) {
-                const double vi = v[i];
-                for (int b = 0; b < nblocks; ++b) {
-                    const int64_t k = (int64_t)b * nc + i;
-                    const double t = -alpha * uc[k] + (double)diag[k] * vi;
-                    uc[k] = t;
-                    s = fma(t, t, s);
-                }
-            }
-            s = block_sum(s);
-            if (threadIdx.x == 0) put(&red_uc[vb], s);
-        }
-    }
-    for (int vb = blockIdx.x; vb < g_u; vb += gridDim.x) {
-        double s = 0.0;
-        for (int64_t i = (int64_t)vb * RED_THREADS + threadIdx.x; i < nr; i += (int64_t)g_u * RED_THREADS) s = fma(u[i], u[i], s);
-        s = block_sum(s);
-        if (threadIdx.x == 0) put(&red_u[vb], s);
-    }
-    if (grid_arrive(bar)) {
-        double uc_total = 0.0;
-        if (CONS_FWD) {
-            uc_total = final_sum_get(red_uc, g_c);
-            if (threadIdx.x == 0) u[nr] = uc_total;
-        }
-        const double tot = final_sum_get(red_u, g_u);
-        if (threadIdx.x == 0) {
-            sc->sum_u = tot;
-            set_beta(sc, CONS_FWD ? uc_total : u[nr]);
-        }
-        grid_release(bar, gen);
-    } else if (!grid_wait(bar, gen, sc, nap)) {
-        return;
-    }
-    // phase 2: every element goes to the thread that had it in phase 1 (the vectors never cross workgroups inside the launch)
-    const double f = fresh(&sc->t1), beta = fresh(&sc->beta);
-    for (int vb = blockIdx.x; vb < g_u; vb += gridDim.x)
-        for (int64_t i = (int64_t)vb * RED_THREADS + threadIdx.x; i < nr; i += (int64_t)g_u * RED_THREADS) u[i] = f * u[i];
-    for (int vb = blockIdx.x; vb < g_c; vb += gridDim.x)
-        for (int64_t i = (int64_t)vb * RED_THREADS + threadIdx.x; i < nc; i += (int64_t)g_c * RED_THREADS) {
-            for (int b = 0; b < nblocks; ++b) {
-                const int64_t k = (int64_t)b * nc + i;
-                uc[k] = f * uc[k];
-            }
-            v[i] = -beta * v[i];
-        }
-}
-
-// CONS_ADJ (single rank): k_cons_adjoint + alpha + rotation + k_update_xw + next iteration's u = -alpha u.  Several ranks: the
-// constraint step and the all-reduce of |v|^2 come first, the launch is alpha + rotation + k_update_xw + the scaling of u (u_mode 1:
-// -alpha u on rank 0, 2: zero on the others, lsqr_solver2.F90:194-198).                              (:236-274)
-template <bool CONS_ADJ>
-__global__ __launch_bounds__(RED_THREADS) void k_lsqr_end(double *__restrict__ v, const float *__restrict__ diag, const double *__restrict__ uc,
-                                                          int64_t nc, int nblocks, double *red, int g_c, Scalars *sc, double *__restrict__ w,
-                                                          double *__restrict__ x, double gamma, double *__restrict__ u, int64_t nr, int u_mode,
-                                                          unsigned int *bar, unsigned int gen, int nap)
-{
-    if (CONS_ADJ) {
-        for (int vb = blockIdx.x; vb < g_c; vb += gridDim.x) {
-            double s = 0.0;
-            for (int64_t i = (int64_t)vb * RED_THREADS + threadIdx.x; i < nc; i += (int64_t)g_c * RED_THREADS) {
-                double t = v[i];
-                for (int b = 0; b < nblocks; ++b) {
-                    const int64_t k = (int64_t)b * nc + i;
-                    t = fma((double)diag[k], uc[k], t);
-                }
-                v[i] = t;
-                s = fma(t, t, s);
-            }
-            s = block_sum(s);
-            if (threadIdx.x == 0) put(&red[vb], s);
-        }
-    }
-    if (grid_arrive(bar)) {
-        double tot = 0.0;
-        if (CONS_ADJ) tot = final_sum_get(red, g_c);
-        if (threadIdx.x == 0) {
-            if (CONS_ADJ) sc->sum_v = tot;
-            set_alpha(sc);
-            rotate(sc);
-        }
-        grid_release(bar, gen);
-    } else if (!grid_wait(bar, gen, sc, nap)) {
-        return;
-    }
-    if (!fresh(&sc->skip)) {
-        const double t1 = fresh(&sc->t1), t2 = fresh(&sc->t2), ia = fresh(&sc->inv_alpha);
-        for (int vb = blockIdx.x; vb < g_c; vb += gridDim.x)
-            for (int64_t i = (int64_t)vb * RED_THREADS + threadIdx.x; i < nc; i += (int64_t)g_c * RED_THREADS) {
-                const double wi = w[i];
-                double xi = t1 * wi + x[i];
-                const double vi = ia * v[i];
-                v[i] = vi;
-                w[i] = t2 * wi + vi;
-                if (gamma != 0.0) {                                    // :478-494
-                    if (fabs(xi) <= gamma) xi = 0.0;
-                    else if (xi <= -gamma) xi = xi + gamma;
-                    else if (xi >= gamma) xi = xi - gamma;
-                }
-                x[i] = xi;
-            }
-    }
-    const double alpha = fresh(&sc->alpha);
-    const int64_t i0 = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x, st = (int64_t)gridDim.x * RED_THREADS;
-    if (u_mode == 1) for (int64_t i = i0; i < nr; i += st) u[i] = -alpha * u[i];
-    else for (int64_t i = i0; i < nr; i += st) u[i] = 0.0;
-}
-
 static inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(RED_BLOCKS, (n + RED_THREADS - 1) / RED_THREADS)); }
 
 #define LAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(RED_THREADS), 0, s, __VA_ARGS__)
@@ -664,8 +445,7 @@ static int transform_slice(tfx_ctx *ctx, LsqrState *L, int dir)
 // fuse_rotate (iterations on a single rank): alpha and the plane rotation come out of the final-sum launch and the
 // normalisation of v is left to k_update_xw
 // defer_scale (iterations on several ranks): after the all-reduce of |v|^2 one launch sets alpha and rotates; v / alpha again in k_update_xw
-// phased: everything after the products (single rank) / after the all-reduce of |v|^2 (several ranks) is left to k_lsqr_end
-static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L, bool fuse_rotate = false, bool defer_scale = false, bool phased = false)
+static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L, bool fuse_rotate = false, bool defer_scale = false)
 {
     hipStream_t s = ctx->stream;
     if (ctx->spatial_unknowns) {                                         // lsqr_solver2.F90:137-145, :228-236
@@ -677,7 +457,6 @@ static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L, bool fuse_rotate = fals
     }
     if (ctx->cons.valid) TFX_TRY(spmtv_dev(ctx, ctx->cons, L->u.p + L->nrows_data, L->v.p, 1));     // lsqr_solver2.F90:147, :238
     const int g = grid_for(L->ncols);
-    if (phased && !ctx->multi()) return 0;                               // the constraint step, alpha and the rotation: k_lsqr_end<true>
     const int vmode = fuse_rotate ? 2 : 1;
     if (g <= ONE_LAUNCH_MAX_BLOCKS) {
         LAUNCH(k_cons_adjoint, g, L->v.p, L->diag.p, L->uc.p, L->ncols, L->nblocks, L->red.p, L->cnt.p + 1, L->sc.p, vmode);
@@ -688,7 +467,6 @@ static int adjoint_and_alpha(tfx_ctx *ctx, LsqrState *L, bool fuse_rotate = fals
     TFX_HIP(hipGetLastError());
     if (fuse_rotate) return 0;
     TFX_TRY(allreduce(ctx, &L->sc.p->sum_v, 1));
-    if (phased) return 0;                                                // alpha and the rotation: k_lsqr_end<false>
     if (defer_scale) {
         LAUNCH(k_alpha_rotate, 1, L->sc.p);
     } else {
@@ -756,29 +534,6 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     TFX_TRY(L->red.ensure(RED_BLOCKS));
     TFX_TRY(L->cnt.ensure(4));
     TFX_HIP(hipMemsetAsync(L->cnt.p, 0, 4 * sizeof(unsigned int), ctx->stream));
-    // Phase kernels (k_lsqr_mid / k_lsqr_end) unless switched off (debug key "lsqr_phased" / TFX_LSQR_PHASED=0) or the ranks reduce through
-    // host hooks (ranks that share a GPU would wait on each other's barriers; a hook synchronises with the host anyway).
-    L->phased = ctx->lsqr_phased != 0 && !(ctx->multi() && !ctx->comm);
-    if (L->phased) {
-        static int per_cu = -1;        // resident workgroups of the larger phase kernel per CU (the same on every MI355X of a box)
-        if (per_cu < 0) {
-            int a = 0, b = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_lsqr_mid<true>, RED_THREADS, 0) != hipSuccess) a = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_lsqr_end<true>, RED_THREADS, 0) != hipSuccess) b = 0;
-            per_cu = std::min(a, b);
-        }
-        const int64_t nuc = (int64_t)nblocks * nc;
-        const int want = grid_for(std::max(std::max(nr, nuc), nc));
-        L->phase_grid = (int)std::min<int64_t>(want, std::min<int64_t>(RED_BLOCKS, (int64_t)ctx->num_cu * std::min(per_cu, 4)));
-        if (ctx->lsqr_phase_grid > 0) L->phase_grid = std::min(L->phase_grid, ctx->lsqr_phase_grid);
-        if (L->phase_grid < 1) L->phased = false;
-    }
-    if (L->phased) {
-        TFX_TRY(L->red2.ensure(RED_BLOCKS));
-        TFX_TRY(L->bar.ensure(64));
-        TFX_HIP(hipMemsetAsync(L->bar.p, 0, 64 * sizeof(unsigned int), ctx->stream));
-        L->bar_gen = 0;
-    }
     if (ctx->spatial_unknowns) {
         const int64_t n123 = (int64_t)ctx->wd_n1 * ctx->wd_n2 * ctx->wd_n3;
         if (ctx->multi()) {
@@ -866,8 +621,6 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     TFX_TRY(adjoint_and_alpha(ctx, L));                                                  // :137-150
     LAUNCH(k_init_scalars, 1, L->sc.p, L->rmin);                                         // :134, :155-156
     LAUNCH(k_copy, grid_for(nc), L->w.p, L->v.p, nc);                                    // :157
-    // the phase kernels scale u for the next iteration at the end of the current one: the first iteration's -alpha u (:194-198) here
-    if (L->phased) LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
     TFX_HIP(hipGetLastError());
     TFX_TRY(read_scalars(ctx, L));
     if (L->h_sc->v_zero) return fail(TFX_E_NUMERIC, "Could not normalize initial v, zero denominator!");
@@ -937,7 +690,7 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
         }
         for (int j = 0; j < chunk; ++j) {
             // u = -alpha u (rank 0) | 0 (others), then u += S_loc v                       :194-209
-            if (!L->phased) LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
+            LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
             if (ctx->spatial_unknowns) {                                                  // :200-209
                 LAUNCH(k_copy, grid_for(nc), L->tw.p, L->v.p, nc);
                 TFX_TRY(transform_slice(ctx, L, 1));
@@ -946,11 +699,7 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
                 TFX_TRY(S_forward(ctx, L->v.p, L->u.p, 1));
             }
             if (ctx->cons.valid) TFX_TRY(spmv_dev(ctx, ctx->cons, L->v.p, L->u.p + L->nrows_data, 1));   // :211 (general C rows)
-            const bool one_rank = !ctx->multi();
-            if (L->phased && one_rank) {                                                  // :211-225 in one launch
-                LAUNCH((k_lsqr_mid<true>), L->phase_grid, L->u.p, nr, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p, grid_for(nr),
-                       L->red2.p, grid_for(nc), L->bar.p, ++L->bar_gen, ctx->lsqr_phase_nap);
-            } else {                                                                      // :211 (diagonal blocks, local)
+            {                                                                             // :211 (diagonal blocks, local)
                 const int g = grid_for(nc);
                 if (g <= ONE_LAUNCH_MAX_BLOCKS) {
                     LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p, L->cnt.p + 2, L->u.p + nr);
@@ -960,38 +709,18 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
                 }
             }
             TFX_HIP(hipGetLastError());
-            if (!(L->phased && one_rank)) {
-                TFX_TRY(allreduce(ctx, L->u.p, nr + 1));                                  // :214
-                if (L->phased) {                                                          // :218-225 in one launch
-                    LAUNCH((k_lsqr_mid<false>), L->phase_grid, L->u.p, nr, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p,
-                           grid_for(nr), L->red2.p, grid_for(nc), L->bar.p, ++L->bar_gen, ctx->lsqr_phase_nap);
-                } else {
-                    TFX_TRY(norm_u(ctx, L));                                              // :218
-                    const int64_t nuc = (int64_t)L->nblocks * nc;                         // u, u_cons /= beta ; v = -beta v   (:218-225)
-                    LAUNCH(k_scale_u_uc_v, grid_for(std::max(std::max(nr, nuc), nc)), L->u.p, nr, L->uc.p, nuc, L->v.p, nc, L->sc.p);
-                }
+            TFX_TRY(allreduce(ctx, L->u.p, nr + 1));                                      // :214
+            TFX_TRY(norm_u(ctx, L));                                                      // :218
+            {                                                                             // u, u_cons /= beta ; v = -beta v   (:218-225)
+                const int64_t nuc = (int64_t)L->nblocks * nc;
+                LAUNCH(k_scale_u_uc_v, grid_for(std::max(std::max(nr, nuc), nc)), L->u.p, nr, L->uc.p, nuc, L->v.p, nc, L->sc.p);
             }
-            const bool fused = one_rank;                           // no reduction between sum_v and alpha
-            TFX_TRY(adjoint_and_alpha(ctx, L, fused, !fused, L->phased));                 // :228-241, :248-266 (alpha and the rotation)
-            if (L->phased) {                                                              // :236-274 and the next :194-198 in one launch
-                const int u_mode = ctx->rank == 0 ? 1 : 2;
-                if (one_rank)
-                    LAUNCH((k_lsqr_end<true>), L->phase_grid, L->v.p, L->diag.p, L->uc.p, nc, L->nblocks, L->red.p, grid_for(nc), L->sc.p, L->w.p,
-                           L->x.p, L->gamma, L->u.p, nr, u_mode, L->bar.p, ++L->bar_gen, ctx->lsqr_phase_nap);
-                else
-                    LAUNCH((k_lsqr_end<false>), L->phase_grid, L->v.p, L->diag.p, L->uc.p, nc, L->nblocks, L->red.p, grid_for(nc), L->sc.p, L->w.p,
-                           L->x.p, L->gamma, L->u.p, nr, u_mode, L->bar.p, ++L->bar_gen, ctx->lsqr_phase_nap);
-            } else {
-                LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, 1.0, L->gamma);   // v / alpha, :241, :269-274
-            }
+            const bool fused = !ctx->multi();                      // no reduction between sum_v and alpha
+            TFX_TRY(adjoint_and_alpha(ctx, L, fused, !fused));                            // :228-241, :248-266 (alpha and the rotation)
+            LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, 1.0, L->gamma);   // v / alpha, :241, :269-274
             TFX_HIP(hipGetLastError());
         }
         TFX_TRY(read_scalars(ctx, L));
-        if (L->h_sc->bar_fail) {
-            L->active = false;
-            return fail(TFX_E_STATE, "tfx_lsqr_iterate: a workgroup of a phase kernel waited %.0f s at the grid barrier and gave up (is another "
-                        "process holding the GPU's CUs? TFX_LSQR_PHASED=0 runs the iteration as separate launches)", (double)BAR_TIMEOUT_TICKS / 1e8);
-        }
         const int did = L->h_sc->iters - L->iter;                                         // iterations that counted
         L->iter = L->h_sc->iters;
         done += did;
