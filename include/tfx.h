@@ -327,6 +327,8 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * keys "band_batches" / "band_fallbacks": return how many row batches used it / fell back to the full select;
  * key "deterministic": accepted and ignored (older hosts set it) - the two matrix products are always reproducible: every fp64 sum
  * is formed in an order fixed by the matrix and its work lists (forward kernel), or exactly in integers (adjoint without a copy);
+ * key "lsqr_merge_tail" (0 / 1, default 1; environment TFX_LSQR_MERGE_TAIL): 1 = the x / w update of an LSQR iteration also does the next
+ *     iteration's u = -alpha u and constraint forward step (one launch instead of three); both forms give identical bits;
  * key "fwd_group" (0 = automatic, 1, 2; larger values are clamped to 2): row blocks that share one staged x tile in the forward product;
  * key "fwd_run" (1..16, default 2; environment TFX_FWD_RUN): consecutive chunks a wave of the forward kernel takes at a time;
  * key "adj_copy" (0 never / 1 always / 2 automatic, default 2; environment TFX_ADJ_COPY): matrices finished from now on get a

@@ -318,9 +318,11 @@ def test_hamersley_joint_cross_gradient_example(tmp_path, golden_dir, host):
     at 100, 0.004802 at 400, 0.0047372 at 1600 iterations), so its iterates depend on how the sums round: the reference's own 1- vs 2-rank
     runs differ by 1.3e-3 in that first r, and one-ulp perturbations of its kernel values move it by 2e-3.  The HIP path's first r is
     0.01251 - 17 % BELOW the reference's, at 400 iterations 0.004761 against 0.004802: sums in tile / tree order with fused multiply-adds
-    lose less of the Lanczos vectors' orthogonality, the same effect test_unconverged_lsqr_is_closer_to_extended_precision_than_sequential_fp64
-    pins against 80-bit arithmetic; on the reference's OWN kernel files (identical matrix bits) the same 16 % appears
-    (tools/hamersley_probe2.py).  What is asserted: (1) the systems are the same - the CONVERGED first solve (1 x 1600 iterations,
+    round less.  The same solve on the reference's own kernel files on the CPU (tools/hamersley_precision.py): sequential fp64 sums like the
+    reference's 0.01507 / 0.0048016, numpy's pairwise fp64 sums 0.01252 / 0.0047613, 80-bit long double 0.01232 / 0.0047434 - the HIP path is
+    1.5 % from the extended-precision recurrence where the reference's arithmetic is 22 % from it (the effect
+    test_unconverged_lsqr_is_closer_to_extended_precision_than_sequential_fp64 pins on a synthetic system); on the reference's OWN kernel
+    files (identical matrix bits) the HIP host shows the same 16 % (tools/hamersley_probe2.py).  What is asserted: (1) the systems are the same - the CONVERGED first solve (1 x 1600 iterations,
     tests/golden/hamersley_xgrad_conv.npz) agrees with the reference's in r, model and data; (2) at 100 and 400 iterations the HIP residual
     is not above the reference's; (3) the 15 x 100 run stays within the stated distance of the reference's (measured 1.05e-2 / 4.9e-2 in the
     two final models, identical for both hosts)."""

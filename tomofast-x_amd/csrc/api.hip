@@ -30,6 +30,7 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     if (const char *e = getenv("TFX_TR_PANEL_ENTRIES")) { if (atof(e) > 0) c->tr_panel_entries = atof(e); }     // like the debug keys "tr_panel_entries" /
     if (const char *e = getenv("TFX_TR_POS_BUDGET")) { if (atof(e) > 0) c->tr_pos_budget = atof(e); }           //   "tr_pos_budget": sweeps force many small panels
     if (const char *e = getenv("TFX_FWD_RUN")) c->fwd_run = std::min(16, std::max(1, atoi(e)));
+    if (const char *e = getenv("TFX_LSQR_MERGE_TAIL")) c->lsqr_merge_tail = atoi(e) != 0;
     if (const char *e = getenv("TFX_ADJ_COPY_MIN_NNZ")) c->adj_copy_min_nnz = atoll(e);
     if (const char *e = getenv("TFX_CHAIN_UNDER_WAVELET")) c->chain_under_wavelet = atoi(e) != 0;
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = std::max(0, std::min(2, atoi(e)));
@@ -247,6 +248,10 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
     }
     if (!strcmp(key, "fwd_run")) {              // chunks per run of the forward kernel (>= 1); the sums stay reproducible for a fixed value
         ctx->fwd_run = std::min(16, std::max(1, value));
+        return 0;
+    }
+    if (!strcmp(key, "lsqr_merge_tail")) {      // 1 (default): k_update_xw_next, 0: k_update_xw + k_scale + k_cons_forward as separate launches; same bits
+        ctx->lsqr_merge_tail = value != 0;
         return 0;
     }
     if (!strcmp(key, "fwd_group")) {            // row blocks per forward super block for matrices finished from now on (0 = automatic)

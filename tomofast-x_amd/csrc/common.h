@@ -302,6 +302,7 @@ struct tfx_ctx {
     } trs;
     double tr_panel_entries = 9.0e8, tr_pos_budget = 1.5e8;   // panel size of the transposition (debug keys "tr_panel_entries" / "tr_pos_budget": tests force many small panels of either shape)
     int64_t reserve_nnz = 0;          // tfx_matrix_reserve: entry bound of the next kernel build into the selected slot (0 = rows x K)
+    int lsqr_merge_tail = 1;          // debug key "lsqr_merge_tail" / TFX_LSQR_MERGE_TAIL: the x / w update of an LSQR iteration also does the next iteration's u = -alpha u and constraint forward step (one launch instead of three; same bits)
     int fwd_run = 2;                  // debug key "fwd_run": consecutive chunks a wave of the forward kernel takes at a time (matrix.hip k_spmv_fwd)
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)
     size_t wave_lds_attr[4] = {0, 0, 0, 0};   // the same for the four wavelet axis kernels (Haar / D4 x forward / inverse)

@@ -39,6 +39,7 @@ struct LsqrState {
     std::vector<int64_t> g_counts, g_displs;   //   cells per rank and first cell of every rank (all-gather of the slices)
     DBuf<double> red;      // block partial sums
     DBuf<unsigned int> cnt;   // arrival counters of the single-launch reductions (zero between launches)
+    bool next_ready = false;  // the tail launch of the last iteration has already done the next iteration's u = -alpha u and constraint forward step
     DBuf<Scalars> sc;
     Scalars *h_sc = nullptr;   // pinned
     int iter = 0;          // iterations completed
@@ -307,6 +308,51 @@ __global__ void k_update_xw(double *__restrict__ v, double *__restrict__ w, doub
     }
 }
 
+// k_update_xw, then - elementwise on the same index, with the v it has just normalised - the constraint forward step of the NEXT iteration
+// (k_cons_forward: u_cons = -alpha u_cons + diag .* v, partial |u_cons|^2, lsqr_solver2.F90:194-211), then the next iteration's
+// u = -alpha u (k_scale; u_mode 1: rank 0, 2: zero on the other ranks, :194-198).  One launch instead of three in a chain that is bound by
+// the latency between dependent launches; the arithmetic and the partial sums are those of the separate kernels (same grid, same
+// mapping), so the bits of a solve do not depend on which form ran.  A void iteration (Scalars::skip) leaves x, w and v alone as
+// k_update_xw does; what it does to u and u_cons is what the separate kernels of the following (equally void) iteration would have done.
+__global__ void k_update_xw_next(double *__restrict__ v, double *__restrict__ w, double *__restrict__ x, int64_t n, Scalars *sc, double gamma,
+                                 double *__restrict__ uc, const float *__restrict__ diag, int nblocks, double *red, unsigned int *counter,
+                                 double *dst, double *__restrict__ u, int64_t nr, int u_mode)
+{
+    const bool skip = sc->skip != 0;
+    const double t1 = sc->t1, t2 = sc->t2, ia = sc->inv_alpha, alpha = sc->alpha;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double vi = v[i];
+        if (!skip) {
+            const double wi = w[i];
+            double xi = t1 * wi + x[i];
+            vi = ia * vi;
+            v[i] = vi;
+            w[i] = t2 * wi + vi;
+            if (gamma != 0.0) {                                    // :478-494
+                if (fabs(xi) <= gamma) xi = 0.0;
+                else if (xi <= -gamma) xi = xi + gamma;
+                else if (xi >= gamma) xi = xi - gamma;
+            }
+            x[i] = xi;
+        }
+        for (int b = 0; b < nblocks; ++b) {
+            const int64_t k = (int64_t)b * n + i;
+            const double t = -alpha * uc[k] + (double)diag[k] * vi;
+            uc[k] = t;
+            s = fma(t, t, s);
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += (int64_t)gridDim.x * blockDim.x)
+        u[i] = (u_mode == 1) ? -alpha * u[i] : 0.0;
+    s = block_sum(s);
+    if (threadIdx.x == 0) red[blockIdx.x] = s;
+    if (dst && last_block_done(counter)) {
+        const double tot = final_sum_dev(red, (int)gridDim.x);
+        if (threadIdx.x == 0) *dst = tot;
+    }
+}
+
 // y += x
 __global__ void k_axpy1(double *__restrict__ y, const double *__restrict__ x, int64_t n)
 {
@@ -524,6 +570,7 @@ int tfx_lsqr_begin(tfx_ctx *ctx, double rmin, double gamma, double target_misfit
     L->active = true;
     L->exact = false;
     L->finished = false;
+    L->next_ready = false;
     const int64_t nc = L->ncols, nr = L->nrows;
     TFX_TRY(L->u.ensure((size_t)nr + 1));
     TFX_TRY(L->v.ensure((size_t)nc));
@@ -690,7 +737,9 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
         }
         for (int j = 0; j < chunk; ++j) {
             // u = -alpha u (rank 0) | 0 (others), then u += S_loc v                       :194-209
-            LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
+            const bool prepared = L->next_ready;          // the previous iteration's tail launch has done :194-198 and :211 already
+            L->next_ready = false;
+            if (!prepared) LAUNCH(k_scale, grid_for(nr), L->u.p, nr, &L->sc.p->alpha, ctx->rank == 0 ? 1 : 2);
             if (ctx->spatial_unknowns) {                                                  // :200-209
                 LAUNCH(k_copy, grid_for(nc), L->tw.p, L->v.p, nc);
                 TFX_TRY(transform_slice(ctx, L, 1));
@@ -699,7 +748,7 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
                 TFX_TRY(S_forward(ctx, L->v.p, L->u.p, 1));
             }
             if (ctx->cons.valid) TFX_TRY(spmv_dev(ctx, ctx->cons, L->v.p, L->u.p + L->nrows_data, 1));   // :211 (general C rows)
-            {                                                                             // :211 (diagonal blocks, local)
+            if (!prepared) {                                                              // :211 (diagonal blocks, local)
                 const int g = grid_for(nc);
                 if (g <= ONE_LAUNCH_MAX_BLOCKS) {
                     LAUNCH(k_cons_forward, g, L->uc.p, L->diag.p, L->v.p, nc, L->nblocks, L->sc.p, L->red.p, L->cnt.p + 2, L->u.p + nr);
@@ -717,7 +766,21 @@ int tfx_lsqr_iterate(tfx_ctx *ctx, int k, int *done_out, double *r_out)
             }
             const bool fused = !ctx->multi();                      // no reduction between sum_v and alpha
             TFX_TRY(adjoint_and_alpha(ctx, L, fused, !fused));                            // :228-241, :248-266 (alpha and the rotation)
-            LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, 1.0, L->gamma);   // v / alpha, :241, :269-274
+            if (ctx->lsqr_merge_tail) {           // v / alpha, :241, :269-274 and the next iteration's :194-198, :211 in one launch
+                const int g = grid_for(nc);
+                const int u_mode = ctx->rank == 0 ? 1 : 2;
+                if (g <= ONE_LAUNCH_MAX_BLOCKS) {
+                    LAUNCH(k_update_xw_next, g, L->v.p, L->w.p, L->x.p, nc, L->sc.p, L->gamma, L->uc.p, L->diag.p, L->nblocks, L->red.p, L->cnt.p + 2,
+                           L->u.p + nr, L->u.p, nr, u_mode);
+                } else {
+                    LAUNCH(k_update_xw_next, g, L->v.p, L->w.p, L->x.p, nc, L->sc.p, L->gamma, L->uc.p, L->diag.p, L->nblocks, L->red.p, L->cnt.p + 2,
+                           (double *)nullptr, L->u.p, nr, u_mode);
+                    LAUNCH(k_final_sum, 1, L->red.p, g, L->u.p + nr);
+                }
+                L->next_ready = true;
+            } else {
+                LAUNCH(k_update_xw, grid_for(nc), L->v.p, L->w.p, L->x.p, nc, L->sc.p, 1.0, L->gamma);   // v / alpha, :241, :269-274
+            }
             TFX_HIP(hipGetLastError());
         }
         TFX_TRY(read_scalars(ctx, L));
