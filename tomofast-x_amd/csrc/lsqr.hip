@@ -310,9 +310,9 @@ __global__ void k_update_xw(double *__restrict__ v, double *__restrict__ w, doub
 
 // k_update_xw, then - elementwise on the same index, with the v it has just normalised - the constraint forward step of the NEXT iteration
 // (k_cons_forward: u_cons = -alpha u_cons + diag .* v, partial |u_cons|^2, lsqr_solver2.F90:194-211), then the next iteration's
-// u = -alpha u (k_scale; u_mode 1: rank 0, 2: zero on the other ranks, :194-198).  One launch instead of three in a chain that is bound by
-// the latency between dependent launches; the arithmetic and the partial sums are those of the separate kernels (same grid, same
-// mapping), so the bits of a solve do not depend on which form ran.  A void iteration (Scalars::skip) leaves x, w and v alone as
+// u = -alpha u (k_scale; u_mode 1: rank 0, 2: zero on the other ranks, :194-198).  One launch instead of three and one pass over v instead
+// of two (2 % of an iteration of the reduced workloads - the launches of the chain pipeline, profiles/README.md round 5); the arithmetic
+// and the partial sums are those of the separate kernels (same grid, same mapping), so the bits of a solve do not depend on which form ran.  A void iteration (Scalars::skip) leaves x, w and v alone as
 // k_update_xw does; what it does to u and u_cons is what the separate kernels of the following (equally void) iteration would have done.
 __global__ void k_update_xw_next(double *__restrict__ v, double *__restrict__ w, double *__restrict__ x, int64_t n, Scalars *sc, double gamma,
                                  double *__restrict__ uc, const float *__restrict__ diag, int nblocks, double *red, unsigned int *counter,
