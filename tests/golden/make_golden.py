@@ -1248,10 +1248,65 @@ def make_hamersley_conv(tmp):
     np.savez_compressed(os.path.join(HERE, "hamersley_xgrad_conv.npz"), **res)
 
 
+EXAMPLE_PARFILES = ["Parfile_2body_induced.txt", "Parfile_2body_remanent.txt", "Parfile_magbubble_slice.txt"] + \
+    ["noddy/Parfile_Noddy_%s.txt" % n for n in ("grav_ellipsoid_fault", "grav_ellipsoid_fault_petro", "grav_ellipsoid_simple", "grav_ellipsoid_simple_petro",
+                                                "mag_ellipsoid_alter", "mag_ellipsoid_fault", "mag_ellipsoid_fault_petro", "mag_ellipsoid_simple",
+                                                "mag_ellipsoid_simple_petro")]
+
+
+def make_examples(tmp, only=None):
+    """Every further example the reference ships a Parfile AND its input files for (parfiles/noddy/: the nine Noddy ellipsoid examples,
+    gravity and magnetic, incl. the petrophysical ADMM ones; the two-body and magbubble Parfiles name grid files that are not in the
+    repository), run by the compiled reference at 8 and at 4 ranks.  examples_inputs.npz: the input DATA files the Parfiles name (grids, observation positions, synthetic models), byte for
+    byte, keyed by their path; example_<name>.npz: the Parfile's keys / values (banners and comments dropped), final model(s) and data of both
+    runs, r of every LSQR solve."""
+    inputs = {}
+    ipath = os.path.join(HERE, "examples_inputs.npz")
+    if os.path.isfile(ipath):
+        with np.load(ipath) as z:
+            inputs = {k: z[k] for k in z.files}
+    for rel in EXAMPLE_PARFILES:
+        name = os.path.basename(rel)[len("Parfile_"):-len(".txt")]
+        if only and name not in only:
+            continue
+        text = open(os.path.join(REFROOT, "parfiles", rel)).read()
+        keys = [ln.strip() for ln in text.splitlines() if "=" in ln and not ln.lstrip().startswith("#") and not ln.lstrip().startswith("=")]
+        par = "\n".join(keys) + "\n"
+        kv = {k.split("=", 1)[0].strip(): k.split("=", 1)[1].strip() for k in keys}
+        outdir = kv["global.outputFolderPath"]
+        named = sorted({v for k, v in kv.items() if k.lower().endswith("file") and v})
+        missing = [v for v in named if not os.path.isfile(os.path.join(REFROOT, v))]
+        if missing:       # (the two-body and the magbubble examples: their grid files are not in the reference's repository - it can not run them either)
+            print("example %s: skipped, the reference does not ship %s" % (name, ", ".join(missing)))
+            continue
+        files = named
+        for f in files:
+            inputs[os.path.normpath(f)] = np.frombuffer(open(os.path.join(REFROOT, f), "rb").read(), np.uint8)
+        res = dict(parfile=par, outdir=outdir, input_files=np.array([os.path.normpath(f) for f in files]))
+        tags = [t for t, k in (("grav", "grav"), ("mag", "magn")) if float(kv.get("inversion.joint.%s.problemWeight" % k, "0").replace("d", "e")) != 0.0]
+        res["tags"] = np.array(tags)
+        for nproc in (8, 4):
+            t0 = time.time()
+            wd, log = run_parfile(tmp, "example_" + name, par, nproc, workdir_links=[(os.path.join(REFROOT, "data"), "data")])
+            od = os.path.join(wd, outdir)
+            for tag in tags:
+                for what, fn in (("model", os.path.join(od, "model", tag + "_final_model_full.txt")), ("data", os.path.join(od, "data", tag + "_final.txt"))):
+                    t = open(fn).read().split()
+                    res["np%d_%s_%s" % (nproc, tag, what)] = np.array([float(v) for v in t[1:]], np.float64)
+            res["np%d_lsqr_r" % nproc] = np.array([float(m.group(1)) for m in re.finditer(r"Finished lsqr solver, r =\s*([0-9.eE+-]+)", log)])
+            print("example %s np%d: %.0f s, %d LSQR solves, final r %.6e" % (name, nproc, time.time() - t0, res["np%d_lsqr_r" % nproc].size,
+                                                                           res["np%d_lsqr_r" % nproc][-1]), flush=True)
+        np.savez_compressed(os.path.join(HERE, "example_%s.npz" % name), **res)
+        np.savez_compressed(ipath, **inputs)
+
+
 if __name__ == "__main__":
     if not os.path.isfile(os.path.join(REFBIN, "tomofastx")):
         sys.exit("oracle/_ref is not built (run oracle/ref_build.sh in the development container)")
     what = sys.argv[1:] or ["wavelet", "prism", "magprism", "lsqr", "e2e", "mag_e2e", "mansf"]
     with tempfile.TemporaryDirectory() as tmp:
         for w in what:
-            globals()["make_" + w](tmp)
+            if w.startswith("examples:"):
+                make_examples(tmp, only=w.split(":", 1)[1].split(","))
+            else:
+                globals()["make_" + w](tmp)
