@@ -1241,6 +1241,12 @@ def make_hamersley_conv(tmp):
         assert len(r) == 1
         res["r_1x%d" % nminor] = r[0]
         print("hamersley xgrad, 1 x %d iterations: r = %.15e" % (nminor, r[0]))
+        if nminor == 100 and os.environ.get("KEEP_SENSIT"):
+            # the reference's kernel files of this example (100 MB) for tools/hamersley_precision.py / tools/hamersley_probe2.py: git-ignored,
+            # travels to the GPU box with oracle/_ref
+            dst = os.path.join(ROOT, "oracle", "_ref", "hamersley_xgrad_SENSIT")
+            shutil.rmtree(dst, ignore_errors=True)
+            shutil.copytree(os.path.join(wd, outdir, "SENSIT"), dst)
     od = os.path.join(wd, outdir)
     for tag in ("grav", "mag"):
         res["%s_model_1x1600" % tag] = read_col(os.path.join(od, "model", tag + "_final_model_full.txt"), 0)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""CPU only. The first LSQR solve of the reference's joint Hamersley example (parfiles/hamersley/Parfile_hamersley_xgrad_joint.txt: 226 data,
+"""(oracle/_ref/hamersley_xgrad_SENSIT: `KEEP_SENSIT=1 python tests/golden/make_golden.py hamersley_conv` in the development container.)
+CPU only. The first LSQR solve of the reference's joint Hamersley example (parfiles/hamersley/Parfile_hamersley_xgrad_joint.txt: 226 data,
 2 x 57 057 unknowns, model damping 5.92e-8 / 2.8e2, problem weights 1 / 2.5e-6; the cross-gradient rows are zero at the zero start model) in
 three arithmetics on the REFERENCE'S OWN kernel files (oracle/_ref/hamersley_xgrad_SENSIT, written by oracle/_ref/tomofastx): fp64 with the
 reference's sequential sums (the C oracle), fp64 with numpy's pairwise / blocked sums, 80-bit long double.  r after 100 / 400 iterations:

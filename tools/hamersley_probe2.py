@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""xgrad Hamersley example, two discriminating runs of the shipping host: (1) ONE major iteration with 100 / 400 / 1600 LSQR iterations (the
+"""(oracle/_ref/hamersley_xgrad_SENSIT: `KEEP_SENSIT=1 python tests/golden/make_golden.py hamersley_conv` in the development container.)
+xgrad Hamersley example, two discriminating runs of the shipping host: (1) ONE major iteration with 100 / 400 / 1600 LSQR iterations (the
 reference: r = 0.014977706, 0.0048015005, 0.0047371974 - the residual is still falling fast at iteration 100) and (2) the full run on the
 REFERENCE'S OWN kernel files (oracle/_ref/hamersley_xgrad_SENSIT, sensit.readFromFiles = 1: identical matrix bits)."""
 import os, re, sys, subprocess, tempfile
