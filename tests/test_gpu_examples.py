@@ -34,7 +34,7 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-def run_example(name, exe, wd):
+def run_example(name, exe, wd, nproc=1):
     g = fh._load_npz(os.path.join(GOLDEN, "example_%s.npz" % name))
     inputs = fh._load_npz(os.path.join(GOLDEN, "examples_inputs.npz"))
     for f in g["input_files"]:
@@ -42,7 +42,8 @@ def run_example(name, exe, wd):
         os.makedirs(os.path.dirname(path), exist_ok=True)
         open(path, "wb").write(inputs[str(f)].tobytes())
     open(os.path.join(wd, "Parfile.txt"), "w").write(str(g["parfile"]))
-    out = fh._sub_run([exe, "-p", "Parfile.txt"], cwd=wd, capture_output=True, text=True, timeout=900)
+    cmd = [exe, "-p", "Parfile.txt"] if nproc == 1 else [fh.MPIEXEC, "-n", str(nproc), exe, "-p", "Parfile.txt"]
+    out = fh._sub_run(cmd, cwd=wd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "THE END" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     od = os.path.join(wd, str(g["outdir"]))
     r = [float(m.group(1)) for m in re.finditer(r"(?:Finished lsqr solver|End of subroutine lsqr_solve_sensit|End of subroutine lsqr_solve), r =\s*([0-9.eE+-]+)", out.stdout)]
@@ -80,3 +81,19 @@ def test_shipped_example(tmp_path, name, host):
     with open(os.path.join(ROOT, "gpurun_out", "examples.jsonl"), "a") as f:
         f.write(json.dumps(report) + "\n")
     assert worst <= 1.0, report
+
+
+@pytest.mark.parametrize("host", ["reference program + drop-in", "shipping Fortran host"])
+@pytest.mark.parametrize("name", ["Noddy_grav_ellipsoid_fault_petro", "Noddy_mag_ellipsoid_fault"])
+def test_shipped_example_on_two_ranks(tmp_path, name, host):
+    """Two of the examples under `mpiexec -n 2` (the ranks share the GPU: the reference's own MPI decomposition around the drop-in modules / the
+    shipping host's column partition, reductions through MPI) against the same reference run."""
+    exe = DROPIN if host.startswith("reference") else fh.EXE
+    if not os.path.isfile(exe) or not os.path.isfile(fh.MPIEXEC):
+        pytest.skip("%s or mpiexec not present" % exe)
+    g, r, res = run_example(name, exe, str(tmp_path), nproc=2)
+    for tag in g["tags"]:
+        ref, ref4 = g["np8_%s_model" % tag], g["np4_%s_model" % tag]
+        own, d = rel(ref4, ref), rel(res["%s_model" % tag], ref)
+        print("example %s on 2 ranks, %s, %s model: rel-L2 %.2e from the reference's 8-rank run (its own 8- vs 4-rank: %.1e)" % (name, host, tag, d, own))
+        assert d <= max(3e-6, 20.0 * own), (d, own)
