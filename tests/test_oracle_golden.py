@@ -470,3 +470,36 @@ def test_joint_inversion_with_clustering(golden_dir, name):
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-7)
     costs = np.array([h["xgrad_cost"] for h in hist])
     assert np.allclose(costs[2:], g["np1_clust_cost"][2:], rtol=1e-6)
+
+
+def test_noddy_gravity_example_end_to_end(golden_dir):
+    """One of the examples the reference ships (parfiles/noddy/Parfile_Noddy_grav_ellipsoid_simple.txt: 40 x 40 x 20 cells, 1600 data,
+    depth weighting power 2.4, Haar r = 0.3, 2 x 100 iterations, data from the example's synthetic model) on the oracle from the example's
+    own input files (tests/golden/examples_inputs.npz), against the compiled reference's 8-rank run; yardstick: its own 8- vs 4-rank distance."""
+    import io
+    g = load(golden_dir, "example_Noddy_grav_ellipsoid_simple")
+    inputs = load(golden_dir, "examples_inputs")
+
+    def text(path, skip=1):
+        return np.loadtxt(io.BytesIO(inputs[path].tobytes()), skiprows=skip, ndmin=2)
+
+    grid_t = text("data/gravmag/ellipsoid/model_grid.txt")
+    grid = [np.ascontiguousarray(grid_t[:, k]) for k in range(6)]
+    dims = (40, 40, 20)
+    assert np.array_equal(grid_t[:, 6:9].astype(int)[1], [2, 1, 1])                 # i fastest, as the kernels index the cells
+    obs = np.ascontiguousarray(text("data/gravmag/ellipsoid/data_grid.txt")[:, :3])
+    m_true = text("data/gravmag/ellipsoid/grav/simple/model_grid-values.txt")[:, 0]
+    cw = orc.column_weight_type1(grid, power=2.4)
+    rp, cols, vals, hist, err = orc.build_matrix_grav(grid, dims, cw, obs, 1, 0.30)
+    S = (rp, cols, vals)
+    d_obs = orc.calc_data(m_true, cw, dims, 1, S, 1.0, np.ones(obs.shape[0]))
+    m, d, rec = oinv.run_inversion(S, cw, dims, 1, d_obs, 2, 100, alpha=1e-11)
+    ref, ref4 = g["np8_grav_model"], g["np4_grav_model"]
+    own = np.linalg.norm(ref4 - ref) / np.linalg.norm(ref)
+    rel = np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    dref = g["np8_grav_data"].reshape(-1, 4)[:, 3]
+    drel = np.linalg.norm(d - dref) / np.linalg.norm(dref)
+    print("Noddy gravity example on the oracle: model rel-L2 %.2e, data rel-L2 %.2e from the reference's 8-rank run (its own 8- vs 4-rank: %.1e); r %s vs %s" %
+          (rel, drel, own, [h["r"] for h in rec], list(g["np8_lsqr_r"])))
+    assert rel <= max(1e-7, 20.0 * own), (rel, own)
+    assert drel <= max(1e-7, 20.0 * own), (drel, own)
