@@ -1066,11 +1066,26 @@ __global__ __launch_bounds__(256) void k_fwd_reduce_flat(const double *__restric
         const int sb = (int)(r / SB), lr = (int)(r - (int64_t)sb * SB);
         const int ns = nslots[sb], p0 = pbase[sb];
         double t = add ? b[r] : 0.0;
+        const double *pr = partial + (int64_t)p0 * SB + lr;
+        if (ns <= FR_GROUPS) {                                // (the common case of a matrix with many rows: every group has at most one tile)
 #pragma unroll 4
-        for (int q = 0; q < FR_GROUPS; ++q) {
-            double s = 0.0;                                   // (thread group q of k_fwd_reduce: every FR_GROUPS-th partial tile, in order)
-            for (int k = q; k < ns; k += FR_GROUPS) s += partial[(int64_t)(p0 + k) * SB + lr];
-            t += s;
+            for (int q = 0; q < FR_GROUPS; ++q) {
+                double s = 0.0;
+                if (q < ns) s += pr[(int64_t)q * SB];
+                t += s;
+            }
+        } else {
+            for (int q = 0; q < FR_GROUPS; ++q) {
+                double s = 0.0;                               // (thread group q of k_fwd_reduce: every FR_GROUPS-th partial tile, in order; four loads in flight)
+                int k = q;
+                for (; k + 3 * FR_GROUPS < ns; k += 4 * FR_GROUPS) {
+                    const double a0 = pr[(int64_t)k * SB], a1 = pr[(int64_t)(k + FR_GROUPS) * SB], a2 = pr[(int64_t)(k + 2 * FR_GROUPS) * SB],
+                                 a3 = pr[(int64_t)(k + 3 * FR_GROUPS) * SB];
+                    s += a0; s += a1; s += a2; s += a3;
+                }
+                for (; k < ns; k += FR_GROUPS) s += pr[(int64_t)k * SB];
+                t += s;
+            }
         }
         b[r] = t;
     }
@@ -1447,7 +1462,10 @@ static int forward_product(tfx_ctx *ctx, TiledMatrix &m, const double *d_x, doub
         if (prof) prof_end(ctx, prof_slot);
         TFX_HIP(hipGetLastError());
     }
-    if (m.nrows >= 65536 || (m.nrows >= 8192 && m.fwd_avg_nslots <= 16.0))
+    // one thread per row where a row has few partial tiles (the transposed copy of a wide kernel: 10^6..10^7 rows, one or two tiles each);
+    // 16 threads per row where it has many (S itself at the headline size and a rank's share of it: 99 856 rows x 164 tiles - the one-thread
+    // form spent 87 us per product there, profiles/README.md round 5); same association, same bits
+    if (m.nrows >= (int64_t)1 << 20 || (m.nrows >= 8192 && m.fwd_avg_nslots <= 16.0))
         hipLaunchKernelGGL(k_fwd_reduce_flat, dim3((unsigned)std::min<int64_t>((m.nrows + 255) / 256, (int64_t)ctx->num_cu * 32)), dim3(256), 0, s,
                            m.fwd_partial.p, m.fwd_nslots.p, m.fwd_pbase.p, SB, m.nrows, d_b, add);
     else
