@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The Hamersley field-data examples through the shipping host under several arithmetic variants of the products (run length of the forward
-kernel, adjoint with / without the transposed copy, row blocks per staged x tile): per-major-iteration LSQR r against the reference's, final models
+kernel, adjoint with / without the transposed copy, merged / separate tail launches of the LSQR iteration): per-major-iteration LSQR r against the reference's, final models
 against the reference's 1-rank run and against each other - how much of the distance to the reference is the example's own sensitivity.
   python tools/hamersley_probe.py [grav|magn|xgrad]  -> text"""
 import os, re, sys, time, subprocess, tempfile
@@ -13,7 +13,7 @@ case = sys.argv[1] if len(sys.argv) > 1 else "xgrad"
 g = fh._load_npz(os.path.join(ROOT, "tests", "golden", "hamersley.npz"))
 tags = ("grav",) if case == "grav" else ("mag",) if case == "magn" else ("grav", "mag")
 variants = [("default", {}), ("fwd_run=1", {"TFX_FWD_RUN": "1"}), ("fwd_run=4", {"TFX_FWD_RUN": "4"}), ("no adjoint copy", {"TFX_ADJ_COPY": "0"}),
-            ("fwd_group=1", {"TFX_FWD_GROUP": "1"})]
+            ("separate tail launches", {"TFX_LSQR_MERGE_TAIL": "0"})]
 if os.environ.get("PROBE_QUICK"):
     variants = variants[:1]
 models, rs = {}, {}
