@@ -134,6 +134,9 @@ int tfx_prism_rows_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const doub
                        double decl, double azim, double intensity, double *rows_out);
 /* Any row generator of the build loop (src/forward/gravmag/sensitivity_gravmag.F90:193-220):
  *   problem_type 1, data_type 1, 1 component     graviprism_z       gravity_field.f90:131-195
+ *   problem_type 1, data_type 1, 3 components    graviprism_full    gravity_field.f90:41-126    (gx, gy, gz = LineX, LineY, LineZ;
+ *                                                the gz rows have the bits of graviprism_z's.  Public in the reference but without a
+ *                                                call site there - data_type 1 maps to graviprism_z only, sensitivity_gravmag.F90:195)
  *   problem_type 1, data_type 2, 1 component     gradiprism_zz      gravity_field.f90:315-362
  *   problem_type 1, data_type 2, 6 components    gradiprism_full    gravity_field.f90:207-310   (XX, YY, ZZ, XY, YZ, ZX)
  *   problem_type 2, nmodel_components 1|3 (susceptibility | magnetisation vector), ndata_components 1|3 (TMI | Bx, By, Bz)

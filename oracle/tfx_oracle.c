@@ -43,6 +43,51 @@ int orc_graviprism_z(int64_t n, const double *X1, const double *X2, const double
     return 0;
 }
 
+/* gravity_field.f90:41-126 (graviprism_full): the three components of the attraction, lines[c*n + i] with c = X, Y, Z
+ * (LineX, LineY, LineZ).  The Z line is graviprism_z's expression term by term (:118 == :186).  Returns 0 or -1 / -2 / -3 when
+ * R+X <= 0 / R+Y <= 0 / R+Z <= 0 ("Data coordinate coincides with model grid boundary (YZ) / (XZ) / (XY)", :96-104). */
+int orc_graviprism_full(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                        const double *Z1, const double *Z2, double xd, double yd, double zd, double *lines)
+{
+    const double twopi = 2.0 * 3.14159265358979323846;
+    static const double signo[2] = {-1.0, 1.0};
+    for (int64_t i = 0; i < n; ++i) {
+        double XX[2], YY[2], ZZ[2];
+        XX[0] = xd - X1[i]; XX[1] = xd - X2[i];              /* :61-66 */
+        YY[0] = yd - Y1[i]; YY[1] = yd - Y2[i];
+        ZZ[0] = zd - Z1[i]; ZZ[1] = zd - Z2[i];
+        double gx = 0.0, gy = 0.0, gz = 0.0;
+        for (int K = 0; K < 2; ++K)
+            for (int L = 0; L < 2; ++L)
+                for (int M = 0; M < 2; ++M) {
+                    double dmu = signo[K] * signo[L] * signo[M];
+                    double Rs = sqrt(XX[K] * XX[K] + YY[L] * YY[L] + ZZ[M] * ZZ[M]);   /* :77 */
+                    double arg1 = atan2(YY[L] * ZZ[M], XX[K] * Rs);                    /* :79-81 */
+                    double arg2 = atan2(XX[K] * ZZ[M], YY[L] * Rs);
+                    double arg3 = atan2(XX[K] * YY[L], ZZ[M] * Rs);
+                    if (arg1 < 0) arg1 = arg1 + twopi;                                 /* :83-91 */
+                    if (arg2 < 0) arg2 = arg2 + twopi;
+                    if (arg3 < 0) arg3 = arg3 + twopi;
+                    double arg4 = Rs + XX[K];                                          /* :93-95 */
+                    double arg5 = Rs + YY[L];
+                    double arg6 = Rs + ZZ[M];
+                    if (arg4 <= 0.) return -1;                                         /* :96-104 */
+                    if (arg5 <= 0.) return -2;
+                    if (arg6 <= 0.) return -3;
+                    arg4 = log(arg4);
+                    arg5 = log(arg5);
+                    arg6 = log(arg6);
+                    gx = gx + dmu * (XX[K] * arg1 - YY[L] * arg6 - ZZ[M] * arg5);      /* :110-112 */
+                    gy = gy + dmu * (YY[L] * arg2 - ZZ[M] * arg4 - XX[K] * arg6);
+                    gz = gz + dmu * (ZZ[M] * arg3 - XX[K] * arg5 - YY[L] * arg4);
+                }
+        lines[i] = G_GRAV * gx;                                                        /* :118-120 */
+        lines[i + n] = G_GRAV * gy;
+        lines[i + 2 * n] = G_GRAV * gz;
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Magnetic kernel: magnetic_field.f90.  dircos (:91-110), sharmbox (:321-457), magprism (:118-297) for the
  * scalar-susceptibility model and TMI data (nmodel_components = ndata_components = 1).

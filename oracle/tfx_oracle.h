@@ -28,6 +28,11 @@ extern "C" {
 int orc_graviprism_z(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
                      const double *Z1, const double *Z2, double xd, double yd, double zd, double *line);
 
+/* src/forward/gravmag/grav/gravity_field.f90:41-126 (graviprism_full): lines[c*n + i], c = X, Y, Z.  Returns 0, or -1 / -2 / -3
+ * when R+X<=0 / R+Y<=0 / R+Z<=0 (:96-104). */
+int orc_graviprism_full(int64_t n, const double *X1, const double *X2, const double *Y1, const double *Y2,
+                        const double *Z1, const double *Z2, double xd, double yd, double zd, double *lines);
+
 /* src/forward/gravmag/mag/magnetic_field.f90: dircos (:91-110) -> magv[3]; magprism (:118-297) + sharmbox (:321-457)
  * for scalar susceptibility and TMI data (1 model component, 1 data component), incl. the in-cell 6-sub-box split.
  * Returns 0 or -1 / -2 (model grid X / Y boundary coincides with the data position, :345-354). */

@@ -10,7 +10,7 @@ reference produced for them.  No reference source text is stored.
 
 Files written:
   wavelet.npz    forward/inverse Haar + D4 on several (odd-sized too) arrays          [gold_wavelet driver]
-  prism.npz      graviprism_z rows on a non-uniform 8x6x5 grid                        [gold_prism driver]
+  prism.npz      graviprism_z + graviprism_full rows on a non-uniform 8x6x5 grid      [gold_prism driver]
   magprism.npz   magprism rows (TMI, scalar model; obs outside and INSIDE cells)      [gold_magprism driver]
   lsqr.npz       S.x, S^T.y and lsqr_solve_sensit solutions for [S; C] systems        [gold_lsqr driver]
   e2e_*.npz      full `tomofastx -p Parfile` runs: SENSIT rows, weights, nnz, partition, models, data
@@ -98,9 +98,13 @@ def make_prism(tmp):
     open(fo, "wb").write(be(obs[:, 0], ">f8") + be(obs[:, 1], ">f8") + be(obs[:, 2], ">f8"))
     run([os.path.join(REFBIN, "gold_prism")], stdin="%d %d\n%s\n%s\n%s\n" % (nel, nd, fg, fo, fout))
     rows = np.fromfile(fout, ">f8").astype(np.float64).reshape(nd, nel)
+    # graviprism_full (gravity_field.f90:41-126) on the same grid / observations: (obs, component X | Y | Z, cell)
+    run([os.path.join(REFBIN, "gold_prism")], stdin="%d %d 1\n%s\n%s\n%s\n" % (nel, nd, fg, fo, fout))
+    rows_full = np.fromfile(fout, ">f8").astype(np.float64).reshape(nd, 3, nel)
+    assert np.array_equal(rows_full[:, 2, :].view(np.int64), rows.view(np.int64))     # LineZ == graviprism_z, bit for bit
     np.savez_compressed(os.path.join(HERE, "prism.npz"), nx=nx, ny=ny, nz=nz, X1=g[0], X2=g[1], Y1=g[2], Y2=g[3],
-                        Z1=g[4], Z2=g[5], obs=obs, rows=rows)
-    print("prism.npz: rows", rows.shape)
+                        Z1=g[4], Z2=g[5], obs=obs, rows=rows, rows_full=rows_full)
+    print("prism.npz: rows", rows.shape, "rows_full", rows_full.shape)
 
 
 def make_magprism(tmp):

@@ -49,6 +49,16 @@ def graviprism_z(grid, xd, yd, zd):
     return ierr, line
 
 
+def graviprism_full(grid, xd, yd, zd):
+    """-> (ierr, lines[3, n]); components X, Y, Z (LineX, LineY, LineZ of gravity_field.f90:41-126)."""
+    X1, X2, Y1, Y2, Z1, Z2 = [f64(g) for g in grid]
+    n = X1.size
+    line = np.empty(3 * n)
+    ierr = lib().orc_graviprism_full(C.c_int64(n), dp(X1), dp(X2), dp(Y1), dp(Y2), dp(Z1), dp(Z2),
+                                     C.c_double(xd), C.c_double(yd), C.c_double(zd), dp(line))
+    return ierr, line.reshape(3, n)
+
+
 def dircos(incl, decl, azim):
     magv = np.empty(3)
     lib().orc_dircos(C.c_double(incl), C.c_double(decl), C.c_double(azim), dp(magv))
@@ -102,10 +112,13 @@ def compress_line(line, cw, dims, ctype, K):
 
 
 def rowgen(kind, grid, o, field=None, ncm=1, ncd=1):
-    """Lines of one observation, [ncd, ncm, N].  kind: 'gz' | 'gzz' | 'ftg' | 'mag'."""
+    """Lines of one observation, [ncd, ncm, N].  kind: 'gz' | 'g3' | 'gzz' | 'ftg' | 'mag'."""
     if kind == "gz":
         ierr, line = graviprism_z(grid, o[0], o[1], o[2])
         lines = line.reshape(1, 1, -1)
+    elif kind == "g3":
+        ierr, l = graviprism_full(grid, o[0], o[1], o[2])
+        lines = l.reshape(3, 1, -1)
     elif kind in ("gzz", "ftg"):
         ierr, l = gradiprism(grid, o[0], o[1], o[2], kind == "gzz")
         lines = l.reshape(l.shape[0], 1, -1)

@@ -21,6 +21,7 @@ import pytest
 import kat_cases
 import oracle_lib as orc
 import oracle_inversion as oinv
+from parity_report import report
 
 pytestmark = pytest.mark.gpu
 
@@ -41,6 +42,16 @@ def load(golden_dir, name):
 def bits_equal(a, b):
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+def nonuniform(nx, ny, nz, rng, x0=100.0, y0=-50.0, z0=0.0):
+    """A tensor-product grid with irregular spacings (cells share their faces bit for bit), i fastest."""
+    xe = x0 + np.concatenate([[0], np.cumsum(rng.uniform(20, 90, nx))])
+    ye = y0 + np.concatenate([[0], np.cumsum(rng.uniform(20, 90, ny))])
+    ze = z0 + np.concatenate([[0], np.cumsum(rng.uniform(10, 60, nz))])
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    i, j, k = i.ravel(), j.ravel(), k.ravel()
+    return [xe[i], xe[i + 1], ye[j], ye[j + 1], ze[k], ze[k + 1]]
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1211,6 +1222,127 @@ def test_gradiprism_rows_vs_reference(ctx, golden_dir):
             scale = atan_scale if c < 3 else log_scale
             assert np.all(np.abs(full[i, c, 0] - g["rows_full"][i, c]) <= 8 * 2.3e-16 * scale), (i, c)
             assert np.max(np.abs(full[i, c, 0] - g["rows_full"][i, c])) <= 1e-9 * np.max(np.abs(g["rows_full"][i, c]))
+
+
+def g3_term_scale(grid, o):
+    """Magnitude of the 24 (x 3) terms a graviprism_full entry is the cancelling sum of (gravity_field.f90:110-112)."""
+    X1, X2, Y1, Y2, Z1, Z2 = grid
+    s = np.zeros(X1.size)
+    for xx in (o[0] - X1, o[0] - X2):
+        for yy in (o[1] - Y1, o[1] - Y2):
+            for zz in (o[2] - Z1, o[2] - Z2):
+                R = np.sqrt(xx * xx + yy * yy + zz * zz)
+                lg = np.abs(np.log(R + xx)) + np.abs(np.log(R + yy)) + np.abs(np.log(R + zz))
+                s += (np.abs(xx) + np.abs(yy) + np.abs(zz)) * (2 * np.pi + lg)
+    return 6.674e-11 * s
+
+
+def test_graviprism_full_rows_vs_reference(ctx, golden_dir):
+    """graviprism_full (gravity_field.f90:41-126): gx, gy, gz rows of the HIP path vs the compiled reference's LineX /
+    LineY / LineZ on the 8x6x5 non-uniform grid (observations above, beside and inside the mesh).  The gz sub-row has the bits of the
+    graviprism_z row (same corner expression, same order); gx / gy sit within a few ulp of the cancelling TERMS and 1e-9 of the row
+    maximum - the row-scale bound of DESIGN section 4."""
+    g = load(golden_dir, "prism")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    ctx.set_grid(int(g["nx"]), int(g["ny"]), int(g["nz"]), *grid)
+    obs = g["obs"]
+    full = ctx.graviprism_full(obs[:, 0], obs[:, 1], obs[:, 2])
+    gz = ctx.graviprism_z(obs[:, 0], obs[:, 1], obs[:, 2])
+    assert full.shape == (obs.shape[0], 3, grid[0].size) == g["rows_full"].shape
+    worst = 0.0
+    for i, o in enumerate(obs):
+        assert bits_equal(full[i, 2], gz[i])
+        scale = g3_term_scale(grid, o)
+        for c in range(3):
+            ref = g["rows_full"][i, c]
+            assert np.all(np.abs(full[i, c] - ref) <= 8 * 2.3e-16 * scale), (i, c)
+            rel = float(np.max(np.abs(full[i, c] - ref)) / np.max(np.abs(ref)))
+            worst = max(worst, rel)
+            assert rel <= 1e-9, (i, c, rel)
+    report("graviprism_full_rows_vs_reference", worst_row_scale_distance=worst, rows=int(obs.shape[0] * 3))
+
+
+def test_graviprism_full_tensor_path_bit_identical_to_general(ctx, golden_dir):
+    """k_prism_g3_tensor (shared nodes in LDS) vs k_prism_g3 (six arrays): same bits; a grid without shared faces takes the general
+    kernel and agrees with the oracle; and the whole 3-component build gives the same matrix on either generator."""
+    g = load(golden_dir, "prism")
+    cases = [((int(g["nx"]), int(g["ny"]), int(g["nz"])), [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")], g["obs"])]
+    xs, ys, zs = tfx.synthetic.observations(70, 37, 3, 2)
+    cases.append(((70, 37, 19), list(tfx.synthetic.grid(70, 37, 19)), np.stack([xs, ys, zs], 1)))
+    for dims, grid, obs in cases:
+        ctx.set_grid(*dims, *grid)
+        assert ctx.debug_set("tensor_grid") == 1
+        rows_t = ctx.graviprism_full(obs[:, 0], obs[:, 1], obs[:, 2])
+        cw = orc.column_weight_type1(grid, 2.0, 0.0, 1.0)
+        ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, 1, 0.2, data_type=1, ndata_components=3)
+        A = ctx.matrix_download_csr()
+        ctx.debug_set("force_general_prism", 1)
+        assert ctx.debug_set("tensor_grid") == 0
+        rows_g = ctx.graviprism_full(obs[:, 0], obs[:, 1], obs[:, 2])
+        ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, 1, 0.2, data_type=1, ndata_components=3)
+        B = ctx.matrix_download_csr()
+        ctx.debug_set("force_general_prism", 0)
+        assert bits_equal(rows_t, rows_g)
+        assert np.array_equal(A[0], B[0]) and np.array_equal(A[1], B[1]) and A[2].tobytes() == B[2].tobytes()
+    dims, grid, obs = cases[0]
+    bent = [a.copy() for a in grid]
+    bent[1][7] += 1e-9
+    ctx.set_grid(*dims, *bent)
+    assert ctx.debug_set("tensor_grid") == 0
+    ierr, ref = orc.graviprism_full(bent, *obs[0])
+    r = ctx.graviprism_full(obs[:1, 0], obs[:1, 1], obs[:1, 2])[0]
+    assert ierr == 0 and np.all(np.abs(r - ref) <= 8 * 2.3e-16 * g3_term_scale(bent, obs[0]))
+
+
+def test_graviprism_full_geometry_errors(ctx):
+    """The three abort tests of graviprism_full (gravity_field.f90:96-104), with the reference's messages; (XY) is the one graviprism_z
+    does not have - the same observation is fine for the one-component rows."""
+    one = [np.array([v], np.float64) for v in (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)]
+    for force_general in (0, 1):
+        ctx.set_grid(1, 1, 1, *one)
+        ctx.debug_set("force_general_prism", force_general)
+        try:
+            for o, plane in (((-1.0, 0.0, 0.0), "(YZ)"), ((0.0, -1.0, 0.0), "(XZ)"), ((0.0, 0.0, -1.0), "(XY)")):
+                with pytest.raises(tfx.TfxError) as e:
+                    ctx.graviprism_full([o[0]], [o[1]], [o[2]])
+                assert e.value.code == -3 and "coincides with model grid boundary " + plane in str(e.value), (o, str(e.value))
+            assert ctx.graviprism_z([0.0], [0.0], [-1.0]).shape == (1, 1)
+            assert ctx.graviprism_full([2.0], [3.0], [-1.0]).shape == (1, 3, 1)
+        finally:
+            ctx.debug_set("force_general_prism", 0)
+    with pytest.raises(tfx.TfxError):
+        ctx.sensit_lines(1, [2.0], [3.0], [-1.0], data_type=1, ndata_components=2)
+
+
+@pytest.mark.parametrize("ctype,rate", [(1, 0.15), (2, 0.15), (0, 1.0)])
+def test_build_graviprism_full_kernel_vs_oracle(ctx, ctype, rate):
+    """The three-component gravity kernel through the whole build (weights, wavelets, threshold, compaction; matrix rows 3 i + c) vs
+    the oracle's build on graviprism_full lines, and its gz rows vs the one-component build, bit for bit."""
+    nx, ny, nz = 20, 14, 9
+    N = nx * ny * nz
+    rng = np.random.default_rng(77)
+    grid = nonuniform(nx, ny, nz, rng)
+    xe0, xe1, ye0, ye1 = grid[0].min(), grid[1].max(), grid[2].min(), grid[3].max()
+    obs = np.stack([rng.uniform(xe0 - 50, xe1 + 50, 7), rng.uniform(ye0 - 50, ye1 + 50, 7), -rng.uniform(0.5, 30.0, 7)], 1)
+    ctx.set_grid(nx, ny, nz, *grid)
+    cw = orc.column_weight_type1(grid, 2.0, 0.0, 1.0)
+    res = ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, ctype, rate, want_hist=True, data_type=1, ndata_components=3)
+    info = ctx.matrix_info()
+    assert info["nrows"] == 3 * obs.shape[0] and info["ncols"] == N
+    built = ctx.matrix_download_csr()
+    rp, cols, vals, hist, err = orc.build_matrix_comp("g3", grid, (nx, ny, nz), cw, obs, ctype, rate, None, 1, 3)
+    frac, maxulp = compare_built_matrix(built, (rp, cols, vals), 3 * obs.shape[0])
+    assert frac >= 0.9999 and maxulp <= 2, (frac, maxulp)
+    assert abs(res["nnz"] - int(rp[-1])) <= 2 * 3 * obs.shape[0]
+    if ctype > 0:
+        assert abs(res["comp_error"] - err) <= 1e-6 * err
+    ctx.calculate_sensit(obs[:, 0], obs[:, 1], obs[:, 2], cw, ctype, rate)
+    one = ctx.matrix_download_csr()
+    for i in range(obs.shape[0]):
+        a0, a1 = built[0][3 * i + 2], built[0][3 * i + 3]
+        b0, b1 = one[0][i], one[0][i + 1]
+        assert np.array_equal(built[1][a0:a1], one[1][b0:b1]) and built[2][a0:a1].tobytes() == one[2][b0:b1].tobytes(), i
+    report("build_graviprism_full_kernel_vs_oracle[%d]" % ctype, identical_sparsity=frac, max_fp32_ulp=maxulp)
 
 
 def test_magprism_components_vs_reference(ctx, golden_dir):

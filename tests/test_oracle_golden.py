@@ -39,6 +39,30 @@ def test_prism_rows_bit_exact(golden_dir):
         assert bits_equal(row, ref)
 
 
+def test_graviprism_full_rows_bit_exact(golden_dir):
+    """graviprism_full (gravity_field.f90:41-126): the three components vs the reference's LineX / LineY / LineZ; the Z line is
+    graviprism_z's, bit for bit (on both sides)."""
+    g = load(golden_dir, "prism")
+    grid = [g[k] for k in ("X1", "X2", "Y1", "Y2", "Z1", "Z2")]
+    assert g["rows_full"].shape == (g["obs"].shape[0], 3, g["X1"].size)
+    for o, ref, ref_z in zip(g["obs"], g["rows_full"], g["rows"]):
+        ierr, lines = orc.graviprism_full(grid, *o)
+        assert ierr == 0
+        assert bits_equal(lines, ref)
+        assert bits_equal(lines[2], ref_z)
+        assert bits_equal(lines[2], orc.graviprism_z(grid, *o)[1])
+
+
+def test_graviprism_full_boundary_errors():
+    """The three abort tests of graviprism_full (gravity_field.f90:96-104): R + X / R + Y / R + Z <= 0."""
+    grid = [np.array([v], np.float64) for v in (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)]
+    assert orc.graviprism_full(grid, 2.0, 3.0, -1.0)[0] == 0
+    assert orc.graviprism_full(grid, -1.0, 0.0, 0.0)[0] == -1      # YY(1) = ZZ(1) = 0, XX < 0: Rs + XX = 0
+    assert orc.graviprism_full(grid, 0.0, -1.0, 0.0)[0] == -2      # Rs + YY = 0
+    assert orc.graviprism_full(grid, 0.0, 0.0, -1.0)[0] == -3      # Rs + ZZ = 0: the test graviprism_z does not have
+    assert orc.graviprism_z(grid, 0.0, 0.0, -1.0)[0] == 0
+
+
 def test_prism_boundary_error():
     # observation exactly on a cell edge line below the cell's x-face: R + X == 0 (gravity_field.f90:176-181)
     grid = [np.array([v], np.float64) for v in (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)]

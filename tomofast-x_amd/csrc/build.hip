@@ -224,6 +224,192 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // =============================================================================================================
+// graviprism_full (gravity_field.f90:41-126): the three components of the attraction, sub-rows X, Y, Z per observation
+// (LineX, LineY, LineZ).  The reference declares it public and never calls it (sensitivity_gravmag.F90:193-213 maps data_type 1 to
+// graviprism_z); here it is tfx_prism_rows / tfx_build_kernel with (problem_type 1, data_type 1, ndata_components 3).
+// =============================================================================================================
+// One corner (:77-112): the three bracketed terms, and the three abort tests R+X <= 0 (1), R+Y <= 0 (2), R+Z <= 0 (64) (:96-104).
+// tz is corner_term()'s expression operation by operation, so the Z sub-row has the bits of the graviprism_z row.
+__device__ __forceinline__ void corner_term3(double XX, double YY, double ZZ, double &tx, double &ty, double &tz, int &bad)
+{
+    const double twopi = 2.0 * 3.14159265358979323846;
+    const double Rs = sqrt(XX * XX + YY * YY + ZZ * ZZ);                                            // :77
+    double arg1 = datan2(YY * ZZ, XX * Rs);                                                         // :79-81
+    double arg2 = datan2(XX * ZZ, YY * Rs);
+    double arg3 = datan2(XX * YY, ZZ * Rs);
+    if (arg1 < 0) arg1 = arg1 + twopi;                                                              // :83-91
+    if (arg2 < 0) arg2 = arg2 + twopi;
+    if (arg3 < 0) arg3 = arg3 + twopi;
+    double arg4 = Rs + XX;                                                                          // :93-95
+    double arg5 = Rs + YY;
+    double arg6 = Rs + ZZ;
+    if (arg4 <= 0.) bad |= 1;                                                                       // :96-104
+    if (arg5 <= 0.) bad |= 2;
+    if (arg6 <= 0.) bad |= 64;
+    arg4 = dlog(arg4);
+    arg5 = dlog(arg5);
+    arg6 = dlog(arg6);
+    tx = XX * arg1 - YY * arg6 - ZZ * arg5;                                                         // :110-112
+    ty = YY * arg2 - ZZ * arg4 - XX * arg6;
+    tz = ZZ * arg3 - XX * arg5 - YY * arg4;
+}
+
+// General grid (six arrays): one thread per cell; rows[(o*3 + c)*N + p], c = X, Y, Z.
+__global__ __launch_bounds__(256) void k_prism_g3(int64_t N, const double *__restrict__ X1, const double *__restrict__ X2,
+                                                  const double *__restrict__ Y1, const double *__restrict__ Y2,
+                                                  const double *__restrict__ Z1, const double *__restrict__ Z2,
+                                                  int nobs, const double *__restrict__ xd, const double *__restrict__ yd,
+                                                  const double *__restrict__ zd, const double *__restrict__ cw,
+                                                  double *__restrict__ rows, int *__restrict__ err,
+                                                  double *__restrict__ sumsq /* [nobs*3][gridDim.x] or null */)
+{
+    __shared__ double s_sq[PRISM_MAX_BATCH];
+    init_math_tables();
+    if (sumsq)
+        for (int o = threadIdx.x; o < nobs * 3; o += blockDim.x) s_sq[o] = 0.0;
+    __syncthreads();
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < N; p0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = p0 + threadIdx.x;
+        const bool active = p < N;
+        const int64_t pc = active ? p : N - 1;
+        const double x1 = X1[pc], x2 = X2[pc], y1 = Y1[pc], y2 = Y2[pc], z1 = Z1[pc], z2 = Z2[pc];
+        const double w = cw ? cw[pc] : 1.0;
+        for (int o = 0; o < nobs; ++o) {
+            double XX[2], YY[2], ZZ[2];
+            XX[0] = xd[o] - x1; XX[1] = xd[o] - x2;                     // :61-66
+            YY[0] = yd[o] - y1; YY[1] = yd[o] - y2;
+            ZZ[0] = zd[o] - z1; ZZ[1] = zd[o] - z2;
+            double g3[3] = {0.0, 0.0, 0.0};
+            int bad = 0;
+#pragma unroll
+            for (int K = 0; K < 2; ++K)
+#pragma unroll
+                for (int L = 0; L < 2; ++L)
+#pragma unroll
+                    for (int M = 0; M < 2; ++M) {
+                        const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;
+                        double tx, ty, tz;
+                        corner_term3(XX[K], YY[L], ZZ[M], tx, ty, tz, bad);
+                        g3[0] = g3[0] + dmu * tx;
+                        g3[1] = g3[1] + dmu * ty;
+                        g3[2] = g3[2] + dmu * tz;
+                    }
+            if (bad && active) atomicOr(err, bad);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double v = g_grav() * g3[c];                                                        // :118-120
+                if (cw) v = v * w;
+                const int sub = o * 3 + c;
+                if (active) rows[(int64_t)sub * N + p] = v;
+                if (sumsq) {
+                    double sq = active ? v * v : 0.0;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) sq += __shfl_down(sq, d);
+                    if ((threadIdx.x & 63) == 0) atomicAdd(&s_sq[sub], sq);
+                }
+            }
+        }
+    }
+    if (sumsq) {
+        __syncthreads();
+        for (int o = threadIdx.x; o < nobs * 3; o += blockDim.x) sumsq[(int64_t)o * gridDim.x + blockIdx.x] = s_sq[o];
+    }
+}
+
+// Tensor-product grid: like k_prism_gz_tensor the three corner terms depend on the node only; a workgroup evaluates the
+// (G3_X+1)(G3_Y+1)(G3_Z+1) nodes of its tile once (1.4 x {sqrt, 3 atan2, 3 log} per cell instead of 8) into three LDS planes and every
+// cell sums its 8 nodes per component in the reference's order -> the bits of k_prism_g3, and the Z sub-row those of k_prism_gz(_tensor).
+constexpr int G3_X = 32, G3_Y = 8, G3_Z = 4;
+constexpr int G3_NODES = (G3_X + 1) * (G3_Y + 1) * (G3_Z + 1);
+__global__ __launch_bounds__(256) void k_prism_g3_tensor(int nx, int ny, int nz, const double *__restrict__ xe,
+                                                         const double *__restrict__ ye, const double *__restrict__ ze, int nobs,
+                                                         const double *__restrict__ xd, const double *__restrict__ yd,
+                                                         const double *__restrict__ zd, const double *__restrict__ cw,
+                                                         double *__restrict__ rows, int *__restrict__ err, double *__restrict__ sumsq)
+{
+    __shared__ double T[3][G3_NODES];
+    __shared__ double s_w[4];
+    init_math_tables();                                   // (published by the first barrier of the observation loop)
+    __shared__ double s_xe[G3_X + 1], s_ye[G3_Y + 1], s_ze[G3_Z + 1];
+    __shared__ int s_node[G3_NODES];                      // LDS slot | a << 12 | b << 18 | c << 22
+    const int tiles_x = (nx + G3_X - 1) / G3_X, tiles_y = (ny + G3_Y - 1) / G3_Y;
+    const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, bz = blockIdx.x / (tiles_x * tiles_y);
+    const int i0 = bx * G3_X, j0 = by * G3_Y, k0 = bz * G3_Z;
+    const int cx = min(G3_X, nx - i0), cy = min(G3_Y, ny - j0), cz = min(G3_Z, nz - k0);
+    const int64_t N = (int64_t)nx * ny * nz;
+    const int nnode = (cx + 1) * (cy + 1) * (cz + 1);
+    int bad = 0;
+    for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
+        const int a = n % (cx + 1), b = (n / (cx + 1)) % (cy + 1), c = n / ((cx + 1) * (cy + 1));
+        s_node[n] = ((c * (G3_Y + 1) + b) * (G3_X + 1) + a) | (a << 12) | (b << 18) | (c << 22);
+    }
+    if (threadIdx.x <= cx) s_xe[threadIdx.x] = xe[i0 + threadIdx.x];
+    if (threadIdx.x <= cy) s_ye[threadIdx.x] = ye[j0 + threadIdx.x];
+    if (threadIdx.x <= cz) s_ze[threadIdx.x] = ze[k0 + threadIdx.x];
+    // one thread per (x, y) column of the tile, one cell per z layer (as in k_prism_gz_tensor)
+    static_assert(G3_X * G3_Y == 256, "one thread per (x, y) column of the tile");
+    constexpr int LAYER = (G3_Y + 1) * (G3_X + 1);
+    const int ta = threadIdx.x % G3_X, tb = threadIdx.x / G3_X;
+    const bool col_ok = ta < cx && tb < cy;
+    const int slot0 = tb * (G3_X + 1) + ta;
+    const int64_t col0 = ((int64_t)k0 * ny + (j0 + tb)) * nx + (i0 + ta), lay = (int64_t)ny * nx;
+    for (int o = 0; o < nobs; ++o) {
+        const double xo = xd[o], yo = yd[o], zo = zd[o];
+        lds_barrier();
+        for (int n = threadIdx.x; n < nnode; n += blockDim.x) {
+            const int code = s_node[n];
+            double tx, ty, tz;
+            corner_term3(xo - s_xe[(code >> 12) & 63], yo - s_ye[(code >> 18) & 15], zo - s_ze[code >> 22], tx, ty, tz, bad);
+            const int id = code & 4095;
+            T[0][id] = tx;
+            T[1][id] = ty;
+            T[2][id] = tz;
+        }
+        lds_barrier();
+        double sq[3] = {0.0, 0.0, 0.0};
+        if (col_ok) {
+#pragma unroll
+            for (int j = 0; j < G3_Z; ++j) {
+                if (j >= cz) break;
+                const int64_t col = col0 + j * lay;
+                const double w = cw ? cw[col] : 1.0;
+#pragma unroll
+                for (int comp = 0; comp < 3; ++comp) {
+                    const double *t0 = &T[comp][slot0 + j * LAYER];
+                    double gsum = 0.0;
+#pragma unroll
+                    for (int K = 0; K < 2; ++K)
+#pragma unroll
+                        for (int L = 0; L < 2; ++L)
+#pragma unroll
+                            for (int M = 0; M < 2; ++M) {
+                                const double dmu = ((K + L + M) & 1) ? 1.0 : -1.0;
+                                gsum = gsum + dmu * t0[(M * (G3_Y + 1) + L) * (G3_X + 1) + K];
+                            }
+                    double v = g_grav() * gsum;                                                     // :118-120
+                    if (cw) v = v * w;
+                    __builtin_nontemporal_store(v, &rows[(int64_t)(o * 3 + comp) * N + col]);
+                    sq[comp] = fma(v, v, sq[comp]);
+                }
+            }
+        }
+        if (sumsq) {                                        // cost_full (sensitivity_gravmag.F90:234), fixed order
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double t = sq[i];
+#pragma unroll
+                for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_down(t, dd);
+                lds_barrier();
+                if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+                lds_barrier();
+                if (threadIdx.x == 0) sumsq[(int64_t)(o * 3 + i) * gridDim.x + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+            }
+        }
+    }
+    if (bad) atomicOr(err, bad);
+}
+
+// =============================================================================================================
 // magnetic rows: magprism + sharmbox (src/forward/gravmag/mag/magnetic_field.f90:118-297, :321-457),
 // scalar susceptibility model, TMI data
 // =============================================================================================================
@@ -844,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_gradiprism_tensor(int nx, int ny, int n
 }
 
 // What produces the lines of one observation (sensitivity_gravmag.F90:193-220): nsub = ncd*ncm lines in (d, k) order.
-enum { GEN_GZ = 0, GEN_GZZ = 1, GEN_FTG = 2, GEN_MAG = 3 };
+enum { GEN_GZ = 0, GEN_GZZ = 1, GEN_FTG = 2, GEN_MAG = 3, GEN_G3 = 4 };
 struct RowGen {
     int kind = GEN_GZ;
     int ncd = 1, ncm = 1;
@@ -980,6 +1166,14 @@ int prism_rows_dev(tfx_ctx *ctx, const RowGen &gen, int nobs, const double *d_x,
     } else if (gen.kind == GEN_FTG) {
         hipLaunchKernelGGL((k_gradiprism<true>), dim3(grid), dim3(256), 0, s, GRID_ARGS, d_rows, d_err, d_sumsq);
         if (nblk) *nblk = grid;
+    } else if (gen.kind == GEN_G3 && ctx->tensor_grid) {
+        const int tiles = ((ctx->nx + G3_X - 1) / G3_X) * ((ctx->ny + G3_Y - 1) / G3_Y) * ((ctx->nz + G3_Z - 1) / G3_Z);
+        hipLaunchKernelGGL(k_prism_g3_tensor, dim3(tiles), dim3(256), 0, s, ctx->nx, ctx->ny, ctx->nz, ctx->edges[0].p, ctx->edges[1].p,
+                           ctx->edges[2].p, nobs, d_x, d_y, d_z, d_cw, d_rows, d_err, d_sumsq);
+        if (nblk) *nblk = tiles;
+    } else if (gen.kind == GEN_G3) {
+        hipLaunchKernelGGL(k_prism_g3, dim3(grid), dim3(256), 0, s, GRID_ARGS, d_rows, d_err, d_sumsq);
+        if (nblk) *nblk = grid;
     } else if (ctx->tensor_grid) {
         const int tiles = ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
         // (gen_grid_limit: the build's overlap mode caps the resident workgroups - see build_kernel_any)
@@ -1000,6 +1194,7 @@ int prism_rows_dev(tfx_ctx *ctx, const RowGen &gen, int nobs, const double *d_x,
 int prism_partials(tfx_ctx *ctx, const RowGen &gen)
 {
     if (ctx->tensor_grid && gen.kind == GEN_GZ) return ((ctx->nx + PT_X - 1) / PT_X) * ((ctx->ny + PT_Y - 1) / PT_Y) * ((ctx->nz + PT_Z - 1) / PT_Z);
+    if (ctx->tensor_grid && gen.kind == GEN_G3) return ((ctx->nx + G3_X - 1) / G3_X) * ((ctx->ny + G3_Y - 1) / G3_Y) * ((ctx->nz + G3_Z - 1) / G3_Z);
     if (ctx->tensor_grid && (gen.kind == GEN_GZZ || gen.kind == GEN_FTG)) return grad_tiles(ctx, gen.kind == GEN_FTG);
     if (ctx->tensor_grid && gen.kind == GEN_MAG) return ((ctx->nx + MT_X - 1) / MT_X) * ((ctx->ny + MT_Y - 1) / MT_Y) * ((ctx->nz + MT_Z - 1) / MT_Z);
     return (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->num_cu * 16);
@@ -2632,6 +2827,7 @@ static int geometry_error(int herr)
     if (herr & 8) return fail(TFX_E_GEOMETRY, "The model grid Y-boundary coincides with the data position");
     if (herr & 16) return fail(TFX_E_GEOMETRY, "Zero denominator in gradiprism_full! Adjust the model grid.");      // gravity_field.f90:275-277
     if (herr & 32) return fail(TFX_E_GEOMETRY, "Bad log argument in gradiprism_full! Adjust the model grid.");      // :282-284
+    if (herr & 64) return fail(TFX_E_GEOMETRY, "Data coordinate coincides with model grid boundary (XY). Adjust the model grid!");   // :102-104
     return 0;
 }
 
@@ -2643,8 +2839,10 @@ static int make_rowgen(RowGen &gen, int problem_type, int data_type, int ncd, in
     if (problem_type == 1) {
         if (ncm != 1) return fail(TFX_E_ARG, "gravity kernels have one model component");
         if (data_type == 1) {                                                                   // sensitivity_gravmag.F90:195-198
-            if (ncd != 1) return fail(TFX_E_ARG, "gravity data (type 1) has one data component");
-            gen.kind = GEN_GZ;
+            // one component: graviprism_z (gravity_field.f90:131-195); three: graviprism_full (:41-126), rows X, Y, Z
+            if (ncd == 1) gen.kind = GEN_GZ;
+            else if (ncd == 3) gen.kind = GEN_G3;
+            else return fail(TFX_E_ARG, "gravity data (type 1) has one (gz) or three (gx, gy, gz) data components");
         } else if (data_type == 2) {                                                            // :199-214
             if (ncd == 1) gen.kind = GEN_GZZ;
             else if (ncd == 6) gen.kind = GEN_FTG;

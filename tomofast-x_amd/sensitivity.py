@@ -184,6 +184,10 @@ class Context:
         check(self._lib.tfx_prism_rows_gz(self._h, C.c_int64(xd.size), ptr(xd), ptr(yd), ptr(zd), ptr(rows)))
         return rows
 
+    # ---- graviprism_full (gravity_field.f90:41-126): rows[ndata, 3, N] = LineX, LineY, LineZ of every observation
+    def graviprism_full(self, Xdata, Ydata, Zdata):
+        return self.sensit_lines(1, Xdata, Ydata, Zdata, data_type=1, ndata_components=3)[:, :, 0, :]
+
     # ---- magprism (TMI, scalar susceptibility); field = (inclination, declination, XaxisDeclination, intensity_nT)
     def magprism(self, Xdata, Ydata, Zdata, field):
         xd, yd, zd = f64(np.atleast_1d(Xdata)), f64(np.atleast_1d(Ydata)), f64(np.atleast_1d(Zdata))
@@ -193,7 +197,7 @@ class Context:
                                            C.c_double(azim), C.c_double(inten), ptr(rows)))
         return rows
 
-    # ---- any row generator of the build loop (graviprism_z, gradiprism_zz / _full, magprism with 1|3 components)
+    # ---- any row generator of the build loop (graviprism_z / _full, gradiprism_zz / _full, magprism with 1|3 components)
     def sensit_lines(self, problem_type, Xdata, Ydata, Zdata, data_type=1, ndata_components=1, nmodel_components=1, mag_field=None):
         """-> rows[ndata, ndata_components, nmodel_components, N] = the reference's sensit_line_full(:, k, d) per observation
         (sensitivity_gravmag.F90:193-220)."""

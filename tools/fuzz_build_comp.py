@@ -15,7 +15,7 @@ tfx = importlib.import_module("tomofast-x_amd")
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 9)
 ctx = tfx.Context(0)
-KINDS = [("gz", 1, 1, 1), ("gzz", 2, 1, 1), ("ftg", 2, 6, 1), ("mag", 1, 1, 1), ("mag", 1, 3, 1), ("mag", 1, 1, 3), ("mag", 1, 3, 3)]
+KINDS = [("gz", 1, 1, 1), ("g3", 1, 3, 1), ("gzz", 2, 1, 1), ("ftg", 2, 6, 1), ("mag", 1, 1, 1), ("mag", 1, 3, 1), ("mag", 1, 1, 3), ("mag", 1, 3, 3)]
 for case in range(ncases):
     nx, ny, nz = (int(rng.integers(2, 17)) for _ in range(3))
     ex = np.concatenate([[0.0], np.cumsum(rng.uniform(20.0, 180.0, nx))])
