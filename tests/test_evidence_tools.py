@@ -109,3 +109,38 @@ def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit):
         bench.main()
     assert called == [4]
+
+
+def test_missing_reference_binary_fails_where_it_was_expected(tmp_path, monkeypatch):
+    """tests/ref_binaries.py: a `-m gpu` test that does not find a reference binary / Fortran host skips on a machine that never had
+    it and FAILS where build() recorded it (oracle/ref_expected.json) or TFX_EXPECT_REFERENCE_BINARIES=1 says so."""
+    import pytest
+    import ref_binaries as rb
+    monkeypatch.setattr(rb, "MARKER", str(tmp_path / "ref_expected.json"))
+    monkeypatch.delenv("TFX_EXPECT_REFERENCE_BINARIES", raising=False)
+    with pytest.raises(pytest.skip.Exception):
+        rb.missing("not built")                                          # no marker, no variable: skip
+    (tmp_path / "ref_expected.json").write_text('{"binaries": ["oracle/_ref/tomofastx"], "mpiexec": true}')
+    with pytest.raises(pytest.fail.Exception):
+        rb.missing("not built")                                          # build() saw the binaries: a missing one fails
+    with pytest.raises(pytest.skip.Exception):
+        rb.missing("not built", "oracle/_ref/never_recorded")            # a binary build() did not record is not expected
+    with pytest.raises(pytest.fail.Exception):
+        rb.missing("not built", "oracle/_ref/tomofastx_not_here", "oracle/_ref/tomofastx") if not os.path.isfile(os.path.join(rb.ROOT, "oracle/_ref/tomofastx")) else rb.missing("not built")
+    monkeypatch.setenv("TFX_EXPECT_REFERENCE_BINARIES", "0")
+    with pytest.raises(pytest.skip.Exception):
+        rb.missing("not built")                                          # explicit opt-out
+    monkeypatch.setenv("TFX_EXPECT_REFERENCE_BINARIES", "1")
+    (tmp_path / "ref_expected.json").unlink()
+    with pytest.raises(pytest.fail.Exception):
+        rb.missing("not built")
+
+
+def test_no_plain_skip_left_in_the_gpu_tests():
+    """Every skip site of the `-m gpu` files goes through ref_binaries.missing."""
+    import glob
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "test_gpu_*.py"))):
+        txt = open(f).read()
+        assert "pytest.skip(" not in txt and "skipif" not in txt and "importorskip" not in txt, f

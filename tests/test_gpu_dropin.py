@@ -13,6 +13,8 @@ import numpy as np
 import pytest
 
 import test_gpu_fortran_host as fh
+from parity_report import report
+import ref_binaries
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +25,19 @@ MPIEXEC = "/opt/conda/bin/mpiexec"
 
 def _need_exe():
     if not os.path.isfile(EXE):
-        pytest.skip("oracle/_ref/dropin/tomofastx_dropin not built (oracle/dropin_build.sh needs /root/reference: development container)")
+        ref_binaries.missing("oracle/_ref/dropin/tomofastx_dropin not built (oracle/dropin_build.sh needs /root/reference: development container)")
+
+
+def test_expected_reference_binaries_are_present():
+    """What build() recorded in the development container (oracle/ref_expected.json) arrived on this box: the compiled reference, the
+    golden drivers, the reference's program with the drop-in modules, the three Fortran hosts, mpiexec.  One clear failure here
+    instead of eighty skipped parity tests."""
+    want, want_mpi = ref_binaries.expected()
+    gone = [p for p in sorted(want) if not os.path.isfile(os.path.join(ref_binaries.ROOT, p))]
+    if want_mpi and not os.path.isfile(ref_binaries.MPIEXEC):
+        gone.append(ref_binaries.MPIEXEC)
+    assert not gone, "recorded as built, missing here: %s" % ", ".join(gone)
+    report("expected_reference_binaries", expected=sorted(want), missing=gone)
 
 
 def test_reference_unit_tests_pass_on_the_dropin(tmp_path):
@@ -41,6 +55,7 @@ def test_reference_unit_tests_pass_on_the_dropin(tmp_path):
     runs = int(txt.split("Number of runs needed to complete the tests:")[1].split()[0]) if "Number of runs needed" in txt else 1
     ntests = txt.count("Test:")
     print("reference unit tests on the drop-in: %d tests, %d failed assertions, %d run(s)" % (ntests, failed, runs))
+    report("dropin_reference_unit_tests", tests=ntests, failed_assertions=failed)
     assert failed == 0 and ntests >= 17
 
 
@@ -70,6 +85,7 @@ def test_config1_parfile_on_the_reference_program_with_the_dropin(tmp_path, gold
     dcost = abs(float(rec[last + 1]) - 9.339172972115141e-11) / 9.339172972115141e-11
     print("config 1 on the reference's own program + drop-in: nnz %d, final model rel-L2 %.3e, final data cost %s (relative distance %.3e)" %
           (nnz, rel, rec[last + 1], dcost))
+    report("config1_mansf_end_to_end[reference program + drop-in]", model_rel_l2=float(rel), data_cost=float(rec[last + 1]), data_cost_rel_distance=float(dcost), nnz=nnz)
     assert rel <= 1e-6, rel
     assert int(float(rec[last])) == 60 and dcost <= 5e-6, (rec[last], dcost)
 
@@ -161,6 +177,7 @@ def test_reference_program_with_the_dropin_matches_the_all_cpu_reference(tmp_pat
         rs = [float(t.split()[0]) for t in out.stdout.split("End of subroutine lsqr_solve_sensit, r =")[1:]]
         assert len(rs) == len(g["np1_lsqr_r"]) and np.allclose(rs, g["np1_lsqr_r"], rtol=1e-4), (rs[-3:], g["np1_lsqr_r"][-3:])
     print("%s on the reference's own program + drop-in: final model rel-L2 %s (asserted <= %.1e)" % (name, ", ".join("%.2e" % r for r in rels), tol))
+    report("dropin_fixture[%s]" % name, model_rel_l2=rels, asserted=tol)
     assert max(rels) <= tol, (name, rels)
 
 
@@ -185,6 +202,7 @@ def test_medium_scale_on_the_reference_program_with_the_dropin(tmp_path, golden_
     own = max(float(g["np%d_model_rel_l2_vs_np1" % n]) for n in (2, 4, 8))
     print("%s on the reference's own program + drop-in: nnz %d (reference %d), final model rel-L2 %.2e (the reference between rank counts: %.1e)" %
           (name, nnz, int(g["nnz_total"]), rel, own))
+    report("dropin_medium_scale[%s]" % name, model_rel_l2=rel, reference_own_rank_scatter=own, nnz=nnz, nnz_reference=int(g["nnz_total"]))
     assert nnz == int(g["nnz_total"])
     assert rel <= 5e-8, rel
 
@@ -196,7 +214,7 @@ def test_two_ranks_of_the_reference_program_with_the_dropin(tmp_path, golden_dir
     modules, against the reference's own 2-rank run of the same Parfile."""
     _need_exe()
     if not os.path.isfile(MPIEXEC):
-        pytest.skip("no mpiexec in this image")
+        ref_binaries.missing("no mpiexec in this image")
     kind, extra, tol = CASES[name]
     g = fh._load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
@@ -222,6 +240,7 @@ def test_two_ranks_of_the_reference_program_with_the_dropin(tmp_path, golden_dir
         rel = np.linalg.norm(model - ref) / np.linalg.norm(ref)
         print("%s, 2 ranks of the reference's own program + drop-in: %s final model rel-L2 %.2e from the reference's 2-rank run (its 1- vs 2-rank: %.1e)" %
               (name, sfx, rel, self_diff))
+        report("dropin_two_ranks[%s, %s]" % (name, sfx), model_rel_l2=float(rel), reference_own_1_vs_2_ranks=float(self_diff))
         assert rel <= max(1e-6, 100.0 * self_diff), (tag, rel)
 
 
@@ -249,6 +268,7 @@ def test_dropin_reloads_the_kernel_files_it_wrote(tmp_path, golden_dir):
     for mode, m in enumerate(models):
         rel = float(np.linalg.norm(m - ref) / np.linalg.norm(ref))
         print("drop-in, sensit.readFromFiles = %d: final model rel-L2 %.2e from the reference" % (mode, rel))
+        report("dropin_sensit_read_from_files[%d]" % mode, model_rel_l2=rel)
         assert rel <= 3e-5
     assert np.array_equal(models[0], models[1]) and np.array_equal(models[0], models[2])
 
@@ -296,7 +316,7 @@ def test_hamersley_field_data_examples_of_the_reference(tmp_path, golden_dir, ca
     against 4.1e-5).  The joint example: test_hamersley_joint_cross_gradient_example."""
     exe = EXE if host.startswith("reference") else fh.EXE
     if not os.path.isfile(exe):
-        pytest.skip("%s not built" % exe)
+        ref_binaries.missing("%s not built" % exe)
     g = fh._load_npz(os.path.join(golden_dir, "hamersley.npz"))
     tag = "grav" if case == "grav" else "mag"
     r, models, data = _run_hamersley(str(tmp_path), g, exe, str(g[case + "_parfile"]), str(g[case + "_outdir"]), (tag,))
@@ -307,6 +327,7 @@ def test_hamersley_field_data_examples_of_the_reference(tmp_path, golden_dir, ca
     drel = float(np.linalg.norm(data[tag] - dref) / np.linalg.norm(dref))
     print("hamersley %s, %s: final model rel-L2 %.2e, final data rel-L2 %.2e from the reference's 1-rank run (its own 1- vs 2-rank: %.1e)" %
           (case, host, rel, drel, own))
+    report("hamersley[%s, %s]" % (case, host), model_rel_l2=rel, data_rel_l2=drel, reference_own_1_vs_2_ranks=own)
     assert rel <= max(1e-6, 20.0 * own), (rel, own)
     assert drel <= max(1e-6, 20.0 * own), (drel, own)
 
@@ -329,7 +350,7 @@ def test_hamersley_joint_cross_gradient_example(tmp_path, golden_dir, host):
     import re
     exe = EXE if host.startswith("reference") else fh.EXE
     if not os.path.isfile(exe):
-        pytest.skip("%s not built" % exe)
+        ref_binaries.missing("%s not built" % exe)
     g = fh._load_npz(os.path.join(golden_dir, "hamersley.npz"))
     c = fh._load_npz(os.path.join(golden_dir, "hamersley_xgrad_conv.npz"))
     par, outdir, tags = str(g["xgrad_parfile"]), str(g["xgrad_outdir"]), ("grav", "mag")
@@ -347,11 +368,13 @@ def test_hamersley_joint_cross_gradient_example(tmp_path, golden_dir, host):
         assert len(r) == 1
         print("hamersley xgrad, %s, 1 x %d iterations: r = %.12e, reference %.12e (relative difference %.1e)" %
               (host, nminor, r[0], r_ref, abs(r[0] - r_ref) / r_ref))
+        report("hamersley_xgrad_first_solve[%s, 1 x %d]" % (host, nminor), r=r[0], r_reference=r_ref, r_rel_diff=abs(r[0] - r_ref) / r_ref)
         if nminor == 1600:
             assert abs(r[0] - r_ref) <= 1e-8 * r_ref, (r[0], r_ref)                      # measured 4.4e-11
             for t in tags:
                 m_rel, d_rel = rel(models[t], c["%s_model_1x1600" % t]), rel(data[t], c["%s_data_1x1600" % t])
                 print("   converged first solve, %s: model rel-L2 %.2e, data rel-L2 %.2e from the reference's" % (t, m_rel, d_rel))
+                report("hamersley_xgrad_converged[%s, %s]" % (host, t), model_rel_l2=m_rel, data_rel_l2=d_rel)
                 assert m_rel <= 1e-7 and d_rel <= 1e-7, (t, m_rel, d_rel)                # measured 4.5e-9 / 1.4e-10 and 2.4e-9 / 1.8e-10
         else:
             assert r[0] <= r_ref * (1.0 + 2e-3), (nminor, r[0], r_ref)                   # at least as converged as the reference's arithmetic
@@ -369,4 +392,5 @@ def test_hamersley_joint_cross_gradient_example(tmp_path, golden_dir, host):
         m_rel, d_rel = rel(models[t], ref), rel(data[t], g["xgrad_np1_%s_data_final" % t])
         own = rel(g["xgrad_np2_%s_model_final" % t], ref)
         print("   15 x 100, %s: final model rel-L2 %.2e, final data rel-L2 %.2e from the reference's 1-rank run (its own 1- vs 2-rank: %.1e)" % (t, m_rel, d_rel, own))
+        report("hamersley_xgrad_15x100[%s, %s]" % (host, t), model_rel_l2=m_rel, data_rel_l2=d_rel, reference_own_1_vs_2_ranks=own)
         assert m_rel <= 0.15 and d_rel <= 0.05, (t, m_rel, d_rel)

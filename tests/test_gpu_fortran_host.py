@@ -8,6 +8,8 @@ import subprocess
 
 import numpy as np
 import pytest
+import ref_binaries
+from parity_report import report
 
 pytestmark = pytest.mark.gpu
 
@@ -96,7 +98,7 @@ def write_inputs(wd, g):
 
 def test_config1_from_parfile_matches_reference_outputs(tmp_path, golden_dir):
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, "mansf.npz"))
     wd = str(tmp_path)
     write_inputs(wd, g)
@@ -120,6 +122,7 @@ def test_config1_from_parfile_matches_reference_outputs(tmp_path, golden_dir):
     # final data cost: SURVEY 8d asks for <= 1e-5 relative; the reference's own 1 / 2 / 4-rank runs scatter by 1.5e-6
     dcost = abs(float(costs[-1][1]) - 9.339172972115141e-11) / 9.339172972115141e-11
     print("config 1 (Fortran host): final model rel-L2 %.3e, final data cost %s (relative distance %.3e)" % (rel, costs[-1][1], dcost))
+    report("config1_mansf_end_to_end[shipping Fortran host]", model_rel_l2=float(rel), data_cost=float(costs[-1][1]), data_cost_rel_distance=float(dcost))
     assert dcost <= 5e-6, dcost          # measured 1.9-2.0e-6 on either host
     assert abs(float(costs[-1][2]) - 0.22595168071843558) <= 1e-5 * 0.22595168071843558            # final model cost
 
@@ -137,7 +140,7 @@ def test_multicomponent_parfiles_match_reference_outputs(tmp_path, golden_dir, n
     magnetisation vector; the Parfile text is ours, tests/golden/make_golden.py) through the Fortran host: same input
     files, same output files."""
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     n = g["X1"].size
@@ -205,7 +208,7 @@ def test_sensit_files_written_like_the_reference_and_reloaded(tmp_path, golden_d
     (written from the fixture) is re-loaded with sensit.readFromFiles = 1 and gives the reference's model."""
     import importlib
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     sio = importlib.import_module("tomofast-x_amd").sensit_io
     g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
@@ -275,7 +278,7 @@ def write_joint_inputs(wd, g):
 def test_joint_parfile_matches_reference_outputs(tmp_path, golden_dir):
     """Joint gravity + magnetic inversion from the Parfile (both problem weights non-zero): two kernels, one LSQR system."""
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, "e2e_joint.npz"))
     wd = str(tmp_path)
     write_joint_inputs(wd, g)
@@ -298,7 +301,7 @@ def test_cross_gradient_parfile_matches_reference(tmp_path, golden_dir, name):
     """inversion.crossGradient.weight /= 0 on a joint run: the host builds the 3 N coupling rows over both models' columns
     (forward or central differences), uploads them as the general constraint matrix, WAVELET_DOMAIN = F."""
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     write_joint_inputs(wd, g)
@@ -319,7 +322,7 @@ def test_clustering_parfile_matches_reference(tmp_path, golden_dir, name):
     """inversion.clustering.*.weight /= 0 on a joint run: the host reads the mixture (and per-cell weight) files, builds the 2 N
     Gaussian-mixture rows each major iteration and uploads them as the general constraint matrix, WAVELET_DOMAIN = F."""
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     write_joint_inputs(wd, g)
@@ -351,9 +354,9 @@ def test_two_ranks_under_mpiexec_match_the_reference_two_rank_run(tmp_path, gold
     reference's nnz-balancing rule, LSQR reductions through the MPI-staged hook, model-update slices gathered per major
     iteration - against the reference's own 2-rank run of the same Parfile."""
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     if not os.path.isfile(MPIEXEC):
-        pytest.skip("no mpiexec in this image")
+        ref_binaries.missing("no mpiexec in this image")
     g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     if name == "e2e_joint":
@@ -428,9 +431,9 @@ def test_config1_with_admm_under_mpiexec(tmp_path, golden_dir, nranks):
     sides come from the gathered model - the final model must be the single-rank run's (the reference's own 1- vs 2- vs 4-rank
     scatter on this Parfile is 5e-12)."""
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     if not os.path.isfile(MPIEXEC):
-        pytest.skip("no mpiexec in this image")
+        ref_binaries.missing("no mpiexec in this image")
     g = _load_npz(os.path.join(golden_dir, "mansf.npz"))
     wd = str(tmp_path)
     write_inputs(wd, g)
@@ -451,9 +454,9 @@ def test_spatial_unknowns_two_ranks_under_mpiexec(tmp_path, golden_dir, name):
     range (tfx_lsqr_set_partition), the constraint rows replicated with each rank's own columns - against the reference's own
     2-rank run of the same Parfile."""
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     if not os.path.isfile(MPIEXEC):
-        pytest.skip("no mpiexec in this image")
+        ref_binaries.missing("no mpiexec in this image")
     g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     if name == "e2e_dgrad":
@@ -514,7 +517,7 @@ def test_row_parallel_build_with_mpi_relayout(tmp_path):
     Same final model as the single-rank run and as the scheme where every rank builds all rows for its own columns."""
     import importlib
     if not os.path.isfile(EXE) or not os.path.isfile(MPIEXEC):
-        pytest.skip("Fortran host / mpiexec not available")
+        ref_binaries.missing("Fortran host / mpiexec not available")
     syn = importlib.import_module("tomofast-x_amd").synthetic
     nx, ny, nz = 32, 24, 12
     grid = syn.grid(nx, ny, nz)
@@ -569,7 +572,7 @@ def test_sensit_files_of_a_multi_rank_run(tmp_path):
     2-rank run with sensit.readFromFiles = 1 on it gives the same model."""
     import importlib
     if not os.path.isfile(EXE) or not os.path.isfile(MPIEXEC):
-        pytest.skip("Fortran host / mpiexec not available")
+        ref_binaries.missing("Fortran host / mpiexec not available")
     pkg = importlib.import_module("tomofast-x_amd")
     syn = pkg.synthetic
     nx, ny, nz = 32, 24, 12
@@ -620,7 +623,7 @@ def test_gradient_damping_parfile_matches_reference(tmp_path, golden_dir):
     """inversion.dampingGradient.grav.weight /= 0: the host builds the first-difference rows, uploads them as the general
     constraint matrix and solves with WAVELET_DOMAIN = F (spatial unknowns, per-iteration device transform)."""
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, "e2e_dgrad.npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
@@ -637,7 +640,7 @@ def test_gradient_damping_parfile_matches_reference(tmp_path, golden_dir):
 def test_mindist_depth_weight_parfile_matches_reference(tmp_path, golden_dir):
     """forward.depthWeighting.type = 3 from the Parfile: calculate_depth_weight -> tfx_column_weight_type3, then the usual run."""
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, "e2e_dw3.npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
@@ -654,7 +657,7 @@ def test_mindist_depth_weight_parfile_matches_reference(tmp_path, golden_dir):
 
 def test_lp_norm_damping_parfile_matches_reference(tmp_path, golden_dir):
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, "e2e_lp.npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
@@ -668,7 +671,7 @@ def test_lp_norm_damping_parfile_matches_reference(tmp_path, golden_dir):
 
 def test_admm_local_bounds_parfile_matches_reference(tmp_path, golden_dir):
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, "e2e_admm_local.npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
@@ -686,7 +689,7 @@ def test_admm_local_bounds_parfile_matches_reference(tmp_path, golden_dir):
 
 def test_data_errors_parfile_matches_reference(tmp_path, golden_dir):
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, "e2e_err.npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
@@ -713,7 +716,7 @@ def test_data_errors_parfile_matches_reference(tmp_path, golden_dir):
 @pytest.mark.parametrize("name", ["e2e_localw", "e2e_localw_lp"])
 def test_local_weights_parfile_matches_reference(tmp_path, golden_dir, name):
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     g = _load_npz(os.path.join(golden_dir, name + ".npz"))
     wd = str(tmp_path)
     write_case_inputs(wd, g)
@@ -734,7 +737,7 @@ def test_local_weights_parfile_matches_reference(tmp_path, golden_dir, name):
 
 def test_parfile_errors_like_the_reference(tmp_path):
     if not os.path.isfile(EXE):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     out = _sub_run([EXE], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "UNKNOWN Parfile" in out.stdout
     open(os.path.join(str(tmp_path), "P.txt"), "w").write("inversion.joint.grav.problemWeight = 1.d0\nfoo.bar = 3\nmodelGrid.size = 2 2 2\n"

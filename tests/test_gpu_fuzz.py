@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import pytest
+import ref_binaries
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +16,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                          ("fuzz_hosts.py", ["6", "907"])])
 def test_randomised_sweep(script, args):
     if script == "fuzz_hosts.py" and not os.path.isfile(os.path.join(ROOT, "tomofast-x_amd", "host", "tomofastx_amd")):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)] + args, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout.splitlines()[-1], out.stdout[-2000:] + out.stderr[-3000:]

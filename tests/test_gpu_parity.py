@@ -22,6 +22,7 @@ import kat_cases
 import oracle_lib as orc
 import oracle_inversion as oinv
 from parity_report import report
+import ref_binaries
 
 pytestmark = pytest.mark.gpu
 
@@ -639,6 +640,8 @@ def test_normalize_columns_vs_reference(ctx, adj_copy):
         same_norm = (norm_g == norm_o)[cols - 1]
         print("normalize_columns: %d of %d norms identical to the sequential sums, worst relative distance %.2e" %
               (np.count_nonzero(norm_g == norm_o), ncols, np.max(np.abs(norm_g - norm_o) / np.maximum(norm_o, 1e-300))))
+        report("normalize_columns", norms_identical=int(np.count_nonzero(norm_g == norm_o)), norms=int(ncols),
+               worst_rel_distance=float(np.max(np.abs(norm_g - norm_o) / np.maximum(norm_o, 1e-300))))
         assert vals_g.size == vals_o.size and bits_equal(vals_g[same_norm], vals_o[same_norm])
         assert np.all(np.abs(vals_g.astype(np.float64) - vals_o) <= 2.0 ** -23 * np.abs(vals_o))
         # the adjoint (on the copy when there is one) sees the normalised values
@@ -882,6 +885,8 @@ def test_lsqr_vs_reference_golden(ctx, golden_dir, case):
             assert it == itref
             assert abs(r - rref) <= (1e-3 if mid else 1e-7) * abs(rref)
         tol = 1e-12 if niter <= 5 else (1e-2 if mid else 1e-8)
+        report("lsqr_vs_reference_golden[%s, %d iterations]" % (case, int(niter)), x_rel_l2=float(np.linalg.norm(x - xref) / np.linalg.norm(xref)),
+               r_rel=float(abs(r - rref) / abs(rref)), iterations=int(it), iterations_reference=int(itref), mid_convergence=bool(mid))
         assert np.linalg.norm(x - xref) <= tol * np.linalg.norm(xref), (case, niter)
 
 
@@ -902,6 +907,8 @@ def test_lsqr_general_constraint_matrix_vs_reference(ctx, golden_dir):
             early = itref < niter
             assert (abs(it - itref) <= 0.1 * itref) if early else (it == itref)
             tol = 1e-12 if niter <= 5 else (1e-9 if (early or niter >= 50) else 1e-3)
+            report("lsqr_general_constraint_matrix[%d iterations]" % int(niter), x_rel_l2=float(np.linalg.norm(x - xref) / np.linalg.norm(xref)),
+                   r_rel=float(abs(r - rref) / abs(rref)), iterations=int(it), iterations_reference=int(itref))
             assert np.linalg.norm(x - xref) <= tol * np.linalg.norm(xref), (niter,)
         # diagonal blocks and a general C together: [S; C; 0.05 I] vs the oracle
         d = np.full(ncols, np.float32(0.05), np.float32)
@@ -1121,6 +1128,8 @@ def test_unconverged_lsqr_is_closer_to_extended_precision_than_sequential_fp64(c
         g_e, g_s = rel(x_gpu, x_ext), rel(x_gpu, x_seq)
         print("LSQR x %d, adj_copy %d: residual seq64 %.9e / gpu %.9e / ext80 %.9e; model rel-L2 gpu-ext80 %.2e, seq64-ext80 %.2e, gpu-seq64 %.2e" %
               (K, adj_copy, r_seq, r_gpu, r_ext, g_e, s_e, g_s))
+        report("unconverged_lsqr_vs_extended_precision[adj_copy=%d]" % adj_copy, iterations=int(K), r_seq64=r_seq, r_gpu=r_gpu, r_ext80=r_ext,
+               model_gpu_vs_ext80=g_e, model_seq64_vs_ext80=s_e, model_gpu_vs_seq64=g_s)
         assert g_e <= s_e, (g_e, s_e)                                   # the solution: nearer the long-double trajectory than the reference's arithmetic
         assert abs(r_gpu - r_ext) <= abs(r_seq - r_ext), (r_gpu, r_seq, r_ext)      # and so is the residual
         assert g_s <= 2.0 * (g_e + s_e)                                 # (triangle: nothing else separates the two fp64 runs)
@@ -1183,6 +1192,7 @@ def test_medium_scale_end_to_end_vs_reference(ctx, golden_dir, name):
            "reference_own_scatter_np2_4_8_vs_np1": ref_scatter, "data_rel_l2": data_rel, "data_cost_rel_diff": cost_rel,
            "data_cost": hist[-1]["cost"], "data_cost_reference": cost_ref}
     print(json.dumps(out))
+    report("medium_scale_end_to_end[%s]" % name, **out)
     try:
         os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
         json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "medium_parity_%s.json" % name), "w"), indent=1)
@@ -1791,6 +1801,8 @@ def test_config1_mansf_end_to_end(ctx, golden_dir):
     dcost = abs(hist[-1]["cost"] - 9.339172972115141e-11) / 9.339172972115141e-11
     print("config 1: final model rel-L2 %.3e, final data cost %.15e (relative distance %.3e; reference rank scatter 1.5e-6)" %
           (rel, hist[-1]["cost"], dcost))
+    report("config1_mansf_end_to_end[python host]", model_rel_l2=rel, data_cost=hist[-1]["cost"], data_cost_rel_distance=dcost,
+           reference_rank_scatter_model=4e-12, reference_rank_scatter_cost=1.5e-6, sparsity_identical=frac, max_fp32_ulp=maxulp)
     assert dcost <= 5e-6, dcost          # measured 1.9-2.0e-6 on either host
 
 
@@ -1947,12 +1959,29 @@ def test_band_select_on_adversarial_rows(ctx, kind):
         assert abs(da - db) <= 1e-12 * max(da, 1e-300)
 
 
+def stratified_rows(ox, oy, RB=2048):
+    """Rows of an ox x oy observation lattice (row = j * ox + i) spread over it: the four corners, two edge midpoints, the centre, and
+    the first / last row of three interior row blocks of the device matrix (RB rows each) - 13 rows when they are all distinct."""
+    D = ox * oy
+    rows = [0, ox - 1, (oy - 1) * ox, D - 1,                        # corners
+            ox // 2, (oy // 2) * ox,                                # midpoints of two edges
+            (oy // 2) * ox + ox // 2]                               # centre
+    nblk = (D + RB - 1) // RB
+    for blk in sorted({max(1, nblk // 4), max(1, nblk // 2), max(1, (3 * nblk) // 4)}):
+        if blk * RB < D:
+            rows += [blk * RB - 1, blk * RB]                        # last row of a block, first of the next
+    out = []
+    for r in rows:
+        if 0 <= r < D and r not in out:
+            out.append(r)
+    return out
+
+
 FULL_SIZE = {
     # BASELINE.json configs[4] (the configuration the metric is quoted on), configs[2] and configs[1] at their full sizes
-    # rows checked against the oracle: corners, centre and interior rows of the observation lattice, first / last rows of row blocks
-    "config5_hamersley_d4": dict(nx=256, ny=256, nz=152, ox=316, oy=316, ctype=2, rate=0.02, rows=(0, 2047, 2048, 31337, 50123, 77777, -1)),
-    "config3_haar_512": dict(nx=512, ny=512, nz=128, ox=256, oy=256, ctype=1, rate=0.01, rows=(0, 4095, 33001, 49999, -1)),
-    "config2_dense_256": dict(nx=256, ny=256, nz=64, ox=64, oy=64, ctype=0, rate=1.0, rows=(0, 2077, -1)),
+    "config5_hamersley_d4": dict(nx=256, ny=256, nz=152, ox=316, oy=316, ctype=2, rate=0.02, min_rows=12),
+    "config3_haar_512": dict(nx=512, ny=512, nz=128, ox=256, oy=256, ctype=1, rate=0.01, min_rows=12),
+    "config2_dense_256": dict(nx=256, ny=256, nz=64, ox=64, oy=64, ctype=0, rate=1.0, min_rows=8),
 }
 
 
@@ -1961,21 +1990,33 @@ def test_full_size_build_properties_and_sampled_rows_vs_oracle(ctx, name):
     """BASELINE's single-GPU configurations at FULL size (config 5: 9.96e6 cells x 99 856 data, D4 r = 0.02, nnz 1.99e10; config 3:
     3.36e7 cells x 65 536 data, Haar r = 0.01, nnz 2.2e10; config 2: 4.19e6 cells x 4096 data kept dense, 1.72e10 entries).
     The oracle cannot build such a matrix, so the check is through size-independent properties of the whole device matrix - entry
-    count, adjoint identity <S x, y> = <x, S^T y>, linearity - plus three rows pulled out with S^T e_r and compared with the
-    oracle's rows (sparsity and fp32 values), plus one forward product entry per pulled row against the oracle's row."""
+    count, adjoint identity <S x, y> = <x, S^T y>, linearity - plus rows stratified over the observation lattice (corners, edges,
+    centre, first / last rows of interior row blocks: stratified_rows) pulled out with S^T e_r and compared with the oracle's rows
+    (sparsity and fp32 values), one forward product entry per pulled row against the oracle's row, and an LSQR run AT THE SIZE THE
+    BENCH TIMES (lsqr_solver2.F90:163-290): the residual it reports is the residual of the augmented system recomputed from the
+    products, two solves give identical bits, the residual falls and the gradient of the damped least-squares functional falls."""
     # (a smaller part FAILS here with the reason instead of skipping: an unexercised configuration must not hide in a green suite)
     assert ctx.device_info()["hbm_bytes"] >= 200e9, "the full-size configurations need the 288 GB of an MI355X"
+    from concurrent.futures import ThreadPoolExecutor
     c = FULL_SIZE[name]
     nx, ny, nz = c["nx"], c["ny"], c["nz"]
     grid = tfx.synthetic.grid(nx, ny, nz)
     xs, ys, zs = tfx.synthetic.observations(nx, ny, c["ox"], c["oy"])
     N, D = nx * ny * nz, xs.size
     K = int(c["rate"] * N) if c["ctype"] > 0 else N
+    rows = stratified_rows(c["ox"], c["oy"])
+    assert len(rows) >= c["min_rows"], rows
+    # the oracle's rows (scalar C, seconds each at 1e7 cells) on host threads while the GPU builds the matrix
+    cw_o = orc.column_weight_type1(grid)
+    pool = ThreadPoolExecutor(max_workers=min(len(rows), max(1, (os.cpu_count() or 2) // 2)))
+    futures = {r: pool.submit(orc.build_row_grav, grid, (nx, ny, nz), cw_o, (xs[r], ys[r], zs[r]), c["ctype"], K) for r in rows}
     ctx.set_grid(nx, ny, nz, *grid)
     cw = ctx.calculate_depth_weight()
     b0, f0 = ctx.debug_set("band_batches"), ctx.debug_set("band_fallbacks")
+    rep = {"cells": N, "data": D, "rows_checked": len(rows)}
     try:
         res = ctx.calculate_sensit(xs, ys, zs, cw, c["ctype"], c["rate"])
+        rep["nnz"] = int(res["nnz"])
         if c["ctype"] > 0:
             nb = ctx.debug_set("band_batches") - b0
             assert nb > 1000 and ctx.debug_set("band_fallbacks") - f0 <= 0.02 * nb    # thresholds by the band select, rare fallbacks
@@ -1986,35 +2027,65 @@ def test_full_size_build_properties_and_sampled_rows_vs_oracle(ctx, name):
         rng = np.random.default_rng(1)
         x, x2, y = rng.standard_normal(N), rng.standard_normal(N), rng.standard_normal(D)
         Sx, Sx2, STy = ctx.mult_vector(x), ctx.mult_vector(x2), ctx.trans_mult_vector(y)
-        assert abs(np.dot(Sx, y) - np.dot(x, STy)) <= 1e-11 * np.linalg.norm(Sx) * np.linalg.norm(y)
-        assert np.allclose(ctx.mult_vector(2.0 * x - 3.0 * x2), 2.0 * Sx - 3.0 * Sx2, rtol=0, atol=1e-11 * np.abs(Sx).max())
-        cw_o = orc.column_weight_type1(grid)
-        for r in c["rows"]:
-            r = r % D
+        rep["adjoint_identity"] = float(abs(np.dot(Sx, y) - np.dot(x, STy)) / (np.linalg.norm(Sx) * np.linalg.norm(y)))
+        assert rep["adjoint_identity"] <= 1e-11
+        rep["linearity"] = float(np.abs(ctx.mult_vector(2.0 * x - 3.0 * x2) - (2.0 * Sx - 3.0 * Sx2)).max() / np.abs(Sx).max())
+        assert rep["linearity"] <= 1e-11
+        worst_scale, worst_ulp, ident, total = 0.0, 0.0, 0, 0
+        for r in rows:
             e = np.zeros(D)
             e[r] = 1.0
             row = ctx.trans_mult_vector(e)                                    # row r of S, dense
             cb = np.nonzero(row)[0] + 1
-            c_ref, v_ref, _ = orc.build_row_grav(grid, (nx, ny, nz), cw_o, (xs[r], ys[r], zs[r]), c["ctype"], K)
+            c_ref, v_ref, _ = futures[r].result()
             common, ib, ir = np.intersect1d(cb, c_ref, return_indices=True)
             assert common.size >= 0.9999 * c_ref.size and abs(cb.size - c_ref.size) <= 0.0001 * c_ref.size + 2
             vb = row[cb - 1].astype(np.float32)
-            # fp32 values: within 2 ulp, or within 1e-8 of the row's largest entry.  The device libm and the host libm differ in
-            # the last bits of log / atan2; the 8 corner terms of a cell (~1e5 each) cancel to ~1e-3 of their size and the
-            # transform adds up to 1e7 such cells into a coefficient, so the difference shows at ~1e-9 of the row scale (measured:
-            # 1.2e-9) - far below the fp32 resolution of the large entries, above it for the smallest kept ones.
+            # fp32 values: within 1 ulp, or within `slack` of the row's largest entry.  The device log / atan2 and the host libm differ
+            # in the last bits; the 8 corner terms of a cell (~1e5 each) cancel to ~1e-3 of their size and the transform adds up to 1e7
+            # such cells into a coefficient, so the difference shows at ~1e-10 of the row scale - far below the fp32 resolution of the
+            # large entries, above it for the smallest kept ones.  (Measured: compressed kernels <= 1.2e-10 of the row maximum, 86-99 %
+            # of the kept values identical in fp32; the dense rows of config 2 - no transform between the prism sums and the
+            # comparison, entries over seven decades - 4.3e-9.  The numbers of every run: gpurun_out/parity_report.jsonl.)
             dv = np.abs(vb[ib].astype(np.float64) - v_ref[ir].astype(np.float64))
             ulp = np.spacing(np.abs(v_ref[ir])).astype(np.float64)
             worst_row = float((dv / np.abs(v_ref).max()).max())
+            worst_scale, worst_ulp = max(worst_scale, worst_row), max(worst_ulp, float((dv / ulp).max()))
+            ident, total = ident + int(np.count_nonzero(dv == 0.0)), total + dv.size
             print("%s row %d: %d of %d kept values identical in fp32, worst |difference| / row maximum %.2e, worst distance %.1f fp32 ulp" %
                   (name, r, int(np.count_nonzero(dv == 0.0)), dv.size, worst_row, float((dv / ulp).max())))
-            # (rounds 1-4 asserted 2 ulp + 1e-8 of the row maximum.  Measured in round 5: compressed kernels <= 1.2e-10 of the row maximum,
-            # 86-99 % of the kept values identical in fp32; the dense rows of config 2 - no transform between the prism sums and the
-            # comparison, entries over seven decades - 4.3e-9)
             slack = 8e-9 if c["ctype"] == 0 else 5e-10
             assert np.all(dv <= 1.0 * ulp + slack * float(np.abs(v_ref).max())), worst_row
             assert abs(Sx[r] - np.dot(v_ref.astype(np.float64), x[c_ref - 1])) <= 1e-6 * np.abs(v_ref).astype(np.float64) @ np.abs(x[c_ref - 1])
+        rep.update(rows=rows, worst_value_distance_over_row_scale=worst_scale, worst_fp32_ulp=worst_ulp, fp32_identical_fraction=ident / max(total, 1))
+
+        # ---- LSQR at this size: b = S m for a smooth model, damping alpha = 1e-7 (lsqr_solver2.F90:163-290)
+        m_true = 1e-3 * np.sin(np.arange(N) * (2 * np.pi / 977.0)) * np.exp(-np.arange(N) / N)
+        b = ctx.mult_vector(m_true)
+        alpha = np.full(N, 1e-7, np.float32)
+        zeros = np.zeros(N)
+
+        def residual(xv):
+            return np.sqrt(np.sum((b - ctx.mult_vector(xv)) ** 2) + np.sum((alpha.astype(np.float64) * xv) ** 2)) / np.linalg.norm(b)
+
+        def gradient(xv):      # of 1/2 |b - S x|^2 + 1/2 |alpha x|^2
+            return np.linalg.norm(ctx.trans_mult_vector(b - ctx.mult_vector(xv)) - alpha.astype(np.float64) ** 2 * xv)
+
+        x5, it5, r5 = ctx.lsqr_solve_sensit(b, 5, 1e-13, 0.0, 0.0, [alpha], [zeros])
+        x10, it10, r10 = ctx.lsqr_solve_sensit(b, 10, 1e-13, 0.0, 0.0, [alpha], [zeros])
+        x10b, it10b, r10b = ctx.lsqr_solve_sensit(b, 10, 1e-13, 0.0, 0.0, [alpha], [zeros])
+        assert it5 == 5 and it10 == it10b == 10
+        assert bits_equal(x10, x10b) and r10 == r10b                                  # (ii) two solves, identical bits
+        r5_true, r10_true = residual(x5), residual(x10)
+        rep.update(lsqr_r5=float(r5), lsqr_r10=float(r10), lsqr_r10_from_products=float(r10_true),
+                   lsqr_r_rel_err=float(max(abs(r5 - r5_true) / r5_true, abs(r10 - r10_true) / r10_true)))
+        assert rep["lsqr_r_rel_err"] <= 1e-10, rep                                      # (i) reported r = residual of the augmented system
+        g0, g5, g10 = gradient(np.zeros(N)), gradient(x5), gradient(x10)
+        rep.update(lsqr_grad0=float(g0), lsqr_grad5=float(g5), lsqr_grad10=float(g10), lsqr_bits_identical=True)
+        assert r10 < r5 < 1.0 and g10 < g5 < g0, rep                                    # (iii) residual and gradient fall
+        report("full_size[%s]" % name, **rep)
     finally:
+        pool.shutdown(wait=True, cancel_futures=True)
         ctx.matrix_free()
 
 
@@ -2050,7 +2121,7 @@ def test_reference_named_entry_points(ctx):
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tomofast-x_amd", "host", "tfx_reference_demo")
     if not os.path.isfile(exe):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout + out.stderr
     assert "Entered subroutine lsqr_solve_sensit" in out.stdout and "End of subroutine lsqr_solve_sensit" in out.stdout
@@ -2098,7 +2169,7 @@ def test_fortran_host_through_c_abi(ctx):
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tomofast-x_amd", "host", "tfx_host_demo")
     if not os.path.isfile(exe):
-        pytest.skip("Fortran host not built (no amdflang)")
+        ref_binaries.missing("Fortran host not built (no amdflang)")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "THE END." in out.stdout, out.stdout + out.stderr
     f = {k: float(v) for k, v in re.findall(r"(nnz_total|r|lsqr iters|model min|max|data cost) =\s*([-+0-9.Ee]+)", out.stdout)}
