@@ -8,8 +8,8 @@ Stated tolerances
   built matrix vs reference SENSIT rows ......................... same nel per row (+-1 on threshold ties), >= 99.9 %
                                                                   identical sparsity, kept values within 2 fp32 ulp
   S x, S^T y (fp64 accumulation, different summation order) ..... 1e-12 of |S| |x|
-  LSQR on the same matrix ....................................... x rel-L2 1e-9 (converged) / 1e-5 (mid-convergence, see
-                                                                  test_oracle_golden.py for why)
+  LSQR on the same matrix ....................................... 10 x the measured distance (profiles/r06_parity.json): x rel-L2
+                                                                  6e-10, the one mid-convergence iterate of the 40 x 60 toy 6e-5
   end-to-end inversion .......................................... final model rel-L2 1e-6, data cost rel 1e-5
 """
 import importlib
@@ -875,16 +875,18 @@ def test_lsqr_vs_reference_golden(ctx, golden_dir, case):
     for (niter, rmin, gamma), xref, rref, itref in zip(g[case + "_runs"], g[case + "_x"], g[case + "_r"], g[case + "_iters"]):
         x, it, r = ctx.lsqr_solve_sensit(b[:nl_s], int(niter), rmin, gamma, 0.0, diag, rhs)
         early = itref < niter
-        # mid-convergence iterates of this ill-conditioned 40 x 60 toy amplify 1e-16 summation-order differences (the
-        # LDS-atomic order is run-dependent): over 300 repetitions (tools/lsqr_scatter.py) the 30-iteration run scatters by up
-        # to 4.6e-4 in x and 3.1e-5 in r, every other run by <= 5e-10 / 3e-15; early and converged iterates are tight
-        mid = int(niter) == 30 or (case == "noC" and int(niter) == 10)
+        # Both products and every norm are bit-reproducible since round 4, so these distances are fixed numbers on this hardware, not a
+        # run-to-run scatter (rounds 1-3 allowed 1e-2 in x / 1e-3 in r for the LDS-atomic order of the old adjoint).  What remains is the
+        # summation ORDER against the reference's sequential loops, which the 30-iteration iterate of this ill-conditioned 40 x 60 toy
+        # amplifies: measured (profiles/r06_parity.json) x 5.98e-6, r 1.09e-7 there; every other run <= 5.9e-11 in x, <= 1.7e-15 in r.
+        # Pinned at 10 x measured.
+        mid = case == "damp" and int(niter) == 30
         if early:
             assert abs(it - itref) <= 0.1 * itref
         else:
             assert it == itref
-            assert abs(r - rref) <= (1e-3 if mid else 1e-7) * abs(rref)
-        tol = 1e-12 if niter <= 5 else (1e-2 if mid else 1e-8)
+            assert abs(r - rref) <= (1.1e-6 if mid else 2e-14) * abs(rref)
+        tol = 1e-14 if niter <= 5 else (6e-5 if mid else 6e-10)
         report("lsqr_vs_reference_golden[%s, %d iterations]" % (case, int(niter)), x_rel_l2=float(np.linalg.norm(x - xref) / np.linalg.norm(xref)),
                r_rel=float(abs(r - rref) / abs(rref)), iterations=int(it), iterations_reference=int(itref), mid_convergence=bool(mid))
         assert np.linalg.norm(x - xref) <= tol * np.linalg.norm(xref), (case, niter)
@@ -906,7 +908,7 @@ def test_lsqr_general_constraint_matrix_vs_reference(ctx, golden_dir):
             x, it, r = ctx.lsqr_solve_sensit(b[:nl_s], int(niter), rmin, gamma)
             early = itref < niter
             assert (abs(it - itref) <= 0.1 * itref) if early else (it == itref)
-            tol = 1e-12 if niter <= 5 else (1e-9 if (early or niter >= 50) else 1e-3)
+            tol = 1e-13          # measured <= 7.9e-15 on every run of this fixture (profiles/r06_parity.json)
             report("lsqr_general_constraint_matrix[%d iterations]" % int(niter), x_rel_l2=float(np.linalg.norm(x - xref) / np.linalg.norm(xref)),
                    r_rel=float(abs(r - rref) / abs(rref)), iterations=int(it), iterations_reference=int(itref))
             assert np.linalg.norm(x - xref) <= tol * np.linalg.norm(xref), (niter,)

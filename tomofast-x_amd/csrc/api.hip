@@ -35,6 +35,7 @@ int tfx_create(int device, void *stream, tfx_ctx **out)
     if (const char *e = getenv("TFX_CHAIN_UNDER_WAVELET")) c->chain_under_wavelet = atoi(e) != 0;
     if (const char *e = getenv("TFX_BUILD_OVERLAP")) c->build_overlap = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("TFX_GEN_WGS_PER_CU")) c->gen_wgs_per_cu = atoi(e);
+    if (const char *e = getenv("TFX_WAVE_PIPE")) c->wave_pipe = std::max(0, std::min(8, atoi(e)));
     if (const char *e = getenv("TFX_GEN_AFTER_WAVELET")) c->gen_after_wavelet = std::max(0, std::min(3, atoi(e)));
     TFX_HIP(hipEventCreate(&c->ev0));
     TFX_HIP(hipEventCreate(&c->ev1));
@@ -210,6 +211,10 @@ int tfx_debug_set(tfx_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "gen_after_wavelet")) {
         ctx->gen_after_wavelet = std::max(0, std::min(3, value));        // axis passes of the wavelet transform ahead of the next generator
         return 0;
+    }
+    if (!strcmp(key, "wave_pipe")) {
+        ctx->wave_pipe = std::max(0, std::min(8, value));
+        return ctx->wave_pipe;
     }
     if (!strcmp(key, "gen_wgs_per_cu")) {
         ctx->gen_wgs_per_cu = value;

@@ -1354,7 +1354,8 @@ struct WaveConst { double sq2, c0, c1, c2, c3, c4; };
 constexpr int WAVE_FUSE_ITEMS = 8;       // pairs per thread the fused D4 level keeps in registers (L <= 256 at 16 lines per tile)
 
 // All levels of one axis on the LDS tile T (L positions x nq lines, pitch P): the lifting steps of wavelet_transform.F90 with the
-// reference's operations in the reference's order.  Ends with a barrier.
+// reference's operations in the reference's order.  Ends with a barrier.  The barriers order LDS only (lds_barrier): global loads a
+// caller has in flight (k_wavelet_axis_pipe prefetches the next tile) stay in flight across the levels.
 template <int TYPE, int DIR>
 __device__ __forceinline__ void wave_levels(double *__restrict__ T, const int L, const int P, const int nq, const bool fast, const int q,
                                             const int mr, const int MR, const bool nq_pow2, const int nq_shift, const int tid, const int nt,
@@ -1384,7 +1385,7 @@ __device__ __forceinline__ void wave_levels(double *__restrict__ T, const int L,
                     hi = hi / wc.sq2;
                     T[a] = lo; T[a + dHI] = hi;
                 }
-                __syncthreads();
+                lds_barrier();
             } else if (TYPE == 1 && DIR == 2) {
                 FOR_ITEMS {
                     double lo = T[a], hi = T[a + dHI];
@@ -1394,7 +1395,7 @@ __device__ __forceinline__ void wave_levels(double *__restrict__ T, const int L,
                     hi = hi + lo;
                     T[a] = lo; T[a + dHI] = hi;
                 }
-                __syncthreads();
+                lds_barrier();
             } else if (TYPE == 2 && DIR == 1 && ng <= WAVE_FUSE_ITEMS * MR) {
                 // Fused D4 level: a thread owns a run of CONSECUTIVE pairs m0 .. m0+cnt-1 of its line and produces their final
                 // (lo, hi) from the RAW values of pairs m0-1 .. m0+cnt, with exactly the reference's operations (same bits):
@@ -1428,7 +1429,7 @@ __device__ __forceinline__ void wave_levels(double *__restrict__ T, const int L,
                         }
                     }
                 }
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int i = 0; i < WAVE_FUSE_ITEMS; ++i) {
                     if (i < cnt) {
@@ -1436,37 +1437,37 @@ __device__ __forceinline__ void wave_levels(double *__restrict__ T, const int L,
                         T[a] = olo[i]; T[a + dHI] = ohi[i];
                     }
                 }
-                __syncthreads();
+                lds_barrier();
             } else if (TYPE == 2 && DIR == 1) {
                 FOR_ITEMS { T[a] = T[a] + T[a + dHI] * wc.c0; }
-                __syncthreads();
+                lds_barrier();
                 FOR_ITEMS {
                     const double prev = (m == 0) ? T[ilmax * P + q] : T[a - dS];
                     T[a + dHI] = T[a + dHI] - T[a] * wc.c1 - prev * wc.c2;
                 }
-                __syncthreads();
+                lds_barrier();
                 FOR_ITEMS {
                     const double nxt = (m == ng - 1) ? T[dHI + q] : T[a + dHI + dS];
                     T[a] = T[a] - nxt;
                 }
-                __syncthreads();
+                lds_barrier();
                 FOR_ITEMS { T[a] = T[a] * wc.c3; T[a + dHI] = T[a + dHI] * wc.c4; }
-                __syncthreads();
+                lds_barrier();
             } else {
                 FOR_ITEMS { T[a] = T[a] * wc.c4; T[a + dHI] = T[a + dHI] * wc.c3; }
-                __syncthreads();
+                lds_barrier();
                 FOR_ITEMS {
                     const double nxt = (m == ng - 1) ? T[dHI + q] : T[a + dHI + dS];
                     T[a] = T[a] + nxt;
                 }
-                __syncthreads();
+                lds_barrier();
                 FOR_ITEMS {
                     const double prev = (m == 0) ? T[ilmax * P + q] : T[a - dS];
                     T[a + dHI] = T[a + dHI] + T[a] * wc.c1 + prev * wc.c2;
                 }
-                __syncthreads();
+                lds_barrier();
                 FOR_ITEMS { T[a] = T[a] - T[a + dHI] * wc.c0; }
-                __syncthreads();
+                lds_barrier();
             }
 #undef FOR_ITEMS
             continue;
@@ -1483,7 +1484,7 @@ __device__ __forceinline__ void wave_levels(double *__restrict__ T, const int L,
                 hi = hi / wc.sq2;
                 LO(m) = lo; HI(m) = hi;
             }
-            __syncthreads();
+            lds_barrier();
         } else if (TYPE == 1 && DIR == 2) {   // Haar inverse, :186-232
             for (int e = tid; e < work; e += nt) {
                 const int m = DIVQ(e), q = e - m * nq;
@@ -1494,41 +1495,41 @@ __device__ __forceinline__ void wave_levels(double *__restrict__ T, const int L,
                 hi = hi + lo;
                 LO(m) = lo; HI(m) = hi;
             }
-            __syncthreads();
+            lds_barrier();
         } else if (TYPE == 2 && DIR == 1) {   // D4 forward, :284-365
             for (int e = tid; e < work; e += nt) { const int m = DIVQ(e), q = e - m * nq; LO(m) = LO(m) + HI(m) * wc.c0; }
-            __syncthreads();
+            lds_barrier();
             for (int e = tid; e < work; e += nt) {
                 const int m = DIVQ(e), q = e - m * nq;
                 const double prev = (m == 0) ? T[ilmax * P + q] : LO(m - 1);
                 HI(m) = HI(m) - LO(m) * wc.c1 - prev * wc.c2;
             }
-            __syncthreads();
+            lds_barrier();
             for (int e = tid; e < work; e += nt) {
                 const int m = DIVQ(e), q = e - m * nq;
                 const double nxt = (m == ng - 1) ? HI(0) : HI(m + 1);
                 LO(m) = LO(m) - nxt;
             }
-            __syncthreads();
+            lds_barrier();
             for (int e = tid; e < work; e += nt) { const int m = DIVQ(e), q = e - m * nq; LO(m) = LO(m) * wc.c3; HI(m) = HI(m) * wc.c4; }
-            __syncthreads();
+            lds_barrier();
         } else {                              // D4 inverse, :413-495
             for (int e = tid; e < work; e += nt) { const int m = DIVQ(e), q = e - m * nq; LO(m) = LO(m) * wc.c4; HI(m) = HI(m) * wc.c3; }
-            __syncthreads();
+            lds_barrier();
             for (int e = tid; e < work; e += nt) {
                 const int m = DIVQ(e), q = e - m * nq;
                 const double nxt = (m == ng - 1) ? HI(0) : HI(m + 1);
                 LO(m) = LO(m) + nxt;
             }
-            __syncthreads();
+            lds_barrier();
             for (int e = tid; e < work; e += nt) {
                 const int m = DIVQ(e), q = e - m * nq;
                 const double prev = (m == 0) ? T[ilmax * P + q] : LO(m - 1);
                 HI(m) = HI(m) + LO(m) * wc.c1 + prev * wc.c2;
             }
-            __syncthreads();
+            lds_barrier();
             for (int e = tid; e < work; e += nt) { const int m = DIVQ(e), q = e - m * nq; LO(m) = LO(m) - HI(m) * wc.c0; }
-            __syncthreads();
+            lds_barrier();
         }
 #undef LO
 #undef HI
@@ -1711,6 +1712,159 @@ __global__ __launch_bounds__(256) void k_wavelet_axis(double *__restrict__ s, in
 #undef DIVQ
 }
 
+// Software-pipelined form: a PERSISTENT workgroup walks tiles t = blockIdx.x, + gridDim.x, ... of the
+// (vector, tile) space and issues the global loads of tile t + 1 into registers (8 x 16 bytes per thread = one 16 x 256 tile) BEFORE
+// it lifts tile t in LDS, so a workgroup always has a tile of reads in flight: the HBM latency is covered by the workgroup itself and
+// not by four co-resident ones (k_wavelet_axis needs 16 waves per CU; three workgroups cost it 30 %).  Restricted to what the build's
+// headline shapes are: every tile full (XT lines, a power of two), L * XT <= 4096 doubles, even line length / strides (16-byte
+// transfers); launch_axis falls back to k_wavelet_axis otherwise.  Same lifting code (wave_levels) -> same bits.
+template <int TYPE, int DIR, int MODE>
+__global__ __launch_bounds__(256) void k_wavelet_axis_pipe(double *__restrict__ s, int64_t vec_stride, WaveAxis ax, WaveConst wc, int ntiles, int total)
+{
+    extern __shared__ __attribute__((aligned(16))) double T[];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int L = ax.L, XT = ax.XT, P = ax.P;
+    const int tid = threadIdx.x;
+    constexpr int nt = 256;
+    const int nq = XT, nq_shift = 31 - __clz(nq);
+    const int q = tid & (nq - 1), mr = tid >> nq_shift, MR = nt >> nq_shift;
+    // MODE 0 (x axis): the tile is one contiguous run of XT * L doubles; transfer k of this thread is pair p = tid + 256 k
+    const int npair = (XT * L) >> 1;
+    const int dq2 = (2 * nt) / L, da2 = 2 * nt - dq2 * L;
+    const int rq2_0 = (2 * tid) / L, ra2_0 = 2 * tid - rq2_0 * L;
+    // MODE 1 (y / z axis): thread (q2, mr2) moves lines 2 q2, 2 q2 + 1 at positions mr2, mr2 + MR2, ...
+    const int sh2 = nq_shift > 0 ? nq_shift - 1 : 0;
+    const int hq = nq >> 1, q2 = tid & (hq - 1), mr2 = tid >> sh2, MR2 = nt >> sh2;
+    const int64_t gstep = (int64_t)MR2 * ax.astride;
+    const int lstep = MR2 * P;
+
+    auto origin = [&](int t) -> double * {
+        const int vec = t / ntiles, ti = t - vec * ntiles;
+        double *base = s + (int64_t)vec * vec_stride;
+        if (MODE == 0) return base + (int64_t)ti * XT * L;
+        const int64_t o = ti / ax.ntiles_inner, tii = ti - o * ax.ntiles_inner;
+        return base + o * ax.outer_stride + tii * XT;
+    };
+    d2 pre[8];
+    auto issue = [&](const double *src) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (tid + k * nt < npair) pre[k] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 2 * (tid + k * nt)));
+        } else {
+            const double *gp = src + (int64_t)mr2 * ax.astride + 2 * q2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (mr2 + k * MR2 < L) pre[k] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(gp + k * gstep));
+        }
+    };
+    auto commit = [&]() {
+        if (MODE == 0) {
+            int rq2 = rq2_0, ra2 = ra2_0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (tid + k * nt < npair) { T[ra2 * P + rq2] = pre[k].x; T[ra2 * P + rq2 + P] = pre[k].y; }
+                rq2 += dq2; ra2 += da2;
+                if (ra2 >= L) { ra2 -= L; rq2 += 1; }
+            }
+        } else {
+            const int la0 = mr2 * P + 2 * q2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (mr2 + k * MR2 < L) { T[la0 + k * lstep] = pre[k].x; T[la0 + k * lstep + 1] = pre[k].y; }
+        }
+    };
+    auto store = [&](double *dst) {
+        if (MODE == 0) {
+            int rq2 = rq2_0, ra2 = ra2_0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (tid + k * nt < npair) {
+                    d2 v;
+                    v.x = T[ra2 * P + rq2];
+                    v.y = T[ra2 * P + rq2 + P];
+                    __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(dst + 2 * (tid + k * nt)));
+                }
+                rq2 += dq2; ra2 += da2;
+                if (ra2 >= L) { ra2 -= L; rq2 += 1; }
+            }
+        } else {
+            double *gp = dst + (int64_t)mr2 * ax.astride + 2 * q2;
+            const int la0 = mr2 * P + 2 * q2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (mr2 + k * MR2 < L) {
+                    d2 v;
+                    v.x = T[la0 + k * lstep];
+                    v.y = T[la0 + k * lstep + 1];
+                    __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(gp + k * gstep));
+                }
+        }
+    };
+
+    // LDS slots of this thread's 8 transfers: the same for every tile, and owned by this thread alone in commit, exchange and store
+    // (so the exchange below needs no barrier between its LDS read and its LDS write)
+    d2 out[8];
+    auto exchange = [&]() {        // out = lifted tile t (LDS -> registers), LDS = tile t + 1 (registers -> LDS)
+        if (MODE == 0) {
+            int rq2 = rq2_0, ra2 = ra2_0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (tid + k * nt < npair) {
+                    const int a = ra2 * P + rq2;
+                    out[k].x = T[a]; out[k].y = T[a + P];
+                    T[a] = pre[k].x; T[a + P] = pre[k].y;
+                }
+                rq2 += dq2; ra2 += da2;
+                if (ra2 >= L) { ra2 -= L; rq2 += 1; }
+            }
+        } else {
+            const int la0 = mr2 * P + 2 * q2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (mr2 + k * MR2 < L) {
+                    const int a = la0 + k * lstep;
+                    out[k].x = T[a]; out[k].y = T[a + 1];
+                    T[a] = pre[k].x; T[a + 1] = pre[k].y;
+                }
+        }
+    };
+    auto store_out = [&](double *dst) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (tid + k * nt < npair) __builtin_nontemporal_store(out[k], reinterpret_cast<d2 *>(dst + 2 * (tid + k * nt)));
+        } else {
+            double *gp = dst + (int64_t)mr2 * ax.astride + 2 * q2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (mr2 + k * MR2 < L) __builtin_nontemporal_store(out[k], reinterpret_cast<d2 *>(gp + k * gstep));
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= total) return;
+    double *cur = origin(t);
+    issue(cur);
+    commit();
+    lds_barrier();
+    for (;;) {
+        const int tn = t + (int)gridDim.x;
+        const bool more = tn < total;
+        double *nxt = more ? origin(tn) : cur;
+        if (more) issue(nxt);                       // tile t + 1: in flight over the whole lifting of tile t
+        wave_levels<TYPE, DIR>(T, L, P, nq, true, q, mr, MR, true, nq_shift, tid, nt, wc);
+        if (!more) { store(cur); break; }
+        // The loads of tile t + 1 are the YOUNGEST vector-memory operations here (the stores of tile t - 1 were issued before them), so
+        // the wait for them drains nothing else; the stores of tile t go out after the exchange and fly over the next lifting.
+        exchange();
+        store_out(cur);
+        lds_barrier();
+        t = tn;
+        cur = nxt;
+    }
+}
+
 static WaveConst wave_consts()
 {
     WaveConst w;
@@ -1734,6 +1888,25 @@ static int launch_axis(tfx_ctx *ctx, double *d, int64_t vec_stride, int64_t nvec
     if (lds > lds_set) {
         TFX_HIP(hipFuncSetAttribute((const void *)k_wavelet_axis<TYPE, DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS_BUDGET + 4096));
         lds_set = WAVE_LDS_BUDGET + 4096;
+    }
+    // software-pipelined persistent form (debug key "wave_pipe" / TFX_WAVE_PIPE = workgroups per CU, 0: off): full power-of-two tiles of
+    // <= 4096 doubles moved by 16-byte transfers, and enough tiles for every workgroup to pipeline over a few
+    const int64_t total = (int64_t)ntiles * nvec;
+    const bool full_tiles = ax.mode == 0 ? (ax.nlines % ax.XT == 0) : (ax.inner % ax.XT == 0);
+    const bool pow2 = (ax.XT & (ax.XT - 1)) == 0 && ax.XT >= 2 && ax.XT <= 256;
+    const bool even = ax.mode == 0 ? ((ax.L & 1) == 0 && (vec_stride & 1) == 0)
+                                   : ((ax.astride & 1) == 0 && (ax.outer_stride & 1) == 0 && (vec_stride & 1) == 0);
+    const int64_t pipe_grid = (int64_t)ctx->wave_pipe * ctx->num_cu;
+    if (ctx->wave_pipe > 0 && full_tiles && pow2 && even && (int64_t)ax.L * ax.XT <= 4096 && total >= 4 * pipe_grid && total < (int64_t)1 << 30 &&
+        lds <= 64 * 1024) {
+        if (ax.mode == 0)
+            hipLaunchKernelGGL((k_wavelet_axis_pipe<TYPE, DIR, 0>), dim3((unsigned)pipe_grid), dim3(256), lds, ctx->stream, d, vec_stride, ax, wave_consts(),
+                               (int)ntiles, (int)total);
+        else
+            hipLaunchKernelGGL((k_wavelet_axis_pipe<TYPE, DIR, 1>), dim3((unsigned)pipe_grid), dim3(256), lds, ctx->stream, d, vec_stride, ax, wave_consts(),
+                               (int)ntiles, (int)total);
+        TFX_HIP(hipGetLastError());
+        return 0;
     }
     hipLaunchKernelGGL((k_wavelet_axis<TYPE, DIR>), dim3(ntiles, (unsigned)nvec), dim3(256), lds, ctx->stream, d, vec_stride, ax, wave_consts());
     TFX_HIP(hipGetLastError());

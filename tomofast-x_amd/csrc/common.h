@@ -283,6 +283,7 @@ struct tfx_ctx {
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int gen_after_wavelet = 3;        // debug key: the overlapped generator of the next batch starts behind this many axis passes of the current batch's wavelet transform (0: at the batch start, 3: behind all of them)
+    int wave_pipe = 0;                // debug key "wave_pipe" / TFX_WAVE_PIPE: workgroups per CU of the software-pipelined wavelet pass (0: one workgroup per tile)
     int gen_wgs_per_cu = 0;           // debug key "gen_wgs_per_cu": resident generator workgroups per CU in overlap mode (0: one per tile)
     int gen_grid_limit = 0;           // (set around the generator launches of the overlapped build)
     int chain_under_wavelet = 1;      // debug key "chain_under_wavelet": overlapped build - the threshold / compaction chain of batch b runs on a third stream beside the wavelet passes of batch b + 1
