@@ -80,6 +80,25 @@ def test_wavelets_bit_exact_vs_oracle_larger(ctx, dims, wtype):
         assert bits_equal(ctx.inverse_wavelet(ref, n1, n2, n3, wtype), orc.wavelet(ref, n1, n2, n3, wtype, inverse=True))
 
 
+@pytest.mark.parametrize("wtype", [1, 2])
+def test_pipelined_wavelet_pass_bit_identical(ctx, wtype):
+    """The software-pipelined persistent form of the axis pass (k_wavelet_axis_pipe, debug key "wave_pipe": measured in round 6 and not
+    the default - profiles/README.md) runs the same lifting code on the same LDS tile: same bits, forward and inverse, on every axis
+    (x: contiguous tiles; y / z: strided 16-byte transfers; a z axis whose length leaves transfers idle)."""
+    n1, n2, n3 = 64, 32, 40
+    rng = np.random.default_rng(23)
+    a = rng.standard_normal((48, n1 * n2 * n3))
+    want_f, want_i = ctx.forward_wavelet(a, n1, n2, n3, wtype), ctx.inverse_wavelet(a, n1, n2, n3, wtype)
+    assert bits_equal(want_f[0], orc.wavelet(a[0], n1, n2, n3, wtype))
+    try:
+        for wgs in (1, 3):
+            assert ctx.debug_set("wave_pipe", wgs) == wgs
+            assert bits_equal(ctx.forward_wavelet(a, n1, n2, n3, wtype), want_f), wgs
+            assert bits_equal(ctx.inverse_wavelet(a, n1, n2, n3, wtype), want_i), wgs
+    finally:
+        ctx.debug_set("wave_pipe", 0)
+
+
 def test_wavelet_unknown_type(ctx):
     with pytest.raises(ValueError):
         ctx.forward_wavelet(np.zeros(8), 2, 2, 2, 3)

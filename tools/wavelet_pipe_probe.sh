@@ -28,24 +28,23 @@ for cfg in ${CFGS:-0 1 2 3 4 6}; do
   tail -1 $O/run_$cfg.log
 done
 python - <<PY
-import csv, glob, json, collections
+import csv, glob, json
 N = 256 * 256 * 152
-out = {"grid": "256x256x152", "rows_per_launch": 26, "bytes_per_launch_read_plus_write": 2 * 26 * 8 * N, "configs": {}}
-shas = {}
+B = 2 * 26 * 8 * N
+out = {"what": "k_wavelet_axis (one workgroup per tile) vs k_wavelet_axis_pipe (persistent, next tile's loads in flight over the lifting) ALONE: "
+               "sequential D4 build of 2 x 26 rows on 256x256x152 cells, rocprofv3 --kernel-trace per-launch durations; second batch (warm) reported",
+       "bytes_per_launch_read_plus_write": B, "configs": []}
 for cfg in "${CFGS:-0 1 2 3 4 6}".split():
-    d = collections.defaultdict(list)
+    L = []
     for f in glob.glob("$O/trace_%s/**/*kernel_trace.csv" % cfg, recursive=True):
         for r in csv.DictReader(open(f)):
             if "k_wavelet_axis" in r["Kernel_Name"]:
-                d[r["Kernel_Name"].split("(")[0][-60:]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-    per = {}
-    for k, v in d.items():
-        v.sort()
-        # launches come in x, y, z order per batch; 2 batches of 26 rows
-        per[k] = {"launches": len(v), "ms_per_axis_pass": [round(sum(x[1] for x in v[a::3]) / max(1, len(v[a::3])) / 1e6, 4) for a in range(3)]}
-        per[k]["TBs_read_plus_write"] = [round(out["bytes_per_launch_read_plus_write"] / (m * 1e-3) / 1e12, 3) if m else None for m in per[k]["ms_per_axis_pass"]]
-    log = open("$O/run_%s.log" % cfg).read().strip().splitlines()
-    out["configs"]["wave_pipe=%s" % cfg] = {"kernels": per, "result": log[-1] if log else ""}
+                L.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r["Kernel_Name"].split("(")[0].replace("void tfx::", "")))
+    L.sort()          # x, y, z of batch 1, then of batch 2
+    log = [l for l in open("$O/run_%s.log" % cfg).read().splitlines() if l.startswith("nnz")]
+    out["configs"].append({"wave_pipe_workgroups_per_cu": int(cfg), "kernel": sorted({x[2] for x in L}), "launches": len(L),
+                           "ms_x_y_z_first_batch": [round(x[1], 4) for x in L[:3]], "ms_x_y_z_second_batch": [round(x[1], 4) for x in L[3:6]],
+                           "TBs_read_plus_write_second_batch": [round(B / (x[1] * 1e-3) / 1e12, 2) for x in L[3:6]], "matrix": log[-1] if log else ""})
 json.dump(out, open("$O/probe.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
