@@ -55,6 +55,12 @@ WORKLOADS = {
                   desc="synthetic gravity 64x64x32 cells, 32x32 obs, Haar r=0.1 (SURVEY 6 CPU-baseline size)"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy ceiling)
+# What ONE rank's share of a P-GPU run of the headline workload costs per LSQR iteration on one MI355X, measured by building exactly
+# that share at full size on a single GPU (tools/one_rank_share.py, profiles/r05_one_rank_share.jsonl; ms, lowest - highest rank): the
+# product kernels + vector work WITHOUT any peer latency - a measured 1 / 2 / 4 / 8-GPU curve is read against these lower bounds.
+EXPECTED_MS_PER_STEP_BOUND = {"workload": "hamersley_1e7", "1": [36.3, 36.3], "2": [18.2, 18.3], "4": [9.3, 9.8], "8": [4.7, 4.8],
+                              "source": "tools/one_rank_share.py (one rank's share built at full size on one GPU, final round-5 code)",
+                              "excludes": "all-reduce latency over xGMI (2 per iteration: 0.8 MB + 8 B), clock differences between GPUs"}
 
 
 def main():
@@ -67,6 +73,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the matrix kernels with HIP events")
     ap.add_argument("--full-select", action="store_true", help="A/B: thresholds by the full radix select instead of the band select")
+    ap.add_argument("--selftest", action="store_true", help="only the N-GPU self-test (tomofast-x_amd/distributed.py::comm_selftest): every "
+                    "collective shape of the path once, step by step with a per-step timeout; prints its JSON verdict and exits")
+    ap.add_argument("--selftest-timeout", type=float, default=float(os.environ.get("TFX_SELFTEST_TIMEOUT", "20")), help="seconds per self-test step")
     args = ap.parse_args()
     if os.environ.get("TFX_BENCH_WATCHDOG"):
         # diagnostics for a run that does not come back (tests set it): after that many seconds every thread's Python stack goes to
@@ -143,16 +152,41 @@ def main():
     if not plan["fits"]:
         sys.exit("bench.py: %s does not fit %d x %.0f GB (peak %.1f GB per rank even without the transposed copy): use more GPUs" %
                  (args.workload, world, plan["hbm_GB"], plan["peak_GB"]))
-    ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
     if w.get("joint"):
         if world > 1:
             sys.exit("the joint workloads run on one GPU")
+        ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
         return bench_joint(args, w, ctx, tfx, log, plan)
-    cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
     # collectives: an RCCL communicator inside libtfx.so (nccl launch) - the library queues its reductions on its own stream;
     # the gloo rehearsal uses the torch.distributed hooks
     comm = tfx.distributed.setup_comm(ctx, rank, world, local_rank, log=log, force=force_comm)
     log("collectives: %s" % json.dumps(comm.report))
+    # ---- N-GPU self-test (N > 1, or --selftest): every collective shape of the path once on a small known-answer input, each step under
+    # a timeout and agreed between the ranks - a call that has never run with real peers fails HERE and says which one, not in the timed
+    # region.  A failure on the RCCL rung moves all ranks to the torch.distributed hooks together (the line then says so).
+    selftest = None
+    if args.selftest or world > 1 or (force_comm and os.environ.get("TFX_BENCH_SELFTEST") == "1"):
+        selftest = tfx.distributed.comm_selftest(ctx, comm, rank, world, local_rank, step_timeout=args.selftest_timeout, log=log)
+        if not selftest["ok"] and comm.rccl and not args.selftest:
+            why = next((s.get("why") for s in selftest["steps"] if s.get("ok") is False), "unknown")
+            if os.environ.get("TFX_COMM") == "rccl":
+                raise RuntimeError("TFX_COMM=rccl but the N-GPU self-test failed: %s" % why)
+            log("self-test failed on the RCCL rung (%s): all ranks fall back to the torch.distributed hooks" % why)
+            comm = tfx.distributed.fall_back_to_hooks(ctx, comm, rank, world, local_rank, why)
+        comm.report["selftest"] = selftest
+        if args.selftest:
+            if rank == 0:
+                print(json.dumps({"selftest": selftest, "n_gpus": world, "comm": {k: v for k, v in comm.report.items() if k != "selftest"},
+                                  "expected_ms_per_step_bound": EXPECTED_MS_PER_STEP_BOUND}))
+                sys.stdout.flush()
+            if comm.rccl:
+                ctx.comm_destroy()
+            ctx.close()
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(0 if selftest["ok"] else 1)
+    ctx.set_grid(nx, ny, nz, *tfx.synthetic.grid(nx, ny, nz))
+    cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
 
     def barrier():
         comm.barrier()
@@ -342,6 +376,7 @@ def main():
             "lsqr_bytes_per_iteration_stored": stored_iter,
             "lsqr_stored_GBs": None if stored_iter is None else round(stored_iter / (ms_per_step * 1e-3) / 1e9, 1),
             "comm": comm.report, "memory_plan": plan,
+            "expected_ms_per_step_bound": EXPECTED_MS_PER_STEP_BOUND if args.workload == "hamersley_1e7" else None,
             "device_memory_used_after_build_GB": round(used_after_build / 1e9, 2),
             "per_rank": [{"rank": r, "spmv_fwd_ms": round(float(v[0]), 4), "spmv_adj_ms": round(float(v[1]), 4),
                           "allreduce_ms": round(float(v[2]), 4), "allreduces_timed": int(v[3]), "nnz": int(v[4]),

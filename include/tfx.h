@@ -97,6 +97,11 @@ int tfx_comm_info(tfx_ctx *ctx, int *nranks_seen, int *rank_seen, int *device_se
 /* Collectives for the host's own exchange steps, on DEVICE buffers, queued on the ctx stream.                              */
 enum { TFX_F64 = 0, TFX_I32 = 1, TFX_I64 = 2 };
 int tfx_comm_allreduce(tfx_ctx *ctx, void *dev_buf, int64_t n, int dtype);           /* sum, in place                       */
+/* MPI_Allgatherv on DEVICE buffers (apply_wavelet_transform's exchange, src/inversion/wavelet_utils.F90:37-72): rank r's counts[r]
+ * doubles land at dev_recv + displs[r] on every rank; counts / displs are host arrays of nranks entries; counts may differ and may be
+ * zero.  RCCL: ONE group of ncclBroadcast calls, one per contributing rank; without a communicator the tfx_allgatherv_fn hook.  The call
+ * LSQR makes itself for multi-rank WAVELET_DOMAIN = F, exposed for the host's own exchange steps and the N-GPU self-test of bench.py. */
+int tfx_comm_allgatherv(tfx_ctx *ctx, const double *dev_send, double *dev_recv, const int64_t *counts, const int64_t *displs);
 int tfx_comm_group_begin(tfx_ctx *ctx);                                               /* ncclGroupStart / End around a set   */
 int tfx_comm_group_end(tfx_ctx *ctx);                                                 /*   of sends and receives             */
 int tfx_comm_send(tfx_ctx *ctx, const void *dev_buf, int64_t bytes, int peer);

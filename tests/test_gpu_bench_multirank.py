@@ -83,10 +83,36 @@ def test_world_size_1_through_the_rccl_startup_has_the_bits_of_the_plain_run(pla
     assert out["config"]["nnz"] == plain_small["config"]["nnz"]
 
 
+def test_selftest_on_a_world_size_1_communicator_runs_the_real_rccl_calls():
+    """bench.py --selftest through the RCCL rung with one rank: the chained in-stream ncclAllReduce of 99 857 doubles, the reduction
+    between two library kernels, the grouped ncclBroadcast all-gather and the partitioned build + 5 LSQR iterations are REAL calls on
+    the communicator (what one GPU can prove; the send / recv group needs a peer and is recorded as not applicable), every step with
+    its verdict, and the gathered x has the bits of the single-rank solve."""
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "TFX_BENCH_FORCE_COMM": "1", "TFX_BENCH_WATCHDOG": "300"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29661",
+           "bench.py", "--gpus", "1", "--selftest", "--workload", "small"]
+    p = _run(cmd, env, 300)
+    assert p.returncode == 0, p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    st = {s["step"]: s for s in out["selftest"]["steps"]}
+    assert out["selftest"]["ok"] and out["comm"]["path"].startswith("RCCL inside libtfx.so"), out
+    assert list(st) == ["ladder", "allreduce_rows_plus_1", "allgatherv_unequal", "relayout_group", "lsqr"]
+    assert st["allreduce_rows_plus_1"]["ok"] and st["allreduce_rows_plus_1"]["doubles"] == 99857 and st["allreduce_rows_plus_1"]["between_kernels_rel_err"] <= 1e-13
+    assert st["allgatherv_unequal"]["ok"] and st["relayout_group"]["ok"] is None
+    assert st["lsqr"]["ok"] and st["lsqr"]["iterations"] == 5 and st["lsqr"]["x_bits_identical"], st["lsqr"]
+    assert out["expected_ms_per_step_bound"]["8"] == [4.7, 4.8]
+
+
 @pytest.mark.parametrize("nranks,workload", [(2, "medium"), (8, "small")])
 def test_ranks_launched_like_the_driver_does_share_the_gpu_and_fall_back_together(nranks, workload, plain_small):
     out, err = _run_bench(nranks, workload, {}, port=29650 + nranks)
     comm = out["comm"]
+    # the N-GPU self-test ran first: on the hook rung the RCCL-only steps are recorded as not applicable, the partitioned build + 5 LSQR
+    # iterations against a single-rank solve of the same problem must hold on any rung
+    st = {s["step"]: s for s in comm["selftest"]["steps"]}
+    assert comm["selftest"]["ok"] and st["allreduce_rows_plus_1"]["ok"] is None and st["lsqr"]["ok"], comm["selftest"]
+    assert st["lsqr"]["x_rel_l2_vs_single_rank"] <= 1e-9 and len(st["lsqr"]["columns_per_rank"]) == nranks, st["lsqr"]
     assert out["n_gpus"] == nranks and out["scaling"] == "strong"
     assert comm["path"].startswith("torch.distributed hooks"), comm
     assert comm["ladder"][0]["stage"] == "pre-flight" and comm["ladder"][0]["ok"] is False and "share a GPU" in comm["ladder"][0]["why"], comm

@@ -264,6 +264,26 @@ int tfx_comm_allreduce(tfx_ctx *ctx, void *dev_buf, int64_t n, int dtype)
     return 0;
 }
 
+int tfx_comm_allgatherv(tfx_ctx *ctx, const double *dev_send, double *dev_recv, const int64_t *counts, const int64_t *displs)
+{
+    tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)
+    if (!ctx || !dev_recv || !counts || !displs) return fail(TFX_E_ARG, "tfx_comm_allgatherv: null argument");
+    const int nr = std::max(1, ctx->nranks);
+    for (int r = 0; r < nr; ++r)
+        if (counts[r] < 0 || displs[r] < 0) return fail(TFX_E_ARG, "tfx_comm_allgatherv: negative count / displacement for rank %d", r);
+    if (counts[std::min(ctx->rank, nr - 1)] > 0 && !dev_send) return fail(TFX_E_ARG, "tfx_comm_allgatherv: null send buffer");
+    TFX_HIP(hipSetDevice(ctx->device));
+    if (!ctx->comm && !ctx->allgatherv) {
+        if (nr > 1) return fail(TFX_E_COMM, "tfx_comm_allgatherv: several ranks but neither a communicator nor an all-gather hook");
+        if (counts[0] > 0)
+            TFX_HIP(hipMemcpyAsync(dev_recv + displs[0], dev_send, (size_t)counts[0] * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    const int rc = comm_allgatherv_f64(ctx, dev_send, dev_recv, counts, displs);
+    if (rc == 1) return fail(TFX_E_COMM, "tfx_comm_allgatherv: neither a communicator nor an all-gather hook");
+    return rc;
+}
+
 int tfx_comm_group_begin(tfx_ctx *ctx)
 {
     tfx::AllocScope alloc_scope_(ctx);      // (an allocation that runs out of memory may give up THIS context's automatic adjoint copies)

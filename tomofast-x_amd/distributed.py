@@ -391,6 +391,195 @@ def _try_rccl(ctx, rank, nranks, device_index, timeout, report):
     return None
 
 
+def comm_selftest(ctx, comm, rank, nranks, device_index=0, step_timeout=20.0, log=None, lsqr_iterations=5):
+    """First contact with N GPUs, step by step (bench.py --selftest, and the first thing a `--gpus N` run does): every collective SHAPE
+    the path uses is executed once on a small, known-answer input - under a per-step timeout, with the ranks agreeing on each outcome
+    over the gloo control channel - so that a call that has never run with N > 1 real peers fails EARLY and says which one it was
+    instead of hanging the timed region.  Steps (reference call sites in brackets):
+      1. ladder                 which rung of setup_comm ran (its own report)
+      2. allreduce_rows_plus_1  three in-stream ncclAllReduce of 99 857 doubles back to back, known integer answer; then the same
+                                reduction BETWEEN two kernels of the library on the ctx stream (forward wavelet -> all-reduce ->
+                                inverse wavelet on 47 x 47 x 45 doubles)                       [lsqr_solver2.F90:214, model.F90:288-293]
+      3. allgatherv_unequal     tfx_comm_allgatherv: one group of ncclBroadcast calls, unequal counts, one of them zero
+                                                                                                  [wavelet_utils.F90:37-72]
+      4. relayout_group         ONE ncclGroup of P - 1 sends + P - 1 receives of different sizes (multiples of a 2048-row block)
+                                                                                                  [sensitivity_gravmag.F90:795-830]
+      5. lsqr                   `small` workload: partitioned build (row-parallel + relayout on RCCL), predicted data, 5 LSQR
+                                iterations; x gathered over gloo and compared with a single-rank solve of the same problem on rank 0
+                                                                                                  [lsqr_solver2.F90:163-290]
+    Steps 2-4 need the library's own communicator; on the hooks rung they are recorded as not applicable.  Returns
+    {"ok": bool, "steps": [...]}; after a failed or timed-out step the remaining ones are not run (the communicator may be wedged)."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from . import synthetic
+    from .sensitivity import Context
+    if log is None:
+        log = lambda msg: None      # noqa
+    dev = torch.device("cuda", device_index)
+    multi = dist.is_available() and dist.is_initialized()
+    steps = [{"step": "ladder", "ok": True, "path": comm.report.get("path"), "rungs": [r.get("stage") for r in comm.report.get("ladder", [])]}]
+    state = {"ok": True}
+
+    def run_step(name, fn, timeout, applicable=True):
+        if not state["ok"]:
+            steps.append({"step": name, "ok": None, "why": "not run: an earlier step failed"})
+            return
+        if not applicable:
+            steps.append({"step": name, "ok": None, "why": "not applicable: no RCCL communicator on this rung (%s)" % comm.report.get("path")})
+            return
+        info = {}
+        t0 = time.time()
+        done, exc = _call_with_timeout(lambda: fn(info), timeout)
+        local = None if (done and exc is None) else ("timed out after %.0f s" % timeout if not done else repr(exc))
+        ok = agree(local is None) if multi else (local is None)
+        rec = {"step": name, "ok": bool(ok), "s": round(time.time() - t0, 3)}
+        rec.update(info)
+        if not ok:
+            reasons = [local]
+            if multi:
+                reasons = [None] * dist.get_world_size()
+                dist.all_gather_object(reasons, local, group=control_group())
+            rec["why"] = next((("rank %d: %s" % (r, x)) for r, x in enumerate(reasons) if x), "unknown")
+            state["ok"] = False
+        steps.append(rec)
+        log("self-test %s: %s" % (name, "ok (%.2f s)" % rec["s"] if ok else "FAILED - " + rec.get("why", "")))
+
+    T = nranks * (nranks + 1) // 2
+
+    def s_allreduce(info):
+        n = 99857                                                       # rows + 1 of the headline problem
+        pat = (torch.arange(n, dtype=torch.float64, device=dev) % 1024) + 1.0
+        buf = pat * float(rank + 1)
+        torch.cuda.synchronize(dev)
+        for _ in range(3):                                              # queued back to back on the ctx stream, no host sync between
+            ctx.comm_allreduce(buf.data_ptr(), n, "f64")
+        ctx.comm_barrier()
+        if not torch.equal(buf, pat * float(T * nranks * nranks)):
+            raise RuntimeError("three chained all-reduces of %d doubles gave a wrong sum (first element %r, expected %r)" %
+                               (n, float(buf[0].item()), float(T * nranks * nranks)))
+        # between two kernels of the library: W x_r -> sum over ranks -> W^-1 = sum of x_r (Haar lifting is linear)
+        n1, n2, n3 = 47, 47, 45
+        g = torch.Generator(device="cpu").manual_seed(7)
+        base = torch.randn(n1 * n2 * n3, dtype=torch.float64, generator=g)
+        mine = (base * float(rank + 1)).to(dev)
+        torch.cuda.synchronize(dev)
+        ctx.wavelet_device(mine.data_ptr(), n1, n2, n3, 1, 1, 1)
+        ctx.comm_allreduce(mine.data_ptr(), mine.numel(), "f64")
+        ctx.wavelet_device(mine.data_ptr(), n1, n2, n3, 1, 1, 2)
+        ctx.comm_barrier()
+        err = float((mine.cpu() - base * float(T)).abs().max() / (base.abs().max() * T))
+        info.update(doubles=n, chained=3, between_kernels_rel_err=err)
+        if not err <= 1e-13:
+            raise RuntimeError("wavelet -> all-reduce -> inverse wavelet: relative error %.2e" % err)
+
+    def s_allgatherv(info):
+        counts = np.array([1000 + 37 * r for r in range(nranks)], np.int64)
+        if nranks >= 3:
+            counts[1] = 0
+        displs = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+        send = torch.full((max(int(counts[rank]), 1),), rank + 0.5, dtype=torch.float64, device=dev)
+        recv = torch.full((int(counts.sum()),), -1.0, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        ctx.comm_allgatherv(send.data_ptr(), recv.data_ptr(), counts, displs)
+        ctx.comm_barrier()
+        got = recv.cpu().numpy()
+        want = np.concatenate([np.full(int(c), r + 0.5) for r, c in enumerate(counts)])
+        info.update(counts=[int(c) for c in counts])
+        if not np.array_equal(got, want):
+            raise RuntimeError("all-gather with unequal counts delivered wrong data")
+
+    def piece(src, dst):
+        return 2048 * (1 + (5 * src + 3 * dst) % 7)                     # int32 elements; different for every ordered pair
+
+    def s_relayout(info):
+        sends, recvs, keep = [], [], []
+        for d in range(nranks):
+            if d != rank:
+                t = torch.full((piece(rank, d),), rank * 64 + d, dtype=torch.int32, device=dev)
+                keep.append(t)
+                sends.append((d, t))
+        for o in range(nranks):
+            if o != rank:
+                t = torch.full((piece(o, rank),), -1, dtype=torch.int32, device=dev)
+                recvs.append((o, t))
+        comm.exchange(sends, recvs)
+        for o, t in recvs:
+            if not bool((t == o * 64 + rank).all().item()):
+                raise RuntimeError("the piece of rank %d arrived damaged" % o)
+        info.update(sends=len(sends), receives=len(recvs), bytes_out=int(sum(4 * t.numel() for _, t in sends)))
+
+    def s_lsqr(info):
+        nx, ny, nz, ox, oy, ctype, rate = 64, 64, 32, 32, 32, 1, 0.1
+        N = nx * ny * nz
+        grid = synthetic.grid(nx, ny, nz)
+        xs, ys, zs = synthetic.observations(nx, ny, ox, oy)
+        ctx.set_grid(nx, ny, nz, *grid)
+        cw = ctx.calculate_depth_weight(2.0, 0.0, 4.0e3)
+        if nranks > 1 and comm.rccl:
+            part = build_partitioned_exchange(ctx, rank, nranks, xs, ys, zs, cw, ctype, rate, device_index=device_index, comm=comm)
+        else:
+            part = build_partitioned(ctx, rank, nranks, xs, ys, zs, cw, ctype, rate, comm=comm)
+        c0, c1 = part["col_range"]
+        xw = ctx.forward_wavelet(synthetic.true_model(nx, ny, nz) / cw, nx, ny, nz, ctype)
+        d_obs = ctx.calc_data(xw[c0:c1], 1.0, None)
+        alpha = np.float32(1e-7)
+        x, it, r = ctx.lsqr_solve_sensit(d_obs, lsqr_iterations, 1e-300, 0.0, 0.0, [np.full(c1 - c0, alpha, np.float32)], [np.zeros(c1 - c0)])
+        ctx.matrix_free()
+        pieces = [(c0, c1, x)]
+        if multi and nranks > 1:
+            pieces = [None] * nranks
+            dist.all_gather_object(pieces, (c0, c1, x), group=control_group())
+        info.update(iterations=int(it), r=float(r), nnz=int(part["nnz_total"]), columns_per_rank=[int(p[1] - p[0]) for p in pieces])
+        if rank == 0:
+            full = np.zeros(N)
+            for a, b, xv in pieces:
+                full[a:b] = xv
+            one = Context(device_index)
+            try:
+                one.set_grid(nx, ny, nz, *grid)
+                res = one.calculate_sensit(xs, ys, zs, cw, ctype, rate)
+                d1 = one.calc_data(xw, 1.0, None)
+                x1, it1, r1 = one.lsqr_solve_sensit(d1, lsqr_iterations, 1e-300, 0.0, 0.0, [np.full(N, alpha, np.float32)], [np.zeros(N)])
+            finally:
+                one.close()
+            rel = float(np.linalg.norm(full - x1) / np.linalg.norm(x1))
+            info.update(single_rank_r=float(r1), x_rel_l2_vs_single_rank=rel, x_bits_identical=bool(np.array_equal(full, x1)),
+                        data_rel_l2_vs_single_rank=float(np.linalg.norm(d_obs - d1) / np.linalg.norm(d1)), nnz_single_rank=int(res["nnz"]))
+            if int(res["nnz"]) != int(part["nnz_total"]) or not rel <= 1e-9 or abs(r - r1) > 1e-9 * abs(r1):
+                raise RuntimeError("x after %d iterations is %.2e from the single-rank solve (r %.12e against %.12e, nnz %d against %d)" %
+                                   (lsqr_iterations, rel, r, r1, part["nnz_total"], res["nnz"]))
+
+    rccl = bool(comm.rccl)
+    run_step("allreduce_rows_plus_1", s_allreduce, step_timeout, applicable=rccl)
+    run_step("allgatherv_unequal", s_allgatherv, step_timeout, applicable=rccl)
+    run_step("relayout_group", s_relayout, step_timeout, applicable=rccl and nranks > 1)
+    run_step("lsqr", s_lsqr, 3.0 * step_timeout)
+    return {"ok": bool(state["ok"]), "steps": steps, "step_timeout_s": step_timeout}
+
+
+def fall_back_to_hooks(ctx, comm, rank, nranks, device_index, why):
+    """After a failed self-test on the RCCL rung: every rank drops the communicator and installs the torch.distributed hooks (the ranks
+    have agreed on the failure inside comm_selftest, so all of them get here)."""
+    import torch.distributed as dist
+    try:
+        ctx.comm_abort()
+    except Exception:      # noqa
+        pass
+    while _stragglers:
+        th = _stragglers.pop()
+        th.join(5.0)
+    ctx.debug_set("force_collectives", 0)
+    hook = TorchAllreduce(device_index)
+    ctx.set_allreduce(hook, rank, nranks)
+    ctx.set_allgatherv(hook.allgatherv)
+    new = HostComm(ctx, rank, nranks, device_index, False)
+    new.report = dict(comm.report)
+    new.report["path"] = "torch.distributed hooks (%s) after the RCCL self-test failed: %s" % (dist.get_backend(), why)
+    new.report["rccl_ranks"] = 0
+    return new
+
+
 def allreduce_numpy(arr, op="sum"):
     """Host-side all-reduce of a numpy array (histograms, scalars) through torch.distributed (any backend)."""
     import torch

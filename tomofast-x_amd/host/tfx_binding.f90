@@ -437,6 +437,13 @@ module tfx_binding
       integer(c_int), value :: dtype
     end function
 
+    ! MPI_Allgatherv on DEVICE buffers of real(8) (wavelet_utils.F90:37-72): counts / displs are host arrays of nranks entries
+    integer(c_int) function tfx_comm_allgatherv(ctx, dev_send, dev_recv, counts, displs) bind(C, name="tfx_comm_allgatherv")
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: ctx, dev_send, dev_recv
+      integer(c_int64_t), intent(in) :: counts(*), displs(*)
+    end function
+
     integer(c_int) function tfx_comm_group_begin(ctx) bind(C, name="tfx_comm_group_begin")
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx

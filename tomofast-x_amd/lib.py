@@ -21,7 +21,7 @@ TFX_E = {-1: "TFX_E_ARG", -2: "TFX_E_HIP", -3: "TFX_E_GEOMETRY", -4: "TFX_E_STAT
 # every symbol include/tfx.h declares (tests check the library exports exactly these)
 SYMBOLS = [
     "tfx_create", "tfx_destroy", "tfx_last_error", "tfx_device_info", "tfx_device_count", "tfx_copy", "tfx_device_malloc", "tfx_device_free", "tfx_set_allreduce", "tfx_set_allgatherv", "tfx_set_grid",
-    "tfx_comm_unique_id", "tfx_comm_init_rccl", "tfx_comm_destroy", "tfx_comm_abort", "tfx_comm_info", "tfx_comm_allreduce", "tfx_comm_group_begin", "tfx_comm_group_end",
+    "tfx_comm_unique_id", "tfx_comm_init_rccl", "tfx_comm_destroy", "tfx_comm_abort", "tfx_comm_info", "tfx_comm_allreduce", "tfx_comm_allgatherv", "tfx_comm_group_begin", "tfx_comm_group_end",
     "tfx_comm_send", "tfx_comm_recv", "tfx_comm_barrier",
     "tfx_column_weight_type1", "tfx_column_weight_type2", "tfx_column_weight_type3", "tfx_prism_rows_gz", "tfx_prism_rows_mag", "tfx_prism_rows", "tfx_wavelet", "tfx_compress_row",
     "tfx_build_kernel_grav", "tfx_build_kernel_mag", "tfx_build_kernel", "tfx_select_problem",

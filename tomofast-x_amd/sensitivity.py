@@ -121,6 +121,13 @@ class Context:
     def comm_allreduce(self, dev_buf, n, dtype="f64"):
         check(self._lib.tfx_comm_allreduce(self._h, ptr(dev_buf), C.c_int64(n), {"f64": 0, "i32": 1, "i64": 2}[dtype]))
 
+    def comm_allgatherv(self, dev_send, dev_recv, counts, displs):
+        """MPI_Allgatherv on device buffers of doubles (tfx_comm_allgatherv): counts / displs per rank, in doubles."""
+        cnt = np.ascontiguousarray(counts, dtype=np.int64)
+        dsp = np.ascontiguousarray(displs, dtype=np.int64)
+        check(self._lib.tfx_comm_allgatherv(self._h, ptr(dev_send), ptr(dev_recv), cnt.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            dsp.ctypes.data_as(C.POINTER(C.c_int64))))
+
     def comm_group_begin(self):
         check(self._lib.tfx_comm_group_begin(self._h))
 
@@ -224,6 +231,10 @@ class Context:
             raise ValueError("array size is not a multiple of n1*n2*n3")
         check(self._lib.tfx_wavelet(self._h, ptr(a), n1, n2, n3, C.c_int64(a.size // n), wtype, direction))
         return a
+
+    def wavelet_device(self, dev_ptr, n1, n2, n3, nvec, wtype, direction):
+        """tfx_wavelet in place on a DEVICE buffer (raw address or torch tensor): kernels on the ctx stream, no host copy."""
+        check(self._lib.tfx_wavelet(self._h, ptr(dev_ptr), n1, n2, n3, C.c_int64(nvec), int(wtype), int(direction)))
 
     def compress_row(self, row, K):
         row = f64(row)
