@@ -84,7 +84,14 @@ def write_parfile_inputs(wd, nx, ny, nz, ox, oy, ctype, rate, nmajor=1, nminor=1
         f.write("%d\n" % xs.size)
         for a, b, c in zip(xs, ys, zs):
             f.write("%.17g %.17g %.17g 0.0\n" % (a, b, c))
+    return write_parfile_text(wd, nx, ny, nz, xs.size, ctype, rate, nmajor=nmajor, nminor=nminor, sensit_read=sensit_read)
+
+
+def write_parfile_text(wd, nx, ny, nz, nd, ctype, rate, nmajor=1, nminor=100, sensit_read=0):
+    """Only the Parfile (the grid / model / data-grid files of write_parfile_inputs stay as they are): a 4e6-cell grid file is 400 MB of
+    text and need not be rewritten to change an iteration count."""
+    import os
     path = os.path.join(wd, "Parfile.txt")
-    open(path, "w").write(PARFILE_TEMPLATE.format(nx=nx, ny=ny, nz=nz, nd=xs.size, ctype=ctype, rate=rate, nmajor=nmajor,
+    open(path, "w").write(PARFILE_TEMPLATE.format(nx=nx, ny=ny, nz=nz, nd=nd, ctype=ctype, rate=rate, nmajor=nmajor,
                                                  nminor=nminor, sensit_read=sensit_read))
     return path
