@@ -355,7 +355,22 @@ int tfx_profile_get(tfx_ctx *ctx, int which, double *total_ms, int64_t *launches
  * key "chunk_exponent_span" (value): diagnostics - per mille of the stored 512-entry chunks whose non-zero values span at most
  * `value` binades (prints the histogram on stderr);
  * key "force_collectives" (0/1): issue the collectives of the multi-rank path even with one rank - with a world-size-1
- * communicator this runs the real ncclAllReduce / ncclBroadcast calls on a single-GPU box.                              */
+ * communicator this runs the real ncclAllReduce / ncclBroadcast calls on a single-GPU box;
+ * key "comm_init_timeout_s" (seconds, default 120; environment TFX_COMM_INIT_TIMEOUT; <= 0 waits for ever): how long tfx_comm_init_rccl
+ *     waits for the rendezvous before it returns TFX_E_COMM;
+ * key "items_per_cu" (default 16; bench.py: environment TFX_ITEMS_PER_CU): work items per CU the tile lists of matrices finished from
+ *     now on are cut into (largest first); key "refinish": rebuilds the work lists of the selected matrix with the current
+ *     "items_per_cu" / "fwd_group" (tools/ab_products.py sweeps them on one resident matrix);
+ * key "gen_after_wavelet" (0..3, default 3; environment TFX_GEN_AFTER_WAVELET): overlapped build - the generator of the next batch is
+ *     queued behind that many axis passes of the current batch's wavelet transform (0: at the batch start, beside all three);
+ * key "gen_wgs_per_cu" (default 0 = one workgroup per tile; environment TFX_GEN_WGS_PER_CU): overlapped build - the gravity generator
+ *     runs as a persistent grid of that many workgroups per CU that walk the tiles (leaves registers / LDS to the main stream's kernels);
+ * key "wave_pipe" (0..8, default 0; environment TFX_WAVE_PIPE): the axis passes of the wavelet transform run as the software-pipelined
+ *     persistent kernel (k_wavelet_axis_pipe: the next tile's loads in flight over the lifting of the current one) with that many
+ *     workgroups per CU, where its shape conditions hold; returns the value set.  Same bits; measured in round 6 and not the default
+ *     (profiles/README.md round 6: 3.6 TB/s at two workgroups per CU against 5.0 for one workgroup per tile).
+ * Every key is read by name in csrc/api.hip; tests/test_cabi_exports.py checks that each one the library accepts, and each one any file
+ * of this repository passes, is described here.                                                                              */
 int tfx_debug_set(tfx_ctx *ctx, const char *key, int value);
 
 /* Diagnostics: evaluates the device build of the prism kernels' fp64 log / atan2 (csrc/fastmath.h: table-reduced replacements of the

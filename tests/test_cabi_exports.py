@@ -104,3 +104,39 @@ def test_parfile_host_reaches_the_gpu_only_through_the_reference_named_entry_poi
                  r"call jinv%calculate_matrix_partitioning\(ipar, line_start, line_end, param_shift\)",
                  r"call jinv%solve\(ipar, iarr, model, delta_model, memory_inv, myrank, nbproc\)"):
         assert re.search(call, code), call
+
+
+def test_every_debug_key_is_documented_in_the_header():
+    """include/tfx.h is the boundary document: every key csrc/api.hip accepts in tfx_debug_set, and every key any file of the repository
+    passes to it (Python hosts, bench.py, tools/, tests/, the Fortran hosts), is described in the header's tfx_debug_set block."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "tfx.h")).read()
+    block = header[header.index("Test / diagnostics switchboard"):header.index("int tfx_debug_set(")]
+    documented = set(re.findall(r'"([a-z_0-9]+)"', block))
+    api = open(os.path.join(root, "tomofast-x_amd", "csrc", "api.hip")).read()
+    body = api[api.index("int tfx_debug_set("):]
+    body = body[:body.index("\n}\n")]
+    accepted = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', body))
+    assert len(accepted) >= 25, accepted
+    assert accepted <= documented, "accepted by the library, missing in include/tfx.h: %s" % sorted(accepted - documented)
+    passed = {}
+    files = [f for pat in ("*.py", "tools/*", "tests/*.py", "tomofast-x_amd/*.py", "tomofast-x_amd/host/*.f90", "tomofast-x_amd/host/dropin/*.f90", "oracle/*.sh")
+             for f in glob.glob(os.path.join(root, pat)) if os.path.isfile(f)]
+    for f in files:
+        if os.path.abspath(f) == os.path.abspath(__file__):
+            continue
+        try:
+            txt = open(f, errors="replace").read()
+        except OSError:
+            continue
+        for key in re.findall(r'debug_set\(\s*(?:[A-Za-z_%0-9]+\s*,\s*)?["\']([a-z_0-9]+)["\']', txt):
+            passed.setdefault(key, f)
+        for key in re.findall(r'"([a-z_0-9]+)"\s*//\s*c_null_char', txt):          # Fortran: tfx_debug_set(ctx, "key"//c_null_char, v)
+            passed.setdefault(key, f)
+    assert len(passed) >= 15, passed
+    unknown = {k: f for k, f in passed.items() if k not in accepted}
+    assert not unknown, "keys passed somewhere in the repository that the library does not know: %s" % unknown
+    missing = {k: f for k, f in passed.items() if k not in documented}
+    assert not missing, "keys passed somewhere in the repository, missing in include/tfx.h: %s" % missing
