@@ -181,7 +181,9 @@ int tfx_build_kernel_mag(tfx_ctx *ctx, int64_t ndata, const double *xd, const do
 /* Storage bound of the NEXT tfx_build_kernel* into the selected slot: at most nnz_upper entries will be kept (0 = no bound given: rows x K,
  * K = int(rate * N), sensitivity_gravmag.F90:64-77).  For a build restricted to a column range [col_begin, col_end) whose entry count is
  * known from a counting pass (the sum of nnz_hist over the range - what a rank of the column-partitioned system holds): without it the
- * range is given the storage of the whole kernel.  A build that finds more entries than reserved fails ("capacity exceeded").        */
+ * range is given the storage of the whole kernel.  A build that finds more entries than reserved fails ("capacity exceeded").  The
+ * reservation is consumed by the next tfx_build_kernel* / tfx_rowstore_build* call whatever its outcome (also one that fails, builds into
+ * a row store or keeps no columns) and is ignored by a build into the other slot (tfx_select_problem).                                  */
 int tfx_matrix_reserve(tfx_ctx *ctx, int64_t nnz_upper);
 
 /* General form: any data type / component counts the reference's build loop handles (:193-311).  The matrix has

@@ -506,6 +506,61 @@ def _random_csr(rng, nrows, ncols, per_row):
     return np.array(rp, np.int64), np.concatenate(cols), np.concatenate(vals)
 
 
+def test_normalize_columns_many_rows_and_non_finite_entries(ctx):
+    """t_sparse_matrix%normalize_columns has no row limit and propagates NaN / Inf (sparse_matrix.f90:414-443): a matrix with
+    more than 2^17 rows (three data components at ~1e5 data, a joint system) - the exact integer column sums coarsen their grid by one
+    bit per doubling instead of refusing; a column holding a NaN gets a NaN norm and NaN entries, a column whose square overflows fp32
+    gets an infinite norm and zero entries, exactly what the reference's fp32 squares / fp64 sum / division give."""
+    rng = np.random.default_rng(5)
+    nrows, ncols = (1 << 18) + 37, 300
+    per = 2
+    cols = (rng.integers(0, ncols, (nrows, per)) + 1).astype(np.int32)
+    cols.sort(axis=1)
+    cols[:, 1] = np.where(cols[:, 1] == cols[:, 0], cols[:, 1] % ncols + 1, cols[:, 1])
+    cols.sort(axis=1)
+    assert np.all(cols[:, 1] > cols[:, 0])
+    vals = (rng.standard_normal((nrows, per)) * 10.0 ** rng.uniform(-4, 4, (nrows, per))).astype(np.float32)
+    rp = np.arange(0, per * nrows + 1, per, dtype=np.int64)
+    cols, vals = cols.ravel(), vals.ravel()
+    norm_o, vals_o = orc.normalize_columns(rp, cols, vals, ncols)
+    ctx.matrix_upload_csr(nrows, ncols, rp, cols, vals)
+    norm_g = ctx.normalize_columns()
+    vals_g = ctx.matrix_download_csr()[2]
+    assert np.all(np.abs(norm_g - norm_o) <= nrows * 2.0 ** -53 * norm_o)
+    same = (norm_g == norm_o)[cols - 1]
+    assert bits_equal(vals_g[same], vals_o[same]) and np.all(np.abs(vals_g.astype(np.float64) - vals_o) <= 2.0 ** -23 * np.abs(vals_o))
+    report("normalize_columns_many_rows", rows=nrows, worst_rel_distance=float(np.max(np.abs(norm_g - norm_o) / norm_o)),
+           norms_identical=int(np.count_nonzero(norm_g == norm_o)), norms=ncols)
+    # non-finite entries: column 3 holds a NaN, column 7 a value whose square overflows fp32, column 11 an infinity
+    nrows, ncols = 400, 16
+    A = rng.standard_normal((nrows, ncols)).astype(np.float32)
+    A[17, 2] = np.nan
+    A[250, 6] = np.float32(3.0e19)
+    A[99, 10] = np.inf
+    S = kat_cases.dense_to_csr(A.astype(np.float64))
+    for adj in (1, 0):
+        ctx.debug_set("adj_copy", adj)
+        try:
+            ctx.matrix_upload_csr(nrows, ncols, S[0], S[1], np.asarray(S[2], np.float32))
+            with np.errstate(all="ignore"):
+                norm_o, vals_o = orc.normalize_columns(S[0], S[1], np.asarray(S[2], np.float32), ncols)
+            norm_g = ctx.normalize_columns()
+            vals_g = ctx.matrix_download_csr()[2]
+        finally:
+            ctx.debug_set("adj_copy", 2)
+        assert np.isnan(norm_g[2]) and np.isnan(norm_o[2]) and np.isposinf(norm_g[6]) and np.isposinf(norm_o[6]) and np.isposinf(norm_g[10])
+        fin = np.isfinite(norm_o)
+        assert np.all(np.abs(norm_g[fin] - norm_o[fin]) <= nrows * 2.0 ** -53 * norm_o[fin])
+        c0 = S[1] - 1
+        assert np.all(np.isnan(vals_g[c0 == 2])) and np.all(np.isnan(vals_o[c0 == 2]))
+        assert np.all(vals_g[c0 == 6] == 0.0) and np.all(vals_o[c0 == 6] == 0.0)
+        inf_col = vals_g[c0 == 10]
+        assert np.count_nonzero(np.isnan(inf_col)) == 1 and np.count_nonzero(inf_col == 0.0) == inf_col.size - 1      # inf / inf, x / inf
+        with np.errstate(all="ignore"):
+            assert np.array_equal(np.isnan(vals_g), np.isnan(vals_o))
+    ctx.matrix_free()
+
+
 @pytest.mark.parametrize("group", [0, 1, 2, 4])
 def test_forward_super_blocks_give_the_same_product(ctx, group):
     """The forward product shares one staged x tile between `fwd_group` row blocks; every grouping must give the oracle's product

@@ -119,3 +119,31 @@ def test_column_restriction_of_constraint_blocks(golden_dir):
     one = tfx.inversion.restrict_columns(Gd, 37, 150)
     keep = (Gd[1] > 37) & (Gd[1] <= 150)
     assert np.array_equal(one[1], Gd[1][keep] - 37) and np.array_equal(one[2], Gd[2][keep]) and int(one[0][-1]) == int(keep.sum())
+
+
+def test_canonical_csr_of_rows_built_with_add(tmp_path):
+    """tfx_reference_api::api_canonical_csr (what the drop-in sparse_matrix / lsqr_solver modules pass to tfx_matrix_upload_csr): rows
+    as the reference's add() builds them - any column order, repeated columns, empty rows (sparse_matrix.f90:213-229) - come out with
+    strictly ascending columns, repeated columns merged by adding their values in the order they were added, and `where` maps every
+    input entry to its output entry.  Compiled here with amdflang against the host objects (no GPU call is made)."""
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tomofast-x_amd", "host")
+    fc = "/opt/rocm/bin/amdflang"
+    if not os.path.isfile(fc) or not os.path.isfile(os.path.join(host, "tfx_reference_api.o")):
+        pytest.skip("no Fortran compiler / host objects (build() makes them where amdflang exists)")
+    exe = str(tmp_path / "canonical_csr_check")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fortran", "canonical_csr_check.f90")
+    cmd = [fc, "-O1", "-I" + host, src] + [os.path.join(host, o) for o in ("tfx_binding.o", "tfx_host_mpi.o", "tfx_reference_api.o")] + \
+          ["-L" + os.path.dirname(host), "-ltfx", "-L" + os.path.join(host, "mpilib"), "-lmpifort", "-lmpi",
+           "-Wl,-rpath," + os.path.dirname(host), "-Wl,-rpath," + os.path.join(host, "mpilib"), "-o", exe]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.split("\n")
+    rp = [int(v) for v in next(l for l in lines if l.startswith("rp")).split()[1:]]
+    ent = [(int(l.split()[1]), int(l.split()[2]), float(l.split()[3])) for l in lines if l.startswith("entry")]
+    where = [int(v) for v in next(l for l in lines if l.startswith("where")).split()[1:]]
+    assert rp == [0, 3, 3, 4, 5, 8]
+    assert ent == [(1, 1, 4.0), (1, 2, 2.0), (1, 7, 1.5), (3, 3, 0.25), (4, 9, 8.0), (5, 1, 5.0), (5, 4, 6.0), (5, 5, 4.0)]
+    assert where == [3, 2, 3, 1, 4, 4, 4, 5, 8, 7, 8, 7, 6]

@@ -522,6 +522,7 @@ int tfx_matrix_reserve(tfx_ctx *ctx, int64_t nnz_upper)
 {
     if (!ctx || nnz_upper < 0) return fail(TFX_E_ARG, "tfx_matrix_reserve: bad arguments");
     ctx->reserve_nnz = nnz_upper;
+    ctx->reserve_slot = ctx->slot;
     return 0;
 }
 

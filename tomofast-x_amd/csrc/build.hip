@@ -41,6 +41,9 @@ __device__ __forceinline__ void init_math_tables()
 // every outstanding store (s_waitcnt vmcnt(0)): in the row generators that drained the non-temporal stores of an observation's rows -
 // which nothing in the kernel ever reads back - at the first barrier of the next observation, so the HBM write latency of each cell phase
 // was exposed instead of running under the next node phase.
+// ONLY LDS IS ORDERED: a global store issued before it may still be in flight after it.  Nothing in these kernels reads back what it
+// stored; a change that does (rows, sumsq) needs __syncthreads() at that point.  The two instructions are the gfx9 encoding (CDNA:
+// lgkmcnt counts LDS operations, s_barrier is the workgroup barrier); common.h refuses to compile the device code for anything else.
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -3308,6 +3311,13 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
     // rs != null: keep the compressed rows (all columns, global 0-based column indices) row-major on the device instead of
     // laying them out as this rank's tiled matrix - the row-parallel half of the multi-GPU build
     const bool to_rs = rs != nullptr;
+    // tfx_matrix_reserve arms ONE build: consumed here, before any exit, so that a build that fails on its arguments, a row-store build or
+    // a counting pass (no columns kept) can not leave it armed for a later, larger build; a build into the other slot ignores it
+    int64_t reserved = 0;
+    if (ctx) {
+        if (ctx->reserve_nnz > 0 && ctx->reserve_slot == ctx->slot) reserved = ctx->reserve_nnz;
+        ctx->reserve_nnz = 0;
+    }
     if (to_rs) { col_begin = 0; col_end = ctx ? ctx->N : 0; }
     if (to_rs && compression_type == 0) return fail(TFX_E_ARG, "the row store is for compressed kernels (dense kernels are built per column range)");
     if (!ctx || !xd || !yd || !zd || !column_weight) return fail(TFX_E_ARG, "tfx_build_kernel: null argument");
@@ -3409,8 +3419,7 @@ static int build_kernel_any(tfx_ctx *ctx, const RowGen &gen, int64_t ndata, cons
         // (a caller that knows how many entries the column range will hold - it has the per-column histogram of a counting pass - says so
         // with tfx_matrix_reserve: a range of a rank-partitioned kernel holds 1 / P of the rows x K bound used otherwise)
         int64_t upper = nrows_m * stride;
-        if (ctx->reserve_nnz > 0) upper = std::min(upper, ctx->reserve_nnz);
-        ctx->reserve_nnz = 0;
+        if (reserved > 0) upper = std::min(upper, reserved);
         TFX_TRY(matrix_begin(ctx, nrows_m, ncm * ncols, upper));
         lap("matrix_begin");
     }

@@ -1,5 +1,11 @@
 // common.h - context, error handling and device-buffer helpers of libtfx.so (gfx950 only).
 #pragma once
+// The device code of this library is written for CDNA (gfx9 instruction encoding: `s_waitcnt lgkmcnt` / `s_barrier` in lds_barrier, DPP
+// row_shl reductions, mbcnt on 64-bit masks, 64-wide wavefronts).  ARCH in the Makefile can be overridden: anything that is not gfx9
+// stops here instead of assembling instructions that mean something else there.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "libtfx.so: device code is written for CDNA / gfx9 (MI355X: --offload-arch=gfx950)"
+#endif
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -194,7 +200,13 @@ struct TiledMatrix {
         // the two allocations (100+ GB: seconds) run on a helper thread while the build's first row blocks are computed; whoever looks at
         // rec / row0 - or destroys the object - waits for it first
         std::future<void> pending;
-        void wait() { if (pending.valid()) pending.get(); }
+        // (get() rethrows what the helper threw; this runs in a destructor, so nothing may leave it: the helper's lambda catches
+        // everything itself, and the catch here is the belt to those braces - a failed set-aside just leaves rec / row0 empty)
+        void wait() noexcept
+        {
+            if (!pending.valid()) return;
+            try { pending.get(); } catch (...) { rec.release(); row0.release(); }
+        }
         ~Prealloc() { wait(); }
     };
     std::unique_ptr<Prealloc> pre;
@@ -302,7 +314,8 @@ struct tfx_ctx {
         tfx::DBuf<float> tvals;
     } trs;
     double tr_panel_entries = 9.0e8, tr_pos_budget = 1.5e8;   // panel size of the transposition (debug keys "tr_panel_entries" / "tr_pos_budget": tests force many small panels of either shape)
-    int64_t reserve_nnz = 0;          // tfx_matrix_reserve: entry bound of the next kernel build into the selected slot (0 = rows x K)
+    int64_t reserve_nnz = 0;          // tfx_matrix_reserve: entry bound of the next kernel build into slot `reserve_slot` (0 = rows x K)
+    int reserve_slot = 0;             // the slot that was selected when the reservation was made: a build into the other slot ignores it
     int lsqr_merge_tail = 1;          // debug key "lsqr_merge_tail" / TFX_LSQR_MERGE_TAIL: the x / w update of an LSQR iteration also does the next iteration's u = -alpha u and constraint forward step (one launch instead of three; same bits)
     int fwd_run = 2;                  // debug key "fwd_run": consecutive chunks a wave of the forward kernel takes at a time (matrix.hip k_spmv_fwd)
     int fwd_group_override = 0;       // debug key "fwd_group": row blocks per forward super block (0 = automatic)

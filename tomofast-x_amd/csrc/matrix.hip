@@ -443,9 +443,14 @@ int matrix_begin(tfx_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz_upper)
             TiledMatrix::Prealloc *pre = m.pre.get();
             const int dev = ctx->device;
             const size_t nrec = (size_t)(capT / CHUNK) * REC_BYTES, nrow0 = (size_t)(capT / CHUNK);
-            auto set_aside = [pre, dev, nrec, nrow0] {
-                (void)hipSetDevice(dev);
-                if (pre->rec.alloc(nrec) != 0 || pre->row0.alloc(nrow0) != 0) {
+            auto set_aside = [pre, dev, nrec, nrow0]() noexcept {
+                try {
+                    (void)hipSetDevice(dev);
+                    if (pre->rec.alloc(nrec) != 0 || pre->row0.alloc(nrow0) != 0) {
+                        pre->rec.release();
+                        pre->row0.release();
+                    }
+                } catch (...) {             // (e.g. bad_alloc while fail() formats its message: the set-aside is optional)
                     pre->rec.release();
                     pre->row0.release();
                 }
@@ -2193,8 +2198,12 @@ int scale_rows_dev(tfx_ctx *ctx, TiledMatrix &m, const float *d_scale)
 // formed in fp32 and added in fp64, then sa(k) = real(sa(k) / column_norm(j), 4) for the columns whose norm is not zero.
 // The sum is formed EXACTLY here (so it has the same bits on every run whatever order the entries arrive in): pass 1 finds the largest
 // square of a column, pass 2 adds every square as two 64-bit integers on a grid fixed by that maximum (units of 2^-40 and 2^-85 of the
-// maximum's binade: 2^17 rows can not overflow either word, bits below 2^-85 of the largest square are dropped), pass 3 rounds once.
-// The reference's sequential fp64 sum differs from the exact one by at most nrows * 2^-53 relative.
+// maximum's binade for up to 2^17 rows; every further doubling of the row count coarsens both words by one bit - `shift` =
+// max(0, ceil(log2 nrows) - 17) - so neither can overflow for any row count: hi < 2^(41 - shift) nrows <= 2^58, lo < 2^(45 - shift) nrows
+// <= 2^62; bits below 2^-(85 - 2 shift) of the largest square are dropped - 2^-65 at 2^27 rows, still far below fp64's 2^-53), pass 3
+// rounds once.  The reference's sequential fp64 sum differs from the exact one by at most nrows * 2^-53 relative.
+// A column that holds a NaN or an infinite square (a value beyond 1.8e19 overflows sa**2 in fp32, as it does in the reference) gets the
+// norm the reference's sum would have - NaN resp. +Inf - and its entries the quotients by it.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_colsq_max(const TileMeta *__restrict__ tiles, int ntiles, const char *__restrict__ rec, int TC, int64_t ncols,
                                                     uint32_t *__restrict__ qmax)
@@ -2211,23 +2220,25 @@ __global__ __launch_bounds__(256) void k_colsq_max(const TileMeta *__restrict__ 
             for (int k = 0; k < 8; ++k) {
                 const int64_t col = col0 + col_slot((int)sl[k]);
                 const float q = cr.v[k] * cr.v[k];                       // sa(k)**2 in MATRIX_PRECISION (:427)
-                if (q > 0.0f && col < ncols) atomicMax(qmax + col, __float_as_uint(q));      // (non-negative floats order like their bit patterns)
+                // (non-negative floats order like their bit patterns; +Inf sits above every finite square and a NaN - sign cleared - above
+                // +Inf, so the maximum also says whether the column holds a non-finite square)
+                if (!(q <= 0.0f) && col < ncols) atomicMax(qmax + col, __float_as_uint(q) & 0x7fffffffu);
             }
         }
     }
 }
 
-__device__ __forceinline__ void colsq_split(float q, uint32_t qmax_bits, unsigned long long &hi, unsigned long long &lo)
+__device__ __forceinline__ void colsq_split(float q, uint32_t qmax_bits, int shift, unsigned long long &hi, unsigned long long &lo)
 {
     const int e = (int)((qmax_bits >> 23) & 0xffu) - 127;            // binade of the column's largest square (denormal: -127, still a valid grid)
-    const double t = ldexp((double)q, 40 - e);                       // exact; < 2^41
+    const double t = ldexp((double)q, 40 - shift - e);               // exact; < 2^(41 - shift)
     const double th = floor(t);
     hi = (unsigned long long)th;
-    lo = (unsigned long long)floor(ldexp(t - th, 45));               // (t - th is exact, < 1)
+    lo = (unsigned long long)floor(ldexp(t - th, 45 - shift));       // (t - th is exact, < 1)
 }
 
 __global__ __launch_bounds__(256) void k_colsq_sum(const TileMeta *__restrict__ tiles, int ntiles, const char *__restrict__ rec, int TC, int64_t ncols,
-                                                    const uint32_t *__restrict__ qmax, unsigned long long *__restrict__ acc)
+                                                    const uint32_t *__restrict__ qmax, unsigned long long *__restrict__ acc, int shift)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int ti = blockIdx.y; ti < ntiles; ti += gridDim.y) {
@@ -2242,8 +2253,10 @@ __global__ __launch_bounds__(256) void k_colsq_sum(const TileMeta *__restrict__ 
                 const int64_t col = col0 + col_slot((int)sl[k]);
                 const float q = cr.v[k] * cr.v[k];
                 if (q > 0.0f && col < ncols) {
+                    const uint32_t qb = qmax[col];
+                    if ((qb >> 23) == 0xffu) continue;                   // a non-finite square in this column: the norm is NaN / Inf whatever the rest adds
                     unsigned long long hi, lo;
-                    colsq_split(q, qmax[col], hi, lo);
+                    colsq_split(q, qb, shift, hi, lo);
                     if (hi) atomicAdd(acc + 2 * col, hi);
                     if (lo) atomicAdd(acc + 2 * col + 1, lo);
                 }
@@ -2252,15 +2265,20 @@ __global__ __launch_bounds__(256) void k_colsq_sum(const TileMeta *__restrict__ 
     }
 }
 
-__global__ void k_colsq_finish(const uint32_t *__restrict__ qmax, const unsigned long long *__restrict__ acc, int64_t ncols, double *__restrict__ norm)
+__global__ void k_colsq_finish(const uint32_t *__restrict__ qmax, const unsigned long long *__restrict__ acc, int64_t ncols, double *__restrict__ norm,
+                               int shift)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ncols) return;
     const uint32_t qb = qmax[j];
     if (qb == 0u) { norm[j] = 0.0; return; }
+    if ((qb >> 23) == 0xffu) {                 // sum(...) of the reference is NaN (a NaN square) or +Inf (an overflowed one); sqrt keeps either
+        norm[j] = (qb & 0x7fffffu) ? __longlong_as_double(0x7ff8000000000000ll) : __longlong_as_double(0x7ff0000000000000ll);
+        return;
+    }
     const int e = (int)((qb >> 23) & 0xffu) - 127;
-    // hi < 2^58, lo < 2^62 in units 2^-45 of hi's: one fp64 sum of the two words, one rounding each for the conversions
-    const double sum = ldexp((double)acc[2 * j] + ldexp((double)acc[2 * j + 1], -45), e - 40);
+    // hi < 2^58, lo < 2^62 in units 2^-(45 - shift) of hi's: one fp64 sum of the two words, one rounding each for the conversions
+    const double sum = ldexp((double)acc[2 * j] + ldexp((double)acc[2 * j + 1], -(45 - shift)), e - (40 - shift));
     norm[j] = sqrt(sum);                                                                    // :432
 }
 
@@ -2319,7 +2337,9 @@ int normalize_columns_dev(tfx_ctx *ctx, TiledMatrix &m, double *d_norm)
         TFX_HIP(hipGetLastError());
         return 0;
     }
-    if (m.nrows > ((int64_t)1 << 17)) return fail(TFX_E_ARG, "normalize_columns: more than 2^17 rows (the exact column sums are sized for that)");
+    int shift = 0;                           // the integer grid coarsens by one bit per doubling of the row count beyond 2^17
+    while (((int64_t)1 << (17 + shift)) < m.nrows) ++shift;
+    if (shift > 24) return fail(TFX_E_ARG, "normalize_columns: more than 2^41 rows");
     const int nt = (int)m.h_tiles.size();
     DBuf<uint32_t> qmax;
     DBuf<unsigned long long> acc;
@@ -2330,9 +2350,9 @@ int normalize_columns_dev(tfx_ctx *ctx, TiledMatrix &m, double *d_norm)
     const dim3 grid(8, (unsigned)std::max(1, std::min(nt, 32768)));
     if (nt > 0) {
         hipLaunchKernelGGL(k_colsq_max, grid, dim3(256), 0, s, m.tiles.p, nt, m.rec.p, m.TC, m.ncols, qmax.p);
-        hipLaunchKernelGGL(k_colsq_sum, grid, dim3(256), 0, s, m.tiles.p, nt, m.rec.p, m.TC, m.ncols, qmax.p, acc.p);
+        hipLaunchKernelGGL(k_colsq_sum, grid, dim3(256), 0, s, m.tiles.p, nt, m.rec.p, m.TC, m.ncols, qmax.p, acc.p, shift);
     }
-    hipLaunchKernelGGL(k_colsq_finish, dim3((unsigned)((m.ncols + 255) / 256)), dim3(256), 0, s, qmax.p, acc.p, m.ncols, d_norm);
+    hipLaunchKernelGGL(k_colsq_finish, dim3((unsigned)((m.ncols + 255) / 256)), dim3(256), 0, s, qmax.p, acc.p, m.ncols, d_norm, shift);
     if (nt > 0)
         hipLaunchKernelGGL(k_div_by_norm<false>, grid, dim3(256), 0, s, m.tiles.p, nt, m.rec.p, m.chunk_row0.p, m.TC, m.RB, m.ncols, d_norm);
     TFX_HIP(hipGetLastError());

@@ -14,7 +14,7 @@ module lsqr_solver
   use mpi_tools, only: exit_MPI
   use sparse_matrix
   use tfx_binding
-  use tfx_reference_api, only: api_matrix => t_sparse_matrix, api_lsqr_solve_sensit => lsqr_solve_sensit, tfx_api_context, api_check
+  use tfx_reference_api, only: api_matrix => t_sparse_matrix, api_lsqr_solve_sensit => lsqr_solve_sensit, tfx_api_context, api_check, api_canonical_csr
   implicit none
   private
 
@@ -128,7 +128,9 @@ contains
     real(kind=CUSTOM_REAL), intent(inout) :: u(nlines)
     type(c_ptr), save :: ctx = c_null_ptr
     type(c_ptr) :: none(1)
-    integer(c_int64_t), allocatable :: rowptr(:)
+    integer(c_int64_t), allocatable :: rowptr(:), rp(:)
+    integer(c_int32_t), allocatable :: cols(:)
+    real(c_float), allocatable :: vals(:)
     integer(c_int) :: iters
     real(c_double) :: r
     integer(kind=8) :: nel
@@ -143,8 +145,9 @@ contains
     if (nel == 0) return
     allocate(rowptr(nlines + 1))
     rowptr = matrix%h%ijl(1:nlines + 1)
-    call api_check(tfx_matrix_upload_csr(ctx, int(nlines, c_int64_t), int(nelements, c_int64_t), rowptr, matrix%h%ija, matrix%h%sa), &
-                   'lsqr_solve (upload)', myrank)
+    ! rows as add() built them (any column order, repeated columns: sparse_matrix.f90:213-229) -> ascending, distinct columns per row
+    call api_canonical_csr(nlines, rowptr, matrix%h%ija, matrix%h%sa, rp, cols, vals)
+    call api_check(tfx_matrix_upload_csr(ctx, int(nlines, c_int64_t), int(nelements, c_int64_t), rp, cols, vals), 'lsqr_solve (upload)', myrank)
     none = c_null_ptr
     call api_check(tfx_lsqr_solve(ctx, int(niter, c_int), rmin, gamma, 0.d0, u, 0_c_int, none, none, x, iters, r), 'lsqr_solve', myrank)
     if (myrank == 0) print *, 'End of subroutine lsqr_solve, r =', r, ' iter =', iters

@@ -20,7 +20,7 @@ module sparse_matrix
   use global_typedefs
   use mpi_tools, only: exit_MPI
   use tfx_binding
-  use tfx_reference_api, only: api_matrix => t_sparse_matrix, tfx_api_context, api_check
+  use tfx_reference_api, only: api_matrix => t_sparse_matrix, tfx_api_context, api_check, api_canonical_csr
   implicit none
   private
 
@@ -30,6 +30,7 @@ module sparse_matrix
     integer :: nl = 0, ncolumns = 0
     integer(kind=8) :: nnz_pred = 0
     logical :: have_rows = .false.
+    integer :: uid = 0                               ! serial number (initialize): which matrix the scratch context holds
     ! device-resident kernels (the sensitivity matrix): block p of the joint system = kernel of problem p
     logical :: on_device = .false.
     logical :: loaded(2) = .false.
@@ -65,6 +66,11 @@ module sparse_matrix
   end type t_sparse_matrix
 
   type(c_ptr), save :: scratch_ctx = c_null_ptr      ! products of host-assembled matrices (unit tests)
+  ! what the scratch context holds: the rows of ONE host-assembled matrix (identified by the serial number it got in initialize, its
+  ! shape and its entry count); every procedure that changes rows clears it, so a matrix multiplied repeatedly is uploaded once
+  integer, save :: uploaded_owner = 0, next_uid = 0
+  integer(kind=8), save :: uploaded_nnz = -1
+  integer, save :: uploaded_nl = -1, uploaded_ncolumns = -1, uploaded_row = -1
 
 contains
 
@@ -88,6 +94,9 @@ contains
     ! the kernels) never receives one here - read_sensitivity_kernel registers its kernels on the device.
     this%nnz_pred = nnz
     this%have_rows = .false.
+    next_uid = next_uid + 1
+    this%uid = next_uid
+    uploaded_owner = 0
     if (present(nl_empty)) continue
   end subroutine sparse_matrix_initialize
 
@@ -101,6 +110,7 @@ contains
 
   subroutine sparse_matrix_reset(this)
     class(t_sparse_matrix), intent(inout) :: this
+    uploaded_owner = 0
     if (this%have_rows) call this%h%reset()
   end subroutine sparse_matrix_reset
 
@@ -117,6 +127,7 @@ contains
     real(kind=CUSTOM_REAL), intent(in) :: value
     integer, intent(in) :: column, myrank
     call need_rows(this, myrank)
+    uploaded_owner = 0
     call this%h%add(value, column, myrank)
   end subroutine sparse_matrix_add
 
@@ -127,6 +138,7 @@ contains
     integer, intent(in) :: columns(nel_add)
     integer, intent(in) :: myrank
     call need_rows(this, myrank)
+    uploaded_owner = 0
     call this%h%add_row(nel_add, values, columns, myrank)
   end subroutine sparse_matrix_add_row
 
@@ -134,6 +146,7 @@ contains
     class(t_sparse_matrix), intent(inout) :: this
     integer, intent(in) :: myrank
     call need_rows(this, myrank)
+    uploaded_owner = 0
     call this%h%new_row(myrank)
   end subroutine sparse_matrix_new_row
 
@@ -141,6 +154,7 @@ contains
     class(t_sparse_matrix), intent(inout) :: this
     integer, intent(in) :: nrows, myrank
     call need_rows(this, myrank)
+    uploaded_owner = 0
     call this%h%add_empty_rows(nrows, myrank)
   end subroutine sparse_matrix_add_empty_rows
 
@@ -178,7 +192,9 @@ contains
     class(t_sparse_matrix), intent(in) :: this
     type(c_ptr) :: ctx
     integer(c_int64_t) :: nnz
-    integer(c_int64_t), allocatable :: rowptr(:)
+    integer(c_int64_t), allocatable :: rowptr(:), rp(:)
+    integer(c_int32_t), allocatable :: cols(:)
+    real(c_float), allocatable :: vals(:)
     if (this%on_device) then
       ctx = tfx_api_context(0, 1)
       return
@@ -186,12 +202,17 @@ contains
     if (.not. c_associated(scratch_ctx)) call check(tfx_create(0_c_int, c_null_ptr, scratch_ctx), 'tfx_create')
     ctx = scratch_ctx
     nnz = this%h%get_number_elements()
+    if (uploaded_owner == this%uid .and. this%uid /= 0 .and. uploaded_nnz == nnz .and. uploaded_nl == this%nl .and. &
+        uploaded_ncolumns == this%ncolumns .and. uploaded_row == this%h%get_current_row_number()) return      ! these rows are there already
     allocate(rowptr(this%nl + 1))
     rowptr = this%h%ijl(1:this%nl + 1)
     rowptr(this%h%get_current_row_number() + 2:) = nnz             ! (rows not closed yet are empty)
+    ! add() takes any column order and repeated columns (sparse_matrix.f90:213-229); the device layout wants ascending, distinct ones
+    call api_canonical_csr(this%nl, rowptr, this%h%ija, this%h%sa, rp, cols, vals)
     call check(tfx_select_problem(ctx, 0_c_int), 'tfx_select_problem')
-    call check(tfx_matrix_upload_csr(ctx, int(this%nl, c_int64_t), int(this%ncolumns, c_int64_t), rowptr, this%h%ija, this%h%sa), &
-               'tfx_matrix_upload_csr')
+    call check(tfx_matrix_upload_csr(ctx, int(this%nl, c_int64_t), int(this%ncolumns, c_int64_t), rp, cols, vals), 'tfx_matrix_upload_csr')
+    uploaded_owner = this%uid
+    uploaded_nnz = nnz; uploaded_nl = this%nl; uploaded_ncolumns = this%ncolumns; uploaded_row = this%h%get_current_row_number()
   end function product_context
 
   ! b (+)= A x over the blocks of the joint matrix (device) or the uploaded rows (host-assembled)
@@ -312,8 +333,33 @@ contains
     endif
     ctx = product_context(this)
     call check(tfx_matrix_normalize_columns(ctx, column_norm), 'normalize_columns')
-    allocate(rowptr(this%nl + 1), cols(this%h%get_number_elements()))
-    call check(tfx_matrix_download_csr(ctx, rowptr, cols, this%h%sa), 'tfx_matrix_download_csr')
+    ! the scaled values go back into the rows as the caller stored them: entry k of the host rows went into entry where(k) of the uploaded
+    ! (sorted, merged) rows; of several entries of one column the first receives the scaled sum and the others zero (the row's
+    ! products are unchanged)
+    block
+      integer(c_int64_t), allocatable :: rp_in(:), rp(:), where(:)
+      integer(c_int32_t), allocatable :: cc(:)
+      real(c_float), allocatable :: vv(:), dv(:)
+      logical, allocatable :: taken(:)
+      integer(c_int64_t) :: k, nnz
+      nnz = this%h%get_number_elements()
+      allocate(rp_in(this%nl + 1))
+      rp_in = this%h%ijl(1:this%nl + 1)
+      rp_in(this%h%get_current_row_number() + 2:) = nnz
+      call api_canonical_csr(this%nl, rp_in, this%h%ija, this%h%sa, rp, cc, vv, where)
+      allocate(rowptr(this%nl + 1), cols(max(rp(this%nl + 1), 1_c_int64_t)), dv(max(rp(this%nl + 1), 1_c_int64_t)), taken(max(rp(this%nl + 1), 1_c_int64_t)))
+      call check(tfx_matrix_download_csr(ctx, rowptr, cols, dv), 'tfx_matrix_download_csr')
+      taken = .false.
+      do k = 1, nnz
+        if (taken(where(k))) then
+          this%h%sa(k) = 0._c_float
+        else
+          this%h%sa(k) = dv(where(k))
+          taken(where(k)) = .true.
+        endif
+      enddo
+    end block
+    uploaded_owner = 0                      ! (the host rows were rewritten: the next product uploads them again)
   end subroutine sparse_matrix_normalize_columns
 
   pure function sparse_matrix_get_total_row_number(this) result(res)

@@ -242,7 +242,7 @@ module tfx_reference_api
   public :: calculate_depth_weight, calculate_and_write_sensit, calculate_new_partitioning, read_sensitivity_kernel
   public :: model_calculate_data, lsqr_solve_sensit, forward_wavelet, inverse_wavelet
   public :: get_full_array, write_sensit_rank_file_enabled
-  public :: tfx_api_kernel_slot, api_check
+  public :: tfx_api_kernel_slot, api_check, api_canonical_csr
 
 contains
 
@@ -514,10 +514,17 @@ contains
     integer, intent(in) :: line_start, param_shift
     integer, intent(in) :: myrank
     real(dp), intent(out) :: b(ndata)
-    integer :: slot
+    integer :: slot, ip
     integer(c_int64_t) :: nr, nc, nz, dbytes
     if (.not. this%on_device) call exit_MPI('part_mult_vector: only the device-resident sensitivity kernel has products.', myrank, 0)
-    slot = merge(0, 1, line_start <= 1 .and. param_shift == 0)
+    ! The caller addresses the block of problem 1 with (line_start 1, param_shift 0) and the block of problem 2 with the rows behind
+    ! problem 1's and param_shift = nelements * nmodel_components(1) - ALSO when problem 2 is the only one solved (line_start 1,
+    ! param_shift /= 0: problem_joint_gravmag.F90:333, model.F90:258-262), so neither number says which slot holds the kernel: the
+    ! kernels recorded by read_sensitivity_kernel do (ADVICE r5)
+    ip = merge(1, 2, param_shift == 0)
+    if (.not. kst(ip)%built) ip = 3 - ip
+    if (.not. kst(ip)%built .or. kst(ip)%slot < 0) call exit_MPI('part_mult_vector: no sensitivity kernel has been loaded.', myrank, 0)
+    slot = kst(ip)%slot
     call api_check(tfx_select_problem(api_ctx, int(slot, c_int)), 'tfx_select_problem', myrank)
     call api_check(tfx_matrix_info(api_ctx, nr, nc, nz, dbytes), 'tfx_matrix_info', myrank)
     if (nr /= ndata .or. nc /= nelements) call exit_MPI('Wrong line index in sparse_matrix_part_mult_vector!', myrank, 0)
@@ -1510,6 +1517,60 @@ contains
 
   ! Ascending columns inside one constraint row (rows are a handful of entries: insertion sort).  Two entries of one row in the same
   ! column - the reference's format allows them, its products simply add both - become one entry with the fp32 sum of the two.
+  ! Rows as tfx_matrix_upload_csr takes them - columns strictly ascending inside a row - from rows as t_sparse_matrix%add builds them
+  ! (sparse_matrix.f90:213-229): ANY column order, and the same column more than once (the stencils of cross_gradient.F90 and
+  ! damping_gradient.F90 add to one column from several directions).  Per row: a stable insertion sort by column (rows of constraint
+  ! matrices hold a handful of entries), entries of one column merged by adding their values in the order they were added (fp32, like
+  ! the sort_row of the constraint path).  where(k) = the entry of the result that input entry k went into (for writing values back).
+  subroutine api_canonical_csr(nl, rowptr, ija, sa, rp, cols, vals, where)
+    integer, intent(in) :: nl
+    integer(c_int64_t), intent(in) :: rowptr(nl + 1)
+    integer(c_int32_t), intent(in) :: ija(*)
+    real(c_float), intent(in) :: sa(*)
+    integer(c_int64_t), allocatable, intent(out) :: rp(:)
+    integer(c_int32_t), allocatable, intent(out) :: cols(:)
+    real(c_float), allocatable, intent(out) :: vals(:)
+    integer(c_int64_t), allocatable, intent(out), optional :: where(:)
+    integer(c_int64_t), allocatable :: idx(:)
+    integer(c_int64_t) :: a, b, i, j, m, n, k, nnz, t
+    integer :: r
+    nnz = rowptr(nl + 1)
+    allocate(rp(nl + 1), cols(max(nnz, 1_c_int64_t)), vals(max(nnz, 1_c_int64_t)), idx(max(nnz, 1_c_int64_t)))
+    if (present(where)) allocate(where(max(nnz, 1_c_int64_t)))
+    m = 0
+    rp(1) = 0
+    do r = 1, nl
+      a = rowptr(r) + 1; b = rowptr(r + 1); n = b - a + 1
+      do i = 1, n
+        idx(i) = a + i - 1
+      enddo
+      do i = 2, n                                    ! stable: equal columns keep the order they were added in
+        t = idx(i)
+        j = i - 1
+        do while (j >= 1)
+          if (ija(idx(j)) <= ija(t)) exit
+          idx(j + 1) = idx(j)
+          j = j - 1
+        enddo
+        idx(j + 1) = t
+      enddo
+      do i = 1, n
+        k = idx(i)
+        if (i > 1) then
+          if (ija(k) == cols(m)) then
+            vals(m) = vals(m) + sa(k)
+            if (present(where)) where(k) = m
+            cycle
+          endif
+        endif
+        m = m + 1
+        cols(m) = ija(k); vals(m) = sa(k)
+        if (present(where)) where(k) = m
+      enddo
+      rp(r + 1) = m
+    enddo
+  end subroutine api_canonical_csr
+
   subroutine sort_row(c, v, n)
     integer(c_int64_t), intent(inout) :: n
     integer(c_int32_t), intent(inout) :: c(n)
