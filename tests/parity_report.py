@@ -1,5 +1,6 @@
 """Measured parity distances, kept: every `-m gpu` test that measures a distance to the oracle / the reference calls report(); the lines
-accumulate in gpurun_out/parity_report.jsonl (merged back from the GPU box by gpurun) and tools/reduce_parity_report.py reduces them to
+accumulate in gpurun_out/parity_report/run_<start>_<pid>.jsonl (merged back from the GPU box by gpurun) and tools/reduce_parity_report.py
+reduces them (newest record per test) to
 the table committed as profiles/rNN_parity.json - the numbers DESIGN.md quotes come from there, not from a scrolled-away test log."""
 import json
 import os
@@ -8,8 +9,16 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_SESSION = "%d_%d" % (int(time.time()), os.getpid())
+
+
+def report_dir():
+    return os.path.join(ROOT, "gpurun_out", "parity_report")
+
+
 def report_path():
-    return os.environ.get("TFX_PARITY_REPORT") or os.path.join(ROOT, "gpurun_out", "parity_report.jsonl")
+    """One file per pytest process (gpurun merges gpurun_out/ file by file: a fixed name would be overwritten by the next call)."""
+    return os.environ.get("TFX_PARITY_REPORT") or os.path.join(report_dir(), "run_%s.jsonl" % _SESSION)
 
 
 def _plain(v):

@@ -144,3 +144,26 @@ def test_no_plain_skip_left_in_the_gpu_tests():
     for f in sorted(glob.glob(os.path.join(here, "test_gpu_*.py"))):
         txt = open(f).read()
         assert "pytest.skip(" not in txt and "skipif" not in txt and "importorskip" not in txt, f
+
+
+def test_parity_report_files_and_their_reduction(tmp_path, monkeypatch):
+    """tests/parity_report.py writes one file per pytest process (gpurun merges gpurun_out/ file by file: a fixed name is overwritten by
+    the next call - it happened in round 6); tools/reduce_parity_report.py keeps the newest record of every test."""
+    import subprocess
+    import parity_report as pr
+    monkeypatch.setattr(pr, "ROOT", str(tmp_path))
+    monkeypatch.delenv("TFX_PARITY_REPORT", raising=False)
+    pr.report("full_size[config5_hamersley_d4]", rows_checked=13, lsqr_r_rel_err=4e-16)
+    pr.report("config1_mansf_end_to_end[python host]", model_rel_l2=1.7e-10)
+    folder = os.path.join(str(tmp_path), "gpurun_out", "parity_report")
+    files = os.listdir(folder)
+    assert len(files) == 1 and files[0].startswith("run_") and str(os.getpid()) in files[0]
+    later = {"test": "full_size[config5_hamersley_d4]", "t": time.time() + 100, "rows_checked": 13, "lsqr_r_rel_err": 5e-16}
+    open(os.path.join(folder, "run_9999999999_1.jsonl"), "w").write(json.dumps(later) + "\n")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "reduce_parity_report.py"), "--folder", folder, "--note", "n"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    out = json.loads(p.stdout)
+    assert out["records"] == 2 and out["note"] == "n"
+    assert out["by_test"]["full_size"]["full_size[config5_hamersley_d4]"]["lsqr_r_rel_err"] == 5e-16
+    assert out["headline_numbers"]["config 1 (8192 cells, 60 x 100 iterations + ADMM), final model rel-L2 vs the reference"] == {"python host": 1.7e-10}
