@@ -286,7 +286,21 @@ def main():
         runs.append(comm.max_over_ranks(dt) if world > 1 else dt)
     prof = [ctx.profile_get(0), ctx.profile_get(1), ctx.profile_get(2)] if not args.no_profile else [(0.0, 0), (0.0, 0), (0.0, 0)]
     ctx.profile_enable(False)
-    ctx.lsqr_end()
+    x_final = ctx.lsqr_end()
+    # ---- the residual LSQR reports against the residual of the augmented system recomputed from the products (outside the timed region):
+    # r = |[b - S x ; -alpha x]| / |b| (lsqr_solver2.F90:163-290; tfx_calc_data all-reduces S x over the ranks)
+    r_check = None
+    try:
+        sx = ctx.calc_data(x_final, 1.0, None)
+        damp2 = float(np.sum((float(np.float32(alpha)) * x_final) ** 2))      # (the damping block is stored in fp32)
+        if world > 1:
+            damp2 = float(comm.allreduce_host(np.array([damp2]))[0])
+        r_true = float(np.sqrt(np.sum((d_obs - sx) ** 2) + damp2) / np.linalg.norm(d_obs))
+        r_check = {"r_from_products": r_true, "rel_err": abs(r - r_true) / r_true if r_true > 0 else None,
+                   "iterations": args.warmup + REPEATS * args.steps}
+        log("final r %.15e, recomputed from the products %.15e (relative difference %.1e)" % (r, r_true, r_check["rel_err"] or 0.0))
+    except Exception as exc:      # noqa  (a diagnostic: it must not take the line down)
+        log("residual check skipped: %r" % (exc,))
     mid = int(np.argsort(runs)[len(runs) // 2])
     t_steps, t_steps_local, ms_gpu = runs[mid], runs_local[mid], runs_gpu[mid]
     ms_per_step = 1e3 * t_steps / args.steps
@@ -405,7 +419,7 @@ def main():
                           "allreduce_ms": round(float(v[2]), 4), "allreduces_timed": int(v[3]), "nnz": int(v[4]),
                           "ms_per_step_wall": round(float(v[5]), 4), "ms_per_step_hip_events": round(float(v[6]), 4)}
                          for r, v in enumerate(per_rank)],
-            "adjoint_identity_rel_err": adj_err, "final_r": r,
+            "adjoint_identity_rel_err": adj_err, "final_r": r, "final_r_check": r_check,
             "roofline": roof, "cpu_baseline": cpu, "reference_config1": ref_cfg1,
         }
         print(json.dumps(out))

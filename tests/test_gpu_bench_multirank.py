@@ -64,6 +64,8 @@ def _run_bench(nranks, workload, extra_env=None, steps=4, warmup=2, port=29640, 
 def plain_small():
     out, _ = _run_bench(1, "small", {}, launcher=False)
     assert out["comm"]["path"] == "single rank"
+    # the line verifies its own residual: |[b - S x; -alpha x]| / |b| recomputed from the products after the timed region
+    assert out["final_r_check"] is not None and out["final_r_check"]["rel_err"] <= 1e-9, out["final_r_check"]
     return out
 
 
@@ -119,6 +121,7 @@ def test_ranks_launched_like_the_driver_does_share_the_gpu_and_fall_back_togethe
     assert comm["rccl_ranks"] == 0
     assert out["build_mode"].startswith("row-parallel + relayout"), out["build_mode"]
     per = out["per_rank"]
+    assert out["final_r_check"] is not None and out["final_r_check"]["rel_err"] <= 1e-9, out["final_r_check"]     # N ranks: S x all-reduced by tfx_calc_data
     assert len(per) == nranks and sum(p["nnz"] for p in per) == out["config"]["nnz"]
     assert max(p["nnz"] for p in per) <= 1.02 * out["config"]["nnz"] / nranks + 4096           # the reference's greedy rule balances the non-zeros
     assert all(p["allreduces_timed"] >= 2 * out["steps"] for p in per)
