@@ -249,3 +249,72 @@ def test_memory_plan_of_the_baseline_configurations():
     assert not mp(nranks=1, nkernels=2, ncells=512 * 512 * 128, ndata=256 * 256, compression_rate=0.02)["fits"]
     r = mp(nranks=1, dense=True, ncells=256 * 256 * 64, ndata=4096, compression_rate=1.0)     # config 2
     assert r["fits"] and 68.0 < r["phases_GB"]["solve"] < 75.0
+
+
+# ---- the step runner of bench.py --selftest (distributed.AgreedSteps): failure on ONE rank is a failure on all ----------------------
+def _steps_worker(rank, world, port, q, scenario):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    import time
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tfx = importlib.import_module("tomofast-x_amd")
+        runner = tfx.distributed.AgreedSteps(True)
+
+        def first(info):
+            info["value"] = 7
+
+        def second(info):
+            if scenario == "one_rank_raises" and rank == 1:
+                raise RuntimeError("scripted failure on rank 1")
+            if scenario == "one_rank_hangs" and rank == 0:
+                time.sleep(20.0)
+            info["seen"] = rank
+
+        def third(info):
+            info["reached"] = True
+
+        t0 = time.time()
+        runner.run("first", first, 5.0)
+        runner.run("second", second, 2.0)
+        runner.run("third", third, 5.0)
+        runner.run("rccl only", third, 5.0, applicable=False, why_not="not applicable: hooks")
+        q.put((rank, runner.ok, runner.steps, time.time() - t0))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["all_fine", "one_rank_raises", "one_rank_hangs"])
+def test_selftest_steps_fail_on_every_rank_together(scenario):
+    """distributed.AgreedSteps (the step runner of `bench.py --selftest` / `comm.selftest`) on 2 ranks over gloo: a step that raises or
+    hangs on ONE rank is recorded as failed on BOTH with the rank and the reason, a hang costs the step's timeout, and the steps behind
+    the failure are recorded as not run - nobody walks into the next collective alone."""
+    world, port = 2, 29591 + ["all_fine", "one_rank_raises", "one_rank_hangs"].index(scenario)
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_steps_worker, args=(r, world, port, q, scenario)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    for rank, ok, steps, dt in res:
+        assert ok != "error", steps
+        names = [s["step"] for s in steps]
+        assert names == ["first", "second", "third", "rccl only"], names
+        assert steps[0]["ok"] is True and steps[0]["value"] == 7
+        assert dt < 15.0, dt
+        if scenario == "all_fine":
+            assert ok is True and steps[1]["ok"] is True and steps[2]["ok"] is True and steps[2]["reached"] and steps[3]["ok"] is None
+            assert steps[3]["why"] == "not applicable: hooks"
+        else:
+            assert ok is False and steps[1]["ok"] is False and steps[2]["ok"] is None and "not run" in steps[2]["why"] and "not run" in steps[3]["why"]
+            if scenario == "one_rank_raises":
+                assert steps[1]["why"].startswith("rank 1:") and "scripted failure on rank 1" in steps[1]["why"]
+            else:
+                assert steps[1]["why"].startswith("rank 0:") and "timed out" in steps[1]["why"]
+    assert [s.get("why") for s in res[0][2]] == [s.get("why") for s in res[1][2]]         # the same story on both ranks

@@ -391,6 +391,44 @@ def _try_rccl(ctx, rank, nranks, device_index, timeout, report):
     return None
 
 
+class AgreedSteps:
+    """Steps that every rank runs in lock-step, each under a timeout and with the outcome AGREED over the gloo control channel (min over
+    the ranks): a step that raises or hangs on ONE rank is a failed step on all of them, its record names the rank and the reason, and
+    the steps after it are recorded as not run - no rank goes on into a collective the others have given up on.  `multi` = a process group
+    exists; fn(info) fills `info` with what it measured."""
+
+    def __init__(self, multi, log=None):
+        self.multi, self.ok, self.steps = bool(multi), True, []
+        self.log = log or (lambda msg: None)
+
+    def run(self, name, fn, timeout, applicable=True, why_not=""):
+        import time
+        if not self.ok:
+            self.steps.append({"step": name, "ok": None, "why": "not run: an earlier step failed"})
+            return None
+        if not applicable:
+            self.steps.append({"step": name, "ok": None, "why": why_not or "not applicable"})
+            return None
+        info = {}
+        t0 = time.time()
+        done, exc = _call_with_timeout(lambda: fn(info), timeout)
+        local = None if (done and exc is None) else ("timed out after %.0f s" % timeout if not done else repr(exc))
+        ok = agree(local is None) if self.multi else (local is None)
+        rec = {"step": name, "ok": bool(ok), "s": round(time.time() - t0, 3)}
+        rec.update(info)
+        if not ok:
+            reasons = [local]
+            if self.multi:
+                import torch.distributed as dist
+                reasons = [None] * dist.get_world_size()
+                dist.all_gather_object(reasons, local, group=control_group())
+            rec["why"] = next((("rank %d: %s" % (r, x)) for r, x in enumerate(reasons) if x), "unknown")
+            self.ok = False
+        self.steps.append(rec)
+        self.log("self-test %s: %s" % (name, "ok (%.2f s)" % rec["s"] if ok else "FAILED - " + rec.get("why", "")))
+        return ok
+
+
 def comm_selftest(ctx, comm, rank, nranks, device_index=0, step_timeout=20.0, log=None, lsqr_iterations=5):
     """First contact with N GPUs, step by step (bench.py --selftest, and the first thing a `--gpus N` run does): every collective SHAPE
     the path uses is executed once on a small, known-answer input - under a per-step timeout, with the ranks agreeing on each outcome
@@ -418,32 +456,12 @@ def comm_selftest(ctx, comm, rank, nranks, device_index=0, step_timeout=20.0, lo
         log = lambda msg: None      # noqa
     dev = torch.device("cuda", device_index)
     multi = dist.is_available() and dist.is_initialized()
-    steps = [{"step": "ladder", "ok": True, "path": comm.report.get("path"), "rungs": [r.get("stage") for r in comm.report.get("ladder", [])]}]
-    state = {"ok": True}
+    runner = AgreedSteps(multi, log)
+    runner.steps.append({"step": "ladder", "ok": True, "path": comm.report.get("path"), "rungs": [r.get("stage") for r in comm.report.get("ladder", [])]})
+    steps, state = runner.steps, runner
 
     def run_step(name, fn, timeout, applicable=True):
-        if not state["ok"]:
-            steps.append({"step": name, "ok": None, "why": "not run: an earlier step failed"})
-            return
-        if not applicable:
-            steps.append({"step": name, "ok": None, "why": "not applicable: no RCCL communicator on this rung (%s)" % comm.report.get("path")})
-            return
-        info = {}
-        t0 = time.time()
-        done, exc = _call_with_timeout(lambda: fn(info), timeout)
-        local = None if (done and exc is None) else ("timed out after %.0f s" % timeout if not done else repr(exc))
-        ok = agree(local is None) if multi else (local is None)
-        rec = {"step": name, "ok": bool(ok), "s": round(time.time() - t0, 3)}
-        rec.update(info)
-        if not ok:
-            reasons = [local]
-            if multi:
-                reasons = [None] * dist.get_world_size()
-                dist.all_gather_object(reasons, local, group=control_group())
-            rec["why"] = next((("rank %d: %s" % (r, x)) for r, x in enumerate(reasons) if x), "unknown")
-            state["ok"] = False
-        steps.append(rec)
-        log("self-test %s: %s" % (name, "ok (%.2f s)" % rec["s"] if ok else "FAILED - " + rec.get("why", "")))
+        runner.run(name, fn, timeout, applicable, "not applicable: no RCCL communicator on this rung (%s)" % comm.report.get("path"))
 
     T = nranks * (nranks + 1) // 2
 
@@ -555,7 +573,7 @@ def comm_selftest(ctx, comm, rank, nranks, device_index=0, step_timeout=20.0, lo
     run_step("allgatherv_unequal", s_allgatherv, step_timeout, applicable=rccl)
     run_step("relayout_group", s_relayout, step_timeout, applicable=rccl and nranks > 1)
     run_step("lsqr", s_lsqr, 3.0 * step_timeout)
-    return {"ok": bool(state["ok"]), "steps": steps, "step_timeout_s": step_timeout}
+    return {"ok": bool(state.ok), "steps": steps, "step_timeout_s": step_timeout}
 
 
 def fall_back_to_hooks(ctx, comm, rank, nranks, device_index, why):
