@@ -318,3 +318,43 @@ def test_selftest_steps_fail_on_every_rank_together(scenario):
             else:
                 assert steps[1]["why"].startswith("rank 0:") and "timed out" in steps[1]["why"]
     assert [s.get("why") for s in res[0][2]] == [s.get("why") for s in res[1][2]]         # the same story on both ranks
+
+
+def _fallback_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tfx = importlib.import_module("tomofast-x_amd")
+        ctx = LadderCtx("ok")
+        ctx.has_comm = True
+        comm = tfx.distributed.HostComm(ctx, rank, world, 0, True)
+        comm.report = {"path": "RCCL inside libtfx.so (tfx_comm_init_rccl)", "ladder": [{"stage": "pre-flight", "ok": True}], "rccl_ranks": world}
+        new = tfx.distributed.fall_back_to_hooks(ctx, comm, rank, world, 0, "rank 1: scripted")
+        q.put((rank, new.rccl, new.report, ctx.calls, ctx.has_comm, (ctx.rank, ctx.nranks)))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), [], False, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failed_selftest_moves_all_ranks_from_rccl_to_the_hooks():
+    """distributed.fall_back_to_hooks (what bench.py does when comm.selftest fails on the RCCL rung): the communicator is aborted, the
+    forced-collectives switch cleared, the torch.distributed hooks installed with the rank / rank count, and the report says why."""
+    world, port = 2, 29597
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    for rank, rccl, report, calls, has_comm, who in res:
+        assert rccl is False, report
+        assert calls[0] == "abort" and "debug_set force_collectives=0" in calls and "set_allreduce" in calls and "set_allgatherv" in calls, calls
+        assert not has_comm and who == (rank, world)
+        assert report["path"].startswith("torch.distributed hooks (gloo) after the RCCL self-test failed: rank 1: scripted") and report["rccl_ranks"] == 0
+        assert report["ladder"] == [{"stage": "pre-flight", "ok": True}]
