@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--full-select", action="store_true", help="A/B: thresholds by the full radix select instead of the band select")
     ap.add_argument("--selftest", action="store_true", help="only the N-GPU self-test (tomofast-x_amd/distributed.py::comm_selftest): every "
                     "collective shape of the path once, step by step with a per-step timeout; prints its JSON verdict and exits")
-    ap.add_argument("--selftest-timeout", type=float, default=float(os.environ.get("TFX_SELFTEST_TIMEOUT", "20")), help="seconds per self-test step")
+    ap.add_argument("--selftest-timeout", type=float, default=float(os.environ.get("TFX_SELFTEST_TIMEOUT", "90")), help="seconds per self-test step (generous: a false time-out would move a healthy RCCL run to the host-staged hooks)")
     args = ap.parse_args()
     if os.environ.get("TFX_BENCH_WATCHDOG"):
         # diagnostics for a run that does not come back (tests set it): after that many seconds every thread's Python stack goes to

@@ -429,7 +429,7 @@ class AgreedSteps:
         return ok
 
 
-def comm_selftest(ctx, comm, rank, nranks, device_index=0, step_timeout=20.0, log=None, lsqr_iterations=5):
+def comm_selftest(ctx, comm, rank, nranks, device_index=0, step_timeout=90.0, log=None, lsqr_iterations=5):
     """First contact with N GPUs, step by step (bench.py --selftest, and the first thing a `--gpus N` run does): every collective SHAPE
     the path uses is executed once on a small, known-answer input - under a per-step timeout, with the ranks agreeing on each outcome
     over the gloo control channel - so that a call that has never run with N > 1 real peers fails EARLY and says which one it was
