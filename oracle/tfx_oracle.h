@@ -8,7 +8,12 @@
  * Every function restates one routine of the reference (cited file:line, paths relative to the
  * reference root).  Plain C, scalar, fp64 with strict IEEE semantics (built with -ffp-contract=off,
  * no -ffast-math) so that results match the reference's x86-64 build bit-for-bit where the
- * operation order is fixed (prism rows, wavelets, threshold, compaction, partition).
+ * operation order is fixed (prism rows, wavelets, threshold, compaction, partition) - and, since round 6,
+ * THROUGH THE SOLVER: norm2(u) is evaluated the way the reference's Fortran runtime (LLVM flang) does
+ * (norm2_flang in tfx_oracle.c) and sum(v**2) sequentially, with which LSQR (all 12 runs of
+ * tests/golden/lsqr.npz incl. exit iterations and residuals) and whole inversions (config 1 = 60 x 100
+ * iterations + ADMM; Haar / D4 / uncompressed, magnetic, multi-component, joint, cross-gradient, ...)
+ * reproduce the reference's final models and data bit for bit (tests/test_oracle_golden.py).
  *
  * Pinned against: oracle/_ref (the unmodified reference compiled by oracle/ref_build.sh) through the
  * golden vectors in tests/golden/ (made by tests/golden/make_golden.py), and against the reference's

@@ -18,6 +18,25 @@ def bits_equal(a, b):
     return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
 
 
+MEASURED = []
+
+
+def model_distance(m, ref, tol, what="", exact=False):
+    """Asserts the distance of the oracle's final model to the reference's (printed with `pytest -s`).  Since round 6 - norm2 evaluated like
+    the reference's Fortran runtime, oracle/tfx_oracle.c norm2_flang - whole inversions through the C oracle reproduce the reference's output
+    BIT FOR BIT (exact=True: config 1 with its 60 x 100 iterations and ADMM, the Haar / D4 / uncompressed, magnetic, joint, cross-gradient,
+    data-error, local-weight and local-bound fixtures); where a constraint is built by vectorised numpy (gradient damping, Lp weights,
+    clustering: pow / exp / log and sums in another order than the Fortran loops) the distance is 1e-16 ... 3e-14, asserted at `tol`."""
+    rel = float(np.linalg.norm(m - ref) / np.linalg.norm(ref))
+    same = bool(bits_equal(np.ascontiguousarray(m, np.float64), np.ascontiguousarray(ref, np.float64)))
+    MEASURED.append((what, rel, same))
+    print("oracle vs reference %s: rel-L2 %.3e, bit-identical %s" % (what, rel, same))
+    assert rel <= tol, (what, rel, tol)
+    if exact:
+        assert same, (what, rel)
+    return rel
+
+
 def test_wavelets_bit_exact(golden_dir):
     g = load(golden_dir, "wavelet")
     keys = sorted(k[:-3] for k in g.files if k.endswith("_in"))
@@ -82,19 +101,13 @@ def test_spmv_lsqr_vs_reference(golden_dir, case):
     assert bits_equal(orc.spmtv(*S, g[case + "_yin"], ncols), g[case + "_STy"])
     for (niter, rmin, gamma), xref, rref, itref in zip(g[case + "_runs"], g[case + "_x"], g[case + "_r"], g[case + "_iters"]):
         x, it, r = orc.lsqr(S, Cm, ncols, g[case + "_b"], int(niter), rmin, gamma)
-        # norm2() of the reference is flang's scaled intrinsic, ours a plain sum: the two differ in the last bit,
-        # and Golub-Kahan amplifies that while it is converging (3e-10 at iteration 20, 4e-6 at 30 on "damp") before
-        # both land on the same converged solution (1e-15).  Early exits by |rhobar| < 1e-30 / r <= rmin are
-        # triggered by rounding-level quantities, so the exit iteration may differ by a few.
-        early_exit = itref < niter
-        if early_exit:
-            assert abs(it - itref) <= 0.1 * itref
-        else:
-            assert it == itref
-        tol = 1e-13 if niter <= 5 else (1e-12 if (early_exit or niter >= 50) else 1e-5)
-        assert np.linalg.norm(x - xref) <= tol * np.linalg.norm(xref), (case, niter)
-        if not early_exit:
-            assert abs(r - rref) <= 1e-7 * abs(rref)
+        # Bit for bit, exit iterations and residuals included: since round 6 the oracle evaluates norm2(u) the way the reference's Fortran
+        # runtime does (LLVM flang: one-pass max-scaled sum, oracle/tfx_oracle.c norm2_flang) and sum(v**2) sequentially.  (Rounds 1-5 used a
+        # plain sum for both: last-bit differences that Golub-Kahan amplified to 4e-6 at the mid-convergence iterate of "damp" and moved
+        # the early exits by a few iterations.)
+        assert it == itref, (case, niter, it, itref)
+        assert bits_equal(x, xref), (case, niter, float(np.linalg.norm(x - xref) / np.linalg.norm(xref)))
+        assert r == rref, (case, niter, r, rref)
 
 
 def test_mindist_weight_type3_bit_exact(golden_dir):
@@ -142,7 +155,7 @@ def test_end_to_end_inversion(golden_dir, name):
     m, d, hist = oinv.run_inversion(S, cw, dims, ctype, g["np1_data_observed"], int(g["nmajor"]), int(g["nminor"]),
                                     alpha=float(g["alpha"]))
     ref = g["np1_model_final"]
-    assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref)
+    model_distance(m, ref, 1e-12, name, exact=True)
     assert np.allclose(d, g["np1_data_final"], rtol=1e-9, atol=1e-9 * np.abs(g["np1_data_final"]).max())
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-7)
     # the reference itself differs between 1 and 2 ranks by about this much
@@ -180,11 +193,11 @@ def test_config1_mansf_end_to_end(golden_dir):
     m, d, hist = oinv.run_inversion(S, cw, dims, 1, d_obs, 60, 100, alpha=0.0,
                                     admm=dict(bounds=g["admm_bounds"], rho=float(g["admm_weight"])))
     ref = g["model_final"]
-    rel = np.linalg.norm(m - ref) / np.linalg.norm(ref)
-    # reference vs itself on 2 / 4 ranks: 4e-12 / 6e-12
-    assert rel <= 1e-9, rel
-    assert abs(m.min() - (-19.951562372333093)) < 1e-6 and abs(m.max() - 259.9972445968676) < 1e-6
-    assert abs(hist[-1]["cost"] - 9.339172972115141e-11) <= 1e-3 * 9.339172972115141e-11
+    # (the reference against itself on 2 / 4 ranks: 4e-12 / 6e-12; the oracle against its 1-rank run: every bit of the final model and data)
+    model_distance(m, ref, 1e-12, "config 1 (mansf_slice)", exact=True)
+    assert bits_equal(np.ascontiguousarray(d, np.float64), np.ascontiguousarray(g["data_final"], np.float64))
+    assert m.min() == -19.951562372333093 and m.max() == 259.9972445968676
+    assert abs(hist[-1]["cost"] - 9.339172972115141e-11) <= 1e-12 * 9.339172972115141e-11
 
 
 def test_magprism_rows_bit_exact(golden_dir):
@@ -218,7 +231,7 @@ def test_magnetic_end_to_end_vs_reference(golden_dir):
     S = orc.build_matrix_mag(grid, dims, cw, g["obs"], g["field"], 1, float(g["rate"]))
     assert np.array_equal(S[0], g["row_ptr"]) and bits_equal(S[1], g["cols"]) and bits_equal(S[2], g["vals"])
     m, d, hist = oinv.run_inversion(S, cw, dims, 1, g["data_observed"], int(g["nmajor"]), int(g["nminor"]), alpha=float(g["alpha"]))
-    assert np.linalg.norm(m - g["model_final"]) <= 1e-9 * np.linalg.norm(g["model_final"])
+    model_distance(m, g["model_final"], 1e-12, "e2e_mag", exact=True)
     # the first solve converges to r ~ 4e-14 (below minResidual), so the second one starts from rounding noise and its
     # residual ratio is only reproducible to a few digits
     assert np.allclose([h["r"] for h in hist], g["lsqr_r"], rtol=1e-3)
@@ -316,7 +329,7 @@ def test_multicomponent_end_to_end(golden_dir, name):
     # the reference's own 1-rank and 2-rank runs differ by up to 8e-6 (e2e_ftg).  Allow 3x that self-difference.
     self_diff = np.linalg.norm(ref2 - ref) / np.linalg.norm(ref)
     tol = max(1e-8, 3.0 * self_diff)
-    assert np.linalg.norm(m - ref) <= tol * np.linalg.norm(ref), (np.linalg.norm(m - ref) / np.linalg.norm(ref), self_diff)
+    model_distance(m, ref, tol, name, exact=True)          # (rounds 1-5: up to 8e-6 on these short mid-convergence solves - the norm2 rounding, amplified)
     dref = g["np1_data_final"].ravel()
     assert np.allclose(d, dref, rtol=100 * tol, atol=10 * tol * np.abs(dref).max())
     assert np.allclose(hist[0]["r"], g["np1_lsqr_r"][0], rtol=1e-5)
@@ -361,7 +374,7 @@ def test_joint_inversion_end_to_end(golden_dir):
         # the reference's own 1- vs 2-rank difference: 2.8e-10 (grav), 5.7e-8 (magn; its block is weighted 0.5 and damped 1e-9)
         self_diff = np.linalg.norm(g["np2_%s_model_final" % tag] - ref) / np.linalg.norm(ref)
         tol = max(1e-8, 3.0 * self_diff)
-        assert np.linalg.norm(m[i] - ref) <= tol * np.linalg.norm(ref), (tag, np.linalg.norm(m[i] - ref) / np.linalg.norm(ref))
+        model_distance(m[i], ref, tol, tag, exact=True)
         dref = g["np1_%s_data_final" % tag]
         assert np.allclose(d[i], dref, rtol=100 * tol, atol=10 * tol * np.abs(dref).max())
     assert np.allclose(hist[0]["r"], g["np1_lsqr_r"][0], rtol=1e-4)
@@ -377,7 +390,7 @@ def test_gradient_damping_end_to_end(golden_dir):
     m, d, hist = oinv.run_inversion_gradient_damping(S, g["np1_column_weight"], dims, grid, int(g["ctype"]), g["np1_data_observed"],
                                                      int(g["nmajor"]), int(g["nminor"]), float(g["alpha"]), float(g["beta"]))
     ref = g["np1_model_final"]
-    assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    model_distance(m, ref, 1e-12, "gradient damping")
     assert np.allclose(d, g["np1_data_final"], rtol=1e-8, atol=1e-10 * np.abs(g["np1_data_final"]).max())
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
     assert np.linalg.norm(g["np2_model_final"] - ref) <= 1e-9 * np.linalg.norm(ref)
@@ -394,7 +407,7 @@ def test_lp_norm_damping_end_to_end(golden_dir):
                                                      int(g["nmajor"]), int(g["nminor"]), float(g["alpha"]), 0.0,
                                                      norm_power=float(g["norm_power"]))
     ref = g["np1_model_final"]
-    assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    model_distance(m, ref, 1e-12, "Lp damping")
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
 
 
@@ -408,7 +421,7 @@ def test_admm_local_bounds_end_to_end(golden_dir):
                                                      int(g["nmajor"]), int(g["nminor"]), float(g["alpha"]), 0.0,
                                                      admm=dict(bounds=g["bounds"], weight=g["bound_weight"], rho=float(g["rho"])))
     ref = g["np1_model_final"]
-    assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    model_distance(m, ref, 1e-12, "local ADMM bounds", exact=True)
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
 
 
@@ -423,7 +436,7 @@ def test_data_errors_end_to_end(golden_dir):
     m, d, hist = oinv.run_inversion(S, g["np1_column_weight"], dims, int(g["ctype"]), g["np1_data_observed"], int(g["nmajor"]),
                                     int(g["nminor"]), alpha=float(g["alpha"]), data_weight=dw)
     ref = g["np1_model_final"]
-    assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    model_distance(m, ref, 1e-12, "data errors", exact=True)
     assert np.allclose(d, g["np1_data_final"], rtol=1e-8, atol=1e-10 * np.abs(g["np1_data_final"]).max())
 
 
@@ -444,7 +457,7 @@ def test_local_weights_end_to_end(golden_dir, name):
                                                      int(g["nminor"]), float(g["alpha"]), 0.0, damping_weight=g["lw_damp"],
                                                      norm_power=float(g["norm_power"]))
     ref = g["np1_model_final"]
-    assert np.linalg.norm(m - ref) <= 1e-9 * np.linalg.norm(ref), np.linalg.norm(m - ref) / np.linalg.norm(ref)
+    model_distance(m, ref, 1e-12, name, exact=(name == "e2e_localw"))
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-6)
 
 
@@ -464,7 +477,7 @@ def test_joint_inversion_with_cross_gradient(golden_dir, name):
                                                 float(g["xgrad_weight"]), int(g["der_type"]))
     for i, tag in enumerate(("grav", "magn")):
         ref = g["np1_%s_model_final" % tag]
-        assert np.linalg.norm(m[i] - ref) <= 1e-9 * np.linalg.norm(ref), (tag, np.linalg.norm(m[i] - ref) / np.linalg.norm(ref))
+        model_distance(m[i], ref, 1e-12, tag, exact=True)
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-7)
     costs = np.array([h["xgrad_cost"] for h in hist])
     assert np.allclose(costs[2:], g["np1_xgrad_cost"][2:], rtol=1e-6)
@@ -490,7 +503,7 @@ def test_joint_inversion_with_clustering(golden_dir, name):
     m, d, hist = oinv.run_joint_inversion_xgrad(probs, dims, grid, int(g["ctype"]), int(g["nmajor"]), int(g["nminor"]), 0.0, coupling=coupling)
     for i, tag in enumerate(("grav", "magn")):
         ref = g["np1_%s_model_final" % tag]
-        assert np.linalg.norm(m[i] - ref) <= 1e-9 * np.linalg.norm(ref), (tag, np.linalg.norm(m[i] - ref) / np.linalg.norm(ref))
+        model_distance(m[i], ref, 1e-12, tag)
     assert np.allclose([h["r"] for h in hist], g["np1_lsqr_r"], rtol=1e-7)
     costs = np.array([h["xgrad_cost"] for h in hist])
     assert np.allclose(costs[2:], g["np1_clust_cost"][2:], rtol=1e-6)
