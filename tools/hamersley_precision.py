@@ -5,7 +5,10 @@ CPU only. The first LSQR solve of the reference's joint Hamersley example (parfi
 three arithmetics on the REFERENCE'S OWN kernel files (oracle/_ref/hamersley_xgrad_SENSIT, written by oracle/_ref/tomofastx): fp64 with the
 reference's sequential sums (the C oracle), fp64 with numpy's pairwise / blocked sums, 80-bit long double.  r after 100 / 400 iterations:
     the compiled reference              1.497770582e-02   4.801500480e-03
-    sequential fp64 (C oracle)          1.506765081e-02   4.801600271e-03
+    sequential fp64 (C oracle)          1.497770582e-02   4.801500480e-03     <- ALL 16 digits of the reference's (1.497770582171863e-02,
+                                                                                4.801500480366518e-03) since round 6: norm2(u) evaluated like the
+                                                                                reference's Fortran runtime (oracle/tfx_oracle.c norm2_flang);
+                                                                                with a plain sum for norm2 (rounds 1-5): 1.506765081e-02 / 4.801600271e-03
     numpy fp64                          1.251982061e-02   4.761320369e-03
     the HIP path (MI355X)               1.250521353e-02   4.761308399e-03
     80-bit long double                  1.231753998e-02   4.743435043e-03
