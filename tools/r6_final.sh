@@ -16,3 +16,4 @@ for w in haar_512 dense_256 medium small; do
 done
 cd $R
 timeout 600 python tools/cpu_baseline_large_probe.py > $O/cpu_large_probe.log 2>&1; tail -30 $O/cpu_large_probe.log
+bash tools/validate_reforder.sh > $O/validate_reforder.log 2>&1; tail -45 $O/validate_reforder.log
