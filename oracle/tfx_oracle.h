@@ -12,8 +12,9 @@
  * THROUGH THE SOLVER: norm2(u) is evaluated the way the reference's Fortran runtime (LLVM flang) does
  * (norm2_flang in tfx_oracle.c) and sum(v**2) sequentially, with which LSQR (all 12 runs of
  * tests/golden/lsqr.npz incl. exit iterations and residuals) and whole inversions (config 1 = 60 x 100
- * iterations + ADMM; Haar / D4 / uncompressed, magnetic, multi-component, joint, cross-gradient, ...)
- * reproduce the reference's final models and data bit for bit (tests/test_oracle_golden.py).
+ * iterations + ADMM; Haar / D4 / uncompressed, magnetic, multi-component, joint, cross-gradient,
+ * gradient damping, Lp, clustering: every end-to-end fixture) reproduce the reference's final models
+ * bit for bit (tests/test_oracle_golden.py).
  *
  * Pinned against: oracle/_ref (the unmodified reference compiled by oracle/ref_build.sh) through the
  * golden vectors in tests/golden/ (made by tests/golden/make_golden.py), and against the reference's

@@ -6,10 +6,19 @@ single gravity problem on one rank with WAVELET_DOMAIN = true (or compression of
   (damping.F90:97-234, admm_method.F90:70-134) -> lsqr_solve_sensit -> inverse wavelet + rescale
   (joint_inverse_problem.F90:559-571) -> model update -> calculate_data (model.F90:220-307).
 """
+import math
+
 import numpy as np
 
 import oracle_lib as orc
 
+
+
+def libm_pow(a, p):
+    """a ** p element by element through the C library's pow (what the reference's `**` compiles to), not numpy's vectorised one (which
+    differs from it in the last bit on some arguments)."""
+    import math
+    return np.array([math.pow(float(v), float(p)) for v in np.asarray(a, np.float64).ravel()], np.float64).reshape(np.shape(a))
 
 def admm_iterate(z, u, x, bounds):
     """admm_method.F90:70-134 with global bounds [lo1 hi1 lo2 hi2 ...]; updates z, u in place; returns x0."""
@@ -164,7 +173,7 @@ def run_joint_inversion(problems, dims, ctype, nmajor, nminor, rmin=1e-13, lsqr=
     return m, d, hist
 
 
-def gradient_damping_rows(m, dims, grid, cw, pw, beta):
+def gradient_damping_rows(m, dims, grid, cw, pw, beta, reference_order=False):
     """damping_gradient%add for the three directions (src/inversion/damping_gradient.F90:94-205; forward differences
     gradient.F90:77-81; spacings grid.F90:371-391): 3 N rows, two entries each (none in the last layer of a direction),
     values cast to fp32 like sparse_matrix.f90:226.  Returns (rowptr, cols 1-based ascending, vals fp32), rhs."""
@@ -192,9 +201,12 @@ def gradient_damping_rows(m, dims, grid, cw, pw, beta):
                     gval = (f.ravel()[nb] - f.ravel()[me]) / delta
                     v1 = (1.0 / delta) * pw * beta * cw[nb]
                     v2 = -(1.0 / delta) * pw * beta * cw[me]
-                    # ascending columns for the upload (me < nb always)
-                    cols += [me + 1, nb + 1]
-                    vals += [np.float32(v2), np.float32(v1)]
+                    if reference_order:    # the order damping_gradient%add puts them into the row (:185-192): f(i + 1) first, then f(i) - the order
+                        cols += [nb + 1, me + 1]                    # the reference's products sum them in (sparse_matrix.f90:320, :399)
+                        vals += [np.float32(v1), np.float32(v2)]
+                    else:                  # ascending columns, as the device layout takes them (me < nb always)
+                        cols += [me + 1, nb + 1]
+                        vals += [np.float32(v2), np.float32(v1)]
                     rp.append(rp[-1] + 2)
                     rhs.append(-pw * beta * gval)
     return (np.array(rp, np.int64), np.array(cols, np.int32), np.array(vals, np.float32)), np.array(rhs)
@@ -239,14 +251,14 @@ def run_inversion_gradient_damping(S, cw, dims, grid, ctype, d_obs, nmajor, nmin
             mult = np.ones(N)
             if norm_power != 2.0:                          # Lp norm multiplier, damping.F90:171-175, :250-262
                 nzm = md != 0.0
-                mult[nzm] = np.abs(md[nzm]) ** (norm_power / 2.0 - 1.0)
+                mult[nzm] = libm_pow(np.abs(md[nzm]), norm_power / 2.0 - 1.0)
             val, r = alpha * pw * mult, -alpha * pw * md * mult   # the reference's order: alpha * pw, Lp multiplier, local weight
             if damping_weight is not None:                 # local weight = local alpha (damping.F90:177-180, :264-267)
                 val, r = val * damping_weight, r * damping_weight
             blocks.append(orc.diag_csr(val.astype(np.float32)))
             rhs.append(r)
         if beta != 0.0:
-            G, grhs = gradient_damping_rows(m, dims, grid, cw, pw, beta)
+            G, grhs = gradient_damping_rows(m, dims, grid, cw, pw, beta, reference_order=True)
             blocks.append(G)
             rhs.append(grhs)
         if admm is not None:                               # local bounds + local weight (joint_inverse_problem.F90:497-527)
@@ -378,19 +390,19 @@ def _gaussian(mu, sigma, wloc, val):
     mu1, mu2 = mu
     s11, s22, s12 = sigma
     if wloc[0] != 0.0 and wloc[1] != 0.0:
-        s12_4 = (s12 * s12) * (s12 * s12)
+        s12_4 = s12 * s12 * s12 * s12          # sigma12**4 as the reference's compiler evaluates it: ((x x) x) x (measured, round 6)
         arg = (-((-mu2 + y) * (mu2 * s11**2 - mu1 * s12**2 + s12**2 * x - s11**2 * y)) / (s12_4 - s11**2 * s22**2)
                - ((-mu1 + x) * (mu2 * s12**2 - mu1 * s22**2 + s22**2 * x - s12**2 * y)) / (-s12_4 + s11**2 * s22**2)) / 2.0
-        norm = 2.0 * np.pi * np.sqrt(-s12_4 + s11**2 * s22**2)
+        norm = 2.0 * math.pi * math.sqrt(-s12_4 + s11**2 * s22**2)
     elif wloc[1] == 0.0:
         arg = -(x - mu1)**2 / s11**2 / 2.0
-        norm = np.sqrt(2.0 * np.pi * s11**2)
+        norm = math.sqrt(2.0 * math.pi * s11**2)
     else:
         arg = -(y - mu2)**2 / s22**2 / 2.0
-        norm = np.sqrt(2.0 * np.pi * s22**2)
+        norm = math.sqrt(2.0 * math.pi * s22**2)
     if arg < -100.0:
-        return np.exp(-100.0)
-    return np.exp(arg) / norm
+        return math.exp(-100.0)
+    return math.exp(arg) / norm
 
 
 def _mixture(mix, wloc, val, cluster_weight):
@@ -401,7 +413,7 @@ def _mixture(mix, wloc, val, cluster_weight):
         mu1, s11, mu2, s22, s12 = mix[i, 1], mix[i, 2], mix[i, 3], mix[i, 4], mix[i, 5]
         gl = cluster_weight[i] * _gaussian((mu1, mu2), (s11, s22, s12), wloc, val)
         gauss = gauss + gl
-        s12_4 = (s12 * s12) * (s12 * s12)
+        s12_4 = s12 * s12 * s12 * s12          # sigma12**4 as the reference's compiler evaluates it: ((x x) x) x (measured, round 6)
         c1 = (s22**2 * (-mu1 + x) + s12**2 * (mu2 - y)) / (s12_4 - s11**2 * s22**2)
         c2 = (s12**2 * (mu1 - x) + s11**2 * (-mu2 + y)) / (s12_4 - s11**2 * s22**2)
         deriv[0] = deriv[0] + c1 * gl
@@ -446,7 +458,7 @@ def clustering_rows(m1, m2, cw1, cw2, weight_glob, mixtures, cell_weight, opt_ty
             if opt_type == 1:
                 f = gauss - pmax[p]
             else:
-                f = -np.log(gauss) + np.log(pmax[p]) if gauss > 0.0 else 0.0
+                f = -math.log(gauss) + math.log(pmax[p]) if gauss > 0.0 else 0.0
             b = -weight_glob[i] * f * wloc[i]
             rhs.append(b)
             cost[i] += b * b
